@@ -1,0 +1,84 @@
+/*
+ * fx_oracle.h -- CPU ORACLE: TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C, line-at-a-time restatement of the reference (lmdu/pyfastx v2.3.1)
+ * hot path, used ONLY by tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg as the checker.  The product (pyfastx_amd/) never imports,
+ * links or calls anything in oracle/.
+ *
+ * Parity pin: every function here is checked against the real reference built
+ * from /root/reference/src (oracle/_ref, see oracle/Makefile) by
+ * tests/golden/make_golden.py, and against the committed golden vectors in
+ * tests/golden/ by tests/test_oracle_golden.py.
+ *
+ * All offsets are 0-based offsets into the UNCOMPRESSED byte stream.
+ */
+#ifndef FX_ORACLE_H
+#define FX_ORACLE_H
+#include <stdint.h>
+
+typedef struct {
+    int64_t hoff;      /* offset of the '>' that starts the header line            */
+    int64_t boff;      /* seq.boff  (index.c:258)                                  */
+    int64_t blen;      /* seq.blen  (index.c:243,348)                              */
+    int64_t slen;      /* seq.slen  (index.c:335-338)                              */
+    int64_t llen;      /* seq.llen  (index.c:330-332)                              */
+    int64_t name_off;  /* offset of first name byte (hoff+1)                       */
+    int32_t name_len;  /* chrom length: full header, or up to first ' '/'\t'       */
+    int32_t elen;      /* seq.elen  (index.c:262-269)                              */
+    int32_t norm;      /* seq.norm  (index.c:237,342)                              */
+    int32_t dlen;      /* seq.dlen  (index.c:271)                                  */
+} fxo_fasta_rec;
+
+typedef struct {
+    int64_t name_off;  /* offset of first name byte (after '@')                    */
+    int64_t rlen;      /* read.rlen (fastq.c:124-128)                              */
+    int64_t soff;      /* read.soff (fastq.c:122)                                  */
+    int64_t qoff;      /* read.qoff (fastq.c:133)                                  */
+    int32_t name_len;  /* name length: '\r' stripped, cut at first ' ' (fastq.c:99-117) */
+    int32_t dlen;      /* read.dlen (fastq.c:103)                                  */
+} fxo_fastq_rec;
+
+typedef struct {
+    int64_t a, c, g, t, n;        /* base table (fastq.c:720-730)                  */
+    int64_t maxlen, minlen;       /* meta (fastq.c:747-751)                        */
+    int32_t minqs, maxqs, phred;  /* meta (fastq.c:738-744, 768-774)               */
+} fxo_fastq_comp;
+
+/* FASTA index scan (index.c:230-372).  Returns number of records; writes at
+ * most `cap` of them to `out` (may be NULL to just count); *seqlen = stat.seqlen. */
+int64_t fxo_fasta_index(const uint8_t *data, int64_t n, int full_name,
+                        fxo_fasta_rec *out, int64_t cap, int64_t *seqlen);
+
+/* FASTA composition (fasta.c:901-950): comp[rec*128 + byte]; returns #records. */
+int64_t fxo_fasta_comp(const uint8_t *data, int64_t n, int64_t *comp, int64_t cap);
+
+/* FASTQ index scan (fastq.c:89-171).  Returns read count (line_num/4);
+ * *size = stat.size (sum of rlen), *line_num = total lines seen. */
+int64_t fxo_fastq_index(const uint8_t *data, int64_t n, fxo_fastq_rec *out,
+                        int64_t cap, int64_t *size, int64_t *line_num);
+
+/* FASTQ composition / phred guess (fastq.c:715-774). */
+void fxo_fastq_composition(const uint8_t *data, int64_t n, fxo_fastq_comp *out);
+
+/* util.c:157-194: in-place removal of bytes 10, 13, 32; optional ASCII upper. */
+int64_t fxo_despace(uint8_t *buf, int64_t n, int upper);
+
+/* util.c:228-269: mode bit0 = reverse, bit1 = complement (comp_map LUT). */
+void fxo_revcomp(uint8_t *buf, int64_t n, int mode);
+
+/* sequence.c:498-510 / fasta.c:293-320: slice [start,stop) (0-based) of a
+ * norm=1 record -> byte range. */
+void fxo_slice_range(int64_t boff, int64_t llen, int32_t elen, int64_t start,
+                     int64_t stop, int64_t *off, int64_t *blen);
+
+/* index.c:683-707 + sequence.c:337-398: read blen bytes at off, despace
+ * [+upper], keep the first min(slen, despaced) bytes, optional reverse /
+ * complement.  flags: 1=upper, 2=reverse, 4=complement.  Returns bytes written. */
+int64_t fxo_fetch(const uint8_t *data, int64_t n, int64_t off, int64_t blen,
+                  int64_t slen, int flags, uint8_t *out);
+
+/* read.c:251-278: quali[i] = qual[i] - phred. */
+void fxo_quali(const uint8_t *data, int64_t qoff, int64_t rlen, int phred, int8_t *out);
+
+#endif

@@ -1,0 +1,156 @@
+"""ctypes binding of the CPU oracle (oracle/fx_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg as the *checker*.  Nothing under pyfastx_amd/
+imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+FASTA_REC = np.dtype([
+    ("hoff", "<i8"), ("boff", "<i8"), ("blen", "<i8"), ("slen", "<i8"), ("llen", "<i8"),
+    ("name_off", "<i8"), ("name_len", "<i4"), ("elen", "<i4"), ("norm", "<i4"), ("dlen", "<i4"),
+], align=True)
+
+FASTQ_REC = np.dtype([
+    ("name_off", "<i8"), ("rlen", "<i8"), ("soff", "<i8"), ("qoff", "<i8"),
+    ("name_len", "<i4"), ("dlen", "<i4"),
+], align=True)
+
+
+class FastqComp(C.Structure):
+    _fields_ = [("a", C.c_int64), ("c", C.c_int64), ("g", C.c_int64), ("t", C.c_int64),
+                ("n", C.c_int64), ("maxlen", C.c_int64), ("minlen", C.c_int64),
+                ("minqs", C.c_int32), ("maxqs", C.c_int32), ("phred", C.c_int32)]
+
+
+def build():
+    """(Re)build oracle/libfxoracle.so with gcc."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "port"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libfxoracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+        L.fxo_fasta_index.restype = i64
+        L.fxo_fasta_index.argtypes = [vp, i64, i32, vp, i64, C.POINTER(i64)]
+        L.fxo_fasta_comp.restype = i64
+        L.fxo_fasta_comp.argtypes = [vp, i64, vp, i64]
+        L.fxo_fastq_index.restype = i64
+        L.fxo_fastq_index.argtypes = [vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64)]
+        L.fxo_fastq_composition.restype = None
+        L.fxo_fastq_composition.argtypes = [vp, i64, C.POINTER(FastqComp)]
+        L.fxo_despace.restype = i64
+        L.fxo_despace.argtypes = [vp, i64, i32]
+        L.fxo_revcomp.restype = None
+        L.fxo_revcomp.argtypes = [vp, i64, i32]
+        L.fxo_slice_range.restype = None
+        L.fxo_slice_range.argtypes = [i64, i64, C.c_int32, i64, i64, C.POINTER(i64), C.POINTER(i64)]
+        L.fxo_fetch.restype = i64
+        L.fxo_fetch.argtypes = [vp, i64, i64, i64, i64, i32, vp]
+        L.fxo_quali.restype = None
+        L.fxo_quali.argtypes = [vp, i64, i64, i32, vp]
+        _LIB = L
+    return _LIB
+
+
+def _buf(data):
+    a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data, a.size
+
+
+def fasta_index(data, full_name=False):
+    """-> (records structured array, total seqlen)."""
+    a, p, n = _buf(data)
+    tot = C.c_int64(0)
+    cnt = lib().fxo_fasta_index(p, n, int(full_name), None, 0, C.byref(tot))
+    out = np.zeros(cnt, dtype=FASTA_REC)
+    lib().fxo_fasta_index(p, n, int(full_name), out.ctypes.data, cnt, C.byref(tot))
+    return out, tot.value
+
+
+def fasta_comp(data, nrec):
+    a, p, n = _buf(data)
+    comp = np.zeros((nrec, 128), dtype=np.int64)
+    lib().fxo_fasta_comp(p, n, comp.ctypes.data, nrec)
+    return comp
+
+
+def fastq_index(data):
+    """-> (records, size, line_num)."""
+    a, p, n = _buf(data)
+    size, ln = C.c_int64(0), C.c_int64(0)
+    cnt = lib().fxo_fastq_index(p, n, None, 0, C.byref(size), C.byref(ln))
+    out = np.zeros(cnt, dtype=FASTQ_REC)
+    lib().fxo_fastq_index(p, n, out.ctypes.data, cnt, C.byref(size), C.byref(ln))
+    return out, size.value, ln.value
+
+
+def fastq_composition(data):
+    a, p, n = _buf(data)
+    o = FastqComp()
+    lib().fxo_fastq_composition(p, n, C.byref(o))
+    return {k: getattr(o, k) for k, _ in FastqComp._fields_}
+
+
+def despace(b, upper=False):
+    a = np.frombuffer(bytes(b), dtype=np.uint8).copy()
+    m = lib().fxo_despace(a.ctypes.data, a.size, int(upper))
+    return a[:m].tobytes()
+
+
+def revcomp(b, mode=3):
+    a = np.frombuffer(bytes(b), dtype=np.uint8).copy()
+    lib().fxo_revcomp(a.ctypes.data, a.size, mode)
+    return a.tobytes()
+
+
+def slice_range(boff, llen, elen, start, stop):
+    off, bl = C.c_int64(0), C.c_int64(0)
+    lib().fxo_slice_range(boff, llen, elen, start, stop, C.byref(off), C.byref(bl))
+    return off.value, bl.value
+
+
+def fetch(data, off, blen, slen, flags=0):
+    a, p, n = _buf(data)
+    out = np.zeros(max(int(blen), 1), dtype=np.uint8)
+    m = lib().fxo_fetch(p, n, int(off), int(blen), int(slen), int(flags), out.ctypes.data)
+    return out[:m].tobytes()
+
+
+def fetch_batch(data, off, blen, slen, flags=0):
+    """Loop of fxo_fetch -> (concatenated bytes array, offsets int64[n+1])."""
+    a, p, n = _buf(data)
+    off = np.asarray(off, dtype=np.int64)
+    blen = np.asarray(blen, dtype=np.int64)
+    slen = np.asarray(slen, dtype=np.int64)
+    flags = np.broadcast_to(np.asarray(flags, dtype=np.int32), off.shape)
+    cap = int(np.minimum(blen, slen).clip(min=0).sum()) + 1
+    out = np.zeros(cap, dtype=np.uint8)
+    offs = np.zeros(off.size + 1, dtype=np.int64)
+    L = lib()
+    base = out.ctypes.data
+    w = 0
+    for i in range(off.size):
+        w += L.fxo_fetch(p, n, int(off[i]), int(blen[i]), int(slen[i]), int(flags[i]), base + w)
+        offs[i + 1] = w
+    return out[:w], offs
+
+
+def quali(data, qoff, rlen, phred=0):
+    a, p, n = _buf(data)
+    out = np.zeros(int(rlen), dtype=np.int8)
+    lib().fxo_quali(p, int(qoff), int(rlen), int(phred), out.ctypes.data)
+    return out
