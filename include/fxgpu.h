@@ -1,0 +1,193 @@
+/*
+ * fxgpu.h -- C ABI of libfxgpu.so: MI355X-native FASTA/FASTQ index build and
+ * batched random access (the drop-in boundary under the pyfastx object API).
+ *
+ * pyfastx (lmdu/pyfastx v2.3.1) has no plugin/FFI layer: its hot path is a set
+ * of internal C functions inside one CPython extension.  Each entry point
+ * below names the reference function(s) whose work it replaces; the
+ * Python-facing mirror (pyfastx_amd/) binds these with ctypes, and
+ * INTEGRATION.md shows the C stub a pyfastx maintainer would add at those
+ * call sites.
+ *
+ * Conventions
+ *   - Plain C: opaque handle, pointers and sizes only.  No torch / HIP types.
+ *   - All offsets are 0-based offsets into the UNCOMPRESSED byte stream, i.e.
+ *     exactly the numbers the reference stores in its .fxi (seq.boff, read.soff...).
+ *   - Every function returns FX_OK (0) or a negative fx_status; the message is
+ *     available from fx_last_error() (thread-local).
+ *   - `where` arguments say where caller-provided arrays live: FX_HOST or
+ *     FX_DEVICE (device pointers must belong to the handle's GPU).
+ *   - There is NO CPU fallback: without a usable gfx950 device every call that
+ *     needs one fails with FX_EDEVICE.
+ *   - A handle is not re-entrant; use one handle per thread / per GPU.
+ */
+#ifndef FXGPU_H
+#define FXGPU_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fx_handle fx_handle;
+
+typedef enum {
+    FX_OK = 0,
+    FX_ENOENT = -1,   /* input file missing            -> FileExistsError (fasta.c:84-87)  */
+    FX_EFORMAT = -2,  /* not FASTA/FASTQ               -> RuntimeError    (fasta.c:107-110) */
+    FX_EIO = -3,      /* read / inflate error                                               */
+    FX_EDEVICE = -4,  /* no GPU, HIP error                                                  */
+    FX_ENOMEM = -5,
+    FX_ERANGE = -6,   /* index / interval out of range -> IndexError / ValueError           */
+    FX_EINVAL = -7,
+    FX_ESTATE = -8    /* call order (e.g. read before build)                                */
+} fx_status;
+
+enum { FX_HOST = 0, FX_DEVICE = 1 };
+
+/* fetch flags (per call) */
+enum {
+    FX_UPPER = 1,       /* remove_space_uppercase, util.c:181-194                 */
+    FX_REVERSE = 2,     /* reverse_seq, util.c:251-261                            */
+    FX_COMPLEMENT = 4   /* complement_seq / comp_map, util.c:228-237, 263-269     */
+};
+
+const char *fx_last_error(void);
+const char *fx_version(void);
+int fx_device_count(void);
+
+/* ------------------------------------------------------------------ staging
+ * Replaces gzopen/gzread streaming in pyfastx_init_index (index.c:15-98) and
+ * the per-query fseeko/fread | zran_seek/zran_read of pyfastx_index_random_read
+ * (index.c:683-692) / pyfastx_read_random_reader (read.c:37-45): the whole
+ * uncompressed stream becomes one resident blob in HBM.                        */
+
+/* Plain or gzip file -> pinned double buffers -> hipMemcpyAsync -> HBM. */
+int fx_open_file(const char *path, int device, fx_handle **out);
+/* Copy nbytes from host memory into HBM. */
+int fx_open_host(const void *data, int64_t nbytes, int device, fx_handle **out);
+/* Adopt (do not copy, do not free) a blob already in this GPU's HBM; 16-byte aligned. */
+int fx_open_device(const void *dptr, int64_t nbytes, int device, fx_handle **out);
+
+/* Shard context (multi-GPU byte-range sharding): this handle holds
+ * bytes [base, base+n) of a longer stream; prev_byte is stream[base-1] (pass
+ * 10 when base == 0); is_last says the shard ends at end-of-stream.  Default
+ * after fx_open_*: base 0, prev_byte 10, is_last 1. */
+int fx_set_shard(fx_handle *h, int64_t base, int prev_byte, int is_last);
+
+int fx_close(fx_handle *h);
+int64_t fx_size(const fx_handle *h);          /* uncompressed bytes held          */
+int fx_is_gzip(const fx_handle *h);           /* is_gzip_format, util.c:307-325   */
+const void *fx_device_ptr(const fx_handle *h);/* device address of the blob       */
+/* Raw bytes [off, off+n) of the stream -> dst (host).  Serves names,
+ * Sequence.raw / .description (sequence.c:299-335), Read.raw (read.c:124-150). */
+int fx_read_bytes(fx_handle *h, int64_t off, int64_t n, void *dst);
+/* First non-space byte of the stream (fasta_validator / fastq_validator, util.c:95-150). */
+int fx_first_byte(fx_handle *h, int *out);
+
+/* ------------------------------------------------------------ FASTA index
+ * Replaces the hot loop of pyfastx_create_index (index.c:230-372).           */
+typedef struct {
+    int64_t n_seq;        /* stat.seqnum                                      */
+    int64_t seq_len;      /* stat.seqlen  (sum of slen)                       */
+    int64_t n_lines;      /* newline-terminated lines seen (incl. EOF line)   */
+    int64_t n_bytes;
+} fx_fasta_summary;
+
+/* Build the record table on the GPU (kept resident in HBM for fetches).
+ * full_name: chrom = whole header (index.c:282-285) instead of first token. */
+int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out);
+
+/* Copy the SoA record table to caller arrays (any pointer may be NULL).
+ * Columns are exactly the .fxi `seq` columns (index.c:178-189) plus the
+ * header-line offset and the name span inside the stream. */
+int fx_fasta_table(fx_handle *h, int where,
+                   int64_t *hoff, int64_t *boff, int64_t *blen, int64_t *slen,
+                   int64_t *llen, int32_t *elen, int32_t *norm, int32_t *dlen,
+                   int32_t *name_len);
+
+/* pyfastx_fasta_calc_composition (fasta.c:851-961): comp[n_seq][128] counts of
+ * every byte value < 128 on the sequence lines of each record ('\r' included,
+ * '\n' excluded).  Needs fx_fasta_build first. */
+int fx_fasta_comp(fx_handle *h, int where, int64_t *comp);
+
+/* ------------------------------------------------------------ FASTQ index
+ * Replaces pyfastx_fastq_create_index (fastq.c:89-171).                      */
+typedef struct {
+    int64_t n_reads;      /* stat.counts = line_num / 4                       */
+    int64_t size;         /* stat.size   = sum of rlen                        */
+    int64_t n_lines;
+    int64_t n_bytes;
+} fx_fastq_summary;
+
+int fx_fastq_build(fx_handle *h, fx_fastq_summary *out);
+int fx_fastq_table(fx_handle *h, int where,
+                   int64_t *name_off, int32_t *name_len, int32_t *dlen,
+                   int64_t *rlen, int64_t *soff, int64_t *qoff);
+
+/* pyfastx_fastq_calc_composition (fastq.c:715-774): base = {A,C,G,T,N},
+ * meta = {maxlen, minlen, minqs, maxqs, phred} in the .fxi column order. */
+int fx_fastq_comp(fx_handle *h, int64_t base[5], int64_t meta[5]);
+
+/* ------------------------------------------------------------------ fetch
+ * Replaces pyfastx_index_fill_cache (index.c:694-707) + remove_space[_uppercase]
+ * (util.c:166-194) + reverse/complement (util.c:239-269) for a BATCH of byte
+ * ranges: query i reads blen[i] bytes at off[i], drops bytes 10/13/32, keeps
+ * the first min(kept, slen[i]) bytes, applies flags, and writes them at
+ * dst + dst_off[i].  out_len[i] (optional) receives the bytes written.
+ * flags: per-call if flags_per_query == NULL, else flags_per_query[i].        */
+int fx_fetch_ranges(fx_handle *h, int where, int64_t n,
+                    const int64_t *off, const int64_t *blen, const int64_t *slen,
+                    int flags, const uint8_t *flags_per_query,
+                    uint8_t *dst, const int64_t *dst_off, int64_t *out_len);
+
+/* Same, but queries are (record id 0-based, start, stop) half-open 0-based
+ * base coordinates resolved against the resident FASTA table with the
+ * arithmetic of pyfastx_sequence_subscript (sequence.c:498-510) for norm=1
+ * records and despace-then-slice (sequence.c:100-110) for norm=0 records. */
+int fx_fasta_fetch(fx_handle *h, int where, int64_t n,
+                   const int64_t *seq_id, const int64_t *start, const int64_t *stop,
+                   int flags, const uint8_t *flags_per_query,
+                   uint8_t *dst, const int64_t *dst_off, int64_t *out_len);
+
+/* FASTQ reads by 0-based id (read.c:37-45, 152-167, 237-278): seq and qual
+ * are rlen bytes each at dst_off[i]; quali = qual - phred as int8
+ * (phred 0 -> 33, read.c:268).  Any of seq/qual/quali may be NULL. */
+int fx_fastq_fetch(fx_handle *h, int where, int64_t n, const int64_t *read_id,
+                   int phred, int seq_flags,
+                   uint8_t *seq, uint8_t *qual, int8_t *quali, const int64_t *dst_off);
+
+/* pyfastx.reverse_complement / reverse_seq / complement_seq on a caller buffer
+ * (module.c:44-59; util.c:239-269).  mode: FX_REVERSE | FX_COMPLEMENT.        */
+int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mode);
+
+/* ----------------------------------------------------- multi-GPU stitching
+ * Boundary summary of this shard for the single all-gather of SURVEY 8e.
+ * Fixed size, plain integers; valid after fx_fasta_build / fx_fastq_build on
+ * a handle configured with fx_set_shard.                                      */
+typedef struct {
+    int64_t base, n_bytes;
+    int64_t n_nl;              /* real newlines in the shard                              */
+    int64_t first_nl, last_nl; /* global offsets, -1 if none                              */
+    int64_t second_nl;         /* global offset of 2nd newline, -1 if none                */
+    int64_t n_hdr;             /* FASTA header lines that START in the shard              */
+    int64_t first_hdr, last_hdr;
+    int64_t lead_nl;           /* newlines before first_hdr (all of them if n_hdr == 0)   */
+    int64_t lead_v1, lead_c1;  /* lead full lines (both newlines in shard): most ...      */
+    int64_t lead_v2, lead_c2;  /* ... two distinct len+1 values and their counts          */
+    int64_t lead_full;         /* number of full lead lines                               */
+    int64_t tail_nl_after_hdr; /* newlines at/after last_hdr in the shard                 */
+    int64_t tail_hdr_end;      /* offset of newline ending the last header line, or -1    */
+    int64_t tail_first_end;    /* offset of newline ending its first sequence line, or -1 */
+    int64_t tail_bad;          /* bad lines of the last record counted locally            */
+    int32_t first_byte, last_byte;
+    int32_t tail_elen;         /* elen of last record if header newline is local else 0   */
+    int32_t is_last;
+} fx_shard_summary;
+
+int fx_shard_summary_get(fx_handle *h, fx_shard_summary *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,3 @@
+"""pyfastx_amd -- MI355X-native FASTA/FASTQ index build and random access
+behind the pyfastx object API (Fasta / Fastq / Sequence / Read)."""
+__version__ = "0.1.0"

@@ -1,0 +1,265 @@
+"""ctypes binding of libfxgpu.so (include/fxgpu.h) -- the only way pyfastx_amd
+reaches the GPU.  There is no CPU fallback: if the library is missing, or no
+gfx950 device is usable, the calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "csrc", "libfxgpu.so")
+_LIB = None
+
+FX_HOST, FX_DEVICE = 0, 1
+FX_UPPER, FX_REVERSE, FX_COMPLEMENT = 1, 2, 4
+FX_OK, FX_ENOENT, FX_EFORMAT, FX_EIO, FX_EDEVICE, FX_ENOMEM, FX_ERANGE, FX_EINVAL, FX_ESTATE = \
+    0, -1, -2, -3, -4, -5, -6, -7, -8
+
+
+class FxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class FastaSummary(C.Structure):
+    _fields_ = [("n_seq", C.c_int64), ("seq_len", C.c_int64), ("n_lines", C.c_int64), ("n_bytes", C.c_int64)]
+
+
+class FastqSummary(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("size", C.c_int64), ("n_lines", C.c_int64), ("n_bytes", C.c_int64)]
+
+
+class ShardSummary(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in (
+        "base", "n_bytes", "n_nl", "first_nl", "last_nl", "second_nl", "n_hdr", "first_hdr", "last_hdr",
+        "lead_nl", "lead_v1", "lead_c1", "lead_v2", "lead_c2", "lead_full", "tail_nl_after_hdr",
+        "tail_hdr_end", "tail_first_end", "tail_bad")] + [(k, C.c_int32) for k in (
+            "first_byte", "last_byte", "tail_elen", "is_last")]
+
+
+SYMBOLS = [
+    "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_host", "fx_open_device",
+    "fx_set_shard", "fx_close", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
+    "fx_fasta_build", "fx_fasta_table", "fx_fasta_comp", "fx_fastq_build", "fx_fastq_table", "fx_fastq_comp",
+    "fx_fetch_ranges", "fx_fasta_fetch", "fx_fastq_fetch", "fx_revcomp", "fx_shard_summary_get",
+]
+
+
+def so_path():
+    return _SO
+
+
+def lib():
+    """Load libfxgpu.so (after torch, if torch is importable, so both share one HIP runtime)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_SO):
+        raise ImportError(
+            "pyfastx_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C pyfastx_amd/csrc`.  There is no CPU fallback." % _SO)
+    try:
+        import torch  # noqa: F401  (loads torch's bundled libamdhip64 first; ours then binds to the same runtime)
+    except Exception:
+        pass
+    L = C.CDLL(_SO, mode=C.RTLD_GLOBAL)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    L.fx_last_error.restype = C.c_char_p
+    L.fx_version.restype = C.c_char_p
+    L.fx_device_count.restype = i32
+    L.fx_open_file.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+    L.fx_open_host.argtypes = [vp, i64, i32, C.POINTER(vp)]
+    L.fx_open_device.argtypes = [vp, i64, i32, C.POINTER(vp)]
+    L.fx_set_shard.argtypes = [vp, i64, i32, i32]
+    L.fx_close.argtypes = [vp]
+    L.fx_size.restype = i64
+    L.fx_size.argtypes = [vp]
+    L.fx_is_gzip.argtypes = [vp]
+    L.fx_device_ptr.restype = vp
+    L.fx_device_ptr.argtypes = [vp]
+    L.fx_read_bytes.argtypes = [vp, i64, i64, vp]
+    L.fx_first_byte.argtypes = [vp, C.POINTER(i32)]
+    L.fx_fasta_build.argtypes = [vp, i32, C.POINTER(FastaSummary)]
+    L.fx_fasta_table.argtypes = [vp, i32] + [vp] * 9
+    L.fx_fasta_comp.argtypes = [vp, i32, vp]
+    L.fx_fastq_build.argtypes = [vp, C.POINTER(FastqSummary)]
+    L.fx_fastq_table.argtypes = [vp, i32] + [vp] * 6
+    L.fx_fastq_comp.argtypes = [vp, vp, vp]
+    L.fx_fetch_ranges.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.fx_fasta_fetch.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.fx_fastq_fetch.argtypes = [vp, i32, i64, vp, i32, i32, vp, vp, vp, vp]
+    L.fx_revcomp.argtypes = [i32, i32, vp, i64, i32]
+    L.fx_shard_summary_get.argtypes = [vp, C.POINTER(ShardSummary)]
+    for s in SYMBOLS:
+        if getattr(L, s).restype is C.c_int:
+            pass
+    _LIB = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise FxError(rc, lib().fx_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class Blob:
+    """Owning wrapper of an fx_handle: one staged stream resident in HBM."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    # -- constructors -------------------------------------------------------
+    @classmethod
+    def from_file(cls, path, device=0):
+        h = C.c_void_p()
+        check(lib().fx_open_file(os.fsencode(path), device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_bytes(cls, data, device=0):
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        h = C.c_void_p()
+        check(lib().fx_open_host(a.ctypes.data if a.size else None, a.size, device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_device(cls, dptr, nbytes, device=0, keepalive=None):
+        h = C.c_void_p()
+        check(lib().fx_open_device(C.c_void_p(dptr), nbytes, device, C.byref(h)))
+        b = cls(h)
+        b._keep = keepalive
+        return b
+
+    def close(self):
+        if self._h:
+            lib().fx_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- basics -------------------------------------------------------------
+    @property
+    def size(self):
+        return lib().fx_size(self._h)
+
+    @property
+    def is_gzip(self):
+        return bool(lib().fx_is_gzip(self._h))
+
+    @property
+    def device_ptr(self):
+        return lib().fx_device_ptr(self._h)
+
+    def set_shard(self, base, prev_byte, is_last):
+        check(lib().fx_set_shard(self._h, base, prev_byte, int(is_last)))
+
+    def read_bytes(self, off, n):
+        out = np.empty(max(int(n), 0), dtype=np.uint8)
+        if n > 0:
+            check(lib().fx_read_bytes(self._h, int(off), int(n), out.ctypes.data))
+        return out.tobytes()
+
+    def first_byte(self):
+        v = C.c_int(-1)
+        check(lib().fx_first_byte(self._h, C.byref(v)))
+        return v.value
+
+    # -- FASTA --------------------------------------------------------------
+    def fasta_build(self, full_name=False):
+        s = FastaSummary()
+        check(lib().fx_fasta_build(self._h, int(bool(full_name)), C.byref(s)))
+        return s
+
+    def fasta_table(self, n):
+        cols = {k: np.empty(n, dtype=np.int64) for k in ("hoff", "boff", "blen", "slen", "llen")}
+        cols.update({k: np.empty(n, dtype=np.int32) for k in ("elen", "norm", "dlen", "name_len")})
+        check(lib().fx_fasta_table(self._h, FX_HOST, *[_ptr(cols[k]) for k in (
+            "hoff", "boff", "blen", "slen", "llen", "elen", "norm", "dlen", "name_len")]))
+        return cols
+
+    def fasta_comp(self, n):
+        comp = np.zeros((n, 128), dtype=np.int64)
+        check(lib().fx_fasta_comp(self._h, FX_HOST, comp.ctypes.data))
+        return comp
+
+    # -- FASTQ --------------------------------------------------------------
+    def fastq_build(self):
+        s = FastqSummary()
+        check(lib().fx_fastq_build(self._h, C.byref(s)))
+        return s
+
+    def fastq_table(self, n):
+        cols = {k: np.empty(n, dtype=np.int64) for k in ("name_off", "rlen", "soff", "qoff")}
+        cols.update({k: np.empty(n, dtype=np.int32) for k in ("name_len", "dlen")})
+        check(lib().fx_fastq_table(self._h, FX_HOST, _ptr(cols["name_off"]), _ptr(cols["name_len"]),
+                                   _ptr(cols["dlen"]), _ptr(cols["rlen"]), _ptr(cols["soff"]), _ptr(cols["qoff"])))
+        return cols
+
+    def fastq_comp(self):
+        base = np.zeros(5, dtype=np.int64)
+        meta = np.zeros(5, dtype=np.int64)
+        check(lib().fx_fastq_comp(self._h, base.ctypes.data, meta.ctypes.data))
+        return base, meta
+
+    # -- fetch (host arrays) ------------------------------------------------
+    @staticmethod
+    def _i64(a):
+        return np.ascontiguousarray(a, dtype=np.int64)
+
+    def fetch_ranges(self, off, blen, slen, flags=0, flags_per_query=None):
+        """-> (uint8 buffer, offsets int64[n+1] (exclusive cumsum of slen), out_len int64[n])."""
+        off, blen, slen = self._i64(off), self._i64(blen), self._i64(slen)
+        n = off.size
+        offs = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.maximum(slen, 0), out=offs[1:])
+        dst = np.zeros(max(int(offs[-1]), 1), dtype=np.uint8)
+        out_len = np.zeros(n, dtype=np.int64)
+        fpq = None if flags_per_query is None else np.ascontiguousarray(flags_per_query, dtype=np.uint8)
+        if n:
+            check(lib().fx_fetch_ranges(self._h, FX_HOST, n, _ptr(off), _ptr(blen), _ptr(slen), int(flags),
+                                        _ptr(fpq), _ptr(dst), _ptr(offs), _ptr(out_len)))
+        return dst[:int(offs[-1])], offs, out_len
+
+    def fasta_fetch(self, seq_id, start, stop, flags=0, flags_per_query=None):
+        seq_id, start, stop = self._i64(seq_id), self._i64(start), self._i64(stop)
+        n = seq_id.size
+        offs = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.maximum(stop - start, 0), out=offs[1:])
+        dst = np.zeros(max(int(offs[-1]), 1), dtype=np.uint8)
+        out_len = np.zeros(n, dtype=np.int64)
+        fpq = None if flags_per_query is None else np.ascontiguousarray(flags_per_query, dtype=np.uint8)
+        if n:
+            check(lib().fx_fasta_fetch(self._h, FX_HOST, n, _ptr(seq_id), _ptr(start), _ptr(stop), int(flags),
+                                       _ptr(fpq), _ptr(dst), _ptr(offs), _ptr(out_len)))
+        return dst[:int(offs[-1])], offs, out_len
+
+    def fastq_fetch(self, read_id, rlen, phred=0, seq_flags=0, want=("seq", "qual", "quali")):
+        read_id = self._i64(read_id)
+        rlen = self._i64(rlen)
+        n = read_id.size
+        offs = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(rlen, out=offs[1:])
+        tot = max(int(offs[-1]), 1)
+        seq = np.zeros(tot, dtype=np.uint8) if "seq" in want else None
+        qual = np.zeros(tot, dtype=np.uint8) if "qual" in want else None
+        qi = np.zeros(tot, dtype=np.int8) if "quali" in want else None
+        if n:
+            check(lib().fx_fastq_fetch(self._h, FX_HOST, n, _ptr(read_id), int(phred), int(seq_flags),
+                                       _ptr(seq), _ptr(qual), _ptr(qi), _ptr(offs)))
+        return seq, qual, qi, offs
+
+
+def revcomp_bytes(b, mode=FX_REVERSE | FX_COMPLEMENT, device=0):
+    a = np.frombuffer(bytes(b), dtype=np.uint8).copy()
+    if a.size:
+        check(lib().fx_revcomp(device, FX_HOST, a.ctypes.data, a.size, mode))
+    return a.tobytes()

@@ -1,0 +1,741 @@
+// fxgpu.hip -- libfxgpu.so: C ABI (include/fxgpu.h) over the gfx950 kernels in
+// fx_kernels.hpp.  Host side: staging (file -> pinned -> HBM), launch
+// sequencing, table read-back.  No CPU fallback: every compute entry point
+// needs a HIP device and fails with FX_EDEVICE otherwise.
+#include <hip/hip_runtime.h>
+#include <zlib.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/fxgpu.h"
+#include "fx_kernels.hpp"
+
+using namespace fx;
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return fail(e__ == hipErrorOutOfMemory ? FX_ENOMEM : FX_EDEVICE, "%s: %s (%s:%d)", #expr,  \
+                        hipGetErrorString(e__), __FILE__, __LINE__);                                   \
+    } while (0)
+
+extern "C" const char *fx_last_error(void) { return g_err.c_str(); }
+extern "C" const char *fx_version(void) { return "fxgpu 0.1.0 (gfx950)"; }
+extern "C" int fx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------ handle
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    int64_t n = 0;
+    int alloc(int64_t count) {
+        release();
+        n = count;
+        if (count <= 0) { n = 0; return FX_OK; }
+        hipError_t e = hipMalloc((void **)&p, (size_t)count * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; n = 0; return fail(FX_ENOMEM, "hipMalloc(%lld B): %s", (long long)(count * sizeof(T)), hipGetErrorString(e)); }
+        return FX_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    ~DevBuf() { release(); }
+};
+
+struct fx_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // resident stream
+    uint8_t *d_data = nullptr;
+    bool owns = false;
+    int64_t n = 0;
+    bool gz = false;
+    // shard context
+    int64_t base = 0;
+    int prev_byte = '\n';
+    bool is_last = true;
+    // scan products
+    int64_t ntiles = 0;
+    DevBuf<uint16_t> nlmask;
+    DevBuf<uint32_t> tile_nl, tile_hdr;
+    DevBuf<int64_t> tile_nl_off, tile_hdr_off;
+    DevBuf<int64_t> nl;       // line table incl. virtual EOF newline
+    int64_t n_nl = 0;         // entries in nl
+    int64_t n_real_nl = 0;    // real '\n' bytes
+    bool scanned = false, scanned_hdr = false;
+    // FASTA table
+    DevBuf<int64_t> hdr, fa_boff, fa_blen, fa_slen, fa_llen, fa_hdr_line;
+    DevBuf<int32_t> fa_elen, fa_norm, fa_dlen, fa_name_len;
+    DevBuf<uint32_t> fa_bad;
+    DevBuf<unsigned long long> scalars;   // [0] = seqlen total
+    int64_t n_hdr = 0, fa_seqlen = 0;
+    bool fasta_built = false;
+    // FASTQ table
+    DevBuf<int64_t> fq_name_off, fq_rlen, fq_soff, fq_qoff;
+    DevBuf<int32_t> fq_name_len, fq_dlen;
+    DevBuf<FastqAcc> fq_acc;
+    int64_t n_reads = 0, fq_size = 0;
+    long long fq_maxlen = 0, fq_minlen = 0;
+    bool fastq_built = false;
+};
+
+static int use_device(const fx_handle *h) {
+    HIPCHK(hipSetDevice(h->device));
+    return FX_OK;
+}
+
+static int new_handle(int device, fx_handle **out) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(FX_EDEVICE, "no HIP device available (%s); libfxgpu has no CPU fallback", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(FX_EDEVICE, "device %d out of range (have %d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    fx_handle *h = new fx_handle();
+    h->device = device;
+    e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail(FX_EDEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    *out = h;
+    return FX_OK;
+}
+
+static int alloc_blob(fx_handle *h, int64_t n) {
+    // pad to a whole tile so vector loads of the last chunk stay inside the allocation
+    const int64_t padded = ((n + TILE - 1) / TILE) * TILE + TILE;
+    HIPCHK(hipMalloc((void **)&h->d_data, (size_t)padded));
+    h->owns = true;
+    h->n = n;
+    if (padded > n) HIPCHK(hipMemsetAsync(h->d_data + n, 0, (size_t)(padded - n), h->stream));
+    return FX_OK;
+}
+
+extern "C" int fx_close(fx_handle *h) {
+    if (!h) return FX_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->owns && h->d_data) (void)hipFree(h->d_data);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return FX_OK;
+}
+
+extern "C" int64_t fx_size(const fx_handle *h) { return h ? h->n : 0; }
+extern "C" int fx_is_gzip(const fx_handle *h) { return h && h->gz; }
+extern "C" const void *fx_device_ptr(const fx_handle *h) { return h ? h->d_data : nullptr; }
+
+extern "C" int fx_set_shard(fx_handle *h, int64_t base, int prev_byte, int is_last) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    h->base = base;
+    h->prev_byte = base == 0 ? '\n' : (prev_byte & 0xFF);
+    h->is_last = is_last != 0;
+    h->scanned = h->scanned_hdr = h->fasta_built = h->fastq_built = false;
+    return FX_OK;
+}
+
+// ----------------------------------------------------------------- staging
+static const int64_t STAGE_BYTES = 64ll << 20;   // pinned chunk size
+static const int NSTAGE = 3;
+
+struct Stager {          // pinned ring: producer fills slot, H2D async, event marks reuse
+    uint8_t *pin[NSTAGE] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[NSTAGE];
+    bool ev_ok[NSTAGE] = {false, false, false};
+    bool used[NSTAGE] = {false, false, false};
+    int init() {
+        for (int i = 0; i < NSTAGE; ++i) {
+            HIPCHK(hipHostMalloc((void **)&pin[i], (size_t)STAGE_BYTES, hipHostMallocDefault));
+            HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+            ev_ok[i] = true;
+        }
+        return FX_OK;
+    }
+    ~Stager() {
+        for (int i = 0; i < NSTAGE; ++i) {
+            if (ev_ok[i]) (void)hipEventDestroy(ev[i]);
+            if (pin[i]) (void)hipHostFree(pin[i]);
+        }
+    }
+};
+
+static void parallel_pread(int fd, uint8_t *dst, int64_t off, int64_t len, std::atomic<int> *err) {
+    // 4 threads: page-cache -> pinned memcpy is the host-side bottleneck of staging
+    const int T = 4;
+    const int64_t per = (len + T - 1) / T;
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) {
+        const int64_t lo = t * per, hi = std::min(len, lo + per);
+        if (lo >= hi) break;
+        th.emplace_back([=]() {
+            int64_t done = lo;
+            while (done < hi) {
+                ssize_t r = pread(fd, dst + done, (size_t)(hi - done), (off_t)(off + done));
+                if (r <= 0) { err->store(1); return; }
+                done += r;
+            }
+        });
+    }
+    for (auto &x : th) x.join();
+}
+
+extern "C" int fx_open_file(const char *path, int device, fx_handle **out) {
+    if (!path || !out) return fail(FX_EINVAL, "null argument");
+    struct stat st;
+    if (stat(path, &st) != 0 || !S_ISREG(st.st_mode)) return fail(FX_ENOENT, "the input file %s does not exists", path);
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(FX_ENOENT, "cannot open %s", path);
+    unsigned char magic[4] = {0, 0, 0, 0};
+    ssize_t got = pread(fd, magic, 4, 0);
+    const bool gz = got == 4 && magic[0] == 0x1f && magic[1] == 0x8b && magic[2] == 0x08;   // util.c:307-325
+
+    fx_handle *h = nullptr;
+    int rc = new_handle(device, &h);
+    if (rc) { close(fd); return rc; }
+    h->gz = gz;
+    Stager st_;
+    rc = st_.init();
+    if (rc) { close(fd); fx_close(h); return rc; }
+
+    auto bail = [&](int code) { close(fd); fx_close(h); return code; };
+
+    if (!gz) {
+        const int64_t n = (int64_t)st.st_size;
+        rc = alloc_blob(h, n);
+        if (rc) return bail(rc);
+        std::atomic<int> err(0);
+        int slot = 0;
+        for (int64_t off = 0; off < n; off += STAGE_BYTES, slot = (slot + 1) % NSTAGE) {
+            const int64_t len = std::min(STAGE_BYTES, n - off);
+            if (st_.used[slot]) { hipError_t e = hipEventSynchronize(st_.ev[slot]); if (e != hipSuccess) return bail(fail(FX_EDEVICE, "event sync: %s", hipGetErrorString(e))); }
+            parallel_pread(fd, st_.pin[slot], off, len, &err);
+            if (err.load()) return bail(fail(FX_EIO, "read error on %s", path));
+            hipError_t e = hipMemcpyAsync(h->d_data + off, st_.pin[slot], (size_t)len, hipMemcpyHostToDevice, h->stream);
+            if (e == hipSuccess) e = hipEventRecord(st_.ev[slot], h->stream);
+            if (e != hipSuccess) return bail(fail(FX_EDEVICE, "H2D: %s", hipGetErrorString(e)));
+            st_.used[slot] = true;
+        }
+    } else {
+        // single-stream gzip: inflate is inherently serial (zlib on the host), the
+        // inflated bytes stream through the same pinned ring into a growing blob.
+        gzFile g = gzdopen(dup(fd), "rb");
+        if (!g) return bail(fail(FX_EIO, "gzdopen failed for %s", path));
+        gzbuffer(g, 1 << 20);
+        int64_t cap = std::max<int64_t>((int64_t)st.st_size * 5, STAGE_BYTES), n = 0;
+        uint8_t *d = nullptr;
+        hipError_t e = hipMalloc((void **)&d, (size_t)cap + 2 * TILE);
+        if (e != hipSuccess) { gzclose(g); return bail(fail(FX_ENOMEM, "hipMalloc: %s", hipGetErrorString(e))); }
+        int slot = 0;
+        for (;;) {
+            if (st_.used[slot]) (void)hipEventSynchronize(st_.ev[slot]);
+            int64_t fill = 0;
+            while (fill < STAGE_BYTES) {
+                int r = gzread(g, st_.pin[slot] + fill, (unsigned)std::min<int64_t>(STAGE_BYTES - fill, 1 << 30));
+                if (r < 0) { gzclose(g); (void)hipFree(d); return bail(fail(FX_EIO, "gzip inflate error in %s", path)); }
+                if (r == 0) break;
+                fill += r;
+            }
+            if (fill == 0) break;
+            if (n + fill > cap) {           // grow: allocate bigger, device-to-device copy
+                int64_t ncap = std::max(cap * 2, n + fill);
+                uint8_t *nd = nullptr;
+                e = hipMalloc((void **)&nd, (size_t)ncap + 2 * TILE);
+                if (e == hipSuccess) e = hipMemcpyAsync(nd, d, (size_t)n, hipMemcpyDeviceToDevice, h->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+                if (e != hipSuccess) { gzclose(g); (void)hipFree(d); return bail(fail(FX_ENOMEM, "grow: %s", hipGetErrorString(e))); }
+                (void)hipFree(d);
+                d = nd; cap = ncap;
+            }
+            e = hipMemcpyAsync(d + n, st_.pin[slot], (size_t)fill, hipMemcpyHostToDevice, h->stream);
+            if (e == hipSuccess) e = hipEventRecord(st_.ev[slot], h->stream);
+            if (e != hipSuccess) { gzclose(g); (void)hipFree(d); return bail(fail(FX_EDEVICE, "H2D: %s", hipGetErrorString(e))); }
+            st_.used[slot] = true;
+            n += fill;
+            slot = (slot + 1) % NSTAGE;
+            if (fill < STAGE_BYTES) break;
+        }
+        gzclose(g);
+        h->d_data = d; h->owns = true; h->n = n;
+        e = hipMemsetAsync(d + n, 0, (size_t)(cap + 2 * TILE - n), h->stream);
+        if (e != hipSuccess) return bail(fail(FX_EDEVICE, "memset: %s", hipGetErrorString(e)));
+    }
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return bail(fail(FX_EDEVICE, "stream sync: %s", hipGetErrorString(e)));
+    close(fd);
+    *out = h;
+    return FX_OK;
+}
+
+extern "C" int fx_open_host(const void *data, int64_t nbytes, int device, fx_handle **out) {
+    if ((!data && nbytes) || nbytes < 0 || !out) return fail(FX_EINVAL, "bad argument");
+    fx_handle *h = nullptr;
+    int rc = new_handle(device, &h);
+    if (rc) return rc;
+    rc = alloc_blob(h, nbytes);
+    if (rc) { fx_close(h); return rc; }
+    if (nbytes) {
+        hipError_t e = hipMemcpyAsync(h->d_data, data, (size_t)nbytes, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { fx_close(h); return fail(FX_EDEVICE, "H2D: %s", hipGetErrorString(e)); }
+    }
+    const unsigned char *m = (const unsigned char *)data;
+    h->gz = false;
+    (void)m;
+    *out = h;
+    return FX_OK;
+}
+
+extern "C" int fx_open_device(const void *dptr, int64_t nbytes, int device, fx_handle **out) {
+    if (!dptr || nbytes < 0 || !out) return fail(FX_EINVAL, "bad argument");
+    if (((uintptr_t)dptr & 15) != 0) return fail(FX_EINVAL, "device blob must be 16-byte aligned");
+    fx_handle *h = nullptr;
+    int rc = new_handle(device, &h);
+    if (rc) return rc;
+    h->d_data = (uint8_t *)dptr;
+    h->owns = false;
+    h->n = nbytes;
+    *out = h;
+    return FX_OK;
+}
+
+extern "C" int fx_read_bytes(fx_handle *h, int64_t off, int64_t n, void *dst) {
+    if (!h || !dst) return fail(FX_EINVAL, "null argument");
+    int rc = use_device(h);
+    if (rc) return rc;
+    off -= h->base;
+    if (n < 0 || off < 0 || off > h->n) return fail(FX_ERANGE, "read_bytes range [%lld,+%lld) outside stream of %lld bytes", (long long)off, (long long)n, (long long)h->n);
+    const int64_t m = std::min(n, h->n - off);
+    if (m < n) memset((char *)dst + m, 0, (size_t)(n - m));
+    if (m > 0) {
+        HIPCHK(hipMemcpyAsync(dst, h->d_data + off, (size_t)m, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return FX_OK;
+}
+
+extern "C" int fx_first_byte(fx_handle *h, int *out) {
+    // fasta_validator / fastq_validator (util.c:95-150): first byte that is not isspace()
+    if (!h || !out) return fail(FX_EINVAL, "null argument");
+    *out = -1;
+    unsigned char buf[4096];
+    for (int64_t off = 0; off < h->n; off += (int64_t)sizeof buf) {
+        const int64_t m = std::min<int64_t>(sizeof buf, h->n - off);
+        int rc = fx_read_bytes(h, h->base + off, m, buf);
+        if (rc) return rc;
+        for (int64_t i = 0; i < m; ++i) {
+            unsigned char c = buf[i];
+            if (!(c == ' ' || (c >= 9 && c <= 13))) { *out = c; return FX_OK; }
+        }
+    }
+    return FX_OK;
+}
+
+// -------------------------------------------------------------------- scan
+static inline unsigned nblocks(int64_t n, int per) { return (unsigned)std::max<int64_t>(1, (n + per - 1) / per); }
+
+static int run_scan(fx_handle *h, bool want_hdr) {
+    if (h->scanned && (h->scanned_hdr || !want_hdr)) return FX_OK;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (h->n <= 0) return fail(FX_EFORMAT, "empty input");
+    h->ntiles = (h->n + TILE - 1) / TILE;
+    if ((rc = h->nlmask.alloc(h->ntiles * TILE_CHUNKS))) return rc;
+    if ((rc = h->tile_nl.alloc(h->ntiles))) return rc;
+    if ((rc = h->tile_nl_off.alloc(h->ntiles + 1))) return rc;
+    if (want_hdr) {
+        if ((rc = h->tile_hdr.alloc(h->ntiles))) return rc;
+        if ((rc = h->tile_hdr_off.alloc(h->ntiles + 1))) return rc;
+        hipLaunchKernelGGL(k_scan<true>, dim3((unsigned)h->ntiles), dim3(BLOCK), 0, h->stream, h->d_data, h->n,
+                           h->prev_byte, h->nlmask.p, h->tile_nl.p, h->tile_hdr.p);
+        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, h->tile_hdr.p, h->ntiles, h->tile_hdr_off.p);
+    } else {
+        hipLaunchKernelGGL(k_scan<false>, dim3((unsigned)h->ntiles), dim3(BLOCK), 0, h->stream, h->d_data, h->n,
+                           h->prev_byte, h->nlmask.p, h->tile_nl.p, (uint32_t *)nullptr);
+    }
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, h->tile_nl.p, h->ntiles, h->tile_nl_off.p);
+    HIPCHK(hipGetLastError());
+    // totals + last byte back to the host (needed to size the tables)
+    int64_t tot_nl = 0, tot_hdr = 0;
+    uint8_t last = 0;
+    HIPCHK(hipMemcpyAsync(&tot_nl, h->tile_nl_off.p + h->ntiles, 8, hipMemcpyDeviceToHost, h->stream));
+    if (want_hdr) HIPCHK(hipMemcpyAsync(&tot_hdr, h->tile_hdr_off.p + h->ntiles, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&last, h->d_data + h->n - 1, 1, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->n_real_nl = tot_nl;
+    // virtual newline at end-of-stream when the last line is unterminated: reproduces
+    // `position += line.l + 1` for that line (index.c:231, fastq.c:148)
+    const bool virt = h->is_last && last != '\n';
+    h->n_nl = tot_nl + (virt ? 1 : 0);
+    if ((rc = h->nl.alloc(std::max<int64_t>(h->n_nl, 1)))) return rc;
+    hipLaunchKernelGGL(k_linetable, dim3((unsigned)h->ntiles), dim3(BLOCK), 0, h->stream, h->nlmask.p,
+                       h->tile_nl_off.p, h->base, h->nl.p);
+    if (virt) {
+        const int64_t v = h->base + h->n;
+        HIPCHK(hipMemcpyAsync(h->nl.p + tot_nl, &v, 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));     // &v is a stack temporary
+    }
+    if (want_hdr) {
+        h->n_hdr = tot_hdr;
+        if ((rc = h->hdr.alloc(std::max<int64_t>(tot_hdr, 1)))) return rc;
+        if (tot_hdr)
+            hipLaunchKernelGGL(k_hdr_scatter, dim3((unsigned)h->ntiles), dim3(BLOCK), 0, h->stream, h->d_data, h->n,
+                               h->prev_byte, h->tile_hdr.p, h->tile_hdr_off.p, h->base, h->hdr.p);
+        h->scanned_hdr = true;
+    }
+    HIPCHK(hipGetLastError());
+    h->scanned = true;
+    return FX_OK;
+}
+
+// ------------------------------------------------------------- FASTA build
+extern "C" int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    int rc = run_scan(h, true);
+    if (rc) return rc;
+    const int64_t nh = h->n_hdr;
+    if (nh <= 0) return fail(FX_EFORMAT, "no FASTA header line ('>') found");
+    if ((rc = h->fa_boff.alloc(nh)) || (rc = h->fa_blen.alloc(nh)) || (rc = h->fa_slen.alloc(nh)) ||
+        (rc = h->fa_llen.alloc(nh)) || (rc = h->fa_hdr_line.alloc(nh)) || (rc = h->fa_elen.alloc(nh)) ||
+        (rc = h->fa_norm.alloc(nh)) || (rc = h->fa_dlen.alloc(nh)) || (rc = h->fa_name_len.alloc(nh)) ||
+        (rc = h->fa_bad.alloc(nh)) || (rc = h->scalars.alloc(8)))
+        return rc;
+    HIPCHK(hipMemsetAsync(h->scalars.p, 0, 8 * sizeof(unsigned long long), h->stream));
+    FastaCols c;
+    c.hoff = h->hdr.p;   // hoff IS hdr[]; the kernel rewrites the same value
+    c.boff = h->fa_boff.p; c.blen = h->fa_blen.p; c.slen = h->fa_slen.p; c.llen = h->fa_llen.p;
+    c.hdr_line = h->fa_hdr_line.p; c.elen = h->fa_elen.p; c.dlen = h->fa_dlen.p; c.name_len = h->fa_name_len.p;
+    c.bad = h->fa_bad.p;
+    hipLaunchKernelGGL(k_fasta_rec, dim3(nblocks(nh, BLOCK)), dim3(BLOCK), 0, h->stream, h->d_data, h->base, h->nl.p,
+                       h->n_nl, h->hdr.p, nh, full_name, c);
+    const unsigned lb = (unsigned)std::min<int64_t>(nblocks(h->n_nl, BLOCK), 256 * 8);
+    hipLaunchKernelGGL(k_fasta_lines, dim3(lb), dim3(BLOCK), 0, h->stream, h->nl.p, h->n_nl, h->fa_hdr_line.p, nh,
+                       h->fa_llen.p, h->fa_bad.p);
+    hipLaunchKernelGGL(k_fasta_finalize, dim3(nblocks(nh, BLOCK)), dim3(BLOCK), 0, h->stream, h->fa_bad.p,
+                       h->fa_slen.p, nh, h->fa_norm.p, h->scalars.p);
+    HIPCHK(hipGetLastError());
+    unsigned long long tot = 0;
+    HIPCHK(hipMemcpyAsync(&tot, h->scalars.p, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->fa_seqlen = (int64_t)tot;
+    h->fasta_built = true;
+    if (out) { out->n_seq = nh; out->seq_len = h->fa_seqlen; out->n_lines = h->n_nl; out->n_bytes = h->n; }
+    return FX_OK;
+}
+
+template <class T>
+static int copy_out(fx_handle *h, int where, T *dst, const T *src, int64_t n) {
+    if (!dst || n <= 0) return FX_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, (size_t)n * sizeof(T), where == FX_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    return FX_OK;
+}
+
+extern "C" int fx_fasta_table(fx_handle *h, int where, int64_t *hoff, int64_t *boff, int64_t *blen, int64_t *slen,
+                              int64_t *llen, int32_t *elen, int32_t *norm, int32_t *dlen, int32_t *name_len) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    if (!h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build has not run");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const int64_t n = h->n_hdr;
+    if ((rc = copy_out(h, where, hoff, h->hdr.p, n)) || (rc = copy_out(h, where, boff, h->fa_boff.p, n)) ||
+        (rc = copy_out(h, where, blen, h->fa_blen.p, n)) || (rc = copy_out(h, where, slen, h->fa_slen.p, n)) ||
+        (rc = copy_out(h, where, llen, h->fa_llen.p, n)) || (rc = copy_out(h, where, elen, h->fa_elen.p, n)) ||
+        (rc = copy_out(h, where, norm, h->fa_norm.p, n)) || (rc = copy_out(h, where, dlen, h->fa_dlen.p, n)) ||
+        (rc = copy_out(h, where, name_len, h->fa_name_len.p, n)))
+        return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FX_OK;
+}
+
+extern "C" int fx_fasta_comp(fx_handle *h, int where, int64_t *comp) {
+    if (!h || !comp) return fail(FX_EINVAL, "null argument");
+    if (!h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build has not run");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const int64_t n = h->n_hdr * 128;
+    DevBuf<unsigned long long> tmp;
+    unsigned long long *d = (unsigned long long *)comp;
+    if (where != FX_DEVICE) { if ((rc = tmp.alloc(n))) return rc; d = tmp.p; }
+    HIPCHK(hipMemsetAsync(d, 0, (size_t)n * 8, h->stream));
+    hipLaunchKernelGGL(k_fasta_comp, dim3((unsigned)h->ntiles), dim3(BLOCK), 0, h->stream, h->d_data, h->n, h->base,
+                       h->hdr.p, h->fa_boff.p, h->n_hdr, h->tile_hdr.p, d);
+    HIPCHK(hipGetLastError());
+    if (where != FX_DEVICE) HIPCHK(hipMemcpyAsync(comp, d, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FX_OK;
+}
+
+// ------------------------------------------------------------- FASTQ build
+extern "C" int fx_fastq_build(fx_handle *h, fx_fastq_summary *out) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    int rc = run_scan(h, false);
+    if (rc) return rc;
+    const int64_t nr = h->n_nl / 4;                        // fastq.c:159  line_num/4
+    const int64_t nseqline = (h->n_nl + 2) / 4;            // records that have a sequence line
+    const int64_t na = std::max<int64_t>(nr, 1);
+    if ((rc = h->fq_name_off.alloc(na)) || (rc = h->fq_rlen.alloc(na)) || (rc = h->fq_soff.alloc(na)) ||
+        (rc = h->fq_qoff.alloc(na)) || (rc = h->fq_name_len.alloc(na)) || (rc = h->fq_dlen.alloc(na)) ||
+        (rc = h->fq_acc.alloc(1)))
+        return rc;
+    FastqAcc init;
+    memset(&init, 0, sizeof init);
+    init.maxlen = 0; init.minlen = 10000000000LL; init.minqs = 104; init.maxqs = 33;   // fastq.c:667-675
+    HIPCHK(hipMemcpyAsync(h->fq_acc.p, &init, sizeof init, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    FastqCols c;
+    c.name_off = h->fq_name_off.p; c.rlen = h->fq_rlen.p; c.soff = h->fq_soff.p; c.qoff = h->fq_qoff.p;
+    c.name_len = h->fq_name_len.p; c.dlen = h->fq_dlen.p;
+    if (nseqline > 0)
+        hipLaunchKernelGGL(k_fastq_rec, dim3(nblocks(nseqline, BLOCK)), dim3(BLOCK), 0, h->stream, h->d_data, h->base,
+                           h->nl.p, h->n_nl, nr, c, h->fq_acc.p);
+    HIPCHK(hipGetLastError());
+    FastqAcc acc;
+    HIPCHK(hipMemcpyAsync(&acc, h->fq_acc.p, sizeof acc, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->n_reads = nr;
+    h->fq_size = (int64_t)acc.size;
+    h->fq_maxlen = acc.maxlen; h->fq_minlen = acc.minlen;
+    h->fastq_built = true;
+    if (out) { out->n_reads = nr; out->size = h->fq_size; out->n_lines = h->n_nl; out->n_bytes = h->n; }
+    return FX_OK;
+}
+
+extern "C" int fx_fastq_table(fx_handle *h, int where, int64_t *name_off, int32_t *name_len, int32_t *dlen,
+                              int64_t *rlen, int64_t *soff, int64_t *qoff) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    if (!h->fastq_built) return fail(FX_ESTATE, "fx_fastq_build has not run");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const int64_t n = h->n_reads;
+    if ((rc = copy_out(h, where, name_off, h->fq_name_off.p, n)) || (rc = copy_out(h, where, name_len, h->fq_name_len.p, n)) ||
+        (rc = copy_out(h, where, dlen, h->fq_dlen.p, n)) || (rc = copy_out(h, where, rlen, h->fq_rlen.p, n)) ||
+        (rc = copy_out(h, where, soff, h->fq_soff.p, n)) || (rc = copy_out(h, where, qoff, h->fq_qoff.p, n)))
+        return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FX_OK;
+}
+
+extern "C" int fx_fastq_comp(fx_handle *h, int64_t base[5], int64_t meta[5]) {
+    if (!h || !base || !meta) return fail(FX_EINVAL, "null argument");
+    if (!h->fastq_built) return fail(FX_ESTATE, "fx_fastq_build has not run");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const int64_t groups = (h->n_nl + 3) / 4;
+    const unsigned nb = (unsigned)std::min<int64_t>(nblocks(groups, BLOCK / 64), 256 * 8);
+    hipLaunchKernelGGL(k_fastq_comp, dim3(nb), dim3(BLOCK), 0, h->stream, h->d_data, h->base, h->nl.p, h->n_nl, groups,
+                       h->fq_acc.p);
+    HIPCHK(hipGetLastError());
+    FastqAcc acc;
+    HIPCHK(hipMemcpyAsync(&acc, h->fq_acc.p, sizeof acc, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    // reset the counters so a second call does not double count
+    FastqAcc keep = acc;
+    keep.a = keep.c = keep.g = keep.t = keep.n = 0; keep.minqs = 104; keep.maxqs = 33;
+    HIPCHK(hipMemcpyAsync(h->fq_acc.p, &keep, sizeof keep, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    base[0] = (int64_t)acc.a; base[1] = (int64_t)acc.c; base[2] = (int64_t)acc.g; base[3] = (int64_t)acc.t; base[4] = (int64_t)acc.n;
+    int phred = 0;
+    if (acc.maxqs > 74) phred = 64;                        // fastq.c:768-774
+    if (acc.minqs < 59) phred = 33;
+    meta[0] = h->fq_maxlen; meta[1] = h->fq_minlen; meta[2] = acc.minqs; meta[3] = acc.maxqs; meta[4] = phred;
+    return FX_OK;
+}
+
+// ------------------------------------------------------------------- fetch
+struct Staged {           // host arrays mirrored on the device for one call
+    std::vector<void *> bufs;
+    ~Staged() { for (void *p : bufs) (void)hipFree(p); }
+    template <class T> int up(fx_handle *h, const T *src, int64_t n, const T **dst) {
+        *dst = nullptr;
+        if (!src || n <= 0) return FX_OK;
+        void *d = nullptr;
+        hipError_t e = hipMalloc(&d, (size_t)n * sizeof(T));
+        if (e != hipSuccess) return fail(FX_ENOMEM, "hipMalloc: %s", hipGetErrorString(e));
+        bufs.push_back(d);
+        e = hipMemcpyAsync(d, src, (size_t)n * sizeof(T), hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) return fail(FX_EDEVICE, "H2D: %s", hipGetErrorString(e));
+        *dst = (const T *)d;
+        return FX_OK;
+    }
+    template <class T> int scratch(int64_t n, T **dst) {
+        void *d = nullptr;
+        hipError_t e = hipMalloc(&d, (size_t)std::max<int64_t>(n, 1) * sizeof(T));
+        if (e != hipSuccess) return fail(FX_ENOMEM, "hipMalloc: %s", hipGetErrorString(e));
+        bufs.push_back(d);
+        *dst = (T *)d;
+        return FX_OK;
+    }
+};
+
+static unsigned fetch_grid(int64_t nq) {
+    // one wave per query, 4 waves per workgroup; cap at 8 workgroups per CU and grid-stride
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((nq + 3) / 4, 256 * 8 * 4));
+}
+
+static int fetch_common(fx_handle *h, int where, int64_t n, bool by_id, const int64_t *a0, const int64_t *a1,
+                        const int64_t *a2, const int64_t *skip, int flags, const uint8_t *qflags, uint8_t *dst,
+                        const int64_t *dst_off, int64_t *out_len, int64_t dst_bytes_hint) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    if (n < 0 || (n > 0 && (!a0 || !a1 || !a2 || !dst || !dst_off))) return fail(FX_EINVAL, "null query array");
+    if (by_id && !h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build has not run");
+    if (n == 0) return FX_OK;
+    int rc = use_device(h);
+    if (rc) return rc;
+    Staged st;
+    FetchQ q;
+    memset(&q, 0, sizeof q);
+    uint8_t *d_dst = dst;
+    int64_t *d_len = out_len;
+    int64_t total = dst_bytes_hint;
+    if (where == FX_HOST) {
+        const int64_t *d0, *d1, *d2, *d3 = nullptr, *doff;
+        const uint8_t *dfl = nullptr;
+        if ((rc = st.up(h, a0, n, &d0)) || (rc = st.up(h, a1, n, &d1)) || (rc = st.up(h, a2, n, &d2)) ||
+            (rc = st.up(h, skip, n, &d3)) || (rc = st.up(h, dst_off, n, &doff)) || (rc = st.up(h, qflags, n, &dfl)))
+            return rc;
+        a0 = d0; a1 = d1; a2 = d2; skip = d3; qflags = dfl;
+        q.dst_off = doff;
+        if ((rc = st.scratch<int64_t>(n, &d_len))) return rc;
+    } else {
+        q.dst_off = dst_off;
+    }
+    if (by_id) { q.seq_id = a0; q.start = a1; q.stop = a2; }
+    else       { q.off = a0; q.blen = a1; q.take = a2; q.skip = skip; }
+    q.qflags = qflags;
+    q.out_len = d_len;
+    if (where == FX_HOST) {
+        if (total <= 0) return fail(FX_EINVAL, "internal: host fetch needs dst size");
+        if ((rc = st.scratch<uint8_t>(total, &d_dst))) return rc;
+    }
+    FastaTab tab;
+    memset(&tab, 0, sizeof tab);
+    if (h->fasta_built) {
+        tab.boff = h->fa_boff.p; tab.blen = h->fa_blen.p; tab.slen = h->fa_slen.p; tab.llen = h->fa_llen.p;
+        tab.elen = h->fa_elen.p; tab.norm = h->fa_norm.p; tab.n_seq = h->n_hdr;
+    }
+    if (by_id)
+        hipLaunchKernelGGL(k_fetch<true>, dim3(fetch_grid(n)), dim3(BLOCK), 0, h->stream, h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
+    else
+        hipLaunchKernelGGL(k_fetch<false>, dim3(fetch_grid(n)), dim3(BLOCK), 0, h->stream, h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
+    HIPCHK(hipGetLastError());
+    if (where == FX_HOST) {
+        HIPCHK(hipMemcpyAsync(dst, d_dst, (size_t)total, hipMemcpyDeviceToHost, h->stream));
+        if (out_len) HIPCHK(hipMemcpyAsync(out_len, d_len, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return FX_OK;
+}
+
+static int64_t host_extent(int64_t n, const int64_t *dst_off, const int64_t *take, const int64_t *start, const int64_t *stop) {
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t t = take ? take[i] : (stop[i] - start[i]);
+        m = std::max(m, dst_off[i] + std::max<int64_t>(t, 0));
+    }
+    return m;
+}
+
+extern "C" int fx_fetch_ranges(fx_handle *h, int where, int64_t n, const int64_t *off, const int64_t *blen,
+                               const int64_t *slen, int flags, const uint8_t *flags_per_query, uint8_t *dst,
+                               const int64_t *dst_off, int64_t *out_len) {
+    int64_t ext = 0;
+    if (where == FX_HOST && n > 0 && dst_off && slen) ext = std::max<int64_t>(1, host_extent(n, dst_off, slen, nullptr, nullptr));
+    return fetch_common(h, where, n, false, off, blen, slen, nullptr, flags, flags_per_query, dst, dst_off, out_len, ext);
+}
+
+extern "C" int fx_fasta_fetch(fx_handle *h, int where, int64_t n, const int64_t *seq_id, const int64_t *start,
+                              const int64_t *stop, int flags, const uint8_t *flags_per_query, uint8_t *dst,
+                              const int64_t *dst_off, int64_t *out_len) {
+    int64_t ext = 0;
+    if (where == FX_HOST && n > 0 && dst_off && start && stop) ext = std::max<int64_t>(1, host_extent(n, dst_off, nullptr, start, stop));
+    return fetch_common(h, where, n, true, seq_id, start, stop, nullptr, flags, flags_per_query, dst, dst_off, out_len, ext);
+}
+
+extern "C" int fx_fastq_fetch(fx_handle *h, int where, int64_t n, const int64_t *read_id, int phred, int seq_flags,
+                              uint8_t *seq, uint8_t *qual, int8_t *quali, const int64_t *dst_off) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    if (!h->fastq_built) return fail(FX_ESTATE, "fx_fastq_build has not run");
+    if (n < 0 || (n > 0 && (!read_id || !dst_off))) return fail(FX_EINVAL, "null query array");
+    if (n == 0) return FX_OK;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!phred) phred = 33;                                // read.c:268
+    Staged st;
+    const int64_t *d_ids = read_id, *d_off = dst_off;
+    uint8_t *d_seq = seq, *d_qual = qual;
+    int8_t *d_qi = quali;
+    int64_t total = 0;
+    std::vector<int64_t> rl;
+    if (where == FX_HOST) {
+        // output extent needs rlen of the requested reads
+        std::vector<int64_t> all((size_t)h->n_reads);
+        HIPCHK(hipMemcpyAsync(all.data(), h->fq_rlen.p, (size_t)h->n_reads * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int64_t i = 0; i < n; ++i) {
+            if (read_id[i] < 0 || read_id[i] >= h->n_reads) return fail(FX_ERANGE, "read id %lld out of range", (long long)read_id[i]);
+            total = std::max(total, dst_off[i] + all[(size_t)read_id[i]]);
+        }
+        total = std::max<int64_t>(total, 1);
+        if ((rc = st.up(h, read_id, n, &d_ids)) || (rc = st.up(h, dst_off, n, &d_off))) return rc;
+        if (seq && (rc = st.scratch<uint8_t>(total, &d_seq))) return rc;
+        if (qual && (rc = st.scratch<uint8_t>(total, &d_qual))) return rc;
+        if (quali && (rc = st.scratch<int8_t>(total, &d_qi))) return rc;
+    }
+    hipLaunchKernelGGL(k_fastq_fetch, dim3(fetch_grid(n)), dim3(BLOCK), 0, h->stream, h->d_data, h->base, h->fq_rlen.p,
+                       h->fq_soff.p, h->fq_qoff.p, h->n_reads, d_ids, n, phred, seq_flags, d_seq, d_qual, d_qi, d_off);
+    HIPCHK(hipGetLastError());
+    if (where == FX_HOST) {
+        if (seq) HIPCHK(hipMemcpyAsync(seq, d_seq, (size_t)total, hipMemcpyDeviceToHost, h->stream));
+        if (qual) HIPCHK(hipMemcpyAsync(qual, d_qual, (size_t)total, hipMemcpyDeviceToHost, h->stream));
+        if (quali) HIPCHK(hipMemcpyAsync(quali, d_qi, (size_t)total, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return FX_OK;
+}
+
+extern "C" int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mode) {
+    if (!buf && n) return fail(FX_EINVAL, "null buffer");
+    if (n <= 0) return FX_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(FX_EDEVICE, "no HIP device available; libfxgpu has no CPU fallback");
+    HIPCHK(hipSetDevice(device));
+    uint8_t *d = buf;
+    if (where == FX_HOST) {
+        HIPCHK(hipMalloc((void **)&d, (size_t)n));
+        hipError_t e = hipMemcpy(d, buf, (size_t)n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d); return fail(FX_EDEVICE, "H2D: %s", hipGetErrorString(e)); }
+    }
+    const unsigned nb = (unsigned)std::min<int64_t>(nblocks(n, BLOCK), 2048);
+    hipLaunchKernelGGL(k_revcomp, dim3(nb), dim3(BLOCK), 0, 0, d, n, mode);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess && where == FX_HOST) e = hipMemcpy(buf, d, (size_t)n, hipMemcpyDeviceToHost);
+    if (where == FX_HOST) (void)hipFree(d);
+    if (e != hipSuccess) return fail(FX_EDEVICE, "revcomp: %s", hipGetErrorString(e));
+    return FX_OK;
+}
+
+extern "C" int fx_shard_summary_get(fx_handle *h, fx_shard_summary *out) {
+    (void)h; (void)out;
+    return fail(FX_ESTATE, "shard summaries are produced by fx_shard_scan (not built yet)");
+}

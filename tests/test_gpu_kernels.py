@@ -1,0 +1,173 @@
+"""-m gpu: HIP path (through the C ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import fixture_bytes, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from pyfastx_amd import _lib
+    _lib.lib()
+    assert _lib.lib().fx_device_count() >= 1, "no HIP device: the GPU tests must run on the MI355X box"
+    return _lib
+
+
+def fasta_rows(blob_cls, raw, full_name=False):
+    b = blob_cls.from_bytes(raw)
+    s = b.fasta_build(full_name)
+    t = b.fasta_table(s.n_seq)
+    return b, s, t
+
+
+def assert_fasta_equal(oracle, L, raw, full_name=False):
+    recs, tot = oracle.fasta_index(raw, full_name=full_name)
+    b, s, t = fasta_rows(L.Blob, raw, full_name)
+    assert s.n_seq == len(recs)
+    assert s.seq_len == tot
+    for col in ("hoff", "boff", "blen", "slen", "llen", "elen", "norm", "dlen", "name_len"):
+        np.testing.assert_array_equal(t[col], recs[col].astype(t[col].dtype), err_msg=col)
+    comp = b.fasta_comp(s.n_seq)
+    np.testing.assert_array_equal(comp, oracle.fasta_comp(raw, len(recs)))
+    return b, recs, t
+
+
+@pytest.mark.parametrize("fn", ["test.fa", "test.fa.gz"])
+def test_fasta_fixture_index(oracle, L, fn):
+    raw = fixture_bytes(fn)
+    b, recs, t = assert_fasta_equal(oracle, L, raw)
+    g = load_golden("fasta_fixture")[fn]
+    # against the committed reference rows as well
+    for i, row in enumerate(g["seq"]):
+        name = raw[t["hoff"][i] + 1: t["hoff"][i] + 1 + t["name_len"][i]].decode()
+        got = [name] + [int(t[c][i]) for c in ("boff", "blen", "slen", "llen", "elen", "norm", "dlen")]
+        assert got == row[1:]
+    # fetches by (id, start, stop)
+    f = g["fetches"]
+    ids = np.array([x["id"] - 1 for x in f]); st = np.array([x["start"] for x in f]); sp = np.array([x["stop"] for x in f])
+    for key, fl in (("seq", 0), ("reverse", L.FX_REVERSE), ("complement", L.FX_COMPLEMENT),
+                    ("antisense", L.FX_REVERSE | L.FX_COMPLEMENT)):
+        buf, offs, ol = b.fasta_fetch(ids, st, sp, flags=fl)
+        np.testing.assert_array_equal(ol, sp - st)
+        for j, x in enumerate(f):
+            assert buf[offs[j]:offs[j + 1]].tobytes().decode() == x[key], (key, j)
+
+
+def test_fasta_edge_cases(oracle, L):
+    g = load_golden("fasta_edge")
+    for name, case in g.items():
+        if name.endswith(":upper"):
+            continue
+        raw = case["text"].encode()
+        b, recs, t = assert_fasta_equal(oracle, L, raw)
+        for i, row in enumerate(case["seq"]):
+            nm = raw[t["hoff"][i] + 1: t["hoff"][i] + 1 + t["name_len"][i]].decode()
+            got = [nm] + [int(t[c][i]) for c in ("boff", "blen", "slen", "llen", "elen", "norm", "dlen")]
+            assert got == row[1:], (name, got, row)
+        # whole records through fetch_ranges, plain and upper
+        for up, key in ((0, name), (1, name + ":upper")):
+            for rid, rec in g[key]["records"].items():
+                k = int(rid) - 1
+                buf, offs, ol = b.fetch_ranges([t["boff"][k]], [t["blen"][k]], [max(t["slen"][k], 0)], flags=up)
+                assert buf[:ol[0]].tobytes().decode("latin-1") == rec["seq"], (key, rid)
+            for fx in g[key]["fetches"]:
+                buf, offs, ol = b.fasta_fetch([fx["id"] - 1], [fx["start"]], [fx["stop"]], flags=up)
+                assert buf[:ol[0]].tobytes().decode("latin-1") == fx["seq"], (key, fx)
+                buf, offs, ol = b.fasta_fetch([fx["id"] - 1], [fx["start"]], [fx["stop"]], flags=up | 6)
+                assert buf[:ol[0]].tobytes().decode("latin-1") == fx["antisense"], (key, fx)
+
+
+@pytest.mark.parametrize("fn", ["test.fq", "test.fq.gz"])
+def test_fastq_fixture(oracle, L, fn):
+    raw = fixture_bytes(fn)
+    recs, size, ln = oracle.fastq_index(raw)
+    b = L.Blob.from_bytes(raw)
+    s = b.fastq_build()
+    assert (s.n_reads, s.size, s.n_lines) == (len(recs), size, ln)
+    t = b.fastq_table(s.n_reads)
+    for col in ("name_off", "name_len", "dlen", "rlen", "soff", "qoff"):
+        np.testing.assert_array_equal(t[col], recs[col].astype(t[col].dtype), err_msg=col)
+    base, meta = b.fastq_comp()
+    c = oracle.fastq_composition(raw)
+    assert base.tolist() == [c["a"], c["c"], c["g"], c["t"], c["n"]]
+    assert meta.tolist() == [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"], c["phred"]]
+    g = load_golden("fastq_fixture")[fn]
+    assert base.tolist() == g["base"] and meta.tolist() == g["meta"]
+    ids = np.array([r["i"] for r in g["reads"]])
+    seq, qual, qi, offs = b.fastq_fetch(ids, t["rlen"][ids], phred=g["phred"])
+    for j, r in enumerate(g["reads"]):
+        assert seq[offs[j]:offs[j + 1]].tobytes().decode() == r["seq"]
+        assert qual[offs[j]:offs[j + 1]].tobytes().decode() == r["qual"]
+        assert qi[offs[j]:offs[j + 1]].tolist() == r["quali"]
+
+
+def test_fastq_edge_cases(oracle, L):
+    for name, case in load_golden("fastq_edge").items():
+        raw = case["text"].encode()
+        b = L.Blob.from_bytes(raw)
+        s = b.fastq_build()
+        t = b.fastq_table(s.n_reads)
+        assert s.n_reads == case["count"], name
+        assert s.size == case["stat"][1], name
+        for i, row in enumerate(case["read"]):
+            nm = raw[t["name_off"][i]: t["name_off"][i] + t["name_len"][i]].decode()
+            got = [nm, int(t["dlen"][i]), int(t["rlen"][i]), int(t["soff"][i]), int(t["qoff"][i])]
+            assert got == row[1:], (name, got, row)
+        base, meta = b.fastq_comp()
+        assert base.tolist() == case["base"], name
+        assert meta.tolist() == case["meta"], name
+
+
+def test_revcomp(L):
+    for s, want in load_golden("misc")["reverse_complement"]:
+        assert L.revcomp_bytes(s.encode()).decode() == want
+
+
+def _rand_fasta(rng, nrec, width, crlf=False, ragged=False, trailing=True, lower=False):
+    eol = b"\r\n" if crlf else b"\n"
+    out = []
+    for i in range(nrec):
+        out.append(b">seq%d some desc\tx" % i + eol)
+        n = int(rng.integers(0, 5000))
+        alpha = np.frombuffer(b"ACGTNacgtn" if lower else b"ACGTN", dtype=np.uint8)
+        s = alpha[rng.integers(0, alpha.size, n)].tobytes()
+        p = 0
+        while p < n:
+            w = width if not ragged else int(rng.integers(1, width + 1))
+            out.append(s[p:p + w] + eol)
+            p += w
+    raw = b"".join(out)
+    if not trailing and raw.endswith(eol):
+        raw = raw[:-len(eol)]
+    return raw
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fasta_random(oracle, L, seed):
+    rng = np.random.default_rng(seed)
+    raw = _rand_fasta(rng, int(rng.integers(1, 60)), int(rng.integers(5, 120)), crlf=bool(seed & 1),
+                      ragged=(seed % 3 == 2), trailing=(seed != 4), lower=(seed > 2))
+    b, recs, t = assert_fasta_equal(oracle, L, raw)
+    ok = np.nonzero(recs["slen"] > 0)[0]
+    nq = 500
+    ids = rng.choice(ok, nq)
+    st = (rng.random(nq) * recs["slen"][ids]).astype(np.int64)
+    sp = np.minimum(st + rng.integers(0, 300, nq), recs["slen"][ids])
+    fl = rng.integers(0, 8, nq).astype(np.uint8)
+    buf, offs, ol = b.fasta_fetch(ids, st, sp, flags_per_query=fl)
+    for j in range(nq):
+        r = recs[ids[j]]
+        bpl = int(r["llen"]) - int(r["elen"])
+        if r["norm"] and bpl > 0:
+            off, bl = oracle.slice_range(int(r["boff"]), int(r["llen"]), int(r["elen"]), int(st[j]), int(sp[j]))
+            want = oracle.fetch(raw, off, bl, int(sp[j] - st[j]), int(fl[j]))
+        else:
+            full = oracle.fetch(raw, int(r["boff"]), int(r["blen"]), 1 << 60, int(fl[j]) & 1)
+            want = full[st[j]:sp[j]]
+            if fl[j] & 4:
+                want = oracle.revcomp(want, 2)
+            if fl[j] & 2:
+                want = want[::-1]
+        assert buf[offs[j]:offs[j] + ol[j]].tobytes() == want, (seed, j, fl[j])
