@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on MI355X: FASTA index build + 1 M random
+100-bp sub-sequence fetches on a synthetic 3 Gbp hg38-shaped plain FASTA per
+GPU (configs[1]); at N>1 the N pieces form ONE stream sharded by byte range
+across the ranks (configs[4] shape) and stitched with one RCCL all-gather.
+
+A "step" = fx_fasta_build (delimiter scan -> line table -> record table) over
+the shard resident in HBM  +  fx_fasta_fetch of 1 M (id,start,stop,strand)
+queries into a device buffer.  Inputs are resident in HBM before the timed
+region.  One JSON line on rank 0 (contract in the task statement), plus
+`roofline` for the dominant kernel (k_scan, HIP events on the library's own
+stream) and `cpu_baseline` (the real reference built from /root/reference ->
+oracle/_ref when loadable, else the C port) at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gbp", type=float, default=3.0, help="Gbp of FASTA per GPU (3.0 = BASELINE config)")
+    ap.add_argument("--queries", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(blob_t, nbytes, plan, q, verify_rows):
+    """Time the CPU path on this host: reference pyfastx (oracle/_ref) if it
+    loads, else the C port.  Sample = the FULL single-GPU workload."""
+    import tempfile
+    ids, st, sp, strand = q
+    tmpdir = tempfile.mkdtemp(prefix="fxbench")
+    path = os.path.join(tmpdir, "c2.fa")
+    host = blob_t[:nbytes].cpu().numpy()
+    out = {"cores": 1}
+    try:
+        host.tofile(path)
+        sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
+        import pyfastx                                    # the reference itself
+        t0 = time.perf_counter()
+        fa = pyfastx.Fasta(path)                          # benchmark/pyfastx_fasta_build_index.py idiom
+        t1 = time.perf_counter()
+        names = plan["names"]
+        nq = len(ids)
+        for j in range(nq):                               # benchmark/pyfastx_fasta_extract_subsequences.py idiom
+            s = fa[names[ids[j]]][int(st[j]):int(sp[j])]
+            _ = s.antisense if strand[j] else s.seq
+        t2 = time.perf_counter()
+        # full-size parity of the index rows against the real reference
+        import sqlite3
+        db = sqlite3.connect(path + ".fxi")
+        rows = db.execute("SELECT chrom,boff,blen,slen,llen,elen,norm,dlen FROM seq ORDER BY ID").fetchall()
+        db.close()
+        ok = (len(rows) == len(verify_rows)) and all(tuple(a) == tuple(b) for a, b in zip(rows, verify_rows))
+        out.update(kind="reference", index_s=t1 - t0, fetch_s=t2 - t1, rows_equal_gpu=bool(ok),
+                   sample="full workload: pyfastx.Fasta() on the %.2f GB file + %d fa[name][s:e].seq/.antisense"
+                          % (nbytes / 1e9, nq))
+        del fa
+    except Exception as e:                               # reference .so not loadable here: use the C port
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import fxoracle
+        t0 = time.perf_counter()
+        recs, tot = fxoracle.fasta_index(host)
+        t1 = time.perf_counter()
+        nq = min(len(ids), 200_000)
+        r = recs[ids[:nq]]
+        bpl = r["llen"] - r["elen"]
+        off = r["boff"] + st[:nq] + r["elen"] * (st[:nq] // bpl)
+        bl = (sp[:nq] - st[:nq]) + (sp[:nq] // bpl - st[:nq] // bpl) * r["elen"]
+        fxoracle.fetch_batch(host, off, bl, sp[:nq] - st[:nq], np.where(strand[:nq] > 0, 6, 0))
+        t2 = time.perf_counter()
+        scale = len(ids) / nq
+        out.update(kind="port", index_s=t1 - t0, fetch_s=(t2 - t1) * scale,
+                   sample="C port of the scan on the full %.2f GB + %d fetches (scaled to %d); reference unavailable: %s"
+                          % (nbytes / 1e9, nq, len(ids), str(e)[:80]))
+    finally:
+        for f in (path, path + ".fxi"):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+        try:
+            os.rmdir(tmpdir)
+        except OSError:
+            pass
+    return out
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from pyfastx_amd import _lib, synth, shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)    # "nccl" IS RCCL on ROCm
+
+    # ---------------- workload: piece `rank` of the concatenated stream, resident in HBM
+    total_bp = int(a.gbp * 1e9)
+    plan = synth.fasta_plan(total_bp=total_bp, seed=20260612 + rank, tag=("p%d_" % rank) if world > 1 else "")
+    blob, flat, flat_start = synth.fasta_generate(plan, dev, keep_flat=not a.no_verify)
+    # world > 1: the first contig of every piece crosses a shard cut, so queries (answered from
+    # the local shard only -- no collective on the fetch path) use the other contigs
+    q = synth.fasta_queries(plan, n=a.queries, seed=12345 + rank, skip_first=world > 1)
+    ids, st, sp, strand = q
+    qlen = int(sp[0] - st[0])
+    job = shard.ShardedFasta(blob, int(plan["n_bytes"]), dev, rank, world)     # moves the shard cut off the piece boundary
+    id_shift = 1 if (world > 1 and rank > 0) else 0       # local row index of piece contig i is i - id_shift
+    d_ids = torch.from_numpy(ids - id_shift).to(dev); d_st = torch.from_numpy(st).to(dev); d_sp = torch.from_numpy(sp).to(dev)
+    d_fl = torch.from_numpy((strand * 6).astype(np.uint8)).to(dev)               # '-' = reverse|complement
+    d_off = torch.arange(a.queries, device=dev, dtype=torch.int64) * qlen
+    d_out = torch.zeros(a.queries * qlen, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(a.queries, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        job.build()                                       # scan + tables (+ all-gather & stitch when world > 1)
+        t_mid = time.perf_counter()
+        job.fetch_local(a.queries, d_ids, d_st, d_sp, d_fl, d_out, d_off, d_len)
+        job.sync()
+        return t_mid
+
+    for _ in range(a.warmup):
+        step()
+    job.blob.prof_enable(True)
+    job.blob.prof_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    t_index = 0.0
+    for _ in range(a.steps):
+        ts = time.perf_counter()
+        tm = step()
+        t_index += tm - ts
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0, t_index], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    el, ti = float(elapsed[0]), float(elapsed[1])
+    prof = job.blob.prof_read()
+    job.blob.prof_enable(False)
+
+    # ---------------- parity at full size (size-independent properties + analytic truth)
+    verified = None
+    if not a.no_verify:
+        rows = job.local_rows()                           # records that START in this shard, as host arrays
+        nxt = synth.fasta_plan(total_bp=total_bp, seed=20260612 + rank + 1, tag="p%d_" % (rank + 1)) if rank < world - 1 else None
+        verified = bool(job.check_against_plan(plan, rows, nxt))
+        exp = synth.expected_fetch(flat, flat_start, ids, st, qlen, strand, dev)
+        verified = verified and bool((d_out.view(a.queries, qlen) == exp).all()) and bool((d_len == qlen).all())
+        if not verified:
+            raise SystemExit("PARITY FAILURE at full size: refusing to report a speed-up")
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    ms = el / a.steps * 1e3
+    shard_bytes = job.n_bytes
+    scan_ms, scan_n = prof.get("k_scan", (0.0, 0))
+    scan_avg = scan_ms / max(scan_n, 1)
+    achieved = shard_bytes / (scan_avg * 1e-3) / 1e9 if scan_avg > 0 else 0.0
+    line = {
+        "metric": "FASTA index build + 1M random 100bp subseq fetches, 3 Gbp plain FASTA per GPU (throughput of the whole step)",
+        "value": round(world * a.gbp / (el / a.steps), 3), "unit": "Gbp/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "configs[1]: synthetic %.1f Gbp hg38-shaped plain FASTA per GPU (200 contigs, 60-col LF, soft-masked, N runs), "
+                               "index build + %d random %d bp intervals (50%% '-' strand)" % (a.gbp, a.queries, qlen),
+                   "file_bytes_per_gpu": int(plan["n_bytes"]), "parallelism": "byte-range shards x%d, 1 all-gather" % world},
+        "index_build_s": round(ti / a.steps, 6),
+        "fetch_M_per_s": round(world * a.queries / max((el - ti) / a.steps, 1e-9) / 1e6, 2),
+        "parity_verified_full_size": verified,
+        "kernels_ms_avg": {k: round(v[0] / v[1], 4) for k, v in prof.items()},
+        "roofline": {"kernel": "fx::k_scan<true>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": shard.pmc_traffic(ROOT),
+                     "algorithmic_bytes_per_launch": int(shard_bytes), "avg_launch_ms": round(scan_avg, 4)},
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        rows = job.local_rows()
+        names = [n for n in plan["names"]]
+        vrows = [(names[i], int(rows["boff"][i]), int(rows["blen"][i]), int(rows["slen"][i]), int(rows["llen"][i]),
+                  int(rows["elen"][i]), int(rows["norm"][i]), int(rows["dlen"][i])) for i in range(len(names))]
+        cb = cpu_baseline(blob, int(plan["n_bytes"]), plan, q, vrows)
+        cpu_s = cb["index_s"] + cb["fetch_s"]
+        cb["value"] = round(a.gbp / cpu_s, 4)
+        cb["unit"] = "Gbp/s"
+        cb["index_s"] = round(cb["index_s"], 3); cb["fetch_s"] = round(cb["fetch_s"], 3)
+        cb["cpu"] = "%d logical cores on the box, 1 used (reference is single-threaded)" % (os.cpu_count() or 0)
+        line["cpu_baseline"] = cb
+        line["speedup_vs_cpu"] = round(line["value"] / cb["value"], 1)
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -161,31 +161,51 @@ int fx_fastq_fetch(fx_handle *h, int where, int64_t n, const int64_t *read_id,
  * (module.c:44-59; util.c:239-269).  mode: FX_REVERSE | FX_COMPLEMENT.        */
 int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mode);
 
+/* ------------------------------------------------------- sync and timing
+ * Calls that take FX_DEVICE arrays return after ENQUEUEING work on the
+ * handle's stream; fx_sync waits for it.  (FX_HOST calls are synchronous.)   */
+int fx_sync(fx_handle *h);
+
+/* Optional per-kernel timing with HIP events on the handle's own stream
+ * (what bench.py's roofline leg reads).  Kernel ids 0..fx_prof_count()-1,
+ * names from fx_prof_name (they match the rocprofv3 kernel names).           */
+int fx_prof_enable(fx_handle *h, int on);
+int fx_prof_reset(fx_handle *h);
+int fx_prof_count(void);
+const char *fx_prof_name(int id);
+int fx_prof_read(fx_handle *h, int id, double *total_ms, int64_t *launches);
+
 /* ----------------------------------------------------- multi-GPU stitching
  * Boundary summary of this shard for the single all-gather of SURVEY 8e.
  * Fixed size, plain integers; valid after fx_fasta_build / fx_fastq_build on
  * a handle configured with fx_set_shard.                                      */
 typedef struct {
-    int64_t base, n_bytes;
-    int64_t n_nl;              /* real newlines in the shard                              */
-    int64_t first_nl, last_nl; /* global offsets, -1 if none                              */
-    int64_t second_nl;         /* global offset of 2nd newline, -1 if none                */
-    int64_t n_hdr;             /* FASTA header lines that START in the shard              */
+    int64_t base, n_bytes, is_last;
+    int64_t n_nl;              /* entries of the shard's line table (virtual EOF newline included) */
+    int64_t first_nl, second_nl, last_nl;  /* global offsets, -1 if absent                          */
+    int64_t first_nl_prev;     /* byte before first_nl; -1 if first_nl == base (= previous shard's last_byte) */
+    int64_t first_byte, last_byte;
+    int64_t n_hdr;             /* FASTA header lines that START in the shard                        */
     int64_t first_hdr, last_hdr;
-    int64_t lead_nl;           /* newlines before first_hdr (all of them if n_hdr == 0)   */
-    int64_t lead_v1, lead_c1;  /* lead full lines (both newlines in shard): most ...      */
-    int64_t lead_v2, lead_c2;  /* ... two distinct len+1 values and their counts          */
-    int64_t lead_full;         /* number of full lead lines                               */
-    int64_t tail_nl_after_hdr; /* newlines at/after last_hdr in the shard                 */
-    int64_t tail_hdr_end;      /* offset of newline ending the last header line, or -1    */
-    int64_t tail_first_end;    /* offset of newline ending its first sequence line, or -1 */
-    int64_t tail_bad;          /* bad lines of the last record counted locally            */
-    int32_t first_byte, last_byte;
-    int32_t tail_elen;         /* elen of last record if header newline is local else 0   */
-    int32_t is_last;
-} fx_shard_summary;
+    int64_t lead_nl;           /* newlines before first_hdr (all of them if n_hdr == 0)             */
+    int64_t lead_ws;           /* first ' ' or '\t' in [base, min(first_nl, base+65536)), -1 if none */
+    int64_t lead_v1, lead_c1;  /* lead lines with both newlines in the shard: the first two ...     */
+    int64_t lead_v2, lead_c2;  /* ... distinct (len+1) values and how many lines have them          */
+    /* the last record that starts in this shard, as far as the shard can tell */
+    int64_t tail_e;            /* newline ending its header line, -1 if that is in a later shard    */
+    int64_t tail_first_end;    /* newline ending its first sequence line, -1 if later               */
+    int64_t tail_nl_after;     /* shard newlines after tail_e                                       */
+    int64_t tail_bad;          /* bad lines counted locally (valid when tail_first_end >= 0)        */
+    int64_t tail_elen, tail_dlen, tail_name_len;   /* dlen -1: header unterminated; name_len -1: no whitespace seen */
+    int64_t reserved[2];
+} fx_shard_summary;            /* 28 x int64: travels as one all-gather payload */
 
 int fx_shard_summary_get(fx_handle *h, fx_shard_summary *out);
+
+/* After the all-gather the owner of a record that crosses shard cuts rewrites
+ * that row of the resident table (and of what fx_fasta_table returns). */
+int fx_fasta_set_row(fx_handle *h, int64_t k, int64_t boff, int64_t blen, int64_t slen, int64_t llen,
+                     int32_t elen, int32_t norm, int32_t dlen, int32_t name_len);
 
 #ifdef __cplusplus
 }

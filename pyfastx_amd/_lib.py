@@ -32,10 +32,10 @@ class FastqSummary(C.Structure):
 
 class ShardSummary(C.Structure):
     _fields_ = [(k, C.c_int64) for k in (
-        "base", "n_bytes", "n_nl", "first_nl", "last_nl", "second_nl", "n_hdr", "first_hdr", "last_hdr",
-        "lead_nl", "lead_v1", "lead_c1", "lead_v2", "lead_c2", "lead_full", "tail_nl_after_hdr",
-        "tail_hdr_end", "tail_first_end", "tail_bad")] + [(k, C.c_int32) for k in (
-            "first_byte", "last_byte", "tail_elen", "is_last")]
+        "base", "n_bytes", "is_last", "n_nl", "first_nl", "second_nl", "last_nl", "first_nl_prev",
+        "first_byte", "last_byte", "n_hdr", "first_hdr", "last_hdr", "lead_nl", "lead_ws",
+        "lead_v1", "lead_c1", "lead_v2", "lead_c2", "tail_e", "tail_first_end", "tail_nl_after", "tail_bad",
+        "tail_elen", "tail_dlen", "tail_name_len", "reserved0", "reserved1")]
 
 
 SYMBOLS = [
@@ -43,6 +43,7 @@ SYMBOLS = [
     "fx_set_shard", "fx_close", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
     "fx_fasta_build", "fx_fasta_table", "fx_fasta_comp", "fx_fastq_build", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fasta_fetch", "fx_fastq_fetch", "fx_revcomp", "fx_shard_summary_get",
+    "fx_fasta_set_row", "fx_sync", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
 ]
 
 
@@ -91,6 +92,13 @@ def lib():
     L.fx_fastq_fetch.argtypes = [vp, i32, i64, vp, i32, i32, vp, vp, vp, vp]
     L.fx_revcomp.argtypes = [i32, i32, vp, i64, i32]
     L.fx_shard_summary_get.argtypes = [vp, C.POINTER(ShardSummary)]
+    L.fx_fasta_set_row.argtypes = [vp, i64, i64, i64, i64, i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.fx_sync.argtypes = [vp]
+    L.fx_prof_enable.argtypes = [vp, i32]
+    L.fx_prof_reset.argtypes = [vp]
+    L.fx_prof_name.restype = C.c_char_p
+    L.fx_prof_name.argtypes = [i32]
+    L.fx_prof_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64)]
     for s in SYMBOLS:
         if getattr(L, s).restype is C.c_int:
             pass
@@ -172,6 +180,47 @@ class Blob:
         v = C.c_int(-1)
         check(lib().fx_first_byte(self._h, C.byref(v)))
         return v.value
+
+    def sync(self):
+        check(lib().fx_sync(self._h))
+
+    def prof_enable(self, on=True):
+        check(lib().fx_prof_enable(self._h, int(on)))
+
+    def prof_reset(self):
+        check(lib().fx_prof_reset(self._h))
+
+    def prof_read(self):
+        """-> {kernel name: (total ms, launches)} for kernels that ran."""
+        out = {}
+        for i in range(lib().fx_prof_count()):
+            ms, cnt = C.c_double(0), C.c_int64(0)
+            check(lib().fx_prof_read(self._h, i, C.byref(ms), C.byref(cnt)))
+            if cnt.value:
+                out[lib().fx_prof_name(i).decode()] = (ms.value, cnt.value)
+        return out
+
+    # device-array variants (pointers are raw device addresses, e.g. tensor.data_ptr())
+    def fasta_fetch_dev(self, n, seq_id, start, stop, dst, dst_off, flags=0, flags_per_query=0, out_len=0):
+        check(lib().fx_fasta_fetch(self._h, FX_DEVICE, n, seq_id, start, stop, int(flags),
+                                   flags_per_query or None, dst, dst_off, out_len or None))
+
+    def fasta_table_dev(self, **ptrs):
+        order = ("hoff", "boff", "blen", "slen", "llen", "elen", "norm", "dlen", "name_len")
+        check(lib().fx_fasta_table(self._h, FX_DEVICE, *[ptrs.get(k) or None for k in order]))
+
+    def fasta_comp_dev(self, ptr):
+        check(lib().fx_fasta_comp(self._h, FX_DEVICE, ptr))
+
+    def shard_summary(self):
+        from .shard import Summary, FIELDS
+        s = ShardSummary()
+        check(lib().fx_shard_summary_get(self._h, C.byref(s)))
+        return Summary((k, int(getattr(s, k))) for k in FIELDS)
+
+    def fasta_set_row(self, k, boff, blen, slen, llen, elen, norm, dlen, name_len):
+        check(lib().fx_fasta_set_row(self._h, int(k), int(boff), int(blen), int(slen), int(llen), int(elen),
+                                     int(norm), int(dlen), int(name_len)))
 
     # -- FASTA --------------------------------------------------------------
     def fasta_build(self, full_name=False):

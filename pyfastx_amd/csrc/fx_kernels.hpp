@@ -263,7 +263,7 @@ struct FastaCols {
     uint32_t *bad;
 };
 
-__global__ __launch_bounds__(BLOCK) void k_fasta_rec(const uint8_t *__restrict__ data, int64_t gbase,
+__global__ __launch_bounds__(BLOCK) void k_fasta_rec(const uint8_t *__restrict__ data, int64_t gbase, int64_t n_bytes,
                                                     const int64_t *__restrict__ nl, int64_t n_nl,
                                                     const int64_t *__restrict__ hdr, int64_t n_hdr, int full_name,
                                                     FastaCols c) {
@@ -271,6 +271,20 @@ __global__ __launch_bounds__(BLOCK) void k_fasta_rec(const uint8_t *__restrict__
     if (k >= n_hdr) return;
     const int64_t h = hdr[k];
     const int64_t L = lower_bound(nl, n_nl, h);          // line index of the header line
+    if (L >= n_nl) {
+        // only possible for the LAST header of a non-final shard: its line ends in a later
+        // shard.  Leave a stub (dlen = -1) for the host-side stitch; name_len = local
+        // whitespace hit or -1.
+        int nlen = -1;
+        if (!full_name) {
+            const int64_t lim = n_bytes - (h + 1 - gbase);
+            const uint8_t *s = data + (h + 1 - gbase);
+            for (int64_t j = 0; j < lim; ++j) if (s[j] == ' ' || s[j] == '\t') { nlen = (int)j; break; }
+        }
+        c.hoff[k] = h; c.boff[k] = 0; c.blen[k] = 0; c.slen[k] = 0; c.llen[k] = 0; c.hdr_line[k] = n_nl;
+        c.elen[k] = 0; c.dlen[k] = -1; c.name_len[k] = nlen; c.bad[k] = 0;
+        return;
+    }
     const int64_t e = nl[L];                             // its terminating newline
     const int64_t boff = e + 1;                          // index.c:258  start = position
     const int elen = (data[e - 1 - gbase] == '\r') ? 2 : 1;   // index.c:266-269
@@ -319,6 +333,95 @@ __global__ __launch_bounds__(BLOCK) void k_fasta_lines(const int64_t *__restrict
         if (i <= hl + 1) continue;                              // header line or first sequence line
         if (nl[i] - nl[i - 1] != llen[rec]) atomicAdd(&bad[rec], 1u);
     }
+}
+
+// Shard lead statistics (multi-GPU stitch).  The "lead" of a shard is
+// the run of lines before its first header: they belong to a record that
+// started in an earlier shard, whose first-line length (llen) is unknown here.
+// Because only `bad_line > 1` matters (index.c:237), the lead is summarised by
+// its two first distinct line lengths and their counts: with <= 2 distinct
+// values the owner can compute its bad-line count exactly, with >= 3 it is
+// >= 2 whatever llen turns out to be.
+//   lines considered: i in [1, lead_nl) (both delimiting newlines in the shard)
+//   pass 0: v = nl[1]-nl[0];  out[0] += count(d == v), out[1] = min i with d != v
+//   pass 1: v = d at out[1];  out[2] += count(d == v)
+__global__ __launch_bounds__(BLOCK) void k_lead_stats(const int64_t *__restrict__ nl, int64_t lead_nl, int pass,
+                                                     unsigned long long *__restrict__ out) {
+    if (lead_nl < 2) return;
+    int64_t v;
+    if (pass == 0) v = nl[1] - nl[0];
+    else {
+        const int64_t j = (int64_t)out[1];
+        if (j >= lead_nl) return;
+        v = nl[j] - nl[j - 1];
+    }
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    int64_t cnt = 0;
+    unsigned long long first_ne = ~0ull;
+    for (int64_t i = 1 + (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < lead_nl; i += stride) {
+        const int64_t d = nl[i] - nl[i - 1];
+        if (d == v) ++cnt;
+        else if (first_ne == ~0ull) first_ne = (unsigned long long)i;
+    }
+    cnt = wave_sum64(cnt);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        unsigned long long o = __shfl_xor(first_ne, d, 64);
+        first_ne = o < first_ne ? o : first_ne;
+    }
+    if (lane_id() == 0) {
+        if (cnt) atomicAdd(&out[pass == 0 ? 0 : 2], (unsigned long long)cnt);
+        if (pass == 0 && first_ne != ~0ull) atomicMin(&out[1], first_ne);
+    }
+}
+
+// Collect the boundary summary of a shard into S[0..FX_SUMMARY_WORDS) (one
+// workgroup; scalars by thread 0, the bounded whitespace search by all).
+// Field order = fx_shard_summary in include/fxgpu.h.
+constexpr int FX_SUMMARY_WORDS = 28;
+__global__ __launch_bounds__(BLOCK) void k_shard_summary(const uint8_t *__restrict__ data, int64_t n, int64_t gbase,
+                                                        int is_last, const int64_t *__restrict__ nl, int64_t n_nl,
+                                                        const int64_t *__restrict__ hdr, int64_t n_hdr, FastaCols c,
+                                                        const unsigned long long *__restrict__ stats, int64_t lead_nl,
+                                                        int64_t *__restrict__ S) {
+    __shared__ unsigned long long ws;
+    if (threadIdx.x == 0) ws = ~0ull;
+    __syncthreads();
+    const int64_t first_nl = n_nl ? nl[0] : -1;
+    int64_t lim = (first_nl >= 0 ? first_nl - gbase : n);
+    if (lim > 65536) lim = 65536;
+    for (int64_t j = threadIdx.x; j < lim; j += BLOCK)
+        if (data[j] == ' ' || data[j] == '\t') { atomicMin(&ws, (unsigned long long)j); break; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    S[0] = gbase; S[1] = n; S[2] = is_last;
+    S[3] = n_nl; S[4] = first_nl; S[5] = n_nl > 1 ? nl[1] : -1; S[6] = n_nl ? nl[n_nl - 1] : -1;
+    S[7] = (first_nl > gbase) ? (int64_t)data[first_nl - 1 - gbase] : -1;
+    S[8] = data[0]; S[9] = data[n - 1];
+    S[10] = n_hdr; S[11] = n_hdr ? hdr[0] : -1; S[12] = n_hdr ? hdr[n_hdr - 1] : -1;
+    S[13] = lead_nl;
+    S[14] = (ws == ~0ull) ? -1 : gbase + (int64_t)ws;
+    int64_t v1 = 0, c1 = 0, v2 = 0, c2 = 0;
+    if (lead_nl >= 2) {
+        v1 = nl[1] - nl[0]; c1 = (int64_t)stats[0];
+        const int64_t j = (int64_t)stats[1];
+        if (j < lead_nl) { v2 = nl[j] - nl[j - 1]; c2 = (int64_t)stats[2]; }
+    }
+    S[15] = v1; S[16] = c1; S[17] = v2; S[18] = c2;
+    int64_t te = -1, tfe = -1, tna = 0, tbad = 0, telen = 0, tdlen = -1, tname = -1;
+    if (n_hdr) {
+        const int64_t k = n_hdr - 1;
+        tdlen = c.dlen[k]; tname = c.name_len[k];
+        if (tdlen >= 0) {
+            const int64_t L = c.hdr_line[k];
+            te = nl[L]; telen = c.elen[k];
+            tna = n_nl - L - 1;
+            if (L + 1 < n_nl) tfe = nl[L + 1];
+            tbad = c.bad[k];
+        }
+    }
+    S[19] = te; S[20] = tfe; S[21] = tna; S[22] = tbad; S[23] = telen; S[24] = tdlen; S[25] = tname;
+    S[26] = 0; S[27] = 0;
 }
 
 // norm (index.c:237,342) and stat.seqlen (index.c:253-254, 360-369)

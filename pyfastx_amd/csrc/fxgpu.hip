@@ -51,20 +51,67 @@ extern "C" int fx_device_count(void) {
 }
 
 // ------------------------------------------------------------------ handle
-template <class T> struct DevBuf {
+template <class T> struct DevBuf {      // grow-only device array: rebuilds reuse the allocation
     T *p = nullptr;
-    int64_t n = 0;
+    int64_t n = 0, cap = 0;
     int alloc(int64_t count) {
+        if (count <= cap && p) { n = count; return FX_OK; }
         release();
-        n = count;
-        if (count <= 0) { n = 0; return FX_OK; }
+        if (count <= 0) return FX_OK;
         hipError_t e = hipMalloc((void **)&p, (size_t)count * sizeof(T));
-        if (e != hipSuccess) { p = nullptr; n = 0; return fail(FX_ENOMEM, "hipMalloc(%lld B): %s", (long long)(count * sizeof(T)), hipGetErrorString(e)); }
+        if (e != hipSuccess) { p = nullptr; return fail(FX_ENOMEM, "hipMalloc(%lld B): %s", (long long)(count * sizeof(T)), hipGetErrorString(e)); }
+        n = cap = count;
         return FX_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = cap = 0; }
     ~DevBuf() { release(); }
 };
+
+// ------------------------------------------------------------ kernel timing
+// Optional per-kernel HIP-event timing on the handle's own stream (bench.py's
+// roofline leg reads it; off by default so the hot path records no events).
+enum KernelId { K_SCAN = 0, K_TILE_SCAN, K_LINETABLE, K_HDR_SCATTER, K_FASTA_REC, K_FASTA_LINES, K_FASTA_FINALIZE,
+                K_FETCH, K_FASTA_COMP, K_FASTQ_REC, K_FASTQ_COMP, K_FASTQ_FETCH, K_NKERN };
+static const char *const kKernelNames[K_NKERN] = {
+    "k_scan", "k_tile_scan", "k_linetable", "k_hdr_scatter", "k_fasta_rec", "k_fasta_lines", "k_fasta_finalize",
+    "k_fetch", "k_fasta_comp", "k_fastq_rec", "k_fastq_comp", "k_fastq_fetch"};
+
+struct Prof {
+    bool on = false;
+    struct Span { int id; hipEvent_t a, b; };
+    std::vector<Span> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[K_NKERN] = {0};
+    int64_t cnt[K_NKERN] = {0};
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void begin(int id, hipStream_t s) {
+        if (!on) return;
+        Span sp{id, get(), get()};
+        (void)hipEventRecord(sp.a, s);
+        pending.push_back(sp);
+    }
+    void end(hipStream_t s) { if (on) (void)hipEventRecord(pending.back().b, s); }
+    void drain() {            // call after the stream has been synchronised
+        for (auto &sp : pending) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess) { ms[sp.id] += t; cnt[sp.id]++; }
+            pool.push_back(sp.a); pool.push_back(sp.b);
+        }
+        pending.clear();
+    }
+    ~Prof() { drain(); for (auto e : pool) (void)hipEventDestroy(e); }
+};
+#define FX_LAUNCH(h, id, kern, grid, block, ...)                                  \
+    do {                                                                          \
+        (h)->prof.begin(id, (h)->stream);                                         \
+        hipLaunchKernelGGL(kern, grid, block, 0, (h)->stream, __VA_ARGS__);       \
+        (h)->prof.end((h)->stream);                                               \
+    } while (0)
 
 struct fx_handle {
     int device = 0;
@@ -101,6 +148,7 @@ struct fx_handle {
     int64_t n_reads = 0, fq_size = 0;
     long long fq_maxlen = 0, fq_minlen = 0;
     bool fastq_built = false;
+    Prof prof;
 };
 
 static int use_device(const fx_handle *h) {
@@ -355,7 +403,7 @@ extern "C" int fx_first_byte(fx_handle *h, int *out) {
 static inline unsigned nblocks(int64_t n, int per) { return (unsigned)std::max<int64_t>(1, (n + per - 1) / per); }
 
 static int run_scan(fx_handle *h, bool want_hdr) {
-    if (h->scanned && (h->scanned_hdr || !want_hdr)) return FX_OK;
+    // never cached: every build re-reads the stream (a build call is the whole job)
     int rc = use_device(h);
     if (rc) return rc;
     if (h->n <= 0) return fail(FX_EFORMAT, "empty input");
@@ -366,14 +414,14 @@ static int run_scan(fx_handle *h, bool want_hdr) {
     if (want_hdr) {
         if ((rc = h->tile_hdr.alloc(h->ntiles))) return rc;
         if ((rc = h->tile_hdr_off.alloc(h->ntiles + 1))) return rc;
-        hipLaunchKernelGGL(k_scan<true>, dim3((unsigned)h->ntiles), dim3(BLOCK), 0, h->stream, h->d_data, h->n,
+        FX_LAUNCH(h, K_SCAN, (k_scan<true>), dim3((unsigned)h->ntiles), dim3(BLOCK), h->d_data, h->n,
                            h->prev_byte, h->nlmask.p, h->tile_nl.p, h->tile_hdr.p);
-        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, h->tile_hdr.p, h->ntiles, h->tile_hdr_off.p);
+        FX_LAUNCH(h, K_TILE_SCAN, k_tile_scan, dim3(1), dim3(1024), h->tile_hdr.p, h->ntiles, h->tile_hdr_off.p);
     } else {
-        hipLaunchKernelGGL(k_scan<false>, dim3((unsigned)h->ntiles), dim3(BLOCK), 0, h->stream, h->d_data, h->n,
+        FX_LAUNCH(h, K_SCAN, (k_scan<false>), dim3((unsigned)h->ntiles), dim3(BLOCK), h->d_data, h->n,
                            h->prev_byte, h->nlmask.p, h->tile_nl.p, (uint32_t *)nullptr);
     }
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, h->tile_nl.p, h->ntiles, h->tile_nl_off.p);
+    FX_LAUNCH(h, K_TILE_SCAN, k_tile_scan, dim3(1), dim3(1024), h->tile_nl.p, h->ntiles, h->tile_nl_off.p);
     HIPCHK(hipGetLastError());
     // totals + last byte back to the host (needed to size the tables)
     int64_t tot_nl = 0, tot_hdr = 0;
@@ -388,7 +436,7 @@ static int run_scan(fx_handle *h, bool want_hdr) {
     const bool virt = h->is_last && last != '\n';
     h->n_nl = tot_nl + (virt ? 1 : 0);
     if ((rc = h->nl.alloc(std::max<int64_t>(h->n_nl, 1)))) return rc;
-    hipLaunchKernelGGL(k_linetable, dim3((unsigned)h->ntiles), dim3(BLOCK), 0, h->stream, h->nlmask.p,
+    FX_LAUNCH(h, K_LINETABLE, k_linetable, dim3((unsigned)h->ntiles), dim3(BLOCK), h->nlmask.p,
                        h->tile_nl_off.p, h->base, h->nl.p);
     if (virt) {
         const int64_t v = h->base + h->n;
@@ -399,7 +447,7 @@ static int run_scan(fx_handle *h, bool want_hdr) {
         h->n_hdr = tot_hdr;
         if ((rc = h->hdr.alloc(std::max<int64_t>(tot_hdr, 1)))) return rc;
         if (tot_hdr)
-            hipLaunchKernelGGL(k_hdr_scatter, dim3((unsigned)h->ntiles), dim3(BLOCK), 0, h->stream, h->d_data, h->n,
+            FX_LAUNCH(h, K_HDR_SCATTER, k_hdr_scatter, dim3((unsigned)h->ntiles), dim3(BLOCK), h->d_data, h->n,
                                h->prev_byte, h->tile_hdr.p, h->tile_hdr_off.p, h->base, h->hdr.p);
         h->scanned_hdr = true;
     }
@@ -414,7 +462,14 @@ extern "C" int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out
     int rc = run_scan(h, true);
     if (rc) return rc;
     const int64_t nh = h->n_hdr;
-    if (nh <= 0) return fail(FX_EFORMAT, "no FASTA header line ('>') found");
+    if (nh <= 0) {
+        if (h->base == 0 && h->is_last) return fail(FX_EFORMAT, "no FASTA header line ('>') found");
+        // a shard that lies entirely inside one record: empty local table, summary still valid
+        h->fa_seqlen = 0;
+        h->fasta_built = true;
+        if (out) { out->n_seq = 0; out->seq_len = 0; out->n_lines = h->n_nl; out->n_bytes = h->n; }
+        return FX_OK;
+    }
     if ((rc = h->fa_boff.alloc(nh)) || (rc = h->fa_blen.alloc(nh)) || (rc = h->fa_slen.alloc(nh)) ||
         (rc = h->fa_llen.alloc(nh)) || (rc = h->fa_hdr_line.alloc(nh)) || (rc = h->fa_elen.alloc(nh)) ||
         (rc = h->fa_norm.alloc(nh)) || (rc = h->fa_dlen.alloc(nh)) || (rc = h->fa_name_len.alloc(nh)) ||
@@ -426,12 +481,12 @@ extern "C" int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out
     c.boff = h->fa_boff.p; c.blen = h->fa_blen.p; c.slen = h->fa_slen.p; c.llen = h->fa_llen.p;
     c.hdr_line = h->fa_hdr_line.p; c.elen = h->fa_elen.p; c.dlen = h->fa_dlen.p; c.name_len = h->fa_name_len.p;
     c.bad = h->fa_bad.p;
-    hipLaunchKernelGGL(k_fasta_rec, dim3(nblocks(nh, BLOCK)), dim3(BLOCK), 0, h->stream, h->d_data, h->base, h->nl.p,
+    FX_LAUNCH(h, K_FASTA_REC, k_fasta_rec, dim3(nblocks(nh, BLOCK)), dim3(BLOCK), h->d_data, h->base, h->n, h->nl.p,
                        h->n_nl, h->hdr.p, nh, full_name, c);
     const unsigned lb = (unsigned)std::min<int64_t>(nblocks(h->n_nl, BLOCK), 256 * 8);
-    hipLaunchKernelGGL(k_fasta_lines, dim3(lb), dim3(BLOCK), 0, h->stream, h->nl.p, h->n_nl, h->fa_hdr_line.p, nh,
+    FX_LAUNCH(h, K_FASTA_LINES, k_fasta_lines, dim3(lb), dim3(BLOCK), h->nl.p, h->n_nl, h->fa_hdr_line.p, nh,
                        h->fa_llen.p, h->fa_bad.p);
-    hipLaunchKernelGGL(k_fasta_finalize, dim3(nblocks(nh, BLOCK)), dim3(BLOCK), 0, h->stream, h->fa_bad.p,
+    FX_LAUNCH(h, K_FASTA_FINALIZE, k_fasta_finalize, dim3(nblocks(nh, BLOCK)), dim3(BLOCK), h->fa_bad.p,
                        h->fa_slen.p, nh, h->fa_norm.p, h->scalars.p);
     HIPCHK(hipGetLastError());
     unsigned long long tot = 0;
@@ -477,7 +532,7 @@ extern "C" int fx_fasta_comp(fx_handle *h, int where, int64_t *comp) {
     unsigned long long *d = (unsigned long long *)comp;
     if (where != FX_DEVICE) { if ((rc = tmp.alloc(n))) return rc; d = tmp.p; }
     HIPCHK(hipMemsetAsync(d, 0, (size_t)n * 8, h->stream));
-    hipLaunchKernelGGL(k_fasta_comp, dim3((unsigned)h->ntiles), dim3(BLOCK), 0, h->stream, h->d_data, h->n, h->base,
+    FX_LAUNCH(h, K_FASTA_COMP, k_fasta_comp, dim3((unsigned)h->ntiles), dim3(BLOCK), h->d_data, h->n, h->base,
                        h->hdr.p, h->fa_boff.p, h->n_hdr, h->tile_hdr.p, d);
     HIPCHK(hipGetLastError());
     if (where != FX_DEVICE) HIPCHK(hipMemcpyAsync(comp, d, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
@@ -506,7 +561,7 @@ extern "C" int fx_fastq_build(fx_handle *h, fx_fastq_summary *out) {
     c.name_off = h->fq_name_off.p; c.rlen = h->fq_rlen.p; c.soff = h->fq_soff.p; c.qoff = h->fq_qoff.p;
     c.name_len = h->fq_name_len.p; c.dlen = h->fq_dlen.p;
     if (nseqline > 0)
-        hipLaunchKernelGGL(k_fastq_rec, dim3(nblocks(nseqline, BLOCK)), dim3(BLOCK), 0, h->stream, h->d_data, h->base,
+        FX_LAUNCH(h, K_FASTQ_REC, k_fastq_rec, dim3(nblocks(nseqline, BLOCK)), dim3(BLOCK), h->d_data, h->base,
                            h->nl.p, h->n_nl, nr, c, h->fq_acc.p);
     HIPCHK(hipGetLastError());
     FastqAcc acc;
@@ -542,7 +597,7 @@ extern "C" int fx_fastq_comp(fx_handle *h, int64_t base[5], int64_t meta[5]) {
     if (rc) return rc;
     const int64_t groups = (h->n_nl + 3) / 4;
     const unsigned nb = (unsigned)std::min<int64_t>(nblocks(groups, BLOCK / 64), 256 * 8);
-    hipLaunchKernelGGL(k_fastq_comp, dim3(nb), dim3(BLOCK), 0, h->stream, h->d_data, h->base, h->nl.p, h->n_nl, groups,
+    FX_LAUNCH(h, K_FASTQ_COMP, k_fastq_comp, dim3(nb), dim3(BLOCK), h->d_data, h->base, h->nl.p, h->n_nl, groups,
                        h->fq_acc.p);
     HIPCHK(hipGetLastError());
     FastqAcc acc;
@@ -634,9 +689,9 @@ static int fetch_common(fx_handle *h, int where, int64_t n, bool by_id, const in
         tab.elen = h->fa_elen.p; tab.norm = h->fa_norm.p; tab.n_seq = h->n_hdr;
     }
     if (by_id)
-        hipLaunchKernelGGL(k_fetch<true>, dim3(fetch_grid(n)), dim3(BLOCK), 0, h->stream, h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
+        FX_LAUNCH(h, K_FETCH, (k_fetch<true>), dim3(fetch_grid(n)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
     else
-        hipLaunchKernelGGL(k_fetch<false>, dim3(fetch_grid(n)), dim3(BLOCK), 0, h->stream, h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
+        FX_LAUNCH(h, K_FETCH, (k_fetch<false>), dim3(fetch_grid(n)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
     HIPCHK(hipGetLastError());
     if (where == FX_HOST) {
         HIPCHK(hipMemcpyAsync(dst, d_dst, (size_t)total, hipMemcpyDeviceToHost, h->stream));
@@ -701,7 +756,7 @@ extern "C" int fx_fastq_fetch(fx_handle *h, int where, int64_t n, const int64_t 
         if (qual && (rc = st.scratch<uint8_t>(total, &d_qual))) return rc;
         if (quali && (rc = st.scratch<int8_t>(total, &d_qi))) return rc;
     }
-    hipLaunchKernelGGL(k_fastq_fetch, dim3(fetch_grid(n)), dim3(BLOCK), 0, h->stream, h->d_data, h->base, h->fq_rlen.p,
+    FX_LAUNCH(h, K_FASTQ_FETCH, k_fastq_fetch, dim3(fetch_grid(n)), dim3(BLOCK), h->d_data, h->base, h->fq_rlen.p,
                        h->fq_soff.p, h->fq_qoff.p, h->n_reads, d_ids, n, phred, seq_flags, d_seq, d_qual, d_qi, d_off);
     HIPCHK(hipGetLastError());
     if (where == FX_HOST) {
@@ -735,7 +790,103 @@ extern "C" int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mo
     return FX_OK;
 }
 
+extern "C" int fx_sync(fx_handle *h) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->prof.drain();
+    return FX_OK;
+}
+
+extern "C" int fx_prof_enable(fx_handle *h, int on) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    int rc = fx_sync(h);
+    if (rc) return rc;
+    h->prof.on = on != 0;
+    return FX_OK;
+}
+
+extern "C" int fx_prof_reset(fx_handle *h) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    int rc = fx_sync(h);
+    if (rc) return rc;
+    for (int i = 0; i < K_NKERN; ++i) { h->prof.ms[i] = 0; h->prof.cnt[i] = 0; }
+    return FX_OK;
+}
+
+extern "C" int fx_prof_count(void) { return K_NKERN; }
+extern "C" const char *fx_prof_name(int id) { return (id >= 0 && id < K_NKERN) ? kKernelNames[id] : ""; }
+
+extern "C" int fx_prof_read(fx_handle *h, int id, double *total_ms, int64_t *launches) {
+    if (!h || id < 0 || id >= K_NKERN) return fail(FX_EINVAL, "bad argument");
+    int rc = fx_sync(h);
+    if (rc) return rc;
+    if (total_ms) *total_ms = h->prof.ms[id];
+    if (launches) *launches = h->prof.cnt[id];
+    return FX_OK;
+}
+
 extern "C" int fx_shard_summary_get(fx_handle *h, fx_shard_summary *out) {
-    (void)h; (void)out;
-    return fail(FX_ESTATE, "shard summaries are produced by fx_shard_scan (not built yet)");
+    static_assert(sizeof(fx_shard_summary) == FX_SUMMARY_WORDS * 8, "summary layout");
+    if (!h || !out) return fail(FX_EINVAL, "null argument");
+    if (!h->fasta_built && !h->scanned_hdr) return fail(FX_ESTATE, "fx_fasta_build has not run");
+    int rc = use_device(h);
+    if (rc) return rc;
+    DevBuf<unsigned long long> stats;
+    DevBuf<int64_t> S;
+    if ((rc = stats.alloc(4)) || (rc = S.alloc(FX_SUMMARY_WORDS))) return rc;
+    const unsigned long long init[4] = {0ull, ~0ull, 0ull, 0ull};
+    HIPCHK(hipMemcpyAsync(stats.p, init, sizeof init, hipMemcpyHostToDevice, h->stream));
+    // lead_nl = newlines before the first local header
+    int64_t lead_nl = h->n_nl;
+    if (h->n_hdr > 0) {
+        int64_t first_hdr = 0;
+        HIPCHK(hipMemcpyAsync(&first_hdr, h->hdr.p, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        // binary search over the device line table from the host would cost ~25 round trips;
+        // the record kernel already did it: hdr_line[0] is exactly that rank.
+        HIPCHK(hipMemcpyAsync(&lead_nl, h->fa_hdr_line.p, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        (void)first_hdr;
+    } else {
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    if (lead_nl >= 2) {
+        const unsigned nb = (unsigned)std::min<int64_t>(nblocks(lead_nl, BLOCK), 2048);
+        hipLaunchKernelGGL(k_lead_stats, dim3(nb), dim3(BLOCK), 0, h->stream, h->nl.p, lead_nl, 0, stats.p);
+        hipLaunchKernelGGL(k_lead_stats, dim3(nb), dim3(BLOCK), 0, h->stream, h->nl.p, lead_nl, 1, stats.p);
+    }
+    FastaCols c;
+    memset(&c, 0, sizeof c);
+    c.hoff = h->hdr.p; c.boff = h->fa_boff.p; c.blen = h->fa_blen.p; c.slen = h->fa_slen.p; c.llen = h->fa_llen.p;
+    c.hdr_line = h->fa_hdr_line.p; c.elen = h->fa_elen.p; c.dlen = h->fa_dlen.p; c.name_len = h->fa_name_len.p;
+    c.bad = h->fa_bad.p;
+    hipLaunchKernelGGL(k_shard_summary, dim3(1), dim3(BLOCK), 0, h->stream, h->d_data, h->n, h->base, (int)h->is_last,
+                       h->nl.p, h->n_nl, h->hdr.p, h->n_hdr, c, stats.p, lead_nl, S.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, S.p, sizeof(fx_shard_summary), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FX_OK;
+}
+
+template <class T> static int poke(fx_handle *h, T *darr, int64_t k, T v) {
+    HIPCHK(hipMemcpyAsync(darr + k, &v, sizeof(T), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FX_OK;
+}
+
+extern "C" int fx_fasta_set_row(fx_handle *h, int64_t k, int64_t boff, int64_t blen, int64_t slen, int64_t llen,
+                                int32_t elen, int32_t norm, int32_t dlen, int32_t name_len) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    if (!h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build has not run");
+    if (k < 0 || k >= h->n_hdr) return fail(FX_ERANGE, "row %lld out of range", (long long)k);
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = poke(h, h->fa_boff.p, k, boff)) || (rc = poke(h, h->fa_blen.p, k, blen)) ||
+        (rc = poke(h, h->fa_slen.p, k, slen)) || (rc = poke(h, h->fa_llen.p, k, llen)) ||
+        (rc = poke(h, h->fa_elen.p, k, elen)) || (rc = poke(h, h->fa_norm.p, k, norm)) ||
+        (rc = poke(h, h->fa_dlen.p, k, dlen)) || (rc = poke(h, h->fa_name_len.p, k, name_len)))
+        return rc;
+    return FX_OK;
 }

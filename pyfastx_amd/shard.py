@@ -1,0 +1,239 @@
+"""Byte-range sharding of one FASTA stream across GPUs.
+
+Each rank scans only its own byte range [base, base+n) with the HIP kernels
+(line table, headers, record table for records that START in the shard), then
+ONE all-gather of a fixed 28-word boundary summary (fx_shard_summary) lets every
+rank finish the single record of its shard that runs past the cut.  There is
+no other data-path exchange: bytes never move between GPUs.
+
+`stitch_tail` is pure integer logic over the gathered summaries and runs on the
+host; it is what the world_size-2 gloo tests exercise on CPU.
+"""
+import json
+import os
+
+import numpy as np
+
+FIELDS = ["base", "n_bytes", "is_last", "n_nl", "first_nl", "second_nl", "last_nl", "first_nl_prev",
+          "first_byte", "last_byte", "n_hdr", "first_hdr", "last_hdr", "lead_nl", "lead_ws",
+          "lead_v1", "lead_c1", "lead_v2", "lead_c2", "tail_e", "tail_first_end", "tail_nl_after", "tail_bad",
+          "tail_elen", "tail_dlen", "tail_name_len", "reserved0", "reserved1"]
+NWORDS = len(FIELDS)
+
+
+class Summary(dict):
+    __getattr__ = dict.__getitem__
+
+    @classmethod
+    def from_array(cls, a):
+        return cls(zip(FIELDS, (int(x) for x in a)))
+
+    def to_array(self):
+        return np.array([self[k] for k in FIELDS], dtype=np.int64)
+
+
+def count_ne(u, llen):
+    """min(2, number of FULL lead lines of shard u whose len+1 != llen)."""
+    full = u.lead_nl - 1
+    if full <= 0:
+        return 0
+    if u.lead_c1 + u.lead_c2 < full:          # >= 3 distinct lengths: at least two differ from any llen
+        return 2
+    eq = (u.lead_c1 if u.lead_v1 == llen else 0) + (u.lead_c2 if (u.lead_c2 and u.lead_v2 == llen) else 0)
+    return min(2, full - eq)
+
+
+def stream_end(S):
+    """`position` after the last line (index.c:231 semantics; virtual EOF newline included)."""
+    for u in reversed(S):
+        if u.n_nl > 0:
+            return u.last_nl + 1
+    return 0
+
+
+def stitch_tail(S, r, full_name=False):
+    """Final .fxi columns of the LAST record that starts in shard r, given all
+    summaries S (list of Summary in shard order).  None if shard r has no header.
+    Mirrors index.c:234-353 for a record whose lines span shard cuts."""
+    s = S[r]
+    if s.n_hdr == 0:
+        return None
+    h = s.last_hdr
+    e, elen, dlen, name_len = s.tail_e, s.tail_elen, s.tail_dlen, s.tail_name_len
+    have_e = e >= 0
+    have_llen, llen, nseq, bad = False, 0, 0, 0
+    last_nl = s.last_nl
+    if have_e:
+        nseq = s.tail_nl_after
+        if s.tail_first_end >= 0:
+            llen, have_llen, bad = s.tail_first_end - e, True, min(2, s.tail_bad)
+    hn = None
+    ws = -1                                    # whitespace seen in continuation shards while header unterminated
+    for t in range(r + 1, len(S)):
+        u = S[t]
+        if not have_e and ws < 0 and u.lead_ws >= 0:
+            ws = u.lead_ws
+        if u.lead_nl > 0:
+            first = u.first_nl
+            full = u.lead_nl - 1
+            if not have_e:                     # the header line itself crossed the cut
+                pb = u.first_nl_prev if u.first_nl_prev >= 0 else S[t - 1].last_byte
+                e = first
+                elen = 2 if pb == 13 else 1    # index.c:266-269
+                dlen = (e - h) - elen          # index.c:271
+                if full_name:
+                    name_len = dlen
+                elif name_len < 0:
+                    if u.first_nl - u.base > 65536 and ws < 0:
+                        raise ValueError("header line crossing a shard cut continues for more than 64 KiB")
+                    name_len = (ws - (h + 1)) if (0 <= ws < e) else dlen
+                name_len = min(name_len, dlen)
+                have_e = True
+                if full >= 1:                  # first full lead line = first sequence line of the record
+                    llen, have_llen = u.second_nl - u.first_nl, True
+                    bad += count_ne(u, llen)
+                nseq += full
+            elif not have_llen:                # the first sequence line crossed the cut
+                llen, have_llen = first - e, True
+                nseq += u.lead_nl
+                bad += count_ne(u, llen)
+            else:                              # an ordinary line crossed the cut
+                bad += int(first - last_nl != llen)
+                nseq += u.lead_nl
+                bad += count_ne(u, llen)
+            bad = min(bad, 2)
+            last_nl = u.last_nl if u.n_hdr == 0 else last_nl
+        if u.n_hdr > 0:
+            hn = u.first_hdr
+            break
+    if hn is None:
+        hn = stream_end(S)
+    boff = e + 1
+    blen = hn - boff                           # index.c:243,348
+    return {"boff": boff, "blen": blen, "slen": blen - elen * nseq, "llen": llen if nseq > 0 else 0,
+            "elen": elen, "norm": 0 if bad > 1 else 1, "dlen": dlen, "name_len": name_len}
+
+
+def id_offsets(S):
+    out, acc = [], 0
+    for u in S:
+        out.append(acc)
+        acc += u.n_hdr
+    return out, acc
+
+
+def pmc_traffic(root):
+    """HBM bytes per k_scan launch from the committed rocprofv3 --pmc summary (or None)."""
+    p = os.path.join(root, "profiles", "pmc_k_scan.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+class ShardedFasta:
+    """One rank's share of a sharded FASTA index build (one process per GPU).
+
+    `piece` is this rank's generated piece of the concatenated stream, already in
+    HBM.  For world > 1 the cut is moved DELTA bytes into the next piece (so that
+    a record really straddles every boundary): each rank ships its first DELTA
+    bytes to the previous rank once, at setup, outside any timed region."""
+
+    DELTA = 100_003
+
+    def __init__(self, piece, nbytes, dev, rank, world, full_name=False):
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        self.rank, self.world, self.dev, self.full_name = rank, world, dev, full_name
+        self._torch, self._dist = torch, dist
+        if world == 1:
+            self.buf, self.n_bytes, self.base, prev, last = piece, nbytes, 0, 10, True
+        else:
+            d = self.DELTA
+            sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+            mine = torch.tensor([nbytes], dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(sizes, mine)
+            sizes = sizes.cpu().numpy()
+            head = piece[:d].clone()
+            tail_in = torch.empty(d, dtype=torch.uint8, device=dev)
+            ops = []
+            if rank > 0:
+                ops.append(dist.P2POp(dist.isend, head, rank - 1))
+            if rank < world - 1:
+                ops.append(dist.P2POp(dist.irecv, tail_in, rank + 1))
+            for w in dist.batch_isend_irecv(ops) if ops else []:
+                w.wait()
+            lo = d if rank > 0 else 0
+            hi_extra = d if rank < world - 1 else 0
+            n = nbytes - lo + hi_extra
+            buf = torch.zeros(n + 131072, dtype=torch.uint8, device=dev)
+            buf[:nbytes - lo] = piece[lo:nbytes]
+            if hi_extra:
+                buf[nbytes - lo:n] = tail_in
+            prev = int(piece[lo - 1]) if lo else 10
+            self.buf, self.n_bytes = buf, n
+            self.base = int(sizes[:rank].sum()) + lo
+            last = rank == world - 1
+        torch.cuda.synchronize()
+        self.blob = _lib.Blob.from_device(self.buf.data_ptr(), self.n_bytes, device=dev.index, keepalive=self.buf)
+        self.blob.set_shard(self.base, prev, last)
+        self._gather_in = torch.zeros(NWORDS, dtype=torch.int64, device=dev)
+        self._gather_out = torch.zeros(world * NWORDS, dtype=torch.int64, device=dev)
+        self.summary = None
+        self.S = None
+        self.n_local = 0
+
+    def build(self):
+        s = self.blob.fasta_build(self.full_name)
+        self.n_local = s.n_seq
+        if self.world == 1:
+            return s
+        mine = self.blob.shard_summary()
+        self._gather_in.copy_(self._torch.from_numpy(mine.to_array()))
+        self._dist.all_gather_into_tensor(self._gather_out, self._gather_in)      # the ONE collective (RCCL)
+        allw = self._gather_out.cpu().numpy().reshape(self.world, NWORDS)
+        self.S = [Summary.from_array(a) for a in allw]
+        row = stitch_tail(self.S, self.rank, self.full_name)
+        if row is not None:
+            self.blob.fasta_set_row(self.n_local - 1, **row)
+        return s
+
+    def fetch_local(self, n, d_ids, d_st, d_sp, d_fl, d_out, d_off, d_len):
+        self.blob.fasta_fetch_dev(n, d_ids.data_ptr(), d_st.data_ptr(), d_sp.data_ptr(), d_out.data_ptr(),
+                                  d_off.data_ptr(), flags_per_query=d_fl.data_ptr(), out_len=d_len.data_ptr())
+
+    def sync(self):
+        self.blob.sync()
+
+    def local_rows(self):
+        return self.blob.fasta_table(self.n_local)
+
+    def check_against_plan(self, plan, rows, next_plan=None):
+        """Analytic ground truth of the generator vs the rows this rank owns."""
+        d = self.DELTA if self.world > 1 else 0
+        # records of this piece whose '>' lies in this shard: all for world == 1; for world > 1
+        # piece-record 0 starts in the previous rank's shard (rank > 0), and the next piece's
+        # record 0 starts in ours (rank < world-1) -- checked by its owner's neighbour below.
+        first = 1 if (self.world > 1 and self.rank > 0) else 0
+        npiece = len(plan["slen"]) - first
+        shift = self.base - (d if self.rank > 0 else 0)      # global offset of this piece's byte 0
+        ok = True
+        for k in ("hoff", "boff"):
+            ok &= bool((rows[k][:npiece] == plan[k][first:] + shift).all())
+        for k in ("blen", "slen", "llen", "dlen", "name_len"):
+            ok &= bool((rows[k][:npiece] == plan[k][first:]).all())
+        ok &= bool((rows["norm"][:npiece] == 1).all()) and bool((rows["elen"][:npiece] == 1).all())
+        if next_plan is not None:              # the stitched row: first contig of the NEXT piece starts in our shard
+            ok &= len(rows["boff"]) == npiece + 1
+            nshift = shift + int(plan["n_bytes"])
+            j = npiece
+            ok &= int(rows["hoff"][j]) == int(next_plan["hoff"][0]) + nshift
+            ok &= int(rows["boff"][j]) == int(next_plan["boff"][0]) + nshift
+            for k in ("blen", "slen", "llen", "dlen", "name_len"):
+                ok &= int(rows[k][j]) == int(next_plan[k][0])
+            ok &= int(rows["norm"][j]) == 1 and int(rows["elen"][j]) == 1
+        else:
+            ok &= len(rows["boff"]) == npiece
+        return bool(ok)

@@ -1,0 +1,148 @@
+"""Synthetic workloads of BASELINE.json's shapes, generated directly in HBM with
+torch (plumbing only) together with their ANALYTIC ground truth, so that
+full-size runs can be checked without a CPU pass over 3 GB.
+
+C2: hg38-shaped FASTA -- 24 chromosomes proportional to hg38 + 176 scaffolds
+(log-uniform 1 kbp..500 kbp), 60-column LF lines, ~50 % soft-masked blocks,
+telomere / centromere N runs, `>name  AC:.. LN:.. rl:..` headers.
+"""
+import numpy as np
+
+HG38_MBP = [248, 242, 198, 190, 181, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47,
+            51, 156, 57]
+CHR_NAMES = ["chr%d" % i for i in range(1, 23)] + ["chrX", "chrY"]
+
+
+def fasta_plan(total_bp=3_000_000_000, n_scaffolds=176, width=60, seed=20260612, tag=""):
+    """Contig names / lengths / headers and the analytic index rows."""
+    rng = np.random.default_rng(seed)
+    scaff = np.exp(rng.uniform(np.log(1_000), np.log(500_000), n_scaffolds)).astype(np.int64)
+    chrom_total = total_bp - int(scaff.sum())
+    w = np.array(HG38_MBP, dtype=np.float64)
+    chrom = np.floor(w / w.sum() * chrom_total).astype(np.int64)
+    chrom[0] += chrom_total - int(chrom.sum())
+    if total_bp < 50_000_000:          # tiny test plans: keep at least one line per chromosome
+        chrom = np.maximum(chrom, 1)
+    lens = np.concatenate([chrom, scaff])
+    names = [tag + n for n in CHR_NAMES] + ["%schrUn_KI%06dv1" % (tag, 270000 + i) for i in range(n_scaffolds)]
+    headers = []
+    for i, (nm, ln) in enumerate(zip(names, lens)):
+        sep = "\t" if i % 7 == 3 else "  "            # exercise the space-or-tab name split (index.c:289-293)
+        kind = "Chromosome" if i < 24 else "unplaced-scaffold"
+        headers.append((">%s%sAC:CM%06d.2  gi:%d  LN:%d  rl:%s  M5:%032x  AS:synthetic" %
+                        (nm, sep, 663 + i, 568336000 + i, ln, kind, int(rng.integers(0, 2**62)))).encode())
+    # analytic rows (index.c:230-372 semantics for a well-formed LF file)
+    n = len(lens)
+    hoff = np.zeros(n, np.int64); boff = np.zeros(n, np.int64); blen = np.zeros(n, np.int64)
+    llen = np.zeros(n, np.int64); dlen = np.zeros(n, np.int64); name_len = np.zeros(n, np.int64)
+    pos = 0
+    for i in range(n):
+        L = int(lens[i])
+        nlines = (L + width - 1) // width
+        hoff[i] = pos
+        boff[i] = pos + len(headers[i]) + 1
+        blen[i] = L + nlines
+        llen[i] = (min(L, width) + 1) if L > 0 else 0
+        dlen[i] = len(headers[i]) - 1
+        name_len[i] = len(names[i])
+        pos = int(boff[i] + blen[i])
+    return {"names": names, "headers": headers, "slen": lens.astype(np.int64), "hoff": hoff, "boff": boff,
+            "blen": blen, "llen": llen, "dlen": dlen, "name_len": name_len, "width": width,
+            "n_bytes": pos, "n_chrom": 24, "seed": seed}
+
+
+def fasta_generate(plan, device, keep_flat=True):
+    """-> (blob uint8[n_bytes(+pad)] on `device`, flat bases uint8[sum slen] or None, flat_start int64[n])."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(plan["seed"]))
+    rng = np.random.default_rng(plan["seed"] + 1)
+    nb = int(plan["n_bytes"])
+    pad = (-nb) % 65536 + 65536
+    blob = torch.zeros(nb + pad, dtype=torch.uint8, device=device)
+    total = int(plan["slen"].sum())
+    flat = torch.empty(total, dtype=torch.uint8, device=device) if keep_flat else None
+    flat_start = np.zeros(len(plan["slen"]), np.int64)
+    # byte -> base LUT with P(A,C,G,T) ~= .295/.205/.205/.295
+    lut = torch.empty(256, dtype=torch.uint8, device=device)
+    lut[:76] = ord("A"); lut[76:128] = ord("C"); lut[128:180] = ord("G"); lut[180:] = ord("T")
+    w = plan["width"]
+    fpos = 0
+    for i, L in enumerate(plan["slen"].tolist()):
+        hdr = plan["headers"][i]
+        ho, bo = int(plan["hoff"][i]), int(plan["boff"][i])
+        blob[ho:ho + len(hdr)] = torch.frombuffer(bytearray(hdr), dtype=torch.uint8).to(device)
+        blob[ho + len(hdr)] = 10
+        flat_start[i] = fpos
+        if L == 0:
+            continue
+        seq = lut[torch.randint(0, 256, (L,), dtype=torch.uint8, device=device, generator=g).long()] \
+            if L < (1 << 22) else _lut_big(lut, L, device, g)
+        # soft-masked (lower-case) blocks of 1..50 kb, about half of them masked
+        nblk = max(1, L // 25_000 + 1)
+        blens = torch.from_numpy(rng.integers(1_000, 50_001, nblk * 2)).to(device)
+        bits = torch.from_numpy((rng.random(nblk * 2) < 0.5).astype(np.uint8)).to(device)
+        mask = torch.repeat_interleave(bits, blens)[:L]
+        if mask.numel() < L:
+            mask = torch.cat([mask, torch.zeros(L - mask.numel(), dtype=torch.uint8, device=device)])
+        seq = seq | (mask << 5)                        # 0x20 = lower case
+        del mask, blens, bits
+        if i < plan["n_chrom"] and L > 4_000_000:      # telomeres + one centromere block of N
+            seq[:10_000] = ord("N"); seq[L - 10_000:] = ord("N")
+            c0 = int(rng.integers(L // 3, L // 2)); cl = int(rng.integers(1_000_000, 3_000_001))
+            seq[c0:c0 + cl] = ord("N")
+        if keep_flat:
+            flat[fpos:fpos + L] = seq
+        fpos += L
+        full = L // w
+        if full:
+            view = blob[bo:bo + full * (w + 1)].view(full, w + 1)
+            view[:, :w] = seq[:full * w].view(full, w)
+            view[:, w] = 10
+        rem = L - full * w
+        if rem:
+            p = bo + full * (w + 1)
+            blob[p:p + rem] = seq[full * w:]
+            blob[p + rem] = 10
+        del seq
+    return blob, flat, flat_start
+
+
+def _lut_big(lut, L, device, g):
+    import torch
+    out = torch.empty(L, dtype=torch.uint8, device=device)
+    step = 1 << 26
+    for a in range(0, L, step):
+        b = min(L, a + step)
+        out[a:b] = lut[torch.randint(0, 256, (b - a,), dtype=torch.uint8, device=device, generator=g).long()]
+    return out
+
+
+def fasta_queries(plan, n=1_000_000, qlen=100, seed=12345, skip_first=False):
+    """contig ~ length, start uniform in [0, slen-qlen], 50 % '-' strand."""
+    rng = np.random.default_rng(seed)
+    slen = plan["slen"]
+    ok = np.nonzero(slen >= qlen)[0]
+    if skip_first:
+        ok = ok[ok > 0]
+    p = slen[ok].astype(np.float64)
+    ids = ok[rng.choice(ok.size, n, p=p / p.sum())]
+    start = (rng.random(n) * (slen[ids] - qlen + 1)).astype(np.int64)
+    strand = (rng.random(n) < 0.5).astype(np.uint8)     # 1 = '-'
+    return ids.astype(np.int64), start, start + qlen, strand
+
+
+def expected_fetch(flat, flat_start, ids, start, qlen, strand, device):
+    """Reference answer on device from the un-wrapped bases (torch indexing, not our kernels)."""
+    import torch
+    base = torch.from_numpy(flat_start[ids] + start).to(device)
+    idx = base[:, None] + torch.arange(qlen, device=device)[None, :]
+    out = flat[idx]                                       # [n, qlen]
+    comp = torch.arange(256, dtype=torch.uint8, device=device)
+    for a, b in ("AT", "CG", "MK", "RY", "VB", "HD"):
+        for x, y in ((a, b), (b, a)):
+            comp[ord(x)] = ord(y); comp[ord(x) + 32] = ord(y) + 32
+    comp[ord("U")] = ord("A"); comp[ord("u")] = ord("a")
+    neg = torch.from_numpy(strand.astype(bool)).to(device)
+    rc = comp[out.long()].flip(1)
+    return torch.where(neg[:, None], rc, out)
