@@ -49,7 +49,9 @@ enum { FX_HOST = 0, FX_DEVICE = 1 };
 enum {
     FX_UPPER = 1,       /* remove_space_uppercase, util.c:181-194                 */
     FX_REVERSE = 2,     /* reverse_seq, util.c:251-261                            */
-    FX_COMPLEMENT = 4   /* complement_seq / comp_map, util.c:228-237, 263-269     */
+    FX_COMPLEMENT = 4,  /* complement_seq / comp_map, util.c:228-237, 263-269     */
+    FX_RAW = 8          /* no despace: plain pyfastx_index_random_read (index.c:683-692), for
+                           names, Sequence.raw / .description, Read.raw             */
 };
 
 const char *fx_last_error(void);
@@ -156,6 +158,13 @@ int fx_fasta_fetch(fx_handle *h, int where, int64_t n,
 int fx_fastq_fetch(fx_handle *h, int where, int64_t n, const int64_t *read_id,
                    int phred, int seq_flags,
                    uint8_t *seq, uint8_t *qual, int8_t *quali, const int64_t *dst_off);
+
+/* The same with explicit per-read offsets (the reference's call shape:
+ * pyfastx_read_random_reader(read, buff, offset, bytes), read.c:37-45), for
+ * callers that hold .fxi rows (soff, qoff, rlen) rather than ids. */
+int fx_read_fetch(fx_handle *h, int where, int64_t n, const int64_t *soff, const int64_t *qoff,
+                  const int64_t *rlen, int phred, int seq_flags,
+                  uint8_t *seq, uint8_t *qual, int8_t *quali, const int64_t *dst_off);
 
 /* pyfastx.reverse_complement / reverse_seq / complement_seq on a caller buffer
  * (module.c:44-59; util.c:239-269).  mode: FX_REVERSE | FX_COMPLEMENT.        */

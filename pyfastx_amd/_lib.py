@@ -11,7 +11,7 @@ _SO = os.path.join(_HERE, "csrc", "libfxgpu.so")
 _LIB = None
 
 FX_HOST, FX_DEVICE = 0, 1
-FX_UPPER, FX_REVERSE, FX_COMPLEMENT = 1, 2, 4
+FX_UPPER, FX_REVERSE, FX_COMPLEMENT, FX_RAW = 1, 2, 4, 8
 FX_OK, FX_ENOENT, FX_EFORMAT, FX_EIO, FX_EDEVICE, FX_ENOMEM, FX_ERANGE, FX_EINVAL, FX_ESTATE = \
     0, -1, -2, -3, -4, -5, -6, -7, -8
 
@@ -43,7 +43,7 @@ SYMBOLS = [
     "fx_set_shard", "fx_close", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
     "fx_fasta_build", "fx_fasta_table", "fx_fasta_comp", "fx_fastq_build", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fasta_fetch", "fx_fastq_fetch", "fx_revcomp", "fx_shard_summary_get",
-    "fx_fasta_set_row", "fx_sync", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
+    "fx_fasta_set_row", "fx_read_fetch", "fx_sync", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
 ]
 
 
@@ -91,6 +91,7 @@ def lib():
     L.fx_fasta_fetch.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, vp, vp]
     L.fx_fastq_fetch.argtypes = [vp, i32, i64, vp, i32, i32, vp, vp, vp, vp]
     L.fx_revcomp.argtypes = [i32, i32, vp, i64, i32]
+    L.fx_read_fetch.argtypes = [vp, i32, i64, vp, vp, vp, i32, i32, vp, vp, vp, vp]
     L.fx_shard_summary_get.argtypes = [vp, C.POINTER(ShardSummary)]
     L.fx_fasta_set_row.argtypes = [vp, i64, i64, i64, i64, i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.fx_sync.argtypes = [vp]
@@ -305,6 +306,24 @@ class Blob:
             check(lib().fx_fastq_fetch(self._h, FX_HOST, n, _ptr(read_id), int(phred), int(seq_flags),
                                        _ptr(seq), _ptr(qual), _ptr(qi), _ptr(offs)))
         return seq, qual, qi, offs
+
+    def read_fetch(self, soff, qoff, rlen, phred=0, seq_flags=0, want=("seq", "qual", "quali")):
+        soff, qoff, rlen = self._i64(soff), self._i64(qoff), self._i64(rlen)
+        n = soff.size
+        offs = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(rlen, out=offs[1:])
+        tot = max(int(offs[-1]), 1)
+        seq = np.zeros(tot, dtype=np.uint8) if "seq" in want else None
+        qual = np.zeros(tot, dtype=np.uint8) if "qual" in want else None
+        qi = np.zeros(tot, dtype=np.int8) if "quali" in want else None
+        if n:
+            check(lib().fx_read_fetch(self._h, FX_HOST, n, _ptr(soff), _ptr(qoff), _ptr(rlen), int(phred),
+                                      int(seq_flags), _ptr(seq), _ptr(qual), _ptr(qi), _ptr(offs)))
+        return seq, qual, qi, offs
+
+
+def _noop():
+    pass
 
 
 def revcomp_bytes(b, mode=FX_REVERSE | FX_COMPLEMENT, device=0):

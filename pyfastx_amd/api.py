@@ -1,0 +1,878 @@
+"""Host-side mirror of the reference's Python objects (Fasta, Sequence, Fastq,
+Read; src/fasta.c, sequence.c, fastq.c, read.c): same constructor kwargs, same
+getters, same exception classes, same repr strings -- with the hot path behind
+them (index scan, composition, sub-sequence / read fetch, reverse-complement,
+phred) running as HIP kernels through libfxgpu.so.  The `.fxi` SQLite file is
+written host-side from the GPU-produced arrays (fxi.py).
+
+There is no CPU fallback: building an index or touching sequence data needs the
+MI355X; only pure SQLite metadata (len, size, names ...) works without one.
+"""
+import gzip
+import os
+
+import numpy as np
+
+from . import _lib, fxi
+
+VERSION = "2.3.1"          # API level mirrored (reference src/version.h:1)
+
+_F_UP, _F_REV, _F_COMP, _F_RAW = _lib.FX_UPPER, _lib.FX_REVERSE, _lib.FX_COMPLEMENT, _lib.FX_RAW
+
+
+def _is_gzip(path):
+    """util.c:307-325"""
+    try:
+        with open(path, "rb") as f:
+            m = f.read(4)
+    except OSError:
+        return False
+    return len(m) == 4 and m[0] == 0x1F and m[1] == 0x8B and m[2] == 0x08
+
+
+def _first_nonspace(path, gz):
+    """fasta_validator / fastq_validator (util.c:95-150) without staging the file."""
+    op = gzip.open if gz else open
+    with op(path, "rb") as f:
+        while True:
+            chunk = f.read(65536)
+            if not chunk:
+                return -1
+            s = chunk.lstrip(b" \t\n\r\x0b\x0c")
+            if s:
+                return s[0]
+
+
+def _decode(b):
+    return bytes(b).decode("latin-1")
+
+
+def _fx_to_py(e):
+    """fx_status -> the exception class the reference raises at that point."""
+    c = e.code
+    if c == _lib.FX_ENOENT:
+        return FileExistsError(str(e))
+    if c == _lib.FX_ERANGE:
+        return IndexError(str(e))
+    if c == _lib.FX_EINVAL:
+        return ValueError(str(e))
+    return RuntimeError(str(e))
+
+
+class _Staged:
+    """Lazily staged HBM-resident stream shared by an index object and its children."""
+
+    def __init__(self, path, device):
+        self.path, self.device, self._blob = path, device, None
+
+    @property
+    def blob(self):
+        if self._blob is None:
+            try:
+                self._blob = _lib.Blob.from_file(self.path, self.device)
+            except _lib.FxError as e:
+                raise _fx_to_py(e)
+        return self._blob
+
+    def raw(self, off, n):
+        """pyfastx_index_random_read (index.c:683-692): bytes as they are."""
+        if n <= 0:
+            return b""
+        return self.blob.read_bytes(off, n)
+
+    def fetch(self, off, blen, slen, flags):
+        """pyfastx_index_fill_cache + the getter's slen-byte copy (index.c:694-707, sequence.c:346-347)."""
+        if slen <= 0 or blen <= 0:
+            return b""
+        buf, offs, ol = self.blob.fetch_ranges([off], [blen], [slen], flags=flags)
+        return buf[:int(ol[0])].tobytes()
+
+
+# =========================================================================== FASTA
+class Fasta:
+    """pyfastx.Fasta (fasta.c:39-135, 1156-1210)."""
+
+    def __init__(self, file_name, index_file=None, uppercase=False, build_index=True, full_index=False,
+                 full_name=False, memory_index=False, key_func=None, device=0):
+        if key_func is not None and not callable(key_func):
+            raise TypeError("key_func must be a callable function")                       # fasta.c:71-74
+        if not os.path.isfile(file_name):
+            raise FileExistsError("the input fasta file %s does not exists" % file_name)   # fasta.c:84-87
+        self.file_name = file_name
+        self._uppercase, self._full_name, self._key_func = bool(uppercase), bool(full_name), key_func
+        self._has_index = bool(build_index)
+        self.is_gzip = _is_gzip(file_name)
+        self._st = _Staged(file_name, device)
+        self._index_file = ":memory:" if memory_index else (index_file or file_name + ".fxi")   # index.c:45-61
+        self._db = None
+        self._full_index = False
+        self._seq_counts = 0
+        self.size = 0
+        if _first_nonspace(file_name, self.is_gzip) != ord(">"):                          # fasta.c:107-110
+            raise RuntimeError("%s is not plain or gzip compressed fasta formatted file" % file_name)
+        if build_index:
+            self.build_index()
+            if full_index:
+                self._calc_composition()
+
+    # ---------------------------------------------------------------- index
+    def build_index(self):
+        """pyfastx_build_index (index.c:418-429): load the .fxi if present else create it."""
+        if self._db is not None:
+            return
+        if fxi.exists(self._index_file):
+            self._db = fxi.connect(self._index_file)
+            if not fxi.has_fasta_index(self._db):                                         # index.c:402-411
+                raise RuntimeError("the index file %s was damaged" % self._index_file)
+        else:
+            self._create_index()
+        row = self._db.execute("SELECT * FROM stat LIMIT 1").fetchone()                    # fasta.c:17-37
+        if row is None:
+            raise RuntimeError("get seq count and length error")
+        self._seq_counts, self.size = int(row[0]), int(row[1])
+        self._has_index = True
+
+    def _create_index(self):
+        """pyfastx_create_index (index.c:109-388) with the scan on the GPU."""
+        blob = self._st.blob
+        try:
+            s = blob.fasta_build(self._full_name)
+        except _lib.FxError as e:
+            raise _fx_to_py(e)
+        t = blob.fasta_table(s.n_seq)
+        if self._key_func is None:
+            names = self._gather(t["hoff"] + 1, t["name_len"])
+        else:        # index.c:303-318: key_func(header text after '>'), '\r' of a CRLF header included
+            hl = t["dlen"].astype(np.int64) + (t["elen"] == 2)
+            names = [self._key_func(h) for h in self._gather(t["hoff"] + 1, hl)]
+        self._db = fxi.connect(self._index_file)
+        fxi.write_fasta(self._db, names, t, s.seq_len)
+        if self.is_gzip:
+            fxi.write_gzindex_header(self._db, os.path.getsize(self.file_name), blob.size)
+
+    def _gather(self, off, length):
+        """Raw byte spans of the resident stream as a list of str (one batched GPU gather)."""
+        length = np.asarray(length, dtype=np.int64)
+        if length.size == 0:
+            return []
+        buf, offs, _ = self._st.blob.fetch_ranges(off, length, length, flags=_F_RAW)
+        b = buf.tobytes()
+        o = offs.tolist()
+        return [b[o[i]:o[i + 1]].decode("latin-1") for i in range(length.size)]
+
+    def _calc_composition(self):
+        """pyfastx_fasta_calc_composition (fasta.c:851-961)."""
+        if self._full_index:
+            return
+        if self._db.execute("SELECT * FROM comp LIMIT 1").fetchone() is not None:
+            self._full_index = True
+            return
+        blob = self._st.blob
+        s = blob.fasta_build(self._full_name)
+        fxi.write_fasta_comp(self._db, blob.fasta_comp(s.n_seq))
+        self._full_index = True
+
+    def _total_comp(self):
+        self._calc_composition()
+        return {int(l): int(n) for _, _, l, n in self._db.execute("SELECT * FROM comp WHERE seqid=0")}
+
+    # ------------------------------------------------------------ protocols
+    def __len__(self):
+        return self._seq_counts
+
+    def __repr__(self):
+        if self._has_index:
+            return "<Fasta> %s contains %d sequences" % (self.file_name, self._seq_counts)      # fasta.c:138-144
+        return "<Fasta> %s" % self.file_name
+
+    def _make(self, row):
+        return Sequence(self, *row)
+
+    def __getitem__(self, item):
+        """pyfastx_fasta_subscript (fasta.c:521-546)."""
+        self._need_index()
+        if isinstance(item, (int, np.integer)) and not isinstance(item, bool):
+            i = int(item)
+            if i < 0:
+                i += self._seq_counts
+            if i >= self._seq_counts:
+                raise IndexError("index out of range")
+            row = self._db.execute("SELECT * FROM seq WHERE ID=? LIMIT 1", (i + 1,)).fetchone()
+            if row is None:
+                raise IndexError("Index Error")
+            return self._make(row)
+        if type(item) is str:
+            row = self._db.execute("SELECT * FROM seq WHERE chrom=? LIMIT 1", (item,)).fetchone()
+            if row is None:
+                raise KeyError("%s does not exist in fasta file" % item)
+            return self._make(row)
+        raise KeyError("the key must be index number or sequence name")
+
+    def __contains__(self, key):
+        if type(key) is not str or self._db is None:
+            return False
+        return self._db.execute("SELECT 1 FROM seq WHERE chrom=? LIMIT 1", (key,)).fetchone() is not None
+
+    def __iter__(self):
+        if self._has_index:                                   # fasta.c:146-172 -> Sequence objects in file order
+            self._need_index()
+            for row in self._db.execute("SELECT * FROM seq ORDER BY ID").fetchall():
+                yield self._make(row)
+            return
+        # build_index=False: (name, seq) tuples (index.c:604-664); records come from the same GPU scan,
+        # kept in memory only, and whole sequences are fetched in batches
+        blob = self._st.blob
+        s = blob.fasta_build(self._full_name)
+        t = blob.fasta_table(s.n_seq)
+        names = self._gather(t["hoff"] + 1, t["name_len"])
+        fl = _F_UP if self._uppercase else 0
+        step = 256
+        for a in range(0, s.n_seq, step):
+            b = min(s.n_seq, a + step)
+            want = np.maximum(t["slen"][a:b], 0)
+            buf, offs, ol = blob.fetch_ranges(t["boff"][a:b], t["blen"][a:b], want, flags=fl)
+            for k in range(b - a):
+                yield names[a + k], _decode(buf[offs[k]:offs[k] + ol[k]])
+
+    def _need_index(self):
+        if self._db is None:
+            raise RuntimeError("the index has not been built: call build_index()")
+
+    def keys(self):
+        self._need_index()
+        return FastaKeys(self._db, self._seq_counts)
+
+    # ----------------------------------------------------------- statistics
+    # (SQL over the .fxi exactly as the reference does; fasta.c:573-849)
+    def count(self, n):
+        return int(self._db.execute("SELECT COUNT(*) FROM seq WHERE slen>=?", (int(n),)).fetchone()[0])
+
+    def nl(self, p=50):
+        if p < 0 or p > 100:
+            raise ValueError("the value must between 0 and 100")
+        half, acc, i, j = p / 100.0 * self.size, 0, 0, 0
+        for (j,) in self._db.execute("SELECT slen FROM seq ORDER BY slen DESC"):
+            i += 1
+            acc += j
+            if acc >= half:
+                break
+        if not j:
+            raise RuntimeError("can not calculate N50 and L50")
+        return (int(j), i)
+
+    @property
+    def longest(self):
+        row = self._db.execute("SELECT ID,MAX(slen) FROM seq LIMIT 1").fetchone()
+        return self[int(row[0]) - 1]
+
+    @property
+    def shortest(self):
+        row = self._db.execute("SELECT ID,MIN(slen) FROM seq LIMIT 1").fetchone()
+        return self[int(row[0]) - 1]
+
+    @property
+    def mean(self):
+        return float(self._db.execute("SELECT AVG(slen) FROM seq").fetchone()[0])
+
+    @property
+    def median(self):
+        n = self._seq_counts                                   # fasta.c:786-849
+        if n % 2 == 0:
+            sql = "SELECT AVG(slen) FROM (SELECT slen FROM seq ORDER BY slen LIMIT %d,2)" % ((n - 1) // 2)
+        else:
+            sql = "SELECT slen FROM seq ORDER BY slen LIMIT %d,1" % ((n - 1) // 2)
+        return float(self._db.execute(sql).fetchone()[0])
+
+    @property
+    def composition(self):
+        return {chr(l): n for l, n in sorted(self._total_comp().items()) if n > 0 and 32 <= l < 127}
+
+    @property
+    def gc_content(self):
+        c = self._total_comp()
+        a, cc, g, t = (c.get(65, 0) + c.get(97, 0), c.get(67, 0) + c.get(99, 0),
+                       c.get(71, 0) + c.get(103, 0), c.get(84, 0) + c.get(116, 0))
+        if a + cc + g + t <= 0:
+            raise RuntimeError("could not calculate gc content")
+        return float(np.float32(g + cc) / np.float32(a + cc + g + t) * np.float32(100))      # (float) arithmetic, fasta.c:1013
+
+    @property
+    def gc_skew(self):
+        c = self._total_comp()
+        cc, g = c.get(67, 0) + c.get(99, 0), c.get(71, 0) + c.get(103, 0)
+        if cc + g <= 0:
+            raise RuntimeError("could not calculate gc skew")
+        return float(np.float32(g - cc) / np.float32(g + cc))
+
+    @property
+    def type(self):
+        """fasta.c:1106-1154"""
+        letters = {chr(l) for l, n in self._total_comp().items() if 32 < l < 127 and n > 0}
+
+        def subset(alpha):
+            return letters <= set(alpha)
+        if subset("ACGTNacgtn") or subset("abcdghkmnrstvwyABCDGHKMNRSTVWY*-"):
+            return "DNA"
+        if subset("ACGUNacgun") or subset("abcdghkmnrsuvwyABCDGHKMNRSUVWY*-"):
+            return "RNA"
+        if subset("acdefghiklmnpqrstvwyACDEFGHIKLMNPQRSTVWY*-"):
+            return "protein"
+        return "unknown"
+
+    # -------------------------------------------------------- fetch / flank
+    def _info(self, name, exc=NameError, msg="Sequence %s does not exists"):
+        row = self._db.execute("SELECT * FROM seq WHERE chrom=? LIMIT 1", (name,)).fetchone()
+        if row is None:
+            raise exc(msg % name)
+        return row
+
+    def fetch(self, chrom, intervals, strand="+"):
+        """pyfastx_fasta_fetch (fasta.c:384-515): 1-based inclusive intervals of one
+        sequence, concatenated; strand '-' reverse-complements the result.  One GPU
+        batch of byte ranges instead of loading the whole chromosome."""
+        if not isinstance(intervals, (tuple, list)):
+            raise ValueError("intervals must be list or tuple")
+        if len(intervals) == 0:
+            raise ValueError("intervals must be list or tuple")
+        row = self._info(chrom)
+        seq = self._make(row)
+        if isinstance(intervals[0], (int, np.integer)):
+            if len(intervals) != 2:
+                raise ValueError("list or tuple should include only start and end")
+            pairs = [(int(intervals[0]), int(intervals[1]))]
+        else:
+            pairs = [(int(iv[0]), int(iv[1])) for iv in intervals]
+        for s, e in pairs:
+            if s > e:
+                raise ValueError("start position should less than end position")
+        out = seq._fetch_many([s - 1 for s, _ in pairs], [e for _, e in pairs])
+        res = b"".join(out)
+        if strand == "-":
+            res = _lib.revcomp_bytes(res, _F_REV | _F_COMP, self._st.device)
+        return _decode(res)
+
+    def flank(self, chrom, start, end, flank_length=50, use_cache=False):
+        """pyfastx_fasta_flank (fasta.c:322-382)."""
+        if flank_length < 0:
+            raise ValueError("Flank length must be non-negative")
+        seq = self._make(self._info(chrom, NameError, "sequence %s does not exists"))
+        ls = max(start - flank_length - 1, 0)
+        le = max(start - 1, ls)
+        re_ = min(end + flank_length, seq._seq_len)
+        rs = min(end, re_)
+        left, right = seq._fetch_many([ls, rs], [le, re_])
+        return _decode(left), _decode(right)
+
+    def fetch_many(self, names_or_ids, starts, stops, strand=None):
+        """Batched extension: 0-based half-open (start, stop) on many
+        sequences in ONE kernel launch -> (uint8 buffer, int64 offsets[n+1])."""
+        self._need_index()
+        n = len(starts)
+        rows = {}
+        off = np.empty(n, np.int64); bl = np.empty(n, np.int64); sl = np.empty(n, np.int64)
+        for i in range(n):
+            key = names_or_ids[i]
+            r = rows.get(key)
+            if r is None:
+                r = rows[key] = self[key]
+            if not r._normal:
+                raise ValueError("fetch_many needs line-regular (norm=1) sequences")
+            off[i], bl[i] = r._range(int(starts[i]), int(stops[i]))
+            sl[i] = int(stops[i]) - int(starts[i])
+        fl = (_F_UP if self._uppercase else 0)
+        fpq = None
+        if strand is not None:
+            fpq = np.array([fl | ((_F_REV | _F_COMP) if s in ("-", 1, True) else 0) for s in strand], dtype=np.uint8)
+        buf, offs, ol = self._st.blob.fetch_ranges(off, bl, sl, flags=fl, flags_per_query=fpq)
+        return buf, offs
+
+
+class FastaKeys:
+    """Minimal sqlite-backed view of sequence names (fakeys.c; sort/filter DSL is out of scope)."""
+
+    def __init__(self, db, n):
+        self._db, self._n = db, n
+
+    def __len__(self):
+        return self._n
+
+    def __iter__(self):
+        for (nm,) in self._db.execute("SELECT chrom FROM seq ORDER BY ID"):
+            yield nm
+
+    def __getitem__(self, i):
+        if i < 0:
+            i += self._n
+        row = self._db.execute("SELECT chrom FROM seq WHERE ID=?", (i + 1,)).fetchone()
+        if row is None:
+            raise IndexError("index out of range")
+        return row[0]
+
+    def __contains__(self, name):
+        return self._db.execute("SELECT 1 FROM seq WHERE chrom=? LIMIT 1", (name,)).fetchone() is not None
+
+
+class Sequence:
+    """pyfastx.Sequence (sequence.c:755-807).  start/end are 1-based inclusive."""
+
+    def __init__(self, fasta, sid, name, boff, blen, slen, llen, elen, norm, dlen, start=1, end=None, complete=True):
+        self._fa = fasta
+        self.id, self._name = int(sid), name
+        self._offset, self._byte_len, self._full_len = int(boff), int(blen), int(slen)
+        self._line_len, self._end_len, self._normal, self._desc_len = int(llen), int(elen), int(norm), int(dlen)
+        self.start = int(start)
+        self.end = int(slen if end is None else end)
+        self._complete = bool(complete)
+        self._seq_len = self.end - self.start + 1 if not complete else int(slen)
+
+    # ----------------------------------------------------------- arithmetic
+    def _range(self, a, b):
+        """0-based [a,b) of the FULL record -> (offset, byte_len); sequence.c:498-510, fasta.c:293-320."""
+        bpl = self._line_len - self._end_len
+        if bpl <= 0:
+            raise ZeroDivisionError("record has an empty first line (llen == elen)")
+        bs, be = a // bpl, b // bpl
+        return self._offset + a + self._end_len * bs, (b - a) + (be - bs) * self._end_len
+
+    def _fetch_many(self, starts, stops, flags=0):
+        """Bases [a,b) (0-based, of the full record) for several intervals, one GPU batch."""
+        fl = flags | (_F_UP if self._fa._uppercase else 0)
+        st = self._fa._st
+        if self._normal and self._line_len - self._end_len > 0:
+            offs, bls, sls = [], [], []
+            for a, b in zip(starts, stops):
+                if b > a:
+                    o, l = self._range(a, b)
+                else:
+                    o, l = self._offset, 0
+                offs.append(o); bls.append(l); sls.append(max(b - a, 0))
+            buf, o, ol = st.blob.fetch_ranges(offs, bls, sls, flags=fl)
+            return [buf[o[i]:o[i] + ol[i]].tobytes() for i in range(len(offs))]
+        # norm = 0: despace the whole record, then slice (sequence.c:100-110)
+        full = st.fetch(self._offset, self._byte_len, max(self._full_len, 0), fl & _F_UP)
+        out = []
+        for a, b in zip(starts, stops):
+            s = full[a:b]
+            if flags & _F_COMP:
+                s = _lib.revcomp_bytes(s, _F_COMP, st.device)
+            if flags & _F_REV:
+                s = s[::-1]
+            out.append(s)
+        return out
+
+    def _get(self, flags=0):
+        if self._seq_len <= 0:
+            return ""
+        return _decode(self._fetch_many([self.start - 1], [self.end], flags)[0])
+
+    # -------------------------------------------------------------- getters
+    @property
+    def name(self):
+        return self._name if self._complete else "%s:%d-%d" % (self._name, self.start, self.end)    # sequence.c:291-297
+
+    @property
+    def seq(self):
+        return self._get()
+
+    @property
+    def reverse(self):
+        return self._get(_F_REV)
+
+    @property
+    def complement(self):
+        return self._get(_F_COMP)
+
+    @property
+    def antisense(self):
+        return self._get(_F_REV | _F_COMP)
+
+    @property
+    def description(self):
+        return _decode(self._fa._st.raw(self._offset - self._desc_len - self._end_len, self._desc_len))   # sequence.c:299-313
+
+    @property
+    def raw(self):
+        if self._complete:                                                                               # sequence.c:314-335
+            return _decode(self._fa._st.raw(self._offset - self._desc_len - self._end_len - 1,
+                                            self._byte_len + self._desc_len + self._end_len + 1))
+        if self._normal and self._seq_len > 0:
+            o, l = self._range(self.start - 1, self.end)
+            return _decode(self._fa._st.raw(o, l))
+        return _decode(self._fa._st.raw(self._offset, self._byte_len))
+
+    def _counts(self):
+        b = np.frombuffer(self.seq.encode("latin-1"), dtype=np.uint8)
+        return np.bincount(b, minlength=256)
+
+    @property
+    def composition(self):
+        c = self._counts()
+        return {chr(l): int(c[l]) for l in range(32, 127) if c[l] > 0}
+
+    @property
+    def gc_content(self):
+        c = self._counts()
+        a, cc, g, t = c[65] + c[97], c[67] + c[99], c[71] + c[103], c[84] + c[116]
+        return float(np.float32(g + cc) / np.float32(a + cc + g + t) * np.float32(100))
+
+    @property
+    def gc_skew(self):
+        c = self._counts()
+        cc, g = c[67] + c[99], c[71] + c[103]
+        return float(np.float32(int(g) - int(cc)) / np.float32(g + cc))
+
+    def search(self, subseq, strand="+"):
+        """sequence.c:519-558: 1-based position of the first hit (of its last base for '-')."""
+        q = subseq
+        if strand == "-":
+            q = _decode(_lib.revcomp_bytes(subseq.encode("latin-1"), _F_REV | _F_COMP, self._fa._st.device))
+        i = self.seq.find(q)
+        if i < 0:
+            return None
+        return i + len(q) if strand == "-" else i + 1
+
+    # ------------------------------------------------------------ protocols
+    def __len__(self):
+        return self._seq_len
+
+    def __str__(self):
+        return self.seq
+
+    def __repr__(self):
+        if self._complete:
+            return "<Sequence> %s with length of %d" % (self._name, self._seq_len)           # sequence.c:400-406
+        return "<Sequence> %s from %d to %d" % (self._name, self.start, self.end)
+
+    def __contains__(self, key):
+        return type(key) is str and key in self.seq
+
+    def __iter__(self):
+        """Line iteration (sequence.c:162-263): complete sequences only, line ends stripped."""
+        if not self._complete:
+            raise RuntimeError("sliced subsequence cannot be read line by line")
+        raw = self._fa._st.raw(self._offset, self._byte_len)
+        for ln in raw.split(b"\n"):
+            if ln.endswith(b"\r"):
+                ln = ln[:-1]
+            if ln:
+                yield _decode(ln)
+
+    def __getitem__(self, item):
+        """pyfastx_sequence_subscript (sequence.c:412-517) from ABSOLUTE coordinates (the
+        reference's nested slicing is cache-history dependent)."""
+        if isinstance(item, slice):
+            a, b, step = item.indices(self._seq_len)
+            if step != 1:
+                raise ValueError("slice step cannot > 1")
+            if b < a:
+                b = a
+            sub = Sequence(self._fa, self.id, self._name, self._offset, self._byte_len, self._full_len, self._line_len,
+                           self._end_len, self._normal, self._desc_len, start=self.start + a, end=self.start + b - 1,
+                           complete=self._complete and (b - a) == self._seq_len)
+            return sub
+        i = int(item)
+        if i < 0:
+            i += self._seq_len
+        if i < 0 or i >= self._seq_len:
+            raise IndexError("index out of range")
+        return _decode(self._fetch_many([self.start - 1 + i], [self.start + i])[0])
+
+
+# =========================================================================== FASTQ
+class Fastq:
+    """pyfastx.Fastq (fastq.c:257-380, 1057-1107)."""
+
+    def __init__(self, file_name, index_file=None, phred=0, build_index=True, full_index=False, full_name=False,
+                 device=0):
+        if not os.path.isfile(file_name):
+            raise FileExistsError("input fastq file %s does not exists" % file_name)          # fastq.c:278-281
+        self.file_name = file_name
+        self.is_gzip = _is_gzip(file_name)
+        if _first_nonspace(file_name, self.is_gzip) != ord("@"):                              # fastq.c:300-304
+            raise RuntimeError("%s is not plain or gzip compressed fastq formatted file" % file_name)
+        self._st = _Staged(file_name, device)
+        self._index_file = index_file or file_name + ".fxi"
+        self._phred = int(phred)
+        self._has_index = bool(build_index)
+        self._full_name = bool(full_name)
+        self._db = None
+        self._counts, self.size, self.avglen = 0, 0, 0.0
+        self._meta = None
+        if fxi.exists(self._index_file):                                                      # fastq.c:347-351
+            self._load_index()
+        elif build_index:
+            self._create_index()
+        if build_index and full_index:
+            self._calc_composition()
+
+    def build_index(self):
+        if self._db is None:
+            if fxi.exists(self._index_file):
+                self._load_index()
+            else:
+                self._create_index()
+        self._has_index = True
+        return True
+
+    def _load_index(self):
+        self._db = fxi.connect(self._index_file)
+        try:
+            row = self._db.execute("SELECT * FROM stat LIMIT 1").fetchone()
+        except Exception:
+            row = None
+        if row is None:
+            raise RuntimeError("the index file %s was damaged" % self._index_file)            # fastq.c:210-214
+        self._counts, self.size, self.avglen = int(row[0]), int(row[1]), float(row[2])
+        m = self._db.execute("SELECT phred FROM meta LIMIT 1").fetchone()
+        if m and not self._phred:
+            self._phred = int(m[0])
+
+    def _create_index(self):
+        """pyfastx_fastq_create_index (fastq.c:8-182) with the scan on the GPU."""
+        blob = self._st.blob
+        try:
+            s = blob.fastq_build()
+        except _lib.FxError as e:
+            raise _fx_to_py(e)
+        t = blob.fastq_table(s.n_reads)
+        names = []
+        step = 1 << 20
+        for a in range(0, s.n_reads, step):
+            b = min(s.n_reads, a + step)
+            ln = t["name_len"][a:b].astype(np.int64)
+            buf, offs, _ = blob.fetch_ranges(t["name_off"][a:b], ln, ln, flags=_F_RAW)
+            raw = buf.tobytes()
+            o = offs.tolist()
+            names.extend(raw[o[i]:o[i + 1]].decode("latin-1") for i in range(b - a))
+        self._db = fxi.connect(self._index_file)
+        fxi.write_fastq(self._db, names, t, s.size)
+        if self.is_gzip:
+            fxi.write_gzindex_header(self._db, os.path.getsize(self.file_name), blob.size)
+        self._counts, self.size = int(s.n_reads), int(s.size)
+        self.avglen = self.size * 1.0 / self._counts if self._counts else float("nan")
+
+    def _calc_composition(self):
+        """pyfastx_fastq_calc_composition (fastq.c:663-795)."""
+        if self._meta is not None:
+            return
+        row = self._db.execute("SELECT * FROM meta LIMIT 1").fetchone()
+        if row is None:
+            blob = self._st.blob
+            blob.fastq_build()
+            base, meta = blob.fastq_comp()
+            fxi.write_fastq_comp(self._db, base, meta)
+            row = tuple(int(x) for x in meta)
+        self._meta = {"maxlen": int(row[0]), "minlen": int(row[1]), "minqs": int(row[2]), "maxqs": int(row[3]),
+                      "phred": int(row[4])}
+        if not self._phred:
+            self._phred = self._meta["phred"]
+
+    # ------------------------------------------------------------ protocols
+    def __len__(self):
+        return self._counts
+
+    def __repr__(self):
+        if self._has_index:
+            return "<Fastq> %s contains %d reads" % (self.file_name, self._counts)             # fastq.c:547-553
+        return "<Fastq> %s" % self.file_name
+
+    def __getitem__(self, item):
+        """pyfastx_fastq_subscript (fastq.c:521-545)."""
+        if isinstance(item, str):
+            row = self._db.execute("SELECT * FROM read WHERE name=? LIMIT 1", (item,)).fetchone()
+            if row is None:
+                raise KeyError("%s does not exist in fastq file" % item)
+            return Read(self, *row)
+        if isinstance(item, (int, np.integer)) and not isinstance(item, bool):
+            i = int(item)
+            if i < 0:
+                i += self._counts
+            if i >= self._counts:
+                raise IndexError("index out of range")
+            row = self._db.execute("SELECT * FROM read WHERE ID=? LIMIT 1", (i + 1,)).fetchone()
+            if row is None:
+                raise IndexError("Index Error")
+            return Read(self, *row)
+        raise KeyError("the key must be index number or read name")
+
+    def __contains__(self, key):
+        if not isinstance(key, str) or self._db is None:
+            return False
+        return self._db.execute("SELECT 1 FROM read WHERE name=? LIMIT 1", (key,)).fetchone() is not None
+
+    def __iter__(self):
+        if self._has_index:
+            for row in self._db.execute("SELECT * FROM read ORDER BY ID").fetchall():
+                yield Read(self, *row)
+            return
+        # build_index=False: (name, seq, qual) tuples, from an in-memory GPU scan + batched gathers
+        blob = self._st.blob
+        s = blob.fastq_build()
+        t = blob.fastq_table(s.n_reads)
+        step = 1 << 16
+        for a in range(0, s.n_reads, step):
+            b = min(s.n_reads, a + step)
+            ids = np.arange(a, b, dtype=np.int64)
+            seq, qual, _, offs = blob.fastq_fetch(ids, t["rlen"][a:b], want=("seq", "qual"))
+            ln = (t["dlen"][a:b] - 1).astype(np.int64) if self._full_name else t["name_len"][a:b].astype(np.int64)
+            nb, no, _ = blob.fetch_ranges(t["name_off"][a:b], ln, ln, flags=_F_RAW)
+            for k in range(b - a):
+                nm = _decode(nb[no[k]:no[k + 1]]).rstrip("\r")
+                yield nm, _decode(seq[offs[k]:offs[k + 1]]), _decode(qual[offs[k]:offs[k + 1]])
+
+    def keys(self):
+        return [r[0] for r in self._db.execute("SELECT name FROM read ORDER BY ID")]
+
+    # -------------------------------------------------------------- getters
+    @property
+    def phred(self):
+        self._calc_composition()
+        return self._phred
+
+    @property
+    def composition(self):
+        self._calc_composition()
+        a, c, g, t, n = self._db.execute("SELECT * FROM base LIMIT 1").fetchone()
+        return {"A": a, "C": c, "G": g, "T": t, "N": n}
+
+    @property
+    def gc_content(self):
+        self._calc_composition()
+        a, c, g, t, n = self._db.execute("SELECT * FROM base LIMIT 1").fetchone()
+        return float(np.float32(g + c) / np.float32(a + c + g + t) * np.float32(100))          # fastq.c:809-878
+
+    @property
+    def maxlen(self):
+        self._calc_composition()
+        return self._meta["maxlen"]
+
+    @property
+    def minlen(self):
+        self._calc_composition()
+        return self._meta["minlen"]
+
+    @property
+    def maxqual(self):
+        self._calc_composition()
+        return self._meta["maxqs"]
+
+    @property
+    def minqual(self):
+        self._calc_composition()
+        return self._meta["minqs"]
+
+    @property
+    def encoding_type(self):
+        """fastq.c:797-878: platforms compatible with the observed quality range."""
+        self._calc_composition()
+        lo, hi = self._meta["minqs"], self._meta["maxqs"]
+        if lo < 33 or hi > 126:
+            return ["Unknown"]
+        out = []
+        for name, a, b in (("Sanger Phred+33", 33, 73), ("Illumina 1.8+ Phred+33", 33, 74),
+                           ("Solexa Solexa+64", 59, 104), ("Illumina 1.3+ Phred+64", 64, 104),
+                           ("Illumina 1.5+ Phred+64", 66, 104), ("PacBio HiFi Phred+33", 33, 126)):
+            if lo >= a and hi <= b:
+                out.append(name)
+        return out
+
+    def fetch_many(self, ids, want=("seq", "qual", "quali")):
+        """Batched extension: reads by 0-based id in one launch -> dict of buffers + offsets."""
+        ids = np.asarray(ids, dtype=np.int64)
+        blob = self._st.blob
+        if not getattr(self, "_dev_table", False):
+            blob.fastq_build()
+            self._dev_table = True
+        q = "SELECT rlen FROM read WHERE ID=?"
+        rlen = np.array([self._db.execute(q, (int(i) + 1,)).fetchone()[0] for i in ids], dtype=np.int64)
+        seq, qual, qi, offs = blob.fastq_fetch(ids, rlen, phred=self._phred, want=want)
+        return {"seq": seq, "qual": qual, "quali": qi, "offsets": offs}
+
+
+class Read:
+    """pyfastx.Read (read.c:288-323)."""
+
+    def __init__(self, fq, rid, name, dlen, rlen, soff, qoff):
+        self._fq = fq
+        self.id, self.name = int(rid), name
+        self._desc_len, self._read_len, self._soff, self._qoff = int(dlen), int(rlen), int(soff), int(qoff)
+
+    def __len__(self):
+        return self._read_len
+
+    def __repr__(self):
+        return "<Read> %s with length of %d" % (self.name, self._read_len)                     # read.c:280-282
+
+    def __str__(self):
+        return self.seq
+
+    def _bytes(self, off, n):
+        return self._fq._st.raw(off, n)
+
+    @property
+    def seq(self):
+        return _decode(self._bytes(self._soff, self._read_len))                                # read.c:152-167
+
+    @property
+    def qual(self):
+        return _decode(self._bytes(self._qoff, self._read_len))                                # read.c:237-249
+
+    @property
+    def quali(self):
+        """read.c:251-278 -- `qual - phred` (phred 0 -> 33) computed by the read-fetch kernel."""
+        _, _, qi, _ = self._fq._st.blob.read_fetch([self._soff], [self._qoff], [self._read_len],
+                                                    phred=self._fq._phred, want=("quali",))
+        return qi[:self._read_len].tolist()
+
+    def _rc(self, mode):
+        return _decode(_lib.revcomp_bytes(self._bytes(self._soff, self._read_len), mode, self._fq._st.device))
+
+    @property
+    def reverse(self):
+        return self._rc(_F_REV)
+
+    @property
+    def complement(self):
+        return self._rc(_F_COMP)
+
+    @property
+    def antisense(self):
+        return self._rc(_F_REV | _F_COMP)
+
+    @property
+    def description(self):
+        d = self._bytes(self._soff - self._desc_len - 1, self._desc_len)                        # read.c:214-235
+        if d.endswith(b"\r"):
+            d = d[:-1]
+        return _decode(d)
+
+    @property
+    def raw(self):
+        off = self._soff - self._desc_len - 1                                                   # read.c:124-150
+        n = self._qoff + self._read_len - off + 2
+        r = self._bytes(off, n)
+        if len(r) >= 2 and r[n - 2:n - 1] == b"\n":
+            r = r[:n - 1]
+        elif len(r) >= 2 and r[n - 2:n - 1] == b"\r" and r[n - 1:n] == b"\n":
+            r = r[:n]
+        else:
+            r = r[:n - 2]
+        return _decode(r.rstrip(b"\x00"))
+
+
+# ============================================================== module functions
+def version(debug=False):
+    """module.c:14-28"""
+    if debug:
+        return "pyfastx_amd: %s; %s" % (VERSION, _lib.lib().fx_version().decode())
+    return VERSION
+
+
+def gzip_check(file_name):
+    """module.c:30-42"""
+    return _is_gzip(file_name)
+
+
+def reverse_complement(seq, device=0):
+    """module.c:44-59 -> reverse_complement_seq (util.c:239-249) on the GPU."""
+    return _decode(_lib.revcomp_bytes(seq.encode("latin-1"), _F_REV | _F_COMP, device))

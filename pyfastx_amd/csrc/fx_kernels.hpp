@@ -520,7 +520,7 @@ __global__ __launch_bounds__(BLOCK) void k_fetch(const uint8_t *__restrict__ dat
         for (int64_t p = lo; p < hi && rank < end; p += 64) {
             const int64_t pp = p + lane;
             uint8_t c = (pp < hi) ? data[pp] : (uint8_t)'\n';
-            const bool keep = !(c == 10 || c == 13 || c == 32);
+            const bool keep = (fl & 8) ? (pp < hi) : !(c == 10 || c == 13 || c == 32);   // FX_RAW keeps every byte
             const unsigned long long bal = __ballot(keep);
             const int64_t r = rank + __popcll(bal & ((1ull << lane) - 1ull));
             if (keep && r >= skip && r < end) {
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_fetch(const uint8_t *__restrict
     const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
     for (int64_t i = wave; i < nq; i += nwaves) {
-        const int64_t id = ids[i];
+        const int64_t id = ids ? ids[i] : i;           // ids == null: the arrays are per query already
         if (id < 0 || id >= n_reads) continue;
         const int64_t n = rlen[id], so = soff[id] - gbase, qo = qoff[id] - gbase, d = dst_off[i];
         for (int64_t j = lane; j < n; j += 64) {

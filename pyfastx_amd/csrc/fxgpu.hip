@@ -768,6 +768,47 @@ extern "C" int fx_fastq_fetch(fx_handle *h, int where, int64_t n, const int64_t 
     return FX_OK;
 }
 
+extern "C" int fx_read_fetch(fx_handle *h, int where, int64_t n, const int64_t *soff, const int64_t *qoff,
+                             const int64_t *rlen, int phred, int seq_flags, uint8_t *seq, uint8_t *qual, int8_t *quali,
+                             const int64_t *dst_off) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    if (n < 0 || (n > 0 && (!soff || !qoff || !rlen || !dst_off))) return fail(FX_EINVAL, "null query array");
+    if (n == 0) return FX_OK;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!phred) phred = 33;                                // read.c:268
+    Staged st;
+    const int64_t *d_s = soff, *d_q = qoff, *d_r = rlen, *d_off = dst_off;
+    uint8_t *d_seq = seq, *d_qual = qual;
+    int8_t *d_qi = quali;
+    int64_t total = 0;
+    if (where == FX_HOST) {
+        for (int64_t i = 0; i < n; ++i) {
+            if (rlen[i] < 0 || soff[i] < h->base || qoff[i] < h->base || soff[i] + rlen[i] > h->base + h->n ||
+                qoff[i] + rlen[i] > h->base + h->n)
+                return fail(FX_ERANGE, "read %lld lies outside the stream", (long long)i);
+            total = std::max(total, dst_off[i] + rlen[i]);
+        }
+        total = std::max<int64_t>(total, 1);
+        if ((rc = st.up(h, soff, n, &d_s)) || (rc = st.up(h, qoff, n, &d_q)) || (rc = st.up(h, rlen, n, &d_r)) ||
+            (rc = st.up(h, dst_off, n, &d_off)))
+            return rc;
+        if (seq && (rc = st.scratch<uint8_t>(total, &d_seq))) return rc;
+        if (qual && (rc = st.scratch<uint8_t>(total, &d_qual))) return rc;
+        if (quali && (rc = st.scratch<int8_t>(total, &d_qi))) return rc;
+    }
+    FX_LAUNCH(h, K_FASTQ_FETCH, k_fastq_fetch, dim3(fetch_grid(n)), dim3(BLOCK), h->d_data, h->base, d_r, d_s, d_q, n,
+              (const int64_t *)nullptr, n, phred, seq_flags, d_seq, d_qual, d_qi, d_off);
+    HIPCHK(hipGetLastError());
+    if (where == FX_HOST) {
+        if (seq) HIPCHK(hipMemcpyAsync(seq, d_seq, (size_t)total, hipMemcpyDeviceToHost, h->stream));
+        if (qual) HIPCHK(hipMemcpyAsync(qual, d_qual, (size_t)total, hipMemcpyDeviceToHost, h->stream));
+        if (quali) HIPCHK(hipMemcpyAsync(quali, d_qi, (size_t)total, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return FX_OK;
+}
+
 extern "C" int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mode) {
     if (!buf && n) return fail(FX_EINVAL, "null buffer");
     if (n <= 0) return FX_OK;

@@ -1,0 +1,169 @@
+"""`.fxi` (SQLite3) writer / reader, host side.
+
+The GPU produces offset arrays; this module stores them with exactly the schema,
+column order and pragmas the reference uses (index.c:178-224, 342-372;
+fasta.c:890-953; fastq.c:29-60, 136-171, 755-784; util.c:442-540), so an index
+written here opens in reference pyfastx and vice versa.
+"""
+import os
+import sqlite3
+import struct
+
+FASTA_DDL = """
+CREATE TABLE seq (
+    ID INTEGER PRIMARY KEY, --seq identifier
+    chrom TEXT, --seq name
+    boff INTEGER, --seq offset start
+    blen INTEGER, --seq byte length
+    slen INTEGER, --seq length
+    llen INTEGER, --line length
+    elen INTEGER, --end length
+    norm INTEGER, --line with the same length or not
+    dlen INTEGER --description header line length
+);
+CREATE TABLE stat (
+    seqnum INTEGER, --total seq counts
+    seqlen INTEGER, --total seq length
+    avglen REAL, --average seq length
+    medlen REAL, --median seq length
+    n50 INTEGER, --N50 seq length
+    l50 INTEGER --L50 seq count
+);
+CREATE TABLE comp (
+    ID INTEGER PRIMARY KEY, --comp identifier
+    seqid INTEGER, --seq id
+    abc INTEGER, --seq letter
+    num INTEGER -- letter count
+);
+CREATE TABLE gzindex (
+    ID INTEGER PRIMARY KEY,
+    content BLOB
+);
+"""
+
+FASTQ_DDL = """
+CREATE TABLE read (
+    ID INTEGER PRIMARY KEY, --read id
+    name TEXT, --read name
+    dlen INTEGER, --description length
+    rlen INTEGER, --read length
+    soff INTEGER, --read seq offset
+    qoff INTEGER --read qual offset
+);
+CREATE TABLE gzindex (
+    ID INTEGER PRIMARY KEY,
+    content BLOB
+);
+CREATE TABLE stat (
+    counts INTEGER, --read counts
+    size INTEGER, --all read length
+    avglen REAL --average read length
+);
+CREATE TABLE base (
+    a INTEGER,
+    c INTEGER,
+    g INTEGER,
+    t INTEGER,
+    n INTEGER
+);
+CREATE TABLE meta (
+    maxlen INTEGER, --maximum read length
+    minlen INTEGER, --minimum read length
+    minqs INTEGER, --max quality score
+    maxqs INTEGER, --min quality score
+    phred INTEGER --phred value
+);
+"""
+
+
+def connect(path):
+    """sqlite3_open of index.c:170 / fastq.c:62; ConnectionError like the reference."""
+    try:
+        db = sqlite3.connect(path, isolation_level=None, check_same_thread=False)
+    except sqlite3.Error:
+        raise ConnectionError("Could not open index file %s" % path)
+    db.text_factory = lambda b: b.decode("utf-8", "surrogateescape")
+    return db
+
+
+def write_fasta(db, names, cols, seqlen_total):
+    """INSERT INTO seq ... (index.c:226-251, 342-372).  names: list[str];
+    cols: dict of int arrays boff, blen, slen, llen, elen, norm, dlen."""
+    db.executescript(FASTA_DDL)
+    db.execute("PRAGMA synchronous=OFF")
+    db.execute("PRAGMA locking_mode=EXCLUSIVE")
+    db.execute("BEGIN TRANSACTION")
+    n = len(names)
+    it = zip(names, cols["boff"].tolist(), cols["blen"].tolist(), cols["slen"].tolist(), cols["llen"].tolist(),
+             cols["elen"].tolist(), cols["norm"].tolist(), cols["dlen"].tolist())
+    db.executemany("INSERT INTO seq VALUES (NULL,?,?,?,?,?,?,?,?)", it)
+    db.execute("PRAGMA locking_mode=NORMAL")
+    db.execute("COMMIT")
+    try:        # duplicate names: the reference ignores the failure too (index.c:363-366)
+        db.execute("CREATE UNIQUE INDEX chromidx ON seq (chrom)")
+    except sqlite3.Error:
+        pass
+    db.execute("INSERT INTO stat (seqnum,seqlen) VALUES (?,?)", (n, int(seqlen_total)))
+
+
+def write_fasta_comp(db, comp):
+    """fasta.c:890-953: non-zero bins per record, then all 128 totals with seqid 0."""
+    import numpy as np
+    db.execute("PRAGMA synchronous=OFF")
+    db.execute("BEGIN TRANSACTION")
+    rec, abc = np.nonzero(comp)
+    rows = zip((rec + 1).tolist(), abc.tolist(), comp[rec, abc].tolist())
+    db.executemany("INSERT INTO comp VALUES (NULL,?,?,?)", rows)
+    tot = comp.sum(axis=0)
+    db.executemany("INSERT INTO comp VALUES (NULL,0,?,?)", [(j, int(tot[j])) for j in range(128)])
+    db.execute("CREATE INDEX seqidx ON comp (seqid)")
+    db.execute("COMMIT")
+
+
+def write_fastq(db, names, cols, size):
+    """fastq.c:76-171."""
+    db.executescript(FASTQ_DDL)
+    db.execute("PRAGMA synchronous = OFF")
+    db.execute("PRAGMA locking_mode=EXCLUSIVE")
+    db.execute("BEGIN TRANSACTION")
+    it = zip(names, cols["dlen"].tolist(), cols["rlen"].tolist(), cols["soff"].tolist(), cols["qoff"].tolist())
+    db.executemany("INSERT INTO read VALUES (NULL,?,?,?,?,?)", it)
+    db.execute("PRAGMA locking_mode=NORMAL")
+    db.execute("COMMIT")
+    try:
+        db.execute("CREATE UNIQUE INDEX readidx ON read (name)")
+    except sqlite3.Error:
+        pass
+    n = len(names)
+    avg = size * 1.0 / n if n else float("nan")              # fastq.c:161 (0/0 -> nan in C as well)
+    db.execute("INSERT INTO stat VALUES (?,?,?)", (n, int(size), avg))
+
+
+def write_fastq_comp(db, base, meta):
+    """fastq.c:755-790 (meta column order: maxlen, minlen, minqs, maxqs, phred)."""
+    db.execute("INSERT INTO base VALUES (?,?,?,?,?)", tuple(int(x) for x in base))
+    db.execute("INSERT INTO meta VALUES (?,?,?,?,?)", tuple(int(x) for x in meta))
+
+
+def write_gzindex_header(db, compressed_size, uncompressed_size, spacing=1048576, window=32768):
+    """The eight scalar rows of util.c:461-489 with npoints = 0: a syntactically valid
+    zran export that lets the reader rebuild its checkpoints on demand (ZRAN_AUTO_BUILD,
+    index.c:70).  Checkpoint windows are not produced here (parity unpinned)."""
+    db.execute("BEGIN TRANSACTION")
+    rows = [b"GZIDX", struct.pack("<B", 1), struct.pack("<B", 0), struct.pack("<Q", compressed_size),
+            struct.pack("<Q", uncompressed_size), struct.pack("<I", spacing), struct.pack("<I", window),
+            struct.pack("<I", 0)]
+    db.executemany("INSERT INTO gzindex VALUES (NULL,?)", [(sqlite3.Binary(r),) for r in rows])
+    db.execute("COMMIT")
+
+
+def has_fasta_index(db):
+    """pyfastx_load_index's sanity check (index.c:402-411)."""
+    try:
+        return db.execute("SELECT * FROM seq LIMIT 1").fetchone() is not None
+    except sqlite3.Error:
+        return False
+
+
+def exists(path):
+    return path != ":memory:" and os.path.exists(path)

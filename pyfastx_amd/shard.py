@@ -122,6 +122,17 @@ def id_offsets(S):
     return out, acc
 
 
+def allgather_summaries(mine, world, device="cpu"):
+    """THE collective of the sharded build: one all-gather of the fixed-size boundary
+    summary (28 x int64 per rank; RCCL over xGMI on GPUs, gloo in the CPU tests)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(mine.to_array()).to(device)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return [Summary.from_array(o.cpu().numpy()) for o in outs]
+
+
 def pmc_traffic(root):
     """HBM bytes per k_scan launch from the committed rocprofv3 --pmc summary (or None)."""
     p = os.path.join(root, "profiles", "pmc_k_scan.json")
@@ -179,8 +190,6 @@ class ShardedFasta:
         torch.cuda.synchronize()
         self.blob = _lib.Blob.from_device(self.buf.data_ptr(), self.n_bytes, device=dev.index, keepalive=self.buf)
         self.blob.set_shard(self.base, prev, last)
-        self._gather_in = torch.zeros(NWORDS, dtype=torch.int64, device=dev)
-        self._gather_out = torch.zeros(world * NWORDS, dtype=torch.int64, device=dev)
         self.summary = None
         self.S = None
         self.n_local = 0
@@ -190,11 +199,7 @@ class ShardedFasta:
         self.n_local = s.n_seq
         if self.world == 1:
             return s
-        mine = self.blob.shard_summary()
-        self._gather_in.copy_(self._torch.from_numpy(mine.to_array()))
-        self._dist.all_gather_into_tensor(self._gather_out, self._gather_in)      # the ONE collective (RCCL)
-        allw = self._gather_out.cpu().numpy().reshape(self.world, NWORDS)
-        self.S = [Summary.from_array(a) for a in allw]
+        self.S = allgather_summaries(self.blob.shard_summary(), self.world, self.dev)   # the ONE collective (RCCL)
         row = stitch_tail(self.S, self.rank, self.full_name)
         if row is not None:
             self.blob.fasta_set_row(self.n_local - 1, **row)

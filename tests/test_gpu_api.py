@@ -1,0 +1,222 @@
+"""-m gpu: the pyfastx-shaped object API (Fasta / Sequence / Fastq / Read) over
+the HIP path, checked against golden vectors dumped from the real reference
+(tests/golden/make_golden.py).  Reads like the reference's own tests
+(tests/test_fasta.py, test_sequence.py, test_fastq.py, test_read.py)."""
+import os
+import shutil
+import sqlite3
+
+import pytest
+
+from conftest import DATA, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fx():
+    import pyfastx_amd
+    from pyfastx_amd import _lib
+    assert _lib.lib().fx_device_count() >= 1
+    return pyfastx_amd
+
+
+@pytest.fixture()
+def files(tmp_path):
+    out = {}
+    for fn in ("test.fa", "test.fa.gz", "test.fq", "test.fq.gz"):
+        p = tmp_path / fn
+        shutil.copy(os.path.join(DATA, fn), p)
+        os.chmod(p, 0o644)
+        out[fn] = str(p)
+    return out
+
+
+@pytest.mark.parametrize("fn", ["test.fa", "test.fa.gz"])
+def test_fasta_index_file_matches_reference(fx, files, fn):
+    g = load_golden("fasta_fixture")[fn]
+    fa = fx.Fasta(files[fn], full_index=True)
+    assert len(fa) == g["count"] and fa.size == g["size"]
+    assert fa.is_gzip == fn.endswith(".gz") == fx.gzip_check(files[fn])
+    db = sqlite3.connect(files[fn] + ".fxi")            # the .fxi itself, row for row
+    assert [list(r) for r in db.execute("SELECT * FROM seq")] == g["seq"]
+    assert list(db.execute("SELECT seqnum,seqlen FROM stat").fetchone()) == g["stat"]
+    assert [list(r[1:]) for r in db.execute("SELECT * FROM comp")] == g["comp"]
+    db.close()
+    assert fa.composition == g["composition"]
+    assert fa.gc_content == g["gc_content"]
+    assert repr(fa) == "<Fasta> %s contains %d sequences" % (files[fn], g["count"])
+    assert fa.type == "DNA"
+    # reopening loads the existing index instead of rebuilding
+    fb = fx.Fasta(files[fn])
+    assert len(fb) == g["count"] and fb[0].seq == fa[0].seq
+
+
+@pytest.mark.parametrize("fn", ["test.fa", "test.fa.gz"])
+def test_sequence_getters(fx, files, fn):
+    g = load_golden("fasta_fixture")[fn]
+    fa = fx.Fasta(files[fn])
+    for rid, rec in list(g["records"].items())[::7]:
+        s = fa[int(rid) - 1]
+        assert s.id == int(rid) and s.seq == rec["seq"] and str(s) == rec["seq"] and len(s) == len(rec["seq"])
+        assert s.description == rec["desc"] and s.raw == rec["raw"]
+        assert fa[s.name].seq == rec["seq"] and s.name in fa
+        assert repr(s) == "<Sequence> %s with length of %d" % (s.name, len(s))
+    for f in g["fetches"]:
+        sub = fa[f["id"] - 1][f["start"]:f["stop"]]
+        assert sub.seq == f["seq"] and sub.antisense == f["antisense"]
+        assert sub.complement == f["complement"] and sub.reverse == f["reverse"]
+        assert sub.name == f["name"] and (sub.start, sub.end) == (f["start"] + 1, f["stop"])
+        if f["raw"] is not None:
+            assert sub.raw == f["raw"]
+    s = fa[3]
+    full = s.seq
+    assert s[5:10].seq == full[5:10] and s[20:].seq == full[20:] and s[-10:].seq == full[-10:]
+    assert s[10:100][:20].seq == full[10:30]            # nested slices: absolute coordinates
+    assert s[7] == full[7] and s[-1] == full[-1]
+    assert "".join(s) == full                           # line iteration
+    assert full[10:25] in s and s.search(full[10:25]) == full.find(full[10:25]) + 1
+
+
+@pytest.mark.parametrize("fn", ["test.fa", "test.fa.gz"])
+def test_fetch_and_flank(fx, files, fn):
+    g = load_golden("fasta_fixture")[fn]
+    fa = fx.Fasta(files[fn])
+    for f in g["fetch"]:
+        iv = tuple(f["intervals"][0]) if len(f["intervals"]) == 1 else [tuple(x) for x in f["intervals"]]
+        assert fa.fetch(f["name"], iv, strand=f["strand"]) == f["seq"]
+    for f in g["flank"]:
+        assert list(fa.flank(f["name"], f["start"], f["end"], flank_length=f["flank"], use_cache=f["use_cache"])) == f["out"]
+
+
+def test_fasta_statistics(fx, files):
+    fa = fx.Fasta(files["test.fa"])
+    lens = sorted((len(s) for s in fa), reverse=True)
+    half, acc = sum(lens) / 2, 0
+    for l50, n50 in enumerate(lens, 1):
+        acc += n50
+        if acc >= half:
+            break
+    assert fa.nl(50) == (n50, l50) == (516, 66)
+    assert round(fa.mean, 3) == round(sum(lens) / len(lens), 3)
+    assert fa.median == sorted(lens)[105] == 386.0
+    assert fa.count(200) == sum(1 for x in lens if x >= 200)
+    assert len(fa.longest) == max(lens) and len(fa.shortest) == min(lens)
+    assert list(fa.keys())[:2] == [fa[0].name, fa[1].name]
+
+
+def test_fasta_options(fx, files, tmp_path):
+    up = fx.Fasta(files["test.fa"], uppercase=True)
+    assert up[0].seq == fx.Fasta(files["test.fa"])[0].seq.upper()
+    os.unlink(files["test.fa"] + ".fxi")
+    kf = fx.Fasta(files["test.fa"], key_func=lambda x: x.split()[1])
+    assert kf[5].name == kf[5].description.split()[1]
+    os.unlink(files["test.fa"] + ".fxi")
+    fn = fx.Fasta(files["test.fa"], full_name=True, memory_index=True)
+    assert fn[0].name == fn[0].description and not os.path.exists(files["test.fa"] + ".fxi")
+    tup = list(fx.Fasta(files["test.fa.gz"], build_index=False))
+    ref = fx.Fasta(files["test.fa.gz"])
+    assert [n for n, _ in tup] == list(ref.keys()) and tup[10][1] == ref[10].seq
+    assert repr(fx.Fasta(files["test.fa"], build_index=False)) == "<Fasta> %s" % files["test.fa"]
+
+
+def test_fasta_edge_inputs_via_api(fx, tmp_path):
+    g = load_golden("fasta_edge")
+    for name, case in g.items():
+        up = name.endswith(":upper")
+        p = tmp_path / (name.replace(":", "_") + ".fa")
+        p.write_bytes(case["text"].encode())
+        fa = fx.Fasta(str(p), uppercase=up, full_index=True)
+        db = sqlite3.connect(str(p) + ".fxi")
+        assert [list(r) for r in db.execute("SELECT * FROM seq")] == case["seq"], name
+        assert [list(r[1:]) for r in db.execute("SELECT * FROM comp")] == case["comp"], name
+        db.close()
+        for rid, rec in case["records"].items():
+            assert fa[int(rid) - 1].seq == rec["seq"], (name, rid)
+            if "desc" in rec:
+                assert fa[int(rid) - 1].description == rec["desc"] and fa[int(rid) - 1].raw == rec["raw"], (name, rid)
+        for f in case["fetches"]:
+            sub = fa[f["id"] - 1][f["start"]:f["stop"]]
+            assert sub.seq == f["seq"] and sub.antisense == f["antisense"], (name, f)
+
+
+def test_fasta_exceptions(fx, files, tmp_path):
+    fa = fx.Fasta(files["test.fa"])
+    with pytest.raises(TypeError):
+        fx.Fasta(files["test.fa"], key_func=1)
+    with pytest.raises(FileExistsError):
+        fx.Fasta("a_file_not_exists")
+    with pytest.raises(ValueError):
+        fa.fetch("seq1", {"a": 1})
+    with pytest.raises(NameError):
+        fa.fetch("seq1", (1, 10))
+    with pytest.raises(ValueError):
+        fa.fetch(fa[0].name, (1, 10, 20))
+    with pytest.raises(ValueError):
+        fa.fetch(fa[0].name, (20, 10))
+    with pytest.raises(IndexError):
+        fa[len(fa)]
+    with pytest.raises(KeyError):
+        fa[list()]
+    with pytest.raises(KeyError):
+        fa["no_such_sequence"]
+    with pytest.raises(ValueError):
+        fa.nl(101)
+    bad = tmp_path / "non.fa"
+    bad.write_text("abc")
+    with pytest.raises(RuntimeError):
+        fx.Fasta(str(bad))
+    with pytest.raises(ValueError):
+        fa[0][::2]
+    with pytest.raises(RuntimeError):
+        iter(fa[0][2:9]).__next__()
+
+
+@pytest.mark.parametrize("fn", ["test.fq", "test.fq.gz"])
+def test_fastq_and_reads(fx, files, fn):
+    g = load_golden("fastq_fixture")[fn]
+    fq = fx.Fastq(files[fn], full_index=True)
+    assert len(fq) == g["count"] and fq.size == g["size"] and fq.avglen == g["stat"][2]
+    db = sqlite3.connect(files[fn] + ".fxi")
+    assert [list(r) for r in db.execute("SELECT * FROM read")] == g["read"]
+    assert list(db.execute("SELECT * FROM base").fetchone()) == g["base"]
+    assert list(db.execute("SELECT * FROM meta").fetchone()) == g["meta"]
+    db.close()
+    assert fq.phred == g["phred"] == 33 and (fq.minqual, fq.maxqual) == (35, 70)
+    assert (fq.minlen, fq.maxlen) == (150, 150)
+    assert "Sanger Phred+33" in fq.encoding_type
+    assert repr(fq) == "<Fastq> %s contains %d reads" % (files[fn], g["count"])
+    for r in g["reads"]:
+        rd = fq[r["i"]]
+        assert (rd.name, rd.seq, rd.qual, rd.quali) == (r["name"], r["seq"], r["qual"], r["quali"])
+        assert (rd.antisense, rd.complement, rd.reverse) == (r["antisense"], r["complement"], r["reverse"])
+        assert rd.raw == r["raw"] and rd.description == r["desc"] and len(rd) == len(r["seq"])
+        assert fq[rd.name].id == rd.id and rd.name in fq
+    out = fq.fetch_many([r["i"] for r in g["reads"][:50]])
+    for j, r in enumerate(g["reads"][:50]):
+        a, b = out["offsets"][j], out["offsets"][j + 1]
+        assert out["seq"][a:b].tobytes().decode() == r["seq"] and out["quali"][a:b].tolist() == r["quali"]
+    with pytest.raises(IndexError):
+        fq[len(fq)]
+    with pytest.raises(KeyError):
+        fq["nope"]
+    tup = list(fx.Fastq(files[fn], build_index=False, index_file=files[fn] + ".none"))
+    assert len(tup) == g["count"] and tup[0][1] == fq[0].seq and tup[0][2] == fq[0].qual and tup[0][0] == fq[0].name
+
+
+def test_module_functions(fx):
+    assert fx.reverse_complement("ATGC") == "GCAT"
+    assert fx.version() == "2.3.1"
+    for s, want in load_golden("misc")["reverse_complement"]:
+        assert fx.reverse_complement(s) == want
+
+
+def test_batched_fetch_many(fx, files):
+    g = load_golden("fasta_fixture")["test.fa"]
+    fa = fx.Fasta(files["test.fa"])
+    f = g["fetches"]
+    buf, offs = fa.fetch_many([x["id"] - 1 for x in f], [x["start"] for x in f], [x["stop"] for x in f],
+                              strand=["-" if i % 2 else "+" for i in range(len(f))])
+    for i, x in enumerate(f):
+        want = x["antisense"] if i % 2 else x["seq"]
+        assert buf[offs[i]:offs[i + 1]].tobytes().decode() == want

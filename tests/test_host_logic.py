@@ -1,0 +1,143 @@
+"""CPU: host-side logic around the kernels -- .fxi writer, slice arithmetic,
+error classes, shard stitch -- none of which needs a GPU."""
+import os
+import sqlite3
+
+import numpy as np
+import pytest
+
+from conftest import DATA, fixture_bytes, load_golden
+import shard_ref
+
+
+def test_fxi_writer_reproduces_reference_file(oracle, tmp_path):
+    """Feed the writer the (oracle) arrays -> the .fxi equals the reference's rows and schema."""
+    from pyfastx_amd import fxi
+    g = load_golden("fasta_fixture")["test.fa"]
+    raw = fixture_bytes("test.fa")
+    recs, tot = oracle.fasta_index(raw)
+    names = [raw[r["name_off"]:r["name_off"] + r["name_len"]].decode() for r in recs]
+    cols = {k: recs[k] for k in ("boff", "blen", "slen", "llen", "elen", "norm", "dlen")}
+    p = str(tmp_path / "t.fxi")
+    db = fxi.connect(p)
+    fxi.write_fasta(db, names, cols, tot)
+    fxi.write_fasta_comp(db, oracle.fasta_comp(raw, len(recs)))
+    db.close()
+    db = sqlite3.connect(p)
+    assert [list(r) for r in db.execute("SELECT * FROM seq")] == g["seq"]
+    assert [list(r[1:]) for r in db.execute("SELECT * FROM comp")] == g["comp"]
+    assert db.execute("SELECT * FROM stat").fetchone() == (211, 86262, None, None, None, None)
+    cols_of = lambda t: [r[1] for r in db.execute("PRAGMA table_info(%s)" % t)]
+    assert cols_of("seq") == ["ID", "chrom", "boff", "blen", "slen", "llen", "elen", "norm", "dlen"]   # index.c:178-189
+    assert cols_of("stat") == ["seqnum", "seqlen", "avglen", "medlen", "n50", "l50"]
+    assert cols_of("comp") == ["ID", "seqid", "abc", "num"] and cols_of("gzindex") == ["ID", "content"]
+    idx = {r[1] for r in db.execute("PRAGMA index_list(seq)")} | {r[1] for r in db.execute("PRAGMA index_list(comp)")}
+    assert {"chromidx", "seqidx"} <= idx
+
+
+def test_fxi_fastq_writer(oracle, tmp_path):
+    from pyfastx_amd import fxi
+    g = load_golden("fastq_fixture")["test.fq"]
+    raw = fixture_bytes("test.fq")
+    recs, size, ln = oracle.fastq_index(raw)
+    names = [raw[r["name_off"]:r["name_off"] + r["name_len"]].decode() for r in recs]
+    db = fxi.connect(str(tmp_path / "q.fxi"))
+    fxi.write_fastq(db, names, {k: recs[k] for k in ("dlen", "rlen", "soff", "qoff")}, size)
+    c = oracle.fastq_composition(raw)
+    fxi.write_fastq_comp(db, [c[k] for k in "acgtn"], [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"], c["phred"]])
+    assert [list(r) for r in db.execute("SELECT * FROM read")] == g["read"]
+    assert list(db.execute("SELECT * FROM stat").fetchone()) == g["stat"]
+    assert list(db.execute("SELECT * FROM base").fetchone()) == g["base"]
+    assert list(db.execute("SELECT * FROM meta").fetchone()) == g["meta"]
+    assert [r[1] for r in db.execute("PRAGMA table_info(meta)")] == ["maxlen", "minlen", "minqs", "maxqs", "phred"]
+
+
+def test_slice_arithmetic_matches_oracle(oracle):
+    from pyfastx_amd.api import Sequence
+    rng = np.random.default_rng(3)
+    for _ in range(2000):
+        llen = int(rng.integers(2, 200)); elen = int(rng.integers(1, 3))
+        if llen - elen <= 0:
+            continue
+        slen = int(rng.integers(1, 5000)); boff = int(rng.integers(0, 10**9))
+        s = Sequence(None, 1, "x", boff, slen * 2, slen, llen, elen, 1, 5)
+        a = int(rng.integers(0, slen)); b = int(rng.integers(a, slen + 1))
+        assert s._range(a, b) == oracle.slice_range(boff, llen, elen, a, b)
+
+
+def test_error_classes_before_any_gpu_work(tmp_path):
+    import pyfastx_amd as fx
+    with pytest.raises(TypeError):
+        fx.Fasta(os.path.join(DATA, "test.fa"), key_func=1)
+    with pytest.raises(FileExistsError):
+        fx.Fasta("a_file_not_exists")
+    with pytest.raises(FileExistsError):
+        fx.Fastq("a_file_not_exists")
+    bad = tmp_path / "non.fa"
+    bad.write_text("abc")
+    with pytest.raises(RuntimeError):
+        fx.Fasta(str(bad))
+    with pytest.raises(RuntimeError):
+        fx.Fastq(os.path.join(DATA, "test.fa"))
+    assert fx.gzip_check(os.path.join(DATA, "test.fa.gz")) and not fx.gzip_check(os.path.join(DATA, "test.fa"))
+
+
+def test_existing_index_is_loaded_without_gpu(oracle, tmp_path):
+    """An .fxi next to the file is reused (index.c:418-429): metadata works with no device."""
+    import pyfastx_amd as fx
+    from pyfastx_amd import fxi
+    import shutil
+    p = str(tmp_path / "test.fa")
+    shutil.copy(os.path.join(DATA, "test.fa"), p)
+    raw = fixture_bytes("test.fa")
+    recs, tot = oracle.fasta_index(raw)
+    names = [raw[r["name_off"]:r["name_off"] + r["name_len"]].decode() for r in recs]
+    db = fxi.connect(p + ".fxi")
+    fxi.write_fasta(db, names, {k: recs[k] for k in ("boff", "blen", "slen", "llen", "elen", "norm", "dlen")}, tot)
+    db.close()
+    fa = fx.Fasta(p)
+    assert len(fa) == 211 and fa.size == 86262 and fa.nl(50) == (516, 66) and fa.median == 386.0
+    assert fa[0].name == "JZ822577.1" and len(fa[-1]) == 134 and "JZ822578.1" in fa
+    assert fa[1][5:30].name == "JZ822578.1:6-30" and fa.count(200) > 0
+
+
+def _expect(oracle, raw, full_name=False):
+    recs, _ = oracle.fasta_index(raw, full_name=full_name)
+    return {k: [int(x) for x in recs[k]] for k in ("hoff", "boff", "blen", "slen", "llen", "elen", "norm", "dlen", "name_len")}
+
+
+def test_stitch_every_cut_of_every_edge_case(oracle):
+    for name, case in load_golden("fasta_edge").items():
+        if name.endswith(":upper"):
+            continue
+        raw = case["text"].encode()
+        if len(raw) > 600:
+            continue
+        want = _expect(oracle, raw)
+        for c in range(1, len(raw)):
+            assert shard_ref.stitched_rows(raw, [c]) == want, (name, c)
+        for c in range(1, len(raw) - 2):
+            assert shard_ref.stitched_rows(raw, [c, c + 1]) == want, (name, c)
+            assert shard_ref.stitched_rows(raw, [c, c + 2], full_name=True) == _expect(oracle, raw, True), (name, c)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_stitch_random(oracle, seed):
+    rng = np.random.default_rng(seed)
+    eol = b"\r\n" if seed & 1 else b"\n"
+    parts = []
+    for i in range(int(rng.integers(1, 12))):
+        parts.append(b">r%d d%d" % (i, i) + eol)
+        w = int(rng.integers(1, 30))
+        s = bytes(rng.choice(list(b"ACGTN"), int(rng.integers(0, 400))).astype(np.uint8))
+        for p in range(0, len(s), w):
+            ww = w if seed % 3 else int(rng.integers(1, w + 1))
+            parts.append(s[p:p + ww] + eol)
+    raw = b"".join(parts)
+    if seed == 7:
+        raw = raw.rstrip()
+    want = _expect(oracle, raw)
+    for g in (2, 3, 4, 8, 16):
+        for _ in range(10):
+            cuts = sorted(set(int(x) for x in rng.integers(1, len(raw), g - 1)))
+            assert shard_ref.stitched_rows(raw, cuts) == want, (seed, cuts)
