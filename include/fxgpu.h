@@ -50,6 +50,7 @@ enum {
     FX_UPPER = 1,       /* remove_space_uppercase, util.c:181-194                 */
     FX_REVERSE = 2,     /* reverse_seq, util.c:251-261                            */
     FX_COMPLEMENT = 4,  /* complement_seq / comp_map, util.c:228-237, 263-269     */
+    FX_LONG = 16,       /* hint: ranges are long (KiB+): one wave per query, 1 KiB per step   */
     FX_RAW = 8          /* no despace: plain pyfastx_index_random_read (index.c:683-692), for
                            names, Sequence.raw / .description, Read.raw             */
 };

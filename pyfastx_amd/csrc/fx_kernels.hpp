@@ -25,6 +25,7 @@ constexpr int UNROLL = 8;                       // 16-byte loads in flight per l
 constexpr int CHUNK = 16;                       // bytes per lane per load (global_load_dwordx4)
 constexpr int TILE = BLOCK * CHUNK * UNROLL;    // 32 KiB of file per workgroup
 constexpr int TILE_CHUNKS = BLOCK * UNROLL;     // 2048 mask words (u16) per tile
+constexpr int GROUP = BLOCK;                    // tiles per prefix group (one count per thread of a consumer block)
 
 // ---------------------------------------------------------------- SWAR bytes
 // 0x80 in every byte of x that is zero (exact, no borrow false positives).
@@ -118,67 +119,138 @@ __device__ __forceinline__ int64_t upper_bound(const int64_t *__restrict__ a, in
 // before it: a FASTA header is a '>' that follows '\n' or starts the stream
 // (index.c:234, line.s[0] == 62).
 // Replaces: ks_getuntil's byte loop kseq.c:78-80 and the memcpy kseq.c:94.
+// Launch shape (tuned with tools/scanbench.hip on MI355X, 3 GB input): 1024-thread
+// workgroups, 4 loads in flight per lane, non-temporal loads (the stream is read
+// exactly once; nt keeps it from displacing L2/MALL lines): 5.6 TB/s including the
+// mask store, vs 4.7 TB/s for 256 threads x 8 loads with default-policy loads.  A
+// workgroup covers SCAN_TILES (2) consecutive 32 KiB tiles and emits one count per tile.
+constexpr int SCAN_BLOCK = 1024;
+constexpr int SCAN_UNROLL = 4;
+constexpr int SCAN_SPAN = SCAN_BLOCK * CHUNK * SCAN_UNROLL;     // 64 KiB per workgroup
+constexpr int SCAN_TILES = SCAN_SPAN / TILE;                    // 2
+constexpr int ROWS_PER_TILE = SCAN_UNROLL / SCAN_TILES;         // 2 rows of 16 KiB per tile
+
+__device__ __forceinline__ uint4 load16_nt(const uint8_t *__restrict__ data, int64_t p, int64_t n) {
+    if (p + CHUNK <= n) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(data + p);
+        uint4 v;
+        v.x = __builtin_nontemporal_load(&q->x); v.y = __builtin_nontemporal_load(&q->y);
+        v.z = __builtin_nontemporal_load(&q->z); v.w = __builtin_nontemporal_load(&q->w);
+        return v;
+    }
+    return load16(data, p, n);
+}
+
 template <bool HDR>
-__global__ __launch_bounds__(BLOCK) void k_scan(const uint8_t *__restrict__ data, int64_t n, int prev_byte,
-                                               uint16_t *__restrict__ nlmask, uint32_t *__restrict__ tile_nl,
-                                               uint32_t *__restrict__ tile_hdr) {
-    __shared__ uint32_t lds4[4];
-    const int64_t tile = blockIdx.x;
-    const int64_t tbase = tile * (int64_t)TILE;
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan(const uint8_t *__restrict__ data, int64_t n, int prev_byte,
+                                                    uint16_t *__restrict__ nlmask, uint32_t *__restrict__ tile_nl,
+                                                    uint32_t *__restrict__ tile_hdr, int64_t ntiles) {
+    __shared__ uint32_t red[2][SCAN_TILES][SCAN_BLOCK / 64];
+    const int64_t span = blockIdx.x;
+    const int64_t sbase = span * (int64_t)SCAN_SPAN;
     const int tid = threadIdx.x;
-    uint4 v[UNROLL];
+    uint4 v[SCAN_UNROLL];
 #pragma unroll
-    for (int j = 0; j < UNROLL; ++j) v[j] = load16(data, tbase + (int64_t)(j * BLOCK + tid) * CHUNK, n);
-    uint32_t cnt = 0, hcnt = 0;
+    for (int j = 0; j < SCAN_UNROLL; ++j) v[j] = load16_nt(data, sbase + (int64_t)(j * SCAN_BLOCK + tid) * CHUNK, n);
+    uint32_t cnt[SCAN_TILES], hcnt[SCAN_TILES];
 #pragma unroll
-    for (int j = 0; j < UNROLL; ++j) {
+    for (int t = 0; t < SCAN_TILES; ++t) { cnt[t] = 0; hcnt[t] = 0; }
+#pragma unroll
+    for (int j = 0; j < SCAN_UNROLL; ++j) {
         const uint32_t m = eq_mask16(v[j], 0x0A0A0A0Au);
-        nlmask[tile * TILE_CHUNKS + j * BLOCK + tid] = (uint16_t)m;
-        cnt += __popc(m);
+        nlmask[span * (SCAN_SPAN / CHUNK) + j * SCAN_BLOCK + tid] = (uint16_t)m;
+        cnt[j / ROWS_PER_TILE] += __popc(m);
         if (HDR) {
             if (any_eq16(v[j], 0x3E3E3E3Eu)) {
                 uint32_t g = eq_mask16(v[j], 0x3E3E3E3Eu);
-                const int64_t p = tbase + (int64_t)(j * BLOCK + tid) * CHUNK;
+                const int64_t p = sbase + (int64_t)(j * SCAN_BLOCK + tid) * CHUNK;
                 while (g) {
                     const int k = __ffs(g) - 1;
                     g &= g - 1;
                     const int64_t pos = p + k;
                     const int prev = pos ? (int)data[pos - 1] : prev_byte;
-                    hcnt += (prev == '\n');
+                    hcnt[j / ROWS_PER_TILE] += (prev == '\n');
                 }
             }
         }
     }
-    const uint32_t tot = block_sum(cnt, lds4);
-    if (tid == 0) tile_nl[tile] = tot;
-    if (HDR) {
-        const uint32_t htot = block_sum(hcnt, lds4);
-        if (tid == 0) tile_hdr[tile] = htot;
+    const int w = tid >> 6, l = tid & 63;
+#pragma unroll
+    for (int t = 0; t < SCAN_TILES; ++t) {
+        const uint32_t a = wave_sum(cnt[t]);
+        if (l == 0) red[0][t][w] = a;
+        if (HDR) { const uint32_t b = wave_sum(hcnt[t]); if (l == 0) red[1][t][w] = b; }
+    }
+    __syncthreads();
+    if (tid < SCAN_TILES * (HDR ? 2 : 1)) {
+        const int t = tid % SCAN_TILES, which = tid / SCAN_TILES;
+        uint32_t s = 0;
+#pragma unroll
+        for (int i = 0; i < SCAN_BLOCK / 64; ++i) s += red[which][t][i];
+        const int64_t tile = span * SCAN_TILES + t;
+        if (tile < ntiles) (which ? tile_hdr : tile_nl)[tile] = s;
     }
 }
 
 // ======================================================================= K2
-// Exclusive prefix sums over the per-tile counts (one workgroup; the arrays are
-// ~n/32768 entries).  off[i] = sum(cnt[0..i)), off[ntiles] = total.
-__global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t *__restrict__ cnt, int64_t ntiles,
-                                                   int64_t *__restrict__ off) {
-    __shared__ int64_t part[1024];
-    const int tid = threadIdx.x;
-    const int64_t per = (ntiles + 1023) / 1024;
-    const int64_t lo = (int64_t)tid * per, hi = (lo + per < ntiles) ? lo + per : ntiles;
-    int64_t s = 0;
-    for (int64_t i = lo; i < hi; ++i) s += cnt[i];
-    part[tid] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {          // Hillis-Steele inclusive scan in LDS
-        int64_t t = (tid >= d) ? part[tid - d] : 0;
+// The global prefix of the per-tile counts is two-level: k_group_sum adds up each
+// GROUP (256) of tile counts (one wave per group), k_group_scan scans those sums
+// (ntiles/256 words: 364 for a 3 GB file), and every consumer workgroup adds the
+// counts of the tiles before it inside its own group (tile_prefix below).
+__global__ __launch_bounds__(BLOCK) void k_group_sum(const uint32_t *__restrict__ tile_a, const uint32_t *__restrict__ tile_b,
+                                                    int64_t ntiles, int64_t ngroups,
+                                                    unsigned long long *__restrict__ grp_cnt) {
+    const int lane = lane_id();
+    const int64_t g = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    if (g >= ngroups) return;
+    uint32_t a = 0, b = 0;
+#pragma unroll
+    for (int k = 0; k < GROUP / 64; ++k) {
+        const int64_t t = g * GROUP + k * 64 + lane;
+        if (t < ntiles) { a += tile_a[t]; if (tile_b) b += tile_b[t]; }
+    }
+    a = wave_sum(a);
+    if (tile_b) b = wave_sum(b);
+    if (lane == 0) { grp_cnt[g] = a; if (tile_b) grp_cnt[ngroups + g] = b; }
+}
+
+// Exclusive prefix over the per-GROUP counts (ntiles/256 words: 364 for a 3 GB
+// file), one workgroup, `nsets` independent arrays back to back.
+// off[s*(ngroups+1) + g] = sum(cnt[s*ngroups + 0..g)), last entry = total.
+__global__ __launch_bounds__(1024) void k_group_scan(const unsigned long long *__restrict__ cnt, int64_t ngroups,
+                                                    int nsets, int64_t *__restrict__ off) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long carry;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int s = 0; s < nsets; ++s) {
+        if (tid == 0) carry = 0;
         __syncthreads();
-        part[tid] += t;
+        for (int64_t g0 = 0; g0 < ngroups; g0 += 1024) {
+            const int64_t g = g0 + tid;
+            const unsigned long long v = g < ngroups ? cnt[s * ngroups + g] : 0ull;
+            unsigned long long inc = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { unsigned long long t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+            if (lane == 63) wsum[w] = inc;
+            __syncthreads();
+            unsigned long long base = carry;
+            for (int i = 0; i < w; ++i) base += wsum[i];
+            if (g < ngroups) off[s * (ngroups + 1) + g] = (int64_t)(base + inc - v);
+            __syncthreads();
+            if (tid == 1023) carry = base + inc;
+            __syncthreads();
+        }
+        if (tid == 0) off[s * (ngroups + 1) + ngroups] = (int64_t)carry;
         __syncthreads();
     }
-    int64_t run = part[tid] - s;
-    for (int64_t i = lo; i < hi; ++i) { off[i] = run; run += cnt[i]; }
-    if (tid == 1023) off[ntiles] = part[1023];
+}
+
+// prefix of a tile inside its group: sum of the counts of the tiles before it (<= 255 loads, one per thread)
+__device__ __forceinline__ int64_t tile_prefix(const uint32_t *__restrict__ tile_cnt, const int64_t *__restrict__ grp_off,
+                                               int64_t tile, uint32_t *lds4) {
+    const int64_t g = tile / GROUP, idx = g * GROUP + threadIdx.x;
+    const uint32_t v = idx < tile ? tile_cnt[idx] : 0u;
+    return grp_off[g] + (int64_t)block_sum(v, lds4);
 }
 
 // ======================================================================= K3
@@ -189,18 +261,21 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t *__restrict__
 // nl[i] is the offset of the '\n' that terminates line i; it carries
 // `position += line.l + 1` (index.c:231, fastq.c:148) for every line at once.
 __global__ __launch_bounds__(BLOCK) void k_linetable(const uint16_t *__restrict__ nlmask,
-                                                    const int64_t *__restrict__ tile_off, int64_t gbase,
+                                                    const uint32_t *__restrict__ tile_nl,
+                                                    const int64_t *__restrict__ grp_off, int64_t gbase,
                                                     int64_t *__restrict__ nl) {
     __shared__ uint32_t lds4[4];
     const int64_t tile = blockIdx.x;
     const int tid = threadIdx.x;
+    if (tile_nl[tile] == 0) return;
+    const int64_t tbase_rank = tile_prefix(tile_nl, grp_off, tile, lds4);
     const uint4 mv = *reinterpret_cast<const uint4 *>(nlmask + tile * TILE_CHUNKS + tid * 8);
     const uint32_t w[4] = {mv.x, mv.y, mv.z, mv.w};
     const uint32_t cnt = __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);
     uint32_t total;
     uint32_t r = block_excl_scan(cnt, lds4, &total);
     if (cnt == 0) return;
-    int64_t *dst = nl + tile_off[tile] + r;
+    int64_t *dst = nl + tbase_rank + r;
     const int64_t p0 = gbase + tile * (int64_t)TILE + (int64_t)tid * 8 * CHUNK;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -219,14 +294,14 @@ __global__ __launch_bounds__(BLOCK) void k_linetable(const uint16_t *__restrict_
 // order so hdr[] comes out sorted.
 __global__ __launch_bounds__(BLOCK) void k_hdr_scatter(const uint8_t *__restrict__ data, int64_t n, int prev_byte,
                                                       const uint32_t *__restrict__ tile_hdr,
-                                                      const int64_t *__restrict__ tile_hdr_off, int64_t gbase,
+                                                      const int64_t *__restrict__ grp_off, int64_t gbase,
                                                       int64_t *__restrict__ hdr) {
     __shared__ uint32_t lds4[4];
     const int64_t tile = blockIdx.x;
     if (tile_hdr[tile] == 0) return;
     const int tid = threadIdx.x;
     const int64_t tbase = tile * (int64_t)TILE;
-    int64_t run = tile_hdr_off[tile];
+    int64_t run = tile_prefix(tile_hdr, grp_off, tile, lds4);
     for (int j = 0; j < UNROLL; ++j) {
         const int64_t p = tbase + (int64_t)(j * BLOCK + tid) * CHUNK;
         const uint4 v = load16(data, p, n);
@@ -310,29 +385,48 @@ __global__ __launch_bounds__(BLOCK) void k_fasta_rec(const uint8_t *__restrict__
 
 // ======================================================================= K6
 // bad_line (index.c:325-327): lines after the first of a record whose length
-// differs from the first.  One thread per line; the record is found by binary
-// search over hdr_line[] (wave-uniform in the common case of long records).
-// Bad lines are rare in well-formed files (the short last line of each record),
-// so the global atomic is rarely taken.
+// (+1) differs from the first line's.  Each wave owns a contiguous span of the
+// line table and walks it 64 lines at a time, keeping the record of the current
+// window in (wave-uniform) registers: one binary search per span, not per line.
+// A window that crosses a record boundary takes the per-lane search path.  Bad
+// lines are rare in well-formed files (the short last line of each record), so
+// counts are kept per lane and flushed with one atomic per (wave, record).
+constexpr int LINES_PER_WAVE = 64 * 64;
 __global__ __launch_bounds__(BLOCK) void k_fasta_lines(const int64_t *__restrict__ nl, int64_t n_nl,
                                                       const int64_t *__restrict__ hdr_line, int64_t n_hdr,
                                                       const int64_t *__restrict__ llen, uint32_t *__restrict__ bad) {
-    const int64_t stride = (int64_t)gridDim.x * BLOCK;
-    for (int64_t i0 = (int64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63); i0 < n_nl; i0 += stride) {
-        const int64_t i = i0 + lane_id();
-        // records of the first and last line of this wave's 64-line window
-        const int64_t ilast = (i0 + 63 < n_nl) ? i0 + 63 : n_nl - 1;
-        const int64_t r0 = upper_bound(hdr_line, n_hdr, i0) - 1;
-        int64_t r1 = r0;
-        if (r0 + 1 < n_hdr && hdr_line[r0 + 1] <= ilast) r1 = upper_bound(hdr_line, n_hdr, ilast) - 1;
-        if (i >= n_nl) continue;
-        int64_t rec = r0;
-        if (r1 != r0) rec = r0 + upper_bound(hdr_line + (r0 + 1), r1 - r0, i);   // search inside [r0+1, r1]
-        if (rec < 0) continue;                                  // before the first header
-        const int64_t hl = hdr_line[rec];
-        if (i <= hl + 1) continue;                              // header line or first sequence line
-        if (nl[i] - nl[i - 1] != llen[rec]) atomicAdd(&bad[rec], 1u);
+    const int lane = lane_id();
+    const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const int64_t lo = wave * LINES_PER_WAVE;
+    if (lo >= n_nl) return;
+    const int64_t hi = (lo + LINES_PER_WAVE < n_nl) ? lo + LINES_PER_WAVE : n_nl;
+    int64_t rec = upper_bound(hdr_line, n_hdr, lo) - 1;          // record of line `lo` (-1: before the first header)
+    int64_t hl = rec >= 0 ? hdr_line[rec] : -2;                  // its header line index
+    int64_t next_hl = (rec + 1 < n_hdr) ? hdr_line[rec + 1] : n_nl;
+    int64_t ll = rec >= 0 ? llen[rec] : 0;
+    uint32_t cnt = 0;
+    for (int64_t i0 = lo; i0 < hi; i0 += 64) {
+        const int64_t i = i0 + lane;
+        const int64_t ilast = (i0 + 63 < hi) ? i0 + 63 : hi - 1;
+        if (ilast < next_hl) {                                   // whole window inside the current record
+            if (rec >= 0 && i < hi && i > hl + 1) cnt += (nl[i] - nl[i - 1] != ll);
+            continue;
+        }
+        // boundary window: flush, then every lane finds its own record
+        cnt = wave_sum(cnt);
+        if (lane == 0 && cnt && rec >= 0) atomicAdd(&bad[rec], cnt);
+        cnt = 0;
+        if (i < hi) {
+            const int64_t r = upper_bound(hdr_line, n_hdr, i) - 1;
+            if (r >= 0 && i > hdr_line[r] + 1 && nl[i] - nl[i - 1] != llen[r]) atomicAdd(&bad[r], 1u);
+        }
+        rec = upper_bound(hdr_line, n_hdr, ilast) - 1;           // state for the next window
+        hl = rec >= 0 ? hdr_line[rec] : -2;
+        next_hl = (rec + 1 < n_hdr) ? hdr_line[rec + 1] : n_nl;
+        ll = rec >= 0 ? llen[rec] : 0;
     }
+    cnt = wave_sum(cnt);
+    if (lane == 0 && cnt && rec >= 0) atomicAdd(&bad[rec], cnt);
 }
 
 // Shard lead statistics (multi-GPU stitch).  The "lead" of a shard is
@@ -478,61 +572,105 @@ __device__ __forceinline__ void build_comp_lut(uint8_t *lut) {
     }
 }
 
-template <bool BY_ID>
+// G lanes cooperate on one query (64/G queries in flight per wave); each lane
+// loads V aligned bytes per step, so a step covers a G*V-byte window:
+//   <16, 8>  128-byte window, 4 queries per wave  -- ~100-bp random access
+//   <64,16>  1 KiB window, 1 query per wave       -- long ranges (whole records)
+// The keep mask of a lane's V bytes is SWAR, the rank of its first kept byte is
+// an exclusive prefix over the G lanes (__shfl_up, width G), kept bytes whose
+// rank falls in [skip, skip+take) are stored (mirrored for FX_REVERSE).
+template <bool BY_ID, int G, int V>
 __global__ __launch_bounds__(BLOCK) void k_fetch(const uint8_t *__restrict__ data, int64_t gbase, int64_t n_bytes,
                                                 FetchQ q, FastaTab tab, int64_t nq, int flags_all,
                                                 uint8_t *__restrict__ dst) {
     __shared__ uint8_t lut[256];
     build_comp_lut(lut);
     __syncthreads();
-    const int lane = lane_id();
+    constexpr int QPW = 64 / G, NW = V / 4;
+    const int lane = lane_id(), sub = lane & (G - 1), grp = lane / G;
     const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
-    for (int64_t i = wave; i < nq; i += nwaves) {
-        int64_t off, blen, skip, take;
-        if (BY_ID) {
-            const int64_t id = q.seq_id[i], a = q.start[i], b = q.stop[i];
-            if (id < 0 || id >= tab.n_seq || a < 0 || b < a || b > tab.slen[id]) { // caller validates; stay safe
-                if (lane == 0 && q.out_len) q.out_len[i] = -1;
-                continue;
+    for (int64_t i0 = wave * QPW; i0 < nq; i0 += nwaves * QPW) {
+        const int64_t i = i0 + grp;
+        bool ok = i < nq;
+        int64_t off = 0, blen = 0, skip = 0, take = 0;
+        if (ok) {
+            if (BY_ID) {
+                const int64_t id = q.seq_id[i], a = q.start[i], b = q.stop[i];
+                if (id < 0 || id >= tab.n_seq || a < 0 || b < a || b > tab.slen[id]) {   // caller validates; stay safe
+                    if (sub == 0 && q.out_len) q.out_len[i] = -1;
+                    ok = false;
+                } else {
+                    take = b - a;
+                    const int64_t el = tab.elen[id], bpl = tab.llen[id] - el;
+                    if (tab.norm[id] && bpl > 0) {             // sequence.c:498-510
+                        const int64_t bs = a / bpl, be = b / bpl;
+                        off = tab.boff[id] + a + el * bs;
+                        blen = take + (be - bs) * el;
+                    } else {                                   // sequence.c:100-110: despace whole record, then slice
+                        off = tab.boff[id]; blen = tab.blen[id]; skip = a;
+                    }
+                }
+            } else {
+                off = q.off[i]; blen = q.blen[i]; take = q.take[i]; skip = q.skip ? q.skip[i] : 0;
             }
-            take = b - a;
-            const int64_t bpl = tab.llen[id] - tab.elen[id];
-            if (tab.norm[id] && bpl > 0) {                 // sequence.c:498-510
-                const int64_t bs = a / bpl, be = b / bpl;
-                off = tab.boff[id] + a + (int64_t)tab.elen[id] * bs;
-                blen = take + (be - bs) * tab.elen[id];
-                skip = 0;
-            } else {                                       // sequence.c:100-110: despace whole record, then slice
-                off = tab.boff[id]; blen = tab.blen[id]; skip = a;
-            }
-        } else {
-            off = q.off[i]; blen = q.blen[i]; take = q.take[i]; skip = q.skip ? q.skip[i] : 0;
         }
-        const int fl = q.qflags ? q.qflags[i] : flags_all;
+        const int fl = (ok && q.qflags) ? q.qflags[i] : flags_all;
         // clamp to the bytes we hold (fread past EOF returns short, index.c:689)
         int64_t lo = off - gbase, hi = lo + blen;
         if (lo < 0) lo = 0;
         if (hi > n_bytes) hi = n_bytes;
-        uint8_t *out = dst + q.dst_off[i];
-        int64_t rank = 0;                                  // kept bytes before this window
+        if (!ok) { lo = 0; hi = 0; }
+        uint8_t *out = dst + (ok ? q.dst_off[i] : 0);
         const int64_t end = skip + take;
-        for (int64_t p = lo; p < hi && rank < end; p += 64) {
-            const int64_t pp = p + lane;
-            uint8_t c = (pp < hi) ? data[pp] : (uint8_t)'\n';
-            const bool keep = (fl & 8) ? (pp < hi) : !(c == 10 || c == 13 || c == 32);   // FX_RAW keeps every byte
-            const unsigned long long bal = __ballot(keep);
-            const int64_t r = rank + __popcll(bal & ((1ull << lane) - 1ull));
-            if (keep && r >= skip && r < end) {
-                if ((fl & 1) && c >= 'a' && c <= 'z') c -= 32;
-                if (fl & 4) c = lut[c];
-                const int64_t o = r - skip;
-                out[(fl & 2) ? (take - 1 - o) : o] = c;
+        int64_t rank = 0;                                      // kept bytes before this window
+        for (int64_t p = lo & ~(int64_t)(V - 1); p < hi && rank < end; p += G * V) {
+            const int64_t pp = p + (int64_t)sub * V;
+            uint32_t w[NW];
+#pragma unroll
+            for (int k = 0; k < NW; ++k) w[k] = 0;
+            if (pp < hi) {
+                if (V == 16) { const uint4 t = *reinterpret_cast<const uint4 *>(data + pp); w[0] = t.x; w[1] = t.y; w[NW - 2] = t.z; w[NW - 1] = t.w; }
+                else         { const uint2 t = *reinterpret_cast<const uint2 *>(data + pp); w[0] = t.x; w[NW - 1] = t.y; }
             }
-            rank += __popcll(bal);
+            // bits of the lane's V bytes that are inside [lo,hi) and not white space
+            int64_t a0 = lo - pp, a1 = hi - pp;
+            a0 = a0 < 0 ? 0 : (a0 > V ? V : a0);
+            a1 = a1 < 0 ? 0 : (a1 > V ? V : a1);
+            uint32_t km = (a1 > a0) ? (((1u << a1) - 1u) & ~((1u << a0) - 1u)) & ((V == 16) ? 0xFFFFu : 0xFFu) : 0u;
+            if (!(fl & 8)) {                                   // jump_table (util.c:157-164): drop 10, 13, 32
+                uint32_t sp = 0;
+#pragma unroll
+                for (int k = 0; k < NW; ++k)
+                    sp |= flags4(zero_bytes(w[k] ^ 0x0A0A0A0Au) | zero_bytes(w[k] ^ 0x0D0D0D0Du) |
+                                 zero_bytes(w[k] ^ 0x20202020u)) << (4 * k);
+                km &= ~sp;
+            }
+            const int kcnt = __popc(km);
+            int inc = kcnt;
+#pragma unroll
+            for (int d = 1; d < G; d <<= 1) { const int t = __shfl_up(inc, d, G); if (sub >= d) inc += t; }
+            const int total = __shfl(inc, G - 1, G);
+            int64_t r = rank + inc - kcnt;
+            while (km) {
+                const int j = __ffs(km) - 1;
+                km &= km - 1;
+                if (r >= skip && r < end) {
+                    uint32_t word = w[0];
+#pragma unroll
+                    for (int k = 1; k < NW; ++k) word = (j >> 2) == k ? w[k] : word;
+                    uint8_t c = (uint8_t)(word >> ((j & 3) * 8));
+                    if ((fl & 1) && c >= 'a' && c <= 'z') c -= 32;
+                    if (fl & 4) c = lut[c];
+                    const int64_t o = r - skip;
+                    out[(fl & 2) ? (take - 1 - o) : o] = c;
+                }
+                ++r;
+            }
+            rank += total;
         }
-        if (lane == 0 && q.out_len) {
-            int64_t got = rank - skip;
+        if (ok && sub == 0 && q.out_len) {
+            const int64_t got = rank - skip;
             q.out_len[i] = got < 0 ? 0 : (got > take ? take : got);
         }
     }

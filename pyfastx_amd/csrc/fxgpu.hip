@@ -73,7 +73,7 @@ template <class T> struct DevBuf {      // grow-only device array: rebuilds reus
 enum KernelId { K_SCAN = 0, K_TILE_SCAN, K_LINETABLE, K_HDR_SCATTER, K_FASTA_REC, K_FASTA_LINES, K_FASTA_FINALIZE,
                 K_FETCH, K_FASTA_COMP, K_FASTQ_REC, K_FASTQ_COMP, K_FASTQ_FETCH, K_NKERN };
 static const char *const kKernelNames[K_NKERN] = {
-    "k_scan", "k_tile_scan", "k_linetable", "k_hdr_scatter", "k_fasta_rec", "k_fasta_lines", "k_fasta_finalize",
+    "k_scan", "k_group_scan", "k_linetable", "k_hdr_scatter", "k_fasta_rec", "k_fasta_lines", "k_fasta_finalize",
     "k_fetch", "k_fasta_comp", "k_fastq_rec", "k_fastq_comp", "k_fastq_fetch"};
 
 struct Prof {
@@ -129,7 +129,8 @@ struct fx_handle {
     int64_t ntiles = 0;
     DevBuf<uint16_t> nlmask;
     DevBuf<uint32_t> tile_nl, tile_hdr;
-    DevBuf<int64_t> tile_nl_off, tile_hdr_off;
+    DevBuf<unsigned long long> grp_cnt;       // per-group (256 tiles) newline / header counts
+    DevBuf<int64_t> grp_off;                  // their exclusive prefixes (+ totals)
     DevBuf<int64_t> nl;       // line table incl. virtual EOF newline
     int64_t n_nl = 0;         // entries in nl
     int64_t n_real_nl = 0;    // real '\n' bytes
@@ -408,26 +409,28 @@ static int run_scan(fx_handle *h, bool want_hdr) {
     if (rc) return rc;
     if (h->n <= 0) return fail(FX_EFORMAT, "empty input");
     h->ntiles = (h->n + TILE - 1) / TILE;
-    if ((rc = h->nlmask.alloc(h->ntiles * TILE_CHUNKS))) return rc;
+    const int64_t ngroups = (h->ntiles + GROUP - 1) / GROUP;
+    const int nsets = want_hdr ? 2 : 1;
+    const int64_t nspans = (h->ntiles + SCAN_TILES - 1) / SCAN_TILES;
+    if ((rc = h->nlmask.alloc(nspans * SCAN_TILES * TILE_CHUNKS))) return rc;
     if ((rc = h->tile_nl.alloc(h->ntiles))) return rc;
-    if ((rc = h->tile_nl_off.alloc(h->ntiles + 1))) return rc;
-    if (want_hdr) {
-        if ((rc = h->tile_hdr.alloc(h->ntiles))) return rc;
-        if ((rc = h->tile_hdr_off.alloc(h->ntiles + 1))) return rc;
-        FX_LAUNCH(h, K_SCAN, (k_scan<true>), dim3((unsigned)h->ntiles), dim3(BLOCK), h->d_data, h->n,
-                           h->prev_byte, h->nlmask.p, h->tile_nl.p, h->tile_hdr.p);
-        FX_LAUNCH(h, K_TILE_SCAN, k_tile_scan, dim3(1), dim3(1024), h->tile_hdr.p, h->ntiles, h->tile_hdr_off.p);
-    } else {
-        FX_LAUNCH(h, K_SCAN, (k_scan<false>), dim3((unsigned)h->ntiles), dim3(BLOCK), h->d_data, h->n,
-                           h->prev_byte, h->nlmask.p, h->tile_nl.p, (uint32_t *)nullptr);
-    }
-    FX_LAUNCH(h, K_TILE_SCAN, k_tile_scan, dim3(1), dim3(1024), h->tile_nl.p, h->ntiles, h->tile_nl_off.p);
+    if ((rc = h->grp_cnt.alloc(2 * ngroups)) || (rc = h->grp_off.alloc(2 * (ngroups + 1)))) return rc;
+    if (want_hdr && (rc = h->tile_hdr.alloc(h->ntiles))) return rc;
+    if (want_hdr)
+        FX_LAUNCH(h, K_SCAN, (k_scan<true>), dim3((unsigned)nspans), dim3(SCAN_BLOCK), h->d_data, h->n, h->prev_byte,
+                  h->nlmask.p, h->tile_nl.p, h->tile_hdr.p, h->ntiles);
+    else
+        FX_LAUNCH(h, K_SCAN, (k_scan<false>), dim3((unsigned)nspans), dim3(SCAN_BLOCK), h->d_data, h->n, h->prev_byte,
+                  h->nlmask.p, h->tile_nl.p, (uint32_t *)nullptr, h->ntiles);
+    FX_LAUNCH(h, K_TILE_SCAN, k_group_sum, dim3(nblocks(ngroups, BLOCK / 64)), dim3(BLOCK), h->tile_nl.p,
+              want_hdr ? h->tile_hdr.p : (const uint32_t *)nullptr, h->ntiles, ngroups, h->grp_cnt.p);
+    FX_LAUNCH(h, K_TILE_SCAN, k_group_scan, dim3(1), dim3(1024), h->grp_cnt.p, ngroups, nsets, h->grp_off.p);
     HIPCHK(hipGetLastError());
     // totals + last byte back to the host (needed to size the tables)
     int64_t tot_nl = 0, tot_hdr = 0;
     uint8_t last = 0;
-    HIPCHK(hipMemcpyAsync(&tot_nl, h->tile_nl_off.p + h->ntiles, 8, hipMemcpyDeviceToHost, h->stream));
-    if (want_hdr) HIPCHK(hipMemcpyAsync(&tot_hdr, h->tile_hdr_off.p + h->ntiles, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&tot_nl, h->grp_off.p + ngroups, 8, hipMemcpyDeviceToHost, h->stream));
+    if (want_hdr) HIPCHK(hipMemcpyAsync(&tot_hdr, h->grp_off.p + (ngroups + 1) + ngroups, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(&last, h->d_data + h->n - 1, 1, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->n_real_nl = tot_nl;
@@ -436,8 +439,8 @@ static int run_scan(fx_handle *h, bool want_hdr) {
     const bool virt = h->is_last && last != '\n';
     h->n_nl = tot_nl + (virt ? 1 : 0);
     if ((rc = h->nl.alloc(std::max<int64_t>(h->n_nl, 1)))) return rc;
-    FX_LAUNCH(h, K_LINETABLE, k_linetable, dim3((unsigned)h->ntiles), dim3(BLOCK), h->nlmask.p,
-                       h->tile_nl_off.p, h->base, h->nl.p);
+    FX_LAUNCH(h, K_LINETABLE, k_linetable, dim3((unsigned)h->ntiles), dim3(BLOCK), h->nlmask.p, h->tile_nl.p,
+              h->grp_off.p, h->base, h->nl.p);
     if (virt) {
         const int64_t v = h->base + h->n;
         HIPCHK(hipMemcpyAsync(h->nl.p + tot_nl, &v, 8, hipMemcpyHostToDevice, h->stream));
@@ -448,7 +451,7 @@ static int run_scan(fx_handle *h, bool want_hdr) {
         if ((rc = h->hdr.alloc(std::max<int64_t>(tot_hdr, 1)))) return rc;
         if (tot_hdr)
             FX_LAUNCH(h, K_HDR_SCATTER, k_hdr_scatter, dim3((unsigned)h->ntiles), dim3(BLOCK), h->d_data, h->n,
-                               h->prev_byte, h->tile_hdr.p, h->tile_hdr_off.p, h->base, h->hdr.p);
+                               h->prev_byte, h->tile_hdr.p, h->grp_off.p + (ngroups + 1), h->base, h->hdr.p);
         h->scanned_hdr = true;
     }
     HIPCHK(hipGetLastError());
@@ -483,7 +486,7 @@ extern "C" int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out
     c.bad = h->fa_bad.p;
     FX_LAUNCH(h, K_FASTA_REC, k_fasta_rec, dim3(nblocks(nh, BLOCK)), dim3(BLOCK), h->d_data, h->base, h->n, h->nl.p,
                        h->n_nl, h->hdr.p, nh, full_name, c);
-    const unsigned lb = (unsigned)std::min<int64_t>(nblocks(h->n_nl, BLOCK), 256 * 8);
+    const unsigned lb = nblocks(h->n_nl, LINES_PER_WAVE * (BLOCK / 64));
     FX_LAUNCH(h, K_FASTA_LINES, k_fasta_lines, dim3(lb), dim3(BLOCK), h->nl.p, h->n_nl, h->fa_hdr_line.p, nh,
                        h->fa_llen.p, h->fa_bad.p);
     FX_LAUNCH(h, K_FASTA_FINALIZE, k_fasta_finalize, dim3(nblocks(nh, BLOCK)), dim3(BLOCK), h->fa_bad.p,
@@ -659,6 +662,7 @@ static int fetch_common(fx_handle *h, int where, int64_t n, bool by_id, const in
     Staged st;
     FetchQ q;
     memset(&q, 0, sizeof q);
+    const int64_t *host_blen = (where == FX_HOST && !by_id) ? a1 : nullptr;
     uint8_t *d_dst = dst;
     int64_t *d_len = out_len;
     int64_t total = dst_bytes_hint;
@@ -688,10 +692,19 @@ static int fetch_common(fx_handle *h, int where, int64_t n, bool by_id, const in
         tab.boff = h->fa_boff.p; tab.blen = h->fa_blen.p; tab.slen = h->fa_slen.p; tab.llen = h->fa_llen.p;
         tab.elen = h->fa_elen.p; tab.norm = h->fa_norm.p; tab.n_seq = h->n_hdr;
     }
-    if (by_id)
-        FX_LAUNCH(h, K_FETCH, (k_fetch<true>), dim3(fetch_grid(n)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
-    else
-        FX_LAUNCH(h, K_FETCH, (k_fetch<false>), dim3(fetch_grid(n)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
+    // lanes per query: 16 (128-byte window, 4 queries per wave) for short random access,
+    // 64 (1 KiB window) when the caller says the ranges are long (FX_LONG) or host arrays show it
+    bool longq = (flags & 16) != 0;
+    if (where == FX_HOST && !by_id && host_blen) {
+        double sum = 0;
+        for (int64_t i = 0; i < n; ++i) sum += (double)host_blen[i];
+        longq = longq || sum / (double)n > 512.0;
+    }
+    const unsigned grid = longq ? fetch_grid(n) : fetch_grid((n + 3) / 4);
+    if (by_id && !longq)       FX_LAUNCH(h, K_FETCH, (k_fetch<true, 16, 8>), dim3(grid), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
+    else if (by_id)            FX_LAUNCH(h, K_FETCH, (k_fetch<true, 64, 16>), dim3(grid), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
+    else if (!longq)           FX_LAUNCH(h, K_FETCH, (k_fetch<false, 16, 8>), dim3(grid), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
+    else                       FX_LAUNCH(h, K_FETCH, (k_fetch<false, 64, 16>), dim3(grid), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
     HIPCHK(hipGetLastError());
     if (where == FX_HOST) {
         HIPCHK(hipMemcpyAsync(dst, d_dst, (size_t)total, hipMemcpyDeviceToHost, h->stream));
