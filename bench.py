@@ -111,11 +111,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    backend = os.environ.get("FX_BENCH_BACKEND", "nccl")    # "nccl" IS RCCL on ROCm; "gloo" only for the 1-GPU plumbing test
+    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)    # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # ---------------- workload: piece `rank` of the concatenated stream, resident in HBM
     total_bp = int(a.gbp * 1e9)
@@ -159,7 +164,7 @@ def main():
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0, t_index], dtype=torch.float64, device=dev)
+    elapsed = torch.tensor([t1 - t0, t_index], dtype=torch.float64, device=job.comm_dev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     el, ti = float(elapsed[0]), float(elapsed[1])

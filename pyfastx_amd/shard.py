@@ -159,23 +159,28 @@ class ShardedFasta:
         from . import _lib
         self.rank, self.world, self.dev, self.full_name = rank, world, dev, full_name
         self._torch, self._dist = torch, dist
+        self.comm_dev = dev
         if world == 1:
             self.buf, self.n_bytes, self.base, prev, last = piece, nbytes, 0, 10, True
         else:
             d = self.DELTA
-            sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-            mine = torch.tensor([nbytes], dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(sizes, mine)
-            sizes = sizes.cpu().numpy()
-            head = piece[:d].clone()
-            tail_in = torch.empty(d, dtype=torch.uint8, device=dev)
+            # collectives run on the GPU tensors with RCCL ("nccl"); with gloo (tests) on host copies
+            cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+            self.comm_dev = cdev
+            mine = torch.tensor([nbytes], dtype=torch.int64, device=cdev)
+            outs = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(outs, mine)
+            sizes = np.array([int(o.item()) for o in outs], dtype=np.int64)
+            head = piece[:d].to(cdev).clone()
+            tail_c = torch.empty(d, dtype=torch.uint8, device=cdev)
             ops = []
             if rank > 0:
                 ops.append(dist.P2POp(dist.isend, head, rank - 1))
             if rank < world - 1:
-                ops.append(dist.P2POp(dist.irecv, tail_in, rank + 1))
+                ops.append(dist.P2POp(dist.irecv, tail_c, rank + 1))
             for w in dist.batch_isend_irecv(ops) if ops else []:
                 w.wait()
+            tail_in = tail_c.to(dev)
             lo = d if rank > 0 else 0
             hi_extra = d if rank < world - 1 else 0
             n = nbytes - lo + hi_extra
@@ -199,7 +204,7 @@ class ShardedFasta:
         self.n_local = s.n_seq
         if self.world == 1:
             return s
-        self.S = allgather_summaries(self.blob.shard_summary(), self.world, self.dev)   # the ONE collective (RCCL)
+        self.S = allgather_summaries(self.blob.shard_summary(), self.world, self.comm_dev)   # the ONE collective (RCCL)
         row = stitch_tail(self.S, self.rank, self.full_name)
         if row is not None:
             self.blob.fasta_set_row(self.n_local - 1, **row)
