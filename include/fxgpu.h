@@ -171,6 +171,17 @@ int fx_read_fetch(fx_handle *h, int where, int64_t n, const int64_t *soff, const
  * (module.c:44-59; util.c:239-269).  mode: FX_REVERSE | FX_COMPLEMENT.        */
 int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mode);
 
+/* ------------------------------------------------------------ gzip inputs
+ * fx_open_file inflates BGZF (bgzip) inputs on the GPU, one work-item per
+ * member; other gzip files are inflated by zlib on the host (a single deflate
+ * stream is serial).  fx_gz_points lists restart points for the .fxi `gzindex`
+ * table (pyfastx_build_gzip_index / pyfastx_gzip_index_export, util.c:442-540,
+ * 728-742): for BGZF, member boundaries about `spacing` uncompressed bytes apart
+ * (bit offset 0, no 32 KiB window needed).  Call with cap = 0 to get the count.
+ * Non-BGZF inputs report 0 points.                                            */
+int fx_gz_points(fx_handle *h, int64_t spacing, int64_t *cmp_off, int64_t *uncmp_off, int64_t cap,
+                 int64_t *n_out, int64_t *compressed_size);
+
 /* ------------------------------------------------------- sync and timing
  * Calls that take FX_DEVICE arrays return after ENQUEUEING work on the
  * handle's stream; fx_sync waits for it.  (FX_HOST calls are synchronous.)   */
@@ -180,6 +191,7 @@ int fx_sync(fx_handle *h);
  * (what bench.py's roofline leg reads).  Kernel ids 0..fx_prof_count()-1,
  * names from fx_prof_name (they match the rocprofv3 kernel names).           */
 int fx_prof_enable(fx_handle *h, int on);
+int fx_prof_default(int on);   /* handles opened afterwards start with timing on (covers k_bgzf_inflate in fx_open_file) */
 int fx_prof_reset(fx_handle *h);
 int fx_prof_count(void);
 const char *fx_prof_name(int id);

@@ -43,7 +43,7 @@ SYMBOLS = [
     "fx_set_shard", "fx_close", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
     "fx_fasta_build", "fx_fasta_table", "fx_fasta_comp", "fx_fastq_build", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fasta_fetch", "fx_fastq_fetch", "fx_revcomp", "fx_shard_summary_get",
-    "fx_fasta_set_row", "fx_read_fetch", "fx_sync", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
+    "fx_fasta_set_row", "fx_read_fetch", "fx_gz_points", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
 ]
 
 
@@ -94,8 +94,10 @@ def lib():
     L.fx_read_fetch.argtypes = [vp, i32, i64, vp, vp, vp, i32, i32, vp, vp, vp, vp]
     L.fx_shard_summary_get.argtypes = [vp, C.POINTER(ShardSummary)]
     L.fx_fasta_set_row.argtypes = [vp, i64, i64, i64, i64, i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.fx_gz_points.argtypes = [vp, i64, vp, vp, i64, C.POINTER(i64), C.POINTER(i64)]
     L.fx_sync.argtypes = [vp]
     L.fx_prof_enable.argtypes = [vp, i32]
+    L.fx_prof_default.argtypes = [i32]
     L.fx_prof_reset.argtypes = [vp]
     L.fx_prof_name.restype = C.c_char_p
     L.fx_prof_name.argtypes = [i32]
@@ -181,6 +183,16 @@ class Blob:
         v = C.c_int(-1)
         check(lib().fx_first_byte(self._h, C.byref(v)))
         return v.value
+
+    def gz_points(self, spacing=1048576):
+        """-> (cmp_off int64[], uncmp_off int64[], compressed_size) restart points for the gzindex table."""
+        n, cs = C.c_int64(0), C.c_int64(0)
+        check(lib().fx_gz_points(self._h, spacing, None, None, 0, C.byref(n), C.byref(cs)))
+        a = np.zeros(n.value, dtype=np.int64)
+        b = np.zeros(n.value, dtype=np.int64)
+        if n.value:
+            check(lib().fx_gz_points(self._h, spacing, a.ctypes.data, b.ctypes.data, n.value, C.byref(n), C.byref(cs)))
+        return a, b, cs.value
 
     def sync(self):
         check(lib().fx_sync(self._h))

@@ -148,7 +148,8 @@ class Fasta:
         self._db = fxi.connect(self._index_file)
         fxi.write_fasta(self._db, names, t, s.seq_len)
         if self.is_gzip:
-            fxi.write_gzindex_header(self._db, os.path.getsize(self.file_name), blob.size)
+            c, u, _ = blob.gz_points()
+            fxi.write_gzindex(self._db, os.path.getsize(self.file_name), blob.size, c, u)
 
     def _gather(self, off, length):
         """Raw byte spans of the resident stream as a list of str (one batched GPU gather)."""
@@ -647,7 +648,8 @@ class Fastq:
         self._db = fxi.connect(self._index_file)
         fxi.write_fastq(self._db, names, t, s.size)
         if self.is_gzip:
-            fxi.write_gzindex_header(self._db, os.path.getsize(self.file_name), blob.size)
+            c, u, _ = blob.gz_points()
+            fxi.write_gzindex(self._db, os.path.getsize(self.file_name), blob.size, c, u)
         self._counts, self.size = int(s.n_reads), int(s.size)
         self.avglen = self.size * 1.0 / self._counts if self._counts else float("nan")
 

@@ -19,6 +19,7 @@
 
 #include "../../include/fxgpu.h"
 #include "fx_kernels.hpp"
+#include "fx_inflate.hpp"
 
 using namespace fx;
 
@@ -71,10 +72,10 @@ template <class T> struct DevBuf {      // grow-only device array: rebuilds reus
 // Optional per-kernel HIP-event timing on the handle's own stream (bench.py's
 // roofline leg reads it; off by default so the hot path records no events).
 enum KernelId { K_SCAN = 0, K_TILE_SCAN, K_LINETABLE, K_HDR_SCATTER, K_FASTA_REC, K_FASTA_LINES, K_FASTA_FINALIZE,
-                K_FETCH, K_FASTA_COMP, K_FASTQ_REC, K_FASTQ_COMP, K_FASTQ_FETCH, K_NKERN };
+                K_FETCH, K_FASTA_COMP, K_FASTQ_REC, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_NKERN };
 static const char *const kKernelNames[K_NKERN] = {
     "k_scan", "k_group_scan", "k_linetable", "k_hdr_scatter", "k_fasta_rec", "k_fasta_lines", "k_fasta_finalize",
-    "k_fetch", "k_fasta_comp", "k_fastq_rec", "k_fastq_comp", "k_fastq_fetch"};
+    "k_fetch", "k_fasta_comp", "k_fastq_rec", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_inflate"};
 
 struct Prof {
     bool on = false;
@@ -149,8 +150,14 @@ struct fx_handle {
     int64_t n_reads = 0, fq_size = 0;
     long long fq_maxlen = 0, fq_minlen = 0;
     bool fastq_built = false;
+    // BGZF member table (compressed offset of each member, offset of its data in the inflated stream)
+    std::vector<int64_t> gz_moff, gz_uoff;
+    int64_t gz_csize = 0;
+    bool bgzf = false;
     Prof prof;
 };
+
+static bool g_prof_default = false;       // fx_prof_default(): handles are created with timing on (covers staging kernels)
 
 static int use_device(const fx_handle *h) {
     HIPCHK(hipSetDevice(h->device));
@@ -165,6 +172,7 @@ static int new_handle(int device, fx_handle **out) {
     HIPCHK(hipSetDevice(device));
     fx_handle *h = new fx_handle();
     h->device = device;
+    h->prof.on = g_prof_default;
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(FX_EDEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
     *out = h;
@@ -249,6 +257,78 @@ static void parallel_pread(int fd, uint8_t *dst, int64_t off, int64_t len, std::
     for (auto &x : th) x.join();
 }
 
+static inline unsigned nblocks(int64_t n, int per) { return (unsigned)std::max<int64_t>(1, (n + per - 1) / per); }
+
+// ------------------------------------------------------------------- BGZF
+// Member walk (SAM spec 4.1): gzip header with FEXTRA and a 'B','C' subfield whose
+// value is BSIZE = total member size - 1; trailer = CRC32, ISIZE.
+struct BgzfTable { std::vector<int64_t> moff, coff, uoff; std::vector<int32_t> clen, isize; int64_t total = 0; };
+
+static bool parse_bgzf(const uint8_t *f, int64_t n, BgzfTable &t) {
+    int64_t p = 0;
+    while (p < n) {
+        if (p + 18 > n || f[p] != 0x1f || f[p + 1] != 0x8b || f[p + 2] != 8) return false;
+        const int flg = f[p + 3];
+        if (!(flg & 4) || (flg & ~4)) return false;          // FEXTRA only (what bgzip writes)
+        const int xlen = f[p + 10] | (f[p + 11] << 8);
+        if (p + 12 + xlen > n) return false;
+        int64_t bsize = -1;
+        for (int64_t q = p + 12; q + 4 <= p + 12 + xlen;) {
+            const int slen = f[q + 2] | (f[q + 3] << 8);
+            if (f[q] == 'B' && f[q + 1] == 'C' && slen == 2 && q + 6 <= p + 12 + xlen) bsize = f[q + 4] | (f[q + 5] << 8);
+            q += 4 + slen;
+        }
+        if (bsize < 0) return false;
+        const int64_t msize = bsize + 1, hlen = 12 + xlen;
+        if (p + msize > n || msize < hlen + 8) return false;
+        const uint8_t *tr = f + p + msize - 8;
+        const uint32_t isz = tr[4] | (tr[5] << 8) | (tr[6] << 16) | ((uint32_t)tr[7] << 24);
+        if (isz > 65536) return false;
+        t.moff.push_back(p); t.coff.push_back(p + hlen); t.clen.push_back((int32_t)(msize - hlen - 8));
+        t.uoff.push_back(t.total); t.isize.push_back((int32_t)isz);
+        t.total += isz;
+        p += msize;
+    }
+    return !t.moff.empty();
+}
+
+template <class T> static int upload(fx_handle *h, DevBuf<T> &d, const std::vector<T> &v) {
+    int rc = d.alloc((int64_t)v.size());
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    return FX_OK;
+}
+
+// compressed bytes (host, pinned) -> HBM -> k_bgzf_inflate -> resident blob
+static int bgzf_to_blob(fx_handle *h, const uint8_t *file, int64_t fsize, const BgzfTable &t, const char *path) {
+    DevBuf<uint8_t> d_c;
+    DevBuf<int64_t> d_coff, d_uoff;
+    DevBuf<int32_t> d_clen, d_isize, d_status;
+    int rc;
+    if ((rc = d_c.alloc(fsize + 16))) return rc;
+    HIPCHK(hipMemcpyAsync(d_c.p, file, (size_t)fsize, hipMemcpyHostToDevice, h->stream));
+    if ((rc = upload(h, d_coff, t.coff)) || (rc = upload(h, d_uoff, t.uoff)) || (rc = upload(h, d_clen, t.clen)) ||
+        (rc = upload(h, d_isize, t.isize)))
+        return rc;
+    const int64_t nmem = (int64_t)t.moff.size();
+    if ((rc = d_status.alloc(nmem))) return rc;
+    HIPCHK(hipMemsetAsync(d_status.p, 0xFF, (size_t)nmem * 4, h->stream));
+    if ((rc = alloc_blob(h, t.total))) return rc;
+    FX_LAUNCH(h, K_BGZF_INFLATE, k_bgzf_inflate, dim3(nblocks(nmem, INFL_BLOCK)), dim3(INFL_BLOCK), d_c.p, d_coff.p,
+              d_clen.p, d_uoff.p, d_isize.p, nmem, h->d_data, d_status.p);
+    HIPCHK(hipGetLastError());
+    std::vector<int32_t> status((size_t)nmem);
+    HIPCHK(hipMemcpyAsync(status.data(), d_status.p, (size_t)nmem * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int64_t m = 0; m < nmem; ++m)
+        if (status[m] != INFL_OK)
+            return fail(FX_EIO, "BGZF member %lld of %s (offset %lld) failed to inflate: code %d", (long long)m, path,
+                        (long long)t.moff[m], status[m]);
+    h->bgzf = true;
+    h->gz_moff = t.moff; h->gz_uoff = t.uoff; h->gz_csize = fsize;
+    return FX_OK;
+}
+
 extern "C" int fx_open_file(const char *path, int device, fx_handle **out) {
     if (!path || !out) return fail(FX_EINVAL, "null argument");
     struct stat st;
@@ -286,6 +366,22 @@ extern "C" int fx_open_file(const char *path, int device, fx_handle **out) {
             st_.used[slot] = true;
         }
     } else {
+        // BGZF (bgzip): every member inflates independently -> GPU (k_bgzf_inflate)
+        {
+            const int64_t fsize = (int64_t)st.st_size;
+            uint8_t *host = nullptr;
+            hipError_t he = hipHostMalloc((void **)&host, (size_t)fsize + 16, hipHostMallocDefault);
+            if (he != hipSuccess) return bail(fail(FX_ENOMEM, "hipHostMalloc(%lld): %s", (long long)fsize, hipGetErrorString(he)));
+            std::atomic<int> err(0);
+            parallel_pread(fd, host, 0, fsize, &err);
+            BgzfTable tab;
+            int brc = 1;
+            if (!err.load() && parse_bgzf(host, fsize, tab)) brc = bgzf_to_blob(h, host, fsize, tab, path);
+            (void)hipHostFree(host);
+            if (brc == FX_OK) { close(fd); *out = h; return FX_OK; }
+            if (brc < 0) return bail(brc);
+            // brc == 1: not BGZF -> fall through to the single-stream path
+        }
         // single-stream gzip: inflate is inherently serial (zlib on the host), the
         // inflated bytes stream through the same pinned ring into a growing blob.
         gzFile g = gzdopen(dup(fd), "rb");
@@ -401,7 +497,6 @@ extern "C" int fx_first_byte(fx_handle *h, int *out) {
 }
 
 // -------------------------------------------------------------------- scan
-static inline unsigned nblocks(int64_t n, int per) { return (unsigned)std::max<int64_t>(1, (n + per - 1) / per); }
 
 static int run_scan(fx_handle *h, bool want_hdr) {
     // never cached: every build re-reads the stream (a build call is the whole job)
@@ -844,6 +939,24 @@ extern "C" int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mo
     return FX_OK;
 }
 
+extern "C" int fx_gz_points(fx_handle *h, int64_t spacing, int64_t *cmp_off, int64_t *uncmp_off, int64_t cap,
+                            int64_t *n_out, int64_t *compressed_size) {
+    if (!h || !n_out) return fail(FX_EINVAL, "null argument");
+    if (compressed_size) *compressed_size = h->gz_csize;
+    int64_t n = 0, next = 0;
+    if (h->bgzf) {
+        if (spacing <= 0) spacing = 1048576;                 // zran spacing used by the reference (index.c:70)
+        for (size_t m = 0; m < h->gz_moff.size(); ++m) {
+            if (h->gz_uoff[m] < next && m != 0) continue;
+            if (cmp_off && uncmp_off && n < cap) { cmp_off[n] = h->gz_moff[m]; uncmp_off[n] = h->gz_uoff[m]; }
+            ++n;
+            next = h->gz_uoff[m] + spacing;
+        }
+    }
+    *n_out = n;
+    return FX_OK;
+}
+
 extern "C" int fx_sync(fx_handle *h) {
     if (!h) return fail(FX_EINVAL, "null handle");
     int rc = use_device(h);
@@ -860,6 +973,8 @@ extern "C" int fx_prof_enable(fx_handle *h, int on) {
     h->prof.on = on != 0;
     return FX_OK;
 }
+
+extern "C" int fx_prof_default(int on) { g_prof_default = on != 0; return FX_OK; }
 
 extern "C" int fx_prof_reset(fx_handle *h) {
     if (!h) return fail(FX_EINVAL, "null handle");

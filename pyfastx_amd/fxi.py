@@ -145,14 +145,21 @@ def write_fastq_comp(db, base, meta):
     db.execute("INSERT INTO meta VALUES (?,?,?,?,?)", tuple(int(x) for x in meta))
 
 
-def write_gzindex_header(db, compressed_size, uncompressed_size, spacing=1048576, window=32768):
-    """The eight scalar rows of util.c:461-489 with npoints = 0: a syntactically valid
-    zran export that lets the reader rebuild its checkpoints on demand (ZRAN_AUTO_BUILD,
-    index.c:70).  Checkpoint windows are not produced here (parity unpinned)."""
+def write_gzindex(db, compressed_size, uncompressed_size, cmp_off=(), uncmp_off=(), spacing=1048576, window=32768):
+    """zran export layout of util.c:461-529: "GZIDX", version 1, flags, compressed_size,
+    uncompressed_size, spacing, window_size, npoints, then per point cmp_offset (u64),
+    uncmp_offset (u64), bits (u8), has-data flag (u8); one window row per point with data.
+    BGZF restart points sit on member boundaries: bits = 0 and no 32 KiB window is needed
+    (has-data = 0, which version-1 importers accept, util.c:621-651).  For single-stream gzip
+    no points are written (npoints = 0): the reader rebuilds them on demand (ZRAN_AUTO_BUILD,
+    index.c:70).  Checkpoint placement is not asserted by any reference test ("parity
+    unpinned", DESIGN.md)."""
     db.execute("BEGIN TRANSACTION")
     rows = [b"GZIDX", struct.pack("<B", 1), struct.pack("<B", 0), struct.pack("<Q", compressed_size),
             struct.pack("<Q", uncompressed_size), struct.pack("<I", spacing), struct.pack("<I", window),
-            struct.pack("<I", 0)]
+            struct.pack("<I", len(cmp_off))]
+    for c, u in zip(cmp_off, uncmp_off):
+        rows += [struct.pack("<Q", int(c)), struct.pack("<Q", int(u)), struct.pack("<B", 0), struct.pack("<B", 0)]
     db.executemany("INSERT INTO gzindex VALUES (NULL,?)", [(sqlite3.Binary(r),) for r in rows])
     db.execute("COMMIT")
 

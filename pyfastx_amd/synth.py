@@ -146,3 +146,67 @@ def expected_fetch(flat, flat_start, ids, start, qlen, strand, device):
     neg = torch.from_numpy(strand.astype(bool)).to(device)
     rc = comp[out.long()].flip(1)
     return torch.where(neg[:, None], rc, out)
+
+
+# --------------------------------------------------------------------------- C3: FASTQ
+def fastq_generate(n_reads, device, rlen=150, seed=7):
+    """Fixed-shape synthetic FASTQ in HBM: `@SYN:1:FC:1:<tile4>:<x5>:<i9> 1:N:0:ACGT` headers (unique
+    names, one space), rlen bases i.i.d. ACGT with 0.1 % N, '+', qualities uniform 35..70, LF.
+    -> (blob uint8, dict of analytic columns as numpy int64)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    head = b"@SYN:1:FC:1:0000:00000:000000000 1:N:0:ACGT\n"
+    hl = len(head)
+    rec = hl + rlen + 1 + 2 + rlen + 1
+    t = torch.empty((n_reads, rec), dtype=torch.uint8, device=device)
+    t[:, :hl] = torch.frombuffer(bytearray(head), dtype=torch.uint8).to(device)
+    idx = torch.arange(n_reads, device=device, dtype=torch.int64)
+    for k in range(9):                                   # <i9>
+        t[:, 31 - k] = (48 + (idx // (10 ** k)) % 10).to(torch.uint8)
+    tile = (idx // 50_000) % 10_000
+    for k in range(4):
+        t[:, 15 - k] = (48 + (tile // (10 ** k)) % 10).to(torch.uint8)
+    x = (idx * 7919) % 100_000
+    for k in range(5):
+        t[:, 21 - k] = (48 + (x // (10 ** k)) % 10).to(torch.uint8)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    step = 1 << 20
+    for a in range(0, n_reads, step):
+        b = min(n_reads, a + step)
+        r = torch.randint(0, 4000, (b - a, rlen), device=device, generator=g)
+        bases = lut[(r & 3).long()]
+        bases[r >= 3996] = ord("N")
+        t[a:b, hl:hl + rlen] = bases
+        t[a:b, hl + rlen + 3:hl + 2 * rlen + 3] = torch.randint(35, 71, (b - a, rlen), device=device, generator=g,
+                                                                dtype=torch.uint8)
+    t[:, hl + rlen] = 10
+    t[:, hl + rlen + 1] = ord("+")
+    t[:, hl + rlen + 2] = 10
+    t[:, rec - 1] = 10
+    n_bytes = n_reads * rec
+    blob = torch.zeros(n_bytes + 131072, dtype=torch.uint8, device=device)
+    blob[:n_bytes] = t.view(-1)
+    i = np.arange(n_reads, dtype=np.int64)
+    cols = {"name_off": i * rec + 1, "name_len": np.full(n_reads, 31, np.int64), "dlen": np.full(n_reads, hl - 1, np.int64),
+            "rlen": np.full(n_reads, rlen, np.int64), "soff": i * rec + hl, "qoff": i * rec + hl + rlen + 3,
+            "n_bytes": n_bytes, "rec": rec}
+    return blob, cols
+
+
+# --------------------------------------------------------------------------- C4: BGZF framing
+def bgzf_compress(raw, block=65280, level=6):
+    """bgzip-compatible framing of `raw` (SAM spec 4.1): independent raw-deflate members of
+    <= `block` input bytes, 18-byte header with the 'BC' BSIZE subfield, CRC32 + ISIZE trailer,
+    and the 28-byte empty EOF member.  (No bgzip binary is needed.)"""
+    import struct
+    import zlib
+    out = []
+    for a in list(range(0, len(raw), block)) + [None]:
+        chunk = b"" if a is None else raw[a:a + block]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        cd = co.compress(chunk) + co.flush()
+        bsize = len(cd) + 25
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + cd +
+                   struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    return b"".join(out)

@@ -141,3 +141,45 @@ def test_stitch_random(oracle, seed):
         for _ in range(10):
             cuts = sorted(set(int(x) for x in rng.integers(1, len(raw), g - 1)))
             assert shard_ref.stitched_rows(raw, cuts) == want, (seed, cuts)
+
+
+def test_reference_opens_our_gz_fxi(oracle, tmp_path):
+    """The .fxi contract in the other direction: an index written by fxi.py for a gzip input --
+    including BGZF-style gzindex points without windows -- is accepted by the REAL reference's
+    loader (pyfastx_load_index + pyfastx_gzip_index_import, index.c:391-416, util.c:542-726).
+    Runs only where oracle/_ref was built (needs /root/reference at build time)."""
+    import glob
+    import shutil
+    import sys
+    from conftest import ROOT
+    if not glob.glob(os.path.join(ROOT, "oracle", "_ref", "pyfastx*.so")):
+        pytest.skip("oracle/_ref not built here")
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
+    import pyfastx
+    from pyfastx_amd import fxi, synth
+    raw = fixture_bytes("test.fa")
+    for name, payload, pts in (("plain.fa", raw, None),
+                               ("bgzf.fa.gz", synth.bgzf_compress(raw, block=8000), "bgzf")):
+        p = str(tmp_path / name)
+        open(p, "wb").write(payload)
+        recs, tot = oracle.fasta_index(raw)
+        names = [raw[r["name_off"]:r["name_off"] + r["name_len"]].decode() for r in recs]
+        db = fxi.connect(p + ".fxi")
+        fxi.write_fasta(db, names, {k: recs[k] for k in ("boff", "blen", "slen", "llen", "elen", "norm", "dlen")}, tot)
+        if pts:
+            # member starts as restart points, as fx_gz_points reports them
+            offs, uoffs, q, u = [], [], 0, 0
+            while q < len(payload):
+                bsize = payload[q + 16] | (payload[q + 17] << 8)
+                isz = int.from_bytes(payload[q + bsize - 3:q + bsize + 1], "little")
+                offs.append(q); uoffs.append(u)
+                q += bsize + 1; u += isz
+            fxi.write_gzindex(db, len(payload), len(raw), offs[::4], uoffs[::4])
+        db.close()
+        fa = pyfastx.Fasta(p)                               # loads OUR index, builds nothing
+        assert len(fa) == 211 and fa.size == 86262
+        g = load_golden("fasta_fixture")["test.fa"]
+        for f in g["fetches"][:40]:
+            assert fa[f["id"] - 1][f["start"]:f["stop"]].seq == f["seq"]
+        assert fa[0].name == "JZ822577.1" and fa.fetch("JZ822578.1", (1, 10)) == g["records"]["2"]["seq"][:10]
+        del fa

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""C3-shaped FASTQ at scale on one MI355X: index build, composition, 1 M read fetches
+(seq + qual + int8 quali), verified against the generator's analytic truth / torch.
+usage: python tools/fastq_scale.py [n_reads]   (default 10 M reads = 3.5 GB)"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pyfastx_amd import _lib, synth  # noqa: E402
+
+
+def main():
+    n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
+    dev = torch.device("cuda", 0)
+    blob_t, cols = synth.fastq_generate(n, dev)
+    nb = cols["n_bytes"]
+    b = _lib.Blob.from_device(blob_t.data_ptr(), nb, device=0, keepalive=blob_t)
+    b.fastq_build(); b.fastq_comp()                       # warm-up (allocations)
+    b.prof_enable(True); b.prof_reset()
+    R = 5
+    t0 = time.perf_counter()
+    for _ in range(R):
+        s = b.fastq_build()
+    t1 = time.perf_counter()
+    for _ in range(R):
+        base, meta = b.fastq_comp()
+    t2 = time.perf_counter()
+    assert (s.n_reads, s.size) == (n, n * 150)
+    t = b.fastq_table(n)
+    for k in ("name_off", "name_len", "dlen", "rlen", "soff", "qoff"):
+        assert (t[k] == cols[k]).all(), k
+    rec = cols["rec"]
+    v = blob_t[:nb].view(n, rec)
+    so, qo = int(cols["soff"][0]), int(cols["qoff"][0])
+    seqs = v[:, so:so + 150]
+    want = [int((seqs == c).sum()) for c in b"ACGT"]
+    want.append(n * 150 - sum(want))
+    assert base.tolist() == want, (base.tolist(), want)
+    q = v[:, qo:qo + 150]
+    assert meta.tolist() == [150, 150, int(q.min()), int(q.max()), 33], meta.tolist()
+    # 1 M random read fetches on device
+    nq = 1_000_000
+    rng = np.random.default_rng(99)
+    ids = torch.from_numpy(rng.integers(0, n, nq)).to(dev)
+    off = torch.arange(nq, device=dev, dtype=torch.int64) * 150
+    o_seq = torch.zeros(nq * 150, dtype=torch.uint8, device=dev); o_q = torch.zeros_like(o_seq)
+    o_qi = torch.zeros(nq * 150, dtype=torch.int8, device=dev)
+    L = _lib.lib()
+    def fetch():
+        _lib.check(L.fx_fastq_fetch(b._h, _lib.FX_DEVICE, nq, ids.data_ptr(), 33, 0, o_seq.data_ptr(), o_q.data_ptr(),
+                                    o_qi.data_ptr(), off.data_ptr()))
+        b.sync()
+    fetch()
+    t3 = time.perf_counter()
+    for _ in range(R):
+        fetch()
+    t4 = time.perf_counter()
+    assert bool((o_seq.view(nq, 150) == seqs[ids]).all()) and bool((o_q.view(nq, 150) == q[ids]).all())
+    assert bool((o_qi.view(nq, 150) == (q[ids].to(torch.int16) - 33).to(torch.int8)).all())
+    prof = {k: round(v[0] / v[1], 4) for k, v in b.prof_read().items()}
+    print(json.dumps({"workload": "synthetic FASTQ %d x 150 bp (%.2f GB)" % (n, nb / 1e9), "index_build_ms": round((t1 - t0) / R * 1e3, 3),
+                      "index_build_GBps": round(nb / ((t1 - t0) / R) / 1e9, 1), "composition_ms": round((t2 - t1) / R * 1e3, 3),
+                      "fetch_1M_reads_ms": round((t4 - t3) / R * 1e3, 3), "M_reads_per_s": round(nq / ((t4 - t3) / R) / 1e6, 1),
+                      "kernels_ms_avg": prof, "verified": True}))
+
+
+if __name__ == "__main__":
+    main()
