@@ -190,7 +190,7 @@ int fx_sync(fx_handle *h);
 /* Optional per-kernel timing with HIP events on the handle's own stream
  * (what bench.py's roofline leg reads).  Kernel ids 0..fx_prof_count()-1,
  * names from fx_prof_name (they match the rocprofv3 kernel names).           */
-int fx_prof_enable(fx_handle *h, int on);
+int fx_prof_enable(fx_handle *h, int on);      /* 0 off, 1 every kernel, 2 only k_scan (2 events per build) */
 int fx_prof_default(int on);   /* handles opened afterwards start with timing on (covers k_bgzf_inflate in fx_open_file) */
 int fx_prof_reset(fx_handle *h);
 int fx_prof_count(void);

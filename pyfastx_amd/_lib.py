@@ -197,7 +197,8 @@ class Blob:
     def sync(self):
         check(lib().fx_sync(self._h))
 
-    def prof_enable(self, on=True):
+    def prof_enable(self, on=1):
+        """0 off, 1 every kernel, 2 only k_scan."""
         check(lib().fx_prof_enable(self._h, int(on)))
 
     def prof_reset(self):

@@ -263,7 +263,7 @@ __device__ __forceinline__ int64_t tile_prefix(const uint32_t *__restrict__ tile
 __global__ __launch_bounds__(BLOCK) void k_linetable(const uint16_t *__restrict__ nlmask,
                                                     const uint32_t *__restrict__ tile_nl,
                                                     const int64_t *__restrict__ grp_off, int64_t gbase,
-                                                    int64_t *__restrict__ nl) {
+                                                    int64_t *__restrict__ nl, int64_t cap) {
     __shared__ uint32_t lds4[4];
     const int64_t tile = blockIdx.x;
     const int tid = threadIdx.x;
@@ -275,7 +275,9 @@ __global__ __launch_bounds__(BLOCK) void k_linetable(const uint16_t *__restrict_
     uint32_t total;
     uint32_t r = block_excl_scan(cnt, lds4, &total);
     if (cnt == 0) return;
-    int64_t *dst = nl + tbase_rank + r;
+    // `cap`: the table is allocated from an estimate before the host knows the total (it learns it
+    // while this kernel runs); ranks beyond it are dropped and the host re-runs with the exact size
+    int64_t rk = tbase_rank + r;
     const int64_t p0 = gbase + tile * (int64_t)TILE + (int64_t)tid * 8 * CHUNK;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -283,7 +285,8 @@ __global__ __launch_bounds__(BLOCK) void k_linetable(const uint16_t *__restrict_
         while (m) {
             const int k = __ffs(m) - 1;
             m &= m - 1;
-            *dst++ = p0 + q * 32 + k;
+            if (rk < cap) nl[rk] = p0 + q * 32 + k;
+            ++rk;
         }
     }
 }
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(BLOCK) void k_linetable(const uint16_t *__restrict_
 __global__ __launch_bounds__(BLOCK) void k_hdr_scatter(const uint8_t *__restrict__ data, int64_t n, int prev_byte,
                                                       const uint32_t *__restrict__ tile_hdr,
                                                       const int64_t *__restrict__ grp_off, int64_t gbase,
-                                                      int64_t *__restrict__ hdr) {
+                                                      int64_t *__restrict__ hdr, int64_t cap) {
     __shared__ uint32_t lds4[4];
     const int64_t tile = blockIdx.x;
     if (tile_hdr[tile] == 0) return;
@@ -318,11 +321,14 @@ __global__ __launch_bounds__(BLOCK) void k_hdr_scatter(const uint8_t *__restrict
         while (hm) {
             const int k = __ffs(hm) - 1;
             hm &= hm - 1;
-            hdr[run + r++] = gbase + p + k;
+            if (run + r < cap) hdr[run + r] = gbase + p + k;
+            ++r;
         }
         run += total;
     }
 }
+
+__global__ void k_set_i64(int64_t *p, int64_t v) { *p = v; }
 
 // ======================================================================= K5
 // FASTA record table: one thread per header.  Everything is a gather from the
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(BLOCK) void k_fasta_rec(const uint8_t *__restrict__
 // A window that crosses a record boundary takes the per-lane search path.  Bad
 // lines are rare in well-formed files (the short last line of each record), so
 // counts are kept per lane and flushed with one atomic per (wave, record).
-constexpr int LINES_PER_WAVE = 64 * 64;
+constexpr int LINES_PER_WAVE = 128 * 32;                         // 32 windows of 128 lines (2 per lane)
 __global__ __launch_bounds__(BLOCK) void k_fasta_lines(const int64_t *__restrict__ nl, int64_t n_nl,
                                                       const int64_t *__restrict__ hdr_line, int64_t n_hdr,
                                                       const int64_t *__restrict__ llen, uint32_t *__restrict__ bad) {
@@ -405,20 +411,30 @@ __global__ __launch_bounds__(BLOCK) void k_fasta_lines(const int64_t *__restrict
     int64_t next_hl = (rec + 1 < n_hdr) ? hdr_line[rec + 1] : n_nl;
     int64_t ll = rec >= 0 ? llen[rec] : 0;
     uint32_t cnt = 0;
-    for (int64_t i0 = lo; i0 < hi; i0 += 64) {
-        const int64_t i = i0 + lane;
-        const int64_t ilast = (i0 + 63 < hi) ? i0 + 63 : hi - 1;
+    for (int64_t i0 = lo; i0 < hi; i0 += 128) {
+        const int64_t i = i0 + 2 * lane;                         // this lane: lines i and i+1 (lo is even: 16-byte aligned pair)
+        const int64_t ilast = (i0 + 127 < hi) ? i0 + 127 : hi - 1;
         if (ilast < next_hl) {                                   // whole window inside the current record
-            if (rec >= 0 && i < hi && i > hl + 1) cnt += (nl[i] - nl[i - 1] != ll);
+            if (rec >= 0 && i < hi) {
+                int64_t a, b;
+                if (i + 1 < hi) { const longlong2 v = *reinterpret_cast<const longlong2 *>(nl + i); a = v.x; b = v.y; }
+                else            { a = nl[i]; b = a; }
+                const int64_t prev = i > 0 ? nl[i - 1] : -1;
+                if (i > hl + 1) cnt += (a - prev != ll);
+                if (i + 1 < hi && i + 1 > hl + 1) cnt += (b - a != ll);
+            }
             continue;
         }
-        // boundary window: flush, then every lane finds its own record
+        // boundary window: flush, then every lane finds the record of each of its lines
         cnt = wave_sum(cnt);
         if (lane == 0 && cnt && rec >= 0) atomicAdd(&bad[rec], cnt);
         cnt = 0;
-        if (i < hi) {
-            const int64_t r = upper_bound(hdr_line, n_hdr, i) - 1;
-            if (r >= 0 && i > hdr_line[r] + 1 && nl[i] - nl[i - 1] != llen[r]) atomicAdd(&bad[r], 1u);
+        for (int k = 0; k < 2; ++k) {
+            const int64_t j = i + k;
+            if (j < hi) {
+                const int64_t r = upper_bound(hdr_line, n_hdr, j) - 1;
+                if (r >= 0 && j > hdr_line[r] + 1 && nl[j] - nl[j - 1] != llen[r]) atomicAdd(&bad[r], 1u);
+            }
         }
         rec = upper_bound(hdr_line, n_hdr, ilast) - 1;           // state for the next window
         hl = rec >= 0 ? hdr_line[rec] : -2;
@@ -574,7 +590,7 @@ __device__ __forceinline__ void build_comp_lut(uint8_t *lut) {
 
 // G lanes cooperate on one query (64/G queries in flight per wave); each lane
 // loads V aligned bytes per step, so a step covers a G*V-byte window:
-//   <16, 8>  128-byte window, 4 queries per wave  -- ~100-bp random access
+//   < 8,16>  128-byte window, 8 queries per wave  -- ~100-bp random access
 //   <64,16>  1 KiB window, 1 query per wave       -- long ranges (whole records)
 // The keep mask of a lane's V bytes is SWAR, the rank of its first kept byte is
 // an exclusive prefix over the G lanes (__shfl_up, width G), kept bytes whose
