@@ -121,9 +121,21 @@ typedef struct {
     int64_t size;         /* stat.size   = sum of rlen                        */
     int64_t n_lines;
     int64_t n_bytes;
+    int64_t first_id;     /* global 0-based id of this shard's first read (0 for a whole file) */
 } fx_fastq_summary;
 
 int fx_fastq_build(fx_handle *h, fx_fastq_summary *out);
+
+/* Sharded FASTQ: records are short, so a shard carries a HALO -- the first
+ * bytes of the next shard appended to its own range (fx_set_halo) -- and owns every record
+ * whose header line STARTS in its core.  The only context it needs is the global line
+ * numbering: phase 1 (fx_fastq_scan) reports the newlines of the core, ONE all-gather of
+ * those two integers per rank gives every rank line_offset (newlines in earlier cores) and
+ * prev_nl (offset of the last of them, -1 if none), phase 2 (fx_fastq_build_ctx) builds the
+ * table.  Composition and fetch then work on the owned records.                           */
+int fx_set_halo(fx_handle *h, int64_t halo_bytes);
+int fx_fastq_scan(fx_handle *h, int64_t *n_nl_core, int64_t *last_nl_core);
+int fx_fastq_build_ctx(fx_handle *h, int64_t line_offset, int64_t prev_nl, fx_fastq_summary *out);
 int fx_fastq_table(fx_handle *h, int where,
                    int64_t *name_off, int32_t *name_len, int32_t *dlen,
                    int64_t *rlen, int64_t *soff, int64_t *qoff);

@@ -27,7 +27,8 @@ class FastaSummary(C.Structure):
 
 
 class FastqSummary(C.Structure):
-    _fields_ = [("n_reads", C.c_int64), ("size", C.c_int64), ("n_lines", C.c_int64), ("n_bytes", C.c_int64)]
+    _fields_ = [("n_reads", C.c_int64), ("size", C.c_int64), ("n_lines", C.c_int64), ("n_bytes", C.c_int64),
+                ("first_id", C.c_int64)]
 
 
 class ShardSummary(C.Structure):
@@ -41,7 +42,7 @@ class ShardSummary(C.Structure):
 SYMBOLS = [
     "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_host", "fx_open_device",
     "fx_set_shard", "fx_close", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
-    "fx_fasta_build", "fx_fasta_table", "fx_fasta_comp", "fx_fastq_build", "fx_fastq_table", "fx_fastq_comp",
+    "fx_fasta_build", "fx_fasta_table", "fx_fasta_comp", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fasta_fetch", "fx_fastq_fetch", "fx_revcomp", "fx_shard_summary_get",
     "fx_fasta_set_row", "fx_read_fetch", "fx_gz_points", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
 ]
@@ -86,6 +87,9 @@ def lib():
     L.fx_fasta_comp.argtypes = [vp, i32, vp]
     L.fx_fastq_build.argtypes = [vp, C.POINTER(FastqSummary)]
     L.fx_fastq_table.argtypes = [vp, i32] + [vp] * 6
+    L.fx_set_halo.argtypes = [vp, i64]
+    L.fx_fastq_scan.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.fx_fastq_build_ctx.argtypes = [vp, i64, i64, C.POINTER(FastqSummary)]
     L.fx_fastq_comp.argtypes = [vp, vp, vp]
     L.fx_fetch_ranges.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, vp, vp]
     L.fx_fasta_fetch.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, vp, vp]
@@ -258,6 +262,20 @@ class Blob:
     def fastq_build(self):
         s = FastqSummary()
         check(lib().fx_fastq_build(self._h, C.byref(s)))
+        return s
+
+    def set_halo(self, halo):
+        check(lib().fx_set_halo(self._h, int(halo)))
+
+    def fastq_scan(self):
+        """phase 1 of a sharded FASTQ build -> (newlines in the core, offset of the last one or -1)"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(lib().fx_fastq_scan(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def fastq_build_ctx(self, line_offset, prev_nl):
+        s = FastqSummary()
+        check(lib().fx_fastq_build_ctx(self._h, int(line_offset), int(prev_nl), C.byref(s)))
         return s
 
     def fastq_table(self, n):

@@ -712,11 +712,11 @@ __global__ __launch_bounds__(BLOCK) void k_revcomp(uint8_t *__restrict__ buf, in
 }
 
 // ================================================================ FASTQ (K4')
-// One thread per read k: the four lines of record k are nl[4k-1]+1 .. nl[4k+3]
-// (fastq.c:89-149, `line_num % 4` state machine becomes a gather).  Also
-// reduces stat.size (sum of rlen, including an incomplete trailing record's
-// sequence line, fastq.c:125) and the min/max quality-line length for
-// meta.maxlen/minlen (fastq.c:747-751).
+// The `line_num % 4` state machine of fastq.c:89-149 becomes a gather from the
+// line table: record k owns lines 4k .. 4k+3.  Shard context (FqCtx) makes the
+// same kernels serve byte-range shards: nl[] is local (index i = global line
+// loff + i), a record is owned by the shard in whose core its header line STARTS,
+// and the bytes of its remaining lines may lie in the halo that follows the core.
 struct FastqCols {
     int64_t *name_off, *rlen, *soff, *qoff;
     int32_t *name_len, *dlen;
@@ -724,88 +724,169 @@ struct FastqCols {
 struct FastqAcc {            // device accumulators
     unsigned long long size;
     unsigned long long a, c, g, t, n;
+    unsigned long long n_owned;
     long long maxlen, minlen;
     int minqs, maxqs;
+    int err;                 // 1: a record ran past the halo
+    int pad;
+};
+struct FqCtx {
+    int64_t gbase;           // global offset of data[0]
+    int64_t core_end;        // global offset one past the shard's core
+    int64_t loff;            // global line index of nl[0]
+    int64_t prev_nl;         // global offset of newline loff-1 (-1: none)
+    int64_t k_first;         // first record owned by this shard (global id of local row 0)
+    int is_last;
 };
 
-__global__ __launch_bounds__(BLOCK) void k_fastq_rec(const uint8_t *__restrict__ data, int64_t gbase,
-                                                    const int64_t *__restrict__ nl, int64_t n_nl, int64_t n_reads,
+// global offset where line j (0..3) of record k starts / the newline that ends it
+__device__ __forceinline__ int64_t fq_line_end(const FqCtx &x, const int64_t *nl, int64_t k, int j) { return nl[4 * k + j - x.loff]; }
+__device__ __forceinline__ int64_t fq_line_start(const FqCtx &x, const int64_t *nl, int64_t k, int j) {
+    const int64_t i = 4 * k + j - 1 - x.loff;
+    return (i >= 0 ? nl[i] : x.prev_nl) + 1;
+}
+
+// One thread per candidate record: columns of the `read` table (fastq.c:99-145), stat.size
+// (sum of rlen, including an incomplete trailing record's sequence line, fastq.c:125) and the
+// min/max quality-line length for meta.maxlen/minlen (fastq.c:747-751).
+__global__ __launch_bounds__(BLOCK) void k_fastq_rec(const uint8_t *__restrict__ data, FqCtx x,
+                                                    const int64_t *__restrict__ nl, int64_t n_nl, int64_t n_cand,
                                                     FastqCols c, FastqAcc *acc) {
-    const int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    int64_t rl = 0;
+    __shared__ long long red[4][BLOCK / 64];
+    int64_t rl_sum = 0;
     long long qmax = 0, qmin = 10000000000LL;
-    if (4 * k + 1 < n_nl) {                               // sequence line exists
-        const int64_t s0 = k ? nl[4 * k - 1] + 1 : gbase; // start of header line
-        const int64_t e0 = nl[4 * k];
-        const int64_t soff = e0 + 1, e1 = nl[4 * k + 1];
-        const int64_t l1 = e1 - soff;
-        rl = (l1 > 0 && data[e1 - 1 - gbase] == '\r') ? l1 - 1 : l1;     // fastq.c:124-128
-        if (k < n_reads) {
+    unsigned owned = 0;
+    int err = 0;
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < n_cand; t += stride) {
+        const int64_t k = x.k_first + t;
+        const int64_t i0 = 4 * k - x.loff;                // local index of the newline ending the header line
+        if (i0 - 1 >= n_nl) continue;                     // header start unknown: no such line
+        const int64_t s0 = fq_line_start(x, nl, k, 0);
+        if (s0 >= x.core_end) continue;                   // owned by a later shard (or past the data)
+        if (i0 + 3 < n_nl) {                              // all four lines present
+            const int64_t e0 = nl[i0], soff = e0 + 1, e1 = nl[i0 + 1];
+            const int64_t l1 = e1 - soff;
+            const int64_t rl = (l1 > 0 && data[e1 - 1 - x.gbase] == '\r') ? l1 - 1 : l1;   // fastq.c:124-128
             const int dlen = (int)(e0 - s0);              // fastq.c:103 (includes '@' and '\r')
             int64_t nlen = dlen - 1;
-            if (nlen > 0 && data[e0 - 1 - gbase] == '\r') --nlen;        // fastq.c:107-109
-            const uint8_t *s = data + (s0 + 1 - gbase);
-            for (int64_t j = 0; j < nlen; ++j) if (s[j] == ' ') { nlen = j; break; }   // fastq.c:112-117
-            const int64_t qoff = nl[4 * k + 2] + 1, e3 = nl[4 * k + 3];
+            if (nlen > 0 && data[e0 - 1 - x.gbase] == '\r') --nlen;        // fastq.c:107-109
+            // first ' ' of the name (fastq.c:112-117), 8 aligned bytes at a time
+            const int64_t nb = s0 + 1 - x.gbase, ne = nb + nlen;
+            for (int64_t p = nb & ~7ll; p < ne; p += 8) {
+                const uint2 w = *reinterpret_cast<const uint2 *>(data + p);
+                uint32_t m = flags4(zero_bytes(w.x ^ 0x20202020u)) | (flags4(zero_bytes(w.y ^ 0x20202020u)) << 4);
+                if (p < nb) m &= 0xFFu << (nb - p);
+                if (m) { const int64_t hit = p + __ffs(m) - 1; if (hit < ne) nlen = hit - nb; break; }
+            }
+            const int64_t qoff = nl[i0 + 2] + 1, e3 = nl[i0 + 3];
             long long ql = e3 - qoff;
-            if (ql > 0 && data[e3 - 1 - gbase] == '\r') --ql;            // fastq.c:734-737 (trailing CR)
-            qmax = ql; qmin = ql;
-            c.name_off[k] = s0 + 1; c.name_len[k] = (int32_t)nlen; c.dlen[k] = dlen;
-            c.rlen[k] = rl; c.soff[k] = soff; c.qoff[k] = qoff;
+            if (ql > 0 && data[e3 - 1 - x.gbase] == '\r') --ql;            // fastq.c:734-737 (trailing CR)
+            qmax = ql > qmax ? ql : qmax; qmin = ql < qmin ? ql : qmin;
+            c.name_off[t] = s0 + 1; c.name_len[t] = (int32_t)nlen; c.dlen[t] = dlen;
+            c.rlen[t] = rl; c.soff[t] = soff; c.qoff[t] = qoff;
+            rl_sum += rl;
+            ++owned;
+        } else if (!x.is_last) {
+            err = 1;                                      // the record runs past the halo
+        } else if (i0 + 1 < n_nl) {                       // incomplete trailing record: its sequence line still counts (fastq.c:125)
+            const int64_t soff = nl[i0] + 1, e1 = nl[i0 + 1];
+            const int64_t l1 = e1 - soff;
+            rl_sum += (l1 > 0 && data[e1 - 1 - x.gbase] == '\r') ? l1 - 1 : l1;
         }
     }
-    rl = wave_sum64(rl);
+    // one set of atomics per workgroup
+    rl_sum = wave_sum64(rl_sum);
+    long long own = wave_sum64((int64_t)owned);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         long long a = __shfl_xor(qmax, d, 64), b = __shfl_xor(qmin, d, 64);
         qmax = a > qmax ? a : qmax; qmin = b < qmin ? b : qmin;
     }
-    if (lane_id() == 0) {
-        if (rl) atomicAdd(&acc->size, (unsigned long long)rl);
-        atomicMax(&acc->maxlen, qmax);
-        atomicMin(&acc->minlen, qmin);
+    if (__any(err)) acc->err = 1;
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 0) { red[0][w] = rl_sum; red[1][w] = own; red[2][w] = qmax; red[3][w] = qmin; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long s = 0, o = 0, mx = 0, mn = 10000000000LL;
+        for (int i = 0; i < BLOCK / 64; ++i) { s += red[0][i]; o += red[1][i]; mx = red[2][i] > mx ? red[2][i] : mx; mn = red[3][i] < mn ? red[3][i] : mn; }
+        if (s) atomicAdd(&acc->size, (unsigned long long)s);
+        if (o) atomicAdd(&acc->n_owned, (unsigned long long)o);
+        if (o) { atomicMax(&acc->maxlen, mx); atomicMin(&acc->minlen, mn); }
     }
 }
 
-// FASTQ composition (fastq.c:715-753): one wave per read, lanes stride the
-// sequence line (count A/C/G/T uppercase, '\r' ignored, everything else N) and
-// the quality line (min/max byte, '\r' ignored).
-__global__ __launch_bounds__(BLOCK) void k_fastq_comp(const uint8_t *__restrict__ data, int64_t gbase,
+// FASTQ composition (fastq.c:715-753).  16 lanes per record, 4 records per wave; a lane
+// reads 16 aligned bytes per step (256-byte window per record).  Sequence line: SWAR
+// compare+popcount for 'A','C','G','T' (upper case only) and '\r' (ignored); every other
+// byte is N.  Quality line: min / max byte, '\r' ignored.
+__device__ __forceinline__ uint32_t valid16(int64_t pp, int64_t lo, int64_t hi) {
+    int64_t a0 = lo - pp, a1 = hi - pp;
+    a0 = a0 < 0 ? 0 : (a0 > 16 ? 16 : a0);
+    a1 = a1 < 0 ? 0 : (a1 > 16 ? 16 : a1);
+    return a1 > a0 ? (((1u << a1) - 1u) & ~((1u << a0) - 1u)) : 0u;
+}
+__global__ __launch_bounds__(BLOCK) void k_fastq_comp(const uint8_t *__restrict__ data, FqCtx x,
                                                      const int64_t *__restrict__ nl, int64_t n_nl,
-                                                     int64_t n_lines4, FastqAcc *acc) {
-    const int lane = lane_id();
+                                                     int64_t n_cand, FastqAcc *acc) {
+    const int lane = lane_id(), sub = lane & 15, grp = lane >> 4;
     const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
-    unsigned long long ca = 0, cc = 0, cg = 0, ct = 0, cn = 0;
+    uint32_t ca = 0, cc = 0, cg = 0, ct = 0, cn = 0;       // per lane, flushed per record batch (no overflow: <= 16 per step)
+    unsigned long long ta = 0, tc = 0, tg = 0, tt = 0, tn = 0;
     int qmin = 104, qmax = 33;                             // fastq.c:667-668
-    for (int64_t k = wave; k < n_lines4; k += nwaves) {
-        if (4 * k + 1 < n_nl) {                            // line_num % 4 == 2
-            const int64_t s = nl[4 * k] + 1 - gbase, e = nl[4 * k + 1] - gbase;
-            for (int64_t p = s + lane; p < e; p += 64) {
-                const uint8_t c = data[p];
-                ca += (c == 'A'); cc += (c == 'C'); cg += (c == 'G'); ct += (c == 'T');
-                cn += !(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 13);
+    for (int64_t t0 = wave * 4; t0 < n_cand; t0 += nwaves * 4) {
+        const int64_t k = x.k_first + t0 + grp;
+        const int64_t i0 = 4 * k - x.loff;
+        bool mine = (t0 + grp) < n_cand && i0 - 1 < n_nl && i0 < n_nl;
+        if (mine) mine = fq_line_start(x, nl, k, 0) < x.core_end;
+        if (mine && i0 + 1 < n_nl) {                       // line_num % 4 == 2
+            const int64_t s = nl[i0] + 1 - x.gbase, e = nl[i0 + 1] - x.gbase;
+            for (int64_t p = (s & ~15ll) + sub * 16; p < e; p += 256) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(data + p);
+                const uint32_t ok = valid16(p, s, e);
+                const uint32_t ma = eq_mask16(v, 0x41414141u) & ok, mc = eq_mask16(v, 0x43434343u) & ok;
+                const uint32_t mg = eq_mask16(v, 0x47474747u) & ok, mt = eq_mask16(v, 0x54545454u) & ok;
+                const uint32_t mr = eq_mask16(v, 0x0D0D0D0Du) & ok;
+                ca += __popc(ma); cc += __popc(mc); cg += __popc(mg); ct += __popc(mt);
+                cn += __popc(ok & ~(ma | mc | mg | mt | mr));
             }
         }
-        if (4 * k + 3 < n_nl) {                            // line_num % 4 == 0
-            const int64_t s = nl[4 * k + 2] + 1 - gbase, e = nl[4 * k + 3] - gbase;
-            for (int64_t p = s + lane; p < e; p += 64) {
-                const int c = (int)(signed char)data[p];
-                if (c != 13) { qmin = c < qmin ? c : qmin; qmax = c > qmax ? c : qmax; }
+        if (mine && i0 + 3 < n_nl) {                       // line_num % 4 == 0
+            const int64_t s = nl[i0 + 2] + 1 - x.gbase, e = nl[i0 + 3] - x.gbase;
+            for (int64_t p = (s & ~15ll) + sub * 16; p < e; p += 256) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(data + p);
+                uint32_t ok = valid16(p, s, e) & ~eq_mask16(v, 0x0D0D0D0Du);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                while (ok) {
+                    const int j = __ffs(ok) - 1;
+                    ok &= ok - 1;
+                    const int q = (int)(signed char)(w[j >> 2] >> ((j & 3) * 8));
+                    qmin = q < qmin ? q : qmin; qmax = q > qmax ? q : qmax;
+                }
             }
         }
+        ta += ca; tc += cc; tg += cg; tt += ct; tn += cn;
+        ca = cc = cg = ct = cn = 0;
     }
-    ca = wave_sum64(ca); cc = wave_sum64(cc); cg = wave_sum64(cg); ct = wave_sum64(ct); cn = wave_sum64(cn);
+    ta = wave_sum64(ta); tc = wave_sum64(tc); tg = wave_sum64(tg); tt = wave_sum64(tt); tn = wave_sum64(tn);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         int a = __shfl_xor(qmin, d, 64), b = __shfl_xor(qmax, d, 64);
         qmin = a < qmin ? a : qmin; qmax = b > qmax ? b : qmax;
     }
     if (lane == 0) {
-        if (ca) atomicAdd(&acc->a, ca); if (cc) atomicAdd(&acc->c, cc); if (cg) atomicAdd(&acc->g, cg);
-        if (ct) atomicAdd(&acc->t, ct); if (cn) atomicAdd(&acc->n, cn);
+        if (ta) atomicAdd(&acc->a, ta); if (tc) atomicAdd(&acc->c, tc); if (tg) atomicAdd(&acc->g, tg);
+        if (tt) atomicAdd(&acc->t, tt); if (tn) atomicAdd(&acc->n, tn);
         atomicMin(&acc->minqs, qmin); atomicMax(&acc->maxqs, qmax);
     }
+}
+
+// number of entries of the sorted table that are < key, and the last such entry (-1 if none)
+__global__ void k_count_below(const int64_t *__restrict__ a, int64_t n, int64_t key, int64_t *out) {
+    const int64_t c = lower_bound(a, n, key);
+    out[0] = c;
+    out[1] = c ? a[c - 1] : -1;
 }
 
 // FASTQ read fetch (read.c:37-45,152-167,237-278): one wave per read copies

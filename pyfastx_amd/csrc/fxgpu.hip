@@ -154,6 +154,9 @@ struct fx_handle {
     int64_t n_reads = 0, fq_size = 0;
     long long fq_maxlen = 0, fq_minlen = 0;
     bool fastq_built = false;
+    int64_t halo = 0;          // trailing bytes of the blob that belong to the next shard's core
+    FqCtx fq_ctx;
+    int64_t fq_ncand = 0;
     // BGZF member table (compressed offset of each member, offset of its data in the inflated stream)
     std::vector<int64_t> gz_moff, gz_uoff;
     int64_t gz_csize = 0;
@@ -658,15 +661,20 @@ extern "C" int fx_fasta_comp(fx_handle *h, int where, int64_t *comp) {
 }
 
 // ------------------------------------------------------------- FASTQ build
-extern "C" int fx_fastq_build(fx_handle *h, fx_fastq_summary *out) {
-    if (!h) return fail(FX_EINVAL, "null handle");
-    int rc = run_scan(h, false);
+// Phase 2 of the FASTQ build: records from the line table, given where this shard's lines sit in
+// the global numbering (loff = newlines in earlier shards' cores, prev_nl = offset of the last of them).
+static int fastq_records(fx_handle *h, int64_t loff, int64_t prev_nl, fx_fastq_summary *out) {
+    int rc = use_device(h);
     if (rc) return rc;
-    const int64_t nr = h->n_nl / 4;                        // fastq.c:159  line_num/4
-    const int64_t nseqline = (h->n_nl + 2) / 4;            // records that have a sequence line
-    const int64_t na = std::max<int64_t>(nr, 1);
-    if ((rc = h->fq_name_off.alloc(na)) || (rc = h->fq_rlen.alloc(na)) || (rc = h->fq_soff.alloc(na)) ||
-        (rc = h->fq_qoff.alloc(na)) || (rc = h->fq_name_len.alloc(na)) || (rc = h->fq_dlen.alloc(na)) ||
+    FqCtx x;
+    x.gbase = h->base; x.core_end = h->base + h->n - h->halo; x.loff = loff; x.prev_nl = prev_nl; x.is_last = h->is_last;
+    const int64_t k0 = (loff + 3) / 4;
+    x.k_first = k0 + ((loff % 4 == 0 && prev_nl + 1 < h->base) ? 1 : 0);   // that record's header began in the previous shard
+    h->fq_ctx = x;
+    const int64_t ncand = std::max<int64_t>((h->n_nl + loff + 3) / 4 + 1 - x.k_first, 1);
+    h->fq_ncand = ncand;
+    if ((rc = h->fq_name_off.alloc(ncand)) || (rc = h->fq_rlen.alloc(ncand)) || (rc = h->fq_soff.alloc(ncand)) ||
+        (rc = h->fq_qoff.alloc(ncand)) || (rc = h->fq_name_len.alloc(ncand)) || (rc = h->fq_dlen.alloc(ncand)) ||
         (rc = h->fq_acc.alloc(1)))
         return rc;
     FastqAcc init;
@@ -677,19 +685,54 @@ extern "C" int fx_fastq_build(fx_handle *h, fx_fastq_summary *out) {
     FastqCols c;
     c.name_off = h->fq_name_off.p; c.rlen = h->fq_rlen.p; c.soff = h->fq_soff.p; c.qoff = h->fq_qoff.p;
     c.name_len = h->fq_name_len.p; c.dlen = h->fq_dlen.p;
-    if (nseqline > 0)
-        FX_LAUNCH(h, K_FASTQ_REC, k_fastq_rec, dim3(nblocks(nseqline, BLOCK)), dim3(BLOCK), h->d_data, h->base,
-                           h->nl.p, h->n_nl, nr, c, h->fq_acc.p);
+    FX_LAUNCH(h, K_FASTQ_REC, k_fastq_rec, dim3(std::min(nblocks(ncand, BLOCK), 256u * 16u)), dim3(BLOCK), h->d_data, x,
+              h->nl.p, h->n_nl, ncand, c, h->fq_acc.p);
     HIPCHK(hipGetLastError());
     FastqAcc acc;
     HIPCHK(hipMemcpyAsync(&acc, h->fq_acc.p, sizeof acc, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->n_reads = nr;
+    if (acc.err) return fail(FX_ERANGE, "a FASTQ record that starts in this shard runs past its %lld-byte halo", (long long)h->halo);
+    h->n_reads = (int64_t)acc.n_owned;
     h->fq_size = (int64_t)acc.size;
     h->fq_maxlen = acc.maxlen; h->fq_minlen = acc.minlen;
     h->fastq_built = true;
-    if (out) { out->n_reads = nr; out->size = h->fq_size; out->n_lines = h->n_nl; out->n_bytes = h->n; }
+    if (out) { out->n_reads = h->n_reads; out->size = h->fq_size; out->n_lines = h->n_nl; out->n_bytes = h->n; out->first_id = x.k_first; }
     return FX_OK;
+}
+
+extern "C" int fx_set_halo(fx_handle *h, int64_t halo_bytes) {
+    if (!h || halo_bytes < 0 || halo_bytes > h->n) return fail(FX_EINVAL, "bad halo");
+    h->halo = halo_bytes;
+    h->fasta_built = h->fastq_built = false;
+    return FX_OK;
+}
+
+extern "C" int fx_fastq_scan(fx_handle *h, int64_t *n_nl_core, int64_t *last_nl_core) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    int rc = run_scan(h, false);
+    if (rc) return rc;
+    int64_t res[2] = {h->n_nl, -1};
+    DevBuf<int64_t> d;
+    if ((rc = d.alloc(2))) return rc;
+    hipLaunchKernelGGL(k_count_below, dim3(1), dim3(1), 0, h->stream, h->nl.p, h->n_nl, h->base + h->n - h->halo, d.p);
+    HIPCHK(hipMemcpyAsync(res, d.p, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (n_nl_core) *n_nl_core = res[0];
+    if (last_nl_core) *last_nl_core = res[1];
+    return FX_OK;
+}
+
+extern "C" int fx_fastq_build_ctx(fx_handle *h, int64_t line_offset, int64_t prev_nl, fx_fastq_summary *out) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    if (!h->scanned) return fail(FX_ESTATE, "fx_fastq_scan has not run");
+    return fastq_records(h, line_offset, prev_nl, out);
+}
+
+extern "C" int fx_fastq_build(fx_handle *h, fx_fastq_summary *out) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    int rc = run_scan(h, false);
+    if (rc) return rc;
+    return fastq_records(h, 0, -1, out);
 }
 
 extern "C" int fx_fastq_table(fx_handle *h, int where, int64_t *name_off, int32_t *name_len, int32_t *dlen,
@@ -712,10 +755,9 @@ extern "C" int fx_fastq_comp(fx_handle *h, int64_t base[5], int64_t meta[5]) {
     if (!h->fastq_built) return fail(FX_ESTATE, "fx_fastq_build has not run");
     int rc = use_device(h);
     if (rc) return rc;
-    const int64_t groups = (h->n_nl + 3) / 4;
-    const unsigned nb = (unsigned)std::min<int64_t>(nblocks(groups, BLOCK / 64), 256 * 8);
-    FX_LAUNCH(h, K_FASTQ_COMP, k_fastq_comp, dim3(nb), dim3(BLOCK), h->d_data, h->base, h->nl.p, h->n_nl, groups,
-                       h->fq_acc.p);
+    const unsigned nb = (unsigned)std::min<int64_t>(nblocks(h->fq_ncand, (BLOCK / 64) * 4), 256 * 8);
+    FX_LAUNCH(h, K_FASTQ_COMP, k_fastq_comp, dim3(nb), dim3(BLOCK), h->d_data, h->fq_ctx, h->nl.p, h->n_nl, h->fq_ncand,
+              h->fq_acc.p);
     HIPCHK(hipGetLastError());
     FastqAcc acc;
     HIPCHK(hipMemcpyAsync(&acc, h->fq_acc.p, sizeof acc, hipMemcpyDeviceToHost, h->stream));

@@ -247,3 +247,26 @@ class ShardedFasta:
         else:
             ok &= len(rows["boff"]) == npiece
         return bool(ok)
+
+
+# ------------------------------------------------------------------ FASTQ shards
+def fastq_contexts(cores):
+    """cores[r] = (newlines in shard r's core, offset of the last one or -1), in shard order
+    (the payload of the one all-gather).  -> [(line_offset, prev_nl)] for fx_fastq_build_ctx."""
+    out, loff, prev = [], 0, -1
+    for n_nl, last in cores:
+        out.append((loff, prev))
+        loff += n_nl
+        if n_nl > 0:
+            prev = last
+    return out
+
+
+def allgather_fastq_cores(mine, world, device="cpu"):
+    """One all-gather of two int64 per rank (gloo in tests, RCCL on GPUs)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor(list(mine), dtype=torch.int64, device=device)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return [tuple(int(v) for v in o.cpu()) for o in outs]

@@ -77,3 +77,83 @@ def test_long_lines_across_many_shards(oracle, L):
     n = len(raw)
     check(oracle, L, raw, [n // 8 * i for i in range(1, 8)])
     check(oracle, L, raw, [5, 11, 30, 40000, 40010, n - 3])
+
+
+# ------------------------------------------------------------------ FASTQ shards (halo + line numbering)
+def _rand_fastq(rng, n, crlf=False, trailing=True):
+    eol = b"\r\n" if crlf else b"\n"
+    out = []
+    for i in range(n):
+        ln = int(rng.integers(1, 200))
+        seq = bytes(rng.choice(list(b"ACGTNacgt"), ln).astype(np.uint8))
+        qual = bytes(rng.integers(35, 71, ln).astype(np.uint8))
+        name = b"@r%d" % i + (b" extra words %d" % (i * 7) if i % 3 else b"")
+        out += [name + eol, seq + eol, b"+" + (name[1:] if i % 5 == 0 else b"") + eol, qual + eol]
+    raw = b"".join(out)
+    return raw if trailing else raw[:-len(eol)]
+
+
+def fastq_sharded(L, raw, cuts, halo=4096):
+    from pyfastx_amd import shard
+    bounds = [0] + list(cuts) + [len(raw)]
+    blobs, cores = [], []
+    for i in range(len(bounds) - 1):
+        lo, hi = bounds[i], bounds[i + 1]
+        h = min(halo, len(raw) - hi)
+        b = L.Blob.from_bytes(raw[lo:hi + h])
+        b.set_shard(lo, raw[lo - 1] if lo else 10, hi == len(raw))
+        b.set_halo(h)
+        cores.append(b.fastq_scan())
+        blobs.append(b)
+    cols = {k: [] for k in ("name_off", "name_len", "dlen", "rlen", "soff", "qoff")}
+    size, nreads, base, meta, next_id = 0, 0, np.zeros(5, np.int64), None, 0
+    for b, (loff, prev) in zip(blobs, shard.fastq_contexts(cores)):
+        s = b.fastq_build_ctx(loff, prev)
+        if s.n_reads:
+            assert s.first_id == next_id
+        next_id += s.n_reads
+        t = b.fastq_table(s.n_reads)
+        for k in cols:
+            cols[k].append(t[k])
+        size += s.size
+        nreads += s.n_reads
+        bs, mt = b.fastq_comp()
+        base += bs
+        meta = mt.copy() if meta is None else np.array([max(meta[0], mt[0]), min(meta[1], mt[1]), min(meta[2], mt[2]),
+                                                        max(meta[3], mt[3]), 0])
+    return {k: np.concatenate(v) for k, v in cols.items()}, size, nreads, base, meta
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fastq_shards(oracle, L, seed):
+    rng = np.random.default_rng(500 + seed)
+    raw = _rand_fastq(rng, int(rng.integers(5, 300)), crlf=bool(seed & 1), trailing=(seed != 4))
+    if seed == 5:
+        raw += b"@tail\nACGT\n+\n"                       # incomplete trailing record
+    recs, size, ln = oracle.fastq_index(raw)
+    c = oracle.fastq_composition(raw)
+    for g in (1, 2, 3, 7):
+        cuts = sorted(set(int(x) for x in rng.integers(1, len(raw), g - 1)))
+        got, gsize, n, base, meta = fastq_sharded(L, raw, cuts)
+        assert n == len(recs) and gsize == size, (seed, cuts)
+        for k in got:
+            np.testing.assert_array_equal(got[k], recs[k].astype(got[k].dtype), err_msg="%s cuts=%s" % (k, cuts))
+        assert base.tolist() == [c["a"], c["c"], c["g"], c["t"], c["n"]], (seed, cuts)
+        assert meta[:4].tolist() == [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"]], (seed, cuts)
+
+
+def test_fastq_every_cut_small(oracle, L):
+    raw = b"@r1 d1\r\nACGT\r\n+\r\nIIII\r\n@r2\r\nGGCCA\r\n+r2\r\n#!5AB\r\n@r3 x y\r\nA\r\n+\r\nI\r\n"
+    recs, size, ln = oracle.fastq_index(raw)
+    for c in range(1, len(raw)):
+        got, gsize, n, base, meta = fastq_sharded(L, raw, [c], halo=64)
+        assert n == len(recs) and gsize == size, c
+        for k in got:
+            np.testing.assert_array_equal(got[k], recs[k].astype(got[k].dtype), err_msg="%s cut=%d" % (k, c))
+
+
+def test_fastq_halo_too_small_is_an_error(L):
+    raw = _rand_fastq(np.random.default_rng(1), 50)
+    with pytest.raises(L.FxError) as e:
+        fastq_sharded(L, raw, [len(raw) // 2], halo=3)
+    assert e.value.code == L.FX_ERANGE
