@@ -364,27 +364,51 @@ class Fasta:
         left, right = seq._fetch_many([ls, rs], [le, re_])
         return _decode(left), _decode(right)
 
+    def _table(self):
+        """The seq table as numpy columns (cached): what the batched calls index into."""
+        if getattr(self, "_tab", None) is None:
+            rows = self._db.execute("SELECT chrom,boff,blen,slen,llen,elen,norm FROM seq ORDER BY ID").fetchall()
+            self._tab = {"index": {r[0]: i for i, r in enumerate(rows)},
+                         "boff": np.array([r[1] for r in rows], np.int64), "blen": np.array([r[2] for r in rows], np.int64),
+                         "slen": np.array([r[3] for r in rows], np.int64), "llen": np.array([r[4] for r in rows], np.int64),
+                         "elen": np.array([r[5] for r in rows], np.int64), "norm": np.array([r[6] for r in rows], np.int64)}
+        return self._tab
+
     def fetch_many(self, names_or_ids, starts, stops, strand=None):
-        """Batched extension: 0-based half-open (start, stop) on many
-        sequences in ONE kernel launch -> (uint8 buffer, int64 offsets[n+1])."""
+        """Batched extension: 0-based half-open (start, stop) on many sequences in ONE
+        kernel launch -> (uint8 buffer, int64 offsets[n+1]).  names_or_ids: sequence names or 0-based
+        ids; strand: optional per-query '+'/'-' (or 0/1).  Byte ranges come from the vectorised
+        sequence.c:498-510 arithmetic; the despace / reverse-complement runs on the GPU."""
         self._need_index()
-        n = len(starts)
-        rows = {}
-        off = np.empty(n, np.int64); bl = np.empty(n, np.int64); sl = np.empty(n, np.int64)
-        for i in range(n):
-            key = names_or_ids[i]
-            r = rows.get(key)
-            if r is None:
-                r = rows[key] = self[key]
-            if not r._normal:
-                raise ValueError("fetch_many needs line-regular (norm=1) sequences")
-            off[i], bl[i] = r._range(int(starts[i]), int(stops[i]))
-            sl[i] = int(stops[i]) - int(starts[i])
+        t = self._table()
+        starts = np.asarray(starts, dtype=np.int64)
+        stops = np.asarray(stops, dtype=np.int64)
+        first = names_or_ids[0] if len(names_or_ids) else 0
+        if isinstance(first, str):
+            ix = t["index"]
+            try:
+                ids = np.fromiter((ix[k] for k in names_or_ids), dtype=np.int64, count=len(names_or_ids))
+            except KeyError as e:
+                raise KeyError("%s does not exist in fasta file" % e.args[0])
+        else:
+            ids = np.asarray(names_or_ids, dtype=np.int64)
+            if ids.size and (ids.min() < 0 or ids.max() >= self._seq_counts):
+                raise IndexError("index out of range")
+        if starts.size and (starts.min() < 0 or (stops < starts).any() or (stops > t["slen"][ids]).any()):
+            raise ValueError("interval outside the sequence")
+        elen = t["elen"][ids]
+        bpl = t["llen"][ids] - elen
+        if (t["norm"][ids] == 0).any() or (bpl <= 0).any():
+            raise ValueError("fetch_many needs line-regular (norm=1) sequences")
+        off = t["boff"][ids] + starts + elen * (starts // bpl)
+        bl = (stops - starts) + (stops // bpl - starts // bpl) * elen
         fl = (_F_UP if self._uppercase else 0)
         fpq = None
         if strand is not None:
-            fpq = np.array([fl | ((_F_REV | _F_COMP) if s in ("-", 1, True) else 0) for s in strand], dtype=np.uint8)
-        buf, offs, ol = self._st.blob.fetch_ranges(off, bl, sl, flags=fl, flags_per_query=fpq)
+            neg = np.array([s in ("-", 1, True) for s in strand], dtype=bool) if not isinstance(strand, np.ndarray) \
+                else (strand != 0) & (strand != ord("+"))
+            fpq = np.where(neg, fl | _F_REV | _F_COMP, fl).astype(np.uint8)
+        buf, offs, ol = self._st.blob.fetch_ranges(off, bl, stops - starts, flags=fl, flags_per_query=fpq)
         return buf, offs
 
 

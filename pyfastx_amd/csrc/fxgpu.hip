@@ -154,6 +154,8 @@ struct fx_handle {
     int64_t n_reads = 0, fq_size = 0;
     long long fq_maxlen = 0, fq_minlen = 0;
     bool fastq_built = false;
+    DevBuf<uint8_t> arena;     // scratch for host-array calls (Staged)
+    int64_t arena_used = 0;
     int64_t halo = 0;          // trailing bytes of the blob that belong to the next shard's core
     FqCtx fq_ctx;
     int64_t fq_ncand = 0;
@@ -776,26 +778,48 @@ extern "C" int fx_fastq_comp(fx_handle *h, int64_t base[5], int64_t meta[5]) {
 }
 
 // ------------------------------------------------------------------- fetch
-struct Staged {           // host arrays mirrored on the device for one call
-    std::vector<void *> bufs;
-    ~Staged() { for (void *p : bufs) (void)hipFree(p); }
-    template <class T> int up(fx_handle *h, const T *src, int64_t n, const T **dst) {
+// Per-call device mirrors of host query arrays come out of a grow-only arena owned by the
+// handle (no hipMalloc/hipFree per call -- they dominate a single 100-byte query otherwise).
+// A request that does not fit falls back to hipMalloc for this call and enlarges the arena
+// for the next one.
+struct Staged {
+    fx_handle *h;
+    std::vector<void *> spill;
+    int64_t want = 0;
+    explicit Staged(fx_handle *hh) : h(hh) { h->arena_used = 0; }
+    ~Staged() {
+        for (void *p : spill) (void)hipFree(p);
+        if (want > h->arena.cap) {                       // only reached after the call's final sync
+            (void)hipStreamSynchronize(h->stream);
+            (void)h->arena.alloc(want + want / 2);
+        }
+    }
+    void *take(int64_t bytes) {
+        bytes = (std::max<int64_t>(bytes, 1) + 255) & ~255ll;
+        want += bytes;
+        if (h->arena.p && h->arena_used + bytes <= h->arena.cap) {
+            void *p = h->arena.p + h->arena_used;
+            h->arena_used += bytes;
+            return p;
+        }
+        void *d = nullptr;
+        if (hipMalloc(&d, (size_t)bytes) != hipSuccess) return nullptr;
+        spill.push_back(d);
+        return d;
+    }
+    template <class T> int up(fx_handle *, const T *src, int64_t n, const T **dst) {
         *dst = nullptr;
         if (!src || n <= 0) return FX_OK;
-        void *d = nullptr;
-        hipError_t e = hipMalloc(&d, (size_t)n * sizeof(T));
-        if (e != hipSuccess) return fail(FX_ENOMEM, "hipMalloc: %s", hipGetErrorString(e));
-        bufs.push_back(d);
-        e = hipMemcpyAsync(d, src, (size_t)n * sizeof(T), hipMemcpyHostToDevice, h->stream);
+        void *d = take(n * (int64_t)sizeof(T));
+        if (!d) return fail(FX_ENOMEM, "device scratch allocation failed");
+        hipError_t e = hipMemcpyAsync(d, src, (size_t)n * sizeof(T), hipMemcpyHostToDevice, h->stream);
         if (e != hipSuccess) return fail(FX_EDEVICE, "H2D: %s", hipGetErrorString(e));
         *dst = (const T *)d;
         return FX_OK;
     }
     template <class T> int scratch(int64_t n, T **dst) {
-        void *d = nullptr;
-        hipError_t e = hipMalloc(&d, (size_t)std::max<int64_t>(n, 1) * sizeof(T));
-        if (e != hipSuccess) return fail(FX_ENOMEM, "hipMalloc: %s", hipGetErrorString(e));
-        bufs.push_back(d);
+        void *d = take(n * (int64_t)sizeof(T));
+        if (!d) return fail(FX_ENOMEM, "device scratch allocation failed");
         *dst = (T *)d;
         return FX_OK;
     }
@@ -815,7 +839,7 @@ static int fetch_common(fx_handle *h, int where, int64_t n, bool by_id, const in
     if (n == 0) return FX_OK;
     int rc = use_device(h);
     if (rc) return rc;
-    Staged st;
+    Staged st(h);
     FetchQ q;
     memset(&q, 0, sizeof q);
     const int64_t *host_blen = (where == FX_HOST && !by_id) ? a1 : nullptr;
@@ -908,7 +932,7 @@ extern "C" int fx_fastq_fetch(fx_handle *h, int where, int64_t n, const int64_t 
     int rc = use_device(h);
     if (rc) return rc;
     if (!phred) phred = 33;                                // read.c:268
-    Staged st;
+    Staged st(h);
     const int64_t *d_ids = read_id, *d_off = dst_off;
     uint8_t *d_seq = seq, *d_qual = qual;
     int8_t *d_qi = quali;
@@ -950,7 +974,7 @@ extern "C" int fx_read_fetch(fx_handle *h, int where, int64_t n, const int64_t *
     int rc = use_device(h);
     if (rc) return rc;
     if (!phred) phred = 33;                                // read.c:268
-    Staged st;
+    Staged st(h);
     const int64_t *d_s = soff, *d_q = qoff, *d_r = rlen, *d_off = dst_off;
     uint8_t *d_seq = seq, *d_qual = qual;
     int8_t *d_qi = quali;
