@@ -4,11 +4,11 @@
 GPU (configs[1]); at N>1 the N pieces form ONE stream sharded by byte range
 across the ranks (configs[4] shape) and stitched with one RCCL all-gather.
 
-A "step" = fx_fasta_build (delimiter scan -> line table -> record table) over
+A "step" = fx_fasta_build (one-read granule scan -> prefixes -> record table) over
 the shard resident in HBM  +  fx_fasta_fetch of 1 M (id,start,stop,strand)
 queries into a device buffer.  Inputs are resident in HBM before the timed
 region.  One JSON line on rank 0 (contract in the task statement), plus
-`roofline` for the dominant kernel (k_scan, HIP events on the library's own
+`roofline` for the dominant kernel (k_span_scan, HIP events on the library's own
 stream) and `cpu_baseline` (the real reference built from /root/reference ->
 oracle/_ref when loadable, else the C port) at N=1.
 """
@@ -149,7 +149,7 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    job.blob.prof_enable(2)                               # events around the dominant kernel only (k_scan)
+    job.blob.prof_enable(2)                               # events around the dominant kernel only (k_span_scan)
     job.blob.prof_reset()
     if world > 1:
         dist.barrier()
@@ -215,7 +215,7 @@ def main():
         return
     ms = el / a.steps * 1e3
     shard_bytes = job.n_bytes
-    scan_ms, scan_n = prof.get("k_scan", (0.0, 0))
+    scan_ms, scan_n = prof.get("k_span_scan", (0.0, 0))
     scan_avg = scan_ms / max(scan_n, 1)
     achieved = shard_bytes / (scan_avg * 1e-3) / 1e9 if scan_avg > 0 else 0.0
     line = {
@@ -231,7 +231,7 @@ def main():
         "parity_verified_full_size": verified,
         "composition_pass_ms": None if comp_ms is None else round(comp_ms, 3),
         "kernels_ms_avg": {k: round(v[0] / v[1], 4) for k, v in prof_all.items()},
-        "roofline": {"kernel": "fx::k_scan<true>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": "fx::k_span_scan<true>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": shard.pmc_traffic(ROOT),
                      "algorithmic_bytes_per_launch": int(shard_bytes), "avg_launch_ms": round(scan_avg, 4)},
     }

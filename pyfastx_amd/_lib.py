@@ -202,7 +202,7 @@ class Blob:
         check(lib().fx_sync(self._h))
 
     def prof_enable(self, on=1):
-        """0 off, 1 every kernel, 2 only k_scan."""
+        """0 off, 1 every kernel, 2 only the dominant scan kernel (k_span_scan / k_scan)."""
         check(lib().fx_prof_enable(self._h, int(on)))
 
     def prof_reset(self):

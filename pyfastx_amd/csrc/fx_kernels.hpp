@@ -4,14 +4,13 @@
 // (kseq.c:59-109 feeding index.c:230-339 / fastq.c:89-149).  None of that
 // structure survives here: the stream is resident in HBM and is processed as
 //
-//   K1 k_scan          bytes -> 1 bit/byte newline mask + per-tile counts      (HBM-bound, reads the file once)
-//   K2 k_tile_scan     exclusive prefix over the per-tile counts               (tiny)
-//   K3 k_linetable     newline mask -> int64 line table nl[]                   (reads n/8 bytes, writes 8 B/line)
-//   K4 k_hdr_scatter   '>' at line start -> hdr[] (only tiles that have one)
-//   K5 k_fasta_rec     one thread per record: gathers from nl[]/hdr[]          (index.c:234-339 columns)
-//   K6 k_fasta_lines   one thread per line: bad-line count per record          (index.c:325-327)
-//   K7 k_fetch         one wave per query: gather, despace, upper, revcomp     (index.c:683-707, util.c:157-269)
-//   ... FASTQ and composition kernels below.
+//   FASTA index   fx_spanscan.hpp: one read of the stream, per-4-KiB summaries, no line table
+//   FASTQ index   K1 k_scan       bytes -> 1 bit/byte newline mask + per-tile counts   (reads the file once)
+//                 K2 k_group_*    exclusive prefix over the per-tile counts            (tiny)
+//                 K3 k_linetable  newline mask -> int64 line table nl[]               (n/8 bytes in, 8 B/line out)
+//                 k_fastq_rec / k_fastq_comp / k_fastq_fetch
+//   fetch         K7 k_fetch      G lanes per query: gather, despace, upper, revcomp   (index.c:683-707, util.c:157-269)
+//   composition   k_fasta_comp
 //
 // Integer/byte work only: no MFMA anywhere; the roofline is HBM bandwidth.
 #pragma once
@@ -291,260 +290,18 @@ __global__ __launch_bounds__(BLOCK) void k_linetable(const uint16_t *__restrict_
     }
 }
 
-// ======================================================================= K4
-// Header offsets.  Tiles without a header exit immediately (for a genome that
-// is all but ~n_seq of them); the others are re-read row by row in position
-// order so hdr[] comes out sorted.
-__global__ __launch_bounds__(BLOCK) void k_hdr_scatter(const uint8_t *__restrict__ data, int64_t n, int prev_byte,
-                                                      const uint32_t *__restrict__ tile_hdr,
-                                                      const int64_t *__restrict__ grp_off, int64_t gbase,
-                                                      int64_t *__restrict__ hdr, int64_t cap) {
-    __shared__ uint32_t lds4[4];
-    const int64_t tile = blockIdx.x;
-    if (tile_hdr[tile] == 0) return;
-    const int tid = threadIdx.x;
-    const int64_t tbase = tile * (int64_t)TILE;
-    int64_t run = tile_prefix(tile_hdr, grp_off, tile, lds4);
-    for (int j = 0; j < UNROLL; ++j) {
-        const int64_t p = tbase + (int64_t)(j * BLOCK + tid) * CHUNK;
-        const uint4 v = load16(data, p, n);
-        uint32_t g = eq_mask16(v, 0x3E3E3E3Eu), hm = 0;
-        while (g) {
-            const int k = __ffs(g) - 1;
-            g &= g - 1;
-            const int64_t pos = p + k;
-            const int prev = pos ? (int)data[pos - 1] : prev_byte;
-            if (prev == '\n') hm |= 1u << k;
-        }
-        uint32_t total;
-        uint32_t r = block_excl_scan(__popc(hm), lds4, &total);
-        while (hm) {
-            const int k = __ffs(hm) - 1;
-            hm &= hm - 1;
-            if (run + r < cap) hdr[run + r] = gbase + p + k;
-            ++r;
-        }
-        run += total;
-    }
-}
-
 __global__ void k_set_i64(int64_t *p, int64_t v) { *p = v; }
 
-// ======================================================================= K5
-// FASTA record table: one thread per header.  Everything is a gather from the
-// line table; column semantics follow index.c:234-339 exactly, including the
-// quirks (elen taken from the header line only, index.c:266-269; blen/boff in
-// "position" units that over-count by one when the stream lacks a final '\n',
-// index.c:231 -- the virtual newline appended to nl[] reproduces that).
-//   n_nl counts the virtual EOF newline when present; all offsets are global,
-//   data is indexed with (offset - gbase).
+// FASTA record table columns (SoA, one entry per header line).  Column semantics follow
+// index.c:234-339 exactly, including the quirks (elen taken from the header line only,
+// index.c:266-269; blen/boff in "position" units that over-count by one when the stream lacks a
+// final '\n', index.c:231 -- the virtual end-of-stream newline reproduces that).  The kernels
+// that fill it live in fx_spanscan.hpp.
 struct FastaCols {
     int64_t *hoff, *boff, *blen, *slen, *llen, *hdr_line;
     int32_t *elen, *dlen, *name_len;
     uint32_t *bad;
 };
-
-__global__ __launch_bounds__(BLOCK) void k_fasta_rec(const uint8_t *__restrict__ data, int64_t gbase, int64_t n_bytes,
-                                                    const int64_t *__restrict__ nl, int64_t n_nl,
-                                                    const int64_t *__restrict__ hdr, int64_t n_hdr, int full_name,
-                                                    FastaCols c) {
-    const int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (k >= n_hdr) return;
-    const int64_t h = hdr[k];
-    const int64_t L = lower_bound(nl, n_nl, h);          // line index of the header line
-    if (L >= n_nl) {
-        // only possible for the LAST header of a non-final shard: its line ends in a later
-        // shard.  Leave a stub (dlen = -1) for the host-side stitch; name_len = local
-        // whitespace hit or -1.
-        int nlen = -1;
-        if (!full_name) {
-            const int64_t lim = n_bytes - (h + 1 - gbase);
-            const uint8_t *s = data + (h + 1 - gbase);
-            for (int64_t j = 0; j < lim; ++j) if (s[j] == ' ' || s[j] == '\t') { nlen = (int)j; break; }
-        }
-        c.hoff[k] = h; c.boff[k] = 0; c.blen[k] = 0; c.slen[k] = 0; c.llen[k] = 0; c.hdr_line[k] = n_nl;
-        c.elen[k] = 0; c.dlen[k] = -1; c.name_len[k] = nlen; c.bad[k] = 0;
-        return;
-    }
-    const int64_t e = nl[L];                             // its terminating newline
-    const int64_t boff = e + 1;                          // index.c:258  start = position
-    const int elen = (data[e - 1 - gbase] == '\r') ? 2 : 1;   // index.c:266-269
-    const int dlen = (int)(e - h) - elen;                // index.c:271
-    int name_len = dlen;
-    if (!full_name) {                                    // index.c:289-293: cut at ' ' or '\t'
-        const uint8_t *s = data + (h + 1 - gbase);
-        for (name_len = 0; name_len < dlen; ++name_len)
-            if (s[name_len] == ' ' || s[name_len] == '\t') break;
-    }
-    int64_t hn, Ln;
-    if (k + 1 < n_hdr) { hn = hdr[k + 1]; Ln = lower_bound(nl, n_nl, hn); }
-    else               { hn = nl[n_nl - 1] + 1; Ln = n_nl; }       // EOF "position"
-    const int64_t nseq = Ln - L - 1;                     // sequence lines of this record
-    const int64_t blen = hn - boff;                      // index.c:243,348
-    c.hoff[k] = h; c.boff[k] = boff; c.blen[k] = blen;
-    c.slen[k] = blen - (int64_t)elen * nseq;             // sum(line.l - line_end + 1), index.c:335-338
-    c.llen[k] = nseq > 0 ? nl[L + 1] - nl[L] : 0;        // first line length + 1, index.c:330-332
-    c.hdr_line[k] = L;
-    c.elen[k] = elen; c.dlen[k] = dlen; c.name_len[k] = name_len;
-    c.bad[k] = 0;
-}
-
-// ======================================================================= K6
-// bad_line (index.c:325-327): lines after the first of a record whose length
-// (+1) differs from the first line's.  Each wave owns a contiguous span of the
-// line table and walks it 64 lines at a time, keeping the record of the current
-// window in (wave-uniform) registers: one binary search per span, not per line.
-// A window that crosses a record boundary takes the per-lane search path.  Bad
-// lines are rare in well-formed files (the short last line of each record), so
-// counts are kept per lane and flushed with one atomic per (wave, record).
-constexpr int LINES_PER_WAVE = 128 * 32;                         // 32 windows of 128 lines (2 per lane)
-__global__ __launch_bounds__(BLOCK) void k_fasta_lines(const int64_t *__restrict__ nl, int64_t n_nl,
-                                                      const int64_t *__restrict__ hdr_line, int64_t n_hdr,
-                                                      const int64_t *__restrict__ llen, uint32_t *__restrict__ bad) {
-    const int lane = lane_id();
-    const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
-    const int64_t lo = wave * LINES_PER_WAVE;
-    if (lo >= n_nl) return;
-    const int64_t hi = (lo + LINES_PER_WAVE < n_nl) ? lo + LINES_PER_WAVE : n_nl;
-    int64_t rec = upper_bound(hdr_line, n_hdr, lo) - 1;          // record of line `lo` (-1: before the first header)
-    int64_t hl = rec >= 0 ? hdr_line[rec] : -2;                  // its header line index
-    int64_t next_hl = (rec + 1 < n_hdr) ? hdr_line[rec + 1] : n_nl;
-    int64_t ll = rec >= 0 ? llen[rec] : 0;
-    uint32_t cnt = 0;
-    for (int64_t i0 = lo; i0 < hi; i0 += 128) {
-        const int64_t i = i0 + 2 * lane;                         // this lane: lines i and i+1 (lo is even: 16-byte aligned pair)
-        const int64_t ilast = (i0 + 127 < hi) ? i0 + 127 : hi - 1;
-        if (ilast < next_hl) {                                   // whole window inside the current record
-            if (rec >= 0 && i < hi) {
-                int64_t a, b;
-                if (i + 1 < hi) { const longlong2 v = *reinterpret_cast<const longlong2 *>(nl + i); a = v.x; b = v.y; }
-                else            { a = nl[i]; b = a; }
-                const int64_t prev = i > 0 ? nl[i - 1] : -1;
-                if (i > hl + 1) cnt += (a - prev != ll);
-                if (i + 1 < hi && i + 1 > hl + 1) cnt += (b - a != ll);
-            }
-            continue;
-        }
-        // boundary window: flush, then every lane finds the record of each of its lines
-        cnt = wave_sum(cnt);
-        if (lane == 0 && cnt && rec >= 0) atomicAdd(&bad[rec], cnt);
-        cnt = 0;
-        for (int k = 0; k < 2; ++k) {
-            const int64_t j = i + k;
-            if (j < hi) {
-                const int64_t r = upper_bound(hdr_line, n_hdr, j) - 1;
-                if (r >= 0 && j > hdr_line[r] + 1 && nl[j] - nl[j - 1] != llen[r]) atomicAdd(&bad[r], 1u);
-            }
-        }
-        rec = upper_bound(hdr_line, n_hdr, ilast) - 1;           // state for the next window
-        hl = rec >= 0 ? hdr_line[rec] : -2;
-        next_hl = (rec + 1 < n_hdr) ? hdr_line[rec + 1] : n_nl;
-        ll = rec >= 0 ? llen[rec] : 0;
-    }
-    cnt = wave_sum(cnt);
-    if (lane == 0 && cnt && rec >= 0) atomicAdd(&bad[rec], cnt);
-}
-
-// Shard lead statistics (multi-GPU stitch).  The "lead" of a shard is
-// the run of lines before its first header: they belong to a record that
-// started in an earlier shard, whose first-line length (llen) is unknown here.
-// Because only `bad_line > 1` matters (index.c:237), the lead is summarised by
-// its two first distinct line lengths and their counts: with <= 2 distinct
-// values the owner can compute its bad-line count exactly, with >= 3 it is
-// >= 2 whatever llen turns out to be.
-//   lines considered: i in [1, lead_nl) (both delimiting newlines in the shard)
-//   pass 0: v = nl[1]-nl[0];  out[0] += count(d == v), out[1] = min i with d != v
-//   pass 1: v = d at out[1];  out[2] += count(d == v)
-__global__ __launch_bounds__(BLOCK) void k_lead_stats(const int64_t *__restrict__ nl, int64_t lead_nl, int pass,
-                                                     unsigned long long *__restrict__ out) {
-    if (lead_nl < 2) return;
-    int64_t v;
-    if (pass == 0) v = nl[1] - nl[0];
-    else {
-        const int64_t j = (int64_t)out[1];
-        if (j >= lead_nl) return;
-        v = nl[j] - nl[j - 1];
-    }
-    const int64_t stride = (int64_t)gridDim.x * BLOCK;
-    int64_t cnt = 0;
-    unsigned long long first_ne = ~0ull;
-    for (int64_t i = 1 + (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < lead_nl; i += stride) {
-        const int64_t d = nl[i] - nl[i - 1];
-        if (d == v) ++cnt;
-        else if (first_ne == ~0ull) first_ne = (unsigned long long)i;
-    }
-    cnt = wave_sum64(cnt);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        unsigned long long o = __shfl_xor(first_ne, d, 64);
-        first_ne = o < first_ne ? o : first_ne;
-    }
-    if (lane_id() == 0) {
-        if (cnt) atomicAdd(&out[pass == 0 ? 0 : 2], (unsigned long long)cnt);
-        if (pass == 0 && first_ne != ~0ull) atomicMin(&out[1], first_ne);
-    }
-}
-
-// Collect the boundary summary of a shard into S[0..FX_SUMMARY_WORDS) (one
-// workgroup; scalars by thread 0, the bounded whitespace search by all).
-// Field order = fx_shard_summary in include/fxgpu.h.
-constexpr int FX_SUMMARY_WORDS = 28;
-__global__ __launch_bounds__(BLOCK) void k_shard_summary(const uint8_t *__restrict__ data, int64_t n, int64_t gbase,
-                                                        int is_last, const int64_t *__restrict__ nl, int64_t n_nl,
-                                                        const int64_t *__restrict__ hdr, int64_t n_hdr, FastaCols c,
-                                                        const unsigned long long *__restrict__ stats, int64_t lead_nl,
-                                                        int64_t *__restrict__ S) {
-    __shared__ unsigned long long ws;
-    if (threadIdx.x == 0) ws = ~0ull;
-    __syncthreads();
-    const int64_t first_nl = n_nl ? nl[0] : -1;
-    int64_t lim = (first_nl >= 0 ? first_nl - gbase : n);
-    if (lim > 65536) lim = 65536;
-    for (int64_t j = threadIdx.x; j < lim; j += BLOCK)
-        if (data[j] == ' ' || data[j] == '\t') { atomicMin(&ws, (unsigned long long)j); break; }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    S[0] = gbase; S[1] = n; S[2] = is_last;
-    S[3] = n_nl; S[4] = first_nl; S[5] = n_nl > 1 ? nl[1] : -1; S[6] = n_nl ? nl[n_nl - 1] : -1;
-    S[7] = (first_nl > gbase) ? (int64_t)data[first_nl - 1 - gbase] : -1;
-    S[8] = data[0]; S[9] = data[n - 1];
-    S[10] = n_hdr; S[11] = n_hdr ? hdr[0] : -1; S[12] = n_hdr ? hdr[n_hdr - 1] : -1;
-    S[13] = lead_nl;
-    S[14] = (ws == ~0ull) ? -1 : gbase + (int64_t)ws;
-    int64_t v1 = 0, c1 = 0, v2 = 0, c2 = 0;
-    if (lead_nl >= 2) {
-        v1 = nl[1] - nl[0]; c1 = (int64_t)stats[0];
-        const int64_t j = (int64_t)stats[1];
-        if (j < lead_nl) { v2 = nl[j] - nl[j - 1]; c2 = (int64_t)stats[2]; }
-    }
-    S[15] = v1; S[16] = c1; S[17] = v2; S[18] = c2;
-    int64_t te = -1, tfe = -1, tna = 0, tbad = 0, telen = 0, tdlen = -1, tname = -1;
-    if (n_hdr) {
-        const int64_t k = n_hdr - 1;
-        tdlen = c.dlen[k]; tname = c.name_len[k];
-        if (tdlen >= 0) {
-            const int64_t L = c.hdr_line[k];
-            te = nl[L]; telen = c.elen[k];
-            tna = n_nl - L - 1;
-            if (L + 1 < n_nl) tfe = nl[L + 1];
-            tbad = c.bad[k];
-        }
-    }
-    S[19] = te; S[20] = tfe; S[21] = tna; S[22] = tbad; S[23] = telen; S[24] = tdlen; S[25] = tname;
-    S[26] = 0; S[27] = 0;
-}
-
-// norm (index.c:237,342) and stat.seqlen (index.c:253-254, 360-369)
-__global__ __launch_bounds__(BLOCK) void k_fasta_finalize(const uint32_t *__restrict__ bad,
-                                                         const int64_t *__restrict__ slen, int64_t n_hdr,
-                                                         int32_t *__restrict__ norm,
-                                                         unsigned long long *__restrict__ seqlen_total) {
-    const int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    int64_t s = 0;
-    if (k < n_hdr) { norm[k] = bad[k] > 1 ? 0 : 1; s = slen[k]; }
-    s = wave_sum64(s);
-    if (lane_id() == 0 && s) atomicAdd(seqlen_total, (unsigned long long)s);
-}
 
 // ======================================================================= K7
 // Batched fetch.  One wave per query: lanes read consecutive bytes of
@@ -936,7 +693,8 @@ __device__ __forceinline__ uint32_t cnt_eq16(const uint4 &v, uint32_t pat) {
 
 __global__ __launch_bounds__(BLOCK) void k_fasta_comp(const uint8_t *__restrict__ data, int64_t n, int64_t gbase,
                                                      const int64_t *__restrict__ hdr, const int64_t *__restrict__ boff,
-                                                     int64_t n_hdr, const uint32_t *__restrict__ tile_hdr,
+                                                     int64_t n_hdr, const int64_t *__restrict__ hdr_prefix,
+                                                     int64_t ngran, int gran_per_tile,
                                                      unsigned long long *__restrict__ comp) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t lds4[4];
@@ -948,7 +706,9 @@ __global__ __launch_bounds__(BLOCK) void k_fasta_comp(const uint8_t *__restrict_
     __syncthreads();
     // record that owns the first byte of the tile
     const int64_t rec0 = upper_bound(hdr, n_hdr, gbase + tbase) - 1;
-    const bool fast = rec0 >= 0 && tile_hdr[tile] == 0 && (gbase + tbase) >= boff[rec0];
+    // does a header line start inside this tile?  (hdr_prefix: header lines before each 4 KiB granule)
+    const int64_t g0 = tile * gran_per_tile, g1 = (g0 + gran_per_tile < ngran) ? g0 + gran_per_tile : ngran;
+    const bool fast = rec0 >= 0 && hdr_prefix[g1] == hdr_prefix[g0] && (gbase + tbase) >= boff[rec0];
     if (fast) {
         const uint32_t pats[10] = {0x41414141u, 0x43434343u, 0x47474747u, 0x54545454u, 0x4E4E4E4Eu,
                                    0x61616161u, 0x63636363u, 0x67676767u, 0x74747474u, 0x6E6E6E6Eu};

@@ -20,6 +20,7 @@
 
 #include "../../include/fxgpu.h"
 #include "fx_kernels.hpp"
+#include "fx_spanscan.hpp"
 #include "fx_inflate.hpp"
 
 using namespace fx;
@@ -72,11 +73,13 @@ template <class T> struct DevBuf {      // grow-only device array: rebuilds reus
 // ------------------------------------------------------------ kernel timing
 // Optional per-kernel HIP-event timing on the handle's own stream (bench.py's
 // roofline leg reads it; off by default so the hot path records no events).
-enum KernelId { K_SCAN = 0, K_TILE_SCAN, K_LINETABLE, K_HDR_SCATTER, K_FASTA_REC, K_FASTA_LINES, K_FASTA_FINALIZE,
-                K_FETCH, K_FASTA_COMP, K_FASTQ_REC, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_NKERN };
+enum KernelId { K_SPAN_SCAN = 0, K_GRAN_REDUCE, K_CHUNK_SCAN, K_GRAN_PREFIX, K_HDR_COLLECT, K_FASTA_REC, K_GRAN_LINES,
+                K_GRAN_EXACT, K_FASTA_FINALIZE, K_FETCH, K_FASTA_COMP, K_SCAN, K_TILE_SCAN, K_LINETABLE, K_FASTQ_REC,
+                K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_NKERN };
 static const char *const kKernelNames[K_NKERN] = {
-    "k_scan", "k_group_scan", "k_linetable", "k_hdr_scatter", "k_fasta_rec", "k_fasta_lines", "k_fasta_finalize",
-    "k_fetch", "k_fasta_comp", "k_fastq_rec", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_inflate"};
+    "k_span_scan", "k_gran_reduce", "k_chunk_scan", "k_gran_prefix", "k_hdr_collect", "k_fasta_rec", "k_gran_lines",
+    "k_gran_exact", "k_fasta_finalize", "k_fetch", "k_fasta_comp", "k_scan", "k_group_scan", "k_linetable", "k_fastq_rec",
+    "k_fastq_comp", "k_fastq_fetch", "k_bgzf_inflate"};
 
 struct Prof {
     bool on = false;
@@ -133,18 +136,24 @@ struct fx_handle {
     // scan products
     int64_t ntiles = 0;
     DevBuf<uint16_t> nlmask;
-    DevBuf<uint32_t> tile_nl, tile_hdr;
+    DevBuf<uint32_t> tile_nl;
     DevBuf<unsigned long long> grp_cnt;       // per-group (256 tiles) newline / header counts
     DevBuf<int64_t> grp_off;                  // their exclusive prefixes (+ totals)
     DevBuf<int64_t> nl;       // line table incl. virtual EOF newline
     int64_t n_nl = 0;         // entries in nl
     int64_t n_real_nl = 0;    // real '\n' bytes
-    bool scanned = false, scanned_hdr = false;
+    bool scanned = false;
+    // FASTA scan products (fx_spanscan.hpp): per-granule summaries and their prefixes
+    int64_t ngran = 0;
+    DevBuf<GranOut> gran;
+    DevBuf<uint32_t> hdr_grans, irr_grans;    // granules holding a header line / needing the exact walk
+    DevBuf<ChunkTot> chunks;
+    DevBuf<unsigned long long> ctl;           // Totals (8 words) + list counters
+    DevBuf<int64_t> nl_prefix, hdr_prefix, prevnl;
     // FASTA table
     DevBuf<int64_t> hdr, fa_boff, fa_blen, fa_slen, fa_llen, fa_hdr_line;
     DevBuf<int32_t> fa_elen, fa_norm, fa_dlen, fa_name_len;
     DevBuf<uint32_t> fa_bad;
-    DevBuf<unsigned long long> scalars;   // [0] = seqlen total
     int64_t n_hdr = 0, fa_seqlen = 0;
     bool fasta_built = false;
     // FASTQ table
@@ -217,7 +226,7 @@ extern "C" int fx_set_shard(fx_handle *h, int64_t base, int prev_byte, int is_la
     h->base = base;
     h->prev_byte = base == 0 ? '\n' : (prev_byte & 0xFF);
     h->is_last = is_last != 0;
-    h->scanned = h->scanned_hdr = h->fasta_built = h->fastq_built = false;
+    h->scanned = h->fasta_built = h->fastq_built = false;
     return FX_OK;
 }
 
@@ -507,53 +516,43 @@ extern "C" int fx_first_byte(fx_handle *h, int *out) {
 
 // -------------------------------------------------------------------- scan
 
-static int run_scan(fx_handle *h, bool want_hdr) {
-    // never cached: every build re-reads the stream (a build call is the whole job)
+// Newline mask -> line table, used by the FASTQ path (records are "every four lines", so the
+// line table is the natural intermediate there).  Never cached: every build re-reads the stream.
+static int run_scan(fx_handle *h) {
     int rc = use_device(h);
     if (rc) return rc;
     if (h->n <= 0) return fail(FX_EFORMAT, "empty input");
     h->ntiles = (h->n + TILE - 1) / TILE;
     const int64_t ngroups = (h->ntiles + GROUP - 1) / GROUP;
-    const int nsets = want_hdr ? 2 : 1;
     const int64_t nspans = (h->ntiles + SCAN_TILES - 1) / SCAN_TILES;
     if ((rc = h->nlmask.alloc(nspans * SCAN_TILES * TILE_CHUNKS))) return rc;
     if ((rc = h->tile_nl.alloc(h->ntiles))) return rc;
     if ((rc = h->grp_cnt.alloc(2 * ngroups)) || (rc = h->grp_off.alloc(2 * (ngroups + 1)))) return rc;
-    if (want_hdr && (rc = h->tile_hdr.alloc(h->ntiles))) return rc;
-    if (want_hdr)
-        FX_LAUNCH(h, K_SCAN, (k_scan<true>), dim3((unsigned)nspans), dim3(SCAN_BLOCK), h->d_data, h->n, h->prev_byte,
-                  h->nlmask.p, h->tile_nl.p, h->tile_hdr.p, h->ntiles);
-    else
-        FX_LAUNCH(h, K_SCAN, (k_scan<false>), dim3((unsigned)nspans), dim3(SCAN_BLOCK), h->d_data, h->n, h->prev_byte,
-                  h->nlmask.p, h->tile_nl.p, (uint32_t *)nullptr, h->ntiles);
+    FX_LAUNCH(h, K_SCAN, (k_scan<false>), dim3((unsigned)nspans), dim3(SCAN_BLOCK), h->d_data, h->n, h->prev_byte,
+              h->nlmask.p, h->tile_nl.p, (uint32_t *)nullptr, h->ntiles);
     FX_LAUNCH(h, K_TILE_SCAN, k_group_sum, dim3(nblocks(ngroups, BLOCK / 64)), dim3(BLOCK), h->tile_nl.p,
-              want_hdr ? h->tile_hdr.p : (const uint32_t *)nullptr, h->ntiles, ngroups, h->grp_cnt.p);
-    FX_LAUNCH(h, K_TILE_SCAN, k_group_scan, dim3(1), dim3(1024), h->grp_cnt.p, ngroups, nsets, h->grp_off.p);
+              (const uint32_t *)nullptr, h->ntiles, ngroups, h->grp_cnt.p);
+    FX_LAUNCH(h, K_TILE_SCAN, k_group_scan, dim3(1), dim3(1024), h->grp_cnt.p, ngroups, 1, h->grp_off.p);
     HIPCHK(hipGetLastError());
-    // The tables are sized from an estimate (previous build, else one line per 32 bytes) so the
-    // line-table and header kernels can be enqueued at once; the host fetches the real totals
-    // while they run and only re-runs them in the rare case the estimate was too small.
+    // The table is sized from an estimate (previous build, else one line per 32 bytes) so the
+    // line-table kernel can be enqueued at once; the host fetches the real total while it runs
+    // and only re-runs it in the rare case the estimate was too small.
     if (h->nl.cap < h->n / 32 + 1024 && (rc = h->nl.alloc(h->n / 32 + 1024))) return rc;
-    if (want_hdr && h->hdr.cap < 4096 && (rc = h->hdr.alloc(4096))) return rc;
-    int64_t tot_nl = 0, tot_hdr = 0;
+    int64_t tot_nl = 0;
     uint8_t last = 0;
     HIPCHK(hipMemcpyAsync(&tot_nl, h->grp_off.p + ngroups, 8, hipMemcpyDeviceToHost, h->stream));
-    if (want_hdr) HIPCHK(hipMemcpyAsync(&tot_hdr, h->grp_off.p + (ngroups + 1) + ngroups, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(&last, h->d_data + h->n - 1, 1, hipMemcpyDeviceToHost, h->stream));
     hipEvent_t got;
     HIPCHK(hipEventCreateWithFlags(&got, hipEventDisableTiming));
     HIPCHK(hipEventRecord(got, h->stream));
     FX_LAUNCH(h, K_LINETABLE, k_linetable, dim3((unsigned)h->ntiles), dim3(BLOCK), h->nlmask.p, h->tile_nl.p,
               h->grp_off.p, h->base, h->nl.p, h->nl.cap);
-    if (want_hdr)
-        FX_LAUNCH(h, K_HDR_SCATTER, k_hdr_scatter, dim3((unsigned)h->ntiles), dim3(BLOCK), h->d_data, h->n,
-                  h->prev_byte, h->tile_hdr.p, h->grp_off.p + (ngroups + 1), h->base, h->hdr.p, h->hdr.cap);
     hipError_t ee = hipEventSynchronize(got);
     (void)hipEventDestroy(got);
     if (ee != hipSuccess) return fail(FX_EDEVICE, "event sync: %s", hipGetErrorString(ee));
     h->n_real_nl = tot_nl;
     // virtual newline at end-of-stream when the last line is unterminated: reproduces
-    // `position += line.l + 1` for that line (index.c:231, fastq.c:148)
+    // `position += line.l + 1` for that line (fastq.c:148)
     const bool virt = h->is_last && last != '\n';
     h->n_nl = tot_nl + (virt ? 1 : 0);
     if (h->n_nl > h->nl.cap) {                               // estimate too small: exact size, run again
@@ -563,60 +562,98 @@ static int run_scan(fx_handle *h, bool want_hdr) {
                   h->grp_off.p, h->base, h->nl.p, h->nl.cap);
     }
     if (virt) hipLaunchKernelGGL(k_set_i64, dim3(1), dim3(1), 0, h->stream, h->nl.p + tot_nl, h->base + h->n);
-    if (want_hdr) {
-        h->n_hdr = tot_hdr;
-        if (tot_hdr > h->hdr.cap) {
-            HIPCHK(hipStreamSynchronize(h->stream));
-            if ((rc = h->hdr.alloc(tot_hdr + tot_hdr / 16))) return rc;
-            FX_LAUNCH(h, K_HDR_SCATTER, k_hdr_scatter, dim3((unsigned)h->ntiles), dim3(BLOCK), h->d_data, h->n,
-                      h->prev_byte, h->tile_hdr.p, h->grp_off.p + (ngroups + 1), h->base, h->hdr.p, h->hdr.cap);
-        }
-        h->scanned_hdr = true;
-    }
     HIPCHK(hipGetLastError());
     h->scanned = true;
     return FX_OK;
 }
 
 // ------------------------------------------------------------- FASTA build
-extern "C" int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out) {
-    if (!h) return fail(FX_EINVAL, "null handle");
-    int rc = run_scan(h, true);
-    if (rc) return rc;
-    const int64_t nh = h->n_hdr;
-    if (nh <= 0) {
-        if (h->base == 0 && h->is_last) return fail(FX_EFORMAT, "no FASTA header line ('>') found");
-        // a shard that lies entirely inside one record: empty local table, summary still valid
-        h->fa_seqlen = 0;
-        h->fasta_built = true;
-        if (out) { out->n_seq = 0; out->seq_len = 0; out->n_lines = h->n_nl; out->n_bytes = h->n; }
-        return FX_OK;
-    }
-    if ((rc = h->fa_boff.alloc(nh)) || (rc = h->fa_blen.alloc(nh)) || (rc = h->fa_slen.alloc(nh)) ||
-        (rc = h->fa_llen.alloc(nh)) || (rc = h->fa_hdr_line.alloc(nh)) || (rc = h->fa_elen.alloc(nh)) ||
-        (rc = h->fa_norm.alloc(nh)) || (rc = h->fa_dlen.alloc(nh)) || (rc = h->fa_name_len.alloc(nh)) ||
-        (rc = h->fa_bad.alloc(nh)) || (rc = h->scalars.alloc(8)))
-        return rc;
-    HIPCHK(hipMemsetAsync(h->scalars.p, 0, 8 * sizeof(unsigned long long), h->stream));
+static ScanCtx scan_ctx(const fx_handle *h) {
+    ScanCtx x;
+    x.data = h->d_data; x.n = h->n; x.gbase = h->base; x.ngran = h->ngran;
+    x.go = h->gran.p; x.nl_prefix = h->nl_prefix.p; x.hdr_prefix = h->hdr_prefix.p; x.prevnl = h->prevnl.p;
+    return x;
+}
+static FastaCols fasta_cols(fx_handle *h) {
     FastaCols c;
-    c.hoff = h->hdr.p;   // hoff IS hdr[]; the kernel rewrites the same value
-    c.boff = h->fa_boff.p; c.blen = h->fa_blen.p; c.slen = h->fa_slen.p; c.llen = h->fa_llen.p;
+    c.hoff = h->hdr.p; c.boff = h->fa_boff.p; c.blen = h->fa_blen.p; c.slen = h->fa_slen.p; c.llen = h->fa_llen.p;
     c.hdr_line = h->fa_hdr_line.p; c.elen = h->fa_elen.p; c.dlen = h->fa_dlen.p; c.name_len = h->fa_name_len.p;
     c.bad = h->fa_bad.p;
-    FX_LAUNCH(h, K_FASTA_REC, k_fasta_rec, dim3(nblocks(nh, BLOCK)), dim3(BLOCK), h->d_data, h->base, h->n, h->nl.p,
-                       h->n_nl, h->hdr.p, nh, full_name, c);
-    const unsigned lb = nblocks(h->n_nl, LINES_PER_WAVE * (BLOCK / 64));
-    FX_LAUNCH(h, K_FASTA_LINES, k_fasta_lines, dim3(lb), dim3(BLOCK), h->nl.p, h->n_nl, h->fa_hdr_line.p, nh,
-                       h->fa_llen.p, h->fa_bad.p);
-    FX_LAUNCH(h, K_FASTA_FINALIZE, k_fasta_finalize, dim3(nblocks(nh, BLOCK)), dim3(BLOCK), h->fa_bad.p,
-                       h->fa_slen.p, nh, h->fa_norm.p, h->scalars.p);
+    return c;
+}
+static int alloc_fasta_table(fx_handle *h, int64_t cap) {
+    int rc;
+    if ((rc = h->hdr.alloc(cap)) || (rc = h->fa_hdr_line.alloc(cap)) || (rc = h->fa_boff.alloc(cap)) ||
+        (rc = h->fa_blen.alloc(cap)) || (rc = h->fa_slen.alloc(cap)) || (rc = h->fa_llen.alloc(cap)) ||
+        (rc = h->fa_elen.alloc(cap)) || (rc = h->fa_norm.alloc(cap)) || (rc = h->fa_dlen.alloc(cap)) ||
+        (rc = h->fa_name_len.alloc(cap)) || (rc = h->fa_bad.alloc(cap)))
+        return rc;
+    return FX_OK;
+}
+
+// ctl layout (64 words): [0..8) Totals, [8] / [9] = header-granule / irregular list counts (u32), [16..44) shard summary
+static Totals *ctl_totals(fx_handle *h) { return (Totals *)h->ctl.p; }
+static uint32_t *ctl_counter(fx_handle *h, int i) { return (uint32_t *)(h->ctl.p + 8 + i); }
+
+extern "C" int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (h->n <= 0) return fail(FX_EFORMAT, "empty input");
+    // ---- the one pass over the stream: 4 KiB granule summaries (fx_spanscan.hpp)
+    const int64_t nfull = h->n / GRAN, ngran = nfull + 1, nchunks = (ngran + CHUNK_GRANS - 1) / CHUNK_GRANS;
+    h->ngran = ngran;
+    if ((rc = h->gran.alloc(ngran)) || (rc = h->hdr_grans.alloc(ngran)) || (rc = h->irr_grans.alloc(ngran)) ||
+        (rc = h->chunks.alloc(nchunks)) || (rc = h->ctl.alloc(64)) || (rc = h->nl_prefix.alloc(ngran + 1)) ||
+        (rc = h->hdr_prefix.alloc(ngran + 1)) || (rc = h->prevnl.alloc(ngran + 1)))
+        return rc;
+    if (h->hdr.cap < 4096 && (rc = alloc_fasta_table(h, 4096))) return rc;
+    HIPCHK(hipMemsetAsync(h->ctl.p, 0, 16 * sizeof(unsigned long long), h->stream));
+    GranList hgl{h->hdr_grans.p, ctl_counter(h, 0)}, irr{h->irr_grans.p, ctl_counter(h, 1)};
+    const int SCAN_WG = 512;                                  // 8 waves = 8 granules per workgroup (tools/scanbench2.hip)
+    if (nfull > 0)
+        FX_LAUNCH(h, K_SPAN_SCAN, (k_span_scan<true>), dim3(nblocks(nfull * 64, SCAN_WG)), dim3(SCAN_WG), h->d_data, h->n,
+                  h->prev_byte, (int)h->is_last, (int64_t)0, nfull, h->gran.p, hgl);
+    hipLaunchKernelGGL((k_span_scan<false>), dim3(1), dim3(64), 0, h->stream, h->d_data, h->n, h->prev_byte, (int)h->is_last,
+                       nfull, ngran, h->gran.p, hgl);
+    FX_LAUNCH(h, K_GRAN_REDUCE, k_gran_reduce, dim3((unsigned)nchunks), dim3(CHUNK_GRANS), h->gran.p, ngran, h->base,
+              h->chunks.p);
+    FX_LAUNCH(h, K_CHUNK_SCAN, k_chunk_scan, dim3(1), dim3(1024), h->chunks.p, nchunks, ctl_totals(h));
+    FX_LAUNCH(h, K_GRAN_PREFIX, k_gran_prefix, dim3((unsigned)nchunks), dim3(CHUNK_GRANS), h->gran.p, ngran, h->base,
+              h->chunks.p, ctl_totals(h), h->nl_prefix.p, h->hdr_prefix.p, h->prevnl.p);
     HIPCHK(hipGetLastError());
-    unsigned long long tot = 0;
-    HIPCHK(hipMemcpyAsync(&tot, h->scalars.p, 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->fa_seqlen = (int64_t)tot;
+    // ---- records.  The tables are sized from an estimate (previous build, else 4096 records) so that
+    // everything is enqueued without a host round trip; if more header lines turn up, grow and redo
+    // only this cheap part.
+    const ScanCtx x = scan_ctx(h);
+    Totals tot;
+    for (;;) {
+        const int64_t cap = h->hdr.cap;
+        const FastaCols c = fasta_cols(h);
+        const RecView rv{h->fa_boff.p, h->fa_llen.p, h->fa_dlen.p, h->fa_bad.p};
+        FX_LAUNCH(h, K_HDR_COLLECT, k_hdr_collect, dim3(512), dim3(BLOCK), h->d_data, h->n, h->base, h->prev_byte,
+                  (int)h->is_last, hgl, h->nl_prefix.p, h->hdr_prefix.p, h->hdr.p, h->fa_hdr_line.p, cap);
+        FX_LAUNCH(h, K_FASTA_REC, k_fasta_rec2, dim3(nblocks(cap, BLOCK)), dim3(BLOCK), x, ctl_totals(h), cap, h->hdr.p,
+                  h->fa_hdr_line.p, full_name, c);
+        FX_LAUNCH(h, K_GRAN_LINES, k_gran_lines, dim3(nblocks(ngran, BLOCK)), dim3(BLOCK), x, rv, cap, irr);
+        FX_LAUNCH(h, K_GRAN_EXACT, k_gran_exact, dim3(512), dim3(BLOCK), x, rv, cap, irr, (int)h->is_last, h->hdr.p);
+        FX_LAUNCH(h, K_FASTA_FINALIZE, k_fasta_finalize2, dim3(nblocks(cap, BLOCK)), dim3(BLOCK), h->fa_bad.p,
+                  h->fa_slen.p, cap, h->fa_norm.p, ctl_totals(h));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&tot, ctl_totals(h), sizeof tot, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (tot.n_hdr <= cap) break;
+        if ((rc = alloc_fasta_table(h, tot.n_hdr + tot.n_hdr / 16 + 16))) return rc;
+        HIPCHK(hipMemsetAsync(ctl_counter(h, 1), 0, 4, h->stream));                   // irregular list is rebuilt
+        HIPCHK(hipMemsetAsync(&ctl_totals(h)->seq_len, 0, 8, h->stream));
+    }
+    h->n_hdr = tot.n_hdr;
+    h->n_nl = tot.n_nl;
+    h->fa_seqlen = tot.seq_len;
     h->fasta_built = true;
-    if (out) { out->n_seq = nh; out->seq_len = h->fa_seqlen; out->n_lines = h->n_nl; out->n_bytes = h->n; }
+    if (tot.n_hdr <= 0 && h->base == 0 && h->is_last) { h->fasta_built = false; return fail(FX_EFORMAT, "no FASTA header line ('>') found"); }
+    // (a shard that lies entirely inside one record has an empty local table; its summary is still valid)
+    if (out) { out->n_seq = h->n_hdr; out->seq_len = h->fa_seqlen; out->n_lines = h->n_nl; out->n_bytes = h->n; }
     return FX_OK;
 }
 
@@ -654,8 +691,8 @@ extern "C" int fx_fasta_comp(fx_handle *h, int where, int64_t *comp) {
     unsigned long long *d = (unsigned long long *)comp;
     if (where != FX_DEVICE) { if ((rc = tmp.alloc(n))) return rc; d = tmp.p; }
     HIPCHK(hipMemsetAsync(d, 0, (size_t)n * 8, h->stream));
-    FX_LAUNCH(h, K_FASTA_COMP, k_fasta_comp, dim3((unsigned)h->ntiles), dim3(BLOCK), h->d_data, h->n, h->base,
-                       h->hdr.p, h->fa_boff.p, h->n_hdr, h->tile_hdr.p, d);
+    FX_LAUNCH(h, K_FASTA_COMP, k_fasta_comp, dim3((unsigned)((h->n + TILE - 1) / TILE)), dim3(BLOCK), h->d_data, h->n, h->base,
+                       h->hdr.p, h->fa_boff.p, h->n_hdr, h->hdr_prefix.p, h->ngran, TILE / GRAN, d);
     HIPCHK(hipGetLastError());
     if (where != FX_DEVICE) HIPCHK(hipMemcpyAsync(comp, d, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -711,7 +748,7 @@ extern "C" int fx_set_halo(fx_handle *h, int64_t halo_bytes) {
 
 extern "C" int fx_fastq_scan(fx_handle *h, int64_t *n_nl_core, int64_t *last_nl_core) {
     if (!h) return fail(FX_EINVAL, "null handle");
-    int rc = run_scan(h, false);
+    int rc = run_scan(h);
     if (rc) return rc;
     int64_t res[2] = {h->n_nl, -1};
     DevBuf<int64_t> d;
@@ -732,7 +769,7 @@ extern "C" int fx_fastq_build_ctx(fx_handle *h, int64_t line_offset, int64_t pre
 
 extern "C" int fx_fastq_build(fx_handle *h, fx_fastq_summary *out) {
     if (!h) return fail(FX_EINVAL, "null handle");
-    int rc = run_scan(h, false);
+    int rc = run_scan(h);
     if (rc) return rc;
     return fastq_records(h, 0, -1, out);
 }
@@ -1060,7 +1097,7 @@ extern "C" int fx_prof_enable(fx_handle *h, int on) {
     int rc = fx_sync(h);
     if (rc) return rc;
     h->prof.on = on != 0;
-    h->prof.mask = (on == 2) ? (1u << K_SCAN) : ~0u;       // 2: only the dominant kernel (2 events per build)
+    h->prof.mask = (on == 2) ? ((1u << K_SPAN_SCAN) | (1u << K_SCAN)) : ~0u;   // 2: only the dominant kernel (2 events per build)
     return FX_OK;
 }
 
@@ -1087,44 +1124,16 @@ extern "C" int fx_prof_read(fx_handle *h, int id, double *total_ms, int64_t *lau
 }
 
 extern "C" int fx_shard_summary_get(fx_handle *h, fx_shard_summary *out) {
-    static_assert(sizeof(fx_shard_summary) == FX_SUMMARY_WORDS * 8, "summary layout");
+    static_assert(sizeof(fx_shard_summary) == 28 * 8, "summary layout");
     if (!h || !out) return fail(FX_EINVAL, "null argument");
-    if (!h->fasta_built && !h->scanned_hdr) return fail(FX_ESTATE, "fx_fasta_build has not run");
+    if (!h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build has not run");
     int rc = use_device(h);
     if (rc) return rc;
-    DevBuf<unsigned long long> stats;
-    DevBuf<int64_t> S;
-    if ((rc = stats.alloc(4)) || (rc = S.alloc(FX_SUMMARY_WORDS))) return rc;
-    const unsigned long long init[4] = {0ull, ~0ull, 0ull, 0ull};
-    HIPCHK(hipMemcpyAsync(stats.p, init, sizeof init, hipMemcpyHostToDevice, h->stream));
-    // lead_nl = newlines before the first local header
-    int64_t lead_nl = h->n_nl;
-    if (h->n_hdr > 0) {
-        int64_t first_hdr = 0;
-        HIPCHK(hipMemcpyAsync(&first_hdr, h->hdr.p, 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        // binary search over the device line table from the host would cost ~25 round trips;
-        // the record kernel already did it: hdr_line[0] is exactly that rank.
-        HIPCHK(hipMemcpyAsync(&lead_nl, h->fa_hdr_line.p, 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        (void)first_hdr;
-    } else {
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
-    if (lead_nl >= 2) {
-        const unsigned nb = (unsigned)std::min<int64_t>(nblocks(lead_nl, BLOCK), 2048);
-        hipLaunchKernelGGL(k_lead_stats, dim3(nb), dim3(BLOCK), 0, h->stream, h->nl.p, lead_nl, 0, stats.p);
-        hipLaunchKernelGGL(k_lead_stats, dim3(nb), dim3(BLOCK), 0, h->stream, h->nl.p, lead_nl, 1, stats.p);
-    }
-    FastaCols c;
-    memset(&c, 0, sizeof c);
-    c.hoff = h->hdr.p; c.boff = h->fa_boff.p; c.blen = h->fa_blen.p; c.slen = h->fa_slen.p; c.llen = h->fa_llen.p;
-    c.hdr_line = h->fa_hdr_line.p; c.elen = h->fa_elen.p; c.dlen = h->fa_dlen.p; c.name_len = h->fa_name_len.p;
-    c.bad = h->fa_bad.p;
-    hipLaunchKernelGGL(k_shard_summary, dim3(1), dim3(BLOCK), 0, h->stream, h->d_data, h->n, h->base, (int)h->is_last,
-                       h->nl.p, h->n_nl, h->hdr.p, h->n_hdr, c, stats.p, lead_nl, S.p);
+    int64_t *S = (int64_t *)(h->ctl.p + 16);                    // 28 words of the control block (no allocation per call)
+    hipLaunchKernelGGL(k_shard_summary2, dim3(1), dim3(BLOCK), 0, h->stream, scan_ctx(h), (int)h->is_last, ctl_totals(h),
+                       h->hdr.cap, h->hdr.p, h->fa_hdr_line.p, fasta_cols(h), S);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, S.p, sizeof(fx_shard_summary), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(out, S, sizeof(fx_shard_summary), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return FX_OK;
 }

@@ -134,8 +134,8 @@ def allgather_summaries(mine, world, device="cpu"):
 
 
 def pmc_traffic(root):
-    """HBM bytes per k_scan launch from the committed rocprofv3 --pmc summary (or None)."""
-    p = os.path.join(root, "profiles", "pmc_k_scan.json")
+    """HBM bytes per k_span_scan launch from the committed rocprofv3 --pmc summary (or None)."""
+    p = os.path.join(root, "profiles", "pmc_k_span_scan.json")
     try:
         with open(p) as f:
             return json.load(f).get("hbm_bytes_per_launch")
