@@ -299,7 +299,7 @@ __global__ void k_set_i64(int64_t *p, int64_t v) { *p = v; }
 // that fill it live in fx_spanscan.hpp.
 struct FastaCols {
     int64_t *hoff, *boff, *blen, *slen, *llen, *hdr_line;
-    int32_t *elen, *dlen, *name_len;
+    int32_t *elen, *dlen, *name_len, *norm;
     uint32_t *bad;
 };
 

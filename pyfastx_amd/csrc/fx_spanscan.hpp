@@ -42,8 +42,23 @@ constexpr int SPAN_GRANS = 65536 / GRAN;
 constexpr int SPAN = GRAN * SPAN_GRANS;     // 64 KiB: granularity of the post-scan passes
 constexpr uint32_t SP_NONE = 0xFFFFFFFFu;
 
-// per-granule summary written by phase 1 (40 bytes, 8-byte aligned)
-struct GranOut { uint32_t n, h, first, last, v1, c1, v2, c2, ovf, pad; };
+// per-granule summary: in registers (GranOut) and as stored by phase 1 (GranPk, one 16-byte word:
+// every field is < 2^13 because it counts or addresses bytes of one granule)
+struct GranOut { uint32_t n, h, first, last, v1, c1, v2, c2, ovf; };   // first/last: SP_NONE when n == 0
+struct __attribute__((aligned(16))) GranPk { uint32_t nh, fl, d1, d2; };
+__device__ __forceinline__ GranPk gran_pack(const GranOut &o) {
+    GranPk p;
+    p.nh = o.n | (o.h << 16); p.fl = (o.first & 0xFFFFu) | (o.last << 16);
+    p.d1 = o.v1 | (o.c1 << 16); p.d2 = o.v2 | (o.c2 << 16) | (o.ovf << 31);
+    return p;
+}
+__device__ __forceinline__ GranOut gran_unpack(const GranPk &p) {
+    GranOut o;
+    o.n = p.nh & 0xFFFFu; o.h = p.nh >> 16;
+    o.first = o.n ? (p.fl & 0xFFFFu) : SP_NONE; o.last = o.n ? (p.fl >> 16) : SP_NONE;
+    o.v1 = p.d1 & 0xFFFFu; o.c1 = p.d1 >> 16; o.v2 = p.d2 & 0xFFFFu; o.c2 = (p.d2 >> 16) & 0x7FFFu; o.ovf = p.d2 >> 31;
+    return o;
+}
 
 struct DiffSet {                // first two distinct values with counts (+ overflow)
     uint32_t v1, c1, v2, c2, ovf;
@@ -122,7 +137,7 @@ struct GranList { uint32_t *g; uint32_t *count; };
 
 template <bool FULL>
 __device__ __forceinline__ void granule(const uint8_t *__restrict__ data, int64_t n, int prev_byte, int is_last,
-                                        int64_t g, GranOut *__restrict__ out, const GranList &hgl, uint32_t &L) {
+                                        int64_t g, GranPk *__restrict__ out, const GranList &hgl, uint32_t &L) {
     const int lane = lane_id();
     const int64_t sbase = g * (int64_t)GRAN;
 
@@ -221,88 +236,44 @@ __device__ __forceinline__ void granule(const uint8_t *__restrict__ data, int64_
     if (lane == 0) {
         GranOut o;
         o.n = n_w; o.h = h_w; o.first = (uint32_t)first_w; o.last = (uint32_t)carry;
-        o.v1 = wd.v1; o.c1 = wd.c1; o.v2 = wd.v2; o.c2 = wd.c2; o.ovf = wd.ovf; o.pad = 0;
-        out[g] = o;
+        o.v1 = wd.v1; o.c1 = wd.c1; o.v2 = wd.v2; o.c2 = wd.c2; o.ovf = wd.ovf;
+        out[g] = gran_pack(o);
         if (h_w) hgl.g[atomicAdd(hgl.count, 1u)] = (uint32_t)g;
     }
 }
 
-// grid-stride over granules, one wave per granule per step.  FULL = true covers the n / GRAN granules
-// that lie entirely inside the stream; the last, partial one (which also holds the virtual end-of-stream
-// newline) is a single-wave launch of the FULL = false instantiation, so its bounds-checked loads
-// cost the main kernel neither registers nor branches.
-template <bool FULL>
+// One wave per granule.  Only the granules that lie entirely inside the stream (n / GRAN of them) are
+// launched here; the last, partial one (which also holds the virtual end-of-stream newline) is done by
+// k_gran_reduce with the FULL = false instantiation, so its bounds-checked loads cost this kernel
+// neither registers nor branches.
 __global__ __launch_bounds__(1024) void k_span_scan(const uint8_t *__restrict__ data, int64_t n, int prev_byte,
-                                                    int is_last, int64_t g_begin, int64_t g_end,
-                                                    GranOut *__restrict__ out, GranList hgl) {
+                                                   int is_last, int64_t g_end, GranPk *__restrict__ out, GranList hgl) {
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     uint32_t L = 0;
-    for (int64_t g = g_begin + wave; g < g_end; g += nwaves) granule<FULL>(data, n, prev_byte, is_last, g, out, hgl, L);
-}
-
-// ============================================================== header collection
-// One wave per granule that holds a header line (hgl): re-read its 4 KiB, exact masks, and write
-// every header's offset and the number of stream newlines before it straight to their final,
-// position-ordered slots: hdr[hdr_prefix[g] + rank], hdr_line[...] = nl_prefix[g] + newlines before.
-__global__ __launch_bounds__(BLOCK) void k_hdr_collect(const uint8_t *__restrict__ data, int64_t n, int64_t gbase,
-                                                      int prev_byte, int is_last, GranList hgl,
-                                                      const int64_t *__restrict__ nl_prefix,
-                                                      const int64_t *__restrict__ hdr_prefix,
-                                                      int64_t *__restrict__ hdr, int64_t *__restrict__ hdr_line, int64_t cap) {
-    const int lane = lane_id();
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int64_t cnt = *hgl.count;
-    for (int64_t i = wave; i < cnt; i += nwaves) {
-        const int64_t g = hgl.g[i];
-        const int64_t sbase = g * (int64_t)GRAN;
-        int64_t hrank = hdr_prefix[g], nlb = nl_prefix[g];
-        for (int j = 0; j < GR_ROWS; ++j) {
-            const int64_t p = sbase + j * 1024 + lane * CHUNK;
-            uint4 v = load16(data, p, n);
-            if (is_last && n >= p && n < p + CHUNK && n > 0 && data[n - 1] != '\n') {
-                const int k = (int)(n - p);
-                const uint32_t b = 0x0Au << ((k & 3) * 8);
-                if ((k >> 2) == 0) v.x |= b; else if ((k >> 2) == 1) v.y |= b; else if ((k >> 2) == 2) v.z |= b; else v.w |= b;
-            }
-            const uint32_t nlm = eq_mask16(v, 0x0A0A0A0Au);
-            uint32_t hm = header_mask16(v, nlm, data, p, prev_byte);
-            const uint32_t cn = __popc(nlm), ch = __popc(hm);
-            const uint32_t in = wave_incl_scan(cn), ih = wave_incl_scan(ch);
-            int64_t r = hrank + ih - ch;
-            const int64_t nb0 = nlb + in - cn;
-            while (hm) {
-                const int k = __ffs(hm) - 1;
-                hm &= hm - 1;
-                if (r < cap) { hdr[r] = gbase + p + k; hdr_line[r] = nb0 + __popc(nlm & ((1u << k) - 1u)); }
-                ++r;
-            }
-            nlb += (uint32_t)__shfl((int)in, 63, 64);
-            hrank += (uint32_t)__shfl((int)ih, 63, 64);
-        }
-    }
+    for (int64_t g = wave; g < g_end; g += nwaves) granule<true>(data, n, prev_byte, is_last, g, out, hgl, L);
 }
 
 // ============================================================== granule prefixes
-// Exclusive prefixes over the granule summaries, three small kernels (no atomics, deterministic):
-//   k_gran_reduce   one workgroup per CHUNK of 256 granules (1 MiB of stream): totals
-//   k_chunk_scan    one workgroup: exclusive scan of the chunk totals (+ grand totals)
-//   k_gran_prefix   one workgroup per chunk: per-granule prefixes = chunk base + local scan
+// Exclusive prefixes over the granule summaries in two small kernels (no atomics, deterministic):
+//   k_gran_reduce   one workgroup per CHUNK of 1024 granules (4 MiB of stream): totals.  The workgroup
+//                   that owns the last granule first computes it (the partial tail of the stream).
+//   k_gran_prefix   one workgroup per chunk: base = join of the totals of the chunks before it (one
+//                   load per thread up to 4 GiB of stream), then a local scan; the last one writes Totals.
 // nl_prefix[g] / hdr_prefix[g] = newlines / header lines before granule g (entry [ngran] = totals),
 // prevnl[g] = global offset of the last newline before granule g (-1: none in this shard).
-constexpr int CHUNK_GRANS = 256;
+constexpr int CHUNK_GRANS = 1024;
 struct ChunkTot { long long n, h, last, pad; };
 struct Totals {                       // device-side scalars of one build, copied to the host once at the end
-    long long n_nl, n_hdr, last_nl, seq_len, n_hdr_gran, n_irregular, pad0, pad1;
+    long long n_nl, n_hdr, last_nl, seq_len, pad0, pad1, pad2, pad3;
 };
 
-__device__ __forceinline__ long long shfl_xor64(long long v, int d) {
-    const int lo = __shfl_xor((int)(v & 0xFFFFFFFFll), d, 64), hi = __shfl_xor((int)(v >> 32), d, 64);
-    return ((long long)hi << 32) | (unsigned int)lo;
-}
 __device__ __forceinline__ long long shfl_up64(long long v, int d) {
     const int lo = __shfl_up((int)(v & 0xFFFFFFFFll), d, 64), hi = __shfl_up((int)(v >> 32), d, 64);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ long long shfl64(long long v, int l) {
+    const int lo = __shfl((int)(v & 0xFFFFFFFFll), l, 64), hi = __shfl((int)(v >> 32), l, 64);
     return ((long long)hi << 32) | (unsigned int)lo;
 }
 struct Tri { long long n, h, last; };
@@ -316,7 +287,8 @@ __device__ __forceinline__ Tri tri_wave_incl(Tri v) {
     }
     return v;
 }
-// inclusive scan of v over the threads of the workgroup (<= 1024 threads); *total = join of all
+// inclusive scan of v over the threads of the workgroup (<= 1024 threads); *total = join of all;
+// lds (16 entries) keeps the per-wave totals until the next call
 __device__ __forceinline__ Tri tri_block_incl(Tri v, Tri *lds, Tri *total) {
     const int w = threadIdx.x >> 6, l = lane_id(), nw = (blockDim.x + 63) >> 6;
     const Tri inc = tri_wave_incl(v);
@@ -328,74 +300,90 @@ __device__ __forceinline__ Tri tri_block_incl(Tri v, Tri *lds, Tri *total) {
     *total = tot;
     return tri_join(base, inc);
 }
-__device__ __forceinline__ Tri gran_tri(const GranOut *__restrict__ go, int64_t g, int64_t ngran, int64_t gbase) {
+__device__ __forceinline__ Tri gran_tri(const GranPk *__restrict__ go, int64_t g, int64_t ngran, int64_t gbase) {
     if (g >= ngran) return Tri{0, 0, -1};
-    const GranOut o = go[g];
+    const GranOut o = gran_unpack(go[g]);
     return Tri{(long long)o.n, (long long)o.h, o.n ? gbase + g * (long long)GRAN + o.last : -1};
 }
 
-__global__ __launch_bounds__(CHUNK_GRANS) void k_gran_reduce(const GranOut *__restrict__ go, int64_t ngran, int64_t gbase,
-                                                            ChunkTot *__restrict__ ct) {
+__global__ __launch_bounds__(CHUNK_GRANS) void k_gran_reduce(const uint8_t *__restrict__ data, int64_t n, int prev_byte,
+                                                            int is_last, GranList hgl, GranPk *__restrict__ go,
+                                                            int64_t ngran, int64_t gbase, ChunkTot *__restrict__ ct) {
     __shared__ Tri lds[CHUNK_GRANS / 64];
+    if (blockIdx.x == gridDim.x - 1) {          // the tail granule (index ngran - 1) belongs to the last chunk
+        if (threadIdx.x < 64) { uint32_t L = 0; granule<false>(data, n, prev_byte, is_last, ngran - 1, go, hgl, L); }
+        __threadfence_block();
+        __syncthreads();
+    }
     Tri tot;
     tri_block_incl(gran_tri(go, (int64_t)blockIdx.x * CHUNK_GRANS + threadIdx.x, ngran, gbase), lds, &tot);
     if (threadIdx.x == 0) ct[blockIdx.x] = ChunkTot{tot.n, tot.h, tot.last, 0};
 }
 
-// in place: ct[c] becomes the join of the chunks before c; tot gets the grand totals
-__global__ __launch_bounds__(1024) void k_chunk_scan(ChunkTot *__restrict__ ct, int64_t nchunks, Totals *__restrict__ tot) {
-    __shared__ Tri lds[16];
-    __shared__ Tri carry_s;
-    if (threadIdx.x == 0) carry_s = Tri{0, 0, -1};
-    __syncthreads();
-    for (int64_t c0 = 0; c0 < nchunks; c0 += 1024) {
-        const int64_t c = c0 + threadIdx.x;
-        Tri v{0, 0, -1};
-        if (c < nchunks) { const ChunkTot t = ct[c]; v = Tri{t.n, t.h, t.last}; }
-        Tri total;
-        const Tri inc = tri_block_incl(v, lds, &total);
-        const Tri carry = carry_s;
-        // exclusive = carry + (inclusive of the previous thread); recover it from the inclusive value of lane-1
-        Tri prev{shfl_up64(inc.n, 1), shfl_up64(inc.h, 1), shfl_up64(inc.last, 1)};
-        if (lane_id() == 0) {            // first lane of a wave: inclusive value of the last lane of the previous wave
-            prev = Tri{0, 0, -1};
-            for (int i = 0; i < (int)(threadIdx.x >> 6); ++i) prev = tri_join(prev, lds[i]);
-        }
-        const Tri ex = tri_join(carry, prev);
-        if (c < nchunks) ct[c] = ChunkTot{ex.n, ex.h, ex.last, 0};
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = tri_join(carry, total);
-        __syncthreads();
+// inclusive scan of three 32-bit values (sum, sum, max) over the workgroup; lds: 3 x 16 words
+struct Tri32 { uint32_t n, h; int32_t last; };
+__device__ __forceinline__ Tri32 tri32_block_incl(Tri32 v, uint32_t (*lds)[16], Tri32 *total) {
+    const int w = threadIdx.x >> 6, l = lane_id(), nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t a = __shfl_up(v.n, d, 64), b = __shfl_up(v.h, d, 64);
+        const int32_t c = __shfl_up(v.last, d, 64);
+        if (l >= d) { v.n += a; v.h += b; v.last = c > v.last ? c : v.last; }
     }
-    if (threadIdx.x == 0) { const Tri t = carry_s; tot->n_nl = t.n; tot->n_hdr = t.h; tot->last_nl = t.last; }
+    __syncthreads();
+    if (l == 63) { lds[0][w] = v.n; lds[1][w] = v.h; lds[2][w] = (uint32_t)v.last; }
+    __syncthreads();
+    Tri32 base{0, 0, -1}, tot{0, 0, -1};
+    for (int i = 0; i < nw; ++i) {
+        const uint32_t a = lds[0][i], b = lds[1][i];
+        const int32_t c = (int32_t)lds[2][i];
+        if (i < w) { base.n += a; base.h += b; base.last = c > base.last ? c : base.last; }
+        tot.n += a; tot.h += b; tot.last = c > tot.last ? c : tot.last;
+    }
+    *total = tot;
+    return Tri32{base.n + v.n, base.h + v.h, base.last > v.last ? base.last : v.last};
 }
 
-__global__ __launch_bounds__(CHUNK_GRANS) void k_gran_prefix(const GranOut *__restrict__ go, int64_t ngran, int64_t gbase,
-                                                            const ChunkTot *__restrict__ ct, const Totals *__restrict__ tot,
+__global__ __launch_bounds__(CHUNK_GRANS) void k_gran_prefix(const GranPk *__restrict__ go, int64_t ngran, int64_t gbase,
+                                                            const ChunkTot *__restrict__ ct, Totals *__restrict__ tot,
                                                             int64_t *__restrict__ nl_prefix, int64_t *__restrict__ hdr_prefix,
                                                             int64_t *__restrict__ prevnl) {
     __shared__ Tri lds[CHUNK_GRANS / 64];
+    __shared__ uint32_t lds32[3][16];
+    // base: join of the totals of the chunks before this one
+    Tri b{0, 0, -1};
+    for (int64_t c = threadIdx.x; c < (int64_t)blockIdx.x; c += CHUNK_GRANS) { const ChunkTot t = ct[c]; b = tri_join(b, Tri{t.n, t.h, t.last}); }
+    Tri base{0, 0, -1};
+    if (blockIdx.x) tri_block_incl(b, lds, &base);         // workgroup-uniform branch
+    // local scan in 32 bits: counts of one chunk are < 2^23, offsets relative to the chunk start < 2^22
     const int64_t g = (int64_t)blockIdx.x * CHUNK_GRANS + threadIdx.x;
-    const Tri v = gran_tri(go, g, ngran, gbase);
-    Tri total;
-    const Tri inc = tri_block_incl(v, lds, &total);
-    const ChunkTot b = ct[blockIdx.x];
+    Tri32 v{0, 0, -1};
     if (g < ngran) {
-        nl_prefix[g] = b.n + inc.n - v.n;
-        hdr_prefix[g] = b.h + inc.h - v.h;
-        // exclusive max: the inclusive value of the previous thread
-        long long pm = shfl_up64(inc.last, 1);
-        if (lane_id() == 0) { pm = -1; for (int i = 0; i < (int)(threadIdx.x >> 6); ++i) pm = lds[i].last > pm ? lds[i].last : pm; }
-        if (threadIdx.x == 0) pm = -1;
-        prevnl[g] = b.last > pm ? b.last : pm;
+        const GranOut o = gran_unpack(go[g]);
+        v = Tri32{o.n, o.h, o.n ? (int32_t)(threadIdx.x * GRAN + o.last) : -1};
     }
-    if (g == ngran - 1) { nl_prefix[ngran] = tot->n_nl; hdr_prefix[ngran] = tot->n_hdr; prevnl[ngran] = tot->last_nl; }
+    Tri32 total;
+    const Tri32 inc = tri32_block_incl(v, lds32, &total);
+    const int64_t cstart = gbase + (int64_t)blockIdx.x * CHUNK_GRANS * GRAN;
+    if (g < ngran) {
+        nl_prefix[g] = base.n + (inc.n - v.n);
+        hdr_prefix[g] = base.h + (inc.h - v.h);
+        // exclusive max: the inclusive value of the previous thread
+        int32_t pm = __shfl_up(inc.last, 1, 64);
+        if (lane_id() == 0) { pm = -1; for (int i = 0; i < (int)(threadIdx.x >> 6); ++i) { const int32_t c = (int32_t)lds32[2][i]; pm = c > pm ? c : pm; } }
+        prevnl[g] = pm >= 0 ? cstart + pm : base.last;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const int64_t tn = base.n + total.n, th = base.h + total.h, tl = total.last >= 0 ? cstart + total.last : base.last;
+        nl_prefix[ngran] = tn; hdr_prefix[ngran] = th; prevnl[ngran] = tl;
+        tot->n_nl = tn; tot->n_hdr = th; tot->last_nl = tl;
+    }
 }
 
 // ============================================================== navigation by granule
 struct ScanCtx {
     const uint8_t *data; int64_t n, gbase, ngran;
-    const GranOut *go;
+    const GranPk *go;
     const int64_t *nl_prefix, *hdr_prefix, *prevnl;      // [ngran + 1]
 };
 
@@ -406,7 +394,7 @@ __device__ __forceinline__ int64_t next_nl(const ScanCtx &c, int64_t x) {
     if (y > c.n) return -1;
     const int64_t g = y / GRAN;
     if (g < c.ngran) {
-        const GranOut o = c.go[g];
+        const GranOut o = gran_unpack(c.go[g]);
         const int64_t gs = g * (int64_t)GRAN;
         if (o.n && gs + o.last >= y) {                    // the answer is in this granule
             if (gs + o.first >= y) return c.gbase + gs + o.first;
@@ -425,151 +413,299 @@ __device__ __forceinline__ int64_t next_nl(const ScanCtx &c, int64_t x) {
     int64_t lo = g + 1, hi = c.ngran;
     if (lo >= hi || c.prevnl[c.ngran] < key) return -1;
     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (c.prevnl[mid + 1] >= key) hi = mid; else lo = mid + 1; }
-    return c.gbase + lo * (int64_t)GRAN + c.go[lo].first;
+    return c.gbase + lo * (int64_t)GRAN + (c.go[lo].fl & 0xFFFFu);
 }
 
 // ============================================================== record table
-// One thread per header: the columns of index.c:234-339 from the header offset, its line index,
-// and the two newlines that follow it (end of the header line, end of the first sequence line).
-__global__ __launch_bounds__(BLOCK) void k_fasta_rec2(ScanCtx x, const Totals *__restrict__ tot, int64_t cap,
-                                                     const int64_t *__restrict__ hdr, const int64_t *__restrict__ hdr_line,
-                                                     int full_name, FastaCols c) {
-    const int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const int64_t n_hdr = tot->n_hdr < cap ? tot->n_hdr : cap;
-    if (k >= n_hdr) return;
-    const int64_t h = hdr[k], L = hdr_line[k];
-    const int64_t e = next_nl(x, h);                       // newline that ends the header line
+// first newline (and, if want_ws, first ' ' / '\t') at a local offset >= y, 64 bytes per step (four
+// independent 16-byte loads).  Returns local offsets, -1 when the shard's bytes end first.
+__device__ __forceinline__ void scan_line(const uint8_t *__restrict__ data, int64_t n, int64_t y, bool want_ws,
+                                          int64_t *e_out, int64_t *ws_out, int *cr_before) {
+    int64_t e = -1, ws = -1;
+    int cr = 0;                                            // is the byte before the newline a '\r'
+    unsigned long long prevC = 0;
+    for (int64_t p = y & ~(int64_t)(CHUNK - 1); p < n; p += 4 * CHUNK) {
+        unsigned long long M = 0, W = 0, C = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 v = load16(data, p + i * CHUNK, n);
+            M |= (unsigned long long)eq_mask16(v, 0x0A0A0A0Au) << (16 * i);
+            C |= (unsigned long long)eq_mask16(v, 0x0D0D0D0Du) << (16 * i);
+            if (want_ws) W |= (unsigned long long)(eq_mask16(v, 0x20202020u) | eq_mask16(v, 0x09090909u)) << (16 * i);
+        }
+        if (p < y) { const unsigned long long keep = ~0ull << (y - p); M &= keep; W &= keep; }
+        if (want_ws && ws < 0 && W) ws = p + (__ffsll(W) - 1);
+        if (M) {
+            const int k = __ffsll(M) - 1;
+            e = p + k;
+            cr = k ? (int)((C >> (k - 1)) & 1ull) : (int)(prevC >> 63);
+            break;
+        }
+        prevC = C;
+    }
+    *e_out = e; *ws_out = ws; *cr_before = cr;
+}
+
+// columns of index.c:234-339 that depend only on the header line and the line after it, read from
+// memory by one thread (the fall-back of k_hdr_rec for records whose first two lines leave the granule)
+__device__ __forceinline__ void record_at(const ScanCtx &x, int is_last, int full_name, int64_t h, int64_t k,
+                                          const FastaCols &c) {
+    int64_t e, ws, e1, dummy;
+    int cr, cr1;
+    scan_line(x.data, x.n, h + 1 - x.gbase, !full_name, &e, &ws, &cr);
+    if (e < 0 && is_last) { e = x.n; cr = x.data[x.n - 1] == '\r'; }     // virtual end-of-stream newline (index.c:231)
     if (e < 0) {
         // only possible for the LAST header of a non-final shard: its line ends in a later shard.
         // Leave a stub (dlen = -1) for the host-side stitch; name_len = local whitespace hit or -1.
-        int nlen = -1;
-        if (!full_name) {
-            const int64_t lim = x.n - (h + 1 - x.gbase);
-            const uint8_t *s = x.data + (h + 1 - x.gbase);
-            for (int64_t j = 0; j < lim; ++j) if (s[j] == ' ' || s[j] == '\t') { nlen = (int)j; break; }
-        }
-        c.boff[k] = 0; c.blen[k] = 0; c.slen[k] = 0; c.llen[k] = 0;
-        c.elen[k] = 0; c.dlen[k] = -1; c.name_len[k] = nlen; c.bad[k] = 0;
+        c.boff[k] = 0; c.llen[k] = 0; c.elen[k] = 0; c.dlen[k] = -1;
+        c.name_len[k] = (!full_name && ws >= 0) ? (int32_t)(ws - (h + 1 - x.gbase)) : -1;
         return;
     }
-    const int64_t boff = e + 1;                            // index.c:258  start = position
-    const int elen = (x.data[e - 1 - x.gbase] == '\r') ? 2 : 1;   // index.c:266-269
-    const int dlen = (int)(e - h) - elen;                  // index.c:271
-    int name_len = dlen;
-    if (!full_name) {                                      // index.c:289-293: cut at ' ' or '\t'
-        const uint8_t *s = x.data + (h + 1 - x.gbase);
-        for (name_len = 0; name_len < dlen; ++name_len)
-            if (s[name_len] == ' ' || s[name_len] == '\t') break;
-    }
-    int64_t hn, Ln;
-    if (k + 1 < tot->n_hdr && k + 1 < cap) { hn = hdr[k + 1]; Ln = hdr_line[k + 1]; }
-    else                                   { hn = tot->last_nl + 1; Ln = tot->n_nl; }   // EOF "position" (index.c:231)
-    const int64_t nseq = Ln - L - 1;                       // sequence lines of this record
-    const int64_t blen = hn - boff;                        // index.c:243,348
+    const int elen = cr ? 2 : 1;                           // index.c:266-269
+    const int dlen = (int)(e - (h - x.gbase)) - elen;      // index.c:271
+    int name_len = dlen;                                   // index.c:289-293: cut at ' ' or '\t'
+    if (!full_name && ws >= 0 && ws - (h + 1 - x.gbase) < dlen) name_len = (int)(ws - (h + 1 - x.gbase));
+    // first sequence line (index.c:330-332): the line after the header line, unless that is a header too
     int64_t llen = 0;
-    if (nseq > 0) llen = next_nl(x, e) - e;                // first line length + 1, index.c:330-332
-    c.boff[k] = boff; c.blen[k] = blen;
-    c.slen[k] = blen - (int64_t)elen * nseq;               // sum(line.l - line_end + 1), index.c:335-338
+    if (e + 1 < x.n && x.data[e + 1] != '>') {
+        scan_line(x.data, x.n, e + 1, false, &e1, &dummy, &cr1);
+        if (e1 < 0 && is_last) e1 = x.n;
+        if (e1 >= 0) llen = e1 - e;
+    }
+    c.boff[k] = x.gbase + e + 1;                           // index.c:258  start = position
     c.llen[k] = llen;
     c.elen[k] = elen; c.dlen[k] = dlen; c.name_len[k] = name_len;
-    c.bad[k] = 0;
 }
 
-// ============================================================== bad_line (index.c:325-327)
-// One thread per granule.  A granule that lies inside one record's body past its first sequence line,
-// without a header line and with <= 2 distinct line lengths, is answered from its summary: lines that
-// differ from the record's llen = those of the two summarised lengths that differ, plus the line that
-// crosses into the granule.  Everything else goes to the irregular list for k_gran_exact.
-struct RecView { const int64_t *boff, *llen; const int32_t *dlen; uint32_t *bad; };
-
-__global__ __launch_bounds__(BLOCK) void k_gran_lines(ScanCtx x, RecView rv, int64_t cap, GranList irr) {
-    const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (g >= x.ngran) return;
-    const GranOut o = x.go[g];
-    if (!o.n) return;
-    const int64_t r = x.hdr_prefix[g] - 1;                 // record that owns the first byte of the granule
-    if (o.h == 0) {
-        if (r < 0 || r >= cap) return;                     // before the first header: the shard summary handles the lead
-        if (rv.dlen[r] < 0) return;
-        const int64_t ll = rv.llen[r];
-        if (!ll) return;                                   // no sequence line: the only newline after the header ends it
-        const int64_t e1 = rv.boff[r] - 1 + ll;            // end of the first sequence line
-        const int64_t gs = x.gbase + g * (int64_t)GRAN;
-        if (e1 >= gs + GRAN) return;                       // nothing but the header line can end here
-        if (e1 < gs && !o.ovf) {
-            DiffSet ds;
-            ds.v1 = o.v1; ds.c1 = o.c1; ds.v2 = o.v2; ds.c2 = o.c2; ds.ovf = 0;
-            const uint32_t mism = ds.count_ne((uint32_t)ll) + ((gs + o.first - x.prevnl[g]) != ll ? 1u : 0u);
-            if (mism) atomicAdd(&rv.bad[r], mism);
-            return;
+// ---- 4096-bit masks spread over a wave: bit (16 * lane + k) of row j <-> granule byte j*1024 + 16*lane + k
+struct Mask4 { uint32_t r[GR_ROWS]; };
+__device__ __forceinline__ uint32_t mask_row(const Mask4 &m, int row) {     // row is wave-uniform
+    uint32_t v = m.r[0];
+#pragma unroll
+    for (int j = 1; j < GR_ROWS; ++j) v = (row == j) ? m.r[j] : v;
+    return v;
+}
+// first set bit at a granule position > pos (pos wave-uniform, may be -1), or -1
+__device__ __forceinline__ int mask_next(const Mask4 &m, int pos) {
+    const int lane = lane_id();
+    const int row0 = (pos + 1) >> 10, l0 = ((pos + 1) >> 4) & 63, b0 = (pos + 1) & 15;     // first candidate byte
+#pragma unroll
+    for (int j = 0; j < GR_ROWS; ++j) {
+        if (j < row0) continue;
+        uint32_t c = m.r[j];
+        if (j == row0) { if (lane < l0) c = 0; else if (lane == l0) c &= 0xFFFFu << b0; }
+        const unsigned long long bal = __ballot(c != 0);
+        if (bal) {
+            const int l = __ffsll(bal) - 1;
+            return j * 1024 + l * 16 + (__ffs(rdlane(c, l)) - 1);
         }
     }
-    irr.g[atomicAdd(irr.count, 1u)] = (uint32_t)g;
+    return -1;
+}
+__device__ __forceinline__ int mask_bit(const Mask4 &m, int pos) {           // pos wave-uniform, 0 <= pos < GRAN
+    return (int)((rdlane(mask_row(m, pos >> 10), (pos >> 4) & 63) >> (pos & 15)) & 1u);
 }
 
-// One wave per irregular granule: walk its newlines exactly.  For the newline at p with predecessor q
-// (in the lane, in a lower lane, in an earlier row, or prevnl[g]) the record is the last header <= p
-// (headers of this granule are hdr[hdr_prefix[g] .. hdr_prefix[g+1])); the header line and the first
-// sequence line are skipped, any other line with p - q != llen counts.
-__global__ __launch_bounds__(BLOCK) void k_gran_exact(ScanCtx x, RecView rv, int64_t cap, GranList irr, int is_last,
-                                                     const int64_t *__restrict__ hdr) {
+// One wave per granule that holds a header line: re-read its 4 KiB once, build the exact masks of
+// '\n', header starts, white space, '\r' and '>' in registers, write every header's offset and the
+// number of stream newlines before it straight to their final, position-ordered slots
+// (hdr_prefix[g] + rank), then fill -- header by header, all lanes together, from those masks -- the
+// columns that depend only on the record's first two lines (blen / slen / norm: k_fasta_finalize2).
+// A header whose first two lines run past the granule falls back to reading memory (record_at).
+__global__ __launch_bounds__(BLOCK) void k_hdr_rec(ScanCtx x, int prev_byte, int is_last, int full_name, GranList hgl,
+                                                  FastaCols c, int64_t cap) {
     const int lane = lane_id();
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int64_t cnt = *irr.count;
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int64_t cnt = *hgl.count;
     for (int64_t i = wave; i < cnt; i += nwaves) {
-        const int64_t g = irr.g[i];
+        const int64_t g = hgl.g[i];
         const int64_t sbase = g * (int64_t)GRAN;
-        const int64_t hb = x.hdr_prefix[g];
-        int64_t he = x.hdr_prefix[g + 1];
-        if (he > cap) he = cap;
-        int64_t carry = x.prevnl[g];                       // wave-uniform: latest newline so far (global, -1 none)
+        uint4 v[GR_ROWS];
+#pragma unroll
+        for (int j = 0; j < GR_ROWS; ++j) v[j] = load16(x.data, sbase + j * 1024 + lane * CHUNK, x.n);
+        if (is_last && sbase + GRAN > x.n) {
+#pragma unroll
+            for (int j = 0; j < GR_ROWS; ++j) {
+                const int64_t p = sbase + j * 1024 + lane * CHUNK;
+                if (x.n >= p && x.n < p + CHUNK && x.n > 0 && x.data[x.n - 1] != '\n') {
+                    const int k = (int)(x.n - p);
+                    const uint32_t b = 0x0Au << ((k & 3) * 8);
+                    if ((k >> 2) == 0) v[j].x |= b; else if ((k >> 2) == 1) v[j].y |= b; else if ((k >> 2) == 2) v[j].z |= b; else v[j].w |= b;
+                }
+            }
+        }
+        Mask4 nl, hm, ws, cr, gt;
+        int64_t hrank = x.hdr_prefix[g], nlb = x.nl_prefix[g];
+        const int64_t hrank0 = hrank;
+#pragma unroll
+        for (int j = 0; j < GR_ROWS; ++j) {
+            const int64_t p = sbase + j * 1024 + lane * CHUNK;
+            nl.r[j] = eq_mask16(v[j], 0x0A0A0A0Au);
+            hm.r[j] = header_mask16(v[j], nl.r[j], x.data, p, prev_byte);
+            ws.r[j] = full_name ? 0u : (eq_mask16(v[j], 0x20202020u) | eq_mask16(v[j], 0x09090909u));
+            cr.r[j] = eq_mask16(v[j], 0x0D0D0D0Du);
+            gt.r[j] = eq_mask16(v[j], 0x3E3E3E3Eu);
+            const uint32_t cn = __popc(nl.r[j]), ch = __popc(hm.r[j]);
+            const uint32_t in = wave_incl_scan(cn), ih = wave_incl_scan(ch);
+            int64_t r = hrank + ih - ch;
+            const int64_t nb0 = nlb + in - cn;
+            uint32_t hh = hm.r[j];
+            while (hh) {
+                const int k = __ffs(hh) - 1;
+                hh &= hh - 1;
+                if (r < cap) { c.hoff[r] = x.gbase + p + k; c.hdr_line[r] = nb0 + __popc(nl.r[j] & ((1u << k) - 1u)); c.bad[r] = 0; }
+                ++r;
+            }
+            nlb += (uint32_t)__shfl((int)in, 63, 64);
+            hrank += (uint32_t)__shfl((int)ih, 63, 64);
+        }
+        // records, in position order (everything below is wave-uniform)
+        int64_t r = hrank0;
+        for (int hp = mask_next(hm, -1); hp >= 0; hp = mask_next(hm, hp), ++r) {
+            if (r >= cap) break;
+            const int64_t h = x.gbase + sbase + hp;
+            const int e = mask_next(nl, hp);                          // end of the header line
+            const int e1 = (e >= 0 && e + 1 < GRAN) ? mask_next(nl, e) : -1;   // end of the line after it
+            const bool inside = e >= 0 && e + 1 < GRAN && (e1 >= 0 || sbase + e + 1 >= x.n);
+            if (!inside) {                                            // runs past the granule: read memory
+                if (lane == 0) record_at(x, is_last, full_name, h, r, c);
+                continue;
+            }
+            const int elen = mask_bit(cr, e - 1) ? 2 : 1;             // index.c:266-269 (e - 1 >= hp)
+            const int dlen = e - hp - elen;                           // index.c:271
+            int name_len = dlen;                                      // index.c:289-293: cut at ' ' or '\t'
+            if (!full_name) { const int w = mask_next(ws, hp); if (w >= 0 && w - (hp + 1) < dlen) name_len = w - (hp + 1); }
+            // first sequence line (index.c:330-332): the line after the header line, unless that is a header too
+            int64_t llen = 0;
+            if (sbase + e + 1 < x.n && !mask_bit(gt, e + 1) && e1 >= 0) llen = e1 - e;
+            if (lane == 0) {
+                c.boff[r] = x.gbase + sbase + e + 1;                  // index.c:258  start = position
+                c.llen[r] = llen; c.elen[r] = elen; c.dlen[r] = dlen; c.name_len[r] = name_len;
+            }
+        }
+    }
+}
+
+// ============================================================== bad_line (index.c:325-327)
+struct RecView { const int64_t *boff, *llen; const int32_t *dlen; uint32_t *bad; const int64_t *hdr; };
+
+// Walk the newlines of one granule exactly, all 64 lanes.  For the newline at p with predecessor q (in
+// the lane, in a lower lane, in an earlier row, or prevnl[g]) the record is the last header <= p
+// (headers of this granule are hdr[hdr_prefix[g] .. hdr_prefix[g+1])); the header line and the first
+// sequence line are skipped, any other line with p - q != llen counts.
+__device__ __forceinline__ void exact_walk(const ScanCtx &x, const RecView &rv, int64_t cap, int is_last, int64_t g) {
+    const int lane = lane_id();
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int64_t sbase = g * (int64_t)GRAN, gs = x.gbase + sbase;
+    // everything the walk needs is requested up front (independent loads, one latency)
+    uint4 v[GR_ROWS];
+#pragma unroll
+    for (int j = 0; j < GR_ROWS; ++j) v[j] = load16(x.data, sbase + j * 1024 + lane * CHUNK, x.n);
+    const int64_t hb = x.hdr_prefix[g];
+    int64_t he = x.hdr_prefix[g + 1];
+    if (he > cap) he = cap;
+    int64_t carry = x.prevnl[g];                           // wave-uniform: latest newline so far (global, -1 none)
+    const int64_t r0 = hb - 1;                             // record that owns the first byte of the granule
+    const bool ok0 = r0 >= 0 && r0 < cap;
+    const int32_t d0 = ok0 ? rv.dlen[r0] : -1;
+    const int64_t e0 = ok0 ? rv.boff[r0] - 1 : 0, ll0 = ok0 ? rv.llen[r0] : 0;
+    const int64_t h1 = he > hb ? rv.hdr[hb] : 0x7FFFFFFFFFFFFFFFll;   // first header line of this granule
+    if (is_last && sbase + GRAN > x.n) {
+#pragma unroll
         for (int j = 0; j < GR_ROWS; ++j) {
             const int64_t p0 = sbase + j * 1024 + lane * CHUNK;
-            uint4 v = load16(x.data, p0, x.n);
-            if (is_last && x.n >= p0 && x.n < p0 + CHUNK && x.n > 0 && x.data[x.n - 1] != '\n') {
+            if (x.n >= p0 && x.n < p0 + CHUNK && x.n > 0 && x.data[x.n - 1] != '\n') {
                 const int k = (int)(x.n - p0);
                 const uint32_t b = 0x0Au << ((k & 3) * 8);
-                if ((k >> 2) == 0) v.x |= b; else if ((k >> 2) == 1) v.y |= b; else if ((k >> 2) == 2) v.z |= b; else v.w |= b;
+                if ((k >> 2) == 0) v[j].x |= b; else if ((k >> 2) == 1) v[j].y |= b; else if ((k >> 2) == 2) v[j].z |= b; else v[j].w |= b;
             }
-            uint32_t m = eq_mask16(v, 0x0A0A0A0Au);
-            const unsigned long long bal = __ballot(m != 0);
-            if (!bal) continue;
-            const int64_t pl = x.gbase + p0 + (31 - __clz(m | 1u));          // last newline of this lane
-            const unsigned long long lower = bal & lt;
-            const int prevlane = 63 - __clzll(lower | 1ull);
-            const int plo = __builtin_amdgcn_ds_bpermute(prevlane << 2, (int)(pl & 0xFFFFFFFFll));
-            const int phi = __builtin_amdgcn_ds_bpermute(prevlane << 2, (int)(pl >> 32));
-            int64_t q = lower ? (((int64_t)phi << 32) | (unsigned int)plo) : carry;
-            while (m) {
-                const int k = __ffs(m) - 1;
-                m &= m - 1;
-                const int64_t p = x.gbase + p0 + k;
-                // record of p: headers of this granule that start before p
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < GR_ROWS; ++j) {
+        uint32_t m = eq_mask16(v[j], 0x0A0A0A0Au);
+        const unsigned long long bal = __ballot(m != 0);
+        if (!bal) continue;
+        const int cb = j * 1024 + lane * CHUNK;
+        const int pl = cb + (31 - __clz(m | 1u));           // last newline of this lane (granule-local)
+        const unsigned long long lower = bal & lt;
+        const int pprev = __builtin_amdgcn_ds_bpermute((63 - __clzll(lower | 1ull)) << 2, pl);
+        int64_t q = lower ? gs + pprev : carry;
+        while (m) {
+            const int k = __ffs(m) - 1;
+            m &= m - 1;
+            const int64_t p = gs + cb + k;
+            if (p < h1) {                                   // still in the record that owns the granule start
+                if (d0 >= 0 && p != e0 && p != e0 + ll0 && q >= 0 && p - q != ll0) atomicAdd(&rv.bad[r0], 1u);
+            } else {                                        // a record that starts in this granule: last header <= p
                 int64_t lo = hb, hi = he;
-                while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (hdr[mid] < p) lo = mid + 1; else hi = mid; }
+                while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rv.hdr[mid] < p) lo = mid + 1; else hi = mid; }
                 const int64_t r = lo - 1;
                 if (r >= 0 && r < cap && rv.dlen[r] >= 0) {
                     const int64_t e = rv.boff[r] - 1, ll = rv.llen[r];
                     if (p != e && p != e + ll && q >= 0 && p - q != ll) atomicAdd(&rv.bad[r], 1u);
                 }
-                q = p;
             }
-            const int last_lane = 63 - __clzll(bal);
-            carry = ((int64_t)__builtin_amdgcn_readlane((int)(pl >> 32), last_lane) << 32) |
-                    (unsigned int)__builtin_amdgcn_readlane((int)(pl & 0xFFFFFFFFll), last_lane);
+            q = p;
         }
+        carry = gs + (int)rdlane((uint32_t)pl, 63 - __clzll(bal));
     }
 }
 
-// norm (index.c:237,342), stat.seqlen (index.c:253-254, 360-369)
-__global__ __launch_bounds__(BLOCK) void k_fasta_finalize2(const uint32_t *__restrict__ bad, const int64_t *__restrict__ slen,
-                                                          int64_t cap, int32_t *__restrict__ norm, Totals *__restrict__ tot) {
+// One thread per granule.  A granule that lies inside one record's body past its first sequence line,
+// without a header line and with <= 2 distinct line lengths, is answered from its summary: lines that
+// differ from the record's llen = those of the two summarised lengths that differ, plus the line that
+// crosses into the granule.  Anything else is irregular: the wave walks those granules exactly, one
+// after the other, all lanes together.
+__global__ __launch_bounds__(BLOCK) void k_gran_lines(ScanCtx x, RecView rv, int64_t cap, int is_last) {
+    const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    bool irregular = false;
+    if (g < x.ngran) {
+        const GranOut o = gran_unpack(x.go[g]);
+        const int64_t r = x.hdr_prefix[g] - 1;             // record that owns the first byte of the granule
+        if (o.n && o.h) irregular = true;
+        else if (o.n && r >= 0 && r < cap && rv.dlen[r] >= 0) {   // r < 0: before the first header -- the shard summary handles the lead
+            const int64_t ll = rv.llen[r];                 // 0: no sequence line, the only newline after the header ends it
+            const int64_t e1 = rv.boff[r] - 1 + ll;        // end of the first sequence line
+            const int64_t gs = x.gbase + g * (int64_t)GRAN;
+            if (ll && e1 < gs + GRAN) {                    // else nothing but the header line can end here
+                if (e1 < gs && !o.ovf) {
+                    DiffSet ds;
+                    ds.v1 = o.v1; ds.c1 = o.c1; ds.v2 = o.v2; ds.c2 = o.c2; ds.ovf = 0;
+                    const uint32_t mism = ds.count_ne((uint32_t)ll) + ((gs + o.first - x.prevnl[g]) != ll ? 1u : 0u);
+                    if (mism) atomicAdd(&rv.bad[r], mism);
+                } else irregular = true;
+            }
+        }
+    }
+    unsigned long long todo = __ballot(irregular);
+    const int64_t g0 = g - lane_id();
+    while (todo) {
+        const int l = __ffsll(todo) - 1;
+        todo &= todo - 1;
+        exact_walk(x, rv, cap, is_last, g0 + l);
+    }
+}
+
+// blen, slen (index.c:243,335-338,348), norm (index.c:237,342), stat.seqlen (index.c:253-254, 360-369)
+__global__ __launch_bounds__(BLOCK) void k_fasta_finalize2(int64_t cap, FastaCols c, Totals *__restrict__ tot) {
+    const int64_t *__restrict__ hdr = c.hoff, *__restrict__ hdr_line = c.hdr_line;
     const int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const int64_t n_hdr = tot->n_hdr < cap ? tot->n_hdr : cap;
     int64_t s = 0;
-    if (k < n_hdr) { norm[k] = bad[k] > 1 ? 0 : 1; s = slen[k]; }
+    if (k < n_hdr) {
+        if (c.dlen[k] >= 0) {
+            int64_t hn, Ln;
+            if (k + 1 < n_hdr) { hn = hdr[k + 1]; Ln = hdr_line[k + 1]; }
+            else               { hn = tot->last_nl + 1; Ln = tot->n_nl; }     // EOF "position" (index.c:231)
+            const int64_t nseq = Ln - hdr_line[k] - 1;     // sequence lines of this record
+            const int64_t blen = hn - c.boff[k];
+            s = blen - (int64_t)c.elen[k] * nseq;          // sum(line.l - line_end + 1)
+            c.blen[k] = blen; c.slen[k] = s;
+            c.norm[k] = c.bad[k] > 1 ? 0 : 1;
+        } else { c.blen[k] = 0; c.slen[k] = 0; c.norm[k] = 1; }
+    }
     s = wave_sum64(s);
     if (lane_id() == 0 && s) atomicAdd((unsigned long long *)&tot->seq_len, (unsigned long long)s);
 }
@@ -601,7 +737,7 @@ __global__ __launch_bounds__(BLOCK) void k_shard_summary2(ScanCtx x, int is_last
     DiffSet ds;
     ds.clear();
     for (int64_t g = tid; g < g_first; g += BLOCK) {
-        const GranOut o = x.go[g];
+        const GranOut o = gran_unpack(x.go[g]);
         if (!o.n) continue;
         ds.add(o.v1, o.c1); ds.add(o.v2, o.c2); ds.ovf |= o.ovf;
         const int64_t pv = x.prevnl[g];

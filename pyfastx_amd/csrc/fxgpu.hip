@@ -73,13 +73,13 @@ template <class T> struct DevBuf {      // grow-only device array: rebuilds reus
 // ------------------------------------------------------------ kernel timing
 // Optional per-kernel HIP-event timing on the handle's own stream (bench.py's
 // roofline leg reads it; off by default so the hot path records no events).
-enum KernelId { K_SPAN_SCAN = 0, K_GRAN_REDUCE, K_CHUNK_SCAN, K_GRAN_PREFIX, K_HDR_COLLECT, K_FASTA_REC, K_GRAN_LINES,
-                K_GRAN_EXACT, K_FASTA_FINALIZE, K_FETCH, K_FASTA_COMP, K_SCAN, K_TILE_SCAN, K_LINETABLE, K_FASTQ_REC,
-                K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_NKERN };
+enum KernelId { K_SPAN_SCAN = 0, K_GRAN_REDUCE, K_GRAN_PREFIX, K_HDR_REC, K_GRAN_LINES, K_FASTA_FINALIZE, K_FETCH,
+                K_FASTA_COMP, K_SCAN, K_TILE_SCAN, K_LINETABLE, K_FASTQ_REC, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE,
+                K_NKERN };
 static const char *const kKernelNames[K_NKERN] = {
-    "k_span_scan", "k_gran_reduce", "k_chunk_scan", "k_gran_prefix", "k_hdr_collect", "k_fasta_rec", "k_gran_lines",
-    "k_gran_exact", "k_fasta_finalize", "k_fetch", "k_fasta_comp", "k_scan", "k_group_scan", "k_linetable", "k_fastq_rec",
-    "k_fastq_comp", "k_fastq_fetch", "k_bgzf_inflate"};
+    "k_span_scan", "k_gran_reduce", "k_gran_prefix", "k_hdr_rec", "k_gran_lines", "k_fasta_finalize", "k_fetch",
+    "k_fasta_comp", "k_scan", "k_group_scan", "k_linetable", "k_fastq_rec", "k_fastq_comp", "k_fastq_fetch",
+    "k_bgzf_inflate"};
 
 struct Prof {
     bool on = false;
@@ -145,10 +145,11 @@ struct fx_handle {
     bool scanned = false;
     // FASTA scan products (fx_spanscan.hpp): per-granule summaries and their prefixes
     int64_t ngran = 0;
-    DevBuf<GranOut> gran;
-    DevBuf<uint32_t> hdr_grans, irr_grans;    // granules holding a header line / needing the exact walk
+    DevBuf<GranPk> gran;
+    DevBuf<uint32_t> hdr_grans;               // granules holding a header line
     DevBuf<ChunkTot> chunks;
-    DevBuf<unsigned long long> ctl;           // Totals (8 words) + list counters
+    DevBuf<unsigned long long> ctl;           // Totals (8 words) + list counter + shard summary
+    Totals *pin_tot = nullptr;                // pinned host copy of Totals (async read-back without staging)
     DevBuf<int64_t> nl_prefix, hdr_prefix, prevnl;
     // FASTA table
     DevBuf<int64_t> hdr, fa_boff, fa_blen, fa_slen, fa_llen, fa_hdr_line;
@@ -212,6 +213,7 @@ extern "C" int fx_close(fx_handle *h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->owns && h->d_data) (void)hipFree(h->d_data);
+    if (h->pin_tot) (void)hipHostFree(h->pin_tot);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return FX_OK;
@@ -578,7 +580,7 @@ static FastaCols fasta_cols(fx_handle *h) {
     FastaCols c;
     c.hoff = h->hdr.p; c.boff = h->fa_boff.p; c.blen = h->fa_blen.p; c.slen = h->fa_slen.p; c.llen = h->fa_llen.p;
     c.hdr_line = h->fa_hdr_line.p; c.elen = h->fa_elen.p; c.dlen = h->fa_dlen.p; c.name_len = h->fa_name_len.p;
-    c.bad = h->fa_bad.p;
+    c.norm = h->fa_norm.p; c.bad = h->fa_bad.p;
     return c;
 }
 static int alloc_fasta_table(fx_handle *h, int64_t cap) {
@@ -591,7 +593,7 @@ static int alloc_fasta_table(fx_handle *h, int64_t cap) {
     return FX_OK;
 }
 
-// ctl layout (64 words): [0..8) Totals, [8] / [9] = header-granule / irregular list counts (u32), [16..44) shard summary
+// ctl layout (64 words): [0..8) Totals, [8] = header-granule list count (u32), [16..44) shard summary
 static Totals *ctl_totals(fx_handle *h) { return (Totals *)h->ctl.p; }
 static uint32_t *ctl_counter(fx_handle *h, int i) { return (uint32_t *)(h->ctl.p + 8 + i); }
 
@@ -603,22 +605,20 @@ extern "C" int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out
     // ---- the one pass over the stream: 4 KiB granule summaries (fx_spanscan.hpp)
     const int64_t nfull = h->n / GRAN, ngran = nfull + 1, nchunks = (ngran + CHUNK_GRANS - 1) / CHUNK_GRANS;
     h->ngran = ngran;
-    if ((rc = h->gran.alloc(ngran)) || (rc = h->hdr_grans.alloc(ngran)) || (rc = h->irr_grans.alloc(ngran)) ||
-        (rc = h->chunks.alloc(nchunks)) || (rc = h->ctl.alloc(64)) || (rc = h->nl_prefix.alloc(ngran + 1)) ||
-        (rc = h->hdr_prefix.alloc(ngran + 1)) || (rc = h->prevnl.alloc(ngran + 1)))
+    if ((rc = h->gran.alloc(ngran)) || (rc = h->hdr_grans.alloc(ngran)) || (rc = h->chunks.alloc(nchunks)) ||
+        (rc = h->ctl.alloc(64)) || (rc = h->nl_prefix.alloc(ngran + 1)) || (rc = h->hdr_prefix.alloc(ngran + 1)) ||
+        (rc = h->prevnl.alloc(ngran + 1)))
         return rc;
+    if (!h->pin_tot) HIPCHK(hipHostMalloc((void **)&h->pin_tot, sizeof(Totals), hipHostMallocDefault));
     if (h->hdr.cap < 4096 && (rc = alloc_fasta_table(h, 4096))) return rc;
     HIPCHK(hipMemsetAsync(h->ctl.p, 0, 16 * sizeof(unsigned long long), h->stream));
-    GranList hgl{h->hdr_grans.p, ctl_counter(h, 0)}, irr{h->irr_grans.p, ctl_counter(h, 1)};
+    GranList hgl{h->hdr_grans.p, ctl_counter(h, 0)};
     const int SCAN_WG = 512;                                  // 8 waves = 8 granules per workgroup (tools/scanbench2.hip)
     if (nfull > 0)
-        FX_LAUNCH(h, K_SPAN_SCAN, (k_span_scan<true>), dim3(nblocks(nfull * 64, SCAN_WG)), dim3(SCAN_WG), h->d_data, h->n,
-                  h->prev_byte, (int)h->is_last, (int64_t)0, nfull, h->gran.p, hgl);
-    hipLaunchKernelGGL((k_span_scan<false>), dim3(1), dim3(64), 0, h->stream, h->d_data, h->n, h->prev_byte, (int)h->is_last,
-                       nfull, ngran, h->gran.p, hgl);
-    FX_LAUNCH(h, K_GRAN_REDUCE, k_gran_reduce, dim3((unsigned)nchunks), dim3(CHUNK_GRANS), h->gran.p, ngran, h->base,
-              h->chunks.p);
-    FX_LAUNCH(h, K_CHUNK_SCAN, k_chunk_scan, dim3(1), dim3(1024), h->chunks.p, nchunks, ctl_totals(h));
+        FX_LAUNCH(h, K_SPAN_SCAN, k_span_scan, dim3(nblocks(nfull * 64, SCAN_WG)), dim3(SCAN_WG), h->d_data, h->n,
+                  h->prev_byte, (int)h->is_last, nfull, h->gran.p, hgl);
+    FX_LAUNCH(h, K_GRAN_REDUCE, k_gran_reduce, dim3((unsigned)nchunks), dim3(CHUNK_GRANS), h->d_data, h->n, h->prev_byte,
+              (int)h->is_last, hgl, h->gran.p, ngran, h->base, h->chunks.p);
     FX_LAUNCH(h, K_GRAN_PREFIX, k_gran_prefix, dim3((unsigned)nchunks), dim3(CHUNK_GRANS), h->gran.p, ngran, h->base,
               h->chunks.p, ctl_totals(h), h->nl_prefix.p, h->hdr_prefix.p, h->prevnl.p);
     HIPCHK(hipGetLastError());
@@ -630,21 +630,16 @@ extern "C" int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out
     for (;;) {
         const int64_t cap = h->hdr.cap;
         const FastaCols c = fasta_cols(h);
-        const RecView rv{h->fa_boff.p, h->fa_llen.p, h->fa_dlen.p, h->fa_bad.p};
-        FX_LAUNCH(h, K_HDR_COLLECT, k_hdr_collect, dim3(512), dim3(BLOCK), h->d_data, h->n, h->base, h->prev_byte,
-                  (int)h->is_last, hgl, h->nl_prefix.p, h->hdr_prefix.p, h->hdr.p, h->fa_hdr_line.p, cap);
-        FX_LAUNCH(h, K_FASTA_REC, k_fasta_rec2, dim3(nblocks(cap, BLOCK)), dim3(BLOCK), x, ctl_totals(h), cap, h->hdr.p,
-                  h->fa_hdr_line.p, full_name, c);
-        FX_LAUNCH(h, K_GRAN_LINES, k_gran_lines, dim3(nblocks(ngran, BLOCK)), dim3(BLOCK), x, rv, cap, irr);
-        FX_LAUNCH(h, K_GRAN_EXACT, k_gran_exact, dim3(512), dim3(BLOCK), x, rv, cap, irr, (int)h->is_last, h->hdr.p);
-        FX_LAUNCH(h, K_FASTA_FINALIZE, k_fasta_finalize2, dim3(nblocks(cap, BLOCK)), dim3(BLOCK), h->fa_bad.p,
-                  h->fa_slen.p, cap, h->fa_norm.p, ctl_totals(h));
+        const RecView rv{h->fa_boff.p, h->fa_llen.p, h->fa_dlen.p, h->fa_bad.p, h->hdr.p};
+        FX_LAUNCH(h, K_HDR_REC, k_hdr_rec, dim3(512), dim3(BLOCK), x, h->prev_byte, (int)h->is_last, full_name, hgl, c, cap);
+        FX_LAUNCH(h, K_GRAN_LINES, k_gran_lines, dim3(nblocks(ngran, BLOCK)), dim3(BLOCK), x, rv, cap, (int)h->is_last);
+        FX_LAUNCH(h, K_FASTA_FINALIZE, k_fasta_finalize2, dim3(nblocks(cap, BLOCK)), dim3(BLOCK), cap, c, ctl_totals(h));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&tot, ctl_totals(h), sizeof tot, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->pin_tot, ctl_totals(h), sizeof tot, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        tot = *h->pin_tot;
         if (tot.n_hdr <= cap) break;
         if ((rc = alloc_fasta_table(h, tot.n_hdr + tot.n_hdr / 16 + 16))) return rc;
-        HIPCHK(hipMemsetAsync(ctl_counter(h, 1), 0, 4, h->stream));                   // irregular list is rebuilt
         HIPCHK(hipMemsetAsync(&ctl_totals(h)->seq_len, 0, 8, h->stream));
     }
     h->n_hdr = tot.n_hdr;

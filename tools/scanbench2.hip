@@ -60,17 +60,29 @@ int check(const std::vector<uint8_t> &hb) {
     CK(hipMalloc((void **)&d, (size_t)n + 64));
     CK(hipMemset(d, 0x41, (size_t)n + 64));
     CK(hipMemcpy(d, hb.data(), (size_t)n, hipMemcpyHostToDevice));
-    GranOut *go;
-    CK(hipMalloc((void **)&go, (size_t)ngran * sizeof(GranOut)));
+    GranPk *go;
+    CK(hipMalloc((void **)&go, (size_t)ngran * sizeof(GranPk)));
     GranList gl;
     CK(hipMalloc((void **)&gl.g, (size_t)ngran * 4));
     CK(hipMalloc((void **)&gl.count, 4));
     CK(hipMemset(gl.count, 0, 4));
-    hipLaunchKernelGGL(k_span_scan<true>, dim3(2048), dim3(BLOCK), 0, 0, d, n, (int)'\n', 1, (int64_t)0, n / GRAN, go, gl);
-    hipLaunchKernelGGL(k_span_scan<false>, dim3(1), dim3(64), 0, 0, d, n, (int)'\n', 1, n / GRAN, n / GRAN + 1, go, gl);
+    const int64_t nchunks = (ngran + CHUNK_GRANS - 1) / CHUNK_GRANS;
+    ChunkTot *ct; Totals *tot; int64_t *dpn, *dph, *dpv;
+    CK(hipMalloc((void **)&ct, nchunks * sizeof(ChunkTot))); CK(hipMalloc((void **)&tot, sizeof(Totals)));
+    CK(hipMemset(tot, 0, sizeof(Totals)));
+    CK(hipMalloc((void **)&dpn, (ngran + 1) * 8)); CK(hipMalloc((void **)&dph, (ngran + 1) * 8)); CK(hipMalloc((void **)&dpv, (ngran + 1) * 8));
+    hipLaunchKernelGGL(k_span_scan, dim3((unsigned)((n / GRAN * 64 + 511) / 512)), dim3(512), 0, 0, d, n, (int)'\n', 1, n / GRAN, go, gl);
+    hipLaunchKernelGGL(k_gran_reduce, dim3((unsigned)nchunks), dim3(CHUNK_GRANS), 0, 0, d, n, (int)'\n', 1, gl, go, ngran, (int64_t)1000, ct);
+    hipLaunchKernelGGL(k_gran_prefix, dim3((unsigned)nchunks), dim3(CHUNK_GRANS), 0, 0, go, ngran, (int64_t)1000, ct, tot, dpn, dph, dpv);
     CK(hipDeviceSynchronize());
+    std::vector<GranPk> hp(ngran);
+    CK(hipMemcpy(hp.data(), go, (size_t)ngran * sizeof(GranPk), hipMemcpyDeviceToHost));
     std::vector<GranOut> hg(ngran);
-    CK(hipMemcpy(hg.data(), go, (size_t)ngran * sizeof(GranOut), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < ngran; ++i) {
+        const GranPk &q = hp[i]; GranOut &o = hg[i];
+        o.n = q.nh & 0xFFFF; o.h = q.nh >> 16; o.first = o.n ? (q.fl & 0xFFFF) : SP_NONE; o.last = o.n ? (q.fl >> 16) : SP_NONE;
+        o.v1 = q.d1 & 0xFFFF; o.c1 = q.d1 >> 16; o.v2 = q.d2 & 0xFFFF; o.c2 = (q.d2 >> 16) & 0x7FFF; o.ovf = q.d2 >> 31;
+    }
     // reference
     std::vector<RefSpan> ref(ngran);
     std::vector<RefHdr> rh;
@@ -104,27 +116,22 @@ int check(const std::vector<uint8_t> &hb) {
         if (!ok) { ++bad; printf("granule %lld mismatch: gpu n=%u h=%u f=%u l=%u v1=%u c1=%u v2=%u c2=%u ovf=%u | ref n=%u h=%u f=%u l=%u nd=%zu\n",
                           (long long)s, o.n, o.h, o.first, o.last, o.v1, o.c1, o.v2, o.c2, o.ovf, r.n_nl, r.n_hdr, r.first, r.last, r.d.size()); }
     }
-    // prefixes on the host (the product does this in k_span_prefix), then k_hdr_collect
-    std::vector<int64_t> pn(ngran + 1, 0), ph(ngran + 1, 0);
-    for (int64_t s = 0; s < ngran; ++s) { pn[s + 1] = pn[s] + hg[s].n; ph[s + 1] = ph[s] + hg[s].h; }
+    // device prefixes vs host prefixes
+    std::vector<int64_t> pn(ngran + 1, 0), ph(ngran + 1, 0), pv(ngran + 1, -1);
+    for (int64_t s = 0; s < ngran; ++s) { pn[s + 1] = pn[s] + hg[s].n; ph[s + 1] = ph[s] + hg[s].h;
+        pv[s + 1] = hg[s].n ? 1000 + s * GRAN + hg[s].last : pv[s]; }
+    std::vector<int64_t> gn(ngran + 1), gh(ngran + 1), gv(ngran + 1);
+    CK(hipMemcpy(gn.data(), dpn, (ngran + 1) * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(gh.data(), dph, (ngran + 1) * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(gv.data(), dpv, (ngran + 1) * 8, hipMemcpyDeviceToHost));
+    for (int64_t s = 0; s <= ngran && bad < 10; ++s)
+        if (gn[s] != pn[s] || gh[s] != ph[s] || gv[s] != pv[s]) { ++bad; printf("prefix %lld: gpu %lld %lld %lld | ref %lld %lld %lld\n", (long long)s,
+            (long long)gn[s], (long long)gh[s], (long long)gv[s], (long long)pn[s], (long long)ph[s], (long long)pv[s]); }
     uint32_t ngl = 0;
     CK(hipMemcpy(&ngl, gl.count, 4, hipMemcpyDeviceToHost));
-    int64_t *dpn, *dph, *dh, *dhl;
-    const int64_t nh = ph[ngran];
-    CK(hipMalloc((void **)&dpn, (ngran + 1) * 8)); CK(hipMalloc((void **)&dph, (ngran + 1) * 8));
-    CK(hipMalloc((void **)&dh, (nh + 1) * 8)); CK(hipMalloc((void **)&dhl, (nh + 1) * 8));
-    CK(hipMemcpy(dpn, pn.data(), (ngran + 1) * 8, hipMemcpyHostToDevice));
-    CK(hipMemcpy(dph, ph.data(), (ngran + 1) * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_hdr_collect, dim3(256), dim3(BLOCK), 0, 0, d, n, (int64_t)1000, (int)'\n', 1, gl, dpn, dph, dh, dhl, nh);
-    CK(hipDeviceSynchronize());
-    std::vector<int64_t> gh(nh), ghl(nh);
-    CK(hipMemcpy(gh.data(), dh, nh * 8, hipMemcpyDeviceToHost));
-    CK(hipMemcpy(ghl.data(), dhl, nh * 8, hipMemcpyDeviceToHost));
-    if ((size_t)nh != rh.size()) { printf("header count %lld vs %zu\n", (long long)nh, rh.size()); ++bad; }
-    else for (size_t i = 0; i < rh.size() && bad < 10; ++i)
-        if (gh[i] != rh[i].pos + 1000 || ghl[i] != rh[i].line) { ++bad; printf("hdr %zu: gpu pos=%lld line=%lld | ref pos=%lld line=%lld\n", i, (long long)gh[i], (long long)ghl[i], (long long)rh[i].pos + 1000, (long long)rh[i].line); }
+    if ((size_t)ph[ngran] != rh.size()) { printf("header count %lld vs %zu\n", (long long)ph[ngran], rh.size()); ++bad; }
     printf("check: %lld bytes, %lld granules, %zu headers in %u granules, %s\n", (long long)n, (long long)ngran, rh.size(), ngl, bad ? "MISMATCH" : "all equal");
-    for (void *q : {(void *)d, (void *)go, (void *)gl.g, (void *)gl.count, (void *)dpn, (void *)dph, (void *)dh, (void *)dhl}) (void)hipFree(q);
+    for (void *q : {(void *)d, (void *)go, (void *)gl.g, (void *)gl.count, (void *)dpn, (void *)dph, (void *)dpv, (void *)ct, (void *)tot}) (void)hipFree(q);
     return bad;
 }
 
@@ -152,8 +159,8 @@ int main() {
     CK(hipMalloc((void **)&d, n + (1 << 20)));
     hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, d, n + (1 << 20));
     const int64_t ngran = n / GRAN + 1;
-    GranOut *go;
-    CK(hipMalloc((void **)&go, (size_t)ngran * sizeof(GranOut)));
+    GranPk *go;
+    CK(hipMalloc((void **)&go, (size_t)ngran * sizeof(GranPk)));
     GranList gl;
     CK(hipMalloc((void **)&gl.g, (size_t)ngran * 4));
     CK(hipMalloc((void **)&gl.count, 4));
@@ -166,8 +173,7 @@ int main() {
     for (int r = 0; r < R + 2; ++r) {
         CK(hipMemsetAsync(gl.count, 0, 4, 0));
         CK(hipEventRecord(a, 0));
-        hipLaunchKernelGGL(k_span_scan<true>, dim3(grid), dim3(blk), 0, 0, d, n, (int)'\n', 1, (int64_t)0, n / GRAN, go, gl);
-        hipLaunchKernelGGL(k_span_scan<false>, dim3(1), dim3(64), 0, 0, d, n, (int)'\n', 1, n / GRAN, n / GRAN + 1, go, gl);
+        hipLaunchKernelGGL(k_span_scan, dim3(grid), dim3(blk), 0, 0, d, n, (int)'\n', 1, n / GRAN, go, gl);
         CK(hipEventRecord(b, 0));
         CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
