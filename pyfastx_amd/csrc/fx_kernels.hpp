@@ -345,56 +345,193 @@ __device__ __forceinline__ void build_comp_lut(uint8_t *lut) {
     }
 }
 
+// ---- helpers of the line-arithmetic fetch path (k_fetch, BY_ID, norm = 1 records) ------------------
+typedef uint4 __attribute__((aligned(1))) uint4_u;       // 16 bytes at any byte address (gfx9 unaligned access mode)
+typedef uint2 __attribute__((aligned(1))) uint2_u;
+typedef uint32_t __attribute__((aligned(1))) uint32_u;
+typedef uint16_t __attribute__((aligned(1))) uint16_u;
+
+// 32-bit word i of the 128-bit mask whose low T bytes (0 <= T <= 16) are 0xFF
+__device__ __forceinline__ uint32_t lowbytes_word(int T, int i) {
+    const int tt = T - 4 * i;
+    return tt >= 4 ? 0xFFFFFFFFu : (tt <= 0 ? 0u : ((1u << (8 * tt)) - 1u));
+}
+// 0x80 in every byte of w that is < 0x80 and <= 0x20 (white space and control bytes)
+__device__ __forceinline__ uint32_t le20_bytes(uint32_t w) { return ~(((w & 0x7F7F7F7Fu) + 0x5F5F5F5Fu) | w) & 0x80808080u; }
+// Py_TOUPPER on four bytes (util.c:181-194): 'a'..'z' -> 'A'..'Z', everything else unchanged
+__device__ __forceinline__ uint32_t upper4(uint32_t w) {
+    const uint32_t x = w & 0x7F7F7F7Fu;
+    const uint32_t lower = (x + 0x1F1F1F1Fu) & ~(x + 0x05050505u) & ~w & 0x80808080u;     // 0x61 <= c <= 0x7A
+    return w - (lower >> 2);
+}
+__device__ __forceinline__ uint32_t lut4(const uint8_t *lut, uint32_t w) {
+    return (uint32_t)lut[w & 0xFF] | ((uint32_t)lut[(w >> 8) & 0xFF] << 8) | ((uint32_t)lut[(w >> 16) & 0xFF] << 16) |
+           ((uint32_t)lut[w >> 24] << 24);
+}
+__device__ __forceinline__ bool is_space3(uint32_t c) { return c == 10u || c == 13u || c == 32u; }   // jump_table, util.c:157-164
+// the low `len` (1..16) bytes of v to p, any alignment
+__device__ __forceinline__ void store_low_bytes(uint8_t *p, uint4 v, int len) {
+    if (len >= 16) { *reinterpret_cast<uint4_u *>(p) = v; return; }
+    if (len & 8) { *reinterpret_cast<uint2_u *>(p) = make_uint2(v.x, v.y); p += 8; v.x = v.z; v.y = v.w; }
+    if (len & 4) { *reinterpret_cast<uint32_u *>(p) = v.x; p += 4; v.x = v.y; }
+    if (len & 2) { *reinterpret_cast<uint16_u *>(p) = (uint16_t)v.x; p += 2; v.x >>= 16; }
+    if (len & 1) *p = (uint8_t)v.x;
+}
+
 // G lanes cooperate on one query (64/G queries in flight per wave); each lane
 // loads V aligned bytes per step, so a step covers a G*V-byte window:
 //   < 8,16>  128-byte window, 8 queries per wave  -- ~100-bp random access
 //   <64,16>  1 KiB window, 1 query per wave       -- long ranges (whole records)
-// The keep mask of a lane's V bytes is SWAR, the rank of its first kept byte is
+// General path: the keep mask of a lane's V bytes is SWAR, the rank of its first kept byte is
 // an exclusive prefix over the G lanes (__shfl_up, width G), kept bytes whose
 // rank falls in [skip, skip+take) are stored (mirrored for FX_REVERSE).
+// Line-arithmetic path (BY_ID, norm = 1, >= 16 bases per line): base i of a record sits at byte
+// boff + i + elen * (i / bases_per_line) (sequence.c:498-510), so a lane produces 16 OUTPUT bytes
+// from one unaligned 16-byte load -- two when a line end falls inside, merged with a byte mask --
+// and writes them with one unaligned 16-byte store: no keep mask, no ranks, no per-byte loop.  It
+// checks that the skipped bytes are line terminators and that no white space hides inside the
+// lines; if either fails the query is redone by the general path, so results always equal
+// "read the byte range, drop 10/13/32" (index.c:694-707, util.c:157-194).
 template <bool BY_ID, int G, int V>
 __global__ __launch_bounds__(BLOCK) void k_fetch(const uint8_t *__restrict__ data, int64_t gbase, int64_t n_bytes,
                                                 FetchQ q, FastaTab tab, int64_t nq, int flags_all,
                                                 uint8_t *__restrict__ dst) {
     __shared__ uint8_t lut[256];
+    // BY_ID: the record table of a genome (a few hundred rows) is copied to LDS once per workgroup, so
+    // resolving a query costs one LDS read instead of a second dependent trip to memory
+    constexpr int TABCAP = BY_ID ? 512 : 1;
+    __shared__ int64_t s_boff[TABCAP], s_slen[TABCAP], s_blen[TABCAP];
+    __shared__ int32_t s_llen[TABCAP], s_en[TABCAP];           // s_en = elen | norm << 8
+    const bool tab_lds = BY_ID && tab.n_seq <= TABCAP && tab.n_seq > 0;
     build_comp_lut(lut);
+    if (tab_lds)
+        for (int r = threadIdx.x; r < (int)tab.n_seq; r += BLOCK) {
+            s_boff[r] = tab.boff[r]; s_slen[r] = tab.slen[r]; s_blen[r] = tab.blen[r];
+            const int64_t ll = tab.llen[r];
+            s_llen[r] = ll > 0x7FFFFFFFll ? 0x7FFFFFFF : (int32_t)ll;
+            s_en[r] = tab.elen[r] | (tab.norm[r] << 8);
+        }
     __syncthreads();
     constexpr int QPW = 64 / G, NW = V / 4;
     const int lane = lane_id(), sub = lane & (G - 1), grp = lane / G;
     const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
+    // query descriptors are fetched one iteration ahead (the loop is a chain of dependent memory round
+    // trips: descriptor -> table -> sequence bytes; this takes the first one off the critical path)
+    int64_t d_a0 = 0, d_a1 = 0, d_a2 = 0, d_a3 = 0, d_off = 0;
+    int d_fl = flags_all;
+    auto fetch_desc = [&](int64_t i) {
+        if (i >= nq) return;
+        if (BY_ID) { d_a0 = q.seq_id[i]; d_a1 = q.start[i]; d_a2 = q.stop[i]; }
+        else       { d_a0 = q.off[i]; d_a1 = q.blen[i]; d_a2 = q.take[i]; d_a3 = q.skip ? q.skip[i] : 0; }
+        d_off = q.dst_off[i];
+        d_fl = q.qflags ? q.qflags[i] : flags_all;
+    };
+    fetch_desc(wave * QPW + grp);
     for (int64_t i0 = wave * QPW; i0 < nq; i0 += nwaves * QPW) {
         const int64_t i = i0 + grp;
         bool ok = i < nq;
+        const int64_t c_a0 = d_a0, c_a1 = d_a1, c_a2 = d_a2, c_a3 = d_a3, c_off = d_off;
+        const int fl = d_fl;
+        fetch_desc(i + nwaves * QPW);
         int64_t off = 0, blen = 0, skip = 0, take = 0;
+        int64_t r_boff = 0, r_el = 0, r_bpl = 0;
+        bool r_norm = false;
         if (ok) {
             if (BY_ID) {
-                const int64_t id = q.seq_id[i], a = q.start[i], b = q.stop[i];
-                if (id < 0 || id >= tab.n_seq || a < 0 || b < a || b > tab.slen[id]) {   // caller validates; stay safe
+                const int64_t id = c_a0, a = c_a1, b = c_a2;
+                int64_t r_slen = 0, r_blen = 0;
+                if (id >= 0 && id < tab.n_seq) {
+                    if (tab_lds) { r_boff = s_boff[id]; r_slen = s_slen[id]; r_blen = s_blen[id]; r_el = s_en[id] & 0xFF; r_norm = (s_en[id] >> 8) != 0;
+                                   r_bpl = (int64_t)s_llen[id] - r_el; if (s_llen[id] == 0x7FFFFFFF) r_bpl = tab.llen[id] - r_el; }
+                    else         { r_boff = tab.boff[id]; r_slen = tab.slen[id]; r_blen = tab.blen[id]; r_el = tab.elen[id]; r_norm = tab.norm[id] != 0;
+                                   r_bpl = tab.llen[id] - r_el; }
+                }
+                if (id < 0 || id >= tab.n_seq || a < 0 || b < a || b > r_slen) {   // caller validates; stay safe
                     if (sub == 0 && q.out_len) q.out_len[i] = -1;
                     ok = false;
                 } else {
                     take = b - a;
-                    const int64_t el = tab.elen[id], bpl = tab.llen[id] - el;
-                    if (tab.norm[id] && bpl > 0) {             // sequence.c:498-510
-                        const int64_t bs = a / bpl, be = b / bpl;
-                        off = tab.boff[id] + a + el * bs;
-                        blen = take + (be - bs) * el;
+                    if (r_norm && r_bpl > 0) {                 // sequence.c:498-510
+                        int64_t bs, be;
+                        if (((uint64_t)b | (uint64_t)r_bpl) >> 32) { bs = a / r_bpl; be = b / r_bpl; }
+                        else { bs = (uint32_t)a / (uint32_t)r_bpl; be = (uint32_t)b / (uint32_t)r_bpl; }
+                        off = r_boff + a + r_el * bs;
+                        blen = take + (be - bs) * r_el;
                     } else {                                   // sequence.c:100-110: despace whole record, then slice
-                        off = tab.boff[id]; blen = tab.blen[id]; skip = a;
+                        off = r_boff; blen = r_blen; skip = a;
                     }
                 }
             } else {
-                off = q.off[i]; blen = q.blen[i]; take = q.take[i]; skip = q.skip ? q.skip[i] : 0;
+                off = c_a0; blen = c_a1; take = c_a2; skip = c_a3;
             }
         }
-        const int fl = (ok && q.qflags) ? q.qflags[i] : flags_all;
+        uint8_t *out = dst + (ok ? c_off : 0);
+        if (BY_ID) {
+            // ---- line-arithmetic path
+            bool fast = false;
+            int64_t a = 0, el = 0, bpl = 0, in_a = 0;
+            if (ok && take > 0 && !(fl & 8)) {
+                a = c_a1; el = r_el; bpl = r_bpl;
+                in_a = off - gbase;                               // local offset of base `a` (off was computed above)
+                fast = r_norm && bpl >= 16 && bpl < (1ll << 31) && a + take < (1ll << 31) &&
+                       in_a >= 16 && in_a + blen + 32 <= n_bytes;
+            }
+            bool redo = false;
+            if (fast) {
+                const uint32_t bpl32 = (uint32_t)bpl;
+                const uint32_t r0 = (uint32_t)a % bpl32;          // column of base `a` in its line
+                const bool rev = (fl & 2) != 0;
+                bool irregular = false;
+                for (int64_t s0 = 0; s0 < take; s0 += G * 16) {
+                    const int64_t oc = s0 + 16 * sub;             // this lane writes out[oc, oc + len)
+                    const int len = (int)(take - oc < 16 ? take - oc : 16);
+                    if (len <= 0) continue;
+                    // forward indices [f0, f0 + len) of the query; `lead` unused bytes in front of them in the
+                    // lane's 16-byte window (reverse strand: the partial chunk is the head of the query)
+                    const int64_t f0 = rev ? take - oc - len : oc;
+                    const int lead = rev ? 16 - len : 0;
+                    const uint32_t xx = r0 + (uint32_t)f0;
+                    const uint32_t k = xx / bpl32, t = bpl32 - (xx - k * bpl32);   // line of f0 (relative), bases to its end
+                    const uint8_t *p1 = data + in_a + f0 + el * (int64_t)k - lead;
+                    uint4 v = *reinterpret_cast<const uint4_u *>(p1);
+                    if (t < (uint32_t)len) {                      // a line ends inside: bytes from index lead + t on come from el further
+                        const uint4 w = *reinterpret_cast<const uint4_u *>(p1 + el);
+                        const int T = lead + (int)t;
+                        const uint32_t m0 = lowbytes_word(T, 0), m1 = lowbytes_word(T, 1), m2 = lowbytes_word(T, 2), m3 = lowbytes_word(T, 3);
+                        v.x = (v.x & m0) | (w.x & ~m0); v.y = (v.y & m1) | (w.y & ~m1);
+                        v.z = (v.z & m2) | (w.z & ~m2); v.w = (v.w & m3) | (w.w & ~m3);
+                    }
+                    if (t < (uint32_t)len || (t == (uint32_t)len && f0 + len < take)) {   // the terminator after base f0 + t - 1 is skipped
+                        const uint8_t *gp = p1 + lead + t;
+                        irregular |= !is_space3(gp[0]) || (el == 2 && !is_space3(gp[1]));
+                    }
+                    {   // no white space among the bases taken
+                        const int lo_b = lead, hi_b = lead + len;
+                        uint32_t f = le20_bytes(v.x) & lowbytes_word(hi_b, 0) & ~lowbytes_word(lo_b, 0);
+                        f |= le20_bytes(v.y) & lowbytes_word(hi_b, 1) & ~lowbytes_word(lo_b, 1);
+                        f |= le20_bytes(v.z) & lowbytes_word(hi_b, 2) & ~lowbytes_word(lo_b, 2);
+                        f |= le20_bytes(v.w) & lowbytes_word(hi_b, 3) & ~lowbytes_word(lo_b, 3);
+                        irregular |= f != 0;
+                    }
+                    if (fl & 1) { v.x = upper4(v.x); v.y = upper4(v.y); v.z = upper4(v.z); v.w = upper4(v.w); }
+                    if (fl & 4) { v.x = lut4(lut, v.x); v.y = lut4(lut, v.y); v.z = lut4(lut, v.z); v.w = lut4(lut, v.w); }
+                    if (rev) v = make_uint4(__builtin_bswap32(v.w), __builtin_bswap32(v.z), __builtin_bswap32(v.y), __builtin_bswap32(v.x));
+                    store_low_bytes(out + oc, v, len);
+                }
+                const unsigned long long ib = __ballot(irregular);
+                redo = ((ib >> (grp * G)) & (G == 64 ? ~0ull : ((1ull << G) - 1ull))) != 0;
+                if (!redo && sub == 0 && q.out_len) q.out_len[i] = take;
+            }
+            if (fast && !redo) ok = false;                         // done: nothing left for the general path
+            if (!ok) { take = 0; blen = 0; }
+        }
+        // ---- general path
         // clamp to the bytes we hold (fread past EOF returns short, index.c:689)
         int64_t lo = off - gbase, hi = lo + blen;
         if (lo < 0) lo = 0;
         if (hi > n_bytes) hi = n_bytes;
         if (!ok) { lo = 0; hi = 0; }
-        uint8_t *out = dst + (ok ? q.dst_off[i] : 0);
         const int64_t end = skip + take;
         int64_t rank = 0;                                      // kept bytes before this window
         for (int64_t p = lo & ~(int64_t)(V - 1); p < hi && rank < end; p += G * V) {
