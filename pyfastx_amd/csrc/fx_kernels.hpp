@@ -5,12 +5,9 @@
 // structure survives here: the stream is resident in HBM and is processed as
 //
 //   FASTA index   fx_spanscan.hpp: one read of the stream, per-4-KiB summaries, no line table
-//   FASTQ index   K1 k_scan       bytes -> 1 bit/byte newline mask + per-tile counts   (reads the file once)
-//                 K2 k_group_*    exclusive prefix over the per-tile counts            (tiny)
-//                 K3 k_linetable  newline mask -> int64 line table nl[]               (n/8 bytes in, 8 B/line out)
-//                 k_fastq_rec / k_fastq_comp / k_fastq_fetch
-//   fetch         K7 k_fetch      G lanes per query: gather, despace, upper, revcomp   (index.c:683-707, util.c:157-269)
-//   composition   k_fasta_comp
+//   FASTQ index   fx_fastq.hpp: count pass + emit pass (one lane per newline), no line table
+//   fetch         k_fetch / k_fastq_fetch: gather, despace, upper, revcomp, phred  (index.c:683-707, util.c:157-269, read.c)
+//   composition   k_fasta_comp (here), k_fastq_comp (fx_fastq.hpp)
 //
 // Integer/byte work only: no MFMA anywhere; the roofline is HBM bandwidth.
 #pragma once
@@ -23,21 +20,22 @@ constexpr int BLOCK = 256;                      // 4 waves of 64
 constexpr int UNROLL = 8;                       // 16-byte loads in flight per lane
 constexpr int CHUNK = 16;                       // bytes per lane per load (global_load_dwordx4)
 constexpr int TILE = BLOCK * CHUNK * UNROLL;    // 32 KiB of file per workgroup
-constexpr int TILE_CHUNKS = BLOCK * UNROLL;     // 2048 mask words (u16) per tile
-constexpr int GROUP = BLOCK;                    // tiles per prefix group (one count per thread of a consumer block)
 
 // ---------------------------------------------------------------- SWAR bytes
 // 0x80 in every byte of x that is zero (exact, no borrow false positives).
 __device__ __forceinline__ uint32_t zero_bytes(uint32_t x) {
     return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
 }
-// gather the four 0x80 flags of a word into bits 0..3
-__device__ __forceinline__ uint32_t flags4(uint32_t t) {
-    return (((t >> 7) & 0x01010101u) * 0x00204081u >> 21) & 0xFu;
-}
+// gather the four 0x80 flags of a word into bits 0..3: v_dot4_u32_u8 with byte weights 1,2,4,8 gives 128 * mask
+__device__ __forceinline__ uint32_t flags4(uint32_t t) { return __builtin_amdgcn_udot4(t, 0x08040201u, 0u, false) >> 7; }
+// 16-bit mask of the bytes of v equal to the byte replicated in pat (bit k <-> byte k): two dot4 accumulations
+// per 8 bytes (weights 1..8 and 16..128), 128 * mask8 each
 __device__ __forceinline__ uint32_t eq_mask16(const uint4 &v, uint32_t pat) {
-    return flags4(zero_bytes(v.x ^ pat)) | (flags4(zero_bytes(v.y ^ pat)) << 4) |
-           (flags4(zero_bytes(v.z ^ pat)) << 8) | (flags4(zero_bytes(v.w ^ pat)) << 12);
+    uint32_t lo = __builtin_amdgcn_udot4(zero_bytes(v.x ^ pat), 0x08040201u, 0u, false);
+    lo = __builtin_amdgcn_udot4(zero_bytes(v.y ^ pat), 0x80402010u, lo, false);
+    uint32_t hi = __builtin_amdgcn_udot4(zero_bytes(v.z ^ pat), 0x08040201u, 0u, false);
+    hi = __builtin_amdgcn_udot4(zero_bytes(v.w ^ pat), 0x80402010u, hi, false);
+    return (lo >> 7) | (hi << 1);
 }
 __device__ __forceinline__ uint32_t any_eq16(const uint4 &v, uint32_t pat) {
     return zero_bytes(v.x ^ pat) | zero_bytes(v.y ^ pat) | zero_bytes(v.z ^ pat) | zero_bytes(v.w ^ pat);
@@ -108,189 +106,6 @@ __device__ __forceinline__ int64_t upper_bound(const int64_t *__restrict__ a, in
     while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (a[mid] <= key) lo = mid + 1; else hi = mid; }
     return lo;
 }
-
-// ======================================================================= K1
-// Delimiter scan.  One workgroup per 32 KiB tile; every lane issues UNROLL
-// independent 16-byte loads (a wave covers 1 KiB contiguous per instruction),
-// turns each into a 16-bit "byte == '\n'" mask with SWAR arithmetic, stores the
-// mask (2 B/lane, coalesced) and counts.  With HDR the lane also tests for '>'
-// and, only when one is present (rare outside header lines), checks the byte
-// before it: a FASTA header is a '>' that follows '\n' or starts the stream
-// (index.c:234, line.s[0] == 62).
-// Replaces: ks_getuntil's byte loop kseq.c:78-80 and the memcpy kseq.c:94.
-// Launch shape (tuned with tools/scanbench.hip on MI355X, 3 GB input): 1024-thread
-// workgroups, 4 loads in flight per lane, non-temporal loads (the stream is read
-// exactly once; nt keeps it from displacing L2/MALL lines): 5.6 TB/s including the
-// mask store, vs 4.7 TB/s for 256 threads x 8 loads with default-policy loads.  A
-// workgroup covers SCAN_TILES (2) consecutive 32 KiB tiles and emits one count per tile.
-constexpr int SCAN_BLOCK = 1024;
-constexpr int SCAN_UNROLL = 4;
-constexpr int SCAN_SPAN = SCAN_BLOCK * CHUNK * SCAN_UNROLL;     // 64 KiB per workgroup
-constexpr int SCAN_TILES = SCAN_SPAN / TILE;                    // 2
-constexpr int ROWS_PER_TILE = SCAN_UNROLL / SCAN_TILES;         // 2 rows of 16 KiB per tile
-
-__device__ __forceinline__ uint4 load16_nt(const uint8_t *__restrict__ data, int64_t p, int64_t n) {
-    if (p + CHUNK <= n) {
-        const uint4 *q = reinterpret_cast<const uint4 *>(data + p);
-        uint4 v;
-        v.x = __builtin_nontemporal_load(&q->x); v.y = __builtin_nontemporal_load(&q->y);
-        v.z = __builtin_nontemporal_load(&q->z); v.w = __builtin_nontemporal_load(&q->w);
-        return v;
-    }
-    return load16(data, p, n);
-}
-
-template <bool HDR>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan(const uint8_t *__restrict__ data, int64_t n, int prev_byte,
-                                                    uint16_t *__restrict__ nlmask, uint32_t *__restrict__ tile_nl,
-                                                    uint32_t *__restrict__ tile_hdr, int64_t ntiles) {
-    __shared__ uint32_t red[2][SCAN_TILES][SCAN_BLOCK / 64];
-    const int64_t span = blockIdx.x;
-    const int64_t sbase = span * (int64_t)SCAN_SPAN;
-    const int tid = threadIdx.x;
-    uint4 v[SCAN_UNROLL];
-#pragma unroll
-    for (int j = 0; j < SCAN_UNROLL; ++j) v[j] = load16_nt(data, sbase + (int64_t)(j * SCAN_BLOCK + tid) * CHUNK, n);
-    uint32_t cnt[SCAN_TILES], hcnt[SCAN_TILES];
-#pragma unroll
-    for (int t = 0; t < SCAN_TILES; ++t) { cnt[t] = 0; hcnt[t] = 0; }
-#pragma unroll
-    for (int j = 0; j < SCAN_UNROLL; ++j) {
-        const uint32_t m = eq_mask16(v[j], 0x0A0A0A0Au);
-        nlmask[span * (SCAN_SPAN / CHUNK) + j * SCAN_BLOCK + tid] = (uint16_t)m;
-        cnt[j / ROWS_PER_TILE] += __popc(m);
-        if (HDR) {
-            if (any_eq16(v[j], 0x3E3E3E3Eu)) {
-                uint32_t g = eq_mask16(v[j], 0x3E3E3E3Eu);
-                const int64_t p = sbase + (int64_t)(j * SCAN_BLOCK + tid) * CHUNK;
-                while (g) {
-                    const int k = __ffs(g) - 1;
-                    g &= g - 1;
-                    const int64_t pos = p + k;
-                    const int prev = pos ? (int)data[pos - 1] : prev_byte;
-                    hcnt[j / ROWS_PER_TILE] += (prev == '\n');
-                }
-            }
-        }
-    }
-    const int w = tid >> 6, l = tid & 63;
-#pragma unroll
-    for (int t = 0; t < SCAN_TILES; ++t) {
-        const uint32_t a = wave_sum(cnt[t]);
-        if (l == 0) red[0][t][w] = a;
-        if (HDR) { const uint32_t b = wave_sum(hcnt[t]); if (l == 0) red[1][t][w] = b; }
-    }
-    __syncthreads();
-    if (tid < SCAN_TILES * (HDR ? 2 : 1)) {
-        const int t = tid % SCAN_TILES, which = tid / SCAN_TILES;
-        uint32_t s = 0;
-#pragma unroll
-        for (int i = 0; i < SCAN_BLOCK / 64; ++i) s += red[which][t][i];
-        const int64_t tile = span * SCAN_TILES + t;
-        if (tile < ntiles) (which ? tile_hdr : tile_nl)[tile] = s;
-    }
-}
-
-// ======================================================================= K2
-// The global prefix of the per-tile counts is two-level: k_group_sum adds up each
-// GROUP (256) of tile counts (one wave per group), k_group_scan scans those sums
-// (ntiles/256 words: 364 for a 3 GB file), and every consumer workgroup adds the
-// counts of the tiles before it inside its own group (tile_prefix below).
-__global__ __launch_bounds__(BLOCK) void k_group_sum(const uint32_t *__restrict__ tile_a, const uint32_t *__restrict__ tile_b,
-                                                    int64_t ntiles, int64_t ngroups,
-                                                    unsigned long long *__restrict__ grp_cnt) {
-    const int lane = lane_id();
-    const int64_t g = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
-    if (g >= ngroups) return;
-    uint32_t a = 0, b = 0;
-#pragma unroll
-    for (int k = 0; k < GROUP / 64; ++k) {
-        const int64_t t = g * GROUP + k * 64 + lane;
-        if (t < ntiles) { a += tile_a[t]; if (tile_b) b += tile_b[t]; }
-    }
-    a = wave_sum(a);
-    if (tile_b) b = wave_sum(b);
-    if (lane == 0) { grp_cnt[g] = a; if (tile_b) grp_cnt[ngroups + g] = b; }
-}
-
-// Exclusive prefix over the per-GROUP counts (ntiles/256 words: 364 for a 3 GB
-// file), one workgroup, `nsets` independent arrays back to back.
-// off[s*(ngroups+1) + g] = sum(cnt[s*ngroups + 0..g)), last entry = total.
-__global__ __launch_bounds__(1024) void k_group_scan(const unsigned long long *__restrict__ cnt, int64_t ngroups,
-                                                    int nsets, int64_t *__restrict__ off) {
-    __shared__ unsigned long long wsum[16];
-    __shared__ unsigned long long carry;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int s = 0; s < nsets; ++s) {
-        if (tid == 0) carry = 0;
-        __syncthreads();
-        for (int64_t g0 = 0; g0 < ngroups; g0 += 1024) {
-            const int64_t g = g0 + tid;
-            const unsigned long long v = g < ngroups ? cnt[s * ngroups + g] : 0ull;
-            unsigned long long inc = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { unsigned long long t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
-            if (lane == 63) wsum[w] = inc;
-            __syncthreads();
-            unsigned long long base = carry;
-            for (int i = 0; i < w; ++i) base += wsum[i];
-            if (g < ngroups) off[s * (ngroups + 1) + g] = (int64_t)(base + inc - v);
-            __syncthreads();
-            if (tid == 1023) carry = base + inc;
-            __syncthreads();
-        }
-        if (tid == 0) off[s * (ngroups + 1) + ngroups] = (int64_t)carry;
-        __syncthreads();
-    }
-}
-
-// prefix of a tile inside its group: sum of the counts of the tiles before it (<= 255 loads, one per thread)
-__device__ __forceinline__ int64_t tile_prefix(const uint32_t *__restrict__ tile_cnt, const int64_t *__restrict__ grp_off,
-                                               int64_t tile, uint32_t *lds4) {
-    const int64_t g = tile / GROUP, idx = g * GROUP + threadIdx.x;
-    const uint32_t v = idx < tile ? tile_cnt[idx] : 0u;
-    return grp_off[g] + (int64_t)block_sum(v, lds4);
-}
-
-// ======================================================================= K3
-// Newline mask -> line table.  One workgroup per tile; each lane takes 8
-// consecutive 16-bit masks (one 16-byte load = 128 bytes of file), the block
-// does an exclusive scan of the popcounts, and every lane writes the GLOBAL
-// offsets of its newlines at nl[tile_off + rank].
-// nl[i] is the offset of the '\n' that terminates line i; it carries
-// `position += line.l + 1` (index.c:231, fastq.c:148) for every line at once.
-__global__ __launch_bounds__(BLOCK) void k_linetable(const uint16_t *__restrict__ nlmask,
-                                                    const uint32_t *__restrict__ tile_nl,
-                                                    const int64_t *__restrict__ grp_off, int64_t gbase,
-                                                    int64_t *__restrict__ nl, int64_t cap) {
-    __shared__ uint32_t lds4[4];
-    const int64_t tile = blockIdx.x;
-    const int tid = threadIdx.x;
-    if (tile_nl[tile] == 0) return;
-    const int64_t tbase_rank = tile_prefix(tile_nl, grp_off, tile, lds4);
-    const uint4 mv = *reinterpret_cast<const uint4 *>(nlmask + tile * TILE_CHUNKS + tid * 8);
-    const uint32_t w[4] = {mv.x, mv.y, mv.z, mv.w};
-    const uint32_t cnt = __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);
-    uint32_t total;
-    uint32_t r = block_excl_scan(cnt, lds4, &total);
-    if (cnt == 0) return;
-    // `cap`: the table is allocated from an estimate before the host knows the total (it learns it
-    // while this kernel runs); ranks beyond it are dropped and the host re-runs with the exact size
-    int64_t rk = tbase_rank + r;
-    const int64_t p0 = gbase + tile * (int64_t)TILE + (int64_t)tid * 8 * CHUNK;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        uint32_t m = w[q];                        // two 16-bit masks = 32 bytes of file, bit i = byte i
-        while (m) {
-            const int k = __ffs(m) - 1;
-            m &= m - 1;
-            if (rk < cap) nl[rk] = p0 + q * 32 + k;
-            ++rk;
-        }
-    }
-}
-
-__global__ void k_set_i64(int64_t *p, int64_t v) { *p = v; }
 
 // FASTA record table columns (SoA, one entry per header line).  Column semantics follow
 // index.c:234-339 exactly, including the quirks (elen taken from the header line only,
@@ -603,184 +418,6 @@ __global__ __launch_bounds__(BLOCK) void k_revcomp(uint8_t *__restrict__ buf, in
             buf[i] = lut[buf[i]];
         }
     }
-}
-
-// ================================================================ FASTQ (K4')
-// The `line_num % 4` state machine of fastq.c:89-149 becomes a gather from the
-// line table: record k owns lines 4k .. 4k+3.  Shard context (FqCtx) makes the
-// same kernels serve byte-range shards: nl[] is local (index i = global line
-// loff + i), a record is owned by the shard in whose core its header line STARTS,
-// and the bytes of its remaining lines may lie in the halo that follows the core.
-struct FastqCols {
-    int64_t *name_off, *rlen, *soff, *qoff;
-    int32_t *name_len, *dlen;
-};
-struct FastqAcc {            // device accumulators
-    unsigned long long size;
-    unsigned long long a, c, g, t, n;
-    unsigned long long n_owned;
-    long long maxlen, minlen;
-    int minqs, maxqs;
-    int err;                 // 1: a record ran past the halo
-    int pad;
-};
-struct FqCtx {
-    int64_t gbase;           // global offset of data[0]
-    int64_t core_end;        // global offset one past the shard's core
-    int64_t loff;            // global line index of nl[0]
-    int64_t prev_nl;         // global offset of newline loff-1 (-1: none)
-    int64_t k_first;         // first record owned by this shard (global id of local row 0)
-    int is_last;
-};
-
-// global offset where line j (0..3) of record k starts / the newline that ends it
-__device__ __forceinline__ int64_t fq_line_end(const FqCtx &x, const int64_t *nl, int64_t k, int j) { return nl[4 * k + j - x.loff]; }
-__device__ __forceinline__ int64_t fq_line_start(const FqCtx &x, const int64_t *nl, int64_t k, int j) {
-    const int64_t i = 4 * k + j - 1 - x.loff;
-    return (i >= 0 ? nl[i] : x.prev_nl) + 1;
-}
-
-// One thread per candidate record: columns of the `read` table (fastq.c:99-145), stat.size
-// (sum of rlen, including an incomplete trailing record's sequence line, fastq.c:125) and the
-// min/max quality-line length for meta.maxlen/minlen (fastq.c:747-751).
-__global__ __launch_bounds__(BLOCK) void k_fastq_rec(const uint8_t *__restrict__ data, FqCtx x,
-                                                    const int64_t *__restrict__ nl, int64_t n_nl, int64_t n_cand,
-                                                    FastqCols c, FastqAcc *acc) {
-    __shared__ long long red[4][BLOCK / 64];
-    int64_t rl_sum = 0;
-    long long qmax = 0, qmin = 10000000000LL;
-    unsigned owned = 0;
-    int err = 0;
-    const int64_t stride = (int64_t)gridDim.x * BLOCK;
-    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < n_cand; t += stride) {
-        const int64_t k = x.k_first + t;
-        const int64_t i0 = 4 * k - x.loff;                // local index of the newline ending the header line
-        if (i0 - 1 >= n_nl) continue;                     // header start unknown: no such line
-        const int64_t s0 = fq_line_start(x, nl, k, 0);
-        if (s0 >= x.core_end) continue;                   // owned by a later shard (or past the data)
-        if (i0 + 3 < n_nl) {                              // all four lines present
-            const int64_t e0 = nl[i0], soff = e0 + 1, e1 = nl[i0 + 1];
-            const int64_t l1 = e1 - soff;
-            const int64_t rl = (l1 > 0 && data[e1 - 1 - x.gbase] == '\r') ? l1 - 1 : l1;   // fastq.c:124-128
-            const int dlen = (int)(e0 - s0);              // fastq.c:103 (includes '@' and '\r')
-            int64_t nlen = dlen - 1;
-            if (nlen > 0 && data[e0 - 1 - x.gbase] == '\r') --nlen;        // fastq.c:107-109
-            // first ' ' of the name (fastq.c:112-117), 8 aligned bytes at a time
-            const int64_t nb = s0 + 1 - x.gbase, ne = nb + nlen;
-            for (int64_t p = nb & ~7ll; p < ne; p += 8) {
-                const uint2 w = *reinterpret_cast<const uint2 *>(data + p);
-                uint32_t m = flags4(zero_bytes(w.x ^ 0x20202020u)) | (flags4(zero_bytes(w.y ^ 0x20202020u)) << 4);
-                if (p < nb) m &= 0xFFu << (nb - p);
-                if (m) { const int64_t hit = p + __ffs(m) - 1; if (hit < ne) nlen = hit - nb; break; }
-            }
-            const int64_t qoff = nl[i0 + 2] + 1, e3 = nl[i0 + 3];
-            long long ql = e3 - qoff;
-            if (ql > 0 && data[e3 - 1 - x.gbase] == '\r') --ql;            // fastq.c:734-737 (trailing CR)
-            qmax = ql > qmax ? ql : qmax; qmin = ql < qmin ? ql : qmin;
-            c.name_off[t] = s0 + 1; c.name_len[t] = (int32_t)nlen; c.dlen[t] = dlen;
-            c.rlen[t] = rl; c.soff[t] = soff; c.qoff[t] = qoff;
-            rl_sum += rl;
-            ++owned;
-        } else if (!x.is_last) {
-            err = 1;                                      // the record runs past the halo
-        } else if (i0 + 1 < n_nl) {                       // incomplete trailing record: its sequence line still counts (fastq.c:125)
-            const int64_t soff = nl[i0] + 1, e1 = nl[i0 + 1];
-            const int64_t l1 = e1 - soff;
-            rl_sum += (l1 > 0 && data[e1 - 1 - x.gbase] == '\r') ? l1 - 1 : l1;
-        }
-    }
-    // one set of atomics per workgroup
-    rl_sum = wave_sum64(rl_sum);
-    long long own = wave_sum64((int64_t)owned);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        long long a = __shfl_xor(qmax, d, 64), b = __shfl_xor(qmin, d, 64);
-        qmax = a > qmax ? a : qmax; qmin = b < qmin ? b : qmin;
-    }
-    if (__any(err)) acc->err = 1;
-    const int w = threadIdx.x >> 6;
-    if (lane_id() == 0) { red[0][w] = rl_sum; red[1][w] = own; red[2][w] = qmax; red[3][w] = qmin; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        long long s = 0, o = 0, mx = 0, mn = 10000000000LL;
-        for (int i = 0; i < BLOCK / 64; ++i) { s += red[0][i]; o += red[1][i]; mx = red[2][i] > mx ? red[2][i] : mx; mn = red[3][i] < mn ? red[3][i] : mn; }
-        if (s) atomicAdd(&acc->size, (unsigned long long)s);
-        if (o) atomicAdd(&acc->n_owned, (unsigned long long)o);
-        if (o) { atomicMax(&acc->maxlen, mx); atomicMin(&acc->minlen, mn); }
-    }
-}
-
-// FASTQ composition (fastq.c:715-753).  16 lanes per record, 4 records per wave; a lane
-// reads 16 aligned bytes per step (256-byte window per record).  Sequence line: SWAR
-// compare+popcount for 'A','C','G','T' (upper case only) and '\r' (ignored); every other
-// byte is N.  Quality line: min / max byte, '\r' ignored.
-__device__ __forceinline__ uint32_t valid16(int64_t pp, int64_t lo, int64_t hi) {
-    int64_t a0 = lo - pp, a1 = hi - pp;
-    a0 = a0 < 0 ? 0 : (a0 > 16 ? 16 : a0);
-    a1 = a1 < 0 ? 0 : (a1 > 16 ? 16 : a1);
-    return a1 > a0 ? (((1u << a1) - 1u) & ~((1u << a0) - 1u)) : 0u;
-}
-__global__ __launch_bounds__(BLOCK) void k_fastq_comp(const uint8_t *__restrict__ data, FqCtx x,
-                                                     const int64_t *__restrict__ nl, int64_t n_nl,
-                                                     int64_t n_cand, FastqAcc *acc) {
-    const int lane = lane_id(), sub = lane & 15, grp = lane >> 4;
-    const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
-    uint32_t ca = 0, cc = 0, cg = 0, ct = 0, cn = 0;       // per lane, flushed per record batch (no overflow: <= 16 per step)
-    unsigned long long ta = 0, tc = 0, tg = 0, tt = 0, tn = 0;
-    int qmin = 104, qmax = 33;                             // fastq.c:667-668
-    for (int64_t t0 = wave * 4; t0 < n_cand; t0 += nwaves * 4) {
-        const int64_t k = x.k_first + t0 + grp;
-        const int64_t i0 = 4 * k - x.loff;
-        bool mine = (t0 + grp) < n_cand && i0 - 1 < n_nl && i0 < n_nl;
-        if (mine) mine = fq_line_start(x, nl, k, 0) < x.core_end;
-        if (mine && i0 + 1 < n_nl) {                       // line_num % 4 == 2
-            const int64_t s = nl[i0] + 1 - x.gbase, e = nl[i0 + 1] - x.gbase;
-            for (int64_t p = (s & ~15ll) + sub * 16; p < e; p += 256) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(data + p);
-                const uint32_t ok = valid16(p, s, e);
-                const uint32_t ma = eq_mask16(v, 0x41414141u) & ok, mc = eq_mask16(v, 0x43434343u) & ok;
-                const uint32_t mg = eq_mask16(v, 0x47474747u) & ok, mt = eq_mask16(v, 0x54545454u) & ok;
-                const uint32_t mr = eq_mask16(v, 0x0D0D0D0Du) & ok;
-                ca += __popc(ma); cc += __popc(mc); cg += __popc(mg); ct += __popc(mt);
-                cn += __popc(ok & ~(ma | mc | mg | mt | mr));
-            }
-        }
-        if (mine && i0 + 3 < n_nl) {                       // line_num % 4 == 0
-            const int64_t s = nl[i0 + 2] + 1 - x.gbase, e = nl[i0 + 3] - x.gbase;
-            for (int64_t p = (s & ~15ll) + sub * 16; p < e; p += 256) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(data + p);
-                uint32_t ok = valid16(p, s, e) & ~eq_mask16(v, 0x0D0D0D0Du);
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                while (ok) {
-                    const int j = __ffs(ok) - 1;
-                    ok &= ok - 1;
-                    const int q = (int)(signed char)(w[j >> 2] >> ((j & 3) * 8));
-                    qmin = q < qmin ? q : qmin; qmax = q > qmax ? q : qmax;
-                }
-            }
-        }
-        ta += ca; tc += cc; tg += cg; tt += ct; tn += cn;
-        ca = cc = cg = ct = cn = 0;
-    }
-    ta = wave_sum64(ta); tc = wave_sum64(tc); tg = wave_sum64(tg); tt = wave_sum64(tt); tn = wave_sum64(tn);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        int a = __shfl_xor(qmin, d, 64), b = __shfl_xor(qmax, d, 64);
-        qmin = a < qmin ? a : qmin; qmax = b > qmax ? b : qmax;
-    }
-    if (lane == 0) {
-        if (ta) atomicAdd(&acc->a, ta); if (tc) atomicAdd(&acc->c, tc); if (tg) atomicAdd(&acc->g, tg);
-        if (tt) atomicAdd(&acc->t, tt); if (tn) atomicAdd(&acc->n, tn);
-        atomicMin(&acc->minqs, qmin); atomicMax(&acc->maxqs, qmax);
-    }
-}
-
-// number of entries of the sorted table that are < key, and the last such entry (-1 if none)
-__global__ void k_count_below(const int64_t *__restrict__ a, int64_t n, int64_t key, int64_t *out) {
-    const int64_t c = lower_bound(a, n, key);
-    out[0] = c;
-    out[1] = c ? a[c - 1] : -1;
 }
 
 // FASTQ read fetch (read.c:37-45,152-167,237-278): one wave per read copies

@@ -135,7 +135,9 @@ __device__ __forceinline__ uint32_t wave_sum_small(uint32_t c) {
 // Granules that hold a header line are appended to hgl (order irrelevant): k_hdr_collect re-reads them.
 struct GranList { uint32_t *g; uint32_t *count; };
 
-template <bool FULL>
+// MODE 0: the full FASTA summary.  MODE 1 (FASTQ, where records are "every four lines"): newline count and the
+// first / last newline only -- no line-length set, no header lines.
+template <bool FULL, int MODE = 0>
 __device__ __forceinline__ void granule(const uint8_t *__restrict__ data, int64_t n, int prev_byte, int is_last,
                                         int64_t g, GranPk *__restrict__ out, const GranList &hgl, uint32_t &L) {
     const int lane = lane_id();
@@ -173,9 +175,20 @@ __device__ __forceinline__ void granule(const uint8_t *__restrict__ data, int64_
     uint32_t n_w = 0, h_w = 0;                  // wave-uniform counts
     int first_w = -1, carry = -1;               // wave-uniform: first / latest newline (granule-local)
 
+    uint32_t n_lane = 0;                         // MODE 1: per-lane newline count
 #pragma unroll
     for (int j = 0; j < GR_ROWS; ++j) {
         const uint32_t cb = j * 1024 + lane * CHUNK;
+        if (MODE == 1) {
+            const uint32_t m = eq_mask16(v[j], 0x0A0A0A0Au);
+            n_lane += __popc(m);
+            const unsigned long long b = __ballot(m != 0);
+            if (b) {
+                if (first_w < 0) first_w = (int)rdlane(cb + (__ffs(m) - 1), __ffsll(b) - 1);
+                carry = (int)rdlane(cb + (31 - __clz(m)), 63 - __clzll(b));
+            }
+            continue;
+        }
         const uint32_t t0 = zero_bytes(v[j].x ^ 0x0A0A0A0Au), t1 = zero_bytes(v[j].y ^ 0x0A0A0A0Au);
         const uint32_t t2 = zero_bytes(v[j].z ^ 0x0A0A0A0Au), t3 = zero_bytes(v[j].w ^ 0x0A0A0A0Au);
         const uint32_t q = (t0 >> 7) | (t1 >> 6) | (t2 >> 5) | (t3 >> 4);      // bit 8*b+k <-> byte 4*k+b
@@ -233,6 +246,7 @@ __device__ __forceinline__ void granule(const uint8_t *__restrict__ data, int64_
             h_w += wave_sum_small(__popc(header_mask16(v[j], nlm, data, sbase + cb, prev_byte)));
         }
     }
+    if (MODE == 1) n_w = wave_sum(n_lane);
     if (lane == 0) {
         GranOut o;
         o.n = n_w; o.h = h_w; o.first = (uint32_t)first_w; o.last = (uint32_t)carry;
@@ -246,12 +260,13 @@ __device__ __forceinline__ void granule(const uint8_t *__restrict__ data, int64_
 // launched here; the last, partial one (which also holds the virtual end-of-stream newline) is done by
 // k_gran_reduce with the FULL = false instantiation, so its bounds-checked loads cost this kernel
 // neither registers nor branches.
+template <int MODE>
 __global__ __launch_bounds__(1024) void k_span_scan(const uint8_t *__restrict__ data, int64_t n, int prev_byte,
                                                    int is_last, int64_t g_end, GranPk *__restrict__ out, GranList hgl) {
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     uint32_t L = 0;
-    for (int64_t g = wave; g < g_end; g += nwaves) granule<true>(data, n, prev_byte, is_last, g, out, hgl, L);
+    for (int64_t g = wave; g < g_end; g += nwaves) granule<true, MODE>(data, n, prev_byte, is_last, g, out, hgl, L);
 }
 
 // ============================================================== granule prefixes
@@ -306,12 +321,13 @@ __device__ __forceinline__ Tri gran_tri(const GranPk *__restrict__ go, int64_t g
     return Tri{(long long)o.n, (long long)o.h, o.n ? gbase + g * (long long)GRAN + o.last : -1};
 }
 
+template <int MODE>
 __global__ __launch_bounds__(CHUNK_GRANS) void k_gran_reduce(const uint8_t *__restrict__ data, int64_t n, int prev_byte,
                                                             int is_last, GranList hgl, GranPk *__restrict__ go,
                                                             int64_t ngran, int64_t gbase, ChunkTot *__restrict__ ct) {
     __shared__ Tri lds[CHUNK_GRANS / 64];
     if (blockIdx.x == gridDim.x - 1) {          // the tail granule (index ngran - 1) belongs to the last chunk
-        if (threadIdx.x < 64) { uint32_t L = 0; granule<false>(data, n, prev_byte, is_last, ngran - 1, go, hgl, L); }
+        if (threadIdx.x < 64) { uint32_t L = 0; granule<false, MODE>(data, n, prev_byte, is_last, ngran - 1, go, hgl, L); }
         __threadfence_block();
         __syncthreads();
     }

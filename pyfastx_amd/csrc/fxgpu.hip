@@ -21,6 +21,7 @@
 #include "../../include/fxgpu.h"
 #include "fx_kernels.hpp"
 #include "fx_spanscan.hpp"
+#include "fx_fastq.hpp"
 #include "fx_inflate.hpp"
 
 using namespace fx;
@@ -74,12 +75,10 @@ template <class T> struct DevBuf {      // grow-only device array: rebuilds reus
 // Optional per-kernel HIP-event timing on the handle's own stream (bench.py's
 // roofline leg reads it; off by default so the hot path records no events).
 enum KernelId { K_SPAN_SCAN = 0, K_GRAN_REDUCE, K_GRAN_PREFIX, K_HDR_REC, K_GRAN_LINES, K_FASTA_FINALIZE, K_FETCH,
-                K_FASTA_COMP, K_SCAN, K_TILE_SCAN, K_LINETABLE, K_FASTQ_REC, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE,
-                K_NKERN };
+                K_FASTA_COMP, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_NKERN };
 static const char *const kKernelNames[K_NKERN] = {
     "k_span_scan", "k_gran_reduce", "k_gran_prefix", "k_hdr_rec", "k_gran_lines", "k_fasta_finalize", "k_fetch",
-    "k_fasta_comp", "k_scan", "k_group_scan", "k_linetable", "k_fastq_rec", "k_fastq_comp", "k_fastq_fetch",
-    "k_bgzf_inflate"};
+    "k_fasta_comp", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_inflate"};
 
 struct Prof {
     bool on = false;
@@ -133,16 +132,8 @@ struct fx_handle {
     int64_t base = 0;
     int prev_byte = '\n';
     bool is_last = true;
-    // scan products
-    int64_t ntiles = 0;
-    DevBuf<uint16_t> nlmask;
-    DevBuf<uint32_t> tile_nl;
-    DevBuf<unsigned long long> grp_cnt;       // per-group (256 tiles) newline / header counts
-    DevBuf<int64_t> grp_off;                  // their exclusive prefixes (+ totals)
-    DevBuf<int64_t> nl;       // line table incl. virtual EOF newline
-    int64_t n_nl = 0;         // entries in nl
-    int64_t n_real_nl = 0;    // real '\n' bytes
-    bool scanned = false;
+    int64_t n_nl = 0;         // newlines of the shard, the virtual end-of-stream one included
+    bool scanned = false;     // granule summaries + prefixes are valid (FASTQ count pass)
     // FASTA scan products (fx_spanscan.hpp): per-granule summaries and their prefixes
     int64_t ngran = 0;
     DevBuf<GranPk> gran;
@@ -159,16 +150,15 @@ struct fx_handle {
     bool fasta_built = false;
     // FASTQ table
     DevBuf<int64_t> fq_name_off, fq_rlen, fq_soff, fq_qoff;
-    DevBuf<int32_t> fq_name_len, fq_dlen;
+    DevBuf<int32_t> fq_name_len, fq_dlen, fq_qlen;
     DevBuf<FastqAcc> fq_acc;
-    int64_t n_reads = 0, fq_size = 0;
+    int64_t n_reads = 0, fq_size = 0, fq_seq_rows = 0;    // complete records; rows that have a sequence line (>= n_reads)
+    int64_t fq_c2 = 0;         // newlines of the shard below core_end - 1 (ownership of records, fx_fastq_scan)
     long long fq_maxlen = 0, fq_minlen = 0;
     bool fastq_built = false;
     DevBuf<uint8_t> arena;     // scratch for host-array calls (Staged)
     int64_t arena_used = 0;
     int64_t halo = 0;          // trailing bytes of the blob that belong to the next shard's core
-    FqCtx fq_ctx;
-    int64_t fq_ncand = 0;
     // BGZF member table (compressed offset of each member, offset of its data in the inflated stream)
     std::vector<int64_t> gz_moff, gz_uoff;
     int64_t gz_csize = 0;
@@ -518,57 +508,6 @@ extern "C" int fx_first_byte(fx_handle *h, int *out) {
 
 // -------------------------------------------------------------------- scan
 
-// Newline mask -> line table, used by the FASTQ path (records are "every four lines", so the
-// line table is the natural intermediate there).  Never cached: every build re-reads the stream.
-static int run_scan(fx_handle *h) {
-    int rc = use_device(h);
-    if (rc) return rc;
-    if (h->n <= 0) return fail(FX_EFORMAT, "empty input");
-    h->ntiles = (h->n + TILE - 1) / TILE;
-    const int64_t ngroups = (h->ntiles + GROUP - 1) / GROUP;
-    const int64_t nspans = (h->ntiles + SCAN_TILES - 1) / SCAN_TILES;
-    if ((rc = h->nlmask.alloc(nspans * SCAN_TILES * TILE_CHUNKS))) return rc;
-    if ((rc = h->tile_nl.alloc(h->ntiles))) return rc;
-    if ((rc = h->grp_cnt.alloc(2 * ngroups)) || (rc = h->grp_off.alloc(2 * (ngroups + 1)))) return rc;
-    FX_LAUNCH(h, K_SCAN, (k_scan<false>), dim3((unsigned)nspans), dim3(SCAN_BLOCK), h->d_data, h->n, h->prev_byte,
-              h->nlmask.p, h->tile_nl.p, (uint32_t *)nullptr, h->ntiles);
-    FX_LAUNCH(h, K_TILE_SCAN, k_group_sum, dim3(nblocks(ngroups, BLOCK / 64)), dim3(BLOCK), h->tile_nl.p,
-              (const uint32_t *)nullptr, h->ntiles, ngroups, h->grp_cnt.p);
-    FX_LAUNCH(h, K_TILE_SCAN, k_group_scan, dim3(1), dim3(1024), h->grp_cnt.p, ngroups, 1, h->grp_off.p);
-    HIPCHK(hipGetLastError());
-    // The table is sized from an estimate (previous build, else one line per 32 bytes) so the
-    // line-table kernel can be enqueued at once; the host fetches the real total while it runs
-    // and only re-runs it in the rare case the estimate was too small.
-    if (h->nl.cap < h->n / 32 + 1024 && (rc = h->nl.alloc(h->n / 32 + 1024))) return rc;
-    int64_t tot_nl = 0;
-    uint8_t last = 0;
-    HIPCHK(hipMemcpyAsync(&tot_nl, h->grp_off.p + ngroups, 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(&last, h->d_data + h->n - 1, 1, hipMemcpyDeviceToHost, h->stream));
-    hipEvent_t got;
-    HIPCHK(hipEventCreateWithFlags(&got, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(got, h->stream));
-    FX_LAUNCH(h, K_LINETABLE, k_linetable, dim3((unsigned)h->ntiles), dim3(BLOCK), h->nlmask.p, h->tile_nl.p,
-              h->grp_off.p, h->base, h->nl.p, h->nl.cap);
-    hipError_t ee = hipEventSynchronize(got);
-    (void)hipEventDestroy(got);
-    if (ee != hipSuccess) return fail(FX_EDEVICE, "event sync: %s", hipGetErrorString(ee));
-    h->n_real_nl = tot_nl;
-    // virtual newline at end-of-stream when the last line is unterminated: reproduces
-    // `position += line.l + 1` for that line (fastq.c:148)
-    const bool virt = h->is_last && last != '\n';
-    h->n_nl = tot_nl + (virt ? 1 : 0);
-    if (h->n_nl > h->nl.cap) {                               // estimate too small: exact size, run again
-        HIPCHK(hipStreamSynchronize(h->stream));
-        if ((rc = h->nl.alloc(h->n_nl + h->n_nl / 16))) return rc;
-        FX_LAUNCH(h, K_LINETABLE, k_linetable, dim3((unsigned)h->ntiles), dim3(BLOCK), h->nlmask.p, h->tile_nl.p,
-                  h->grp_off.p, h->base, h->nl.p, h->nl.cap);
-    }
-    if (virt) hipLaunchKernelGGL(k_set_i64, dim3(1), dim3(1), 0, h->stream, h->nl.p + tot_nl, h->base + h->n);
-    HIPCHK(hipGetLastError());
-    h->scanned = true;
-    return FX_OK;
-}
-
 // ------------------------------------------------------------- FASTA build
 static ScanCtx scan_ctx(const fx_handle *h) {
     ScanCtx x;
@@ -597,12 +536,11 @@ static int alloc_fasta_table(fx_handle *h, int64_t cap) {
 static Totals *ctl_totals(fx_handle *h) { return (Totals *)h->ctl.p; }
 static uint32_t *ctl_counter(fx_handle *h, int i) { return (uint32_t *)(h->ctl.p + 8 + i); }
 
-extern "C" int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out) {
-    if (!h) return fail(FX_EINVAL, "null handle");
-    int rc = use_device(h);
-    if (rc) return rc;
-    if (h->n <= 0) return fail(FX_EFORMAT, "empty input");
-    // ---- the one pass over the stream: 4 KiB granule summaries (fx_spanscan.hpp)
+// Granule summaries + prefixes of the resident stream.  MODE 0: FASTA (line-length sets, header lines);
+// MODE 1: FASTQ (newline count / first / last only).  Enqueues only; h->ctl holds the totals afterwards.
+template <int MODE>
+static int granule_pass(fx_handle *h) {
+    int rc;
     const int64_t nfull = h->n / GRAN, ngran = nfull + 1, nchunks = (ngran + CHUNK_GRANS - 1) / CHUNK_GRANS;
     h->ngran = ngran;
     if ((rc = h->gran.alloc(ngran)) || (rc = h->hdr_grans.alloc(ngran)) || (rc = h->chunks.alloc(nchunks)) ||
@@ -610,18 +548,31 @@ extern "C" int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out
         (rc = h->prevnl.alloc(ngran + 1)))
         return rc;
     if (!h->pin_tot) HIPCHK(hipHostMalloc((void **)&h->pin_tot, sizeof(Totals), hipHostMallocDefault));
-    if (h->hdr.cap < 4096 && (rc = alloc_fasta_table(h, 4096))) return rc;
     HIPCHK(hipMemsetAsync(h->ctl.p, 0, 16 * sizeof(unsigned long long), h->stream));
     GranList hgl{h->hdr_grans.p, ctl_counter(h, 0)};
     const int SCAN_WG = 512;                                  // 8 waves = 8 granules per workgroup (tools/scanbench2.hip)
     if (nfull > 0)
-        FX_LAUNCH(h, K_SPAN_SCAN, k_span_scan, dim3(nblocks(nfull * 64, SCAN_WG)), dim3(SCAN_WG), h->d_data, h->n,
+        FX_LAUNCH(h, K_SPAN_SCAN, (k_span_scan<MODE>), dim3(nblocks(nfull * 64, SCAN_WG)), dim3(SCAN_WG), h->d_data, h->n,
                   h->prev_byte, (int)h->is_last, nfull, h->gran.p, hgl);
-    FX_LAUNCH(h, K_GRAN_REDUCE, k_gran_reduce, dim3((unsigned)nchunks), dim3(CHUNK_GRANS), h->d_data, h->n, h->prev_byte,
+    FX_LAUNCH(h, K_GRAN_REDUCE, (k_gran_reduce<MODE>), dim3((unsigned)nchunks), dim3(CHUNK_GRANS), h->d_data, h->n, h->prev_byte,
               (int)h->is_last, hgl, h->gran.p, ngran, h->base, h->chunks.p);
     FX_LAUNCH(h, K_GRAN_PREFIX, k_gran_prefix, dim3((unsigned)nchunks), dim3(CHUNK_GRANS), h->gran.p, ngran, h->base,
               h->chunks.p, ctl_totals(h), h->nl_prefix.p, h->hdr_prefix.p, h->prevnl.p);
     HIPCHK(hipGetLastError());
+    return FX_OK;
+}
+
+extern "C" int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (h->n <= 0) return fail(FX_EFORMAT, "empty input");
+    h->scanned = false;
+    // ---- the one pass over the stream: 4 KiB granule summaries and their prefixes (fx_spanscan.hpp)
+    if ((rc = granule_pass<0>(h))) return rc;
+    const int64_t ngran = h->ngran;
+    if (h->hdr.cap < 4096 && (rc = alloc_fasta_table(h, 4096))) return rc;
+    GranList hgl{h->hdr_grans.p, ctl_counter(h, 0)};
     // ---- records.  The tables are sized from an estimate (previous build, else 4096 records) so that
     // everything is enqueued without a host round trip; if more header lines turn up, grow and redo
     // only this cheap part.
@@ -695,65 +646,86 @@ extern "C" int fx_fasta_comp(fx_handle *h, int where, int64_t *comp) {
 }
 
 // ------------------------------------------------------------- FASTQ build
-// Phase 2 of the FASTQ build: records from the line table, given where this shard's lines sit in
-// the global numbering (loff = newlines in earlier shards' cores, prev_nl = offset of the last of them).
+// Count pass (fx_fastq.hpp): granule newline counts + prefixes, and the newlines of the shard's core
+// (what the next shards need to number their lines).
+static int fastq_count(fx_handle *h, int64_t *n_nl_core, int64_t *last_nl_core) {
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (h->n <= 0) return fail(FX_EFORMAT, "empty input");
+    h->fasta_built = h->fastq_built = false;
+    if ((rc = granule_pass<1>(h))) return rc;
+    int64_t *res = (int64_t *)(h->ctl.p + 48);                // 3 words of the control block
+    hipLaunchKernelGGL(k_core_count, dim3(1), dim3(64), 0, h->stream, scan_ctx(h), (int)h->is_last, h->n - h->halo, res);
+    HIPCHK(hipGetLastError());
+    int64_t host[3];
+    HIPCHK(hipMemcpyAsync(h->pin_tot, ctl_totals(h), sizeof(Totals), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(host, res, sizeof host, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->n_nl = h->pin_tot->n_nl;
+    h->fq_c2 = host[2];
+    h->scanned = true;
+    if (n_nl_core) *n_nl_core = host[0];
+    if (last_nl_core) *last_nl_core = host[1];
+    return FX_OK;
+}
+
+// Emit pass: the read table, given where this shard's lines sit in the global numbering
+// (loff = newlines in earlier shards' cores, prev_nl = offset of the last of them).
 static int fastq_records(fx_handle *h, int64_t loff, int64_t prev_nl, fx_fastq_summary *out) {
     int rc = use_device(h);
     if (rc) return rc;
-    FqCtx x;
-    x.gbase = h->base; x.core_end = h->base + h->n - h->halo; x.loff = loff; x.prev_nl = prev_nl; x.is_last = h->is_last;
+    // Ownership: record k's header line starts right after global newline 4k-1 (k = 0: at offset 0); the
+    // shard owns the records whose header line STARTS in [base, core_end).
+    const int64_t N = h->n_nl;                                 // shard newlines (virtual end-of-stream one included)
     const int64_t k0 = (loff + 3) / 4;
-    x.k_first = k0 + ((loff % 4 == 0 && prev_nl + 1 < h->base) ? 1 : 0);   // that record's header began in the previous shard
-    h->fq_ctx = x;
-    const int64_t ncand = std::max<int64_t>((h->n_nl + loff + 3) / 4 + 1 - x.k_first, 1);
-    h->fq_ncand = ncand;
-    if ((rc = h->fq_name_off.alloc(ncand)) || (rc = h->fq_rlen.alloc(ncand)) || (rc = h->fq_soff.alloc(ncand)) ||
-        (rc = h->fq_qoff.alloc(ncand)) || (rc = h->fq_name_len.alloc(ncand)) || (rc = h->fq_dlen.alloc(ncand)) ||
-        (rc = h->fq_acc.alloc(1)))
+    const int64_t k_first = k0 + ((loff % 4 == 0 && prev_nl + 1 < h->base) ? 1 : 0);   // that record's header began in the previous shard
+    const int64_t core_len = h->n - h->halo;
+    const int64_t k_end = core_len > 0 ? (loff + h->fq_c2) / 4 + 1 : k_first;           // exclusive
+    const int64_t complete = (loff + N) / 4;                   // records whose four lines end inside what we hold
+    const int64_t nrows = std::max<int64_t>(k_end - k_first, 0);
+    const int64_t n_reads = std::max<int64_t>(std::min(k_end, complete) - k_first, 0);
+    // rows that have at least their sequence line (an incomplete trailing record still counts in stat.size, fastq.c:125)
+    const int64_t n_seq = loff + N >= 2 ? std::max<int64_t>(std::min(k_end, (loff + N - 2) / 4 + 1) - k_first, 0) : 0;
+    if (!h->is_last && k_end > complete)
+        return fail(FX_ERANGE, "a FASTQ record that starts in this shard runs past its %lld-byte halo", (long long)h->halo);
+    const int64_t cap = std::max<int64_t>(nrows, 1);
+    if ((rc = h->fq_name_off.alloc(cap)) || (rc = h->fq_rlen.alloc(cap)) || (rc = h->fq_soff.alloc(cap)) ||
+        (rc = h->fq_qoff.alloc(cap)) || (rc = h->fq_name_len.alloc(cap)) || (rc = h->fq_dlen.alloc(cap)) ||
+        (rc = h->fq_qlen.alloc(cap)) || (rc = h->fq_acc.alloc(1)))
         return rc;
     FastqAcc init;
     memset(&init, 0, sizeof init);
     init.maxlen = 0; init.minlen = 10000000000LL; init.minqs = 104; init.maxqs = 33;   // fastq.c:667-675
     HIPCHK(hipMemcpyAsync(h->fq_acc.p, &init, sizeof init, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    FastqCols c;
-    c.name_off = h->fq_name_off.p; c.rlen = h->fq_rlen.p; c.soff = h->fq_soff.p; c.qoff = h->fq_qoff.p;
-    c.name_len = h->fq_name_len.p; c.dlen = h->fq_dlen.p;
-    FX_LAUNCH(h, K_FASTQ_REC, k_fastq_rec, dim3(std::min(nblocks(ncand, BLOCK), 256u * 16u)), dim3(BLOCK), h->d_data, x,
-              h->nl.p, h->n_nl, ncand, c, h->fq_acc.p);
+    const FqTab t{h->fq_name_off.p, h->fq_rlen.p, h->fq_soff.p, h->fq_qoff.p, h->fq_name_len.p, h->fq_dlen.p, h->fq_qlen.p};
+    const FqOwn own{loff, prev_nl, k_first, nrows};
+    FX_LAUNCH(h, K_FASTQ_EMIT, k_fastq_emit, dim3(nblocks(h->ngran, BLOCK / 64)), dim3(BLOCK), scan_ctx(h), h->prev_byte,
+              (int)h->is_last, own, t);
+    FX_LAUNCH(h, K_FASTQ_STATS, k_fastq_stats, dim3((unsigned)std::min<int64_t>(nblocks(n_seq, BLOCK), 1024)), dim3(BLOCK), t,
+              n_seq, n_reads, h->fq_acc.p);
     HIPCHK(hipGetLastError());
     FastqAcc acc;
     HIPCHK(hipMemcpyAsync(&acc, h->fq_acc.p, sizeof acc, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (acc.err) return fail(FX_ERANGE, "a FASTQ record that starts in this shard runs past its %lld-byte halo", (long long)h->halo);
-    h->n_reads = (int64_t)acc.n_owned;
+    h->n_reads = n_reads;
+    h->fq_seq_rows = n_seq;
     h->fq_size = (int64_t)acc.size;
     h->fq_maxlen = acc.maxlen; h->fq_minlen = acc.minlen;
     h->fastq_built = true;
-    if (out) { out->n_reads = h->n_reads; out->size = h->fq_size; out->n_lines = h->n_nl; out->n_bytes = h->n; out->first_id = x.k_first; }
+    if (out) { out->n_reads = h->n_reads; out->size = h->fq_size; out->n_lines = h->n_nl; out->n_bytes = h->n; out->first_id = k_first; }
     return FX_OK;
 }
 
 extern "C" int fx_set_halo(fx_handle *h, int64_t halo_bytes) {
     if (!h || halo_bytes < 0 || halo_bytes > h->n) return fail(FX_EINVAL, "bad halo");
     h->halo = halo_bytes;
-    h->fasta_built = h->fastq_built = false;
+    h->scanned = h->fasta_built = h->fastq_built = false;
     return FX_OK;
 }
 
 extern "C" int fx_fastq_scan(fx_handle *h, int64_t *n_nl_core, int64_t *last_nl_core) {
     if (!h) return fail(FX_EINVAL, "null handle");
-    int rc = run_scan(h);
-    if (rc) return rc;
-    int64_t res[2] = {h->n_nl, -1};
-    DevBuf<int64_t> d;
-    if ((rc = d.alloc(2))) return rc;
-    hipLaunchKernelGGL(k_count_below, dim3(1), dim3(1), 0, h->stream, h->nl.p, h->n_nl, h->base + h->n - h->halo, d.p);
-    HIPCHK(hipMemcpyAsync(res, d.p, 16, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (n_nl_core) *n_nl_core = res[0];
-    if (last_nl_core) *last_nl_core = res[1];
-    return FX_OK;
+    return fastq_count(h, n_nl_core, last_nl_core);
 }
 
 extern "C" int fx_fastq_build_ctx(fx_handle *h, int64_t line_offset, int64_t prev_nl, fx_fastq_summary *out) {
@@ -764,7 +736,7 @@ extern "C" int fx_fastq_build_ctx(fx_handle *h, int64_t line_offset, int64_t pre
 
 extern "C" int fx_fastq_build(fx_handle *h, fx_fastq_summary *out) {
     if (!h) return fail(FX_EINVAL, "null handle");
-    int rc = run_scan(h);
+    int rc = fastq_count(h, nullptr, nullptr);
     if (rc) return rc;
     return fastq_records(h, 0, -1, out);
 }
@@ -789,9 +761,9 @@ extern "C" int fx_fastq_comp(fx_handle *h, int64_t base[5], int64_t meta[5]) {
     if (!h->fastq_built) return fail(FX_ESTATE, "fx_fastq_build has not run");
     int rc = use_device(h);
     if (rc) return rc;
-    const unsigned nb = (unsigned)std::min<int64_t>(nblocks(h->fq_ncand, (BLOCK / 64) * 4), 256 * 8);
-    FX_LAUNCH(h, K_FASTQ_COMP, k_fastq_comp, dim3(nb), dim3(BLOCK), h->d_data, h->fq_ctx, h->nl.p, h->n_nl, h->fq_ncand,
-              h->fq_acc.p);
+    const FqTab t{h->fq_name_off.p, h->fq_rlen.p, h->fq_soff.p, h->fq_qoff.p, h->fq_name_len.p, h->fq_dlen.p, h->fq_qlen.p};
+    const unsigned nb = (unsigned)std::min<int64_t>(nblocks(std::max<int64_t>(h->fq_seq_rows, 1), (BLOCK / 64) * 4), 256 * 8);
+    FX_LAUNCH(h, K_FASTQ_COMP, k_fastq_comp, dim3(nb), dim3(BLOCK), h->d_data, h->base, t, h->fq_seq_rows, h->n_reads, h->fq_acc.p);
     HIPCHK(hipGetLastError());
     FastqAcc acc;
     HIPCHK(hipMemcpyAsync(&acc, h->fq_acc.p, sizeof acc, hipMemcpyDeviceToHost, h->stream));
@@ -1092,7 +1064,7 @@ extern "C" int fx_prof_enable(fx_handle *h, int on) {
     int rc = fx_sync(h);
     if (rc) return rc;
     h->prof.on = on != 0;
-    h->prof.mask = (on == 2) ? ((1u << K_SPAN_SCAN) | (1u << K_SCAN)) : ~0u;   // 2: only the dominant kernel (2 events per build)
+    h->prof.mask = (on == 2) ? (1u << K_SPAN_SCAN) : ~0u;   // 2: only the dominant kernel (2 events per build)
     return FX_OK;
 }
 

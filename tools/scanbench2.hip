@@ -71,8 +71,8 @@ int check(const std::vector<uint8_t> &hb) {
     CK(hipMalloc((void **)&ct, nchunks * sizeof(ChunkTot))); CK(hipMalloc((void **)&tot, sizeof(Totals)));
     CK(hipMemset(tot, 0, sizeof(Totals)));
     CK(hipMalloc((void **)&dpn, (ngran + 1) * 8)); CK(hipMalloc((void **)&dph, (ngran + 1) * 8)); CK(hipMalloc((void **)&dpv, (ngran + 1) * 8));
-    hipLaunchKernelGGL(k_span_scan, dim3((unsigned)((n / GRAN * 64 + 511) / 512)), dim3(512), 0, 0, d, n, (int)'\n', 1, n / GRAN, go, gl);
-    hipLaunchKernelGGL(k_gran_reduce, dim3((unsigned)nchunks), dim3(CHUNK_GRANS), 0, 0, d, n, (int)'\n', 1, gl, go, ngran, (int64_t)1000, ct);
+    hipLaunchKernelGGL(k_span_scan<0>, dim3((unsigned)((n / GRAN * 64 + 511) / 512)), dim3(512), 0, 0, d, n, (int)'\n', 1, n / GRAN, go, gl);
+    hipLaunchKernelGGL(k_gran_reduce<0>, dim3((unsigned)nchunks), dim3(CHUNK_GRANS), 0, 0, d, n, (int)'\n', 1, gl, go, ngran, (int64_t)1000, ct);
     hipLaunchKernelGGL(k_gran_prefix, dim3((unsigned)nchunks), dim3(CHUNK_GRANS), 0, 0, go, ngran, (int64_t)1000, ct, tot, dpn, dph, dpv);
     CK(hipDeviceSynchronize());
     std::vector<GranPk> hp(ngran);
@@ -173,7 +173,7 @@ int main() {
     for (int r = 0; r < R + 2; ++r) {
         CK(hipMemsetAsync(gl.count, 0, 4, 0));
         CK(hipEventRecord(a, 0));
-        hipLaunchKernelGGL(k_span_scan, dim3(grid), dim3(blk), 0, 0, d, n, (int)'\n', 1, n / GRAN, go, gl);
+        hipLaunchKernelGGL(k_span_scan<0>, dim3(grid), dim3(blk), 0, 0, d, n, (int)'\n', 1, n / GRAN, go, gl);
         CK(hipEventRecord(b, 0));
         CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
