@@ -236,6 +236,18 @@ typedef struct {
 
 int fx_shard_summary_get(fx_handle *h, fx_shard_summary *out);
 
+/* Device-resident variant of the same exchange, so that a sharded build never leaves the GPU between
+ * the collective and the fetches: fx_shard_summary_dev ENQUEUES the summary (28 x int64) into d_out (a
+ * device buffer of the caller, e.g. the send buffer of the all-gather); after the all-gather,
+ * fx_fasta_stitch_dev ENQUEUES the completion of this rank's last record from the gathered summaries
+ * d_all[world][28] (device) -- the integer logic of index.c:234-353 across shard cuts -- and rewrites
+ * that row of the resident table.  Both run on the handle's stream: order them against the collective's
+ * stream with fx_stream() (an opaque hipStream_t) and stream events.  A header line whose name does not
+ * end within 64 KiB of a cut is reported by the next fx_fasta_table (FX_ERANGE).                      */
+int fx_shard_summary_dev(fx_handle *h, int64_t *d_out);
+int fx_fasta_stitch_dev(fx_handle *h, const int64_t *d_all, int world, int rank, int full_name);
+void *fx_stream(fx_handle *h);
+
 /* After the all-gather the owner of a record that crosses shard cuts rewrites
  * that row of the resident table (and of what fx_fasta_table returns). */
 int fx_fasta_set_row(fx_handle *h, int64_t k, int64_t boff, int64_t blen, int64_t slen, int64_t llen,

@@ -44,7 +44,7 @@ SYMBOLS = [
     "fx_set_shard", "fx_close", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
     "fx_fasta_build", "fx_fasta_table", "fx_fasta_comp", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fasta_fetch", "fx_fastq_fetch", "fx_revcomp", "fx_shard_summary_get",
-    "fx_fasta_set_row", "fx_read_fetch", "fx_gz_points", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
+    "fx_fasta_set_row", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
 ]
 
 
@@ -98,6 +98,10 @@ def lib():
     L.fx_read_fetch.argtypes = [vp, i32, i64, vp, vp, vp, i32, i32, vp, vp, vp, vp]
     L.fx_shard_summary_get.argtypes = [vp, C.POINTER(ShardSummary)]
     L.fx_fasta_set_row.argtypes = [vp, i64, i64, i64, i64, i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.fx_shard_summary_dev.argtypes = [vp, vp]
+    L.fx_fasta_stitch_dev.argtypes = [vp, vp, i32, i32, i32]
+    L.fx_stream.restype = vp
+    L.fx_stream.argtypes = [vp]
     L.fx_gz_points.argtypes = [vp, i64, vp, vp, i64, C.POINTER(i64), C.POINTER(i64)]
     L.fx_sync.argtypes = [vp]
     L.fx_prof_enable.argtypes = [vp, i32]
@@ -235,6 +239,18 @@ class Blob:
         s = ShardSummary()
         check(lib().fx_shard_summary_get(self._h, C.byref(s)))
         return Summary((k, int(getattr(s, k))) for k in FIELDS)
+
+    def shard_summary_dev(self, d_out):
+        """Enqueue the 28-word boundary summary into a device buffer (no host round trip)."""
+        check(lib().fx_shard_summary_dev(self._h, d_out))
+
+    def fasta_stitch_dev(self, d_all, world, rank, full_name=False):
+        """Enqueue the completion of this shard's last record from the gathered summaries (device)."""
+        check(lib().fx_fasta_stitch_dev(self._h, d_all, int(world), int(rank), int(bool(full_name))))
+
+    @property
+    def stream(self):
+        return lib().fx_stream(self._h)
 
     def fasta_set_row(self, k, boff, blen, slen, llen, elen, norm, dlen, name_len):
         check(lib().fx_fasta_set_row(self._h, int(k), int(boff), int(blen), int(slen), int(llen), int(elen),

@@ -818,4 +818,88 @@ __global__ __launch_bounds__(BLOCK) void k_shard_summary2(ScanCtx x, int is_last
     S[26] = 0; S[27] = 0;
 }
 
+// ============================================================== stitch (multi-GPU)
+// After the all-gather every rank holds the boundary summaries of all shards (world x 28 words, field
+// order = fx_shard_summary).  One thread finishes the last record that starts in shard r -- the only
+// one that can run past the cut -- with pure integer logic (index.c:234-353 across shard cuts) and
+// rewrites that row of the resident table.  Same logic as pyfastx_amd/shard.py:stitch_tail, which the
+// CPU tests exercise; this kernel keeps the whole sharded build on the device (no host round trip
+// between the collective and the fetches).
+enum { SS_BASE = 0, SS_NBYTES, SS_ISLAST, SS_NNL, SS_FIRSTNL, SS_SECONDNL, SS_LASTNL, SS_FIRSTNLPREV, SS_FIRSTBYTE, SS_LASTBYTE,
+       SS_NHDR, SS_FIRSTHDR, SS_LASTHDR, SS_LEADNL, SS_LEADWS, SS_V1, SS_C1, SS_V2, SS_C2, SS_TE, SS_TFE, SS_TNA, SS_TBAD,
+       SS_TELEN, SS_TDLEN, SS_TNAME, SS_WORDS = 28 };
+
+// min(2, number of FULL lead lines of shard u whose len+1 != llen)
+__device__ __forceinline__ int64_t lead_count_ne(const int64_t *u, int64_t llen) {
+    const int64_t full = u[SS_LEADNL] - 1;
+    if (full <= 0) return 0;
+    if (u[SS_C1] + u[SS_C2] < full) return 2;            // >= 3 distinct lengths: at least two differ from any llen
+    const int64_t eq = (u[SS_V1] == llen ? u[SS_C1] : 0) + ((u[SS_C2] && u[SS_V2] == llen) ? u[SS_C2] : 0);
+    return full - eq < 2 ? full - eq : 2;
+}
+
+__global__ void k_stitch_tail(const int64_t *__restrict__ S, int world, int r, int full_name, FastaCols c, int64_t cap,
+                              int *__restrict__ err) {
+    if (threadIdx.x || blockIdx.x) return;
+    const int64_t *s = S + (int64_t)r * SS_WORDS;
+    if (s[SS_NHDR] == 0 || s[SS_NHDR] > cap) return;
+    const int64_t k = s[SS_NHDR] - 1;
+    const int64_t h = s[SS_LASTHDR];
+    int64_t e = s[SS_TE], elen = s[SS_TELEN], dlen = s[SS_TDLEN], name_len = s[SS_TNAME];
+    bool have_e = e >= 0, have_llen = false;
+    int64_t llen = 0, nseq = 0, bad = 0, last_nl = s[SS_LASTNL];
+    if (have_e) {
+        nseq = s[SS_TNA];
+        if (s[SS_TFE] >= 0) { llen = s[SS_TFE] - e; have_llen = true; bad = s[SS_TBAD] < 2 ? s[SS_TBAD] : 2; }
+    }
+    int64_t hn = -1, ws = -1;                             // ws: white space seen in continuation shards while the header is unterminated
+    for (int t = r + 1; t < world; ++t) {
+        const int64_t *u = S + (int64_t)t * SS_WORDS;
+        if (!have_e && ws < 0 && u[SS_LEADWS] >= 0) ws = u[SS_LEADWS];
+        if (u[SS_LEADNL] > 0) {
+            const int64_t first = u[SS_FIRSTNL], full = u[SS_LEADNL] - 1;
+            if (!have_e) {                                // the header line itself crossed the cut
+                const int64_t pb = u[SS_FIRSTNLPREV] >= 0 ? u[SS_FIRSTNLPREV] : (u - SS_WORDS)[SS_LASTBYTE];
+                e = first;
+                elen = pb == 13 ? 2 : 1;                  // index.c:266-269
+                dlen = (e - h) - elen;                    // index.c:271
+                if (full_name) name_len = dlen;
+                else if (name_len < 0) {
+                    if (u[SS_FIRSTNL] - u[SS_BASE] > 65536 && ws < 0) *err = 1;   // name end further than 64 KiB past the cut
+                    name_len = (ws >= 0 && ws < e) ? ws - (h + 1) : dlen;
+                }
+                if (name_len > dlen) name_len = dlen;
+                have_e = true;
+                if (full >= 1) { llen = u[SS_SECONDNL] - u[SS_FIRSTNL]; have_llen = true; bad += lead_count_ne(u, llen); }
+                nseq += full;
+            } else if (!have_llen) {                      // the first sequence line crossed the cut
+                llen = first - e; have_llen = true;
+                nseq += u[SS_LEADNL];
+                bad += lead_count_ne(u, llen);
+            } else {                                      // an ordinary line crossed the cut
+                bad += (first - last_nl != llen) ? 1 : 0;
+                nseq += u[SS_LEADNL];
+                bad += lead_count_ne(u, llen);
+            }
+            if (bad > 2) bad = 2;
+            if (u[SS_NHDR] == 0) last_nl = u[SS_LASTNL];
+        }
+        if (u[SS_NHDR] > 0) { hn = u[SS_FIRSTHDR]; break; }
+    }
+    if (hn < 0) {                                         // `position` after the last line (index.c:231)
+        hn = 0;
+        for (int t = world - 1; t >= 0; --t) { const int64_t *u = S + (int64_t)t * SS_WORDS; if (u[SS_NNL] > 0) { hn = u[SS_LASTNL] + 1; break; } }
+    }
+    const int64_t boff = e + 1, blen = hn - boff;         // index.c:243,348
+    c.boff[k] = boff; c.blen[k] = blen; c.slen[k] = blen - elen * nseq; c.llen[k] = nseq > 0 ? llen : 0;
+    c.elen[k] = (int32_t)elen; c.norm[k] = bad > 1 ? 0 : 1; c.dlen[k] = (int32_t)dlen; c.name_len[k] = (int32_t)name_len;
+}
+
+// fx_fasta_set_row: one launch instead of eight 4/8-byte copies
+__global__ void k_set_row(FastaCols c, int64_t k, int64_t boff, int64_t blen, int64_t slen, int64_t llen, int32_t elen,
+                          int32_t norm, int32_t dlen, int32_t name_len) {
+    c.boff[k] = boff; c.blen[k] = blen; c.slen[k] = slen; c.llen[k] = llen;
+    c.elen[k] = elen; c.norm[k] = norm; c.dlen[k] = dlen; c.name_len[k] = name_len;
+}
+
 }  // namespace fx

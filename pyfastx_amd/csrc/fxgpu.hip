@@ -548,7 +548,7 @@ static int granule_pass(fx_handle *h) {
         (rc = h->prevnl.alloc(ngran + 1)))
         return rc;
     if (!h->pin_tot) HIPCHK(hipHostMalloc((void **)&h->pin_tot, sizeof(Totals), hipHostMallocDefault));
-    HIPCHK(hipMemsetAsync(h->ctl.p, 0, 16 * sizeof(unsigned long long), h->stream));
+    HIPCHK(hipMemsetAsync(h->ctl.p, 0, 64 * sizeof(unsigned long long), h->stream));
     GranList hgl{h->hdr_grans.p, ctl_counter(h, 0)};
     const int SCAN_WG = 512;                                  // 8 waves = 8 granules per workgroup (tools/scanbench2.hip)
     if (nfull > 0)
@@ -623,7 +623,10 @@ extern "C" int fx_fasta_table(fx_handle *h, int where, int64_t *hoff, int64_t *b
         (rc = copy_out(h, where, norm, h->fa_norm.p, n)) || (rc = copy_out(h, where, dlen, h->fa_dlen.p, n)) ||
         (rc = copy_out(h, where, name_len, h->fa_name_len.p, n)))
         return rc;
+    int stitch_err = 0;
+    HIPCHK(hipMemcpyAsync(&stitch_err, h->ctl.p + 60, sizeof stitch_err, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (stitch_err) return fail(FX_ERANGE, "header line crossing a shard cut continues for more than 64 KiB");
     return FX_OK;
 }
 
@@ -1090,26 +1093,44 @@ extern "C" int fx_prof_read(fx_handle *h, int id, double *total_ms, int64_t *lau
     return FX_OK;
 }
 
-extern "C" int fx_shard_summary_get(fx_handle *h, fx_shard_summary *out) {
-    static_assert(sizeof(fx_shard_summary) == 28 * 8, "summary layout");
-    if (!h || !out) return fail(FX_EINVAL, "null argument");
+static int shard_summary_launch(fx_handle *h, int64_t *d_out) {
+    static_assert(sizeof(fx_shard_summary) == SS_WORDS * 8, "summary layout");
     if (!h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build has not run");
     int rc = use_device(h);
     if (rc) return rc;
-    int64_t *S = (int64_t *)(h->ctl.p + 16);                    // 28 words of the control block (no allocation per call)
     hipLaunchKernelGGL(k_shard_summary2, dim3(1), dim3(BLOCK), 0, h->stream, scan_ctx(h), (int)h->is_last, ctl_totals(h),
-                       h->hdr.cap, h->hdr.p, h->fa_hdr_line.p, fasta_cols(h), S);
+                       h->hdr.cap, h->hdr.p, h->fa_hdr_line.p, fasta_cols(h), d_out);
     HIPCHK(hipGetLastError());
+    return FX_OK;
+}
+
+extern "C" int fx_shard_summary_get(fx_handle *h, fx_shard_summary *out) {
+    if (!h || !out) return fail(FX_EINVAL, "null argument");
+    int64_t *S = h->ctl.p ? (int64_t *)(h->ctl.p + 16) : nullptr;   // 28 words of the control block (no allocation per call)
+    int rc = shard_summary_launch(h, S);
+    if (rc) return rc;
     HIPCHK(hipMemcpyAsync(out, S, sizeof(fx_shard_summary), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return FX_OK;
 }
 
-template <class T> static int poke(fx_handle *h, T *darr, int64_t k, T v) {
-    HIPCHK(hipMemcpyAsync(darr + k, &v, sizeof(T), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+extern "C" int fx_shard_summary_dev(fx_handle *h, int64_t *d_out) {
+    if (!h || !d_out) return fail(FX_EINVAL, "null argument");
+    return shard_summary_launch(h, d_out);
+}
+
+extern "C" int fx_fasta_stitch_dev(fx_handle *h, const int64_t *d_all, int world, int rank, int full_name) {
+    if (!h || !d_all || world < 1 || rank < 0 || rank >= world) return fail(FX_EINVAL, "bad argument");
+    if (!h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build has not run");
+    int rc = use_device(h);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_stitch_tail, dim3(1), dim3(1), 0, h->stream, d_all, world, rank, full_name, fasta_cols(h), h->hdr.cap,
+                       (int *)(h->ctl.p + 60));
+    HIPCHK(hipGetLastError());
     return FX_OK;
 }
+
+extern "C" void *fx_stream(fx_handle *h) { return h ? (void *)h->stream : nullptr; }
 
 extern "C" int fx_fasta_set_row(fx_handle *h, int64_t k, int64_t boff, int64_t blen, int64_t slen, int64_t llen,
                                 int32_t elen, int32_t norm, int32_t dlen, int32_t name_len) {
@@ -1118,10 +1139,7 @@ extern "C" int fx_fasta_set_row(fx_handle *h, int64_t k, int64_t boff, int64_t b
     if (k < 0 || k >= h->n_hdr) return fail(FX_ERANGE, "row %lld out of range", (long long)k);
     int rc = use_device(h);
     if (rc) return rc;
-    if ((rc = poke(h, h->fa_boff.p, k, boff)) || (rc = poke(h, h->fa_blen.p, k, blen)) ||
-        (rc = poke(h, h->fa_slen.p, k, slen)) || (rc = poke(h, h->fa_llen.p, k, llen)) ||
-        (rc = poke(h, h->fa_elen.p, k, elen)) || (rc = poke(h, h->fa_norm.p, k, norm)) ||
-        (rc = poke(h, h->fa_dlen.p, k, dlen)) || (rc = poke(h, h->fa_name_len.p, k, name_len)))
-        return rc;
+    hipLaunchKernelGGL(k_set_row, dim3(1), dim3(1), 0, h->stream, fasta_cols(h), k, boff, blen, slen, llen, elen, norm, dlen, name_len);
+    HIPCHK(hipGetLastError());
     return FX_OK;
 }

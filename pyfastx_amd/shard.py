@@ -198,13 +198,29 @@ class ShardedFasta:
         self.summary = None
         self.S = None
         self.n_local = 0
+        self._ext = self._mine = self._all = None
 
     def build(self):
         s = self.blob.fasta_build(self.full_name)
         self.n_local = s.n_seq
         if self.world == 1:
             return s
-        self.S = allgather_summaries(self.blob.shard_summary(), self.world, self.comm_dev)   # the ONE collective (RCCL)
+        if self.comm_dev.type == "cuda":
+            # device-resident exchange: summary kernel -> RCCL all-gather -> stitch kernel, ordered with
+            # stream events only (the library's stream is wrapped as a torch ExternalStream)
+            torch = self._torch
+            if self._ext is None:
+                self._ext = torch.cuda.ExternalStream(self.blob.stream, device=self.dev)
+                self._mine = torch.zeros(NWORDS, dtype=torch.int64, device=self.dev)
+                self._all = torch.zeros(self.world * NWORDS, dtype=torch.int64, device=self.dev)
+            cur = torch.cuda.current_stream(self.dev)
+            self.blob.shard_summary_dev(self._mine.data_ptr())
+            cur.wait_stream(self._ext)
+            self._dist.all_gather_into_tensor(self._all, self._mine)          # the ONE collective (RCCL over xGMI)
+            self._ext.wait_stream(cur)
+            self.blob.fasta_stitch_dev(self._all.data_ptr(), self.world, self.rank, self.full_name)
+            return s
+        self.S = allgather_summaries(self.blob.shard_summary(), self.world, self.comm_dev)   # gloo (CPU tests): host path
         row = stitch_tail(self.S, self.rank, self.full_name)
         if row is not None:
             self.blob.fasta_set_row(self.n_local - 1, **row)

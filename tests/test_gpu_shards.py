@@ -30,12 +30,38 @@ def sharded_rows(L, raw, cuts, full_name=False):
     return {c: np.concatenate([t[c] for t in rows]) for c in COLS}, S
 
 
+def sharded_rows_dev(L, raw, cuts, full_name=False):
+    """Same, with the device-resident exchange: summaries written by fx_shard_summary_dev into one device
+    buffer (what the all-gather would assemble), last records finished by fx_fasta_stitch_dev."""
+    import torch
+    bounds = [0] + list(cuts) + [len(raw)]
+    world = len(bounds) - 1
+    allS = torch.zeros(world * 28, dtype=torch.int64, device="cuda:0")
+    blobs = []
+    for i in range(world):
+        lo, hi = bounds[i], bounds[i + 1]
+        b = L.Blob.from_bytes(raw[lo:hi])
+        b.set_shard(lo, raw[lo - 1] if lo else 10, hi == len(raw))
+        s = b.fasta_build(full_name)
+        b.shard_summary_dev(allS.data_ptr() + i * 28 * 8)
+        b.sync()
+        blobs.append((b, s.n_seq))
+    rows = []
+    for r, (b, n) in enumerate(blobs):
+        b.fasta_stitch_dev(allS.data_ptr(), world, r, full_name)
+        rows.append(b.fasta_table(n))
+    return {c: np.concatenate([t[c] for t in rows]) for c in COLS}
+
+
 def check(oracle, L, raw, cuts, full_name=False):
     recs, tot = oracle.fasta_index(raw, full_name=full_name)
     got, S = sharded_rows(L, raw, cuts, full_name)
     assert len(got["boff"]) == len(recs), (cuts, len(got["boff"]), len(recs))
     for c in COLS:
         np.testing.assert_array_equal(got[c], recs[c].astype(got[c].dtype), err_msg="%s cuts=%s" % (c, cuts))
+    dev = sharded_rows_dev(L, raw, cuts, full_name)
+    for c in COLS:
+        np.testing.assert_array_equal(dev[c], got[c], err_msg="device stitch: %s cuts=%s" % (c, cuts))
 
 
 @pytest.fixture(scope="module")
@@ -157,3 +183,40 @@ def test_fastq_halo_too_small_is_an_error(L):
     with pytest.raises(L.FxError) as e:
         fastq_sharded(L, raw, [len(raw) // 2], halo=3)
     assert e.value.code == L.FX_ERANGE
+
+
+def test_device_exchange_stream_ordering(oracle, L):
+    """The plumbing of ShardedFasta.build's device path on one GPU: summaries are produced on the library's
+    stream, 'gathered' by torch on ITS stream (a plain copy stands in for the RCCL all-gather), stitched on
+    the library's stream again -- ordered by stream events only (torch ExternalStream), no host sync."""
+    import torch
+    from test_gpu_kernels import _rand_fasta
+    rng = np.random.default_rng(7)
+    raw = _rand_fasta(rng, 12, 61, crlf=False, ragged=False, trailing=True, lower=True)
+    cuts = sorted(set(int(x) for x in rng.integers(1, len(raw), 3)))
+    bounds = [0] + cuts + [len(raw)]
+    world = len(bounds) - 1
+    dev = torch.device("cuda", 0)
+    allS = torch.zeros(world * 28, dtype=torch.int64, device=dev)
+    cur = torch.cuda.current_stream(dev)
+    blobs = []
+    for i in range(world):
+        lo, hi = bounds[i], bounds[i + 1]
+        b = L.Blob.from_bytes(raw[lo:hi])
+        b.set_shard(lo, raw[lo - 1] if lo else 10, hi == len(raw))
+        s = b.fasta_build()
+        ext = torch.cuda.ExternalStream(b.stream, device=dev)
+        mine = torch.zeros(28, dtype=torch.int64, device=dev)
+        b.shard_summary_dev(mine.data_ptr())
+        cur.wait_stream(ext)
+        allS[i * 28:(i + 1) * 28].copy_(mine)               # stands in for all_gather_into_tensor
+        blobs.append((b, s.n_seq, ext, mine))
+    rows = []
+    for r, (b, n, ext, _) in enumerate(blobs):
+        ext.wait_stream(cur)
+        b.fasta_stitch_dev(allS.data_ptr(), world, r)
+        rows.append(b.fasta_table(n))
+    got = {c: np.concatenate([t[c] for t in rows]) for c in COLS}
+    recs, _ = oracle.fasta_index(raw)
+    for c in COLS:
+        np.testing.assert_array_equal(got[c], recs[c].astype(got[c].dtype), err_msg=c)
