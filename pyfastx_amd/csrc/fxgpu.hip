@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -247,9 +248,14 @@ struct Stager {          // pinned ring: producer fills slot, H2D async, event m
     }
 };
 
+static int stage_threads() {
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::min<unsigned>(16u, std::max<unsigned>(4u, hw / 8));
+}
+
 static void parallel_pread(int fd, uint8_t *dst, int64_t off, int64_t len, std::atomic<int> *err) {
-    // 4 threads: page-cache -> pinned memcpy is the host-side bottleneck of staging
-    const int T = 4;
+    // page-cache -> pinned memcpy is the host-side bottleneck of staging: spread it over threads
+    const int T = stage_threads();
     const int64_t per = (len + T - 1) / T;
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t) {
@@ -265,6 +271,67 @@ static void parallel_pread(int fd, uint8_t *dst, int64_t off, int64_t len, std::
         });
     }
     for (auto &x : th) x.join();
+}
+
+// Plain files: T host threads, each with its own pair of pinned 8 MiB buffers and its own HIP stream,
+// walk the file in an interleaved pattern (thread t takes pieces t, t+T, ...): pread into pinned memory,
+// hipMemcpyAsync to the blob, double-buffered.  The pinned buffers are allocated once per process
+// (pinning 256 MiB costs about as much as moving 1 GB) and reused by later opens.
+static const int64_t PIECE_BYTES = 8ll << 20;
+struct PinPool {
+    std::mutex mu;
+    std::vector<uint8_t *> bufs;
+    uint8_t *get() {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (!bufs.empty()) { uint8_t *p = bufs.back(); bufs.pop_back(); return p; }
+        }
+        uint8_t *p = nullptr;
+        if (hipHostMalloc((void **)&p, (size_t)PIECE_BYTES, hipHostMallocDefault) != hipSuccess) return nullptr;
+        return p;
+    }
+    void put(uint8_t *p) { std::lock_guard<std::mutex> g(mu); bufs.push_back(p); }
+};
+static PinPool g_pins;
+
+static int stage_plain_file(fx_handle *h, int fd, int64_t n, const char *path) {
+    const int T = (int)std::min<int64_t>(stage_threads(), std::max<int64_t>(1, (n + PIECE_BYTES - 1) / PIECE_BYTES));
+    std::atomic<int> err(0);                 // 1: read error, 2: device error
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+        th.emplace_back([&, t]() {
+            if (hipSetDevice(h->device) != hipSuccess) { err.store(2); return; }
+            uint8_t *pin[2] = {g_pins.get(), g_pins.get()};
+            hipStream_t st = nullptr;
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            bool used[2] = {false, false};
+            bool ok = pin[0] && pin[1] && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+                      hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+            if (!ok) err.store(2);
+            int slot = 0;
+            for (int64_t off = (int64_t)t * PIECE_BYTES; ok && off < n && !err.load(); off += (int64_t)T * PIECE_BYTES, slot ^= 1) {
+                const int64_t len = std::min(PIECE_BYTES, n - off);
+                if (used[slot] && hipEventSynchronize(ev[slot]) != hipSuccess) { err.store(2); break; }
+                int64_t done = 0;
+                while (done < len) {
+                    const ssize_t r = pread(fd, pin[slot] + done, (size_t)(len - done), (off_t)(off + done));
+                    if (r <= 0) { err.store(1); break; }
+                    done += r;
+                }
+                if (done < len) break;
+                if (hipMemcpyAsync(h->d_data + off, pin[slot], (size_t)len, hipMemcpyHostToDevice, st) != hipSuccess ||
+                    hipEventRecord(ev[slot], st) != hipSuccess) { err.store(2); break; }
+                used[slot] = true;
+            }
+            if (st) (void)hipStreamSynchronize(st);
+            for (int i = 0; i < 2; ++i) { if (ev[i]) (void)hipEventDestroy(ev[i]); if (pin[i]) g_pins.put(pin[i]); }
+            if (st) (void)hipStreamDestroy(st);
+        });
+    for (auto &x : th) x.join();
+    if (err.load() == 1) return fail(FX_EIO, "read error on %s", path);
+    if (err.load() == 2) return fail(FX_EDEVICE, "staging %s to the device failed", path);
+    return FX_OK;
 }
 
 static inline unsigned nblocks(int64_t n, int per) { return (unsigned)std::max<int64_t>(1, (n + per - 1) / per); }
@@ -354,8 +421,6 @@ extern "C" int fx_open_file(const char *path, int device, fx_handle **out) {
     if (rc) { close(fd); return rc; }
     h->gz = gz;
     Stager st_;
-    rc = st_.init();
-    if (rc) { close(fd); fx_close(h); return rc; }
 
     auto bail = [&](int code) { close(fd); fx_close(h); return code; };
 
@@ -363,18 +428,10 @@ extern "C" int fx_open_file(const char *path, int device, fx_handle **out) {
         const int64_t n = (int64_t)st.st_size;
         rc = alloc_blob(h, n);
         if (rc) return bail(rc);
-        std::atomic<int> err(0);
-        int slot = 0;
-        for (int64_t off = 0; off < n; off += STAGE_BYTES, slot = (slot + 1) % NSTAGE) {
-            const int64_t len = std::min(STAGE_BYTES, n - off);
-            if (st_.used[slot]) { hipError_t e = hipEventSynchronize(st_.ev[slot]); if (e != hipSuccess) return bail(fail(FX_EDEVICE, "event sync: %s", hipGetErrorString(e))); }
-            parallel_pread(fd, st_.pin[slot], off, len, &err);
-            if (err.load()) return bail(fail(FX_EIO, "read error on %s", path));
-            hipError_t e = hipMemcpyAsync(h->d_data + off, st_.pin[slot], (size_t)len, hipMemcpyHostToDevice, h->stream);
-            if (e == hipSuccess) e = hipEventRecord(st_.ev[slot], h->stream);
-            if (e != hipSuccess) return bail(fail(FX_EDEVICE, "H2D: %s", hipGetErrorString(e)));
-            st_.used[slot] = true;
-        }
+        if (hipStreamSynchronize(h->stream) != hipSuccess)   // the pad memset precedes the copies of the staging streams
+            return bail(fail(FX_EDEVICE, "stream sync failed"));
+        rc = stage_plain_file(h, fd, n, path);
+        if (rc) return bail(rc);
     } else {
         // BGZF (bgzip): every member inflates independently -> GPU (k_bgzf_inflate)
         {
@@ -393,7 +450,9 @@ extern "C" int fx_open_file(const char *path, int device, fx_handle **out) {
             // brc == 1: not BGZF -> fall through to the single-stream path
         }
         // single-stream gzip: inflate is inherently serial (zlib on the host), the
-        // inflated bytes stream through the same pinned ring into a growing blob.
+        // inflated bytes stream through a pinned ring into a growing blob.
+        rc = st_.init();
+        if (rc) return bail(rc);
         gzFile g = gzdopen(dup(fd), "rb");
         if (!g) return bail(fail(FX_EIO, "gzdopen failed for %s", path));
         gzbuffer(g, 1 << 20);
