@@ -420,9 +420,22 @@ __global__ __launch_bounds__(BLOCK) void k_revcomp(uint8_t *__restrict__ buf, in
     }
 }
 
-// FASTQ read fetch (read.c:37-45,152-167,237-278): one wave per read copies
-// rlen bytes at soff and at qoff; quali = qual - phred as int8.
-__global__ __launch_bounds__(BLOCK) void k_fastq_fetch(const uint8_t *__restrict__ data, int64_t gbase,
+// out[i] = col[idx[i]], -1 for an index outside [0, n)
+__global__ __launch_bounds__(BLOCK) void k_gather_i64(const int64_t *__restrict__ col, int64_t n, const int64_t *__restrict__ idx,
+                                                     int64_t nq, int64_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < nq) { const int64_t k = idx[i]; out[i] = (k >= 0 && k < n) ? col[k] : -1; }
+}
+
+// FASTQ read fetch (read.c:37-45,152-167,237-278).  16 lanes per read, 4 reads per wave; a lane moves 16
+// bytes of the sequence line and 16 of the quality line per step with unaligned 16-byte loads / stores
+// (a 150-base read is one step).  quali = qual - phred as int8, four bytes at a time.  The chain of
+// dependent round trips (id -> table row -> bytes) is software-pipelined: ids are fetched two iterations
+// ahead and table rows one iteration ahead, so only the byte loads are on the critical path.
+__device__ __forceinline__ uint32_t sub_bytes(uint32_t x, uint32_t y) {        // per-byte x - y (mod 256), y < 0x80 in every byte
+    return ((x | 0x80808080u) - y) ^ (~x & 0x80808080u);
+}
+__global__ __launch_bounds__(BLOCK) void k_fastq_fetch(const uint8_t *__restrict__ data, int64_t gbase, int64_t n_bytes,
                                                       const int64_t *__restrict__ rlen, const int64_t *__restrict__ soff,
                                                       const int64_t *__restrict__ qoff, int64_t n_reads,
                                                       const int64_t *__restrict__ ids, int64_t nq, int phred, int flags,
@@ -431,22 +444,59 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_fetch(const uint8_t *__restrict
     __shared__ uint8_t lut[256];
     build_comp_lut(lut);
     __syncthreads();
-    const int lane = lane_id();
+    const int lane = lane_id(), sub = lane & 15, grp = lane >> 4;
     const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
-    for (int64_t i = wave; i < nq; i += nwaves) {
-        const int64_t id = ids ? ids[i] : i;           // ids == null: the arrays are per query already
-        if (id < 0 || id >= n_reads) continue;
-        const int64_t n = rlen[id], so = soff[id] - gbase, qo = qoff[id] - gbase, d = dst_off[i];
-        for (int64_t j = lane; j < n; j += 64) {
-            if (seq) {
-                uint8_t c = data[so + j];
-                if (flags & 4) c = lut[c];
-                seq[d + ((flags & 2) ? (n - 1 - j) : j)] = c;
+    const int64_t stride = (((int64_t)gridDim.x * BLOCK) >> 6) * 4;
+    const uint32_t ph4 = (uint32_t)(phred & 0x7F) * 0x01010101u;
+    const bool rev = (flags & 2) != 0;
+    // pipeline registers: id two iterations ahead, table row one iteration ahead
+    int64_t i = wave * 4 + grp;
+    auto get_id = [&](int64_t q) -> int64_t { return q < nq ? (ids ? ids[q] : q) : -1; };   // ids == null: the arrays are per query already
+    int64_t id1 = get_id(i), id2 = get_id(i + stride);
+    int64_t r_n = 0, r_so = 0, r_qo = 0, r_d = 0;
+    auto get_row = [&](int64_t id, int64_t q) {
+        if (id >= 0 && id < n_reads) { r_n = rlen[id]; r_so = soff[id] - gbase; r_qo = qoff[id] - gbase; r_d = dst_off[q]; }
+        else r_n = -1;
+    };
+    get_row(id1, i);
+    for (; i - grp < nq; i += stride) {                       // wave-uniform trip count
+        const int64_t n = r_n, so = r_so, qo = r_qo, d = r_d;
+        id1 = id2;
+        id2 = get_id(i + 2 * stride);
+        get_row(id1, i + stride);
+        if (n <= 0) continue;
+        const bool inside = so >= 16 && qo >= 16 && so + n + 16 <= n_bytes && qo + n + 16 <= n_bytes;   // room for whole 16-byte accesses
+        for (int64_t s0 = 0; s0 < n; s0 += 256) {
+            const int64_t oc = s0 + 16 * sub;                 // this lane's output chunk [oc, oc + len)
+            const int len = (int)(n - oc < 16 ? n - oc : 16);
+            if (len <= 0) continue;
+            if (inside) {
+                const uint4 qv = *reinterpret_cast<const uint4_u *>(data + qo + oc);
+                if (seq) {
+                    // reverse strand: forward bytes [n - oc - len, n - oc), reversed; the partial chunk is the head of the read
+                    const int64_t f0 = rev ? n - oc - len : oc;
+                    const int lead = rev ? 16 - len : 0;
+                    uint4 v = *reinterpret_cast<const uint4_u *>(data + so + f0 - lead);
+                    if (flags & 4) { v.x = lut4(lut, v.x); v.y = lut4(lut, v.y); v.z = lut4(lut, v.z); v.w = lut4(lut, v.w); }
+                    if (rev) v = make_uint4(__builtin_bswap32(v.w), __builtin_bswap32(v.z), __builtin_bswap32(v.y), __builtin_bswap32(v.x));
+                    store_low_bytes(seq + d + oc, v, len);
+                }
+                if (qual) store_low_bytes(qual + d + oc, qv, len);
+                if (quali) store_low_bytes(reinterpret_cast<uint8_t *>(quali) + d + oc,
+                                           make_uint4(sub_bytes(qv.x, ph4), sub_bytes(qv.y, ph4), sub_bytes(qv.z, ph4), sub_bytes(qv.w, ph4)), len);
+            } else {                                          // reads at the very edge of the blob: byte by byte
+                for (int k = 0; k < len; ++k) {
+                    const int64_t j = oc + k;
+                    if (seq) {
+                        uint8_t c = data[so + j];
+                        if (flags & 4) c = lut[c];
+                        seq[d + (rev ? (n - 1 - j) : j)] = c;
+                    }
+                    const uint8_t qc = data[qo + j];
+                    if (qual) qual[d + j] = qc;
+                    if (quali) quali[d + j] = (int8_t)((int)(signed char)qc - phred);
+                }
             }
-            const uint8_t qc = data[qo + j];
-            if (qual) qual[d + j] = qc;
-            if (quali) quali[d + j] = (int8_t)((int)(signed char)qc - phred);
         }
     }
 }

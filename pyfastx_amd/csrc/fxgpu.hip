@@ -1005,21 +1005,25 @@ extern "C" int fx_fastq_fetch(fx_handle *h, int where, int64_t n, const int64_t 
     int64_t total = 0;
     std::vector<int64_t> rl;
     if (where == FX_HOST) {
-        // output extent needs rlen of the requested reads
-        std::vector<int64_t> all((size_t)h->n_reads);
-        HIPCHK(hipMemcpyAsync(all.data(), h->fq_rlen.p, (size_t)h->n_reads * 8, hipMemcpyDeviceToHost, h->stream));
+        // output extent needs rlen of the requested reads: gather them on the device (n values, not the whole column)
+        if ((rc = st.up(h, read_id, n, &d_ids))) return rc;
+        int64_t *d_rl = nullptr;
+        if ((rc = st.scratch<int64_t>(n, &d_rl))) return rc;
+        hipLaunchKernelGGL(k_gather_i64, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, h->fq_rlen.p, h->n_reads, d_ids, n, d_rl);
+        rl.resize((size_t)n);
+        HIPCHK(hipMemcpyAsync(rl.data(), d_rl, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         for (int64_t i = 0; i < n; ++i) {
-            if (read_id[i] < 0 || read_id[i] >= h->n_reads) return fail(FX_ERANGE, "read id %lld out of range", (long long)read_id[i]);
-            total = std::max(total, dst_off[i] + all[(size_t)read_id[i]]);
+            if (rl[(size_t)i] < 0) return fail(FX_ERANGE, "read id %lld out of range", (long long)read_id[i]);
+            total = std::max(total, dst_off[i] + rl[(size_t)i]);
         }
         total = std::max<int64_t>(total, 1);
-        if ((rc = st.up(h, read_id, n, &d_ids)) || (rc = st.up(h, dst_off, n, &d_off))) return rc;
+        if ((rc = st.up(h, dst_off, n, &d_off))) return rc;
         if (seq && (rc = st.scratch<uint8_t>(total, &d_seq))) return rc;
         if (qual && (rc = st.scratch<uint8_t>(total, &d_qual))) return rc;
         if (quali && (rc = st.scratch<int8_t>(total, &d_qi))) return rc;
     }
-    FX_LAUNCH(h, K_FASTQ_FETCH, k_fastq_fetch, dim3(fetch_grid(n)), dim3(BLOCK), h->d_data, h->base, h->fq_rlen.p,
+    FX_LAUNCH(h, K_FASTQ_FETCH, k_fastq_fetch, dim3(fetch_grid((n + 3) / 4)), dim3(BLOCK), h->d_data, h->base, h->n, h->fq_rlen.p,
                        h->fq_soff.p, h->fq_qoff.p, h->n_reads, d_ids, n, phred, seq_flags, d_seq, d_qual, d_qi, d_off);
     HIPCHK(hipGetLastError());
     if (where == FX_HOST) {
@@ -1060,7 +1064,7 @@ extern "C" int fx_read_fetch(fx_handle *h, int where, int64_t n, const int64_t *
         if (qual && (rc = st.scratch<uint8_t>(total, &d_qual))) return rc;
         if (quali && (rc = st.scratch<int8_t>(total, &d_qi))) return rc;
     }
-    FX_LAUNCH(h, K_FASTQ_FETCH, k_fastq_fetch, dim3(fetch_grid(n)), dim3(BLOCK), h->d_data, h->base, d_r, d_s, d_q, n,
+    FX_LAUNCH(h, K_FASTQ_FETCH, k_fastq_fetch, dim3(fetch_grid((n + 3) / 4)), dim3(BLOCK), h->d_data, h->base, h->n, d_r, d_s, d_q, n,
               (const int64_t *)nullptr, n, phred, seq_flags, d_seq, d_qual, d_qi, d_off);
     HIPCHK(hipGetLastError());
     if (where == FX_HOST) {
