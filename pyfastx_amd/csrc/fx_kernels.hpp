@@ -395,9 +395,21 @@ __global__ __launch_bounds__(BLOCK) void k_fetch(const uint8_t *__restrict__ dat
             }
             rank += total;
         }
-        if (ok && sub == 0 && q.out_len) {
-            const int64_t got = rank - skip;
-            q.out_len[i] = got < 0 ? 0 : (got > take ? take : got);
+        if (ok) {
+            int64_t got = rank - skip;
+            got = got < 0 ? 0 : (got > take ? take : got);
+            // FX_REVERSE mirrors around `take`; when the range held fewer bases than that (irregular records: the
+            // reference reverses the bytes it actually got, util.c:251-261) the result sits `take - got` too high
+            if ((fl & 2) && got < take && got > 0) {
+                const int64_t delta = take - got;
+                for (int64_t j0 = 0; j0 < got; j0 += G) {           // lanes move in lock step: load, then store
+                    const int64_t j = j0 + sub;
+                    uint8_t c = 0;
+                    if (j < got) c = out[delta + j];
+                    if (j < got) out[j] = c;
+                }
+            }
+            if (sub == 0 && q.out_len) q.out_len[i] = got;
         }
     }
 }

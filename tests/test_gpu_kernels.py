@@ -171,3 +171,116 @@ def test_fasta_random(oracle, L, seed):
             if fl[j] & 2:
                 want = want[::-1]
         assert buf[offs[j]:offs[j] + ol[j]].tobytes() == want, (seed, j, fl[j])
+
+
+def _pad_to(raw_parts, target):
+    """bytes of sequence lines (width 60) so that the next byte written lands exactly at offset `target`"""
+    cur = sum(len(p) for p in raw_parts)
+    need = target - cur
+    assert need > 2
+    body = (b"ACGT" * ((need // 4) + 2))[:need - 1]
+    out, p = [], 0
+    while p < len(body):
+        out.append(body[p:p + 60]); p += 60
+    s = b"\n".join(out)
+    s = s[:need - 1] + b"\n"
+    return s
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+def test_fasta_granule_shapes(oracle, L, crlf):
+    """Shapes that matter to the 4 KiB granule machinery: header lines that start exactly at, one byte before /
+    after, or run across a granule boundary; lines much longer than a granule (unwrapped FASTA); a record with
+    one odd middle line (the norm = 1 quirk); '>' inside sequence lines; blank lines; no trailing newline."""
+    rng = np.random.default_rng(11 + crlf)
+    alpha = np.frombuffer(b"ACGTNacgtnRYKM", dtype=np.uint8)
+    parts = [b">first record\n"]
+    for target in (4096, 8191, 12289, 16384 - 7, 20480 + 4090):      # header '>' lands at / around granule boundaries
+        parts.append(_pad_to(parts, target))
+        parts.append(b">hdr_at_%d with a fairly long description to cross things %s\n" % (target, b"x" * int(rng.integers(0, 40))))
+    # unwrapped records: one line of 3 ... 40 KiB
+    for n in (3000, 4096 - 20, 9000, 40000):
+        parts.append(b">unwrapped_%d\n" % n + alpha[rng.integers(0, alpha.size, n)].tobytes() + b"\n")
+    # regular 60-column record over many granules, then the same with ONE odd middle line (still norm = 1) and with two (norm = 0)
+    for odd in (0, 1, 2):
+        body = alpha[rng.integers(0, 5, 30000)].tobytes()
+        lines = [body[p:p + 60] for p in range(0, len(body), 60)]
+        for k in range(odd):
+            lines[100 + 37 * k] = lines[100 + 37 * k][:41]
+        parts.append(b">odd%d\n" % odd + b"\n".join(lines) + b"\n")
+    parts.append(b">gt_inside\nACGT>ACGT\n>ACGT is a header\nAC\n\n\nGT\n>last no newline\nACGTAC")
+    raw = b"".join(parts)
+    if crlf:
+        raw = raw.replace(b"\n", b"\r\n")
+    b, recs, t = assert_fasta_equal(oracle, L, raw)
+    assert len(recs) >= 15
+    ok = np.nonzero(recs["slen"] > 0)[0]
+    nq = 800
+    ids = rng.choice(ok, nq)
+    st = (rng.random(nq) * recs["slen"][ids]).astype(np.int64)
+    sp = np.minimum(st + rng.integers(0, 700, nq), recs["slen"][ids])
+    fl = rng.integers(0, 8, nq).astype(np.uint8)
+    buf, offs, ol = b.fasta_fetch(ids, st, sp, flags_per_query=fl)
+    for j in range(nq):
+        r = recs[ids[j]]
+        bpl = int(r["llen"]) - int(r["elen"])
+        if r["norm"] and bpl > 0:
+            off, bl = oracle.slice_range(int(r["boff"]), int(r["llen"]), int(r["elen"]), int(st[j]), int(sp[j]))
+            want = oracle.fetch(raw, off, bl, int(sp[j] - st[j]), int(fl[j]))
+        else:
+            full = oracle.fetch(raw, int(r["boff"]), int(r["blen"]), 1 << 60, int(fl[j]) & 1)
+            want = full[st[j]:sp[j]]
+            if fl[j] & 4:
+                want = oracle.revcomp(want, 2)
+            if fl[j] & 2:
+                want = want[::-1]
+        assert buf[offs[j]:offs[j] + ol[j]].tobytes() == want, (crlf, j, int(ids[j]), int(st[j]), int(sp[j]), int(fl[j]))
+
+
+def _rand_fastq(rng, nrec, maxlen, crlf=False, plus_name=False, trailing=True):
+    eol = b"\r\n" if crlf else b"\n"
+    out = []
+    alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for i in range(nrec):
+        n = int(rng.integers(1, maxlen + 1))
+        name = b"@read%d/%d" % (i, n) + (b" extra words here" if i % 3 else b"") + (b"_" * int(rng.integers(0, 30)))
+        out.append(name + eol)
+        out.append(alpha[rng.integers(0, alpha.size, n)].tobytes() + eol)
+        out.append((b"+" + name[1:] if plus_name and i % 2 else b"+") + eol)
+        out.append(rng.integers(33, 75, n).astype(np.uint8).tobytes() + eol)
+    raw = b"".join(out)
+    if not trailing:
+        raw = raw[:-len(eol)]
+    return raw
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fastq_random(oracle, L, seed):
+    """Short reads (many newlines per granule, several compaction rounds), long reads (lines longer than a
+    granule), CRLF, '+name' lines, unterminated last line -- index, composition and read fetches vs the oracle."""
+    rng = np.random.default_rng(500 + seed)
+    maxlen = (8, 150, 150, 30000, 3000, 2)[seed]
+    nrec = (4000, 1500, 1500, 40, 300, 6000)[seed]
+    raw = _rand_fastq(rng, nrec, maxlen, crlf=bool(seed & 1), plus_name=(seed >= 2), trailing=(seed != 4))
+    recs, size, ln = oracle.fastq_index(raw)
+    b = L.Blob.from_bytes(raw)
+    s = b.fastq_build()
+    assert (s.n_reads, s.size, s.n_lines) == (len(recs), size, ln)
+    t = b.fastq_table(s.n_reads)
+    for col in ("name_off", "name_len", "dlen", "rlen", "soff", "qoff"):
+        np.testing.assert_array_equal(t[col], recs[col].astype(t[col].dtype), err_msg=col)
+    base, meta = b.fastq_comp()
+    c = oracle.fastq_composition(raw)
+    assert base.tolist() == [c["a"], c["c"], c["g"], c["t"], c["n"]]
+    assert meta.tolist() == [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"], c["phred"]]
+    ids = rng.integers(0, s.n_reads, 300)
+    for flags in (0, L.FX_REVERSE | L.FX_COMPLEMENT):
+        seq, qual, qi, offs = b.fastq_fetch(ids, t["rlen"][ids], phred=33, seq_flags=flags)
+        for j, k in enumerate(ids):
+            so, qo, n = int(recs["soff"][k]), int(recs["qoff"][k]), int(recs["rlen"][k])
+            want = raw[so:so + n]
+            if flags:
+                want = oracle.revcomp(want, 3)
+            assert seq[offs[j]:offs[j + 1]].tobytes() == want, (seed, j)
+            assert qual[offs[j]:offs[j + 1]].tobytes() == raw[qo:qo + n], (seed, j)
+            assert qi[offs[j]:offs[j + 1]].tolist() == [q - 33 for q in raw[qo:qo + n]], (seed, j)
