@@ -274,7 +274,7 @@ __global__ __launch_bounds__(1024) void k_span_scan(const uint8_t *__restrict__ 
 //   k_gran_reduce   one workgroup per CHUNK of 1024 granules (4 MiB of stream): totals.  The workgroup
 //                   that owns the last granule first computes it (the partial tail of the stream).
 //   k_gran_prefix   one workgroup per chunk: base = join of the totals of the chunks before it (one
-//                   load per thread up to 4 GiB of stream), then a local scan; the last one writes Totals.
+//                   load per thread up to 4 GiB of stream), then a local 32-bit scan; the last one writes Totals.
 // nl_prefix[g] / hdr_prefix[g] = newlines / header lines before granule g (entry [ngran] = totals),
 // prevnl[g] = global offset of the last newline before granule g (-1: none in this shard).
 constexpr int CHUNK_GRANS = 1024;
@@ -366,7 +366,8 @@ __global__ __launch_bounds__(CHUNK_GRANS) void k_gran_prefix(const GranPk *__res
                                                             int64_t *__restrict__ prevnl) {
     __shared__ Tri lds[CHUNK_GRANS / 64];
     __shared__ uint32_t lds32[3][16];
-    // base: join of the totals of the chunks before this one
+    // base: join of the totals of the chunks before this one (a ticketed "last workgroup scans the totals"
+    // variant inside k_gran_reduce was measured slower: 47 us for the pair instead of 31)
     Tri b{0, 0, -1};
     for (int64_t c = threadIdx.x; c < (int64_t)blockIdx.x; c += CHUNK_GRANS) { const ChunkTot t = ct[c]; b = tri_join(b, Tri{t.n, t.h, t.last}); }
     Tri base{0, 0, -1};
@@ -463,18 +464,49 @@ __device__ __forceinline__ void scan_line(const uint8_t *__restrict__ data, int6
 }
 
 // columns of index.c:234-339 that depend only on the header line and the line after it, read from
-// memory by one thread (the fall-back of k_hdr_rec for records whose first two lines leave the granule)
+// memory by the whole wave, 1 KiB per step (the fall-back of k_hdr_rec for records whose first two lines
+// leave the granule; all arguments wave-uniform).
+// first newline (and, if want_ws, first ' ' / '\t') at a local offset >= y; -1 when the shard's bytes end first
+__device__ __forceinline__ void scan_line_wave(const uint8_t *__restrict__ data, int64_t n, int64_t y, bool want_ws,
+                                               int64_t *e_out, int64_t *ws_out, int *cr_before) {
+    const int lane = lane_id();
+    int64_t e = -1, ws = -1;
+    int cr = 0, prev_cr = 0;                               // prev_cr: is the last byte of the previous window a '\r'
+    for (int64_t p0 = y & ~(int64_t)(CHUNK - 1); p0 < n; p0 += 64 * CHUNK) {
+        const int64_t p = p0 + lane * CHUNK;
+        const uint4 v = load16(data, p, n);
+        uint32_t m = eq_mask16(v, 0x0A0A0A0Au), c = eq_mask16(v, 0x0D0D0D0Du);
+        uint32_t w = want_ws ? (eq_mask16(v, 0x20202020u) | eq_mask16(v, 0x09090909u)) : 0u;
+        if (p < y) { const uint32_t keep = (y - p >= CHUNK) ? 0u : (0xFFFFu << (y - p)); m &= keep; w &= keep; }
+        const unsigned long long bw = __ballot(w != 0), bm = __ballot(m != 0);
+        if (want_ws && ws < 0 && bw) { const int l = __ffsll(bw) - 1; ws = p0 + l * CHUNK + (__ffs(rdlane(w, l)) - 1); }
+        if (bm) {
+            const int l = __ffsll(bm) - 1;
+            const int k = __ffs(rdlane(m, l)) - 1;
+            e = p0 + l * CHUNK + k;
+            if (k) cr = (int)((rdlane(c, l) >> (k - 1)) & 1u);
+            else   cr = l ? (int)(rdlane(c, l - 1) >> 15) : prev_cr;
+            break;
+        }
+        prev_cr = (int)(rdlane(c, 63) >> 15);
+    }
+    *e_out = e; *ws_out = ws; *cr_before = cr;
+}
+
 __device__ __forceinline__ void record_at(const ScanCtx &x, int is_last, int full_name, int64_t h, int64_t k,
                                           const FastaCols &c) {
     int64_t e, ws, e1, dummy;
     int cr, cr1;
-    scan_line(x.data, x.n, h + 1 - x.gbase, !full_name, &e, &ws, &cr);
+    scan_line_wave(x.data, x.n, h + 1 - x.gbase, !full_name, &e, &ws, &cr);
     if (e < 0 && is_last) { e = x.n; cr = x.data[x.n - 1] == '\r'; }     // virtual end-of-stream newline (index.c:231)
+    const bool lead = lane_id() == 0;
     if (e < 0) {
         // only possible for the LAST header of a non-final shard: its line ends in a later shard.
         // Leave a stub (dlen = -1) for the host-side stitch; name_len = local whitespace hit or -1.
-        c.boff[k] = 0; c.llen[k] = 0; c.elen[k] = 0; c.dlen[k] = -1;
-        c.name_len[k] = (!full_name && ws >= 0) ? (int32_t)(ws - (h + 1 - x.gbase)) : -1;
+        if (lead) {
+            c.boff[k] = 0; c.llen[k] = 0; c.elen[k] = 0; c.dlen[k] = -1;
+            c.name_len[k] = (!full_name && ws >= 0) ? (int32_t)(ws - (h + 1 - x.gbase)) : -1;
+        }
         return;
     }
     const int elen = cr ? 2 : 1;                           // index.c:266-269
@@ -484,13 +516,15 @@ __device__ __forceinline__ void record_at(const ScanCtx &x, int is_last, int ful
     // first sequence line (index.c:330-332): the line after the header line, unless that is a header too
     int64_t llen = 0;
     if (e + 1 < x.n && x.data[e + 1] != '>') {
-        scan_line(x.data, x.n, e + 1, false, &e1, &dummy, &cr1);
+        scan_line_wave(x.data, x.n, e + 1, false, &e1, &dummy, &cr1);
         if (e1 < 0 && is_last) e1 = x.n;
         if (e1 >= 0) llen = e1 - e;
     }
-    c.boff[k] = x.gbase + e + 1;                           // index.c:258  start = position
-    c.llen[k] = llen;
-    c.elen[k] = elen; c.dlen[k] = dlen; c.name_len[k] = name_len;
+    if (lead) {
+        c.boff[k] = x.gbase + e + 1;                       // index.c:258  start = position
+        c.llen[k] = llen;
+        c.elen[k] = elen; c.dlen[k] = dlen; c.name_len[k] = name_len;
+    }
 }
 
 // ---- 4096-bit masks spread over a wave: bit (16 * lane + k) of row j <-> granule byte j*1024 + 16*lane + k
@@ -585,7 +619,7 @@ __global__ __launch_bounds__(BLOCK) void k_hdr_rec(ScanCtx x, int prev_byte, int
             const int e1 = (e >= 0 && e + 1 < GRAN) ? mask_next(nl, e) : -1;   // end of the line after it
             const bool inside = e >= 0 && e + 1 < GRAN && (e1 >= 0 || sbase + e + 1 >= x.n);
             if (!inside) {                                            // runs past the granule: read memory
-                if (lane == 0) record_at(x, is_last, full_name, h, r, c);
+                record_at(x, is_last, full_name, h, r, c);
                 continue;
             }
             const int elen = mask_bit(cr, e - 1) ? 2 : 1;             // index.c:266-269 (e - 1 >= hp)
@@ -672,36 +706,38 @@ __device__ __forceinline__ void exact_walk(const ScanCtx &x, const RecView &rv, 
 // One thread per granule.  A granule that lies inside one record's body past its first sequence line,
 // without a header line and with <= 2 distinct line lengths, is answered from its summary: lines that
 // differ from the record's llen = those of the two summarised lengths that differ, plus the line that
-// crosses into the granule.  Anything else is irregular: the wave walks those granules exactly, one
-// after the other, all lanes together.
-__global__ __launch_bounds__(BLOCK) void k_gran_lines(ScanCtx x, RecView rv, int64_t cap, int is_last) {
+// crosses into the granule.  Anything else is irregular and goes to a list; k_gran_exact walks those
+// granules, one wave each (they cluster where records are short, so they are spread over the chip
+// instead of being walked by the wave that found them).
+__global__ __launch_bounds__(BLOCK) void k_gran_lines(ScanCtx x, RecView rv, int64_t cap, GranList irr) {
     const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    bool irregular = false;
-    if (g < x.ngran) {
-        const GranOut o = gran_unpack(x.go[g]);
-        const int64_t r = x.hdr_prefix[g] - 1;             // record that owns the first byte of the granule
-        if (o.n && o.h) irregular = true;
-        else if (o.n && r >= 0 && r < cap && rv.dlen[r] >= 0) {   // r < 0: before the first header -- the shard summary handles the lead
-            const int64_t ll = rv.llen[r];                 // 0: no sequence line, the only newline after the header ends it
-            const int64_t e1 = rv.boff[r] - 1 + ll;        // end of the first sequence line
-            const int64_t gs = x.gbase + g * (int64_t)GRAN;
-            if (ll && e1 < gs + GRAN) {                    // else nothing but the header line can end here
-                if (e1 < gs && !o.ovf) {
-                    DiffSet ds;
-                    ds.v1 = o.v1; ds.c1 = o.c1; ds.v2 = o.v2; ds.c2 = o.c2; ds.ovf = 0;
-                    const uint32_t mism = ds.count_ne((uint32_t)ll) + ((gs + o.first - x.prevnl[g]) != ll ? 1u : 0u);
-                    if (mism) atomicAdd(&rv.bad[r], mism);
-                } else irregular = true;
-            }
+    if (g >= x.ngran) return;
+    const GranOut o = gran_unpack(x.go[g]);
+    if (!o.n) return;
+    const int64_t r = x.hdr_prefix[g] - 1;                 // record that owns the first byte of the granule
+    const int64_t pv = x.prevnl[g];
+    if (!o.h) {
+        if (r < 0 || r >= cap || rv.dlen[r] < 0) return;   // r < 0: before the first header -- the shard summary handles the lead
+        const int64_t ll = rv.llen[r];                     // 0: no sequence line, the only newline after the header ends it
+        const int64_t e1 = rv.boff[r] - 1 + ll;            // end of the first sequence line
+        const int64_t gs = x.gbase + g * (int64_t)GRAN;
+        if (!ll || e1 >= gs + GRAN) return;                // nothing but the header line can end here
+        if (e1 < gs && !o.ovf) {
+            DiffSet ds;
+            ds.v1 = o.v1; ds.c1 = o.c1; ds.v2 = o.v2; ds.c2 = o.c2; ds.ovf = 0;
+            const uint32_t mism = ds.count_ne((uint32_t)ll) + ((gs + o.first - pv) != ll ? 1u : 0u);
+            if (mism) atomicAdd(&rv.bad[r], mism);
+            return;
         }
     }
-    unsigned long long todo = __ballot(irregular);
-    const int64_t g0 = g - lane_id();
-    while (todo) {
-        const int l = __ffsll(todo) - 1;
-        todo &= todo - 1;
-        exact_walk(x, rv, cap, is_last, g0 + l);
-    }
+    irr.g[atomicAdd(irr.count, 1u)] = (uint32_t)g;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_gran_exact(ScanCtx x, RecView rv, int64_t cap, GranList irr, int is_last) {
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t cnt = *irr.count;
+    for (int64_t i = wave; i < cnt; i += nwaves) exact_walk(x, rv, cap, is_last, irr.g[i]);
 }
 
 // blen, slen (index.c:243,335-338,348), norm (index.c:237,342), stat.seqlen (index.c:253-254, 360-369)

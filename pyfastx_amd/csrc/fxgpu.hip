@@ -75,10 +75,10 @@ template <class T> struct DevBuf {      // grow-only device array: rebuilds reus
 // ------------------------------------------------------------ kernel timing
 // Optional per-kernel HIP-event timing on the handle's own stream (bench.py's
 // roofline leg reads it; off by default so the hot path records no events).
-enum KernelId { K_SPAN_SCAN = 0, K_GRAN_REDUCE, K_GRAN_PREFIX, K_HDR_REC, K_GRAN_LINES, K_FASTA_FINALIZE, K_FETCH,
+enum KernelId { K_SPAN_SCAN = 0, K_GRAN_REDUCE, K_GRAN_PREFIX, K_HDR_REC, K_GRAN_LINES, K_GRAN_EXACT, K_FASTA_FINALIZE, K_FETCH,
                 K_FASTA_COMP, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_NKERN };
 static const char *const kKernelNames[K_NKERN] = {
-    "k_span_scan", "k_gran_reduce", "k_gran_prefix", "k_hdr_rec", "k_gran_lines", "k_fasta_finalize", "k_fetch",
+    "k_span_scan", "k_gran_reduce", "k_gran_prefix", "k_hdr_rec", "k_gran_lines", "k_gran_exact", "k_fasta_finalize", "k_fetch",
     "k_fasta_comp", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_inflate"};
 
 struct Prof {
@@ -138,7 +138,7 @@ struct fx_handle {
     // FASTA scan products (fx_spanscan.hpp): per-granule summaries and their prefixes
     int64_t ngran = 0;
     DevBuf<GranPk> gran;
-    DevBuf<uint32_t> hdr_grans;               // granules holding a header line
+    DevBuf<uint32_t> hdr_grans, irr_grans;    // granules holding a header line / needing the exact walk
     DevBuf<ChunkTot> chunks;
     DevBuf<unsigned long long> ctl;           // Totals (8 words) + list counter + shard summary
     Totals *pin_tot = nullptr;                // pinned host copy of Totals (async read-back without staging)
@@ -591,7 +591,7 @@ static int alloc_fasta_table(fx_handle *h, int64_t cap) {
     return FX_OK;
 }
 
-// ctl layout (64 words): [0..8) Totals, [8] = header-granule list count (u32), [16..44) shard summary
+// ctl layout (64 words): [0..8) Totals, [8] / [9] = header-granule / irregular list counts (u32), [16..44) shard summary
 static Totals *ctl_totals(fx_handle *h) { return (Totals *)h->ctl.p; }
 static uint32_t *ctl_counter(fx_handle *h, int i) { return (uint32_t *)(h->ctl.p + 8 + i); }
 
@@ -602,7 +602,8 @@ static int granule_pass(fx_handle *h) {
     int rc;
     const int64_t nfull = h->n / GRAN, ngran = nfull + 1, nchunks = (ngran + CHUNK_GRANS - 1) / CHUNK_GRANS;
     h->ngran = ngran;
-    if ((rc = h->gran.alloc(ngran)) || (rc = h->hdr_grans.alloc(ngran)) || (rc = h->chunks.alloc(nchunks)) ||
+    if ((rc = h->gran.alloc(ngran)) || (rc = h->hdr_grans.alloc(ngran)) || (MODE == 0 && (rc = h->irr_grans.alloc(ngran))) ||
+        (rc = h->chunks.alloc(nchunks)) ||
         (rc = h->ctl.alloc(64)) || (rc = h->nl_prefix.alloc(ngran + 1)) || (rc = h->hdr_prefix.alloc(ngran + 1)) ||
         (rc = h->prevnl.alloc(ngran + 1)))
         return rc;
@@ -641,8 +642,10 @@ extern "C" int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out
         const int64_t cap = h->hdr.cap;
         const FastaCols c = fasta_cols(h);
         const RecView rv{h->fa_boff.p, h->fa_llen.p, h->fa_dlen.p, h->fa_bad.p, h->hdr.p};
+        const GranList irr{h->irr_grans.p, ctl_counter(h, 1)};
         FX_LAUNCH(h, K_HDR_REC, k_hdr_rec, dim3(512), dim3(BLOCK), x, h->prev_byte, (int)h->is_last, full_name, hgl, c, cap);
-        FX_LAUNCH(h, K_GRAN_LINES, k_gran_lines, dim3(nblocks(ngran, BLOCK)), dim3(BLOCK), x, rv, cap, (int)h->is_last);
+        FX_LAUNCH(h, K_GRAN_LINES, k_gran_lines, dim3(nblocks(ngran, BLOCK)), dim3(BLOCK), x, rv, cap, irr);
+        FX_LAUNCH(h, K_GRAN_EXACT, k_gran_exact, dim3(512), dim3(BLOCK), x, rv, cap, irr, (int)h->is_last);
         FX_LAUNCH(h, K_FASTA_FINALIZE, k_fasta_finalize2, dim3(nblocks(cap, BLOCK)), dim3(BLOCK), cap, c, ctl_totals(h));
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h->pin_tot, ctl_totals(h), sizeof tot, hipMemcpyDeviceToHost, h->stream));
@@ -651,6 +654,7 @@ extern "C" int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out
         if (tot.n_hdr <= cap) break;
         if ((rc = alloc_fasta_table(h, tot.n_hdr + tot.n_hdr / 16 + 16))) return rc;
         HIPCHK(hipMemsetAsync(&ctl_totals(h)->seq_len, 0, 8, h->stream));
+        HIPCHK(hipMemsetAsync(ctl_counter(h, 1), 0, 4, h->stream));                   // the irregular list is rebuilt
     }
     h->n_hdr = tot.n_hdr;
     h->n_nl = tot.n_nl;
