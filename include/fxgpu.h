@@ -109,6 +109,12 @@ int fx_fasta_table(fx_handle *h, int where,
                    int64_t *llen, int32_t *elen, int32_t *norm, int32_t *dlen,
                    int32_t *name_len);
 
+/* Install the record table of an existing .fxi instead of scanning (pyfastx_load_index, index.c:391-429):
+ * host arrays of the `seq` columns; afterwards fx_fasta_fetch works exactly as after fx_fasta_build.
+ * (Composition and the shard summary still need a scan.) */
+int fx_fasta_set_table(fx_handle *h, int64_t n, const int64_t *boff, const int64_t *blen, const int64_t *slen,
+                       const int64_t *llen, const int32_t *elen, const int32_t *norm);
+
 /* pyfastx_fasta_calc_composition (fasta.c:851-961): comp[n_seq][128] counts of
  * every byte value < 128 on the sequence lines of each record ('\r' included,
  * '\n' excluded).  Needs fx_fasta_build first. */

@@ -377,8 +377,7 @@ class Fasta:
     def fetch_many(self, names_or_ids, starts, stops, strand=None):
         """Batched extension: 0-based half-open (start, stop) on many sequences in ONE
         kernel launch -> (uint8 buffer, int64 offsets[n+1]).  names_or_ids: sequence names or 0-based
-        ids; strand: optional per-query '+'/'-' (or 0/1).  Byte ranges come from the vectorised
-        sequence.c:498-510 arithmetic; the despace / reverse-complement runs on the GPU."""
+        ids; strand: optional per-query '+'/'-' (or 0/1)."""
         self._need_index()
         t = self._table()
         starts = np.asarray(starts, dtype=np.int64)
@@ -396,19 +395,18 @@ class Fasta:
                 raise IndexError("index out of range")
         if starts.size and (starts.min() < 0 or (stops < starts).any() or (stops > t["slen"][ids]).any()):
             raise ValueError("interval outside the sequence")
-        elen = t["elen"][ids]
-        bpl = t["llen"][ids] - elen
-        if (t["norm"][ids] == 0).any() or (bpl <= 0).any():
-            raise ValueError("fetch_many needs line-regular (norm=1) sequences")
-        off = t["boff"][ids] + starts + elen * (starts // bpl)
-        bl = (stops - starts) + (stops // bpl - starts // bpl) * elen
         fl = (_F_UP if self._uppercase else 0)
         fpq = None
         if strand is not None:
             neg = np.array([s in ("-", 1, True) for s in strand], dtype=bool) if not isinstance(strand, np.ndarray) \
                 else (strand != 0) & (strand != ord("+"))
             fpq = np.where(neg, fl | _F_REV | _F_COMP, fl).astype(np.uint8)
-        buf, offs, ol = self._st.blob.fetch_ranges(off, bl, stops - starts, flags=fl, flags_per_query=fpq)
+        blob = self._st.blob
+        if not getattr(blob, "_table_ready", False):       # index loaded from an existing .fxi: install its rows once
+            blob.fasta_set_table(t["boff"], t["blen"], t["slen"], t["llen"], t["elen"], t["norm"])
+        # (record id, start, stop) resolved on the GPU with the sequence.c:498-510 arithmetic (line-regular
+        # records) or despace-then-slice (sequence.c:100-110)
+        buf, offs, ol = blob.fasta_fetch(ids, starts, stops, flags=fl, flags_per_query=fpq)
         return buf, offs
 
 

@@ -666,6 +666,26 @@ extern "C" int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out
     return FX_OK;
 }
 
+// The resident record table from an existing .fxi (pyfastx_load_index, index.c:391-429): batched fetches by
+// (record id, start, stop) then work without re-scanning the file.
+extern "C" int fx_fasta_set_table(fx_handle *h, int64_t n, const int64_t *boff, const int64_t *blen, const int64_t *slen,
+                                  const int64_t *llen, const int32_t *elen, const int32_t *norm) {
+    if (!h || n < 0 || (n > 0 && (!boff || !blen || !slen || !llen || !elen || !norm))) return fail(FX_EINVAL, "bad argument");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = alloc_fasta_table(h, std::max<int64_t>(n, 1)))) return rc;
+    auto up = [&](void *d, const void *s_, size_t bytes) { return hipMemcpyAsync(d, s_, bytes, hipMemcpyHostToDevice, h->stream); };
+    if (n) {
+        HIPCHK(up(h->fa_boff.p, boff, (size_t)n * 8)); HIPCHK(up(h->fa_blen.p, blen, (size_t)n * 8));
+        HIPCHK(up(h->fa_slen.p, slen, (size_t)n * 8)); HIPCHK(up(h->fa_llen.p, llen, (size_t)n * 8));
+        HIPCHK(up(h->fa_elen.p, elen, (size_t)n * 4)); HIPCHK(up(h->fa_norm.p, norm, (size_t)n * 4));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->n_hdr = n;
+    h->fasta_built = true;
+    return FX_OK;
+}
+
 template <class T>
 static int copy_out(fx_handle *h, int where, T *dst, const T *src, int64_t n) {
     if (!dst || n <= 0) return FX_OK;

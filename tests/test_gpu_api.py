@@ -220,3 +220,18 @@ def test_batched_fetch_many(fx, files):
     for i, x in enumerate(f):
         want = x["antisense"] if i % 2 else x["seq"]
         assert buf[offs[i]:offs[i + 1]].tobytes().decode() == want
+
+
+def test_fetch_many_on_loaded_index(fx, files):
+    """An index that already exists on disk is LOADED (no scan, index.c:391-429); fetch_many installs its rows
+    in HBM (fx_fasta_set_table) and answers by (id, start, stop) exactly like a freshly built one."""
+    g = load_golden("fasta_fixture")["test.fa"]
+    fx.Fasta(files["test.fa"])                       # builds and writes test.fa.fxi
+    fa = fx.Fasta(files["test.fa"])                  # loads it
+    f = g["fetches"]
+    names = [fa[x["id"] - 1].name for x in f]
+    buf, offs = fa.fetch_many(names, [x["start"] for x in f], [x["stop"] for x in f],
+                              strand=["-" if i % 3 == 0 else "+" for i in range(len(f))])
+    for i, x in enumerate(f):
+        want = x["antisense"] if i % 3 == 0 else x["seq"]
+        assert buf[offs[i]:offs[i + 1]].tobytes().decode() == want
