@@ -33,7 +33,18 @@ struct BitIn {
     int err;
 };
 
+typedef uint64_t __attribute__((aligned(1))) uint64_u;    // 8 bytes at any address (gfx9 unaligned access mode)
+
+// One unaligned 8-byte load tops the bit buffer up to >= 56 bits: every input byte costs 1/7 of a memory round
+// trip instead of one (the decoder is a chain of dependent round trips, so this is what it runs at).  The bits of
+// a partially consumed byte are OR-ed in again by the next refill at the same position: same data, harmless.
 __device__ __forceinline__ void refill(BitIn &b) {
+    if (b.p + 8 <= b.end) {
+        b.buf |= *reinterpret_cast<const uint64_u *>(b.p) << b.cnt;
+        b.p += (63 - b.cnt) >> 3;
+        b.cnt |= 56;
+        return;
+    }
     while (b.cnt <= 56 && b.p < b.end) { b.buf |= (uint64_t)(*b.p++) << b.cnt; b.cnt += 8; }
 }
 __device__ __forceinline__ uint32_t getbits(BitIn &b, int n) {
@@ -115,7 +126,22 @@ __device__ inline int inflate_codes(BitIn &b, const Huff &lc, const Huff &dc, ui
             if (o + len > cap) return INFL_EOUTPUT;
             const uint8_t *src = out + o - dist;
             uint8_t *dst = out + o;
-            for (int i = 0; i < len; ++i) dst[i] = src[i];   // byte order matters when dist < len (run replication)
+            int i = 0;
+            if (dist >= 8) {            // an 8-byte step never reads a byte written in the same step, so the loads of
+                                        // a 32-byte group are independent: one round trip per group, not per byte
+                for (; i + 32 <= len && dist >= 32; i += 32) {
+                    const uint64_t a = *reinterpret_cast<const uint64_u *>(src + i), c = *reinterpret_cast<const uint64_u *>(src + i + 8);
+                    const uint64_t d = *reinterpret_cast<const uint64_u *>(src + i + 16), e = *reinterpret_cast<const uint64_u *>(src + i + 24);
+                    *reinterpret_cast<uint64_u *>(dst + i) = a; *reinterpret_cast<uint64_u *>(dst + i + 8) = c;
+                    *reinterpret_cast<uint64_u *>(dst + i + 16) = d; *reinterpret_cast<uint64_u *>(dst + i + 24) = e;
+                }
+                for (; i + 8 <= len; i += 8) *reinterpret_cast<uint64_u *>(dst + i) = *reinterpret_cast<const uint64_u *>(src + i);
+                if (i < len) {          // 1..7 bytes left: one more load, byte stores (never past o + len)
+                    uint64_t t = *reinterpret_cast<const uint64_u *>(src + i);
+                    for (; i < len; ++i) { dst[i] = (uint8_t)t; t >>= 8; }
+                }
+            }
+            for (; i < len; ++i) dst[i] = src[i];            // byte order matters when dist < len (run replication)
             o += len;
         }
     }
