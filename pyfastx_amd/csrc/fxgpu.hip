@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <zlib.h>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -253,26 +254,6 @@ static int stage_threads() {
     return (int)std::min<unsigned>(16u, std::max<unsigned>(4u, hw / 8));
 }
 
-static void parallel_pread(int fd, uint8_t *dst, int64_t off, int64_t len, std::atomic<int> *err) {
-    // page-cache -> pinned memcpy is the host-side bottleneck of staging: spread it over threads
-    const int T = stage_threads();
-    const int64_t per = (len + T - 1) / T;
-    std::vector<std::thread> th;
-    for (int t = 0; t < T; ++t) {
-        const int64_t lo = t * per, hi = std::min(len, lo + per);
-        if (lo >= hi) break;
-        th.emplace_back([=]() {
-            int64_t done = lo;
-            while (done < hi) {
-                ssize_t r = pread(fd, dst + done, (size_t)(hi - done), (off_t)(off + done));
-                if (r <= 0) { err->store(1); return; }
-                done += r;
-            }
-        });
-    }
-    for (auto &x : th) x.join();
-}
-
 // Plain files: T host threads, each with its own pair of pinned 8 MiB buffers and its own HIP stream,
 // walk the file in an interleaved pattern (thread t takes pieces t, t+T, ...): pread into pinned memory,
 // hipMemcpyAsync to the blob, double-buffered.  The pinned buffers are allocated once per process
@@ -294,7 +275,7 @@ struct PinPool {
 };
 static PinPool g_pins;
 
-static int stage_plain_file(fx_handle *h, int fd, int64_t n, const char *path) {
+static int stage_plain_file(fx_handle *h, int fd, int64_t n, const char *path, uint8_t *d_dst) {
     const int T = (int)std::min<int64_t>(stage_threads(), std::max<int64_t>(1, (n + PIECE_BYTES - 1) / PIECE_BYTES));
     std::atomic<int> err(0);                 // 1: read error, 2: device error
     std::vector<std::thread> th;
@@ -320,7 +301,7 @@ static int stage_plain_file(fx_handle *h, int fd, int64_t n, const char *path) {
                     done += r;
                 }
                 if (done < len) break;
-                if (hipMemcpyAsync(h->d_data + off, pin[slot], (size_t)len, hipMemcpyHostToDevice, st) != hipSuccess ||
+                if (hipMemcpyAsync(d_dst + off, pin[slot], (size_t)len, hipMemcpyHostToDevice, st) != hipSuccess ||
                     hipEventRecord(ev[slot], st) != hipSuccess) { err.store(2); break; }
                 used[slot] = true;
             }
@@ -376,14 +357,14 @@ template <class T> static int upload(fx_handle *h, DevBuf<T> &d, const std::vect
     return FX_OK;
 }
 
-// compressed bytes (host, pinned) -> HBM -> k_bgzf_inflate -> resident blob
-static int bgzf_to_blob(fx_handle *h, const uint8_t *file, int64_t fsize, const BgzfTable &t, const char *path) {
+// compressed bytes (file -> pinned pieces -> HBM, stage_plain_file) -> k_bgzf_inflate -> resident blob
+static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize, const BgzfTable &t, const char *path) {
     DevBuf<uint8_t> d_c;
     DevBuf<int64_t> d_coff, d_uoff;
     DevBuf<int32_t> d_clen, d_isize, d_status;
     int rc;
     if ((rc = d_c.alloc(fsize + 16))) return rc;
-    HIPCHK(hipMemcpyAsync(d_c.p, file, (size_t)fsize, hipMemcpyHostToDevice, h->stream));
+    if ((rc = stage_plain_file(h, fd, fsize, path, d_c.p))) return rc;
     if ((rc = upload(h, d_coff, t.coff)) || (rc = upload(h, d_uoff, t.uoff)) || (rc = upload(h, d_clen, t.clen)) ||
         (rc = upload(h, d_isize, t.isize)))
         return rc;
@@ -430,21 +411,22 @@ extern "C" int fx_open_file(const char *path, int device, fx_handle **out) {
         if (rc) return bail(rc);
         if (hipStreamSynchronize(h->stream) != hipSuccess)   // the pad memset precedes the copies of the staging streams
             return bail(fail(FX_EDEVICE, "stream sync failed"));
-        rc = stage_plain_file(h, fd, n, path);
+        rc = stage_plain_file(h, fd, n, path, h->d_data);
         if (rc) return bail(rc);
     } else {
         // BGZF (bgzip): every member inflates independently -> GPU (k_bgzf_inflate)
         {
             const int64_t fsize = (int64_t)st.st_size;
-            uint8_t *host = nullptr;
-            hipError_t he = hipHostMalloc((void **)&host, (size_t)fsize + 16, hipHostMallocDefault);
-            if (he != hipSuccess) return bail(fail(FX_ENOMEM, "hipHostMalloc(%lld): %s", (long long)fsize, hipGetErrorString(he)));
-            std::atomic<int> err(0);
-            parallel_pread(fd, host, 0, fsize, &err);
+            // the member walk only touches the 18-byte header and the trailer of each member: map the file
+            // (page cache) instead of copying 1 GB to the host first
+            void *mp = mmap(nullptr, (size_t)fsize, PROT_READ, MAP_PRIVATE, fd, 0);
             BgzfTable tab;
             int brc = 1;
-            if (!err.load() && parse_bgzf(host, fsize, tab)) brc = bgzf_to_blob(h, host, fsize, tab, path);
-            (void)hipHostFree(host);
+            if (mp != MAP_FAILED) {
+                const bool is_bgzf = parse_bgzf((const uint8_t *)mp, fsize, tab);
+                (void)munmap(mp, (size_t)fsize);
+                if (is_bgzf) brc = bgzf_to_blob(h, fd, fsize, tab, path);
+            }
             if (brc == FX_OK) { close(fd); *out = h; return FX_OK; }
             if (brc < 0) return bail(brc);
             // brc == 1: not BGZF -> fall through to the single-stream path
