@@ -232,7 +232,7 @@ def main():
         "composition_pass_ms": None if comp_ms is None else round(comp_ms, 3),
         "kernels_ms_avg": {k: round(v[0] / v[1], 4) for k, v in prof_all.items()},
         "roofline": {"kernel": "fx::k_span_scan<0>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": shard.pmc_traffic(ROOT),
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": shard.pmc_traffic(ROOT, shard_bytes),
                      "algorithmic_bytes_per_launch": int(shard_bytes), "avg_launch_ms": round(scan_avg, 4)},
     }
     if world == 1 and not a.no_cpu_baseline:

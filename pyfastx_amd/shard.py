@@ -133,12 +133,16 @@ def allgather_summaries(mine, world, device="cpu"):
     return [Summary.from_array(o.cpu().numpy()) for o in outs]
 
 
-def pmc_traffic(root):
-    """HBM bytes per k_span_scan launch from the committed rocprofv3 --pmc summary (or None)."""
+def pmc_traffic(root, file_bytes=None):
+    """HBM bytes per k_span_scan launch from the committed rocprofv3 --pmc summary; None when there is no
+    summary or it was collected on a different workload size."""
     p = os.path.join(root, "profiles", "pmc_k_span_scan.json")
     try:
         with open(p) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
+            j = json.load(f)
+        if file_bytes is not None and int(j.get("file_bytes", -1)) != int(file_bytes):
+            return None
+        return j.get("hbm_bytes_per_launch")
     except Exception:
         return None
 
