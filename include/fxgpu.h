@@ -185,6 +185,16 @@ int fx_read_fetch(fx_handle *h, int where, int64_t n, const int64_t *soff, const
                   const int64_t *rlen, int phred, int seq_flags,
                   uint8_t *seq, uint8_t *qual, int8_t *quali, const int64_t *dst_off);
 
+/* ------------------------------------------------------------------ names
+ * Batched name -> record id, replacing one `SELECT ... WHERE chrom=? LIMIT 1` B-tree probe per name
+ * (pyfastx_index_get_seq_by_name, index.c:527-566; pyfastx_fastq_get_read_by_name, fastq.c:486-519) with an
+ * open-addressing table of record ids in HBM whose keys are the name bytes of the resident stream.
+ * kind: 0 = FASTA sequence names (first token, or the whole header after full_name), 1 = FASTQ read names.
+ * Query names are packed: bytes of query i = qbytes[qoff[i] .. qoff[i+1]); with FX_HOST the packed buffer must
+ * be readable 8 bytes past its end.  out_ids[i] = 0-based id of the first record with that name, -1 if none. */
+int fx_names_build(fx_handle *h, int kind);
+int fx_names_lookup(fx_handle *h, int where, int64_t nq, const uint8_t *qbytes, const int64_t *qoff, int64_t *out_ids);
+
 /* pyfastx.reverse_complement / reverse_seq / complement_seq on a caller buffer
  * (module.c:44-59; util.c:239-269).  mode: FX_REVERSE | FX_COMPLEMENT.        */
 int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mode);

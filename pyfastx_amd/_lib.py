@@ -43,7 +43,7 @@ SYMBOLS = [
     "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_host", "fx_open_device",
     "fx_set_shard", "fx_close", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
     "fx_fasta_build", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_comp", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
-    "fx_fetch_ranges", "fx_fasta_fetch", "fx_fastq_fetch", "fx_revcomp", "fx_shard_summary_get",
+    "fx_fetch_ranges", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_revcomp", "fx_shard_summary_get",
     "fx_fasta_set_row", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
 ]
 
@@ -95,6 +95,8 @@ def lib():
     L.fx_fetch_ranges.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, vp, vp]
     L.fx_fasta_fetch.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, vp, vp]
     L.fx_fastq_fetch.argtypes = [vp, i32, i64, vp, i32, i32, vp, vp, vp, vp]
+    L.fx_names_build.argtypes = [vp, i32]
+    L.fx_names_lookup.argtypes = [vp, i32, i64, vp, vp, vp]
     L.fx_revcomp.argtypes = [i32, i32, vp, i64, i32]
     L.fx_read_fetch.argtypes = [vp, i32, i64, vp, vp, vp, i32, i32, vp, vp, vp, vp]
     L.fx_shard_summary_get.argtypes = [vp, C.POINTER(ShardSummary)]
@@ -315,6 +317,22 @@ class Blob:
         meta = np.zeros(5, dtype=np.int64)
         check(lib().fx_fastq_comp(self._h, base.ctypes.data, meta.ctypes.data))
         return base, meta
+
+    # -- names ----------------------------------------------------------------
+    def names_build(self, kind):
+        """kind 0: FASTA sequence names, 1: FASTQ read names -> id table in HBM."""
+        check(lib().fx_names_build(self._h, int(kind)))
+
+    def names_lookup(self, names):
+        """list of str / bytes -> int64 ids (0-based, -1 when absent), one kernel launch."""
+        enc = [x if isinstance(x, bytes) else x.encode("utf-8", "surrogateescape") for x in names]
+        offs = np.zeros(len(enc) + 1, dtype=np.int64)
+        np.cumsum([len(x) for x in enc], out=offs[1:])
+        packed = np.frombuffer(b"".join(enc) + b"\0" * 16, dtype=np.uint8)
+        out = np.empty(len(enc), dtype=np.int64)
+        if enc:
+            check(lib().fx_names_lookup(self._h, FX_HOST, len(enc), _ptr(packed), _ptr(offs), _ptr(out)))
+        return out
 
     # -- fetch (host arrays) ------------------------------------------------
     @staticmethod

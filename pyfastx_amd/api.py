@@ -139,6 +139,7 @@ class Fasta:
             s = blob.fasta_build(self._full_name)
         except _lib.FxError as e:
             raise _fx_to_py(e)
+        self._scanned_here = True
         t = blob.fasta_table(s.n_seq)
         if self._key_func is None:
             names = self._gather(t["hoff"] + 1, t["name_len"])
@@ -384,11 +385,23 @@ class Fasta:
         stops = np.asarray(stops, dtype=np.int64)
         first = names_or_ids[0] if len(names_or_ids) else 0
         if isinstance(first, str):
-            ix = t["index"]
-            try:
-                ids = np.fromiter((ix[k] for k in names_or_ids), dtype=np.int64, count=len(names_or_ids))
-            except KeyError as e:
-                raise KeyError("%s does not exist in fasta file" % e.args[0])
+            ids = None
+            if getattr(self, "_scanned_here", False) and self._key_func is None:
+                try:                                          # name table in HBM (fx_names_lookup)
+                    if not getattr(self, "_names_ready", False):
+                        self._st.blob.names_build(0)
+                        self._names_ready = True
+                    ids = self._st.blob.names_lookup(names_or_ids)
+                    if (ids < 0).any():
+                        raise KeyError("%s does not exist in fasta file" % names_or_ids[int(np.nonzero(ids < 0)[0][0])])
+                except _lib.FxError:
+                    ids = None
+            if ids is None:
+                ix = t["index"]
+                try:
+                    ids = np.fromiter((ix[k] for k in names_or_ids), dtype=np.int64, count=len(names_or_ids))
+                except KeyError as e:
+                    raise KeyError("%s does not exist in fasta file" % e.args[0])
         else:
             ids = np.asarray(names_or_ids, dtype=np.int64)
             if ids.size and (ids.min() < 0 or ids.max() >= self._seq_counts):
@@ -800,16 +813,35 @@ class Fastq:
                 out.append(name)
         return out
 
-    def fetch_many(self, ids, want=("seq", "qual", "quali")):
-        """Batched extension: reads by 0-based id in one launch -> dict of buffers + offsets."""
-        ids = np.asarray(ids, dtype=np.int64)
+    def ids_of(self, names):
+        """Batched `fq[name].id - 1`: read names -> 0-based ids (-1 when absent) through the name table in HBM
+        (fx_names_lookup) instead of one SQLite probe per name (fastq.c:486-519)."""
+        blob = self._dev()
+        if not getattr(self, "_names_ready", False):
+            blob.names_build(1)
+            self._names_ready = True
+        return blob.names_lookup(names)
+
+    def _dev(self):
         blob = self._st.blob
         if not getattr(self, "_dev_table", False):
-            blob.fastq_build()
+            s = blob.fastq_build()
+            self._rlen_host = blob.fastq_table(s.n_reads)["rlen"]
             self._dev_table = True
-        q = "SELECT rlen FROM read WHERE ID=?"
-        rlen = np.array([self._db.execute(q, (int(i) + 1,)).fetchone()[0] for i in ids], dtype=np.int64)
-        seq, qual, qi, offs = blob.fastq_fetch(ids, rlen, phred=self._phred, want=want)
+        return blob
+
+    def fetch_many(self, ids_or_names, want=("seq", "qual", "quali")):
+        """Batched extension: reads by 0-based id (or by name) in one launch -> dict of buffers + offsets."""
+        blob = self._dev()
+        if len(ids_or_names) and isinstance(ids_or_names[0], str):
+            ids = self.ids_of(ids_or_names)
+            if (ids < 0).any():
+                raise KeyError("%s does not exist in fastq file" % ids_or_names[int(np.nonzero(ids < 0)[0][0])])
+        else:
+            ids = np.asarray(ids_or_names, dtype=np.int64)
+            if ids.size and (ids.min() < 0 or ids.max() >= self._rlen_host.size):
+                raise IndexError("index out of range")
+        seq, qual, qi, offs = blob.fastq_fetch(ids, self._rlen_host[ids], phred=self._phred, want=want)
         return {"seq": seq, "qual": qual, "quali": qi, "offsets": offs}
 
 

@@ -24,6 +24,7 @@
 #include "fx_kernels.hpp"
 #include "fx_spanscan.hpp"
 #include "fx_fastq.hpp"
+#include "fx_names.hpp"
 #include "fx_inflate.hpp"
 
 using namespace fx;
@@ -143,6 +144,11 @@ struct fx_handle {
     DevBuf<ChunkTot> chunks;
     DevBuf<unsigned long long> ctl;           // Totals (8 words) + list counter + shard summary
     Totals *pin_tot = nullptr;                // pinned host copy of Totals (async read-back without staging)
+    // name -> id table (fx_names.hpp)
+    DevBuf<uint32_t> nm_table;
+    DevBuf<int64_t> nm_off;                   // FASTA: hoff + 1 materialised; FASTQ uses fq_name_off directly
+    uint64_t nm_mask = 0;
+    int nm_kind = -1;                         // 0 FASTA, 1 FASTQ, -1 none
     DevBuf<int64_t> nl_prefix, hdr_prefix, prevnl;
     // FASTA table
     DevBuf<int64_t> hdr, fa_boff, fa_blen, fa_slen, fa_llen, fa_hdr_line;
@@ -221,6 +227,7 @@ extern "C" int fx_set_shard(fx_handle *h, int64_t base, int prev_byte, int is_la
     h->prev_byte = base == 0 ? '\n' : (prev_byte & 0xFF);
     h->is_last = is_last != 0;
     h->scanned = h->fasta_built = h->fastq_built = false;
+    h->nm_kind = -1;
     return FX_OK;
 }
 
@@ -1077,6 +1084,67 @@ extern "C" int fx_read_fetch(fx_handle *h, int where, int64_t n, const int64_t *
         if (seq) HIPCHK(hipMemcpyAsync(seq, d_seq, (size_t)total, hipMemcpyDeviceToHost, h->stream));
         if (qual) HIPCHK(hipMemcpyAsync(qual, d_qual, (size_t)total, hipMemcpyDeviceToHost, h->stream));
         if (quali) HIPCHK(hipMemcpyAsync(quali, d_qi, (size_t)total, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return FX_OK;
+}
+
+// ------------------------------------------------------------- names
+__global__ void k_add_i64(const int64_t *__restrict__ a, int64_t add, int64_t n, int64_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + add;
+}
+
+extern "C" int fx_names_build(fx_handle *h, int kind) {
+    if (!h || (kind != 0 && kind != 1)) return fail(FX_EINVAL, "bad argument");
+    if (kind == 0 ? !h->fasta_built : !h->fastq_built) return fail(FX_ESTATE, "the index has not been built");
+    if (kind == 0 && !h->hdr.p) return fail(FX_ESTATE, "names need a scanned index (fx_fasta_build), not an installed table");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const int64_t n = kind == 0 ? h->n_hdr : h->n_reads;
+    if (n >= 0xFFFFFFFFll) return fail(FX_ERANGE, "too many records for the 32-bit name table");
+    int64_t cap = 1024;
+    while (cap < 2 * n) cap <<= 1;
+    if ((rc = h->nm_table.alloc(cap))) return rc;
+    HIPCHK(hipMemsetAsync(h->nm_table.p, 0, (size_t)cap * 4, h->stream));
+    const int64_t *noff = h->fq_name_off.p;
+    const int32_t *nlen = h->fq_name_len.p;
+    if (kind == 0) {
+        if ((rc = h->nm_off.alloc(std::max<int64_t>(n, 1)))) return rc;
+        hipLaunchKernelGGL(k_add_i64, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, h->hdr.p, (int64_t)1, n, h->nm_off.p);
+        noff = h->nm_off.p; nlen = h->fa_name_len.p;
+    }
+    if (n) hipLaunchKernelGGL(k_names_build, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, h->d_data, h->base, noff, nlen, n,
+                              h->nm_table.p, (uint64_t)(cap - 1));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->nm_mask = (uint64_t)(cap - 1);
+    h->nm_kind = kind;
+    return FX_OK;
+}
+
+extern "C" int fx_names_lookup(fx_handle *h, int where, int64_t nq, const uint8_t *qbytes, const int64_t *qoff, int64_t *out_ids) {
+    if (!h || nq < 0 || (nq > 0 && (!qbytes || !qoff || !out_ids))) return fail(FX_EINVAL, "bad argument");
+    if (h->nm_kind < 0) return fail(FX_ESTATE, "fx_names_build has not run");
+    if (nq == 0) return FX_OK;
+    int rc = use_device(h);
+    if (rc) return rc;
+    Staged st(h);
+    const uint8_t *d_q = qbytes;
+    const int64_t *d_off = qoff;
+    int64_t *d_out = out_ids;
+    if (where == FX_HOST) {
+        const int64_t total = qoff[nq];
+        if ((rc = st.up(h, qbytes, std::max<int64_t>(total, 1) + 8, &d_q))) return rc;     // + 8: whole-word reads of the last key
+        if ((rc = st.up(h, qoff, nq + 1, &d_off)) || (rc = st.scratch<int64_t>(nq, &d_out))) return rc;
+    }
+    const int64_t *noff = h->nm_kind == 0 ? h->nm_off.p : h->fq_name_off.p;
+    const int32_t *nlen = h->nm_kind == 0 ? h->fa_name_len.p : h->fq_name_len.p;
+    hipLaunchKernelGGL(k_names_lookup, dim3(nblocks(nq, BLOCK)), dim3(BLOCK), 0, h->stream, h->d_data, h->base, noff, nlen,
+                       h->nm_table.p, h->nm_mask, d_q, d_off, nq, d_out);
+    HIPCHK(hipGetLastError());
+    if (where == FX_HOST) {
+        HIPCHK(hipMemcpyAsync(out_ids, d_out, (size_t)nq * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     return FX_OK;

@@ -235,3 +235,18 @@ def test_fetch_many_on_loaded_index(fx, files):
     for i, x in enumerate(f):
         want = x["antisense"] if i % 3 == 0 else x["seq"]
         assert buf[offs[i]:offs[i + 1]].tobytes().decode() == want
+
+
+def test_fastq_fetch_many_by_name(fx, files):
+    g = load_golden("fastq_fixture")["test.fq"]
+    fq = fx.Fastq(files["test.fq"])
+    reads = g["reads"][:40]
+    names = [fq[r["i"]].name for r in reads]
+    assert fq.ids_of(names + ["no such read"]).tolist() == [r["i"] for r in reads] + [-1]
+    out = fq.fetch_many(names)
+    offs = out["offsets"]
+    for j, r in enumerate(reads):
+        assert out["seq"][offs[j]:offs[j + 1]].tobytes().decode() == r["seq"]
+        assert out["qual"][offs[j]:offs[j + 1]].tobytes().decode() == r["qual"]
+    with pytest.raises(KeyError):
+        fq.fetch_many(["no such read"])

@@ -284,3 +284,37 @@ def test_fastq_random(oracle, L, seed):
             assert seq[offs[j]:offs[j + 1]].tobytes() == want, (seed, j)
             assert qual[offs[j]:offs[j + 1]].tobytes() == raw[qo:qo + n], (seed, j)
             assert qi[offs[j]:offs[j + 1]].tolist() == [q - 33 for q in raw[qo:qo + n]], (seed, j)
+
+
+def test_names_lookup(oracle, L):
+    """fx_names_build / fx_names_lookup: every name resolves to its record, absent names to -1, duplicate
+    names to the FIRST record (what `SELECT ... WHERE chrom=? LIMIT 1` returns, index.c:527-566)."""
+    rng = np.random.default_rng(3)
+    raw = fixture_bytes("test.fa")
+    b, s, t = fasta_rows(L.Blob, raw)
+    names = [raw[t["hoff"][i] + 1: t["hoff"][i] + 1 + t["name_len"][i]].decode() for i in range(s.n_seq)]
+    b.names_build(0)
+    perm = rng.permutation(s.n_seq)
+    got = b.names_lookup([names[i] for i in perm] + ["nope", "", names[0] + "x", names[5][:-1]])
+    assert got[:s.n_seq].tolist() == perm.tolist()
+    assert got[s.n_seq:].tolist() == [-1, -1, -1, -1]
+    # duplicates, empty names, names of very different lengths, full_name
+    raw = b">dup 1\nAC\n>x\nGT\n>dup 2\nTT\n>\nAA\n>" + b"L" * 300 + b" tail\nCC\n>dup\nGG\n"
+    b, s, t = fasta_rows(L.Blob, raw)
+    b.names_build(0)
+    assert b.names_lookup(["dup", "x", "", "L" * 300, "L" * 299, "dup 1"]).tolist() == [0, 1, 3, 4, -1, -1]
+    b, s, t = fasta_rows(L.Blob, raw, full_name=True)
+    b.names_build(0)
+    assert b.names_lookup(["dup 1", "dup 2", "dup", "L" * 300 + " tail"]).tolist() == [0, 2, 5, 4]
+    # FASTQ read names
+    raw = _rand_fastq(rng, 5000, 60, crlf=True, plus_name=True)
+    recs, size, ln = oracle.fastq_index(raw)
+    fq = L.Blob.from_bytes(raw)
+    sq = fq.fastq_build()
+    fq.names_build(1)
+    rn = [raw[int(recs["name_off"][i]): int(recs["name_off"][i]) + int(recs["name_len"][i])].decode() for i in range(sq.n_reads)]
+    first = {}
+    for i, nme in enumerate(rn):
+        first.setdefault(nme, i)
+    pick = rng.integers(0, sq.n_reads, 2000)
+    assert fq.names_lookup([rn[i] for i in pick]).tolist() == [first[rn[i]] for i in pick]
