@@ -768,10 +768,15 @@ __global__ __launch_bounds__(BLOCK) void k_fasta_finalize2(int64_t cap, FastaCol
 // llen is unknown here.  Because only `bad_line > 1` matters (index.c:237), the lead is summarised by
 // the same two-distinct-values set as a granule: merge of the lead granules' sets, the lines that
 // cross between them, and an exact walk of the part of the first header's granule before that header.
-__global__ __launch_bounds__(BLOCK) void k_shard_summary2(ScanCtx x, int is_last, const Totals *__restrict__ tot, int64_t cap,
-                                                         const int64_t *__restrict__ hdr, const int64_t *__restrict__ hdr_line,
-                                                         FastaCols c, int64_t *__restrict__ S) {
-    __shared__ DiffSet sets[BLOCK];
+constexpr int SUMM_BLOCK = 1024;       // the lead of a shard can be a whole chromosome (10^5 granules): many loads in flight
+__device__ __forceinline__ DiffSet diffset_shfl_xor(const DiffSet &d, int m) {
+    return DiffSet{(uint32_t)__shfl_xor((int)d.v1, m, 64), (uint32_t)__shfl_xor((int)d.c1, m, 64), (uint32_t)__shfl_xor((int)d.v2, m, 64),
+                   (uint32_t)__shfl_xor((int)d.c2, m, 64), (uint32_t)__shfl_xor((int)d.ovf, m, 64)};
+}
+__global__ __launch_bounds__(SUMM_BLOCK) void k_shard_summary2(ScanCtx x, int is_last, const Totals *__restrict__ tot, int64_t cap,
+                                                              const int64_t *__restrict__ hdr, const int64_t *__restrict__ hdr_line,
+                                                              FastaCols c, int64_t *__restrict__ S) {
+    __shared__ DiffSet sets[SUMM_BLOCK / 64];
     __shared__ unsigned long long ws;
     const int tid = threadIdx.x;
     if (tid == 0) ws = ~0ull;
@@ -782,39 +787,62 @@ __global__ __launch_bounds__(BLOCK) void k_shard_summary2(ScanCtx x, int is_last
     // whitespace in the bytes before the first newline (a header line cut by the shard boundary)
     int64_t lim = first_nl >= 0 ? first_nl - x.gbase : x.n;
     if (lim > 65536) lim = 65536;
-    for (int64_t j = tid; j < lim; j += BLOCK)
+    for (int64_t j = tid; j < lim; j += SUMM_BLOCK)
         if (x.data[j] == ' ' || x.data[j] == '\t') { atomicMin(&ws, (unsigned long long)j); break; }
-    // lead: whole granules before the first header's granule
+    // lead: whole granules before the first header's granule, four independent loads per thread per step
     const int64_t g_first = n_hdr ? (first_hdr - x.gbase) / GRAN : x.ngran;
     DiffSet ds;
     ds.clear();
-    for (int64_t g = tid; g < g_first; g += BLOCK) {
-        const GranOut o = gran_unpack(x.go[g]);
-        if (!o.n) continue;
-        ds.add(o.v1, o.c1); ds.add(o.v2, o.c2); ds.ovf |= o.ovf;
-        const int64_t pv = x.prevnl[g];
-        if (pv >= 0) ds.add((uint32_t)(x.gbase + g * (int64_t)GRAN + o.first - pv), 1);
+    for (int64_t g0 = tid; g0 < g_first; g0 += 4 * SUMM_BLOCK) {
+        GranPk pk[4];
+        int64_t pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t g = g0 + u * SUMM_BLOCK;
+            pk[u] = g < g_first ? x.go[g] : GranPk{0, 0, 0, 0};
+            pv[u] = g < g_first ? x.prevnl[g] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const GranOut o = gran_unpack(pk[u]);
+            if (!o.n) continue;
+            ds.add(o.v1, o.c1); ds.add(o.v2, o.c2); ds.ovf |= o.ovf;
+            if (pv[u] >= 0) ds.add((uint32_t)(x.gbase + (g0 + u * SUMM_BLOCK) * (int64_t)GRAN + o.first - pv[u]), 1);
+        }
     }
-    sets[tid] = ds;
+    // merge: butterfly inside the wave (the two-value set is a commutative, associative merge), then 16 wave results
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const DiffSet o = diffset_shfl_xor(ds, m);
+        ds.add(o.v1, o.c1); ds.add(o.v2, o.c2); ds.ovf |= o.ovf;
+    }
+    if ((tid & 63) == 0) sets[tid >> 6] = ds;
     __syncthreads();
     if (tid >= 64) return;
-    // wave 0: the part of granule g_first before the header, 64 bytes per lane
+    // wave 0: the part of granule g_first before the header, 64 bytes per lane (four 16-byte loads, newline masks)
     DiffSet mine;
     mine.clear();
     int64_t lf = -1, ll = -1;                              // first / last newline seen by this lane (global)
     if (n_hdr) {
         const int64_t a = g_first * (int64_t)GRAN + tid * 64, b = first_hdr - x.gbase;
-        for (int64_t p = a; p < a + 64 && p < b; ++p)
-            if (x.data[p] == '\n') {
-                const int64_t gp = x.gbase + p;
-                if (ll >= 0) mine.add((uint32_t)(gp - ll), 1);
-                if (lf < 0) lf = gp;
-                ll = gp;
-            }
+        unsigned long long m = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (a + i * CHUNK < b) m |= (unsigned long long)eq_mask16(load16(x.data, a + i * CHUNK, x.n), 0x0A0A0A0Au) << (16 * i);
+        if (b - a < 64) m &= (b - a <= 0) ? 0ull : (~0ull >> (64 - (b - a)));       // only bytes before the header
+        while (m) {
+            const int k = __ffsll(m) - 1;
+            m &= m - 1;
+            const int64_t gp = x.gbase + a + k;
+            if (ll >= 0) mine.add((uint32_t)(gp - ll), 1);
+            if (lf < 0) lf = gp;
+            ll = gp;
+        }
     }
     DiffSet all;
     all.clear();
-    if (tid == 0) for (int i = 0; i < BLOCK; ++i) { const DiffSet d = sets[i]; all.add(d.v1, d.c1); all.add(d.v2, d.c2); all.ovf |= d.ovf; }
+    if (tid == 0)
+        for (int i = 0; i < SUMM_BLOCK / 64; ++i) { const DiffSet d = sets[i]; all.add(d.v1, d.c1); all.add(d.v2, d.c2); all.ovf |= d.ovf; }
     int64_t carry = n_hdr ? x.prevnl[g_first] : -1;
     for (int l = 0; l < 64; ++l) {                         // lane order = position order
         const DiffSet d{(uint32_t)__shfl((int)mine.v1, l, 64), (uint32_t)__shfl((int)mine.c1, l, 64), (uint32_t)__shfl((int)mine.v2, l, 64),

@@ -1235,7 +1235,7 @@ static int shard_summary_launch(fx_handle *h, int64_t *d_out) {
     if (!h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build has not run");
     int rc = use_device(h);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_shard_summary2, dim3(1), dim3(BLOCK), 0, h->stream, scan_ctx(h), (int)h->is_last, ctl_totals(h),
+    hipLaunchKernelGGL(k_shard_summary2, dim3(1), dim3(SUMM_BLOCK), 0, h->stream, scan_ctx(h), (int)h->is_last, ctl_totals(h),
                        h->hdr.cap, h->hdr.p, h->fa_hdr_line.p, fasta_cols(h), d_out);
     HIPCHK(hipGetLastError());
     return FX_OK;

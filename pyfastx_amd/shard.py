@@ -157,7 +157,9 @@ class ShardedFasta:
 
     DELTA = 100_003
 
-    def __init__(self, piece, nbytes, dev, rank, world, full_name=False):
+    def __init__(self, piece, nbytes, dev, rank, world, full_name=False, logical=None):
+        """logical: None = one process per GPU (torch.distributed); else {"sizes": [...], "next_head": tensor or None}
+        -- the same shard built without a process group (G logical shards on one GPU)."""
         import torch
         import torch.distributed as dist
         from . import _lib
@@ -168,30 +170,34 @@ class ShardedFasta:
             self.buf, self.n_bytes, self.base, prev, last = piece, nbytes, 0, 10, True
         else:
             d = self.DELTA
-            # collectives run on the GPU tensors with RCCL ("nccl"); with gloo (tests) on host copies
-            cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
-            self.comm_dev = cdev
-            mine = torch.tensor([nbytes], dtype=torch.int64, device=cdev)
-            outs = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(outs, mine)
-            sizes = np.array([int(o.item()) for o in outs], dtype=np.int64)
-            head = piece[:d].to(cdev).clone()
-            tail_c = torch.empty(d, dtype=torch.uint8, device=cdev)
-            ops = []
-            if rank > 0:
-                ops.append(dist.P2POp(dist.isend, head, rank - 1))
-            if rank < world - 1:
-                ops.append(dist.P2POp(dist.irecv, tail_c, rank + 1))
-            for w in dist.batch_isend_irecv(ops) if ops else []:
-                w.wait()
-            tail_in = tail_c.to(dev)
+            if logical is not None:
+                sizes = np.asarray(logical["sizes"], dtype=np.int64)
+                tail_in = logical["next_head"]
+            else:
+                # collectives run on the GPU tensors with RCCL ("nccl"); with gloo (tests) on host copies
+                cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+                self.comm_dev = cdev
+                mine = torch.tensor([nbytes], dtype=torch.int64, device=cdev)
+                outs = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(outs, mine)
+                sizes = np.array([int(o.item()) for o in outs], dtype=np.int64)
+                head = piece[:d].to(cdev).clone()
+                tail_c = torch.empty(d, dtype=torch.uint8, device=cdev)
+                ops = []
+                if rank > 0:
+                    ops.append(dist.P2POp(dist.isend, head, rank - 1))
+                if rank < world - 1:
+                    ops.append(dist.P2POp(dist.irecv, tail_c, rank + 1))
+                for w in dist.batch_isend_irecv(ops) if ops else []:
+                    w.wait()
+                tail_in = tail_c.to(dev)
             lo = d if rank > 0 else 0
             hi_extra = d if rank < world - 1 else 0
             n = nbytes - lo + hi_extra
             buf = torch.zeros(n + 131072, dtype=torch.uint8, device=dev)
             buf[:nbytes - lo] = piece[lo:nbytes]
             if hi_extra:
-                buf[nbytes - lo:n] = tail_in
+                buf[nbytes - lo:n] = tail_in[:d]
             prev = int(piece[lo - 1]) if lo else 10
             self.buf, self.n_bytes = buf, n
             self.base = int(sizes[:rank].sum()) + lo
@@ -204,26 +210,44 @@ class ShardedFasta:
         self.n_local = 0
         self._ext = self._mine = self._all = None
 
-    def build(self):
+    def _dev_buffers(self):
+        torch = self._torch
+        if self._ext is None:
+            self._ext = torch.cuda.ExternalStream(self.blob.stream, device=self.dev)
+            self._mine = torch.zeros(NWORDS, dtype=torch.int64, device=self.dev)
+            self._all = torch.zeros(self.world * NWORDS, dtype=torch.int64, device=self.dev)
+
+    def build_begin(self):
+        """Local scan + tables + this shard's boundary summary into the send buffer (device, enqueued)."""
         s = self.blob.fasta_build(self.full_name)
         self.n_local = s.n_seq
+        if self.world > 1:
+            self._dev_buffers()
+            self.blob.shard_summary_dev(self._mine.data_ptr())
+        return s
+
+    def build_end(self):
+        """After self._all holds every shard's summary: finish the record that crosses the cut (enqueued)."""
+        if self.world > 1:
+            self.blob.fasta_stitch_dev(self._all.data_ptr(), self.world, self.rank, self.full_name)
+
+    def build(self):
         if self.world == 1:
+            s = self.blob.fasta_build(self.full_name)
+            self.n_local = s.n_seq
             return s
         if self.comm_dev.type == "cuda":
             # device-resident exchange: summary kernel -> RCCL all-gather -> stitch kernel, ordered with
             # stream events only (the library's stream is wrapped as a torch ExternalStream)
-            torch = self._torch
-            if self._ext is None:
-                self._ext = torch.cuda.ExternalStream(self.blob.stream, device=self.dev)
-                self._mine = torch.zeros(NWORDS, dtype=torch.int64, device=self.dev)
-                self._all = torch.zeros(self.world * NWORDS, dtype=torch.int64, device=self.dev)
-            cur = torch.cuda.current_stream(self.dev)
-            self.blob.shard_summary_dev(self._mine.data_ptr())
+            s = self.build_begin()
+            cur = self._torch.cuda.current_stream(self.dev)
             cur.wait_stream(self._ext)
             self._dist.all_gather_into_tensor(self._all, self._mine)          # the ONE collective (RCCL over xGMI)
             self._ext.wait_stream(cur)
-            self.blob.fasta_stitch_dev(self._all.data_ptr(), self.world, self.rank, self.full_name)
+            self.build_end()
             return s
+        s = self.blob.fasta_build(self.full_name)
+        self.n_local = s.n_seq
         self.S = allgather_summaries(self.blob.shard_summary(), self.world, self.comm_dev)   # gloo (CPU tests): host path
         row = stitch_tail(self.S, self.rank, self.full_name)
         if row is not None:
