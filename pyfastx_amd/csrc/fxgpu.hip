@@ -78,10 +78,10 @@ template <class T> struct DevBuf {      // grow-only device array: rebuilds reus
 // Optional per-kernel HIP-event timing on the handle's own stream (bench.py's
 // roofline leg reads it; off by default so the hot path records no events).
 enum KernelId { K_SPAN_SCAN = 0, K_GRAN_REDUCE, K_GRAN_PREFIX, K_HDR_REC, K_GRAN_LINES, K_GRAN_EXACT, K_FASTA_FINALIZE, K_FETCH,
-                K_FASTA_COMP, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_NKERN };
+                K_FASTA_COMP, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_NKERN };
 static const char *const kKernelNames[K_NKERN] = {
     "k_span_scan", "k_gran_reduce", "k_gran_prefix", "k_hdr_rec", "k_gran_lines", "k_gran_exact", "k_fasta_finalize", "k_fetch",
-    "k_fasta_comp", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_inflate"};
+    "k_fasta_comp", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy"};
 
 struct Prof {
     bool on = false;
@@ -370,17 +370,28 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize, const BgzfTable &t,
     DevBuf<int64_t> d_coff, d_uoff;
     DevBuf<int32_t> d_clen, d_isize, d_status;
     int rc;
-    if ((rc = d_c.alloc(fsize + 16))) return rc;
+    if ((rc = d_c.alloc(fsize + 40))) return rc;          // the bit reader looks two 8-byte words ahead
+    HIPCHK(hipMemsetAsync(d_c.p + fsize, 0, 40, h->stream));
     if ((rc = stage_plain_file(h, fd, fsize, path, d_c.p))) return rc;
     if ((rc = upload(h, d_coff, t.coff)) || (rc = upload(h, d_uoff, t.uoff)) || (rc = upload(h, d_clen, t.clen)) ||
         (rc = upload(h, d_isize, t.isize)))
         return rc;
     const int64_t nmem = (int64_t)t.moff.size();
+    // match tokens: a match is >= 3 bytes, so member m needs at most isize / 3 + 1 slots
+    std::vector<int64_t> toff((size_t)nmem + 1, 0);
+    for (int64_t m = 0; m < nmem; ++m) toff[(size_t)m + 1] = toff[(size_t)m] + t.isize[(size_t)m] / 3 + 1;
+    DevBuf<uint64_t> d_tok;
+    DevBuf<int64_t> d_toff;
+    DevBuf<int32_t> d_ntok;
+    if ((rc = d_tok.alloc(toff[(size_t)nmem])) || (rc = upload(h, d_toff, toff)) || (rc = d_ntok.alloc(nmem))) return rc;
     if ((rc = d_status.alloc(nmem))) return rc;
     HIPCHK(hipMemsetAsync(d_status.p, 0xFF, (size_t)nmem * 4, h->stream));
+    HIPCHK(hipMemsetAsync(d_ntok.p, 0, (size_t)nmem * 4, h->stream));
     if ((rc = alloc_blob(h, t.total))) return rc;
-    FX_LAUNCH(h, K_BGZF_INFLATE, k_bgzf_inflate, dim3(nblocks(nmem, INFL_BLOCK)), dim3(INFL_BLOCK), d_c.p, d_coff.p,
-              d_clen.p, d_uoff.p, d_isize.p, nmem, h->d_data, d_status.p);
+    FX_LAUNCH(h, K_BGZF_INFLATE, k_bgzf_decode, dim3(nblocks(nmem, INFL_BLOCK)), dim3(INFL_BLOCK), d_c.p, d_coff.p,
+              d_clen.p, d_uoff.p, d_isize.p, nmem, h->d_data, d_status.p, d_tok.p, d_toff.p, d_ntok.p);
+    FX_LAUNCH(h, K_BGZF_COPY, k_bgzf_copy, dim3(nblocks(nmem, COPY_BLOCK / 64)), dim3(COPY_BLOCK), d_uoff.p, nmem, h->d_data,
+              d_tok.p, d_toff.p, d_ntok.p);
     HIPCHK(hipGetLastError());
     std::vector<int32_t> status((size_t)nmem);
     HIPCHK(hipMemcpyAsync(status.data(), d_status.p, (size_t)nmem * 4, hipMemcpyDeviceToHost, h->stream));
