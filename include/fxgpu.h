@@ -101,6 +101,14 @@ typedef struct {
  * full_name: chrom = whole header (index.c:282-285) instead of first token. */
 int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out);
 
+/* The same in two halves: _begin ENQUEUES the whole build on the handle's stream and returns; _end waits for it and
+ * reports the totals.  Device-side consumers -- fx_fasta_fetch with FX_DEVICE arrays, fx_shard_summary_dev,
+ * fx_fasta_stitch_dev -- may be enqueued between the two (they read the record count from device memory), so a
+ * "build, then answer a batch" step costs one host synchronisation.  Calls that need host-side totals
+ * (fx_fasta_table, fx_fasta_comp, ...) complete a pending build themselves. */
+int fx_fasta_build_begin(fx_handle *h, int full_name);
+int fx_fasta_build_end(fx_handle *h, fx_fasta_summary *out);
+
 /* Copy the SoA record table to caller arrays (any pointer may be NULL).
  * Columns are exactly the .fxi `seq` columns (index.c:178-189) plus the
  * header-line offset and the name span inside the stream. */

@@ -42,7 +42,7 @@ class ShardSummary(C.Structure):
 SYMBOLS = [
     "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_host", "fx_open_device",
     "fx_set_shard", "fx_close", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
-    "fx_fasta_build", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_comp", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
+    "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_comp", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_revcomp", "fx_shard_summary_get",
     "fx_fasta_set_row", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
 ]
@@ -83,6 +83,8 @@ def lib():
     L.fx_read_bytes.argtypes = [vp, i64, i64, vp]
     L.fx_first_byte.argtypes = [vp, C.POINTER(i32)]
     L.fx_fasta_build.argtypes = [vp, i32, C.POINTER(FastaSummary)]
+    L.fx_fasta_build_begin.argtypes = [vp, i32]
+    L.fx_fasta_build_end.argtypes = [vp, C.POINTER(FastaSummary)]
     L.fx_fasta_table.argtypes = [vp, i32] + [vp] * 9
     L.fx_fasta_set_table.argtypes = [vp, i64] + [vp] * 6
     L.fx_fasta_comp.argtypes = [vp, i32, vp]
@@ -266,6 +268,16 @@ class Blob:
         b = [np.ascontiguousarray(x, dtype=np.int32) for x in (elen, norm)]
         check(lib().fx_fasta_set_table(self._h, a[0].size, *[_ptr(x) for x in a + b]))
         self._table_ready = True
+
+    def fasta_build_begin(self, full_name=False):
+        """Enqueue the build and return (no host synchronisation); see fasta_build_end."""
+        self._table_ready = True
+        check(lib().fx_fasta_build_begin(self._h, int(bool(full_name))))
+
+    def fasta_build_end(self):
+        s = FastaSummary()
+        check(lib().fx_fasta_build_end(self._h, C.byref(s)))
+        return s
 
     def fasta_build(self, full_name=False):
         self._table_ready = True

@@ -135,7 +135,12 @@ struct FetchQ {
     const int64_t *dst_off;
     int64_t *out_len;
 };
-struct FastaTab { const int64_t *boff, *blen, *slen, *llen; const int32_t *elen, *norm; int64_t n_seq; };
+struct FastaTab {
+    const int64_t *boff, *blen, *slen, *llen;
+    const int32_t *elen, *norm;
+    int64_t n_seq;                   // records in the table -- or its capacity while a build is still in flight ...
+    const long long *n_seq_dev;      // ... in which case the count is read here (device memory), null otherwise
+};
 
 __device__ __forceinline__ void build_comp_lut(uint8_t *lut) {
     // IUPAC complement (util.c:204-237): A<->T C<->G M<->K R<->Y V<->B H<->D, U->A, case kept,
@@ -217,10 +222,11 @@ __global__ __launch_bounds__(BLOCK) void k_fetch(const uint8_t *__restrict__ dat
     constexpr int TABCAP = BY_ID ? 512 : 1;
     __shared__ int64_t s_boff[TABCAP], s_slen[TABCAP], s_blen[TABCAP];
     __shared__ int32_t s_llen[TABCAP], s_en[TABCAP];           // s_en = elen | norm << 8
-    const bool tab_lds = BY_ID && tab.n_seq <= TABCAP && tab.n_seq > 0;
+    const int64_t n_seq = (BY_ID && tab.n_seq_dev) ? (*tab.n_seq_dev < tab.n_seq ? (int64_t)*tab.n_seq_dev : tab.n_seq) : tab.n_seq;
+    const bool tab_lds = BY_ID && n_seq <= TABCAP && n_seq > 0;
     build_comp_lut(lut);
     if (tab_lds)
-        for (int r = threadIdx.x; r < (int)tab.n_seq; r += BLOCK) {
+        for (int r = threadIdx.x; r < (int)n_seq; r += BLOCK) {
             s_boff[r] = tab.boff[r]; s_slen[r] = tab.slen[r]; s_blen[r] = tab.blen[r];
             const int64_t ll = tab.llen[r];
             s_llen[r] = ll > 0x7FFFFFFFll ? 0x7FFFFFFF : (int32_t)ll;
@@ -256,13 +262,13 @@ __global__ __launch_bounds__(BLOCK) void k_fetch(const uint8_t *__restrict__ dat
             if (BY_ID) {
                 const int64_t id = c_a0, a = c_a1, b = c_a2;
                 int64_t r_slen = 0, r_blen = 0;
-                if (id >= 0 && id < tab.n_seq) {
+                if (id >= 0 && id < n_seq) {
                     if (tab_lds) { r_boff = s_boff[id]; r_slen = s_slen[id]; r_blen = s_blen[id]; r_el = s_en[id] & 0xFF; r_norm = (s_en[id] >> 8) != 0;
                                    r_bpl = (int64_t)s_llen[id] - r_el; if (s_llen[id] == 0x7FFFFFFF) r_bpl = tab.llen[id] - r_el; }
                     else         { r_boff = tab.boff[id]; r_slen = tab.slen[id]; r_blen = tab.blen[id]; r_el = tab.elen[id]; r_norm = tab.norm[id] != 0;
                                    r_bpl = tab.llen[id] - r_el; }
                 }
-                if (id < 0 || id >= tab.n_seq || a < 0 || b < a || b > r_slen) {   // caller validates; stay safe
+                if (id < 0 || id >= n_seq || a < 0 || b < a || b > r_slen) {   // caller validates; stay safe
                     if (sub == 0 && q.out_len) q.out_len[i] = -1;
                     ok = false;
                 } else {

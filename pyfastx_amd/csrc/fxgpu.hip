@@ -156,6 +156,8 @@ struct fx_handle {
     DevBuf<uint32_t> fa_bad;
     int64_t n_hdr = 0, fa_seqlen = 0;
     bool fasta_built = false;
+    bool build_pending = false;               // fx_fasta_build_begin enqueued, totals not read back yet
+    int pending_full_name = 0;
     // FASTQ table
     DevBuf<int64_t> fq_name_off, fq_rlen, fq_soff, fq_qoff;
     DevBuf<int32_t> fq_name_len, fq_dlen, fq_qlen;
@@ -223,6 +225,7 @@ extern "C" const void *fx_device_ptr(const fx_handle *h) { return h ? h->d_data 
 
 extern "C" int fx_set_shard(fx_handle *h, int64_t base, int prev_byte, int is_last) {
     if (!h) return fail(FX_EINVAL, "null handle");
+    if (h->build_pending) { (void)hipStreamSynchronize(h->stream); h->build_pending = false; }
     h->base = base;
     h->prev_byte = base == 0 ? '\n' : (prev_byte & 0xFF);
     h->is_last = is_last != 0;
@@ -622,48 +625,80 @@ static int granule_pass(fx_handle *h) {
     return FX_OK;
 }
 
-extern "C" int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out) {
+// records: everything after the granule pass, for the current table capacity (enqueue only)
+static int enqueue_records(fx_handle *h, int full_name) {
+    const ScanCtx x = scan_ctx(h);
+    const int64_t cap = h->hdr.cap, ngran = h->ngran;
+    const FastaCols c = fasta_cols(h);
+    const RecView rv{h->fa_boff.p, h->fa_llen.p, h->fa_dlen.p, h->fa_bad.p, h->hdr.p};
+    const GranList hgl{h->hdr_grans.p, ctl_counter(h, 0)}, irr{h->irr_grans.p, ctl_counter(h, 1)};
+    FX_LAUNCH(h, K_HDR_REC, k_hdr_rec, dim3(512), dim3(BLOCK), x, h->prev_byte, (int)h->is_last, full_name, hgl, c, cap);
+    FX_LAUNCH(h, K_GRAN_LINES, k_gran_lines, dim3(nblocks(ngran, BLOCK)), dim3(BLOCK), x, rv, cap, irr);
+    FX_LAUNCH(h, K_GRAN_EXACT, k_gran_exact, dim3(512), dim3(BLOCK), x, rv, cap, irr, (int)h->is_last);
+    FX_LAUNCH(h, K_FASTA_FINALIZE, k_fasta_finalize2, dim3(nblocks(cap, BLOCK)), dim3(BLOCK), cap, c, ctl_totals(h));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h->pin_tot, ctl_totals(h), sizeof(Totals), hipMemcpyDeviceToHost, h->stream));
+    return FX_OK;
+}
+
+// Enqueue the whole build on the handle's stream and return: granule pass, prefixes, records.  The tables are
+// sized from an estimate (previous build, else 4096 records), so nothing here needs a host round trip; device-side
+// consumers (fx_fasta_fetch, fx_shard_summary_dev, fx_fasta_stitch_dev) may be enqueued right behind it -- they read
+// the record count from device memory.  fx_fasta_build_end (or any call that needs host-side totals) completes it.
+extern "C" int fx_fasta_build_begin(fx_handle *h, int full_name) {
     if (!h) return fail(FX_EINVAL, "null handle");
     int rc = use_device(h);
     if (rc) return rc;
     if (h->n <= 0) return fail(FX_EFORMAT, "empty input");
     h->scanned = false;
-    // ---- the one pass over the stream: 4 KiB granule summaries and their prefixes (fx_spanscan.hpp)
-    if ((rc = granule_pass<0>(h))) return rc;
-    const int64_t ngran = h->ngran;
+    h->nm_kind = -1;
+    if ((rc = granule_pass<0>(h))) return rc;      // the one pass over the stream: granule summaries + prefixes
     if (h->hdr.cap < 4096 && (rc = alloc_fasta_table(h, 4096))) return rc;
-    GranList hgl{h->hdr_grans.p, ctl_counter(h, 0)};
-    // ---- records.  The tables are sized from an estimate (previous build, else 4096 records) so that
-    // everything is enqueued without a host round trip; if more header lines turn up, grow and redo
-    // only this cheap part.
-    const ScanCtx x = scan_ctx(h);
+    if ((rc = enqueue_records(h, full_name))) return rc;
+    h->build_pending = true;
+    h->pending_full_name = full_name;
+    h->fasta_built = true;
+    return FX_OK;
+}
+
+// Wait for a pending build and read its totals; if more header lines turned up than the tables hold, grow them
+// and redo only the (cheap) record part.
+static int finish_build(fx_handle *h) {
+    if (!h->build_pending) return FX_OK;
+    int rc = use_device(h);
+    if (rc) return rc;
     Totals tot;
     for (;;) {
-        const int64_t cap = h->hdr.cap;
-        const FastaCols c = fasta_cols(h);
-        const RecView rv{h->fa_boff.p, h->fa_llen.p, h->fa_dlen.p, h->fa_bad.p, h->hdr.p};
-        const GranList irr{h->irr_grans.p, ctl_counter(h, 1)};
-        FX_LAUNCH(h, K_HDR_REC, k_hdr_rec, dim3(512), dim3(BLOCK), x, h->prev_byte, (int)h->is_last, full_name, hgl, c, cap);
-        FX_LAUNCH(h, K_GRAN_LINES, k_gran_lines, dim3(nblocks(ngran, BLOCK)), dim3(BLOCK), x, rv, cap, irr);
-        FX_LAUNCH(h, K_GRAN_EXACT, k_gran_exact, dim3(512), dim3(BLOCK), x, rv, cap, irr, (int)h->is_last);
-        FX_LAUNCH(h, K_FASTA_FINALIZE, k_fasta_finalize2, dim3(nblocks(cap, BLOCK)), dim3(BLOCK), cap, c, ctl_totals(h));
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(h->pin_tot, ctl_totals(h), sizeof tot, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         tot = *h->pin_tot;
-        if (tot.n_hdr <= cap) break;
+        if (tot.n_hdr <= h->hdr.cap) break;
         if ((rc = alloc_fasta_table(h, tot.n_hdr + tot.n_hdr / 16 + 16))) return rc;
         HIPCHK(hipMemsetAsync(&ctl_totals(h)->seq_len, 0, 8, h->stream));
         HIPCHK(hipMemsetAsync(ctl_counter(h, 1), 0, 4, h->stream));                   // the irregular list is rebuilt
+        if ((rc = enqueue_records(h, h->pending_full_name))) return rc;
     }
+    h->build_pending = false;
     h->n_hdr = tot.n_hdr;
     h->n_nl = tot.n_nl;
     h->fa_seqlen = tot.seq_len;
-    h->fasta_built = true;
     if (tot.n_hdr <= 0 && h->base == 0 && h->is_last) { h->fasta_built = false; return fail(FX_EFORMAT, "no FASTA header line ('>') found"); }
     // (a shard that lies entirely inside one record has an empty local table; its summary is still valid)
+    return FX_OK;
+}
+
+extern "C" int fx_fasta_build_end(fx_handle *h, fx_fasta_summary *out) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    if (!h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build_begin has not run");
+    int rc = finish_build(h);
+    if (rc) return rc;
     if (out) { out->n_seq = h->n_hdr; out->seq_len = h->fa_seqlen; out->n_lines = h->n_nl; out->n_bytes = h->n; }
     return FX_OK;
+}
+
+extern "C" int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out) {
+    int rc = fx_fasta_build_begin(h, full_name);
+    if (rc) return rc;
+    return fx_fasta_build_end(h, out);
 }
 
 // The resident record table from an existing .fxi (pyfastx_load_index, index.c:391-429): batched fetches by
@@ -698,6 +733,7 @@ extern "C" int fx_fasta_table(fx_handle *h, int where, int64_t *hoff, int64_t *b
     if (!h) return fail(FX_EINVAL, "null handle");
     if (!h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build has not run");
     int rc = use_device(h);
+    if (!rc) rc = finish_build(h);
     if (rc) return rc;
     const int64_t n = h->n_hdr;
     if ((rc = copy_out(h, where, hoff, h->hdr.p, n)) || (rc = copy_out(h, where, boff, h->fa_boff.p, n)) ||
@@ -717,6 +753,7 @@ extern "C" int fx_fasta_comp(fx_handle *h, int where, int64_t *comp) {
     if (!h || !comp) return fail(FX_EINVAL, "null argument");
     if (!h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build has not run");
     int rc = use_device(h);
+    if (!rc) rc = finish_build(h);
     if (rc) return rc;
     const int64_t n = h->n_hdr * 128;
     DevBuf<unsigned long long> tmp;
@@ -961,6 +998,7 @@ static int fetch_common(fx_handle *h, int where, int64_t n, bool by_id, const in
     if (h->fasta_built) {
         tab.boff = h->fa_boff.p; tab.blen = h->fa_blen.p; tab.slen = h->fa_slen.p; tab.llen = h->fa_llen.p;
         tab.elen = h->fa_elen.p; tab.norm = h->fa_norm.p; tab.n_seq = h->n_hdr;
+        if (h->build_pending) { tab.n_seq_dev = (const long long *)&ctl_totals(h)->n_hdr; tab.n_seq = h->hdr.cap; }
     }
     // lanes per query: 16 (128-byte window, 4 queries per wave) for short random access,
     // 64 (1 KiB window) when the caller says the ranges are long (FX_LONG) or host arrays show it
@@ -1111,6 +1149,7 @@ extern "C" int fx_names_build(fx_handle *h, int kind) {
     if (kind == 0 ? !h->fasta_built : !h->fastq_built) return fail(FX_ESTATE, "the index has not been built");
     if (kind == 0 && !h->hdr.p) return fail(FX_ESTATE, "names need a scanned index (fx_fasta_build), not an installed table");
     int rc = use_device(h);
+    if (!rc) rc = finish_build(h);
     if (rc) return rc;
     const int64_t n = kind == 0 ? h->n_hdr : h->n_reads;
     if (n >= 0xFFFFFFFFll) return fail(FX_ERANGE, "too many records for the 32-bit name table");
@@ -1271,6 +1310,7 @@ extern "C" int fx_fasta_stitch_dev(fx_handle *h, const int64_t *d_all, int world
     if (!h || !d_all || world < 1 || rank < 0 || rank >= world) return fail(FX_EINVAL, "bad argument");
     if (!h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build has not run");
     int rc = use_device(h);
+    if (!rc) rc = finish_build(h);
     if (rc) return rc;
     hipLaunchKernelGGL(k_stitch_tail, dim3(1), dim3(1), 0, h->stream, d_all, world, rank, full_name, fasta_cols(h), h->hdr.cap,
                        (int *)(h->ctl.p + 60));
@@ -1284,9 +1324,10 @@ extern "C" int fx_fasta_set_row(fx_handle *h, int64_t k, int64_t boff, int64_t b
                                 int32_t elen, int32_t norm, int32_t dlen, int32_t name_len) {
     if (!h) return fail(FX_EINVAL, "null handle");
     if (!h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build has not run");
-    if (k < 0 || k >= h->n_hdr) return fail(FX_ERANGE, "row %lld out of range", (long long)k);
     int rc = use_device(h);
+    if (!rc) rc = finish_build(h);
     if (rc) return rc;
+    if (k < 0 || k >= h->n_hdr) return fail(FX_ERANGE, "row %lld out of range", (long long)k);
     hipLaunchKernelGGL(k_set_row, dim3(1), dim3(1), 0, h->stream, fasta_cols(h), k, boff, blen, slen, llen, elen, norm, dlen, name_len);
     HIPCHK(hipGetLastError());
     return FX_OK;

@@ -218,34 +218,40 @@ class ShardedFasta:
             self._all = torch.zeros(self.world * NWORDS, dtype=torch.int64, device=self.dev)
 
     def build_begin(self):
-        """Local scan + tables + this shard's boundary summary into the send buffer (device, enqueued)."""
-        s = self.blob.fasta_build(self.full_name)
-        self.n_local = s.n_seq
+        """Enqueue: local scan + tables (+ this shard's boundary summary into the send buffer).  No host sync."""
+        self.blob.fasta_build_begin(self.full_name)
         if self.world > 1:
             self._dev_buffers()
             self.blob.shard_summary_dev(self._mine.data_ptr())
-        return s
 
     def build_end(self):
-        """After self._all holds every shard's summary: finish the record that crosses the cut (enqueued)."""
+        """Enqueue, after self._all holds every shard's summary: finish the record that crosses the cut."""
         if self.world > 1:
             self.blob.fasta_stitch_dev(self._all.data_ptr(), self.world, self.rank, self.full_name)
 
-    def build(self):
-        if self.world == 1:
-            s = self.blob.fasta_build(self.full_name)
-            self.n_local = s.n_seq
-            return s
-        if self.comm_dev.type == "cuda":
-            # device-resident exchange: summary kernel -> RCCL all-gather -> stitch kernel, ordered with
-            # stream events only (the library's stream is wrapped as a torch ExternalStream)
-            s = self.build_begin()
+    def build_async(self):
+        """The whole sharded build enqueued on the device -- scan, summary kernel, RCCL all-gather, stitch kernel,
+        ordered with stream events only -- so that device-side consumers (fetch_local) can follow without a host
+        round trip; finish() is the one synchronisation.  (gloo, i.e. the CPU tests: the host path, synchronous.)"""
+        if self.world > 1 and self.comm_dev.type != "cuda":
+            return self.build()
+        self.build_begin()
+        if self.world > 1:
             cur = self._torch.cuda.current_stream(self.dev)
             cur.wait_stream(self._ext)
             self._dist.all_gather_into_tensor(self._all, self._mine)          # the ONE collective (RCCL over xGMI)
             self._ext.wait_stream(cur)
             self.build_end()
-            return s
+
+    def finish(self):
+        s = self.blob.fasta_build_end()
+        self.n_local = s.n_seq
+        return s
+
+    def build(self):
+        if self.world == 1 or self.comm_dev.type == "cuda":
+            self.build_async()
+            return self.finish()
         s = self.blob.fasta_build(self.full_name)
         self.n_local = s.n_seq
         self.S = allgather_summaries(self.blob.shard_summary(), self.world, self.comm_dev)   # gloo (CPU tests): host path
