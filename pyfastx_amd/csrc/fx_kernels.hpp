@@ -53,13 +53,16 @@ __device__ __forceinline__ uint4 load16(const uint8_t *__restrict__ data, int64_
 // ------------------------------------------------------------- wave / block
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// inclusive prefix sum over the 64 lanes with DPP row shifts / broadcasts: six v_add_u32_dpp instead of six
+// ds_bpermute round trips (row_shr:1,2,4,8 inside each row of 16, row_bcast:15 into rows 1 and 3, row_bcast:31
+// into rows 2 and 3 -- the GFX9 scan sequence)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    const int l = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (l >= d) v += t;
-    }
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
     return v;
 }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
