@@ -37,9 +37,6 @@ __device__ __forceinline__ uint32_t eq_mask16(const uint4 &v, uint32_t pat) {
     hi = __builtin_amdgcn_udot4(zero_bytes(v.w ^ pat), 0x80402010u, hi, false);
     return (lo >> 7) | (hi << 1);
 }
-__device__ __forceinline__ uint32_t any_eq16(const uint4 &v, uint32_t pat) {
-    return zero_bytes(v.x ^ pat) | zero_bytes(v.y ^ pat) | zero_bytes(v.z ^ pat) | zero_bytes(v.w ^ pat);
-}
 
 // 16 bytes at data[p..p+16); bytes at or beyond n read as 0 (never '\n' or '>').
 __device__ __forceinline__ uint4 load16(const uint8_t *__restrict__ data, int64_t p, int64_t n) {
@@ -75,19 +72,6 @@ __device__ __forceinline__ int64_t wave_sum64(int64_t v) {
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
     return v;
 }
-// exclusive prefix of v over the 256 threads of the block (thread order); *total = block sum.
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *lds4, uint32_t *total) {
-    const int w = threadIdx.x >> 6, l = lane_id();
-    uint32_t inc = wave_incl_scan(v);
-    __syncthreads();                       // protect lds4 reuse across calls
-    if (l == 63) lds4[w] = inc;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < BLOCK / 64; ++i) { uint32_t s = lds4[i]; if (i < w) base += s; tot += s; }
-    *total = tot;
-    return base + inc - v;
-}
 __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *lds4) {
     const int w = threadIdx.x >> 6, l = lane_id();
     v = wave_sum(v);
@@ -97,12 +81,6 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *lds4) {
     return lds4[0] + lds4[1] + lds4[2] + lds4[3];
 }
 
-// first index i in [0,n) with a[i] >= key  (n if none)
-__device__ __forceinline__ int64_t lower_bound(const int64_t *__restrict__ a, int64_t n, int64_t key) {
-    int64_t lo = 0, hi = n;
-    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
-    return lo;
-}
 // first index i in [0,n) with a[i] > key  (n if none)
 __device__ __forceinline__ int64_t upper_bound(const int64_t *__restrict__ a, int64_t n, int64_t key) {
     int64_t lo = 0, hi = n;

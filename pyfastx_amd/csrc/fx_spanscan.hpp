@@ -78,7 +78,6 @@ struct DiffSet {                // first two distinct values with counts (+ over
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, int lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(lane));
 }
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // wave-uniform DiffSet fed by per-lane distances
 struct WaveDiff : DiffSet {
