@@ -13,5 +13,5 @@ rm -rf $OUT/prof
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o pmc -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-verify > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
 done
-python tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE "k_span_scan<true>" 3050025703 $OUT/pmc_k_span_scan.json | head -20
+python tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE "k_span_scan<0>" 3050025703 $OUT/pmc_k_span_scan.json | head -20
 find $OUT -name '*.csv' -size +5M -delete
