@@ -276,7 +276,7 @@ __global__ __launch_bounds__(1024) void k_span_scan(const uint8_t *__restrict__ 
 //                   load per thread up to 4 GiB of stream), then a local 32-bit scan; the last one writes Totals.
 // nl_prefix[g] / hdr_prefix[g] = newlines / header lines before granule g (entry [ngran] = totals),
 // prevnl[g] = global offset of the last newline before granule g (-1: none in this shard).
-constexpr int CHUNK_GRANS = 1024;
+constexpr int CHUNK_GRANS = 1024;        // largest chunk (thread-block size bound of the prefix kernels)
 struct ChunkTot { long long n, h, last, pad; };
 struct Totals {                       // device-side scalars of one build, copied to the host once at the end
     long long n_nl, n_hdr, last_nl, seq_len, pad0, pad1, pad2, pad3;
@@ -320,18 +320,21 @@ __device__ __forceinline__ Tri gran_tri(const GranPk *__restrict__ go, int64_t g
     return Tri{(long long)o.n, (long long)o.h, o.n ? gbase + g * (long long)GRAN + o.last : -1};
 }
 
-template <int MODE>
-__global__ __launch_bounds__(CHUNK_GRANS) void k_gran_reduce(const uint8_t *__restrict__ data, int64_t n, int prev_byte,
-                                                            int is_last, GranList hgl, GranPk *__restrict__ go,
-                                                            int64_t ngran, int64_t gbase, ChunkTot *__restrict__ ct) {
-    __shared__ Tri lds[CHUNK_GRANS / 64];
+// CG = granules per chunk = threads per workgroup: 256 up to 8 GB of stream (more, smaller workgroups hide the
+// latency of these tiny kernels better), 1024 beyond (k_gran_prefix sums the totals of all earlier chunks in
+// every workgroup: work ~ nchunks^2 / CG)
+template <int MODE, int CG>
+__global__ __launch_bounds__(CG) void k_gran_reduce(const uint8_t *__restrict__ data, int64_t n, int prev_byte,
+                                                   int is_last, GranList hgl, GranPk *__restrict__ go,
+                                                   int64_t ngran, int64_t gbase, ChunkTot *__restrict__ ct) {
+    __shared__ Tri lds[CG / 64];
     if (blockIdx.x == gridDim.x - 1) {          // the tail granule (index ngran - 1) belongs to the last chunk
         if (threadIdx.x < 64) { uint32_t L = 0; granule<false, MODE>(data, n, prev_byte, is_last, ngran - 1, go, hgl, L); }
         __threadfence_block();
         __syncthreads();
     }
     Tri tot;
-    tri_block_incl(gran_tri(go, (int64_t)blockIdx.x * CHUNK_GRANS + threadIdx.x, ngran, gbase), lds, &tot);
+    tri_block_incl(gran_tri(go, (int64_t)blockIdx.x * CG + threadIdx.x, ngran, gbase), lds, &tot);
     if (threadIdx.x == 0) ct[blockIdx.x] = ChunkTot{tot.n, tot.h, tot.last, 0};
 }
 
@@ -359,20 +362,21 @@ __device__ __forceinline__ Tri32 tri32_block_incl(Tri32 v, uint32_t (*lds)[16], 
     return Tri32{base.n + v.n, base.h + v.h, base.last > v.last ? base.last : v.last};
 }
 
-__global__ __launch_bounds__(CHUNK_GRANS) void k_gran_prefix(const GranPk *__restrict__ go, int64_t ngran, int64_t gbase,
+template <int CG>
+__global__ __launch_bounds__(CG) void k_gran_prefix(const GranPk *__restrict__ go, int64_t ngran, int64_t gbase,
                                                             const ChunkTot *__restrict__ ct, Totals *__restrict__ tot,
                                                             int64_t *__restrict__ nl_prefix, int64_t *__restrict__ hdr_prefix,
                                                             int64_t *__restrict__ prevnl) {
-    __shared__ Tri lds[CHUNK_GRANS / 64];
+    __shared__ Tri lds[CG / 64];
     __shared__ uint32_t lds32[3][16];
     // base: join of the totals of the chunks before this one (a ticketed "last workgroup scans the totals"
     // variant inside k_gran_reduce was measured slower: 47 us for the pair instead of 31)
     Tri b{0, 0, -1};
-    for (int64_t c = threadIdx.x; c < (int64_t)blockIdx.x; c += CHUNK_GRANS) { const ChunkTot t = ct[c]; b = tri_join(b, Tri{t.n, t.h, t.last}); }
+    for (int64_t c = threadIdx.x; c < (int64_t)blockIdx.x; c += CG) { const ChunkTot t = ct[c]; b = tri_join(b, Tri{t.n, t.h, t.last}); }
     Tri base{0, 0, -1};
     if (blockIdx.x) tri_block_incl(b, lds, &base);         // workgroup-uniform branch
     // local scan in 32 bits: counts of one chunk are < 2^23, offsets relative to the chunk start < 2^22
-    const int64_t g = (int64_t)blockIdx.x * CHUNK_GRANS + threadIdx.x;
+    const int64_t g = (int64_t)blockIdx.x * CG + threadIdx.x;
     Tri32 v{0, 0, -1};
     if (g < ngran) {
         const GranOut o = gran_unpack(go[g]);
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(CHUNK_GRANS) void k_gran_prefix(const GranPk *__res
     }
     Tri32 total;
     const Tri32 inc = tri32_block_incl(v, lds32, &total);
-    const int64_t cstart = gbase + (int64_t)blockIdx.x * CHUNK_GRANS * GRAN;
+    const int64_t cstart = gbase + (int64_t)blockIdx.x * CG * GRAN;
     if (g < ngran) {
         nl_prefix[g] = base.n + (inc.n - v.n);
         hdr_prefix[g] = base.h + (inc.h - v.h);

@@ -603,7 +603,9 @@ static uint32_t *ctl_counter(fx_handle *h, int i) { return (uint32_t *)(h->ctl.p
 template <int MODE>
 static int granule_pass(fx_handle *h) {
     int rc;
-    const int64_t nfull = h->n / GRAN, ngran = nfull + 1, nchunks = (ngran + CHUNK_GRANS - 1) / CHUNK_GRANS;
+    const int64_t nfull = h->n / GRAN, ngran = nfull + 1;
+    const bool small = ngran <= (2ll << 20);                  // up to 8 GB of stream: 256 granules per chunk, else 1024
+    const int64_t cg = small ? 256 : 1024, nchunks = (ngran + cg - 1) / cg;
     h->ngran = ngran;
     if ((rc = h->gran.alloc(ngran)) || (rc = h->hdr_grans.alloc(ngran)) || (MODE == 0 && (rc = h->irr_grans.alloc(ngran))) ||
         (rc = h->chunks.alloc(nchunks)) ||
@@ -617,10 +619,17 @@ static int granule_pass(fx_handle *h) {
     if (nfull > 0)
         FX_LAUNCH(h, K_SPAN_SCAN, (k_span_scan<MODE>), dim3(nblocks(nfull * 64, SCAN_WG)), dim3(SCAN_WG), h->d_data, h->n,
                   h->prev_byte, (int)h->is_last, nfull, h->gran.p, hgl);
-    FX_LAUNCH(h, K_GRAN_REDUCE, (k_gran_reduce<MODE>), dim3((unsigned)nchunks), dim3(CHUNK_GRANS), h->d_data, h->n, h->prev_byte,
-              (int)h->is_last, hgl, h->gran.p, ngran, h->base, h->chunks.p);
-    FX_LAUNCH(h, K_GRAN_PREFIX, k_gran_prefix, dim3((unsigned)nchunks), dim3(CHUNK_GRANS), h->gran.p, ngran, h->base,
-              h->chunks.p, ctl_totals(h), h->nl_prefix.p, h->hdr_prefix.p, h->prevnl.p);
+    if (small) {
+        FX_LAUNCH(h, K_GRAN_REDUCE, (k_gran_reduce<MODE, 256>), dim3((unsigned)nchunks), dim3(256), h->d_data, h->n, h->prev_byte,
+                  (int)h->is_last, hgl, h->gran.p, ngran, h->base, h->chunks.p);
+        FX_LAUNCH(h, K_GRAN_PREFIX, (k_gran_prefix<256>), dim3((unsigned)nchunks), dim3(256), h->gran.p, ngran, h->base,
+                  h->chunks.p, ctl_totals(h), h->nl_prefix.p, h->hdr_prefix.p, h->prevnl.p);
+    } else {
+        FX_LAUNCH(h, K_GRAN_REDUCE, (k_gran_reduce<MODE, 1024>), dim3((unsigned)nchunks), dim3(1024), h->d_data, h->n, h->prev_byte,
+                  (int)h->is_last, hgl, h->gran.p, ngran, h->base, h->chunks.p);
+        FX_LAUNCH(h, K_GRAN_PREFIX, (k_gran_prefix<1024>), dim3((unsigned)nchunks), dim3(1024), h->gran.p, ngran, h->base,
+                  h->chunks.p, ctl_totals(h), h->nl_prefix.p, h->hdr_prefix.p, h->prevnl.p);
+    }
     HIPCHK(hipGetLastError());
     return FX_OK;
 }

@@ -72,8 +72,8 @@ int check(const std::vector<uint8_t> &hb) {
     CK(hipMemset(tot, 0, sizeof(Totals)));
     CK(hipMalloc((void **)&dpn, (ngran + 1) * 8)); CK(hipMalloc((void **)&dph, (ngran + 1) * 8)); CK(hipMalloc((void **)&dpv, (ngran + 1) * 8));
     hipLaunchKernelGGL(k_span_scan<0>, dim3((unsigned)((n / GRAN * 64 + 511) / 512)), dim3(512), 0, 0, d, n, (int)'\n', 1, n / GRAN, go, gl);
-    hipLaunchKernelGGL(k_gran_reduce<0>, dim3((unsigned)nchunks), dim3(CHUNK_GRANS), 0, 0, d, n, (int)'\n', 1, gl, go, ngran, (int64_t)1000, ct);
-    hipLaunchKernelGGL(k_gran_prefix, dim3((unsigned)nchunks), dim3(CHUNK_GRANS), 0, 0, go, ngran, (int64_t)1000, ct, tot, dpn, dph, dpv);
+    hipLaunchKernelGGL((k_gran_reduce<0, CHUNK_GRANS>), dim3((unsigned)nchunks), dim3(CHUNK_GRANS), 0, 0, d, n, (int)'\n', 1, gl, go, ngran, (int64_t)1000, ct);
+    hipLaunchKernelGGL(k_gran_prefix<CHUNK_GRANS>, dim3((unsigned)nchunks), dim3(CHUNK_GRANS), 0, 0, go, ngran, (int64_t)1000, ct, tot, dpn, dph, dpv);
     CK(hipDeviceSynchronize());
     std::vector<GranPk> hp(ngran);
     CK(hipMemcpy(hp.data(), go, (size_t)ngran * sizeof(GranPk), hipMemcpyDeviceToHost));
