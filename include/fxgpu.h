@@ -203,6 +203,14 @@ int fx_read_fetch(fx_handle *h, int where, int64_t n, const int64_t *soff, const
 int fx_names_build(fx_handle *h, int kind);
 int fx_names_lookup(fx_handle *h, int where, int64_t nq, const uint8_t *qbytes, const int64_t *qoff, int64_t *out_ids);
 
+/* Sorted order of the record names for the UNIQUE INDEX of the .fxi -- what `CREATE UNIQUE INDEX chromidx ON seq
+ * (chrom)` (index.c:363) / `readidx ON read (name)` (fastq.c:152) sort on the CPU after the inserts.  order[i]
+ * (n records, `where` = FX_HOST / FX_DEVICE) = 0-based id of the i-th smallest name in SQLite's BINARY collation
+ * (memcmp, the shorter name first on a common prefix); equal names keep id order.  *n_dup (host) = number of
+ * adjacent equal pairs: 0 means the names are distinct and fx_fxi_bulk_index may write the index from `order`;
+ * otherwise the reference's CREATE UNIQUE INDEX fails (and is ignored), so no index is written.  kind as above. */
+int fx_names_sort(fx_handle *h, int kind, int where, int64_t *order, int64_t *n_dup);
+
 /* pyfastx.reverse_complement / reverse_seq / complement_seq on a caller buffer
  * (module.c:44-59; util.c:239-269).  mode: FX_REVERSE | FX_COMPLEMENT.        */
 int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mode);
@@ -217,6 +225,25 @@ int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mode);
  * Non-BGZF inputs report 0 points.                                            */
 int fx_gz_points(fx_handle *h, int64_t spacing, int64_t *cmp_off, int64_t *uncmp_off, int64_t cap,
                  int64_t *n_out, int64_t *compressed_size);
+
+/* ------------------------------------------------------------ .fxi bulk load
+ * Host-side.  Replaces the per-record `sqlite3_step(INSERT)` of index.c:239-251 / fastq.c:136-149 for the one big
+ * table of an index file: rows arrive in rowid order, so the table b-tree (leaf pages left to right, a few interior
+ * pages on top) is written straight into the database file that SQLite created.  `path`: a database with the
+ * schema in place and NO open connection; `rootpage`: sqlite_master.rootpage of the (empty) table; rows i = 0..n-1
+ * get rowid i+1 and are (NULL [the INTEGER PRIMARY KEY], names[name_off[i] .. name_off[i+1]) as TEXT, cols[0][i], ...
+ * cols[ncols-1][i] as INTEGER).  FX_ERANGE: some row needs an overflow page -- use INSERTs instead.  The UNIQUE
+ * INDEX is created by SQLite afterwards. */
+int fx_fxi_bulk_rows(const char *path, int rootpage, int64_t n, const uint8_t *names, const int64_t *name_off,
+                     int ncols, const int64_t *const *cols);
+
+/* The UNIQUE INDEX on the name column (index.c:363 `CREATE UNIQUE INDEX chromidx`, fastq.c:152 `readidx`) loaded the
+ * same way: `rootpage` of the (empty) index; names / name_off as given to fx_fxi_bulk_rows; order[i] = 0-based row of
+ * the i-th smallest name (memcmp order, the shorter first on a common prefix = SQLite's BINARY collation;
+ * fx_names_sort produces it on the GPU and reports whether the names are distinct -- only then may this be used).
+ * FX_ERANGE: an entry would need an overflow page -- let SQLite build the index. */
+int fx_fxi_bulk_index(const char *path, int rootpage, int64_t n, const uint8_t *names, const int64_t *name_off,
+                      const int64_t *order);
 
 /* ------------------------------------------------------- sync and timing
  * Calls that take FX_DEVICE arrays return after ENQUEUEING work on the

@@ -43,13 +43,36 @@ SYMBOLS = [
     "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_host", "fx_open_device",
     "fx_set_shard", "fx_close", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
     "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_comp", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
-    "fx_fetch_ranges", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_revcomp", "fx_shard_summary_get",
-    "fx_fasta_set_row", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
+    "fx_fetch_ranges", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_revcomp", "fx_shard_summary_get",
+    "fx_fasta_set_row", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
 ]
 
 
 def so_path():
     return _SO
+
+
+def fxi_bulk_rows(path, rootpage, packed_names, name_off, cols):
+    """Host-side bulk load of an index table (fx_fxi_bulk_rows): packed_names uint8, name_off int64[n+1],
+    cols: list of int64 arrays.  The database file must have no open connection."""
+    names = np.ascontiguousarray(packed_names, dtype=np.uint8)
+    offs = np.ascontiguousarray(name_off, dtype=np.int64)
+    arrs = [np.ascontiguousarray(c, dtype=np.int64) for c in cols]
+    ptrs = (C.c_void_p * max(len(arrs), 1))(*[a.ctypes.data for a in arrs])
+    check(lib().fx_fxi_bulk_rows(os.fsencode(path), int(rootpage), offs.size - 1, names.ctypes.data if names.size else None,
+                                 offs.ctypes.data, len(arrs), ptrs))
+
+
+def fxi_bulk_index(path, rootpage, packed_names, name_off, order):
+    """Host-side bulk load of the UNIQUE INDEX on the name column (fx_fxi_bulk_index): names in row order,
+    order[i] = row of the i-th smallest name."""
+    names = np.ascontiguousarray(packed_names, dtype=np.uint8)
+    offs = np.ascontiguousarray(name_off, dtype=np.int64)
+    order = np.ascontiguousarray(order, dtype=np.int64)
+    if order.size != offs.size - 1:
+        raise ValueError("order must have one entry per row")
+    check(lib().fx_fxi_bulk_index(os.fsencode(path), int(rootpage), offs.size - 1, names.ctypes.data if names.size else None,
+                                  offs.ctypes.data, order.ctypes.data if order.size else None))
 
 
 def lib():
@@ -108,6 +131,9 @@ def lib():
     L.fx_stream.restype = vp
     L.fx_stream.argtypes = [vp]
     L.fx_gz_points.argtypes = [vp, i64, vp, vp, i64, C.POINTER(i64), C.POINTER(i64)]
+    L.fx_names_sort.argtypes = [vp, i32, i32, vp, C.POINTER(i64)]
+    L.fx_fxi_bulk_rows.argtypes = [C.c_char_p, i32, i64, vp, vp, i32, vp]
+    L.fx_fxi_bulk_index.argtypes = [C.c_char_p, i32, i64, vp, vp, vp]
     L.fx_sync.argtypes = [vp]
     L.fx_prof_enable.argtypes = [vp, i32]
     L.fx_prof_default.argtypes = [i32]
@@ -345,6 +371,14 @@ class Blob:
         if enc:
             check(lib().fx_names_lookup(self._h, FX_HOST, len(enc), _ptr(packed), _ptr(offs), _ptr(out)))
         return out
+
+    def names_sort(self, kind, n):
+        """-> (order int64[n], n_dup): sorted order of the n record names (BINARY collation) computed on the GPU."""
+        n = int(n)
+        order = np.empty(n, dtype=np.int64)
+        ndup = C.c_int64(0)
+        check(lib().fx_names_sort(self._h, int(kind), FX_HOST, _ptr(order) if n else None, C.byref(ndup)))
+        return order, int(ndup.value)
 
     # -- fetch (host arrays) ------------------------------------------------
     @staticmethod

@@ -89,6 +89,24 @@ class _Staged:
 
 
 # =========================================================================== FASTA
+def _bulk_index(path, blob, kind, n, name_off, name_len, write):
+    """The bulk route to a NEW .fxi (fxi._bulk_table): the names come off the GPU as one packed buffer (one gather),
+    their sorted order from Blob.names_sort, and both b-trees are written as pages instead of n INSERTs + a CPU
+    sort.  -> open connection, or None when this route does not apply (an existing file, an in-memory index, a
+    record too large for a page) and the caller writes the index with INSERTs."""
+    if path == ":memory:" or os.path.exists(path):
+        return None
+    ln = np.maximum(np.asarray(name_len, dtype=np.int64), 0)
+    packed, offs, _ = blob.fetch_ranges(name_off, ln, ln, flags=_F_RAW)
+    order, ndup = blob.names_sort(kind, n)
+    try:
+        return write(path, packed[:int(offs[-1])], offs, None if ndup else order)
+    except _lib.FxError as e:
+        if e.code != _lib.FX_ERANGE:
+            raise
+        return None
+
+
 class Fasta:
     """pyfastx.Fasta (fasta.c:39-135, 1156-1210)."""
 
@@ -141,13 +159,18 @@ class Fasta:
             raise _fx_to_py(e)
         self._scanned_here = True
         t = blob.fasta_table(s.n_seq)
-        if self._key_func is None:
-            names = self._gather(t["hoff"] + 1, t["name_len"])
-        else:        # index.c:303-318: key_func(header text after '>'), '\r' of a CRLF header included
-            hl = t["dlen"].astype(np.int64) + (t["elen"] == 2)
-            names = [self._key_func(h) for h in self._gather(t["hoff"] + 1, hl)]
-        self._db = fxi.connect(self._index_file)
-        fxi.write_fasta(self._db, names, t, s.seq_len)
+        self._db = None
+        if self._key_func is None and s.n_seq:
+            self._db = _bulk_index(self._index_file, blob, 0, s.n_seq, t["hoff"] + 1, t["name_len"],
+                                   lambda p, names, offs, order: fxi.write_fasta_bulk(p, names, offs, t, s.seq_len, order))
+        if self._db is None:
+            if self._key_func is None:
+                names = self._gather(t["hoff"] + 1, t["name_len"])
+            else:    # index.c:303-318: key_func(header text after '>'), '\r' of a CRLF header included
+                hl = t["dlen"].astype(np.int64) + (t["elen"] == 2)
+                names = [self._key_func(h) for h in self._gather(t["hoff"] + 1, hl)]
+            self._db = fxi.connect(self._index_file)
+            fxi.write_fasta(self._db, names, t, s.seq_len)
         if self.is_gzip:
             c, u, _ = blob.gz_points()
             fxi.write_gzindex(self._db, os.path.getsize(self.file_name), blob.size, c, u)
@@ -671,17 +694,22 @@ class Fastq:
         except _lib.FxError as e:
             raise _fx_to_py(e)
         t = blob.fastq_table(s.n_reads)
-        names = []
-        step = 1 << 20
-        for a in range(0, s.n_reads, step):
-            b = min(s.n_reads, a + step)
-            ln = t["name_len"][a:b].astype(np.int64)
-            buf, offs, _ = blob.fetch_ranges(t["name_off"][a:b], ln, ln, flags=_F_RAW)
-            raw = buf.tobytes()
-            o = offs.tolist()
-            names.extend(raw[o[i]:o[i + 1]].decode("latin-1") for i in range(b - a))
-        self._db = fxi.connect(self._index_file)
-        fxi.write_fastq(self._db, names, t, s.size)
+        self._db = None
+        if s.n_reads:
+            self._db = _bulk_index(self._index_file, blob, 1, s.n_reads, t["name_off"], t["name_len"],
+                                   lambda p, names, offs, order: fxi.write_fastq_bulk(p, names, offs, t, s.size, order))
+        if self._db is None:
+            names = []
+            step = 1 << 20
+            for a in range(0, s.n_reads, step):
+                b = min(s.n_reads, a + step)
+                ln = t["name_len"][a:b].astype(np.int64)
+                buf, offs, _ = blob.fetch_ranges(t["name_off"][a:b], ln, ln, flags=_F_RAW)
+                raw = buf.tobytes()
+                o = offs.tolist()
+                names.extend(raw[o[i]:o[i + 1]].decode("latin-1") for i in range(b - a))
+            self._db = fxi.connect(self._index_file)
+            fxi.write_fastq(self._db, names, t, s.size)
         if self.is_gzip:
             c, u, _ = blob.gz_points()
             fxi.write_gzindex(self._db, os.path.getsize(self.file_name), blob.size, c, u)

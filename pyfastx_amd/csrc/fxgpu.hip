@@ -26,6 +26,8 @@
 #include "fx_fastq.hpp"
 #include "fx_names.hpp"
 #include "fx_inflate.hpp"
+#include "fx_fxi.hpp"
+#include "fx_sort.hpp"
 
 using namespace fx;
 
@@ -1209,6 +1211,38 @@ extern "C" int fx_names_lookup(fx_handle *h, int where, int64_t nq, const uint8_
     return FX_OK;
 }
 
+extern "C" int fx_names_sort(fx_handle *h, int kind, int where, int64_t *order, int64_t *n_dup) {
+    if (!h || (kind != 0 && kind != 1) || !n_dup) return fail(FX_EINVAL, "bad argument");
+    if (kind == 0 ? !h->fasta_built : !h->fastq_built) return fail(FX_ESTATE, "the index has not been built");
+    if (kind == 0 && !h->hdr.p) return fail(FX_ESTATE, "names need a scanned index (fx_fasta_build), not an installed table");
+    int rc = use_device(h);
+    if (!rc) rc = finish_build(h);
+    if (rc) return rc;
+    const int64_t n = kind == 0 ? h->n_hdr : h->n_reads;
+    *n_dup = 0;
+    if (n == 0) return FX_OK;
+    if (!order) return fail(FX_EINVAL, "null order");
+    if (n >= 0xFFFFFFFFll) return fail(FX_ERANGE, "too many records for the 32-bit sort index");
+    const int64_t *noff = h->fq_name_off.p;
+    const int32_t *nlen = h->fq_name_len.p;
+    if (kind == 0) {
+        if ((rc = h->nm_off.alloc(n))) return rc;
+        hipLaunchKernelGGL(k_add_i64, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, h->hdr.p, (int64_t)1, n, h->nm_off.p);
+        noff = h->nm_off.p; nlen = h->fa_name_len.p;
+    }
+    Staged st(h);
+    int64_t *d_order = order, *d_ndup = nullptr;
+    if (where == FX_HOST && (rc = st.scratch<int64_t>(n, &d_order))) return rc;
+    if ((rc = st.scratch<int64_t>(1, &d_ndup))) return rc;
+    const char *what = "";
+    const int e = sort_names(h->d_data, h->base, noff, nlen, n, d_order, d_ndup, h->stream, &what);
+    if (e) return fail(e == (int)hipErrorOutOfMemory ? FX_ENOMEM : FX_EDEVICE, "name sort, %s: %s", what, hipGetErrorString((hipError_t)e));
+    HIPCHK(hipMemcpyAsync(n_dup, d_ndup, 8, hipMemcpyDeviceToHost, h->stream));
+    if (where == FX_HOST) HIPCHK(hipMemcpyAsync(order, d_order, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FX_OK;
+}
+
 extern "C" int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mode) {
     if (!buf && n) return fail(FX_EINVAL, "null buffer");
     if (n <= 0) return FX_OK;
@@ -1339,5 +1373,28 @@ extern "C" int fx_fasta_set_row(fx_handle *h, int64_t k, int64_t boff, int64_t b
     if (k < 0 || k >= h->n_hdr) return fail(FX_ERANGE, "row %lld out of range", (long long)k);
     hipLaunchKernelGGL(k_set_row, dim3(1), dim3(1), 0, h->stream, fasta_cols(h), k, boff, blen, slen, llen, elen, norm, dlen, name_len);
     HIPCHK(hipGetLastError());
+    return FX_OK;
+}
+
+// ------------------------------------------------------------- .fxi bulk load (host side)
+extern "C" int fx_fxi_bulk_rows(const char *path, int rootpage, int64_t n, const uint8_t *names, const int64_t *name_off,
+                                int ncols, const int64_t *const *cols) {
+    if (!path || n < 0 || (n > 0 && (!names || !name_off || (ncols > 0 && !cols)))) return fail(FX_EINVAL, "bad argument");
+    const fxi::Rows r{n, names, name_off, ncols, cols};
+    const int rc = fxi::bulk_load_table(path, (uint32_t)rootpage, r);
+    if (rc == fxi::E_ROW) return fail(FX_ERANGE, "a row does not fit a b-tree page without overflow: use the INSERT path");
+    if (rc == fxi::E_IO) return fail(FX_EIO, "cannot write %s", path);
+    if (rc) return fail(FX_EINVAL, "%s is not a SQLite database this loader can extend", path);
+    return FX_OK;
+}
+
+extern "C" int fx_fxi_bulk_index(const char *path, int rootpage, int64_t n, const uint8_t *names, const int64_t *name_off,
+                                 const int64_t *order) {
+    if (!path || n < 0 || (n > 0 && (!names || !name_off || !order))) return fail(FX_EINVAL, "bad argument");
+    const fxi::Entries e{n, names, name_off, order};
+    const int rc = fxi::bulk_load_index(path, (uint32_t)rootpage, e);
+    if (rc == fxi::E_ROW) return fail(FX_ERANGE, "an index entry does not fit a b-tree page without overflow: use CREATE INDEX");
+    if (rc == fxi::E_IO) return fail(FX_EIO, "cannot write %s", path);
+    if (rc) return fail(FX_EINVAL, "%s is not a SQLite database this loader can extend", path);
     return FX_OK;
 }

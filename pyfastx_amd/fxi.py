@@ -139,6 +139,68 @@ def write_fastq(db, names, cols, size):
     db.execute("INSERT INTO stat VALUES (?,?,?)", (n, int(size), avg))
 
 
+def _bulk_table(path, ddl, table, index_sql, index_name, packed_names, name_off, col_list, order, threads):
+    """A NEW index file without one INSERT per record: SQLite creates the file and the schema, fx_fxi_bulk_rows
+    writes the b-tree of `table` straight into it (rows arrive in rowid order) and, when `order` (the sorted order
+    of distinct names, Blob.names_sort) is given, fx_fxi_bulk_index writes the UNIQUE INDEX b-tree the same way.
+    Without `order` SQLite builds the index; a failure on duplicate names is ignored as in index.c:363-366 /
+    fastq.c:152-156.  Names are stored as the raw bytes of the file, like sqlite3_bind_text in the reference.
+    Returns an open connection.  FX_ERANGE (a row needs an overflow page): the file is removed and the error
+    re-raised -- the caller falls back to the INSERT path."""
+    from . import _lib
+    db = connect(path)
+    db.executescript(ddl)
+    if order is not None:
+        db.execute(index_sql)
+    root = dict(db.execute("SELECT name, rootpage FROM sqlite_master").fetchall())
+    db.close()
+    try:
+        _lib.fxi_bulk_rows(path, root[table], packed_names, name_off, col_list)
+    except _lib.FxError as e:
+        if e.code == _lib.FX_ERANGE:
+            os.remove(path)
+        raise
+    reindex = False
+    if order is not None:
+        try:
+            _lib.fxi_bulk_index(path, root[index_name], packed_names, name_off, order)
+        except _lib.FxError as e:                             # a name too long for an in-page index entry
+            if e.code != _lib.FX_ERANGE:
+                raise
+            reindex = True
+    db = connect(path)
+    db.execute("PRAGMA synchronous = OFF")
+    if reindex or order is None:
+        db.execute("PRAGMA threads = %d" % int(threads))      # sorter threads of CREATE INDEX / REINDEX
+    if reindex:
+        db.execute("REINDEX %s" % index_name)                 # SQLite fills the (still empty) index from the table
+    if order is None:
+        try:
+            db.execute(index_sql)
+        except sqlite3.Error:
+            pass
+    return db
+
+
+def write_fastq_bulk(path, packed_names, name_off, cols, size, order=None, threads=8):
+    """The result of write_fastq (fastq.c:76-171) through _bulk_table.  packed_names uint8 + name_off int64[n+1]:
+    the read names back to back; cols as for write_fastq."""
+    db = _bulk_table(path, FASTQ_DDL, "read", "CREATE UNIQUE INDEX readidx ON read (name)", "readidx", packed_names, name_off,
+                     [cols["dlen"], cols["rlen"], cols["soff"], cols["qoff"]], order, threads)
+    n = len(name_off) - 1
+    avg = size * 1.0 / n if n else float("nan")              # fastq.c:161
+    db.execute("INSERT INTO stat VALUES (?,?,?)", (n, int(size), avg))
+    return db
+
+
+def write_fasta_bulk(path, packed_names, name_off, cols, seqlen_total, order=None, threads=8):
+    """The result of write_fasta (index.c:226-251, 342-372) through _bulk_table."""
+    db = _bulk_table(path, FASTA_DDL, "seq", "CREATE UNIQUE INDEX chromidx ON seq (chrom)", "chromidx", packed_names, name_off,
+                     [cols[k] for k in ("boff", "blen", "slen", "llen", "elen", "norm", "dlen")], order, threads)
+    db.execute("INSERT INTO stat (seqnum,seqlen) VALUES (?,?)", (len(name_off) - 1, int(seqlen_total)))
+    return db
+
+
 def write_fastq_comp(db, base, meta):
     """fastq.c:755-790 (meta column order: maxlen, minlen, minqs, maxqs, phred)."""
     db.execute("INSERT INTO base VALUES (?,?,?,?,?)", tuple(int(x) for x in base))

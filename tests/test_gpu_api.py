@@ -250,3 +250,66 @@ def test_fastq_fetch_many_by_name(fx, files):
         assert out["qual"][offs[j]:offs[j + 1]].tobytes().decode() == r["qual"]
     with pytest.raises(KeyError):
         fq.fetch_many(["no such read"])
+
+
+def _idx(path):
+    db = sqlite3.connect(path)
+    ok = db.execute("PRAGMA integrity_check").fetchall()
+    idx = sorted(r[0] for r in db.execute("SELECT name FROM sqlite_master WHERE type='index'"))
+    db.close()
+    return ok, idx
+
+
+def test_bulk_written_index_is_sound(fx, files, tmp_path):
+    """A new .fxi is written as b-tree pages (fx_fxi_bulk_rows / fx_names_sort / fx_fxi_bulk_index): SQLite's own
+    integrity_check (page structure, index entries vs rows, ordering, uniqueness) accepts it, by-name access goes
+    through the index, later INSERTs (composition) land on it, and the special cases fall back as the reference does."""
+    import numpy as np
+    g = load_golden("fasta_fixture")["test.fa"]
+    fa = fx.Fasta(files["test.fa"], full_index=True)        # comp rows INSERTed on top of the bulk-written file
+    assert _idx(files["test.fa"] + ".fxi") == ([("ok",)], ["chromidx", "seqidx"])
+    db = sqlite3.connect(files["test.fa"] + ".fxi")
+    plan = db.execute("EXPLAIN QUERY PLAN SELECT * FROM seq WHERE chrom=?", ("x",)).fetchall()
+    assert "chromidx" in plan[0][-1]
+    for rid, rec in list(g["records"].items())[::9]:
+        assert db.execute("SELECT ID FROM seq WHERE chrom=?", (rec["name"],)).fetchone()[0] == int(rid)
+    db.close()
+    fq = fx.Fastq(files["test.fq"], full_index=True)
+    assert _idx(files["test.fq"] + ".fxi") == ([("ok",)], ["readidx"])
+    # many records, shuffled numeric suffixes: several leaf and interior pages in both b-trees
+    rng = np.random.default_rng(5)
+    n = 120000
+    ids = rng.permutation(n).tolist()
+    p = tmp_path / "many.fq"
+    p.write_bytes(b"".join(b"@SRR8539271.%d len=%d\nACGTNACGTA\n+\nIIIIIHHHHH\n" % (i + 1, i % 97) for i in ids))
+    fq = fx.Fastq(str(p))
+    assert len(fq) == n and _idx(str(p) + ".fxi") == ([("ok",)], ["readidx"])
+    for j in rng.integers(0, n, 30).tolist():
+        r = fq["SRR8539271.%d" % (ids[j] + 1)]
+        assert r.id == j + 1 and r.seq == "ACGTNACGTA"
+    db = sqlite3.connect(str(p) + ".fxi")
+    assert db.execute("SELECT count(*), min(ID), max(ID) FROM read").fetchone() == (n, 1, n)
+    want = sorted(b"SRR8539271.%d" % (i + 1) for i in ids)
+    got = [r[0].encode() for r in db.execute("SELECT name FROM read INDEXED BY readidx ORDER BY name")]
+    assert got == want
+    db.close()
+    # duplicate names: the reference's CREATE UNIQUE INDEX fails and is ignored (index.c:363-366) -> no index
+    p = tmp_path / "dup.fa"
+    p.write_bytes(b">a 1\nACGT\n>b\nGG\n>a 2\nTTTT\n")
+    fa = fx.Fasta(str(p))
+    assert _idx(str(p) + ".fxi") == ([("ok",)], []) and len(fa) == 3 and fa["a"].id == 1
+    # a name too long for an in-page index entry (REINDEX by SQLite), one too long for a table page (INSERT path)
+    for L, tag in ((1500, "mid"), (5000, "big")):
+        p = tmp_path / ("long_%s.fa" % tag)
+        p.write_bytes(b">" + b"N" * L + b"\nACGT\n>short\nGGCC\n")
+        fa = fx.Fasta(str(p))
+        assert _idx(str(p) + ".fxi") == ([("ok",)], ["chromidx"])
+        assert fa["N" * L].seq == "ACGT" and fa["short"].id == 2
+    # non-ASCII header bytes are stored as they are in the file (sqlite3_bind_text of the raw bytes, index.c:239-251)
+    p = tmp_path / "latin.fa"
+    p.write_bytes(b">caf\xc3\xa9 x\nACGT\n>plain\nGG\n")
+    fa = fx.Fasta(str(p))
+    db = sqlite3.connect(str(p) + ".fxi")
+    assert db.execute("SELECT CAST(chrom AS BLOB) FROM seq WHERE ID=1").fetchone()[0] == b"caf\xc3\xa9"
+    db.close()
+    assert fa["café"].seq == "ACGT"

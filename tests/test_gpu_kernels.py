@@ -318,3 +318,53 @@ def test_names_lookup(oracle, L):
         first.setdefault(nme, i)
     pick = rng.integers(0, sq.n_reads, 2000)
     assert fq.names_lookup([rn[i] for i in pick]).tolist() == [first[rn[i]] for i in pick]
+
+
+def _py_order(names):
+    """BINARY collation of SQLite = Python's bytes ordering; equal names in id order (sorted() is stable)."""
+    return sorted(range(len(names)), key=names.__getitem__)
+
+
+def test_names_sort(oracle, L):
+    """fx_names_sort: the order `CREATE UNIQUE INDEX ... (name)` sorts into (index.c:363, fastq.c:152), computed on
+    the GPU over the names in the resident stream; n_dup = number of adjacent equal names."""
+    rng = np.random.default_rng(11)
+    raw = fixture_bytes("test.fa")
+    b, s, t = fasta_rows(L.Blob, raw)
+    names = [raw[t["hoff"][i] + 1: t["hoff"][i] + 1 + t["name_len"][i]] for i in range(s.n_seq)]
+    order, ndup = b.names_sort(0, s.n_seq)
+    assert order.tolist() == _py_order(names) and ndup == 0
+    # duplicates, the empty name, prefixes of each other, a NUL byte, lengths across several 8-byte chunks
+    heads = [b"dup 1", b"x", b"dup 2", b"", b"L" * 300 + b" tail", b"dup", b"abcdefgh", b"abcdefghi", b"abcdefg",
+             b"abcdefgh\x01", b"ab\x00c", b"ab", b"\xff\xfe", b"L" * 300, b"L" * 299 + b"M", b"abcdefghabcdefgh", b"abcdefghabcdefg"]
+    raw = b"".join(b">" + h + b"\nACGT\n" for h in heads)
+    for full in (False, True):
+        b, s, t = fasta_rows(L.Blob, raw, full_name=full)
+        names = [raw[t["hoff"][i] + 1: t["hoff"][i] + 1 + t["name_len"][i]] for i in range(s.n_seq)]
+        order, ndup = b.names_sort(0, s.n_seq)
+        assert order.tolist() == _py_order(names), full
+        srt = [names[i] for i in order]
+        assert ndup == sum(srt[i] == srt[i + 1] for i in range(len(srt) - 1))
+        assert (ndup == 0) == full                          # first tokens: "dup" three times; whole headers: distinct
+    # FASTQ read names: random (duplicates likely with short names) and sequencer-style (long common prefix)
+    for n, maxlen in ((5000, 6), (20000, 60)):
+        raw = _rand_fastq(rng, n, maxlen, crlf=bool(n & 1), plus_name=True)
+        recs, size, ln = oracle.fastq_index(raw)
+        fq = L.Blob.from_bytes(raw)
+        sq = fq.fastq_build()
+        rn = [raw[int(recs["name_off"][i]): int(recs["name_off"][i]) + int(recs["name_len"][i])] for i in range(sq.n_reads)]
+        order, ndup = fq.names_sort(1, sq.n_reads)
+        assert order.tolist() == _py_order(rn)
+        assert ndup == len(rn) - len(set(rn))
+    n = 30000
+    ids = rng.permutation(n)
+    raw = b"".join(b"@SRR8539271.%d %d/1\nACGTN\n+\nIIIII\n" % (i + 1, i) for i in ids.tolist())
+    fq = L.Blob.from_bytes(raw)
+    sq = fq.fastq_build()
+    order, ndup = fq.names_sort(1, n)
+    assert ndup == 0 and order.tolist() == _py_order([b"SRR8539271.%d" % (i + 1) for i in ids.tolist()])
+    # an empty FASTQ
+    fq = L.Blob.from_bytes(b"")
+    fq.fastq_build()
+    order, ndup = fq.names_sort(1, 0)
+    assert order.size == 0 and ndup == 0

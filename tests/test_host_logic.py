@@ -183,3 +183,65 @@ def test_reference_opens_our_gz_fxi(oracle, tmp_path):
             assert fa[f["id"] - 1][f["start"]:f["stop"]].seq == f["seq"]
         assert fa[0].name == "JZ822577.1" and fa.fetch("JZ822578.1", (1, 10)) == g["records"]["2"]["seq"][:10]
         del fa
+
+
+def _fxi_rows(path):
+    import sqlite3
+    db = sqlite3.connect(path)
+    ok = db.execute("PRAGMA integrity_check").fetchall()
+    rows = db.execute("SELECT * FROM read ORDER BY ID").fetchall()
+    stat = db.execute("SELECT * FROM stat").fetchall()
+    idx = db.execute("SELECT name FROM sqlite_master WHERE type='index'").fetchall()
+    db.close()
+    return ok, rows, stat, idx
+
+
+@pytest.mark.parametrize("n,maxname", [(0, 10), (1, 10), (37, 30), (5000, 60), (300000, 45), (2000, 1500), (30000, 900)])
+def test_fxi_bulk_table_equals_inserts(tmp_path, n, maxname):
+    """fx_fxi_bulk_rows (b-tree pages written directly, host code of libfxgpu.so) produces a database that SQLite
+    reads exactly like the one made of INSERTs: same rows, integrity_check ok, unique index created on top."""
+    from pyfastx_amd import fxi
+    rng = np.random.default_rng(n + maxname)
+    lens = rng.integers(0 if n < 100 else 1, maxname + 1, n)
+    alpha = np.frombuffer(b"ACGT:_0123456789abcxyz", dtype=np.uint8)
+    names = [alpha[rng.integers(0, alpha.size, int(L))].tobytes().decode() + ("_%d" % i) for i, L in enumerate(lens)]
+    cols = {"dlen": rng.integers(1, 300, n), "rlen": rng.integers(0, 1 << 17, n),
+            "soff": np.sort(rng.integers(0, 1 << 45, n)), "qoff": rng.integers(-5, 1 << 62, n)}
+    cols = {k: v.astype(np.int64) for k, v in cols.items()}
+    if n > 3:
+        cols["rlen"][:4] = [0, 1, 127, 128]                 # serial types 8, 9, 1, 2
+    a, b = str(tmp_path / "a.fxi"), str(tmp_path / "b.fxi")
+    db = fxi.connect(a)
+    fxi.write_fastq(db, names, cols, int(cols["rlen"].sum()))
+    db.close()
+    enc = [x.encode() for x in names]
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in enc], out=offs[1:])
+    packed = np.frombuffer(b"".join(enc), dtype=np.uint8)
+    db = fxi.write_fastq_bulk(b, packed, offs, cols, int(cols["rlen"].sum()))
+    db.close()
+    # c: the UNIQUE INDEX b-tree written directly as well (fx_fxi_bulk_index) from the sorted order of the names
+    c = str(tmp_path / "c.fxi")
+    order = np.array(sorted(range(n), key=lambda i: enc[i]), dtype=np.int64)
+    db = fxi.write_fastq_bulk(c, packed, offs, cols, int(cols["rlen"].sum()), order=order)
+    db.close()
+    import sqlite3
+    ra = _fxi_rows(a)
+    for other in (b, c):
+        rb = _fxi_rows(other)
+        assert rb[0] == [("ok",)], rb[0][:3]                # integrity_check also matches index entries with rows
+        assert ra[1] == rb[1] and ra[2] == rb[2] and ra[3] == rb[3]
+        db = sqlite3.connect(other)
+        plan = db.execute("EXPLAIN QUERY PLAN SELECT ID FROM read WHERE name=?", ("x",)).fetchall()
+        assert "readidx" in plan[0][-1]
+        for i in rng.integers(0, n, min(n, 50)) if n else []:  # by-name and by-id probes through the index / rowid
+            assert db.execute("SELECT ID FROM read WHERE name=?", (names[int(i)],)).fetchone()[0] == int(i) + 1
+            assert db.execute("SELECT name FROM read WHERE ID=?", (int(i) + 1,)).fetchone()[0] == names[int(i)]
+        assert db.execute("SELECT ID FROM read WHERE name=?", ("no such read",)).fetchone() is None
+        got = [r[0] for r in db.execute("SELECT name FROM read INDEXED BY readidx ORDER BY name").fetchall()]
+        assert got == [enc[int(i)].decode() for i in order]  # a full walk of the index b-tree
+        if n:                                                # a written index keeps working under later changes
+            db.execute("DELETE FROM read WHERE ID=?", (n // 2 + 1,))
+            db.execute("INSERT INTO read VALUES (NULL,'zz new',1,2,3,4)")
+            assert db.execute("PRAGMA integrity_check").fetchall() == [("ok",)]
+        db.close()
