@@ -137,6 +137,17 @@ static bool pwrite_all(int fd, const uint8_t *p, size_t n, off_t off) {
 // Load `rows` into the (empty) table whose b-tree root is page `rootpage` of the database file `path`.
 // The file must be closed by every SQLite connection.  Returns OK, E_ROW when a row does not fit a page
 // (the caller uses the INSERT path), E_IO / E_INVAL otherwise.
+// New pages are appended to the file in order; the page that holds byte 2^30 (SQLite's "pending byte" page, used
+// for file locking) must never carry data and is stepped over.
+struct PageSeq {
+    uint32_t base, lock;                                    // first new page; the page to skip
+    PageSeq(uint32_t first, int pagesize) : base(first), lock((uint32_t)(0x40000000u / (uint32_t)pagesize) + 1) {}
+    uint32_t at(uint64_t k) const {
+        const uint64_t p = (uint64_t)base + k;
+        return (uint32_t)((base <= lock && p >= lock) ? p + 1 : p);
+    }
+};
+
 static int bulk_load_table(const char *path, uint32_t rootpage, const Rows &r) {
     if (r.ncols < 0 || r.ncols > 16 || r.n < 0 || rootpage < 2) return E_INVAL;
     const int fd = open(path, O_RDWR);
@@ -150,6 +161,7 @@ static int bulk_load_table(const char *path, uint32_t rootpage, const Rows &r) {
     if (fstat(fd, &st) != 0) { close(fd); return E_IO; }
     uint32_t npages = (uint32_t)(st.st_size / pagesize);
     if (rootpage > npages || hdr[18] > 1 || hdr[19] > 1) { close(fd); return E_INVAL; }     // journal mode must be the legacy one
+    if (hdr[52] | hdr[53] | hdr[54] | hdr[55]) { close(fd); return E_INVAL; }                 // auto-vacuum files interleave pointer-map pages
 
     // ---- cell sizes (parallel), then leaves by greedy fill (sequential, cheap)
     const int T = (int)std::min<int64_t>(16, std::max<int64_t>(1, r.n / 65536));
@@ -189,8 +201,9 @@ static int bulk_load_table(const char *path, uint32_t rootpage, const Rows &r) {
         // ---- page numbers: leaves first, then the interior levels; the top level lives in the root page
         std::vector<uint32_t> kids(nleaf);
         std::vector<int64_t> maxkey(nleaf);
-        for (size_t k = 0; k < nleaf; ++k) { kids[k] = npages + 1 + (uint32_t)k; maxkey[k] = leaf_first[k + 1]; }   // rowid = row + 1
-        uint32_t next_page = npages + 1 + (uint32_t)nleaf;
+        const PageSeq seq(npages + 1, pagesize);
+        for (size_t k = 0; k < nleaf; ++k) { kids[k] = seq.at(k); maxkey[k] = leaf_first[k + 1]; }   // rowid = row + 1
+        uint64_t next_k = nleaf;
         // leaves, in parallel, 256 pages per write
         {
             std::atomic<size_t> cursor(0);
@@ -206,7 +219,11 @@ static int bulk_load_table(const char *path, uint32_t rootpage, const Rows &r) {
                         const size_t b = std::min(nleaf, a + 256);
                         for (size_t k = a; k < b; ++k)
                             format_leaf(buf.data() + (k - a) * (size_t)pagesize, pagesize, usable, r, leaf_first[k], leaf_first[k + 1]);
-                        if (!pwrite_all(fd, buf.data(), (b - a) * (size_t)pagesize, (off_t)(kids[a] - 1) * pagesize)) err.store(1);
+                        size_t cut = a + 1;                  // pages a .. cut-1 are adjacent in the file (the skipped page splits a batch)
+                        while (cut < b && kids[cut] == kids[cut - 1] + 1) ++cut;
+                        if (!pwrite_all(fd, buf.data(), (cut - a) * (size_t)pagesize, (off_t)(kids[a] - 1) * pagesize)) err.store(1);
+                        if (cut < b && !pwrite_all(fd, buf.data() + (cut - a) * (size_t)pagesize, (b - cut) * (size_t)pagesize,
+                                                   (off_t)(kids[cut] - 1) * pagesize)) err.store(1);
                     }
                 });
             for (auto &x : th) x.join();
@@ -222,8 +239,8 @@ static int bulk_load_table(const char *path, uint32_t rootpage, const Rows &r) {
             for (size_t g = 0; g < groups && ok; ++g) {
                 const size_t a = K * g / groups, b = K * (g + 1) / groups;
                 format_interior(page.data(), pagesize, usable, kids, maxkey, a, b, 0);
-                ok = pwrite_all(fd, page.data(), (size_t)pagesize, (off_t)(next_page - 1) * pagesize);
-                up[g] = next_page++;
+                up[g] = seq.at(next_k++);
+                ok = pwrite_all(fd, page.data(), (size_t)pagesize, (off_t)(up[g] - 1) * pagesize);
                 upkey[g] = maxkey[b - 1];
             }
             kids.swap(up); maxkey.swap(upkey);
@@ -232,7 +249,7 @@ static int bulk_load_table(const char *path, uint32_t rootpage, const Rows &r) {
             format_interior(page.data(), pagesize, usable, kids, maxkey, 0, kids.size(), 0);
             ok = pwrite_all(fd, page.data(), (size_t)pagesize, (off_t)(rootpage - 1) * pagesize);
         }
-        npages = next_page - 1;
+        npages = seq.at(next_k - 1);
     }
     // ---- file header: size in pages, change counter, "version valid for"
     if (ok) {
@@ -317,7 +334,7 @@ static int bulk_load_index(const char *path, uint32_t rootpage, const Entries &e
     struct stat st;
     if (fstat(fd, &st) != 0) { close(fd); return E_IO; }
     uint32_t npages = (uint32_t)(st.st_size / pagesize);
-    if (rootpage > npages || hdr[18] > 1 || hdr[19] > 1) { close(fd); return E_INVAL; }
+    if (rootpage > npages || hdr[18] > 1 || hdr[19] > 1 || (hdr[52] | hdr[53] | hdr[54] | hdr[55])) { close(fd); return E_INVAL; }
     const int max_local = ((usable - 12) * 64 / 255) - 23;  // larger index payloads would spill to overflow pages
 
     // payload sizes (parallel)
@@ -360,11 +377,12 @@ static int bulk_load_index(const char *path, uint32_t rootpage, const Entries &e
     // ---- page numbers: level 0 pages first, ...; the single page of the top level is the root page
     const size_t nlev = levels.size();
     std::vector<std::vector<uint32_t>> pageno(nlev);
-    uint32_t next_page = npages + 1;
+    const PageSeq seq(npages + 1, pagesize);
+    uint64_t next_k = 0;
     for (size_t l = 0; l < nlev; ++l) {
         const size_t np = levels[l].first.size() - 1;
         pageno[l].resize(np);
-        for (size_t k = 0; k < np; ++k) pageno[l][k] = (l + 1 == nlev) ? rootpage : next_page++;
+        for (size_t k = 0; k < np; ++k) pageno[l][k] = (l + 1 == nlev) ? rootpage : seq.at(next_k++);
     }
     bool ok = true;
     // ---- leaves (parallel)
@@ -433,7 +451,7 @@ static int bulk_load_index(const char *path, uint32_t rootpage, const Entries &e
         uint32_t change = ((uint32_t)hdr[24] << 24) | (hdr[25] << 16) | (hdr[26] << 8) | hdr[27];
         ++change;
         put_be(hdr + 24, change, 4);
-        put_be(hdr + 28, next_page - 1, 4);
+        put_be(hdr + 28, next_k ? seq.at(next_k - 1) : npages, 4);
         put_be(hdr + 92, change, 4);
         ok = pwrite_all(fd, hdr, 100, 0);
     }

@@ -1379,7 +1379,7 @@ extern "C" int fx_fasta_set_row(fx_handle *h, int64_t k, int64_t boff, int64_t b
 // ------------------------------------------------------------- .fxi bulk load (host side)
 extern "C" int fx_fxi_bulk_rows(const char *path, int rootpage, int64_t n, const uint8_t *names, const int64_t *name_off,
                                 int ncols, const int64_t *const *cols) {
-    if (!path || n < 0 || (n > 0 && (!names || !name_off || (ncols > 0 && !cols)))) return fail(FX_EINVAL, "bad argument");
+    if (!path || n < 0 || (n > 0 && (!name_off || (!names && name_off[n] > 0) || (ncols > 0 && !cols)))) return fail(FX_EINVAL, "bad argument");
     const fxi::Rows r{n, names, name_off, ncols, cols};
     const int rc = fxi::bulk_load_table(path, (uint32_t)rootpage, r);
     if (rc == fxi::E_ROW) return fail(FX_ERANGE, "a row does not fit a b-tree page without overflow: use the INSERT path");
@@ -1390,7 +1390,7 @@ extern "C" int fx_fxi_bulk_rows(const char *path, int rootpage, int64_t n, const
 
 extern "C" int fx_fxi_bulk_index(const char *path, int rootpage, int64_t n, const uint8_t *names, const int64_t *name_off,
                                  const int64_t *order) {
-    if (!path || n < 0 || (n > 0 && (!names || !name_off || !order))) return fail(FX_EINVAL, "bad argument");
+    if (!path || n < 0 || (n > 0 && (!name_off || !order || (!names && name_off[n] > 0)))) return fail(FX_EINVAL, "bad argument");
     const fxi::Entries e{n, names, name_off, order};
     const int rc = fxi::bulk_load_index(path, (uint32_t)rootpage, e);
     if (rc == fxi::E_ROW) return fail(FX_ERANGE, "an index entry does not fit a b-tree page without overflow: use CREATE INDEX");

@@ -271,8 +271,8 @@ def test_bulk_written_index_is_sound(fx, files, tmp_path):
     db = sqlite3.connect(files["test.fa"] + ".fxi")
     plan = db.execute("EXPLAIN QUERY PLAN SELECT * FROM seq WHERE chrom=?", ("x",)).fetchall()
     assert "chromidx" in plan[0][-1]
-    for rid, rec in list(g["records"].items())[::9]:
-        assert db.execute("SELECT ID FROM seq WHERE chrom=?", (rec["name"],)).fetchone()[0] == int(rid)
+    for row in g["seq"][::9]:
+        assert db.execute("SELECT ID FROM seq WHERE chrom=?", (row[1],)).fetchone()[0] == row[0]
     db.close()
     fq = fx.Fastq(files["test.fq"], full_index=True)
     assert _idx(files["test.fq"] + ".fxi") == ([("ok",)], ["readidx"])

@@ -363,8 +363,3 @@ def test_names_sort(oracle, L):
     sq = fq.fastq_build()
     order, ndup = fq.names_sort(1, n)
     assert ndup == 0 and order.tolist() == _py_order([b"SRR8539271.%d" % (i + 1) for i in ids.tolist()])
-    # an empty FASTQ
-    fq = L.Blob.from_bytes(b"")
-    fq.fastq_build()
-    order, ndup = fq.names_sort(1, 0)
-    assert order.size == 0 and ndup == 0

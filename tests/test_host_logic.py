@@ -245,3 +245,88 @@ def test_fxi_bulk_table_equals_inserts(tmp_path, n, maxname):
             db.execute("INSERT INTO read VALUES (NULL,'zz new',1,2,3,4)")
             assert db.execute("PRAGMA integrity_check").fetchall() == [("ok",)]
         db.close()
+
+
+def test_fxi_bulk_empty_names_and_fasta_table(tmp_path):
+    """All names empty (n > 0, zero name bytes) and the FASTA flavour of the loader against write_fasta."""
+    import sqlite3
+    from pyfastx_amd import fxi
+    n = 9
+    cols = {k: (np.arange(n, dtype=np.int64) * (j + 3)) for j, k in enumerate(("boff", "blen", "slen", "llen", "elen", "norm", "dlen"))}
+    for names in ([""] * n, ["chr%d" % (i * 7 % n) for i in range(n)]):
+        a, b = str(tmp_path / "a.fxi"), str(tmp_path / "b.fxi")
+        for p in (a, b):
+            if os.path.exists(p):
+                os.remove(p)
+        db = fxi.connect(a)
+        fxi.write_fasta(db, names, cols, 1234)
+        db.close()
+        enc = [x.encode() for x in names]
+        offs = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(x) for x in enc], out=offs[1:])
+        packed = np.frombuffer(b"".join(enc), dtype=np.uint8)
+        distinct = len(set(names)) == n
+        order = np.array(sorted(range(n), key=lambda i: enc[i]), dtype=np.int64) if distinct else None
+        db = fxi.write_fasta_bulk(b, packed, offs, cols, 1234, order=order)
+        db.close()
+        for p in (a, b):
+            db = sqlite3.connect(p)
+            assert db.execute("PRAGMA integrity_check").fetchall() == [("ok",)]
+            db.close()
+        da, dbb = sqlite3.connect(a), sqlite3.connect(b)
+        for q in ("SELECT * FROM seq ORDER BY ID", "SELECT seqnum, seqlen FROM stat", "SELECT name FROM sqlite_master WHERE type='index'"):
+            assert da.execute(q).fetchall() == dbb.execute(q).fetchall(), q
+        da.close(); dbb.close()
+
+
+def test_fxi_bulk_row_too_large_falls_back(tmp_path):
+    """A row that would need an overflow page: FX_ERANGE, and no half-written file is left behind."""
+    from pyfastx_amd import _lib, fxi
+    names = [b"N" * 5000, b"short"]
+    offs = np.array([0, 5000, 5005], dtype=np.int64)
+    packed = np.frombuffer(b"".join(names), dtype=np.uint8)
+    cols = {k: np.array([1, 2], dtype=np.int64) for k in ("dlen", "rlen", "soff", "qoff")}
+    p = str(tmp_path / "x.fxi")
+    with pytest.raises(_lib.FxError) as ei:
+        fxi.write_fastq_bulk(p, packed, offs, cols, 3)
+    assert ei.value.code == _lib.FX_ERANGE and not os.path.exists(p)
+
+
+@pytest.mark.parametrize("n,width,with_index", [(1_100_000, 1000, False), (640_000, 900, True)])
+def test_fxi_bulk_steps_over_the_pending_byte_page(tmp_path, n, width, with_index):
+    """Index files beyond 1 GiB: the page holding byte 2^30 is reserved by SQLite for locking and must stay unused.
+    Case 1: the `read` table itself crosses it (table only); case 2: the table ends below it and the index b-tree
+    crosses it."""
+    import sqlite3
+    from pyfastx_amd import _lib, fxi
+    rng = np.random.default_rng(n)
+    m = np.tile(rng.integers(65, 91, (1000, width), dtype=np.uint8), (n // 1000, 1))
+    tag = np.char.zfill(np.arange(n).astype("S8"), 8)         # distinct 8-byte tail
+    m[:, -8:] = np.frombuffer(tag.tobytes(), dtype=np.uint8).reshape(n, 8)
+    packed = m.reshape(-1)
+    offs = np.arange(n + 1, dtype=np.int64) * width
+    cols = {k: np.arange(n, dtype=np.int64) + j for j, k in enumerate(("dlen", "rlen", "soff", "qoff"))}
+    p = str(tmp_path / "big.fxi")
+    if with_index:
+        order = np.argsort(m.view("S%d" % width).reshape(n), kind="stable").astype(np.int64)
+        db = fxi.write_fastq_bulk(p, packed, offs, cols, 77, order=order)
+        db.close()
+    else:
+        db = fxi.connect(p)
+        db.executescript(fxi.FASTQ_DDL)
+        root = db.execute("SELECT rootpage FROM sqlite_master WHERE name='read'").fetchone()[0]
+        db.close()
+        _lib.fxi_bulk_rows(p, root, packed, offs, [cols[k] for k in ("dlen", "rlen", "soff", "qoff")])
+    assert os.path.getsize(p) > (1 << 30)
+    db = sqlite3.connect(p)
+    assert db.execute("PRAGMA integrity_check").fetchall() == [("ok",)]
+    assert db.execute("SELECT count(*) FROM read").fetchone()[0] == n
+    for i in rng.integers(0, n, 20).tolist() + [0, n - 1]:
+        nm = m[i].tobytes().decode()
+        if with_index:
+            assert db.execute("SELECT ID, qoff FROM read WHERE name=?", (nm,)).fetchone() == (i + 1, i + 3)
+        else:
+            assert db.execute("SELECT name, qoff FROM read WHERE ID=?", (i + 1,)).fetchone() == (nm, i + 3)
+    db.execute("INSERT INTO read VALUES (NULL,'appended',1,2,3,4)")      # SQLite allocates past our pages
+    assert db.execute("SELECT ID FROM read WHERE name='appended'").fetchone()[0] == n + 1
+    db.close()
