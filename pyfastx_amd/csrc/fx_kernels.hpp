@@ -7,7 +7,7 @@
 //   FASTA index   fx_spanscan.hpp: one read of the stream, per-4-KiB summaries, no line table
 //   FASTQ index   fx_fastq.hpp: count pass + emit pass (one lane per newline), no line table
 //   fetch         k_fetch / k_fastq_fetch: gather, despace, upper, revcomp, phred  (index.c:683-707, util.c:157-269, read.c)
-//   composition   k_fasta_comp (here), k_fastq_comp (fx_fastq.hpp)
+//   composition   k_fasta_comp (fx_comp.hpp), k_fastq_comp (fx_fastq.hpp)
 //
 // Integer/byte work only: no MFMA anywhere; the roofline is HBM bandwidth.
 #pragma once
@@ -498,85 +498,6 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_fetch(const uint8_t *__restrict
                 }
             }
         }
-    }
-}
-
-// ============================================================ FASTA composition
-// fasta.c:901-950: per-record histogram of the bytes on sequence lines ('\n'
-// excluded, '\r' included, header lines excluded, bytes before the first header
-// dropped).  One workgroup per tile.  Fast path (tile lies inside one record's
-// sequence block): SWAR compare+popcount for the ten bytes that make up
-// essentially all of a genome (ACGTN acgtn); any other byte value falls to an
-// LDS histogram.  (A private per-thread LDS histogram with one ds_add per byte was
-// measured slower -- 2.4-2.7 ms vs 2.2 ms for 3 GB: LDS atomics, not VALU, became
-// the limit -- so the SWAR counters stay.)  Slow path (tile touches a header line or a record boundary):
-// per byte record lookup.  Results are flushed with 64-bit global atomics, a
-// handful per tile.
-__device__ __forceinline__ uint32_t cnt_eq16(const uint4 &v, uint32_t pat) {
-    return __popc(zero_bytes(v.x ^ pat)) + __popc(zero_bytes(v.y ^ pat)) + __popc(zero_bytes(v.z ^ pat)) +
-           __popc(zero_bytes(v.w ^ pat));
-}
-
-__global__ __launch_bounds__(BLOCK) void k_fasta_comp(const uint8_t *__restrict__ data, int64_t n, int64_t gbase,
-                                                     const int64_t *__restrict__ hdr, const int64_t *__restrict__ boff,
-                                                     int64_t n_hdr, const int64_t *__restrict__ hdr_prefix,
-                                                     int64_t ngran, int gran_per_tile,
-                                                     unsigned long long *__restrict__ comp) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t lds4[4];
-    const int tid = threadIdx.x;
-    const int64_t tile = blockIdx.x;
-    const int64_t tbase = tile * (int64_t)TILE;
-    const int64_t tend = (tbase + TILE < n) ? tbase + TILE : n;
-    hist[tid] = 0;
-    __syncthreads();
-    // record that owns the first byte of the tile
-    const int64_t rec0 = upper_bound(hdr, n_hdr, gbase + tbase) - 1;
-    // does a header line start inside this tile?  (hdr_prefix: header lines before each 4 KiB granule)
-    const int64_t g0 = tile * gran_per_tile, g1 = (g0 + gran_per_tile < ngran) ? g0 + gran_per_tile : ngran;
-    const bool fast = rec0 >= 0 && hdr_prefix[g1] == hdr_prefix[g0] && (gbase + tbase) >= boff[rec0];
-    if (fast) {
-        const uint32_t pats[10] = {0x41414141u, 0x43434343u, 0x47474747u, 0x54545454u, 0x4E4E4E4Eu,
-                                   0x61616161u, 0x63636363u, 0x67676767u, 0x74747474u, 0x6E6E6E6Eu};
-        uint32_t c10[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        uint32_t other = 0;
-        for (int j = 0; j < UNROLL; ++j) {
-            const int64_t p = tbase + (int64_t)(j * BLOCK + tid) * CHUNK;
-            if (p >= tend) break;
-            const uint4 v = load16(data, p, n);
-            const int valid = (int)((tend - p < CHUNK) ? (tend - p) : CHUNK);
-            uint32_t known = cnt_eq16(v, 0x0A0A0A0Au);
-#pragma unroll
-            for (int a = 0; a < 10; ++a) { const uint32_t c = cnt_eq16(v, pats[a]); c10[a] += c; known += c; }
-            if (known != (uint32_t)valid) {                // some other byte value: exact per-byte pass
-                other = 1;
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                for (int k = 0; k < valid; ++k) {
-                    const uint32_t b = (w[k >> 2] >> ((k & 3) * 8)) & 0xFF;
-                    const uint32_t u = b & 0xDF;
-                    const bool common = (b == 10) || u == 'A' || u == 'C' || u == 'G' || u == 'T' || u == 'N';
-                    if (!common && b < 128) atomicAdd(&hist[b], 1u);
-                }
-            }
-        }
-        const uint8_t sym[10] = {'A', 'C', 'G', 'T', 'N', 'a', 'c', 'g', 't', 'n'};
-#pragma unroll
-        for (int a = 0; a < 10; ++a) {
-            const uint32_t s = block_sum(c10[a], lds4);
-            if (tid == 0 && s) atomicAdd(&comp[rec0 * 128 + sym[a]], (unsigned long long)s);
-        }
-        const uint32_t any_other = block_sum(other, lds4);
-        if (any_other && tid < 128 && hist[tid]) atomicAdd(&comp[rec0 * 128 + tid], (unsigned long long)hist[tid]);
-        return;
-    }
-    // slow path: byte by byte with record / header-line awareness
-    for (int64_t p = tbase + tid; p < tend; p += BLOCK) {
-        const uint8_t b = data[p];
-        if (b == '\n' || b >= 128) continue;
-        const int64_t rec = upper_bound(hdr, n_hdr, gbase + p) - 1;
-        if (rec < 0) continue;
-        if (gbase + p < boff[rec]) continue;               // inside the header line
-        atomicAdd(&comp[rec * 128 + b], 1ull);
     }
 }
 

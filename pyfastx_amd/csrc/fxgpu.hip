@@ -24,6 +24,7 @@
 #include "fx_kernels.hpp"
 #include "fx_spanscan.hpp"
 #include "fx_fastq.hpp"
+#include "fx_comp.hpp"
 #include "fx_names.hpp"
 #include "fx_inflate.hpp"
 #include "fx_fxi.hpp"
@@ -80,10 +81,10 @@ template <class T> struct DevBuf {      // grow-only device array: rebuilds reus
 // Optional per-kernel HIP-event timing on the handle's own stream (bench.py's
 // roofline leg reads it; off by default so the hot path records no events).
 enum KernelId { K_SPAN_SCAN = 0, K_GRAN_REDUCE, K_GRAN_PREFIX, K_HDR_REC, K_GRAN_LINES, K_GRAN_EXACT, K_FASTA_FINALIZE, K_FETCH,
-                K_FASTA_COMP, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_NKERN };
+                K_FASTA_COMP, K_FASTA_COMP_EDGE, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_NKERN };
 static const char *const kKernelNames[K_NKERN] = {
     "k_span_scan", "k_gran_reduce", "k_gran_prefix", "k_hdr_rec", "k_gran_lines", "k_gran_exact", "k_fasta_finalize", "k_fetch",
-    "k_fasta_comp", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy"};
+    "k_fasta_comp", "k_fasta_comp_edge", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy"};
 
 struct Prof {
     bool on = false;
@@ -771,8 +772,18 @@ extern "C" int fx_fasta_comp(fx_handle *h, int where, int64_t *comp) {
     unsigned long long *d = (unsigned long long *)comp;
     if (where != FX_DEVICE) { if ((rc = tmp.alloc(n))) return rc; d = tmp.p; }
     HIPCHK(hipMemsetAsync(d, 0, (size_t)n * 8, h->stream));
-    FX_LAUNCH(h, K_FASTA_COMP, k_fasta_comp, dim3((unsigned)((h->n + TILE - 1) / TILE)), dim3(BLOCK), h->d_data, h->n, h->base,
-                       h->hdr.p, h->fa_boff.p, h->n_hdr, h->hdr_prefix.p, h->ngran, TILE / GRAN, d);
+    // one wave per run of granules (a multiple of the pipeline depth): 8 = 32 KiB measured best on 3 GB (0.525 ms;
+    // 16: 0.550, 4: 0.569), shorter runs for small inputs so that the machine still fills
+    const int gpw = h->ngran >= 65536 ? 4 * COMP_DEPTH : h->ngran >= 16384 ? 2 * COMP_DEPTH : COMP_DEPTH;
+    const int64_t waves = (h->ngran + gpw - 1) / gpw;
+    const dim3 grid((unsigned)((waves + COMP_WPB - 1) / COMP_WPB));
+    DevBuf<int32_t> edge;                                    // [0]: number of runs left to the second launch, [1..]: their ids
+    if ((rc = edge.alloc(waves + 1))) return rc;
+    HIPCHK(hipMemsetAsync(edge.p, 0, 4, h->stream));
+    FX_LAUNCH(h, K_FASTA_COMP, k_fasta_comp<true>, grid, dim3(COMP_WPB * 64), h->d_data, h->n, h->base,
+                       h->hdr.p, h->fa_boff.p, h->n_hdr, h->hdr_prefix.p, h->ngran, gpw, edge.p, d);
+    FX_LAUNCH(h, K_FASTA_COMP_EDGE, k_fasta_comp<false>, grid, dim3(COMP_WPB * 64), h->d_data, h->n, h->base,
+                       h->hdr.p, h->fa_boff.p, h->n_hdr, h->hdr_prefix.p, h->ngran, gpw, edge.p, d);
     HIPCHK(hipGetLastError());
     if (where != FX_DEVICE) HIPCHK(hipMemcpyAsync(comp, d, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

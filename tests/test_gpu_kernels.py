@@ -363,3 +363,47 @@ def test_names_sort(oracle, L):
     sq = fq.fastq_build()
     order, ndup = fq.names_sort(1, n)
     assert ndup == 0 and order.tolist() == _py_order([b"SRR8539271.%d" % (i + 1) for i in ids.tolist()])
+
+
+def test_fasta_comp_letters(oracle, L):
+    """k_fasta_comp: records long enough for the straight (whole-granule) path and for every phase of a wave's
+    run, with soft-masked runs, N runs, CRLF, IUPAC codes, protein letters, '*', NUL and bytes >= 128 -- every bin of
+    every record against the oracle (fasta.c:901-950)."""
+    rng = np.random.default_rng(77)
+
+    def body(n, alphabet, width, eol=b"\n", lower_runs=True, rare=None):
+        a = np.frombuffer(alphabet, dtype=np.uint8)[rng.integers(0, len(alphabet), n)].copy()
+        if lower_runs:                                       # soft-masked stretches
+            for _ in range(max(1, n // 5000)):
+                s = int(rng.integers(0, n)); e = min(n, s + int(rng.integers(1, 3000)))
+                a[s:e] |= 0x20
+        for _ in range(max(1, n // 40000)):                  # runs of N
+            s = int(rng.integers(0, n)); e = min(n, s + int(rng.integers(1, 6000)))
+            a[s:e] = ord("N") | (a[s:e] & 0x20)
+        if rare is not None:
+            idx = rng.integers(0, n, max(1, n // rare[1]))
+            a[idx] = np.frombuffer(rare[0], dtype=np.uint8)[rng.integers(0, len(rare[0]), idx.size)]
+        a[a == 10] = 65
+        a[a == 62] = 65                                      # no '>' (it would start a record at a line start)
+        rows = [a[i:i + width].tobytes() for i in range(0, n, width)]
+        return eol.join(rows) + eol
+
+    parts = [b">dna plain\n" + body(700_000, b"ACGT", 60),
+             b">dna crlf\r\n" + body(300_000, b"ACGT", 70, eol=b"\r\n"),
+             b">iupac\n" + body(400_000, b"ACGT", 80, rare=(b"RYKMSWBDHVUryn-*.", 50)),
+             b">protein\n" + body(250_000, b"ACDEFGHIKLMNPQRSTVWY*", 60, lower_runs=False),
+             b">noise\n" + body(300_000, b"ACGT", 4095, rare=(bytes(range(256)), 300)),
+             b">one long line\n" + body(200_000, b"ACGTN", 10**9),
+             b">short\nACGTNacgtn\n", b">empty\n", b">tail without newline\nACGTacgtNNnn*"]
+    raw = b"".join(parts)
+    recs, tot = oracle.fasta_index(raw)
+    b, s, t = fasta_rows(L.Blob, raw)
+    assert s.n_seq == len(recs) == len(parts)
+    got = b.fasta_comp(s.n_seq)
+    want = oracle.fasta_comp(raw, len(recs))
+    np.testing.assert_array_equal(got, want)
+    assert int(want[0][ord("a")]) > 0 and int(want[3][ord("W")]) > 0 and int(want[4][0]) > 0    # the cases are really in there
+    # the same stream cut into shards: every shard counts its own bytes, rows add up (records that cross a cut
+    # are completed by the owner of the header, see shard.py) -- here just the totals per letter
+    tot_letters = got.sum(axis=0)
+    assert int(tot_letters[ord("\n")]) == 0 and int(tot_letters[13]) == int(want[:, 13].sum())

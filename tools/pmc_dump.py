@@ -1,0 +1,11 @@
+import csv, glob, sys, collections
+d=sys.argv[1]
+rows=collections.defaultdict(dict)
+for f in glob.glob(d+"/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "k_fasta_comp" not in r["Kernel_Name"]: continue
+        key=(r["Dispatch_Id"], r["Kernel_Name"].split("(")[0][-30:], r.get("Grid_Size",""))
+        rows[key][r["Counter_Name"]]=float(r["Counter_Value"])
+for k in sorted(rows, key=lambda x:int(x[0])):
+    v=rows[k]
+    print(k, {a:round(b) for a,b in v.items()})
