@@ -210,64 +210,195 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_stats(FqTab t, int64_t n_seq_ro
     }
 }
 
-// FASTQ composition (fastq.c:715-753).  16 lanes per record, 4 records per wave; a lane
-// reads 16 aligned bytes per step (256-byte window per record).  Sequence line: SWAR
-// compare+popcount for 'A','C','G','T' (upper case only) and '\r' (ignored); every other
-// byte is N.  Quality line: min / max byte, '\r' ignored.
-__device__ __forceinline__ uint32_t valid16(int64_t pp, int64_t lo, int64_t hi) {
-    int64_t a0 = lo - pp, a1 = hi - pp;
-    a0 = a0 < 0 ? 0 : (a0 > 16 ? 16 : a0);
-    a1 = a1 < 0 ? 0 : (a1 > 16 ? 16 : a1);
-    return a1 > a0 ? (((1u << a1) - 1u) & ~((1u << a0) - 1u)) : 0u;
+// FASTQ composition (fastq.c:715-753): A C G T (upper case only) over the sequence lines, every other byte but
+// '\r' is N; min / max byte of the quality lines, '\r' ignored.  16 lanes per record, 4 records per wave; a lane
+// takes 16 bytes of the line per step (unaligned 16-byte loads from the line start, so only the last piece of a
+// line is partial; bytes past its end are replaced by '\r').
+// Sequence: no compare per letter -- as in k_fasta_comp (fx_comp.hpp) the 3-bit code (b >> 1) & 7 picks a one-hot
+// class byte (A C G T N '\r') through v_perm_b32 and the byte it stands for through a second one; the four words
+// of a piece are added bit-plane-wise (three full adders), and only the carry-out word ("four more at this bit") is
+// popcounted per class.  A piece with a byte outside A C G T N '\r' (lower case, IUPAC codes: N for the reference)
+// is fixed up byte by byte through a per-wave LDS array: take the aliased class back out, add one N.
+// Quality: the 16 bytes go through packed 16-bit min / max (v_pk_min_u16 / v_pk_max_u16 on the even and odd
+// bytes); a piece whose smallest byte is below '!' or whose largest is above 127 -- a '\r', or bytes the reference
+// reads as negative chars -- takes the exact per-byte loop instead.
+constexpr uint32_t FQ_OH_LO = 0x04080201u, FQ_OH_HI = 0x10200000u;     // A 1, C 2, T 8, G 4 | -, -, \r 32, N 16
+constexpr uint32_t FQ_EX_LO = 0x47544341u, FQ_EX_HI = 0x4E0D8080u;     // 'A' 'C' 'T' 'G' | none, none, '\r', 'N'
+
+__device__ const uint4 fq_sixteen_zeros = {0u, 0u, 0u, 0u};
+typedef unsigned short __attribute__((ext_vector_type(2))) fq_u16x2;
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    const fq_u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(fq_u16x2, a), __builtin_bit_cast(fq_u16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
 }
-__global__ __launch_bounds__(BLOCK) void k_fastq_comp(const uint8_t *__restrict__ data, int64_t gbase, FqTab t,
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    const fq_u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(fq_u16x2, a), __builtin_bit_cast(fq_u16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+// 16 bytes at p (any alignment); within 16 bytes of the end of the blob: byte by byte, zeros past the end
+__device__ __forceinline__ uint4 fq_load16(const uint8_t *__restrict__ data, int64_t p, int64_t n_bytes) {
+    if (p + 16 <= n_bytes) return *reinterpret_cast<const uint4_u *>(data + p);
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 16; ++k) if (p + k < n_bytes) w[k >> 2] |= (uint32_t)data[p + k] << ((k & 3) * 8);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+// keep the first `keep` (1..15) bytes of v, the others become `fill` (a byte replicated over the word)
+__device__ __forceinline__ void fq_keep_first(uint32_t (&x)[4], int keep, uint32_t fill) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = keep - 4 * i;
+        const uint32_t m = k >= 4 ? 0xFFFFFFFFu : k <= 0 ? 0u : ((1u << (8 * k)) - 1u);
+        x[i] = (x[i] & m) | (fill & ~m);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_fastq_comp(const uint8_t *__restrict__ data, int64_t gbase, int64_t n_bytes, FqTab t,
                                                      int64_t n_seq_rows, int64_t n_rows, FastqAcc *acc) {
-    const int lane = lane_id(), sub = lane & 15, grp = lane >> 4;
+    __shared__ int fix_all[BLOCK / 64][8];                 // per wave: signed corrections of the class counts (slot = class bit index)
+    const int lane = lane_id(), sub = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+    int *fix = fix_all[wv];
+    if (lane < 8) fix[lane] = 0;
     const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
-    uint32_t ca = 0, cc = 0, cg = 0, ct = 0, cn = 0;       // per lane, flushed per record batch (no overflow: <= 16 per step)
-    unsigned long long ta = 0, tc = 0, tg = 0, tt = 0, tn = 0;
+    uint32_t ones = 0, twos = 0;                           // bit planes of the one-hot words: 1s and 2s per bit position
+    uint32_t c4[6] = {0, 0, 0, 0, 0, 0};                   // per class: popcount of the carry-outs (each worth 4)
     int qmin = 104, qmax = 33;                             // fastq.c:667-668
-    for (int64_t t0 = wave * 4; t0 < n_seq_rows; t0 += nwaves * 4) {
-        const int64_t i = t0 + grp;
-        if (i < n_seq_rows) {                              // line_num % 4 == 2
-            const int64_t s = t.soff[i] - gbase, e = s + t.rlen[i];
-            for (int64_t p = (s & ~15ll) + sub * 16; p < e; p += 256) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(data + p);
-                const uint32_t ok = valid16(p, s, e);
-                const uint32_t ma = eq_mask16(v, 0x41414141u) & ok, mc = eq_mask16(v, 0x43434343u) & ok;
-                const uint32_t mg = eq_mask16(v, 0x47474747u) & ok, mt = eq_mask16(v, 0x54545454u) & ok;
-                const uint32_t mr = eq_mask16(v, 0x0D0D0D0Du) & ok;
-                ca += __popc(ma); cc += __popc(mc); cg += __popc(mg); ct += __popc(mt);
-                cn += __popc(ok & ~(ma | mc | mg | mt | mr));
-            }
+
+    auto seq_piece = [&](const uint4 &v, int64_t left) {   // 16 bytes of a sequence line, `left` of them inside it
+        uint32_t x[4] = {v.x, v.y, v.z, v.w};
+        if (left < 16) fq_keep_first(x, (int)left, 0x0D0D0D0Du);
+        uint32_t h[4], dacc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t code = (x[k] >> 1) & 0x07070707u;
+            h[k] = __builtin_amdgcn_perm(FQ_OH_HI, FQ_OH_LO, code);
+            dacc |= x[k] ^ __builtin_amdgcn_perm(FQ_EX_HI, FQ_EX_LO, code);
         }
-        if (i < n_rows) {                                  // line_num % 4 == 0
-            const int64_t s = t.qoff[i] - gbase, e = s + t.qlen[i];
-            for (int64_t p = (s & ~15ll) + sub * 16; p < e; p += 256) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(data + p);
-                uint32_t ok = valid16(p, s, e) & ~eq_mask16(v, 0x0D0D0D0Du);
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                while (ok) {
-                    const int j = __ffs(ok) - 1;
-                    ok &= ok - 1;
-                    const int q = (int)(signed char)(w[j >> 2] >> ((j & 3) * 8));
-                    qmin = q < qmin ? q : qmin; qmax = q > qmax ? q : qmax;
+        if (dacc) {                                        // a byte that is none of A C G T N \r: N for the reference
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t code = (x[k] >> 1) & 0x07070707u;
+                const uint32_t d = x[k] ^ __builtin_amdgcn_perm(FQ_EX_HI, FQ_EX_LO, code);
+                if (!d) continue;
+#pragma unroll 1
+                for (int j = 0; j < 4; ++j) {
+                    if (!((d >> (8 * j)) & 0xFFu)) continue;
+                    const uint32_t hk = (h[k] >> (8 * j)) & 0xFFu;     // what the planes take this byte for
+                    if (hk) atomicSub(&fix[__ffs(hk) - 1], 1);
+                    atomicAdd(&fix[4], 1);
                 }
             }
         }
-        ta += ca; tc += cc; tg += cg; tt += ct; tn += cn;
-        ca = cc = cg = ct = cn = 0;
+        const uint32_t tA = __builtin_amdgcn_bitop3_b32(ones, h[0], h[1], 0xE8);
+        ones = __builtin_amdgcn_bitop3_b32(ones, h[0], h[1], 0x96);
+        const uint32_t tB = __builtin_amdgcn_bitop3_b32(ones, h[2], h[3], 0xE8);
+        ones = __builtin_amdgcn_bitop3_b32(ones, h[2], h[3], 0x96);
+        const uint32_t f = __builtin_amdgcn_bitop3_b32(twos, tA, tB, 0xE8);
+        twos = __builtin_amdgcn_bitop3_b32(twos, tA, tB, 0x96);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) c4[c] += __popc(f & (0x01010101u << c));
+    };
+    auto qual_piece = [&](const uint4 &v, int64_t left) {  // 16 bytes of a quality line
+        uint32_t lo[4] = {v.x, v.y, v.z, v.w}, hi[4] = {v.x, v.y, v.z, v.w};
+        const int keep = left < 16 ? (int)left : 16;
+        if (keep < 16) { fq_keep_first(lo, keep, 0xFFFFFFFFu); fq_keep_first(hi, keep, 0u); }
+        uint32_t mn = 0x00FF00FFu, mx = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mn = pk_min_u16(mn, pk_min_u16(lo[k] & 0x00FF00FFu, (lo[k] >> 8) & 0x00FF00FFu));
+            mx = pk_max_u16(mx, pk_max_u16(hi[k] & 0x00FF00FFu, (hi[k] >> 8) & 0x00FF00FFu));
+        }
+        const int cmin = (int)min(mn & 0xFFFFu, mn >> 16), cmax = (int)max(mx & 0xFFFFu, mx >> 16);
+        if (cmin >= 33 && cmax < 128) {
+            qmin = cmin < qmin ? cmin : qmin; qmax = cmax > qmax ? cmax : qmax;
+        } else {                                           // '\r' (skipped) or bytes outside the printable range: exactly as fastq.c:733-737
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            for (int j = 0; j < keep; ++j) {
+                const int q = (int)(signed char)(w[j >> 2] >> ((j & 3) * 8));
+                if (q == 13) continue;
+                qmin = q < qmin ? q : qmin; qmax = q > qmax ? q : qmax;
+            }
+        }
+    };
+
+    // A wave takes FQ_RPW = 4 * FQ_U consecutive records per iteration (FQ_U per 16-lane group).  Table rows are read
+    // one iteration ahead; the first piece of every sequence line and quality line of the iteration is requested
+    // before any of them is counted (reads up to 256 bytes need no more than those loads): 2 * FQ_U loads in
+    // flight per lane -- with one record per group the kernel was bound by the load round trip, 2.8 ms for 7 GB.
+    constexpr int FQ_U = 3, FQ_RPW = 4 * FQ_U;
+    const uint8_t *safe = n_bytes >= 16 ? data : reinterpret_cast<const uint8_t *>(&fq_sixteen_zeros);
+    const int64_t stride = nwaves * FQ_RPW;
+    int64_t i0 = wave * FQ_RPW + grp * FQ_U;               // first record of this group in this iteration
+    // the next iteration's rows, raw: the loads are unconditional (index clamped) and nothing is computed from them
+    // until the next pass -- anything else makes every one of them a round trip of its own
+    int64_t r_soff[FQ_U], r_rlen[FQ_U], r_qoff[FQ_U];
+    int32_t r_qlen[FQ_U];
+    const int64_t last_seq = n_seq_rows - 1, last_row = n_rows > 0 ? n_rows - 1 : 0;
+#pragma unroll
+    for (int u = 0; u < FQ_U; ++u) {
+        const int64_t is = i0 + u < last_seq ? i0 + u : last_seq, iq = i0 + u < last_row ? i0 + u : last_row;
+        r_soff[u] = t.soff[is]; r_rlen[u] = t.rlen[is]; r_qoff[u] = t.qoff[iq]; r_qlen[u] = t.qlen[iq];
     }
-    ta = wave_sum64(ta); tc = wave_sum64(tc); tg = wave_sum64(tg); tt = wave_sum64(tt); tn = wave_sum64(tn);
+    for (int64_t t0 = wave * FQ_RPW; t0 < n_seq_rows; t0 += stride) {
+        int64_t ps[FQ_U], e[FQ_U], pq[FQ_U], qe[FQ_U];
+        uint4 vs[FQ_U], vq[FQ_U];
+#pragma unroll
+        for (int u = 0; u < FQ_U; ++u) {
+            const int64_t i = i0 + u;
+            const int64_t s = r_soff[u] - gbase, q = r_qoff[u] - gbase;
+            ps[u] = s + sub * 16; e[u] = i < n_seq_rows ? s + r_rlen[u] : 0;       // e <= ps: nothing to do
+            pq[u] = q + sub * 16; qe[u] = i < n_rows ? q + r_qlen[u] : 0;
+        }
+        // the 2 * FQ_U loads of the iteration, branch-free (a lane with nothing to read, or within 16 bytes of the end
+        // of the blob, reads 16 bytes that are always there instead): loads inside branches are waited for one by one
+#pragma unroll
+        for (int u = 0; u < FQ_U; ++u) {
+            const bool ls = ps[u] < e[u] && ps[u] + 16 <= n_bytes, lq = pq[u] < qe[u] && pq[u] + 16 <= n_bytes;
+            vs[u] = *reinterpret_cast<const uint4_u *>(ls ? data + ps[u] : safe);
+            vq[u] = *reinterpret_cast<const uint4_u *>(lq ? data + pq[u] : safe);
+        }
+        i0 += stride;                                      // next iteration's rows: requested after the data, used after the counting
+#pragma unroll
+        for (int u = 0; u < FQ_U; ++u) {
+            const int64_t is = i0 + u < last_seq ? i0 + u : last_seq, iq = i0 + u < last_row ? i0 + u : last_row;
+            r_soff[u] = t.soff[is]; r_rlen[u] = t.rlen[is]; r_qoff[u] = t.qoff[iq]; r_qlen[u] = t.qlen[iq];
+        }
+#pragma unroll
+        for (int u = 0; u < FQ_U; ++u) {                   // the last bytes of the blob: byte by byte
+            if (ps[u] < e[u] && ps[u] + 16 > n_bytes) vs[u] = fq_load16(data, ps[u], n_bytes);
+            if (pq[u] < qe[u] && pq[u] + 16 > n_bytes) vq[u] = fq_load16(data, pq[u], n_bytes);
+        }
+#pragma unroll
+        for (int u = 0; u < FQ_U; ++u) {
+            if (ps[u] < e[u]) {
+                seq_piece(vs[u], e[u] - ps[u]);
+                for (int64_t p = ps[u] + 256; p < e[u]; p += 256) seq_piece(fq_load16(data, p, n_bytes), e[u] - p);
+            }
+            if (pq[u] < qe[u]) {
+                qual_piece(vq[u], qe[u] - pq[u]);
+                for (int64_t p = pq[u] + 256; p < qe[u]; p += 256) qual_piece(fq_load16(data, p, n_bytes), qe[u] - p);
+            }
+        }
+    }
+    // class totals of the lane: 1 * ones + 2 * twos + 4 * carry-outs, then the wave, then the accumulators
+    unsigned long long tot[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const uint32_t m = 0x01010101u << c;
+        tot[c] = wave_sum64((long long)(__popc(ones & m) + 2 * __popc(twos & m) + 4 * c4[c]));
+    }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         int a = __shfl_xor(qmin, d, 64), b = __shfl_xor(qmax, d, 64);
         qmin = a < qmin ? a : qmin; qmax = b > qmax ? b : qmax;
     }
     if (lane == 0) {
-        if (ta) atomicAdd(&acc->a, ta); if (tc) atomicAdd(&acc->c, tc); if (tg) atomicAdd(&acc->g, tg);
-        if (tt) atomicAdd(&acc->t, tt); if (tn) atomicAdd(&acc->n, tn);
+        // class bits: 0 A, 1 C, 2 G, 3 T, 4 N (bit 5, '\r', is not counted)
+        const long long ta = (long long)tot[0] + fix[0], tc = (long long)tot[1] + fix[1], tg = (long long)tot[2] + fix[2],
+                        tt = (long long)tot[3] + fix[3], tn = (long long)tot[4] + fix[4];
+        if (ta) atomicAdd(&acc->a, (unsigned long long)ta); if (tc) atomicAdd(&acc->c, (unsigned long long)tc);
+        if (tg) atomicAdd(&acc->g, (unsigned long long)tg); if (tt) atomicAdd(&acc->t, (unsigned long long)tt);
+        if (tn) atomicAdd(&acc->n, (unsigned long long)tn);
         atomicMin(&acc->minqs, qmin); atomicMax(&acc->maxqs, qmax);
     }
 }

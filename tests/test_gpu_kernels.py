@@ -407,3 +407,33 @@ def test_fasta_comp_letters(oracle, L):
     # are completed by the owner of the header, see shard.py) -- here just the totals per letter
     tot_letters = got.sum(axis=0)
     assert int(tot_letters[ord("\n")]) == 0 and int(tot_letters[13]) == int(want[:, 13].sum())
+
+
+def test_fastq_comp_letters(oracle, L):
+    """k_fastq_comp: lower case, IUPAC codes, '*', bytes >= 128 (all N for the reference, fastq.c:715-753), reads
+    shorter / longer than one 16-byte piece and than the 256-byte window, CRLF, quality bytes below '!' and above
+    127 -- base counts and min / max quality against the oracle."""
+    rng = np.random.default_rng(91)
+    for eol in (b"\n", b"\r\n"):
+        out = []
+        alpha = np.frombuffer(b"ACGTNacgtnRYKM*-." + bytes([200, 255, 1]), dtype=np.uint8)
+        for i in range(3000):
+            n = int((1, 15, 16, 17, 150, 255, 256, 257, 700)[i % 9] if i % 4 else rng.integers(1, 400))
+            seq = alpha[rng.integers(0, 5 if i % 3 else alpha.size, n)].tobytes().replace(b"\n", b"A")
+            lo, hi = ((33, 75), (40, 41), (64, 105), (33, 127))[i % 4]
+            q = rng.integers(lo, hi, n).astype(np.uint8)
+            if i % 97 == 0:
+                q[rng.integers(0, n)] = 14                    # below '!'
+            if i % 101 == 0:
+                q[rng.integers(0, n)] = 200                   # a negative char for the reference
+            out += [b"@r%d some text" % i + eol, seq + eol, b"+" + eol, q.tobytes() + eol]
+        raw = b"".join(out)
+        c = oracle.fastq_composition(raw)
+        b = L.Blob.from_bytes(raw)
+        s = b.fastq_build()
+        assert s.n_reads == 3000
+        base, meta = b.fastq_comp()
+        assert base.tolist() == [c["a"], c["c"], c["g"], c["t"], c["n"]], eol
+        assert meta.tolist() == [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"], c["phred"]], eol
+        base2, meta2 = b.fastq_comp()                        # a second call starts from clean accumulators
+        assert base2.tolist() == base.tolist() and meta2.tolist() == meta.tolist()
