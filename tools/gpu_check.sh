@@ -5,6 +5,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ( time timeout 900 python -m pytest tests -m gpu -x -q ) > $OUT/pytest.log 2>&1
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" ) > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 tail -3 $OUT/pytest.log
 timeout 600 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
