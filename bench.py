@@ -213,6 +213,30 @@ def main():
         if not okc:
             raise SystemExit("PARITY FAILURE (composition) at full size")
 
+    if world > 1 and not a.no_verify:
+        # composition across the cuts (shard.ShardedFasta.composition: local counting + two small all-gathers):
+        # the contigs that lie wholly in this rank's piece row by row, and -- for the contig that crosses each cut,
+        # whose bases sit on two ranks -- the sum of all rows of all ranks against the sum of all bincounts
+        tc = time.perf_counter()
+        comp = job.composition()
+        comp_ms = (time.perf_counter() - tc) * 1e3
+        first = 1 if rank > 0 else 0
+        okc = True
+        for i in range(first, len(plan["slen"])):
+            L = int(plan["slen"][i])
+            seg = flat[int(flat_start[i]):int(flat_start[i]) + L]
+            okc &= bool((torch.bincount(seg.long(), minlength=128)[:128].cpu() == torch.from_numpy(comp[i - first])).all())
+        tot = torch.from_numpy(comp.sum(axis=0)).to(dev)
+        want = torch.zeros(128, dtype=torch.int64, device=dev)
+        for i in range(len(plan["slen"])):
+            L = int(plan["slen"][i])
+            want += torch.bincount(flat[int(flat_start[i]):int(flat_start[i]) + L].long(), minlength=128)[:128]
+        both = torch.stack([tot, want]).to(job.comm_dev)
+        dist.all_reduce(both, op=dist.ReduceOp.SUM)
+        okc &= bool((both[0] == both[1]).all())
+        if not okc:
+            raise SystemExit("PARITY FAILURE (composition across shards) at full size")
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()

@@ -127,6 +127,12 @@ int fx_fasta_set_table(fx_handle *h, int64_t n, const int64_t *boff, const int64
  * every byte value < 128 on the sequence lines of each record ('\r' included,
  * '\n' excluded).  Needs fx_fasta_build first. */
 int fx_fasta_comp(fx_handle *h, int where, int64_t *comp);
+/* The same for one byte-range shard (fx_set_shard).  The bytes of a shard that precede its first header line belong
+ * to a record whose header lies in an earlier shard: they are counted into lead[128] (host), from global offset
+ * lead_from on -- the later of the shard's start and that record's boff, so that a header line crossing the cut is
+ * left out (lead_from < 0: nothing is counted, e.g. shard 0).  The owner of the record adds the lead rows of the
+ * following shards up to and including the first one that holds a header line (pyfastx_amd/shard.py).              */
+int fx_fasta_comp_shard(fx_handle *h, int where, int64_t *comp, int64_t lead_from, int64_t *lead);
 
 /* ------------------------------------------------------------ FASTQ index
  * Replaces pyfastx_fastq_create_index (fastq.c:89-171).                      */

@@ -42,7 +42,7 @@ class ShardSummary(C.Structure):
 SYMBOLS = [
     "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_host", "fx_open_device",
     "fx_set_shard", "fx_close", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
-    "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_comp", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
+    "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_revcomp", "fx_shard_summary_get",
     "fx_fasta_set_row", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
 ]
@@ -111,6 +111,7 @@ def lib():
     L.fx_fasta_table.argtypes = [vp, i32] + [vp] * 9
     L.fx_fasta_set_table.argtypes = [vp, i64] + [vp] * 6
     L.fx_fasta_comp.argtypes = [vp, i32, vp]
+    L.fx_fasta_comp_shard.argtypes = [vp, i32, vp, i64, vp]
     L.fx_fastq_build.argtypes = [vp, C.POINTER(FastqSummary)]
     L.fx_fastq_table.argtypes = [vp, i32] + [vp] * 6
     L.fx_set_halo.argtypes = [vp, i64]
@@ -322,6 +323,14 @@ class Blob:
         comp = np.zeros((n, 128), dtype=np.int64)
         check(lib().fx_fasta_comp(self._h, FX_HOST, comp.ctypes.data))
         return comp
+
+    def fasta_comp_shard(self, n, lead_from):
+        """-> (comp int64[n,128] of the records that start in this shard, lead int64[128]: the bytes before the
+        shard's first header line from global offset lead_from on; lead_from < 0: not counted)."""
+        comp = np.zeros((max(n, 1), 128), dtype=np.int64)
+        lead = np.zeros(128, dtype=np.int64)
+        check(lib().fx_fasta_comp_shard(self._h, FX_HOST, comp.ctypes.data, int(lead_from), lead.ctypes.data))
+        return comp[:n], lead
 
     # -- FASTQ --------------------------------------------------------------
     def fastq_build(self):

@@ -128,14 +128,18 @@ __device__ __forceinline__ uint32_t comp_symbol(int slot) {    // slot c: upper-
     const int c = slot & 7;
     return (c == 0 ? 'A' : c == 1 ? 'C' : c == 2 ? 'G' : c == 3 ? 'T' : c == 4 ? 'N' : 13u) | (slot >= 8 ? 0x20u : 0u);
 }
+// Record indices: 0 .. n_hdr-1, and -1 = the bytes of the shard that precede its first header line (they belong to a
+// record of an earlier shard; counted into row n_hdr from offset lead_from on when lead_from >= 0, see fx_fasta_comp).
+// COMP_NONE = no record.
+constexpr int64_t COMP_NONE = -2;
 // blk_cnt != null: counts of record blk_rec are gathered per workgroup in LDS (slots as above) and reach comp with
 // one set of atomics per workgroup -- thousands of waves adding to the same few cache lines of one chromosome's row
 // serialise in L2 otherwise
 __device__ __forceinline__ void comp_flush(CompState &s, uint32_t *__restrict__ rare_hist, unsigned long long *__restrict__ comp,
-                                           uint32_t *__restrict__ blk_cnt, int64_t blk_rec) {
-    if (s.rec >= 0) {
+                                           uint32_t *__restrict__ blk_cnt, int64_t blk_rec, int64_t n_hdr) {
+    if (s.rec != COMP_NONE) {
         const int lane = lane_id();
-        unsigned long long *row = comp + s.rec * 128;
+        unsigned long long *row = comp + (s.rec >= 0 ? s.rec : n_hdr) * 128;
         uint32_t mine = 0;                      // lane c: upper-case count of class c, lane 8 + c: lower-case count
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -269,7 +273,7 @@ template <bool PURE>
 __global__ __launch_bounds__(COMP_WPB * 64) void k_fasta_comp(const uint8_t *__restrict__ data, int64_t n, int64_t gbase,
                                                      const int64_t *__restrict__ hdr, const int64_t *__restrict__ boff,
                                                      int64_t n_hdr, const int64_t *__restrict__ hdr_prefix,
-                                                     int64_t ngran, int gpw, int32_t *__restrict__ edge_list,
+                                                     int64_t ngran, int gpw, int32_t *__restrict__ edge_list, int64_t lead_from,
                                                      unsigned long long *__restrict__ comp) {
     __shared__ uint32_t rare_all[COMP_WPB][128];
     __shared__ uint32_t blk_cnt[16];
@@ -279,14 +283,16 @@ __global__ __launch_bounds__(COMP_WPB * 64) void k_fasta_comp(const uint8_t *__r
     int64_t nreal = (n + FX_GRAN - 1) / FX_GRAN;            // granules that hold bytes (the one after the last byte holds nothing)
     if (nreal > ngran) nreal = ngran;
     CompState s;
-    s.rec = -1; s.rare = false;
+    s.rec = COMP_NONE; s.rare = false;
     comp_reset(s);
     const int team = 1;
+    const int64_t rmin = lead_from >= 0 ? -1 : 0;           // lowest record index that is counted
+    auto rec_boff = [&](int64_t r) { return r >= 0 ? uniform64(boff[r]) : lead_from; };   // where the record's sequence bytes begin
     if (PURE) {
         if (threadIdx.x < 16) blk_cnt[threadIdx.x] = 0;
         __syncthreads();
         const int64_t gblock = (int64_t)blockIdx.x * COMP_WPB * gpw;      // the workgroup's first granule and its record
-        const int64_t blk_rec = gblock < nreal ? uniform64(hdr_prefix[gblock]) - 1 : -1;
+        const int64_t blk_rec = gblock < nreal ? uniform64(hdr_prefix[gblock]) - 1 : COMP_NONE;
         const int64_t gfirst = wave * gpw;
         bool active = gfirst < nreal;
         if (active) {
@@ -300,8 +306,8 @@ __global__ __launch_bounds__(COMP_WPB * 64) void k_fasta_comp(const uint8_t *__r
                 for (int k = 0; k < COMP_DEPTH; ++k) comp_load_granule(buf[k], data, (gfirst + k) * (int64_t)FX_GRAN, lane);
             }
             const int64_t r0 = uniform64(hdr_prefix[gfirst]) - 1;
-            const bool pure = candidate && uniform64(hdr_prefix[gfirst + cnt]) == r0 + 1 && r0 >= 0 &&
-                              gbase + gfirst * (int64_t)FX_GRAN >= uniform64(boff[r0]);
+            const bool pure = candidate && uniform64(hdr_prefix[gfirst + cnt]) == r0 + 1 && r0 >= rmin &&
+                              gbase + gfirst * (int64_t)FX_GRAN >= rec_boff(r0);
             if (!pure) {                        // left to the second launch
                 if (lane == 0) edge_list[1 + atomicAdd(&edge_list[0], 1)] = (int32_t)wave;
             } else {
@@ -338,13 +344,13 @@ __global__ __launch_bounds__(COMP_WPB * 64) void k_fasta_comp(const uint8_t *__r
                     comp_rare_pass(data, n, (gfirst + g) * (int64_t)FX_GRAN, 0, FX_GRAN, rare_hist);
                     s.rare = true;
                 }
-                comp_flush(s, rare_hist, comp, blk_cnt, blk_rec);
+                comp_flush(s, rare_hist, comp, blk_cnt, blk_rec, n_hdr);
             }
         }
         __syncthreads();
-        if (threadIdx.x < 16 && blk_rec >= 0) {
+        if (threadIdx.x < 16 && blk_rec >= rmin) {
             const uint32_t v = blk_cnt[threadIdx.x];
-            if (v) atomicAdd(&comp[blk_rec * 128 + comp_symbol((int)threadIdx.x)], (unsigned long long)v);
+            if (v) atomicAdd(&comp[(blk_rec >= 0 ? blk_rec : n_hdr) * 128 + comp_symbol((int)threadIdx.x)], (unsigned long long)v);
         }
         return;
     }
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(COMP_WPB * 64) void k_fasta_comp(const uint8_t *__r
     // All control values are wave-uniform.
     for (;;) {
         bool have = false, full = false;
-        int64_t rr = -1, gseg = 0;
+        int64_t rr = COMP_NONE, gseg = 0;
         int a = 0, b = 0;
         while (!have && i < cnt) {
             const int64_t g = gfirst + (int64_t)i * team;
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(COMP_WPB * 64) void k_fasta_comp(const uint8_t *__r
                 loaded = true;
                 const int64_t hb = uniform64(hdr_prefix[g]), he = uniform64(hdr_prefix[g + 1]);
                 r = hb - 1;                     // record that owns the first byte of the granule
-                if (whole && he == hb && r >= 0 && gbase + gs >= uniform64(boff[r])) {     // inside one record's sequence block
+                if (whole && he == hb && r >= rmin && gbase + gs >= rec_boff(r)) {     // inside one record's sequence block
                     have = true; full = true; rr = r; a = 0; b = FX_GRAN;
                     ++i; loaded = false;
                     break;
@@ -393,14 +399,14 @@ __global__ __launch_bounds__(COMP_WPB * 64) void k_fasta_comp(const uint8_t *__r
             }
             const int64_t nexth = (r + 1 < n_hdr) ? uniform64(hdr[r + 1]) - gbase : INT64_MAX;
             const int64_t bb = nexth < ge ? nexth : ge;
-            if (r >= 0) {
-                int64_t aa = uniform64(boff[r]) - gbase;
+            if (r >= rmin) {
+                int64_t aa = rec_boff(r) - gbase;
                 if (aa < gs) aa = gs;
                 if (aa < bb) { have = true; rr = r; a = (int)(aa - gs); b = (int)(bb - gs); }
             }
             if (nexth >= ge) { ++i; loaded = false; } else ++r;
         }
-        if (rr != s.rec) { comp_flush(s, rare_hist, comp, nullptr, -1); s.rec = rr; }
+        if (rr != s.rec) { comp_flush(s, rare_hist, comp, nullptr, COMP_NONE, n_hdr); s.rec = rr; }
         if (!have) break;
         const uint32_t dacc = full ? comp_add_granule<true>(s, v, 0, FX_GRAN) : comp_add_granule<false>(s, v, a, b);
         if (__ballot(dacc != 0)) {

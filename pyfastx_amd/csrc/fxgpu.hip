@@ -761,17 +761,19 @@ extern "C" int fx_fasta_table(fx_handle *h, int where, int64_t *hoff, int64_t *b
     return FX_OK;
 }
 
-extern "C" int fx_fasta_comp(fx_handle *h, int where, int64_t *comp) {
+// comp: n_hdr x 128 (where = FX_HOST / FX_DEVICE); lead (host, 128 words or null): counts of the bytes before the
+// shard's first header line from global offset lead_from on (lead_from < 0: not counted)
+static int fasta_comp_impl(fx_handle *h, int where, int64_t *comp, int64_t lead_from, int64_t *lead) {
     if (!h || !comp) return fail(FX_EINVAL, "null argument");
     if (!h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build has not run");
     int rc = use_device(h);
     if (!rc) rc = finish_build(h);
     if (rc) return rc;
     const int64_t n = h->n_hdr * 128;
-    DevBuf<unsigned long long> tmp;
-    unsigned long long *d = (unsigned long long *)comp;
-    if (where != FX_DEVICE) { if ((rc = tmp.alloc(n))) return rc; d = tmp.p; }
-    HIPCHK(hipMemsetAsync(d, 0, (size_t)n * 8, h->stream));
+    DevBuf<unsigned long long> tmp;                          // n_hdr rows + the row of the leading bytes
+    if ((rc = tmp.alloc(n + 128))) return rc;
+    unsigned long long *d = tmp.p;
+    HIPCHK(hipMemsetAsync(d, 0, (size_t)(n + 128) * 8, h->stream));
     // one wave per run of granules (a multiple of the pipeline depth): 8 = 32 KiB measured best on 3 GB (0.525 ms;
     // 16: 0.550, 4: 0.569), shorter runs for small inputs so that the machine still fills
     const int gpw = h->ngran >= 65536 ? 4 * COMP_DEPTH : h->ngran >= 16384 ? 2 * COMP_DEPTH : COMP_DEPTH;
@@ -781,13 +783,21 @@ extern "C" int fx_fasta_comp(fx_handle *h, int where, int64_t *comp) {
     if ((rc = edge.alloc(waves + 1))) return rc;
     HIPCHK(hipMemsetAsync(edge.p, 0, 4, h->stream));
     FX_LAUNCH(h, K_FASTA_COMP, k_fasta_comp<true>, grid, dim3(COMP_WPB * 64), h->d_data, h->n, h->base,
-                       h->hdr.p, h->fa_boff.p, h->n_hdr, h->hdr_prefix.p, h->ngran, gpw, edge.p, d);
+                       h->hdr.p, h->fa_boff.p, h->n_hdr, h->hdr_prefix.p, h->ngran, gpw, edge.p, lead_from, d);
     FX_LAUNCH(h, K_FASTA_COMP_EDGE, k_fasta_comp<false>, grid, dim3(COMP_WPB * 64), h->d_data, h->n, h->base,
-                       h->hdr.p, h->fa_boff.p, h->n_hdr, h->hdr_prefix.p, h->ngran, gpw, edge.p, d);
+                       h->hdr.p, h->fa_boff.p, h->n_hdr, h->hdr_prefix.p, h->ngran, gpw, edge.p, lead_from, d);
     HIPCHK(hipGetLastError());
-    if (where != FX_DEVICE) HIPCHK(hipMemcpyAsync(comp, d, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    if (n) HIPCHK(hipMemcpyAsync(comp, d, (size_t)n * 8, where == FX_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    if (lead) HIPCHK(hipMemcpyAsync(lead, d + n, 128 * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return FX_OK;
+}
+
+extern "C" int fx_fasta_comp(fx_handle *h, int where, int64_t *comp) { return fasta_comp_impl(h, where, comp, -1, nullptr); }
+
+extern "C" int fx_fasta_comp_shard(fx_handle *h, int where, int64_t *comp, int64_t lead_from, int64_t *lead) {
+    if (!lead) return fail(FX_EINVAL, "null argument");
+    return fasta_comp_impl(h, where, comp, lead_from, lead);
 }
 
 // ------------------------------------------------------------- FASTQ build

@@ -270,6 +270,26 @@ class ShardedFasta:
     def local_rows(self):
         return self.blob.fasta_table(self.n_local)
 
+    def composition(self):
+        """Per-record 128-bin composition (fasta.c:901-950) of the records this rank owns, complete across the cuts:
+        every rank counts its own bytes once (k_fasta_comp), two more small all-gathers move (a) the boff of each
+        shard's last record -- where the next shards' leading bytes start to count -- and (b) the 128 counts of
+        the bytes before each shard's first header line to the rank that owns that record."""
+        torch, dist = self._torch, self._dist
+        n = self.n_local
+        if self.world == 1:
+            return self.blob.fasta_comp(n)
+        rows = self.local_rows()
+        mine = torch.tensor([self.base, int(rows["boff"][-1]) if n else -1, n], dtype=torch.int64, device=self.comm_dev)
+        allv = [torch.zeros(3, dtype=torch.int64, device=self.comm_dev) for _ in range(self.world)]
+        dist.all_gather(allv, mine)
+        info = [[int(x) for x in v.cpu()] for v in allv]
+        bases, boffs, nh = [v[0] for v in info], [v[1] for v in info], [v[2] for v in info]
+        comp, lead = self.blob.fasta_comp_shard(n, comp_lead_from(bases, boffs, self.rank))
+        leads = [torch.zeros(128, dtype=torch.int64, device=self.comm_dev) for _ in range(self.world)]
+        dist.all_gather(leads, torch.from_numpy(lead).to(self.comm_dev))
+        return comp_fold_leads(comp, [v.cpu().numpy() for v in leads], nh, self.rank)
+
     def check_against_plan(self, plan, rows, next_plan=None):
         """Analytic ground truth of the generator vs the rows this rank owns."""
         d = self.DELTA if self.world > 1 else 0
@@ -297,6 +317,31 @@ class ShardedFasta:
         else:
             ok &= len(rows["boff"]) == npiece
         return bool(ok)
+
+
+# ------------------------------------------------------------------ composition across shards
+def comp_lead_from(bases, last_boffs, r):
+    """Global offset from which the bytes before shard r's first header line are counted: they belong to the last
+    record of the nearest earlier shard that holds a header line, and start no earlier than that record's boff (its
+    header line may cross the cut).  bases[t]: first byte of shard t; last_boffs[t]: boff of the last record that
+    starts in shard t AFTER stitching, -1 if none.  -1: nothing before shard r owns them (fasta.c:901-950 drops
+    the bytes before the first header)."""
+    for t in range(r - 1, -1, -1):
+        if last_boffs[t] >= 0:
+            return max(int(bases[r]), int(last_boffs[t]))
+    return -1
+
+
+def comp_fold_leads(comp, leads, n_hdrs, r):
+    """Add to the last row of shard r's composition the lead rows of the following shards, up to and including the
+    first one that holds a header line (whose lead is what precedes that header).  In place; comp may be empty."""
+    if n_hdrs[r] == 0:
+        return comp
+    for t in range(r + 1, len(leads)):
+        comp[-1] += leads[t]
+        if n_hdrs[t] > 0:
+            break
+    return comp
 
 
 # ------------------------------------------------------------------ FASTQ shards

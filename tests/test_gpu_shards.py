@@ -220,3 +220,60 @@ def test_device_exchange_stream_ordering(oracle, L):
     recs, _ = oracle.fasta_index(raw)
     for c in COLS:
         np.testing.assert_array_equal(got[c], recs[c].astype(got[c].dtype), err_msg=c)
+
+
+def sharded_comp(L, raw, cuts):
+    """k_fasta_comp on every shard + the exchange of shard.py (lead_from / lead rows), with G logical shards."""
+    from pyfastx_amd import shard
+    bounds = [0] + list(cuts) + [len(raw)]
+    blobs, S = [], []
+    for i in range(len(bounds) - 1):
+        lo, hi = bounds[i], bounds[i + 1]
+        b = L.Blob.from_bytes(raw[lo:hi])
+        b.set_shard(lo, raw[lo - 1] if lo else 10, hi == len(raw))
+        s = b.fasta_build(False)
+        blobs.append((b, s.n_seq))
+        S.append(b.shard_summary())
+    last_boff = []
+    for r, (b, n) in enumerate(blobs):
+        row = shard.stitch_tail(S, r, False)
+        if row is not None:
+            b.fasta_set_row(n - 1, **row)
+        last_boff.append(int(b.fasta_table(n)["boff"][-1]) if n else -1)
+    bases, nh = bounds[:-1], [n for _, n in blobs]
+    comps, leads = [], []
+    for r, (b, n) in enumerate(blobs):
+        c, lead = b.fasta_comp_shard(n, shard.comp_lead_from(bases, last_boff, r))
+        comps.append(c); leads.append(lead)
+    out = [shard.comp_fold_leads(comps[r], leads, nh, r) for r in range(len(blobs))]
+    return np.concatenate([c for c in out if len(c)]) if any(len(c) for c in out) else np.zeros((0, 128), dtype=np.int64)
+
+
+def test_composition_across_cuts(oracle, L):
+    """Per-record composition with the stream cut into shards equals the composition of the whole stream: every cut
+    of the edge cases (header lines, CRLF, blank lines crossing the cut), two adjacent cuts, and random cuts of a
+    larger random file whose records span several shards."""
+    for name, case in load_golden("fasta_edge").items():
+        if name.endswith(":upper"):
+            continue
+        raw = case["text"].encode()
+        if len(raw) > 300 or name in ("single_long_line", "wide_then_narrow") or not raw.lstrip().startswith(b">"):
+            continue
+        n = len(oracle.fasta_index(raw)[0])
+        want = oracle.fasta_comp(raw, n)
+        for c in range(1, len(raw)):
+            np.testing.assert_array_equal(sharded_comp(L, raw, [c]), want, err_msg="%s cut %d" % (name, c))
+        for c in range(1, len(raw) - 3, 3):
+            np.testing.assert_array_equal(sharded_comp(L, raw, [c, c + 2]), want, err_msg="%s cuts %d,%d" % (name, c, c + 2))
+    rng = np.random.default_rng(8)
+    parts = []
+    for i in range(9):
+        parts.append(b">rec%d some description that is long enough to cross a cut now and then\n" % i)
+        s = np.frombuffer(b"ACGTNacgtnRY", dtype=np.uint8)[rng.integers(0, 12, int(rng.integers(1, 90000)))].tobytes()
+        parts += [s[p:p + 60] + b"\n" for p in range(0, len(s), 60)]
+    raw = b"".join(parts)
+    want = oracle.fasta_comp(raw, 9)
+    for g in (2, 3, 5, 16):
+        for _ in range(4):
+            cuts = sorted(set(int(x) for x in rng.integers(1, len(raw), g - 1)))
+            np.testing.assert_array_equal(sharded_comp(L, raw, cuts), want, err_msg=str(cuts))

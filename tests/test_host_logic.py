@@ -330,3 +330,49 @@ def test_fxi_bulk_steps_over_the_pending_byte_page(tmp_path, n, width, with_inde
     db.execute("INSERT INTO read VALUES (NULL,'appended',1,2,3,4)")      # SQLite allocates past our pages
     assert db.execute("SELECT ID FROM read WHERE name='appended'").fetchone()[0] == n + 1
     db.close()
+
+
+def test_comp_exchange_logic(oracle):
+    """shard.comp_lead_from / comp_fold_leads (the host side of the sharded composition) against the composition
+    of the whole stream, with the per-shard counting emulated on the CPU: a shard counts the bytes of the records
+    whose header it holds, and -- into its lead row -- the bytes before its first header from lead_from on."""
+    from pyfastx_amd import shard
+    rng = np.random.default_rng(4)
+    for trial in range(40):
+        parts = []
+        for i in range(int(rng.integers(1, 6))):
+            parts.append(b">r%d %s\n" % (i, b"x" * int(rng.integers(0, 40))))
+            s = bytes(rng.choice(list(b"ACGTNacgt"), int(rng.integers(0, 200))).astype(np.uint8))
+            w = int(rng.integers(1, 50))
+            parts += [s[p:p + w] + b"\n" for p in range(0, len(s), w)]
+        raw = (b"junk\n" if trial % 5 == 0 else b"") + b"".join(parts)
+        recs, _ = oracle.fasta_index(raw)
+        n = len(recs)
+        want = oracle.fasta_comp(raw, n)
+        hoff, boff = [int(x) for x in recs["hoff"]], [int(x) for x in recs["boff"]]
+        g = int(rng.integers(2, 6))
+        cuts = sorted(set(int(x) for x in rng.integers(1, len(raw), g - 1)))
+        bounds = [0] + cuts + [len(raw)]
+        owned = [[i for i in range(n) if lo <= hoff[i] < hi] for lo, hi in zip(bounds[:-1], bounds[1:])]
+        last_boffs = [boff[o[-1]] if o else -1 for o in owned]            # after stitching: the true boff
+        comps, leads, nh = [], [], []
+        for r, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
+            c = np.zeros((len(owned[r]), 128), dtype=np.int64)
+            lead = np.zeros(128, dtype=np.int64)
+            lf = shard.comp_lead_from(bounds[:-1], last_boffs, r)
+            first_h = hoff[owned[r][0]] if owned[r] else hi
+            for p in range(lo, hi):
+                b = raw[p]
+                if b == 10 or b >= 128:
+                    continue
+                if p < first_h:
+                    if lf >= 0 and p >= lf:
+                        lead[b] += 1
+                    continue
+                k = max(j for j, i in enumerate(owned[r]) if hoff[i] <= p)
+                if p >= boff[owned[r][k]]:
+                    c[k, b] += 1
+            comps.append(c); leads.append(lead); nh.append(len(owned[r]))
+        got = [shard.comp_fold_leads(comps[r], leads, nh, r) for r in range(len(comps))]
+        got = np.concatenate([x for x in got if len(x)]) if n else np.zeros((0, 128), dtype=np.int64)
+        np.testing.assert_array_equal(got, want, err_msg="trial %d cuts %s" % (trial, cuts))
