@@ -285,7 +285,6 @@ __global__ __launch_bounds__(COMP_WPB * 64) void k_fasta_comp(const uint8_t *__r
     CompState s;
     s.rec = COMP_NONE; s.rare = false;
     comp_reset(s);
-    const int team = 1;
     const int64_t rmin = lead_from >= 0 ? -1 : 0;           // lowest record index that is counted
     auto rec_boff = [&](int64_t r) { return r >= 0 ? uniform64(boff[r]) : lead_from; };   // where the record's sequence bytes begin
     if (PURE) {
@@ -373,7 +372,7 @@ __global__ __launch_bounds__(COMP_WPB * 64) void k_fasta_comp(const uint8_t *__r
         int64_t rr = COMP_NONE, gseg = 0;
         int a = 0, b = 0;
         while (!have && i < cnt) {
-            const int64_t g = gfirst + (int64_t)i * team;
+            const int64_t g = gfirst + i;
             const int64_t gs = g * (int64_t)FX_GRAN;
             const int64_t ge = (gs + FX_GRAN < n) ? gs + FX_GRAN : n;
             gseg = gs;
