@@ -6,12 +6,13 @@
 // the order is an LSD radix sort over them in place: the names are cut into 8-byte big-endian chunks (zero padded),
 // a permutation is stable-sorted by name length first and then by chunk  ceil(maxlen/8)-1, ..., 1, 0; after the last
 // pass it is ordered by (chunk 0, chunk 1, ..., length) = memcmp order with the shorter name first on a tie, which is
-// SQLite's BINARY collation.  Each pass gathers one 8-byte key per name through the current permutation (a random
-// 8-byte read per name) and runs rocPRIM's stable radix sort on (key, index) pairs; a final pass compares neighbours
-// to count duplicate names.  The permutation goes to fx_fxi_bulk_index, which writes the index b-tree from it.
-#include <cstring>                     // before hip_runtime.h: rocPRIM's texture iterator uses memset unqualified
+// SQLite's BINARY collation.  Each chunk gathers one 8-byte key per name through the current permutation (a random
+// 8-byte read per name) and sorts the (key, index) pairs by it with up to eight stable 8-bit counting passes
+// (k_rs_hist / k_rs_scan / k_rs_scatter below); a pass whose digit is the same in every key -- the shared prefix of
+// sequencer read names -- is detected from its histogram and skipped.  A final kernel compares neighbours to count
+// duplicate names.  The permutation goes to fx_fxi_bulk_index, which writes the index b-tree from it.
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
+#include <cstring>
 
 #include "fx_sort.hpp"
 
@@ -50,6 +51,118 @@ __global__ __launch_bounds__(SB) void k_sort_keys(const uint8_t *__restrict__ da
     keys[i] = k;
 }
 
+// ------------------------------------------------------------------ stable 8-bit counting pass over (key, value) pairs
+// A workgroup of 4 waves owns a tile of RS_TILE = 4096 consecutive pairs, wave w the 1024 pairs [w * 1024, ...) of it in
+// 16 rounds of 64 consecutive pairs -- so "earlier in the input" is (workgroup, wave, round, lane), and a pair's place
+// in the output is   start of its digit's bucket  +  pairs with that digit in earlier workgroups  (k_rs_scan)
+//                  + ... in earlier waves of the workgroup + ... in earlier rounds of the wave + ... in lower lanes.
+constexpr int RS_BLOCK = 256, RS_ROUNDS = 16, RS_TILE = RS_BLOCK * RS_ROUNDS;
+
+__device__ __forceinline__ uint32_t rs_incl_scan64(uint32_t v) {     // inclusive prefix sum over the wave (DPP, as wave_incl_scan)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+// lanes of the wave that hold the same 8-bit digit as this one (and are valid): eight ballots
+__device__ __forceinline__ uint64_t rs_peers(uint32_t d, bool valid) {
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t m = __ballot(bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+// hist[bin * nblk + blk] = pairs of tile blk whose digit is bin
+__global__ __launch_bounds__(RS_BLOCK) void k_rs_hist(const uint64_t *__restrict__ keys, int64_t n, int shift, int64_t nblk,
+                                                      uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    h[tid] = 0;
+    __syncthreads();
+    const int64_t start = (int64_t)blockIdx.x * RS_TILE + w * (RS_TILE / 4);
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const int64_t i = start + r * 64 + lane;
+        const bool valid = i < n;
+        const uint32_t d = valid ? (uint32_t)(keys[i] >> shift) & 255u : 0u;
+        const uint64_t peers = rs_peers(d, valid);     // one LDS atomic per distinct digit of the wave, not per pair
+        if (valid && (peers & ((1ull << lane) - 1)) == 0) atomicAdd(&h[d], (uint32_t)__popcll(peers));
+    }
+    __syncthreads();
+    hist[(int64_t)tid * nblk + blockIdx.x] = h[tid];
+}
+
+// one workgroup per bin: hist[bin][*] -> exclusive prefix over the tiles (in place), totals[bin] = its sum
+__global__ __launch_bounds__(RS_BLOCK) void k_rs_scan(uint32_t *__restrict__ hist, int64_t nblk, uint32_t *__restrict__ totals) {
+    __shared__ uint32_t wsum[RS_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    uint32_t *row = hist + (int64_t)blockIdx.x * nblk;
+    const int64_t per = (nblk + RS_BLOCK - 1) / RS_BLOCK, a = tid * per, b = a + per < nblk ? a + per : nblk;
+    uint32_t s = 0;
+    for (int64_t j = a; j < b; ++j) s += row[j];
+    const uint32_t inc = rs_incl_scan64(s);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t base = inc - s;
+    for (int k = 0; k < w; ++k) base += wsum[k];
+    for (int64_t j = a; j < b; ++j) { const uint32_t v = row[j]; row[j] = base; base += v; }
+    if (tid == RS_BLOCK - 1) totals[blockIdx.x] = base;
+}
+
+__global__ __launch_bounds__(RS_BLOCK) void k_rs_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                         uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, int64_t n, int shift,
+                                                         int64_t nblk, const uint32_t *__restrict__ offs, const uint32_t *__restrict__ totals) {
+    __shared__ uint32_t cnt[RS_BLOCK / 64][256];          // per wave: pairs seen so far per digit
+    __shared__ uint32_t base[256];                        // where this tile's pairs of a digit start in the output
+    __shared__ uint32_t wsum[RS_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < RS_BLOCK / 64; ++k) cnt[k][tid] = 0;
+    {                                                     // bucket starts: exclusive scan of the 256 totals
+        const uint32_t t = totals[tid], inc = rs_incl_scan64(t);
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t b = inc - t;
+        for (int k = 0; k < w; ++k) b += wsum[k];
+        base[tid] = b + offs[(int64_t)tid * nblk + blockIdx.x];
+    }
+    __syncthreads();
+    uint64_t k[RS_ROUNDS];
+    uint32_t v[RS_ROUNDS], dr[RS_ROUNDS];                 // digit << 16 | rank among the wave's pairs of that digit
+    const int64_t start = (int64_t)blockIdx.x * RS_TILE + w * (RS_TILE / 4);
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const int64_t i = start + r * 64 + lane;
+        const bool valid = i < n;
+        k[r] = valid ? kin[i] : 0ull;
+        v[r] = valid ? vin[i] : 0u;
+        const uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
+        const uint64_t peers = rs_peers(d, valid);
+        const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1));
+        const uint32_t prior = cnt[w][d];                 // all lanes read before the first lane of each digit adds
+        if (valid && below == 0) cnt[w][d] = prior + (uint32_t)__popcll(peers);
+        dr[r] = (d << 16) | (prior + below);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const int64_t i = start + r * 64 + lane;
+        if (i < n) {
+            const uint32_t d = dr[r] >> 16;
+            uint32_t pos = base[d] + (dr[r] & 0xFFFFu);
+            for (int q = 0; q < w; ++q) pos += cnt[q][d];
+            kout[pos] = k[r];
+            vout[pos] = v[r];
+        }
+    }
+}
+
 __global__ __launch_bounds__(SB) void k_sort_finish(const uint8_t *__restrict__ data, int64_t gbase, const int64_t *__restrict__ name_off,
                                                     const int32_t *__restrict__ name_len, const uint32_t *__restrict__ vals, int64_t n,
                                                     int64_t *__restrict__ order, int64_t *__restrict__ ndup) {
@@ -75,15 +188,39 @@ __global__ __launch_bounds__(SB) void k_sort_finish(const uint8_t *__restrict__ 
         if (e__ != hipSuccess) { *where = what; cleanup(); return (int)e__; } \
     } while (0)
 
+struct RadixScratch { uint32_t *hist = nullptr, *totals = nullptr; int64_t nblk = 0; };
+
+// sort the pairs by bits [begin_bit, end_bit) of the key, stable; cur: index of the buffer pair that holds the data,
+// updated.  Digits that are equal in all keys cost a histogram but no data movement.
+static hipError_t radix_sort_pairs(uint64_t *keys[2], uint32_t *vals[2], int &cur, int64_t n, int begin_bit, int end_bit,
+                                   const RadixScratch &sc, hipStream_t s) {
+    uint32_t totals[256];
+    for (int shift = begin_bit; shift < end_bit; shift += 8) {
+        hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)sc.nblk), dim3(RS_BLOCK), 0, s, keys[cur], n, shift, sc.nblk, sc.hist);
+        hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(RS_BLOCK), 0, s, sc.hist, sc.nblk, sc.totals);
+        hipError_t e = hipMemcpyAsync(totals, sc.totals, sizeof totals, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return e;
+        bool single = false;
+        for (int b = 0; b < 256; ++b) single = single || (int64_t)totals[b] == n;
+        if (single) continue;
+        hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)sc.nblk), dim3(RS_BLOCK), 0, s, keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
+                           n, shift, sc.nblk, sc.hist, sc.totals);
+        cur ^= 1;
+    }
+    return hipGetLastError();
+}
+
 int sort_names(const uint8_t *data, int64_t gbase, const int64_t *name_off, const int32_t *name_len, int64_t n,
                int64_t *d_order, int64_t *d_ndup, hipStream_t s, const char **where) {
     uint64_t *keys[2] = {nullptr, nullptr};
     uint32_t *vals[2] = {nullptr, nullptr};
-    void *tmp = nullptr;
+    RadixScratch sc;
     unsigned *d_max = nullptr;
     auto cleanup = [&]() {
         for (int k = 0; k < 2; ++k) { if (keys[k]) (void)hipFree(keys[k]); if (vals[k]) (void)hipFree(vals[k]); }
-        if (tmp) (void)hipFree(tmp);
+        if (sc.hist) (void)hipFree(sc.hist);
+        if (sc.totals) (void)hipFree(sc.totals);
         if (d_max) (void)hipFree(d_max);
     };
     *where = "";
@@ -94,10 +231,10 @@ int sort_names(const uint8_t *data, int64_t gbase, const int64_t *name_off, cons
         SORTCHK(hipMalloc((void **)&keys[k], N * 8), "hipMalloc(sort keys)");
         SORTCHK(hipMalloc((void **)&vals[k], N * 4), "hipMalloc(sort values)");
     }
+    sc.nblk = (n + RS_TILE - 1) / RS_TILE;
+    SORTCHK(hipMalloc((void **)&sc.hist, (size_t)sc.nblk * 256 * 4), "hipMalloc(sort histograms)");
+    SORTCHK(hipMalloc((void **)&sc.totals, 256 * 4), "hipMalloc");
     SORTCHK(hipMalloc((void **)&d_max, 4), "hipMalloc");
-    size_t tmp_bytes = 0;
-    SORTCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys[0], keys[1], vals[0], vals[1], N, 0u, 64u, s), "radix_sort_pairs(size)");
-    SORTCHK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8), "hipMalloc(sort scratch)");
     SORTCHK(hipMemsetAsync(d_max, 0, 4, s), "memset");
     const unsigned nb = (unsigned)((n + SB - 1) / SB);
     hipLaunchKernelGGL(k_sort_init, dim3(nb), dim3(SB), 0, s, name_len, n, keys[0], vals[0], d_max);
@@ -105,14 +242,12 @@ int sort_names(const uint8_t *data, int64_t gbase, const int64_t *name_off, cons
     SORTCHK(hipMemcpyAsync(&max_len, d_max, 4, hipMemcpyDeviceToHost, s), "memcpy");
     SORTCHK(hipStreamSynchronize(s), "k_sort_init");
     int cur = 0;
-    unsigned len_bits = 1;
-    while (len_bits < 32 && (max_len >> len_bits)) ++len_bits;
-    SORTCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys[cur], keys[cur ^ 1], vals[cur], vals[cur ^ 1], N, 0u, len_bits, s), "radix_sort_pairs(length)");
-    cur ^= 1;
+    int len_bits = 8;
+    while (len_bits < 32 && (max_len >> len_bits)) len_bits += 8;
+    SORTCHK(radix_sort_pairs(keys, vals, cur, n, 0, len_bits, sc, s), "radix passes (length)");
     for (int c = (int)((max_len + 7) / 8) - 1; c >= 0; --c) {
         hipLaunchKernelGGL(k_sort_keys, dim3(nb), dim3(SB), 0, s, data, gbase, name_off, name_len, vals[cur], n, c, keys[cur]);
-        SORTCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys[cur], keys[cur ^ 1], vals[cur], vals[cur ^ 1], N, 0u, 64u, s), "radix_sort_pairs(chunk)");
-        cur ^= 1;
+        SORTCHK(radix_sort_pairs(keys, vals, cur, n, 0, 64, sc, s), "radix passes (chunk)");
     }
     hipLaunchKernelGGL(k_sort_finish, dim3(nb), dim3(SB), 0, s, data, gbase, name_off, name_len, vals[cur], n, d_order, d_ndup);
     SORTCHK(hipGetLastError(), "k_sort_finish");

@@ -1,4 +1,4 @@
-// fx_sort.hpp -- interface of fx_sort.hip (its own translation unit: it is the only one that pulls in rocPRIM).
+// fx_sort.hpp -- interface of fx_sort.hip (order of the record names: a hand-written LSD radix sort, its own unit).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
