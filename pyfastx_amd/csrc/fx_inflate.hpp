@@ -31,7 +31,10 @@
 
 namespace fx {
 
-constexpr int INFL_BLOCK = 64;           // decode: one wave per workgroup, 44 KiB of LDS tables
+#ifndef FX_INFL_BLOCK
+#define FX_INFL_BLOCK 64
+#endif
+constexpr int INFL_BLOCK = FX_INFL_BLOCK; // decode: members per workgroup (one wave, possibly partly filled); 0.7 KiB of LDS tables each
 constexpr int MAXBITS = 15, MAXLCODES = 286, MAXDCODES = 30, FIXLCODES = 288;
 
 enum InflStatus { INFL_OK = 0, INFL_EINPUT = 1, INFL_EOUTPUT = 2, INFL_EBLOCK = 3, INFL_ECODES = 4, INFL_EDIST = 5,
