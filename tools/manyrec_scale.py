@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""A FASTA of MANY small records (transcriptome / metagenome shape) at scale on one MI355X: every 4 KiB granule holds
+several header lines, so the build runs through k_hdr_rec / k_gran_exact everywhere and the composition through the
+segment path of k_fasta_comp.  Index rows, composition and by-name fetches are verified against the generator's
+analytic truth; the .fxi (seq table + chromidx) is written as b-tree pages and checked by SQLite.
+usage: python tools/manyrec_scale.py [n_records] [bases_per_record]   (default 5 M x 300)"""
+import json
+import os
+import sqlite3
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pyfastx_amd import _lib, fxi  # noqa: E402
+
+
+def main():
+    n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 5_000_000
+    L = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    W = 60
+    dev = torch.device("cuda", 0)
+    head = b">tx0000000 gene=G len=%d\n" % L
+    hl = len(head)
+    nlines = (L + W - 1) // W
+    rec = hl + L + nlines
+    t = torch.empty((n, rec), dtype=torch.uint8, device=dev)
+    t[:, :hl] = torch.frombuffer(bytearray(head), dtype=torch.uint8).to(dev)
+    idx = torch.arange(n, device=dev, dtype=torch.int64)
+    for k in range(7):
+        t[:, 9 - k] = (48 + (idx // (10 ** k)) % 10).to(torch.uint8)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    lut = torch.tensor(list(b"ACGTacgtNn"), dtype=torch.uint8, device=dev)
+    body = t[:, hl:].view(n, nlines, -1) if (L % W == 0) else None
+    seq_cols = []                                            # column indices of the bases inside a record
+    for j in range(L):
+        seq_cols.append(hl + j + j // W)
+    seq_cols = torch.tensor(seq_cols, device=dev)
+    step = 1 << 18
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        r = torch.randint(0, 1000, (b - a, L), device=dev, generator=g)
+        bases = lut[(r & 7).long()]
+        bases[r >= 995] = lut[8 + (r[r >= 995] & 1)]
+        t[a:b, seq_cols] = bases
+    nl_cols = torch.tensor([hl + min((k + 1) * W, L) + k for k in range(nlines)], device=dev)
+    t[:, nl_cols] = 10
+    nb = n * rec
+    blob_t = torch.zeros(nb + 131072, dtype=torch.uint8, device=dev)
+    blob_t[:nb] = t.view(-1)
+    b = _lib.Blob.from_device(blob_t.data_ptr(), nb, device=0, keepalive=blob_t)
+    b.fasta_build()                                          # warm-up (allocations)
+    b.prof_enable(True); b.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        s = b.fasta_build()
+    t1 = time.perf_counter()
+    assert (s.n_seq, s.seq_len) == (n, n * L), (s.n_seq, s.seq_len)
+    rows = b.fasta_table(n)
+    i = np.arange(n, dtype=np.int64)
+    want = {"hoff": i * rec, "boff": i * rec + hl, "blen": np.full(n, L + nlines), "slen": np.full(n, L),
+            "llen": np.full(n, min(W, L) + 1), "elen": np.full(n, 1), "norm": np.full(n, 1), "dlen": np.full(n, hl - 2),
+            "name_len": np.full(n, 9)}
+    for k, v in want.items():
+        assert (rows[k] == v).all(), k
+    t2 = time.perf_counter()
+    comp = b.fasta_comp(n)
+    t3 = time.perf_counter()
+    seqs = t[:, seq_cols]
+    for c in b"ACGTacgtNn":
+        assert (torch.from_numpy(comp[:, c]).to(dev) == (seqs == c).sum(dim=1)).all(), chr(c)
+    assert int(comp.sum()) == n * L
+    # names: hash table + sort + the .fxi as pages
+    t4 = time.perf_counter()
+    order, ndup = b.names_sort(0, n)
+    t5 = time.perf_counter()
+    assert ndup == 0 and (order == i).all()                  # zero-padded numbers: already in order
+    ln = rows["name_len"].astype(np.int64)
+    packed, offs, _ = b.fetch_ranges(rows["hoff"] + 1, ln, ln, flags=_lib.FX_RAW)
+    path = "/dev/shm/manyrec.fxi" if os.path.isdir("/dev/shm") else "/tmp/manyrec.fxi"
+    if os.path.exists(path):
+        os.remove(path)
+    t6 = time.perf_counter()
+    db = fxi.write_fasta_bulk(path, packed[:int(offs[-1])], offs, rows, s.seq_len, order=order)
+    db.close()
+    t7 = time.perf_counter()
+    db = sqlite3.connect(path)
+    assert db.execute("PRAGMA integrity_check").fetchall() == [("ok",)]
+    rng = np.random.default_rng(1)
+    for j in rng.integers(0, n, 100).tolist():
+        assert db.execute("SELECT ID, boff, slen FROM seq WHERE chrom=?", ("tx%07d" % j,)).fetchone() == (j + 1, j * rec + hl, L)
+    db.close()
+    size = os.path.getsize(path)
+    os.remove(path)
+    prof = {k: round(v[0] / v[1], 4) for k, v in b.prof_read().items()}
+    print(json.dumps({"workload": "synthetic FASTA %d records x %d bp (%.2f GB), %d-column lines" % (n, L, nb / 1e9, W),
+                      "index_build_ms": round((t1 - t0) / 3 * 1e3, 3), "index_build_GBps": round(nb / ((t1 - t0) / 3) / 1e9, 1),
+                      "composition_ms": round((t3 - t2) * 1e3, 2), "names_sort_ms": round((t5 - t4) * 1e3, 1),
+                      "fxi_write_s": round(t7 - t6, 2), "fxi_MB": round(size / 1e6, 1), "fxi_rows_per_s_M": round(n / (t7 - t6) / 1e6, 2),
+                      "kernels_ms_avg": prof, "verified": True}))
+
+
+if __name__ == "__main__":
+    main()
