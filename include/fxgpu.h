@@ -133,6 +133,13 @@ int fx_fasta_comp(fx_handle *h, int where, int64_t *comp);
  * left out (lead_from < 0: nothing is counted, e.g. shard 0).  The owner of the record adds the lead rows of the
  * following shards up to and including the first one that holds a header line (pyfastx_amd/shard.py).              */
 int fx_fasta_comp_shard(fx_handle *h, int where, int64_t *comp, int64_t lead_from, int64_t *lead);
+/* The same composition in the form the `comp` table stores it (fasta.c:904-914): only the non-zero bins, as triples
+ * (seqid = record index + 1, abc = byte value, num = count) in record order, letters ascending -- the dense matrix
+ * never leaves HBM (5 M records: 5 GB dense, ~50 M triples).  cap: room in seqid / abc / num (where = FX_HOST /
+ * FX_DEVICE); *n_out: number of triples -- with FX_ERANGE when it exceeds cap (nothing is written then);
+ * total[128] (host): column sums, the seqid = 0 rows of the table (fasta.c:943-950). */
+int fx_fasta_comp_sparse(fx_handle *h, int where, int64_t cap, int64_t *seqid, int64_t *abc, int64_t *num,
+                         int64_t *n_out, int64_t *total);
 
 /* ------------------------------------------------------------ FASTQ index
  * Replaces pyfastx_fastq_create_index (fastq.c:89-171).                      */
@@ -250,6 +257,10 @@ int fx_fxi_bulk_rows(const char *path, int rootpage, int64_t n, const uint8_t *n
  * FX_ERANGE: an entry would need an overflow page -- let SQLite build the index. */
 int fx_fxi_bulk_index(const char *path, int rootpage, int64_t n, const uint8_t *names, const int64_t *name_off,
                       const int64_t *order);
+/* A non-unique INDEX on an INTEGER column (fasta.c:952 `CREATE INDEX seqidx ON comp (seqid)`): key[row], order[i] =
+ * row of the i-th entry in (key, rowid) order.  fx_fxi_bulk_rows with names = name_off = NULL loads a table without a
+ * TEXT column (`comp`: rowid, then cols[] as INTEGERs). */
+int fx_fxi_bulk_index_int(const char *path, int rootpage, int64_t n, const int64_t *key, const int64_t *order);
 
 /* ------------------------------------------------------- sync and timing
  * Calls that take FX_DEVICE arrays return after ENQUEUEING work on the

@@ -42,9 +42,9 @@ class ShardSummary(C.Structure):
 SYMBOLS = [
     "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_host", "fx_open_device",
     "fx_set_shard", "fx_close", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
-    "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
+    "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_revcomp", "fx_shard_summary_get",
-    "fx_fasta_set_row", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
+    "fx_fasta_set_row", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
 ]
 
 
@@ -54,11 +54,15 @@ def so_path():
 
 def fxi_bulk_rows(path, rootpage, packed_names, name_off, cols):
     """Host-side bulk load of an index table (fx_fxi_bulk_rows): packed_names uint8, name_off int64[n+1],
-    cols: list of int64 arrays.  The database file must have no open connection."""
-    names = np.ascontiguousarray(packed_names, dtype=np.uint8)
-    offs = np.ascontiguousarray(name_off, dtype=np.int64)
+    cols: list of int64 arrays.  packed_names = name_off = None: a table without a TEXT column (comp).
+    The database file must have no open connection."""
     arrs = [np.ascontiguousarray(c, dtype=np.int64) for c in cols]
     ptrs = (C.c_void_p * max(len(arrs), 1))(*[a.ctypes.data for a in arrs])
+    if name_off is None:
+        check(lib().fx_fxi_bulk_rows(os.fsencode(path), int(rootpage), arrs[0].size if arrs else 0, None, None, len(arrs), ptrs))
+        return
+    names = np.ascontiguousarray(packed_names, dtype=np.uint8)
+    offs = np.ascontiguousarray(name_off, dtype=np.int64)
     check(lib().fx_fxi_bulk_rows(os.fsencode(path), int(rootpage), offs.size - 1, names.ctypes.data if names.size else None,
                                  offs.ctypes.data, len(arrs), ptrs))
 
@@ -73,6 +77,16 @@ def fxi_bulk_index(path, rootpage, packed_names, name_off, order):
         raise ValueError("order must have one entry per row")
     check(lib().fx_fxi_bulk_index(os.fsencode(path), int(rootpage), offs.size - 1, names.ctypes.data if names.size else None,
                                   offs.ctypes.data, order.ctypes.data if order.size else None))
+
+
+def fxi_bulk_index_int(path, rootpage, key, order):
+    """Host-side bulk load of a non-unique INDEX on an INTEGER column (fx_fxi_bulk_index_int)."""
+    key = np.ascontiguousarray(key, dtype=np.int64)
+    order = np.ascontiguousarray(order, dtype=np.int64)
+    if key.size != order.size:
+        raise ValueError("one key and one order entry per row")
+    check(lib().fx_fxi_bulk_index_int(os.fsencode(path), int(rootpage), key.size, key.ctypes.data if key.size else None,
+                                      order.ctypes.data if order.size else None))
 
 
 def lib():
@@ -112,6 +126,7 @@ def lib():
     L.fx_fasta_set_table.argtypes = [vp, i64] + [vp] * 6
     L.fx_fasta_comp.argtypes = [vp, i32, vp]
     L.fx_fasta_comp_shard.argtypes = [vp, i32, vp, i64, vp]
+    L.fx_fasta_comp_sparse.argtypes = [vp, i32, i64, vp, vp, vp, C.POINTER(i64), vp]
     L.fx_fastq_build.argtypes = [vp, C.POINTER(FastqSummary)]
     L.fx_fastq_table.argtypes = [vp, i32] + [vp] * 6
     L.fx_set_halo.argtypes = [vp, i64]
@@ -135,6 +150,7 @@ def lib():
     L.fx_names_sort.argtypes = [vp, i32, i32, vp, C.POINTER(i64)]
     L.fx_fxi_bulk_rows.argtypes = [C.c_char_p, i32, i64, vp, vp, i32, vp]
     L.fx_fxi_bulk_index.argtypes = [C.c_char_p, i32, i64, vp, vp, vp]
+    L.fx_fxi_bulk_index_int.argtypes = [C.c_char_p, i32, i64, vp, vp]
     L.fx_sync.argtypes = [vp]
     L.fx_prof_enable.argtypes = [vp, i32]
     L.fx_prof_default.argtypes = [i32]
@@ -323,6 +339,22 @@ class Blob:
         comp = np.zeros((n, 128), dtype=np.int64)
         check(lib().fx_fasta_comp(self._h, FX_HOST, comp.ctypes.data))
         return comp
+
+    def fasta_comp_sparse(self, guess=0):
+        """-> (seqid, abc, num int64 arrays: the non-zero bins in record order, seqid 1-based; total int64[128])."""
+        total = np.zeros(128, dtype=np.int64)
+        cap = int(guess)
+        for _ in range(2):
+            arrs = [np.empty(max(cap, 1), dtype=np.int64) for _ in range(3)]
+            nout = C.c_int64(0)
+            rc = lib().fx_fasta_comp_sparse(self._h, FX_HOST, cap, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data,
+                                            C.byref(nout), total.ctypes.data)
+            if rc == FX_ERANGE and nout.value > cap:
+                cap = int(nout.value)
+                continue
+            check(rc)
+            return arrs[0][:nout.value], arrs[1][:nout.value], arrs[2][:nout.value], total
+        raise FxError(FX_ERANGE, "composition did not fit twice")
 
     def fasta_comp_shard(self, n, lead_from):
         """-> (comp int64[n,128] of the records that start in this shard, lead int64[128]: the bytes before the

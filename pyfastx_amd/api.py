@@ -17,6 +17,7 @@ from . import _lib, fxi
 
 VERSION = "2.3.1"          # API level mirrored (reference src/version.h:1)
 
+_COMP_BULK_MIN = 50_000          # records from which the comp table is bulk-loaded (see Fasta._calc_composition)
 _F_UP, _F_REV, _F_COMP, _F_RAW = _lib.FX_UPPER, _lib.FX_REVERSE, _lib.FX_COMPLEMENT, _lib.FX_RAW
 
 
@@ -194,7 +195,16 @@ class Fasta:
             return
         blob = self._st.blob
         s = blob.fasta_build(self._full_name)
-        fxi.write_fasta_comp(self._db, blob.fasta_comp(s.n_seq))
+        if s.n_seq >= _COMP_BULK_MIN and self._index_file != ":memory:":
+            # many records: the non-zero bins come off the GPU as triples (the dense matrix stays in HBM) and the
+            # comp table + seqidx go into the file as b-tree pages instead of ~10 INSERTs per record
+            seqid, abc, num, total = blob.fasta_comp_sparse(guess=s.n_seq * 12)
+            self._db.close()
+            self._db = fxi.write_fasta_comp_bulk(
+                self._index_file, np.concatenate([seqid, np.zeros(128, dtype=np.int64)]),
+                np.concatenate([abc, np.arange(128, dtype=np.int64)]), np.concatenate([num, total]))
+        else:
+            fxi.write_fasta_comp(self._db, blob.fasta_comp(s.n_seq))
         self._full_index = True
 
     def _total_comp(self):

@@ -415,4 +415,90 @@ __global__ __launch_bounds__(COMP_WPB * 64) void k_fasta_comp(const uint8_t *__r
     }
 }
 
+// ------------------------------------------------------------------ sparse form of the composition
+// The `comp` table of the .fxi holds only the non-zero bins of a record (fasta.c:904-914) -- about ten of 128 for DNA --
+// and a dense matrix of a many-record file is large (5 M records: 5 GB; a protein database: more than the host has):
+// k_comp_count / k_comp_emit turn the dense rows, which stay in HBM, into (record, letter, count) triples in record
+// order, and the column totals.  One wave per record (grid-stride): lane l looks at bins l and l + 64.
+__global__ __launch_bounds__(BLOCK) void k_comp_count(const unsigned long long *__restrict__ comp, int64_t n_rec,
+                                                     int32_t *__restrict__ cnt, unsigned long long *__restrict__ total) {
+    const int lane = lane_id();
+    const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
+    unsigned long long s0 = 0, s1 = 0;
+    for (int64_t r = wave; r < n_rec; r += nwaves) {
+        const unsigned long long a = comp[r * 128 + lane], b = comp[r * 128 + 64 + lane];
+        s0 += a; s1 += b;
+        const int c = __popcll(__ballot(a != 0)) + __popcll(__ballot(b != 0));
+        if (lane == 0) cnt[r] = c;
+    }
+    if (s0) atomicAdd(&total[lane], s0);
+    if (s1) atomicAdd(&total[64 + lane], s1);
+}
+
+// exclusive prefix sum of cnt[0..n) into off[0..n] (off[n] = total), three small kernels, 1024 elements per workgroup
+constexpr int SCAN_CHUNK = 1024;
+__global__ __launch_bounds__(BLOCK) void k_cnt_chunk_sums(const int32_t *__restrict__ cnt, int64_t n, int64_t *__restrict__ sums) {
+    __shared__ uint32_t lds4[BLOCK / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+    uint32_t s = 0;
+    for (int k = threadIdx.x; k < SCAN_CHUNK; k += BLOCK) if (base + k < n) s += (uint32_t)cnt[base + k];
+    s = block_sum(s, lds4);
+    if (threadIdx.x == 0) sums[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(BLOCK) void k_cnt_chunk_bases(int64_t *__restrict__ sums, int64_t nchunks) {   // one workgroup: in place -> exclusive
+    __shared__ int64_t wtot[BLOCK / 64];
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t a = 0; a < nchunks; a += BLOCK) {
+        const int64_t i = a + threadIdx.x;
+        const int64_t v = i < nchunks ? sums[i] : 0;
+        int64_t inc = v;                                    // inclusive scan over the wave (shuffles: 64-bit values)
+        for (int d = 1; d < 64; d <<= 1) { const int64_t t = __shfl_up(inc, d, 64); if (lane_id() >= d) inc += t; }
+        if (lane_id() == 63) wtot[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        int64_t b = carry;
+        for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) b += wtot[k];
+        if (i < nchunks) sums[i] = b + inc - v;
+        __syncthreads();
+        if (threadIdx.x == BLOCK - 1) carry = b + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[nchunks] = carry;            // grand total
+}
+__global__ __launch_bounds__(BLOCK) void k_cnt_offsets(const int32_t *__restrict__ cnt, int64_t n, const int64_t *__restrict__ bases,
+                                                      int64_t *__restrict__ off) {
+    __shared__ uint32_t wtot[BLOCK / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    // thread t owns elements base + 4t .. 4t+3 (consecutive, so one pass of wave scans is enough)
+    uint32_t v[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int64_t i = base + 4 * threadIdx.x + k; v[k] = i < n ? (uint32_t)cnt[i] : 0u; s += v[k]; }
+    const uint32_t inc = wave_incl_scan(s);
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    uint32_t b = inc - s;
+    for (int k = 0; k < w; ++k) b += wtot[k];
+    int64_t o = bases[blockIdx.x] + b;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int64_t i = base + 4 * threadIdx.x + k; if (i < n) off[i] = o; o += v[k]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) off[n] = bases[gridDim.x];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_comp_emit(const unsigned long long *__restrict__ comp, int64_t n_rec,
+                                                    const int64_t *__restrict__ off, int64_t *__restrict__ seqid,
+                                                    int64_t *__restrict__ abc, int64_t *__restrict__ num) {
+    const int lane = lane_id();
+    const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
+    const uint64_t lt = (1ull << lane) - 1;
+    for (int64_t r = wave; r < n_rec; r += nwaves) {
+        const unsigned long long a = comp[r * 128 + lane], b = comp[r * 128 + 64 + lane];
+        const uint64_t ma = __ballot(a != 0), mb = __ballot(b != 0);
+        const int64_t o = off[r];
+        if (a) { const int64_t p = o + __popcll(ma & lt); seqid[p] = r + 1; abc[p] = lane; num[p] = (int64_t)a; }
+        if (b) { const int64_t p = o + __popcll(ma) + __popcll(mb & lt); seqid[p] = r + 1; abc[p] = 64 + lane; num[p] = (int64_t)b; }
+    }
+}
+
 }  // namespace fx

@@ -74,7 +74,7 @@ static inline void put_be(uint8_t *p, uint64_t v, int n) { for (int i = n - 1; i
 
 struct Rows {
     int64_t n;
-    const uint8_t *names;
+    const uint8_t *names;             // null (with name_off null): the table has no TEXT column after the key
     const int64_t *name_off;          // n + 1 offsets into names
     int ncols;
     const int64_t *const *cols;
@@ -83,8 +83,9 @@ struct Rows {
 // size of the leaf cell of row i (payload-size varint + rowid varint + record); 0 when the row cannot be
 // stored without an overflow page
 static inline int cell_size(const Rows &r, int64_t i, int usable) {
-    const int64_t L = r.name_off[i + 1] - r.name_off[i];
-    const int tlen = varint_len((uint64_t)(13 + 2 * L));
+    const bool text = r.name_off != nullptr;
+    const int64_t L = text ? r.name_off[i + 1] - r.name_off[i] : 0;
+    const int tlen = text ? varint_len((uint64_t)(13 + 2 * L)) : 0;
     int hdr = 1 + 1 + tlen + r.ncols, body = (int)L;
     for (int c = 0; c < r.ncols; ++c) { int nb; int_serial(r.cols[c][i], &nb); body += nb; }
     const int64_t payload = hdr + body;
@@ -92,8 +93,9 @@ static inline int cell_size(const Rows &r, int64_t i, int usable) {
     return varint_len((uint64_t)payload) + varint_len((uint64_t)(i + 1)) + (int)payload;
 }
 static inline int put_cell(uint8_t *p, const Rows &r, int64_t i) {
-    const int64_t L = r.name_off[i + 1] - r.name_off[i];
-    const int tlen = varint_len((uint64_t)(13 + 2 * L));
+    const bool text = r.name_off != nullptr;
+    const int64_t L = text ? r.name_off[i + 1] - r.name_off[i] : 0;
+    const int tlen = text ? varint_len((uint64_t)(13 + 2 * L)) : 0;
     const int hdr = 1 + 1 + tlen + r.ncols;
     int body = (int)L, nb[16], st[16];
     for (int c = 0; c < r.ncols; ++c) { st[c] = int_serial(r.cols[c][i], &nb[c]); body += nb[c]; }
@@ -102,9 +104,9 @@ static inline int put_cell(uint8_t *p, const Rows &r, int64_t i) {
     q += put_varint(q, (uint64_t)(i + 1));
     *q++ = (uint8_t)hdr;
     *q++ = 0;                                              // INTEGER PRIMARY KEY column: NULL, the rowid is the value
-    q += put_varint(q, (uint64_t)(13 + 2 * L));
+    if (text) q += put_varint(q, (uint64_t)(13 + 2 * L));
     for (int c = 0; c < r.ncols; ++c) *q++ = (uint8_t)st[c];
-    memcpy(q, r.names + r.name_off[i], (size_t)L); q += L;
+    if (L) { memcpy(q, r.names + r.name_off[i], (size_t)L); q += L; }
     for (int c = 0; c < r.ncols; ++c) { put_be(q, (uint64_t)r.cols[c][i], nb[c]); q += nb[c]; }
     return (int)(q - p);
 }
@@ -285,27 +287,39 @@ static int bulk_load_table(const char *path, uint32_t rootpage, const Rows &r) {
 // as the divider of its parent, and the same happens between the pages of every upper level.
 struct Entries {
     int64_t n;
-    const uint8_t *names;             // packed in ROW order (the same buffer the table loader got)
-    const int64_t *name_off;          // n + 1
-    const int64_t *order;             // order[i] = 0-based row of the i-th smallest name; its rowid is order[i] + 1
+    const uint8_t *names;             // TEXT key: packed in ROW order (the same buffer the table loader got) ...
+    const int64_t *name_off;          // ... n + 1 offsets
+    const int64_t *ikey;              // or INTEGER key (names / name_off null): ikey[row]
+    const int64_t *order;             // order[i] = 0-based row of the i-th smallest key; its rowid is order[i] + 1
 };
 static inline int entry_payload(const Entries &e, int64_t i) {
-    const int64_t r = e.order[i], L = e.name_off[r + 1] - e.name_off[r];
-    int nb;
+    const int64_t r = e.order[i];
+    int nb, kb;
     int_serial(r + 1, &nb);
+    if (e.ikey) { int_serial(e.ikey[r], &kb); return 1 + 1 + 1 + kb + nb; }
+    const int64_t L = e.name_off[r + 1] - e.name_off[r];
     return 1 + varint_len((uint64_t)(13 + 2 * L)) + 1 + (int)L + nb;
 }
-static inline int put_entry(uint8_t *p, const Entries &e, int64_t i) {      // varint(payload) + record(name, rowid)
-    const int64_t r = e.order[i], L = e.name_off[r + 1] - e.name_off[r];
+static inline int put_entry(uint8_t *p, const Entries &e, int64_t i) {      // varint(payload) + record(key, rowid)
+    const int64_t r = e.order[i];
     int nb;
     const int st = int_serial(r + 1, &nb);
-    const int tlen = varint_len((uint64_t)(13 + 2 * L));
     uint8_t *q = p;
-    q += put_varint(q, (uint64_t)(1 + tlen + 1 + L + nb));
-    *q++ = (uint8_t)(1 + tlen + 1);
-    q += put_varint(q, (uint64_t)(13 + 2 * L));
-    *q++ = (uint8_t)st;
-    memcpy(q, e.names + e.name_off[r], (size_t)L); q += L;
+    if (e.ikey) {
+        int kb;
+        const int kst = int_serial(e.ikey[r], &kb);
+        q += put_varint(q, (uint64_t)(3 + kb + nb));
+        *q++ = 3; *q++ = (uint8_t)kst; *q++ = (uint8_t)st;
+        put_be(q, (uint64_t)e.ikey[r], kb); q += kb;
+    } else {
+        const int64_t L = e.name_off[r + 1] - e.name_off[r];
+        const int tlen = varint_len((uint64_t)(13 + 2 * L));
+        q += put_varint(q, (uint64_t)(1 + tlen + 1 + L + nb));
+        *q++ = (uint8_t)(1 + tlen + 1);
+        q += put_varint(q, (uint64_t)(13 + 2 * L));
+        *q++ = (uint8_t)st;
+        if (L) { memcpy(q, e.names + e.name_off[r], (size_t)L); q += L; }
+    }
     put_be(q, (uint64_t)(r + 1), nb); q += nb;
     return (int)(q - p);
 }

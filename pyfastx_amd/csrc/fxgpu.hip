@@ -761,16 +761,13 @@ extern "C" int fx_fasta_table(fx_handle *h, int where, int64_t *hoff, int64_t *b
     return FX_OK;
 }
 
-// comp: n_hdr x 128 (where = FX_HOST / FX_DEVICE); lead (host, 128 words or null): counts of the bytes before the
-// shard's first header line from global offset lead_from on (lead_from < 0: not counted)
-static int fasta_comp_impl(fx_handle *h, int where, int64_t *comp, int64_t lead_from, int64_t *lead) {
-    if (!h || !comp) return fail(FX_EINVAL, "null argument");
+// dense composition of the records of this handle into tmp (n_hdr rows + the row of the leading bytes), enqueued
+static int fasta_comp_dense(fx_handle *h, int64_t lead_from, DevBuf<unsigned long long> &tmp, DevBuf<int32_t> &edge) {
     if (!h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build has not run");
     int rc = use_device(h);
     if (!rc) rc = finish_build(h);
     if (rc) return rc;
     const int64_t n = h->n_hdr * 128;
-    DevBuf<unsigned long long> tmp;                          // n_hdr rows + the row of the leading bytes
     if ((rc = tmp.alloc(n + 128))) return rc;
     unsigned long long *d = tmp.p;
     HIPCHK(hipMemsetAsync(d, 0, (size_t)(n + 128) * 8, h->stream));
@@ -779,16 +776,71 @@ static int fasta_comp_impl(fx_handle *h, int where, int64_t *comp, int64_t lead_
     const int gpw = h->ngran >= 65536 ? 4 * COMP_DEPTH : h->ngran >= 16384 ? 2 * COMP_DEPTH : COMP_DEPTH;
     const int64_t waves = (h->ngran + gpw - 1) / gpw;
     const dim3 grid((unsigned)((waves + COMP_WPB - 1) / COMP_WPB));
-    DevBuf<int32_t> edge;                                    // [0]: number of runs left to the second launch, [1..]: their ids
-    if ((rc = edge.alloc(waves + 1))) return rc;
+    if ((rc = edge.alloc(waves + 1))) return rc;            // [0]: number of runs left to the second launch, [1..]: their ids
     HIPCHK(hipMemsetAsync(edge.p, 0, 4, h->stream));
     FX_LAUNCH(h, K_FASTA_COMP, k_fasta_comp<true>, grid, dim3(COMP_WPB * 64), h->d_data, h->n, h->base,
                        h->hdr.p, h->fa_boff.p, h->n_hdr, h->hdr_prefix.p, h->ngran, gpw, edge.p, lead_from, d);
     FX_LAUNCH(h, K_FASTA_COMP_EDGE, k_fasta_comp<false>, grid, dim3(COMP_WPB * 64), h->d_data, h->n, h->base,
                        h->hdr.p, h->fa_boff.p, h->n_hdr, h->hdr_prefix.p, h->ngran, gpw, edge.p, lead_from, d);
     HIPCHK(hipGetLastError());
-    if (n) HIPCHK(hipMemcpyAsync(comp, d, (size_t)n * 8, where == FX_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
-    if (lead) HIPCHK(hipMemcpyAsync(lead, d + n, 128 * 8, hipMemcpyDeviceToHost, h->stream));
+    return FX_OK;
+}
+
+// comp: n_hdr x 128 (where = FX_HOST / FX_DEVICE); lead (host, 128 words or null): counts of the bytes before the
+// shard's first header line from global offset lead_from on (lead_from < 0: not counted)
+static int fasta_comp_impl(fx_handle *h, int where, int64_t *comp, int64_t lead_from, int64_t *lead) {
+    if (!h || !comp) return fail(FX_EINVAL, "null argument");
+    DevBuf<unsigned long long> tmp;
+    DevBuf<int32_t> edge;
+    int rc = fasta_comp_dense(h, lead_from, tmp, edge);
+    if (rc) return rc;
+    const int64_t n = h->n_hdr * 128;
+    if (n) HIPCHK(hipMemcpyAsync(comp, tmp.p, (size_t)n * 8, where == FX_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    if (lead) HIPCHK(hipMemcpyAsync(lead, tmp.p + n, 128 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FX_OK;
+}
+
+extern "C" int fx_fasta_comp_sparse(fx_handle *h, int where, int64_t cap, int64_t *seqid, int64_t *abc, int64_t *num,
+                                    int64_t *n_out, int64_t *total) {
+    if (!h || !n_out || !total || cap < 0 || (cap > 0 && (!seqid || !abc || !num))) return fail(FX_EINVAL, "bad argument");
+    DevBuf<unsigned long long> dense, tot;
+    DevBuf<int32_t> edge, cnt;
+    DevBuf<int64_t> sums, off, out;
+    int rc = fasta_comp_dense(h, -1, dense, edge);
+    if (rc) return rc;
+    const int64_t n = h->n_hdr, nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if ((rc = tot.alloc(128)) || (rc = cnt.alloc(std::max<int64_t>(n, 1))) || (rc = sums.alloc(nchunks + 1)) || (rc = off.alloc(n + 1))) return rc;
+    HIPCHK(hipMemsetAsync(tot.p, 0, 128 * 8, h->stream));
+    HIPCHK(hipMemsetAsync(off.p, 0, (size_t)(n + 1) * 8, h->stream));
+    if (n) {
+        const unsigned nb = (unsigned)std::min<int64_t>(nblocks(n, BLOCK / 64), 2048);
+        hipLaunchKernelGGL(k_comp_count, dim3(nb), dim3(BLOCK), 0, h->stream, dense.p, n, cnt.p, tot.p);
+        hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, cnt.p, n, sums.p);
+        hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, sums.p, nchunks);
+        hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, cnt.p, n, sums.p, off.p);
+        HIPCHK(hipGetLastError());
+    }
+    int64_t count = 0;
+    HIPCHK(hipMemcpyAsync(&count, off.p + n, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(total, tot.p, 128 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *n_out = count;
+    if (count > cap) return fail(FX_ERANGE, "%lld triples, room for %lld", (long long)count, (long long)cap);
+    if (count == 0) return FX_OK;
+    int64_t *ds = seqid, *da = abc, *dn = num;
+    if (where != FX_DEVICE) {
+        if ((rc = out.alloc(3 * count))) return rc;
+        ds = out.p; da = out.p + count; dn = out.p + 2 * count;
+    }
+    const unsigned nb = (unsigned)std::min<int64_t>(nblocks(n, BLOCK / 64), 2048);
+    hipLaunchKernelGGL(k_comp_emit, dim3(nb), dim3(BLOCK), 0, h->stream, dense.p, n, off.p, ds, da, dn);
+    HIPCHK(hipGetLastError());
+    if (where != FX_DEVICE) {
+        HIPCHK(hipMemcpyAsync(seqid, ds, (size_t)count * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(abc, da, (size_t)count * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(num, dn, (size_t)count * 8, hipMemcpyDeviceToHost, h->stream));
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     return FX_OK;
 }
@@ -1404,7 +1456,9 @@ extern "C" int fx_fasta_set_row(fx_handle *h, int64_t k, int64_t boff, int64_t b
 // ------------------------------------------------------------- .fxi bulk load (host side)
 extern "C" int fx_fxi_bulk_rows(const char *path, int rootpage, int64_t n, const uint8_t *names, const int64_t *name_off,
                                 int ncols, const int64_t *const *cols) {
-    if (!path || n < 0 || (n > 0 && (!name_off || (!names && name_off[n] > 0) || (ncols > 0 && !cols)))) return fail(FX_EINVAL, "bad argument");
+    // names == name_off == null: a table without a TEXT column (comp)
+    if (!path || n < 0 || (n > 0 && ((name_off && !names && name_off[n] > 0) || (!name_off && names) || (ncols > 0 && !cols))))
+        return fail(FX_EINVAL, "bad argument");
     const fxi::Rows r{n, names, name_off, ncols, cols};
     const int rc = fxi::bulk_load_table(path, (uint32_t)rootpage, r);
     if (rc == fxi::E_ROW) return fail(FX_ERANGE, "a row does not fit a b-tree page without overflow: use the INSERT path");
@@ -1416,9 +1470,18 @@ extern "C" int fx_fxi_bulk_rows(const char *path, int rootpage, int64_t n, const
 extern "C" int fx_fxi_bulk_index(const char *path, int rootpage, int64_t n, const uint8_t *names, const int64_t *name_off,
                                  const int64_t *order) {
     if (!path || n < 0 || (n > 0 && (!name_off || !order || (!names && name_off[n] > 0)))) return fail(FX_EINVAL, "bad argument");
-    const fxi::Entries e{n, names, name_off, order};
+    const fxi::Entries e{n, names, name_off, nullptr, order};
     const int rc = fxi::bulk_load_index(path, (uint32_t)rootpage, e);
     if (rc == fxi::E_ROW) return fail(FX_ERANGE, "an index entry does not fit a b-tree page without overflow: use CREATE INDEX");
+    if (rc == fxi::E_IO) return fail(FX_EIO, "cannot write %s", path);
+    if (rc) return fail(FX_EINVAL, "%s is not a SQLite database this loader can extend", path);
+    return FX_OK;
+}
+
+extern "C" int fx_fxi_bulk_index_int(const char *path, int rootpage, int64_t n, const int64_t *key, const int64_t *order) {
+    if (!path || n < 0 || (n > 0 && (!key || !order))) return fail(FX_EINVAL, "bad argument");
+    const fxi::Entries e{n, nullptr, nullptr, key, order};
+    const int rc = fxi::bulk_load_index(path, (uint32_t)rootpage, e);
     if (rc == fxi::E_IO) return fail(FX_EIO, "cannot write %s", path);
     if (rc) return fail(FX_EINVAL, "%s is not a SQLite database this loader can extend", path);
     return FX_OK;

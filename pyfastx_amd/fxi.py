@@ -120,6 +120,40 @@ def write_fasta_comp(db, comp):
     db.execute("COMMIT")
 
 
+def comp_rows(comp):
+    """The rows of the `comp` table for a dense per-record composition (fasta.c:890-953): the non-zero bins of
+    every record in record order, then all 128 totals with seqid 0.  -> (seqid, abc, num) int64 arrays."""
+    import numpy as np
+    rec, abc = np.nonzero(comp)
+    tot = comp.sum(axis=0) if len(comp) else np.zeros(128, dtype=np.int64)
+    seqid = np.concatenate([rec.astype(np.int64) + 1, np.zeros(128, dtype=np.int64)])
+    letters = np.concatenate([abc.astype(np.int64), np.arange(128, dtype=np.int64)])
+    num = np.concatenate([comp[rec, abc].astype(np.int64), tot.astype(np.int64)])
+    return seqid, letters, num
+
+
+def write_fasta_comp_bulk(path, seqid, abc, num):
+    """write_fasta_comp for many rows: the `comp` table and its `seqidx` index written as b-tree pages
+    (fx_fxi_bulk_rows without a TEXT column, fx_fxi_bulk_index_int) into a database that has NO open connection and
+    an empty comp table; rows as comp_rows returns them (the last 128 are the seqid-0 totals).  Returns an open
+    connection."""
+    import numpy as np
+    from . import _lib
+    db = connect(path)
+    if db.execute("SELECT count(*) FROM comp").fetchone()[0]:
+        db.close()
+        raise ValueError("comp table is not empty")
+    db.execute("CREATE INDEX seqidx ON comp (seqid)")
+    root = dict(db.execute("SELECT name, rootpage FROM sqlite_master").fetchall())
+    db.close()
+    n = len(seqid)
+    _lib.fxi_bulk_rows(path, root["comp"], None, None, [seqid, abc, num])
+    # (seqid, rowid) order: the seqid-0 totals (the last 128 rows) first, then the records' rows as they are
+    order = np.concatenate([np.arange(n - 128, n, dtype=np.int64), np.arange(0, n - 128, dtype=np.int64)])
+    _lib.fxi_bulk_index_int(path, root["seqidx"], seqid, order)
+    return connect(path)
+
+
 def write_fastq(db, names, cols, size):
     """fastq.c:76-171."""
     db.executescript(FASTQ_DDL)

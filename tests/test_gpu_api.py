@@ -313,3 +313,29 @@ def test_bulk_written_index_is_sound(fx, files, tmp_path):
     assert db.execute("SELECT CAST(chrom AS BLOB) FROM seq WHERE ID=1").fetchone()[0] == b"caf\xc3\xa9"
     db.close()
     assert fa["café"].seq == "ACGT"
+
+
+def test_bulk_written_comp_table(fx, tmp_path, monkeypatch):
+    """full_index on a file with many records: comp + seqidx are bulk-loaded from the sparse GPU composition; the
+    table equals the one the INSERT path writes for the same file (threshold forced down / up)."""
+    import numpy as np
+    from pyfastx_amd import api
+    rng = np.random.default_rng(2)
+    parts = []
+    for i in range(3000):
+        parts.append(b">s%d d\n" % i)
+        s = np.frombuffer(b"ACGTNacgt", dtype=np.uint8)[rng.integers(0, 9, int(rng.integers(0, 300)))].tobytes()
+        parts += [s[p:p + 70] + b"\n" for p in range(0, len(s), 70)]
+    tables = []
+    for tag, thr in (("bulk", 1), ("ins", 10**9)):
+        p = tmp_path / ("many_%s.fa" % tag)
+        p.write_bytes(b"".join(parts))
+        monkeypatch.setattr(api, "_COMP_BULK_MIN", thr)
+        fa = fx.Fasta(str(p), full_index=True)
+        assert fa.composition == fx.Fasta(str(p)).composition          # second object: loads the table from the file
+        db = sqlite3.connect(str(p) + ".fxi")
+        assert db.execute("PRAGMA integrity_check").fetchall() == [("ok",)]
+        tables.append((db.execute("SELECT * FROM comp ORDER BY ID").fetchall(),
+                       sorted(r[0] for r in db.execute("SELECT name FROM sqlite_master WHERE type='index'"))))
+        db.close()
+    assert tables[0] == tables[1] and tables[0][1] == ["chromidx", "seqidx"]

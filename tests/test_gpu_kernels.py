@@ -437,3 +437,26 @@ def test_fastq_comp_letters(oracle, L):
         assert meta.tolist() == [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"], c["phred"]], eol
         base2, meta2 = b.fastq_comp()                        # a second call starts from clean accumulators
         assert base2.tolist() == base.tolist() and meta2.tolist() == meta.tolist()
+
+
+def test_fasta_comp_sparse(oracle, L):
+    """fx_fasta_comp_sparse: the non-zero bins as (seqid, letter, count) triples in record order + column totals equal
+    the dense composition (fasta.c:904-950); records without bytes, many records (several scan chunks), the fixture."""
+    rng = np.random.default_rng(12)
+    raws = [fixture_bytes("test.fa"), b">only header\n", b">a\nACGT\n>empty\n>b\nNNNN\nacgtRY\n"]
+    parts = []
+    for i in range(5000):                                    # > 4 chunks of 1024 records
+        parts.append(b">r%d\n" % i)
+        n = int(rng.integers(0, 200))
+        if n:
+            parts.append(np.frombuffer(b"ACGTNacgtn*", dtype=np.uint8)[rng.integers(0, 11, n)].tobytes() + b"\n")
+    raws.append(b"".join(parts))
+    for raw in raws:
+        b, s, t = fasta_rows(L.Blob, raw)
+        dense = b.fasta_comp(s.n_seq)
+        for guess in (0, s.n_seq * 12):
+            seqid, abc, num, total = b.fasta_comp_sparse(guess=guess)
+            rec, letter = np.nonzero(dense)
+            assert seqid.tolist() == (rec + 1).tolist() and abc.tolist() == letter.tolist()
+            assert num.tolist() == dense[rec, letter].tolist()
+            assert total.tolist() == (dense.sum(axis=0).tolist() if s.n_seq else [0] * 128)

@@ -376,3 +376,42 @@ def test_comp_exchange_logic(oracle):
         got = [shard.comp_fold_leads(comps[r], leads, nh, r) for r in range(len(comps))]
         got = np.concatenate([x for x in got if len(x)]) if n else np.zeros((0, 128), dtype=np.int64)
         np.testing.assert_array_equal(got, want, err_msg="trial %d cuts %s" % (trial, cuts))
+
+
+@pytest.mark.parametrize("nrec", [0, 1, 50, 40000])
+def test_fxi_bulk_comp_table_equals_inserts(tmp_path, nrec):
+    """The `comp` table and its non-unique `seqidx` index written as pages (fx_fxi_bulk_rows without a TEXT column,
+    fx_fxi_bulk_index_int) on top of an index file that already holds the other tables: same rows as the INSERT path
+    (fasta.c:890-953), integrity_check ok, `WHERE seqid=?` served by the index."""
+    import sqlite3
+    from pyfastx_amd import fxi
+    rng = np.random.default_rng(nrec)
+    comp = np.zeros((nrec, 128), dtype=np.int64)
+    for c, p in zip(b"ACGTNacgtn\r", (1, 1, 1, 1, .3, .5, .5, .5, .5, .1, .05)):
+        comp[:, c] = rng.integers(0, 1 << 20, nrec) * (rng.random(nrec) < p)
+    if nrec > 3:
+        comp[2] = 0                                          # a record without any byte
+        comp[3, 77] = 1 << 40                                # a large count, another letter
+    names = ["r%d" % i for i in range(nrec)]
+    cols = {k: np.arange(nrec, dtype=np.int64) + j for j, k in enumerate(("boff", "blen", "slen", "llen", "elen", "norm", "dlen"))}
+    a, b = str(tmp_path / "a.fxi"), str(tmp_path / "b.fxi")
+    for p in (a, b):
+        db = fxi.connect(p)
+        fxi.write_fasta(db, names, cols, 7)
+        if p == a:
+            fxi.write_fasta_comp(db, comp)
+        db.close()
+    db = fxi.write_fasta_comp_bulk(b, *fxi.comp_rows(comp))
+    db.close()
+    da, dbb = sqlite3.connect(a), sqlite3.connect(b)
+    assert dbb.execute("PRAGMA integrity_check").fetchall() == [("ok",)]
+    for q in ("SELECT * FROM comp ORDER BY ID", "SELECT * FROM seq ORDER BY ID", "SELECT * FROM comp WHERE seqid=0",
+              "SELECT abc, num FROM comp WHERE seqid=3 ORDER BY ID", "SELECT name FROM sqlite_master WHERE type='index' ORDER BY name"):
+        assert da.execute(q).fetchall() == dbb.execute(q).fetchall(), q
+    plan = dbb.execute("EXPLAIN QUERY PLAN SELECT * FROM comp WHERE seqid=?", (5,)).fetchall()
+    assert "seqidx" in plan[0][-1]
+    dbb.execute("INSERT INTO comp VALUES (NULL, 9, 65, 1)")  # the loaded b-trees keep working
+    assert dbb.execute("PRAGMA integrity_check").fetchall() == [("ok",)]
+    da.close(); dbb.close()
+    with pytest.raises(ValueError):
+        fxi.write_fasta_comp_bulk(b, *fxi.comp_rows(comp))   # comp must be empty

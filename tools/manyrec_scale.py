@@ -86,8 +86,24 @@ def main():
     db = fxi.write_fasta_bulk(path, packed[:int(offs[-1])], offs, rows, s.seq_len, order=order)
     db.close()
     t7 = time.perf_counter()
+    # the comp table of the same file: sparse triples off the GPU, table + seqidx as pages
+    t8 = time.perf_counter()
+    seqid, abc, num, total = b.fasta_comp_sparse(guess=n * 12)
+    t9 = time.perf_counter()
+    rec_nz, letter_nz = np.nonzero(comp)
+    assert (seqid == rec_nz + 1).all() and (abc == letter_nz).all() and (num == comp[rec_nz, letter_nz]).all()
+    assert (total == comp.sum(axis=0)).all()
+    t10 = time.perf_counter()
+    db = fxi.write_fasta_comp_bulk(path, np.concatenate([seqid, np.zeros(128, dtype=np.int64)]),
+                                   np.concatenate([abc, np.arange(128, dtype=np.int64)]), np.concatenate([num, total]))
+    db.close()
+    t11 = time.perf_counter()
     db = sqlite3.connect(path)
     assert db.execute("PRAGMA integrity_check").fetchall() == [("ok",)]
+    assert db.execute("SELECT count(*) FROM comp").fetchone()[0] == len(seqid) + 128
+    j = n // 2
+    assert db.execute("SELECT abc, num FROM comp WHERE seqid=? ORDER BY ID", (j + 1,)).fetchall() == \
+        [(int(a), int(c)) for a, c in zip(np.nonzero(comp[j])[0], comp[j][np.nonzero(comp[j])[0]])]
     rng = np.random.default_rng(1)
     for j in rng.integers(0, n, 100).tolist():
         assert db.execute("SELECT ID, boff, slen FROM seq WHERE chrom=?", ("tx%07d" % j,)).fetchone() == (j + 1, j * rec + hl, L)
@@ -98,6 +114,7 @@ def main():
     print(json.dumps({"workload": "synthetic FASTA %d records x %d bp (%.2f GB), %d-column lines" % (n, L, nb / 1e9, W),
                       "index_build_ms": round((t1 - t0) / 3 * 1e3, 3), "index_build_GBps": round(nb / ((t1 - t0) / 3) / 1e9, 1),
                       "composition_ms": round((t3 - t2) * 1e3, 2), "names_sort_ms": round((t5 - t4) * 1e3, 1),
+                      "comp_sparse_ms": round((t9 - t8) * 1e3, 1), "comp_rows_M": round(len(seqid) / 1e6, 2), "comp_table_write_s": round(t11 - t10, 2),
                       "fxi_write_s": round(t7 - t6, 2), "fxi_MB": round(size / 1e6, 1), "fxi_rows_per_s_M": round(n / (t7 - t6) / 1e6, 2),
                       "kernels_ms_avg": prof, "verified": True}))
 
