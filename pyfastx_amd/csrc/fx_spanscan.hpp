@@ -136,9 +136,11 @@ struct GranList { uint32_t *g; uint32_t *count; };
 
 // MODE 0: the full FASTA summary.  MODE 1 (FASTQ, where records are "every four lines"): newline count and the
 // first / last newline only -- no line-length set, no header lines.
+// Returns (wave-uniform) the number of header lines that start in the granule.  The caller puts the granule on
+// the list hgl when that is non-zero (k_span_scan: once per workgroup, see there).
 template <bool FULL, int MODE = 0>
-__device__ __forceinline__ void granule(const uint8_t *__restrict__ data, int64_t n, int prev_byte, int is_last,
-                                        int64_t g, GranPk *__restrict__ out, const GranList &hgl, uint32_t &L) {
+__device__ __forceinline__ uint32_t granule(const uint8_t *__restrict__ data, int64_t n, int prev_byte, int is_last,
+                                            int64_t g, GranPk *__restrict__ out, uint32_t &L) {
     const int lane = lane_id();
     const int64_t sbase = g * (int64_t)GRAN;
 
@@ -251,21 +253,41 @@ __device__ __forceinline__ void granule(const uint8_t *__restrict__ data, int64_
         o.n = n_w; o.h = h_w; o.first = (uint32_t)first_w; o.last = (uint32_t)carry;
         o.v1 = wd.v1; o.c1 = wd.c1; o.v2 = wd.v2; o.c2 = wd.c2; o.ovf = wd.ovf;
         out[g] = gran_pack(o);
-        if (h_w) hgl.g[atomicAdd(hgl.count, 1u)] = (uint32_t)g;
     }
+    return h_w;
 }
 
 // One wave per granule.  Only the granules that lie entirely inside the stream (n / GRAN of them) are
 // launched here; the last, partial one (which also holds the virtual end-of-stream newline) is done by
 // k_gran_reduce with the FULL = false instantiation, so its bounds-checked loads cost this kernel
 // neither registers nor branches.
+// The granules that hold header lines go on a list (k_hdr_rec visits them).  Appending one by one -- an atomic with
+// return on ONE counter per granule -- is fine for chromosomes and was the whole run time for a file of short records
+// (5 M records: 405 k granules, all with headers, 11 ns per atomic = 4.6 ms): the waves of a workgroup collect their
+// granules in LDS and the last one to finish reserves the block's slots with a single atomic.  No barrier at the end,
+// so no wave waits for another; the one at the start costs nothing (the waves of a workgroup start together).
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_span_scan(const uint8_t *__restrict__ data, int64_t n, int prev_byte,
                                                    int is_last, int64_t g_end, GranPk *__restrict__ out, GranList hgl) {
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    uint32_t L = 0;
-    for (int64_t g = wave; g < g_end; g += nwaves) granule<true, MODE>(data, n, prev_byte, is_last, g, out, hgl, L);
+    __shared__ uint32_t hl_n, hl_done, hl_g[16];
+    if (MODE == 0) {
+        if (threadIdx.x == 0) { hl_n = 0; hl_done = 0; }
+        __syncthreads();
+    }
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;        // one granule per wave
+    uint32_t L = 0, h_w = 0;
+    if (g < g_end) h_w = granule<true, MODE>(data, n, prev_byte, is_last, g, out, L);
+    if (MODE == 0 && lane_id() == 0) {
+        if (h_w) hl_g[atomicAdd(&hl_n, 1u)] = (uint32_t)g;
+        __threadfence_block();
+        if (atomicAdd(&hl_done, 1u) == (blockDim.x >> 6) - 1) {      // the last wave of the workgroup
+            const uint32_t cnt = hl_n;
+            if (cnt) {
+                const uint32_t base = atomicAdd(hgl.count, cnt);
+                for (uint32_t k = 0; k < cnt; ++k) hgl.g[base + k] = hl_g[k];
+            }
+        }
+    }
 }
 
 // ============================================================== granule prefixes
@@ -329,7 +351,11 @@ __global__ __launch_bounds__(CG) void k_gran_reduce(const uint8_t *__restrict__ 
                                                    int64_t ngran, int64_t gbase, ChunkTot *__restrict__ ct) {
     __shared__ Tri lds[CG / 64];
     if (blockIdx.x == gridDim.x - 1) {          // the tail granule (index ngran - 1) belongs to the last chunk
-        if (threadIdx.x < 64) { uint32_t L = 0; granule<false, MODE>(data, n, prev_byte, is_last, ngran - 1, go, hgl, L); }
+        if (threadIdx.x < 64) {
+            uint32_t L = 0;
+            const uint32_t h_w = granule<false, MODE>(data, n, prev_byte, is_last, ngran - 1, go, L);
+            if (MODE == 0 && h_w && threadIdx.x == 0) hgl.g[atomicAdd(hgl.count, 1u)] = (uint32_t)(ngran - 1);
+        }
         __threadfence_block();
         __syncthreads();
     }
@@ -761,8 +787,14 @@ __global__ __launch_bounds__(BLOCK) void k_fasta_finalize2(int64_t cap, FastaCol
             c.norm[k] = c.bad[k] > 1 ? 0 : 1;
         } else { c.blen[k] = 0; c.slen[k] = 0; c.norm[k] = 1; }
     }
+    // one atomic per workgroup (per wave it was 78 k atomics on one address for 5 M records: 0.95 ms)
+    __shared__ unsigned long long blk;
+    if (threadIdx.x == 0) blk = 0;
+    __syncthreads();
     s = wave_sum64(s);
-    if (lane_id() == 0 && s) atomicAdd((unsigned long long *)&tot->seq_len, (unsigned long long)s);
+    if (lane_id() == 0 && s) atomicAdd(&blk, (unsigned long long)s);
+    __syncthreads();
+    if (threadIdx.x == 0 && blk) atomicAdd((unsigned long long *)&tot->seq_len, blk);
 }
 
 // ============================================================== shard boundary summary
