@@ -585,15 +585,34 @@ __device__ __forceinline__ int mask_bit(const Mask4 &m, int pos) {           // 
     return (int)((rdlane(mask_row(m, pos >> 10), (pos >> 4) & 63) >> (pos & 15)) & 1u);
 }
 
+// first set bit of the 4096-bit mask M (16 bits per 16-byte chunk, in LDS) at a granule position > pos and < limit; -1 if none
+__device__ __forceinline__ int lds_next(const uint16_t *M, int pos, int limit) {
+    const int p = pos + 1;
+    if (p >= limit) return -1;
+    int q = p >> 4;
+    uint32_t w = (uint32_t)M[q] & (0xFFFFu << (p & 15)) & 0xFFFFu;
+    while (!w) {
+        if (++q >= GRAN / CHUNK || q * CHUNK >= limit) return -1;
+        w = M[q];
+    }
+    const int r = q * CHUNK + __ffs(w) - 1;
+    return r < limit ? r : -1;
+}
+__device__ __forceinline__ int lds_bit(const uint16_t *M, int pos) { return (M[pos >> 4] >> (pos & 15)) & 1; }
+
 // One wave per granule that holds a header line: re-read its 4 KiB once, build the exact masks of
-// '\n', header starts, white space, '\r' and '>' in registers, write every header's offset and the
-// number of stream newlines before it straight to their final, position-ordered slots
-// (hdr_prefix[g] + rank), then fill -- header by header, all lanes together, from those masks -- the
-// columns that depend only on the record's first two lines (blen / slen / norm: k_fasta_finalize2).
-// A header whose first two lines run past the granule falls back to reading memory (record_at).
+// '\n', header starts, white space, '\r' and '>', write every header's offset and the number of stream
+// newlines before it straight to their final, position-ordered slots (hdr_prefix[g] + rank), then fill the
+// columns that depend only on the record's first two lines (blen / slen / norm: k_fasta_finalize2) -- ONE LANE PER
+// HEADER LINE: the masks go to LDS (2 KiB per wave) and every lane that owns a header finds the end of its
+// line, of the line after it and the first white space by walking those masks (a file of short records has a
+// dozen headers per granule; doing them one after the other with wave-wide ballots was 3.3 ms for 5 M records).
+// A header whose first two lines run past the granule falls back to reading memory (record_at, whole wave).
 __global__ __launch_bounds__(BLOCK) void k_hdr_rec(ScanCtx x, int prev_byte, int is_last, int full_name, GranList hgl,
                                                   FastaCols c, int64_t cap) {
-    const int lane = lane_id();
+    __shared__ uint16_t lds_all[BLOCK / 64][4][GRAN / CHUNK];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    uint16_t *NL = lds_all[wv][0], *WS = lds_all[wv][1], *CR = lds_all[wv][2], *GT = lds_all[wv][3];
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int64_t cnt = *hgl.count;
@@ -614,53 +633,70 @@ __global__ __launch_bounds__(BLOCK) void k_hdr_rec(ScanCtx x, int prev_byte, int
                 }
             }
         }
-        Mask4 nl, hm, ws, cr, gt;
+        uint32_t hmask[GR_ROWS];
+        int rfirst[GR_ROWS];                                // record of the lane's first header of row j, relative to hrank0
         int64_t hrank = x.hdr_prefix[g], nlb = x.nl_prefix[g];
         const int64_t hrank0 = hrank;
 #pragma unroll
         for (int j = 0; j < GR_ROWS; ++j) {
             const int64_t p = sbase + j * 1024 + lane * CHUNK;
-            nl.r[j] = eq_mask16(v[j], 0x0A0A0A0Au);
-            hm.r[j] = header_mask16(v[j], nl.r[j], x.data, p, prev_byte);
-            ws.r[j] = full_name ? 0u : (eq_mask16(v[j], 0x20202020u) | eq_mask16(v[j], 0x09090909u));
-            cr.r[j] = eq_mask16(v[j], 0x0D0D0D0Du);
-            gt.r[j] = eq_mask16(v[j], 0x3E3E3E3Eu);
-            const uint32_t cn = __popc(nl.r[j]), ch = __popc(hm.r[j]);
+            const uint32_t nl = eq_mask16(v[j], 0x0A0A0A0Au);
+            const uint32_t hm = header_mask16(v[j], nl, x.data, p, prev_byte);
+            hmask[j] = hm;
+            NL[j * 64 + lane] = (uint16_t)nl;
+            WS[j * 64 + lane] = (uint16_t)(full_name ? 0u : (eq_mask16(v[j], 0x20202020u) | eq_mask16(v[j], 0x09090909u)));
+            CR[j * 64 + lane] = (uint16_t)eq_mask16(v[j], 0x0D0D0D0Du);
+            GT[j * 64 + lane] = (uint16_t)eq_mask16(v[j], 0x3E3E3E3Eu);
+            const uint32_t cn = __popc(nl), ch = __popc(hm);
             const uint32_t in = wave_incl_scan(cn), ih = wave_incl_scan(ch);
             int64_t r = hrank + ih - ch;
+            rfirst[j] = (int)(r - hrank0);
             const int64_t nb0 = nlb + in - cn;
-            uint32_t hh = hm.r[j];
+            uint32_t hh = hm;
             while (hh) {
                 const int k = __ffs(hh) - 1;
                 hh &= hh - 1;
-                if (r < cap) { c.hoff[r] = x.gbase + p + k; c.hdr_line[r] = nb0 + __popc(nl.r[j] & ((1u << k) - 1u)); c.bad[r] = 0; }
+                if (r < cap) { c.hoff[r] = x.gbase + p + k; c.hdr_line[r] = nb0 + __popc(nl & ((1u << k) - 1u)); c.bad[r] = 0; }
                 ++r;
             }
             nlb += (uint32_t)__shfl((int)in, 63, 64);
             hrank += (uint32_t)__shfl((int)ih, 63, 64);
         }
-        // records, in position order (everything below is wave-uniform)
-        int64_t r = hrank0;
-        for (int hp = mask_next(hm, -1); hp >= 0; hp = mask_next(hm, hp), ++r) {
-            if (r >= cap) break;
-            const int64_t h = x.gbase + sbase + hp;
-            const int e = mask_next(nl, hp);                          // end of the header line
-            const int e1 = (e >= 0 && e + 1 < GRAN) ? mask_next(nl, e) : -1;   // end of the line after it
-            const bool inside = e >= 0 && e + 1 < GRAN && (e1 >= 0 || sbase + e + 1 >= x.n);
-            if (!inside) {                                            // runs past the granule: read memory
-                record_at(x, is_last, full_name, h, r, c);
-                continue;
-            }
-            const int elen = mask_bit(cr, e - 1) ? 2 : 1;             // index.c:266-269 (e - 1 >= hp)
-            const int dlen = e - hp - elen;                           // index.c:271
-            int name_len = dlen;                                      // index.c:289-293: cut at ' ' or '\t'
-            if (!full_name) { const int w = mask_next(ws, hp); if (w >= 0 && w - (hp + 1) < dlen) name_len = w - (hp + 1); }
-            // first sequence line (index.c:330-332): the line after the header line, unless that is a header too
-            int64_t llen = 0;
-            if (sbase + e + 1 < x.n && !mask_bit(gt, e + 1) && e1 >= 0) llen = e1 - e;
-            if (lane == 0) {
-                c.boff[r] = x.gbase + sbase + e + 1;                  // index.c:258  start = position
-                c.llen[r] = llen; c.elen[r] = elen; c.dlen[r] = dlen; c.name_len[r] = name_len;
+        // records: every lane takes its own header lines, lowest first; the loop runs as long as any lane has one left
+#pragma unroll
+        for (int j = 0; j < GR_ROWS; ++j) {
+            uint32_t hh = hmask[j];
+            int rr = rfirst[j];
+            while (__ballot(hh != 0)) {
+                const bool has = hh != 0 && hrank0 + rr < cap;
+                const int hp = j * 1024 + lane * CHUNK + (hh ? __ffs(hh) - 1 : 0);
+                bool fallback = false;
+                if (has) {
+                    const int e = lds_next(NL, hp, GRAN);                                     // end of the header line
+                    const int e1 = (e >= 0 && e + 1 < GRAN) ? lds_next(NL, e, GRAN) : -1;     // end of the line after it
+                    const bool inside = e >= 0 && e + 1 < GRAN && (e1 >= 0 || sbase + e + 1 >= x.n);
+                    if (!inside) fallback = true;                                             // runs past the granule: read memory
+                    else {
+                        const int elen = lds_bit(CR, e - 1) ? 2 : 1;                          // index.c:266-269 (e - 1 >= hp)
+                        const int dlen = e - hp - elen;                                       // index.c:271
+                        int name_len = dlen;                                                  // index.c:289-293: cut at ' ' or '\t'
+                        if (!full_name) { const int w = lds_next(WS, hp, e); if (w >= 0 && w - (hp + 1) < dlen) name_len = w - (hp + 1); }
+                        // first sequence line (index.c:330-332): the line after the header line, unless that is a header too
+                        int64_t llen = 0;
+                        if (sbase + e + 1 < x.n && !lds_bit(GT, e + 1) && e1 >= 0) llen = e1 - e;
+                        const int64_t r = hrank0 + rr;
+                        c.boff[r] = x.gbase + sbase + e + 1;                                  // index.c:258  start = position
+                        c.llen[r] = llen; c.elen[r] = elen; c.dlen[r] = dlen; c.name_len[r] = name_len;
+                    }
+                }
+                unsigned long long fb = __ballot(fallback);
+                while (fb) {                                                                  // wave-uniform from here
+                    const int l = __ffsll(fb) - 1;
+                    fb &= fb - 1;
+                    const int hq = (int)rdlane((uint32_t)hp, l), rq = (int)rdlane((uint32_t)rr, l);
+                    record_at(x, is_last, full_name, x.gbase + sbase + hq, hrank0 + rq, c);
+                }
+                if (hh) { hh &= hh - 1; ++rr; }
             }
         }
     }
@@ -673,7 +709,7 @@ struct RecView { const int64_t *boff, *llen; const int32_t *dlen; uint32_t *bad;
 // the lane, in a lower lane, in an earlier row, or prevnl[g]) the record is the last header <= p
 // (headers of this granule are hdr[hdr_prefix[g] .. hdr_prefix[g+1])); the header line and the first
 // sequence line are skipped, any other line with p - q != llen counts.
-__device__ __forceinline__ void exact_walk(const ScanCtx &x, const RecView &rv, int64_t cap, int is_last, int64_t g) {
+__device__ __forceinline__ void exact_walk(const ScanCtx &x, const RecView &rv, int64_t cap, int is_last, int prev_byte, int64_t g) {
     const int lane = lane_id();
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int64_t sbase = g * (int64_t)GRAN, gs = x.gbase + sbase;
@@ -689,7 +725,6 @@ __device__ __forceinline__ void exact_walk(const ScanCtx &x, const RecView &rv, 
     const bool ok0 = r0 >= 0 && r0 < cap;
     const int32_t d0 = ok0 ? rv.dlen[r0] : -1;
     const int64_t e0 = ok0 ? rv.boff[r0] - 1 : 0, ll0 = ok0 ? rv.llen[r0] : 0;
-    const int64_t h1 = he > hb ? rv.hdr[hb] : 0x7FFFFFFFFFFFFFFFll;   // first header line of this granule
     if (is_last && sbase + GRAN > x.n) {
 #pragma unroll
         for (int j = 0; j < GR_ROWS; ++j) {
@@ -701,12 +736,20 @@ __device__ __forceinline__ void exact_walk(const ScanCtx &x, const RecView &rv, 
             }
         }
     }
+    // The record of a newline at p is the last header line <= p: hdr_prefix[g] - 1 + the header lines of this granule
+    // before p, counted from the exact header masks (wave prefix per row) -- no search in the header array.
+    int64_t hseen = 0;                                     // wave-uniform: header lines in the rows already done
 #pragma unroll
     for (int j = 0; j < GR_ROWS; ++j) {
         uint32_t m = eq_mask16(v[j], 0x0A0A0A0Au);
+        const int cb = j * 1024 + lane * CHUNK;
+        uint32_t hm = 0;
+        if (he > hb) hm = header_mask16(v[j], m, x.data, sbase + cb, prev_byte);    // he > hb is wave-uniform
+        const uint32_t ch = __popc(hm), ih = wave_incl_scan(ch);
+        const int64_t hbefore = hseen + ih - ch;           // header lines of the granule before this lane's chunk
+        hseen += (uint32_t)__shfl((int)ih, 63, 64);
         const unsigned long long bal = __ballot(m != 0);
         if (!bal) continue;
-        const int cb = j * 1024 + lane * CHUNK;
         const int pl = cb + (31 - __clz(m | 1u));           // last newline of this lane (granule-local)
         const unsigned long long lower = bal & lt;
         const int pprev = __builtin_amdgcn_ds_bpermute((63 - __clzll(lower | 1ull)) << 2, pl);
@@ -715,16 +758,12 @@ __device__ __forceinline__ void exact_walk(const ScanCtx &x, const RecView &rv, 
             const int k = __ffs(m) - 1;
             m &= m - 1;
             const int64_t p = gs + cb + k;
-            if (p < h1) {                                   // still in the record that owns the granule start
+            const int64_t r = hb - 1 + hbefore + __popc(hm & ((1u << k) - 1u));
+            if (r == r0) {                                  // still in the record that owns the granule start
                 if (d0 >= 0 && p != e0 && p != e0 + ll0 && q >= 0 && p - q != ll0) atomicAdd(&rv.bad[r0], 1u);
-            } else {                                        // a record that starts in this granule: last header <= p
-                int64_t lo = hb, hi = he;
-                while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rv.hdr[mid] < p) lo = mid + 1; else hi = mid; }
-                const int64_t r = lo - 1;
-                if (r >= 0 && r < cap && rv.dlen[r] >= 0) {
-                    const int64_t e = rv.boff[r] - 1, ll = rv.llen[r];
-                    if (p != e && p != e + ll && q >= 0 && p - q != ll) atomicAdd(&rv.bad[r], 1u);
-                }
+            } else if (r >= 0 && r < cap && rv.dlen[r] >= 0) {
+                const int64_t e = rv.boff[r] - 1, ll = rv.llen[r];
+                if (p != e && p != e + ll && q >= 0 && p - q != ll) atomicAdd(&rv.bad[r], 1u);
             }
             q = p;
         }
@@ -762,11 +801,11 @@ __global__ __launch_bounds__(BLOCK) void k_gran_lines(ScanCtx x, RecView rv, int
     irr.g[atomicAdd(irr.count, 1u)] = (uint32_t)g;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_gran_exact(ScanCtx x, RecView rv, int64_t cap, GranList irr, int is_last) {
+__global__ __launch_bounds__(BLOCK) void k_gran_exact(ScanCtx x, RecView rv, int64_t cap, GranList irr, int is_last, int prev_byte) {
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int64_t cnt = *irr.count;
-    for (int64_t i = wave; i < cnt; i += nwaves) exact_walk(x, rv, cap, is_last, irr.g[i]);
+    for (int64_t i = wave; i < cnt; i += nwaves) exact_walk(x, rv, cap, is_last, prev_byte, irr.g[i]);
 }
 
 // blen, slen (index.c:243,335-338,348), norm (index.c:237,342), stat.seqlen (index.c:253-254, 360-369)

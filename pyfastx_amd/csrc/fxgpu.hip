@@ -644,9 +644,9 @@ static int enqueue_records(fx_handle *h, int full_name) {
     const FastaCols c = fasta_cols(h);
     const RecView rv{h->fa_boff.p, h->fa_llen.p, h->fa_dlen.p, h->fa_bad.p, h->hdr.p};
     const GranList hgl{h->hdr_grans.p, ctl_counter(h, 0)}, irr{h->irr_grans.p, ctl_counter(h, 1)};
-    FX_LAUNCH(h, K_HDR_REC, k_hdr_rec, dim3(512), dim3(BLOCK), x, h->prev_byte, (int)h->is_last, full_name, hgl, c, cap);
+    FX_LAUNCH(h, K_HDR_REC, k_hdr_rec, dim3(2048), dim3(BLOCK), x, h->prev_byte, (int)h->is_last, full_name, hgl, c, cap);
     FX_LAUNCH(h, K_GRAN_LINES, k_gran_lines, dim3(nblocks(ngran, BLOCK)), dim3(BLOCK), x, rv, cap, irr);
-    FX_LAUNCH(h, K_GRAN_EXACT, k_gran_exact, dim3(512), dim3(BLOCK), x, rv, cap, irr, (int)h->is_last);
+    FX_LAUNCH(h, K_GRAN_EXACT, k_gran_exact, dim3(2048), dim3(BLOCK), x, rv, cap, irr, (int)h->is_last, h->prev_byte);
     FX_LAUNCH(h, K_FASTA_FINALIZE, k_fasta_finalize2, dim3(nblocks(cap, BLOCK)), dim3(BLOCK), cap, c, ctl_totals(h));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h->pin_tot, ctl_totals(h), sizeof(Totals), hipMemcpyDeviceToHost, h->stream));
