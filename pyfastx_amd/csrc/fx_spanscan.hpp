@@ -556,35 +556,6 @@ __device__ __forceinline__ void record_at(const ScanCtx &x, int is_last, int ful
     }
 }
 
-// ---- 4096-bit masks spread over a wave: bit (16 * lane + k) of row j <-> granule byte j*1024 + 16*lane + k
-struct Mask4 { uint32_t r[GR_ROWS]; };
-__device__ __forceinline__ uint32_t mask_row(const Mask4 &m, int row) {     // row is wave-uniform
-    uint32_t v = m.r[0];
-#pragma unroll
-    for (int j = 1; j < GR_ROWS; ++j) v = (row == j) ? m.r[j] : v;
-    return v;
-}
-// first set bit at a granule position > pos (pos wave-uniform, may be -1), or -1
-__device__ __forceinline__ int mask_next(const Mask4 &m, int pos) {
-    const int lane = lane_id();
-    const int row0 = (pos + 1) >> 10, l0 = ((pos + 1) >> 4) & 63, b0 = (pos + 1) & 15;     // first candidate byte
-#pragma unroll
-    for (int j = 0; j < GR_ROWS; ++j) {
-        if (j < row0) continue;
-        uint32_t c = m.r[j];
-        if (j == row0) { if (lane < l0) c = 0; else if (lane == l0) c &= 0xFFFFu << b0; }
-        const unsigned long long bal = __ballot(c != 0);
-        if (bal) {
-            const int l = __ffsll(bal) - 1;
-            return j * 1024 + l * 16 + (__ffs(rdlane(c, l)) - 1);
-        }
-    }
-    return -1;
-}
-__device__ __forceinline__ int mask_bit(const Mask4 &m, int pos) {           // pos wave-uniform, 0 <= pos < GRAN
-    return (int)((rdlane(mask_row(m, pos >> 10), (pos >> 4) & 63) >> (pos & 15)) & 1u);
-}
-
 // first set bit of the 4096-bit mask M (16 bits per 16-byte chunk, in LDS) at a granule position > pos and < limit; -1 if none
 __device__ __forceinline__ int lds_next(const uint16_t *M, int pos, int limit) {
     const int p = pos + 1;
