@@ -138,13 +138,10 @@ struct GranList { uint32_t *g; uint32_t *count; };
 // first / last newline only -- no line-length set, no header lines.
 // Returns (wave-uniform) the number of header lines that start in the granule.  The caller puts the granule on
 // the list hgl when that is non-zero (k_span_scan: once per workgroup, see there).
-template <bool FULL, int MODE = 0>
-__device__ __forceinline__ uint32_t granule(const uint8_t *__restrict__ data, int64_t n, int prev_byte, int is_last,
-                                            int64_t g, GranPk *__restrict__ out, uint32_t &L) {
+template <bool FULL>
+__device__ __forceinline__ void granule_load(uint4 (&v)[GR_ROWS], const uint8_t *__restrict__ data, int64_t n, int is_last, int64_t g) {
     const int lane = lane_id();
     const int64_t sbase = g * (int64_t)GRAN;
-
-    uint4 v[GR_ROWS];
     if (FULL) {
         const uint4 *q = reinterpret_cast<const uint4 *>(data + sbase + lane * CHUNK);
 #pragma unroll
@@ -170,6 +167,13 @@ __device__ __forceinline__ uint32_t granule(const uint8_t *__restrict__ data, in
             }
         }
     }
+}
+
+template <int MODE = 0>
+__device__ __forceinline__ uint32_t granule_body(const uint4 (&v)[GR_ROWS], const uint8_t *__restrict__ data, int prev_byte,
+                                                 int64_t g, GranPk *__restrict__ out, uint32_t &L) {
+    const int lane = lane_id();
+    const int64_t sbase = g * (int64_t)GRAN;
 
     WaveDiff wd;
     wd.clear();
@@ -257,6 +261,14 @@ __device__ __forceinline__ uint32_t granule(const uint8_t *__restrict__ data, in
     return h_w;
 }
 
+template <bool FULL, int MODE = 0>
+__device__ __forceinline__ uint32_t granule(const uint8_t *__restrict__ data, int64_t n, int prev_byte, int is_last,
+                                            int64_t g, GranPk *__restrict__ out, uint32_t &L) {
+    uint4 v[GR_ROWS];
+    granule_load<FULL>(v, data, n, is_last, g);
+    return granule_body<MODE>(v, data, prev_byte, g, out, L);
+}
+
 // One wave per granule.  Only the granules that lie entirely inside the stream (n / GRAN of them) are
 // launched here; the last, partial one (which also holds the virtual end-of-stream newline) is done by
 // k_gran_reduce with the FULL = false instantiation, so its bounds-checked loads cost this kernel
@@ -266,19 +278,32 @@ __device__ __forceinline__ uint32_t granule(const uint8_t *__restrict__ data, in
 // (5 M records: 405 k granules, all with headers, 11 ns per atomic = 4.6 ms): the waves of a workgroup collect their
 // granules in LDS and the last one to finish reserves the block's slots with a single atomic.  No barrier at the end,
 // so no wave waits for another; the one at the start costs nothing (the waves of a workgroup start together).
+#ifndef FX_SCAN_GPW
+#define FX_SCAN_GPW 1
+#endif
+// consecutive granules per wave, all requested before the first is processed.  1 is best: 3.2 GB in 0.468 ms against
+// 0.482 ms with 2 and 0.528 ms with 4 (tools/scanbench2.hip) -- more loads in flight per wave do not make up for
+// fewer, longer-lived waves here
+constexpr int SCAN_GPW = FX_SCAN_GPW;
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_span_scan(const uint8_t *__restrict__ data, int64_t n, int prev_byte,
                                                    int is_last, int64_t g_end, GranPk *__restrict__ out, GranList hgl) {
-    __shared__ uint32_t hl_n, hl_done, hl_g[16];
+    __shared__ uint32_t hl_n, hl_done, hl_g[16 * SCAN_GPW];
     if (MODE == 0) {
         if (threadIdx.x == 0) { hl_n = 0; hl_done = 0; }
         __syncthreads();
     }
-    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;        // one granule per wave
-    uint32_t L = 0, h_w = 0;
-    if (g < g_end) h_w = granule<true, MODE>(data, n, prev_byte, is_last, g, out, L);
+    const int64_t g0 = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * SCAN_GPW;
+    uint4 v[SCAN_GPW][GR_ROWS];
+#pragma unroll
+    for (int k = 0; k < SCAN_GPW; ++k) if (g0 + k < g_end) granule_load<true>(v[k], data, n, is_last, g0 + k);
+    uint32_t L = 0, hmask = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_GPW; ++k)
+        if (g0 + k < g_end && granule_body<MODE>(v[k], data, prev_byte, g0 + k, out, L)) hmask |= 1u << k;
     if (MODE == 0 && lane_id() == 0) {
-        if (h_w) hl_g[atomicAdd(&hl_n, 1u)] = (uint32_t)g;
+#pragma unroll
+        for (int k = 0; k < SCAN_GPW; ++k) if ((hmask >> k) & 1u) hl_g[atomicAdd(&hl_n, 1u)] = (uint32_t)(g0 + k);
         __threadfence_block();
         if (atomicAdd(&hl_done, 1u) == (blockDim.x >> 6) - 1) {      // the last wave of the workgroup
             const uint32_t cnt = hl_n;

@@ -620,7 +620,7 @@ static int granule_pass(fx_handle *h) {
     GranList hgl{h->hdr_grans.p, ctl_counter(h, 0)};
     const int SCAN_WG = 512;                                  // 8 waves = 8 granules per workgroup (tools/scanbench2.hip)
     if (nfull > 0)
-        FX_LAUNCH(h, K_SPAN_SCAN, (k_span_scan<MODE>), dim3(nblocks(nfull * 64, SCAN_WG)), dim3(SCAN_WG), h->d_data, h->n,
+        FX_LAUNCH(h, K_SPAN_SCAN, (k_span_scan<MODE>), dim3(nblocks((nfull + SCAN_GPW - 1) / SCAN_GPW * 64, SCAN_WG)), dim3(SCAN_WG), h->d_data, h->n,
                   h->prev_byte, (int)h->is_last, nfull, h->gran.p, hgl);
     if (small) {
         FX_LAUNCH(h, K_GRAN_REDUCE, (k_gran_reduce<MODE, 256>), dim3((unsigned)nchunks), dim3(256), h->d_data, h->n, h->prev_byte,

@@ -71,7 +71,7 @@ int check(const std::vector<uint8_t> &hb) {
     CK(hipMalloc((void **)&ct, nchunks * sizeof(ChunkTot))); CK(hipMalloc((void **)&tot, sizeof(Totals)));
     CK(hipMemset(tot, 0, sizeof(Totals)));
     CK(hipMalloc((void **)&dpn, (ngran + 1) * 8)); CK(hipMalloc((void **)&dph, (ngran + 1) * 8)); CK(hipMalloc((void **)&dpv, (ngran + 1) * 8));
-    hipLaunchKernelGGL(k_span_scan<0>, dim3((unsigned)((n / GRAN * 64 + 511) / 512)), dim3(512), 0, 0, d, n, (int)'\n', 1, n / GRAN, go, gl);
+    hipLaunchKernelGGL(k_span_scan<0>, dim3((unsigned)(((n / GRAN + SCAN_GPW - 1) / SCAN_GPW * 64 + 511) / 512)), dim3(512), 0, 0, d, n, (int)'\n', 1, n / GRAN, go, gl);
     hipLaunchKernelGGL((k_gran_reduce<0, CHUNK_GRANS>), dim3((unsigned)nchunks), dim3(CHUNK_GRANS), 0, 0, d, n, (int)'\n', 1, gl, go, ngran, (int64_t)1000, ct);
     hipLaunchKernelGGL(k_gran_prefix<CHUNK_GRANS>, dim3((unsigned)nchunks), dim3(CHUNK_GRANS), 0, 0, go, ngran, (int64_t)1000, ct, tot, dpn, dph, dpv);
     CK(hipDeviceSynchronize());
@@ -167,7 +167,7 @@ int main() {
     CK(hipDeviceSynchronize());
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-  for (int rep = 0; rep < 2; ++rep) for (int blk : {256, 512, 1024}) for (int grid : {(int)((ngran * 64 + blk - 1) / blk)}) {
+  for (int rep = 0; rep < 2; ++rep) for (int blk : {256, 512, 1024}) for (int grid : {(int)(((ngran + SCAN_GPW - 1) / SCAN_GPW * 64 + blk - 1) / blk)}) {
     float tot = 0, best = 1e9f;
     const int R = 40;
     for (int r = 0; r < R + 2; ++r) {
