@@ -275,7 +275,7 @@ class Fasta:
 
     def keys(self):
         self._need_index()
-        return FastaKeys(self._db, self._seq_counts)
+        return FastaKeys(self, self._seq_counts)
 
     # ----------------------------------------------------------- statistics
     # (SQL over the .fxi exactly as the reference does; fasta.c:573-849)
@@ -459,8 +459,12 @@ class Fasta:
 class FastaKeys:
     """Minimal sqlite-backed view of sequence names (fakeys.c; sort/filter DSL is out of scope)."""
 
-    def __init__(self, db, n):
-        self._db, self._n = db, n
+    def __init__(self, owner, n):
+        self._owner, self._n = owner, n                      # the Fasta: its connection may be re-opened (bulk-loaded comp table)
+
+    @property
+    def _db(self):
+        return self._owner._db
 
     def __len__(self):
         return self._n

@@ -331,8 +331,10 @@ def test_bulk_written_comp_table(fx, tmp_path, monkeypatch):
         p = tmp_path / ("many_%s.fa" % tag)
         p.write_bytes(b"".join(parts))
         monkeypatch.setattr(api, "_COMP_BULK_MIN", thr)
-        fa = fx.Fasta(str(p), full_index=True)
+        fa = fx.Fasta(str(p))
+        keys = fa.keys()                                     # taken before the index file is re-opened by the bulk load
         assert fa.composition == fx.Fasta(str(p)).composition          # second object: loads the table from the file
+        assert keys[3] == "s3" and "s7" in keys and len(keys) == 3000
         db = sqlite3.connect(str(p) + ".fxi")
         assert db.execute("PRAGMA integrity_check").fetchall() == [("ok",)]
         tables.append((db.execute("SELECT * FROM comp ORDER BY ID").fetchall(),
