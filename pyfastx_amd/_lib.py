@@ -315,20 +315,32 @@ class Blob:
     def fasta_build_begin(self, full_name=False):
         """Enqueue the build and return (no host synchronisation); see fasta_build_end."""
         self._table_ready = True
+        self._n_fasta = None
         check(lib().fx_fasta_build_begin(self._h, int(bool(full_name))))
 
     def fasta_build_end(self):
         s = FastaSummary()
         check(lib().fx_fasta_build_end(self._h, C.byref(s)))
+        self._n_fasta = int(s.n_seq)
         return s
 
     def fasta_build(self, full_name=False):
         self._table_ready = True
         s = FastaSummary()
         check(lib().fx_fasta_build(self._h, int(bool(full_name)), C.byref(s)))
+        self._n_fasta = int(s.n_seq)
         return s
 
+    def _check_rows(self, n, kind):
+        """The C entries fill n_seq / n_reads rows whatever the caller allocated: refuse a wrong n here."""
+        have = getattr(self, "_n_fasta" if kind == 0 else "_n_fastq", None)
+        if have is None and kind == 0:
+            have = int(self.fasta_build_end().n_seq)         # a build was only enqueued: wait for it, learn the count
+        if have is not None and int(n) != have:
+            raise ValueError("the table holds %d records, the caller asked for %d" % (have, int(n)))
+
     def fasta_table(self, n):
+        self._check_rows(n, 0)
         cols = {k: np.empty(n, dtype=np.int64) for k in ("hoff", "boff", "blen", "slen", "llen")}
         cols.update({k: np.empty(n, dtype=np.int32) for k in ("elen", "norm", "dlen", "name_len")})
         check(lib().fx_fasta_table(self._h, FX_HOST, *[_ptr(cols[k]) for k in (
@@ -336,6 +348,7 @@ class Blob:
         return cols
 
     def fasta_comp(self, n):
+        self._check_rows(n, 0)
         comp = np.zeros((n, 128), dtype=np.int64)
         check(lib().fx_fasta_comp(self._h, FX_HOST, comp.ctypes.data))
         return comp
@@ -359,6 +372,7 @@ class Blob:
     def fasta_comp_shard(self, n, lead_from):
         """-> (comp int64[n,128] of the records that start in this shard, lead int64[128]: the bytes before the
         shard's first header line from global offset lead_from on; lead_from < 0: not counted)."""
+        self._check_rows(n, 0)
         comp = np.zeros((max(n, 1), 128), dtype=np.int64)
         lead = np.zeros(128, dtype=np.int64)
         check(lib().fx_fasta_comp_shard(self._h, FX_HOST, comp.ctypes.data, int(lead_from), lead.ctypes.data))
@@ -368,6 +382,7 @@ class Blob:
     def fastq_build(self):
         s = FastqSummary()
         check(lib().fx_fastq_build(self._h, C.byref(s)))
+        self._n_fastq = int(s.n_reads)
         return s
 
     def set_halo(self, halo):
@@ -382,9 +397,11 @@ class Blob:
     def fastq_build_ctx(self, line_offset, prev_nl):
         s = FastqSummary()
         check(lib().fx_fastq_build_ctx(self._h, int(line_offset), int(prev_nl), C.byref(s)))
+        self._n_fastq = int(s.n_reads)
         return s
 
     def fastq_table(self, n):
+        self._check_rows(n, 1)
         cols = {k: np.empty(n, dtype=np.int64) for k in ("name_off", "rlen", "soff", "qoff")}
         cols.update({k: np.empty(n, dtype=np.int32) for k in ("name_len", "dlen")})
         check(lib().fx_fastq_table(self._h, FX_HOST, _ptr(cols["name_off"]), _ptr(cols["name_len"]),

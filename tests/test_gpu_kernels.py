@@ -460,3 +460,21 @@ def test_fasta_comp_sparse(oracle, L):
             assert seqid.tolist() == (rec + 1).tolist() and abc.tolist() == letter.tolist()
             assert num.tolist() == dense[rec, letter].tolist()
             assert total.tolist() == (dense.sum(axis=0).tolist() if s.n_seq else [0] * 128)
+
+
+def test_table_getters_refuse_a_wrong_row_count(L):
+    """fx_fasta_table / fx_fasta_comp / fx_fastq_table fill as many rows as the index has; the binding allocates by
+    the caller's n, so a stale or guessed n is refused instead of overrunning the arrays."""
+    b, s, t = fasta_rows(L.Blob, b">a\nACGT\n>b\nGG\n")
+    assert s.n_seq == 2
+    for bad in (0, 1, 3):
+        with pytest.raises(ValueError):
+            b.fasta_table(bad)
+        with pytest.raises(ValueError):
+            b.fasta_comp(bad)
+    b.fasta_build_begin()                                    # only enqueued: the getter waits for the count itself
+    assert b.fasta_table(2)["slen"].tolist() == [4, 2]
+    fq = L.Blob.from_bytes(b"@r\nAC\n+\nII\n")
+    assert fq.fastq_build().n_reads == 1
+    with pytest.raises(ValueError):
+        fq.fastq_table(2)

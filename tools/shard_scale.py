@@ -68,6 +68,7 @@ def main():
         times.append((t, t2))
     ok = True
     for r, j in enumerate(jobs):
+        j.finish()                                         # the count of this shard's records (local_rows allocates by it)
         rows = j.local_rows()
         ok &= bool(j.check_against_plan(plans[r], rows, plans[r + 1] if r + 1 < G else None))
     bt, st = times[-1]
