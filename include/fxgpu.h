@@ -224,6 +224,11 @@ int fx_names_lookup(fx_handle *h, int where, int64_t nq, const uint8_t *qbytes, 
  * otherwise the reference's CREATE UNIQUE INDEX fails (and is ignored), so no index is written.  kind as above. */
 int fx_names_sort(fx_handle *h, int kind, int where, int64_t *order, int64_t *n_dup);
 
+/* The record names back to back (what the `chrom` / `name` column of the .fxi stores), gathered from the record table
+ * that is already in HBM: dst[name_off[i] .. name_off[i+1]) = name of record i, name_off: n + 1 host words, *total =
+ * name_off[n].  FX_ERANGE when total > cap (only *total is valid then; n * longest name is a safe cap).  Host buffers. */
+int fx_names_pack(fx_handle *h, int kind, uint8_t *dst, int64_t cap, int64_t *name_off, int64_t *total);
+
 /* pyfastx.reverse_complement / reverse_seq / complement_seq on a caller buffer
  * (module.c:44-59; util.c:239-269).  mode: FX_REVERSE | FX_COMPLEMENT.        */
 int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mode);

@@ -43,7 +43,7 @@ SYMBOLS = [
     "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_host", "fx_open_device",
     "fx_set_shard", "fx_close", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
     "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
-    "fx_fetch_ranges", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_revcomp", "fx_shard_summary_get",
+    "fx_fetch_ranges", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
     "fx_fasta_set_row", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
 ]
 
@@ -148,6 +148,7 @@ def lib():
     L.fx_stream.argtypes = [vp]
     L.fx_gz_points.argtypes = [vp, i64, vp, vp, i64, C.POINTER(i64), C.POINTER(i64)]
     L.fx_names_sort.argtypes = [vp, i32, i32, vp, C.POINTER(i64)]
+    L.fx_names_pack.argtypes = [vp, i32, vp, i64, vp, C.POINTER(i64)]
     L.fx_fxi_bulk_rows.argtypes = [C.c_char_p, i32, i64, vp, vp, i32, vp]
     L.fx_fxi_bulk_index.argtypes = [C.c_char_p, i32, i64, vp, vp, vp]
     L.fx_fxi_bulk_index_int.argtypes = [C.c_char_p, i32, i64, vp, vp]
@@ -430,6 +431,21 @@ class Blob:
             check(lib().fx_names_lookup(self._h, FX_HOST, len(enc), _ptr(packed), _ptr(offs), _ptr(out)))
         return out
 
+    def names_pack(self, kind, n, guess=0):
+        """-> (packed uint8, name_off int64[n+1]): the names of the n records back to back, from the table in HBM."""
+        offs = np.zeros(int(n) + 1, dtype=np.int64)
+        total = C.c_int64(0)
+        cap = int(guess)
+        for _ in range(2):
+            buf = np.empty(max(cap, 1), dtype=np.uint8)
+            rc = lib().fx_names_pack(self._h, int(kind), buf.ctypes.data, cap, offs.ctypes.data, C.byref(total))
+            if rc == FX_ERANGE and total.value > cap:
+                cap = int(total.value)
+                continue
+            check(rc)
+            return buf[:total.value], offs
+        raise FxError(FX_ERANGE, "names did not fit twice")
+
     def names_sort(self, kind, n):
         """-> (order int64[n], n_dup): sorted order of the n record names (BINARY collation) computed on the GPU."""
         n = int(n)
@@ -449,7 +465,7 @@ class Blob:
         n = off.size
         offs = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(np.maximum(slen, 0), out=offs[1:])
-        dst = np.zeros(max(int(offs[-1]), 1), dtype=np.uint8)
+        dst = np.empty(max(int(offs[-1]), 1), dtype=np.uint8)     # the copy back fills all of it (np.zeros would touch every page first)
         out_len = np.zeros(n, dtype=np.int64)
         fpq = None if flags_per_query is None else np.ascontiguousarray(flags_per_query, dtype=np.uint8)
         if n:
@@ -462,7 +478,7 @@ class Blob:
         n = seq_id.size
         offs = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(np.maximum(stop - start, 0), out=offs[1:])
-        dst = np.zeros(max(int(offs[-1]), 1), dtype=np.uint8)
+        dst = np.empty(max(int(offs[-1]), 1), dtype=np.uint8)     # the copy back fills all of it (np.zeros would touch every page first)
         out_len = np.zeros(n, dtype=np.int64)
         fpq = None if flags_per_query is None else np.ascontiguousarray(flags_per_query, dtype=np.uint8)
         if n:

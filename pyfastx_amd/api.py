@@ -98,10 +98,10 @@ def _bulk_index(path, blob, kind, n, name_off, name_len, write):
     if path == ":memory:" or os.path.exists(path):
         return None
     ln = np.maximum(np.asarray(name_len, dtype=np.int64), 0)
-    packed, offs, _ = blob.fetch_ranges(name_off, ln, ln, flags=_F_RAW)
+    packed, offs = blob.names_pack(kind, n, guess=int(ln.sum()))
     order, ndup = blob.names_sort(kind, n)
     try:
-        return write(path, packed[:int(offs[-1])], offs, None if ndup else order)
+        return write(path, packed, offs, None if ndup else order)
     except _lib.FxError as e:
         if e.code != _lib.FX_ERANGE:
             raise

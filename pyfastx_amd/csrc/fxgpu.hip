@@ -328,6 +328,59 @@ static int stage_plain_file(fx_handle *h, int fd, int64_t n, const char *path, u
     return FX_OK;
 }
 
+// Large results to pageable host memory.  hipMemcpy to a pageable destination runs at ~5 GB/s (the runtime stages it
+// through one bounce buffer); here several threads move 8 MiB pieces device -> pinned (own streams) -> destination, the
+// copy out of one piece overlapping the transfer of the next: 20+ GB/s.  Used for the name buffer of an index file,
+// the sort order and the composition triples (hundreds of MB to GB); small results keep the plain asynchronous copy.
+// Everything already enqueued on the handle's stream is waited for first.
+static const int64_t D2H_LARGE = 32ll << 20;
+static int d2h_large(fx_handle *h, void *dst, const void *d_src, int64_t n) {
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(FX_EDEVICE, "stream synchronisation failed");
+    const int T = (int)std::min<int64_t>(std::min(stage_threads(), 8), std::max<int64_t>(1, n / PIECE_BYTES));
+    std::atomic<int> err(0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+        th.emplace_back([&, t]() {
+            if (hipSetDevice(h->device) != hipSuccess) { err.store(1); return; }
+            uint8_t *pin[2] = {g_pins.get(), g_pins.get()};
+            hipStream_t st = nullptr;
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            bool ok = pin[0] && pin[1] && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+                      hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+            if (!ok) err.store(1);
+            int64_t pend_off[2] = {-1, -1}, pend_len[2] = {0, 0};
+            int slot = 0;
+            auto drain = [&](int sl) {                       // wait for the piece in slot sl and copy it out
+                if (pend_off[sl] < 0) return;
+                if (hipEventSynchronize(ev[sl]) != hipSuccess) { err.store(1); return; }
+                memcpy((uint8_t *)dst + pend_off[sl], pin[sl], (size_t)pend_len[sl]);
+                pend_off[sl] = -1;
+            };
+            for (int64_t off = (int64_t)t * PIECE_BYTES; ok && off < n && !err.load(); off += (int64_t)T * PIECE_BYTES, slot ^= 1) {
+                const int64_t len = std::min(PIECE_BYTES, n - off);
+                drain(slot);                                  // the slot's previous piece (two iterations ago)
+                if (hipMemcpyAsync(pin[slot], (const uint8_t *)d_src + off, (size_t)len, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipEventRecord(ev[slot], st) != hipSuccess) { err.store(1); break; }
+                pend_off[slot] = off; pend_len[slot] = len;
+                drain(slot ^ 1);                              // copy the other slot out while this one travels
+            }
+            drain(0); drain(1);
+            for (int i = 0; i < 2; ++i) { if (ev[i]) (void)hipEventDestroy(ev[i]); if (pin[i]) g_pins.put(pin[i]); }
+            if (st) (void)hipStreamDestroy(st);
+        });
+    for (auto &x : th) x.join();
+    if (err.load()) return fail(FX_EDEVICE, "device to host copy failed");
+    return FX_OK;
+}
+// device -> host on the handle's stream (small) or through d2h_large; the caller still synchronises the stream
+static int to_host(fx_handle *h, void *dst, const void *d_src, int64_t bytes) {
+    if (bytes <= 0) return FX_OK;
+    if (bytes >= D2H_LARGE) return d2h_large(h, dst, d_src, bytes);
+    HIPCHK(hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, h->stream));
+    return FX_OK;
+}
+
 static inline unsigned nblocks(int64_t n, int per) { return (unsigned)std::max<int64_t>(1, (n + per - 1) / per); }
 
 // ------------------------------------------------------------------- BGZF
@@ -837,9 +890,7 @@ extern "C" int fx_fasta_comp_sparse(fx_handle *h, int where, int64_t cap, int64_
     hipLaunchKernelGGL(k_comp_emit, dim3(nb), dim3(BLOCK), 0, h->stream, dense.p, n, off.p, ds, da, dn);
     HIPCHK(hipGetLastError());
     if (where != FX_DEVICE) {
-        HIPCHK(hipMemcpyAsync(seqid, ds, (size_t)count * 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(abc, da, (size_t)count * 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(num, dn, (size_t)count * 8, hipMemcpyDeviceToHost, h->stream));
+        if ((rc = to_host(h, seqid, ds, count * 8)) || (rc = to_host(h, abc, da, count * 8)) || (rc = to_host(h, num, dn, count * 8))) return rc;
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     return FX_OK;
@@ -1107,8 +1158,8 @@ static int fetch_common(fx_handle *h, int where, int64_t n, bool by_id, const in
     }
     HIPCHK(hipGetLastError());
     if (where == FX_HOST) {
-        HIPCHK(hipMemcpyAsync(dst, d_dst, (size_t)total, hipMemcpyDeviceToHost, h->stream));
-        if (out_len) HIPCHK(hipMemcpyAsync(out_len, d_len, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+        if ((rc = to_host(h, dst, d_dst, total))) return rc;
+        if (out_len && (rc = to_host(h, out_len, d_len, n * 8))) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     return FX_OK;
@@ -1288,6 +1339,56 @@ extern "C" int fx_names_lookup(fx_handle *h, int where, int64_t nq, const uint8_
     return FX_OK;
 }
 
+__global__ void k_len_clamp(const int32_t *__restrict__ len, int64_t n, int32_t *__restrict__ l32, int64_t *__restrict__ l64) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int32_t v = len[i] > 0 ? len[i] : 0; l32[i] = v; l64[i] = v; }
+}
+
+// The record names back to back, straight from the record table in HBM: no query arrays go up (fx_fetch_ranges with
+// host arrays uploads 32 bytes per name and walks them twice on the host: 130 ms for 20 M names, most of it not the names)
+extern "C" int fx_names_pack(fx_handle *h, int kind, uint8_t *dst, int64_t cap, int64_t *name_off, int64_t *total_out) {
+    if (!h || (kind != 0 && kind != 1) || !total_out || !name_off || cap < 0 || (cap > 0 && !dst)) return fail(FX_EINVAL, "bad argument");
+    if (kind == 0 ? !h->fasta_built : !h->fastq_built) return fail(FX_ESTATE, "the index has not been built");
+    if (kind == 0 && !h->hdr.p) return fail(FX_ESTATE, "names need a scanned index (fx_fasta_build), not an installed table");
+    int rc = use_device(h);
+    if (!rc) rc = finish_build(h);
+    if (rc) return rc;
+    const int64_t n = kind == 0 ? h->n_hdr : h->n_reads;
+    name_off[0] = 0;
+    *total_out = 0;
+    if (n == 0) return FX_OK;
+    const int64_t *noff = h->fq_name_off.p;
+    const int32_t *nlen = h->fq_name_len.p;
+    if (kind == 0) {
+        if ((rc = h->nm_off.alloc(n))) return rc;
+        hipLaunchKernelGGL(k_add_i64, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, h->hdr.p, (int64_t)1, n, h->nm_off.p);
+        noff = h->nm_off.p; nlen = h->fa_name_len.p;
+    }
+    const int64_t nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    DevBuf<int32_t> l32;
+    DevBuf<int64_t> l64, sums, off;
+    DevBuf<uint8_t> out;
+    if ((rc = l32.alloc(n)) || (rc = l64.alloc(n)) || (rc = sums.alloc(nchunks + 1)) || (rc = off.alloc(n + 1))) return rc;
+    hipLaunchKernelGGL(k_len_clamp, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, nlen, n, l32.p, l64.p);
+    hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, l32.p, n, sums.p);
+    hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, sums.p, nchunks);
+    hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, l32.p, n, sums.p, off.p);
+    HIPCHK(hipGetLastError());
+    int64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, off.p + n, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *total_out = total;
+    if (total > cap) return fail(FX_ERANGE, "%lld name bytes, room for %lld", (long long)total, (long long)cap);
+    if ((rc = to_host(h, name_off, off.p, (n + 1) * 8))) return rc;
+    if (total) {
+        if ((rc = out.alloc(total + 64))) return rc;
+        if ((rc = fetch_common(h, FX_DEVICE, n, false, noff, l64.p, l64.p, nullptr, FX_RAW, nullptr, out.p, off.p, nullptr, 0))) return rc;
+        if ((rc = to_host(h, dst, out.p, total))) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FX_OK;
+}
+
 extern "C" int fx_names_sort(fx_handle *h, int kind, int where, int64_t *order, int64_t *n_dup) {
     if (!h || (kind != 0 && kind != 1) || !n_dup) return fail(FX_EINVAL, "bad argument");
     if (kind == 0 ? !h->fasta_built : !h->fastq_built) return fail(FX_ESTATE, "the index has not been built");
@@ -1315,7 +1416,7 @@ extern "C" int fx_names_sort(fx_handle *h, int kind, int where, int64_t *order, 
     const int e = sort_names(h->d_data, h->base, noff, nlen, n, d_order, d_ndup, h->stream, &what);
     if (e) return fail(e == (int)hipErrorOutOfMemory ? FX_ENOMEM : FX_EDEVICE, "name sort, %s: %s", what, hipGetErrorString((hipError_t)e));
     HIPCHK(hipMemcpyAsync(n_dup, d_ndup, 8, hipMemcpyDeviceToHost, h->stream));
-    if (where == FX_HOST) HIPCHK(hipMemcpyAsync(order, d_order, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    if (where == FX_HOST && (rc = to_host(h, order, d_order, n * 8))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     return FX_OK;
 }

@@ -478,3 +478,27 @@ def test_table_getters_refuse_a_wrong_row_count(L):
     assert fq.fastq_build().n_reads == 1
     with pytest.raises(ValueError):
         fq.fastq_table(2)
+
+
+def test_names_pack(oracle, L):
+    """fx_names_pack: the names back to back + their offsets, from the record table in HBM (FASTA first token / whole
+    header, FASTQ read names; empty names; more than one scan chunk of records)."""
+    rng = np.random.default_rng(21)
+    raw = fixture_bytes("test.fa")
+    for full in (False, True):
+        b, s, t = fasta_rows(L.Blob, raw, full_name=full)
+        want = [raw[t["hoff"][i] + 1: t["hoff"][i] + 1 + t["name_len"][i]] for i in range(s.n_seq)]
+        for guess in (0, 10**6):
+            packed, offs = b.names_pack(0, s.n_seq, guess=guess)
+            assert offs[0] == 0 and offs[-1] == packed.size == sum(len(x) for x in want)
+            assert [packed[offs[i]:offs[i + 1]].tobytes() for i in range(s.n_seq)] == want
+    b, s, t = fasta_rows(L.Blob, b">\nAC\n>x y\nGG\n>\n>zz\n")
+    packed, offs = b.names_pack(0, s.n_seq)
+    assert packed.tobytes() == b"xzz" and offs.tolist() == [0, 0, 1, 1, 3]
+    raw = _rand_fastq(rng, 3000, 40, crlf=True, plus_name=True)
+    recs, size, ln = oracle.fastq_index(raw)
+    fq = L.Blob.from_bytes(raw)
+    sq = fq.fastq_build()
+    packed, offs = fq.names_pack(1, sq.n_reads)
+    want = [raw[int(recs["name_off"][i]): int(recs["name_off"][i]) + int(recs["name_len"][i])] for i in range(sq.n_reads)]
+    assert [packed[offs[i]:offs[i + 1]].tobytes() for i in range(sq.n_reads)] == want

@@ -85,7 +85,7 @@ def main():
     fx_t = {}
     tA = time.perf_counter()
     ln = t["name_len"].astype(np.int64)
-    packed_n, offs_all, _ = b.fetch_ranges(t["name_off"], ln, ln, flags=_lib.FX_RAW)
+    packed_n, offs_all = b.names_pack(1, n, guess=int(ln.sum()))
     tB = time.perf_counter()
     order, ndup = b.names_sort(1, n)
     tC = time.perf_counter()

@@ -78,7 +78,7 @@ def main():
     t5 = time.perf_counter()
     assert ndup == 0 and (order == i).all()                  # zero-padded numbers: already in order
     ln = rows["name_len"].astype(np.int64)
-    packed, offs, _ = b.fetch_ranges(rows["hoff"] + 1, ln, ln, flags=_lib.FX_RAW)
+    packed, offs = b.names_pack(0, n, guess=int(ln.sum()))
     path = "/dev/shm/manyrec.fxi" if os.path.isdir("/dev/shm") else "/tmp/manyrec.fxi"
     if os.path.exists(path):
         os.remove(path)
