@@ -190,8 +190,8 @@ def _bulk_table(path, ddl, table, index_sql, index_name, packed_names, name_off,
     db.close()
     try:
         _lib.fxi_bulk_rows(path, root[table], packed_names, name_off, col_list)
-    except _lib.FxError as e:
-        if e.code == _lib.FX_ERANGE:
+    except BaseException:                                     # row too large (FX_ERANGE), disk full, ...: no half-written index file
+        if os.path.exists(path):
             os.remove(path)
         raise
     reindex = False
@@ -200,6 +200,8 @@ def _bulk_table(path, ddl, table, index_sql, index_name, packed_names, name_off,
             _lib.fxi_bulk_index(path, root[index_name], packed_names, name_off, order)
         except _lib.FxError as e:                             # a name too long for an in-page index entry
             if e.code != _lib.FX_ERANGE:
+                if os.path.exists(path):
+                    os.remove(path)
                 raise
             reindex = True
     db = connect(path)
