@@ -502,3 +502,119 @@ def test_names_pack(oracle, L):
     packed, offs = fq.names_pack(1, sq.n_reads)
     want = [raw[int(recs["name_off"][i]): int(recs["name_off"][i]) + int(recs["name_len"][i])] for i in range(sq.n_reads)]
     assert [packed[offs[i]:offs[i + 1]].tobytes() for i in range(sq.n_reads)] == want
+
+
+def test_fasta_mixed_shapes_60mb(oracle, L):
+    """One 60 MB stream of every shape at once -- multi-MB records, thousands of tiny ones, a header line longer
+    than two granules, CRLF records, ragged records (norm = 0), protein / IUPAC / noise bytes, blank lines, an
+    unterminated last line -- through the C ABI against the oracle: every index row, every composition bin, the sparse
+    composition, the names, their sort order, and 3000 random fetches with all flag combinations."""
+    rng = np.random.default_rng(2024)
+    parts = []
+
+    def lines(seq, width, eol):
+        return eol.join(seq[p:p + width] for p in range(0, len(seq), width)) + eol if seq else b""
+
+    def bases(n, alpha=b"ACGTacgtNn"):
+        return np.frombuffer(alpha, dtype=np.uint8)[rng.integers(0, len(alpha), n)].tobytes()
+
+    for i in range(24):                                      # big records
+        parts.append(b">big%d desc %d\n" % (i, i) + lines(bases(int(rng.integers(1, 4) * 1_000_000)), (60, 70, 80, 61)[i % 4], b"\n"))
+    for i in range(30000):                                   # tiny records, every granule has several headers
+        parts.append(b">t%d\n" % i + lines(bases(int(rng.integers(0, 400))), 60, b"\n"))
+    parts.append(b">long header " + b"x" * 9000 + b"\n" + lines(bases(5000), 50, b"\n"))
+    for i in range(200):                                     # CRLF
+        parts.append(b">crlf%d\tq\r\n" % i + lines(bases(int(rng.integers(1, 3000))), 72, b"\r\n"))
+    for i in range(200):                                     # ragged: line lengths vary -> norm = 0
+        s, out, p = bases(int(rng.integers(1, 3000))), [], 0
+        while p < len(s):
+            w = int(rng.integers(1, 90)); out.append(s[p:p + w]); p += w
+        parts.append(b">rag%d\n" % i + b"\n".join(out) + b"\n")
+    parts.append(b">protein\n" + lines(bases(300000, b"ACDEFGHIKLMNPQRSTVWY*"), 60, b"\n"))
+    noise = bytes(rng.integers(0, 256, 200000, dtype=np.uint8)).replace(b"\n", b"A").replace(b">", b"G")
+    parts.append(b">noise\n" + lines(noise, 100, b"\n"))
+    parts.append(b">blank lines\nACGT\n\n\nAC\n\n>last, unterminated\nACGTNNNNacgt")
+    order = rng.permutation(len(parts) - 1).tolist() + [len(parts) - 1]      # shuffled, the unterminated one last
+    raw = b"".join(parts[i] for i in order)
+    assert 40_000_000 < len(raw) < 120_000_000
+    b, recs, t = assert_fasta_equal(oracle, L, raw)          # rows + dense composition
+    n = len(recs)
+    dense = oracle.fasta_comp(raw, n)
+    seqid, abc, num, total = b.fasta_comp_sparse(guess=n * 12)
+    rr, ll = np.nonzero(dense)
+    assert (seqid == rr + 1).all() and (abc == ll).all() and (num == dense[rr, ll]).all() and (total == dense.sum(axis=0)).all()
+    names = [raw[int(recs["hoff"][i]) + 1: int(recs["hoff"][i]) + 1 + int(recs["name_len"][i])] for i in range(n)]
+    packed, offs = b.names_pack(0, n)
+    assert packed.tobytes() == b"".join(names) and offs[-1] == packed.size
+    order_gpu, ndup = b.names_sort(0, n)
+    assert order_gpu.tolist() == sorted(range(n), key=names.__getitem__) and ndup == 0
+    ok = np.nonzero(recs["slen"] > 0)[0]
+    nq = 3000
+    ids = rng.choice(ok, nq)
+    st = (rng.random(nq) * recs["slen"][ids]).astype(np.int64)
+    sp = np.minimum(st + rng.integers(0, 400, nq), recs["slen"][ids])
+    fl = rng.integers(0, 8, nq).astype(np.uint8)
+    buf, offs, ol = b.fasta_fetch(ids, st, sp, flags_per_query=fl)
+    for j in range(nq):
+        r = recs[ids[j]]
+        bpl = int(r["llen"]) - int(r["elen"])
+        if r["norm"] and bpl > 0:
+            off, bl = oracle.slice_range(int(r["boff"]), int(r["llen"]), int(r["elen"]), int(st[j]), int(sp[j]))
+            want = oracle.fetch(raw, off, bl, int(sp[j] - st[j]), int(fl[j]))
+        else:
+            full = oracle.fetch(raw, int(r["boff"]), int(r["blen"]), 1 << 60, int(fl[j]) & 1)
+            want = full[st[j]:sp[j]]
+            if fl[j] & 4:
+                want = oracle.revcomp(want, 2)
+            if fl[j] & 2:
+                want = want[::-1]
+        assert buf[offs[j]:offs[j] + ol[j]].tobytes() == want, (j, int(ids[j]), int(fl[j]))
+
+
+def test_fastq_mixed_shapes_40mb(oracle, L):
+    """One 40 MB FASTQ stream with reads from 1 base to 200 kb, '+name' lines, lower case and IUPAC bases, qualities
+    over the whole printable range -- index rows, composition, names, their order, name lookups and read fetches
+    (seq, reverse complement, qual, phred-adjusted qualities) against the oracle."""
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(b"ACGTNacgtnRYKM", dtype=np.uint8)
+    out = []
+    lens = np.concatenate([rng.integers(1, 400, 120000), rng.integers(1000, 20000, 300), [200000, 131072, 4096, 4095, 16, 15, 17]])
+    rng.shuffle(lens)
+    for i, n in enumerate(lens.tolist()):
+        name = b"@m%d/%d extra %d" % (i, n, i % 7) if i % 3 else b"@m%d/%d" % (i, n)
+        seq = alpha[rng.integers(0, 5 if i % 5 else alpha.size, n)].tobytes()
+        qual = rng.integers(33, 127, n).astype(np.uint8).tobytes()
+        out += [name + b"\n", seq + b"\n", (b"+" + name[1:] if i % 4 == 0 else b"+") + b"\n", qual + b"\n"]
+    raw = b"".join(out)
+    assert 30_000_000 < len(raw) < 80_000_000
+    recs, size, ln = oracle.fastq_index(raw)
+    b = L.Blob.from_bytes(raw)
+    s = b.fastq_build()
+    assert (s.n_reads, s.size, s.n_lines) == (len(recs), size, ln) and s.n_reads == len(lens)
+    t = b.fastq_table(s.n_reads)
+    for col in ("name_off", "name_len", "dlen", "rlen", "soff", "qoff"):
+        np.testing.assert_array_equal(t[col], recs[col].astype(t[col].dtype), err_msg=col)
+    base, meta = b.fastq_comp()
+    c = oracle.fastq_composition(raw)
+    assert base.tolist() == [c["a"], c["c"], c["g"], c["t"], c["n"]]
+    assert meta.tolist() == [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"], c["phred"]]
+    n = s.n_reads
+    names = [raw[int(recs["name_off"][i]): int(recs["name_off"][i]) + int(recs["name_len"][i])] for i in range(n)]
+    packed, offs = b.names_pack(1, n)
+    assert packed.tobytes() == b"".join(names)
+    order, ndup = b.names_sort(1, n)
+    assert ndup == 0 and order.tolist() == sorted(range(n), key=names.__getitem__)
+    b.names_build(1)
+    pick = rng.integers(0, n, 3000)
+    assert b.names_lookup([names[i].decode() for i in pick] + ["absent"]).tolist() == pick.tolist() + [-1]
+    ids = np.concatenate([rng.integers(0, n, 600), np.argsort(lens)[-8:]])       # the longest reads as well
+    for flags in (0, L.FX_REVERSE | L.FX_COMPLEMENT):
+        seq, qual, qi, offs = b.fastq_fetch(ids, t["rlen"][ids], phred=33, seq_flags=flags)
+        for j, k in enumerate(ids):
+            so, qo, m = int(recs["soff"][k]), int(recs["qoff"][k]), int(recs["rlen"][k])
+            want = raw[so:so + m]
+            if flags:
+                want = oracle.revcomp(want, 3)
+            assert seq[offs[j]:offs[j + 1]].tobytes() == want, (j, int(k))
+            assert qual[offs[j]:offs[j + 1]].tobytes() == raw[qo:qo + m], (j, int(k))
+            assert (qi[offs[j]:offs[j + 1]].astype(np.int16) + 33 == np.frombuffer(raw[qo:qo + m], dtype=np.uint8)).all(), (j, int(k))
