@@ -504,12 +504,8 @@ def test_names_pack(oracle, L):
     assert [packed[offs[i]:offs[i + 1]].tobytes() for i in range(sq.n_reads)] == want
 
 
-def test_fasta_mixed_shapes_60mb(oracle, L):
-    """One 60 MB stream of every shape at once -- multi-MB records, thousands of tiny ones, a header line longer
-    than two granules, CRLF records, ragged records (norm = 0), protein / IUPAC / noise bytes, blank lines, an
-    unterminated last line -- through the C ABI against the oracle: every index row, every composition bin, the sparse
-    composition, the names, their sort order, and 3000 random fetches with all flag combinations."""
-    rng = np.random.default_rng(2024)
+def _mixed_fasta(rng, nbig=24, ntiny=30000):
+    """Every FASTA shape in one stream (see test_fasta_mixed_shapes_60mb)."""
     parts = []
 
     def lines(seq, width, eol):
@@ -518,9 +514,9 @@ def test_fasta_mixed_shapes_60mb(oracle, L):
     def bases(n, alpha=b"ACGTacgtNn"):
         return np.frombuffer(alpha, dtype=np.uint8)[rng.integers(0, len(alpha), n)].tobytes()
 
-    for i in range(24):                                      # big records
+    for i in range(nbig):                                      # big records
         parts.append(b">big%d desc %d\n" % (i, i) + lines(bases(int(rng.integers(1, 4) * 1_000_000)), (60, 70, 80, 61)[i % 4], b"\n"))
-    for i in range(30000):                                   # tiny records, every granule has several headers
+    for i in range(ntiny):                                   # tiny records, every granule has several headers
         parts.append(b">t%d\n" % i + lines(bases(int(rng.integers(0, 400))), 60, b"\n"))
     parts.append(b">long header " + b"x" * 9000 + b"\n" + lines(bases(5000), 50, b"\n"))
     for i in range(200):                                     # CRLF
@@ -536,6 +532,16 @@ def test_fasta_mixed_shapes_60mb(oracle, L):
     parts.append(b">blank lines\nACGT\n\n\nAC\n\n>last, unterminated\nACGTNNNNacgt")
     order = rng.permutation(len(parts) - 1).tolist() + [len(parts) - 1]      # shuffled, the unterminated one last
     raw = b"".join(parts[i] for i in order)
+    return raw
+
+
+def test_fasta_mixed_shapes_60mb(oracle, L):
+    """One 60 MB stream of every shape at once -- multi-MB records, thousands of tiny ones, a header line longer
+    than two granules, CRLF records, ragged records (norm = 0), protein / IUPAC / noise bytes, blank lines, an
+    unterminated last line -- through the C ABI against the oracle: every index row, every composition bin, the sparse
+    composition, the names, their sort order, and 3000 random fetches with all flag combinations."""
+    rng = np.random.default_rng(2024)
+    raw = _mixed_fasta(rng)
     assert 40_000_000 < len(raw) < 120_000_000
     b, recs, t = assert_fasta_equal(oracle, L, raw)          # rows + dense composition
     n = len(recs)

@@ -277,3 +277,17 @@ def test_composition_across_cuts(oracle, L):
         for _ in range(4):
             cuts = sorted(set(int(x) for x in rng.integers(1, len(raw), g - 1)))
             np.testing.assert_array_equal(sharded_comp(L, raw, cuts), want, err_msg=str(cuts))
+
+
+def test_mixed_shapes_in_shards(oracle, L):
+    """A 20 MB stream of every FASTA shape cut into 2 .. 16 shards at random offsets: the stitched rows (host and
+    device stitch) and the composition folded across the cuts equal those of the whole stream."""
+    from test_gpu_kernels import _mixed_fasta
+    rng = np.random.default_rng(31)
+    raw = _mixed_fasta(rng, nbig=6, ntiny=8000)
+    n = len(oracle.fasta_index(raw)[0])
+    want = oracle.fasta_comp(raw, n)
+    for g in (2, 3, 8, 16):
+        cuts = sorted(set(int(x) for x in rng.integers(1, len(raw), g - 1)))
+        check(oracle, L, raw, cuts)
+        np.testing.assert_array_equal(sharded_comp(L, raw, cuts), want, err_msg=str(cuts))
