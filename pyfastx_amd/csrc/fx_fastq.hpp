@@ -64,7 +64,10 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_emit(ScanCtx x, int prev_byte, 
     if (sbase + GRAN <= x.n) {
         const uint4 *q = reinterpret_cast<const uint4 *>(x.data + sbase + lane * CHUNK);
 #pragma unroll
-        for (int j = 0; j < GR_ROWS; ++j) v[j] = q[j * 64];
+        for (int j = 0; j < GR_ROWS; ++j) {                // streamed once: non-temporal, like the scan
+            v[j].x = __builtin_nontemporal_load(&q[j * 64].x); v[j].y = __builtin_nontemporal_load(&q[j * 64].y);
+            v[j].z = __builtin_nontemporal_load(&q[j * 64].z); v[j].w = __builtin_nontemporal_load(&q[j * 64].w);
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < GR_ROWS; ++j) v[j] = load16(x.data, sbase + j * 1024 + lane * CHUNK, x.n);
