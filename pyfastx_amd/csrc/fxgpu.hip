@@ -1092,8 +1092,9 @@ struct Staged {
 };
 
 static unsigned fetch_grid(int64_t nq) {
-    // one wave per query, 4 waves per workgroup; cap at 8 workgroups per CU and grid-stride
-    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((nq + 3) / 4, 256 * 8 * 4));
+    // one wave per query, 4 waves per workgroup; a capped grid, grid-stride beyond it (FX_FETCH_WG: tuning override)
+    static const int64_t cap = []() { const char *e = getenv("FX_FETCH_WG"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : (int64_t)256 * 8 * 4; }();
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((nq + 3) / 4, cap));
 }
 
 static int fetch_common(fx_handle *h, int where, int64_t n, bool by_id, const int64_t *a0, const int64_t *a1,
