@@ -32,7 +32,9 @@ def main():
     for k in range(7):
         t[:, 9 - k] = (48 + (idx // (10 ** k)) % 10).to(torch.uint8)
     g = torch.Generator(device=dev); g.manual_seed(3)
-    lut = torch.tensor(list(b"ACGTacgtNn"), dtype=torch.uint8, device=dev)
+    protein = len(sys.argv) > 3 and sys.argv[3] == "protein"
+    letters = b"ACDEFGHIKLMNPQRSTVWY" if protein else b"ACGTacgtNn"
+    lut = torch.tensor(list((letters * 2)[:16]) if protein else list(letters), dtype=torch.uint8, device=dev)
     body = t[:, hl:].view(n, nlines, -1) if (L % W == 0) else None
     seq_cols = []                                            # column indices of the bases inside a record
     for j in range(L):
@@ -42,8 +44,9 @@ def main():
     for a in range(0, n, step):
         b = min(n, a + step)
         r = torch.randint(0, 1000, (b - a, L), device=dev, generator=g)
-        bases = lut[(r & 7).long()]
-        bases[r >= 995] = lut[8 + (r[r >= 995] & 1)]
+        bases = lut[(r & 15).long()] if protein else lut[(r & 7).long()]
+        if not protein:
+            bases[r >= 995] = lut[8 + (r[r >= 995] & 1)]
         t[a:b, seq_cols] = bases
     nl_cols = torch.tensor([hl + min((k + 1) * W, L) + k for k in range(nlines)], device=dev)
     t[:, nl_cols] = 10
@@ -69,7 +72,7 @@ def main():
     comp = b.fasta_comp(n)
     t3 = time.perf_counter()
     seqs = t[:, seq_cols]
-    for c in b"ACGTacgtNn":
+    for c in set(letters):
         assert (torch.from_numpy(comp[:, c]).to(dev) == (seqs == c).sum(dim=1)).all(), chr(c)
     assert int(comp.sum()) == n * L
     # names: hash table + sort + the .fxi as pages
@@ -111,7 +114,7 @@ def main():
     size = os.path.getsize(path)
     os.remove(path)
     prof = {k: round(v[0] / v[1], 4) for k, v in b.prof_read().items()}
-    print(json.dumps({"workload": "synthetic FASTA %d records x %d bp (%.2f GB), %d-column lines" % (n, L, nb / 1e9, W),
+    print(json.dumps({"workload": "synthetic %s FASTA %d records x %d residues (%.2f GB), %d-column lines" % ("protein" if protein else "DNA", n, L, nb / 1e9, W),
                       "index_build_ms": round((t1 - t0) / 3 * 1e3, 3), "index_build_GBps": round(nb / ((t1 - t0) / 3) / 1e9, 1),
                       "composition_ms": round((t3 - t2) * 1e3, 2), "names_sort_ms": round((t5 - t4) * 1e3, 1),
                       "comp_sparse_ms": round((t9 - t8) * 1e3, 1), "comp_rows_M": round(len(seqid) / 1e6, 2), "comp_table_write_s": round(t11 - t10, 2),
