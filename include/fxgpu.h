@@ -183,6 +183,12 @@ int fx_fetch_ranges(fx_handle *h, int where, int64_t n,
                     int flags, const uint8_t *flags_per_query,
                     uint8_t *dst, const int64_t *dst_off, int64_t *out_len);
 
+/* The same for ONE range and a host buffer -- what a single getter of the reference does (pyfastx_index_fill_cache +
+ * the copy of slen bytes, index.c:694-707, sequence.c:346-347; pyfastx_read_random_reader, read.c:37-45): descriptor
+ * and result travel through pinned host memory, one launch and one wait per call.  skip / take as in FetchQ: the
+ * first `skip` kept bytes are dropped, at most `take` are stored at dst; *out_len = bytes stored. */
+int fx_fetch_one(fx_handle *h, int64_t off, int64_t blen, int64_t skip, int64_t take, int flags, uint8_t *dst, int64_t *out_len);
+
 /* Same, but queries are (record id 0-based, start, stop) half-open 0-based
  * base coordinates resolved against the resident FASTA table with the
  * arithmetic of pyfastx_sequence_subscript (sequence.c:498-510) for norm=1

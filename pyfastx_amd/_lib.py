@@ -43,7 +43,7 @@ SYMBOLS = [
     "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_host", "fx_open_device",
     "fx_set_shard", "fx_close", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
     "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
-    "fx_fetch_ranges", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
+    "fx_fetch_ranges", "fx_fetch_one", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
     "fx_fasta_set_row", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
 ]
 
@@ -133,6 +133,7 @@ def lib():
     L.fx_fastq_scan.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.fx_fastq_build_ctx.argtypes = [vp, i64, i64, C.POINTER(FastqSummary)]
     L.fx_fastq_comp.argtypes = [vp, vp, vp]
+    L.fx_fetch_one.argtypes = [vp, i64, i64, i64, i64, i32, vp, C.POINTER(i64)]
     L.fx_fetch_ranges.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, vp, vp]
     L.fx_fasta_fetch.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, vp, vp]
     L.fx_fastq_fetch.argtypes = [vp, i32, i64, vp, i32, i32, vp, vp, vp, vp]
@@ -458,6 +459,13 @@ class Blob:
     @staticmethod
     def _i64(a):
         return np.ascontiguousarray(a, dtype=np.int64)
+
+    def fetch_one(self, off, blen, slen, flags=0, skip=0):
+        """One range -> bytes (fx_fetch_one: one launch, one wait, no staging copies)."""
+        buf = C.create_string_buffer(max(int(slen), 1))
+        got = C.c_int64(0)
+        check(lib().fx_fetch_one(self._h, int(off), int(blen), int(skip), int(slen), int(flags), buf, C.byref(got)))
+        return buf.raw[:got.value]
 
     def fetch_ranges(self, off, blen, slen, flags=0, flags_per_query=None):
         """-> (uint8 buffer, offsets int64[n+1] (exclusive cumsum of slen), out_len int64[n])."""

@@ -85,8 +85,7 @@ class _Staged:
         """pyfastx_index_fill_cache + the getter's slen-byte copy (index.c:694-707, sequence.c:346-347)."""
         if slen <= 0 or blen <= 0:
             return b""
-        buf, offs, ol = self.blob.fetch_ranges([off], [blen], [slen], flags=flags)
-        return buf[:int(ol[0])].tobytes()
+        return self.blob.fetch_one(off, blen, slen, flags=flags)
 
 
 # =========================================================================== FASTA
@@ -519,6 +518,8 @@ class Sequence:
                 else:
                     o, l = self._offset, 0
                 offs.append(o); bls.append(l); sls.append(max(b - a, 0))
+            if len(offs) == 1:                               # a getter of one Sequence: one launch, no staging copies
+                return [st.blob.fetch_one(offs[0], bls[0], sls[0], flags=fl) if sls[0] > 0 and bls[0] > 0 else b""]
             buf, o, ol = st.blob.fetch_ranges(offs, bls, sls, flags=fl)
             return [buf[o[i]:o[i] + ol[i]].tobytes() for i in range(len(offs))]
         # norm = 0: despace the whole record, then slice (sequence.c:100-110)

@@ -147,6 +147,8 @@ struct fx_handle {
     DevBuf<ChunkTot> chunks;
     DevBuf<unsigned long long> ctl;           // Totals (8 words) + list counter + shard summary
     Totals *pin_tot = nullptr;                // pinned host copy of Totals (async read-back without staging)
+    struct OneBox { int64_t off, blen, skip, take, dst_off, out_len; } *one_box = nullptr;   // fx_fetch_one: descriptor in pinned host memory
+    uint8_t *one_out = nullptr;               // ... and its result buffer (pinned, ONE_CAP bytes): no copies either way
     // name -> id table (fx_names.hpp)
     DevBuf<uint32_t> nm_table;
     DevBuf<int64_t> nm_off;                   // FASTA: hoff + 1 materialised; FASTQ uses fq_name_off directly
@@ -217,6 +219,8 @@ extern "C" int fx_close(fx_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->owns && h->d_data) (void)hipFree(h->d_data);
     if (h->pin_tot) (void)hipHostFree(h->pin_tot);
+    if (h->one_box) (void)hipHostFree(h->one_box);
+    if (h->one_out) (void)hipHostFree(h->one_out);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return FX_OK;
@@ -1181,6 +1185,44 @@ extern "C" int fx_fetch_ranges(fx_handle *h, int where, int64_t n, const int64_t
     int64_t ext = 0;
     if (where == FX_HOST && n > 0 && dst_off && slen) ext = std::max<int64_t>(1, host_extent(n, dst_off, slen, nullptr, nullptr));
     return fetch_common(h, where, n, false, off, blen, slen, nullptr, flags, flags_per_query, dst, dst_off, out_len, ext);
+}
+
+// One range for one caller (Sequence.seq, Read.seq, fa.fetch of a single interval): the per-object API of the
+// reference makes one such call per getter.  A batch entry point pays for it with three small uploads, a download
+// and two synchronisations (~65 us); here the descriptor and the result live in pinned host memory that the kernel
+// reads and writes directly, so a call is one launch and one wait.
+static const int64_t ONE_CAP = 1 << 20;
+extern "C" int fx_fetch_one(fx_handle *h, int64_t off, int64_t blen, int64_t skip, int64_t take, int flags, uint8_t *dst,
+                            int64_t *out_len) {
+    if (!h || !out_len || (take > 0 && !dst)) return fail(FX_EINVAL, "null argument");
+    *out_len = 0;
+    if (take <= 0 || blen <= 0) return FX_OK;
+    if (take > ONE_CAP) {                                    // long results: the batch path (staged copies)
+        const int64_t zero = 0;
+        return fetch_common(h, FX_HOST, 1, false, &off, &blen, &take, &skip, flags, nullptr, dst, &zero, out_len, take);
+    }
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!h->one_box) {
+        HIPCHK(hipHostMalloc((void **)&h->one_box, sizeof(*h->one_box), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&h->one_out, (size_t)ONE_CAP + 64, hipHostMallocDefault));
+    }
+    *h->one_box = {off, blen, skip, take, 0, 0};
+    FetchQ q;
+    memset(&q, 0, sizeof q);
+    q.off = &h->one_box->off; q.blen = &h->one_box->blen; q.skip = &h->one_box->skip; q.take = &h->one_box->take;
+    q.dst_off = &h->one_box->dst_off; q.out_len = &h->one_box->out_len;
+    FastaTab tab;
+    memset(&tab, 0, sizeof tab);
+    if (blen > 512) hipLaunchKernelGGL((k_fetch<false, 64, 16>), dim3(1), dim3(BLOCK), 0, h->stream, h->d_data, h->base, h->n, q, tab, (int64_t)1, flags, h->one_out);
+    else            hipLaunchKernelGGL((k_fetch<false, 8, 16>), dim3(1), dim3(BLOCK), 0, h->stream, h->d_data, h->base, h->n, q, tab, (int64_t)1, flags, h->one_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int64_t got = h->one_box->out_len;
+    if (got < 0 || got > take) return fail(FX_ERANGE, "range outside the stream");
+    memcpy(dst, h->one_out, (size_t)got);
+    *out_len = got;
+    return FX_OK;
 }
 
 extern "C" int fx_fasta_fetch(fx_handle *h, int where, int64_t n, const int64_t *seq_id, const int64_t *start,

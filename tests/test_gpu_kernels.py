@@ -624,3 +624,24 @@ def test_fastq_mixed_shapes_40mb(oracle, L):
             assert seq[offs[j]:offs[j + 1]].tobytes() == want, (j, int(k))
             assert qual[offs[j]:offs[j + 1]].tobytes() == raw[qo:qo + m], (j, int(k))
             assert (qi[offs[j]:offs[j + 1]].astype(np.int16) + 33 == np.frombuffer(raw[qo:qo + m], dtype=np.uint8)).all(), (j, int(k))
+
+
+def test_fetch_one_equals_batch(oracle, L):
+    """fx_fetch_one (descriptor and result through pinned host memory, one launch) returns what fx_fetch_ranges
+    returns for the same range: all flag combinations, skip, short and long ranges, and a result above its 1 MiB
+    buffer (which takes the batch path)."""
+    rng = np.random.default_rng(5)
+    seq = np.frombuffer(b"ACGTNacgtnRY", dtype=np.uint8)[rng.integers(0, 12, 3_000_000)].tobytes()
+    raw = b">r\n" + b"\n".join(seq[i:i + 60] for i in range(0, len(seq), 60)) + b"\n"
+    b = L.Blob.from_bytes(raw)
+    for _ in range(200):
+        off = int(rng.integers(3, len(raw) - 10))
+        blen = int(rng.integers(1, min(5000, len(raw) - off)))
+        take = int(rng.integers(1, blen + 1))
+        fl = int(rng.integers(0, 8))
+        want, _, ol = b.fetch_ranges([off], [blen], [take], flags=fl)
+        assert b.fetch_one(off, blen, take, flags=fl) == want[:int(ol[0])].tobytes()
+    big = 2_500_000                                          # > 1 MiB of result
+    want, _, ol = b.fetch_ranges([3], [big], [big], flags=1)
+    assert b.fetch_one(3, big, big, flags=1) == want[:int(ol[0])].tobytes() and int(ol[0]) > (1 << 20)
+    assert b.fetch_one(3, 100, 50, flags=0, skip=20) == oracle.fetch(raw, 3, 100, 1 << 30, 0)[20:70]
