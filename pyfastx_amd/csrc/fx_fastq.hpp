@@ -24,6 +24,10 @@
 #pragma once
 #include "fx_spanscan.hpp"
 
+#ifndef FX_FQ_U
+#define FX_FQ_U 2                       // records per 16-lane group and iteration in k_fastq_comp (10 M reads: 1.18 ms; 3: 1.22, 4: 1.21)
+#endif
+
 namespace fx {
 
 struct FqTab { int64_t *name_off, *rlen, *soff, *qoff; int32_t *name_len, *dlen, *qlen; };
@@ -327,8 +331,8 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp(const uint8_t *__restrict_
     // A wave takes FQ_RPW = 4 * FQ_U consecutive records per iteration (FQ_U per 16-lane group).  Table rows are read
     // one iteration ahead; the first piece of every sequence line and quality line of the iteration is requested
     // before any of them is counted (reads up to 256 bytes need no more than those loads): 2 * FQ_U loads in
-    // flight per lane -- with one record per group the kernel was bound by the load round trip, 2.8 ms for 7 GB.
-    constexpr int FQ_U = 3, FQ_RPW = 4 * FQ_U;
+    // flight per lane -- with one record per group and loads inside branches the kernel was bound by load round trips, 2.8 ms for 7 GB.
+    constexpr int FQ_U = FX_FQ_U, FQ_RPW = 4 * FQ_U;
     const uint8_t *safe = n_bytes >= 16 ? data : reinterpret_cast<const uint8_t *>(&fq_sixteen_zeros);
     const int64_t stride = nwaves * FQ_RPW;
     int64_t i0 = wave * FQ_RPW + grp * FQ_U;               // first record of this group in this iteration

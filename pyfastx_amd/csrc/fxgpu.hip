@@ -1028,7 +1028,7 @@ extern "C" int fx_fastq_comp(fx_handle *h, int64_t base[5], int64_t meta[5]) {
     int per_cu = 0, n_cu = 256;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fastq_comp, BLOCK, 0) != hipSuccess || per_cu <= 0) per_cu = 3;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
-    const unsigned nb = (unsigned)std::min<int64_t>(nblocks(std::max<int64_t>(h->fq_seq_rows, 1), (BLOCK / 64) * 12), (int64_t)per_cu * n_cu);
+    const unsigned nb = (unsigned)std::min<int64_t>(nblocks(std::max<int64_t>(h->fq_seq_rows, 1), (BLOCK / 64) * 4 * FX_FQ_U), (int64_t)per_cu * n_cu);
     FX_LAUNCH(h, K_FASTQ_COMP, k_fastq_comp, dim3(nb), dim3(BLOCK), h->d_data, h->base, h->n, t, h->fq_seq_rows, h->n_reads, h->fq_acc.p);
     HIPCHK(hipGetLastError());
     FastqAcc acc;
