@@ -38,6 +38,7 @@ namespace fx {
 
 constexpr int COMP_GPW = 32;                    // granules per wave at most: 16 words per lane and granule -> 512 per flush at most
 constexpr int COMP_NPL = 10;                    // planes 2^0 .. 2^9
+constexpr int64_t COMP_SMALL = 2048;            // records of at most this many bytes are counted by k_fasta_comp_small
 #ifndef FX_COMP_DEPTH
 #define FX_COMP_DEPTH 2
 #endif
@@ -361,12 +362,16 @@ __global__ __launch_bounds__(COMP_WPB * 64) void k_fasta_comp(const uint8_t *__r
     const int cnt = (int)(nreal - gfirst < gpw ? nreal - gfirst : gpw);    // granules of this wave: gfirst + i, i < cnt
     rare_hist[lane] = 0; rare_hist[lane + 64] = 0;
     uint4 v[4];
-    bool loaded = false;
+    bool loaded = false, table = false;
     int i = 0;
-    int64_t r = -1;
+    int64_t r = -1, hb = 0;
+    unsigned long long segmask = 0;                          // table mode: lanes whose record has bytes to count in this granule
+    int seg_a = 0, seg_b = 0;                               // ... and this lane's byte range (granule-relative)
     // every pass of the loop produces the next (record, byte range) segment of the wave's granules -- one per
     // granule inside a sequence block -- flushes the counters when the record changes, and counts the segment.
-    // All control values are wave-uniform.
+    // The segments of a granule that holds header lines come from a table built once per granule, one lane per
+    // record (two vector loads instead of two scalar round trips per record); records of at most COMP_SMALL bytes
+    // are left out: k_fasta_comp_small counts them.  All control values are wave-uniform.
     for (;;) {
         bool have = false, full = false;
         int64_t rr = COMP_NONE, gseg = 0;
@@ -388,20 +393,45 @@ __global__ __launch_bounds__(COMP_WPB * 64) void k_fasta_comp(const uint8_t *__r
                     }
                 }
                 loaded = true;
-                const int64_t hb = uniform64(hdr_prefix[g]), he = uniform64(hdr_prefix[g + 1]);
+                hb = uniform64(hdr_prefix[g]);
+                const int64_t he = uniform64(hdr_prefix[g + 1]);
                 r = hb - 1;                     // record that owns the first byte of the granule
                 if (whole && he == hb && r >= rmin && gbase + gs >= rec_boff(r)) {     // inside one record's sequence block
                     have = true; full = true; rr = r; a = 0; b = FX_GRAN;
                     ++i; loaded = false;
                     break;
                 }
+                table = he - hb + 1 <= 64;
+                if (table) {                    // lane k <-> record hb - 1 + k
+                    const int64_t rk = hb - 1 + lane;
+                    const bool valid = lane <= he - hb && rk >= rmin && rk < n_hdr;
+                    int64_t rb = 0, re = 0;
+                    if (valid) {
+                        rb = (rk >= 0 ? boff[rk] : lead_from) - gbase;
+                        re = rk + 1 < n_hdr ? hdr[rk + 1] - gbase : n;
+                    }
+                    const int64_t aa = rb > gs ? rb : gs, bb = re < ge ? re : ge;
+                    const bool small = rk >= 0 && rb >= 0 && re - rb <= COMP_SMALL;      // k_fasta_comp_small's records
+                    segmask = __ballot(valid && aa < bb && !small);
+                    seg_a = (int)(aa - gs); seg_b = (int)(bb - gs);
+                }
+            }
+            if (table) {
+                if (!segmask) { ++i; loaded = false; continue; }
+                const int l = __ffsll(segmask) - 1;
+                segmask &= segmask - 1;
+                have = true; rr = hb - 1 + l;
+                a = __builtin_amdgcn_readlane(seg_a, l); b = __builtin_amdgcn_readlane(seg_b, l);
+                if (!segmask) { ++i; loaded = false; }
+                break;
             }
             const int64_t nexth = (r + 1 < n_hdr) ? uniform64(hdr[r + 1]) - gbase : INT64_MAX;
             const int64_t bb = nexth < ge ? nexth : ge;
             if (r >= rmin) {
                 int64_t aa = rec_boff(r) - gbase;
                 if (aa < gs) aa = gs;
-                if (aa < bb) { have = true; rr = r; a = (int)(aa - gs); b = (int)(bb - gs); }
+                const bool small = r >= 0 && rec_boff(r) - gbase >= 0 && (nexth == INT64_MAX ? n : nexth) - (rec_boff(r) - gbase) <= COMP_SMALL;
+                if (aa < bb && !small) { have = true; rr = r; a = (int)(aa - gs); b = (int)(bb - gs); }
             }
             if (nexth >= ge) { ++i; loaded = false; } else ++r;
         }
@@ -411,6 +441,99 @@ __global__ __launch_bounds__(COMP_WPB * 64) void k_fasta_comp(const uint8_t *__r
         if (__ballot(dacc != 0)) {
             comp_rare_pass(data, n, gseg, a, b, rare_hist);
             s.rare = true;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ short records
+// A record of at most COMP_SMALL bytes (from its first sequence byte to the next header line) is counted whole by ONE
+// 16-lane group -- four records per wave, 16 bytes per lane and step -- and its row is written once, instead of being met
+// as a masked segment by every granule it touches and flushed there (a file of short records spent 7.5 ms in those
+// flushes where this kernel needs about one).  Same classification; the four words of a piece go through three full
+// adders and only the carry-out is popcounted, as in k_fastq_comp.  Unexpected bytes: per-group LDS histogram, and the
+// aliased class is taken back out.
+__global__ __launch_bounds__(BLOCK) void k_fasta_comp_small(const uint8_t *__restrict__ data, int64_t n, int64_t gbase,
+                                                           const int64_t *__restrict__ hdr, const int64_t *__restrict__ boff,
+                                                           int64_t n_hdr, unsigned long long *__restrict__ comp) {
+    __shared__ int rare_all[BLOCK / 64][4][128];
+    const int lane = lane_id(), sub = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+    int *rare = rare_all[wv][grp];
+    for (int k = sub; k < 128; k += 16) rare[k] = 0;
+    const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
+    for (int64_t r0 = wave * 4; r0 < n_hdr; r0 += nwaves * 4) {
+        const int64_t r = r0 + grp;
+        int64_t s = 0, e = 0;
+        if (r < n_hdr) {
+            s = boff[r] - gbase;
+            e = r + 1 < n_hdr ? hdr[r + 1] - gbase : n;
+            if (e - s > COMP_SMALL || s < 0) e = s;          // not a short record (or not filled in): nothing to do here
+        }
+        uint32_t ones = 0, twos = 0, lones = 0, ltwos = 0, c4[6] = {0, 0, 0, 0, 0, 0}, l4[5] = {0, 0, 0, 0, 0};
+        bool any_rare = false;
+        for (int64_t p = s + sub * 16; p < e; p += 256) {
+            uint4 v;
+            if (p + 16 <= n) v = *reinterpret_cast<const uint4_u *>(data + p);
+            else {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (int k = 0; k < 16; ++k) if (p + k < n) w[k >> 2] |= (uint32_t)data[p + k] << ((k & 3) * 8);
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            uint32_t x[4] = {v.x, v.y, v.z, v.w}, h[4], hl[4], dacc = 0;
+            const int left = (int)(e - p);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (left < 16) { const uint32_t m = word_range_mask(0, left - 4 * k); x[k] = (x[k] & m) | (0x0A0A0A0Au & ~m); }
+                uint32_t d;
+                comp_classify(x[k], h[k], hl[k], d);
+                dacc |= d;
+            }
+            if (dacc) {
+                any_rare = true;
+#pragma unroll 1
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t hh, ll, d;
+                    comp_classify(x[k], hh, ll, d);
+                    if (!d) continue;
+#pragma unroll 1
+                    for (int j = 0; j < 4; ++j) {
+                        if (!((d >> (8 * j)) & 0xFFu)) continue;
+                        const uint32_t byte = (x[k] >> (8 * j)) & 0xFFu, hk = (hh >> (8 * j)) & 0xFFu, lk = (ll >> (8 * j)) & 0xFFu;
+                        if (byte < 128) atomicAdd(&rare[byte], 1);
+                        if (hk) {
+                            const uint32_t sym = hk == 1 ? 'A' : hk == 2 ? 'C' : hk == 4 ? 'G' : hk == 8 ? 'T' : hk == 16 ? 'N' : 13u;
+                            atomicSub(&rare[hk == 32 ? 13u : (sym | (lk ? 0x20u : 0u))], 1);
+                        }
+                    }
+                }
+            }
+            uint32_t tA, tB, f;
+            csa(tA, ones, ones, h[0], h[1]);   csa(tB, ones, ones, h[2], h[3]);   csa(f, twos, twos, tA, tB);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) c4[c] += __popc(f & (0x01010101u << c));
+            csa(tA, lones, lones, hl[0], hl[1]); csa(tB, lones, lones, hl[2], hl[3]); csa(f, ltwos, ltwos, tA, tB);
+#pragma unroll
+            for (int c = 0; c < 5; ++c) l4[c] += __popc(f & (0x01010101u << c));
+        }
+        // the group's totals (xor shuffles stay inside the 16 lanes), one lane per class writes the row
+        uint32_t mine = 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const uint32_t m = 0x01010101u << c;
+            uint32_t tot = __popc(ones & m) + 2 * __popc(twos & m) + 4 * c4[c];
+            uint32_t lo = c < 5 ? __popc(lones & m) + 2 * __popc(ltwos & m) + 4 * l4[c] : 0u;
+            tot -= lo;
+#pragma unroll
+            for (int d = 8; d > 0; d >>= 1) { tot += __shfl_xor(tot, d, 64); lo += __shfl_xor(lo, d, 64); }
+            if (sub == c) mine = tot;
+            if (c < 5 && sub == 8 + c) mine = lo;
+        }
+        if (mine && r < n_hdr) atomicAdd(&comp[r * 128 + comp_symbol(sub)], (unsigned long long)mine);
+        const unsigned long long rb = __ballot(any_rare);
+        if ((rb >> (grp * 16)) & 0xFFFFull) {               // this group met unexpected bytes: its histogram joins the row
+            for (int k = sub; k < 128; k += 16) {
+                const int vv = rare[k];
+                if (vv) { atomicAdd(&comp[r * 128 + k], (unsigned long long)(long long)vv); rare[k] = 0; }
+            }
         }
     }
 }

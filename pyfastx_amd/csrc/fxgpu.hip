@@ -81,10 +81,10 @@ template <class T> struct DevBuf {      // grow-only device array: rebuilds reus
 // Optional per-kernel HIP-event timing on the handle's own stream (bench.py's
 // roofline leg reads it; off by default so the hot path records no events).
 enum KernelId { K_SPAN_SCAN = 0, K_GRAN_REDUCE, K_GRAN_PREFIX, K_HDR_REC, K_GRAN_LINES, K_GRAN_EXACT, K_FASTA_FINALIZE, K_FETCH,
-                K_FASTA_COMP, K_FASTA_COMP_EDGE, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_NKERN };
+                K_FASTA_COMP, K_FASTA_COMP_EDGE, K_FASTA_COMP_SMALL, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_NKERN };
 static const char *const kKernelNames[K_NKERN] = {
     "k_span_scan", "k_gran_reduce", "k_gran_prefix", "k_hdr_rec", "k_gran_lines", "k_gran_exact", "k_fasta_finalize", "k_fetch",
-    "k_fasta_comp", "k_fasta_comp_edge", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy"};
+    "k_fasta_comp", "k_fasta_comp_edge", "k_fasta_comp_small", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy"};
 
 struct Prof {
     bool on = false;
@@ -839,6 +839,13 @@ static int fasta_comp_dense(fx_handle *h, int64_t lead_from, DevBuf<unsigned lon
                        h->hdr.p, h->fa_boff.p, h->n_hdr, h->hdr_prefix.p, h->ngran, gpw, edge.p, lead_from, d);
     FX_LAUNCH(h, K_FASTA_COMP_EDGE, k_fasta_comp<false>, grid, dim3(COMP_WPB * 64), h->d_data, h->n, h->base,
                        h->hdr.p, h->fa_boff.p, h->n_hdr, h->hdr_prefix.p, h->ngran, gpw, edge.p, lead_from, d);
+    if (h->n_hdr > 0) {                                      // short records: one 16-lane group each
+        int per_cu = 0, n_cu = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fasta_comp_small, BLOCK, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+        const unsigned nb = (unsigned)std::min<int64_t>(nblocks(h->n_hdr, (BLOCK / 64) * 4), (int64_t)per_cu * n_cu);
+        FX_LAUNCH(h, K_FASTA_COMP_SMALL, k_fasta_comp_small, dim3(nb), dim3(BLOCK), h->d_data, h->n, h->base, h->hdr.p, h->fa_boff.p, h->n_hdr, d);
+    }
     HIPCHK(hipGetLastError());
     return FX_OK;
 }

@@ -122,6 +122,7 @@ static int run(const Built &B, bool verify, int reps, const char *what) {
             CK(hipMemsetAsync(de, 0, 4, 0));
             hipLaunchKernelGGL(k_fasta_comp<true>, dim3(nb), dim3(COMP_WPB * 64), 0, 0, d, n, (int64_t)0, dh, db, nr, dp, ngran, gpw, de, (int64_t)-1, dc);
             hipLaunchKernelGGL(k_fasta_comp<false>, dim3(nb), dim3(COMP_WPB * 64), 0, 0, d, n, (int64_t)0, dh, db, nr, dp, ngran, gpw, de, (int64_t)-1, dc);
+            hipLaunchKernelGGL(k_fasta_comp_small, dim3(2048), dim3(BLOCK), 0, 0, d, n, (int64_t)0, dh, db, nr, dc);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
         }
