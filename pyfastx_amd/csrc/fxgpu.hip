@@ -840,9 +840,11 @@ static int fasta_comp_dense(fx_handle *h, int64_t lead_from, DevBuf<unsigned lon
     FX_LAUNCH(h, K_FASTA_COMP_EDGE, k_fasta_comp<false>, grid, dim3(COMP_WPB * 64), h->d_data, h->n, h->base,
                        h->hdr.p, h->fa_boff.p, h->n_hdr, h->hdr_prefix.p, h->ngran, gpw, edge.p, lead_from, d);
     if (h->n_hdr > 0) {                                      // short records: one 16-lane group each
-        int per_cu = 0, n_cu = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fasta_comp_small, BLOCK, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
-        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+        static int per_cu = 0, n_cu = 256;                  // asked once
+        if (!per_cu) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fasta_comp_small, BLOCK, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+        }
         const unsigned nb = (unsigned)std::min<int64_t>(nblocks(h->n_hdr, (BLOCK / 64) * 4), (int64_t)per_cu * n_cu);
         FX_LAUNCH(h, K_FASTA_COMP_SMALL, k_fasta_comp_small, dim3(nb), dim3(BLOCK), h->d_data, h->n, h->base, h->hdr.p, h->fa_boff.p, h->n_hdr, d);
     }
@@ -1032,9 +1034,11 @@ extern "C" int fx_fastq_comp(fx_handle *h, int64_t base[5], int64_t meta[5]) {
     if (rc) return rc;
     const FqTab t{h->fq_name_off.p, h->fq_rlen.p, h->fq_soff.p, h->fq_qoff.p, h->fq_name_len.p, h->fq_dlen.p, h->fq_qlen.p};
     // a grid-stride kernel: exactly as many workgroups as are resident at once (no partial last round)
-    int per_cu = 0, n_cu = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fastq_comp, BLOCK, 0) != hipSuccess || per_cu <= 0) per_cu = 3;
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+    static int per_cu = 0, n_cu = 256;                      // asked once
+    if (!per_cu) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fastq_comp, BLOCK, 0) != hipSuccess || per_cu <= 0) per_cu = 3;
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+    }
     const unsigned nb = (unsigned)std::min<int64_t>(nblocks(std::max<int64_t>(h->fq_seq_rows, 1), (BLOCK / 64) * 4 * FX_FQ_U), (int64_t)per_cu * n_cu);
     FX_LAUNCH(h, K_FASTQ_COMP, k_fastq_comp, dim3(nb), dim3(BLOCK), h->d_data, h->base, h->n, t, h->fq_seq_rows, h->n_reads, h->fq_acc.p);
     HIPCHK(hipGetLastError());
