@@ -415,3 +415,62 @@ def test_fxi_bulk_comp_table_equals_inserts(tmp_path, nrec):
     da.close(); dbb.close()
     with pytest.raises(ValueError):
         fxi.write_fasta_comp_bulk(b, *fxi.comp_rows(comp))   # comp must be empty
+
+
+@pytest.mark.parametrize("page_size", [512, 1024, 8192, 65536])
+def test_fxi_bulk_loaders_other_page_sizes(tmp_path, page_size):
+    """The page loaders take the page size (and the reserved bytes) from the file header: databases created with a
+    page size other than SQLite's default are loaded and verified the same way."""
+    import sqlite3
+    from pyfastx_amd import _lib, fxi
+    rng = np.random.default_rng(page_size)
+    n = 20000
+    names = [("read_%d_%s" % (i, "x" * int(rng.integers(0, 40)))).encode() for i in range(n)]
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in names], out=offs[1:])
+    packed = np.frombuffer(b"".join(names), dtype=np.uint8)
+    cols = [rng.integers(0, 1 << 40, n).astype(np.int64) for _ in range(4)]
+    order = np.array(sorted(range(n), key=names.__getitem__), dtype=np.int64)
+    p = str(tmp_path / "p.fxi")
+    db = sqlite3.connect(p)
+    db.execute("PRAGMA page_size = %d" % page_size)
+    db.executescript(fxi.FASTQ_DDL)
+    db.execute("CREATE UNIQUE INDEX readidx ON read (name)")
+    root = dict(db.execute("SELECT name, rootpage FROM sqlite_master").fetchall())
+    assert db.execute("PRAGMA page_size").fetchone()[0] == page_size
+    db.close()
+    _lib.fxi_bulk_rows(p, root["read"], packed, offs, cols)
+    _lib.fxi_bulk_index(p, root["readidx"], packed, offs, order)
+    db = sqlite3.connect(p)
+    assert db.execute("PRAGMA integrity_check").fetchall() == [("ok",)]
+    assert db.execute("SELECT count(*) FROM read").fetchone()[0] == n
+    for i in rng.integers(0, n, 40).tolist():
+        assert db.execute("SELECT ID, dlen, qoff FROM read WHERE name=?", (names[i].decode(),)).fetchone() == (i + 1, int(cols[0][i]), int(cols[3][i]))
+    db.close()
+
+
+def test_fxi_bulk_integer_serial_types(tmp_path):
+    """Every INTEGER serial type of the record format (0, 1, 1/2/3/4/6/8-byte two's complement, both signs, the
+    extremes) read back by SQLite exactly as written by the page loader."""
+    import sqlite3
+    from pyfastx_amd import _lib, fxi
+    vals = [0, 1, -1, 2, 127, 128, -128, -129, 32767, 32768, -32768, -32769, 8388607, 8388608, -8388608, -8388609,
+            2147483647, 2147483648, -2147483648, -2147483649, 140737488355327, 140737488355328, -140737488355328,
+            -140737488355329, 9223372036854775807, -9223372036854775808]
+    n = len(vals)
+    cols = [np.array(vals, dtype=np.int64), np.array(vals[::-1], dtype=np.int64),
+            np.array(vals, dtype=np.int64) // 3, np.arange(n, dtype=np.int64)]
+    names = [b"n%d" % i for i in range(n)]
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in names], out=offs[1:])
+    p = str(tmp_path / "i.fxi")
+    db = fxi.connect(p)
+    db.executescript(fxi.FASTQ_DDL)
+    root = db.execute("SELECT rootpage FROM sqlite_master WHERE name='read'").fetchone()[0]
+    db.close()
+    _lib.fxi_bulk_rows(p, root, np.frombuffer(b"".join(names), dtype=np.uint8), offs, cols)
+    db = sqlite3.connect(p)
+    assert db.execute("PRAGMA integrity_check").fetchall() == [("ok",)]
+    got = db.execute("SELECT dlen, rlen, soff, qoff FROM read ORDER BY ID").fetchall()
+    assert got == [tuple(int(c[i]) for c in cols) for i in range(n)]
+    db.close()
