@@ -474,3 +474,26 @@ def test_fxi_bulk_integer_serial_types(tmp_path):
     got = db.execute("SELECT dlen, rlen, soff, qoff FROM read ORDER BY ID").fetchall()
     assert got == [tuple(int(c[i]) for c in cols) for i in range(n)]
     db.close()
+
+
+@pytest.mark.parametrize("pragma", ["PRAGMA auto_vacuum = FULL", "PRAGMA journal_mode = WAL"])
+def test_fxi_bulk_refuses_files_it_cannot_extend(tmp_path, pragma):
+    """Auto-vacuum databases interleave pointer-map pages and WAL databases keep their tail elsewhere: the page loaders
+    refuse both (FX_EINVAL) instead of writing pages SQLite would not find; a non-database is refused as well."""
+    import sqlite3
+    from pyfastx_amd import _lib, fxi
+    p = str(tmp_path / "v.fxi")
+    db = sqlite3.connect(p)
+    db.execute(pragma)
+    db.executescript(fxi.FASTQ_DDL)
+    root = db.execute("SELECT rootpage FROM sqlite_master WHERE name='read'").fetchone()[0]
+    db.close()
+    one = np.array([1], dtype=np.int64)
+    with pytest.raises(_lib.FxError) as ei:
+        _lib.fxi_bulk_rows(p, root, np.frombuffer(b"a", dtype=np.uint8), np.array([0, 1], dtype=np.int64), [one, one, one, one])
+    assert ei.value.code == _lib.FX_EINVAL
+    q = str(tmp_path / "not_a_db")
+    open(q, "wb").write(b"x" * 8192)
+    with pytest.raises(_lib.FxError) as ei:
+        _lib.fxi_bulk_rows(q, 2, np.frombuffer(b"a", dtype=np.uint8), np.array([0, 1], dtype=np.int64), [one, one, one, one])
+    assert ei.value.code == _lib.FX_EINVAL
