@@ -612,12 +612,16 @@ __global__ __launch_bounds__(BLOCK) void k_hdr_rec(ScanCtx x, int prev_byte, int
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int64_t cnt = *hgl.count;
-    for (int64_t i = wave; i < cnt; i += nwaves) {
-        const int64_t g = hgl.g[i];
-        const int64_t sbase = g * (int64_t)GRAN;
-        uint4 v[GR_ROWS];
+    // the granule of the NEXT pass is requested as soon as this one's bytes have been turned into masks, so its
+    // load (and the list lookup in front of it) travels while the header lines are worked on
+    int64_t i = wave, g = i < cnt ? hgl.g[i] : 0;
+    uint4 v[GR_ROWS];
+    if (i < cnt) {
 #pragma unroll
-        for (int j = 0; j < GR_ROWS; ++j) v[j] = load16(x.data, sbase + j * 1024 + lane * CHUNK, x.n);
+        for (int j = 0; j < GR_ROWS; ++j) v[j] = load16(x.data, g * (int64_t)GRAN + j * 1024 + lane * CHUNK, x.n);
+    }
+    for (; i < cnt; i += nwaves) {
+        const int64_t sbase = g * (int64_t)GRAN;
         if (is_last && sbase + GRAN > x.n) {
 #pragma unroll
             for (int j = 0; j < GR_ROWS; ++j) {
@@ -657,6 +661,12 @@ __global__ __launch_bounds__(BLOCK) void k_hdr_rec(ScanCtx x, int prev_byte, int
             }
             nlb += (uint32_t)__shfl((int)in, 63, 64);
             hrank += (uint32_t)__shfl((int)ih, 63, 64);
+        }
+        // (sbase keeps addressing this granule below; g moves on to the next one now)
+        if (i + nwaves < cnt) {
+            g = hgl.g[i + nwaves];
+#pragma unroll
+            for (int j = 0; j < GR_ROWS; ++j) v[j] = load16(x.data, g * (int64_t)GRAN + j * 1024 + lane * CHUNK, x.n);
         }
         // records: every lane takes its own header lines, lowest first; the loop runs as long as any lane has one left
 #pragma unroll
