@@ -715,22 +715,13 @@ struct RecView { const int64_t *boff, *llen; const int32_t *dlen; uint32_t *bad;
 // the lane, in a lower lane, in an earlier row, or prevnl[g]) the record is the last header <= p
 // (headers of this granule are hdr[hdr_prefix[g] .. hdr_prefix[g+1])); the header line and the first
 // sequence line are skipped, any other line with p - q != llen counts.
-__device__ __forceinline__ void exact_walk(const ScanCtx &x, const RecView &rv, int64_t cap, int is_last, int prev_byte, int64_t g) {
+// v: the granule's bytes (requested by the caller); on return v is free again -- the caller requests the next granule
+// into it before the rows are walked (exact_rows), which only needs the masks.
+struct ExactMasks { uint32_t nl[GR_ROWS], hm[GR_ROWS]; };
+__device__ __forceinline__ void exact_masks(const ScanCtx &x, uint4 (&v)[GR_ROWS], int is_last, int prev_byte, int64_t g, bool has_hdr,
+                                            ExactMasks &mk) {
     const int lane = lane_id();
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int64_t sbase = g * (int64_t)GRAN, gs = x.gbase + sbase;
-    // everything the walk needs is requested up front (independent loads, one latency)
-    uint4 v[GR_ROWS];
-#pragma unroll
-    for (int j = 0; j < GR_ROWS; ++j) v[j] = load16(x.data, sbase + j * 1024 + lane * CHUNK, x.n);
-    const int64_t hb = x.hdr_prefix[g];
-    int64_t he = x.hdr_prefix[g + 1];
-    if (he > cap) he = cap;
-    int64_t carry = x.prevnl[g];                           // wave-uniform: latest newline so far (global, -1 none)
-    const int64_t r0 = hb - 1;                             // record that owns the first byte of the granule
-    const bool ok0 = r0 >= 0 && r0 < cap;
-    const int32_t d0 = ok0 ? rv.dlen[r0] : -1;
-    const int64_t e0 = ok0 ? rv.boff[r0] - 1 : 0, ll0 = ok0 ? rv.llen[r0] : 0;
+    const int64_t sbase = g * (int64_t)GRAN;
     if (is_last && sbase + GRAN > x.n) {
 #pragma unroll
         for (int j = 0; j < GR_ROWS; ++j) {
@@ -742,15 +733,29 @@ __device__ __forceinline__ void exact_walk(const ScanCtx &x, const RecView &rv, 
             }
         }
     }
+#pragma unroll
+    for (int j = 0; j < GR_ROWS; ++j) {
+        mk.nl[j] = eq_mask16(v[j], 0x0A0A0A0Au);
+        mk.hm[j] = has_hdr ? header_mask16(v[j], mk.nl[j], x.data, sbase + j * 1024 + lane * CHUNK, prev_byte) : 0u;
+    }
+}
+__device__ __forceinline__ void exact_rows(const ScanCtx &x, const RecView &rv, int64_t cap, int64_t g, int64_t hb, const ExactMasks &mk) {
+    const int lane = lane_id();
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int64_t sbase = g * (int64_t)GRAN, gs = x.gbase + sbase;
+    int64_t carry = x.prevnl[g];                           // wave-uniform: latest newline so far (global, -1 none)
+    const int64_t r0 = hb - 1;                             // record that owns the first byte of the granule
+    const bool ok0 = r0 >= 0 && r0 < cap;
+    const int32_t d0 = ok0 ? rv.dlen[r0] : -1;
+    const int64_t e0 = ok0 ? rv.boff[r0] - 1 : 0, ll0 = ok0 ? rv.llen[r0] : 0;
     // The record of a newline at p is the last header line <= p: hdr_prefix[g] - 1 + the header lines of this granule
     // before p, counted from the exact header masks (wave prefix per row) -- no search in the header array.
     int64_t hseen = 0;                                     // wave-uniform: header lines in the rows already done
 #pragma unroll
     for (int j = 0; j < GR_ROWS; ++j) {
-        uint32_t m = eq_mask16(v[j], 0x0A0A0A0Au);
+        uint32_t m = mk.nl[j];
+        const uint32_t hm = mk.hm[j];
         const int cb = j * 1024 + lane * CHUNK;
-        uint32_t hm = 0;
-        if (he > hb) hm = header_mask16(v[j], m, x.data, sbase + cb, prev_byte);    // he > hb is wave-uniform
         const uint32_t ch = __popc(hm), ih = wave_incl_scan(ch);
         const int64_t hbefore = hseen + ih - ch;           // header lines of the granule before this lane's chunk
         hseen += (uint32_t)__shfl((int)ih, 63, 64);
@@ -808,10 +813,29 @@ __global__ __launch_bounds__(BLOCK) void k_gran_lines(ScanCtx x, RecView rv, int
 }
 
 __global__ __launch_bounds__(BLOCK) void k_gran_exact(ScanCtx x, RecView rv, int64_t cap, GranList irr, int is_last, int prev_byte) {
+    const int lane = lane_id();
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int64_t cnt = *irr.count;
-    for (int64_t i = wave; i < cnt; i += nwaves) exact_walk(x, rv, cap, is_last, prev_byte, irr.g[i]);
+    int64_t i = wave, g = i < cnt ? irr.g[i] : 0;
+    uint4 v[GR_ROWS];
+    if (i < cnt) {
+#pragma unroll
+        for (int j = 0; j < GR_ROWS; ++j) v[j] = load16(x.data, g * (int64_t)GRAN + j * 1024 + lane * CHUNK, x.n);
+    }
+    for (; i < cnt; i += nwaves) {
+        const int64_t gc = g, hb = x.hdr_prefix[gc];
+        int64_t he = x.hdr_prefix[gc + 1];
+        if (he > cap) he = cap;
+        ExactMasks mk;
+        exact_masks(x, v, is_last, prev_byte, gc, he > hb, mk);
+        if (i + nwaves < cnt) {                            // the next granule travels while this one's rows are walked
+            g = irr.g[i + nwaves];
+#pragma unroll
+            for (int j = 0; j < GR_ROWS; ++j) v[j] = load16(x.data, g * (int64_t)GRAN + j * 1024 + lane * CHUNK, x.n);
+        }
+        exact_rows(x, rv, cap, gc, hb, mk);
+    }
 }
 
 // blen, slen (index.c:243,335-338,348), norm (index.c:237,342), stat.seqlen (index.c:253-254, 360-369)
