@@ -16,4 +16,5 @@ find $OUT/prof -name '*.db' -size +20M -delete
 timeout 600 python tools/fastq_scale.py 2e7 > $OUT/fastq_scale.json 2> $OUT/fastq_scale.err; cat $OUT/fastq_scale.json
 timeout 900 python tools/bgzf_scale.py 3.0 > $OUT/bgzf_scale.json 2> $OUT/bgzf_scale.err; cat $OUT/bgzf_scale.json
 timeout 600 python tools/e2e_file.py 3.0 > $OUT/e2e.json 2> $OUT/e2e.err; cat $OUT/e2e.json
+timeout 600 python tools/manyrec_scale.py 5e6 300 > $OUT/manyrec.json 2> $OUT/manyrec.err; cat $OUT/manyrec.json
 nproc; free -g | head -2
