@@ -497,3 +497,69 @@ def test_fxi_bulk_refuses_files_it_cannot_extend(tmp_path, pragma):
     with pytest.raises(_lib.FxError) as ei:
         _lib.fxi_bulk_rows(q, 2, np.frombuffer(b"a", dtype=np.uint8), np.array([0, 1], dtype=np.int64), [one, one, one, one])
     assert ei.value.code == _lib.FX_EINVAL
+
+
+def test_reference_opens_our_bulk_written_fxi(oracle, tmp_path):
+    """The REAL reference (oracle/_ref, compiled from /root/reference) opens index files whose b-trees were written as
+    pages by fx_fxi_bulk_rows / fx_fxi_bulk_index / fx_fxi_bulk_index_int -- FASTA (seq + chromidx, comp + seqidx) and
+    FASTQ (read + readidx) -- and answers by id, by name (through the bulk-loaded UNIQUE INDEX) and with composition
+    exactly as from its own index.  Runs only where oracle/_ref was built."""
+    import glob
+    import shutil
+    import sys
+    from conftest import ROOT, DATA
+    if not glob.glob(os.path.join(ROOT, "oracle", "_ref", "pyfastx*.so")):
+        pytest.skip("oracle/_ref not built here")
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
+    import pyfastx
+    from pyfastx_amd import fxi
+    # ---- FASTA
+    raw = fixture_bytes("test.fa")
+    recs, tot = oracle.fasta_index(raw)
+    n = len(recs)
+    names = [raw[r["name_off"]:r["name_off"] + r["name_len"]] for r in recs]
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in names], out=offs[1:])
+    packed = np.frombuffer(b"".join(names), dtype=np.uint8)
+    order = np.array(sorted(range(n), key=names.__getitem__), dtype=np.int64)
+    cols = {k: recs[k].astype(np.int64) for k in ("boff", "blen", "slen", "llen", "elen", "norm", "dlen")}
+    ours, theirs = str(tmp_path / "ours.fa"), str(tmp_path / "theirs.fa")
+    for p in (ours, theirs):
+        open(p, "wb").write(raw)
+    db = fxi.write_fasta_bulk(ours + ".fxi", packed, offs, cols, tot, order=order)
+    db.close()
+    db = fxi.write_fasta_comp_bulk(ours + ".fxi", *fxi.comp_rows(oracle.fasta_comp(raw, n)))
+    db.close()
+    fa, fb = pyfastx.Fasta(ours), pyfastx.Fasta(theirs, full_index=True)       # loads OUR index / builds its own
+    assert len(fa) == len(fb) == n and fa.size == fb.size
+    assert fa.composition == fb.composition and fa.gc_content == fb.gc_content
+    rng = np.random.default_rng(3)
+    for i in rng.integers(0, n, 60).tolist():
+        nm = names[i].decode()
+        assert fa[nm].id == fb[nm].id == i + 1 and fa[nm].seq == fb[nm].seq          # by name: chromidx
+        assert fa[i].name == nm and fa[i][3:40].seq == fb[i][3:40].seq
+        assert fa[i].composition == fb[i].composition and fa[i].gc_content == fb[i].gc_content
+    assert "no such name" not in fa and names[5].decode() in fa
+    assert fa.fetch(names[7].decode(), (1, 30)) == fb.fetch(names[7].decode(), (1, 30))
+    del fa, fb
+    # ---- FASTQ
+    rawq = fixture_bytes("test.fq")
+    rq, size, ln = oracle.fastq_index(rawq)
+    m = len(rq)
+    qn = [rawq[int(r["name_off"]):int(r["name_off"]) + int(r["name_len"])] for r in rq]
+    qo = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in qn], out=qo[1:])
+    qorder = np.array(sorted(range(m), key=qn.__getitem__), dtype=np.int64)
+    qcols = {k: rq[k].astype(np.int64) for k in ("dlen", "rlen", "soff", "qoff")}
+    oq, tq = str(tmp_path / "ours.fq"), str(tmp_path / "theirs.fq")
+    for p in (oq, tq):
+        open(p, "wb").write(rawq)
+    db = fxi.write_fastq_bulk(oq + ".fxi", np.frombuffer(b"".join(qn), dtype=np.uint8), qo, qcols, size, order=qorder)
+    c = oracle.fastq_composition(rawq)
+    fxi.write_fastq_comp(db, [c["a"], c["c"], c["g"], c["t"], c["n"]], [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"], c["phred"]])
+    db.close()
+    qa, qb = pyfastx.Fastq(oq), pyfastx.Fastq(tq)
+    assert len(qa) == len(qb) == m and qa.size == qb.size and qa.composition == qb.composition
+    for i in rng.integers(0, m, 40).tolist():
+        nm = qn[i].decode()
+        assert qa[nm].id == qb[nm].id == i + 1 and qa[nm].seq == qb[nm].seq and qa[i].qual == qb[i].qual
