@@ -456,32 +456,172 @@ class Fasta:
 
 
 class FastaKeys:
-    """Minimal sqlite-backed view of sequence names (fakeys.c; sort/filter DSL is out of scope)."""
+    """pyfastx.FastaKeys (fakeys.c): a view of the sequence names over the .fxi with the reference's sort / filter
+    vocabulary -- `keys.sort(by='id'|'name'|'length', reverse=False)`, `keys.filter(keys > 700, keys % 'JZ8226')`,
+    `keys.reset()`.  Comparisons and `%` do not filter by themselves: they return SQL fragments (comparisons accumulate,
+    so that `600 <= keys <= 700` yields both bounds, fakeys.c:310-352) which filter() joins with AND."""
+
+    _SORTS = {"id": "ID", "name": "chrom", "length": "slen"}                       # fakeys.c:7-8, 284-295
 
     def __init__(self, owner, n):
         self._owner, self._n = owner, n                      # the Fasta: its connection may be re-opened (bulk-loaded comp table)
+        self._filter = self._order = self._temp = None
+        self._cursor = None
 
     @property
     def _db(self):
         return self._owner._db
 
+    def _where(self):
+        return "WHERE %s" % self._filter if self._filter else ""
+
+    def _select(self, tail=""):
+        return "SELECT chrom FROM seq %s %s %s" % (self._where(), self._order or "ORDER BY ID", tail)
+
     def __len__(self):
         return self._n
 
-    def __iter__(self):
-        for (nm,) in self._db.execute("SELECT chrom FROM seq ORDER BY ID"):
-            yield nm
+    def __repr__(self):
+        return "<FastaKeys> contains %d keys" % self._n                             # fakeys.c:168-170
 
-    def __getitem__(self, i):
+    def __iter__(self):
+        self._cursor = self._db.execute(self._select())                              # fakeys.c:140-145: restarts, returns self
+        return self
+
+    def __next__(self):
+        if self._cursor is None:
+            raise StopIteration
+        row = self._cursor.fetchone()
+        if row is None:
+            self._cursor = None
+            raise StopIteration
+        return row[0]
+
+    def __getitem__(self, item):
+        if isinstance(item, slice):                                                  # fakeys.c:215-246 (the step is ignored there too)
+            start, stop, step = item.indices(self._n)
+            n = len(range(start, stop, step))
+            if n <= 0:
+                return []
+            return [r[0] for r in self._db.execute(self._select("LIMIT %d OFFSET %d" % (n, start)))]
+        if not hasattr(item, "__index__"):
+            raise TypeError("fakeys indices must be integers or slices")
+        i = item.__index__()
         if i < 0:
             i += self._n
-        row = self._db.execute("SELECT chrom FROM seq WHERE ID=?", (i + 1,)).fetchone()
-        if row is None:
+        if i + 1 > self._n:
             raise IndexError("index out of range")
+        if self._filter or self._order:
+            row = self._db.execute(self._select("LIMIT 1 OFFSET ?"), (i,)).fetchone()
+        else:
+            row = self._db.execute("SELECT chrom FROM seq WHERE ID=?", (i + 1,)).fetchone()
+        if row is None:
+            raise ValueError("get item error")
         return row[0]
 
     def __contains__(self, name):
-        return self._db.execute("SELECT 1 FROM seq WHERE chrom=? LIMIT 1", (name,)).fetchone() is not None
+        if type(name) is not str:
+            return False
+        sql = "SELECT 1 FROM seq %s chrom=? LIMIT 1" % ("WHERE %s AND" % self._filter if self._filter else "WHERE")
+        return self._db.execute(sql, (name,)).fetchone() is not None
+
+    def sort(self, by="id", reverse=False):
+        if by not in self._SORTS:
+            raise ValueError("key only can be id, name or length")
+        if by != "id" or reverse:                                                    # fakeys.c:297-299: sort('id') keeps the previous order
+            self._order = "ORDER BY %s %s" % (self._SORTS[by], "DESC" if reverse else "ASC")
+        return self
+
+    def _compare(self, sign, other):
+        if not isinstance(other, int):                                                # PyLong_Check, fakeys.c:316
+            raise ValueError("the compared item must be an integer")
+        term = "slen %s %d" % (sign, int(other))
+        self._temp = term if self._temp is None else self._temp + " AND " + term
+        return self._temp
+
+    def __lt__(self, other):
+        return self._compare("<", other)
+
+    def __le__(self, other):
+        return self._compare("<=", other)
+
+    def __eq__(self, other):
+        return self._compare("=", other)
+
+    def __ne__(self, other):
+        return self._compare("<>", other)
+
+    def __gt__(self, other):
+        return self._compare(">", other)
+
+    def __ge__(self, other):
+        return self._compare(">=", other)
+
+    __hash__ = object.__hash__
+
+    def __mod__(self, tag):
+        if type(tag) is not str:
+            raise ValueError("the tag after % must be a string")
+        return "chrom LIKE '%%%s%%'" % tag                                            # fakeys.c:354-361
+
+    def filter(self, *conds):
+        if not conds:
+            raise ValueError("no comparison condition provided")
+        self._filter = " AND ".join(conds)
+        self._temp = None
+        self._n = int(self._db.execute("SELECT COUNT(1) FROM seq %s LIMIT 1" % self._where()).fetchone()[0])
+        return self
+
+    def reset(self):
+        self._filter = self._order = self._temp = None
+        row = self._db.execute("SELECT seqnum FROM stat").fetchone()
+        if row is None:
+            raise RuntimeError("get sequence counts error")
+        self._n = int(row[0])
+        return self
+
+
+class FastqKeys:
+    """pyfastx.FastqKeys (fqkeys.c): read names in file order -- len, index, `in`, iteration; no slices (sq_item only)."""
+
+    def __init__(self, owner, n):
+        self._owner, self._n = owner, n
+        self._cursor = None
+
+    def __len__(self):
+        return self._n
+
+    def __repr__(self):
+        return "<FastqKeys> contains %d keys" % self._n                              # fqkeys.c:45-47
+
+    def __iter__(self):
+        self._cursor = self._owner._db.execute("SELECT name FROM read ORDER BY ID")
+        return self
+
+    def __next__(self):
+        row = self._cursor.fetchone() if self._cursor is not None else None
+        if row is None:
+            self._cursor = None
+            raise StopIteration
+        return row[0]
+
+    def __getitem__(self, i):
+        if not hasattr(i, "__index__"):
+            raise TypeError("sequence index must be integer, not '%s'" % type(i).__name__)
+        i = i.__index__()
+        if i < 0:
+            i += self._n
+        if i < 0 or i + 1 > self._n:
+            raise IndexError("index out of range")
+        row = self._owner._db.execute("SELECT name FROM read WHERE ID=? LIMIT 1", (i + 1,)).fetchone()
+        if row is None:
+            raise ValueError("get item error")
+        return row[0]
+
+    def __contains__(self, name):
+        if type(name) is not str:
+            return False
+        return self._owner._db.execute("SELECT 1 FROM read WHERE name=? LIMIT 1", (name,)).fetchone() is not None
 
 
 class Sequence:
@@ -801,7 +941,7 @@ class Fastq:
                 yield nm, _decode(seq[offs[k]:offs[k + 1]]), _decode(qual[offs[k]:offs[k + 1]])
 
     def keys(self):
-        return [r[0] for r in self._db.execute("SELECT name FROM read ORDER BY ID")]
+        return FastqKeys(self, self._counts)                                                   # fastq.c:555-557
 
     # -------------------------------------------------------------- getters
     @property

@@ -563,3 +563,113 @@ def test_reference_opens_our_bulk_written_fxi(oracle, tmp_path):
     for i in rng.integers(0, m, 40).tolist():
         nm = qn[i].decode()
         assert qa[nm].id == qb[nm].id == i + 1 and qa[nm].seq == qb[nm].seq and qa[i].qual == qb[i].qual
+
+
+def _ref_pyfastx():
+    import glob
+    import sys
+    from conftest import ROOT
+    if not glob.glob(os.path.join(ROOT, "oracle", "_ref", "pyfastx*.so")):
+        return None
+    if os.path.join(ROOT, "oracle", "_ref") not in sys.path:
+        sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
+    import pyfastx
+    return pyfastx
+
+
+def _indexed_pair(oracle, tmp_path):
+    """test.fa / test.fq with index files written by fxi.py from the oracle's rows -> paths (no GPU involved)."""
+    from pyfastx_amd import fxi
+    raw = fixture_bytes("test.fa")
+    pa = str(tmp_path / "k.fa")
+    open(pa, "wb").write(raw)
+    recs, tot = oracle.fasta_index(raw)
+    names = [raw[r["name_off"]:r["name_off"] + r["name_len"]].decode() for r in recs]
+    db = fxi.connect(pa + ".fxi")
+    fxi.write_fasta(db, names, {k: recs[k] for k in ("boff", "blen", "slen", "llen", "elen", "norm", "dlen")}, tot)
+    db.close()
+    rawq = fixture_bytes("test.fq")
+    pq = str(tmp_path / "k.fq")
+    open(pq, "wb").write(rawq)
+    rq, size, ln = oracle.fastq_index(rawq)
+    qn = [rawq[int(r["name_off"]):int(r["name_off"]) + int(r["name_len"])].decode() for r in rq]
+    db = fxi.connect(pq + ".fxi")
+    fxi.write_fastq(db, qn, {k: rq[k] for k in ("dlen", "rlen", "soff", "qoff")}, size)
+    db.close()
+    return pa, names, [int(x) for x in recs["slen"]], pq, qn
+
+
+def test_fasta_keys_sort_filter(oracle, tmp_path):
+    """FastaKeys / FastqKeys (fakeys.c, fqkeys.c) over an existing index: the cases of the reference's
+    tests/test_fakeys.py and tests/test_fqkeys.py, checked against plain Python over (name, length) pairs and -- where
+    oracle/_ref is built -- against the real reference opening the same files."""
+    from pyfastx_amd import api
+    pa, names, lens, pq, qn = _indexed_pair(oracle, tmp_path)
+    fa = api.Fasta(pa)                                       # loads the index; nothing is staged on a device
+    n = len(names)
+    keys = fa.keys()
+    assert repr(keys) == "<FastaKeys> contains %d keys" % n and len(keys) == n
+    assert list(keys) == names and list(keys) == names       # iteration restarts
+    assert keys[0] == names[0] and keys[-1] == names[-1] and keys[17 - n] == names[17]
+    assert keys[30:40] == names[30:40] and keys[-20:-10] == names[-20:-10] and keys[n - 3:n + 9] == names[-3:] and keys[5:2] == []
+    assert names[9] in keys and "nope" not in keys and 7 not in keys
+    assert list(keys.sort("id", reverse=True)) == names[::-1]
+    assert list(keys.sort("name")) == sorted(names)
+    by_len = [nm for nm, _ in sorted(zip(names, lens), key=lambda x: x[1])]            # stable, as sqlite's rowid order within ties
+    got = list(keys.sort("length"))
+    assert sorted(got) == sorted(by_len) and [lens[names.index(g)] for g in got] == sorted(lens)
+    assert keys[0] == got[0] and keys[-1] == got[-1] and keys[3:6] == got[3:6]
+    keys.reset()
+    assert list(keys) == names
+    ids = fa.keys()
+    assert list(ids.filter(ids > 700)) == [nm for nm, l in zip(names, lens) if l > 700]
+    assert len(ids) == sum(l > 700 for l in lens)
+    assert list(ids.filter(600 <= ids <= 700)) == [nm for nm, l in zip(names, lens) if 600 <= l <= 700]
+    assert list(ids.filter(ids % "JZ8226")) == [nm for nm in names if "JZ8226" in nm]
+    want = sorted((nm for nm, l in zip(names, lens) if "JZ8226" in nm and l >= 300), reverse=True)
+    assert list(ids.filter(ids % "JZ8226", ids >= 300).sort("name", reverse=True)) == want
+    assert ids[0] == want[0] and ids[-1] == want[-1] and len(ids) == len(want)
+    assert want[1] in ids and [nm for nm in names if nm not in want][0] not in ids       # `in` honours the filter
+    ids.reset()
+    assert len(ids) == n
+    assert list(ids.filter(ids == lens[4])) == [nm for nm, l in zip(names, lens) if l == lens[4]]
+    assert list(ids.filter(ids != lens[4], ids < 200)) == [nm for nm, l in zip(names, lens) if l != lens[4] and l < 200]
+    k2 = fa.keys()
+    with pytest.raises(IndexError):
+        k2[len(k2)]
+    with pytest.raises(ValueError):
+        k2 % list
+    with pytest.raises(ValueError):
+        k2.filter()
+    with pytest.raises(ValueError):
+        k2.sort("sort")
+    with pytest.raises(ValueError):
+        k2 > list
+    with pytest.raises(TypeError):
+        k2[list]
+    # FASTQ keys
+    fq = api.Fastq(pq)
+    qk = fq.keys()
+    assert repr(qk) == "<FastqKeys> contains %d keys" % len(qn) and len(qk) == len(qn)
+    assert list(qk) == qn and qk[0] == qn[0] and qk[-1] == qn[-1] and qk[123] == qn[123]
+    assert qn[77] in qk and "zzz" not in qk and 3 not in qk
+    with pytest.raises(IndexError):
+        qk[len(qn)]
+    # ---- the same questions put to the real reference on the same files
+    ref = _ref_pyfastx()
+    if ref is None:
+        return
+    ra = ref.Fasta(pa)
+    rk, ok = ra.keys(), fa.keys()
+    assert repr(rk) == repr(ok) and list(rk) == list(ok)
+    for by in ("id", "name", "length"):
+        for rev in (False, True):
+            assert list(rk.sort(by, reverse=rev)) == list(ok.sort(by, reverse=rev)), (by, rev)
+            assert rk[0] == ok[0] and rk[-2] == ok[-2] and rk[4:9] == ok[4:9]
+    rk.reset(); ok.reset()
+    assert (rk > 500) == (ok > 500) and (rk <= 900) == (ok <= 900) and (rk % "JZ83") == (ok % "JZ83")   # the fragments themselves
+    assert list(rk.filter(rk >= 250, rk % "JZ82")) == list(ok.filter(ok >= 250, ok % "JZ82")) and len(rk) == len(ok)
+    assert list(rk.filter(300 <= rk <= 400).sort("length", reverse=True)) == list(ok.filter(300 <= ok <= 400).sort("length", reverse=True))
+    assert rk[1:7] == ok[1:7] and (names[0] in rk) == (names[0] in ok)
+    rq_ = ref.Fastq(pq)
+    assert list(rq_.keys()) == list(fq.keys()) and repr(rq_.keys()) == repr(fq.keys()) and rq_.keys()[-5] == fq.keys()[-5]
