@@ -290,6 +290,22 @@ class ShardedFasta:
         dist.all_gather(leads, torch.from_numpy(lead).to(self.comm_dev))
         return comp_fold_leads(comp, [v.cpu().numpy() for v in leads], nh, self.rank)
 
+    def fetcher(self):
+        """ShardFetcher over all ranks' shards (SURVEY 8e "Fetch"): the global record table and every shard's byte range
+        are collected once (all_gather_object of the small per-rank tables -- setup, not the data path); afterwards
+        every rank answers, from its own HBM, the queries whose first byte it holds, and only pieces of queries that
+        cross a cut are exchanged."""
+        if self.world == 1:
+            t = self.local_rows()
+            return ShardFetcher({0: self.blob}, [self.base], [self.base + self.n_bytes], t)
+        cols = ("boff", "blen", "slen", "llen", "elen", "norm")
+        rows = self.local_rows()
+        outs = [None] * self.world
+        self._dist.all_gather_object(outs, (self.base, self.n_bytes, {c: np.asarray(rows[c]) for c in cols}))
+        table = {c: np.concatenate([o[2][c] for o in outs]) for c in cols}
+        return ShardFetcher({self.rank: self.blob}, [o[0] for o in outs], [o[0] + o[1] for o in outs], table,
+                            exchange=allgather_pieces)
+
     def check_against_plan(self, plan, rows, next_plan=None):
         """Analytic ground truth of the generator vs the rows this rank owns."""
         d = self.DELTA if self.world > 1 else 0
@@ -365,3 +381,140 @@ def allgather_fastq_cores(mine, world, device="cpu"):
     outs = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(outs, t)
     return [tuple(int(v) for v in o.cpu()) for o in outs]
+
+
+# ------------------------------------------------------------------ fetch over byte-range shards ("Fetch")
+# The resident stream is range-partitioned across the GPUs, so a query is answered by the rank that holds its bytes.
+# Host side, per batch: (record, start, stop) -> byte range of the global stream (the reference's line arithmetic),
+# ranges -> pieces per shard (vectorised; almost every query is one piece), every rank fetches the pieces inside its
+# own range with the ordinary fetch kernel (global offsets: the kernel clamps to the bytes it holds), and only the
+# handful of queries that cross a cut exchange their pieces (one all_gather_object of a few hundred bytes; nothing
+# when no query crosses).  A query is ANSWERED by the rank that holds its first byte.
+F_UP, F_REV, F_COMP = 1, 2, 4
+
+
+def slice_ranges(table, ids, starts, stops):
+    """(record id, 0-based [start, stop)) -> off, blen, skip, take over the global stream.  Line-regular records
+    (norm=1): exactly the bytes, sequence.c:498-510.  Others: the whole record, sliced after despacing
+    (sequence.c:100-110) -- skip = start."""
+    ids = np.asarray(ids, dtype=np.int64)
+    a = np.asarray(starts, dtype=np.int64)
+    b = np.asarray(stops, dtype=np.int64)
+    boff, blen = np.asarray(table["boff"], dtype=np.int64)[ids], np.asarray(table["blen"], dtype=np.int64)[ids]
+    llen, elen = np.asarray(table["llen"], dtype=np.int64)[ids], np.asarray(table["elen"], dtype=np.int64)[ids]
+    bpl = llen - elen
+    reg = (np.asarray(table["norm"])[ids] != 0) & (bpl > 0)
+    safe = np.where(bpl > 0, bpl, 1)
+    bs, be = a // safe, b // safe
+    off = np.where(reg, boff + a + elen * bs, boff)
+    ln = np.where(reg, (b - a) + (be - bs) * elen, blen)
+    return off, ln, np.where(reg, 0, a), b - a
+
+
+def route_ranges(bases, ends, off, blen):
+    """Byte ranges [off, off+blen) of the global stream -> their pieces per shard [bases[r], ends[r]).
+    -> dict: q (query of each piece), r (shard), poff, plen, cnt (pieces per query), first (shard of the first byte);
+    pieces are ordered by (q, r).  Bytes past the end of the stream belong to nobody (fread semantics, index.c:689)."""
+    bases, ends = np.asarray(bases, dtype=np.int64), np.asarray(ends, dtype=np.int64)
+    off, blen = np.asarray(off, dtype=np.int64), np.asarray(blen, dtype=np.int64)
+    n = off.size
+    stop = np.minimum(off + np.maximum(blen, 0), ends[-1] if ends.size else 0)
+    live = stop > off
+    first = np.clip(np.searchsorted(bases, off, "right") - 1, 0, max(bases.size - 1, 0))
+    last = np.clip(np.searchsorted(bases, stop - 1, "right") - 1, 0, max(bases.size - 1, 0))
+    cnt = np.where(live, last - first + 1, 0).astype(np.int64)
+    start = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(cnt, out=start[1:])
+    q = np.repeat(np.arange(n, dtype=np.int64), cnt)
+    r = first[q] + (np.arange(int(start[-1]), dtype=np.int64) - start[q])
+    poff = np.maximum(off[q], bases[r])
+    plen = np.minimum(stop[q], ends[r]) - poff
+    return {"q": q, "r": r, "poff": poff, "plen": plen, "cnt": cnt, "first": first, "start": start}
+
+
+def _finish(pieces, skip, take, flags):
+    """Pieces of one query (despaced, upper-cased / complemented by the kernel, in stream order) -> its answer:
+    slice after despacing, then reverse (util.c:239-269 order: the complement is bytewise, the reversal is not)."""
+    s = b"".join(pieces)[skip:skip + take]
+    return s[::-1] if flags & F_REV else s
+
+
+class ShardFetcher:
+    """Batched fetch over the byte-range shards of one stream.
+
+    fetchers: {shard index: object with Blob.fetch_ranges} for the shards THIS process holds (one entry per rank in
+    the one-process-per-GPU run; all of them for G logical shards on one GPU); bases/ends: every shard's byte range;
+    table: the global record table (rows concatenated in shard order).  exchange: None, or a callable that takes this
+    process's cross-cut pieces and returns everybody's (all_gather_object over the process group)."""
+
+    def __init__(self, fetchers, bases, ends, table, exchange=None):
+        self.f, self.table, self.exchange = dict(fetchers), table, exchange
+        self.bases, self.ends = np.asarray(bases, dtype=np.int64), np.asarray(ends, dtype=np.int64)
+
+    def fetch(self, ids, starts, stops, flags=0, flags_per_query=None):
+        """-> (qidx, buf, offs): the queries this process answers (those whose first byte it holds), their bases back
+        to back, offsets[len(qidx)+1]."""
+        n = len(ids)
+        fl = np.full(n, int(flags), dtype=np.uint8) if flags_per_query is None else np.asarray(flags_per_query, dtype=np.uint8)
+        off, blen, skip, take = slice_ranges(self.table, ids, starts, stops)
+        P = route_ranges(self.bases, self.ends, off, blen)
+        q, r = P["q"], P["r"]
+        simple = (P["cnt"] == 1) & (skip == 0)               # one piece, no slicing after despace: the kernel does it all
+        psimple = simple[q]
+        held = np.isin(r, np.fromiter(self.f.keys(), dtype=np.int64, count=len(self.f)))
+        answers = {}
+        loose = []                                            # (query, shard, bytes) of the other pieces we hold
+        for sh, fx in self.f.items():
+            mine = np.nonzero(held & (r == sh))[0]
+            if not mine.size:
+                continue
+            qq = q[mine]
+            s = psimple[mine]
+            want = np.where(s, take[qq], P["plen"][mine])
+            kfl = np.where(s, fl[qq], fl[qq] & np.uint8(F_UP | F_COMP)).astype(np.uint8)
+            buf, offs, ol = fx.fetch_ranges(P["poff"][mine], P["plen"][mine], want, flags_per_query=kfl)
+            for k in np.nonzero(~s)[0].tolist():
+                loose.append((int(qq[k]), int(sh), buf[offs[k]:offs[k] + ol[k]].tobytes()))
+            ks = np.nonzero(s)[0]
+            answers[sh] = (qq[ks], buf, offs[ks], ol[ks])
+        everybody = self.exchange(loose) if self.exchange is not None else loose
+        by_q = {}
+        for qi, sh, bts in sorted(everybody):
+            by_q.setdefault(qi, []).append(bts)
+        # ---- what this process answers, in query order: runs of kernel output + the few answers put together here
+        own = np.fromiter(self.f.keys(), dtype=np.int64, count=len(self.f))
+        mine_q = np.nonzero(np.isin(P["first"], own))[0]
+        m = mine_q.size
+        pos = np.full(n, -1, dtype=np.int64)
+        pos[mine_q] = np.arange(m, dtype=np.int64)
+        bufs, src = [], np.full(m, -1, dtype=np.int64)
+        so, sl = np.zeros(m, dtype=np.int64), np.zeros(m, dtype=np.int64)
+        for sh, (qq, buf, o, ol) in answers.items():
+            pq = pos[qq]
+            src[pq], so[pq], sl[pq] = len(bufs), o, ol
+            bufs.append(buf)
+        for j in np.nonzero(src < 0)[0].tolist():
+            qi = int(mine_q[j])
+            ans = _finish(by_q.get(qi, []), int(skip[qi]), int(take[qi]), int(fl[qi]))
+            src[j], sl[j] = len(bufs), len(ans)
+            bufs.append(np.frombuffer(ans, dtype=np.uint8))
+        offs = np.zeros(m + 1, dtype=np.int64)
+        np.cumsum(sl, out=offs[1:])
+        if m == 0:
+            return mine_q, np.zeros(0, dtype=np.uint8), offs
+        brk = np.nonzero((src[1:] != src[:-1]) | (so[1:] != so[:-1] + sl[:-1]))[0] + 1
+        lo = np.concatenate([[0], brk])
+        hi = np.concatenate([brk, [m]])
+        if lo.size == 1:                                     # the usual batch: the kernel's output is the answer
+            return mine_q, bufs[int(src[0])][int(so[0]):int(so[-1] + sl[-1])], offs
+        runs = [bufs[int(src[a])][int(so[a]):int(so[e - 1] + sl[e - 1])] for a, e in zip(lo.tolist(), hi.tolist())]
+        return mine_q, np.concatenate(runs), offs
+
+
+def allgather_pieces(pieces):
+    """exchange= for ShardFetcher in the one-process-per-GPU run: every rank's cross-cut pieces to every rank (a few
+    hundred bytes per cut; the only exchange of the fetch path, and only for queries that cross a cut)."""
+    import torch.distributed as dist
+    outs = [None] * dist.get_world_size()
+    dist.all_gather_object(outs, pieces)
+    return [p for o in outs for p in o]

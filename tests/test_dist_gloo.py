@@ -96,3 +96,59 @@ def test_cut_inside_header_and_first_line(oracle):
         recs, _ = oracle.fasta_index(raw)
         for k in ("boff", "blen", "slen", "llen", "elen", "norm", "dlen", "name_len"):
             assert got[k] == [int(x) for x in recs[k]], (cut, k)
+
+
+def _fetch_worker(rank, world, port, raw, cuts, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    import fxoracle as oracle
+    from pyfastx_amd import shard
+    from test_host_logic import _OracleShard, _shard_queries
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bases, ends = [0] + list(cuts), list(cuts) + [len(raw)]
+    recs, _ = oracle.fasta_index(raw)
+    table = {k: recs[k] for k in ("boff", "blen", "slen", "llen", "elen", "norm")}
+    ids, st, sp, fl = _shard_queries(np.random.default_rng(77), recs, 400)     # the same batch on every rank
+    # a query across each cut
+    for c in cuts:
+        i = int(np.searchsorted(recs["boff"], c, "right")) - 1
+        ids, st, sp, fl = np.append(ids, i), np.append(st, 0), np.append(sp, int(recs["slen"][i])), np.append(fl, np.uint8(6))
+    f = shard.ShardFetcher({rank: _OracleShard(oracle, raw, bases[rank], ends[rank])}, bases, ends, table,
+                           exchange=shard.allgather_pieces)              # the only exchange: pieces of cross-cut queries
+    qidx, buf, offs = f.fetch(ids, st, sp, flags_per_query=fl)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (qidx, buf, offs))                   # result collection for the check
+    if rank == 0:
+        q.put((ids, st, sp, fl, gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,seed", [(2, 11), (3, 12)])
+def test_sharded_fetch_over_gloo(oracle, world, seed):
+    """One process per shard: every rank answers the queries whose first byte it holds, cross-cut pieces travel by
+    all_gather_object (shard.allgather_pieces); together every query is answered exactly once and correctly."""
+    from test_host_logic import _expected_fetch
+    raw = _fasta(seed)
+    rng = np.random.default_rng(seed)
+    cuts = sorted(set(int(x) for x in rng.integers(100, len(raw) - 100, world - 1)))
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fetch_worker, args=(r, world, port, raw, cuts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ids, st, sp, fl, gathered = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    recs, _ = oracle.fasta_index(raw)
+    seen = np.zeros(len(ids), dtype=np.int64)
+    for qidx, buf, offs in gathered:
+        seen[qidx] += 1
+        for j, qi in enumerate(qidx.tolist()):
+            assert buf[offs[j]:offs[j + 1]].tobytes() == _expected_fetch(oracle, raw, recs, int(ids[qi]), int(st[qi]), int(sp[qi]), int(fl[qi]))
+    assert (seen == 1).all()

@@ -291,3 +291,50 @@ def test_mixed_shapes_in_shards(oracle, L):
         cuts = sorted(set(int(x) for x in rng.integers(1, len(raw), g - 1)))
         check(oracle, L, raw, cuts)
         np.testing.assert_array_equal(sharded_comp(L, raw, cuts), want, err_msg=str(cuts))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fetch_over_shards(oracle, L, seed):
+    """SURVEY 8e "Fetch" through the HIP kernels: every shard a Blob over its own bytes, queries routed by
+    shard.ShardFetcher (the same object the multi-GPU run uses, all shards held by this process), answers equal to the
+    oracle's on the whole stream -- including the queries that cross a cut and records that are not line-regular."""
+    from pyfastx_amd import shard
+    from test_host_logic import _shard_queries, _expected_fetch
+    from test_gpu_kernels import _rand_fasta
+    rng = np.random.default_rng(4200 + seed)
+    raw = _rand_fasta(rng, 30, int(rng.integers(20, 90)), crlf=bool(seed & 1), ragged=False, trailing=(seed != 2), lower=True)
+    raw += _rand_fasta(rng, 4, 50, crlf=bool(seed & 1), ragged=True, trailing=True)      # a few norm=0 records
+    recs, _ = oracle.fasta_index(raw)
+    G = (2, 4, 8, 16)[seed]
+    cuts = sorted(set(int(x) for x in rng.integers(1, len(raw) - 1, G - 1)))
+    got, _ = sharded_rows(L, raw, cuts)
+    table = {k: got[k] for k in ("boff", "blen", "slen", "llen", "elen", "norm")}
+    bases, ends = [0] + cuts, cuts + [len(raw)]
+    blobs = {}
+    for r in range(len(bases)):
+        b = L.Blob.from_bytes(raw[bases[r]:ends[r]])
+        b.set_shard(bases[r], raw[bases[r] - 1] if bases[r] else 10, ends[r] == len(raw))
+        blobs[r] = b
+    ids, st, sp, fl = _shard_queries(rng, recs, 3000)
+    for c in cuts:                                            # windows across every cut that lies inside a sequence
+        i = int(np.searchsorted(recs["boff"], c, "right")) - 1
+        if i >= 0 and recs["slen"][i] > 300 and recs["norm"][i] and recs["boff"][i] < c < recs["boff"][i] + recs["blen"][i]:
+            mid = int((c - recs["boff"][i]) // int(recs["llen"][i])) * int(recs["llen"][i] - recs["elen"][i])
+            mid = min(mid, int(recs["slen"][i]) - 1)
+            ids, st, sp = np.append(ids, i), np.append(st, max(mid - 150, 0)), np.append(sp, min(mid + 150, int(recs["slen"][i])))
+            fl = np.append(fl, np.uint8(rng.integers(0, 8)))
+    f = shard.ShardFetcher(blobs, bases, ends, table)
+    qidx, buf, offs = f.fetch(ids, st, sp, flags_per_query=fl)
+    assert qidx.tolist() == list(range(len(ids)))
+    for j in range(len(ids)):
+        assert buf[offs[j]:offs[j + 1]].tobytes() == _expected_fetch(oracle, raw, recs, int(ids[j]), int(st[j]), int(sp[j]), int(fl[j])), (seed, j)
+    # one process per shard: each answers what it holds; together exactly once
+    pool, seen = [], np.zeros(len(ids), dtype=np.int64)
+    for r in blobs:
+        shard.ShardFetcher({r: blobs[r]}, bases, ends, table, exchange=lambda mine: (pool.extend(mine), [])[1]).fetch(ids, st, sp, flags_per_query=fl)
+    for r in blobs:
+        qidx, buf, offs = shard.ShardFetcher({r: blobs[r]}, bases, ends, table, exchange=lambda mine: list(pool)).fetch(ids, st, sp, flags_per_query=fl)
+        seen[qidx] += 1
+        for j, qi in enumerate(qidx.tolist()):
+            assert buf[offs[j]:offs[j + 1]].tobytes() == _expected_fetch(oracle, raw, recs, int(ids[qi]), int(st[qi]), int(sp[qi]), int(fl[qi]))
+    assert (seen == 1).all()

@@ -673,3 +673,112 @@ def test_fasta_keys_sort_filter(oracle, tmp_path):
     assert rk[1:7] == ok[1:7] and (names[0] in rk) == (names[0] in ok)
     rq_ = ref.Fastq(pq)
     assert list(rq_.keys()) == list(fq.keys()) and repr(rq_.keys()) == repr(fq.keys()) and rq_.keys()[-5] == fq.keys()[-5]
+
+
+class _OracleShard:
+    """Stand-in for Blob.fetch_ranges on one byte-range shard: the oracle's fetch on the bytes the shard holds, with
+    the kernel's clamping of a range to them (fx_kernels.hpp, "clamp to the bytes we hold")."""
+
+    def __init__(self, oracle, raw, base, end):
+        self.o, self.raw, self.base, self.end = oracle, raw[base:end], base, end
+
+    def fetch_ranges(self, off, blen, slen, flags=0, flags_per_query=None):
+        n = len(off)
+        offs = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.maximum(slen, 0), out=offs[1:])
+        buf = np.zeros(max(int(offs[-1]), 1), dtype=np.uint8)
+        ol = np.zeros(n, dtype=np.int64)
+        for i in range(n):
+            lo, hi = max(int(off[i]), self.base), min(int(off[i] + blen[i]), self.end)
+            fl = int(flags if flags_per_query is None else flags_per_query[i])
+            s = self.o.fetch(self.raw, lo - self.base, hi - lo, int(slen[i]), fl) if hi > lo else b""
+            buf[offs[i]:offs[i] + len(s)] = np.frombuffer(s, dtype=np.uint8)
+            ol[i] = len(s)
+        return buf[:int(offs[-1])], offs, ol
+
+
+def _shard_queries(rng, recs, nq):
+    ok = np.nonzero(recs["slen"] > 0)[0]
+    ids = rng.choice(ok, nq)
+    st = (rng.random(nq) * recs["slen"][ids]).astype(np.int64)
+    sp = np.minimum(st + rng.integers(0, 400, nq), recs["slen"][ids])
+    whole = rng.random(nq) < 0.1
+    st[whole], sp[whole] = 0, recs["slen"][ids][whole]
+    return ids, st, sp, rng.integers(0, 8, nq).astype(np.uint8)
+
+
+def _expected_fetch(oracle, raw, recs, i, a, b, fl):
+    r = recs[i]
+    if r["norm"] and r["llen"] > r["elen"]:
+        off, bl = oracle.slice_range(int(r["boff"]), int(r["llen"]), int(r["elen"]), a, b)
+        return oracle.fetch(raw, off, bl, b - a, fl)
+    s = oracle.fetch(raw, r["boff"], r["blen"], r["slen"], fl & 5)[a:b]       # despace the record, slice, then reverse
+    return s[::-1] if fl & 2 else s
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fetch_over_byte_range_shards(oracle, seed):
+    """SURVEY 8e "Fetch": queries bucketed by the shard that holds their bytes, queries crossing a cut split and put
+    together again -- shard.ShardFetcher with the per-shard kernel replaced by the oracle on the shard's bytes; the
+    answers must equal the oracle's on the whole stream, for cuts anywhere (inside lines, inside CRLF, shards holding
+    a fraction of one record)."""
+    from pyfastx_amd import shard
+    rng = np.random.default_rng(7100 + seed)
+    eol = b"\r\n" if seed & 1 else b"\n"
+    parts = []
+    for i in range(12):
+        parts.append(b">c%d d" % i + eol)
+        s = bytes(rng.choice(list(b"ACGTNacgtn"), int(rng.integers(1, 4000))).astype(np.uint8))
+        w = int(rng.integers(7, 80))
+        ragged = i % 5 == 3
+        p = 0
+        while p < len(s):
+            k = w if not ragged else int(rng.integers(1, w + 1))
+            parts.append(s[p:p + k] + eol)
+            p += k
+    raw = b"".join(parts)
+    if seed == 4:
+        raw = raw[:-len(eol)]
+    recs, _ = oracle.fasta_index(raw)
+    G = (2, 3, 5, 8, 16, 2)[seed]
+    cuts = sorted(set(int(x) for x in rng.integers(1, len(raw) - 1, G - 1)))
+    bases, ends = [0] + cuts, cuts + [len(raw)]
+    table = {k: recs[k] for k in ("boff", "blen", "slen", "llen", "elen", "norm")}
+    ids, st, sp, fl = _shard_queries(rng, recs, 600)
+    # make sure some queries cross each cut: a window around every cut that lies inside a sequence
+    extra = []
+    for c in cuts:
+        i = int(np.searchsorted(recs["boff"], c, "right")) - 1
+        if i >= 0 and recs["boff"][i] < c < recs["boff"][i] + recs["blen"][i] and recs["slen"][i] > 4:
+            bpl = max(int(recs["llen"][i] - recs["elen"][i]), 1)
+            mid = min(int((c - recs["boff"][i]) // int(recs["llen"][i]) * bpl), int(recs["slen"][i]) - 1)
+            extra.append((i, max(mid - 150, 0), min(mid + 150, int(recs["slen"][i]))))
+    if extra:
+        e = np.array(extra, dtype=np.int64)
+        ids, st, sp = np.concatenate([ids, e[:, 0]]), np.concatenate([st, e[:, 1]]), np.concatenate([sp, e[:, 2]])
+        fl = np.concatenate([fl, rng.integers(0, 8, len(extra)).astype(np.uint8)])
+    want = [_expected_fetch(oracle, raw, recs, int(i), int(a), int(b), int(f)) for i, a, b, f in zip(ids, st, sp, fl)]
+    shards = {r: _OracleShard(oracle, raw, bases[r], ends[r]) for r in range(len(bases))}
+    # (1) all shards in one process (G logical shards on one GPU)
+    qidx, buf, offs = shard.ShardFetcher(shards, bases, ends, table).fetch(ids, st, sp, flags_per_query=fl)
+    assert qidx.tolist() == list(range(len(ids)))
+    for j in range(len(ids)):
+        assert buf[offs[j]:offs[j + 1]].tobytes() == want[j], (seed, j)
+    off, bl, _, _ = shard.slice_ranges(table, ids, st, sp)
+    P = shard.route_ranges(bases, ends, off, bl)
+    assert (P["cnt"] > 1).sum() >= (1 if extra else 0) and int(P["plen"].sum()) == int(np.minimum(off + bl, len(raw)).sum() - off.sum())
+    # (2) one process per shard: every process fetches what it holds, the cross-cut pieces are exchanged, every query
+    # is answered exactly once
+    procs = [shard.ShardFetcher({r: shards[r]}, bases, ends, table, exchange=lambda mine: mine) for r in shards]
+    pool = []
+    for pr in procs:                                          # first round: collect what each would contribute
+        pr.exchange = lambda mine, pool=pool: (pool.extend(mine), [])[1]
+        pr.fetch(ids, st, sp, flags_per_query=fl)
+    seen = np.zeros(len(ids), dtype=np.int64)
+    for pr in procs:                                          # second round: everybody sees everybody's pieces
+        pr.exchange = lambda mine, pool=pool: list(pool)
+        qidx, buf, offs = pr.fetch(ids, st, sp, flags_per_query=fl)
+        seen[qidx] += 1
+        for j, qi in enumerate(qidx.tolist()):
+            assert buf[offs[j]:offs[j + 1]].tobytes() == want[qi], (seed, qi)
+    assert (seen == 1).all()
