@@ -452,8 +452,8 @@ class ShardFetcher:
         self.bases, self.ends = np.asarray(bases, dtype=np.int64), np.asarray(ends, dtype=np.int64)
 
     def fetch(self, ids, starts, stops, flags=0, flags_per_query=None):
-        """-> (qidx, buf, offs): the queries this process answers (those whose first byte it holds), their bases back
-        to back, offsets[len(qidx)+1]."""
+        """-> (qidx, buf, offs): the queries this process answers (those whose first byte it holds; ordered by shard,
+        then by position in the batch), their bases back to back, offsets[len(qidx)+1]."""
         n = len(ids)
         fl = np.full(n, int(flags), dtype=np.uint8) if flags_per_query is None else np.asarray(flags_per_query, dtype=np.uint8)
         off, blen, skip, take = slice_ranges(self.table, ids, starts, stops)
@@ -484,6 +484,7 @@ class ShardFetcher:
         # ---- what this process answers, in query order: runs of kernel output + the few answers put together here
         own = np.fromiter(self.f.keys(), dtype=np.int64, count=len(self.f))
         mine_q = np.nonzero(np.isin(P["first"], own))[0]
+        mine_q = mine_q[np.argsort(P["first"][mine_q], kind="stable")]     # shard by shard: the kernels' outputs stay whole
         m = mine_q.size
         pos = np.full(n, -1, dtype=np.int64)
         pos[mine_q] = np.arange(m, dtype=np.int64)
