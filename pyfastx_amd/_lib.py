@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "csrc", "libfxgpu.so")
+_SO = os.environ.get("FX_LIBFXGPU") or os.path.join(_HERE, "csrc", "libfxgpu.so")   # the override is for kernel experiments (tools/)
 _LIB = None
 
 FX_HOST, FX_DEVICE = 0, 1

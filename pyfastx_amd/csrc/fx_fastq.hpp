@@ -2,22 +2,32 @@
 //
 // The reference runs a `line_num % 4` state machine over the lines of the file (fastq.c:89-149).
 // A FASTQ record is "four lines", so the only global fact a byte range needs is the line number of
-// its first newline.  Build = two streaming reads of the stream:
+// its first newline.  The build reads the stream ONCE when its lines are not very short:
 //
-//   k_span_scan<1> + k_gran_reduce<1> + k_gran_prefix     newline count / first / last per 4 KiB
-//        granule and their exclusive prefixes (the same kernels the FASTA build uses, count-only mode)
-//   k_fastq_emit      one wave per granule: re-read its 4 KiB (kept in LDS), compact the newline
-//        positions into LDS, then ONE LANE PER NEWLINE: global line index = loff + nl_prefix[g] + rank,
-//        phase = index & 3, and the lane writes the field(s) of record index >> 2 that this newline
-//        determines (header end: name_off / name_len / dlen / soff; sequence end: rlen; '+' line end:
-//        qoff; quality end: qlen).  No line table, no record-level gathers from memory, no atomics.
+//   k_fastq_lines     one wave per 4 KiB granule: newline / space / CR masks of the granule (the last two into LDS), the newline
+//        positions compacted, then one lane per newline writes a 32-bit LINE RECORD -- position in the granule,
+//        "a CR precedes the newline", first space of the line (from its second byte; what a header line's name ends
+//        at) -- into the granule's slot of FQL_CAP records, and the granule's newline count / first / last exactly
+//        as k_span_scan<1> would.  4 bytes per line instead of the line.
+//   k_gran_reduce<1> + k_gran_prefix     exclusive prefixes of the granule counts (shared with the FASTA build)
+//   k_fastq_rows      one wave per granule, one lane per line record: global line index = loff + nl_prefix[g] + rank,
+//        phase = index & 3, and the lane writes the field(s) of record index >> 2 that this newline determines
+//        (header end: name_off / name_len / dlen / soff; sequence end: rlen; '+' line end: qoff; quality end: qlen).
+//        It touches the stream only for a header line that began in an earlier granule (its name may end there).
+//   k_fastq_emit      the same rows from the BYTES of a granule (re-read into LDS): for the granules on a list --
+//        those with more than FQL_CAP lines and the partial last one -- or, when the sampled line density says most
+//        granules would overflow (lines shorter than ~40 bytes), for all of them after a count-only k_span_scan<1>:
+//        the two-read build.
+//   No line table, no record-level gathers from memory; one atomic per workgroup that has an overflowing granule.
 //
-// (A single-pass variant -- the emit kernel getting its line numbers by a decoupled look-back over
-// per-granule counts published by the other waves -- was built and measured: correct, but 213 ms instead
-// of 2.8 ms for 7 GB.  With 1.7 M four-KiB tiles in flight 8 k at a time, every wave walks back over
-// thousands of "counted, prefix not yet known" words with device-scope loads; look-back needs tiles
-// that are large against the number in flight, and large tiles would have to sit in LDS while they wait.
-// Two streaming reads at 6.8 and 4.5 TB/s are the better trade.)
+// 20 M reads of 150 bp (7 GB): two reads 1.05 + 1.55 ms; see DESIGN.md for the one-read numbers.
+//
+// (Measured dead ends, both correct and both slower.  (1) One kernel, the line numbers by a decoupled look-back over
+// per-granule counts published by the other waves: 213 ms -- 1.7 M four-KiB tiles, 8 k in flight, every wave walks
+// back over thousands of "counted, prefix not yet known" words.  (2) The same with 64 KiB tiles -- a persistent grid
+// of 16-wave workgroups, tile in LDS, one 64-bit look-back word per tile polled 256 tiles per round trip, next tile
+// requested early: 4.1 ms at best against 2.6 ms for two reads.  Load, count, barrier, look-back, barrier, emit is
+// ~10 us per tile and workgroup, and the registers of the emit stage leave room for one such workgroup per CU.)
 //
 // Byte-range shards use the same two kernels: the count pass is fx_fastq_scan, one
 // all-gather of two integers gives every rank `loff` / `prev_nl`, the emit pass is fx_fastq_build_ctx.
@@ -57,25 +67,21 @@ __device__ __forceinline__ int64_t first_space(const uint8_t *base, int64_t nb, 
     return ne;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_fastq_emit(ScanCtx x, int prev_byte, int is_last, FqOwn own, FqTab t) {
-    __shared__ uint4 s_data[BLOCK / 64][GRAN / 16];
-    __shared__ uint16_t s_pos[BLOCK / 64][FQ_POSCAP];
-    const int lane = lane_id(), w = threadIdx.x >> 6;
-    const int64_t g = (int64_t)blockIdx.x * (BLOCK / 64) + w;
-    if (g >= x.ngran) return;                              // waves are independent: no workgroup barrier below
-    const int64_t sbase = g * (int64_t)GRAN;
-    uint4 v[GR_ROWS];
+// A wave's granule: its 4 KiB into registers (non-temporal: streamed once) with the virtual end-of-stream newline
+// of an unterminated last line put in (fastq.c:148).
+__device__ __forceinline__ void fq_load_granule(const ScanCtx &x, int is_last, int64_t sbase, uint4 (&v)[GR_ROWS]) {
+    const int lane = lane_id();
     if (sbase + GRAN <= x.n) {
         const uint4 *q = reinterpret_cast<const uint4 *>(x.data + sbase + lane * CHUNK);
 #pragma unroll
-        for (int j = 0; j < GR_ROWS; ++j) {                // streamed once: non-temporal, like the scan
+        for (int j = 0; j < GR_ROWS; ++j) {
             v[j].x = __builtin_nontemporal_load(&q[j * 64].x); v[j].y = __builtin_nontemporal_load(&q[j * 64].y);
             v[j].z = __builtin_nontemporal_load(&q[j * 64].z); v[j].w = __builtin_nontemporal_load(&q[j * 64].w);
         }
     } else {
 #pragma unroll
         for (int j = 0; j < GR_ROWS; ++j) v[j] = load16(x.data, sbase + j * 1024 + lane * CHUNK, x.n);
-        if (is_last) {                                     // virtual end-of-stream newline (fastq.c:148)
+        if (is_last) {
 #pragma unroll
             for (int j = 0; j < GR_ROWS; ++j) {
                 const int64_t p = sbase + j * 1024 + lane * CHUNK;
@@ -87,43 +93,60 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_emit(ScanCtx x, int prev_byte, 
             }
         }
     }
-    uint32_t nlm[GR_ROWS], ex[GR_ROWS];                    // newline mask of the lane's chunk, rank of its first newline in the granule
-    uint32_t M = 0;
+}
+
+// granule -> LDS, newline masks of the lane's chunks; -> newlines in the granule
+__device__ __forceinline__ uint32_t fq_masks(const uint4 (&v)[GR_ROWS], uint4 *sd, uint32_t (&nlm)[GR_ROWS]) {
+    const int lane = lane_id();
+    uint32_t c = 0;
 #pragma unroll
     for (int j = 0; j < GR_ROWS; ++j) {
-        s_data[w][j * 64 + lane] = v[j];
+        sd[j * 64 + lane] = v[j];
         nlm[j] = eq_mask16(v[j], 0x0A0A0A0Au);
-        const uint32_t c = __popc(nlm[j]);
-        const uint32_t inc = wave_incl_scan(c);
-        ex[j] = M + inc - c;
-        M += (uint32_t)__shfl((int)inc, 63, 64);
+        c += __popc(nlm[j]);
     }
-    if (!M) return;
-    const uint8_t *sb = reinterpret_cast<const uint8_t *>(&s_data[w][0]);
+    return wave_sum(c);
+}
+
+// ONE LANE PER NEWLINE of the wave's granule (already in LDS at sb): I0 = global line index of its first newline,
+// q_carry = global offset of the newline before it (-1: none).
+template <int POSCAP>
+__device__ __forceinline__ void fq_emit_rows(const ScanCtx &x, int prev_byte, const FqOwn &own, const FqTab &t, const uint8_t *sb,
+                                             uint16_t *spos, const uint32_t (&nlm)[GR_ROWS],
+                                             uint32_t M, int64_t sbase, int64_t I0, int64_t q_carry) {
+    const int lane = lane_id();
+    uint32_t ex[GR_ROWS];                                  // rank of each chunk's first newline in the granule
+    {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < GR_ROWS; ++j) {
+            const uint32_t c = __popc(nlm[j]);
+            const uint32_t inc = wave_incl_scan(c);
+            ex[j] = acc + inc - c;
+            acc += (uint32_t)__shfl((int)inc, 63, 64);
+        }
+    }
     const int64_t gs = x.gbase + sbase;                    // global offset of the granule
-    const int64_t I0 = own.loff + x.nl_prefix[g];          // global line index of the granule's first newline
-    int64_t q_carry = x.prevnl[g];                         // newline before the current round's first one
-    if (q_carry < 0) q_carry = own.prev_nl;
-    for (uint32_t lo = 0; lo < M; lo += FQ_POSCAP) {
-        // ---- compact the newline positions of ranks [lo, lo + FQ_POSCAP) into LDS
+    for (uint32_t lo = 0; lo < M; lo += POSCAP) {
+        // ---- compact the newline positions of ranks [lo, lo + POSCAP) into LDS
 #pragma unroll
         for (int j = 0; j < GR_ROWS; ++j) {
             uint32_t m = nlm[j], r = ex[j];
             while (m) {
                 const int k = __ffs(m) - 1;
                 m &= m - 1;
-                if (r - lo < (uint32_t)FQ_POSCAP) s_pos[w][r - lo] = (uint16_t)(j * 1024 + lane * CHUNK + k);
+                if (r - lo < (uint32_t)POSCAP) spos[r - lo] = (uint16_t)(j * 1024 + lane * CHUNK + k);
                 ++r;
             }
         }
-        const uint32_t cnt = (M - lo < (uint32_t)FQ_POSCAP) ? M - lo : (uint32_t)FQ_POSCAP;
+        const uint32_t cnt = (M - lo < (uint32_t)POSCAP) ? M - lo : (uint32_t)POSCAP;
         // ---- one lane per newline
         for (uint32_t t0 = 0; t0 < cnt; t0 += 64) {
             const uint32_t i = t0 + lane;
             if (i >= cnt) continue;
-            const int lp = s_pos[w][i];
+            const int lp = spos[i];
             const int64_t p = gs + lp;
-            const int64_t q = i ? gs + s_pos[w][i - 1] : q_carry;     // previous newline (-1: none)
+            const int64_t q = i ? gs + spos[i - 1] : q_carry;         // previous newline (-1: none)
             const int64_t idx = I0 + lo + i;
             const int64_t row = (idx >> 2) - own.k_first;
             if (row < 0 || row >= own.nrows) continue;
@@ -152,8 +175,232 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_emit(ScanCtx x, int prev_byte, 
             default: t.qlen[row] = (int32_t)(len - cr); break;        // quality line, trailing CR dropped (fastq.c:734-737)
             }
         }
-        q_carry = gs + s_pos[w][cnt - 1];
+        q_carry = gs + spos[cnt - 1];
     }
+}
+
+// list == null: every granule of the shard; else the granules list[0 .. nlist)
+__global__ __launch_bounds__(BLOCK) void k_fastq_emit(ScanCtx x, int prev_byte, int is_last, FqOwn own, FqTab t,
+                                                     const uint32_t *__restrict__ list, int64_t nlist) {
+    __shared__ uint4 s_data[BLOCK / 64][GRAN / 16];
+    __shared__ uint16_t s_pos[BLOCK / 64][FQ_POSCAP];
+    const int w = threadIdx.x >> 6;
+    int64_t g = (int64_t)blockIdx.x * (BLOCK / 64) + w;
+    if (g >= (list ? nlist : x.ngran)) return;             // waves are independent: no workgroup barrier below
+    if (list) g = list[g];
+    const int64_t sbase = g * (int64_t)GRAN;
+    uint4 v[GR_ROWS];
+    fq_load_granule(x, is_last, sbase, v);
+    uint32_t nlm[GR_ROWS];                                 // newline mask of the lane's chunks
+    const uint32_t M = fq_masks(v, &s_data[w][0], nlm);
+    if (!M) return;
+    int64_t q_carry = x.prevnl[g];                         // newline before the granule's first one
+    if (q_carry < 0) q_carry = own.prev_nl;
+    fq_emit_rows<FQ_POSCAP>(x, prev_byte, own, t, reinterpret_cast<const uint8_t *>(&s_data[w][0]), &s_pos[w][0], nlm, M, sbase,
+                            own.loff + x.nl_prefix[g], q_carry);
+}
+
+// ---- line records
+constexpr int FQL_CAP = 128;                   // line records per granule slot (lines of 32 bytes on average fill it)
+constexpr uint32_t FQL_CR = 1u << 12, FQL_HAS = 1u << 13;     // record: pos (12 bits) | CR | has-space | space pos << 14
+
+// first set bit of a 4096-bit LDS mask at a position in [a, b), or -1  (a < b)
+__device__ __forceinline__ int fq_first_bit(const uint64_t *m, int a, int b) {
+    const int w1 = (b - 1) >> 6;
+    for (int wd = a >> 6; wd <= w1; ++wd) {
+        uint64_t v = m[wd];
+        if (wd == (a >> 6)) v &= ~0ull << (a & 63);
+        if (wd == w1 && (b & 63)) v &= (1ull << (b & 63)) - 1ull;
+        if (v) return wd * 64 + __ffsll((long long)v) - 1;
+    }
+    return -1;
+}
+
+// the count pass of the one-read build: granules [0, g_end) (all but the partial last one).  A wave takes FQL_G
+// consecutive granules and asks for the next one before it works on the one it has.
+#ifndef FX_FQL_G
+#define FX_FQL_G 4
+#endif
+constexpr int FQL_G = FX_FQL_G;
+
+__global__ __launch_bounds__(BLOCK) void k_fastq_lines(const uint8_t *__restrict__ data, int64_t n, int prev_byte, int64_t g_end,
+                                                      GranPk *__restrict__ out, uint32_t *__restrict__ recs, GranList ovl) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_sp[BLOCK / 64][GRAN / CHUNK], s_cr[BLOCK / 64][GRAN / CHUNK];   // bit k of word c <-> byte 16 c + k
+    __shared__ uint16_t s_pos[BLOCK / 64][FQL_CAP];
+    __shared__ uint32_t ov_n, ov_done, ov_g[(BLOCK / 64) * FQL_G];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { ov_n = 0; ov_done = 0; }
+    __syncthreads();
+    const int64_t gw = ((int64_t)blockIdx.x * (BLOCK / 64) + w) * FQL_G;
+    uint4 v[GR_ROWS];
+    if (gw < g_end) granule_load<true>(v, data, n, 0, gw);
+    for (int kk = 0; kk < FQL_G; ++kk) {
+        const int64_t g = gw + kk;
+        if (g >= g_end) break;
+        const int64_t sbase = g * (int64_t)GRAN;
+        uint32_t nlm[GR_ROWS], c = 0;
+        int first = GRAN, last = -1;
+#pragma unroll
+        for (int j = 0; j < GR_ROWS; ++j) {
+            nlm[j] = eq_mask16(v[j], 0x0A0A0A0Au);
+            s_sp[w][j * 64 + lane] = (uint16_t)eq_mask16(v[j], 0x20202020u);
+            s_cr[w][j * 64 + lane] = (uint16_t)eq_mask16(v[j], 0x0D0D0D0Du);
+            c += __popc(nlm[j]);
+            if (nlm[j]) {
+                const int cb = j * 1024 + lane * CHUNK;
+                if (first == GRAN) first = cb + __ffs(nlm[j]) - 1;
+                last = cb + 31 - __clz(nlm[j]);
+            }
+        }
+        if (kk + 1 < FQL_G && g + 1 < g_end) granule_load<true>(v, data, n, 0, g + 1);       // the next granule is on its way
+        const uint32_t M = wave_sum(c);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const int f = __shfl_xor(first, d, 64), l = __shfl_xor(last, d, 64);
+            first = f < first ? f : first; last = l > last ? l : last;
+        }
+        if (lane == 0) {
+            GranOut o;
+            o.n = M; o.h = 0; o.first = (uint32_t)first; o.last = (uint32_t)last;
+            o.v1 = o.c1 = o.v2 = o.c2 = o.ovf = 0;
+            out[g] = gran_pack(o);
+        }
+        if (M > (uint32_t)FQL_CAP) {                          // more lines than a slot holds: k_fastq_emit reads the granule again
+            if (lane == 0) ov_g[atomicAdd(&ov_n, 1u)] = (uint32_t)g;
+            continue;
+        }
+        if (!M) continue;
+        // ---- compact the newline positions
+        uint32_t r0 = 0;
+#pragma unroll
+        for (int j = 0; j < GR_ROWS; ++j) {
+            const uint32_t cj = __popc(nlm[j]);
+            const uint32_t inc = wave_incl_scan(cj);
+            uint32_t m = nlm[j], r = r0 + inc - cj;
+            while (m) {
+                const int k = __ffs(m) - 1;
+                m &= m - 1;
+                s_pos[w][r++] = (uint16_t)(j * 1024 + lane * CHUNK + k);
+            }
+            r0 += (uint32_t)__shfl((int)inc, 63, 64);
+        }
+        const uint64_t *spm = reinterpret_cast<const uint64_t *>(&s_sp[w][0]);
+        uint32_t *slot = recs + g * (int64_t)FQL_CAP;
+        for (uint32_t i = lane; i < M; i += 64) {
+            const int lp = s_pos[w][i];
+            const int ql = i ? (int)s_pos[w][i - 1] : -1;                // previous newline of the granule
+            int cr;
+            if (lp) cr = (s_cr[w][(lp - 1) >> 4] >> ((lp - 1) & 15)) & 1;
+            else    cr = (sbase ? data[sbase - 1] : prev_byte) == '\r';
+            // a header's name ends at the first space from the line's SECOND byte on (fastq.c:112-117).  The first
+            // line of the granule may have begun earlier: every byte of it that lies here is searched, k_fastq_rows sorts it out
+            const int from = i ? ql + 2 : 0;
+            const int sp = from < lp ? fq_first_bit(spm, from, lp) : -1;
+            slot[i] = (uint32_t)lp | (cr ? FQL_CR : 0u) | (sp >= 0 ? FQL_HAS | ((uint32_t)sp << 14) : 0u);
+        }
+    }
+    // ---- the overflowing granules of the workgroup: one append (the last wave to arrive does it)
+    if (lane == 0) {
+        __threadfence_block();
+        if (atomicAdd(&ov_done, 1u) == (BLOCK / 64) - 1) {
+            const uint32_t cnt = ov_n;
+            if (cnt) {
+                const uint32_t base = atomicAdd(ovl.count, cnt);
+                for (uint32_t k = 0; k < cnt; ++k) ovl.g[base + k] = ov_g[k];
+            }
+        }
+    }
+}
+
+// rows from the line records: granules [0, g_end) that did not overflow.  A wave takes FQR_G consecutive granules and
+// asks for their summaries, then for their records, before it computes anything: one wave per granule spent its time
+// waiting for two dependent round trips (0.73 ms for 1.7 M granules; the traffic is worth 0.25 ms).
+#ifndef FX_FQR_G
+#define FX_FQR_G 4
+#endif
+constexpr int FQR_G = FX_FQR_G;
+
+__device__ __forceinline__ void fq_row_of_line(const ScanCtx &x, const FqOwn &own, const FqTab &t, int64_t gs, uint32_t i, uint32_t r,
+                                               int64_t q, int64_t idx) {
+    const int64_t p = gs + (r & 0xFFFu);
+    const int64_t row = (idx >> 2) - own.k_first;
+    if (row < 0 || row >= own.nrows) return;
+    const int64_t len = p - q - 1;                                        // bytes of the line that ends at p
+    const int cr = (len > 0 && (r & FQL_CR)) ? 1 : 0;
+    switch ((int)(idx & 3)) {
+    case 0: {                                                             // header line  (fastq.c:99-117)
+        int64_t nlen = len - 1;
+        if (nlen > 0 && cr) --nlen;                                       // fastq.c:107-109
+        const int64_t nb = q + 2, ne = nb + nlen;                         // the name's first byte, the end of the search
+        int64_t sp = (r & FQL_HAS) ? gs + ((r >> 14) & 0xFFFu) : ne;      // first space among the line's bytes in this granule
+        if (i == 0 && nb < gs) {                                          // the line began in an earlier granule: those bytes first
+            const int64_t e = ne < gs ? ne : gs;
+            const int64_t hit = x.gbase + first_space(x.data, nb - x.gbase, e - x.gbase);
+            if (hit < e) sp = hit;
+        } else if (i == 0 && sp < nb) {                                   // it begins exactly here and its FIRST byte is a space
+            sp = x.gbase + first_space(x.data, nb - x.gbase, ne - x.gbase);
+        }
+        const int64_t hit = sp < ne ? sp : ne;
+        t.name_off[row] = nb; t.name_len[row] = (int32_t)(hit - nb); t.dlen[row] = (int32_t)len;   // fastq.c:103: '@' and '\r' included
+        t.soff[row] = p + 1;                                              // fastq.c:122
+        break;
+    }
+    case 1: t.rlen[row] = len - cr; break;                                // fastq.c:124-128
+    case 2: t.qoff[row] = p + 1; break;                                   // fastq.c:133
+    default: t.qlen[row] = (int32_t)(len - cr); break;                    // quality line, trailing CR dropped (fastq.c:734-737)
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_fastq_rows(ScanCtx x, FqOwn own, FqTab t, const uint32_t *__restrict__ recs, int64_t g_end) {
+    const int lane = lane_id();
+    const int64_t g0 = ((int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * FQR_G;
+    if (g0 >= g_end) return;
+    uint32_t M[FQR_G];
+    int64_t I0[FQR_G], q0[FQR_G];
+#pragma unroll
+    for (int k = 0; k < FQR_G; ++k) {
+        M[k] = 0;
+        if (g0 + k < g_end) { M[k] = x.go[g0 + k].nh & 0xFFFFu; I0[k] = x.nl_prefix[g0 + k]; q0[k] = x.prevnl[g0 + k]; }
+        if (M[k] > (uint32_t)FQL_CAP) M[k] = 0;                           // overflowed: k_fastq_emit reads that granule again
+    }
+    uint32_t r[FQR_G], rp[FQR_G];
+#pragma unroll
+    for (int k = 0; k < FQR_G; ++k) {
+        const uint32_t *slot = recs + (g0 + k) * (int64_t)FQL_CAP;
+        r[k] = rp[k] = 0;
+        if ((uint32_t)lane < M[k]) { r[k] = slot[lane]; if (lane) rp[k] = slot[lane - 1]; }
+    }
+#pragma unroll
+    for (int k = 0; k < FQR_G; ++k) {
+        const int64_t gs = x.gbase + (g0 + k) * (int64_t)GRAN;
+        const int64_t qq = q0[k] < 0 ? own.prev_nl : q0[k];
+        if ((uint32_t)lane < M[k])
+            fq_row_of_line(x, own, t, gs, (uint32_t)lane, r[k], lane ? gs + (rp[k] & 0xFFFu) : qq, own.loff + I0[k] + lane);
+        if (M[k] > 64u) {                                                  // lines of less than 64 bytes on average
+            const uint32_t *slot = recs + (g0 + k) * (int64_t)FQL_CAP;
+            const uint32_t i = 64u + lane;
+            if (i < M[k]) fq_row_of_line(x, own, t, gs, i, slot[i], gs + (slot[i - 1] & 0xFFFu), own.loff + I0[k] + i);
+        }
+    }
+}
+
+// newlines in up to three 256 KiB windows of the stream (start, middle, end): the line density that decides
+// between the two forms of the build (fastq_count).  out[0] += newlines, out[1] += bytes looked at.
+constexpr int64_t FQ_SAMPLE = 256 * 1024;
+__global__ __launch_bounds__(BLOCK) void k_nl_sample(const uint8_t *__restrict__ data, int64_t n, unsigned long long *out) {
+    const int64_t len = n < FQ_SAMPLE ? n : FQ_SAMPLE;
+    int64_t lo = blockIdx.x == 0 ? 0 : (blockIdx.x == 1 ? (n / 2) & ~15ll : (n - len) & ~15ll);
+    if (blockIdx.x > 0 && n <= (int64_t)(blockIdx.x + 1) * FQ_SAMPLE) return;      // short stream: the first window(s) cover it
+    const int64_t hi = lo + len < n ? lo + len : n;
+    uint32_t c = 0;
+    for (int64_t p = lo + (int64_t)threadIdx.x * CHUNK; p < hi; p += (int64_t)BLOCK * CHUNK) {
+        uint32_t m = eq_mask16(load16(data, p, n), 0x0A0A0A0Au);
+        if (hi - p < CHUNK) m &= (1u << (hi - p)) - 1u;
+        c += __popc(m);
+    }
+    c = wave_sum(c);
+    if (lane_id() == 0) { atomicAdd(&out[0], (unsigned long long)c); }
+    if (threadIdx.x == 0) atomicAdd(&out[1], (unsigned long long)(hi - lo));
 }
 
 // newlines of the shard at a local offset < cut: out[0] = count, out[1] = global offset of the last (-1: none)

@@ -81,10 +81,10 @@ template <class T> struct DevBuf {      // grow-only device array: rebuilds reus
 // Optional per-kernel HIP-event timing on the handle's own stream (bench.py's
 // roofline leg reads it; off by default so the hot path records no events).
 enum KernelId { K_SPAN_SCAN = 0, K_GRAN_REDUCE, K_GRAN_PREFIX, K_HDR_REC, K_GRAN_LINES, K_GRAN_EXACT, K_FASTA_FINALIZE, K_FETCH,
-                K_FASTA_COMP, K_FASTA_COMP_EDGE, K_FASTA_COMP_SMALL, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_NKERN };
+                K_FASTA_COMP, K_FASTA_COMP_EDGE, K_FASTA_COMP_SMALL, K_FASTQ_LINES, K_FASTQ_ROWS, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_NKERN };
 static const char *const kKernelNames[K_NKERN] = {
     "k_span_scan", "k_gran_reduce", "k_gran_prefix", "k_hdr_rec", "k_gran_lines", "k_gran_exact", "k_fasta_finalize", "k_fetch",
-    "k_fasta_comp", "k_fasta_comp_edge", "k_fasta_comp_small", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy"};
+    "k_fasta_comp", "k_fasta_comp_edge", "k_fasta_comp_small", "k_fastq_lines", "k_fastq_rows", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy"};
 
 struct Prof {
     bool on = false;
@@ -167,6 +167,9 @@ struct fx_handle {
     DevBuf<int64_t> fq_name_off, fq_rlen, fq_soff, fq_qoff;
     DevBuf<int32_t> fq_name_len, fq_dlen, fq_qlen;
     DevBuf<FastqAcc> fq_acc;
+    DevBuf<uint32_t> fq_lines;                // k_fastq_lines: FQL_CAP line records per granule
+    bool fq_by_lines = false;                 // the last count pass wrote line records (else: counts only)
+    int64_t fq_nlist = 0;                     // granules k_fastq_emit has to read again (overflowing ones + the partial last)
     int64_t n_reads = 0, fq_size = 0, fq_seq_rows = 0;    // complete records; rows that have a sequence line (>= n_reads)
     int64_t fq_c2 = 0;         // newlines of the shard below core_end - 1 (ownership of records, fx_fastq_scan)
     long long fq_maxlen = 0, fq_minlen = 0;
@@ -661,7 +664,7 @@ static uint32_t *ctl_counter(fx_handle *h, int i) { return (uint32_t *)(h->ctl.p
 // Granule summaries + prefixes of the resident stream.  MODE 0: FASTA (line-length sets, header lines);
 // MODE 1: FASTQ (newline count / first / last only).  Enqueues only; h->ctl holds the totals afterwards.
 template <int MODE>
-static int granule_pass(fx_handle *h) {
+static int granule_pass(fx_handle *h, bool fq_lines = false) {
     int rc;
     const int64_t nfull = h->n / GRAN, ngran = nfull + 1;
     const bool small = ngran <= (2ll << 20);                  // up to 8 GB of stream: 256 granules per chunk, else 1024
@@ -676,7 +679,11 @@ static int granule_pass(fx_handle *h) {
     HIPCHK(hipMemsetAsync(h->ctl.p, 0, 64 * sizeof(unsigned long long), h->stream));
     GranList hgl{h->hdr_grans.p, ctl_counter(h, 0)};
     const int SCAN_WG = 512;                                  // 8 waves = 8 granules per workgroup (tools/scanbench2.hip)
-    if (nfull > 0)
+    if (nfull > 0 && MODE == 1 && fq_lines) {                 // FASTQ, one-read build: the count pass also writes the line records
+        if ((rc = h->fq_lines.alloc(nfull * FQL_CAP))) return rc;
+        FX_LAUNCH(h, K_FASTQ_LINES, k_fastq_lines, dim3(nblocks(nfull, (BLOCK / 64) * FQL_G)), dim3(BLOCK), h->d_data, h->n, h->prev_byte, nfull,
+                  h->gran.p, h->fq_lines.p, hgl);
+    } else if (nfull > 0)
         FX_LAUNCH(h, K_SPAN_SCAN, (k_span_scan<MODE>), dim3(nblocks((nfull + SCAN_GPW - 1) / SCAN_GPW * 64, SCAN_WG)), dim3(SCAN_WG), h->d_data, h->n,
                   h->prev_byte, (int)h->is_last, nfull, h->gran.p, hgl);
     if (small) {
@@ -924,14 +931,36 @@ static int fastq_count(fx_handle *h, int64_t *n_nl_core, int64_t *last_nl_core) 
     if (rc) return rc;
     if (h->n <= 0) return fail(FX_EFORMAT, "empty input");
     h->fasta_built = h->fastq_built = false;
-    if ((rc = granule_pass<1>(h))) return rc;
+    // One read or two?  Line records pay when most granules fit their slot: ask three windows of the stream.
+    static const int force = [] { const char *e = getenv("FX_FQ_LINES"); return e ? atoi(e) : -1; }();   // 0 / 1: experiments
+    bool by_lines = force > 0;
+    if (force < 0 && h->n >= 4 * GRAN) {
+        if ((rc = h->ctl.alloc(64))) return rc;
+        HIPCHK(hipMemsetAsync(h->ctl.p + 56, 0, 2 * sizeof(unsigned long long), h->stream));
+        hipLaunchKernelGGL(k_nl_sample, dim3(3), dim3(BLOCK), 0, h->stream, h->d_data, h->n, h->ctl.p + 56);
+        HIPCHK(hipGetLastError());
+        unsigned long long smp[2];
+        HIPCHK(hipMemcpyAsync(smp, h->ctl.p + 56, sizeof smp, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        by_lines = smp[1] > 0 && (double)smp[0] / (double)smp[1] * GRAN <= 0.7 * FQL_CAP;
+    }
+    if ((rc = granule_pass<1>(h, by_lines))) return rc;
     int64_t *res = (int64_t *)(h->ctl.p + 48);                // 3 words of the control block
     hipLaunchKernelGGL(k_core_count, dim3(1), dim3(64), 0, h->stream, scan_ctx(h), (int)h->is_last, h->n - h->halo, res);
     HIPCHK(hipGetLastError());
     int64_t host[3];
     HIPCHK(hipMemcpyAsync(h->pin_tot, ctl_totals(h), sizeof(Totals), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(host, res, sizeof host, hipMemcpyDeviceToHost, h->stream));
+    uint32_t n_over = 0;
+    if (by_lines) HIPCHK(hipMemcpyAsync(&n_over, ctl_counter(h, 0), sizeof n_over, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->fq_by_lines = by_lines;
+    if (by_lines) {                                           // the partial last granule goes on the list as well
+        const uint32_t tail = (uint32_t)(h->ngran - 1);
+        HIPCHK(hipMemcpyAsync(h->hdr_grans.p + n_over, &tail, sizeof tail, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->fq_nlist = (int64_t)n_over + 1;
+    }
     h->n_nl = h->pin_tot->n_nl;
     h->fq_c2 = host[2];
     h->scanned = true;
@@ -942,11 +971,10 @@ static int fastq_count(fx_handle *h, int64_t *n_nl_core, int64_t *last_nl_core) 
 
 // Emit pass: the read table, given where this shard's lines sit in the global numbering
 // (loff = newlines in earlier shards' cores, prev_nl = offset of the last of them).
-static int fastq_records(fx_handle *h, int64_t loff, int64_t prev_nl, fx_fastq_summary *out) {
-    int rc = use_device(h);
-    if (rc) return rc;
-    // Ownership: record k's header line starts right after global newline 4k-1 (k = 0: at offset 0); the
-    // shard owns the records whose header line STARTS in [base, core_end).
+struct FqPlan { FqOwn own; int64_t n_reads, n_seq; };
+// Ownership: record k's header line starts right after global newline 4k-1 (k = 0: at offset 0); the
+// shard owns the records whose header line STARTS in [base, core_end).
+static int fastq_plan(fx_handle *h, int64_t loff, int64_t prev_nl, FqPlan *pl) {
     const int64_t N = h->n_nl;                                 // shard newlines (virtual end-of-stream one included)
     const int64_t k0 = (loff + 3) / 4;
     const int64_t k_first = k0 + ((loff % 4 == 0 && prev_nl + 1 < h->base) ? 1 : 0);   // that record's header began in the previous shard
@@ -954,37 +982,66 @@ static int fastq_records(fx_handle *h, int64_t loff, int64_t prev_nl, fx_fastq_s
     const int64_t k_end = core_len > 0 ? (loff + h->fq_c2) / 4 + 1 : k_first;           // exclusive
     const int64_t complete = (loff + N) / 4;                   // records whose four lines end inside what we hold
     const int64_t nrows = std::max<int64_t>(k_end - k_first, 0);
-    const int64_t n_reads = std::max<int64_t>(std::min(k_end, complete) - k_first, 0);
+    pl->n_reads = std::max<int64_t>(std::min(k_end, complete) - k_first, 0);
     // rows that have at least their sequence line (an incomplete trailing record still counts in stat.size, fastq.c:125)
-    const int64_t n_seq = loff + N >= 2 ? std::max<int64_t>(std::min(k_end, (loff + N - 2) / 4 + 1) - k_first, 0) : 0;
+    pl->n_seq = loff + N >= 2 ? std::max<int64_t>(std::min(k_end, (loff + N - 2) / 4 + 1) - k_first, 0) : 0;
     if (!h->is_last && k_end > complete)
         return fail(FX_ERANGE, "a FASTQ record that starts in this shard runs past its %lld-byte halo", (long long)h->halo);
-    const int64_t cap = std::max<int64_t>(nrows, 1);
+    pl->own = FqOwn{loff, prev_nl, k_first, nrows};
+    return FX_OK;
+}
+static int fastq_alloc(fx_handle *h, int64_t cap) {
+    int rc;
+    cap = std::max<int64_t>(cap, 1);
     if ((rc = h->fq_name_off.alloc(cap)) || (rc = h->fq_rlen.alloc(cap)) || (rc = h->fq_soff.alloc(cap)) ||
         (rc = h->fq_qoff.alloc(cap)) || (rc = h->fq_name_len.alloc(cap)) || (rc = h->fq_dlen.alloc(cap)) ||
         (rc = h->fq_qlen.alloc(cap)) || (rc = h->fq_acc.alloc(1)))
         return rc;
+    return FX_OK;
+}
+static FqTab fastq_tab(fx_handle *h) {
+    return FqTab{h->fq_name_off.p, h->fq_rlen.p, h->fq_soff.p, h->fq_qoff.p, h->fq_name_len.p, h->fq_dlen.p, h->fq_qlen.p};
+}
+// size / maxlen / minlen over the table, the handle's FASTQ state, the summary
+static int fastq_finish(fx_handle *h, const FqPlan &pl, fx_fastq_summary *out) {
     FastqAcc init;
     memset(&init, 0, sizeof init);
     init.maxlen = 0; init.minlen = 10000000000LL; init.minqs = 104; init.maxqs = 33;   // fastq.c:667-675
     HIPCHK(hipMemcpyAsync(h->fq_acc.p, &init, sizeof init, hipMemcpyHostToDevice, h->stream));
-    const FqTab t{h->fq_name_off.p, h->fq_rlen.p, h->fq_soff.p, h->fq_qoff.p, h->fq_name_len.p, h->fq_dlen.p, h->fq_qlen.p};
-    const FqOwn own{loff, prev_nl, k_first, nrows};
-    FX_LAUNCH(h, K_FASTQ_EMIT, k_fastq_emit, dim3(nblocks(h->ngran, BLOCK / 64)), dim3(BLOCK), scan_ctx(h), h->prev_byte,
-              (int)h->is_last, own, t);
-    FX_LAUNCH(h, K_FASTQ_STATS, k_fastq_stats, dim3((unsigned)std::min<int64_t>(nblocks(n_seq, BLOCK), 1024)), dim3(BLOCK), t,
-              n_seq, n_reads, h->fq_acc.p);
+    const FqTab t = fastq_tab(h);
+    FX_LAUNCH(h, K_FASTQ_STATS, k_fastq_stats, dim3((unsigned)std::min<int64_t>(nblocks(pl.n_seq, BLOCK), 1024)), dim3(BLOCK), t,
+              pl.n_seq, pl.n_reads, h->fq_acc.p);
     HIPCHK(hipGetLastError());
     FastqAcc acc;
     HIPCHK(hipMemcpyAsync(&acc, h->fq_acc.p, sizeof acc, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->n_reads = n_reads;
-    h->fq_seq_rows = n_seq;
+    h->n_reads = pl.n_reads;
+    h->fq_seq_rows = pl.n_seq;
     h->fq_size = (int64_t)acc.size;
     h->fq_maxlen = acc.maxlen; h->fq_minlen = acc.minlen;
     h->fastq_built = true;
-    if (out) { out->n_reads = h->n_reads; out->size = h->fq_size; out->n_lines = h->n_nl; out->n_bytes = h->n; out->first_id = k_first; }
+    if (out) { out->n_reads = h->n_reads; out->size = h->fq_size; out->n_lines = h->n_nl; out->n_bytes = h->n; out->first_id = pl.own.k_first; }
     return FX_OK;
+}
+
+// Emit pass: the read table, given where this shard's lines sit in the global numbering
+// (loff = newlines in earlier shards' cores, prev_nl = offset of the last of them).
+static int fastq_records(fx_handle *h, int64_t loff, int64_t prev_nl, fx_fastq_summary *out) {
+    int rc = use_device(h);
+    if (rc) return rc;
+    FqPlan pl;
+    if ((rc = fastq_plan(h, loff, prev_nl, &pl)) || (rc = fastq_alloc(h, pl.own.nrows))) return rc;
+    if (h->fq_by_lines) {
+        if (h->ngran > 1)
+            FX_LAUNCH(h, K_FASTQ_ROWS, k_fastq_rows, dim3(nblocks(h->ngran - 1, (BLOCK / 64) * FQR_G)), dim3(BLOCK), scan_ctx(h), pl.own, fastq_tab(h),
+                      h->fq_lines.p, h->ngran - 1);
+        FX_LAUNCH(h, K_FASTQ_EMIT, k_fastq_emit, dim3(nblocks(h->fq_nlist, BLOCK / 64)), dim3(BLOCK), scan_ctx(h), h->prev_byte,
+                  (int)h->is_last, pl.own, fastq_tab(h), (const uint32_t *)h->hdr_grans.p, h->fq_nlist);
+    } else {
+        FX_LAUNCH(h, K_FASTQ_EMIT, k_fastq_emit, dim3(nblocks(h->ngran, BLOCK / 64)), dim3(BLOCK), scan_ctx(h), h->prev_byte,
+                  (int)h->is_last, pl.own, fastq_tab(h), (const uint32_t *)nullptr, (int64_t)0);
+    }
+    return fastq_finish(h, pl, out);
 }
 
 extern "C" int fx_set_halo(fx_handle *h, int64_t halo_bytes) {
