@@ -645,3 +645,58 @@ def test_fetch_one_equals_batch(oracle, L):
     want, _, ol = b.fetch_ranges([3], [big], [big], flags=1)
     assert b.fetch_one(3, big, big, flags=1) == want[:int(ol[0])].tobytes() and int(ol[0]) > (1 << 20)
     assert b.fetch_one(3, 100, 50, flags=0, skip=20) == oracle.fetch(raw, 3, 100, 1 << 30, 0)[20:70]
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+def test_fastq_line_records(oracle, L, crlf):
+    """The one-read FASTQ build (k_fastq_lines -> k_fastq_rows): a stream whose sampled windows hold long reads, so the
+    count pass writes line records, with everything in it that the records have to get right -- a run of 4-byte reads
+    that overflows the slots of its granules (those go back through k_fastq_emit), reads longer than a granule (granules
+    without a newline), names that cross a granule boundary, header lines that do not start with '@' or start with a
+    space, spaces in sequence / quality lines, empty names, CRLF -- against the oracle, row by row."""
+    rng = np.random.default_rng(31 + crlf)
+    eol = b"\r\n" if crlf else b"\n"
+    alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
+
+    def rec(name, n, plus=b"+", seq=None, qual=None):
+        s = alpha[rng.integers(0, 5, n)].tobytes() if seq is None else seq
+        q = rng.integers(33, 127, n).astype(np.uint8).tobytes() if qual is None else qual
+        return name + eol + s + eol + plus + eol + q + eol
+
+    parts = []
+    for i in range(700):                                      # long reads: what the three sampled windows see
+        parts.append(rec(b"@long%d len=%d x" % (i, i), int(rng.integers(1500, 6000))))
+    dense = b"".join(rec(b"@s%d" % i, 4) for i in range(900))                  # ~4-byte lines: > 128 lines per granule
+    odd = [rec(b"no_at_sign%d some words" % 1, 50), rec(b"  two leading spaces", 30), rec(b"@", 10), rec(b"@ x", 10),
+           rec(b"@q", 40, seq=b"ACGT ACGT" * 4 + b"ACGT", qual=b"II II" * 8),   # spaces where no name is
+           rec(b"@" + b"n" * 5000 + b" tail", 20), rec(b"@w" + b"x" * 9000, 9000, plus=b"+" + b"w" * 9000)]
+    mid = len(parts) // 3
+    parts[mid:mid] = [dense] + odd
+    # names across granule boundaries: pad so that a header line starts a few bytes before a multiple of 4096
+    raw = b"".join(parts)
+    for k in range(12):
+        pad = (-len(raw) - 5 - k) % 4096
+        raw += rec(b"@pad", max(pad - 20, 1) // 2 + 1)
+        raw += rec(b"@cross_%d_boundary name rest" % k, 33)
+    raw += b"".join(rec(b"@tail%d t" % i, int(rng.integers(1500, 6000))) for i in range(300))
+    assert len(raw) > 3 * 262144 + 4 * len(dense)             # the dense run is not in a sampled window
+    recs, size, ln = oracle.fastq_index(raw)
+    b = L.Blob.from_bytes(raw)
+    s = b.fastq_build()
+    assert (s.n_reads, s.size, s.n_lines) == (len(recs), size, ln)
+    t = b.fastq_table(s.n_reads)
+    for col in ("name_off", "name_len", "dlen", "rlen", "soff", "qoff"):
+        np.testing.assert_array_equal(t[col], recs[col].astype(t[col].dtype), err_msg=col)
+    base, meta = b.fastq_comp()
+    c = oracle.fastq_composition(raw)
+    assert base.tolist() == [c["a"], c["c"], c["g"], c["t"], c["n"]]
+    assert meta.tolist() == [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"], c["phred"]]
+    # the same stream unterminated
+    raw2 = raw[:-len(eol)]
+    recs2, size2, ln2 = oracle.fastq_index(raw2)
+    b2 = L.Blob.from_bytes(raw2)
+    s2 = b2.fastq_build()
+    assert (s2.n_reads, s2.size, s2.n_lines) == (len(recs2), size2, ln2)
+    t2 = b2.fastq_table(s2.n_reads)
+    for col in ("name_off", "name_len", "dlen", "rlen", "soff", "qoff"):
+        np.testing.assert_array_equal(t2[col], recs2[col].astype(t2[col].dtype), err_msg=col)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """FASTQ index build only, C3 shape: wall time per build, per-kernel averages, rows against the generator's truth.
-FX_FQ_ONEPASS=0 selects the two-pass build.   usage: python tools/fq_build_bench.py [n_reads]"""
+FX_FQ_LINES=0 selects the two-read build (count-only pass + k_fastq_emit over every granule).   usage: python tools/fq_build_bench.py [n_reads]"""
 import json
 import os
 import sys
@@ -30,7 +30,7 @@ def main():
     t = b.fastq_table(n)
     for k in ("name_off", "name_len", "dlen", "rlen", "soff", "qoff"):
         ok &= bool((t[k] == cols[k]).all())
-    print(json.dumps({"reads": n, "GB": round(nb / 1e9, 2), "onepass": os.environ.get("FX_FQ_ONEPASS", "1"),
+    print(json.dumps({"reads": n, "GB": round(nb / 1e9, 2), "FX_FQ_LINES": os.environ.get("FX_FQ_LINES", "auto"),
                       "build_ms": round((t1 - t0) / R * 1e3, 3), "GBps": round(nb / ((t1 - t0) / R) / 1e9, 1), "kernels_ms_avg": prof,
                       "rows_equal_truth": ok}))
     if not ok:
