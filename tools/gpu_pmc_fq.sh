@@ -10,3 +10,8 @@ FX_PMC_KERNEL=k_fastq python tools/pmc_dump.py $OUT/sq | tail -4 > $OUT/sq_fq.tx
 timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/sq2 -o pmc -- python tools/fq_build_bench.py $N > $OUT/sq2.json 2> $OUT/sq2.err
 FX_PMC_KERNEL=k_fastq python tools/pmc_dump.py $OUT/sq2 | tail -4 > $OUT/sq2_fq.txt; cat $OUT/sq2_fq.txt
 find $OUT -name '*.csv' -size +2M -delete
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o pmc -- python tools/fq_build_bench.py $N > $OUT/$C.json 2> $OUT/$C.err
+  FX_PMC_KERNEL=k_fastq python tools/pmc_dump.py $OUT/$C | tail -4 > $OUT/${C}_fq.txt; cat $OUT/${C}_fq.txt
+done
+find $OUT -name '*.csv' -size +2M -delete
