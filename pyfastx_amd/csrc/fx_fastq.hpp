@@ -4,13 +4,13 @@
 // A FASTQ record is "four lines", so the only global fact a byte range needs is the line number of
 // its first newline.  The build reads the stream ONCE when its lines are not very short:
 //
-//   k_fastq_lines     one wave per 4 KiB granule: newline / space / CR masks of the granule (the last two into LDS), the newline
-//        positions compacted, then one lane per newline writes a 32-bit LINE RECORD -- position in the granule,
+//   k_fastq_lines     a wave per 4 KiB granule (four in a row, the next one requested early): newline / space / CR
+//        masks of the granule (the last two into LDS), the newline positions compacted, then one lane per newline writes a 32-bit LINE RECORD -- position in the granule,
 //        "a CR precedes the newline", first space of the line (from its second byte; what a header line's name ends
 //        at) -- into the granule's slot of FQL_CAP records, and the granule's newline count / first / last exactly
 //        as k_span_scan<1> would.  4 bytes per line instead of the line.
 //   k_gran_reduce<1> + k_gran_prefix     exclusive prefixes of the granule counts (shared with the FASTA build)
-//   k_fastq_rows      one wave per granule, one lane per line record: global line index = loff + nl_prefix[g] + rank,
+//   k_fastq_rows      a wave per four granules, one lane per line record: global line index = loff + nl_prefix[g] + rank,
 //        phase = index & 3, and the lane writes the field(s) of record index >> 2 that this newline determines
 //        (header end: name_off / name_len / dlen / soff; sequence end: rlen; '+' line end: qoff; quality end: qlen).
 //        It touches the stream only for a header line that began in an earlier granule (its name may end there).
@@ -20,7 +20,10 @@
 //        the two-read build.
 //   No line table, no record-level gathers from memory; one atomic per workgroup that has an overflowing granule.
 //
-// 20 M reads of 150 bp (7 GB): two reads 1.05 + 1.55 ms; see DESIGN.md for the one-read numbers.
+// 20 M reads of 150 bp (7 GB): 1.37 + 0.06 (prefixes) + 0.53 ms = 2.26 ms with k_fastq_stats; two reads: 1.05 + 0.06 + 1.55.
+// k_fastq_lines reads the stream exactly once (PMC: 1.000 x) at 5.1 TB/s with the VALU ~60 % busy (506 instructions per
+// granule, half of them the three exact byte masks); a copy of the granule in LDS and a byte scan of the lines that start
+// with '@' instead of the space / CR maps was slower (1.49 ms).
 //
 // (Measured dead ends, both correct and both slower.  (1) One kernel, the line numbers by a decoupled look-back over
 // per-granule counts published by the other waves: 213 ms -- 1.7 M four-KiB tiles, 8 k in flight, every wave walks
@@ -29,7 +32,7 @@
 // requested early: 4.1 ms at best against 2.6 ms for two reads.  Load, count, barrier, look-back, barrier, emit is
 // ~10 us per tile and workgroup, and the registers of the emit stage leave room for one such workgroup per CU.)
 //
-// Byte-range shards use the same two kernels: the count pass is fx_fastq_scan, one
+// Byte-range shards use the same kernels: the count pass is fx_fastq_scan, one
 // all-gather of two integers gives every rank `loff` / `prev_nl`, the emit pass is fx_fastq_build_ctx.
 #pragma once
 #include "fx_spanscan.hpp"
