@@ -18,6 +18,7 @@ from . import _lib, fxi
 VERSION = "2.3.1"          # API level mirrored (reference src/version.h:1)
 
 _COMP_BULK_MIN = 50_000          # records from which the comp table is bulk-loaded (see Fasta._calc_composition)
+_ITER_BATCH_BASES = 64 << 20     # bases fetched ahead of an iteration over an indexed file, per batch
 _F_UP, _F_REV, _F_COMP, _F_RAW = _lib.FX_UPPER, _lib.FX_REVERSE, _lib.FX_COMPLEMENT, _lib.FX_RAW
 
 
@@ -250,8 +251,29 @@ class Fasta:
     def __iter__(self):
         if self._has_index:                                   # fasta.c:146-172 -> Sequence objects in file order
             self._need_index()
-            for row in self._db.execute("SELECT * FROM seq ORDER BY ID").fetchall():
-                yield self._make(row)
+            # the sequences of the records ahead come off the GPU in batches (one gather per ~64 MB of
+            # bases or 4096 records) and ride along in the Sequence objects; `.seq` of an object taken from the iterator
+            # costs nothing more.  A record larger than a batch is fetched when (and if) it is asked for.
+            rows = self._db.execute("SELECT * FROM seq ORDER BY ID").fetchall()
+            fl = _F_UP if self._uppercase else 0
+            i, n = 0, len(rows)
+            while i < n:
+                j, tot = i, 0
+                while j < n and j - i < 4096 and (tot == 0 or tot + max(rows[j][4], 0) <= _ITER_BATCH_BASES):
+                    tot += max(rows[j][4], 0)
+                    j += 1
+                pick = [k for k in range(i, j) if 0 < rows[k][4] <= _ITER_BATCH_BASES]
+                got = {}
+                if pick:
+                    buf, offs, ol = self._st.blob.fetch_ranges([rows[k][2] for k in pick], [rows[k][3] for k in pick],
+                                                               [rows[k][4] for k in pick], flags=fl)
+                    got = {k: _decode(buf[offs[m]:offs[m] + ol[m]]) for m, k in enumerate(pick)}
+                for k in range(i, j):
+                    sq = self._make(rows[k])
+                    if k in got:
+                        sq._prefetched = got[k]
+                    yield sq
+                i = j
             return
         # build_index=False: (name, seq) tuples (index.c:604-664); records come from the same GPU scan,
         # kept in memory only, and whole sequences are fetched in batches
@@ -677,6 +699,13 @@ class Sequence:
     def _get(self, flags=0):
         if self._seq_len <= 0:
             return ""
+        if flags == 0 and self._complete and getattr(self, "_prefetched", None) is not None:
+            return self._prefetched                             # came with the iterator's batch (Fasta.__iter__)
+        if self._complete:
+            # a whole sequence is the whole record despaced (pyfastx_sequence_get_fullseq, sequence.c:76-98) -- not the
+            # line arithmetic, which a record with ONE odd line (norm = 1 all the same, index.c:342) would get wrong
+            fl = flags | (_F_UP if self._fa._uppercase else 0)
+            return _decode(self._fa._st.fetch(self._offset, self._byte_len, self._seq_len, fl))
         return _decode(self._fetch_many([self.start - 1], [self.end], flags)[0])
 
     # -------------------------------------------------------------- getters
@@ -922,9 +951,18 @@ class Fastq:
 
     def __iter__(self):
         if self._has_index:
-            for row in self._db.execute("SELECT * FROM read ORDER BY ID").fetchall():
-                yield Read(self, *row)
-            return
+            # sequence and quality lines of 16384 reads per gather ride along in the Read objects
+            cur = self._db.execute("SELECT * FROM read ORDER BY ID")
+            while True:
+                rows = cur.fetchmany(16384)
+                if not rows:
+                    return
+                seq, qual, _, offs = self._st.blob.read_fetch([r[4] for r in rows], [r[5] for r in rows], [r[3] for r in rows],
+                                                              want=("seq", "qual"))
+                for m, row in enumerate(rows):
+                    rd = Read(self, *row)
+                    rd._pre = (_decode(seq[offs[m]:offs[m + 1]]), _decode(qual[offs[m]:offs[m + 1]]))
+                    yield rd
         # build_index=False: (name, seq, qual) tuples, from an in-memory GPU scan + batched gathers
         blob = self._st.blob
         s = blob.fastq_build()
@@ -1050,10 +1088,14 @@ class Read:
 
     @property
     def seq(self):
+        if getattr(self, "_pre", None) is not None:
+            return self._pre[0]                                                                # came with the iterator's batch
         return _decode(self._bytes(self._soff, self._read_len))                                # read.c:152-167
 
     @property
     def qual(self):
+        if getattr(self, "_pre", None) is not None:
+            return self._pre[1]
         return _decode(self._bytes(self._qoff, self._read_len))                                # read.c:237-249
 
     @property

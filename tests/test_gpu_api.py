@@ -341,3 +341,50 @@ def test_bulk_written_comp_table(fx, tmp_path, monkeypatch):
                        sorted(r[0] for r in db.execute("SELECT name FROM sqlite_master WHERE type='index'"))))
         db.close()
     assert tables[0] == tables[1] and tables[0][1] == ["chromidx", "seqidx"]
+
+
+def test_iteration_rides_on_batched_fetches(fx, files, tmp_path, oracle):
+    """`for s in fa` / `for r in fq` over an indexed file hand out objects whose sequence (and quality)
+    came off the GPU in one gather per batch; what they return is what the one-by-one getters return, and what the
+    oracle says -- also for a record with ONE odd line (norm = 1 all the same, index.c:342), whose whole sequence is the
+    whole record despaced (sequence.c:76-98), not the line arithmetic."""
+    from conftest import fixture_bytes
+    raw = fixture_bytes("test.fa")
+    recs, _ = oracle.fasta_index(raw)
+    fa = fx.Fasta(files["test.fa"])
+    seen = 0
+    for i, s in enumerate(fa):
+        want = oracle.fetch(raw, recs[i]["boff"], recs[i]["blen"], recs[i]["slen"]).decode()
+        assert s.seq == want == fa[i].seq and s.id == i + 1 and len(s) == len(want)
+        if i % 37 == 0:
+            assert s.antisense == oracle.fetch(raw, recs[i]["boff"], recs[i]["blen"], recs[i]["slen"], 6).decode()
+            assert s[3:20].seq == want[3:20]
+        seen += 1
+    assert seen == len(recs)
+    up = fx.Fasta(files["test.fa"], uppercase=True)
+    assert [s.seq for s in up][:5] == [fa[i].seq.upper() for i in range(5)]
+    # one odd line in the middle, one long last line, an empty record, a record with no trailing newline
+    odd = tmp_path / "odd.fa"
+    text = b">a\nACGTACGT\nAC\nGGGGTTTT\nCCCCAAAA\n>b\nACGT\nACGTACGTAC\n>e\n>c\nTTTTGGGG\nTTTTGG"
+    odd.write_bytes(text)
+    fo = fx.Fasta(str(odd))
+    r2, _ = oracle.fasta_index(text)
+    assert [int(x) for x in r2["norm"]] == [1, 1, 1, 1]
+    want = [oracle.fetch(text, r["boff"], r["blen"], r["slen"]).decode() for r in r2]
+    assert want[0] == "ACGTACGTACGGGGTTTTCCCCAAAA"
+    assert [s.seq for s in fo] == want == [fo[i].seq for i in range(4)]
+    assert fo[0].antisense == oracle.fetch(text, r2[0]["boff"], r2[0]["blen"], r2[0]["slen"], 6).decode()
+    assert str(fo[0]) == want[0] and fo[1].reverse == want[1][::-1]
+    # FASTQ
+    rawq = fixture_bytes("test.fq")
+    rq, size, ln = oracle.fastq_index(rawq)
+    fq = fx.Fastq(files["test.fq"])
+    n = 0
+    for i, r in enumerate(fq):
+        so, qo, m = int(rq["soff"][i]), int(rq["qoff"][i]), int(rq["rlen"][i])
+        assert r.seq == rawq[so:so + m].decode() == fq[i].seq and r.qual == rawq[qo:qo + m].decode() == fq[i].qual
+        assert r.id == i + 1 and len(r) == m
+        if i % 97 == 0:
+            assert r.quali == [c - 33 for c in rawq[qo:qo + m]] and r.antisense == oracle.revcomp(rawq[so:so + m], 3).decode()
+        n += 1
+    assert n == len(rq)
