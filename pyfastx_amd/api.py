@@ -267,7 +267,8 @@ class Fasta:
                 if pick:
                     buf, offs, ol = self._st.blob.fetch_ranges([rows[k][2] for k in pick], [rows[k][3] for k in pick],
                                                                [rows[k][4] for k in pick], flags=fl)
-                    got = {k: _decode(buf[offs[m]:offs[m] + ol[m]]) for m, k in enumerate(pick)}
+                    ball, o, l = _decode(buf), offs.tolist(), ol.tolist()                 # one decode per batch
+                    got = {k: ball[o[m]:o[m] + l[m]] for m, k in enumerate(pick)}
                 for k in range(i, j):
                     sq = self._make(rows[k])
                     if k in got:
@@ -959,9 +960,10 @@ class Fastq:
                     return
                 seq, qual, _, offs = self._st.blob.read_fetch([r[4] for r in rows], [r[5] for r in rows], [r[3] for r in rows],
                                                               want=("seq", "qual"))
+                sall, qall, o = _decode(seq[:int(offs[-1])]), _decode(qual[:int(offs[-1])]), offs.tolist()   # one decode per batch
                 for m, row in enumerate(rows):
                     rd = Read(self, *row)
-                    rd._pre = (_decode(seq[offs[m]:offs[m + 1]]), _decode(qual[offs[m]:offs[m + 1]]))
+                    rd._pre = (sall[o[m]:o[m + 1]], qall[o[m]:o[m + 1]])
                     yield rd
         # build_index=False: (name, seq, qual) tuples, from an in-memory GPU scan + batched gathers
         blob = self._st.blob
