@@ -669,11 +669,40 @@ class Sequence:
         bs, be = a // bpl, b // bpl
         return self._offset + a + self._end_len * bs, (b - a) + (be - bs) * self._end_len
 
+    def _line_regular(self):
+        """May slices of this record go through the line arithmetic?  `norm` says "at most one line of another length"
+        (index.c:342): true of a record whose last line is the short one, and of a record with ONE odd line anywhere
+        else, which the arithmetic gets wrong.  The two are told apart once per record (cached in the Fasta) from the
+        record's byte length and the length of its last line; the odd kind is sliced after despacing the whole record,
+        which is what the reference returns from a warm cache and from Fasta.fetch() (sequence.c:100-110, fasta.c:440-461)."""
+        bpl = self._line_len - self._end_len
+        if not self._normal or bpl <= 0:
+            return False
+        cache = self._fa.__dict__.setdefault("_regular", {})
+        ok = cache.get(self.id)
+        if ok is None:
+            n, e = self._full_len, self._end_len
+            lines = -(-n // bpl)
+            ok = n <= 0 or lines <= 1
+            if not ok and self._byte_len == n + lines * e:
+                stop = min(self._offset + self._byte_len, self._fa._st.blob.size)   # blen counts a newline an unterminated file lacks
+                k = min(stop - self._offset, bpl + 2 * e + 1)
+                tail = self._fa._st.raw(stop - k, k)
+                if tail.endswith(b"\n"):
+                    tail = tail[:-1]
+                p = tail.rfind(b"\n")
+                last = tail[p + 1:] if p >= 0 else None
+                if last is not None and e == 2 and last.endswith(b"\r"):
+                    last = last[:-1]
+                ok = last is not None and len(last) == n - (lines - 1) * bpl
+            cache[self.id] = ok
+        return ok
+
     def _fetch_many(self, starts, stops, flags=0):
         """Bases [a,b) (0-based, of the full record) for several intervals, one GPU batch."""
         fl = flags | (_F_UP if self._fa._uppercase else 0)
         st = self._fa._st
-        if self._normal and self._line_len - self._end_len > 0:
+        if self._line_regular():
             offs, bls, sls = [], [], []
             for a, b in zip(starts, stops):
                 if b > a:

@@ -375,6 +375,17 @@ def test_iteration_rides_on_batched_fetches(fx, files, tmp_path, oracle):
     assert [s.seq for s in fo] == want == [fo[i].seq for i in range(4)]
     assert fo[0].antisense == oracle.fetch(text, r2[0]["boff"], r2[0]["blen"], r2[0]["slen"], 6).decode()
     assert str(fo[0]) == want[0] and fo[1].reverse == want[1][::-1]
+    # ... and their slices are slices of that, as the reference's fetch() and warm-cache slices are (fasta.c:440-461):
+    # the record is recognised as not line-regular from its last line, once
+    for k in (0, 1, 3):
+        w = want[k]
+        for a, b in ((0, len(w)), (2, 20), (9, 11), (len(w) - 3, len(w)), (5, 5)):
+            b = min(b, len(w))
+            if a <= b:
+                assert fo[k][a:b].seq == w[a:b], (k, a, b)
+        assert fo.fetch("abec"[k], (3, min(12, len(w)))) == w[2:min(12, len(w))]
+        assert fo.fetch("abec"[k], [(1, 4), (6, 9)], strand="-") == oracle.revcomp((w[0:4] + w[5:9]).encode(), 3).decode()
+    assert fo._regular == {1: False, 2: False, 4: True}
     # FASTQ
     rawq = fixture_bytes("test.fq")
     rq, size, ln = oracle.fastq_index(rawq)
