@@ -329,7 +329,10 @@ class Fasta:
 
     @property
     def mean(self):
-        return float(self._db.execute("SELECT AVG(slen) FROM seq").fetchone()[0])
+        m = float(self._db.execute("SELECT AVG(slen) FROM seq").fetchone()[0])
+        if not m:
+            raise RuntimeError("could not calculate average length")        # fasta.c:770-782: a mean of 0 is an error there
+        return m
 
     @property
     def median(self):
@@ -338,7 +341,10 @@ class Fasta:
             sql = "SELECT AVG(slen) FROM (SELECT slen FROM seq ORDER BY slen LIMIT %d,2)" % ((n - 1) // 2)
         else:
             sql = "SELECT slen FROM seq ORDER BY slen LIMIT %d,1" % ((n - 1) // 2)
-        return float(self._db.execute(sql).fetchone()[0])
+        m = float(self._db.execute(sql).fetchone()[0])
+        if not m:
+            raise RuntimeError("could not calculate median length")         # fasta.c:827-839: so is a median of 0
+        return m
 
     @property
     def composition(self):
