@@ -127,3 +127,37 @@ def test_fastq_side_by_side(both, tmp_path, seed):
         if k > 300:
             break
     del rq
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_gzip_inputs_side_by_side(both, tmp_path, seed):
+    """The same for compressed inputs: plain gzip (inflated on the host here) and BGZF (inflated on the GPU) against the
+    reference reading through its gzip layer.  Offsets in the index are offsets in the inflated stream on both sides."""
+    import gzip
+    from pyfastx_amd import synth
+    fx, ref = both
+    rng = np.random.default_rng(8800 + seed)
+    raw = _fasta_text(rng, dict(_FASTA_STYLES[seed % 2]))    # line-regular styles (LF / CRLF)
+    while len(raw) < 150_000:                                 # several BGZF members
+        raw += _fasta_text(rng, dict(_FASTA_STYLES[seed % 2])).replace(b">r", b">s%d_" % len(raw))
+    payload = synth.bgzf_compress(raw, block=int(rng.integers(3000, 60000))) if seed & 1 else gzip.compress(raw, 6)
+    po, pt = _two_copies(tmp_path, "r.fa.gz", payload)
+    fa, rf = fx.Fasta(po, full_index=True), ref.Fasta(pt, full_index=True)
+    a, b = _tables(po, ("seq", "comp")), _tables(pt, ("seq", "comp"))
+    assert a == b and fa.is_gzip and rf.is_gzip and len(fa) == len(rf) and fa.size == rf.size
+    rows = [r for r in a["seq"] if r[4] > 0]
+    for row in [rows[i] for i in rng.integers(0, len(rows), 25).tolist()]:
+        i, name, slen = row[0] - 1, row[1], row[4]
+        whole = rf[i].seq
+        assert fa[i].seq == whole and fa[name].antisense == rf[name].antisense
+        x = int(rng.integers(0, slen)); y = int(rng.integers(x, slen + 1))
+        if y > x:
+            assert fa[i][x:y].seq == whole[x:y] and fa.fetch(name, (x + 1, y), strand="-") == rf.fetch(name, (x + 1, y), strand="-")
+    rawq = _fastq_text(rng, 1500, 150, crlf=bool(seed & 2), plus_name=False, trailing=True, qlo=33, qhi=74)
+    payload = synth.bgzf_compress(rawq, block=20000) if seed & 1 else gzip.compress(rawq, 6)
+    qo, qt = _two_copies(tmp_path, "r.fq.gz", payload)
+    fq, rq = fx.Fastq(qo, full_index=True), ref.Fastq(qt, full_index=True)
+    assert _tables(qo, ("read", "stat", "base", "meta")) == _tables(qt, ("read", "stat", "base", "meta"))
+    for i in rng.integers(0, len(rq), 30).tolist():
+        assert (fq[i].name, fq[i].seq, fq[i].qual, fq[i].quali) == (rq[i].name, rq[i].seq, rq[i].qual, rq[i].quali)
+    del rf, rq
