@@ -119,7 +119,9 @@ def test_fastq_side_by_side(both, tmp_path, seed):
     for i in rng.integers(0, n, 40).tolist():
         r, t = fq[i], rq[i]
         assert (r.id, r.name, len(r), r.seq, r.qual, r.quali) == (t.id, t.name, len(t), t.seq, t.qual, t.quali)
-        assert r.description == t.description and r.raw == t.raw and repr(r) == repr(t)
+        assert r.description == t.description and repr(r) == repr(t)
+        if i < n - 1 or raw.endswith(b"\n"):                 # the last read of an unterminated file: the reference's raw runs two bytes
+            assert r.raw == t.raw                             # past the end of the file into whatever its buffer held (read.c:124-150)
         assert r.antisense == t.antisense and r.reverse == t.reverse and r.complement == t.complement
         assert fq[t.name].id == t.id and t.name in fq
     for k, (r, t) in enumerate(zip(fq, rq)):                 # iteration (batched fetches on our side)
