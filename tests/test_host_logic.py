@@ -782,3 +782,54 @@ def test_fetch_over_byte_range_shards(oracle, seed):
         for j, qi in enumerate(qidx.tolist()):
             assert buf[offs[j]:offs[j + 1]].tobytes() == want[qi], (seed, qi)
     assert (seen == 1).all()
+
+
+def test_line_regular_rule(oracle):
+    """Sequence._line_regular (api.py): whenever it lets a norm=1 record through to the line arithmetic of
+    sequence.c:498-510, the arithmetic is right at EVERY position of the record -- brute force over random records with
+    odd lines anywhere, blank lines, CRLF and unterminated ends; and it does let the ordinary records through."""
+    from pyfastx_amd import api
+
+    class _St:
+        def __init__(self, text):
+            self.text = text
+            self.blob = type("B", (), {"size": len(text)})()
+
+        def raw(self, off, n):
+            return self.text[off:off + n]
+
+    class _Fa:
+        _uppercase = False
+
+    rng = np.random.default_rng(4)
+    passed = odd = 0
+    for it in range(1500):
+        eol = b"\r\n" if it % 2 else b"\n"
+        parts = []
+        for i in range(5):
+            parts.append(b">r%d" % i + eol)
+            w = int(rng.integers(2, 9))
+            for j in range(int(rng.integers(0, 6))):
+                parts.append(b"A" * (w if rng.random() < 0.8 else int(rng.integers(1, 2 * w + 2))) + eol)
+            if rng.random() < 0.2:
+                parts.append(eol)
+        text = b"".join(parts)
+        if it % 7 == 0 and text.endswith(eol):
+            text = text[:-len(eol)]
+        recs, _ = oracle.fasta_index(text)
+        fa = _Fa()
+        fa._st = _St(text)
+        for k, r in enumerate(recs):
+            s = api.Sequence(fa, k + 1, "r", *(int(r[c]) for c in ("boff", "blen", "slen", "llen", "elen", "norm", "dlen")))
+            if not s._line_regular():
+                odd += bool(r["norm"])
+                continue
+            passed += 1
+            n = int(r["slen"])
+            full = oracle.fetch(text, r["boff"], r["blen"], r["slen"])
+            for a in range(n):
+                off, bl = s._range(a, n)
+                assert oracle.fetch(text, off, bl, n - a, 0) == full[a:], (text, k, a)
+                off, bl = s._range(0, a + 1)
+                assert oracle.fetch(text, off, bl, a + 1, 0) == full[:a + 1], (text, k, a)
+    assert passed > 3000 and odd > 1000
