@@ -2,4 +2,4 @@
 behind the pyfastx object API (Fasta / Fastq / Sequence / Read)."""
 __version__ = "0.1.0"
 
-from .api import Fasta, Fastq, Sequence, Read, FastaKeys, version, gzip_check, reverse_complement  # noqa: E402,F401
+from .api import Fasta, Fastq, Fastx, Sequence, Read, FastaKeys, FastqKeys, version, gzip_check, reverse_complement  # noqa: E402,F401

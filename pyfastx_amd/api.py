@@ -1178,6 +1178,61 @@ class Read:
         return _decode(r.rstrip(b"\x00"))
 
 
+# ============================================================== Fastx
+_SPACE = frozenset(" \t\n\r\x0b\x0c")                       # isspace(): what ends a name in kseq (KS_SEP_SPACE, kseq.h:9)
+
+
+def _name_comment(header):
+    """kseq_read (kseq.c:145-146): the name runs to the first isspace() character, the comment is the rest of the line
+    after that one character (ks_getuntil2 in line mode drops a trailing CR only from a string longer than one)."""
+    for i, c in enumerate(header):
+        if c in _SPACE:
+            return header[:i], header[i + 1:]
+    return header, ""
+
+
+class Fastx:
+    """pyfastx.Fastx (fastx.c:32-147): iteration over a FASTA or FASTQ file WITHOUT an index file -- tuples
+    (name, seq[, comment]) or (name, seq, qual[, comment]).  The reference walks the file with kseq_read; here the
+    records come from the same GPU scan as everything else, kept in memory only, and whole records are fetched in batches
+    (Fasta / Fastq with build_index=False).  Well-formed files give the same tuples; kseq's tolerance of multi-line
+    FASTQ records and of white space inside sequence lines is not reproduced (the index-building parsers, which this
+    engine restates, do not have it either)."""
+
+    def __init__(self, file_name, format="auto", uppercase=False, comment=False, device=0):
+        if not os.path.isfile(file_name):
+            raise FileExistsError("the input file %s does not exists" % file_name)             # fastx.c:47-50
+        self.file_name, self._uppercase, self._comment, self._device = file_name, bool(uppercase), bool(comment), device
+        if format == "auto":                                                                     # fastx.c:61-69
+            c = _first_nonspace(file_name, _is_gzip(file_name))
+            self._format = 1 if c == ord(">") else 2 if c == ord("@") else 0
+        else:
+            self._format = {"fasta": 1, "fastq": 2}.get(format, 0)
+        if self._format == 0:
+            raise RuntimeError("%s is not fasta or fastq sequence file" % file_name)           # fastx.c:71-74
+
+    def __repr__(self):
+        return "<Fastx> %s %s" % ("fasta" if self._format == 1 else "fastq", self.file_name)    # fastx.c:126-132
+
+    def __iter__(self):
+        if self._format == 1:
+            src = Fasta(self.file_name, build_index=False, uppercase=self._uppercase, full_name=self._comment, device=self._device)
+            for name, seq in src:
+                if self._comment:
+                    nm, cm = _name_comment(name)
+                    yield nm, seq, cm
+                else:
+                    yield name, seq
+        else:
+            src = Fastq(self.file_name, build_index=False, full_name=self._comment, device=self._device)
+            for name, seq, qual in src:                                                          # (uppercase is not applied to FASTQ: fastx.c:97-103)
+                if self._comment:
+                    nm, cm = _name_comment(name)
+                    yield nm, seq, qual, cm
+                else:
+                    yield name, seq, qual
+
+
 # ============================================================== module functions
 def version(debug=False):
     """module.c:14-28"""

@@ -163,3 +163,27 @@ def test_gzip_inputs_side_by_side(both, tmp_path, seed):
     for i in rng.integers(0, len(rq), 30).tolist():
         assert (fq[i].name, fq[i].seq, fq[i].qual, fq[i].quali) == (rq[i].name, rq[i].seq, rq[i].qual, rq[i].quali)
     del rf, rq
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fastx_side_by_side(both, tmp_path, seed):
+    """Fastx (fastx.c): index-free iteration -- (name, seq[, comment]) / (name, seq, qual[, comment]) tuples of well-formed
+    files, plain and gzip, with and without upper-casing, against the reference's kseq walk."""
+    import gzip
+    fx, ref = both
+    rng = np.random.default_rng(8900 + seed)
+    raw = _fasta_text(rng, dict(_FASTA_STYLES[seed % 2]))              # line-regular FASTA, LF / CRLF, lower case in style 1
+    rawq = _fastq_text(rng, 700, 150, crlf=bool(seed & 1), plus_name=bool(seed & 2), trailing=(seed != 4), qlo=33, qhi=74)
+    for name, payload in (("x.fa", raw), ("x.fq", rawq), ("x.fa.gz", gzip.compress(raw)), ("x.fq.gz", gzip.compress(rawq))):
+        po, pt = _two_copies(tmp_path, name, payload)
+        for kw in (dict(), dict(comment=True), dict(uppercase=True), dict(uppercase=True, comment=True)):
+            ours, theirs = fx.Fastx(po, **kw), ref.Fastx(pt, **kw)
+            assert repr(ours).split(" ")[:2] == repr(theirs).split(" ")[:2]
+            assert list(ours) == list(theirs), (name, kw)
+        assert not os.path.exists(po + ".fxi")                            # no index file is written
+    with pytest.raises(FileExistsError):
+        fx.Fastx(str(tmp_path / "nope.fa"))
+    bad = tmp_path / "bad.txt"
+    bad.write_text("hello\n")
+    with pytest.raises(RuntimeError):
+        fx.Fastx(str(bad))
