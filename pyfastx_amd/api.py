@@ -1215,22 +1215,18 @@ class Fastx:
         return "<Fastx> %s %s" % ("fasta" if self._format == 1 else "fastq", self.file_name)    # fastx.c:126-132
 
     def __iter__(self):
+        # whole header lines from the scan, cut here: kseq ends a name at ANY isspace() character, the index builders at a
+        # space or tab (FASTA) / a space (FASTQ)
         if self._format == 1:
-            src = Fasta(self.file_name, build_index=False, uppercase=self._uppercase, full_name=self._comment, device=self._device)
-            for name, seq in src:
-                if self._comment:
-                    nm, cm = _name_comment(name)
-                    yield nm, seq, cm
-                else:
-                    yield name, seq
+            src = Fasta(self.file_name, build_index=False, uppercase=self._uppercase, full_name=True, device=self._device)
+            for header, seq in src:
+                nm, cm = _name_comment(header)
+                yield (nm, seq, cm) if self._comment else (nm, seq)
         else:
-            src = Fastq(self.file_name, build_index=False, full_name=self._comment, device=self._device)
-            for name, seq, qual in src:                                                          # (uppercase is not applied to FASTQ: fastx.c:97-103)
-                if self._comment:
-                    nm, cm = _name_comment(name)
-                    yield nm, seq, qual, cm
-                else:
-                    yield name, seq, qual
+            src = Fastq(self.file_name, build_index=False, full_name=True, device=self._device)
+            for header, seq, qual in src:                                                        # (uppercase is not applied to FASTQ: fastx.c:97-103)
+                nm, cm = _name_comment(header)
+                yield (nm, seq, qual, cm) if self._comment else (nm, seq, qual)
 
 
 # ============================================================== module functions
