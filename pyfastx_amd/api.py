@@ -289,7 +289,10 @@ class Fasta:
             want = np.maximum(t["slen"][a:b], 0)
             buf, offs, ol = blob.fetch_ranges(t["boff"][a:b], t["blen"][a:b], want, flags=fl)
             for k in range(b - a):
-                yield names[a + k], _decode(buf[offs[k]:offs[k] + ol[k]])
+                if getattr(self, "_with_cr", False):                      # Fastx: did the header line end with CR?
+                    yield names[a + k], _decode(buf[offs[k]:offs[k] + ol[k]]), bool(t["elen"][a + k] == 2)
+                else:
+                    yield names[a + k], _decode(buf[offs[k]:offs[k] + ol[k]])
 
     def _need_index(self):
         if self._db is None:
@@ -1012,8 +1015,12 @@ class Fastq:
             ln = (t["dlen"][a:b] - 1).astype(np.int64) if self._full_name else t["name_len"][a:b].astype(np.int64)
             nb, no, _ = blob.fetch_ranges(t["name_off"][a:b], ln, ln, flags=_F_RAW)
             for k in range(b - a):
-                nm = _decode(nb[no[k]:no[k + 1]]).rstrip("\r")
-                yield nm, _decode(seq[offs[k]:offs[k + 1]]), _decode(qual[offs[k]:offs[k + 1]])
+                full = _decode(nb[no[k]:no[k + 1]])
+                nm = full.rstrip("\r")
+                if getattr(self, "_with_cr", False):                      # Fastx: did the header line end with CR?
+                    yield nm, _decode(seq[offs[k]:offs[k + 1]]), _decode(qual[offs[k]:offs[k + 1]]), len(nm) != len(full)
+                else:
+                    yield nm, _decode(seq[offs[k]:offs[k + 1]]), _decode(qual[offs[k]:offs[k + 1]])
 
     def keys(self):
         return FastqKeys(self, self._counts)                                                   # fastq.c:555-557
@@ -1184,11 +1191,12 @@ _SPACE = frozenset(" \t\n\r\x0b\x0c")                       # isspace(): what en
 
 def _name_comment(header):
     """kseq_read (kseq.c:145-146): the name runs to the first isspace() character, the comment is the rest of the line
-    after that one character (ks_getuntil2 in line mode drops a trailing CR only from a string longer than one)."""
+    after that one character (ks_getuntil2 in line mode drops a trailing CR only from a string longer than one).
+    -> (name, comment or None when nothing follows the name)."""
     for i, c in enumerate(header):
         if c in _SPACE:
             return header[:i], header[i + 1:]
-    return header, ""
+    return header, None
 
 
 class Fastx:
@@ -1217,15 +1225,27 @@ class Fastx:
     def __iter__(self):
         # whole header lines from the scan, cut here: kseq ends a name at ANY isspace() character, the index builders at a
         # space or tab (FASTA) / a space (FASTQ)
+        # A record without a comment: the reference hands out None until its comment buffer exists -- from the first
+        # header whose name is followed by anything but the newline, a CR included -- and "" afterwards (kseq.c:146 with
+        # Py_BuildValue "s#" on a NULL pointer, fastx.c:10-12, 28-30).
+        buffered = False
         if self._format == 1:
             src = Fasta(self.file_name, build_index=False, uppercase=self._uppercase, full_name=True, device=self._device)
-            for header, seq in src:
+            src._with_cr = True
+            for header, seq, cr in src:
                 nm, cm = _name_comment(header)
+                buffered = buffered or cm is not None or cr
+                if cm is None and buffered:
+                    cm = ""
                 yield (nm, seq, cm) if self._comment else (nm, seq)
         else:
             src = Fastq(self.file_name, build_index=False, full_name=True, device=self._device)
-            for header, seq, qual in src:                                                        # (uppercase is not applied to FASTQ: fastx.c:97-103)
+            src._with_cr = True
+            for header, seq, qual, cr in src:                                                    # (uppercase is not applied to FASTQ: fastx.c:97-103)
                 nm, cm = _name_comment(header)
+                buffered = buffered or cm is not None or cr
+                if cm is None and buffered:
+                    cm = ""
                 yield (nm, seq, qual, cm) if self._comment else (nm, seq, qual)
 
 
