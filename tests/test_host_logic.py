@@ -833,3 +833,32 @@ def test_line_regular_rule(oracle):
                 off, bl = s._range(0, a + 1)
                 assert oracle.fetch(text, off, bl, a + 1, 0) == full[:a + 1], (text, k, a)
     assert passed > 3000 and odd > 1000
+
+
+def test_fastx_name_comment_rule(tmp_path):
+    """Fastx's cut of a header line into (name, comment) and its None-then-"" rule for records without a comment
+    (api._name_comment + the `buffered` flag of Fastx.__iter__), replayed on header lines taken from the bytes and
+    compared with what the compiled reference's Fastx returns for the same files."""
+    from pyfastx_amd.api import _name_comment
+    from test_oracle_vs_reference import _FASTA_STYLES, _fasta_text, _fastq_text
+    assert _name_comment("abc def  ghi") == ("abc", "def  ghi") and _name_comment("abc") == ("abc", None)
+    assert _name_comment("a\tb c") == ("a", "b c") and _name_comment("a\x0bb") == ("a", "b") and _name_comment("") == ("", None)
+    ref = _ref_pyfastx()
+    if ref is None:
+        pytest.skip("oracle/_ref not built here")
+    for seed in range(60):
+        rng = np.random.default_rng(8900 + seed)
+        raw = _fasta_text(rng, dict(_FASTA_STYLES[seed % 2]))
+        rawq = _fastq_text(rng, 50, 150, crlf=bool(seed & 1), plus_name=bool(seed & 2), trailing=(seed % 8 != 4), qlo=33, qhi=74)
+        for kind, data in (("fa", raw), ("fq", rawq)):
+            p = str(tmp_path / ("x." + kind))
+            open(p, "wb").write(data)
+            theirs = [(t[0], t[-1]) for t in ref.Fastx(p, comment=True)]
+            lines = data.split(b"\n")
+            heads = [l for l in lines if l.startswith(b">")] if kind == "fa" else lines[0::4][:len(theirs)]
+            buffered, mine = False, []
+            for l in heads:
+                nm, cm = _name_comment(l[1:].rstrip(b"\r").decode())
+                buffered = buffered or cm is not None or l.endswith(b"\r")
+                mine.append((nm, "" if cm is None and buffered else cm))
+            assert mine == theirs, (seed, kind)
