@@ -12,12 +12,15 @@
 // (fastq.c:29-36) and `seq` (index.c:178-189) have it.
 #pragma once
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/statvfs.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -150,6 +153,36 @@ static bool pwrite_all(int fd, const uint8_t *p, size_t n, off_t off) {
     return true;
 }
 
+// The file grown to its final size and mapped: the writer threads format their pages in place.  pwrite() takes the
+// inode lock for every call, so sixteen threads writing one file queue up behind each other; stores into a shared
+// mapping do not.  (No mapping -- a file system that refuses it -- and the pages go through pwrite as before.)
+struct FileMap {
+    uint8_t *p = nullptr;
+    size_t len = 0;
+    bool open(int fd, size_t newlen) {
+        if (getenv("FX_FXI_NO_MMAP")) return false;
+        // a store into a mapping of a full file system is a SIGBUS, a pwrite an error return: map only when the space is there
+        struct stat st;
+        struct statvfs vfs;
+        if (fstat(fd, &st) != 0 || fstatvfs(fd, &vfs) != 0) return false;
+        const uint64_t grow = newlen > (size_t)st.st_size ? newlen - (size_t)st.st_size : 0;
+        if ((uint64_t)vfs.f_bavail * (uint64_t)vfs.f_frsize < grow + (64u << 20)) return false;
+        if (ftruncate(fd, (off_t)newlen) != 0) return false;
+        void *m = mmap(nullptr, newlen, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (m == MAP_FAILED) return false;
+        p = (uint8_t *)m; len = newlen;
+        return true;
+    }
+    void close() { if (p) munmap(p, len); p = nullptr; }
+    ~FileMap() { close(); }
+};
+// one page into the mapping or through pwrite
+static bool put_page(int fd, const FileMap &m, const uint8_t *pg, int pagesize, uint32_t pageno) {
+    const size_t off = (size_t)(pageno - 1) * (size_t)pagesize;
+    if (m.p) { memcpy(m.p + off, pg, (size_t)pagesize); return true; }
+    return pwrite_all(fd, pg, (size_t)pagesize, (off_t)off);
+}
+
 // Load `rows` into the (empty) table whose b-tree root is page `rootpage` of the database file `path`.
 // The file must be closed by every SQLite connection.  Returns OK, E_ROW when a row does not fit a page
 // (the caller uses the INSERT path), E_IO / E_INVAL otherwise.
@@ -220,6 +253,11 @@ static int bulk_load_table(const char *path, uint32_t rootpage, const Rows &r) {
         const PageSeq seq(npages + 1, pagesize);
         for (size_t k = 0; k < nleaf; ++k) { kids[k] = seq.at(k); maxkey[k] = leaf_first[k + 1]; }   // rowid = row + 1
         uint64_t next_k = nleaf;
+        const size_t fan = (size_t)((usable - 12) / 15) + 1;             // children per interior page
+        uint64_t total = nleaf;                                            // all new pages: the leaves + every interior level but the top
+        for (size_t K = nleaf; K > fan; K = (K + fan - 1) / fan) total += (K + fan - 1) / fan;
+        FileMap map;
+        map.open(fd, (size_t)seq.at(total - 1) * (size_t)pagesize);
         // leaves, in parallel, 256 pages per write
         {
             std::atomic<size_t> cursor(0);
@@ -228,11 +266,16 @@ static int bulk_load_table(const char *path, uint32_t rootpage, const Rows &r) {
             const int TW = (int)std::min<size_t>((size_t)max_threads(), std::max<size_t>(1, nleaf / 512));
             for (int t = 0; t < TW; ++t)
                 th.emplace_back([&]() {
-                    std::vector<uint8_t> buf((size_t)pagesize * 256);
+                    std::vector<uint8_t> buf(map.p ? 0 : (size_t)pagesize * 256);
                     for (;;) {
                         const size_t a = cursor.fetch_add(256);
                         if (a >= nleaf || err.load()) return;
                         const size_t b = std::min(nleaf, a + 256);
+                        if (map.p) {                         // in place
+                            for (size_t k = a; k < b; ++k)
+                                format_leaf(map.p + (size_t)(kids[k] - 1) * (size_t)pagesize, pagesize, usable, r, leaf_first[k], leaf_first[k + 1]);
+                            continue;
+                        }
                         for (size_t k = a; k < b; ++k)
                             format_leaf(buf.data() + (k - a) * (size_t)pagesize, pagesize, usable, r, leaf_first[k], leaf_first[k + 1]);
                         size_t cut = a + 1;                  // pages a .. cut-1 are adjacent in the file (the skipped page splits a batch)
@@ -247,7 +290,6 @@ static int bulk_load_table(const char *path, uint32_t rootpage, const Rows &r) {
         }
         // interior levels: a cell is 4 + varint(rowid) <= 13 bytes, + 2 for its pointer.  Children are spread evenly
         // over the pages of a level, so no page ends up with a single child.
-        const size_t fan = (size_t)((usable - 12) / 15) + 1;             // children per interior page
         while (ok && kids.size() > fan) {
             const size_t K = kids.size(), groups = (K + fan - 1) / fan;
             std::vector<uint32_t> up(groups);
@@ -256,16 +298,18 @@ static int bulk_load_table(const char *path, uint32_t rootpage, const Rows &r) {
                 const size_t a = K * g / groups, b = K * (g + 1) / groups;
                 format_interior(page.data(), pagesize, usable, kids, maxkey, a, b, 0);
                 up[g] = seq.at(next_k++);
-                ok = pwrite_all(fd, page.data(), (size_t)pagesize, (off_t)(up[g] - 1) * pagesize);
+                ok = put_page(fd, map, page.data(), pagesize, up[g]);
                 upkey[g] = maxkey[b - 1];
             }
             kids.swap(up); maxkey.swap(upkey);
         }
         if (ok) {
             format_interior(page.data(), pagesize, usable, kids, maxkey, 0, kids.size(), 0);
-            ok = pwrite_all(fd, page.data(), (size_t)pagesize, (off_t)(rootpage - 1) * pagesize);
+            ok = put_page(fd, map, page.data(), pagesize, rootpage);
         }
+        if (ok && next_k != total) ok = false;               // the page count the file was sized for
         npages = seq.at(next_k - 1);
+        map.close();
     }
     // ---- file header: size in pages, change counter, "version valid for"
     if (ok) {
@@ -413,6 +457,8 @@ static int bulk_load_index(const char *path, uint32_t rootpage, const Entries &e
         for (size_t k = 0; k < np; ++k) pageno[l][k] = (l + 1 == nlev) ? rootpage : seq.at(next_k++);
     }
     bool ok = true;
+    FileMap map;
+    if (next_k) map.open(fd, (size_t)seq.at(next_k - 1) * (size_t)pagesize);
     // ---- leaves (parallel)
     {
         const Level &lv = levels[0];
@@ -423,12 +469,13 @@ static int bulk_load_index(const char *path, uint32_t rootpage, const Entries &e
         std::vector<std::thread> th;
         for (int t = 0; t < TW; ++t)
             th.emplace_back([&]() {
-                std::vector<uint8_t> pg((size_t)pagesize);
+                std::vector<uint8_t> own((size_t)pagesize);
                 uint8_t tmp[8192];
                 for (;;) {
                     const size_t k = cursor.fetch_add(1);
                     if (k >= np || err.load()) return;
-                    memset(pg.data(), 0, (size_t)pagesize);
+                    uint8_t *const pg = map.p ? map.p + (size_t)(pageno[0][k] - 1) * (size_t)pagesize : own.data();   // in place when mapped
+                    memset(pg, 0, (size_t)pagesize);
                     // items of page k: entries first[k] .. end, where the promoted one (if any) is excluded
                     int64_t a = lv.first[k], b = lv.first[k + 1];
                     if (k + 1 < np) --b;                     // the last item before the next page is this page's divider
@@ -436,13 +483,13 @@ static int bulk_load_index(const char *path, uint32_t rootpage, const Entries &e
                     for (int64_t i = a; i < b; ++i, ++c) {
                         const int len = put_entry(tmp, e, i);
                         top -= len;
-                        memcpy(pg.data() + top, tmp, (size_t)len);
-                        put_be(pg.data() + 8 + 2 * c, (uint64_t)top, 2);
+                        memcpy(pg + top, tmp, (size_t)len);
+                        put_be(pg + 8 + 2 * c, (uint64_t)top, 2);
                     }
                     pg[0] = 0x0A;
-                    put_be(pg.data() + 3, (uint64_t)c, 2);
-                    put_be(pg.data() + 5, (uint64_t)(top == 65536 ? 0 : top), 2);
-                    if (!pwrite_all(fd, pg.data(), (size_t)pagesize, (off_t)(pageno[0][k] - 1) * pagesize)) err.store(1);
+                    put_be(pg + 3, (uint64_t)c, 2);
+                    put_be(pg + 5, (uint64_t)(top == 65536 ? 0 : top), 2);
+                    if (!map.p && !pwrite_all(fd, pg, (size_t)pagesize, (off_t)(pageno[0][k] - 1) * pagesize)) err.store(1);
                 }
             });
         for (auto &x : th) x.join();
@@ -471,7 +518,7 @@ static int bulk_load_index(const char *path, uint32_t rootpage, const Entries &e
             put_be(pg.data() + 3, (uint64_t)c, 2);
             put_be(pg.data() + 5, (uint64_t)(top == 65536 ? 0 : top), 2);
             put_be(pg.data() + 8, pageno[l - 1][(size_t)b], 4);   // right-most child: the page after the last divider kept here
-            ok = pwrite_all(fd, pg.data(), (size_t)pagesize, (off_t)(pageno[l][k] - 1) * pagesize);
+            ok = put_page(fd, map, pg.data(), pagesize, pageno[l][k]);
         }
     }
     if (ok && nlev == 1 && levels[0].first.size() - 1 == 1) { /* the single leaf was written to the root page above */ }
@@ -481,6 +528,7 @@ static int bulk_load_index(const char *path, uint32_t rootpage, const Entries &e
         put_be(hdr + 24, change, 4);
         put_be(hdr + 28, next_k ? seq.at(next_k - 1) : npages, 4);
         put_be(hdr + 92, change, 4);
+        map.close();
         ok = pwrite_all(fd, hdr, 100, 0);
     }
     close(fd);
