@@ -862,3 +862,25 @@ def test_fastx_name_comment_rule(tmp_path):
                 buffered = buffered or cm is not None or l.endswith(b"\r")
                 mine.append((nm, "" if cm is None and buffered else cm))
             assert mine == theirs, (seed, kind)
+
+
+def test_shard_fetcher_degenerate_batches(oracle):
+    """ShardFetcher: an empty batch, a batch of zero-length and past-the-end intervals, one shard only, a shard that
+    holds a single byte."""
+    from pyfastx_amd import shard
+    raw = b">a\nACGTACGT\nACGT\n>b\nTTTT\n>e\n>c\nGGGGCCCC\nGG"
+    recs, _ = oracle.fasta_index(raw)
+    table = {k: recs[k] for k in ("boff", "blen", "slen", "llen", "elen", "norm")}
+    for cuts in ([], [1], [5, 6], [len(raw) - 1], list(range(3, len(raw) - 1, 7))):
+        bases, ends = [0] + cuts, cuts + [len(raw)]
+        f = shard.ShardFetcher({r: _OracleShard(oracle, raw, bases[r], ends[r]) for r in range(len(bases))}, bases, ends, table)
+        q, buf, offs = f.fetch([], [], [])
+        assert q.size == 0 and buf.size == 0 and offs.tolist() == [0]
+        ids = np.array([0, 0, 1, 2, 3, 3, 3], dtype=np.int64)
+        st = np.array([0, 5, 4, 0, 0, 9, 10], dtype=np.int64)
+        sp = np.array([0, 5, 4, 0, 10, 10, 10], dtype=np.int64)
+        fl = np.array([0, 6, 2, 4, 6, 0, 1], dtype=np.uint8)
+        q, buf, offs = f.fetch(ids, st, sp, flags_per_query=fl)
+        assert sorted(q.tolist()) == list(range(7))
+        for j, qi in enumerate(q.tolist()):
+            assert buf[offs[j]:offs[j + 1]].tobytes() == _expected_fetch(oracle, raw, recs, int(ids[qi]), int(st[qi]), int(sp[qi]), int(fl[qi])), (cuts, qi)
