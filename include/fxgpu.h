@@ -123,6 +123,15 @@ int fx_fasta_table(fx_handle *h, int where,
 int fx_fasta_set_table(fx_handle *h, int64_t n, const int64_t *boff, const int64_t *blen, const int64_t *slen,
                        const int64_t *llen, const int32_t *elen, const int32_t *norm);
 
+/* Which records may be sliced with the line arithmetic of pyfastx_sequence_subscript (sequence.c:498-510)?  `norm`
+ * (index.c:342: at most ONE line of another length) is 1 both for a record whose last line is the short one and for a
+ * record with one odd line in the middle -- where the arithmetic addresses the wrong bytes (the reference returns them
+ * from a cold cache and the true slice from a warm one, sequence.c:100-110).  reg[i] = 1: every line of record i but
+ * the last holds exactly llen - elen bases (decided by the scan / fx_fasta_set_table / the stitch from the row and ONE
+ * byte of the stream: the byte in front of the last line is a newline).  fx_fasta_fetch slices the other records after
+ * despacing them; so do all batched paths above it.  n_seq values, where = FX_HOST / FX_DEVICE. */
+int fx_fasta_line_regular(fx_handle *h, int where, int32_t *reg);
+
 /* pyfastx_fasta_calc_composition (fasta.c:851-961): comp[n_seq][128] counts of
  * every byte value < 128 on the sequence lines of each record ('\r' included,
  * '\n' excluded).  Needs fx_fasta_build first. */
@@ -180,6 +189,14 @@ int fx_fastq_comp(fx_handle *h, int64_t base[5], int64_t meta[5]);
  * flags: per-call if flags_per_query == NULL, else flags_per_query[i].        */
 int fx_fetch_ranges(fx_handle *h, int where, int64_t n,
                     const int64_t *off, const int64_t *blen, const int64_t *slen,
+                    int flags, const uint8_t *flags_per_query,
+                    uint8_t *dst, const int64_t *dst_off, int64_t *out_len);
+
+/* The same with a slice taken AFTER despacing: of the bytes query i keeps, the first skip[i] are dropped and at most
+ * take[i] stored -- pyfastx_sequence_get_subseq on a record that is not line-regular (sequence.c:100-110: the whole
+ * record is despaced, then `seq + start - 1` is copied), without moving the record to the host. */
+int fx_fetch_slices(fx_handle *h, int where, int64_t n,
+                    const int64_t *off, const int64_t *blen, const int64_t *skip, const int64_t *take,
                     int flags, const uint8_t *flags_per_query,
                     uint8_t *dst, const int64_t *dst_off, int64_t *out_len);
 
@@ -310,7 +327,9 @@ typedef struct {
     int64_t tail_nl_after;     /* shard newlines after tail_e                                       */
     int64_t tail_bad;          /* bad lines counted locally (valid when tail_first_end >= 0)        */
     int64_t tail_elen, tail_dlen, tail_name_len;   /* dlen -1: header unterminated; name_len -1: no whitespace seen */
-    int64_t reserved[2];
+    int64_t lead_prev_nl;      /* second-to-last newline before first_hdr (of the shard if n_hdr == 0), -1 if lead_nl < 2   */
+    int64_t second_last_nl;    /* second-to-last newline of the shard, -1 if n_nl < 2: with the field above, the length of
+                                  the LAST line of a record that ends in a later shard (line-regular test, see above)     */
 } fx_shard_summary;            /* 28 x int64: travels as one all-gather payload */
 
 int fx_shard_summary_get(fx_handle *h, fx_shard_summary *out);
@@ -328,7 +347,8 @@ int fx_fasta_stitch_dev(fx_handle *h, const int64_t *d_all, int world, int rank,
 void *fx_stream(fx_handle *h);
 
 /* After the all-gather the owner of a record that crosses shard cuts rewrites
- * that row of the resident table (and of what fx_fasta_table returns). */
+ * that row of the resident table (and of what fx_fasta_table returns).  norm: bit 0 = the norm column, bit 1 = the
+ * line-regular bit of that record (fx_fasta_line_regular). */
 int fx_fasta_set_row(fx_handle *h, int64_t k, int64_t boff, int64_t blen, int64_t slen, int64_t llen,
                      int32_t elen, int32_t norm, int32_t dlen, int32_t name_len);
 

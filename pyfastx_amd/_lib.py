@@ -36,14 +36,14 @@ class ShardSummary(C.Structure):
         "base", "n_bytes", "is_last", "n_nl", "first_nl", "second_nl", "last_nl", "first_nl_prev",
         "first_byte", "last_byte", "n_hdr", "first_hdr", "last_hdr", "lead_nl", "lead_ws",
         "lead_v1", "lead_c1", "lead_v2", "lead_c2", "tail_e", "tail_first_end", "tail_nl_after", "tail_bad",
-        "tail_elen", "tail_dlen", "tail_name_len", "reserved0", "reserved1")]
+        "tail_elen", "tail_dlen", "tail_name_len", "lead_prev_nl", "second_last_nl")]
 
 
 SYMBOLS = [
     "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_host", "fx_open_device",
     "fx_set_shard", "fx_close", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
-    "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
-    "fx_fetch_ranges", "fx_fetch_one", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
+    "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_line_regular", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
+    "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
     "fx_fasta_set_row", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
 ]
 
@@ -124,6 +124,7 @@ def lib():
     L.fx_fasta_build_end.argtypes = [vp, C.POINTER(FastaSummary)]
     L.fx_fasta_table.argtypes = [vp, i32] + [vp] * 9
     L.fx_fasta_set_table.argtypes = [vp, i64] + [vp] * 6
+    L.fx_fasta_line_regular.argtypes = [vp, i32, vp]
     L.fx_fasta_comp.argtypes = [vp, i32, vp]
     L.fx_fasta_comp_shard.argtypes = [vp, i32, vp, i64, vp]
     L.fx_fasta_comp_sparse.argtypes = [vp, i32, i64, vp, vp, vp, C.POINTER(i64), vp]
@@ -136,6 +137,7 @@ def lib():
     L.fx_fetch_one.argtypes = [vp, i64, i64, i64, i64, i32, vp, C.POINTER(i64)]
     L.fx_fetch_ranges.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, vp, vp]
     L.fx_fasta_fetch.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.fx_fetch_slices.argtypes = [vp, i32, i64, vp, vp, vp, vp, i32, vp, vp, vp, vp]
     L.fx_fastq_fetch.argtypes = [vp, i32, i64, vp, i32, i32, vp, vp, vp, vp]
     L.fx_names_build.argtypes = [vp, i32]
     L.fx_names_lookup.argtypes = [vp, i32, i64, vp, vp, vp]
@@ -302,9 +304,9 @@ class Blob:
     def stream(self):
         return lib().fx_stream(self._h)
 
-    def fasta_set_row(self, k, boff, blen, slen, llen, elen, norm, dlen, name_len):
+    def fasta_set_row(self, k, boff, blen, slen, llen, elen, norm, dlen, name_len, reg=0):
         check(lib().fx_fasta_set_row(self._h, int(k), int(boff), int(blen), int(slen), int(llen), int(elen),
-                                     int(norm), int(dlen), int(name_len)))
+                                     (int(norm) & 1) | (int(bool(reg)) << 1), int(dlen), int(name_len)))
 
     # -- FASTA --------------------------------------------------------------
     def fasta_set_table(self, boff, blen, slen, llen, elen, norm):
@@ -313,6 +315,7 @@ class Blob:
         b = [np.ascontiguousarray(x, dtype=np.int32) for x in (elen, norm)]
         check(lib().fx_fasta_set_table(self._h, a[0].size, *[_ptr(x) for x in a + b]))
         self._table_ready = True
+        self._n_fasta = int(a[0].size)
 
     def fasta_build_begin(self, full_name=False):
         """Enqueue the build and return (no host synchronisation); see fasta_build_end."""
@@ -348,6 +351,14 @@ class Blob:
         check(lib().fx_fasta_table(self._h, FX_HOST, *[_ptr(cols[k]) for k in (
             "hoff", "boff", "blen", "slen", "llen", "elen", "norm", "dlen", "name_len")]))
         return cols
+
+    def fasta_line_regular(self, n):
+        """int32[n]: 1 where slices of the record may use the line arithmetic (fx_fasta_line_regular)."""
+        self._check_rows(n, 0)
+        reg = np.zeros(n, dtype=np.int32)
+        if n:
+            check(lib().fx_fasta_line_regular(self._h, FX_HOST, reg.ctypes.data))
+        return reg
 
     def fasta_comp(self, n):
         self._check_rows(n, 0)
@@ -467,8 +478,9 @@ class Blob:
         check(lib().fx_fetch_one(self._h, int(off), int(blen), int(skip), int(slen), int(flags), buf, C.byref(got)))
         return buf.raw[:got.value]
 
-    def fetch_ranges(self, off, blen, slen, flags=0, flags_per_query=None):
-        """-> (uint8 buffer, offsets int64[n+1] (exclusive cumsum of slen), out_len int64[n])."""
+    def fetch_ranges(self, off, blen, slen, flags=0, flags_per_query=None, skip=None):
+        """-> (uint8 buffer, offsets int64[n+1] (exclusive cumsum of slen), out_len int64[n]).  skip: kept bytes dropped
+        in front of each answer (fx_fetch_slices: slice after despacing)."""
         off, blen, slen = self._i64(off), self._i64(blen), self._i64(slen)
         n = off.size
         offs = np.zeros(n + 1, dtype=np.int64)
@@ -476,7 +488,11 @@ class Blob:
         dst = np.empty(max(int(offs[-1]), 1), dtype=np.uint8)     # the copy back fills all of it (np.zeros would touch every page first)
         out_len = np.zeros(n, dtype=np.int64)
         fpq = None if flags_per_query is None else np.ascontiguousarray(flags_per_query, dtype=np.uint8)
-        if n:
+        if n and skip is not None:
+            skip = self._i64(skip)
+            check(lib().fx_fetch_slices(self._h, FX_HOST, n, _ptr(off), _ptr(blen), _ptr(skip), _ptr(slen), int(flags),
+                                        _ptr(fpq), _ptr(dst), _ptr(offs), _ptr(out_len)))
+        elif n:
             check(lib().fx_fetch_ranges(self._h, FX_HOST, n, _ptr(off), _ptr(blen), _ptr(slen), int(flags),
                                         _ptr(fpq), _ptr(dst), _ptr(offs), _ptr(out_len)))
         return dst[:int(offs[-1])], offs, out_len

@@ -49,6 +49,12 @@ def _decode(b):
     return bytes(b).decode("latin-1")
 
 
+def _text(b):
+    """Header text (names, descriptions, raw records) as the reference's "s" format / SQLite TEXT reads it: UTF-8; bytes
+    that are not valid UTF-8 survive as surrogate escapes instead of raising (fxi.connect reads names back the same way)."""
+    return bytes(b).decode("utf-8", "surrogateescape")
+
+
 def _fx_to_py(e):
     """fx_status -> the exception class the reference raises at that point."""
     c = e.code
@@ -166,10 +172,10 @@ class Fasta:
                                    lambda p, names, offs, order: fxi.write_fasta_bulk(p, names, offs, t, s.seq_len, order))
         if self._db is None:
             if self._key_func is None:
-                names = self._gather(t["hoff"] + 1, t["name_len"])
+                names = self._gather(t["hoff"] + 1, t["name_len"])          # raw bytes: stored verbatim, like sqlite3_bind_text
             else:    # index.c:303-318: key_func(header text after '>'), '\r' of a CRLF header included
                 hl = t["dlen"].astype(np.int64) + (t["elen"] == 2)
-                names = [self._key_func(h) for h in self._gather(t["hoff"] + 1, hl)]
+                names = [self._key_func(_text(h)) for h in self._gather(t["hoff"] + 1, hl)]
             self._db = fxi.connect(self._index_file)
             fxi.write_fasta(self._db, names, t, s.seq_len)
         if self.is_gzip:
@@ -177,14 +183,14 @@ class Fasta:
             fxi.write_gzindex(self._db, os.path.getsize(self.file_name), blob.size, c, u)
 
     def _gather(self, off, length):
-        """Raw byte spans of the resident stream as a list of str (one batched GPU gather)."""
+        """Raw byte spans of the resident stream as a list of bytes (one batched GPU gather)."""
         length = np.asarray(length, dtype=np.int64)
         if length.size == 0:
             return []
         buf, offs, _ = self._st.blob.fetch_ranges(off, length, length, flags=_F_RAW)
         b = buf.tobytes()
         o = offs.tolist()
-        return [b[o[i]:o[i + 1]].decode("latin-1") for i in range(length.size)]
+        return [b[o[i]:o[i + 1]] for i in range(length.size)]
 
     def _calc_composition(self):
         """pyfastx_fasta_calc_composition (fasta.c:851-961)."""
@@ -199,10 +205,18 @@ class Fasta:
             # many records: the non-zero bins come off the GPU as triples (the dense matrix stays in HBM) and the
             # comp table + seqidx go into the file as b-tree pages instead of ~10 INSERTs per record
             seqid, abc, num, total = blob.fasta_comp_sparse(guess=s.n_seq * 12)
+            rows = (np.concatenate([seqid, np.zeros(128, dtype=np.int64)]), np.concatenate([abc, np.arange(128, dtype=np.int64)]),
+                    np.concatenate([num, total]))
             self._db.close()
-            self._db = fxi.write_fasta_comp_bulk(
-                self._index_file, np.concatenate([seqid, np.zeros(128, dtype=np.int64)]),
-                np.concatenate([abc, np.arange(128, dtype=np.int64)]), np.concatenate([num, total]))
+            try:
+                self._db = fxi.write_fasta_comp_bulk(self._index_file, *rows)
+            except Exception:
+                # disk full, a table that is not empty, ...: the page loader has given its pages back (fx_fxi.hpp);
+                # reconnect, clear what the attempt left behind and write the rows with INSERTs
+                self._db = fxi.connect(self._index_file)
+                self._db.execute("DROP INDEX IF EXISTS seqidx")
+                self._db.execute("DELETE FROM comp")
+                fxi.write_fasta_comp_rows(self._db, *rows)
         else:
             fxi.write_fasta_comp(self._db, blob.fasta_comp(s.n_seq))
         self._full_index = True
@@ -281,7 +295,7 @@ class Fasta:
         blob = self._st.blob
         s = blob.fasta_build(self._full_name)
         t = blob.fasta_table(s.n_seq)
-        names = self._gather(t["hoff"] + 1, t["name_len"])
+        names = [_text(x) for x in self._gather(t["hoff"] + 1, t["name_len"])]
         fl = _F_UP if self._uppercase else 0
         step = 256
         for a in range(0, s.n_seq, step):
@@ -428,6 +442,25 @@ class Fasta:
         rs = min(end, re_)
         left, right = seq._fetch_many([ls, rs], [le, re_])
         return _decode(left), _decode(right)
+
+    def _regular(self, sq):
+        """Sequence._line_regular for one record (cached per record; the whole column once the table is in HBM)."""
+        reg = getattr(self, "_reg", None)
+        if reg is None and getattr(self._st._blob, "_table_ready", False) and getattr(self._st._blob, "_n_fasta", None) == self._seq_counts:
+            self._reg = reg = self._st.blob.fasta_line_regular(self._seq_counts)
+        if reg is not None:
+            return bool(reg[sq.id - 1])
+        cache = self.__dict__.setdefault("_regular_one", {})
+        ok = cache.get(sq.id)
+        if ok is None:
+            from .shard import line_regular_rule
+            size = self._st.blob.size
+
+            def byte_at(p):
+                return self._st.raw(p, 1)[0] if 0 <= p < size else None
+            ok = bool(line_regular_rule(sq._offset, sq._byte_len, sq._full_len, sq._line_len, sq._end_len, sq._normal, byte_at))
+            cache[sq.id] = ok
+        return ok
 
     def _table(self):
         """The seq table as numpy columns (cached): what the batched calls index into."""
@@ -681,31 +714,12 @@ class Sequence:
     def _line_regular(self):
         """May slices of this record go through the line arithmetic?  `norm` says "at most one line of another length"
         (index.c:342): true of a record whose last line is the short one, and of a record with ONE odd line anywhere
-        else, which the arithmetic gets wrong.  The two are told apart once per record (cached in the Fasta) from the
-        record's byte length and the length of its last line; the odd kind is sliced after despacing the whole record,
-        which is what the reference returns from a warm cache and from Fasta.fetch() (sequence.c:100-110, fasta.c:440-461)."""
-        bpl = self._line_len - self._end_len
-        if not self._normal or bpl <= 0:
-            return False
-        cache = self._fa.__dict__.setdefault("_regular", {})
-        ok = cache.get(self.id)
-        if ok is None:
-            n, e = self._full_len, self._end_len
-            lines = -(-n // bpl)
-            ok = n <= 0 or lines <= 1
-            if not ok and self._byte_len == n + lines * e:
-                stop = min(self._offset + self._byte_len, self._fa._st.blob.size)   # blen counts a newline an unterminated file lacks
-                k = min(stop - self._offset, bpl + 2 * e + 1)
-                tail = self._fa._st.raw(stop - k, k)
-                if tail.endswith(b"\n"):
-                    tail = tail[:-1]
-                p = tail.rfind(b"\n")
-                last = tail[p + 1:] if p >= 0 else None
-                if last is not None and e == 2 and last.endswith(b"\r"):
-                    last = last[:-1]
-                ok = last is not None and len(last) == n - (lines - 1) * bpl
-            cache[self.id] = ok
-        return ok
+        else, which the arithmetic gets wrong.  The two are told apart by the line-regular column of the resident table
+        (fx_fasta_line_regular: the scan, fx_fasta_set_table and the shard stitch all fill it with the same rule) or,
+        for an index loaded from a file whose table has not been installed, by the same rule on the row and one byte
+        of the stream (shard.line_regular_rule); the odd kind is sliced after despacing the whole record, which is what
+        the reference returns from a warm cache and from Fasta.fetch() (sequence.c:100-110, fasta.c:440-461)."""
+        return self._fa._regular(self)
 
     def _fetch_many(self, starts, stops, flags=0):
         """Bases [a,b) (0-based, of the full record) for several intervals, one GPU batch."""
@@ -770,13 +784,13 @@ class Sequence:
 
     @property
     def description(self):
-        return _decode(self._fa._st.raw(self._offset - self._desc_len - self._end_len, self._desc_len))   # sequence.c:299-313
+        return _text(self._fa._st.raw(self._offset - self._desc_len - self._end_len, self._desc_len))   # sequence.c:299-313
 
     @property
     def raw(self):
         if self._complete:                                                                               # sequence.c:314-335
-            return _decode(self._fa._st.raw(self._offset - self._desc_len - self._end_len - 1,
-                                            self._byte_len + self._desc_len + self._end_len + 1))
+            return _text(self._fa._st.raw(self._offset - self._desc_len - self._end_len - 1,
+                                          self._byte_len + self._desc_len + self._end_len + 1))
         if self._normal and self._seq_len > 0:
             o, l = self._range(self.start - 1, self.end)
             return _decode(self._fa._st.raw(o, l))
@@ -930,7 +944,7 @@ class Fastq:
                 buf, offs, _ = blob.fetch_ranges(t["name_off"][a:b], ln, ln, flags=_F_RAW)
                 raw = buf.tobytes()
                 o = offs.tolist()
-                names.extend(raw[o[i]:o[i + 1]].decode("latin-1") for i in range(b - a))
+                names.extend(raw[o[i]:o[i + 1]] for i in range(b - a))        # raw bytes, stored verbatim
             self._db = fxi.connect(self._index_file)
             fxi.write_fastq(self._db, names, t, s.size)
         if self.is_gzip:
@@ -1015,7 +1029,7 @@ class Fastq:
             ln = (t["dlen"][a:b] - 1).astype(np.int64) if self._full_name else t["name_len"][a:b].astype(np.int64)
             nb, no, _ = blob.fetch_ranges(t["name_off"][a:b], ln, ln, flags=_F_RAW)
             for k in range(b - a):
-                full = _decode(nb[no[k]:no[k + 1]])
+                full = _text(nb[no[k]:no[k + 1]])
                 nm = full.rstrip("\r")
                 if getattr(self, "_with_cr", False):                      # Fastx: did the header line end with CR?
                     yield nm, _decode(seq[offs[k]:offs[k + 1]]), _decode(qual[offs[k]:offs[k + 1]]), len(nm) != len(full)
@@ -1169,7 +1183,7 @@ class Read:
         d = self._bytes(self._soff - self._desc_len - 1, self._desc_len)                        # read.c:214-235
         if d.endswith(b"\r"):
             d = d[:-1]
-        return _decode(d)
+        return _text(d)
 
     @property
     def raw(self):
@@ -1182,7 +1196,7 @@ class Read:
             r = r[:n]
         else:
             r = r[:n - 2]
-        return _decode(r.rstrip(b"\x00"))
+        return _text(r.rstrip(b"\x00"))
 
 
 # ============================================================== Fastx

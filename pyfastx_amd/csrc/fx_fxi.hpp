@@ -320,6 +320,9 @@ static int bulk_load_table(const char *path, uint32_t rootpage, const Rows &r) {
         put_be(hdr + 92, change, 4);
         ok = pwrite_all(fd, hdr, 100, 0);
     }
+    // failure: the header still says the old page count -- give the pages appended so far back instead of leaving
+    // them orphaned behind the database (the root page may have been rewritten: the caller discards or refills the table)
+    if (!ok) (void)!ftruncate(fd, st.st_size);
     close(fd);
     return ok ? OK : E_IO;
 }
@@ -531,6 +534,10 @@ static int bulk_load_index(const char *path, uint32_t rootpage, const Entries &e
         map.close();
         ok = pwrite_all(fd, hdr, 100, 0);
     }
+    map.close();
+    // failure: the header still says the old page count -- give the pages appended so far back instead of leaving
+    // them orphaned behind the database (the root page may have been rewritten: the caller discards or refills the table)
+    if (!ok) (void)!ftruncate(fd, st.st_size);
     close(fd);
     return ok ? OK : E_IO;
 }

@@ -97,7 +97,31 @@ struct FastaCols {
     int64_t *hoff, *boff, *blen, *slen, *llen, *hdr_line;
     int32_t *elen, *dlen, *name_len, *norm;
     uint32_t *bad;
+    int32_t *reg;                    // line-regular (line_regular below): may slices use the line arithmetic?
 };
+
+// `norm` (index.c:342) says "at most one line of another length": true of a record whose LAST line is the short one,
+// and of a record with one odd line anywhere else -- where the line arithmetic of sequence.c:498-510 reads the wrong
+// bytes (the reference returns them from a cold cache and the true slice from a warm one).  A record is LINE-REGULAR
+// when every sequence line but the last holds exactly llen - elen bases and the last one 1 .. llen - elen: then base i
+// sits at boff + i + elen * (i / bpl) for every i.  Given norm = 1 that is decided by the columns and ONE byte of the
+// stream: the record has ceil(slen / bpl) lines, and the byte in front of the last line -- x = slen - (lines - 1) * bpl
+// bases + elen terminator bytes before the record's end -- is a newline.  (Were the odd line somewhere else, that
+// position would lie inside a full last line.  More than one line after it would make two short lines: norm = 0.)
+// Slices of records that fail the test are cut from the despaced record (sequence.c:100-110) by every fetch path.
+// -> 1 / 0, -1 when the deciding byte is not among the n bytes held here (a record that crosses a shard cut).
+__device__ __forceinline__ int line_regular(const uint8_t *__restrict__ data, int64_t n, int64_t gbase, int64_t boff, int64_t blen,
+                                            int64_t slen, int64_t llen, int64_t elen, int norm) {
+    const int64_t bpl = llen - elen;
+    if (!norm || bpl <= 0 || elen <= 0) return 0;
+    if (slen <= bpl) return 1;                               // at most one line of bases
+    const int64_t lines = (slen + bpl - 1) / bpl;
+    if (blen != slen + lines * elen) return 0;               // not ceil(slen / bpl) sequence lines
+    const int64_t x = slen - (lines - 1) * bpl;              // bases of the last line if the record is regular
+    const int64_t p = boff + blen - (x + elen) - 1 - gbase;
+    if (p < 0 || p >= n) return -1;
+    return data[p] == '\n' ? 1 : 0;
+}
 
 // ======================================================================= K7
 // Batched fetch.  One wave per query: lanes read consecutive bytes of
@@ -118,7 +142,7 @@ struct FetchQ {
 };
 struct FastaTab {
     const int64_t *boff, *blen, *slen, *llen;
-    const int32_t *elen, *norm;
+    const int32_t *elen, *norm;      // norm here = the line-regular column (FastaCols::reg), not index.c's norm
     int64_t n_seq;                   // records in the table -- or its capacity while a build is still in flight ...
     const long long *n_seq_dev;      // ... in which case the count is read here (device memory), null otherwise
 };

@@ -839,7 +839,8 @@ __global__ __launch_bounds__(BLOCK) void k_gran_exact(ScanCtx x, RecView rv, int
 }
 
 // blen, slen (index.c:243,335-338,348), norm (index.c:237,342), stat.seqlen (index.c:253-254, 360-369)
-__global__ __launch_bounds__(BLOCK) void k_fasta_finalize2(int64_t cap, FastaCols c, Totals *__restrict__ tot) {
+__global__ __launch_bounds__(BLOCK) void k_fasta_finalize2(int64_t cap, FastaCols c, Totals *__restrict__ tot,
+                                                          const uint8_t *__restrict__ data, int64_t n_bytes, int64_t gbase) {
     const int64_t *__restrict__ hdr = c.hoff, *__restrict__ hdr_line = c.hdr_line;
     const int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const int64_t n_hdr = tot->n_hdr < cap ? tot->n_hdr : cap;
@@ -853,8 +854,13 @@ __global__ __launch_bounds__(BLOCK) void k_fasta_finalize2(int64_t cap, FastaCol
             const int64_t blen = hn - c.boff[k];
             s = blen - (int64_t)c.elen[k] * nseq;          // sum(line.l - line_end + 1)
             c.blen[k] = blen; c.slen[k] = s;
-            c.norm[k] = c.bad[k] > 1 ? 0 : 1;
-        } else { c.blen[k] = 0; c.slen[k] = 0; c.norm[k] = 1; }
+            const int norm = c.bad[k] > 1 ? 0 : 1;
+            c.norm[k] = norm;
+            // (the last record of a shard that is not the last one: provisional like its other columns, k_stitch_tail decides)
+            int reg = line_regular(data, n_bytes, gbase, c.boff[k], blen, s, nseq > 0 ? c.llen[k] : 0, c.elen[k], norm);
+            if (reg < 0) reg = c.bad[k] == 0;              // byte not held here: no odd line at all is regular whatever it says
+            c.reg[k] = reg;
+        } else { c.blen[k] = 0; c.slen[k] = 0; c.norm[k] = 1; c.reg[k] = 0; }
     }
     // one atomic per workgroup (per wave it was 78 k atomics on one address for 5 M records: 0.95 ms)
     __shared__ unsigned long long blk;
@@ -864,6 +870,36 @@ __global__ __launch_bounds__(BLOCK) void k_fasta_finalize2(int64_t cap, FastaCol
     if (lane_id() == 0 && s) atomicAdd(&blk, (unsigned long long)s);
     __syncthreads();
     if (threadIdx.x == 0 && blk) atomicAdd((unsigned long long *)&tot->seq_len, blk);
+}
+
+// the line-regular column for a table that did not come from a scan (fx_fasta_set_table: rows of an existing .fxi)
+__global__ __launch_bounds__(BLOCK) void k_line_regular(const uint8_t *__restrict__ data, int64_t n_bytes, int64_t gbase, int64_t n,
+                                                       const int64_t *__restrict__ boff, const int64_t *__restrict__ blen,
+                                                       const int64_t *__restrict__ slen, const int64_t *__restrict__ llen,
+                                                       const int32_t *__restrict__ elen, const int32_t *__restrict__ norm,
+                                                       int32_t *__restrict__ reg) {
+    const int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (k < n) reg[k] = line_regular(data, n_bytes, gbase, boff[k], blen[k], slen[k], llen[k], elen[k], norm[k]) > 0 ? 1 : 0;
+}
+
+// last newline of the shard at a global offset < p (p wave-uniform), -1 if none: the granule that holds byte p - 1 is
+// read by the whole wave (64 bytes per lane), below it prevnl[] answers.  Bytes of the stream only (not the virtual one).
+__device__ __forceinline__ int64_t prev_nl_wave(const ScanCtx &x, int64_t p) {
+    const int64_t y = (p - x.gbase < x.n) ? p - x.gbase : x.n;       // local offsets < y are searched
+    if (y <= 0) return -1;
+    const int64_t g = (y - 1) / GRAN;
+    const int64_t a = g * (int64_t)GRAN + lane_id() * 64;
+    unsigned long long m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (a + i * CHUNK < y) m |= (unsigned long long)eq_mask16(load16(x.data, a + i * CHUNK, x.n), 0x0A0A0A0Au) << (16 * i);
+    if (y - a < 64) m &= (y - a <= 0) ? 0ull : (~0ull >> (64 - (y - a)));
+    const unsigned long long b = __ballot(m != 0);
+    if (!b) return x.prevnl[g];
+    const int l = 63 - __clzll(b);
+    const int hi = __shfl((int)(m >> 32), l, 64), lo = __shfl((int)(m & 0xFFFFFFFFull), l, 64);
+    const unsigned long long ml = ((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo;
+    return x.gbase + g * (int64_t)GRAN + l * 64 + (63 - __clzll(ml));
 }
 
 // ============================================================== shard boundary summary
@@ -959,8 +995,13 @@ __global__ __launch_bounds__(SUMM_BLOCK) void k_shard_summary2(ScanCtx x, int is
             carry = la;
         }
     }
-    if (tid != 0) return;
+    // the second-to-last newline of the lead and of the whole shard: what a record that ENDS here or in the next shard
+    // needs to know the length of its last line (k_stitch_tail: line-regular test across the cut)
     const int64_t lead_nl = n_hdr ? hdr_line[0] : n_nl;
+    const int64_t lead_last = n_hdr ? first_hdr - 1 : tot->last_nl;
+    const int64_t lead_prev = lead_nl >= 2 ? prev_nl_wave(x, lead_last) : -1;
+    const int64_t second_last = n_nl >= 2 ? prev_nl_wave(x, tot->last_nl) : -1;
+    if (tid != 0) return;
     S[0] = x.gbase; S[1] = x.n; S[2] = is_last;
     S[3] = n_nl; S[4] = first_nl; S[5] = first_nl >= 0 ? next_nl(x, first_nl) : -1; S[6] = n_nl ? tot->last_nl : -1;
     S[7] = (first_nl > x.gbase) ? (int64_t)x.data[first_nl - 1 - x.gbase] : -1;
@@ -983,7 +1024,7 @@ __global__ __launch_bounds__(SUMM_BLOCK) void k_shard_summary2(ScanCtx x, int is
         }
     }
     S[19] = te; S[20] = tfe; S[21] = tna; S[22] = tbad; S[23] = telen; S[24] = tdlen; S[25] = tname;
-    S[26] = 0; S[27] = 0;
+    S[26] = lead_prev; S[27] = second_last;
 }
 
 // ============================================================== stitch (multi-GPU)
@@ -995,7 +1036,7 @@ __global__ __launch_bounds__(SUMM_BLOCK) void k_shard_summary2(ScanCtx x, int is
 // between the collective and the fetches).
 enum { SS_BASE = 0, SS_NBYTES, SS_ISLAST, SS_NNL, SS_FIRSTNL, SS_SECONDNL, SS_LASTNL, SS_FIRSTNLPREV, SS_FIRSTBYTE, SS_LASTBYTE,
        SS_NHDR, SS_FIRSTHDR, SS_LASTHDR, SS_LEADNL, SS_LEADWS, SS_V1, SS_C1, SS_V2, SS_C2, SS_TE, SS_TFE, SS_TNA, SS_TBAD,
-       SS_TELEN, SS_TDLEN, SS_TNAME, SS_WORDS = 28 };
+       SS_TELEN, SS_TDLEN, SS_TNAME, SS_LEADPREVNL, SS_SECONDLASTNL, SS_WORDS = 28 };
 
 // min(2, number of FULL lead lines of shard u whose len+1 != llen)
 __device__ __forceinline__ int64_t lead_count_ne(const int64_t *u, int64_t llen) {
@@ -1021,6 +1062,7 @@ __global__ void k_stitch_tail(const int64_t *__restrict__ S, int world, int r, i
         if (s[SS_TFE] >= 0) { llen = s[SS_TFE] - e; have_llen = true; bad = s[SS_TBAD] < 2 ? s[SS_TBAD] : 2; }
     }
     int64_t hn = -1, ws = -1;                             // ws: white space seen in continuation shards while the header is unterminated
+    int t_hdr = -1;                                       // the shard that holds the next header line
     for (int t = r + 1; t < world; ++t) {
         const int64_t *u = S + (int64_t)t * SS_WORDS;
         if (!have_e && ws < 0 && u[SS_LEADWS] >= 0) ws = u[SS_LEADWS];
@@ -1052,22 +1094,49 @@ __global__ void k_stitch_tail(const int64_t *__restrict__ S, int world, int r, i
             if (bad > 2) bad = 2;
             if (u[SS_NHDR] == 0) last_nl = u[SS_LASTNL];
         }
-        if (u[SS_NHDR] > 0) { hn = u[SS_FIRSTHDR]; break; }
+        if (u[SS_NHDR] > 0) { hn = u[SS_FIRSTHDR]; t_hdr = t; break; }
     }
     if (hn < 0) {                                         // `position` after the last line (index.c:231)
         hn = 0;
         for (int t = world - 1; t >= 0; --t) { const int64_t *u = S + (int64_t)t * SS_WORDS; if (u[SS_NNL] > 0) { hn = u[SS_LASTNL] + 1; break; } }
     }
     const int64_t boff = e + 1, blen = hn - boff;         // index.c:243,348
-    c.boff[k] = boff; c.blen[k] = blen; c.slen[k] = blen - elen * nseq; c.llen[k] = nseq > 0 ? llen : 0;
+    const int64_t slen = blen - elen * nseq;
+    if (nseq <= 0) llen = 0;
+    // line-regular (fx_kernels.hpp: line_regular): the byte that decides it may sit on another rank, so the same
+    // question is put to the summaries -- is the last line of the record (the two newlines before hn) x + elen long?
+    int reg = 0;
+    const int64_t bpl = llen - elen;
+    if (bad <= 1 && bpl > 0 && elen > 0) {
+        if (bad == 0 || slen <= bpl) reg = 1;
+        else {
+            const int64_t lines = (slen + bpl - 1) / bpl;
+            if (lines == nseq) {
+                const int64_t x = slen - (lines - 1) * bpl;
+                int found = 0;
+                int64_t prev = -1;
+                for (int t = t_hdr >= 0 ? t_hdr : world - 1; t >= r && found < 2; --t) {
+                    const int64_t *u = S + (int64_t)t * SS_WORDS;
+                    const bool lead = t == t_hdr;         // only the newlines before its first header line count there
+                    const int64_t cnt = lead ? u[SS_LEADNL] : u[SS_NNL];
+                    if (cnt <= 0) continue;
+                    if (found == 0) { if (cnt >= 2) { prev = lead ? u[SS_LEADPREVNL] : u[SS_SECONDLASTNL]; found = 2; } else found = 1; }
+                    else { prev = lead ? u[SS_FIRSTHDR] - 1 : u[SS_LASTNL]; found = 2; }
+                }
+                reg = (found == 2 && (hn - 1) - prev == x + elen) ? 1 : 0;
+            }
+        }
+    }
+    c.boff[k] = boff; c.blen[k] = blen; c.slen[k] = slen; c.llen[k] = llen;
     c.elen[k] = (int32_t)elen; c.norm[k] = bad > 1 ? 0 : 1; c.dlen[k] = (int32_t)dlen; c.name_len[k] = (int32_t)name_len;
+    c.reg[k] = reg;
 }
 
 // fx_fasta_set_row: one launch instead of eight 4/8-byte copies
 __global__ void k_set_row(FastaCols c, int64_t k, int64_t boff, int64_t blen, int64_t slen, int64_t llen, int32_t elen,
-                          int32_t norm, int32_t dlen, int32_t name_len) {
+                          int32_t norm, int32_t dlen, int32_t name_len, int32_t reg) {
     c.boff[k] = boff; c.blen[k] = blen; c.slen[k] = slen; c.llen[k] = llen;
-    c.elen[k] = elen; c.norm[k] = norm; c.dlen[k] = dlen; c.name_len[k] = name_len;
+    c.elen[k] = elen; c.norm[k] = norm & 1; c.dlen[k] = dlen; c.name_len[k] = name_len; c.reg[k] = reg;
 }
 
 }  // namespace fx

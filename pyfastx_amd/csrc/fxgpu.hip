@@ -157,7 +157,7 @@ struct fx_handle {
     DevBuf<int64_t> nl_prefix, hdr_prefix, prevnl;
     // FASTA table
     DevBuf<int64_t> hdr, fa_boff, fa_blen, fa_slen, fa_llen, fa_hdr_line;
-    DevBuf<int32_t> fa_elen, fa_norm, fa_dlen, fa_name_len;
+    DevBuf<int32_t> fa_elen, fa_norm, fa_dlen, fa_name_len, fa_reg;
     DevBuf<uint32_t> fa_bad;
     int64_t n_hdr = 0, fa_seqlen = 0;
     bool fasta_built = false;
@@ -644,7 +644,7 @@ static FastaCols fasta_cols(fx_handle *h) {
     FastaCols c;
     c.hoff = h->hdr.p; c.boff = h->fa_boff.p; c.blen = h->fa_blen.p; c.slen = h->fa_slen.p; c.llen = h->fa_llen.p;
     c.hdr_line = h->fa_hdr_line.p; c.elen = h->fa_elen.p; c.dlen = h->fa_dlen.p; c.name_len = h->fa_name_len.p;
-    c.norm = h->fa_norm.p; c.bad = h->fa_bad.p;
+    c.norm = h->fa_norm.p; c.bad = h->fa_bad.p; c.reg = h->fa_reg.p;
     return c;
 }
 static int alloc_fasta_table(fx_handle *h, int64_t cap) {
@@ -652,7 +652,7 @@ static int alloc_fasta_table(fx_handle *h, int64_t cap) {
     if ((rc = h->hdr.alloc(cap)) || (rc = h->fa_hdr_line.alloc(cap)) || (rc = h->fa_boff.alloc(cap)) ||
         (rc = h->fa_blen.alloc(cap)) || (rc = h->fa_slen.alloc(cap)) || (rc = h->fa_llen.alloc(cap)) ||
         (rc = h->fa_elen.alloc(cap)) || (rc = h->fa_norm.alloc(cap)) || (rc = h->fa_dlen.alloc(cap)) ||
-        (rc = h->fa_name_len.alloc(cap)) || (rc = h->fa_bad.alloc(cap)))
+        (rc = h->fa_name_len.alloc(cap)) || (rc = h->fa_bad.alloc(cap)) || (rc = h->fa_reg.alloc(cap)))
         return rc;
     return FX_OK;
 }
@@ -711,7 +711,7 @@ static int enqueue_records(fx_handle *h, int full_name) {
     FX_LAUNCH(h, K_HDR_REC, k_hdr_rec, dim3(2048), dim3(BLOCK), x, h->prev_byte, (int)h->is_last, full_name, hgl, c, cap);
     FX_LAUNCH(h, K_GRAN_LINES, k_gran_lines, dim3(nblocks(ngran, BLOCK)), dim3(BLOCK), x, rv, cap, irr);
     FX_LAUNCH(h, K_GRAN_EXACT, k_gran_exact, dim3(2048), dim3(BLOCK), x, rv, cap, irr, (int)h->is_last, h->prev_byte);
-    FX_LAUNCH(h, K_FASTA_FINALIZE, k_fasta_finalize2, dim3(nblocks(cap, BLOCK)), dim3(BLOCK), cap, c, ctl_totals(h));
+    FX_LAUNCH(h, K_FASTA_FINALIZE, k_fasta_finalize2, dim3(nblocks(cap, BLOCK)), dim3(BLOCK), cap, c, ctl_totals(h), h->d_data, h->n, h->base);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h->pin_tot, ctl_totals(h), sizeof(Totals), hipMemcpyDeviceToHost, h->stream));
     return FX_OK;
@@ -790,6 +790,10 @@ extern "C" int fx_fasta_set_table(fx_handle *h, int64_t n, const int64_t *boff, 
         HIPCHK(up(h->fa_boff.p, boff, (size_t)n * 8)); HIPCHK(up(h->fa_blen.p, blen, (size_t)n * 8));
         HIPCHK(up(h->fa_slen.p, slen, (size_t)n * 8)); HIPCHK(up(h->fa_llen.p, llen, (size_t)n * 8));
         HIPCHK(up(h->fa_elen.p, elen, (size_t)n * 4)); HIPCHK(up(h->fa_norm.p, norm, (size_t)n * 4));
+        // the .fxi has no column for "line-regular": decided here, once, from the rows and one byte of the stream each
+        hipLaunchKernelGGL(k_line_regular, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, h->d_data, h->n, h->base, n, h->fa_boff.p,
+                           h->fa_blen.p, h->fa_slen.p, h->fa_llen.p, h->fa_elen.p, h->fa_norm.p, h->fa_reg.p);
+        HIPCHK(hipGetLastError());
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     h->n_hdr = n;
@@ -1209,7 +1213,7 @@ static int fetch_common(fx_handle *h, int where, int64_t n, bool by_id, const in
     memset(&tab, 0, sizeof tab);
     if (h->fasta_built) {
         tab.boff = h->fa_boff.p; tab.blen = h->fa_blen.p; tab.slen = h->fa_slen.p; tab.llen = h->fa_llen.p;
-        tab.elen = h->fa_elen.p; tab.norm = h->fa_norm.p; tab.n_seq = h->n_hdr;
+        tab.elen = h->fa_elen.p; tab.norm = h->fa_reg.p; tab.n_seq = h->n_hdr;     // slices go by the line-regular column
         if (h->build_pending) { tab.n_seq_dev = (const long long *)&ctl_totals(h)->n_hdr; tab.n_seq = h->hdr.cap; }
     }
     // lanes per query: 16 (128-byte window, 4 queries per wave) for short random access,
@@ -1253,6 +1257,15 @@ extern "C" int fx_fetch_ranges(fx_handle *h, int where, int64_t n, const int64_t
     int64_t ext = 0;
     if (where == FX_HOST && n > 0 && dst_off && slen) ext = std::max<int64_t>(1, host_extent(n, dst_off, slen, nullptr, nullptr));
     return fetch_common(h, where, n, false, off, blen, slen, nullptr, flags, flags_per_query, dst, dst_off, out_len, ext);
+}
+
+extern "C" int fx_fetch_slices(fx_handle *h, int where, int64_t n, const int64_t *off, const int64_t *blen, const int64_t *skip,
+                               const int64_t *take, int flags, const uint8_t *flags_per_query, uint8_t *dst,
+                               const int64_t *dst_off, int64_t *out_len) {
+    if (n > 0 && !skip) return fail(FX_EINVAL, "null query array");
+    int64_t ext = 0;
+    if (where == FX_HOST && n > 0 && dst_off && take) ext = std::max<int64_t>(1, host_extent(n, dst_off, take, nullptr, nullptr));
+    return fetch_common(h, where, n, false, off, blen, take, skip, flags, flags_per_query, dst, dst_off, out_len, ext);
 }
 
 // One range for one caller (Sequence.seq, Read.seq, fa.fetch of a single interval): the per-object API of the
@@ -1652,6 +1665,17 @@ extern "C" int fx_fasta_stitch_dev(fx_handle *h, const int64_t *d_all, int world
 
 extern "C" void *fx_stream(fx_handle *h) { return h ? (void *)h->stream : nullptr; }
 
+extern "C" int fx_fasta_line_regular(fx_handle *h, int where, int32_t *reg) {
+    if (!h || !reg) return fail(FX_EINVAL, "null argument");
+    if (!h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build has not run");
+    int rc = use_device(h);
+    if (!rc) rc = finish_build(h);
+    if (rc) return rc;
+    if ((rc = copy_out(h, where, reg, h->fa_reg.p, h->n_hdr))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FX_OK;
+}
+
 extern "C" int fx_fasta_set_row(fx_handle *h, int64_t k, int64_t boff, int64_t blen, int64_t slen, int64_t llen,
                                 int32_t elen, int32_t norm, int32_t dlen, int32_t name_len) {
     if (!h) return fail(FX_EINVAL, "null handle");
@@ -1660,7 +1684,9 @@ extern "C" int fx_fasta_set_row(fx_handle *h, int64_t k, int64_t boff, int64_t b
     if (!rc) rc = finish_build(h);
     if (rc) return rc;
     if (k < 0 || k >= h->n_hdr) return fail(FX_ERANGE, "row %lld out of range", (long long)k);
-    hipLaunchKernelGGL(k_set_row, dim3(1), dim3(1), 0, h->stream, fasta_cols(h), k, boff, blen, slen, llen, elen, norm, dlen, name_len);
+    // norm: bit 0 = index.c's norm, bit 1 = line-regular (pyfastx_amd/shard.py: stitch_tail decides both from the summaries)
+    hipLaunchKernelGGL(k_set_row, dim3(1), dim3(1), 0, h->stream, fasta_cols(h), k, boff, blen, slen, llen, elen, norm, dlen, name_len,
+                       (int32_t)((norm >> 1) & 1));
     HIPCHK(hipGetLastError());
     return FX_OK;
 }

@@ -86,9 +86,17 @@ def connect(path):
     return db
 
 
+def _name_bytes(names):
+    """Names as the bytes the `chrom` / `name` TEXT column stores: raw bytes stay as they are (sqlite3_bind_text in the
+    reference, index.c:239-251), str (key_func results) are encoded the way fxi.connect decodes them."""
+    return [x if isinstance(x, (bytes, bytearray)) else str(x).encode("utf-8", "surrogateescape") for x in names]
+
+
 def write_fasta(db, names, cols, seqlen_total):
-    """INSERT INTO seq ... (index.c:226-251, 342-372).  names: list[str];
-    cols: dict of int arrays boff, blen, slen, llen, elen, norm, dlen."""
+    """INSERT INTO seq ... (index.c:226-251, 342-372).  names: list of bytes (or str);
+    cols: dict of int arrays boff, blen, slen, llen, elen, norm, dlen.  The name is bound as bytes and cast to TEXT,
+    so the column holds exactly the bytes of the file, as in the reference and in the bulk loader."""
+    names = _name_bytes(names)
     db.executescript(FASTA_DDL)
     db.execute("PRAGMA synchronous=OFF")
     db.execute("PRAGMA locking_mode=EXCLUSIVE")
@@ -96,7 +104,7 @@ def write_fasta(db, names, cols, seqlen_total):
     n = len(names)
     it = zip(names, cols["boff"].tolist(), cols["blen"].tolist(), cols["slen"].tolist(), cols["llen"].tolist(),
              cols["elen"].tolist(), cols["norm"].tolist(), cols["dlen"].tolist())
-    db.executemany("INSERT INTO seq VALUES (NULL,?,?,?,?,?,?,?,?)", it)
+    db.executemany("INSERT INTO seq VALUES (NULL,CAST(? AS TEXT),?,?,?,?,?,?,?)", it)
     db.execute("PRAGMA locking_mode=NORMAL")
     db.execute("COMMIT")
     try:        # duplicate names: the reference ignores the failure too (index.c:363-366)
@@ -108,14 +116,14 @@ def write_fasta(db, names, cols, seqlen_total):
 
 def write_fasta_comp(db, comp):
     """fasta.c:890-953: non-zero bins per record, then all 128 totals with seqid 0."""
-    import numpy as np
+    write_fasta_comp_rows(db, *comp_rows(comp))
+
+
+def write_fasta_comp_rows(db, seqid, abc, num):
+    """The comp table from its rows (comp_rows / fx_fasta_comp_sparse + the 128 totals), one INSERT each."""
     db.execute("PRAGMA synchronous=OFF")
     db.execute("BEGIN TRANSACTION")
-    rec, abc = np.nonzero(comp)
-    rows = zip((rec + 1).tolist(), abc.tolist(), comp[rec, abc].tolist())
-    db.executemany("INSERT INTO comp VALUES (NULL,?,?,?)", rows)
-    tot = comp.sum(axis=0)
-    db.executemany("INSERT INTO comp VALUES (NULL,0,?,?)", [(j, int(tot[j])) for j in range(128)])
+    db.executemany("INSERT INTO comp VALUES (NULL,?,?,?)", zip(seqid.tolist(), abc.tolist(), num.tolist()))
     db.execute("CREATE INDEX seqidx ON comp (seqid)")
     db.execute("COMMIT")
 
@@ -155,13 +163,14 @@ def write_fasta_comp_bulk(path, seqid, abc, num):
 
 
 def write_fastq(db, names, cols, size):
-    """fastq.c:76-171."""
+    """fastq.c:76-171.  names: list of bytes (or str), stored verbatim (see write_fasta)."""
+    names = _name_bytes(names)
     db.executescript(FASTQ_DDL)
     db.execute("PRAGMA synchronous = OFF")
     db.execute("PRAGMA locking_mode=EXCLUSIVE")
     db.execute("BEGIN TRANSACTION")
     it = zip(names, cols["dlen"].tolist(), cols["rlen"].tolist(), cols["soff"].tolist(), cols["qoff"].tolist())
-    db.executemany("INSERT INTO read VALUES (NULL,?,?,?,?,?)", it)
+    db.executemany("INSERT INTO read VALUES (NULL,CAST(? AS TEXT),?,?,?,?)", it)
     db.execute("PRAGMA locking_mode=NORMAL")
     db.execute("COMMIT")
     try:

@@ -17,7 +17,7 @@ import numpy as np
 FIELDS = ["base", "n_bytes", "is_last", "n_nl", "first_nl", "second_nl", "last_nl", "first_nl_prev",
           "first_byte", "last_byte", "n_hdr", "first_hdr", "last_hdr", "lead_nl", "lead_ws",
           "lead_v1", "lead_c1", "lead_v2", "lead_c2", "tail_e", "tail_first_end", "tail_nl_after", "tail_bad",
-          "tail_elen", "tail_dlen", "tail_name_len", "reserved0", "reserved1"]
+          "tail_elen", "tail_dlen", "tail_name_len", "lead_prev_nl", "second_last_nl"]
 NWORDS = len(FIELDS)
 
 
@@ -51,6 +51,25 @@ def stream_end(S):
     return 0
 
 
+def line_regular_rule(boff, blen, slen, llen, elen, norm, byte_at):
+    """May slices of this record use the line arithmetic of sequence.c:498-510?  The rule of csrc/fx_kernels.hpp
+    (line_regular), restated for the host: `norm` (index.c:342) allows ONE line of another length; the arithmetic is
+    right only when that line is the last one.  Decided by the row and one byte of the stream: the record has
+    ceil(slen / bpl) lines and the byte in front of its last line is a newline.  byte_at(p): stream[p], or None when
+    the caller cannot see it (-> None: undecided)."""
+    bpl = llen - elen
+    if not norm or bpl <= 0 or elen <= 0:
+        return False
+    if slen <= bpl:
+        return True
+    lines = -(-slen // bpl)
+    if blen != slen + lines * elen:
+        return False
+    x = slen - (lines - 1) * bpl
+    c = byte_at(boff + blen - (x + elen) - 1)
+    return None if c is None else c == 10
+
+
 def stitch_tail(S, r, full_name=False):
     """Final .fxi columns of the LAST record that starts in shard r, given all
     summaries S (list of Summary in shard order).  None if shard r has no header.
@@ -68,6 +87,7 @@ def stitch_tail(S, r, full_name=False):
         if s.tail_first_end >= 0:
             llen, have_llen, bad = s.tail_first_end - e, True, min(2, s.tail_bad)
     hn = None
+    t_hdr = -1                                 # the shard that holds the next header line
     ws = -1                                    # whitespace seen in continuation shards while header unterminated
     for t in range(r + 1, len(S)):
         u = S[t]
@@ -104,14 +124,44 @@ def stitch_tail(S, r, full_name=False):
             bad = min(bad, 2)
             last_nl = u.last_nl if u.n_hdr == 0 else last_nl
         if u.n_hdr > 0:
-            hn = u.first_hdr
+            hn, t_hdr = u.first_hdr, t
             break
     if hn is None:
         hn = stream_end(S)
     boff = e + 1
     blen = hn - boff                           # index.c:243,348
-    return {"boff": boff, "blen": blen, "slen": blen - elen * nseq, "llen": llen if nseq > 0 else 0,
-            "elen": elen, "norm": 0 if bad > 1 else 1, "dlen": dlen, "name_len": name_len}
+    slen = blen - elen * nseq
+    if nseq <= 0:
+        llen = 0
+    # line-regular (line_regular_rule): the deciding byte may sit on another rank, so the same question is put to the
+    # summaries -- is the record's last line (between the two newlines before hn) x + elen long?
+    reg, bpl = 0, llen - elen
+    if bad <= 1 and bpl > 0 and elen > 0:
+        if bad == 0 or slen <= bpl:
+            reg = 1
+        else:
+            lines = -(-slen // bpl)
+            if lines == nseq:
+                x = slen - (lines - 1) * bpl
+                found, prev = 0, -1
+                for t in range(t_hdr if t_hdr >= 0 else len(S) - 1, r - 1, -1):
+                    u = S[t]
+                    lead = t == t_hdr          # only the newlines before its first header line count there
+                    cnt = u.lead_nl if lead else u.n_nl
+                    if cnt <= 0:
+                        continue
+                    if found == 0:
+                        if cnt >= 2:
+                            prev, found = (u.lead_prev_nl if lead else u.second_last_nl), 2
+                        else:
+                            found = 1
+                    else:
+                        prev, found = (u.first_hdr - 1 if lead else u.last_nl), 2
+                    if found == 2:
+                        break
+                reg = int(found == 2 and (hn - 1) - prev == x + elen)
+    return {"boff": boff, "blen": blen, "slen": slen, "llen": llen,
+            "elen": elen, "norm": 0 if bad > 1 else 1, "dlen": dlen, "name_len": name_len, "reg": reg}
 
 
 def id_offsets(S):
@@ -297,9 +347,11 @@ class ShardedFasta:
         cross a cut are exchanged."""
         if self.world == 1:
             t = self.local_rows()
+            t["reg"] = self.blob.fasta_line_regular(self.n_local)
             return ShardFetcher({0: self.blob}, [self.base], [self.base + self.n_bytes], t)
-        cols = ("boff", "blen", "slen", "llen", "elen", "norm")
+        cols = ("boff", "blen", "slen", "llen", "elen", "norm", "reg")
         rows = self.local_rows()
+        rows["reg"] = self.blob.fasta_line_regular(self.n_local)
         outs = [None] * self.world
         self._dist.all_gather_object(outs, (self.base, self.n_bytes, {c: np.asarray(rows[c]) for c in cols}))
         table = {c: np.concatenate([o[2][c] for o in outs]) for c in cols}
@@ -395,15 +447,15 @@ F_UP, F_REV, F_COMP = 1, 2, 4
 
 def slice_ranges(table, ids, starts, stops):
     """(record id, 0-based [start, stop)) -> off, blen, skip, take over the global stream.  Line-regular records
-    (norm=1): exactly the bytes, sequence.c:498-510.  Others: the whole record, sliced after despacing
-    (sequence.c:100-110) -- skip = start."""
+    (table["reg"], fx_fasta_line_regular; a table without that column: norm = 1): exactly the bytes,
+    sequence.c:498-510.  Others: the whole record, sliced after despacing (sequence.c:100-110) -- skip = start."""
     ids = np.asarray(ids, dtype=np.int64)
     a = np.asarray(starts, dtype=np.int64)
     b = np.asarray(stops, dtype=np.int64)
     boff, blen = np.asarray(table["boff"], dtype=np.int64)[ids], np.asarray(table["blen"], dtype=np.int64)[ids]
     llen, elen = np.asarray(table["llen"], dtype=np.int64)[ids], np.asarray(table["elen"], dtype=np.int64)[ids]
     bpl = llen - elen
-    reg = (np.asarray(table["norm"])[ids] != 0) & (bpl > 0)
+    reg = (np.asarray(table["reg"] if "reg" in table else table["norm"])[ids] != 0) & (bpl > 0)
     safe = np.where(bpl > 0, bpl, 1)
     bs, be = a // safe, b // safe
     off = np.where(reg, boff + a + elen * bs, boff)
@@ -459,11 +511,11 @@ class ShardFetcher:
         off, blen, skip, take = slice_ranges(self.table, ids, starts, stops)
         P = route_ranges(self.bases, self.ends, off, blen)
         q, r = P["q"], P["r"]
-        simple = (P["cnt"] == 1) & (skip == 0)               # one piece, no slicing after despace: the kernel does it all
+        simple = P["cnt"] == 1                                # one piece: the kernel does it all (slice after despacing included)
         psimple = simple[q]
         held = np.isin(r, np.fromiter(self.f.keys(), dtype=np.int64, count=len(self.f)))
         answers = {}
-        loose = []                                            # (query, shard, bytes) of the other pieces we hold
+        loose = []                                            # (query, shard, bytes): pieces of queries that cross a cut
         for sh, fx in self.f.items():
             mine = np.nonzero(held & (r == sh))[0]
             if not mine.size:
@@ -472,7 +524,9 @@ class ShardFetcher:
             s = psimple[mine]
             want = np.where(s, take[qq], P["plen"][mine])
             kfl = np.where(s, fl[qq], fl[qq] & np.uint8(F_UP | F_COMP)).astype(np.uint8)
-            buf, offs, ol = fx.fetch_ranges(P["poff"][mine], P["plen"][mine], want, flags_per_query=kfl)
+            ksk = np.where(s, skip[qq], 0)
+            buf, offs, ol = fx.fetch_ranges(P["poff"][mine], P["plen"][mine], want, flags_per_query=kfl,
+                                            skip=ksk if ksk.any() else None)
             for k in np.nonzero(~s)[0].tolist():
                 loose.append((int(qq[k]), int(sh), buf[offs[k]:offs[k] + ol[k]].tobytes()))
             ks = np.nonzero(s)[0]

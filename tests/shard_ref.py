@@ -20,7 +20,10 @@ def local_scan(raw, lo, hi, full_name=False):
     gt = np.flatnonzero(a == ord(">"))
     hdr = [int(p) + lo for p in gt if (raw[lo + p - 1] if (lo + p) > 0 else 10) == 10 and (p > 0 or prev == 10)]
     nl_arr = np.array(nl, dtype=np.int64)
-    rows = {k: [] for k in ("hoff", "boff", "blen", "slen", "llen", "elen", "norm", "dlen", "name_len")}
+    rows = {k: [] for k in ("hoff", "boff", "blen", "slen", "llen", "elen", "norm", "dlen", "name_len", "reg")}
+
+    def byte_at(p):                                        # what this shard can see of the stream
+        return raw[p] if lo <= p < hi else None
     tail = dict(tail_e=-1, tail_first_end=-1, tail_nl_after=0, tail_bad=0, tail_elen=0, tail_dlen=-1, tail_name_len=-1)
     for k, h in enumerate(hdr):
         L = int(np.searchsorted(nl_arr, h, side="left"))
@@ -32,7 +35,7 @@ def local_scan(raw, lo, hi, full_name=False):
                     if c in (32, 9):
                         ws = j
                         break
-            vals = dict(hoff=h, boff=0, blen=0, slen=0, llen=0, elen=0, norm=1, dlen=-1, name_len=ws)
+            vals = dict(hoff=h, boff=0, blen=0, slen=0, llen=0, elen=0, norm=1, dlen=-1, name_len=ws, reg=0)
             for kk, v in vals.items():
                 rows[kk].append(v)
             tail.update(tail_dlen=-1, tail_name_len=ws)
@@ -56,8 +59,10 @@ def local_scan(raw, lo, hi, full_name=False):
         blen = hn - boff
         llen = nl[L + 1] - nl[L] if nseq > 0 else 0
         bad = sum(1 for i in range(L + 2, Ln) if nl[i] - nl[i - 1] != llen)
+        from pyfastx_amd.shard import line_regular_rule
+        reg = line_regular_rule(boff, blen, blen - elen * nseq, llen, elen, 0 if bad > 1 else 1, byte_at)
         vals = dict(hoff=h, boff=boff, blen=blen, slen=blen - elen * nseq, llen=llen, elen=elen,
-                    norm=0 if bad > 1 else 1, dlen=dlen, name_len=name_len)
+                    norm=0 if bad > 1 else 1, dlen=dlen, name_len=name_len, reg=int(bad == 0) if reg is None else int(reg))
         for kk, v in vals.items():
             rows[kk].append(v)
         if k == len(hdr) - 1:
@@ -85,7 +90,8 @@ def local_scan(raw, lo, hi, full_name=False):
              first_nl_prev=int(raw[first_nl - 1]) if first_nl > lo else -1,
              first_byte=int(a[0]), last_byte=int(a[-1]), n_hdr=len(hdr), first_hdr=hdr[0] if hdr else -1,
              last_hdr=hdr[-1] if hdr else -1, lead_nl=lead_nl, lead_ws=ws, lead_v1=v1, lead_c1=c1, lead_v2=v2,
-             lead_c2=c2, reserved0=0, reserved1=0)
+             lead_c2=c2, lead_prev_nl=nl[lead_nl - 2] if lead_nl >= 2 else -1,
+             second_last_nl=nl[-2] if len(nl) >= 2 else -1)
     s.update(tail)
     return rows, Summary((k, int(s[k])) for k in FIELDS)
 

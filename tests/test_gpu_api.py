@@ -399,3 +399,30 @@ def test_iteration_rides_on_batched_fetches(fx, files, tmp_path, oracle):
             assert r.quali == [c - 33 for c in rawq[qo:qo + m]] and r.antisense == oracle.revcomp(rawq[so:so + m], 3).decode()
         n += 1
     assert n == len(rq)
+
+
+def test_fetch_many_equals_slices_on_odd_line_records(fx, tmp_path):
+    """the batched fetch_many and the per-object slices return the same bytes for records with one odd line
+    (norm = 1, not line-regular) -- both cut the despaced record; also on an index loaded from the file."""
+    from test_gpu_kernels import _odd_line_fasta
+    rng = np.random.default_rng(5)
+    raw = _odd_line_fasta(rng, False)
+    p = str(tmp_path / "odd.fa")
+    open(p, "wb").write(raw)
+    for reopen in (False, True):
+        fa = fx.Fasta(p)
+        n = len(fa)
+        ids = rng.integers(0, n, 300)
+        lens = np.array([len(fa[int(i)]) for i in ids])
+        st = (rng.random(300) * lens).astype(np.int64)
+        sp = np.minimum(st + rng.integers(1, 200, 300), lens)
+        strand = rng.integers(0, 2, 300)
+        buf, offs = fa.fetch_many(ids, st, sp, strand=strand)
+        for j in range(300):
+            s = fa[int(ids[j])][int(st[j]):int(sp[j])]
+            want = s.antisense if strand[j] else s.seq
+            whole = fa[int(ids[j])].seq[int(st[j]):int(sp[j])]
+            assert buf[offs[j]:offs[j + 1]].tobytes().decode() == want, (reopen, j)
+            if not strand[j]:
+                assert want == whole
+        del fa

@@ -31,6 +31,8 @@ def assert_fasta_equal(oracle, L, raw, full_name=False):
         np.testing.assert_array_equal(t[col], recs[col].astype(t[col].dtype), err_msg=col)
     comp = b.fasta_comp(s.n_seq)
     np.testing.assert_array_equal(comp, oracle.fasta_comp(raw, len(recs)))
+    from test_host_logic import _reg_of                     # the line-regular column: the same rule, on the device
+    np.testing.assert_array_equal(b.fasta_line_regular(s.n_seq), np.array([_reg_of(raw, r) for r in recs], dtype=np.int32), err_msg="reg")
     return b, recs, t
 
 
@@ -700,3 +702,63 @@ def test_fastq_line_records(oracle, L, crlf):
     t2 = b2.fastq_table(s2.n_reads)
     for col in ("name_off", "name_len", "dlen", "rlen", "soff", "qoff"):
         np.testing.assert_array_equal(t2[col], recs2[col].astype(t2[col].dtype), err_msg=col)
+
+
+def _odd_line_fasta(rng, crlf):
+    """Records with ONE odd line in the middle (norm = 1, not line-regular) among ordinary and ragged ones."""
+    eol = b"\r\n" if crlf else b"\n"
+    parts = []
+    for i in range(40):
+        parts.append(b">o%d some text" % i + eol)
+        w = int(rng.integers(17, 90))
+        m = int(rng.integers(3, 30))
+        kind = i % 4                                         # 0: regular, 1: odd middle line, 2: long last line, 3: ragged
+        for j in range(m):
+            k = w
+            if kind == 1 and j == m // 2:
+                k = w - int(rng.integers(1, min(w - 1, 9)))
+            if kind == 2 and j == m - 1:
+                k = w + 3
+            if kind == 3:
+                k = int(rng.integers(1, w + 1))
+            if kind == 0 and j == m - 1:
+                k = int(rng.integers(1, w + 1))
+            parts.append(bytes(rng.choice(list(b"ACGTNacgtn"), k).astype(np.uint8)) + eol)
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+def test_slices_of_records_with_one_odd_line(oracle, L, crlf):
+    """A record with one odd line carries norm = 1 (index.c:342) and is NOT line-regular: every batched path -- by id
+    (fx_fasta_fetch), by byte range with a slice after despacing (fx_fetch_slices) -- returns the true slice of the
+    despaced record (sequence.c:100-110), like Sequence slices do; the device column agrees with the host rule."""
+    from test_host_logic import _reg_of
+    rng = np.random.default_rng(77 + crlf)
+    raw = _odd_line_fasta(rng, crlf)
+    b, recs, t = assert_fasta_equal(oracle, L, raw)
+    reg = b.fasta_line_regular(len(recs))
+    assert ((reg == 0) & (recs["norm"] == 1)).sum() >= 15 and (reg == 1).sum() >= 8
+    nq = 4000
+    ids = rng.integers(0, len(recs), nq)
+    st = (rng.random(nq) * recs["slen"][ids]).astype(np.int64)
+    sp = np.minimum(st + rng.integers(0, 300, nq), recs["slen"][ids])
+    fl = rng.integers(0, 8, nq).astype(np.uint8)
+    buf, offs, ol = b.fasta_fetch(ids, st, sp, flags_per_query=fl)
+    full = [oracle.fetch(raw, r["boff"], r["blen"], r["slen"]) for r in recs]
+    full5 = {f: [oracle.fetch(raw, r["boff"], r["blen"], r["slen"], f) for r in recs] for f in (0, 1, 4, 5)}
+    for j in range(nq):
+        w = full5[int(fl[j]) & 5][ids[j]][st[j]:sp[j]]
+        w = w[::-1] if fl[j] & 2 else w
+        assert buf[offs[j]:offs[j] + ol[j]].tobytes() == w, (j, int(ids[j]), int(st[j]), int(sp[j]), int(fl[j]), int(reg[ids[j]]))
+    # the same through explicit ranges + skip (what ShardFetcher sends for records that are not line-regular)
+    buf, offs, ol = b.fetch_ranges(recs["boff"][ids], recs["blen"][ids], sp - st, flags_per_query=fl, skip=st)
+    for j in range(nq):
+        w = full5[int(fl[j]) & 5][ids[j]][st[j]:sp[j]]
+        w = w[::-1] if fl[j] & 2 else w
+        assert buf[offs[j]:offs[j] + ol[j]].tobytes() == w, ("slices", j)
+    # an installed table (rows of an existing .fxi) gets the same column
+    b2 = L.Blob.from_bytes(raw)
+    b2.fasta_set_table(*[recs[c] for c in ("boff", "blen", "slen", "llen", "elen", "norm")])
+    np.testing.assert_array_equal(b2.fasta_line_regular(len(recs)), reg)
+    buf2, offs2, ol2 = b2.fasta_fetch(ids, st, sp, flags_per_query=fl)
+    assert buf2.tobytes() == b.fasta_fetch(ids, st, sp, flags_per_query=fl)[0].tobytes()

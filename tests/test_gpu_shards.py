@@ -26,8 +26,8 @@ def sharded_rows(L, raw, cuts, full_name=False):
         row = shard.stitch_tail(S, r, full_name)
         if row is not None:
             b.fasta_set_row(n - 1, **row)
-        rows.append(b.fasta_table(n))
-    return {c: np.concatenate([t[c] for t in rows]) for c in COLS}, S
+        rows.append(dict(b.fasta_table(n), reg=b.fasta_line_regular(n)))
+    return {c: np.concatenate([t[c] for t in rows]) for c in COLS + ("reg",)}, S
 
 
 def sharded_rows_dev(L, raw, cuts, full_name=False):
@@ -49,8 +49,8 @@ def sharded_rows_dev(L, raw, cuts, full_name=False):
     rows = []
     for r, (b, n) in enumerate(blobs):
         b.fasta_stitch_dev(allS.data_ptr(), world, r, full_name)
-        rows.append(b.fasta_table(n))
-    return {c: np.concatenate([t[c] for t in rows]) for c in COLS}
+        rows.append(dict(b.fasta_table(n), reg=b.fasta_line_regular(n)))
+    return {c: np.concatenate([t[c] for t in rows]) for c in COLS + ("reg",)}
 
 
 def check(oracle, L, raw, cuts, full_name=False):
@@ -59,8 +59,10 @@ def check(oracle, L, raw, cuts, full_name=False):
     assert len(got["boff"]) == len(recs), (cuts, len(got["boff"]), len(recs))
     for c in COLS:
         np.testing.assert_array_equal(got[c], recs[c].astype(got[c].dtype), err_msg="%s cuts=%s" % (c, cuts))
+    from test_host_logic import _reg_of                     # line-regular: decided across the cuts from the summaries
+    np.testing.assert_array_equal(got["reg"], np.array([_reg_of(raw, r) for r in recs], dtype=np.int32), err_msg="reg cuts=%s" % (cuts,))
     dev = sharded_rows_dev(L, raw, cuts, full_name)
-    for c in COLS:
+    for c in COLS + ("reg",):
         np.testing.assert_array_equal(dev[c], got[c], err_msg="device stitch: %s cuts=%s" % (c, cuts))
 
 
@@ -304,11 +306,13 @@ def test_fetch_over_shards(oracle, L, seed):
     rng = np.random.default_rng(4200 + seed)
     raw = _rand_fasta(rng, 30, int(rng.integers(20, 90)), crlf=bool(seed & 1), ragged=False, trailing=(seed != 2), lower=True)
     raw += _rand_fasta(rng, 4, 50, crlf=bool(seed & 1), ragged=True, trailing=True)      # a few norm=0 records
+    from test_gpu_kernels import _odd_line_fasta
+    raw += _odd_line_fasta(rng, bool(seed & 1))                                           # norm=1 records with one odd line
     recs, _ = oracle.fasta_index(raw)
     G = (2, 4, 8, 16)[seed]
     cuts = sorted(set(int(x) for x in rng.integers(1, len(raw) - 1, G - 1)))
     got, _ = sharded_rows(L, raw, cuts)
-    table = {k: got[k] for k in ("boff", "blen", "slen", "llen", "elen", "norm")}
+    table = {k: got[k] for k in ("boff", "blen", "slen", "llen", "elen", "norm", "reg")}
     bases, ends = [0] + cuts, cuts + [len(raw)]
     blobs = {}
     for r in range(len(bases)):
@@ -338,3 +342,22 @@ def test_fetch_over_shards(oracle, L, seed):
         for j, qi in enumerate(qidx.tolist()):
             assert buf[offs[j]:offs[j + 1]].tobytes() == _expected_fetch(oracle, raw, recs, int(ids[qi]), int(st[qi]), int(sp[qi]), int(fl[qi]))
     assert (seen == 1).all()
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+def test_line_regular_across_cuts(oracle, L, crlf):
+    """Records with one odd line, a long last line, ragged lines: the line-regular bit of the record that crosses a cut
+    comes out of the summaries (k_stitch_tail / shard.stitch_tail) as the rule gives it on the whole stream -- for a
+    cut at every byte of the first records and random cuts over all of them."""
+    from test_gpu_kernels import _odd_line_fasta
+    rng = np.random.default_rng(31 + crlf)
+    raw = _odd_line_fasta(rng, crlf)
+    first = raw[:raw.index(b">o4 ")]
+    for c in range(1, len(first)):
+        check(oracle, L, first, [c])
+    for c in range(2, len(first) - 2, 5):
+        check(oracle, L, first, [c, c + 1])
+        check(oracle, L, first, [c - 1, c + 2])
+    for g in (2, 3, 7, 12):
+        for _ in range(6):
+            check(oracle, L, raw, sorted(set(int(x) for x in rng.integers(1, len(raw), g - 1))))

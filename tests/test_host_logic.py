@@ -101,9 +101,18 @@ def test_existing_index_is_loaded_without_gpu(oracle, tmp_path):
     assert fa[1][5:30].name == "JZ822578.1:6-30" and fa.count(200) > 0
 
 
+def _reg_of(raw, r):
+    """The line-regular bit of one oracle row: shard.line_regular_rule with the whole stream in view."""
+    from pyfastx_amd.shard import line_regular_rule
+    return int(bool(line_regular_rule(int(r["boff"]), int(r["blen"]), int(r["slen"]), int(r["llen"]), int(r["elen"]), int(r["norm"]),
+                                      lambda p: raw[p] if 0 <= p < len(raw) else None)))
+
+
 def _expect(oracle, raw, full_name=False):
     recs, _ = oracle.fasta_index(raw, full_name=full_name)
-    return {k: [int(x) for x in recs[k]] for k in ("hoff", "boff", "blen", "slen", "llen", "elen", "norm", "dlen", "name_len")}
+    out = {k: [int(x) for x in recs[k]] for k in ("hoff", "boff", "blen", "slen", "llen", "elen", "norm", "dlen", "name_len")}
+    out["reg"] = [_reg_of(raw, r) for r in recs]            # the stitched rows carry it too (decided from the summaries there)
+    return out
 
 
 def test_stitch_every_cut_of_every_edge_case(oracle):
@@ -130,8 +139,11 @@ def test_stitch_random(oracle, seed):
         parts.append(b">r%d d%d" % (i, i) + eol)
         w = int(rng.integers(1, 30))
         s = bytes(rng.choice(list(b"ACGTN"), int(rng.integers(0, 400))).astype(np.uint8))
-        for p in range(0, len(s), w):
+        odd = int(rng.integers(0, max(len(s) // w, 1))) if seed in (3, 6, 9) and i % 2 else -1     # ONE odd line somewhere: norm = 1, not regular
+        for j, p in enumerate(range(0, len(s), w)):
             ww = w if seed % 3 else int(rng.integers(1, w + 1))
+            if j == odd:
+                ww = max(w - 1, 1)
             parts.append(s[p:p + ww] + eol)
     raw = b"".join(parts)
     if seed == 7:
@@ -682,7 +694,7 @@ class _OracleShard:
     def __init__(self, oracle, raw, base, end):
         self.o, self.raw, self.base, self.end = oracle, raw[base:end], base, end
 
-    def fetch_ranges(self, off, blen, slen, flags=0, flags_per_query=None):
+    def fetch_ranges(self, off, blen, slen, flags=0, flags_per_query=None, skip=None):
         n = len(off)
         offs = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(np.maximum(slen, 0), out=offs[1:])
@@ -691,7 +703,12 @@ class _OracleShard:
         for i in range(n):
             lo, hi = max(int(off[i]), self.base), min(int(off[i] + blen[i]), self.end)
             fl = int(flags if flags_per_query is None else flags_per_query[i])
-            s = self.o.fetch(self.raw, lo - self.base, hi - lo, int(slen[i]), fl) if hi > lo else b""
+            sk = 0 if skip is None else int(skip[i])
+            if sk and hi > lo:                                # fx_fetch_slices: despace, drop `skip`, keep `slen`, then reverse
+                s = self.o.fetch(self.raw, lo - self.base, hi - lo, sk + int(slen[i]), fl & 5)[sk:]
+                s = s[::-1] if fl & 2 else s
+            else:
+                s = self.o.fetch(self.raw, lo - self.base, hi - lo, int(slen[i]), fl) if hi > lo else b""
             buf[offs[i]:offs[i] + len(s)] = np.frombuffer(s, dtype=np.uint8)
             ol[i] = len(s)
         return buf[:int(offs[-1])], offs, ol
@@ -709,7 +726,7 @@ def _shard_queries(rng, recs, nq):
 
 def _expected_fetch(oracle, raw, recs, i, a, b, fl):
     r = recs[i]
-    if r["norm"] and r["llen"] > r["elen"]:
+    if _reg_of(raw, r):
         off, bl = oracle.slice_range(int(r["boff"]), int(r["llen"]), int(r["elen"]), a, b)
         return oracle.fetch(raw, off, bl, b - a, fl)
     s = oracle.fetch(raw, r["boff"], r["blen"], r["slen"], fl & 5)[a:b]       # despace the record, slice, then reverse
@@ -731,11 +748,19 @@ def test_fetch_over_byte_range_shards(oracle, seed):
         s = bytes(rng.choice(list(b"ACGTNacgtn"), int(rng.integers(1, 4000))).astype(np.uint8))
         w = int(rng.integers(7, 80))
         ragged = i % 5 == 3
-        p = 0
+        odd_at = -1
+        if i % 5 == 1 and w > 2:                              # ONE odd line in the middle, every other line full: norm = 1, not line-regular
+            m = max(len(s) // w, 3)
+            s = (s * (m * w // len(s) + 2))[:m * w + (w - 2)]
+            odd_at = int(rng.integers(1, m))
+        p = j = 0
         while p < len(s):
             k = w if not ragged else int(rng.integers(1, w + 1))
+            if j == odd_at:
+                k = max(w - 2, 1)
             parts.append(s[p:p + k] + eol)
             p += k
+            j += 1
     raw = b"".join(parts)
     if seed == 4:
         raw = raw[:-len(eol)]
@@ -744,6 +769,8 @@ def test_fetch_over_byte_range_shards(oracle, seed):
     cuts = sorted(set(int(x) for x in rng.integers(1, len(raw) - 1, G - 1)))
     bases, ends = [0] + cuts, cuts + [len(raw)]
     table = {k: recs[k] for k in ("boff", "blen", "slen", "llen", "elen", "norm")}
+    table["reg"] = np.array([_reg_of(raw, r) for r in recs], dtype=np.int32)
+    assert ((table["reg"] == 0) & (recs["norm"] == 1) & (recs["slen"] > 0)).sum() >= 1       # the odd kind is in the mix
     ids, st, sp, fl = _shard_queries(rng, recs, 600)
     # make sure some queries cross each cut: a window around every cut that lies inside a sequence
     extra = []
@@ -785,22 +812,10 @@ def test_fetch_over_byte_range_shards(oracle, seed):
 
 
 def test_line_regular_rule(oracle):
-    """Sequence._line_regular (api.py): whenever it lets a norm=1 record through to the line arithmetic of
-    sequence.c:498-510, the arithmetic is right at EVERY position of the record -- brute force over random records with
-    odd lines anywhere, blank lines, CRLF and unterminated ends; and it does let the ordinary records through."""
-    from pyfastx_amd import api
-
-    class _St:
-        def __init__(self, text):
-            self.text = text
-            self.blob = type("B", (), {"size": len(text)})()
-
-        def raw(self, off, n):
-            return self.text[off:off + n]
-
-    class _Fa:
-        _uppercase = False
-
+    """shard.line_regular_rule (= csrc/fx_kernels.hpp line_regular, the column every fetch path goes by): whenever it
+    lets a norm=1 record through to the line arithmetic of sequence.c:498-510, the arithmetic is right at EVERY position
+    of the record -- brute force over random records with odd lines anywhere, blank lines, CRLF and unterminated ends;
+    and it does let the ordinary records through.  A record it turns away is sliced after despacing."""
     rng = np.random.default_rng(4)
     passed = odd = 0
     for it in range(1500):
@@ -817,22 +832,25 @@ def test_line_regular_rule(oracle):
         if it % 7 == 0 and text.endswith(eol):
             text = text[:-len(eol)]
         recs, _ = oracle.fasta_index(text)
-        fa = _Fa()
-        fa._st = _St(text)
         for k, r in enumerate(recs):
-            s = api.Sequence(fa, k + 1, "r", *(int(r[c]) for c in ("boff", "blen", "slen", "llen", "elen", "norm", "dlen")))
-            if not s._line_regular():
+            if not _reg_of(text, r):
                 odd += bool(r["norm"])
                 continue
             passed += 1
             n = int(r["slen"])
             full = oracle.fetch(text, r["boff"], r["blen"], r["slen"])
             for a in range(n):
-                off, bl = s._range(a, n)
+                off, bl = oracle.slice_range(int(r["boff"]), int(r["llen"]), int(r["elen"]), a, n)
                 assert oracle.fetch(text, off, bl, n - a, 0) == full[a:], (text, k, a)
-                off, bl = s._range(0, a + 1)
+                off, bl = oracle.slice_range(int(r["boff"]), int(r["llen"]), int(r["elen"]), 0, a + 1)
                 assert oracle.fetch(text, off, bl, a + 1, 0) == full[:a + 1], (text, k, a)
     assert passed > 3000 and odd > 1000
+    # well-formed records are regular: nothing ordinary takes the slow path
+    for text in (b">a\nACGT\nACGT\nAC\n", b">a\r\nACGT\r\nACGT\r\nAC\r\n", b">a\nACGT\nACGT\n", b">a\nACGT\nAC", b">a\nAC\n", b">a\nACGT\nACGT\nAC"):
+        recs, _ = oracle.fasta_index(text)
+        assert _reg_of(text, recs[0]) == 1, text
+    recs, _ = oracle.fasta_index(b">c\nAAAA\nCC\nGGGG\n")                     # the golden "one odd middle line" record: norm = 1
+    assert int(recs[0]["norm"]) == 1 and _reg_of(b">c\nAAAA\nCC\nGGGG\n", recs[0]) == 0
 
 
 def test_fastx_name_comment_rule(tmp_path):
@@ -871,6 +889,7 @@ def test_shard_fetcher_degenerate_batches(oracle):
     raw = b">a\nACGTACGT\nACGT\n>b\nTTTT\n>e\n>c\nGGGGCCCC\nGG"
     recs, _ = oracle.fasta_index(raw)
     table = {k: recs[k] for k in ("boff", "blen", "slen", "llen", "elen", "norm")}
+    table["reg"] = np.array([_reg_of(raw, r) for r in recs], dtype=np.int32)
     for cuts in ([], [1], [5, 6], [len(raw) - 1], list(range(3, len(raw) - 1, 7))):
         bases, ends = [0] + cuts, cuts + [len(raw)]
         f = shard.ShardFetcher({r: _OracleShard(oracle, raw, bases[r], ends[r]) for r in range(len(bases))}, bases, ends, table)
@@ -884,3 +903,33 @@ def test_shard_fetcher_degenerate_batches(oracle):
         assert sorted(q.tolist()) == list(range(7))
         for j, qi in enumerate(q.tolist()):
             assert buf[offs[j]:offs[j + 1]].tobytes() == _expected_fetch(oracle, raw, recs, int(ids[qi]), int(st[qi]), int(sp[qi]), int(fl[qi])), (cuts, qi)
+
+
+def test_names_are_stored_verbatim_by_every_writer(tmp_path):
+    """the INSERT writers bind the name bytes as they are in the file (CAST(? AS TEXT)), like sqlite3_bind_text
+    in the reference (index.c:239-251) and like the page loader -- a UTF-8 name does not turn into mojibake, invalid UTF-8
+    survives, and fxi.connect reads both back the way names_lookup encodes queries (utf-8 / surrogateescape)."""
+    from pyfastx_amd import fxi
+    names = ["é".encode("utf-8"), b"plain", b"\xff\xfebad", "日本".encode("utf-8")]
+    cols = {k: np.arange(4, dtype=np.int64) for k in ("boff", "blen", "slen", "llen", "elen", "norm", "dlen", "rlen", "soff", "qoff")}
+    for kind in ("fa", "fq", "fa_bulk"):
+        p = str(tmp_path / (kind + ".fxi"))
+        if kind == "fa":
+            db = fxi.connect(p); fxi.write_fasta(db, names, cols, 10)
+        elif kind == "fq":
+            db = fxi.connect(p); fxi.write_fastq(db, names, cols, 10)
+        else:
+            offs = np.zeros(5, dtype=np.int64); np.cumsum([len(x) for x in names], out=offs[1:])
+            db = fxi.write_fasta_bulk(p, np.frombuffer(b"".join(names), dtype=np.uint8), offs, cols, 10)
+        tab, col = ("read", "name") if kind == "fq" else ("seq", "chrom")
+        raw = [bytes(r[0]) for r in db.execute("SELECT CAST(%s AS BLOB) FROM %s ORDER BY ID" % (col, tab))]
+        assert raw == names, kind
+        assert [r[0] for r in db.execute("SELECT typeof(%s) FROM %s" % (col, tab))] == ["text"] * 4
+        back = [r[0] for r in db.execute("SELECT %s FROM %s ORDER BY ID" % (col, tab))]
+        assert back[0] == "é" and back[3] == "日本" and back[2].encode("utf-8", "surrogateescape") == names[2]
+        # by-name probe with a str key, as Fasta.__getitem__ does (SQLite compares the UTF-8 bytes)
+        assert db.execute("SELECT ID FROM %s WHERE %s=?" % (tab, col), ("é",)).fetchone() == (1,)
+        db.close()
+    # str names (key_func results) are encoded the same way
+    db = fxi.connect(str(tmp_path / "k.fxi")); fxi.write_fasta(db, ["é", "x"], {k: v[:2] for k, v in cols.items()}, 3)
+    assert bytes(db.execute("SELECT CAST(chrom AS BLOB) FROM seq WHERE ID=1").fetchone()[0]) == "é".encode("utf-8")
