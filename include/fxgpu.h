@@ -252,6 +252,26 @@ int fx_names_sort(fx_handle *h, int kind, int where, int64_t *order, int64_t *n_
  * name_off[n].  FX_ERANGE when total > cap (only *total is valid then; n * longest name is a safe cap).  Host buffers. */
 int fx_names_pack(fx_handle *h, int kind, uint8_t *dst, int64_t cap, int64_t *name_off, int64_t *total);
 
+/* ------------------------------------------------------------ statistics
+ * Fasta.count(n), nl(p), longest, shortest, mean, median (fasta.c:573-849) ask SQLite to scan or sort the seq table, one
+ * query each.  Here the lengths are already in HBM: one stable radix sort of (slen, id), a scan of the sorted lengths and
+ * one probe kernel answer all of them in a call.
+ *   longest_id / shortest_id: 0-based id of the FIRST record with the extreme length (SQLite's MAX()/MIN() keep the first
+ *   row they met: `SELECT ID,MAX(slen) FROM seq`, fasta.c:682, 715);
+ *   count_ge: records with slen >= count_min (`SELECT COUNT(*) FROM seq WHERE slen>=?`, fasta.c:586);
+ *   med_lo, med_hi: the sorted lengths at (n-1)/2 and, for an even n, the one after it (fasta.c:812-816);
+ *   nx_len, nx_count: N(p) / L(p) -- walking the lengths in descending order, the first length (and how many so far)
+ *   at which the running sum reaches `half`, a double = p / 100.0 * stat.seqlen compared as in fasta.c:630-647; 0, 0
+ *   when the sum never does.  Needs the record table (fx_fasta_build or fx_fasta_set_table). */
+typedef struct {
+    int64_t n_seq, sum_len;
+    int64_t longest_id, longest_len, shortest_id, shortest_len;
+    int64_t count_ge;
+    int64_t med_lo, med_hi;
+    int64_t nx_len, nx_count;
+} fx_len_stats;
+int fx_fasta_len_stats(fx_handle *h, int64_t count_min, double half, fx_len_stats *out);
+
 /* pyfastx.reverse_complement / reverse_seq / complement_seq on a caller buffer
  * (module.c:44-59; util.c:239-269).  mode: FX_REVERSE | FX_COMPLEMENT.        */
 int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mode);

@@ -31,6 +31,11 @@ class FastqSummary(C.Structure):
                 ("first_id", C.c_int64)]
 
 
+class LenStats(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("n_seq", "sum_len", "longest_id", "longest_len", "shortest_id", "shortest_len",
+                                         "count_ge", "med_lo", "med_hi", "nx_len", "nx_count")]
+
+
 class ShardSummary(C.Structure):
     _fields_ = [(k, C.c_int64) for k in (
         "base", "n_bytes", "is_last", "n_nl", "first_nl", "second_nl", "last_nl", "first_nl_prev",
@@ -42,7 +47,7 @@ class ShardSummary(C.Structure):
 SYMBOLS = [
     "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_host", "fx_open_device",
     "fx_set_shard", "fx_close", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
-    "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_line_regular", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
+    "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_line_regular", "fx_fasta_len_stats", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
     "fx_fasta_set_row", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
 ]
@@ -125,6 +130,7 @@ def lib():
     L.fx_fasta_table.argtypes = [vp, i32] + [vp] * 9
     L.fx_fasta_set_table.argtypes = [vp, i64] + [vp] * 6
     L.fx_fasta_line_regular.argtypes = [vp, i32, vp]
+    L.fx_fasta_len_stats.argtypes = [vp, i64, C.c_double, C.POINTER(LenStats)]
     L.fx_fasta_comp.argtypes = [vp, i32, vp]
     L.fx_fasta_comp_shard.argtypes = [vp, i32, vp, i64, vp]
     L.fx_fasta_comp_sparse.argtypes = [vp, i32, i64, vp, vp, vp, C.POINTER(i64), vp]
@@ -351,6 +357,12 @@ class Blob:
         check(lib().fx_fasta_table(self._h, FX_HOST, *[_ptr(cols[k]) for k in (
             "hoff", "boff", "blen", "slen", "llen", "elen", "norm", "dlen", "name_len")]))
         return cols
+
+    def fasta_len_stats(self, count_min=0, half=0.0):
+        """Statistics of the record lengths from the table in HBM (fx_fasta_len_stats) -> LenStats."""
+        st = LenStats()
+        check(lib().fx_fasta_len_stats(self._h, int(count_min), float(half), C.byref(st)))
+        return st
 
     def fasta_line_regular(self, n):
         """int32[n]: 1 where slices of the record may use the line arithmetic (fx_fasta_line_regular)."""

@@ -317,50 +317,101 @@ class Fasta:
         return FastaKeys(self, self._seq_counts)
 
     # ----------------------------------------------------------- statistics
-    # (SQL over the .fxi exactly as the reference does; fasta.c:573-849)
+    # fasta.c:573-849.  The reference sorts / scans the seq table in SQLite for each of them; here they come from ONE
+    # device sort of the lengths (fx_fasta_len_stats) whenever the record table is resident in HBM (an index
+    # built or used for batched fetches in this process) and from the same SQL otherwise (an index file opened for
+    # metadata only is not staged for a median).  The stat-table caching of the reference is kept, quirks included.
+    def _dev_stats(self, count_min=0, half=0.0):
+        b = self._st._blob
+        if b is None or not getattr(b, "_table_ready", False) or getattr(b, "_n_fasta", None) != self._seq_counts or not self._seq_counts:
+            return None
+        try:
+            return b.fasta_len_stats(count_min, half)
+        except _lib.FxError:
+            return None
+
     def count(self, n):
+        st = self._dev_stats(count_min=int(n))
+        if st is not None:
+            return int(st.count_ge)
         return int(self._db.execute("SELECT COUNT(*) FROM seq WHERE slen>=?", (int(n),)).fetchone()[0])
 
     def nl(self, p=50):
         if p < 0 or p > 100:
             raise ValueError("the value must between 0 and 100")
-        half, acc, i, j = p / 100.0 * self.size, 0, 0, 0
-        for (j,) in self._db.execute("SELECT slen FROM seq ORDER BY slen DESC"):
-            i += 1
-            acc += j
-            if acc >= half:
-                break
+        i = j = 0
+        if p == 50:                                            # fasta.c:609-625: the cached pair
+            row = self._db.execute("SELECT n50,l50 FROM stat LIMIT 1").fetchone()
+            if row is not None and row[0]:
+                j, i = int(row[0]), int(row[1] or 0)
+        if not j:
+            half = p / 100.0 * self.size                       # fasta.c:628
+            st = self._dev_stats(half=half)
+            if st is not None:
+                j, i = int(st.nx_len), int(st.nx_count)
+            else:
+                acc = 0
+                for (j,) in self._db.execute("SELECT slen FROM seq ORDER BY slen DESC"):
+                    i += 1
+                    acc += j
+                    if acc >= half:
+                        break
         if not j:
             raise RuntimeError("can not calculate N50 and L50")
-        return (int(j), i)
+        # fasta.c:651-659 stores the pair in n50 / l50 WHATEVER p was (so nl(90) followed by nl(50) answers nl(90)'s pair
+        # from the cache there): mirrored, the columns are part of the index file
+        self._db.execute("UPDATE stat SET n50=?, l50=?", (int(j), int(i)))
+        return (int(j), int(i))
 
     @property
     def longest(self):
+        st = self._dev_stats()
+        if st is not None:
+            return self[int(st.longest_id)]
         row = self._db.execute("SELECT ID,MAX(slen) FROM seq LIMIT 1").fetchone()
         return self[int(row[0]) - 1]
 
     @property
     def shortest(self):
+        st = self._dev_stats()
+        if st is not None:
+            return self[int(st.shortest_id)]
         row = self._db.execute("SELECT ID,MIN(slen) FROM seq LIMIT 1").fetchone()
         return self[int(row[0]) - 1]
 
     @property
     def mean(self):
-        m = float(self._db.execute("SELECT AVG(slen) FROM seq").fetchone()[0])
+        row = self._db.execute("SELECT avglen FROM stat LIMIT 1").fetchone()          # fasta.c:740-752
+        m = float(row[0]) if row is not None and row[0] else 0.0
+        if not m:
+            st = self._dev_stats()
+            if st is not None:
+                m = float(st.sum_len) / float(st.n_seq)         # AVG(): the double sum over the double count
+            else:
+                m = float(self._db.execute("SELECT AVG(slen) FROM seq").fetchone()[0] or 0.0)
         if not m:
             raise RuntimeError("could not calculate average length")        # fasta.c:770-782: a mean of 0 is an error there
+        self._db.execute("UPDATE stat SET avglen=?", (m,))
         return m
 
     @property
     def median(self):
-        n = self._seq_counts                                   # fasta.c:786-849
-        if n % 2 == 0:
-            sql = "SELECT AVG(slen) FROM (SELECT slen FROM seq ORDER BY slen LIMIT %d,2)" % ((n - 1) // 2)
-        else:
-            sql = "SELECT slen FROM seq ORDER BY slen LIMIT %d,1" % ((n - 1) // 2)
-        m = float(self._db.execute(sql).fetchone()[0])
+        row = self._db.execute("SELECT medlen FROM stat LIMIT 1").fetchone()          # fasta.c:792-804
+        m = float(row[0]) if row is not None and row[0] else 0.0
+        if not m:
+            n = self._seq_counts                               # fasta.c:806-825
+            st = self._dev_stats()
+            if st is not None:
+                m = (float(st.med_lo) + float(st.med_hi)) / 2.0 if n % 2 == 0 else float(st.med_lo)
+            else:
+                if n % 2 == 0:
+                    sql = "SELECT AVG(slen) FROM (SELECT slen FROM seq ORDER BY slen LIMIT %d,2)" % ((n - 1) // 2)
+                else:
+                    sql = "SELECT slen FROM seq ORDER BY slen LIMIT %d,1" % ((n - 1) // 2)
+                m = float(self._db.execute(sql).fetchone()[0] or 0.0)
         if not m:
             raise RuntimeError("could not calculate median length")         # fasta.c:827-839: so is a median of 0
+        self._db.execute("UPDATE stat SET medlen=?", (m,))
         return m
 
     @property

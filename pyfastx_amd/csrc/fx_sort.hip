@@ -263,4 +263,135 @@ int sort_names(const uint8_t *data, int64_t gbase, const int64_t *name_off, cons
     return 0;
 }
 
+// ------------------------------------------------------------------ statistics of the record lengths
+__global__ __launch_bounds__(SB) void k_len_init(const int64_t *__restrict__ slen, int64_t n, uint64_t *__restrict__ keys,
+                                                 uint32_t *__restrict__ vals, unsigned long long *__restrict__ mx) {
+    __shared__ unsigned long long blk;
+    if (threadIdx.x == 0) blk = 0;
+    __syncthreads();
+    unsigned long long m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * SB + threadIdx.x; i < n; i += (int64_t)gridDim.x * SB) {
+        const unsigned long long v = slen[i] > 0 ? (unsigned long long)slen[i] : 0ull;
+        keys[i] = v; vals[i] = (uint32_t)i;
+        m = v > m ? v : m;
+    }
+    if (m) atomicMax(&blk, m);
+    __syncthreads();
+    if (threadIdx.x == 0 && blk) atomicMax(mx, blk);
+}
+
+constexpr int LS_CHUNK = 2048;                            // sorted lengths per workgroup of the scan kernels (8 per thread)
+__global__ __launch_bounds__(SB) void k_len_chunk_sums(const uint64_t *__restrict__ a, int64_t n, unsigned long long *__restrict__ sums) {
+    __shared__ unsigned long long blk;
+    if (threadIdx.x == 0) blk = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * LS_CHUNK;
+    unsigned long long s = 0;
+    for (int k = threadIdx.x; k < LS_CHUNK; k += SB) if (base + k < n) s += a[base + k];
+    for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&blk, s);
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = blk;
+}
+// one workgroup: sums[0..nchunks) -> exclusive prefix in place, sums[nchunks] = total
+__global__ __launch_bounds__(SB) void k_len_chunk_bases(unsigned long long *__restrict__ sums, int64_t nchunks) {
+    __shared__ unsigned long long part[SB];
+    const int64_t per = (nchunks + SB - 1) / SB, a = threadIdx.x * per, b = a + per < nchunks ? a + per : nchunks;
+    unsigned long long s = 0;
+    for (int64_t j = a; j < b; ++j) s += sums[j];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+    for (int k = 0; k < SB; ++k) { if (k < (int)threadIdx.x) base += part[k]; tot += part[k]; }
+    for (int64_t j = a; j < b; ++j) { const unsigned long long v = sums[j]; sums[j] = base; base += v; }
+    __syncthreads();
+    if (threadIdx.x == 0) sums[nchunks] = tot;
+}
+// every question is a boundary in the sorted array: the thread that sits on it writes the answer
+__global__ __launch_bounds__(SB) void k_len_probe(const uint64_t *__restrict__ a, const uint32_t *__restrict__ idx, int64_t n,
+                                                  const unsigned long long *__restrict__ bases, int64_t nchunks, unsigned long long count_min,
+                                                  double half, LenStats *__restrict__ out) {
+    __shared__ unsigned long long wtot[SB / 64];
+    const int64_t base = (int64_t)blockIdx.x * LS_CHUNK;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long v[8], s = 0;                         // thread t owns elements base + 8t .. 8t+7
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int64_t i = base + 8 * threadIdx.x + k; v[k] = i < n ? a[i] : 0ull; s += v[k]; }
+    unsigned long long inc = s;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    unsigned long long excl = bases[blockIdx.x] + inc - s;  // sum of the sorted lengths before this thread's first element
+    for (int k = 0; k < w; ++k) excl += wtot[k];
+    const unsigned long long total = bases[nchunks];
+    const uint64_t amax = a[n - 1];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int64_t i = base + 8 * threadIdx.x + k;
+        if (i < n) {
+            const uint64_t prev = i ? (k ? v[k - 1] : a[i - 1]) : 0;
+            if (i == 0) { out->shortest_id = idx[0]; out->shortest_len = (long long)v[k]; out->n = n; out->sum = (long long)total; }
+            if (v[k] == amax && (i == 0 || prev != amax)) { out->longest_id = idx[i]; out->longest_len = (long long)amax; }
+            if (v[k] >= count_min && (i == 0 || prev < count_min)) out->count_ge = n - i;
+            if (i == (n - 1) / 2) { out->med_lo = (long long)v[k]; out->med_hi = (long long)((n % 2 == 0) ? a[i + 1] : v[k]); }
+            // descending walk: this element is number n - i; running sum with it = total - excl, without it = that - v
+            const unsigned long long with = total - excl, without = with - v[k];
+            if ((double)with >= half && (i == n - 1 || !((double)without >= half))) { out->nx_len = (long long)v[k]; out->nx_count = n - i; }
+        }
+        excl += v[k];
+    }
+}
+
+int len_stats(const int64_t *d_slen, int64_t n, int64_t count_min, double half, LenStats *host_out, hipStream_t s, const char **where) {
+    uint64_t *keys[2] = {nullptr, nullptr};
+    uint32_t *vals[2] = {nullptr, nullptr};
+    RadixScratch sc;
+    unsigned long long *d_max = nullptr, *d_sums = nullptr;
+    LenStats *d_out = nullptr;
+    auto cleanup = [&]() {
+        for (int k = 0; k < 2; ++k) { if (keys[k]) (void)hipFree(keys[k]); if (vals[k]) (void)hipFree(vals[k]); }
+        if (sc.hist) (void)hipFree(sc.hist);
+        if (sc.totals) (void)hipFree(sc.totals);
+        if (d_max) (void)hipFree(d_max);
+        if (d_sums) (void)hipFree(d_sums);
+        if (d_out) (void)hipFree(d_out);
+    };
+    *where = "";
+    memset(host_out, 0, sizeof *host_out);
+    if (n <= 0) return 0;
+    if (n >= 0xFFFFFFFFll) { *where = "too many records for the 32-bit sort index"; return (int)hipErrorInvalidValue; }
+    const size_t N = (size_t)n;
+    for (int k = 0; k < 2; ++k) {
+        SORTCHK(hipMalloc((void **)&keys[k], N * 8), "hipMalloc(sort keys)");
+        SORTCHK(hipMalloc((void **)&vals[k], N * 4), "hipMalloc(sort values)");
+    }
+    sc.nblk = (n + RS_TILE - 1) / RS_TILE;
+    const int64_t nchunks = (n + LS_CHUNK - 1) / LS_CHUNK;
+    SORTCHK(hipMalloc((void **)&sc.hist, (size_t)sc.nblk * 256 * 4), "hipMalloc(sort histograms)");
+    SORTCHK(hipMalloc((void **)&sc.totals, 256 * 4), "hipMalloc");
+    SORTCHK(hipMalloc((void **)&d_max, 8), "hipMalloc");
+    SORTCHK(hipMalloc((void **)&d_sums, (size_t)(nchunks + 1) * 8), "hipMalloc");
+    SORTCHK(hipMalloc((void **)&d_out, sizeof(LenStats)), "hipMalloc");
+    SORTCHK(hipMemsetAsync(d_max, 0, 8, s), "memset");
+    SORTCHK(hipMemsetAsync(d_out, 0, sizeof(LenStats), s), "memset");
+    const unsigned nb = (unsigned)((n + SB - 1) / SB);
+    hipLaunchKernelGGL(k_len_init, dim3(nb < 4096u ? nb : 4096u), dim3(SB), 0, s, d_slen, n, keys[0], vals[0], d_max);
+    unsigned long long mx = 0;
+    SORTCHK(hipMemcpyAsync(&mx, d_max, 8, hipMemcpyDeviceToHost, s), "memcpy");
+    SORTCHK(hipStreamSynchronize(s), "k_len_init");
+    int bits = 8;
+    while (bits < 64 && (mx >> bits)) bits += 8;
+    int cur = 0;
+    SORTCHK(radix_sort_pairs(keys, vals, cur, n, 0, bits, sc, s), "radix passes (lengths)");
+    hipLaunchKernelGGL(k_len_chunk_sums, dim3((unsigned)nchunks), dim3(SB), 0, s, keys[cur], n, d_sums);
+    hipLaunchKernelGGL(k_len_chunk_bases, dim3(1), dim3(SB), 0, s, d_sums, nchunks);
+    hipLaunchKernelGGL(k_len_probe, dim3((unsigned)nchunks), dim3(SB), 0, s, keys[cur], vals[cur], n, d_sums, nchunks,
+                       (unsigned long long)(count_min > 0 ? count_min : 0), half, d_out);
+    SORTCHK(hipGetLastError(), "length statistics kernels");
+    SORTCHK(hipMemcpyAsync(host_out, d_out, sizeof(LenStats), hipMemcpyDeviceToHost, s), "memcpy");
+    SORTCHK(hipStreamSynchronize(s), "length statistics");
+    cleanup();
+    return 0;
+}
+
 }  // namespace fx

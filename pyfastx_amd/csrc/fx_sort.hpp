@@ -13,4 +13,18 @@ namespace fx {
 int sort_names(const uint8_t *data, int64_t gbase, const int64_t *name_off, const int32_t *name_len, int64_t n,
                int64_t *d_order, int64_t *d_ndup, hipStream_t s, const char **where);
 
+// Statistics of the record lengths (fasta.c:573-849: count(n), nl(p), longest, shortest, mean, median --
+// the reference asks SQLite to sort / scan the seq table for each of them): ONE stable radix sort of (slen, id) on the
+// GPU, a scan of the sorted lengths and one probe kernel answer them all.  d_slen: n lengths (>= 0) in HBM.
+struct LenStats {
+    long long n, sum;
+    long long longest_id, longest_len;      // FIRST record with the maximum length (SQLite's MAX() keeps the first row it met)
+    long long shortest_id, shortest_len;    // first record with the minimum length
+    long long count_ge;                     // records with slen >= count_min
+    long long med_lo, med_hi;               // sorted[(n-1)/2], sorted[(n-1)/2 + 1] (= med_lo when n is odd): fasta.c:786-849
+    long long nx_len, nx_count;             // walking the lengths in descending order: the first (length, lengths so far)
+                                            // whose running sum >= half (a double, fasta.c:630-647); 0, 0 when none does
+};
+int len_stats(const int64_t *d_slen, int64_t n, int64_t count_min, double half, LenStats *host_out, hipStream_t s, const char **where);
+
 }  // namespace fx

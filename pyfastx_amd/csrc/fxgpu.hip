@@ -1545,6 +1545,19 @@ extern "C" int fx_names_sort(fx_handle *h, int kind, int where, int64_t *order, 
     return FX_OK;
 }
 
+extern "C" int fx_fasta_len_stats(fx_handle *h, int64_t count_min, double half, fx_len_stats *out) {
+    static_assert(sizeof(fx_len_stats) == sizeof(LenStats), "statistics layout");
+    if (!h || !out) return fail(FX_EINVAL, "null argument");
+    if (!h->fasta_built) return fail(FX_ESTATE, "the record table is not resident (fx_fasta_build / fx_fasta_set_table)");
+    int rc = use_device(h);
+    if (!rc) rc = finish_build(h);
+    if (rc) return rc;
+    const char *what = "";
+    const int e = len_stats(h->fa_slen.p, h->n_hdr, count_min, half, reinterpret_cast<LenStats *>(out), h->stream, &what);
+    if (e) return fail(e == (int)hipErrorOutOfMemory ? FX_ENOMEM : FX_EDEVICE, "length statistics, %s: %s", what, hipGetErrorString((hipError_t)e));
+    return FX_OK;
+}
+
 extern "C" int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mode) {
     if (!buf && n) return fail(FX_EINVAL, "null buffer");
     if (n <= 0) return FX_OK;

@@ -762,3 +762,39 @@ def test_slices_of_records_with_one_odd_line(oracle, L, crlf):
     np.testing.assert_array_equal(b2.fasta_line_regular(len(recs)), reg)
     buf2, offs2, ol2 = b2.fasta_fetch(ids, st, sp, flags_per_query=fl)
     assert buf2.tobytes() == b.fasta_fetch(ids, st, sp, flags_per_query=fl)[0].tobytes()
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 200, 4097, 300_000])
+def test_len_stats(L, n):
+    """fx_fasta_len_stats (one device sort of the lengths) against numpy with the reference's definitions
+    (fasta.c:573-849): count, first longest / shortest, the two middle lengths, N(p) / L(p) for several p."""
+    rng = np.random.default_rng(n)
+    for shape in range(3):
+        if shape == 0:
+            slen = rng.integers(0, 50, n)                      # many ties, zeros
+        elif shape == 1:
+            slen = np.exp(rng.uniform(0, np.log(3e8), n)).astype(np.int64)
+        else:
+            slen = np.full(n, 1234)
+        slen = slen.astype(np.int64)
+        b = L.Blob.from_bytes(b">x\nACGT\n")
+        z = np.zeros(n, dtype=np.int64)
+        b.fasta_set_table(z, z, slen, z + 5, (z + 1).astype(np.int32), (z + 1).astype(np.int32))
+        total = int(slen.sum())
+        srt = np.sort(slen)
+        for p in (0, 37, 50, 90, 100):
+            half = p / 100.0 * total
+            for cmin in (0, 25, int(srt[n // 2])):
+                st = b.fasta_len_stats(cmin, half)
+                assert (st.n_seq, st.sum_len) == (n, total)
+                assert st.count_ge == int((slen >= cmin).sum())
+                assert (st.longest_id, st.longest_len) == (int(np.argmax(slen)), int(slen.max()))
+                assert (st.shortest_id, st.shortest_len) == (int(np.argmin(slen)), int(slen.min()))
+                assert st.med_lo == int(srt[(n - 1) // 2]) and st.med_hi == int(srt[(n - 1) // 2 + (1 if n % 2 == 0 else 0)])
+                acc, want = 0, (0, 0)
+                desc = srt[::-1]
+                cs = np.cumsum(desc)
+                hit = np.nonzero(cs.astype(np.float64) >= half)[0]
+                if hit.size:
+                    want = (int(desc[hit[0]]), int(hit[0]) + 1)
+                assert (st.nx_len, st.nx_count) == want, (n, shape, p)
