@@ -67,6 +67,15 @@ int fx_device_count(void);
 
 /* Plain or gzip file -> pinned double buffers -> hipMemcpyAsync -> HBM. */
 int fx_open_file(const char *path, int device, fx_handle **out);
+/* What a file holds and how long its stream is once inflated -- kind 0: plain; 1: BGZF (*n_bytes = sum of the members'
+ * ISIZE, from a walk over their headers); 2: a single gzip stream (*n_bytes = -1: unknown without inflating it). */
+int fx_stream_size(const char *path, int64_t *n_bytes, int *kind);
+/* ONE byte-range shard of a file (whole-file scan semantics of index.c:230-372 across the cuts come from the
+ * stitch below): bytes [off, off + len + halo) of the uncompressed stream, clamped to its end, become the blob, and the
+ * shard context is taken from the file -- base = off, prev_byte = the byte before it, is_last, halo (fx_set_shard /
+ * fx_set_halo need not be called).  A plain file is read only in that range; of a BGZF file only the members that
+ * cover it are read, staged and inflated.  A single gzip stream cannot be entered in the middle: FX_EINVAL. */
+int fx_open_file_range(const char *path, int64_t off, int64_t len, int64_t halo, int device, fx_handle **out);
 /* Copy nbytes from host memory into HBM. */
 int fx_open_host(const void *data, int64_t nbytes, int device, fx_handle **out);
 /* Adopt (do not copy, do not free) a blob already in this GPU's HBM; 16-byte aligned. */

@@ -45,7 +45,7 @@ class ShardSummary(C.Structure):
 
 
 SYMBOLS = [
-    "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_host", "fx_open_device",
+    "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_stream_size", "fx_open_file_range", "fx_open_host", "fx_open_device",
     "fx_set_shard", "fx_close", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
     "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_line_regular", "fx_fasta_len_stats", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
@@ -114,6 +114,8 @@ def lib():
     L.fx_device_count.restype = i32
     L.fx_open_file.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
     L.fx_open_host.argtypes = [vp, i64, i32, C.POINTER(vp)]
+    L.fx_stream_size.argtypes = [C.c_char_p, C.POINTER(i64), C.POINTER(i32)]
+    L.fx_open_file_range.argtypes = [C.c_char_p, i64, i64, i64, i32, C.POINTER(vp)]
     L.fx_open_device.argtypes = [vp, i64, i32, C.POINTER(vp)]
     L.fx_set_shard.argtypes = [vp, i64, i32, i32]
     L.fx_close.argtypes = [vp]
@@ -175,6 +177,13 @@ def lib():
     return L
 
 
+def stream_size(path):
+    """-> (bytes of the uncompressed stream or -1, kind): kind 0 plain, 1 BGZF, 2 single-stream gzip (fx_stream_size)."""
+    n, k = C.c_int64(0), C.c_int(0)
+    check(lib().fx_stream_size(os.fsencode(path), C.byref(n), C.byref(k)))
+    return int(n.value), int(k.value)
+
+
 def check(rc):
     if rc != 0:
         raise FxError(rc, lib().fx_last_error().decode("utf-8", "replace"))
@@ -196,6 +205,16 @@ class Blob:
         h = C.c_void_p()
         check(lib().fx_open_file(os.fsencode(path), device, C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def from_file_range(cls, path, off, length, halo=0, device=0):
+        """One byte-range shard of a file: bytes [off, off + length + halo) of the uncompressed stream (fx_open_file_range);
+        the shard context (base, previous byte, is_last, halo) comes from the file."""
+        h = C.c_void_p()
+        check(lib().fx_open_file_range(os.fsencode(path), int(off), int(length), int(halo), device, C.byref(h)))
+        b = cls(h)
+        b.base = int(off)
+        return b
 
     @classmethod
     def from_bytes(cls, data, device=0):

@@ -95,6 +95,30 @@ class _Staged:
         return self.blob.fetch_one(off, blen, slen, flags=flags)
 
 
+class _ShardedStaged(_Staged):
+    """The stream spread over several devices by byte range (multi.MultiDevice): built lazily like _Staged.blob; `.blob`
+    is the ShardedBlob adapter, `.md` the sharded build itself (merged table, fetcher, composition)."""
+
+    def __init__(self, path, devices, full_name):
+        super().__init__(path, devices[0])
+        self.devices, self.full_name, self._md = list(devices), full_name, None
+
+    @property
+    def md(self):
+        if self._md is None:
+            from .multi import MultiDevice
+            try:
+                self._md = MultiDevice(self.path, self.devices, self.full_name)
+            except _lib.FxError as e:
+                raise _fx_to_py(e)
+            self._blob = self._md.blob
+        return self._md
+
+    @property
+    def blob(self):
+        return self.md.blob
+
+
 # =========================================================================== FASTA
 def _bulk_index(path, blob, kind, n, name_off, name_len, write):
     """The bulk route to a NEW .fxi (fxi._bulk_table): the names come off the GPU as one packed buffer (one gather),
@@ -118,7 +142,10 @@ class Fasta:
     """pyfastx.Fasta (fasta.c:39-135, 1156-1210)."""
 
     def __init__(self, file_name, index_file=None, uppercase=False, build_index=True, full_index=False,
-                 full_name=False, memory_index=False, key_func=None, device=0):
+                 full_name=False, memory_index=False, key_func=None, device=0, devices=None):
+        """devices: several GPUs for ONE file (extension): the stream is cut into len(devices) byte ranges,
+        each device stages and scans only its own, the boundary summaries stitch the records that cross the cuts and ONE
+        index file is written; batched fetches are answered by the device that holds the bytes.  Plain and BGZF files."""
         if key_func is not None and not callable(key_func):
             raise TypeError("key_func must be a callable function")                       # fasta.c:71-74
         if not os.path.isfile(file_name):
@@ -127,7 +154,13 @@ class Fasta:
         self._uppercase, self._full_name, self._key_func = bool(uppercase), bool(full_name), key_func
         self._has_index = bool(build_index)
         self.is_gzip = _is_gzip(file_name)
-        self._st = _Staged(file_name, device)
+        self._sharded = devices is not None and len(devices) > 1
+        if self._sharded:
+            if key_func is not None or not build_index:
+                raise ValueError("devices=[...] builds a plain index: no key_func, build_index must stay on")
+            self._st = _ShardedStaged(file_name, devices, bool(full_name))
+        else:
+            self._st = _Staged(file_name, devices[0] if devices else device)
         self._index_file = ":memory:" if memory_index else (index_file or file_name + ".fxi")   # index.c:45-61
         self._db = None
         self._full_index = False
@@ -159,6 +192,15 @@ class Fasta:
 
     def _create_index(self):
         """pyfastx_create_index (index.c:109-388) with the scan on the GPU."""
+        if self._sharded:                                     # byte-range shards over several devices, ONE index file
+            from .shard import write_merged_index
+            md = self._st.md
+            self._scanned_here = False
+            self._db = write_merged_index(self._index_file, md.table)
+            if self.is_gzip:
+                c, u, _ = md.blobs[0].gz_points()
+                fxi.write_gzindex(self._db, os.path.getsize(self.file_name), md.size, c, u)
+            return
         blob = self._st.blob
         try:
             s = blob.fasta_build(self._full_name)
@@ -197,6 +239,10 @@ class Fasta:
         if self._full_index:
             return
         if self._db.execute("SELECT * FROM comp LIMIT 1").fetchone() is not None:
+            self._full_index = True
+            return
+        if self._sharded:
+            fxi.write_fasta_comp(self._db, self._st.md.composition())
             self._full_index = True
             return
         blob = self._st.blob
@@ -323,7 +369,8 @@ class Fasta:
     # metadata only is not staged for a median).  The stat-table caching of the reference is kept, quirks included.
     def _dev_stats(self, count_min=0, half=0.0):
         b = self._st._blob
-        if b is None or not getattr(b, "_table_ready", False) or getattr(b, "_n_fasta", None) != self._seq_counts or not self._seq_counts:
+        if b is None or not getattr(b, "_table_ready", False) or getattr(b, "_n_fasta", None) != self._seq_counts or not self._seq_counts \
+                or not hasattr(b, "fasta_len_stats"):
             return None
         try:
             return b.fasta_len_stats(count_min, half)
@@ -562,12 +609,51 @@ class Fasta:
             neg = np.array([s in ("-", 1, True) for s in strand], dtype=bool) if not isinstance(strand, np.ndarray) \
                 else (strand != 0) & (strand != ord("+"))
             fpq = np.where(neg, fl | _F_REV | _F_COMP, fl).astype(np.uint8)
+        if self._sharded:                                   # routed to the devices that hold the bytes (shard.ShardFetcher)
+            qidx, sbuf, soffs = self._st.md.fetcher().fetch(ids, starts, stops, flags=fl, flags_per_query=fpq)
+            offs = np.zeros(ids.size + 1, dtype=np.int64)
+            np.cumsum(stops - starts, out=offs[1:])
+            buf = np.zeros(max(int(offs[-1]), 1), dtype=np.uint8)
+            ln = soffs[1:] - soffs[:-1]
+            if sbuf.size:
+                buf[np.repeat(offs[qidx] - soffs[:-1], ln) + np.arange(int(soffs[-1]), dtype=np.int64)] = sbuf[:int(soffs[-1])]
+            return buf[:int(offs[-1])], offs
         blob = self._st.blob
         if not getattr(blob, "_table_ready", False):       # index loaded from an existing .fxi: install its rows once
             blob.fasta_set_table(t["boff"], t["blen"], t["slen"], t["llen"], t["elen"], t["norm"])
         # (record id, start, stop) resolved on the GPU with the sequence.c:498-510 arithmetic (line-regular
         # records) or despace-then-slice (sequence.c:100-110)
         buf, offs, ol = blob.fasta_fetch(ids, starts, stops, flags=fl, flags_per_query=fpq)
+        return buf, offs
+
+
+    def _ids_of(self, names_or_ids):
+        """Sequence names or 0-based ids -> int64 ids (KeyError / IndexError as the subscript raises them)."""
+        first = names_or_ids[0] if len(names_or_ids) else 0
+        if isinstance(first, str):
+            ix = self._table()["index"]
+            try:
+                return np.fromiter((ix[k] for k in names_or_ids), dtype=np.int64, count=len(names_or_ids))
+            except KeyError as e:
+                raise KeyError("%s does not exist in fasta file" % e.args[0])
+        ids = np.asarray(names_or_ids, dtype=np.int64)
+        if ids.size and (ids.min() < 0 or ids.max() >= self._seq_counts):
+            raise IndexError("index out of range")
+        return ids
+
+    def raw_many(self, names_or_ids):
+        """Batched `Sequence.raw` (sequence.c:314-335) -- whole records as they are in the file, header line included:
+        ONE gather for all of them instead of one read per record (what `pyfastx extract` / `sample` write,
+        pyfastxcli.py:282-387).  -> (uint8 buffer, int64 offsets[n+1])."""
+        self._need_index()
+        ids = self._ids_of(names_or_ids)
+        if getattr(self, "_raw_cols", None) is None:
+            rows = self._db.execute("SELECT boff,blen,elen,dlen FROM seq ORDER BY ID").fetchall()
+            a = np.array(rows, dtype=np.int64).reshape(-1, 4)
+            self._raw_cols = (a[:, 0] - a[:, 3] - a[:, 2] - 1, a[:, 1] + a[:, 3] + a[:, 2] + 1)
+        off, ln = self._raw_cols[0][ids], self._raw_cols[1][ids]
+        ln = np.minimum(ln, self._st.blob.size - off)          # blen counts a newline an unterminated file lacks
+        buf, offs, _ = self._st.blob.fetch_ranges(off, ln, ln, flags=_F_RAW)
         return buf, offs
 
 
@@ -1156,7 +1242,8 @@ class Fastq:
         blob = self._st.blob
         if not getattr(self, "_dev_table", False):
             s = blob.fastq_build()
-            self._rlen_host = blob.fastq_table(s.n_reads)["rlen"]
+            self._tab_host = blob.fastq_table(s.n_reads)       # host copy of the read table: what batches index into
+            self._rlen_host = self._tab_host["rlen"]
             self._dev_table = True
         return blob
 
@@ -1173,6 +1260,35 @@ class Fastq:
                 raise IndexError("index out of range")
         seq, qual, qi, offs = blob.fastq_fetch(ids, self._rlen_host[ids], phred=self._phred, want=want)
         return {"seq": seq, "qual": qual, "quali": qi, "offsets": offs}
+
+
+    def raw_many(self, ids_or_names):
+        """Batched `Read.raw` (read.c:124-150): whole four-line records, one gather for all of them.
+        -> (uint8 buffer, int64 offsets[n+1])."""
+        blob = self._dev()
+        if len(ids_or_names) and isinstance(ids_or_names[0], str):
+            ids = self.ids_of(ids_or_names)
+            if (ids < 0).any():
+                raise KeyError("%s does not exist in fastq file" % ids_or_names[int(np.nonzero(ids < 0)[0][0])])
+        else:
+            ids = np.asarray(ids_or_names, dtype=np.int64)
+            if ids.size and (ids.min() < 0 or ids.max() >= self._rlen_host.size):
+                raise IndexError("index out of range")
+        t = self._tab_host
+        off = t["soff"][ids] - t["dlen"][ids] - 1
+        n = t["qoff"][ids] + t["rlen"][ids] - off + 2          # read.c:131: two bytes past the quality line
+        buf, offs, _ = blob.fetch_ranges(off, n, n, flags=_F_RAW)      # bytes past the end of the stream come back as 0
+        # read.c:138-147: the record ends at its newline -- "\n" right after the quality line, or "\r\n"; neither: the
+        # file ends without one
+        end = offs[1:]
+        b2, b1 = buf[end - 2], buf[end - 1]
+        keep = np.where(b2 == 10, n - 1, np.where((b2 == 13) & (b1 == 10), n, n - 2))
+        if (keep == n).all():
+            return buf, offs
+        out_offs = np.zeros(len(ids) + 1, dtype=np.int64)
+        np.cumsum(keep, out=out_offs[1:])
+        sel = np.repeat(offs[:-1] - out_offs[:-1], keep) + np.arange(int(out_offs[-1]), dtype=np.int64)
+        return buf[sel], out_offs
 
 
 class Read:

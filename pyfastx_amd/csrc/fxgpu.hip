@@ -131,6 +131,7 @@ struct fx_handle {
     hipStream_t stream = nullptr;
     // resident stream
     uint8_t *d_data = nullptr;
+    uint8_t *d_alloc = nullptr;               // what is freed when owns (d_data points into it for a BGZF byte range)
     bool owns = false;
     int64_t n = 0;
     bool gz = false;
@@ -220,7 +221,7 @@ extern "C" int fx_close(fx_handle *h) {
     if (!h) return FX_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->owns && h->d_data) (void)hipFree(h->d_data);
+    if (h->owns && (h->d_alloc || h->d_data)) (void)hipFree(h->d_alloc ? h->d_alloc : h->d_data);
     if (h->pin_tot) (void)hipHostFree(h->pin_tot);
     if (h->one_box) (void)hipHostFree(h->one_box);
     if (h->one_out) (void)hipHostFree(h->one_out);
@@ -295,7 +296,7 @@ struct PinPool {
 };
 static PinPool g_pins;
 
-static int stage_plain_file(fx_handle *h, int fd, int64_t n, const char *path, uint8_t *d_dst) {
+static int stage_plain_file(fx_handle *h, int fd, int64_t n, const char *path, uint8_t *d_dst, int64_t file_off = 0) {
     const int T = (int)std::min<int64_t>(stage_threads(), std::max<int64_t>(1, (n + PIECE_BYTES - 1) / PIECE_BYTES));
     std::atomic<int> err(0);                 // 1: read error, 2: device error
     std::vector<std::thread> th;
@@ -316,7 +317,7 @@ static int stage_plain_file(fx_handle *h, int fd, int64_t n, const char *path, u
                 if (used[slot] && hipEventSynchronize(ev[slot]) != hipSuccess) { err.store(2); break; }
                 int64_t done = 0;
                 while (done < len) {
-                    const ssize_t r = pread(fd, pin[slot] + done, (size_t)(len - done), (off_t)(off + done));
+                    const ssize_t r = pread(fd, pin[slot] + done, (size_t)(len - done), (off_t)(file_off + off + done));
                     if (r <= 0) { err.store(1); break; }
                     done += r;
                 }
@@ -430,15 +431,27 @@ template <class T> static int upload(fx_handle *h, DevBuf<T> &d, const std::vect
     return FX_OK;
 }
 
-// compressed bytes (file -> pinned pieces -> HBM, stage_plain_file) -> k_bgzf_inflate -> resident blob
-static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize, const BgzfTable &t, const char *path) {
+// compressed bytes (file -> pinned pieces -> HBM, stage_plain_file) -> k_bgzf_inflate -> resident blob.
+// [m0, m1): the members to inflate (all of them for a whole file; the ones that cover a byte range of the inflated
+// stream for fx_open_file_range -- only their compressed bytes are read and staged).
+static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable &full, const char *path, int64_t m0 = 0, int64_t m1 = -1) {
+    if (m1 < 0) m1 = (int64_t)full.moff.size();
+    BgzfTable t;                                           // the range, offsets relative to its first member
+    const int64_t c0 = full.moff[(size_t)m0], u0 = full.uoff[(size_t)m0];
+    const int64_t c1 = m1 < (int64_t)full.moff.size() ? full.moff[(size_t)m1] : fsize_all;
+    for (int64_t m = m0; m < m1; ++m) {
+        t.moff.push_back(full.moff[(size_t)m]); t.coff.push_back(full.coff[(size_t)m] - c0); t.uoff.push_back(full.uoff[(size_t)m] - u0);
+        t.clen.push_back(full.clen[(size_t)m]); t.isize.push_back(full.isize[(size_t)m]);
+        t.total += full.isize[(size_t)m];
+    }
+    const int64_t fsize = c1 - c0;
     DevBuf<uint8_t> d_c;
     DevBuf<int64_t> d_coff, d_uoff;
     DevBuf<int32_t> d_clen, d_isize, d_status;
     int rc;
     if ((rc = d_c.alloc(fsize + 40))) return rc;          // the bit reader looks two 8-byte words ahead
     HIPCHK(hipMemsetAsync(d_c.p + fsize, 0, 40, h->stream));
-    if ((rc = stage_plain_file(h, fd, fsize, path, d_c.p))) return rc;
+    if ((rc = stage_plain_file(h, fd, fsize, path, d_c.p, c0))) return rc;
     if ((rc = upload(h, d_coff, t.coff)) || (rc = upload(h, d_uoff, t.uoff)) || (rc = upload(h, d_clen, t.clen)) ||
         (rc = upload(h, d_isize, t.isize)))
         return rc;
@@ -467,7 +480,7 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize, const BgzfTable &t,
             return fail(FX_EIO, "BGZF member %lld of %s (offset %lld) failed to inflate: code %d", (long long)m, path,
                         (long long)t.moff[m], status[m]);
     h->bgzf = true;
-    h->gz_moff = t.moff; h->gz_uoff = t.uoff; h->gz_csize = fsize;
+    h->gz_moff = full.moff; h->gz_uoff = full.uoff; h->gz_csize = fsize_all;
     return FX_OK;
 }
 
@@ -563,6 +576,104 @@ extern "C" int fx_open_file(const char *path, int device, fx_handle **out) {
     hipError_t e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return bail(fail(FX_EDEVICE, "stream sync: %s", hipGetErrorString(e)));
     close(fd);
+    *out = h;
+    return FX_OK;
+}
+
+// What kind of stream a file holds and how long it is once inflated: 0 plain, 1 BGZF (sum of the members' ISIZE from
+// a walk over their headers -- no inflation), 2 single-stream gzip (length unknown without inflating it: -1).
+extern "C" int fx_stream_size(const char *path, int64_t *n_bytes, int *kind) {
+    if (!path || !n_bytes || !kind) return fail(FX_EINVAL, "null argument");
+    struct stat st;
+    if (stat(path, &st) != 0 || !S_ISREG(st.st_mode)) return fail(FX_ENOENT, "the input file %s does not exists", path);
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(FX_ENOENT, "cannot open %s", path);
+    unsigned char magic[4] = {0, 0, 0, 0};
+    const bool gz = pread(fd, magic, 4, 0) == 4 && magic[0] == 0x1f && magic[1] == 0x8b && magic[2] == 0x08;
+    *kind = 0; *n_bytes = (int64_t)st.st_size;
+    if (gz) {
+        *kind = 2; *n_bytes = -1;
+        void *mp = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (mp != MAP_FAILED) {
+            BgzfTable tab;
+            if (parse_bgzf((const uint8_t *)mp, (int64_t)st.st_size, tab)) { *kind = 1; *n_bytes = tab.total; }
+            (void)munmap(mp, (size_t)st.st_size);
+        }
+    }
+    close(fd);
+    return FX_OK;
+}
+
+// One byte-range shard of a file ("each GPU ingests only its own range from the host"): bytes
+// [off, off + len + halo) of the UNCOMPRESSED stream, clamped to its end, become the handle's blob, and the shard
+// context is set from the file itself (base = off, prev_byte = the byte before it, is_last, halo).  Plain files: only
+// that range is read.  BGZF: only the members that cover it are read, staged and inflated.  Single-stream gzip cannot
+// be entered in the middle (FX_EINVAL unless the range starts at 0 and covers everything: "replicas only").
+extern "C" int fx_open_file_range(const char *path, int64_t off, int64_t len, int64_t halo, int device, fx_handle **out) {
+    if (!path || !out || off < 0 || len < 0 || halo < 0) return fail(FX_EINVAL, "bad argument");
+    int64_t total = 0;
+    int kind = 0;
+    int rc = fx_stream_size(path, &total, &kind);
+    if (rc) return rc;
+    if (kind == 2) return fail(FX_EINVAL, "%s is a single gzip stream: it cannot be opened by byte range (bgzip it, or open it whole)", path);
+    if (off > total) return fail(FX_ERANGE, "range starts past the end of the stream (%lld > %lld)", (long long)off, (long long)total);
+    const int64_t core = std::min(len, total - off);
+    const int64_t n = std::min(len + halo, total - off);    // bytes held
+    if (n <= 0) return fail(FX_EFORMAT, "empty range");
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(FX_ENOENT, "cannot open %s", path);
+    fx_handle *h = nullptr;
+    rc = new_handle(device, &h);
+    if (rc) { close(fd); return rc; }
+    auto bail = [&](int code) { close(fd); fx_close(h); return code; };
+    int prev = '\n';
+    if (kind == 0) {
+        if ((rc = alloc_blob(h, n))) return bail(rc);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(fail(FX_EDEVICE, "stream sync failed"));
+        if ((rc = stage_plain_file(h, fd, n, path, h->d_data, off))) return bail(rc);
+        unsigned char c = '\n';
+        if (off > 0 && pread(fd, &c, 1, (off_t)(off - 1)) != 1) return bail(fail(FX_EIO, "read error on %s", path));
+        prev = c;
+    } else {
+        struct stat st;
+        if (fstat(fd, &st) != 0) return bail(fail(FX_EIO, "stat failed"));
+        void *mp = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (mp == MAP_FAILED) return bail(fail(FX_EIO, "cannot map %s", path));
+        BgzfTable tab;
+        const bool okb = parse_bgzf((const uint8_t *)mp, (int64_t)st.st_size, tab);
+        (void)munmap(mp, (size_t)st.st_size);
+        if (!okb) return bail(fail(FX_EFORMAT, "%s is not BGZF", path));
+        // members that cover [off - 1, off + n): the byte before the range comes along (prev_byte) when there is one
+        const int64_t lo = off > 0 ? off - 1 : 0;
+        int64_t m0 = (int64_t)(std::upper_bound(tab.uoff.begin(), tab.uoff.end(), lo) - tab.uoff.begin()) - 1;
+        int64_t m1 = (int64_t)(std::lower_bound(tab.uoff.begin(), tab.uoff.end(), off + n) - tab.uoff.begin());
+        if (m0 < 0) m0 = 0;
+        if (m1 <= m0) m1 = m0 + 1;
+        if ((rc = bgzf_to_blob(h, fd, (int64_t)st.st_size, tab, path, m0, m1))) return bail(rc);
+        const int64_t skip = off - tab.uoff[(size_t)m0];   // the blob starts `skip` bytes into the first member inflated
+        h->d_alloc = h->d_data;
+        if (off > 0) {
+            unsigned char c = '\n';
+            if (hipMemcpy(&c, h->d_data + skip - 1, 1, hipMemcpyDeviceToHost) != hipSuccess) return bail(fail(FX_EDEVICE, "D2H failed"));
+            prev = c;
+        }
+        if (skip & 15) {                                   // kernels load 16-byte chunks from the blob's start: keep it aligned --
+            uint8_t *tmp = nullptr;                        // the range moves to the front of the allocation (through a copy: the spans overlap)
+            if (hipMalloc((void **)&tmp, (size_t)n) != hipSuccess) return bail(fail(FX_ENOMEM, "hipMalloc(%lld B) failed", (long long)n));
+            hipError_t e = hipMemcpy(tmp, h->d_data + skip, (size_t)n, hipMemcpyDeviceToDevice);
+            if (e == hipSuccess) e = hipMemcpy(h->d_data, tmp, (size_t)n, hipMemcpyDeviceToDevice);
+            if (e == hipSuccess && h->n > n) e = hipMemset(h->d_data + n, 0, (size_t)std::min<int64_t>(h->n - n, 2 * TILE));
+            (void)hipFree(tmp);
+            if (e != hipSuccess) return bail(fail(FX_EDEVICE, "device copy failed: %s", hipGetErrorString(e)));
+        } else h->d_data += skip;
+        h->n = n;
+        h->gz = true;
+    }
+    close(fd);
+    h->gz = kind != 0;
+    if ((rc = fx_set_shard(h, off, prev, off + core >= total))) { fx_close(h); return rc; }
+    if (n > core && (rc = fx_set_halo(h, n - core))) { fx_close(h); return rc; }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { fx_close(h); return fail(FX_EDEVICE, "stream sync failed"); }
     *out = h;
     return FX_OK;
 }

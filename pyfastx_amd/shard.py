@@ -255,10 +255,41 @@ class ShardedFasta:
         torch.cuda.synchronize()
         self.blob = _lib.Blob.from_device(self.buf.data_ptr(), self.n_bytes, device=dev.index, keepalive=self.buf)
         self.blob.set_shard(self.base, prev, last)
+        self._init_state()
+
+    def _init_state(self):
         self.summary = None
         self.S = None
         self.n_local = 0
         self._ext = self._mine = self._all = None
+        self.force_collective = getattr(self, "force_collective", False)
+
+    @classmethod
+    def from_file(cls, path, dev, rank, world, full_name=False, force_collective=False):
+        """This rank's byte range of a FILE ("each GPU ingests only its own range from the host"): the
+        uncompressed stream is cut into `world` equal ranges, rank r reads (plain) or reads-and-inflates (BGZF) only
+        [size * r / world, size * (r + 1) / world) -- fx_open_file_range -- and nothing moves between GPUs.
+        force_collective: run the all-gather + device stitch even with world == 1 (exercises the RCCL path on one GPU)."""
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        size, kind = _lib.stream_size(path)
+        if kind == 2:
+            raise ValueError("%s is a single gzip stream: it does not shard by byte range (replicas only)" % path)
+        lo, hi = size * rank // world, size * (rank + 1) // world
+        self = cls.__new__(cls)
+        self.rank, self.world, self.dev, self.full_name = rank, world, dev, full_name
+        self._torch, self._dist = torch, dist
+        self.comm_dev = dev
+        if world > 1 or force_collective:
+            self.comm_dev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        self.path, self.stream_bytes = path, size
+        self.buf = None
+        self.base, self.n_bytes = lo, hi - lo
+        self.blob = _lib.Blob.from_file_range(path, lo, hi - lo, 0, device=dev.index)
+        self.force_collective = bool(force_collective)
+        self._init_state()
+        return self
 
     def _dev_buffers(self):
         torch = self._torch
@@ -270,23 +301,23 @@ class ShardedFasta:
     def build_begin(self):
         """Enqueue: local scan + tables (+ this shard's boundary summary into the send buffer).  No host sync."""
         self.blob.fasta_build_begin(self.full_name)
-        if self.world > 1:
+        if self.world > 1 or self.force_collective:
             self._dev_buffers()
             self.blob.shard_summary_dev(self._mine.data_ptr())
 
     def build_end(self):
         """Enqueue, after self._all holds every shard's summary: finish the record that crosses the cut."""
-        if self.world > 1:
+        if self.world > 1 or self.force_collective:
             self.blob.fasta_stitch_dev(self._all.data_ptr(), self.world, self.rank, self.full_name)
 
     def build_async(self):
         """The whole sharded build enqueued on the device -- scan, summary kernel, RCCL all-gather, stitch kernel,
         ordered with stream events only -- so that device-side consumers (fetch_local) can follow without a host
         round trip; finish() is the one synchronisation.  (gloo, i.e. the CPU tests: the host path, synchronous.)"""
-        if self.world > 1 and self.comm_dev.type != "cuda":
+        if (self.world > 1 or self.force_collective) and self.comm_dev.type != "cuda":
             return self.build()
         self.build_begin()
-        if self.world > 1:
+        if self.world > 1 or self.force_collective:
             cur = self._torch.cuda.current_stream(self.dev)
             cur.wait_stream(self._ext)
             self._dist.all_gather_into_tensor(self._all, self._mine)          # the ONE collective (RCCL over xGMI)
@@ -299,7 +330,7 @@ class ShardedFasta:
         return s
 
     def build(self):
-        if self.world == 1 or self.comm_dev.type == "cuda":
+        if (self.world == 1 and not self.force_collective) or self.comm_dev.type == "cuda":
             self.build_async()
             return self.finish()
         s = self.blob.fasta_build(self.full_name)
@@ -309,6 +340,29 @@ class ShardedFasta:
         if row is not None:
             self.blob.fasta_set_row(self.n_local - 1, **row)
         return s
+
+    def gather_index(self):
+        """Every rank's rows and names on every rank (all_gather_object: setup, not the data path) -> the table of the
+        WHOLE file in file order: dict of numpy columns + `names` (list of bytes), `seq_len`, `bases`, `ends`.  What rank 0
+        writes into the one .fxi (write_index) and what ShardFetcher routes by."""
+        part = local_index_part(self.blob, self.n_local, self.base, self.n_bytes)
+        if self.world == 1:
+            outs = [part]
+        else:
+            outs = [None] * self.world
+            self._dist.all_gather_object(outs, part)
+        return merge_index_parts(outs)
+
+    def write_index(self, index_file, table=None):
+        """ONE .fxi for the whole file from the gathered table (rank 0 writes; the other ranks return after the gather):
+        the same schema and rows a single-GPU build of the file writes."""
+        from . import fxi
+        table = self.gather_index() if table is None else table
+        if self.rank == 0:
+            write_merged_index(index_file, table)
+        if self.world > 1:
+            self._dist.barrier()
+        return table
 
     def fetch_local(self, n, d_ids, d_st, d_sp, d_fl, d_out, d_off, d_len):
         self.blob.fasta_fetch_dev(n, d_ids.data_ptr(), d_st.data_ptr(), d_sp.data_ptr(), d_out.data_ptr(),
@@ -340,11 +394,14 @@ class ShardedFasta:
         dist.all_gather(leads, torch.from_numpy(lead).to(self.comm_dev))
         return comp_fold_leads(comp, [v.cpu().numpy() for v in leads], nh, self.rank)
 
-    def fetcher(self):
+    def fetcher(self, table=None):
         """ShardFetcher over all ranks' shards (SURVEY 8e "Fetch"): the global record table and every shard's byte range
         are collected once (all_gather_object of the small per-rank tables -- setup, not the data path); afterwards
         every rank answers, from its own HBM, the queries whose first byte it holds, and only pieces of queries that
-        cross a cut are exchanged."""
+        cross a cut are exchanged.  table: what gather_index returned, when the caller has it already."""
+        if table is not None:
+            return ShardFetcher({self.rank: self.blob}, table["bases"], table["ends"], table,
+                                exchange=allgather_pieces if self.world > 1 else None)
         if self.world == 1:
             t = self.local_rows()
             t["reg"] = self.blob.fasta_line_regular(self.n_local)
@@ -385,6 +442,70 @@ class ShardedFasta:
         else:
             ok &= len(rows["boff"]) == npiece
         return bool(ok)
+
+
+# ------------------------------------------------------------------ one index file from many shards
+HEAD_BYTES = 65536 + 4096          # what a rank shows of its first bytes: a name cut by a shard boundary ends within 64 KiB of it
+
+
+def local_index_part(blob, n_local, base, n_bytes):
+    """What one shard contributes to the index of the whole file: its rows (stitched), line-regular bits, the names it can
+    see (the last one may be cut by the shard's end) and its first bytes (where such a name of the previous shard ends)."""
+    rows = blob.fasta_table(n_local)
+    rows["reg"] = blob.fasta_line_regular(n_local)
+    names = []
+    if n_local:
+        ln = np.maximum(rows["name_len"].astype(np.int64), 0)
+        nb, no, ol = blob.fetch_ranges(rows["hoff"] + 1, ln, ln, flags=8)       # FX_RAW; clamped to the bytes held
+        raw, o, l = nb.tobytes(), no.tolist(), ol.tolist()
+        names = [raw[o[i]:o[i] + l[i]] for i in range(n_local)]
+    head = blob.read_bytes(base, min(HEAD_BYTES, n_bytes))
+    return (int(base), int(n_bytes), {k: np.asarray(v) for k, v in rows.items()}, names, head)
+
+
+def merge_index_parts(parts):
+    """Parts of all shards in shard order -> the table of the whole file (see ShardedFasta.gather_index)."""
+    names = []
+    for r, (base, nb, rows, nm, _) in enumerate(parts):
+        nm = list(nm)
+        if nm:
+            need = int(max(rows["name_len"][-1], 0))
+            t = r + 1
+            while len(nm[-1]) < need and t < len(parts):       # the name runs on in the next shard(s)
+                head = parts[t][4]
+                nm[-1] = nm[-1] + head[:need - len(nm[-1])]
+                if parts[t][1] > len(head):
+                    break
+                t += 1
+        names.extend(nm)
+    cols = list(parts[0][2])
+    table = {c: np.concatenate([p[2][c] for p in parts]) for c in cols}
+    table["names"] = names
+    table["seq_len"] = int(np.maximum(table["slen"], 0).sum())
+    table["bases"] = [p[0] for p in parts]
+    table["ends"] = [p[0] + p[1] for p in parts]
+    return table
+
+
+def write_merged_index(index_file, table, key_func=None):
+    """The .fxi of the whole file from the merged table (index.c:170-224, 342-372 through fxi.py)."""
+    import os
+    from . import fxi
+    names = table["names"]
+    if key_func is not None:
+        raise ValueError("key_func needs the whole header line: build on one device")
+    if index_file != ":memory:" and not os.path.exists(index_file) and len(names):
+        offs = np.zeros(len(names) + 1, dtype=np.int64)
+        np.cumsum([len(x) for x in names], out=offs[1:])
+        packed = np.frombuffer(b"".join(names), dtype=np.uint8) if offs[-1] else np.zeros(0, dtype=np.uint8)
+        try:
+            return fxi.write_fasta_bulk(index_file, packed, offs, table, table["seq_len"], order=None)
+        except Exception:
+            if os.path.exists(index_file):
+                os.remove(index_file)
+    db = fxi.connect(index_file)
+    fxi.write_fasta(db, names, table, table["seq_len"])
+    return db
 
 
 # ------------------------------------------------------------------ composition across shards

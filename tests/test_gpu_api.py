@@ -6,6 +6,7 @@ import os
 import shutil
 import sqlite3
 
+import numpy as np
 import pytest
 
 from conftest import DATA, load_golden
@@ -385,7 +386,10 @@ def test_iteration_rides_on_batched_fetches(fx, files, tmp_path, oracle):
                 assert fo[k][a:b].seq == w[a:b], (k, a, b)
         assert fo.fetch("abec"[k], (3, min(12, len(w)))) == w[2:min(12, len(w))]
         assert fo.fetch("abec"[k], [(1, 4), (6, 9)], strand="-") == oracle.revcomp((w[0:4] + w[5:9]).encode(), 3).decode()
-    assert fo._regular == {1: False, 2: False, 4: True}
+    reg = fo._st.blob.fasta_line_regular(4).tolist()          # the device column every fetch path goes by
+    assert [reg[0], reg[1], reg[3]] == [0, 0, 1]
+    buf, offs = fo.fetch_many([0, 1, 3, 0], [2, 9, 0, 5], [20, 11, 14, 5])       # ... the batched path included
+    assert [buf[offs[i]:offs[i + 1]].tobytes().decode() for i in range(4)] == [want[0][2:20], want[1][9:11], want[3][0:14], ""]
     # FASTQ
     rawq = fixture_bytes("test.fq")
     rq, size, ln = oracle.fastq_index(rawq)
@@ -426,3 +430,48 @@ def test_fetch_many_equals_slices_on_odd_line_records(fx, tmp_path):
             if not strand[j]:
                 assert want == whole
         del fa
+
+
+@pytest.mark.parametrize("kind", ["plain", "crlf", "bgzf"])
+def test_fasta_over_several_devices(fx, tmp_path, oracle, kind):
+    """Fasta(path, devices=[...]) (SURVEY 8e in one process): byte-range shards -- here three logical ones on the one GPU of
+    the test box -- each staged with fx_open_file_range and scanned on its own, stitched, ONE .fxi: the same index file,
+    the same composition, the same answers as the single-device build; records and queries that cross the cuts included."""
+    from test_gpu_kernels import _rand_fasta, _odd_line_fasta
+    from pyfastx_amd import synth
+    rng = np.random.default_rng(17)
+    raw = _rand_fasta(rng, 25, 70, crlf=(kind == "crlf"), ragged=False, trailing=True, lower=True)
+    raw += _odd_line_fasta(rng, kind == "crlf") + _rand_fasta(rng, 3, 40, crlf=(kind == "crlf"), ragged=True, trailing=False)
+    one, many = str(tmp_path / "one.fa"), str(tmp_path / "many.fa")
+    if kind == "bgzf":
+        one, many = one + ".gz", many + ".gz"
+        data = synth.bgzf_compress(raw, block=3000)         # small members: every shard covers a handful of them
+    else:
+        data = raw
+    for p in (one, many):
+        open(p, "wb").write(data)
+    a = fx.Fasta(one, full_index=True)
+    for devs in ([0, 0, 0], [0] * 7):
+        if os.path.exists(many + ".fxi"):
+            os.unlink(many + ".fxi")
+        b = fx.Fasta(many, full_index=True, devices=devs)
+        ta, tb = (sqlite3.connect(p + ".fxi") for p in (one, many))
+        for tab in ("seq", "comp", "gzindex"):
+            assert ta.execute("SELECT * FROM %s" % tab).fetchall() == tb.execute("SELECT * FROM %s" % tab).fetchall(), (tab, devs)
+        assert ta.execute("SELECT seqnum,seqlen FROM stat").fetchall() == tb.execute("SELECT seqnum,seqlen FROM stat").fetchall()
+        n = len(a)
+        assert len(b) == n and b.size == a.size
+        ids = rng.integers(0, n, 500)
+        lens = np.array([len(a[int(i)]) for i in ids])
+        st = (rng.random(500) * lens).astype(np.int64)
+        sp = np.minimum(st + rng.integers(0, 400, 500), lens)
+        strand = rng.integers(0, 2, 500)
+        ba, oa = a.fetch_many(ids, st, sp, strand=strand)
+        bb, ob = b.fetch_many(ids, st, sp, strand=strand)
+        assert (oa == ob).all() and ba.tobytes() == bb.tobytes()
+        for i in range(0, n, 3):                              # per-object getters read through the shards
+            assert b[i].seq == a[i].seq and b[i].name == a[i].name and b[i].description == a[i].description
+            if len(a[i]) > 12:
+                assert b[i][3:11].antisense == a[i][3:11].antisense and b[i].raw == a[i].raw
+        assert [s.name for s in b][:10] == [s.name for s in a][:10]
+        del b

@@ -1,8 +1,10 @@
 """-m gpu: bench.py's N>1 path end to end on the single GPU of the test box:
 two ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one device),
-everything else -- piece generation, cut shifting, shard build on the HIP path,
-all-gather of summaries, stitch, local fetch, full-size parity checks -- is the
-code the 8-GPU run executes."""
+everything else -- the pieces written into ONE file, every rank opening only its byte
+range of it (fx_open_file_range), shard build on the HIP path, all-gather of summaries,
+stitch, local fetch, the merged .fxi, fetches over the whole stream through ShardFetcher,
+full-size parity checks -- is the code the 8-GPU run executes.  The RCCL flavour of the
+collective path runs in test_nccl_collective_path_on_one_gpu (world size 1)."""
 import json
 import os
 import socket
@@ -36,6 +38,62 @@ def test_bench_two_ranks_one_gpu(world):
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == world and line["parity_verified_full_size"] is True
     assert line["value"] > 0 and line["scaling"] == "weak"
+    sf = line["sharded_file"]
+    assert sf["merged_fxi_rows_equal_plan"] is True and sf["every_query_answered_once_and_sample_equals_file"] is True
+    assert sf["open_range_s"] > 0 and sf["queries_crossing_a_cut"] >= 0
+
+
+def test_nccl_collective_path_on_one_gpu(tmp_path):
+    """the `nccl` (= RCCL) branch of the sharded build -- fx_shard_summary_dev into the send buffer,
+    all_gather_into_tensor on torch's stream ordered against the library's stream with ExternalStream events,
+    fx_fasta_stitch_dev (k_stitch_tail) -- executed on an MI355X with a process group of ONE rank (force_collective):
+    the rows must equal the plain single-handle build of the same file, fetches enqueued behind it included."""
+    script = tmp_path / "nccl_one.py"
+    script.write_text('''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="%d", RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)
+from pyfastx_amd import _lib, shard, synth
+plan = synth.fasta_plan(total_bp=30_000_000, seed=5)
+blob, flat, fs = synth.fasta_generate(plan, dev, keep_flat=True)
+nb = int(plan["n_bytes"])
+path = %r
+blob[:nb].cpu().numpy().tofile(path)
+job = shard.ShardedFasta.from_file(path, dev, 0, 1, force_collective=True)
+assert job.comm_dev.type == "cuda" and dist.get_backend() == "nccl"
+ids, st, sp, strand = synth.fasta_queries(plan, n=50000, seed=3)
+d = lambda x: torch.from_numpy(x).to(dev)
+d_out = torch.zeros(50000 * 100, dtype=torch.uint8, device=dev); d_len = torch.zeros(50000, dtype=torch.int64, device=dev)
+d_off = torch.arange(50000, device=dev, dtype=torch.int64) * 100
+for _ in range(3):
+    job.build_async()                                     # summary kernel -> RCCL all-gather -> stitch kernel, stream-ordered
+    job.fetch_local(50000, d(ids), d(st), d(sp), d((strand * 6).astype(np.uint8)), d_out, d_off, d_len)
+    s = job.finish(); job.sync()
+rows = job.local_rows()
+ref = _lib.Blob.from_file(path)
+rs = ref.fasta_build()
+want = ref.fasta_table(rs.n_seq)
+assert s.n_seq == rs.n_seq == len(plan["slen"])
+for k in want:
+    assert (rows[k] == want[k]).all(), k
+assert (job.blob.fasta_line_regular(s.n_seq) == ref.fasta_line_regular(rs.n_seq)).all()
+gathered = job._all.cpu().numpy()
+mine = job.blob.shard_summary().to_array()
+assert (gathered == mine).all()                            # what the all-gather delivered is this shard's summary
+exp = synth.expected_fetch(flat, fs, ids, st, 100, strand, dev)
+assert bool((d_out.view(50000, 100) == exp).all()) and bool((d_len == 100).all())
+dist.destroy_process_group()
+print("NCCL_PATH_OK")
+''' % (ROOT, _free_port(), str(tmp_path / "one.fa")))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0 and "NCCL_PATH_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
 
 
 def test_bench_single_small():

@@ -161,8 +161,8 @@ def test_fasta_random(oracle, L, seed):
     buf, offs, ol = b.fasta_fetch(ids, st, sp, flags_per_query=fl)
     for j in range(nq):
         r = recs[ids[j]]
-        bpl = int(r["llen"]) - int(r["elen"])
-        if r["norm"] and bpl > 0:
+        from test_host_logic import _reg_of
+        if _reg_of(raw, r):                                   # line-regular: the arithmetic; else (the odd-line record included) the true slice
             off, bl = oracle.slice_range(int(r["boff"]), int(r["llen"]), int(r["elen"]), int(st[j]), int(sp[j]))
             want = oracle.fetch(raw, off, bl, int(sp[j] - st[j]), int(fl[j]))
         else:
@@ -225,8 +225,8 @@ def test_fasta_granule_shapes(oracle, L, crlf):
     buf, offs, ol = b.fasta_fetch(ids, st, sp, flags_per_query=fl)
     for j in range(nq):
         r = recs[ids[j]]
-        bpl = int(r["llen"]) - int(r["elen"])
-        if r["norm"] and bpl > 0:
+        from test_host_logic import _reg_of
+        if _reg_of(raw, r):                                   # line-regular: the arithmetic; else (the odd-line record included) the true slice
             off, bl = oracle.slice_range(int(r["boff"]), int(r["llen"]), int(r["elen"]), int(st[j]), int(sp[j]))
             want = oracle.fetch(raw, off, bl, int(sp[j] - st[j]), int(fl[j]))
         else:
@@ -565,8 +565,8 @@ def test_fasta_mixed_shapes_60mb(oracle, L):
     buf, offs, ol = b.fasta_fetch(ids, st, sp, flags_per_query=fl)
     for j in range(nq):
         r = recs[ids[j]]
-        bpl = int(r["llen"]) - int(r["elen"])
-        if r["norm"] and bpl > 0:
+        from test_host_logic import _reg_of
+        if _reg_of(raw, r):                                   # line-regular: the arithmetic; else (the odd-line record included) the true slice
             off, bl = oracle.slice_range(int(r["boff"]), int(r["llen"]), int(r["elen"]), int(st[j]), int(sp[j]))
             want = oracle.fetch(raw, off, bl, int(sp[j] - st[j]), int(fl[j]))
         else:

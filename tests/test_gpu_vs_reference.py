@@ -219,3 +219,55 @@ def test_non_ascii_names_side_by_side(both, tmp_path):
     del fa, rf
     fa, rf = fx.Fasta(po), ref.Fasta(pt)                    # loaded from the files written above
     assert fa["日本"].seq == rf["日本"].seq == "GGGG"
+
+
+def test_batched_cli_side_by_side(both, tmp_path):
+    """`subseq -r / -b / regions`, `sample`, `extract` of pyfastx_amd.cli (one GPU batch each) write the bytes
+    the reference's command loops write (pyfastxcli.py:240-387, restated here over the compiled reference's objects)."""
+    import random
+    fx, ref = both
+    from pyfastx_amd import cli
+    rng = np.random.default_rng(99)
+    raw = _fasta_text(rng, dict(_FASTA_STYLES[0]))
+    rawq = _fastq_text(rng, 300, 120, crlf=False, plus_name=False, trailing=True, qlo=33, qhi=74)
+    (po, pt), (qo, qt) = _two_copies(tmp_path, "c.fa", raw), _two_copies(tmp_path, "c.fq", rawq)
+    rf, rq = ref.Fasta(pt), ref.Fastq(qt)
+    names = list(rf.keys())
+    regions = []
+    for _ in range(200):
+        nm = names[int(rng.integers(0, len(names)))]
+        L = len(rf[nm])
+        if L < 2:
+            continue
+        a = int(rng.integers(1, L))
+        regions.append((nm, a, int(rng.integers(a, L + 1))))
+    reg_file, bed_file, out = str(tmp_path / "r.txt"), str(tmp_path / "r.bed"), str(tmp_path / "out.txt")
+    open(reg_file, "w").write("".join("%s\t%d\t%d\n" % r for r in regions))
+    open(bed_file, "w").write("".join("%s\t%d\t%d\n" % (c, s - 1, e) for c, s, e in regions))
+    want = "".join(">%s:%d-%d\n%s\n" % (c, s, e, rf.fetch(c, (s, e))) for c, s, e in regions)
+    cli.main(["subseq", "-r", reg_file, "-o", out, po]); assert open(out).read() == want
+    cli.main(["subseq", "-b", bed_file, "-o", out, po]); assert open(out).read() == want
+    cli.main(["subseq", "-o", out, po] + ["%s:%d-%d" % r for r in regions[:20]])
+    assert open(out).read() == "".join(">%s:%d-%d\n%s\n" % (c, s, e, rf[c][s - 1:e].seq) for c, s, e in regions[:20])
+    for path_o, obj in ((po, rf), (qo, rq)):
+        for seed, num in ((7, 25), (11, 3)):
+            random.seed(seed)
+            sel = sorted(random.sample(range(len(obj)), k=num))
+            cli.main(["sample", "-n", str(num), "-s", str(seed), "-o", out, path_o])
+            assert open(out).read() == "".join(obj[i].raw for i in sel), (path_o, seed)
+        cli.main(["sample", "-p", "0.1", "-s", "5", "-o", out, path_o])
+        random.seed(5)
+        sel = sorted(random.sample(range(len(obj)), k=int(np.ceil(len(obj) * 0.1))))
+        assert open(out).read() == "".join(obj[i].raw for i in sel)
+    # extract: by names on the command line, by a list file (list order), --sequential-read (file order, once each)
+    pick = [names[i] for i in rng.integers(0, len(names), 15)]
+    cli.main(["extract", "-o", out, po] + pick); assert open(out).read() == "".join(rf[n].raw for n in pick)
+    rnames = [rq[int(i)].name for i in rng.integers(0, len(rq), 40)]
+    lst = str(tmp_path / "names.txt")
+    open(lst, "w").write("".join(n + "\n" for n in rnames))
+    cli.main(["extract", "-l", lst, "-o", out, qo]); assert open(out).read() == "".join(rq[n].raw for n in rnames)
+    cli.main(["extract", "-l", lst, "--sequential-read", "-o", out, qo])
+    assert open(out).read() == "".join(r.raw for r in rq if r.name in set(rnames))
+    open(lst, "w").write("".join(n + "\n" for n in pick))
+    cli.main(["extract", "-l", lst, "--sequential-read", "-o", out, po])
+    assert open(out).read() == "".join(s.raw for s in rf if s.name in set(pick))
