@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-c3", action="store_true")
     ap.add_argument("--no-c4", action="store_true")
+    ap.add_argument("--no-gz-stream", action="store_true", help="skip the single-stream gzip sub-leg of c4")
     return ap.parse_args()
 
 
@@ -417,6 +418,38 @@ def leg_c4(a, host, plan, q, tmpdir):
         if not (out["rows_equal_reference"] and eq):
             raise SystemExit("PARITY FAILURE (C4 vs the reference)")
     _rm(path, path + ".fxi")
+    # ---- the same bytes as ONE gzip stream (no member boundaries): zran-style restart points.  First open:
+    # serial inflate on the host, points captured; every later open: the segments between the points inflated in parallel
+    if not a.no_gz_stream:
+        t0 = time.perf_counter()
+        with get_context("fork").Pool(min(96, os.cpu_count() or 8)) as pool:
+            gz = synth.gzip_single_stream(host, pool)
+        p2 = os.path.join(tmpdir, "c4s.fa.gz")
+        with open(p2, "wb") as f:
+            f.write(gz)
+        gsize = len(gz)
+        del gz
+        t1 = time.perf_counter()
+        fa = fx.Fasta(p2)                                     # serial inflate + scan + .fxi with the restart points
+        t2 = time.perf_counter()
+        npts = len(_tables(p2 + ".fxi", ("gzindex",))["gzindex"])
+        del fa
+        t3 = time.perf_counter()
+        fa = fx.Fasta(p2)                                     # loads the index ...
+        b2, o2 = fa.fetch_many(qnames[:200_000], st[:200_000], sp[:200_000], strand=strand[:200_000])   # ... stages the stream: parallel inflate
+        t4 = time.perf_counter()
+        same = b2.tobytes() == buf[:int(offs[200_000])].tobytes()
+        par = fa._st.blob.gz_checkpoints()["windows"].size == 0      # (a serial inflate would have captured windows again)
+        del fa
+        out["single_stream_gzip"] = {"compressed_bytes": gsize, "host_compress_s_setup_only": round(t1 - t0, 1),
+                                     "first_open_ctor_s": round(t2 - t1, 3), "gzindex_rows": npts,
+                                     "reopen_and_200k_fetches_s": round(t4 - t3, 3), "reopen_used_the_points": bool(par),
+                                     "speedup_of_reopen": round((t2 - t1) / max(t4 - t3, 1e-9), 1), "fetches_equal_bgzf_run": bool(same),
+                                     "note": "one gzip member of the C2 bytes; first open = host zlib inflate (1 core) with restart points captured "
+                                             "every >= 1 MiB; re-open = the index's points, segments inflated by host threads in parallel"}
+        if not same:
+            raise SystemExit("PARITY FAILURE (single-stream gzip re-open)")
+        _rm(p2, p2 + ".fxi")
     return out
 
 

@@ -292,9 +292,25 @@ int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mode);
  * table (pyfastx_build_gzip_index / pyfastx_gzip_index_export, util.c:442-540,
  * 728-742): for BGZF, member boundaries about `spacing` uncompressed bytes apart
  * (bit offset 0, no 32 KiB window needed).  Call with cap = 0 to get the count.
- * Non-BGZF inputs report 0 points.                                            */
+ * Non-BGZF inputs report 0 points here: see fx_gz_checkpoints.                 */
 int fx_gz_points(fx_handle *h, int64_t spacing, int64_t *cmp_off, int64_t *uncmp_off, int64_t cap,
                  int64_t *n_out, int64_t *compressed_size);
+
+/* Single-stream gzip (not BGZF): the restart points zran would build (pyfastx_build_gzip_index, util.c:728-742; spacing
+ * 1 MiB, window 32 KiB, index.c:70) are captured while fx_open_file inflates the stream on the host -- at deflate block
+ * boundaries at least 1 MiB of output apart: offset of the next compressed byte, number of bits of the byte before it
+ * that still belong to the point (zran's `bits`), offset in the inflated stream, and the 32 KiB of output before it
+ * (point 0 is the start of the deflate data and has none).  fx_gz_checkpoints hands them out for the gzindex table
+ * (windows: 32768 bytes per point with has_data, in order; call with cap = 0 for the counts);  fx_open_file_indexed is
+ * fx_open_file with the points of an existing index: the segments between them are inflated by many host threads at
+ * once, each a raw inflate primed with its bits and window (zran_seek + zran_read of index.c:685-686, for every
+ * segment at the same time).  Points that do not describe the file: the serial inflate, silently.  The checkpoint
+ * layout itself is parity-unpinned: indexed_gzip is not part of the reference tree. */
+int fx_gz_checkpoints(fx_handle *h, int64_t cap, int64_t *cmp_off, int64_t *uncmp_off, uint8_t *bits, uint8_t *has_data,
+                      uint8_t *windows, int64_t *n_out, int64_t *n_windows);
+int fx_open_file_indexed(const char *path, int device, int64_t n_points, const int64_t *cmp_off, const int64_t *uncmp_off,
+                         const uint8_t *bits, const uint8_t *has_data, const uint8_t *windows, int64_t uncompressed_size,
+                         fx_handle **out);
 
 /* ------------------------------------------------------------ .fxi bulk load
  * Host-side.  Replaces the per-record `sqlite3_step(INSERT)` of index.c:239-251 / fastq.c:136-149 for the one big

@@ -45,7 +45,7 @@ class ShardSummary(C.Structure):
 
 
 SYMBOLS = [
-    "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_stream_size", "fx_open_file_range", "fx_open_host", "fx_open_device",
+    "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_file_indexed", "fx_gz_checkpoints", "fx_stream_size", "fx_open_file_range", "fx_open_host", "fx_open_device",
     "fx_set_shard", "fx_close", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
     "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_line_regular", "fx_fasta_len_stats", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
@@ -115,6 +115,8 @@ def lib():
     L.fx_open_file.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
     L.fx_open_host.argtypes = [vp, i64, i32, C.POINTER(vp)]
     L.fx_stream_size.argtypes = [C.c_char_p, C.POINTER(i64), C.POINTER(i32)]
+    L.fx_open_file_indexed.argtypes = [C.c_char_p, i32, i64, vp, vp, vp, vp, vp, i64, C.POINTER(vp)]
+    L.fx_gz_checkpoints.argtypes = [vp, i64, vp, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(i64)]
     L.fx_open_file_range.argtypes = [C.c_char_p, i64, i64, i64, i32, C.POINTER(vp)]
     L.fx_open_device.argtypes = [vp, i64, i32, C.POINTER(vp)]
     L.fx_set_shard.argtypes = [vp, i64, i32, i32]
@@ -201,9 +203,18 @@ class Blob:
 
     # -- constructors -------------------------------------------------------
     @classmethod
-    def from_file(cls, path, device=0):
+    def from_file(cls, path, device=0, gzindex=None):
+        """gzindex: the restart points of a single-stream gzip file (fxi.read_gzindex) -> the segments between them are
+        inflated in parallel (fx_open_file_indexed)."""
         h = C.c_void_p()
-        check(lib().fx_open_file(os.fsencode(path), device, C.byref(h)))
+        if gzindex and len(gzindex["cmp"]) and gzindex["windows"] is not None:
+            a = [np.ascontiguousarray(gzindex[k], dtype=np.int64) for k in ("cmp", "uncmp")]
+            b = [np.ascontiguousarray(gzindex[k], dtype=np.uint8) for k in ("bits", "has")]
+            w = np.ascontiguousarray(gzindex["windows"], dtype=np.uint8)
+            check(lib().fx_open_file_indexed(os.fsencode(path), device, a[0].size, _ptr(a[0]), _ptr(a[1]), _ptr(b[0]), _ptr(b[1]),
+                                             _ptr(w) if w.size else None, int(gzindex["uncompressed_size"]), C.byref(h)))
+        else:
+            check(lib().fx_open_file(os.fsencode(path), device, C.byref(h)))
         return cls(h)
 
     @classmethod
@@ -278,6 +289,19 @@ class Blob:
         if n.value:
             check(lib().fx_gz_points(self._h, spacing, a.ctypes.data, b.ctypes.data, n.value, C.byref(n), C.byref(cs)))
         return a, b, cs.value
+
+    def gz_checkpoints(self):
+        """Restart points captured while a single gzip stream was inflated (fx_gz_checkpoints) -> dict cmp, uncmp (int64),
+        bits, has (uint8), windows (uint8 [n_with_data * 32768])."""
+        n, nw = C.c_int64(0), C.c_int64(0)
+        check(lib().fx_gz_checkpoints(self._h, 0, None, None, None, None, None, C.byref(n), C.byref(nw)))
+        out = {"cmp": np.zeros(n.value, dtype=np.int64), "uncmp": np.zeros(n.value, dtype=np.int64),
+               "bits": np.zeros(n.value, dtype=np.uint8), "has": np.zeros(n.value, dtype=np.uint8),
+               "windows": np.zeros(nw.value * 32768, dtype=np.uint8)}
+        if n.value:
+            check(lib().fx_gz_checkpoints(self._h, n.value, _ptr(out["cmp"]), _ptr(out["uncmp"]), _ptr(out["bits"]), _ptr(out["has"]),
+                                          _ptr(out["windows"]) if nw.value else None, C.byref(n), C.byref(nw)))
+        return out
 
     def sync(self):
         check(lib().fx_sync(self._h))

@@ -72,15 +72,37 @@ class _Staged:
 
     def __init__(self, path, device):
         self.path, self.device, self._blob = path, device, None
+        self.gzindex = None          # callable -> restart points of the index file (fxi.read_gzindex), set by the owner
 
     @property
     def blob(self):
         if self._blob is None:
+            pts = None
+            if self.gzindex is not None:                     # a gzip file with an index: inflate the segments in parallel
+                try:
+                    pts = self.gzindex()
+                except Exception:                            # noqa: BLE001  (an unreadable gzindex table: inflate serially)
+                    pts = None
+                if pts is not None and (pts["windows"] is None or int(pts["has"].sum()) == 0
+                                        or pts["compressed_size"] != os.path.getsize(self.path)):
+                    pts = None
             try:
-                self._blob = _lib.Blob.from_file(self.path, self.device)
+                self._blob = _lib.Blob.from_file(self.path, self.device, gzindex=pts)
             except _lib.FxError as e:
                 raise _fx_to_py(e)
         return self._blob
+
+    def write_gzindex(self, db):
+        """The gzindex table of a gzip input: BGZF member boundaries, or the restart points captured while a single
+        stream was inflated (util.c:442-540)."""
+        blob = self.blob
+        c, u, _ = blob.gz_points()
+        if len(c):
+            fxi.write_gzindex(db, os.path.getsize(self.path), blob.size, c, u)
+            return
+        p = blob.gz_checkpoints()
+        fxi.write_gzindex(db, os.path.getsize(self.path), blob.size, p["cmp"], p["uncmp"], bits=p["bits"], has_data=p["has"],
+                          windows=p["windows"])
 
     def raw(self, off, n):
         """pyfastx_index_random_read (index.c:683-692): bytes as they are."""
@@ -182,6 +204,8 @@ class Fasta:
             self._db = fxi.connect(self._index_file)
             if not fxi.has_fasta_index(self._db):                                         # index.c:402-411
                 raise RuntimeError("the index file %s was damaged" % self._index_file)
+            if self.is_gzip and not self._sharded:           # pyfastx_load_index imports the zran points (index.c:433): so do we
+                self._st.gzindex = lambda: fxi.read_gzindex(self._db)
         else:
             self._create_index()
         row = self._db.execute("SELECT * FROM stat LIMIT 1").fetchone()                    # fasta.c:17-37
@@ -221,8 +245,7 @@ class Fasta:
             self._db = fxi.connect(self._index_file)
             fxi.write_fasta(self._db, names, t, s.seq_len)
         if self.is_gzip:
-            c, u, _ = blob.gz_points()
-            fxi.write_gzindex(self._db, os.path.getsize(self.file_name), blob.size, c, u)
+            self._st.write_gzindex(self._db)
 
     def _gather(self, off, length):
         """Raw byte spans of the resident stream as a list of bytes (one batched GPU gather)."""
@@ -1049,6 +1072,8 @@ class Fastq:
 
     def _load_index(self):
         self._db = fxi.connect(self._index_file)
+        if self.is_gzip:                                     # fastq.c:396: the zran points of the index file are used by the next open
+            self._st.gzindex = lambda: fxi.read_gzindex(self._db)
         try:
             row = self._db.execute("SELECT * FROM stat LIMIT 1").fetchone()
         except Exception:
@@ -1085,8 +1110,7 @@ class Fastq:
             self._db = fxi.connect(self._index_file)
             fxi.write_fastq(self._db, names, t, s.size)
         if self.is_gzip:
-            c, u, _ = blob.gz_points()
-            fxi.write_gzindex(self._db, os.path.getsize(self.file_name), blob.size, c, u)
+            self._st.write_gzindex(self._db)
         self._counts, self.size = int(s.n_reads), int(s.size)
         self.avglen = self.size * 1.0 / self._counts if self._counts else float("nan")
 

@@ -182,6 +182,9 @@ struct fx_handle {
     std::vector<int64_t> gz_moff, gz_uoff;
     int64_t gz_csize = 0;
     bool bgzf = false;
+    // restart points of a single gzip stream (captured while it is inflated: GzSerial below)
+    std::vector<int64_t> gzp_cin, gzp_cout;
+    std::vector<uint8_t> gzp_bits, gzp_has, gzp_win;          // gzp_win: GZ_WINDOW bytes per point that has data, in order
     Prof prof;
 };
 
@@ -484,7 +487,189 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
     return FX_OK;
 }
 
+// ------------------------------------------------------------------- single-stream gzip
+// A single deflate stream is inflated by zlib on the host (bit-serial, one core).  While that happens the restart
+// points of zran (indexed_gzip, the reference's random-access layer: index.c:68-70 spacing 1 MiB, window 32 KiB;
+// export layout util.c:461-529) are captured at deflate-block boundaries: compressed offset, pending bits, uncompressed
+// offset and the 32 KiB of output before it.  They go into the .fxi; the NEXT open of the file reads them back and
+// inflates the segments between points in parallel (gzip_indexed_to_blob): every segment is an independent raw
+// inflate primed with its window.
+static const int64_t GZ_SPACING = 1048576, GZ_WINDOW = 32768;
+
+struct GzSerial {
+    z_stream z;
+    const uint8_t *in = nullptr;
+    int64_t nin = 0, fed = 0, last_cout = 0;
+    bool open = false, done = false;
+    fx_handle *h = nullptr;
+    const uint8_t *prev_buf = nullptr;                         // the ring slot filled before this one (windows that straddle two slots)
+    int64_t prev_fill = 0;
+    int init(fx_handle *hh, const uint8_t *p, int64_t n) {
+        memset(&z, 0, sizeof z);
+        if (inflateInit2(&z, 47) != Z_OK) return -1;          // 32 + 15: gzip or zlib header, detected
+        open = true; h = hh; in = p; nin = n;
+        return 0;
+    }
+    ~GzSerial() { if (open) inflateEnd(&z); }
+    void point(const uint8_t *buf, int64_t pos) {
+        const int64_t cout = (int64_t)z.total_out + base_out;
+        const bool first = h->gzp_cin.empty();
+        if (!first && cout - last_cout < GZ_SPACING) return;
+        h->gzp_cin.push_back((int64_t)z.total_in + base_in); h->gzp_cout.push_back(cout);
+        h->gzp_bits.push_back((uint8_t)(z.data_type & 7));
+        h->gzp_has.push_back(first && cout == 0 ? 0 : 1);     // the first point is the start of the deflate data: nothing before it
+        last_cout = cout;
+        if (first && cout == 0) return;
+        const size_t o = h->gzp_win.size();
+        h->gzp_win.resize(o + GZ_WINDOW, 0);
+        uint8_t *w = h->gzp_win.data() + o;
+        if (pos >= GZ_WINDOW) memcpy(w, buf + pos - GZ_WINDOW, GZ_WINDOW);
+        else {
+            const int64_t need = GZ_WINDOW - pos, from_prev = std::min(need, prev_fill);
+            if (from_prev > 0) memcpy(w + (need - from_prev), prev_buf + prev_fill - from_prev, (size_t)from_prev);
+            if (pos > 0) memcpy(w + need, buf, (size_t)pos);
+        }
+    }
+    int64_t base_in = 0, base_out = 0;                         // totals of the members finished so far (inflateReset zeroes zlib's)
+    // inflate into buf[0, cap): bytes produced (0 at the end of the stream), -1 on a data error
+    int64_t fill(uint8_t *buf, int64_t cap) {
+        int64_t pos = 0;
+        while (pos < cap && !done) {
+            if (z.avail_in == 0 && fed < nin) {
+                const int64_t c = std::min<int64_t>(nin - fed, 1 << 30);
+                z.next_in = const_cast<Bytef *>(in + fed); z.avail_in = (uInt)c; fed += c;
+            }
+            const uInt room = (uInt)std::min<int64_t>(cap - pos, 1 << 30);
+            z.next_out = buf + pos; z.avail_out = room;
+            const int ret = inflate(&z, Z_BLOCK);
+            pos += (int64_t)(room - z.avail_out);
+            if (ret == Z_STREAM_END) {
+                // gzread semantics: further gzip members are part of the stream, anything else after the trailer is ignored
+                const int64_t left = (int64_t)z.avail_in + (nin - fed);
+                const uint8_t *nx = z.next_in;
+                if (left >= 18 && nx[0] == 0x1f && nx[1] == 0x8b) {
+                    base_in += (int64_t)z.total_in; base_out += (int64_t)z.total_out;
+                    if (inflateReset(&z) != Z_OK) return -1;
+                } else done = true;
+                continue;
+            }
+            if (ret == Z_BUF_ERROR) {
+                if (z.avail_in == 0 && fed >= nin) return -1;   // the stream ends in the middle of a block
+                continue;
+            }
+            if (ret != Z_OK) return -1;
+            if ((z.data_type & 128) && !(z.data_type & 64)) point(buf, pos);
+        }
+        return pos;
+    }
+};
+
+// The parallel form: segment i = the bytes between restart point i and point i + 1 of the uncompressed stream.
+static int gzip_indexed_to_blob(fx_handle *h, const uint8_t *in, int64_t nin, int64_t npts, const int64_t *cin, const int64_t *cout,
+                                const uint8_t *bits, const uint8_t *has, const uint8_t *wins, int64_t usize) {
+    if (npts < 1 || cout[0] != 0 || usize <= 0) return 1;
+    std::vector<int64_t> woff((size_t)npts, -1);               // window of point i inside wins
+    int64_t nw = 0;
+    for (int64_t i = 0; i < npts; ++i) {
+        if (cin[i] < 0 || cin[i] > nin || cout[i] > usize || (i && cout[i] <= cout[i - 1]) || (i && !has[i])) return 1;
+        if (has[i]) woff[(size_t)i] = (nw++) * GZ_WINDOW;
+    }
+    int rc = alloc_blob(h, usize);
+    if (rc) return rc;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(FX_EDEVICE, "stream sync failed");
+    const int T = (int)std::min<int64_t>(std::max(8u, std::min(64u, std::thread::hardware_concurrency() / 2)), npts);
+    std::atomic<int64_t> next(0);
+    std::atomic<int> err(0);                                   // 1: data does not match the index, 2: device
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+        th.emplace_back([&]() {
+            if (hipSetDevice(h->device) != hipSuccess) { err.store(2); return; }
+            uint8_t *pin[2] = {g_pins.get(), g_pins.get()};
+            hipStream_t st = nullptr;
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            bool used[2] = {false, false};
+            bool ok = pin[0] && pin[1] && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+                      hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+            if (!ok) err.store(2);
+            int slot = 0;
+            z_stream z;
+            for (int64_t i; ok && !err.load() && (i = next.fetch_add(1)) < npts;) {
+                const int64_t o0 = cout[i], o1 = i + 1 < npts ? cout[i + 1] : usize;
+                memset(&z, 0, sizeof z);
+                if (inflateInit2(&z, -15) != Z_OK) { err.store(1); break; }
+                bool bad = false;
+                if (bits[i]) bad = cin[i] < 1 || inflatePrime(&z, bits[i], in[cin[i] - 1] >> (8 - bits[i])) != Z_OK;
+                if (!bad && has[i]) bad = inflateSetDictionary(&z, wins + woff[(size_t)i], (uInt)GZ_WINDOW) != Z_OK;
+                int64_t ipos = cin[i], done = o0;
+                bool wrapped = false;                                          // inside a later gzip member (zlib eats its trailer itself)
+                while (!bad && done < o1) {
+                    if (used[slot] && hipEventSynchronize(ev[slot]) != hipSuccess) { err.store(2); bad = true; break; }
+                    const int64_t want = std::min<int64_t>(o1 - done, PIECE_BYTES);
+                    int64_t got = 0;
+                    while (!bad && got < want) {
+                        if (z.avail_in == 0) {
+                            const int64_t c = std::min<int64_t>(nin - ipos, 1 << 26);
+                            if (c <= 0) { bad = true; break; }
+                            z.next_in = const_cast<Bytef *>(in + ipos); z.avail_in = (uInt)c; ipos += c;
+                        }
+                        const uInt room = (uInt)(want - got);
+                        z.next_out = pin[slot] + got; z.avail_out = room;
+                        const int ret = inflate(&z, Z_NO_FLUSH);
+                        got += (int64_t)(room - z.avail_out);
+                        if (ret == Z_STREAM_END && got < want) {          // the next gzip member goes on: trailer, then its header
+                            ipos -= (int64_t)z.avail_in;
+                            if (!wrapped) ipos += 8;
+                            inflateEnd(&z);
+                            memset(&z, 0, sizeof z);
+                            if (ipos + 18 > nin || inflateInit2(&z, 47) != Z_OK) { bad = true; break; }
+                            wrapped = true;
+                        } else if (ret != Z_OK && ret != Z_STREAM_END && ret != Z_BUF_ERROR) bad = true;
+                        else if (ret == Z_BUF_ERROR && z.avail_in == 0 && ipos >= nin) bad = true;
+                    }
+                    if (bad) break;
+                    if (hipMemcpyAsync(h->d_data + done, pin[slot], (size_t)got, hipMemcpyHostToDevice, st) != hipSuccess ||
+                        hipEventRecord(ev[slot], st) != hipSuccess) { err.store(2); bad = true; break; }
+                    used[slot] = true;
+                    slot ^= 1;
+                    done += got;
+                }
+                inflateEnd(&z);
+                if (bad && !err.load()) err.store(1);
+            }
+            if (st) (void)hipStreamSynchronize(st);
+            for (int k = 0; k < 2; ++k) { if (ev[k]) (void)hipEventDestroy(ev[k]); if (pin[k]) g_pins.put(pin[k]); }
+            if (st) (void)hipStreamDestroy(st);
+        });
+    for (auto &x : th) x.join();
+    if (err.load() == 2) return fail(FX_EDEVICE, "staging the inflated segments failed");
+    if (err.load() == 1) {                                     // the index does not describe this file: inflate it serially instead
+        (void)hipFree(h->d_data);
+        h->d_data = nullptr; h->owns = false; h->n = 0;
+        return 1;
+    }
+    return FX_OK;
+}
+
+static int open_file_impl(const char *path, int device, fx_handle **out, int64_t npts, const int64_t *p_cin, const int64_t *p_cout,
+                          const uint8_t *p_bits, const uint8_t *p_has, const uint8_t *p_wins, int64_t p_usize);
+
 extern "C" int fx_open_file(const char *path, int device, fx_handle **out) {
+    return open_file_impl(path, device, out, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+}
+
+// fx_open_file for a gzip file whose restart points are known (the gzindex rows of its .fxi): the segments between the
+// points are inflated by many host threads at once.  Points that do not fit the file fall back to the serial inflate
+// (which captures fresh points).  Plain and BGZF files ignore the points.
+extern "C" int fx_open_file_indexed(const char *path, int device, int64_t n_points, const int64_t *cmp_off, const int64_t *uncmp_off,
+                                    const uint8_t *bits, const uint8_t *has_data, const uint8_t *windows, int64_t uncompressed_size,
+                                    fx_handle **out) {
+    if (n_points > 0 && (!cmp_off || !uncmp_off || !bits || !has_data)) return fail(FX_EINVAL, "null argument");
+    return open_file_impl(path, device, out, n_points, cmp_off, uncmp_off, bits, has_data, windows, uncompressed_size);
+}
+
+static int open_file_impl(const char *path, int device, fx_handle **out, int64_t npts, const int64_t *p_cin, const int64_t *p_cout,
+                          const uint8_t *p_bits, const uint8_t *p_has, const uint8_t *p_wins, int64_t p_usize) {
     if (!path || !out) return fail(FX_EINVAL, "null argument");
     struct stat st;
     if (stat(path, &st) != 0 || !S_ISREG(st.st_mode)) return fail(FX_ENOENT, "the input file %s does not exists", path);
@@ -528,27 +713,40 @@ extern "C" int fx_open_file(const char *path, int device, fx_handle **out) {
             if (brc < 0) return bail(brc);
             // brc == 1: not BGZF -> fall through to the single-stream path
         }
-        // single-stream gzip: inflate is inherently serial (zlib on the host), the
-        // inflated bytes stream through a pinned ring into a growing blob.
+        // single-stream gzip: with restart points from the index file the segments are inflated in parallel ...
+        const int64_t fsize = (int64_t)st.st_size;
+        void *mp = mmap(nullptr, (size_t)fsize, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (mp == MAP_FAILED) return bail(fail(FX_EIO, "cannot map %s", path));
+        (void)madvise(mp, (size_t)fsize, MADV_SEQUENTIAL);
+        h->gz_csize = fsize;
+        if (npts > 0) {
+            const int prc = gzip_indexed_to_blob(h, (const uint8_t *)mp, fsize, npts, p_cin, p_cout, p_bits, p_has, p_wins, p_usize);
+            if (prc == FX_OK) {
+                (void)munmap(mp, (size_t)fsize);
+                h->gzp_cin.assign(p_cin, p_cin + npts); h->gzp_cout.assign(p_cout, p_cout + npts);
+                h->gzp_bits.assign(p_bits, p_bits + npts); h->gzp_has.assign(p_has, p_has + npts);
+                close(fd);
+                if (hipStreamSynchronize(h->stream) != hipSuccess) { fx_close(h); return fail(FX_EDEVICE, "stream sync failed"); }
+                *out = h;
+                return FX_OK;
+            }
+            if (prc < 0) { (void)munmap(mp, (size_t)fsize); return bail(prc); }
+        }
+        // ... without (or with points that do not fit): serial (zlib on the host), the inflated bytes stream through a
+        // pinned ring into a growing blob and the restart points are captured on the way.
         rc = st_.init();
-        if (rc) return bail(rc);
-        gzFile g = gzdopen(dup(fd), "rb");
-        if (!g) return bail(fail(FX_EIO, "gzdopen failed for %s", path));
-        gzbuffer(g, 1 << 20);
+        if (rc) { (void)munmap(mp, (size_t)fsize); return bail(rc); }
+        GzSerial gs;
+        if (gs.init(h, (const uint8_t *)mp, fsize)) { (void)munmap(mp, (size_t)fsize); return bail(fail(FX_EIO, "inflateInit failed for %s", path)); }
         int64_t cap = std::max<int64_t>((int64_t)st.st_size * 5, STAGE_BYTES), n = 0;
         uint8_t *d = nullptr;
         hipError_t e = hipMalloc((void **)&d, (size_t)cap + 2 * TILE);
-        if (e != hipSuccess) { gzclose(g); return bail(fail(FX_ENOMEM, "hipMalloc: %s", hipGetErrorString(e))); }
+        if (e != hipSuccess) { (void)munmap(mp, (size_t)fsize); return bail(fail(FX_ENOMEM, "hipMalloc: %s", hipGetErrorString(e))); }
         int slot = 0;
         for (;;) {
             if (st_.used[slot]) (void)hipEventSynchronize(st_.ev[slot]);
-            int64_t fill = 0;
-            while (fill < STAGE_BYTES) {
-                int r = gzread(g, st_.pin[slot] + fill, (unsigned)std::min<int64_t>(STAGE_BYTES - fill, 1 << 30));
-                if (r < 0) { gzclose(g); (void)hipFree(d); return bail(fail(FX_EIO, "gzip inflate error in %s", path)); }
-                if (r == 0) break;
-                fill += r;
-            }
+            const int64_t fill = gs.fill(st_.pin[slot], STAGE_BYTES);
+            if (fill < 0) { (void)munmap(mp, (size_t)fsize); (void)hipFree(d); return bail(fail(FX_EIO, "gzip inflate error in %s", path)); }
             if (fill == 0) break;
             if (n + fill > cap) {           // grow: allocate bigger, device-to-device copy
                 int64_t ncap = std::max(cap * 2, n + fill);
@@ -556,19 +754,20 @@ extern "C" int fx_open_file(const char *path, int device, fx_handle **out) {
                 e = hipMalloc((void **)&nd, (size_t)ncap + 2 * TILE);
                 if (e == hipSuccess) e = hipMemcpyAsync(nd, d, (size_t)n, hipMemcpyDeviceToDevice, h->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-                if (e != hipSuccess) { gzclose(g); (void)hipFree(d); return bail(fail(FX_ENOMEM, "grow: %s", hipGetErrorString(e))); }
+                if (e != hipSuccess) { (void)munmap(mp, (size_t)fsize); (void)hipFree(d); return bail(fail(FX_ENOMEM, "grow: %s", hipGetErrorString(e))); }
                 (void)hipFree(d);
                 d = nd; cap = ncap;
             }
             e = hipMemcpyAsync(d + n, st_.pin[slot], (size_t)fill, hipMemcpyHostToDevice, h->stream);
             if (e == hipSuccess) e = hipEventRecord(st_.ev[slot], h->stream);
-            if (e != hipSuccess) { gzclose(g); (void)hipFree(d); return bail(fail(FX_EDEVICE, "H2D: %s", hipGetErrorString(e))); }
+            if (e != hipSuccess) { (void)munmap(mp, (size_t)fsize); (void)hipFree(d); return bail(fail(FX_EDEVICE, "H2D: %s", hipGetErrorString(e))); }
             st_.used[slot] = true;
+            gs.prev_buf = st_.pin[slot]; gs.prev_fill = fill;
             n += fill;
             slot = (slot + 1) % NSTAGE;
             if (fill < STAGE_BYTES) break;
         }
-        gzclose(g);
+        (void)munmap(mp, (size_t)fsize);
         h->d_data = d; h->owns = true; h->n = n;
         e = hipMemsetAsync(d + n, 0, (size_t)(cap + 2 * TILE - n), h->stream);
         if (e != hipSuccess) return bail(fail(FX_EDEVICE, "memset: %s", hipGetErrorString(e)));
@@ -1706,6 +1905,19 @@ extern "C" int fx_gz_points(fx_handle *h, int64_t spacing, int64_t *cmp_off, int
         }
     }
     *n_out = n;
+    return FX_OK;
+}
+
+extern "C" int fx_gz_checkpoints(fx_handle *h, int64_t cap, int64_t *cmp_off, int64_t *uncmp_off, uint8_t *bits, uint8_t *has_data,
+                                 uint8_t *windows, int64_t *n_out, int64_t *n_windows) {
+    if (!h || !n_out) return fail(FX_EINVAL, "null argument");
+    const int64_t n = (int64_t)h->gzp_cin.size();
+    *n_out = n;
+    if (n_windows) *n_windows = (int64_t)(h->gzp_win.size() / GZ_WINDOW);
+    if (cap < n || !cmp_off) return FX_OK;                    // a query for the counts
+    if (!uncmp_off || !bits || !has_data) return fail(FX_EINVAL, "null argument");
+    for (int64_t i = 0; i < n; ++i) { cmp_off[i] = h->gzp_cin[(size_t)i]; uncmp_off[i] = h->gzp_cout[(size_t)i]; bits[i] = h->gzp_bits[(size_t)i]; has_data[i] = h->gzp_has[(size_t)i]; }
+    if (windows && !h->gzp_win.empty()) memcpy(windows, h->gzp_win.data(), h->gzp_win.size());
     return FX_OK;
 }
 

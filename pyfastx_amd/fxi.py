@@ -252,23 +252,56 @@ def write_fastq_comp(db, base, meta):
     db.execute("INSERT INTO meta VALUES (?,?,?,?,?)", tuple(int(x) for x in meta))
 
 
-def write_gzindex(db, compressed_size, uncompressed_size, cmp_off=(), uncmp_off=(), spacing=1048576, window=32768):
+def write_gzindex(db, compressed_size, uncompressed_size, cmp_off=(), uncmp_off=(), spacing=1048576, window=32768, bits=None,
+                  has_data=None, windows=None):
     """zran export layout of util.c:461-529: "GZIDX", version 1, flags, compressed_size,
     uncompressed_size, spacing, window_size, npoints, then per point cmp_offset (u64),
     uncmp_offset (u64), bits (u8), has-data flag (u8); one window row per point with data.
     BGZF restart points sit on member boundaries: bits = 0 and no 32 KiB window is needed
-    (has-data = 0, which version-1 importers accept, util.c:621-651).  For single-stream gzip
-    no points are written (npoints = 0): the reader rebuilds them on demand (ZRAN_AUTO_BUILD,
-    index.c:70).  Checkpoint placement is not asserted by any reference test ("parity
-    unpinned", DESIGN.md)."""
+    (has-data = 0, which version-1 importers accept, util.c:621-651).  Single-stream gzip: the
+    points captured while the stream was inflated (fx_gz_checkpoints) with their bits and windows --
+    what the next open inflates in parallel from (read_gzindex -> fx_open_file_indexed).  Checkpoint
+    placement is not asserted by any reference test ("parity unpinned")."""
+    n = len(cmp_off)
+    bits = [0] * n if bits is None else [int(x) for x in bits]
+    has_data = [0] * n if has_data is None else [int(x) for x in has_data]
     db.execute("BEGIN TRANSACTION")
     rows = [b"GZIDX", struct.pack("<B", 1), struct.pack("<B", 0), struct.pack("<Q", compressed_size),
             struct.pack("<Q", uncompressed_size), struct.pack("<I", spacing), struct.pack("<I", window),
-            struct.pack("<I", len(cmp_off))]
-    for c, u in zip(cmp_off, uncmp_off):
-        rows += [struct.pack("<Q", int(c)), struct.pack("<Q", int(u)), struct.pack("<B", 0), struct.pack("<B", 0)]
+            struct.pack("<I", n)]
+    for c, u, bt, hd in zip(cmp_off, uncmp_off, bits, has_data):
+        rows += [struct.pack("<Q", int(c)), struct.pack("<Q", int(u)), struct.pack("<B", bt), struct.pack("<B", hd)]
+    if windows is not None and sum(has_data):
+        w = memoryview(windows).cast("B") if not isinstance(windows, (bytes, bytearray)) else memoryview(windows)
+        rows += [bytes(w[k * window:(k + 1) * window]) for k in range(sum(has_data))]
     db.executemany("INSERT INTO gzindex VALUES (NULL,?)", [(sqlite3.Binary(r),) for r in rows])
     db.execute("COMMIT")
+
+
+def read_gzindex(db):
+    """The restart points of a gzindex table written by write_gzindex (or by the reference: the same rows) -> dict
+    compressed_size, uncompressed_size, cmp, uncmp, bits, has, windows (numpy uint8, 32768 per point with data; None
+    when a row is missing); None when the table holds no points."""
+    import numpy as np
+    try:
+        rows = [bytes(r[0]) for r in db.execute("SELECT content FROM gzindex ORDER BY ID")]
+    except sqlite3.Error:
+        return None
+    if len(rows) < 8 or rows[0] != b"GZIDX" or rows[1][0] > 1:
+        return None
+    csize, usize = struct.unpack("<Q", rows[3])[0], struct.unpack("<Q", rows[4])[0]
+    window, n = struct.unpack("<I", rows[6])[0], struct.unpack("<I", rows[7])[0]
+    if n == 0 or len(rows) < 8 + 4 * n:
+        return None
+    cmp_ = np.array([struct.unpack("<Q", rows[8 + 4 * i])[0] for i in range(n)], dtype=np.int64)
+    unc = np.array([struct.unpack("<Q", rows[9 + 4 * i])[0] for i in range(n)], dtype=np.int64)
+    bits = np.array([rows[10 + 4 * i][0] for i in range(n)], dtype=np.uint8)
+    has = np.array([rows[11 + 4 * i][0] for i in range(n)], dtype=np.uint8)
+    wrows = rows[8 + 4 * n:]
+    windows = None
+    if window == 32768 and len(wrows) == int(has.sum()) and all(len(w) == window for w in wrows):
+        windows = np.frombuffer(b"".join(wrows), dtype=np.uint8) if wrows else np.zeros(0, dtype=np.uint8)
+    return {"compressed_size": csize, "uncompressed_size": usize, "cmp": cmp_, "uncmp": unc, "bits": bits, "has": has, "windows": windows}
 
 
 def has_fasta_index(db):

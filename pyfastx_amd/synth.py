@@ -210,3 +210,27 @@ def bgzf_compress(raw, block=65280, level=6):
         out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + cd +
                    struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
     return b"".join(out)
+
+
+# --------------------------------------------------------------------------- single-stream gzip, compressed in parallel
+def _deflate_piece(args):
+    import zlib
+    chunk, last, level = args
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    return co.compress(chunk) + co.flush(zlib.Z_FINISH if last else zlib.Z_FULL_FLUSH)
+
+
+def gzip_single_stream(raw, pool=None, piece=8 << 20, level=6):
+    """ONE gzip member (one header, one deflate stream, one trailer) holding `raw`, compressed piece by piece the way pigz
+    does it: every piece is deflated on its own and ends on a full flush (byte aligned, no final block), the last one
+    finishes the stream; concatenated they are a single valid deflate stream.  pool: a multiprocessing pool (setup speed
+    only).  Not BGZF: there are no member boundaries to restart from -- the shape zran-style checkpoints exist for."""
+    import struct
+    import zlib
+    mv = memoryview(raw)
+    jobs = [(bytes(mv[a:a + piece]), a + piece >= len(mv), level) for a in range(0, max(len(mv), 1), piece)]
+    parts = pool.map(_deflate_piece, jobs, chunksize=1) if pool is not None else [_deflate_piece(j) for j in jobs]
+    crc = 0
+    for a in range(0, len(mv), 64 << 20):
+        crc = zlib.crc32(mv[a:a + (64 << 20)], crc)
+    return b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\xff" + b"".join(parts) + struct.pack("<II", crc & 0xFFFFFFFF, len(mv) & 0xFFFFFFFF)
