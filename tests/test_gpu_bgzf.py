@@ -142,10 +142,9 @@ def test_single_stream_gzip_checkpoints(L, tmp_path, shape):
             k += 1
             assert win == raw[u - 32768:u] if u >= 32768 else win[-u:] == raw[:u]
             d = zlib.decompressobj(-15, zdict=win)
-        if bits:                                               # python's zlib has no inflatePrime: re-align the bit stream by hand
-            acc = int.from_bytes(gz[c - 1:c + 200_000], "little") >> (8 - bits)
-            data = acc.to_bytes(200_001, "little")
-        got = d.decompress(data, 50_000)
+        if bits:                                               # python's zlib has no inflatePrime (and a shifted copy of the stream breaks
+            continue                                           # the byte alignment of stored blocks): the parallel re-open below uses
+        got = d.decompress(data, 50_000)                       # every point with the real inflatePrime
         assert got == raw[u:u + len(got)] and len(got) > 0, (shape, i)
     # the index file carries them; the next open inflates in parallel and sees the same stream
     import pyfastx_amd as fx
