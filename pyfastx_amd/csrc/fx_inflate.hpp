@@ -22,9 +22,10 @@
 //                   out[dst + j] = out[src + j % dist] has no dependency inside a token, run
 //                   replication (dist < len) included.
 // This replaces the serial gzread() inflate that feeds the reference's scan (kseq.c:70) and the
-// zran_seek/zran_read random access (index.c:685-686).  The decoder is the canonical-code
-// "count/symbol" scheme (no 2 KiB fast tables): per work-item state is 16+288+16+32 16-bit words,
-// kept in LDS (44 KiB per 64-lane workgroup), code lengths for dynamic blocks in private memory.
+// zran_seek/zran_read random access (index.c:685-686).  The decoder reads a symbol with one or two LDS look-ups (8-bit
+// literal/length and 6-bit distance root tables + sub-tables per work-item, 52 KiB per 64-lane workgroup); codes in no
+// table fall back to the canonical "count/symbol" walk of zlib's contrib/puff (a public algorithm, not part of the
+// reference tree).  Code lengths for dynamic blocks live in private memory.  (See the note at struct Huff.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,7 +35,7 @@ namespace fx {
 #ifndef FX_INFL_BLOCK
 #define FX_INFL_BLOCK 64
 #endif
-constexpr int INFL_BLOCK = FX_INFL_BLOCK; // decode: members per workgroup (one wave, possibly partly filled); 0.7 KiB of LDS tables each
+constexpr int INFL_BLOCK = FX_INFL_BLOCK; // decode: members per workgroup = one wave (32 and 16 measured: 17.9 and 23.5 ms against 17.4); 832 B of LDS tables each
 constexpr int MAXBITS = 15, MAXLCODES = 286, MAXDCODES = 30, FIXLCODES = 288;
 
 enum InflStatus { INFL_OK = 0, INFL_EINPUT = 1, INFL_EOUTPUT = 2, INFL_EBLOCK = 3, INFL_ECODES = 4, INFL_EDIST = 5,
@@ -42,38 +43,37 @@ enum InflStatus { INFL_OK = 0, INFL_EINPUT = 1, INFL_EOUTPUT = 2, INFL_EBLOCK = 
 
 typedef uint64_t __attribute__((aligned(1))) uint64_u;    // 8 bytes at any address (gfx9 unaligned access mode)
 
-// Bit reader.  The compressed bytes are consumed through a window (w0, w1, w2) of aligned 8-byte words; when
-// the read position crosses into w1, w2 moves up and the word after it is requested -- two words (~6 symbols of
-// work) before it is needed, so the decoder does not wait for input.  (The buffer is readable 32 bytes past
+// Bit reader.  `next` holds the 8 bytes at the read position p, requested (one unaligned 8-byte load off the kernel
+// argument) by the refill BEFORE: a refill ORs them into the bit buffer, advances p by the whole bytes that fitted and
+// at once requests the 8 bytes at the new p -- which is exactly what the following refill will want, a whole symbol
+// later.  No window of aligned words to rotate: the rotation's register copies made the compiler wait for the word it
+// had just requested (1-2 us per 8 bytes of input), and a pointer rebuilt from an integer is a FLAT pointer whose loads
+// count as LDS traffic, so every table look-up waited for the prefetch as well.  (The buffer is readable 48 bytes past
 // the last member.)
 struct BitIn {
-    const uint8_t *p, *end;      // next unconsumed byte, end of the member's payload
-    const uint64_t *q;           // aligned word that holds *p
-    uint64_t w0, w1, w2;         // q[0], q[1], q[2]
+    const uint8_t *base;         // the member's payload in the compressed buffer (global memory, off the kernel argument)
+    uint32_t p, end;             // byte offsets in it (a member is < 64 KiB): next unconsumed byte, end of the payload
+    uint64_t next;               // the 8 bytes at p
     uint64_t buf;
-    int cnt;
+    int cnt;                     // bits in buf; the symbol loop lets it go negative (= input exhausted) and checks once per symbol
     int err;
 };
-__device__ __forceinline__ void bit_init(BitIn &b, const uint8_t *p, const uint8_t *end) {
-    b.p = p; b.end = end; b.buf = 0; b.cnt = 0; b.err = 0;
-    b.q = reinterpret_cast<const uint64_t *>((uintptr_t)p & ~(uintptr_t)7);
-    b.w0 = b.q[0]; b.w1 = b.q[1]; b.w2 = b.q[2];
+__device__ __forceinline__ void bit_init(BitIn &b, const uint8_t *cbuf, int64_t p, int64_t end) {
+    b.base = cbuf + p; b.p = 0; b.end = (uint32_t)(end - p); b.buf = 0; b.cnt = 0; b.err = 0;
+    b.next = *reinterpret_cast<const uint64_u *>(b.base);
 }
-// tops the bit buffer up to >= 56 bits; the bits of a partially consumed byte are OR-ed in again by the
-// next refill at the same position: same data, harmless
+// tops the bit buffer up to >= 56 bits (branch-free; a refill of a full buffer moves nothing); the bits of a partially
+// consumed byte are OR-ed in again by the next refill at the same position: same data, harmless
 __device__ __forceinline__ void refill(BitIn &b) {
-    const int s = (int)((uintptr_t)b.p & 7) * 8;
-    const uint64_t w = s ? (b.w0 >> s) | (b.w1 << (64 - s)) : b.w0;      // the 8 bytes at p
-    int64_t avail = b.end - b.p;                                          // bytes of this member left
-    uint64_t v = w;
-    if (avail < 8) v = avail <= 0 ? 0 : (w & (~0ull >> (64 - 8 * avail)));   // never feed bytes of the next member
+    const uint32_t avail = b.end - b.p;                                   // bytes of this member left
+    uint64_t v = b.next;
+    if (avail < 8) v = avail == 0 ? 0 : (v & (~0ull >> (64 - 8 * avail)));   // never feed bytes of the next member
     b.buf |= v << b.cnt;
-    int take = (63 - b.cnt) >> 3;
-    if (take > avail) take = avail < 0 ? 0 : (int)avail;
+    uint32_t take = (uint32_t)(63 - b.cnt) >> 3;
+    take = take > avail ? avail : take;
     b.p += take;
-    b.cnt += take * 8;
-    const uint64_t *nq = reinterpret_cast<const uint64_t *>((uintptr_t)b.p & ~(uintptr_t)7);
-    if (nq != b.q) { b.q = nq; b.w0 = b.w1; b.w1 = b.w2; b.w2 = nq[2]; }   // at most one word forward: take <= 7
+    b.cnt += (int)take * 8;
+    b.next = *reinterpret_cast<const uint64_u *>(b.base + b.p);
 }
 __device__ __forceinline__ uint32_t getbits(BitIn &b, int n) {
     if (b.cnt < n) { refill(b); if (b.cnt < n) { b.err = 1; return 0; } }
@@ -82,31 +82,44 @@ __device__ __forceinline__ uint32_t getbits(BitIn &b, int n) {
     return v;
 }
 
-// LDS-resident canonical Huffman table of one work-item: column `lane` of cnt[][64] / sym[][64].
-struct Huff { uint16_t *cnt; uint16_t *sym; };     // element i of this lane is ptr[i * INFL_BLOCK]
+// Huffman tables of one work-item (column `lane` of the LDS arrays: element i of this lane is ptr[i * INFL_BLOCK]).
+//   lut    root table: index = the next LBITS (literal/length) or DBITS (distance) bits of the stream;
+//          entry = symbol << 4 | code length for codes that fit the index, LINK | offset << 4 | k for the codes that share
+//          these bits and are longer (a sub-table of 2^k entries in `pool`, indexed by the following k bits, entry =
+//          symbol << 4 | remaining length), 0 for unused codes and when the pool is full (-> slow path).
+//   pool   POOL entries per work-item shared by the sub-tables of both codes of a block
+//   sym, cnt (GLOBAL scratch, 320 + 32 words per member): symbols in canonical order and codes per length, read by the
+//          slow path only -- the canonical walk of zlib's contrib/puff (a public algorithm, not part of the reference
+//          tree) -- which no stream of a well-behaved compressor ever reaches.
+// What the stream of a genome looks like decides the sizes: ~13 k symbols per 64 KiB member, three quarters of them
+// matches (zlib takes any match it finds in four-letter text; mean length 6.5), length codes of 2-10 bits, distance
+// codes of 3-12 bits + up to 13 extra bits; one dynamic block per member.  With 832 B per member every member of the
+// file is resident at once (46 723 members = 731 waves on 256 CUs x 3 workgroups), which matters more than anything
+// else here: a member is ONE serial chain of symbols, so the kernel's time is that chain's latency, not anybody's
+// throughput -- and because 64 members share a wave, a path that ONE lane takes is paid for by all of them: a rare slow
+// path (3 % of the symbols) ran in 9 of 10 iterations and made the first table-driven version slower than the bit-serial
+// walk it replaced.  Hence the sub-tables: every code of a normal stream is one or two LDS reads.
+// Measured on the 3.05 GB C4 file (profiles/r02_*): 32.1 ms for the round-1 kernel, of which most was the bit reader's
+// state living in scratch memory behind a non-inlined call; 17 ms now.  PMC (profiles/r02_pmc_bgzf.txt): 160 VALU + 64
+// SALU instructions and 3 LDS reads per symbol, 43 % of the wave cycles issuing, 53 % parked in s_waitcnt; the time moves
+// with neither the instruction count (a 30 % leaner loop: the same) nor the waves per SIMD, and leaving both stores out
+// takes 4 ms off -- what is left is the chain  load 8 bytes -> table -> table  of one symbol after the other.
+constexpr int LBITS = 8, DBITS = 6, POOL = 96, GSYM = 320 + 32;
+constexpr uint32_t LINK = 0x8000u;
+struct Huff { uint16_t *lut; uint16_t *pool; uint16_t *sym; uint16_t *cnt; int bits; };     // sym, cnt: global, contiguous
 
-// The per-length code counts of a table live in REGISTERS while it is in use (16 x 16 bits in 8 VGPRs): the
-// canonical decode walks code lengths 1..15 without touching LDS, and only the final symbol is one LDS read.
-// (With one wave per SIMD at most -- a genome is ~47 k members -- nothing hides a chain of dependent LDS reads.)
-struct HuffCnt { uint32_t c[8]; };
-__device__ __forceinline__ void load_counts(const Huff &h, HuffCnt &r) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r.c[i] = (uint32_t)h.cnt[(2 * i) * INFL_BLOCK] | ((uint32_t)h.cnt[(2 * i + 1) * INFL_BLOCK] << 16);
-}
-
-__device__ __forceinline__ int decode(BitIn &b, const Huff &h, const HuffCnt &r) {
-    if (b.cnt < MAXBITS) refill(b);
+// canonical walk, one code length per step: only for codes that are in no table
+__device__ __forceinline__ int decode_slow(BitIn &b, const Huff &h) {
     uint32_t bits = (uint32_t)b.buf;
     int code = 0, first = 0, index = 0;
-#pragma unroll
     for (int len = 1; len <= MAXBITS; ++len) {
         code |= (int)(bits & 1u);
         bits >>= 1;
-        const int count = (int)((r.c[len >> 1] >> (16 * (len & 1))) & 0xFFFFu);
+        const int count = (int)h.cnt[len];
         if (code - count < first) {
             if (b.cnt < len) { b.err = 1; return -1; }
             b.buf >>= len; b.cnt -= len;
-            return h.sym[(index + (code - first)) * INFL_BLOCK];
+            return h.sym[index + (code - first)];
         }
         index += count; first += count;
         first <<= 1; code <<= 1;
@@ -114,23 +127,87 @@ __device__ __forceinline__ int decode(BitIn &b, const Huff &h, const HuffCnt &r)
     b.err = 1;
     return -1;
 }
+// next symbol; the caller has made sure of >= 15 bits in the buffer (or the input is at its end)
+__device__ __forceinline__ int decode(BitIn &b, const Huff &h) {
+    uint32_t e = h.lut[((uint32_t)b.buf & ((1u << h.bits) - 1u)) * INFL_BLOCK];
+    int len = (int)(e & 15u);
+    if (e & LINK) {                                          // a longer code: the sub-table of these leading bits
+        const uint32_t sub = ((uint32_t)(b.buf >> h.bits)) & ((1u << len) - 1u);
+        e = h.pool[(((e >> 4) & 0x7FFu) + sub) * INFL_BLOCK];
+        len = (e & 15u) ? (int)(e & 15u) + h.bits : 0;
+    }
+    if (__builtin_expect(len != 0, 1)) {
+        if (b.cnt < len) { b.err = 1; return -1; }
+        b.buf >>= len; b.cnt -= len;
+        return (int)(e >> 4);
+    }
+    return decode_slow(b, h);
+}
 
-// Build count/symbol from code lengths (canonical codes).  Returns <0 for an over-subscribed set.
-__device__ inline int construct(const Huff &h, const uint8_t *length, int n) {
-    for (int len = 0; len <= MAXBITS; ++len) h.cnt[len * INFL_BLOCK] = 0;
-    for (int s = 0; s < n; ++s) h.cnt[length[s] * INFL_BLOCK]++;
-    if (h.cnt[0] == n) return 0;
+// Build the tables from code lengths (canonical codes).  Returns <0 for an over-subscribed set, >0 incomplete.
+// pool_used: entries of the work-item's pool taken so far (the two codes of a block share it).
+__device__ __noinline__ int construct(const Huff &h, const uint8_t *length, int n, int &pool_used) {
+    uint16_t count[MAXBITS + 1], offs[MAXBITS + 1], next[MAXBITS + 1];
+    for (int len = 0; len <= MAXBITS; ++len) count[len] = 0;
+    for (int s = 0; s < n; ++s) count[length[s]]++;
+    const int size = 1 << h.bits;
+    for (int i = 0; i < size; ++i) h.lut[i * INFL_BLOCK] = 0;
+    for (int len = 1; len <= MAXBITS; ++len) h.cnt[len] = count[len];
+    if (count[0] == n) return 0;
     int left = 1;
     for (int len = 1; len <= MAXBITS; ++len) {
         left <<= 1;
-        left -= h.cnt[len * INFL_BLOCK];
+        left -= count[len];
         if (left < 0) return left;
     }
-    uint16_t offs[MAXBITS + 1];
-    offs[1] = 0;
-    for (int len = 1; len < MAXBITS; ++len) offs[len + 1] = offs[len] + h.cnt[len * INFL_BLOCK];
-    for (int s = 0; s < n; ++s)
-        if (length[s] != 0) h.sym[(offs[length[s]]++) * INFL_BLOCK] = (uint16_t)s;
+    offs[1] = 0; next[1] = 0;
+    for (int len = 1; len < MAXBITS; ++len) {
+        offs[len + 1] = offs[len] + count[len];
+        next[len + 1] = (uint16_t)((next[len] + count[len]) << 1);
+    }
+    bool any_long = false;
+    for (int s = 0; s < n; ++s) {
+        const int L = length[s];
+        if (!L) continue;
+        h.sym[offs[L]++] = (uint16_t)s;
+        const uint32_t code = next[L]++;
+        const uint32_t rev = __brev(code) >> (32 - L);       // the stream carries codes most significant bit first, bits least first
+        if (L <= h.bits) {
+            const uint16_t e = (uint16_t)((s << 4) | L);
+            for (uint32_t i = rev; i < (uint32_t)size; i += 1u << L) h.lut[i * INFL_BLOCK] = e;
+        } else {                                             // pass A: how many further bits do the codes under this root entry need?
+            const uint32_t p = rev & (uint32_t)(size - 1);
+            const uint32_t need = (uint32_t)(L - h.bits), have = h.lut[p * INFL_BLOCK] & 15u;
+            if (need > have) h.lut[p * INFL_BLOCK] = (uint16_t)(LINK | need);
+            any_long = true;
+        }
+    }
+    if (!any_long) return left;
+    for (int p = 0; p < size; ++p) {                         // pass B: a sub-table per such root entry, while the pool lasts
+        const uint32_t e = h.lut[p * INFL_BLOCK];
+        if (!(e & LINK)) continue;
+        const int k = (int)(e & 15u);
+        if (pool_used + (1 << k) > POOL) { h.lut[p * INFL_BLOCK] = 0; continue; }     // (those codes take the slow path)
+        h.lut[p * INFL_BLOCK] = (uint16_t)(LINK | ((uint32_t)pool_used << 4) | (uint32_t)k);
+        for (int i = 0; i < (1 << k); ++i) h.pool[(pool_used + i) * INFL_BLOCK] = 0;
+        pool_used += 1 << k;
+    }
+    for (int len = 1; len <= MAXBITS; ++len) next[len] = 0;   // pass C: the long codes again, in the same canonical order
+    next[1] = 0;
+    for (int len = 1; len < MAXBITS; ++len) next[len + 1] = (uint16_t)((next[len] + count[len]) << 1);
+    for (int s = 0; s < n; ++s) {
+        const int L = length[s];
+        if (!L) continue;
+        const uint32_t code = next[L]++;
+        if (L <= h.bits) continue;
+        const uint32_t rev = __brev(code) >> (32 - L);
+        const uint32_t e = h.lut[(rev & (uint32_t)(size - 1)) * INFL_BLOCK];
+        if (!(e & LINK)) continue;
+        const int k = (int)(e & 15u), rest = L - h.bits;
+        const uint32_t off = (e >> 4) & 0x7FFu;
+        const uint16_t v = (uint16_t)((s << 4) | rest);
+        for (uint32_t i = rev >> h.bits; i < (1u << k); i += 1u << rest) h.pool[(off + i) * INFL_BLOCK] = v;
+    }
     return left;
 }
 
@@ -150,39 +227,115 @@ __device__ const uint8_t CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4,
 __device__ __forceinline__ uint64_t tok_pack(int64_t dst, int len, int64_t dist) { return (uint64_t)dst | ((uint64_t)len << 17) | ((uint64_t)dist << 26); }
 
 // Literal/length + distance codes of one block: literals -> out[o...], matches -> tok[nt...].
-__device__ inline int inflate_codes(BitIn &b, const Huff &lc, const Huff &dc, uint8_t *out, int64_t &o, int64_t cap,
-                                    uint64_t *tok, int &nt) {
-    HuffCnt lr, dr;
-    load_counts(lc, lr); load_counts(dc, dr);
+// One refill per symbol: a literal/length code (<= 15 bits) with its extra bits (<= 5) and a distance code (<= 15)
+// with its extra bits (<= 13) are 48 bits, the refill leaves >= 56.
+// (Everything that touches the bit reader is force-inlined into the kernel: one call that takes `BitIn &` puts the
+// reader's state into scratch memory, and then every symbol costs a dozen round trips to it -- that, not the Huffman
+// walk, was the 32 ms of the first version.)
+__device__ __forceinline__ int inflate_codes(BitIn &b, const Huff &lc, const Huff &dc, uint8_t *out, int64_t &o, int64_t cap,
+                                             uint64_t *tok, int &nt) {
+    // The loop's memory traffic per symbol is ONE request for the next 8 input bytes and ONE store (a literal byte or
+    // a match token).  vmcnt counts both and the compiler, asked to wait for the input bytes, waits for "everything"
+    // -- i.e. for the store of the symbol before to be acknowledged by the L2, ~2 800 cycles per symbol, which WAS the
+    // kernel's time.  So the request is issued by hand (the compiler does not see it) and waited for with vmcnt(2) right
+    // after the symbol's two stores: memory operations of a wave complete in issue order on gfx9, so "at most two
+    // outstanding" means the request is back while the stores are still on their way.  Paths that leave the loop
+    // without the stores wait for everything.
+    int ret = -1;
+    uint64_t cur = b.next;
+    asm volatile("" : "+v"(cur));                            // (the compiler's own wait for the load behind b.next happens HERE, not at the top of every iteration)
+    // the loop works on copies in registers of 32-bit quantities: positions inside the member and its output (both < 2^17)
+    uint64_t buf = b.buf;
+    int cnt = b.cnt;
+    uint32_t pos = b.p, oo = (uint32_t)o;
+    const uint32_t end = b.end, ocap = (uint32_t)cap;
+    const uint8_t *const base = b.base;
+    uint16_t *const llut = lc.lut, *const dlut = dc.lut, *const pool = lc.pool;
+    BitIn sb;                                                // what the slow path works on
+    sb.err = 0;
     for (;;) {
-        int sym = decode(b, lc, lr);
-        if (sym < 0) return INFL_EINPUT;
-        if (sym < 256) {
-            if (o >= cap) return INFL_EOUTPUT;
-            out[o++] = (uint8_t)sym;
-        } else if (sym == 256) {
-            return INFL_OK;
-        } else {
+        // refill from the 8 bytes at pos (cur: valid here), then ask for the 8 bytes at the new position
+        const uint32_t avail = end - pos;
+        uint64_t v = cur;
+        if (__builtin_expect(avail < 8, 0)) v = avail == 0 ? 0 : (v & (~0ull >> (64 - 8 * avail)));
+        buf |= v << cnt;
+        uint32_t take = (uint32_t)(63 - cnt) >> 3;
+        take = take > avail ? avail : take;
+        pos += take;
+        cnt += (int)take * 8;
+        uint64_t nxt;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(nxt) : "v"(base + pos) : "memory");
+        // literal / length symbol
+        uint32_t e = llut[((uint32_t)buf & ((1u << LBITS) - 1u)) * INFL_BLOCK];
+        int len = (int)(e & 15u);
+        if (e & LINK) {
+            const uint32_t sub = ((uint32_t)(buf >> LBITS)) & ((1u << len) - 1u);
+            e = pool[(((e >> 4) & 0x7FFu) + sub) * INFL_BLOCK];
+            len = (e & 15u) ? (int)(e & 15u) + LBITS : 0;
+        }
+        int sym = (int)(e >> 4);
+        if (__builtin_expect(len == 0, 0)) {                 // in no table
+            sb.buf = buf; sb.cnt = cnt;
+            sym = decode_slow(sb, lc);
+            buf = sb.buf; cnt = sb.cnt;
+            if (sym < 0) { ret = INFL_EINPUT; break; }
+        } else { buf >>= len; cnt -= len; }
+        if (sym == 256) { ret = cnt < 0 ? INFL_EINPUT : INFL_OK; break; }
+        const bool lit = sym < 256;
+        uint64_t t = 0;
+        uint32_t adv = 1;
+        if (!lit) {
             sym -= 257;
-            if (sym >= 29) return INFL_ECODES;
+            if (sym >= 29) { ret = INFL_ECODES; break; }
             int lb, le, db, de;
             len_code(sym, lb, le);
-            const int len = lb + (int)getbits(b, le);
-            const int ds = decode(b, dc, dr);
-            if (ds < 0 || ds >= 30) return INFL_EINPUT;
+            const uint32_t mlen = (uint32_t)lb + ((uint32_t)buf & ((1u << le) - 1u));
+            buf >>= le; cnt -= le;
+            uint32_t d = dlut[((uint32_t)buf & ((1u << DBITS) - 1u)) * INFL_BLOCK];
+            int dl = (int)(d & 15u);
+            if (d & LINK) {
+                const uint32_t sub = ((uint32_t)(buf >> DBITS)) & ((1u << dl) - 1u);
+                d = pool[(((d >> 4) & 0x7FFu) + sub) * INFL_BLOCK];
+                dl = (d & 15u) ? (int)(d & 15u) + DBITS : 0;
+            }
+            int ds = (int)(d >> 4);
+            if (__builtin_expect(dl == 0, 0)) {
+                sb.buf = buf; sb.cnt = cnt;
+                ds = decode_slow(sb, dc);
+                buf = sb.buf; cnt = sb.cnt;
+                if (ds < 0) { ret = INFL_EINPUT; break; }
+            } else { buf >>= dl; cnt -= dl; }
+            if (ds >= 30) { ret = INFL_EINPUT; break; }
             dist_code(ds, db, de);
-            const int64_t dist = db + (int64_t)getbits(b, de);
-            if (b.err) return INFL_EINPUT;
-            if (dist > o) return INFL_EDIST;                 // BGZF members never reference outside themselves
-            if (o + len > cap) return INFL_EOUTPUT;
-            tok[nt++] = tok_pack(o, len, dist);              // at most cap / 3 of them: a match is >= 3 bytes
-            o += len;
+            const uint32_t dist = (uint32_t)db + ((uint32_t)buf & ((1u << de) - 1u));
+            buf >>= de; cnt -= de;
+            if (dist > oo) { ret = INFL_EDIST; break; }      // BGZF members never reference outside themselves
+            t = (uint64_t)oo | ((uint64_t)mlen << 17) | ((uint64_t)dist << 26);        // tok_pack
+            adv = mlen;
+            sym = 0;
         }
+        if (cnt < 0) { ret = INFL_EINPUT; break; }           // the symbol took bits the member does not have
+        if (oo + adv > ocap) { ret = INFL_EOUTPUT; break; }
+        // exactly TWO stores per symbol, whatever it is (lanes of one wave decode different kinds at the same moment, and
+        // a store under a branch would be one instruction per kind): the byte -- of a match, a place holder that
+        // k_bgzf_copy overwrites -- and the token slot -- of a literal, the slot the next match will fill
+        out[oo] = (uint8_t)sym;
+        tok[nt] = t;
+        nt += lit ? 0 : 1;
+        oo += adv;
+        asm volatile("s_waitcnt vmcnt(2)" : "+v"(nxt) : : "memory");       // the request is back; this symbol's stores need not be
+        cur = nxt;
     }
+    uint64_t keep = 0;
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(keep) : : "memory");           // left without the stores: everything, then read p again
+    b.buf = buf; b.cnt = cnt < 0 ? 0 : cnt; b.p = pos; o = oo;
+    b.next = *reinterpret_cast<const uint64_u *>(b.base + b.p);
+    return ret;
 }
 
 // members: cdata_off/cdata_len (compressed payload inside cbuf), uoff (offset in the inflated stream), isize.
 // tok_off[m]: first token slot of member m (isize / 3 + 1 slots each); ntok[m]: tokens written.
+// gsym: GSYM words of scratch per member (the canonical symbol order of its current tables: slow path only).
 __global__ __launch_bounds__(INFL_BLOCK) void k_bgzf_decode(const uint8_t *__restrict__ cbuf,
                                                            const int64_t *__restrict__ cdata_off,
                                                            const int32_t *__restrict__ cdata_len,
@@ -190,15 +343,16 @@ __global__ __launch_bounds__(INFL_BLOCK) void k_bgzf_decode(const uint8_t *__res
                                                            const int32_t *__restrict__ isize, int64_t nmem,
                                                            uint8_t *__restrict__ data, int32_t *__restrict__ status,
                                                            uint64_t *__restrict__ tokens, const int64_t *__restrict__ tok_off,
-                                                           int32_t *__restrict__ ntok) {
-    __shared__ uint16_t t_lcnt[(MAXBITS + 1) * INFL_BLOCK], t_lsym[FIXLCODES * INFL_BLOCK];
-    __shared__ uint16_t t_dcnt[(MAXBITS + 1) * INFL_BLOCK], t_dsym[32 * INFL_BLOCK];
+                                                           int32_t *__restrict__ ntok, uint16_t *__restrict__ gsym) {
+    __shared__ uint16_t t_llut[(1 << LBITS) * INFL_BLOCK], t_dlut[(1 << DBITS) * INFL_BLOCK], t_pool[POOL * INFL_BLOCK];
     const int lane = threadIdx.x;
     const int64_t m = (int64_t)blockIdx.x * INFL_BLOCK + lane;
     if (m >= nmem) return;
-    Huff lc{t_lcnt + lane, t_lsym + lane}, dc{t_dcnt + lane, t_dsym + lane};
+    uint16_t *gs = gsym + m * GSYM;                          // 288 + 32 symbols, 16 + 16 counts
+    Huff lc{t_llut + lane, t_pool + lane, gs, gs + 320, LBITS}, dc{t_dlut + lane, t_pool + lane, gs + FIXLCODES, gs + 336, DBITS};
+    int pool_used = 0;
     BitIn b;
-    bit_init(b, cbuf + cdata_off[m], cbuf + cdata_off[m] + cdata_len[m]);
+    bit_init(b, cbuf, cdata_off[m], cdata_off[m] + cdata_len[m]);
     uint64_t *tok = tokens + tok_off[m];
     int nt = 0;
     uint8_t *out = data + uoff[m];
@@ -223,23 +377,22 @@ __global__ __launch_bounds__(INFL_BLOCK) void k_bgzf_decode(const uint8_t *__res
             for (; s < 256; ++s) lengths[s] = 9;
             for (; s < 280; ++s) lengths[s] = 7;
             for (; s < FIXLCODES; ++s) lengths[s] = 8;
-            construct(lc, lengths, FIXLCODES);
+            pool_used = 0;
+            construct(lc, lengths, FIXLCODES, pool_used);
             for (s = 0; s < MAXDCODES; ++s) lengths[s] = 5;
-            construct(dc, lengths, MAXDCODES);
-            st = inflate_codes(b, lc, dc, out, o, cap, tok, nt);
-            if (st) break;
+            construct(dc, lengths, MAXDCODES, pool_used);
         } else if (type == 2) {                              // dynamic codes
             const int nlen = (int)getbits(b, 5) + 257, ndist = (int)getbits(b, 5) + 1, ncode = (int)getbits(b, 4) + 4;
             if (b.err || nlen > MAXLCODES || ndist > MAXDCODES) { st = INFL_ECODES; break; }
             int idx = 0;
             for (; idx < ncode; ++idx) lengths[CLORDER[idx]] = (uint8_t)getbits(b, 3);
             for (; idx < 19; ++idx) lengths[CLORDER[idx]] = 0;
-            if (construct(lc, lengths, 19) != 0) { st = INFL_ECODES; break; }     // code-length code must be complete
+            pool_used = 0;
+            if (construct(lc, lengths, 19, pool_used) != 0) { st = INFL_ECODES; break; }     // code-length code must be complete
             idx = 0;
-            HuffCnt cr;
-            load_counts(lc, cr);
             while (idx < nlen + ndist) {
-                int sym = decode(b, lc, cr);
+                if (b.cnt < 24) refill(b);
+                int sym = decode(b, lc);
                 if (sym < 0) { st = INFL_EINPUT; break; }
                 if (sym < 16) lengths[idx++] = (uint8_t)sym;
                 else {
@@ -256,13 +409,20 @@ __global__ __launch_bounds__(INFL_BLOCK) void k_bgzf_decode(const uint8_t *__res
             if (st) break;
             if (b.err) { st = INFL_EINPUT; break; }
             if (lengths[256] == 0) { st = INFL_ECODES; break; }
-            int err = construct(lc, lengths, nlen);
-            if (err < 0 || (err > 0 && nlen - lc.cnt[0] != 1)) { st = INFL_ECODES; break; }
-            err = construct(dc, lengths + nlen, ndist);
-            if (err < 0 || (err > 0 && ndist - dc.cnt[0] != 1)) { st = INFL_ECODES; break; }
+            int nz = 0;
+            for (int s = 0; s < nlen; ++s) nz += lengths[s] != 0;
+            pool_used = 0;
+            int err = construct(lc, lengths, nlen, pool_used);
+            if (err < 0 || (err > 0 && nz != 1)) { st = INFL_ECODES; break; }
+            nz = 0;
+            for (int s = 0; s < ndist; ++s) nz += lengths[nlen + s] != 0;
+            err = construct(dc, lengths + nlen, ndist, pool_used);
+            if (err < 0 || (err > 0 && nz != 1)) { st = INFL_ECODES; break; }
+        } else { st = INFL_EBLOCK; break; }
+        if (type != 0) {                                     // the one place the codes are decoded (see inflate_codes)
             st = inflate_codes(b, lc, dc, out, o, cap, tok, nt);
             if (st) break;
-        } else { st = INFL_EBLOCK; break; }
+        }
     } while (!last);
     if (st == INFL_OK && o != cap) st = INFL_ESIZE;          // ISIZE of the member trailer must match
     status[m] = st;

@@ -452,8 +452,8 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
     DevBuf<int64_t> d_coff, d_uoff;
     DevBuf<int32_t> d_clen, d_isize, d_status;
     int rc;
-    if ((rc = d_c.alloc(fsize + 40))) return rc;          // the bit reader looks two 8-byte words ahead
-    HIPCHK(hipMemsetAsync(d_c.p + fsize, 0, 40, h->stream));
+    if ((rc = d_c.alloc(fsize + 48))) return rc;          // the bit reader looks three 8-byte words ahead
+    HIPCHK(hipMemsetAsync(d_c.p + fsize, 0, 48, h->stream));
     if ((rc = stage_plain_file(h, fd, fsize, path, d_c.p, c0))) return rc;
     if ((rc = upload(h, d_coff, t.coff)) || (rc = upload(h, d_uoff, t.uoff)) || (rc = upload(h, d_clen, t.clen)) ||
         (rc = upload(h, d_isize, t.isize)))
@@ -467,11 +467,13 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
     DevBuf<int32_t> d_ntok;
     if ((rc = d_tok.alloc(toff[(size_t)nmem])) || (rc = upload(h, d_toff, toff)) || (rc = d_ntok.alloc(nmem))) return rc;
     if ((rc = d_status.alloc(nmem))) return rc;
+    DevBuf<uint16_t> d_gsym;                                 // canonical symbol order of every member's tables (slow path of the decoder)
+    if ((rc = d_gsym.alloc(nmem * GSYM))) return rc;
     HIPCHK(hipMemsetAsync(d_status.p, 0xFF, (size_t)nmem * 4, h->stream));
     HIPCHK(hipMemsetAsync(d_ntok.p, 0, (size_t)nmem * 4, h->stream));
     if ((rc = alloc_blob(h, t.total))) return rc;
     FX_LAUNCH(h, K_BGZF_INFLATE, k_bgzf_decode, dim3(nblocks(nmem, INFL_BLOCK)), dim3(INFL_BLOCK), d_c.p, d_coff.p,
-              d_clen.p, d_uoff.p, d_isize.p, nmem, h->d_data, d_status.p, d_tok.p, d_toff.p, d_ntok.p);
+              d_clen.p, d_uoff.p, d_isize.p, nmem, h->d_data, d_status.p, d_tok.p, d_toff.p, d_ntok.p, d_gsym.p);
     FX_LAUNCH(h, K_BGZF_COPY, k_bgzf_copy, dim3(nblocks(nmem, COPY_BLOCK / 64)), dim3(COPY_BLOCK), d_uoff.p, nmem, h->d_data,
               d_tok.p, d_toff.p, d_ntok.p);
     HIPCHK(hipGetLastError());
