@@ -528,10 +528,18 @@ class Blob:
 
     def fetch_one(self, off, blen, slen, flags=0, skip=0):
         """One range -> bytes (fx_fetch_one: one launch, one wait, no staging copies)."""
-        buf = C.create_string_buffer(max(int(slen), 1))
-        got = C.c_int64(0)
-        check(lib().fx_fetch_one(self._h, int(off), int(blen), int(skip), int(slen), int(flags), buf, C.byref(got)))
-        return buf.raw[:got.value]
+        slen = int(slen)
+        if slen <= 65536:                                   # the getter path: one buffer per Blob, no allocation per call
+            ob = self.__dict__.get("_one")
+            if ob is None:
+                ob = self.__dict__["_one"] = (C.create_string_buffer(65536), C.c_int64(0))
+            buf, got = ob
+        else:
+            buf, got = C.create_string_buffer(slen), C.c_int64(0)
+        rc = lib().fx_fetch_one(self._h, int(off), int(blen), int(skip), slen, int(flags), buf, C.byref(got))
+        if rc:
+            check(rc)
+        return C.string_at(buf, got.value)
 
     def fetch_ranges(self, off, blen, slen, flags=0, flags_per_query=None, skip=None):
         """-> (uint8 buffer, offsets int64[n+1] (exclusive cumsum of slen), out_len int64[n]).  skip: kept bytes dropped

@@ -320,9 +320,14 @@ class Fasta:
                 raise IndexError("Index Error")
             return self._make(row)
         if type(item) is str:
-            row = self._db.execute("SELECT * FROM seq WHERE chrom=? LIMIT 1", (item,)).fetchone()
+            cache = self.__dict__.setdefault("_rows_by_name", {})     # the B-tree probe (index.c:527-566) once per name: a genome has few
+            row = cache.get(item)
             if row is None:
-                raise KeyError("%s does not exist in fasta file" % item)
+                row = self._db.execute("SELECT * FROM seq WHERE chrom=? LIMIT 1", (item,)).fetchone()
+                if row is None:
+                    raise KeyError("%s does not exist in fasta file" % item)
+                if len(cache) < 1_000_000:
+                    cache[item] = row
             return self._make(row)
         raise KeyError("the key must be index number or sequence name")
 

@@ -425,6 +425,123 @@ __global__ __launch_bounds__(BLOCK) void k_fetch(const uint8_t *__restrict__ dat
     }
 }
 
+// ---------------------------------------------------------------- one getter at a time (fx_fetch_one)
+// The reference's object API makes one call per getter (fa[name][a:b].seq: pyfastx_index_fill_cache + a copy, 4 us of
+// pread and memcpy).  A kernel launch and a stream synchronisation per getter cost 16 us before any byte moves, so single
+// getters are served by a RESIDENT kernel instead: one wave that polls a mailbox in pinned host memory, answers the
+// request it finds there (the general path of k_fetch on one range, staged in LDS and written to pinned memory in
+// 16-byte pieces), acknowledges, and leaves by itself after `idle_limit` empty polls (it is a guest on the device: a
+// hipFree or a device-wide synchronisation elsewhere waits at most that long).  The host relaunches it on demand.
+struct Mailbox {
+    // the request: ONE 64-byte line, read by the device with one load (eight lanes, eight bytes each -- a PCIe round trip
+    // per field was most of the first version's 13 us); head and tail carry the request number and are written last and
+    // first: a torn read shows different numbers and is repeated
+    unsigned long long head;         // host -> device: number of the request (monotonic), written LAST
+    long long off, blen, skip, take;
+    long long flags_quit;            // flags | quit << 32
+    unsigned long long pad0;
+    unsigned long long tail;         // = head, written FIRST
+    // the answer, its own line
+    unsigned long long ack;          // device -> host: request number << 20 | bytes of the answer, written after the bytes are visible
+    unsigned int state;              // 1 serving, 2 about to leave (the host then watches the stream), 0 gone
+    unsigned int pad1[13];
+};
+constexpr int MB_OUT = 65536;        // longest answer the resident kernel stages (longer ones take the launch path)
+
+// (relaxed: the request's fields arrive in the same load, and everything else the kernel reads is the immutable blob --
+// an acquire here would invalidate caches under every poll, for every kernel that runs beside this one)
+__device__ __forceinline__ unsigned long long sys_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ long long bcast64(long long v, int l) {
+    return ((long long)__shfl((int)(v >> 32), l, 64) << 32) | (unsigned)__shfl((int)(v & 0xFFFFFFFFll), l, 64);
+}
+__global__ __launch_bounds__(64) void k_mailbox(const uint8_t *__restrict__ data, int64_t gbase, int64_t n_bytes, Mailbox *mb,
+                                               uint8_t *out_host, unsigned long long served, int idle_limit) {
+    __shared__ uint8_t lut[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[MB_OUT];
+    build_comp_lut(lut);
+    __syncthreads();
+    const int lane = threadIdx.x;
+    const unsigned long long *line = reinterpret_cast<const unsigned long long *>(mb);
+    int idle = 0;
+    bool leaving = false;
+    for (;;) {
+        const long long w = lane < 8 ? (long long)sys_load(line + lane) : 0;        // the whole request line, one load
+        const unsigned long long r = (unsigned long long)bcast64(w, 0), rt = (unsigned long long)bcast64(w, 7);
+        if (r == served || r != rt) {
+            if (leaving) break;                              // announced, looked once more, still nothing
+            if (++idle < idle_limit) { __builtin_amdgcn_s_sleep(1); continue; }
+            // nothing for a while: announce the departure, then look once more (the host may have posted in between)
+            if (lane == 0) { __hip_atomic_store(&mb->state, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); __threadfence_system(); }
+            leaving = true;
+            continue;
+        }
+        if (leaving) { leaving = false; if (lane == 0) __hip_atomic_store(&mb->state, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+        long long f[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f[k] = bcast64(w, 1 + k);
+        const long long fq = bcast64(w, 5);
+        const int fl = (int)(fq & 0xFFFFFFFFll), quit = (int)(fq >> 32);
+        if (quit) break;
+        const int64_t skip = f[2], take = f[3] < MB_OUT ? f[3] : MB_OUT;
+        // ---- the general path of k_fetch for one range, 1 KiB of the stream per step (jump_table, util.c:157-194)
+        int64_t lo = f[0] - gbase, hi = lo + f[1];
+        if (lo < 0) lo = 0;
+        if (hi > n_bytes) hi = n_bytes;
+        const int64_t end = skip + take;
+        int64_t rank = 0;
+        for (int64_t p = lo & ~(int64_t)15; p < hi && rank < end; p += 64 * 16) {
+            const int64_t pp = p + (int64_t)lane * 16;
+            uint32_t w[4] = {0, 0, 0, 0};
+            if (pp < hi) { const uint4 t = *reinterpret_cast<const uint4 *>(data + pp); w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w; }
+            int64_t a0 = lo - pp, a1 = hi - pp;
+            a0 = a0 < 0 ? 0 : (a0 > 16 ? 16 : a0);
+            a1 = a1 < 0 ? 0 : (a1 > 16 ? 16 : a1);
+            uint32_t km = (a1 > a0) ? (((1u << a1) - 1u) & ~((1u << a0) - 1u)) & 0xFFFFu : 0u;
+            if (!(fl & 8)) {
+                uint32_t sp = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    sp |= flags4(zero_bytes(w[k] ^ 0x0A0A0A0Au) | zero_bytes(w[k] ^ 0x0D0D0D0Du) | zero_bytes(w[k] ^ 0x20202020u)) << (4 * k);
+                km &= ~sp;
+            }
+            const uint32_t kcnt = __popc(km), inc = wave_incl_scan(kcnt);
+            const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
+            int64_t rr = rank + inc - kcnt;
+            while (km) {
+                const int j = __ffs(km) - 1;
+                km &= km - 1;
+                if (rr >= skip && rr < end) {
+                    uint8_t c = (uint8_t)(w[j >> 2] >> ((j & 3) * 8));
+                    if ((fl & 1) && c >= 'a' && c <= 'z') c -= 32;
+                    if (fl & 4) c = lut[c];
+                    const int64_t o = rr - skip;
+                    s_out[(fl & 2) ? (take - 1 - o) : o] = c;
+                }
+                ++rr;
+            }
+            rank += total;
+        }
+        int64_t got = rank - skip;
+        got = got < 0 ? 0 : (got > take ? take : got);
+        __syncthreads();
+        const int64_t delta = ((fl & 2) && got < take) ? take - got : 0;       // a reversed answer shorter than asked for sits too high
+        for (int64_t j = (int64_t)lane * 16; j < got; j += 64 * 16) {
+            uint4 v;
+            if (delta == 0) v = *reinterpret_cast<const uint4 *>(s_out + j);
+            else { uint8_t t[16]; for (int k = 0; k < 16; ++k) t[k] = j + k < got ? s_out[delta + j + k] : 0; v = *reinterpret_cast<const uint4 *>(t); }
+            *reinterpret_cast<uint4 *>(out_host + j) = v;       // (the staging buffer is 16 bytes longer than MB_OUT)
+        }
+        __threadfence_system();                              // the bytes are visible to the host ...
+        __syncthreads();
+        if (lane == 0) __hip_atomic_store(&mb->ack, (r << 20) | (unsigned long long)got, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before their count
+        served = r;
+        idle = 0;
+    }
+    if (lane == 0) __hip_atomic_store(&mb->state, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // In-place reverse / complement of one buffer (pyfastx.reverse_complement, module.c:44-59).
 __global__ __launch_bounds__(BLOCK) void k_revcomp(uint8_t *__restrict__ buf, int64_t n, int mode) {
     __shared__ uint8_t lut[256];

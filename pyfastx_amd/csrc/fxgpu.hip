@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -150,6 +151,11 @@ struct fx_handle {
     Totals *pin_tot = nullptr;                // pinned host copy of Totals (async read-back without staging)
     struct OneBox { int64_t off, blen, skip, take, dst_off, out_len; } *one_box = nullptr;   // fx_fetch_one: descriptor in pinned host memory
     uint8_t *one_out = nullptr;               // ... and its result buffer (pinned, ONE_CAP bytes): no copies either way
+    // the resident kernel that serves single getters (fx_kernels.hpp: k_mailbox)
+    Mailbox *mb = nullptr;                    // pinned host memory
+    hipStream_t mb_stream = nullptr;
+    unsigned long long mb_seq = 0;
+    bool mb_running = false, mb_off = false;  // mb_off: the mailbox failed once, single getters keep to the launch path
     // name -> id table (fx_names.hpp)
     DevBuf<uint32_t> nm_table;
     DevBuf<int64_t> nm_off;                   // FASTA: hoff + 1 materialised; FASTQ uses fq_name_off directly
@@ -223,6 +229,14 @@ static int alloc_blob(fx_handle *h, int64_t n) {
 extern "C" int fx_close(fx_handle *h) {
     if (!h) return FX_OK;
     (void)hipSetDevice(h->device);
+    if (h->mb) {                                             // send the resident kernel home
+        if (h->mb_running) {
+            const unsigned long long q = ++h->mb_seq;
+            __atomic_store_n(&h->mb->tail, q, __ATOMIC_RELEASE); h->mb->flags_quit = 1ll << 32; __atomic_store_n(&h->mb->head, q, __ATOMIC_RELEASE);
+        }
+        if (h->mb_stream) { (void)hipStreamSynchronize(h->mb_stream); (void)hipStreamDestroy(h->mb_stream); }
+        (void)hipHostFree(h->mb);
+    }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->owns && (h->d_alloc || h->d_data)) (void)hipFree(h->d_alloc ? h->d_alloc : h->d_data);
     if (h->pin_tot) (void)hipHostFree(h->pin_tot);
@@ -1599,6 +1613,56 @@ extern "C" int fx_fetch_one(fx_handle *h, int64_t off, int64_t blen, int64_t ski
     if (!h->one_box) {
         HIPCHK(hipHostMalloc((void **)&h->one_box, sizeof(*h->one_box), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void **)&h->one_out, (size_t)ONE_CAP + 64, hipHostMallocDefault));
+    }
+    // ---- the resident kernel: post the request in pinned memory, spin on the acknowledgement
+    static const bool mb_env_off = [] { const char *e = getenv("FX_NO_MAILBOX"); return e && atoi(e) != 0; }();
+    if (take <= MB_OUT && !h->mb_off && !mb_env_off && !h->build_pending) {
+        if (!h->mb) {
+            if (hipHostMalloc((void **)&h->mb, sizeof(Mailbox), hipHostMallocDefault) != hipSuccess ||
+                hipStreamCreateWithFlags(&h->mb_stream, hipStreamNonBlocking) != hipSuccess) {
+                if (h->mb) { (void)hipHostFree(h->mb); h->mb = nullptr; }
+                h->mb_off = true;
+            } else memset(h->mb, 0, sizeof(Mailbox));
+        }
+        if (h->mb) {
+            Mailbox *mb = h->mb;
+            const unsigned long long n = ++h->mb_seq;
+            __atomic_store_n(&mb->tail, n, __ATOMIC_RELEASE);            // tail first, head last: see struct Mailbox
+            mb->off = off; mb->blen = blen; mb->skip = skip; mb->take = take; mb->flags_quit = (long long)(unsigned)flags;
+            __atomic_store_n(&mb->head, n, __ATOMIC_RELEASE);
+            auto launch = [&]() {
+                mb->state = 1;
+                hipLaunchKernelGGL(k_mailbox, dim3(1), dim3(64), 0, h->mb_stream, h->d_data, h->base, h->n, mb, h->one_out, n - 1, 300);
+                h->mb_running = hipGetLastError() == hipSuccess;
+                return h->mb_running;
+            };
+            // (a kernel that has left wrote state = 0 as its last act: the next one queues behind it on the same stream)
+            bool ok = (h->mb_running && __atomic_load_n(&mb->state, __ATOMIC_ACQUIRE) != 0) || launch();
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 0; ok; ++spins) {
+                if ((__atomic_load_n(&mb->ack, __ATOMIC_ACQUIRE) >> 20) == n) break;
+                if ((spins & 63) == 63) {
+                    // the kernel may have left between two requests: its stream is idle then, and the request unanswered
+                    if (__atomic_load_n(&mb->state, __ATOMIC_ACQUIRE) != 1 && hipStreamQuery(h->mb_stream) == hipSuccess) {
+                        if ((__atomic_load_n(&mb->ack, __ATOMIC_ACQUIRE) >> 20) == n) break;
+                        ok = launch();
+                    }
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2000)) ok = false;
+                }
+            }
+            if (ok) {
+                const int64_t got = (int64_t)(mb->ack & 0xFFFFFull);
+                if (got < 0 || got > take) return fail(FX_ERANGE, "range outside the stream");
+                memcpy(dst, h->one_out, (size_t)got);
+                *out_len = got;
+                return FX_OK;
+            }
+            // no answer in two seconds (or no launch): stop using the mailbox, send the kernel home, take the launch path
+            h->mb_off = true;
+            { const unsigned long long q = ++h->mb_seq; __atomic_store_n(&mb->tail, q, __ATOMIC_RELEASE); mb->flags_quit = 1ll << 32; __atomic_store_n(&mb->head, q, __ATOMIC_RELEASE); }
+            (void)hipStreamSynchronize(h->mb_stream);
+            h->mb_running = false;
+        }
     }
     *h->one_box = {off, blen, skip, take, 0, 0};
     FetchQ q;
