@@ -108,6 +108,9 @@ class _Staged:
         """pyfastx_index_random_read (index.c:683-692): bytes as they are."""
         if n <= 0:
             return b""
+        if n <= 65536:                                       # a getter's worth of bytes: the resident kernel (fx_fetch_one, FX_RAW)
+            b = self.blob.fetch_one(off, n, n, flags=_F_RAW)
+            return b if len(b) == n else b + b"\0" * (n - len(b))    # past the end of the stream: zeros, as fx_read_bytes gives them
         return self.blob.read_bytes(off, n)
 
     def fetch(self, off, blen, slen, flags):

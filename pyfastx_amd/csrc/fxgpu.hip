@@ -1550,7 +1550,18 @@ static int fetch_common(fx_handle *h, int where, int64_t n, bool by_id, const in
         for (int64_t i = 0; i < n; ++i) sum += (double)host_blen[i];
         longq = longq || sum / (double)n > 512.0;
     }
-    if (!longq) {            // 8 lanes x 16 B per query: 8 queries in flight per wave (measured 0.19 ms vs 0.25 ms for 16 x 8 B)
+    // lanes per query for intervals by record id (FX_FETCH_G: tuning).  The kernel is latency-bound -- PMC (profiles/r02_pmc_fetch.txt):
+    // 57 % of the wave cycles parked in s_waitcnt, 22 % issuing; queries sorted by offset, which share DRAM pages and even lines,
+    // are only 3-6 % faster -- so what counts is how many queries a wave keeps in flight: 4 lanes (16 queries per wave, a 100-base
+    // query in two steps of 64 bytes) 0.117 ms per 1 M, 8 lanes 0.134, 2 lanes 0.160, 16 lanes 0.225.
+    static const int fetch_g = [] { const char *e = getenv("FX_FETCH_G"); return e ? atoi(e) : 4; }();
+    if (!longq && by_id && fetch_g == 4) {
+        FX_LAUNCH(h, K_FETCH, (k_fetch<true, 4, 16>), dim3(fetch_grid((n + 15) / 16)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
+    } else if (!longq && by_id && fetch_g == 2) {
+        FX_LAUNCH(h, K_FETCH, (k_fetch<true, 2, 16>), dim3(fetch_grid((n + 31) / 32)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
+    } else if (!longq && by_id && fetch_g == 16) {
+        FX_LAUNCH(h, K_FETCH, (k_fetch<true, 16, 16>), dim3(fetch_grid((n + 3) / 4)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
+    } else if (!longq) {     // 8 lanes x 16 B per query: 8 queries in flight per wave (measured 0.19 ms vs 0.25 ms for 16 x 8 B)
         const unsigned grid8 = fetch_grid((n + 7) / 8);
         if (by_id) FX_LAUNCH(h, K_FETCH, (k_fetch<true, 8, 16>), dim3(grid8), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
         else       FX_LAUNCH(h, K_FETCH, (k_fetch<false, 8, 16>), dim3(grid8), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
