@@ -489,13 +489,26 @@ class Blob:
 
     def names_lookup(self, names):
         """list of str / bytes -> int64 ids (0-based, -1 when absent), one kernel launch."""
+        n = len(names)
+        out = np.empty(n, dtype=np.int64)
+        if not n:
+            return out
+        if isinstance(names[0], str):
+            # one join + one encode for the whole batch (a list comprehension of a million .encode() calls and a Python sum
+            # of their lengths cost more than the kernel and both copies together); a name cannot hold a newline
+            buf = np.frombuffer(("\n".join(names) + "\n").encode("utf-8", "surrogateescape"), dtype=np.uint8)
+            nl = np.flatnonzero(buf == 10)
+            if nl.size == n:
+                offs = np.zeros(n + 1, dtype=np.int64)
+                offs[1:] = nl - np.arange(n, dtype=np.int64)          # end of name i once the separators are gone
+                packed = np.concatenate([buf[buf != 10], np.zeros(16, dtype=np.uint8)])
+                check(lib().fx_names_lookup(self._h, FX_HOST, n, _ptr(packed), _ptr(offs), _ptr(out)))
+                return out
         enc = [x if isinstance(x, bytes) else x.encode("utf-8", "surrogateescape") for x in names]
-        offs = np.zeros(len(enc) + 1, dtype=np.int64)
-        np.cumsum([len(x) for x in enc], out=offs[1:])
+        offs = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.fromiter(map(len, enc), dtype=np.int64, count=n), out=offs[1:])
         packed = np.frombuffer(b"".join(enc) + b"\0" * 16, dtype=np.uint8)
-        out = np.empty(len(enc), dtype=np.int64)
-        if enc:
-            check(lib().fx_names_lookup(self._h, FX_HOST, len(enc), _ptr(packed), _ptr(offs), _ptr(out)))
+        check(lib().fx_names_lookup(self._h, FX_HOST, n, _ptr(packed), _ptr(offs), _ptr(out)))
         return out
 
     def names_pack(self, kind, n, guess=0):
