@@ -39,7 +39,7 @@ constexpr int INFL_BLOCK = FX_INFL_BLOCK; // decode: members per workgroup = one
 constexpr int MAXBITS = 15, MAXLCODES = 286, MAXDCODES = 30, FIXLCODES = 288;
 
 enum InflStatus { INFL_OK = 0, INFL_EINPUT = 1, INFL_EOUTPUT = 2, INFL_EBLOCK = 3, INFL_ECODES = 4, INFL_EDIST = 5,
-                  INFL_ESIZE = 6 };
+                  INFL_ESIZE = 6, INFL_ECRC = 7 };
 
 typedef uint64_t __attribute__((aligned(1))) uint64_u;    // 8 bytes at any address (gfx9 unaligned access mode)
 
@@ -489,6 +489,70 @@ __global__ __launch_bounds__(COPY_BLOCK) void k_bgzf_copy(const int64_t *__restr
             for (int j = lane; j < n_l; j += 64) data[ub + d_l + j] = ld_byte(data, ub + d_l - k_l + (k_l < n_l ? j % k_l : j));
         }
         __threadfence_block();                             // the next batch may read what this one wrote
+    }
+}
+
+// ---- phase C: the CRC-32 of every member against its trailer (zlib checks it in the reference's gzread; a member that
+// inflates to the right length with wrong bytes must not go unnoticed).  One wave per member, 1 KiB of it per step,
+// read the way everything else reads the stream: 64 lanes x 16 contiguous bytes (the first form gave every lane its own
+// 1 KiB piece, 4 bytes at a time -- 32 x the member in L2 traffic, 12 ms).  CRCs are linear:
+//     crc_0(A || B) = shift_{|B|}(crc_0(A)) ^ crc_0(B)        crc(D) = ~(crc_0(D) ^ shift_{|D|}(~0))
+// so a lane's 16-byte CRC (init 0) meets its neighbours' in a butterfly of six steps (shift by 16, 32, ... 512 bytes),
+// rows are chained with shift by 1 KiB, the member is right-aligned to the rows (zeros in front of init-0 data change
+// nothing) and the all-ones start value is shifted by the member's length once, at the end.  "Shift by 2^k bytes" is a
+// 32 x 32 matrix over GF(2) (computed on the host by repeated squaring, as zlib's crc32_combine does); the seven the hot
+// loop uses are expanded into 4 x 256-entry tables (one LDS look-up per byte of the operand).
+constexpr int CRC_ROW = 1024, CRC_NSH = 7;                   // shifts by 16 << k bytes, k = 0 .. 6 (6 = one row)
+struct CrcTables {
+    uint32_t crc[256];                                       // the byte table of the reflected polynomial 0xEDB88320
+    uint32_t sh[CRC_NSH][4][256];                            // sh[k][b][v] = shift_{16 << k}(v << 8 b)
+    uint32_t pow2[17][32];                                   // matrix of "shift by 2^j bytes", j = 0 .. 16 (column i = image of bit i)
+};
+__device__ __forceinline__ uint32_t crc_shift(const uint32_t (*t)[256], uint32_t v) {
+    return t[0][v & 0xFFu] ^ t[1][(v >> 8) & 0xFFu] ^ t[2][(v >> 16) & 0xFFu] ^ t[3][v >> 24];
+}
+__global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t *__restrict__ data, const int64_t *__restrict__ uoff,
+                                                 const int32_t *__restrict__ isize, const uint8_t *__restrict__ cbuf,
+                                                 const int64_t *__restrict__ cdata_off, const int32_t *__restrict__ cdata_len,
+                                                 int64_t nmem, const CrcTables *__restrict__ T, int32_t *__restrict__ status) {
+    __shared__ uint32_t tab[256], sh[CRC_NSH][4][256];
+    for (int i = threadIdx.x; i < 256; i += 256) tab[i] = T->crc[i];
+    for (int i = threadIdx.x; i < CRC_NSH * 4 * 256; i += 256) (&sh[0][0][0])[i] = (&T->sh[0][0][0])[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t m = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (m >= nmem) return;
+    const int64_t n = isize[m];
+    const uint8_t *p = data + uoff[m];
+    const int64_t nrows = (n + CRC_ROW - 1) / CRC_ROW;
+    uint32_t acc = 0;                                        // crc_0 of the rows so far (wave-uniform)
+    for (int64_t r = 0; r < nrows; ++r) {
+        const int64_t a = n - (nrows - r) * CRC_ROW + lane * 16;   // member-relative offset of this lane's 16 bytes (< 0 in the first row: nothing there)
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (a >= 0) { const uint4 v = *reinterpret_cast<const uint4_u *>(p + a); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+        else if (a > -16) for (int k = (int)-a; k < 16; ++k) w[k >> 2] |= (uint32_t)p[a + k] << ((k & 3) * 8);
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c ^= w[k];
+            c = tab[c & 0xFFu] ^ (c >> 8); c = tab[c & 0xFFu] ^ (c >> 8); c = tab[c & 0xFFu] ^ (c >> 8); c = tab[c & 0xFFu] ^ (c >> 8);
+        }
+#pragma unroll
+        for (int l = 0; l < 6; ++l) {                        // butterfly: after step l every lane holds the crc_0 of its block of 2^(l+1) lanes
+            const uint32_t o = (uint32_t)__shfl_xor((int)c, 1 << l, 64);
+            const bool left = ((lane >> l) & 1) == 0;
+            c = crc_shift(sh[l], left ? c : o) ^ (left ? o : c);
+        }
+        acc = crc_shift(sh[6], acc) ^ c;
+    }
+    if (lane == 0 && status[m] == INFL_OK) {
+        uint32_t init = 0xFFFFFFFFu;                         // shift_n(~0): n in binary, one stored matrix per set bit
+        for (int j = 0; j < 17; ++j)
+            if ((n >> j) & 1) { uint32_t v = 0; for (int b = 0; b < 32; ++b) v ^= ((init >> b) & 1u) ? T->pow2[j][b] : 0u; init = v; }
+        const uint32_t got = n ? ~(acc ^ init) : 0u;
+        const uint8_t *t = cbuf + cdata_off[m] + cdata_len[m];
+        const uint32_t want = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (want != got) status[m] = INFL_ECRC;
     }
 }
 

@@ -81,11 +81,31 @@ template <class T> struct DevBuf {      // grow-only device array: rebuilds reus
 // ------------------------------------------------------------ kernel timing
 // Optional per-kernel HIP-event timing on the handle's own stream (bench.py's
 // roofline leg reads it; off by default so the hot path records no events).
+// The tables of k_bgzf_crc: the byte table of the reflected polynomial 0xEDB88320, the matrices of "append 2^j zero
+// bytes" (column b = image of bit b; squared up from the one-zero-bit operator, as zlib's crc32_combine does), and the
+// seven the kernel's hot loop uses expanded into byte-indexed tables.
+static void crc_tables(CrcTables *T) {
+    for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; T->crc[i] = c; }
+    uint32_t a[32], b[32];
+    a[0] = 0xEDB88320u;                                      // one zero bit
+    for (int n = 1; n < 32; ++n) a[n] = 1u << (n - 1);
+    auto times = [](const uint32_t *mat, uint32_t vec) { uint32_t s = 0; for (int i = 0; vec; vec >>= 1, ++i) if (vec & 1) s ^= mat[i]; return s; };
+    for (int r = 0; r < 3; ++r) { for (int n = 0; n < 32; ++n) b[n] = times(a, a[n]); memcpy(a, b, sizeof a); }      // -> one zero byte
+    for (int j = 0; j < 17; ++j) {
+        memcpy(T->pow2[j], a, sizeof a);
+        for (int n = 0; n < 32; ++n) b[n] = times(a, a[n]);
+        memcpy(a, b, sizeof a);
+    }
+    for (int k = 0; k < CRC_NSH; ++k)                        // shift by 16 << k bytes = 2^(4 + k)
+        for (int byte = 0; byte < 4; ++byte)
+            for (uint32_t v = 0; v < 256; ++v) T->sh[k][byte][v] = times(T->pow2[4 + k], v << (8 * byte));
+}
+
 enum KernelId { K_SPAN_SCAN = 0, K_GRAN_REDUCE, K_GRAN_PREFIX, K_HDR_REC, K_GRAN_LINES, K_GRAN_EXACT, K_FASTA_FINALIZE, K_FETCH,
-                K_FASTA_COMP, K_FASTA_COMP_EDGE, K_FASTA_COMP_SMALL, K_FASTQ_LINES, K_FASTQ_ROWS, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_NKERN };
+                K_FASTA_COMP, K_FASTA_COMP_EDGE, K_FASTA_COMP_SMALL, K_FASTQ_LINES, K_FASTQ_ROWS, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_BGZF_CRC, K_NKERN };
 static const char *const kKernelNames[K_NKERN] = {
     "k_span_scan", "k_gran_reduce", "k_gran_prefix", "k_hdr_rec", "k_gran_lines", "k_gran_exact", "k_fasta_finalize", "k_fetch",
-    "k_fasta_comp", "k_fasta_comp_edge", "k_fasta_comp_small", "k_fastq_lines", "k_fastq_rows", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy"};
+    "k_fasta_comp", "k_fasta_comp_edge", "k_fasta_comp_small", "k_fastq_lines", "k_fastq_rows", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy", "k_bgzf_crc"};
 
 struct Prof {
     bool on = false;
@@ -462,13 +482,20 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
         t.total += full.isize[(size_t)m];
     }
     const int64_t fsize = c1 - c0;
+    static const bool trace = [] { const char *e = getenv("FX_TRACE"); return e && atoi(e) != 0; }();
+    const auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "[fxgpu] bgzf %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
+    };
     DevBuf<uint8_t> d_c;
     DevBuf<int64_t> d_coff, d_uoff;
     DevBuf<int32_t> d_clen, d_isize, d_status;
     int rc;
     if ((rc = d_c.alloc(fsize + 48))) return rc;          // the bit reader looks three 8-byte words ahead
     HIPCHK(hipMemsetAsync(d_c.p + fsize, 0, 48, h->stream));
+    lap("alloc compressed");
     if ((rc = stage_plain_file(h, fd, fsize, path, d_c.p, c0))) return rc;
+    lap("staged");
     if ((rc = upload(h, d_coff, t.coff)) || (rc = upload(h, d_uoff, t.uoff)) || (rc = upload(h, d_clen, t.clen)) ||
         (rc = upload(h, d_isize, t.isize)))
         return rc;
@@ -486,18 +513,30 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
     HIPCHK(hipMemsetAsync(d_status.p, 0xFF, (size_t)nmem * 4, h->stream));
     HIPCHK(hipMemsetAsync(d_ntok.p, 0, (size_t)nmem * 4, h->stream));
     if ((rc = alloc_blob(h, t.total))) return rc;
+    lap("allocations");
     FX_LAUNCH(h, K_BGZF_INFLATE, k_bgzf_decode, dim3(nblocks(nmem, INFL_BLOCK)), dim3(INFL_BLOCK), d_c.p, d_coff.p,
               d_clen.p, d_uoff.p, d_isize.p, nmem, h->d_data, d_status.p, d_tok.p, d_toff.p, d_ntok.p, d_gsym.p);
     FX_LAUNCH(h, K_BGZF_COPY, k_bgzf_copy, dim3(nblocks(nmem, COPY_BLOCK / 64)), dim3(COPY_BLOCK), d_uoff.p, nmem, h->d_data,
               d_tok.p, d_toff.p, d_ntok.p);
+    static const bool no_crc = [] { const char *e = getenv("FX_BGZF_NO_CRC"); return e && atoi(e) != 0; }();
+    DevBuf<CrcTables> d_crc;
+    if (!no_crc) {                                           // every member against the CRC-32 of its trailer, as zlib does in gzread
+        static const CrcTables *tabs = [] { CrcTables *t = new CrcTables; crc_tables(t); return t; }();
+        if ((rc = d_crc.alloc(1))) return rc;
+        HIPCHK(hipMemcpyAsync(d_crc.p, tabs, sizeof(CrcTables), hipMemcpyHostToDevice, h->stream));
+        FX_LAUNCH(h, K_BGZF_CRC, k_bgzf_crc, dim3(nblocks(nmem, 4)), dim3(256), h->d_data, d_uoff.p, d_isize.p, d_c.p, d_coff.p, d_clen.p,
+                  nmem, d_crc.p, d_status.p);
+    }
     HIPCHK(hipGetLastError());
     std::vector<int32_t> status((size_t)nmem);
     HIPCHK(hipMemcpyAsync(status.data(), d_status.p, (size_t)nmem * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    lap("kernels done");
     for (int64_t m = 0; m < nmem; ++m)
         if (status[m] != INFL_OK)
-            return fail(FX_EIO, "BGZF member %lld of %s (offset %lld) failed to inflate: code %d", (long long)m, path,
-                        (long long)t.moff[m], status[m]);
+            return fail(FX_EIO, status[m] == INFL_ECRC ? "BGZF member %lld of %s (offset %lld): CRC-32 of the inflated bytes differs from the trailer (code %d)"
+                                                       : "BGZF member %lld of %s (offset %lld) failed to inflate: code %d",
+                        (long long)m, path, (long long)t.moff[m], status[m]);
     h->bgzf = true;
     h->gz_moff = full.moff; h->gz_uoff = full.uoff; h->gz_csize = fsize_all;
     return FX_OK;

@@ -70,6 +70,21 @@ def test_corrupt_member_is_reported(L, tmp_path):
     assert e.value.code == L.FX_EIO and "BGZF member" in str(e.value)
 
 
+def test_crc_of_every_member_is_checked(L, tmp_path):
+    """a member that inflates to the right length with wrong bytes is an error (zlib's gzread checks the CRC-32 in
+    the reference): stored members (level 0) with one payload byte flipped inflate cleanly -- only the CRC kernel notices."""
+    from pyfastx_amd import synth
+    raw = fixture_bytes("test.fa")
+    bg = bytearray(synth.bgzf_compress(raw, block=20000, level=0))
+    good = L.Blob.from_file(_write(tmp_path, "ok.fa.gz", bytes(bg)))
+    assert good.read_bytes(0, len(raw)) == raw
+    pos = bg.index(raw[30000:30040]) + 7                   # inside the stored payload of the second member
+    bg[pos] ^= 0x20
+    with pytest.raises(L.FxError) as e:
+        L.Blob.from_file(_write(tmp_path, "flip.fa.gz", bytes(bg)))
+    assert e.value.code == L.FX_EIO and "CRC-32" in str(e.value) and "member 1 " in str(e.value)
+
+
 def test_bgzf_fasta_through_the_api(tmp_path):
     import pyfastx_amd as fx
     from pyfastx_amd import synth
