@@ -933,3 +933,69 @@ def test_names_are_stored_verbatim_by_every_writer(tmp_path):
     # str names (key_func results) are encoded the same way
     db = fxi.connect(str(tmp_path / "k.fxi")); fxi.write_fasta(db, ["é", "x"], {k: v[:2] for k, v in cols.items()}, 3)
     assert bytes(db.execute("SELECT CAST(chrom AS BLOB) FROM seq WHERE ID=1").fetchone()[0]) == "é".encode("utf-8")
+
+
+def test_merge_index_parts_completes_names_cut_by_a_shard_boundary():
+    """shard.merge_index_parts (the merged .fxi of a sharded build): rows in shard order, and a name whose header line
+    crosses a cut -- the owner sees only its first bytes -- is completed from the next shards' first bytes, tiny shards
+    in between included."""
+    from pyfastx_amd import shard
+    raw = b">alpha_long_name desc\nACGT\n>beta\nGG\n"
+    cuts = [5, 7, 8, 30]                                    # the first name is cut three times
+    bounds = [0] + cuts + [len(raw)]
+    parts = []
+    for i in range(len(bounds) - 1):
+        lo, hi = bounds[i], bounds[i + 1]
+        rows = {k: np.zeros(0, dtype=np.int64) for k in ("hoff", "boff", "blen", "slen", "llen", "elen", "norm", "dlen", "name_len", "reg")}
+        names = []
+        if lo == 0:
+            rows = {k: np.array([v], dtype=np.int64) for k, v in dict(hoff=0, boff=22, blen=5, slen=4, llen=5, elen=1, norm=1, dlen=20, name_len=15, reg=1).items()}
+            names = [raw[1:hi]]                              # what a fetch clamped to the shard's bytes returns
+        if lo <= 27 < hi:
+            rows = {k: np.array([v], dtype=np.int64) for k, v in dict(hoff=27, boff=33, blen=3, slen=2, llen=3, elen=1, norm=1, dlen=4, name_len=4, reg=1).items()}
+            names = [raw[28:min(32, hi)]]
+        parts.append((lo, hi - lo, rows, names, raw[lo:min(hi, lo + shard.HEAD_BYTES)]))
+    t = shard.merge_index_parts(parts)
+    assert t["names"] == [b"alpha_long_name", b"beta"] and t["boff"].tolist() == [22, 33] and t["seq_len"] == 6
+    assert t["bases"] == bounds[:-1] and t["ends"] == bounds[1:]
+
+
+def test_gzindex_rows_round_trip(tmp_path):
+    """fxi.write_gzindex / read_gzindex: the zran row layout of util.c:461-529 with bits and windows (single-stream gzip)
+    and without (BGZF member boundaries)."""
+    from pyfastx_amd import fxi
+    rng = np.random.default_rng(1)
+    db = fxi.connect(str(tmp_path / "g.fxi"))
+    db.executescript(fxi.FASTA_DDL)
+    cmp_, unc = [10, 5000, 9000], [0, 1048576, 2200000]
+    bits, has = [0, 3, 0], [0, 1, 1]
+    win = rng.integers(0, 256, 2 * 32768, dtype=np.uint8)
+    fxi.write_gzindex(db, 12345, 3000000, cmp_, unc, bits=bits, has_data=has, windows=win)
+    rows = [bytes(r[0]) for r in db.execute("SELECT content FROM gzindex ORDER BY ID")]
+    assert rows[0] == b"GZIDX" and len(rows) == 8 + 4 * 3 + 2 and len(rows[-1]) == 32768
+    g = fxi.read_gzindex(db)
+    assert g["compressed_size"] == 12345 and g["uncompressed_size"] == 3000000
+    assert g["cmp"].tolist() == cmp_ and g["uncmp"].tolist() == unc and g["bits"].tolist() == bits and g["has"].tolist() == has
+    assert g["windows"].tobytes() == win.tobytes()
+    db2 = fxi.connect(str(tmp_path / "b.fxi"))
+    db2.executescript(fxi.FASTA_DDL)
+    fxi.write_gzindex(db2, 99, 500, [0, 40], [0, 300])       # BGZF: no bits, no windows
+    g2 = fxi.read_gzindex(db2)
+    assert g2["cmp"].tolist() == [0, 40] and int(g2["has"].sum()) == 0 and g2["windows"].size == 0
+    db3 = fxi.connect(str(tmp_path / "e.fxi"))
+    db3.executescript(fxi.FASTA_DDL)
+    assert fxi.read_gzindex(db3) is None
+
+
+def test_cli_arguments_match_the_reference_commands():
+    """pyfastx_amd.cli: the options of `pyfastx subseq / sample / extract` (pyfastxcli.py argument definitions) parse, the
+    region syntax is the reference's, and nothing touches a GPU before a file is opened."""
+    import re
+    from pyfastx_amd import cli
+    with pytest.raises(SystemExit):
+        cli.main(["sample", "x.fa"])                         # -n or -p is required, as in the reference
+    assert re.split("[:-]", "chr1:10-20") == ["chr1", "10", "20"]
+    with pytest.raises((FileExistsError, FileNotFoundError, OSError)):
+        cli.main(["subseq", "/nonexistent.fa", "chr1:1-5"])
+    with pytest.raises((FileExistsError, FileNotFoundError, OSError)):
+        cli.main(["extract", "--reverse-complement", "--out-fasta", "-l", "names.txt", "/nonexistent.fq"])
