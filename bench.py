@@ -511,7 +511,7 @@ def main_sharded(a, dev, rank, world, backend):
     dist.barrier()
     try:
         t0 = time.perf_counter()
-        job = shard.ShardedFasta.from_file(path, dev, rank, world)       # page cache -> pinned pieces -> HBM, this rank's range only
+        job = shard.ShardedFasta.from_file(path, dev, rank, world, force_collective=world == 1)   # page cache -> pinned pieces -> HBM, this rank's range only
         t_open = time.perf_counter() - t0
         lo, hi = job.base, job.base + job.n_bytes
         # analytic rows of the whole file (pure numpy, every rank computes them) and the rows this shard must hold
@@ -707,7 +707,9 @@ def main():
     local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # FX_BENCH_FORCE_SHARDED=1: the N > 1 code path with a process group of ONE rank (how the 1-GPU test box runs every
+    # collective of that path over RCCL; needs MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE like any torch.distributed run)
+    if world > 1 or os.environ.get("FX_BENCH_FORCE_SHARDED"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)

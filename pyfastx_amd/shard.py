@@ -346,7 +346,7 @@ class ShardedFasta:
         WHOLE file in file order: dict of numpy columns + `names` (list of bytes), `seq_len`, `bases`, `ends`.  What rank 0
         writes into the one .fxi (write_index) and what ShardFetcher routes by."""
         part = local_index_part(self.blob, self.n_local, self.base, self.n_bytes)
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             outs = [part]
         else:
             outs = [None] * self.world
@@ -360,7 +360,7 @@ class ShardedFasta:
         table = self.gather_index() if table is None else table
         if self.rank == 0:
             write_merged_index(index_file, table)
-        if self.world > 1:
+        if self.world > 1 or self.force_collective:
             self._dist.barrier()
         return table
 
@@ -381,7 +381,7 @@ class ShardedFasta:
         the bytes before each shard's first header line to the rank that owns that record."""
         torch, dist = self._torch, self._dist
         n = self.n_local
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return self.blob.fasta_comp(n)
         rows = self.local_rows()
         mine = torch.tensor([self.base, int(rows["boff"][-1]) if n else -1, n], dtype=torch.int64, device=self.comm_dev)
@@ -401,7 +401,7 @@ class ShardedFasta:
         cross a cut are exchanged.  table: what gather_index returned, when the caller has it already."""
         if table is not None:
             return ShardFetcher({self.rank: self.blob}, table["bases"], table["ends"], table,
-                                exchange=allgather_pieces if self.world > 1 else None)
+                                exchange=allgather_pieces if (self.world > 1 or self.force_collective) else None)
         if self.world == 1:
             t = self.local_rows()
             t["reg"] = self.blob.fasta_line_regular(self.n_local)

@@ -114,3 +114,20 @@ def test_bench_single_small():
         assert line["c4"]["rows_equal_reference"] is True and line["c4"]["fetch_sample_equal_reference"] is True
     assert line["c3"]["full"]["rows_base_meta_fetch_equal_generator"] is True
     assert line["c4"]["inflated_size_ok"] is True and line["c4"]["roofline"]["achieved"] > 0
+
+
+def test_bench_sharded_path_over_nccl_with_one_rank():
+    """bench.py's N > 1 code path -- the pieces written into one file, fx_open_file_range, the step with the all-gather and
+    the stitch, composition across cuts, the merged .fxi, ShardFetcher with its exchange -- with the `nccl` backend and a
+    process group of ONE rank (FX_BENCH_FORCE_SHARDED): every collective call of that path runs over RCCL on an MI355X
+    before an 8-GPU node ever sees it."""
+    env = dict(os.environ, FX_BENCH_FORCE_SHARDED="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--gbp", "0.05",
+           "--queries", "20000"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["parity_verified_full_size"] is True and "1 all-gather (nccl)" in line["config"]["parallelism"]
+    sf = line["sharded_file"]
+    assert sf["merged_fxi_rows_equal_plan"] is True and sf["every_query_answered_once_and_sample_equals_file"] is True
