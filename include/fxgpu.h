@@ -397,6 +397,24 @@ void *fx_stream(fx_handle *h);
 int fx_fasta_set_row(fx_handle *h, int64_t k, int64_t boff, int64_t blen, int64_t slen, int64_t llen,
                      int32_t elen, int32_t norm, int32_t dlen, int32_t name_len);
 
+/* Host side of a batched fetch over byte-range shards (the "Fetch" half of SURVEY 8e; no device work, no handle):
+ * n queries (record id, 0-based [start, stop)) against the GLOBAL record table -> byte ranges of the global stream by
+ * the reference's line arithmetic (sequence.c:498-510: line-regular records exactly the bytes; the others the whole
+ * record, sliced after despacing, sequence.c:100-110) -> the shard [bases[r], ends[r]) that holds the first byte of
+ * each (that rank answers it) and the number of shards the range touches.  Outputs are in ROUTED order -- by
+ * answering shard, then by position in the batch: order[k] = index of the query at routed position k;
+ * shard_start[r] .. shard_start[r + 1] = the routed positions of shard r (n_shard + 1 entries); off / len / skip /
+ * take / fl[k] = what fx_fetch_slices takes for that query (fl: flags_per_query or `flags`), cnt[k] = shards touched
+ * (0: empty range or past the end of the stream, fread semantics index.c:689; > 1: the range crosses a cut and its
+ * pieces are put together by the caller).  Replaces per-batch numpy passes of the Python layer (29 ms per 1 M
+ * queries in round 1). */
+int fx_shard_route(int64_t n, const int64_t *ids, const int64_t *starts, const int64_t *stops,
+                   int64_t n_rec, const int64_t *boff, const int64_t *blen, const int64_t *llen, const int64_t *elen,
+                   const uint8_t *reg, int n_shard, const int64_t *bases, const int64_t *ends,
+                   int flags, const uint8_t *flags_per_query,
+                   int64_t *order, int64_t *shard_start, int64_t *off, int64_t *len, int64_t *skip, int64_t *take,
+                   uint8_t *fl, int32_t *cnt);
+
 #ifdef __cplusplus
 }
 #endif

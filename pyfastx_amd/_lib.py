@@ -49,7 +49,7 @@ SYMBOLS = [
     "fx_set_shard", "fx_close", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
     "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_line_regular", "fx_fasta_len_stats", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
-    "fx_fasta_set_row", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
+    "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
 ]
 
 
@@ -119,6 +119,7 @@ def lib():
     L.fx_gz_checkpoints.argtypes = [vp, i64, vp, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(i64)]
     L.fx_open_file_range.argtypes = [C.c_char_p, i64, i64, i64, i32, C.POINTER(vp)]
     L.fx_open_device.argtypes = [vp, i64, i32, C.POINTER(vp)]
+    L.fx_shard_route.argtypes = [i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp] + [vp] * 8
     L.fx_set_shard.argtypes = [vp, i64, i32, i32]
     L.fx_close.argtypes = [vp]
     L.fx_size.restype = i64
@@ -184,6 +185,24 @@ def stream_size(path):
     n, k = C.c_int64(0), C.c_int(0)
     check(lib().fx_stream_size(os.fsencode(path), C.byref(n), C.byref(k)))
     return int(n.value), int(k.value)
+
+
+def shard_route(ids, starts, stops, cols, bases, ends, flags=0, flags_per_query=None):
+    """fx_shard_route: a batch of (record, start, stop) over the byte-range shards [bases[r], ends[r]) -> dict in ROUTED
+    order (by answering shard, then by position in the batch): order, shard_start[n_shard + 1], off, len, skip, take,
+    fl, cnt.  cols: the global table as contiguous arrays boff, blen, llen, elen (int64) and reg (uint8)."""
+    ids, a, b = (np.ascontiguousarray(x, dtype=np.int64) for x in (ids, starts, stops))
+    n, G = ids.size, len(bases)
+    bases, ends = np.ascontiguousarray(bases, dtype=np.int64), np.ascontiguousarray(ends, dtype=np.int64)
+    fpq = None if flags_per_query is None else np.ascontiguousarray(flags_per_query, dtype=np.uint8)
+    out = {k: np.empty(n, dtype=np.int64) for k in ("order", "off", "len", "skip", "take")}
+    out["shard_start"] = np.zeros(G + 1, dtype=np.int64)
+    out["fl"], out["cnt"] = np.empty(n, dtype=np.uint8), np.empty(n, dtype=np.int32)
+    check(lib().fx_shard_route(n, _ptr(ids), _ptr(a), _ptr(b), cols["boff"].size, _ptr(cols["boff"]), _ptr(cols["blen"]),
+                               _ptr(cols["llen"]), _ptr(cols["elen"]), _ptr(cols["reg"]), G, _ptr(bases), _ptr(ends),
+                               int(flags), _ptr(fpq), _ptr(out["order"]), _ptr(out["shard_start"]), _ptr(out["off"]),
+                               _ptr(out["len"]), _ptr(out["skip"]), _ptr(out["take"]), _ptr(out["fl"]), _ptr(out["cnt"])))
+    return out
 
 
 def check(rc):

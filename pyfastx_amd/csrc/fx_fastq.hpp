@@ -468,7 +468,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_stats(FqTab t, int64_t n_seq_ro
 }
 
 // FASTQ composition (fastq.c:715-753): A C G T (upper case only) over the sequence lines, every other byte but
-// '\r' is N; min / max byte of the quality lines, '\r' ignored.  16 lanes per record, 4 records per wave; a lane
+// '\r' is N; min / max byte of the quality lines, '\r' ignored.  lpr lanes per record, 64 / lpr records per wave; a lane
 // takes 16 bytes of the line per step (unaligned 16-byte loads from the line start, so only the last piece of a
 // line is partial; bytes past its end are replaced by '\r').
 // Sequence: no compare per letter -- as in k_fasta_comp (fx_comp.hpp) the 3-bit code (b >> 1) & 7 picks a one-hot
@@ -482,7 +482,6 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_stats(FqTab t, int64_t n_seq_ro
 constexpr uint32_t FQ_OH_LO = 0x04080201u, FQ_OH_HI = 0x10200000u;     // A 1, C 2, T 8, G 4 | -, -, \r 32, N 16
 constexpr uint32_t FQ_EX_LO = 0x47544341u, FQ_EX_HI = 0x4E0D8080u;     // 'A' 'C' 'T' 'G' | none, none, '\r', 'N'
 
-__device__ const uint4 fq_sixteen_zeros = {0u, 0u, 0u, 0u};
 typedef unsigned short __attribute__((ext_vector_type(2))) fq_u16x2;
 __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
     const fq_u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(fq_u16x2, a), __builtin_bit_cast(fq_u16x2, b));
@@ -509,21 +508,42 @@ __device__ __forceinline__ void fq_keep_first(uint32_t (&x)[4], int keep, uint32
     }
 }
 
+// The straight path of an iteration has no branch and no partial piece: a lane whose piece would run past the end of its
+// line reads the LAST 16 bytes of the line instead (so does a lane that has no piece at all, and a lane of a row past
+// the end of the table reads the last row's).  Twice-read bytes do not change a minimum or a maximum; in the sequence
+// line the first `ov` bytes of such a piece -- the ones an earlier lane has counted -- are turned into '\r' through a
+// mask looked up in LDS.  It holds when 16 <= line length <= 16 * lpr for every record of the iteration; an iteration
+// with any other record (shorter than a piece, longer than one step, no rows at all) takes the general path, piece by
+// piece with its own loads.
 __global__ __launch_bounds__(BLOCK) void k_fastq_comp(const uint8_t *__restrict__ data, int64_t gbase, int64_t n_bytes, FqTab t,
-                                                     int64_t n_seq_rows, int64_t n_rows, FastqAcc *acc) {
+                                                     int64_t n_seq_rows, int64_t n_rows, FastqAcc *acc, int lpr,
+                                                     const uint8_t *__restrict__ safe) {
     __shared__ int fix_all[BLOCK / 64][8];                 // per wave: signed corrections of the class counts (slot = class bit index)
-    const int lane = lane_id(), sub = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+    __shared__ uint4 drop_tab[17];                         // [o]: 0x00 in the first o bytes of the piece, 0xFF in the others
+    // lpr lanes per record (the host picks ceil(mean read length / 16): ten for 150-base reads, where sixteen would leave
+    // four lanes in ten without a piece), 64 / lpr records side by side per wave, the lanes left over idle
+    const int lane = lane_id(), grp = lane / lpr, sub = lane - grp * lpr, wv = threadIdx.x >> 6;
+    const int ngrp = 64 / lpr, step = 16 * lpr;
+    const bool live = grp < ngrp;
     int *fix = fix_all[wv];
     if (lane < 8) fix[lane] = 0;
+    if (threadIdx.x < 17) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = (int)threadIdx.x - 4 * i;        // bytes of word i that are dropped
+            w[i] = k >= 4 ? 0u : k <= 0 ? 0xFFFFFFFFu : ~((1u << (8 * k)) - 1u);
+        }
+        drop_tab[threadIdx.x] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();
     const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
     uint32_t ones = 0, twos = 0;                           // bit planes of the one-hot words: 1s and 2s per bit position
     uint32_t c4[6] = {0, 0, 0, 0, 0, 0};                   // per class: popcount of the carry-outs (each worth 4)
     int qmin = 104, qmax = 33;                             // fastq.c:667-668
 
-    auto seq_piece = [&](const uint4 &v, int64_t left) {   // 16 bytes of a sequence line, `left` of them inside it
-        uint32_t x[4] = {v.x, v.y, v.z, v.w};
-        if (left < 16) fq_keep_first(x, (int)left, 0x0D0D0D0Du);
+    auto seq_count = [&](const uint32_t (&x)[4]) {         // 16 bytes of a sequence line ('\r' where there is nothing to count)
         uint32_t h[4], dacc = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -555,87 +575,148 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp(const uint8_t *__restrict_
 #pragma unroll
         for (int c = 0; c < 5; ++c) c4[c] += __popc(f & (0x01010101u << c));
     };
-    auto qual_piece = [&](const uint4 &v, int64_t left) {  // 16 bytes of a quality line
+    auto seq_piece = [&](const uint4 &v, int64_t left) {   // general path: `left` bytes of the piece lie inside the line
+        uint32_t x[4] = {v.x, v.y, v.z, v.w};
+        if (left < 16) fq_keep_first(x, (int)left, 0x0D0D0D0Du);
+        seq_count(x);
+    };
+    auto qual_exact = [&](const uint4 &v, int keep) {      // fastq.c:733-737, byte by byte
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        for (int j = 0; j < keep; ++j) {
+            const int q = (int)(signed char)(w[j >> 2] >> ((j & 3) * 8));
+            if (q == 13) continue;
+            qmin = q < qmin ? q : qmin; qmax = q > qmax ? q : qmax;
+        }
+    };
+    // even / odd bytes of the four words, zero-extended to 16 bits (one v_perm each), into packed minima and maxima
+    auto qual_minmax = [&](const uint32_t (&lo)[4], const uint32_t (&hi)[4], uint32_t &mn, uint32_t &mx) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mn = pk_min_u16(mn, pk_min_u16(__builtin_amdgcn_perm(0u, lo[k], 0x0C020C00u), __builtin_amdgcn_perm(0u, lo[k], 0x0C030C01u)));
+            mx = pk_max_u16(mx, pk_max_u16(__builtin_amdgcn_perm(0u, hi[k], 0x0C020C00u), __builtin_amdgcn_perm(0u, hi[k], 0x0C030C01u)));
+        }
+    };
+    auto qual_piece = [&](const uint4 &v, int64_t left) {  // general path
         uint32_t lo[4] = {v.x, v.y, v.z, v.w}, hi[4] = {v.x, v.y, v.z, v.w};
         const int keep = left < 16 ? (int)left : 16;
         if (keep < 16) { fq_keep_first(lo, keep, 0xFFFFFFFFu); fq_keep_first(hi, keep, 0u); }
         uint32_t mn = 0x00FF00FFu, mx = 0u;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            mn = pk_min_u16(mn, pk_min_u16(lo[k] & 0x00FF00FFu, (lo[k] >> 8) & 0x00FF00FFu));
-            mx = pk_max_u16(mx, pk_max_u16(hi[k] & 0x00FF00FFu, (hi[k] >> 8) & 0x00FF00FFu));
-        }
+        qual_minmax(lo, hi, mn, mx);
         const int cmin = (int)min(mn & 0xFFFFu, mn >> 16), cmax = (int)max(mx & 0xFFFFu, mx >> 16);
-        if (cmin >= 33 && cmax < 128) {
-            qmin = cmin < qmin ? cmin : qmin; qmax = cmax > qmax ? cmax : qmax;
-        } else {                                           // '\r' (skipped) or bytes outside the printable range: exactly as fastq.c:733-737
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            for (int j = 0; j < keep; ++j) {
-                const int q = (int)(signed char)(w[j >> 2] >> ((j & 3) * 8));
-                if (q == 13) continue;
-                qmin = q < qmin ? q : qmin; qmax = q > qmax ? q : qmax;
-            }
-        }
+        if (cmin >= 33 && cmax < 128) { qmin = cmin < qmin ? cmin : qmin; qmax = cmax > qmax ? cmax : qmax; }
+        else qual_exact(v, keep);                          // '\r' (skipped) or bytes outside the printable range
     };
 
-    // A wave takes FQ_RPW = 4 * FQ_U consecutive records per iteration (FQ_U per 16-lane group).  Table rows are read
-    // one iteration ahead; the first piece of every sequence line and quality line of the iteration is requested
-    // before any of them is counted (reads up to 256 bytes need no more than those loads): 2 * FQ_U loads in
-    // flight per lane -- with one record per group and loads inside branches the kernel was bound by load round trips, 2.8 ms for 7 GB.
-    constexpr int FQ_U = FX_FQ_U, FQ_RPW = 4 * FQ_U;
-    const uint8_t *safe = n_bytes >= 16 ? data : reinterpret_cast<const uint8_t *>(&fq_sixteen_zeros);
+    // A wave takes FQ_RPW = ngrp * FQ_U consecutive records per iteration (FQ_U per group of lpr lanes) and runs three
+    // iterations deep: while iteration k is counted, the pieces of iteration k + 1 (2 * FQ_U loads per lane) and the
+    // table rows of iteration k + 2 are on their way.  `safe` is a kernel argument: a pointer picked from a variable of
+    // the module makes every one of these a flat load.
+    constexpr int FQ_U = FX_FQ_U;
+    const int FQ_RPW = ngrp * FQ_U;
     const int64_t stride = nwaves * FQ_RPW;
-    int64_t i0 = wave * FQ_RPW + grp * FQ_U;               // first record of this group in this iteration
-    // the next iteration's rows, raw: the loads are unconditional (index clamped) and nothing is computed from them
-    // until the next pass -- anything else makes every one of them a round trip of its own
-    int64_t r_soff[FQ_U], r_rlen[FQ_U], r_qoff[FQ_U];
-    int32_t r_qlen[FQ_U];
+    int64_t i0 = wave * FQ_RPW + grp * FQ_U;               // first record of this group in the iteration being planned
+    int64_t ic = i0;                                       // ... in the iteration being counted
+    // table rows: lane j of the wave asks for row (first row of the iteration) + j, j < FQ_RPW -- four loads per
+    // iteration, one or two cache lines each -- and the lanes of a group pick theirs up through ds_bpermute when they
+    // plan.  (Every lane asking for its own group's row: 4 * FQ_U loads with 64 addresses each.)  The loads are
+    // unconditional (index clamped) and nothing is computed from them until the next pass -- anything else makes every
+    // one of them a round trip of its own.
+    int64_t R_soff = 0, R_rlen = 0, R_qoff = 0;
+    int32_t R_qlen = 0;
     const int64_t last_seq = n_seq_rows - 1, last_row = n_rows > 0 ? n_rows - 1 : 0;
-#pragma unroll
-    for (int u = 0; u < FQ_U; ++u) {
-        const int64_t is = i0 + u < last_seq ? i0 + u : last_seq, iq = i0 + u < last_row ? i0 + u : last_row;
-        r_soff[u] = t.soff[is]; r_rlen[u] = t.rlen[is]; r_qoff[u] = t.qoff[iq]; r_qlen[u] = t.qlen[iq];
-    }
-    for (int64_t t0 = wave * FQ_RPW; t0 < n_seq_rows; t0 += stride) {
-        int64_t ps[FQ_U], e[FQ_U], pq[FQ_U], qe[FQ_U];
-        uint4 vs[FQ_U], vq[FQ_U];
+    auto rows_request = [&]() {
+        const int64_t ib = i0 - grp * FQ_U + lane;
+        if (lane < FQ_RPW) {
+            const int64_t is = ib < last_seq ? ib : last_seq, iq = ib < last_row ? ib : last_row;
+            R_soff = t.soff[is]; R_rlen = t.rlen[is]; R_qoff = t.qoff[iq]; R_qlen = t.qlen[iq];
+        }
+    };
+    struct Plan { int64_t as, aq; int ov; };               // where this lane's two pieces start; ov: bytes of the sequence piece to drop (bit 8: general path)
+    auto plan = [&](Plan (&P)[FQ_U]) {                     // from the rows that have arrived
 #pragma unroll
         for (int u = 0; u < FQ_U; ++u) {
             const int64_t i = i0 + u;
-            const int64_t s = r_soff[u] - gbase, q = r_qoff[u] - gbase;
-            ps[u] = s + sub * 16; e[u] = i < n_seq_rows ? s + r_rlen[u] : 0;       // e <= ps: nothing to do
-            pq[u] = q + sub * 16; qe[u] = i < n_rows ? q + r_qlen[u] : 0;
+            const int src = live ? grp * FQ_U + u : 0;
+            const int64_t r_soff_u = shfl64(R_soff, src), r_rlen_u = shfl64(R_rlen, src), r_qoff_u = shfl64(R_qoff, src);
+            const int32_t r_qlen_u = __shfl(R_qlen, src, 64);
+            const bool sv = live && i < n_seq_rows, qv = live && i < n_rows;
+            const int rl = (int)(r_rlen_u < 4096 ? r_rlen_u : 4096), ql = r_qlen_u < 4096 ? r_qlen_u : 4096;
+            const bool slow = (sv && (rl < 16 || rl > step)) || (qv && (ql < 16 || ql > step)) || n_rows <= 0 ||
+                              rl < 16 || ql < 16;          // (a clamped row shorter than a piece: nothing valid to read in its place)
+            const int os = sub * 16 + 16 - rl, oq = sub * 16 + 16 - ql;          // how far the piece would run past the end of the line
+            const int ds = os > 0 ? os : 0, dq = oq > 0 ? oq : 0;
+            P[u].as = r_soff_u - gbase + (sub * 16 - ds);
+            P[u].aq = r_qoff_u - gbase + (sub * 16 - dq);
+            P[u].ov = (sv ? (ds < 16 ? ds : 16) : 16) | (slow ? 256 : 0);
         }
-        // the 2 * FQ_U loads of the iteration, branch-free (a lane with nothing to read, or within 16 bytes of the end
-        // of the blob, reads 16 bytes that are always there instead): loads inside branches are waited for one by one
+    };
+    auto load = [&](const Plan (&P)[FQ_U], uint4 (&S)[FQ_U], uint4 (&Q)[FQ_U]) {
 #pragma unroll
         for (int u = 0; u < FQ_U; ++u) {
-            const bool ls = ps[u] < e[u] && ps[u] + 16 <= n_bytes, lq = pq[u] < qe[u] && pq[u] + 16 <= n_bytes;
-            vs[u] = *reinterpret_cast<const uint4_u *>(ls ? data + ps[u] : safe);
-            vq[u] = *reinterpret_cast<const uint4_u *>(lq ? data + pq[u] : safe);
+            const bool bad = (P[u].ov & 256) != 0;
+            S[u] = *reinterpret_cast<const uint4_u *>(bad ? safe : data + P[u].as);
+            Q[u] = *reinterpret_cast<const uint4_u *>(bad ? safe : data + P[u].aq);
         }
-        i0 += stride;                                      // next iteration's rows: requested after the data, used after the counting
+    };
+    Plan cur[FQ_U], nxt[FQ_U];
+    uint4 vs[FQ_U], vq[FQ_U], ns[FQ_U], nq[FQ_U];
+    // Loads come back in the order they were asked for, so the order is: rows of k + 2, THEN pieces of k + 1 -- waiting
+    // for those rows at the top of the next pass leaves the pieces in flight; the other way round every pass began by
+    // draining everything, and a wave never had more than one iteration of pieces under way (1.64 ms for 7 GB either way).
+    rows_request();
+    plan(cur);
+    i0 += stride;
+    rows_request();
+    __builtin_amdgcn_sched_barrier(0);
+    load(cur, vs, vq);
+    for (int64_t t0 = wave * FQ_RPW; t0 < n_seq_rows; t0 += stride) {
+        plan(nxt);
+        i0 += stride;
+        __builtin_amdgcn_sched_barrier(0);
+        rows_request();
+        __builtin_amdgcn_sched_barrier(0);
+        load(nxt, ns, nq);
+        __builtin_amdgcn_sched_barrier(0);
+        bool slow = false;
 #pragma unroll
-        for (int u = 0; u < FQ_U; ++u) {
-            const int64_t is = i0 + u < last_seq ? i0 + u : last_seq, iq = i0 + u < last_row ? i0 + u : last_row;
-            r_soff[u] = t.soff[is]; r_rlen[u] = t.rlen[is]; r_qoff[u] = t.qoff[iq]; r_qlen[u] = t.qlen[iq];
-        }
+        for (int u = 0; u < FQ_U; ++u) slow |= (cur[u].ov & 256) != 0;
+        if (__builtin_expect(__ballot(slow) == 0ull, 1)) {
+            uint32_t mn = 0x00FF00FFu, mx = 0u;
 #pragma unroll
-        for (int u = 0; u < FQ_U; ++u) {                   // the last bytes of the blob: byte by byte
-            if (ps[u] < e[u] && ps[u] + 16 > n_bytes) vs[u] = fq_load16(data, ps[u], n_bytes);
-            if (pq[u] < qe[u] && pq[u] + 16 > n_bytes) vq[u] = fq_load16(data, pq[u], n_bytes);
-        }
-#pragma unroll
-        for (int u = 0; u < FQ_U; ++u) {
-            if (ps[u] < e[u]) {
-                seq_piece(vs[u], e[u] - ps[u]);
-                for (int64_t p = ps[u] + 256; p < e[u]; p += 256) seq_piece(fq_load16(data, p, n_bytes), e[u] - p);
+            for (int u = 0; u < FQ_U; ++u) {
+                const uint4 m = drop_tab[cur[u].ov];
+                const uint32_t x[4] = {(uint32_t)__builtin_amdgcn_bitop3_b32(m.x, vs[u].x, 0x0D0D0D0Du, 0xCA),      // m ? v : '\r'
+                                       (uint32_t)__builtin_amdgcn_bitop3_b32(m.y, vs[u].y, 0x0D0D0D0Du, 0xCA),
+                                       (uint32_t)__builtin_amdgcn_bitop3_b32(m.z, vs[u].z, 0x0D0D0D0Du, 0xCA),
+                                       (uint32_t)__builtin_amdgcn_bitop3_b32(m.w, vs[u].w, 0x0D0D0D0Du, 0xCA)};
+                seq_count(x);
+                const uint32_t q[4] = {vq[u].x, vq[u].y, vq[u].z, vq[u].w};
+                qual_minmax(q, q, mn, mx);
             }
-            if (pq[u] < qe[u]) {
-                qual_piece(vq[u], qe[u] - pq[u]);
-                for (int64_t p = pq[u] + 256; p < qe[u]; p += 256) qual_piece(fq_load16(data, p, n_bytes), qe[u] - p);
+            const int cmin = (int)min(mn & 0xFFFFu, mn >> 16), cmax = (int)max(mx & 0xFFFFu, mx >> 16);
+            if (cmin >= 33 && cmax < 128) { qmin = cmin < qmin ? cmin : qmin; qmax = cmax > qmax ? cmax : qmax; }
+            else {
+#pragma unroll
+                for (int u = 0; u < FQ_U; ++u) qual_exact(vq[u], 16);
+            }
+        } else {
+            // the general path: the rows again, then piece by piece
+#pragma unroll 1
+            for (int u = 0; u < FQ_U; ++u) {
+                const int64_t i = ic + u;
+                if (live && i < n_seq_rows) {
+                    const int64_t s_ = t.soff[i] - gbase, e = s_ + t.rlen[i];
+                    for (int64_t p = s_ + sub * 16; p < e; p += step) seq_piece(fq_load16(data, p, n_bytes), e - p);
+                }
+                if (live && i < n_rows) {
+                    const int64_t q_ = t.qoff[i] - gbase, e = q_ + t.qlen[i];
+                    for (int64_t p = q_ + sub * 16; p < e; p += step) qual_piece(fq_load16(data, p, n_bytes), e - p);
+                }
             }
         }
+        ic += stride;
+#pragma unroll
+        for (int u = 0; u < FQ_U; ++u) { cur[u] = nxt[u]; vs[u] = ns[u]; vq[u] = nq[u]; }
     }
     // class totals of the lane: 1 * ones + 2 * twos + 4 * carry-outs, then the wave, then the accumulators
     unsigned long long tot[5];

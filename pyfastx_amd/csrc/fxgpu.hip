@@ -1465,8 +1465,13 @@ extern "C" int fx_fastq_comp(fx_handle *h, int64_t base[5], int64_t meta[5]) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fastq_comp, BLOCK, 0) != hipSuccess || per_cu <= 0) per_cu = 3;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
     }
-    const unsigned nb = (unsigned)std::min<int64_t>(nblocks(std::max<int64_t>(h->fq_seq_rows, 1), (BLOCK / 64) * 4 * FX_FQ_U), (int64_t)per_cu * n_cu);
-    FX_LAUNCH(h, K_FASTQ_COMP, k_fastq_comp, dim3(nb), dim3(BLOCK), h->d_data, h->base, h->n, t, h->fq_seq_rows, h->n_reads, h->fq_acc.p);
+    // lanes per record: one 16-byte piece per lane covers the mean read (FX_FQ_LPR: experiments)
+    static const int lpr_force = [] { const char *e = getenv("FX_FQ_LPR"); return e ? atoi(e) : 0; }();
+    const int64_t mean_len = h->fq_seq_rows > 0 ? (h->fq_size + h->fq_seq_rows - 1) / h->fq_seq_rows : 1;
+    const int lpr = (int)std::clamp<int64_t>(lpr_force > 0 ? lpr_force : (mean_len + 15) / 16, 1, 64);
+    const unsigned nb = (unsigned)std::min<int64_t>(nblocks(std::max<int64_t>(h->fq_seq_rows, 1), (BLOCK / 64) * (64 / lpr) * FX_FQ_U), (int64_t)per_cu * n_cu);
+    FX_LAUNCH(h, K_FASTQ_COMP, k_fastq_comp, dim3(nb), dim3(BLOCK), h->d_data, h->base, h->n, t, h->fq_seq_rows, h->n_reads, h->fq_acc.p, lpr,
+              h->n >= 16 ? h->d_data : (const uint8_t *)h->fq_acc.p);      // 16 bytes that can always be read
     HIPCHK(hipGetLastError());
     FastqAcc acc;
     HIPCHK(hipMemcpyAsync(&acc, h->fq_acc.p, sizeof acc, hipMemcpyDeviceToHost, h->stream));
@@ -1633,6 +1638,76 @@ extern "C" int fx_fetch_ranges(fx_handle *h, int where, int64_t n, const int64_t
     int64_t ext = 0;
     if (where == FX_HOST && n > 0 && dst_off && slen) ext = std::max<int64_t>(1, host_extent(n, dst_off, slen, nullptr, nullptr));
     return fetch_common(h, where, n, false, off, blen, slen, nullptr, flags, flags_per_query, dst, dst_off, out_len, ext);
+}
+
+// ------------------------------------------------------------------- routing of a query batch over byte-range shards (host only)
+extern "C" int fx_shard_route(int64_t n, const int64_t *ids, const int64_t *starts, const int64_t *stops, int64_t n_rec,
+                              const int64_t *boff, const int64_t *blen, const int64_t *llen, const int64_t *elen, const uint8_t *reg,
+                              int n_shard, const int64_t *bases, const int64_t *ends, int flags, const uint8_t *flags_per_query,
+                              int64_t *order, int64_t *shard_start, int64_t *off, int64_t *len, int64_t *skip, int64_t *take,
+                              uint8_t *fl, int32_t *cnt) {
+    if (n < 0 || n_shard <= 0 || !bases || !ends || !shard_start) return fail(FX_EINVAL, "fx_shard_route: bad shard list");
+    if (n && (!ids || !starts || !stops || !boff || !blen || !llen || !elen || !reg || !order || !off || !len || !skip || !take || !fl || !cnt))
+        return fail(FX_EINVAL, "fx_shard_route: null argument");
+    const int64_t stream_end = ends[n_shard - 1];
+    const int T = (int)std::clamp<int64_t>(n / 65536, 1, 16);          // threads: blocks of consecutive queries (the order stays stable)
+    std::vector<int64_t> counts((size_t)T * n_shard, 0);
+    std::vector<int32_t> first((size_t)std::max<int64_t>(n, 1));
+    std::atomic<int64_t> bad{-1};
+    auto shard_of = [&](int64_t x) {                                   // last shard whose base is <= x (0 before the first)
+        const int r = (int)(std::upper_bound(bases, bases + n_shard, x) - bases) - 1;
+        return r < 0 ? 0 : r;
+    };
+    // the reference's line arithmetic, and where the range lies
+    auto range_of = [&](int64_t i, int64_t &o, int64_t &l, int64_t &sk, int64_t &tk) {
+        const int64_t id = ids[i], a = starts[i], b = stops[i];
+        const int64_t bpl = llen[id] - elen[id];
+        if (reg[id] && bpl > 0) {                                      // sequence.c:498-510
+            const int64_t bs = a / bpl, be = b / bpl;
+            o = boff[id] + a + elen[id] * bs; l = (b - a) + (be - bs) * elen[id]; sk = 0;
+        } else { o = boff[id]; l = blen[id]; sk = a; }                 // sequence.c:100-110
+        tk = b - a;
+    };
+    auto pass = [&](int t, bool scatter, const int64_t *base_pos) {
+        const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+        std::vector<int64_t> pos;
+        if (scatter) pos.assign(base_pos + (size_t)t * n_shard, base_pos + (size_t)(t + 1) * n_shard);
+        for (int64_t i = lo; i < hi; ++i) {
+            if (!scatter) {
+                if (ids[i] < 0 || ids[i] >= n_rec) { bad.store(i); first[i] = 0; continue; }
+                int64_t o, l, sk, tk;
+                range_of(i, o, l, sk, tk);
+                first[i] = shard_of(o);
+                ++counts[(size_t)t * n_shard + first[i]];
+            } else {
+                int64_t o, l, sk, tk;
+                range_of(i, o, l, sk, tk);
+                const int64_t k = pos[first[i]]++;
+                const int64_t stop = std::min(o + std::max<int64_t>(l, 0), stream_end);
+                order[k] = i; off[k] = o; len[k] = l; skip[k] = sk; take[k] = tk;
+                fl[k] = flags_per_query ? flags_per_query[i] : (uint8_t)flags;
+                cnt[k] = stop > o ? (int32_t)(shard_of(stop - 1) - first[i] + 1) : 0;
+            }
+        }
+    };
+    auto run = [&](bool scatter, const int64_t *base_pos) {
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(pass, t, scatter, base_pos);
+        pass(0, scatter, base_pos);
+        for (auto &x : th) x.join();
+    };
+    run(false, nullptr);
+    if (bad.load() >= 0) return fail(FX_EINVAL, "fx_shard_route: query %lld names record %lld of %lld", (long long)bad.load(),
+                                     (long long)ids[bad.load()], (long long)n_rec);
+    std::vector<int64_t> base_pos((size_t)T * n_shard);
+    int64_t at = 0;
+    for (int r = 0; r < n_shard; ++r) {
+        shard_start[r] = at;
+        for (int t = 0; t < T; ++t) { base_pos[(size_t)t * n_shard + r] = at; at += counts[(size_t)t * n_shard + r]; }
+    }
+    shard_start[n_shard] = at;
+    run(true, base_pos.data());
+    return FX_OK;
 }
 
 extern "C" int fx_fetch_slices(fx_handle *h, int where, int64_t n, const int64_t *off, const int64_t *blen, const int64_t *skip,

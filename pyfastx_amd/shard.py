@@ -623,43 +623,54 @@ class ShardFetcher:
     def __init__(self, fetchers, bases, ends, table, exchange=None):
         self.f, self.table, self.exchange = dict(fetchers), table, exchange
         self.bases, self.ends = np.asarray(bases, dtype=np.int64), np.asarray(ends, dtype=np.int64)
+        reg = table["reg"] if "reg" in table else table["norm"]
+        self._cols = {k: np.ascontiguousarray(table[k], dtype=np.int64) for k in ("boff", "blen", "llen", "elen")}
+        self._cols["reg"] = np.ascontiguousarray(np.asarray(reg) != 0, dtype=np.uint8)
 
     def fetch(self, ids, starts, stops, flags=0, flags_per_query=None):
         """-> (qidx, buf, offs): the queries this process answers (those whose first byte it holds; ordered by shard,
         then by position in the batch), their bases back to back, offsets[len(qidx)+1]."""
+        from . import _lib
         n = len(ids)
-        fl = np.full(n, int(flags), dtype=np.uint8) if flags_per_query is None else np.asarray(flags_per_query, dtype=np.uint8)
-        off, blen, skip, take = slice_ranges(self.table, ids, starts, stops)
-        P = route_ranges(self.bases, self.ends, off, blen)
-        q, r = P["q"], P["r"]
-        simple = P["cnt"] == 1                                # one piece: the kernel does it all (slice after despacing included)
-        psimple = simple[q]
-        held = np.isin(r, np.fromiter(self.f.keys(), dtype=np.int64, count=len(self.f)))
+        # line arithmetic, owning shard and routed order of the whole batch: one pass in the library (fx_shard_route)
+        R = _lib.shard_route(ids, starts, stops, self._cols, self.bases, self.ends, flags, flags_per_query)
+        order, ss, cnt = R["order"], R["shard_start"], R["cnt"]
         answers = {}
         loose = []                                            # (query, shard, bytes): pieces of queries that cross a cut
         for sh, fx in self.f.items():
-            mine = np.nonzero(held & (r == sh))[0]
-            if not mine.size:
+            a, b = int(ss[sh]), int(ss[sh + 1])
+            if a == b:
                 continue
-            qq = q[mine]
-            s = psimple[mine]
-            want = np.where(s, take[qq], P["plen"][mine])
-            kfl = np.where(s, fl[qq], fl[qq] & np.uint8(F_UP | F_COMP)).astype(np.uint8)
-            ksk = np.where(s, skip[qq], 0)
-            buf, offs, ol = fx.fetch_ranges(P["poff"][mine], P["plen"][mine], want, flags_per_query=kfl,
-                                            skip=ksk if ksk.any() else None)
-            for k in np.nonzero(~s)[0].tolist():
-                loose.append((int(qq[k]), int(sh), buf[offs[k]:offs[k] + ol[k]].tobytes()))
-            ks = np.nonzero(s)[0]
-            answers[sh] = (qq[ks], buf, offs[ks], ol[ks])
+            seg = slice(a, b)
+            whole = cnt[seg] == 1                             # one piece: the kernel does it all (slice after despacing included); 0: nothing to read
+            if whole.all():
+                off, ln, tk, kfl, ksk, qq = R["off"][seg], R["len"][seg], R["take"][seg], R["fl"][seg], R["skip"][seg], order[seg]
+            else:
+                k = a + np.nonzero(whole)[0]
+                off, ln, tk, kfl, ksk, qq = R["off"][k], R["len"][k], R["take"][k], R["fl"][k], R["skip"][k], order[k]
+            buf, offs, ol = fx.fetch_ranges(off, ln, tk, flags_per_query=kfl, skip=ksk if ksk.any() else None)
+            answers[sh] = (qq, buf, offs[:-1] if offs.size == qq.size + 1 else offs, ol)
+        # the few queries that cross a cut: their pieces per shard, despaced by the shard that holds them
+        cross = np.nonzero(cnt > 1)[0]
+        if cross.size:
+            P = route_ranges(self.bases, self.ends, R["off"][cross], R["len"][cross])
+            for k in range(P["q"].size):
+                sh = int(P["r"][k])
+                if sh in self.f:
+                    j = int(cross[P["q"][k]])
+                    buf, offs, ol = self.f[sh].fetch_ranges([P["poff"][k]], [P["plen"][k]], [P["plen"][k]],
+                                                            flags=int(R["fl"][j]) & (F_UP | F_COMP))
+                    loose.append((int(order[j]), sh, buf[:int(ol[0])].tobytes()))
+        skip, take, fl = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.uint8)
+        if cross.size:
+            skip[order[cross]], take[order[cross]], fl[order[cross]] = R["skip"][cross], R["take"][cross], R["fl"][cross]
         everybody = self.exchange(loose) if self.exchange is not None else loose
         by_q = {}
         for qi, sh, bts in sorted(everybody):
             by_q.setdefault(qi, []).append(bts)
         # ---- what this process answers, in query order: runs of kernel output + the few answers put together here
-        own = np.fromiter(self.f.keys(), dtype=np.int64, count=len(self.f))
-        mine_q = np.nonzero(np.isin(P["first"], own))[0]
-        mine_q = mine_q[np.argsort(P["first"][mine_q], kind="stable")]     # shard by shard: the kernels' outputs stay whole
+        own = sorted(self.f.keys())
+        mine_q = np.concatenate([order[int(ss[sh]):int(ss[sh + 1])] for sh in own]) if own else np.zeros(0, dtype=np.int64)   # shard by shard: the kernels' outputs stay whole
         m = mine_q.size
         pos = np.full(n, -1, dtype=np.int64)
         pos[mine_q] = np.arange(m, dtype=np.int64)

@@ -999,3 +999,48 @@ def test_cli_arguments_match_the_reference_commands():
         cli.main(["subseq", "/nonexistent.fa", "chr1:1-5"])
     with pytest.raises((FileExistsError, FileNotFoundError, OSError)):
         cli.main(["extract", "--reverse-complement", "--out-fasta", "-l", "names.txt", "/nonexistent.fq"])
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_shard_route_equals_the_vectorised_statement(seed):
+    """fx_shard_route (the library's one-pass routing of a query batch) against shard.slice_ranges + shard.route_ranges:
+    byte ranges, slices after despacing for records that are not line-regular, answering shard, shards touched, and the
+    routed order (by shard, then by position in the batch); a record id outside the table is an error."""
+    from pyfastx_amd import _lib, shard
+    rng = np.random.default_rng(9200 + seed)
+    nrec = 40
+    slen = rng.integers(0, 30_000, nrec)
+    bpl, elen = int(rng.integers(1, 80)), 1 + (seed & 1)
+    blen = slen + (slen + bpl - 1) // bpl * elen
+    boff = np.cumsum(np.concatenate([[30], blen[:-1] + 30]))
+    reg = (rng.random(nrec) > 0.3).astype(np.uint8)
+    table = {"boff": boff, "blen": blen, "llen": np.full(nrec, bpl + elen), "elen": np.full(nrec, elen), "reg": reg}
+    if seed == 2:
+        table["llen"][:5] = elen                              # bytes per line 0: never the line arithmetic
+    total = int(boff[-1] + blen[-1])
+    G = (1, 3, 7)[seed]
+    cuts = sorted(set(int(x) for x in rng.integers(1, total - 1, G - 1)))
+    bases, ends = [0] + cuts, cuts + [total]
+    n = 70_000 * (seed + 1)                                   # past 65536: several threads
+    ids = rng.integers(0, nrec, n)
+    a = (rng.random(n) * np.maximum(slen[ids], 1)).astype(np.int64)
+    b = np.minimum(a + rng.integers(0, 3000, n), slen[ids] + rng.integers(0, 3, n))
+    b[:50] = a[:50] - rng.integers(0, 2, 50)                  # empty and inverted intervals
+    fl = rng.integers(0, 8, n).astype(np.uint8)
+    cols = {k: np.ascontiguousarray(table[k], dtype=np.int64) for k in ("boff", "blen", "llen", "elen")}
+    cols["reg"] = reg
+    R = _lib.shard_route(ids, a, b, cols, bases, ends, 0, fl)
+    off, ln, sk, tk = shard.slice_ranges(table, ids, a, b)
+    P = shard.route_ranges(bases, ends, off, ln)
+    o = R["order"]
+    assert (np.sort(o) == np.arange(n)).all()
+    for k, w in (("off", off), ("len", ln), ("skip", sk), ("take", tk), ("fl", fl), ("cnt", P["cnt"])):
+        assert (R[k] == w[o]).all(), k
+    assert R["shard_start"][0] == 0 and R["shard_start"][-1] == n
+    for r in range(len(bases)):
+        seg = o[R["shard_start"][r]:R["shard_start"][r + 1]]
+        assert (P["first"][seg] == r).all() and (np.diff(seg) > 0).all()
+    assert (R["cnt"] > 1).sum() > 0 or G == 1
+    ids[n // 2] = nrec
+    with pytest.raises(_lib.FxError):
+        _lib.shard_route(ids, a, b, cols, bases, ends)

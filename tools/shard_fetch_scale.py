@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pyfastx_amd import shard, synth  # noqa: E402
+from pyfastx_amd import _lib, shard, synth  # noqa: E402
 
 
 def main():
@@ -74,8 +74,7 @@ def main():
     times = []
     for _ in range(3):
         t0 = time.perf_counter()
-        off, bl, skip, take = shard.slice_ranges(table, ids, st, sp)
-        P = shard.route_ranges(bases, ends, off, bl)
+        P = _lib.shard_route(ids, st, sp, f._cols, bases, ends, 0, fl)        # what fetch() begins with (fx_shard_route)
         t1 = time.perf_counter()
         qidx, buf, offs = f.fetch(ids, st, sp, flags_per_query=fl)
         t2 = time.perf_counter()
