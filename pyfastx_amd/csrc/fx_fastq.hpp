@@ -10,17 +10,18 @@
 //        at) -- into the granule's slot of FQL_CAP records, and the granule's newline count / first / last exactly
 //        as k_span_scan<1> would.  4 bytes per line instead of the line.
 //   k_gran_reduce<1> + k_gran_prefix     exclusive prefixes of the granule counts (shared with the FASTA build)
-//   k_fastq_rows      a wave per four granules, one lane per line record: global line index = loff + nl_prefix[g] + rank,
-//        phase = index & 3, and the lane writes the field(s) of record index >> 2 that this newline determines
-//        (header end: name_off / name_len / dlen / soff; sequence end: rlen; '+' line end: qoff; quality end: qlen).
-//        It touches the stream only for a header line that began in an earlier granule (its name may end there).
+//   k_fastq_rows      a wave per four granules, their line records side by side in LDS, one lane per ROW: global line
+//        index = loff + nl_prefix[g] + rank, and the lane goes through the four lines of record index >> 2 -- header end:
+//        name_off / name_len / dlen / soff; sequence end: rlen; '+' line end: qoff; quality end: qlen -- so every store
+//        covers consecutive rows.  It touches the stream only for a header line that began in an earlier granule (its
+//        name may end there).
 //   k_fastq_emit      the same rows from the BYTES of a granule (re-read into LDS): for the granules on a list --
 //        those with more than FQL_CAP lines and the partial last one -- or, when the sampled line density says most
 //        granules would overflow (lines shorter than ~40 bytes), for all of them after a count-only k_span_scan<1>:
 //        the two-read build.
 //   No line table, no record-level gathers from memory; one atomic per workgroup that has an overflowing granule.
 //
-// 20 M reads of 150 bp (7 GB): 1.37 + 0.06 (prefixes) + 0.53 ms = 2.26 ms with k_fastq_stats; two reads: 1.05 + 0.06 + 1.55.
+// 20 M reads of 150 bp (7 GB): 1.37 + 0.06 (prefixes) + 0.49 ms = 2.2 ms with k_fastq_stats; two reads: 1.05 + 0.06 + 1.55.
 // k_fastq_lines reads the stream exactly once (PMC: 1.000 x) at 5.1 TB/s with the VALU ~60 % busy (506 instructions per
 // granule, half of them the three exact byte masks); a copy of the granule in LDS and a byte scan of the lines that start
 // with '@' instead of the space / CR maps was slower (1.49 ms).
@@ -322,8 +323,11 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines(const uint8_t *__restrict
 #define FX_FQR_G 4
 #endif
 constexpr int FQR_G = FX_FQR_G;
+static_assert(FQR_G <= 8, "a staged line record has three bits for the granule of the wave it came from");
 
-__device__ __forceinline__ void fq_row_of_line(const ScanCtx &x, const FqOwn &own, const FqTab &t, int64_t gs, uint32_t i, uint32_t r,
+// The fields the line record r of line idx determines (line i of its granule, which begins at global offset gs; q =
+// global offset of the newline before it), into row idx >> 2 of the table when the shard owns it.
+__device__ __forceinline__ void fq_row_of_line(const ScanCtx &x, const FqOwn &own, const FqTab &t, int64_t gs, bool first_of_granule, uint32_t r,
                                                int64_t q, int64_t idx) {
     const int64_t p = gs + (r & 0xFFFu);
     const int64_t row = (idx >> 2) - own.k_first;
@@ -336,11 +340,11 @@ __device__ __forceinline__ void fq_row_of_line(const ScanCtx &x, const FqOwn &ow
         if (nlen > 0 && cr) --nlen;                                       // fastq.c:107-109
         const int64_t nb = q + 2, ne = nb + nlen;                         // the name's first byte, the end of the search
         int64_t sp = (r & FQL_HAS) ? gs + ((r >> 14) & 0xFFFu) : ne;      // first space among the line's bytes in this granule
-        if (i == 0 && nb < gs) {                                          // the line began in an earlier granule: those bytes first
+        if (first_of_granule && nb < gs) {                                // the line began in an earlier granule: those bytes first
             const int64_t e = ne < gs ? ne : gs;
             const int64_t hit = x.gbase + first_space(x.data, nb - x.gbase, e - x.gbase);
             if (hit < e) sp = hit;
-        } else if (i == 0 && sp < nb) {                                   // it begins exactly here and its FIRST byte is a space
+        } else if (first_of_granule && sp < nb) {                         // it begins exactly here and its FIRST byte is a space
             sp = x.gbase + first_space(x.data, nb - x.gbase, ne - x.gbase);
         }
         const int64_t hit = sp < ne ? sp : ne;
@@ -354,35 +358,74 @@ __device__ __forceinline__ void fq_row_of_line(const ScanCtx &x, const FqOwn &ow
     }
 }
 
+// ONE LANE PER ROW.  The line records of the wave's granules are consecutive lines of the file (when none of the
+// granules overflowed): they are put side by side in LDS (bits 26-28 of a staged record: which of the wave's granules),
+// and lane k takes row (first row of the wave) + k -- its header, sequence, '+' and quality line one after the other,
+// each from its record and the one before.  Every lane is in the same phase at the same time and every store covers
+// consecutive rows.  (One lane per LINE: four phases side by side in every wave and every fourth lane storing,
+// 0.54 ms for 20 M reads where the traffic is worth 0.2; the same with the fields put together in LDS first: 0.67 ms;
+// this form 0.48-0.50 ms, eight granules per wave 0.77, two 0.55; the x-th eighth of the granules to XCD x, so that
+// neighbouring rows go through one L2: no difference.)
 __global__ __launch_bounds__(BLOCK) void k_fastq_rows(ScanCtx x, FqOwn own, FqTab t, const uint32_t *__restrict__ recs, int64_t g_end) {
+    __shared__ uint32_t s_rec[BLOCK / 64][FQR_G * FQL_CAP];
     const int lane = lane_id();
     const int64_t g0 = ((int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * FQR_G;
-    if (g0 >= g_end) return;
-    uint32_t M[FQR_G];
+    if (g0 >= g_end) return;                                               // waves are independent: no workgroup barrier below
+    uint32_t M[FQR_G], rr[FQR_G];
     int64_t I0[FQR_G], q0[FQR_G];
+    bool whole = true;                                                     // no granule of the wave left to k_fastq_emit
+    // the first 64 records of every slot are asked for together with the summaries that say how many of them count:
+    // one round trip instead of two (a slot always has FQL_CAP entries; what lies past the granule's count is ignored)
+#pragma unroll
+    for (int k = 0; k < FQR_G; ++k) rr[k] = g0 + k < g_end ? recs[(g0 + k) * (int64_t)FQL_CAP + lane] : 0u;
 #pragma unroll
     for (int k = 0; k < FQR_G; ++k) {
-        M[k] = 0;
+        M[k] = 0; I0[k] = 0; q0[k] = -1;
         if (g0 + k < g_end) { M[k] = x.go[g0 + k].nh & 0xFFFFu; I0[k] = x.nl_prefix[g0 + k]; q0[k] = x.prevnl[g0 + k]; }
-        if (M[k] > (uint32_t)FQL_CAP) M[k] = 0;                           // overflowed: k_fastq_emit reads that granule again
+        if (M[k] > (uint32_t)FQL_CAP) { M[k] = 0; whole = false; }        // overflowed: k_fastq_emit reads that granule again
     }
-    uint32_t r[FQR_G], rp[FQR_G];
-#pragma unroll
-    for (int k = 0; k < FQR_G; ++k) {
-        const uint32_t *slot = recs + (g0 + k) * (int64_t)FQL_CAP;
-        r[k] = rp[k] = 0;
-        if ((uint32_t)lane < M[k]) { r[k] = slot[lane]; if (lane) rp[k] = slot[lane - 1]; }
-    }
-#pragma unroll
-    for (int k = 0; k < FQR_G; ++k) {
-        const int64_t gs = x.gbase + (g0 + k) * (int64_t)GRAN;
-        const int64_t qq = q0[k] < 0 ? own.prev_nl : q0[k];
-        if ((uint32_t)lane < M[k])
-            fq_row_of_line(x, own, t, gs, (uint32_t)lane, r[k], lane ? gs + (rp[k] & 0xFFFu) : qq, own.loff + I0[k] + lane);
-        if (M[k] > 64u) {                                                  // lines of less than 64 bytes on average
+    if (!whole) {                                                          // one lane per line, granule by granule
+#pragma unroll 1
+        for (int k = 0; k < FQR_G; ++k) {
             const uint32_t *slot = recs + (g0 + k) * (int64_t)FQL_CAP;
-            const uint32_t i = 64u + lane;
-            if (i < M[k]) fq_row_of_line(x, own, t, gs, i, slot[i], gs + (slot[i - 1] & 0xFFFu), own.loff + I0[k] + i);
+            const int64_t gs = x.gbase + (g0 + k) * (int64_t)GRAN;
+            const int64_t qq = q0[k] < 0 ? own.prev_nl : q0[k];
+            for (uint32_t i = lane; i < M[k]; i += 64)
+                fq_row_of_line(x, own, t, gs, i == 0, slot[i], i ? gs + (slot[i - 1] & 0xFFFu) : qq, own.loff + I0[k] + i);
+        }
+        return;
+    }
+    uint32_t *sr = s_rec[threadIdx.x >> 6];
+    uint32_t cum[FQR_G + 1];
+    cum[0] = 0;
+#pragma unroll
+    for (int k = 0; k < FQR_G; ++k) {
+        cum[k + 1] = cum[k] + M[k];
+        const uint32_t *slot = recs + (g0 + k) * (int64_t)FQL_CAP;
+        if ((uint32_t)lane < M[k]) sr[cum[k] + lane] = rr[k] | ((uint32_t)k << 26);
+        if (64u + lane < M[k]) sr[cum[k] + 64u + lane] = slot[64u + lane] | ((uint32_t)k << 26);      // lines of less than 64 bytes on average
+    }
+    const uint32_t Mtot = cum[FQR_G];
+    if (!Mtot) return;
+    const int64_t L0 = own.loff + I0[0];                                   // global index of the wave's first line
+    const int64_t gs0 = x.gbase + g0 * (int64_t)GRAN;
+    const int64_t qq0 = q0[0] < 0 ? own.prev_nl : q0[0];                   // the newline before the wave's first line
+    const int64_t rb = L0 >> 2, re = (L0 + Mtot - 1) >> 2;                 // rows the wave's lines touch
+    for (int64_t row = rb + lane; row <= re; row += 64) {
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const int64_t jj = 4 * row + ph - L0;
+            if (jj < 0 || jj >= (int64_t)Mtot) continue;
+            const uint32_t j = (uint32_t)jj;
+            const uint32_t r = sr[j];
+            const uint32_t k = (r >> 26) & 7u;
+            const int64_t gs = gs0 + (int64_t)k * GRAN;
+            int64_t q = qq0;
+            if (j) { const uint32_t rp = sr[j - 1]; q = gs0 + (int64_t)((rp >> 26) & 7u) * GRAN + (rp & 0xFFFu); }
+            bool first_of_granule = false;
+#pragma unroll
+            for (int kk = 0; kk < FQR_G; ++kk) first_of_granule |= k == (uint32_t)kk && j == cum[kk];
+            fq_row_of_line(x, own, t, gs, first_of_granule, r & 0x03FFFFFFu, q, L0 + j);
         }
     }
 }
@@ -515,6 +558,14 @@ __device__ __forceinline__ void fq_keep_first(uint32_t (&x)[4], int keep, uint32
 // mask looked up in LDS.  It holds when 16 <= line length <= 16 * lpr for every record of the iteration; an iteration
 // with any other record (shorter than a piece, longer than one step, no rows at all) takes the general path, piece by
 // piece with its own loads.
+// What bounds the kernel is the shape of its loads, not what it does with them: with the counting compiled out it takes
+// the same time (20 M reads of 150 bases, 7 GB: 1.63 ms; with every address rounded down to 16 or to 64 bytes -- wrong
+// answers, timing only -- 1.35 ms, which is also what k_fastq_lines needs to stream the whole file).  PMC: the texture
+// addresser is busy 65 % of the time, 53 cycles per load instruction, and the L1 looks 40 tags up per instruction: 16
+// bytes per lane at any alignment are handled lane by lane.  What helped was fewer of them: lanes per record from the
+// mean read length (16 lanes for a 150-byte line: 2.26 ms; 10: 1.64), the rows of an iteration fetched once per wave
+// instead of once per group (1.67 -> 1.53).  Occupancy (4 to 6 waves), two or three records per group and the depth of
+// the software pipeline made no difference.
 __global__ __launch_bounds__(BLOCK) void k_fastq_comp(const uint8_t *__restrict__ data, int64_t gbase, int64_t n_bytes, FqTab t,
                                                      int64_t n_seq_rows, int64_t n_rows, FastqAcc *acc, int lpr,
                                                      const uint8_t *__restrict__ safe) {
@@ -661,8 +712,8 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp(const uint8_t *__restrict_
     Plan cur[FQ_U], nxt[FQ_U];
     uint4 vs[FQ_U], vq[FQ_U], ns[FQ_U], nq[FQ_U];
     // Loads come back in the order they were asked for, so the order is: rows of k + 2, THEN pieces of k + 1 -- waiting
-    // for those rows at the top of the next pass leaves the pieces in flight; the other way round every pass began by
-    // draining everything, and a wave never had more than one iteration of pieces under way (1.64 ms for 7 GB either way).
+    // for those rows at the top of the next pass leaves the pieces in flight; the other way round every pass begins by
+    // draining everything.
     rows_request();
     plan(cur);
     i0 += stride;
