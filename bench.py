@@ -791,6 +791,7 @@ def main():
         if not verified:
             raise SystemExit("PARITY FAILURE at full size: refusing to report a speed-up")
     comp_ms = None
+    full_index = None
     if world == 1 and not a.no_verify:
         # per-record composition (fasta.c:901-950) at full size vs torch.bincount of the un-wrapped bases
         # (extra information, outside the timed region: full_index is lazy in the reference too)
@@ -811,6 +812,29 @@ def main():
                 okc &= bool((torch.bincount(seg.long(), minlength=128)[:128] == d_comp[i]).all())
         if not okc:
             raise SystemExit("PARITY FAILURE (composition) at full size")
+        # index AND composition in one read of the stream: the counters ride on the scan (fx_fasta_build with
+        # FX_BUILD_COMP: k_scan_comp, then k_comp_attribute + the edge runs), against build + composition pass above
+        d_comp2 = torch.zeros_like(d_comp)
+        job.blob.fasta_build(False, comp=True)
+        job.blob.fasta_comp_dev(d_comp2.data_ptr())
+        job.sync()
+        tc = time.perf_counter()
+        for _ in range(3):
+            job.blob.fasta_build(False, comp=True)
+            job.blob.fasta_comp_dev(d_comp2.data_ptr())
+        job.sync()
+        fused_ms = (time.perf_counter() - tc) / 3 * 1e3
+        if not bool((d_comp2 == d_comp).all()):
+            raise SystemExit("PARITY FAILURE (composition counted on the scan) at full size")
+        tc = time.perf_counter()
+        for _ in range(3):
+            job.blob.fasta_build(False)
+            job.blob.fasta_comp_dev(d_comp2.data_ptr())
+        job.sync()
+        two_ms = (time.perf_counter() - tc) / 3 * 1e3       # leaves the plain build behind
+        full_index = {"index_and_composition_one_read_ms": round(fused_ms, 3), "index_then_composition_two_reads_ms": round(two_ms, 3),
+                      "rows_equal": True}
+        del d_comp2
 
     if world > 1 and not a.no_verify:
         # composition across the cuts (shard.ShardedFasta.composition: local counting + two small all-gathers):
@@ -859,6 +883,7 @@ def main():
         "fetch_M_per_s": round(world * a.queries / max(fetch_ms * 1e-3, 1e-9) / 1e6, 2),
         "parity_verified_full_size": verified,
         "composition_pass_ms": None if comp_ms is None else round(comp_ms, 3),
+        "full_index": full_index,
         "kernels_ms_avg": {k: round(v[0] / v[1], 4) for k, v in prof_all.items()},
         "roofline": {"kernel": "fx::k_span_scan<0>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": shard.pmc_traffic(ROOT, shard_bytes),

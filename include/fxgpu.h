@@ -107,7 +107,13 @@ typedef struct {
 } fx_fasta_summary;
 
 /* Build the record table on the GPU (kept resident in HBM for fetches).
- * full_name: chrom = whole header (index.c:282-285) instead of first token. */
+ * full_name, bit 0: chrom = whole header (index.c:282-285) instead of first token.
+ * bit 1 (FX_BUILD_COMP): count the letters on the way -- the reference's second pass over the file
+ * (pyfastx_fasta_calc_composition, fasta.c:851-961) rides on the index scan, ONE read of the stream for both; a later
+ * fx_fasta_comp / _shard / _sparse then only attributes the counts to the records and reads the bytes of record
+ * boundaries again.  The counts are dropped by the next build or fx_set_shard. */
+#define FX_BUILD_FULL_NAME 1
+#define FX_BUILD_COMP 2
 int fx_fasta_build(fx_handle *h, int full_name, fx_fasta_summary *out);
 
 /* The same in two halves: _begin ENQUEUES the whole build on the handle's stream and returns; _end waits for it and

@@ -385,11 +385,12 @@ class Blob:
         self._table_ready = True
         self._n_fasta = int(a[0].size)
 
-    def fasta_build_begin(self, full_name=False):
-        """Enqueue the build and return (no host synchronisation); see fasta_build_end."""
+    def fasta_build_begin(self, full_name=False, comp=False):
+        """Enqueue the build and return (no host synchronisation); see fasta_build_end.  comp: the composition counters
+        ride on the scan (one read of the stream for index + composition; fasta_comp* then only attribute them)."""
         self._table_ready = True
         self._n_fasta = None
-        check(lib().fx_fasta_build_begin(self._h, int(bool(full_name))))
+        check(lib().fx_fasta_build_begin(self._h, int(bool(full_name)) | (2 if comp else 0)))
 
     def fasta_build_end(self):
         s = FastaSummary()
@@ -397,10 +398,10 @@ class Blob:
         self._n_fasta = int(s.n_seq)
         return s
 
-    def fasta_build(self, full_name=False):
+    def fasta_build(self, full_name=False, comp=False):
         self._table_ready = True
         s = FastaSummary()
-        check(lib().fx_fasta_build(self._h, int(bool(full_name)), C.byref(s)))
+        check(lib().fx_fasta_build(self._h, int(bool(full_name)) | (2 if comp else 0), C.byref(s)))
         self._n_fasta = int(s.n_seq)
         return s
 

@@ -194,6 +194,8 @@ class Fasta:
         self.size = 0
         if _first_nonspace(file_name, self.is_gzip) != ord(">"):                          # fasta.c:107-110
             raise RuntimeError("%s is not plain or gzip compressed fasta formatted file" % file_name)
+        self._want_comp = bool(build_index and full_index)   # the index build then counts the letters on the way (one read of the stream)
+        self._comp_in_build = False
         if build_index:
             self.build_index()
             if full_index:
@@ -231,9 +233,10 @@ class Fasta:
             return
         blob = self._st.blob
         try:
-            s = blob.fasta_build(self._full_name)
+            s = blob.fasta_build(self._full_name, comp=self._want_comp)
         except _lib.FxError as e:
             raise _fx_to_py(e)
+        self._comp_in_build = self._want_comp
         self._scanned_here = True
         t = blob.fasta_table(s.n_seq)
         self._db = None
@@ -273,7 +276,11 @@ class Fasta:
             self._full_index = True
             return
         blob = self._st.blob
-        s = blob.fasta_build(self._full_name)
+        if self._comp_in_build:                                  # the build that made the index has counted already
+            s = blob.fasta_build_end()
+            self._comp_in_build = False
+        else:
+            s = blob.fasta_build(self._full_name, comp=True)    # index scan and letter counts in one read of the stream
         if s.n_seq >= _COMP_BULK_MIN and self._index_file != ":memory:":
             # many records: the non-zero bins come off the GPU as triples (the dense matrix stays in HBM) and the
             # comp table + seqidx go into the file as b-tree pages instead of ~10 INSERTs per record

@@ -172,9 +172,9 @@ __device__ __forceinline__ void comp_flush(CompState &s, uint32_t *__restrict__ 
 // count the bytes [a, b) (granule-relative) of the granule held in v[4] (lane l, load j: bytes (j*64 + l)*16 ..) into s;
 // FULL: the whole granule, no masking.  Returns != 0 in the lanes that met a byte outside the expected set.
 template <bool FULL>
-__device__ __forceinline__ uint32_t comp_add_granule(CompState &s, const uint4 (&v)[4], int a, int b) {
+__device__ __forceinline__ uint32_t comp_add_granule(CompState &s, const uint4 (&v)[4], int a, int b, uint32_t *drow = nullptr) {
     const int lane = lane_id();
-    uint32_t dacc = 0;
+    uint32_t dacc = 0;                          // (drow, optional: the same per load j, i.e. per KiB row of the granule)
     CompCarry ca, cl;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -202,6 +202,7 @@ __device__ __forceinline__ uint32_t comp_add_granule(CompState &s, const uint4 (
             asm volatile("" : "+v"(dacc));
             if (FULL) __builtin_amdgcn_sched_barrier(0);
         }
+        if (drow) { drow[j] = dacc; dacc = 0; }
         csa(ca.f[j & 1], s.all.p[1], s.all.p[1], tA, tB);
         csa(cl.f[j & 1], s.low.p[1], s.low.p[1], uA, uB);
         if (j & 1) {
@@ -212,6 +213,7 @@ __device__ __forceinline__ uint32_t comp_add_granule(CompState &s, const uint4 (
     }
     planes_finish16(s.all, ca);
     planes_finish16(s.low, cl);
+    if (drow) dacc = drow[0] | drow[1] | drow[2] | drow[3];
     return dacc;
 }
 

@@ -169,9 +169,11 @@ __device__ __forceinline__ void granule_load(uint4 (&v)[GR_ROWS], const uint8_t 
     }
 }
 
+// odd (optional, MODE 0): per row, non-zero in the lanes whose chunk holds a byte that is no sequence letter and no line
+// end -- a caller that has classified the bytes anyway (k_scan_comp) passes it in place of the '>' pre-filter below
 template <int MODE = 0>
 __device__ __forceinline__ uint32_t granule_body(const uint4 (&v)[GR_ROWS], const uint8_t *__restrict__ data, int prev_byte,
-                                                 int64_t g, GranPk *__restrict__ out, uint32_t &L) {
+                                                 int64_t g, GranPk *__restrict__ out, uint32_t &L, const uint32_t *odd = nullptr) {
     const int lane = lane_id();
     const int64_t sbase = g * (int64_t)GRAN;
 
@@ -246,7 +248,7 @@ __device__ __forceinline__ uint32_t granule_body(const uint4 (&v)[GR_ROWS], cons
             carry = (int)rdlane(pl, 63 - __clzll(bal));
         }
         // header lines: the exact '>' test only runs where the cheap filter fires (header text)
-        if (__builtin_expect(__ballot(maybe_gt16(v[j])) != 0, 0)) {
+        if (__builtin_expect(__ballot(odd ? odd[j] != 0 : maybe_gt16(v[j])) != 0, 0)) {
             if (!nlm) nlm = flags4(t0) | (flags4(t1) << 4) | (flags4(t2) << 8) | (flags4(t3) << 12);
             h_w += wave_sum_small(__popc(header_mask16(v[j], nlm, data, sbase + cb, prev_byte)));
         }

@@ -26,6 +26,7 @@
 #include "fx_spanscan.hpp"
 #include "fx_fastq.hpp"
 #include "fx_comp.hpp"
+#include "fx_scancomp.hpp"
 #include "fx_names.hpp"
 #include "fx_inflate.hpp"
 #include "fx_fxi.hpp"
@@ -102,10 +103,10 @@ static void crc_tables(CrcTables *T) {
 }
 
 enum KernelId { K_SPAN_SCAN = 0, K_GRAN_REDUCE, K_GRAN_PREFIX, K_HDR_REC, K_GRAN_LINES, K_GRAN_EXACT, K_FASTA_FINALIZE, K_FETCH,
-                K_FASTA_COMP, K_FASTA_COMP_EDGE, K_FASTA_COMP_SMALL, K_FASTQ_LINES, K_FASTQ_ROWS, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_BGZF_CRC, K_NKERN };
+                K_FASTA_COMP, K_FASTA_COMP_EDGE, K_FASTA_COMP_SMALL, K_FASTQ_LINES, K_FASTQ_ROWS, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_BGZF_CRC, K_SCAN_COMP, K_COMP_ATTRIBUTE, K_NKERN };
 static const char *const kKernelNames[K_NKERN] = {
     "k_span_scan", "k_gran_reduce", "k_gran_prefix", "k_hdr_rec", "k_gran_lines", "k_gran_exact", "k_fasta_finalize", "k_fetch",
-    "k_fasta_comp", "k_fasta_comp_edge", "k_fasta_comp_small", "k_fastq_lines", "k_fastq_rows", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy", "k_bgzf_crc"};
+    "k_fasta_comp", "k_fasta_comp_edge", "k_fasta_comp_small", "k_fastq_lines", "k_fastq_rows", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy", "k_bgzf_crc", "k_scan_comp", "k_comp_attribute"};
 
 struct Prof {
     bool on = false;
@@ -190,6 +191,9 @@ struct fx_handle {
     bool fasta_built = false;
     bool build_pending = false;               // fx_fasta_build_begin enqueued, totals not read back yet
     int pending_full_name = 0;
+    DevBuf<uint32_t> comp_runs;               // a build with composition (k_scan_comp): 16 words per run of comp_gpw granules
+    int comp_gpw = 0;
+    bool comp_runs_valid = false;
     // FASTQ table
     DevBuf<int64_t> fq_name_off, fq_rlen, fq_soff, fq_qoff;
     DevBuf<int32_t> fq_name_len, fq_dlen, fq_qlen;
@@ -277,7 +281,7 @@ extern "C" int fx_set_shard(fx_handle *h, int64_t base, int prev_byte, int is_la
     h->base = base;
     h->prev_byte = base == 0 ? '\n' : (prev_byte & 0xFF);
     h->is_last = is_last != 0;
-    h->scanned = h->fasta_built = h->fastq_built = false;
+    h->scanned = h->fasta_built = h->fastq_built = h->comp_runs_valid = false;
     h->nm_kind = -1;
     return FX_OK;
 }
@@ -308,15 +312,18 @@ struct Stager {          // pinned ring: producer fills slot, H2D async, event m
 };
 
 static int stage_threads() {
+    static const int forced = [] { const char *e = getenv("FX_STAGE_THREADS"); return e ? atoi(e) : 0; }();   // experiments
+    if (forced > 0) return std::min(forced, 64);
     const unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::min<unsigned>(16u, std::max<unsigned>(4u, hw / 8));
+    return (int)std::min<unsigned>(8u, std::max<unsigned>(4u, hw / 8));     // 3 GB from the page cache: 8 threads 47 GB/s, 16: 41, 32: 37 (tools/stage_probe.py)
 }
 
-// Plain files: T host threads, each with its own pair of pinned 8 MiB buffers and its own HIP stream,
+// Plain files: T host threads (8: more of them copy out of the page cache more slowly, not faster), each with its own pair of
+// pinned 8 MiB buffers and its own HIP stream,
 // walk the file in an interleaved pattern (thread t takes pieces t, t+T, ...): pread into pinned memory,
 // hipMemcpyAsync to the blob, double-buffered.  The pinned buffers are allocated once per process
 // (pinning 256 MiB costs about as much as moving 1 GB) and reused by later opens.
-static const int64_t PIECE_BYTES = 8ll << 20;
+static const int64_t PIECE_BYTES = [] { const char *e = getenv("FX_STAGE_PIECE_MB"); const int mb = e ? atoi(e) : 0; return (int64_t)(mb > 0 && mb <= 256 ? mb : 8) << 20; }();
 struct PinPool {
     std::mutex mu;
     std::vector<uint8_t *> bufs;
@@ -1028,8 +1035,13 @@ static uint32_t *ctl_counter(fx_handle *h, int i) { return (uint32_t *)(h->ctl.p
 
 // Granule summaries + prefixes of the resident stream.  MODE 0: FASTA (line-length sets, header lines);
 // MODE 1: FASTQ (newline count / first / last only).  Enqueues only; h->ctl holds the totals afterwards.
+static int comp_run_granules(int64_t ngran) {       // granules per run of the composition kernels (a multiple of the pipeline depth)
+    // 8 = 32 KiB measured best on 3 GB (0.525 ms; 16: 0.550, 4: 0.569), shorter runs for small inputs so that the machine still fills
+    return ngran >= 65536 ? 4 * COMP_DEPTH : ngran >= 16384 ? 2 * COMP_DEPTH : COMP_DEPTH;
+}
+
 template <int MODE>
-static int granule_pass(fx_handle *h, bool fq_lines = false) {
+static int granule_pass(fx_handle *h, bool fq_lines = false, bool with_comp = false) {
     int rc;
     const int64_t nfull = h->n / GRAN, ngran = nfull + 1;
     const bool small = ngran <= (2ll << 20);                  // up to 8 GB of stream: 256 granules per chunk, else 1024
@@ -1048,6 +1060,15 @@ static int granule_pass(fx_handle *h, bool fq_lines = false) {
         if ((rc = h->fq_lines.alloc(nfull * FQL_CAP))) return rc;
         FX_LAUNCH(h, K_FASTQ_LINES, k_fastq_lines, dim3(nblocks(nfull, (BLOCK / 64) * FQL_G)), dim3(BLOCK), h->d_data, h->n, h->prev_byte, nfull,
                   h->gran.p, h->fq_lines.p, hgl);
+    } else if (nfull > 0 && MODE == 0 && with_comp) {         // the scan and the composition counters in one read (fx_scancomp.hpp)
+        const int gpw = comp_run_granules(ngran);
+        const int64_t runs = (ngran + gpw - 1) / gpw;
+        if ((rc = h->comp_runs.alloc(runs * RUN_WORDS))) return rc;
+        HIPCHK(hipMemsetAsync(h->comp_runs.p, 0, (size_t)runs * RUN_WORDS * 4, h->stream));
+        FX_LAUNCH(h, K_SCAN_COMP, k_scan_comp, dim3(nblocks(runs, COMP_WPB)), dim3(COMP_WPB * 64), h->d_data, h->n, h->prev_byte,
+                  (int)h->is_last, nfull, h->gran.p, hgl, gpw, h->comp_runs.p);
+        h->comp_gpw = gpw;
+        h->comp_runs_valid = true;
     } else if (nfull > 0)
         FX_LAUNCH(h, K_SPAN_SCAN, (k_span_scan<MODE>), dim3(nblocks((nfull + SCAN_GPW - 1) / SCAN_GPW * 64, SCAN_WG)), dim3(SCAN_WG), h->d_data, h->n,
                   h->prev_byte, (int)h->is_last, nfull, h->gran.p, hgl);
@@ -1093,7 +1114,10 @@ extern "C" int fx_fasta_build_begin(fx_handle *h, int full_name) {
     if (h->n <= 0) return fail(FX_EFORMAT, "empty input");
     h->scanned = false;
     h->nm_kind = -1;
-    if ((rc = granule_pass<0>(h))) return rc;      // the one pass over the stream: granule summaries + prefixes
+    const bool with_comp = (full_name & 2) != 0;   // bit 1: the composition counters ride on the scan (fx_fasta_comp* then reads nothing twice)
+    full_name &= 1;
+    h->comp_runs_valid = false;
+    if ((rc = granule_pass<0>(h, false, with_comp))) return rc;      // the one pass over the stream: granule summaries + prefixes
     if (h->hdr.cap < 4096 && (rc = alloc_fasta_table(h, 4096))) return rc;
     if ((rc = enqueue_records(h, full_name))) return rc;
     h->build_pending = true;
@@ -1204,14 +1228,18 @@ static int fasta_comp_dense(fx_handle *h, int64_t lead_from, DevBuf<unsigned lon
     if ((rc = tmp.alloc(n + 128))) return rc;
     unsigned long long *d = tmp.p;
     HIPCHK(hipMemsetAsync(d, 0, (size_t)(n + 128) * 8, h->stream));
-    // one wave per run of granules (a multiple of the pipeline depth): 8 = 32 KiB measured best on 3 GB (0.525 ms;
-    // 16: 0.550, 4: 0.569), shorter runs for small inputs so that the machine still fills
-    const int gpw = h->ngran >= 65536 ? 4 * COMP_DEPTH : h->ngran >= 16384 ? 2 * COMP_DEPTH : COMP_DEPTH;
+    // one wave per run of granules
+    const bool from_scan = h->comp_runs_valid;              // the build counted on the way (k_scan_comp): the runs only need an owner
+    const int gpw = from_scan ? h->comp_gpw : comp_run_granules(h->ngran);
     const int64_t waves = (h->ngran + gpw - 1) / gpw;
     const dim3 grid((unsigned)((waves + COMP_WPB - 1) / COMP_WPB));
     if ((rc = edge.alloc(waves + 1))) return rc;            // [0]: number of runs left to the second launch, [1..]: their ids
     HIPCHK(hipMemsetAsync(edge.p, 0, 4, h->stream));
-    FX_LAUNCH(h, K_FASTA_COMP, k_fasta_comp<true>, grid, dim3(COMP_WPB * 64), h->d_data, h->n, h->base,
+    if (from_scan)
+        FX_LAUNCH(h, K_COMP_ATTRIBUTE, k_comp_attribute, dim3(nblocks(waves, ATTR_BLOCK)), dim3(ATTR_BLOCK), h->comp_runs.p, waves, gpw, h->n,
+                  h->base, h->fa_boff.p, h->n_hdr, h->hdr_prefix.p, h->ngran, lead_from, edge.p, d);
+    else
+        FX_LAUNCH(h, K_FASTA_COMP, k_fasta_comp<true>, grid, dim3(COMP_WPB * 64), h->d_data, h->n, h->base,
                        h->hdr.p, h->fa_boff.p, h->n_hdr, h->hdr_prefix.p, h->ngran, gpw, edge.p, lead_from, d);
     FX_LAUNCH(h, K_FASTA_COMP_EDGE, k_fasta_comp<false>, grid, dim3(COMP_WPB * 64), h->d_data, h->n, h->base,
                        h->hdr.p, h->fa_boff.p, h->n_hdr, h->hdr_prefix.p, h->ngran, gpw, edge.p, lead_from, d);
@@ -1299,7 +1327,7 @@ static int fastq_count(fx_handle *h, int64_t *n_nl_core, int64_t *last_nl_core) 
     int rc = use_device(h);
     if (rc) return rc;
     if (h->n <= 0) return fail(FX_EFORMAT, "empty input");
-    h->fasta_built = h->fastq_built = false;
+    h->fasta_built = h->fastq_built = h->comp_runs_valid = false;
     // One read or two?  Line records pay when most granules fit their slot: ask three windows of the stream.
     static const int force = [] { const char *e = getenv("FX_FQ_LINES"); return e ? atoi(e) : -1; }();   // 0 / 1: experiments
     bool by_lines = force > 0;
@@ -1416,7 +1444,7 @@ static int fastq_records(fx_handle *h, int64_t loff, int64_t prev_nl, fx_fastq_s
 extern "C" int fx_set_halo(fx_handle *h, int64_t halo_bytes) {
     if (!h || halo_bytes < 0 || halo_bytes > h->n) return fail(FX_EINVAL, "bad halo");
     h->halo = halo_bytes;
-    h->scanned = h->fasta_built = h->fastq_built = false;
+    h->scanned = h->fasta_built = h->fastq_built = h->comp_runs_valid = false;
     return FX_OK;
 }
 

@@ -31,6 +31,13 @@ def assert_fasta_equal(oracle, L, raw, full_name=False):
         np.testing.assert_array_equal(t[col], recs[col].astype(t[col].dtype), err_msg=col)
     comp = b.fasta_comp(s.n_seq)
     np.testing.assert_array_equal(comp, oracle.fasta_comp(raw, len(recs)))
+    # the same with the counters riding on the index scan (fx_fasta_build, FX_BUILD_COMP): one read of the stream
+    s2 = b.fasta_build(full_name, comp=True)
+    assert (s2.n_seq, s2.seq_len) == (s.n_seq, s.seq_len)
+    t2 = b.fasta_table(s2.n_seq)
+    for col in t:
+        np.testing.assert_array_equal(t2[col], t[col], err_msg="fused build: " + col)
+    np.testing.assert_array_equal(b.fasta_comp(s.n_seq), comp, err_msg="fused build: comp")
     from test_host_logic import _reg_of                     # the line-regular column: the same rule, on the device
     np.testing.assert_array_equal(b.fasta_line_regular(s.n_seq), np.array([_reg_of(raw, r) for r in recs], dtype=np.int32), err_msg="reg")
     return b, recs, t
@@ -404,6 +411,12 @@ def test_fasta_comp_letters(oracle, L):
     got = b.fasta_comp(s.n_seq)
     want = oracle.fasta_comp(raw, len(recs))
     np.testing.assert_array_equal(got, want)
+    for _ in range(2):                                       # counters riding on the scan (k_scan_comp + k_comp_attribute), asked for twice
+        assert b.fasta_build(comp=True).n_seq == s.n_seq
+        np.testing.assert_array_equal(b.fasta_comp(s.n_seq), want)
+        np.testing.assert_array_equal(b.fasta_comp(s.n_seq), want)
+    assert b.fasta_build().n_seq == s.n_seq                  # and a plain build drops them
+    np.testing.assert_array_equal(b.fasta_comp(s.n_seq), want)
     assert int(want[0][ord("a")]) > 0 and int(want[3][ord("W")]) > 0 and int(want[4][0]) > 0    # the cases are really in there
     # the same stream cut into shards: every shard counts its own bytes, rows add up (records that cross a cut
     # are completed by the owner of the header, see shard.py) -- here just the totals per letter

@@ -224,7 +224,7 @@ def test_device_exchange_stream_ordering(oracle, L):
         np.testing.assert_array_equal(got[c], recs[c].astype(got[c].dtype), err_msg=c)
 
 
-def sharded_comp(L, raw, cuts):
+def sharded_comp(L, raw, cuts, fused=False):
     """k_fasta_comp on every shard + the exchange of shard.py (lead_from / lead rows), with G logical shards."""
     from pyfastx_amd import shard
     bounds = [0] + list(cuts) + [len(raw)]
@@ -233,7 +233,7 @@ def sharded_comp(L, raw, cuts):
         lo, hi = bounds[i], bounds[i + 1]
         b = L.Blob.from_bytes(raw[lo:hi])
         b.set_shard(lo, raw[lo - 1] if lo else 10, hi == len(raw))
-        s = b.fasta_build(False)
+        s = b.fasta_build(False, comp=fused)                 # fused: the composition counters ride on the scan
         blobs.append((b, s.n_seq))
         S.append(b.shard_summary())
     last_boff = []
@@ -279,6 +279,7 @@ def test_composition_across_cuts(oracle, L):
         for _ in range(4):
             cuts = sorted(set(int(x) for x in rng.integers(1, len(raw), g - 1)))
             np.testing.assert_array_equal(sharded_comp(L, raw, cuts), want, err_msg=str(cuts))
+            np.testing.assert_array_equal(sharded_comp(L, raw, cuts, fused=True), want, err_msg="fused " + str(cuts))
 
 
 def test_mixed_shapes_in_shards(oracle, L):
@@ -293,6 +294,7 @@ def test_mixed_shapes_in_shards(oracle, L):
         cuts = sorted(set(int(x) for x in rng.integers(1, len(raw), g - 1)))
         check(oracle, L, raw, cuts)
         np.testing.assert_array_equal(sharded_comp(L, raw, cuts), want, err_msg=str(cuts))
+        np.testing.assert_array_equal(sharded_comp(L, raw, cuts, fused=True), want, err_msg="fused " + str(cuts))
 
 
 @pytest.mark.parametrize("seed", range(4))
