@@ -346,6 +346,7 @@ def leg_c4(a, host, plan, q, tmpdir):
     csize = os.path.getsize(path)
     L = _lib.lib()
     L.fx_prof_default(1)
+    os.environ.setdefault("FX_TRACE_BGZF", "1")           # the laps of every BGZF open of this leg go to stderr (read at the first open)
     _lib.Blob.from_file(path).close()                     # first touch
     t_open = []
     prof = {}

@@ -224,7 +224,8 @@ __device__ __forceinline__ void dist_code(int ds, int &base, int &ext) {       /
 __device__ const uint8_t CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // match token: dst (17 bits) | len (9 bits) << 17 | dist (16 bits) << 26
-__device__ __forceinline__ uint64_t tok_pack(int64_t dst, int len, int64_t dist) { return (uint64_t)dst | ((uint64_t)len << 17) | ((uint64_t)dist << 26); }
+typedef uint32_t __attribute__((aligned(1))) uint32_u;    // 4 bytes at any address
+constexpr int BM_WORDS = 1024;                            // words of a member's match map: one bit per output byte of at most 64 KiB
 
 // Literal/length + distance codes of one block: literals -> out[o...], matches -> tok[nt...].
 // One refill per symbol: a literal/length code (<= 15 bits) with its extra bits (<= 5) and a distance code (<= 15)
@@ -233,9 +234,9 @@ __device__ __forceinline__ uint64_t tok_pack(int64_t dst, int len, int64_t dist)
 // reader's state into scratch memory, and then every symbol costs a dozen round trips to it -- that, not the Huffman
 // walk, was the 32 ms of the first version.)
 __device__ __forceinline__ int inflate_codes(BitIn &b, const Huff &lc, const Huff &dc, uint8_t *out, int64_t &o, int64_t cap,
-                                             uint64_t *tok, int &nt) {
-    // The loop's memory traffic per symbol is ONE request for the next 8 input bytes and ONE store (a literal byte or
-    // a match token).  vmcnt counts both and the compiler, asked to wait for the input bytes, waits for "everything"
+                                             uint64_t *bm, uint64_t &bmw_io, uint32_t &bwin_io) {
+    // The loop's memory traffic per symbol is ONE request for the next 8 input bytes and TWO stores (the symbol -- a literal
+    // byte, or the 3-byte token of a match put where the match begins -- and the current word of the member's match map).  vmcnt counts both and the compiler, asked to wait for the input bytes, waits for "everything"
     // -- i.e. for the store of the symbol before to be acknowledged by the L2, ~2 800 cycles per symbol, which WAS the
     // kernel's time.  So the request is issued by hand (the compiler does not see it) and waited for with vmcnt(2) right
     // after the symbol's two stores: memory operations of a wave complete in issue order on gfx9, so "at most two
@@ -250,6 +251,8 @@ __device__ __forceinline__ int inflate_codes(BitIn &b, const Huff &lc, const Huf
     uint32_t pos = b.p, oo = (uint32_t)o;
     const uint32_t end = b.end, ocap = (uint32_t)cap;
     const uint8_t *const base = b.base;
+    uint64_t bmw = bmw_io;                                   // bits of the 64 output bytes of window bwin that begin a match
+    uint32_t bwin = bwin_io;
     uint16_t *const llut = lc.lut, *const dlut = dc.lut, *const pool = lc.pool;
     BitIn sb;                                                // what the slow path works on
     sb.err = 0;
@@ -282,7 +285,6 @@ __device__ __forceinline__ int inflate_codes(BitIn &b, const Huff &lc, const Huf
         } else { buf >>= len; cnt -= len; }
         if (sym == 256) { ret = cnt < 0 ? INFL_EINPUT : INFL_OK; break; }
         const bool lit = sym < 256;
-        uint64_t t = 0;
         uint32_t adv = 1;
         if (!lit) {
             sym -= 257;
@@ -310,18 +312,28 @@ __device__ __forceinline__ int inflate_codes(BitIn &b, const Huff &lc, const Huf
             const uint32_t dist = (uint32_t)db + ((uint32_t)buf & ((1u << de) - 1u));
             buf >>= de; cnt -= de;
             if (dist > oo) { ret = INFL_EDIST; break; }      // BGZF members never reference outside themselves
-            t = (uint64_t)oo | ((uint64_t)mlen << 17) | ((uint64_t)dist << 26);        // tok_pack
+            sym = (int)((mlen - 3u) | ((dist - 1u) << 8));                            // the token: 8 + 15 bits (tok_len / tok_dist)
             adv = mlen;
-            sym = 0;
         }
         if (cnt < 0) { ret = INFL_EINPUT; break; }           // the symbol took bits the member does not have
         if (oo + adv > ocap) { ret = INFL_EOUTPUT; break; }
         // exactly TWO stores per symbol, whatever it is (lanes of one wave decode different kinds at the same moment, and
-        // a store under a branch would be one instruction per kind): the byte -- of a match, a place holder that
-        // k_bgzf_copy overwrites -- and the token slot -- of a literal, the slot the next match will fill
-        out[oo] = (uint8_t)sym;
-        tok[nt] = t;
-        nt += lit ? 0 : 1;
+        // a store under a branch would be one instruction per kind).  (1) Four bytes at the symbol's place: the literal,
+        // or the token of the match in the first three of the bytes the match will fill (k_bgzf_copy reads it there and
+        // then overwrites it); the bytes behind belong to symbols that are decoded -- and stored -- later, or to the same
+        // match.  Only within four bytes of the member's end the store is done byte by byte (the next member's bytes are
+        // another lane's).  (2) The word of the match map that holds this position, as far as it is known: the last store
+        // to a word carries all its bits; words no symbol begins in stay zero (the map is cleared before the launch).
+        const uint32_t w = oo >> 6;
+        bmw = w == bwin ? bmw : 0ull;
+        bwin = w;
+        bmw |= lit ? 0ull : 1ull << (oo & 63u);
+        if (__builtin_expect(oo + 4u <= ocap, 1)) *reinterpret_cast<uint32_u *>(out + oo) = (uint32_t)sym;
+        else {
+            out[oo] = (uint8_t)sym;
+            if (!lit) { out[oo + 1] = (uint8_t)(sym >> 8); out[oo + 2] = (uint8_t)(sym >> 16); }
+        }
+        bm[w] = bmw;
         oo += adv;
         asm volatile("s_waitcnt vmcnt(2)" : "+v"(nxt) : : "memory");       // the request is back; this symbol's stores need not be
         cur = nxt;
@@ -329,12 +341,16 @@ __device__ __forceinline__ int inflate_codes(BitIn &b, const Huff &lc, const Huf
     uint64_t keep = 0;
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(keep) : : "memory");           // left without the stores: everything, then read p again
     b.buf = buf; b.cnt = cnt < 0 ? 0 : cnt; b.p = pos; o = oo;
+    bmw_io = bmw; bwin_io = bwin;
     b.next = *reinterpret_cast<const uint64_u *>(b.base + b.p);
     return ret;
 }
 
 // members: cdata_off/cdata_len (compressed payload inside cbuf), uoff (offset in the inflated stream), isize.
-// tok_off[m]: first token slot of member m (isize / 3 + 1 slots each); ntok[m]: tokens written.
+// match_map: BM_WORDS 64-bit words per member, zero on entry: bit k of word w <-> a match begins at output byte 64 w + k
+// of the member (its 3-byte token sits there).  Round 1 kept the matches as a list of 8-byte tokens per member, sized
+// for the worst case (isize / 3 + 1 of them): 8.2 GB of scratch for a 3 GB file, and a hipMalloc of that size that
+// took anything between 1 and 750 ms.  The map is 1/8 of the output: 0.38 GB.
 // gsym: GSYM words of scratch per member (the canonical symbol order of its current tables: slow path only).
 __global__ __launch_bounds__(INFL_BLOCK) void k_bgzf_decode(const uint8_t *__restrict__ cbuf,
                                                            const int64_t *__restrict__ cdata_off,
@@ -342,8 +358,7 @@ __global__ __launch_bounds__(INFL_BLOCK) void k_bgzf_decode(const uint8_t *__res
                                                            const int64_t *__restrict__ uoff,
                                                            const int32_t *__restrict__ isize, int64_t nmem,
                                                            uint8_t *__restrict__ data, int32_t *__restrict__ status,
-                                                           uint64_t *__restrict__ tokens, const int64_t *__restrict__ tok_off,
-                                                           int32_t *__restrict__ ntok, uint16_t *__restrict__ gsym) {
+                                                           uint64_t *__restrict__ match_map, uint16_t *__restrict__ gsym) {
     __shared__ uint16_t t_llut[(1 << LBITS) * INFL_BLOCK], t_dlut[(1 << DBITS) * INFL_BLOCK], t_pool[POOL * INFL_BLOCK];
     const int lane = threadIdx.x;
     const int64_t m = (int64_t)blockIdx.x * INFL_BLOCK + lane;
@@ -353,8 +368,9 @@ __global__ __launch_bounds__(INFL_BLOCK) void k_bgzf_decode(const uint8_t *__res
     int pool_used = 0;
     BitIn b;
     bit_init(b, cbuf, cdata_off[m], cdata_off[m] + cdata_len[m]);
-    uint64_t *tok = tokens + tok_off[m];
-    int nt = 0;
+    uint64_t *bm = match_map + m * BM_WORDS;
+    uint64_t bmw = 0;
+    uint32_t bwin = 0;
     uint8_t *out = data + uoff[m];
     const int64_t cap = isize[m];
     int64_t o = 0;
@@ -420,13 +436,12 @@ __global__ __launch_bounds__(INFL_BLOCK) void k_bgzf_decode(const uint8_t *__res
             if (err < 0 || (err > 0 && nz != 1)) { st = INFL_ECODES; break; }
         } else { st = INFL_EBLOCK; break; }
         if (type != 0) {                                     // the one place the codes are decoded (see inflate_codes)
-            st = inflate_codes(b, lc, dc, out, o, cap, tok, nt);
+            st = inflate_codes(b, lc, dc, out, o, cap, bm, bmw, bwin);
             if (st) break;
         }
     } while (!last);
     if (st == INFL_OK && o != cap) st = INFL_ESIZE;          // ISIZE of the member trailer must match
     status[m] = st;
-    ntok[m] = st == INFL_OK ? nt : 0;
 }
 
 // ---- phase B: resolve the match tokens, one wave per member -------------------------------------------
@@ -454,41 +469,60 @@ __device__ __forceinline__ void copy_plain(uint8_t *base, int64_t dst, int64_t s
     }
 }
 
-constexpr int COPY_BLOCK = 256;
-__global__ __launch_bounds__(COPY_BLOCK) void k_bgzf_copy(const int64_t *__restrict__ uoff, int64_t nmem,
+// A wave takes its member 4 KiB of output at a time: the 64 words of the match map of that stretch (one per lane) become
+// the list of the positions where matches begin (in LDS, in order), and the list is worked through 64 matches at a
+// time -- token from the first three bytes of the match's place, then the copy -- exactly as the token list of round 1
+// was: matches whose source lies before the batch are copied by their own lanes, the others in order by the whole wave.
+constexpr int COPY_BLOCK = 256, COPY_POS = 4096 / 3 + 2;
+__global__ __launch_bounds__(COPY_BLOCK) void k_bgzf_copy(const int64_t *__restrict__ uoff, const int32_t *__restrict__ isize, int64_t nmem,
                                                          uint8_t *__restrict__ data,          // 4-byte aligned, readable 12 bytes past the end
-                                                         const uint64_t *__restrict__ tokens, const int64_t *__restrict__ tok_off,
-                                                         const int32_t *__restrict__ ntok) {
+                                                         const uint64_t *__restrict__ match_map) {
+    __shared__ uint16_t s_pos[COPY_BLOCK / 64][COPY_POS];
     const int lane = threadIdx.x & 63;
     const int64_t m = ((int64_t)blockIdx.x * COPY_BLOCK + threadIdx.x) >> 6;
-    if (m >= nmem) return;
-    const int nt = ntok[m];
-    const uint64_t *T = tokens + tok_off[m];
+    if (m >= nmem) return;                                 // waves are independent: no workgroup barrier below
+    uint16_t *sp = s_pos[threadIdx.x >> 6];
+    const uint64_t *B = match_map + m * BM_WORDS;
     const int64_t ub = uoff[m];                            // member's offset in the stream
-    for (int b0 = 0; b0 < nt; b0 += 64) {
-        const int i = b0 + lane;
-        const bool have = i < nt;
-        const uint64_t t = have ? T[i] : 0ull;
-        const int64_t dst = (int64_t)(t & 0x1FFFFu), dist = (int64_t)(t >> 26);
-        const int len = (int)((t >> 17) & 0x1FFu);
-        const int64_t src = dst - dist;
-        const int64_t need = dist < len ? dist : len;      // source bytes that must be final: [src, src + need)
-        const int64_t D0 = (int64_t)(T[b0] & 0x1FFFFu);    // first output byte of the batch (same address for all lanes)
-        const bool indep = have && src + need <= D0;
-        if (indep) {                                       // copied by its own lane
-            if (dist >= len) copy_plain(data, ub + dst, ub + src, len);
-            else for (int j = 0; j < len; ++j) data[ub + dst + j] = ld_byte(data, ub + src + j % dist);   // run replication
+    const int nwords = (isize[m] + 63) >> 6;
+    uint64_t wnext = lane < nwords ? B[lane] : 0ull;       // the map of a stretch is requested while the stretch before is resolved
+    for (int c0 = 0; c0 < nwords; c0 += 64) {
+        uint64_t wd = wnext;
+        wnext = c0 + 64 + lane < nwords ? B[c0 + 64 + lane] : 0ull;
+        const uint32_t cnt = (uint32_t)__popcll(wd), incl = wave_incl_scan(cnt);
+        const int total = __shfl((int)incl, 63, 64);
+        uint32_t r = incl - cnt;
+        while (wd) {
+            const int k = __ffsll((long long)wd) - 1;
+            wd &= wd - 1;
+            sp[r++] = (uint16_t)(((c0 + lane) << 6) + k);
         }
-        unsigned long long dep = __ballot(have && !indep);
-        while (dep) {                                      // in order, each one as a wave-wide gather
-            __threadfence_block();                         // this wave's earlier stores are at the L2 before these loads
-            const int l = __ffsll(dep) - 1;
-            dep &= dep - 1;
-            const int64_t d_l = __shfl((int)dst, l, 64), k_l = __shfl((int)dist, l, 64);
-            const int n_l = __shfl(len, l, 64);
-            for (int j = lane; j < n_l; j += 64) data[ub + d_l + j] = ld_byte(data, ub + d_l - k_l + (k_l < n_l ? j % k_l : j));
+        for (int b0 = 0; b0 < total; b0 += 64) {
+            const int i = b0 + lane;
+            const bool have = i < total;
+            const int64_t dst = have ? sp[i] : 0;
+            const uint32_t tk = have ? (uint32_t)ld_u64(data, ub + dst) : 0u;       // 8 + 15 bits in the first three bytes of the match's place
+            const int len = (int)(tk & 0xFFu) + 3;
+            const int64_t dist = (int64_t)((tk >> 8) & 0x7FFFu) + 1;
+            const int64_t src = dst - dist;
+            const int64_t need = dist < len ? dist : len;      // source bytes that must be final: [src, src + need)
+            const int64_t D0 = sp[b0];                         // first output byte of the batch (same address for all lanes)
+            const bool indep = have && src + need <= D0;
+            if (indep) {                                       // copied by its own lane
+                if (dist >= len) copy_plain(data, ub + dst, ub + src, len);
+                else for (int j = 0; j < len; ++j) data[ub + dst + j] = ld_byte(data, ub + src + j % dist);   // run replication
+            }
+            unsigned long long dep = __ballot(have && !indep);
+            while (dep) {                                      // in order, each one as a wave-wide gather
+                __threadfence_block();                         // this wave's earlier stores are at the L2 before these loads
+                const int l = __ffsll(dep) - 1;
+                dep &= dep - 1;
+                const int64_t d_l = __shfl((int)dst, l, 64), k_l = __shfl((int)dist, l, 64);
+                const int n_l = __shfl(len, l, 64);
+                for (int j = lane; j < n_l; j += 64) data[ub + d_l + j] = ld_byte(data, ub + d_l - k_l + (k_l < n_l ? j % k_l : j));
+            }
+            __threadfence_block();                             // the next batch may read what this one wrote
         }
-        __threadfence_block();                             // the next batch may read what this one wrote
     }
 }
 

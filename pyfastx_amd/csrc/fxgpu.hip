@@ -489,7 +489,7 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
         t.total += full.isize[(size_t)m];
     }
     const int64_t fsize = c1 - c0;
-    static const bool trace = [] { const char *e = getenv("FX_TRACE"); return e && atoi(e) != 0; }();
+    static const bool trace = [] { const char *e = getenv("FX_TRACE"), *b = getenv("FX_TRACE_BGZF"); return (e && atoi(e) != 0) || (b && atoi(b) != 0); }();
     const auto T0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (trace) fprintf(stderr, "[fxgpu] bgzf %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
@@ -507,24 +507,19 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
         (rc = upload(h, d_isize, t.isize)))
         return rc;
     const int64_t nmem = (int64_t)t.moff.size();
-    // match tokens: a match is >= 3 bytes, so member m needs at most isize / 3 + 1 slots
-    std::vector<int64_t> toff((size_t)nmem + 1, 0);
-    for (int64_t m = 0; m < nmem; ++m) toff[(size_t)m + 1] = toff[(size_t)m] + t.isize[(size_t)m] / 3 + 1;
-    DevBuf<uint64_t> d_tok;
-    DevBuf<int64_t> d_toff;
-    DevBuf<int32_t> d_ntok;
-    if ((rc = d_tok.alloc(toff[(size_t)nmem])) || (rc = upload(h, d_toff, toff)) || (rc = d_ntok.alloc(nmem))) return rc;
+    // where the matches of a member begin: one bit per output byte (k_bgzf_decode sets them, k_bgzf_copy walks them)
+    DevBuf<uint64_t> d_map;
+    if ((rc = d_map.alloc(nmem * BM_WORDS))) return rc;
     if ((rc = d_status.alloc(nmem))) return rc;
     DevBuf<uint16_t> d_gsym;                                 // canonical symbol order of every member's tables (slow path of the decoder)
     if ((rc = d_gsym.alloc(nmem * GSYM))) return rc;
     HIPCHK(hipMemsetAsync(d_status.p, 0xFF, (size_t)nmem * 4, h->stream));
-    HIPCHK(hipMemsetAsync(d_ntok.p, 0, (size_t)nmem * 4, h->stream));
+    HIPCHK(hipMemsetAsync(d_map.p, 0, (size_t)nmem * BM_WORDS * 8, h->stream));
     if ((rc = alloc_blob(h, t.total))) return rc;
     lap("allocations");
     FX_LAUNCH(h, K_BGZF_INFLATE, k_bgzf_decode, dim3(nblocks(nmem, INFL_BLOCK)), dim3(INFL_BLOCK), d_c.p, d_coff.p,
-              d_clen.p, d_uoff.p, d_isize.p, nmem, h->d_data, d_status.p, d_tok.p, d_toff.p, d_ntok.p, d_gsym.p);
-    FX_LAUNCH(h, K_BGZF_COPY, k_bgzf_copy, dim3(nblocks(nmem, COPY_BLOCK / 64)), dim3(COPY_BLOCK), d_uoff.p, nmem, h->d_data,
-              d_tok.p, d_toff.p, d_ntok.p);
+              d_clen.p, d_uoff.p, d_isize.p, nmem, h->d_data, d_status.p, d_map.p, d_gsym.p);
+    FX_LAUNCH(h, K_BGZF_COPY, k_bgzf_copy, dim3(nblocks(nmem, COPY_BLOCK / 64)), dim3(COPY_BLOCK), d_uoff.p, d_isize.p, nmem, h->d_data, d_map.p);
     static const bool no_crc = [] { const char *e = getenv("FX_BGZF_NO_CRC"); return e && atoi(e) != 0; }();
     DevBuf<CrcTables> d_crc;
     if (!no_crc) {                                           // every member against the CRC-32 of its trailer, as zlib does in gzread
@@ -763,13 +758,20 @@ static int open_file_impl(const char *path, int device, fx_handle **out, int64_t
             const int64_t fsize = (int64_t)st.st_size;
             // the member walk only touches the 18-byte header and the trailer of each member: map the file
             // (page cache) instead of copying 1 GB to the host first
+            static const bool trace = [] { const char *e = getenv("FX_TRACE"), *b = getenv("FX_TRACE_BGZF"); return (e && atoi(e) != 0) || (b && atoi(b) != 0); }();
+            const auto T0 = std::chrono::steady_clock::now();
+            auto lap = [&](const char *what) {
+                if (trace) fprintf(stderr, "[fxgpu] open %-27s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
+            };
             void *mp = mmap(nullptr, (size_t)fsize, PROT_READ, MAP_PRIVATE, fd, 0);
             BgzfTable tab;
             int brc = 1;
             if (mp != MAP_FAILED) {
                 const bool is_bgzf = parse_bgzf((const uint8_t *)mp, fsize, tab);
                 (void)munmap(mp, (size_t)fsize);
+                lap("member walk");
                 if (is_bgzf) brc = bgzf_to_blob(h, fd, fsize, tab, path);
+                lap("inflated, scratch freed");
             }
             if (brc == FX_OK) { close(fd); *out = h; return FX_OK; }
             if (brc < 0) return bail(brc);
