@@ -79,6 +79,73 @@ template <class T> struct DevBuf {      // grow-only device array: rebuilds reus
     ~DevBuf() { release(); }
 };
 
+// Scratch of an open (the compressed bytes of a BGZF file, its match map, ...): hundreds of MB that live for tens of
+// milliseconds.  hipFree waits for the device and unmaps -- 20 ms for 1.4 GB -- and the hipMalloc of the next open maps
+// again, so released blocks are kept (per device, up to FX_SCRATCH_CACHE_MB, default 4096; 0 = off) and handed to the
+// next request they fit (at most twice its size).
+struct ScratchPool {
+    struct Block { void *p; size_t cap; int dev; };
+    std::mutex mu;
+    std::vector<Block> idle;
+    size_t held = 0;
+    const size_t limit = [] { const char *e = getenv("FX_SCRATCH_CACHE_MB"); return (size_t)(e ? std::max(0, atoi(e)) : 4096) << 20; }();
+    void *get(int dev, size_t bytes, size_t *cap) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            int best = -1;
+            for (int i = 0; i < (int)idle.size(); ++i)
+                if (idle[i].dev == dev && idle[i].cap >= bytes && idle[i].cap <= 2 * bytes + (1u << 20) && (best < 0 || idle[i].cap < idle[best].cap)) best = i;
+            if (best >= 0) {
+                Block b = idle[best];
+                idle.erase(idle.begin() + best);
+                held -= b.cap;
+                *cap = b.cap;
+                return b.p;
+            }
+        }
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {            // make room: give the idle blocks back and try once more
+            trim();
+            if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        }
+        *cap = bytes;
+        return p;
+    }
+    void put(int dev, void *p, size_t cap) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (held + cap <= limit) { idle.push_back(Block{p, cap, dev}); held += cap; return; }
+        }
+        (void)hipFree(p);
+    }
+    void trim() {
+        std::vector<Block> v;
+        { std::lock_guard<std::mutex> g(mu); v.swap(idle); held = 0; }
+        for (auto &b : v) (void)hipFree(b.p);
+    }
+};
+static ScratchPool g_scratch;
+template <class T> struct ScratchBuf {                      // device array out of the pool; returned to it when it goes out of scope
+    T *p = nullptr;
+    size_t cap_bytes = 0;
+    int dev = 0;
+    hipStream_t stream = nullptr;                            // what uses the block runs on this stream: waited for before the block changes hands
+    int alloc(int device, int64_t count, hipStream_t st = nullptr) {
+        release();
+        if (count <= 0) return FX_OK;
+        dev = device;
+        stream = st;
+        p = (T *)g_scratch.get(device, (size_t)count * sizeof(T), &cap_bytes);
+        if (!p) return fail(FX_ENOMEM, "hipMalloc(%lld B) failed", (long long)(count * sizeof(T)));
+        return FX_OK;
+    }
+    void release() {
+        if (p) { (void)hipStreamSynchronize(stream); g_scratch.put(dev, p, cap_bytes); }
+        p = nullptr; cap_bytes = 0;
+    }
+    ~ScratchBuf() { release(); }
+};
+
 // ------------------------------------------------------------ kernel timing
 // Optional per-kernel HIP-event timing on the handle's own stream (bench.py's
 // roofline leg reads it; off by default so the hot path records no events).
@@ -479,6 +546,13 @@ template <class T> static int upload(fx_handle *h, DevBuf<T> &d, const std::vect
 // [m0, m1): the members to inflate (all of them for a whole file; the ones that cover a byte range of the inflated
 // stream for fx_open_file_range -- only their compressed bytes are read and staged).
 static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable &full, const char *path, int64_t m0 = 0, int64_t m1 = -1) {
+    ScratchBuf<uint8_t> d_c;
+    int rc;
+    static const bool trace = [] { const char *e = getenv("FX_TRACE"), *b = getenv("FX_TRACE_BGZF"); return (e && atoi(e) != 0) || (b && atoi(b) != 0); }();
+    const auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "[fxgpu] bgzf %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
+    };
     if (m1 < 0) m1 = (int64_t)full.moff.size();
     BgzfTable t;                                           // the range, offsets relative to its first member
     const int64_t c0 = full.moff[(size_t)m0], u0 = full.uoff[(size_t)m0];
@@ -489,16 +563,9 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
         t.total += full.isize[(size_t)m];
     }
     const int64_t fsize = c1 - c0;
-    static const bool trace = [] { const char *e = getenv("FX_TRACE"), *b = getenv("FX_TRACE_BGZF"); return (e && atoi(e) != 0) || (b && atoi(b) != 0); }();
-    const auto T0 = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (trace) fprintf(stderr, "[fxgpu] bgzf %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
-    };
-    DevBuf<uint8_t> d_c;
     DevBuf<int64_t> d_coff, d_uoff;
     DevBuf<int32_t> d_clen, d_isize, d_status;
-    int rc;
-    if ((rc = d_c.alloc(fsize + 48))) return rc;          // the bit reader looks three 8-byte words ahead
+    if ((rc = d_c.alloc(h->device, fsize + 48, h->stream))) return rc;          // the bit reader looks three 8-byte words ahead
     HIPCHK(hipMemsetAsync(d_c.p + fsize, 0, 48, h->stream));
     lap("alloc compressed");
     if ((rc = stage_plain_file(h, fd, fsize, path, d_c.p, c0))) return rc;
@@ -508,11 +575,11 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
         return rc;
     const int64_t nmem = (int64_t)t.moff.size();
     // where the matches of a member begin: one bit per output byte (k_bgzf_decode sets them, k_bgzf_copy walks them)
-    DevBuf<uint64_t> d_map;
-    if ((rc = d_map.alloc(nmem * BM_WORDS))) return rc;
+    ScratchBuf<uint64_t> d_map;
+    if ((rc = d_map.alloc(h->device, nmem * BM_WORDS, h->stream))) return rc;
     if ((rc = d_status.alloc(nmem))) return rc;
-    DevBuf<uint16_t> d_gsym;                                 // canonical symbol order of every member's tables (slow path of the decoder)
-    if ((rc = d_gsym.alloc(nmem * GSYM))) return rc;
+    ScratchBuf<uint16_t> d_gsym;                             // canonical symbol order of every member's tables (slow path of the decoder)
+    if ((rc = d_gsym.alloc(h->device, nmem * GSYM, h->stream))) return rc;
     HIPCHK(hipMemsetAsync(d_status.p, 0xFF, (size_t)nmem * 4, h->stream));
     HIPCHK(hipMemsetAsync(d_map.p, 0, (size_t)nmem * BM_WORDS * 8, h->stream));
     if ((rc = alloc_blob(h, t.total))) return rc;
@@ -767,11 +834,14 @@ static int open_file_impl(const char *path, int device, fx_handle **out, int64_t
             BgzfTable tab;
             int brc = 1;
             if (mp != MAP_FAILED) {
+                // (the walk touches 47 k pages of the mapping: 16-20 ms for C4.  Run in a thread of its own beside the staging
+                // of the compressed bytes it made the staging four times slower -- page faults on the mapping against the
+                // preads of the same file -- 116 ms for the pair instead of 45.)
                 const bool is_bgzf = parse_bgzf((const uint8_t *)mp, fsize, tab);
-                (void)munmap(mp, (size_t)fsize);
                 lap("member walk");
                 if (is_bgzf) brc = bgzf_to_blob(h, fd, fsize, tab, path);
-                lap("inflated, scratch freed");
+                (void)munmap(mp, (size_t)fsize);
+                lap("inflated, scratch back");
             }
             if (brc == FX_OK) { close(fd); *out = h; return FX_OK; }
             if (brc < 0) return bail(brc);
