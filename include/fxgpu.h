@@ -88,6 +88,10 @@ int fx_open_device(const void *dptr, int64_t nbytes, int device, fx_handle **out
 int fx_set_shard(fx_handle *h, int64_t base, int prev_byte, int is_last);
 
 int fx_close(fx_handle *h);
+/* Scratch of an open (compressed bytes of a BGZF file, its match map: hundreds of MB for tens of milliseconds) is kept
+ * in a per-process pool for the next open (FX_SCRATCH_CACHE_MB, default 4096; the library empties it by itself before a
+ * device allocation fails).  This gives the idle blocks back to the driver now. */
+int fx_release_scratch(void);
 int64_t fx_size(const fx_handle *h);          /* uncompressed bytes held          */
 int fx_is_gzip(const fx_handle *h);           /* is_gzip_format, util.c:307-325   */
 const void *fx_device_ptr(const fx_handle *h);/* device address of the blob       */

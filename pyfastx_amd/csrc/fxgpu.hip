@@ -63,6 +63,13 @@ extern "C" int fx_device_count(void) {
 }
 
 // ------------------------------------------------------------------ handle
+static void scratch_trim();              // the idle blocks of the scratch pool below go back to the driver
+static hipError_t dev_malloc(void **p, size_t bytes) {     // hipMalloc; when memory is short the pool is emptied and it is tried again
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); scratch_trim(); e = hipMalloc(p, bytes); }
+    return e;
+}
+
 template <class T> struct DevBuf {      // grow-only device array: rebuilds reuse the allocation
     T *p = nullptr;
     int64_t n = 0, cap = 0;
@@ -70,7 +77,7 @@ template <class T> struct DevBuf {      // grow-only device array: rebuilds reus
         if (count <= cap && p) { n = count; return FX_OK; }
         release();
         if (count <= 0) return FX_OK;
-        hipError_t e = hipMalloc((void **)&p, (size_t)count * sizeof(T));
+        hipError_t e = dev_malloc((void **)&p, (size_t)count * sizeof(T));
         if (e != hipSuccess) { p = nullptr; return fail(FX_ENOMEM, "hipMalloc(%lld B): %s", (long long)(count * sizeof(T)), hipGetErrorString(e)); }
         n = cap = count;
         return FX_OK;
@@ -125,6 +132,8 @@ struct ScratchPool {
     }
 };
 static ScratchPool g_scratch;
+static void scratch_trim() { g_scratch.trim(); }
+extern "C" int fx_release_scratch(void) { g_scratch.trim(); return FX_OK; }
 template <class T> struct ScratchBuf {                      // device array out of the pool; returned to it when it goes out of scope
     T *p = nullptr;
     size_t cap_bytes = 0;
@@ -310,7 +319,7 @@ static int new_handle(int device, fx_handle **out) {
 static int alloc_blob(fx_handle *h, int64_t n) {
     // pad to a whole tile so vector loads of the last chunk stay inside the allocation
     const int64_t padded = ((n + TILE - 1) / TILE) * TILE + TILE;
-    HIPCHK(hipMalloc((void **)&h->d_data, (size_t)padded));
+    HIPCHK(dev_malloc((void **)&h->d_data, (size_t)padded));
     h->owns = true;
     h->n = n;
     if (padded > n) HIPCHK(hipMemsetAsync(h->d_data + n, 0, (size_t)(padded - n), h->stream));
@@ -874,7 +883,7 @@ static int open_file_impl(const char *path, int device, fx_handle **out, int64_t
         if (gs.init(h, (const uint8_t *)mp, fsize)) { (void)munmap(mp, (size_t)fsize); return bail(fail(FX_EIO, "inflateInit failed for %s", path)); }
         int64_t cap = std::max<int64_t>((int64_t)st.st_size * 5, STAGE_BYTES), n = 0;
         uint8_t *d = nullptr;
-        hipError_t e = hipMalloc((void **)&d, (size_t)cap + 2 * TILE);
+        hipError_t e = dev_malloc((void **)&d, (size_t)cap + 2 * TILE);
         if (e != hipSuccess) { (void)munmap(mp, (size_t)fsize); return bail(fail(FX_ENOMEM, "hipMalloc: %s", hipGetErrorString(e))); }
         int slot = 0;
         for (;;) {
@@ -885,7 +894,7 @@ static int open_file_impl(const char *path, int device, fx_handle **out, int64_t
             if (n + fill > cap) {           // grow: allocate bigger, device-to-device copy
                 int64_t ncap = std::max(cap * 2, n + fill);
                 uint8_t *nd = nullptr;
-                e = hipMalloc((void **)&nd, (size_t)ncap + 2 * TILE);
+                e = dev_malloc((void **)&nd, (size_t)ncap + 2 * TILE);
                 if (e == hipSuccess) e = hipMemcpyAsync(nd, d, (size_t)n, hipMemcpyDeviceToDevice, h->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
                 if (e != hipSuccess) { (void)munmap(mp, (size_t)fsize); (void)hipFree(d); return bail(fail(FX_ENOMEM, "grow: %s", hipGetErrorString(e))); }
@@ -992,7 +1001,7 @@ extern "C" int fx_open_file_range(const char *path, int64_t off, int64_t len, in
         }
         if (skip & 15) {                                   // kernels load 16-byte chunks from the blob's start: keep it aligned --
             uint8_t *tmp = nullptr;                        // the range moves to the front of the allocation (through a copy: the spans overlap)
-            if (hipMalloc((void **)&tmp, (size_t)n) != hipSuccess) return bail(fail(FX_ENOMEM, "hipMalloc(%lld B) failed", (long long)n));
+            if (dev_malloc((void **)&tmp, (size_t)n) != hipSuccess) return bail(fail(FX_ENOMEM, "hipMalloc(%lld B) failed", (long long)n));
             hipError_t e = hipMemcpy(tmp, h->d_data + skip, (size_t)n, hipMemcpyDeviceToDevice);
             if (e == hipSuccess) e = hipMemcpy(h->d_data, tmp, (size_t)n, hipMemcpyDeviceToDevice);
             if (e == hipSuccess && h->n > n) e = hipMemset(h->d_data + n, 0, (size_t)std::min<int64_t>(h->n - n, 2 * TILE));
@@ -2167,7 +2176,7 @@ extern "C" int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mo
     HIPCHK(hipSetDevice(device));
     uint8_t *d = buf;
     if (where == FX_HOST) {
-        HIPCHK(hipMalloc((void **)&d, (size_t)n));
+        HIPCHK(dev_malloc((void **)&d, (size_t)n));
         hipError_t e = hipMemcpy(d, buf, (size_t)n, hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(d); return fail(FX_EDEVICE, "H2D: %s", hipGetErrorString(e)); }
     }
