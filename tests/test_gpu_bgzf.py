@@ -61,6 +61,41 @@ def test_fixed_huffman_and_stored_members(L, tmp_path):
     assert b.read_bytes(0, b.size) == b"".join(raws)
 
 
+def test_matches_and_literals_at_member_ends(L, tmp_path):
+    """The decoder stores a symbol as four bytes at its place (a literal, or the 3-byte token of a match in the first
+    bytes the match will fill) except within four bytes of the member's end, and the copy pass walks a map of one bit per
+    output byte: members of 1 .. 9 bytes, members that END in a shortest match, in a run (distance 1), in literals after
+    a match, full-size members of repeats, every combination next to a neighbour whose first bytes must survive; and
+    the scratch pool of the opens is emptied and refilled on the way (fx_release_scratch)."""
+    import zlib
+    rng = np.random.default_rng(5)
+    dna = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 70_000)])
+    chunks = [b"A", b"AC", b"ACG", b"ACGT", b"ACGTA", b"AAAAAAAAA", b"ABCABC", b"XYZ" + b"ABCDEFG" + b"XYZ", b"QABCABCABC", b"ABCDABCDABCDAB",
+              dna[:65280], (dna[:997] * 70)[:65280], dna[:300] + b"N" * 5000 + dna[:300], (b"ACGTTGCA" * 9000)[:65279] + b"Z",
+              dna[:1000] + dna[:1000][-3:], dna[:1000] + dna[500:503], b"".join(dna[i:i + 60] + b"\n" for i in range(0, 60_000, 60))]
+    for lvl in (9, 6, 1):
+        out, raw = [], []
+        order = list(range(len(chunks)))
+        rng.shuffle(order)
+        for i in order + order[::-1]:
+            chunk = chunks[i]
+            co = zlib.compressobj(lvl, zlib.DEFLATED, -15)
+            cd = co.compress(chunk) + co.flush()
+            out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(cd) + 25) + cd +
+                       struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+            raw.append(chunk)
+        raw = b"".join(raw)
+        p = _write(tmp_path, "ends%d.gz" % lvl, b"".join(out))
+        for k in range(3):
+            b = L.Blob.from_file(p)
+            assert b.size == len(raw)
+            got = b.read_bytes(0, b.size)
+            assert got == raw, (lvl, k, next(i for i in range(len(raw)) if got[i] != raw[i]))
+            b.close()
+            if k == 1:
+                L.check(L.lib().fx_release_scratch())
+
+
 def test_corrupt_member_is_reported(L, tmp_path):
     from pyfastx_amd import synth
     bg = bytearray(synth.bgzf_compress(fixture_bytes("test.fa"), block=20000))
