@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <zlib.h>
 #include <fcntl.h>
+#include <pthread.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -387,6 +389,36 @@ struct Stager {          // pinned ring: producer fills slot, H2D async, event m
     }
 };
 
+// The CPUs next to the device (sysfs local_cpulist of its PCI function): staging threads bound to them copy out of the
+// page cache into pinned buffers of the same NUMA node the DMA engine then reads from (FX_STAGE_NUMA=0 turns it off).
+static bool device_cpus(int device, cpu_set_t *set) {
+    static const bool on = [] { const char *e = getenv("FX_STAGE_NUMA"); return !e || atoi(e) != 0; }();
+    if (!on) return false;
+    char bus[64] = {0}, path[160];
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) return false;
+    for (char *c = bus; *c; ++c) *c = (char)tolower(*c);
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    char line[4096] = {0};
+    const bool got = fgets(line, sizeof line, f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    CPU_ZERO(set);
+    int n = 0;
+    for (char *p = line; *p && *p != '\n';) {
+        char *e;
+        const long a = strtol(p, &e, 10);
+        if (e == p) break;
+        long b = a;
+        if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET((int)c, set); ++n; }
+        p = *e == ',' ? e + 1 : e;
+        if (p == e && *e != ',') break;
+    }
+    return n > 0;
+}
+
 static int stage_threads() {
     static const int forced = [] { const char *e = getenv("FX_STAGE_THREADS"); return e ? atoi(e) : 0; }();   // experiments
     if (forced > 0) return std::min(forced, 64);
@@ -420,8 +452,11 @@ static int stage_plain_file(fx_handle *h, int fd, int64_t n, const char *path, u
     const int T = (int)std::min<int64_t>(stage_threads(), std::max<int64_t>(1, (n + PIECE_BYTES - 1) / PIECE_BYTES));
     std::atomic<int> err(0);                 // 1: read error, 2: device error
     std::vector<std::thread> th;
+    cpu_set_t near_cpus;
+    const bool bind = device_cpus(h->device, &near_cpus);
     for (int t = 0; t < T; ++t)
         th.emplace_back([&, t]() {
+            if (bind) (void)pthread_setaffinity_np(pthread_self(), sizeof near_cpus, &near_cpus);
             if (hipSetDevice(h->device) != hipSuccess) { err.store(2); return; }
             uint8_t *pin[2] = {g_pins.get(), g_pins.get()};
             hipStream_t st = nullptr;
