@@ -471,8 +471,19 @@ __device__ __forceinline__ void copy_plain(uint8_t *base, int64_t dst, int64_t s
 
 // A wave takes its member 4 KiB of output at a time: the 64 words of the match map of that stretch (one per lane) become
 // the list of the positions where matches begin (in LDS, in order), and the list is worked through 64 matches at a
-// time -- token from the first three bytes of the match's place, then the copy -- exactly as the token list of round 1
-// was: matches whose source lies before the batch are copied by their own lanes, the others in order by the whole wave.
+// time -- token from the first three bytes of the match's place (requested one batch ahead), then the copies.
+// 32 bytes at any address, read at the L2 (sc0 sc1: not from the CU's vector L1, which may hold a line from before a lane
+// of this wave wrote into it) with two instructions; ld_u64 above costs three loads and a funnel shift per 8 bytes, and
+// this kernel is bound by the instructions it issues.  The bytes past the ones a match needs are not used (the blob is
+// readable a tile past its end).  The wait is inside: the compiler does not see these loads.
+__device__ __forceinline__ void ld32_l2(const uint8_t *p, uint64_t (&w)[4]) {
+    uint4 a, b;
+    asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
+    w[0] = a.x | ((uint64_t)a.y << 32); w[1] = a.z | ((uint64_t)a.w << 32);
+    w[2] = b.x | ((uint64_t)b.y << 32); w[3] = b.z | ((uint64_t)b.w << 32);
+}
+
 constexpr int COPY_BLOCK = 256, COPY_POS = 4096 / 3 + 2;
 __global__ __launch_bounds__(COPY_BLOCK) void k_bgzf_copy(const int64_t *__restrict__ uoff, const int32_t *__restrict__ isize, int64_t nmem,
                                                          uint8_t *__restrict__ data,          // 4-byte aligned, readable 12 bytes past the end
@@ -497,31 +508,61 @@ __global__ __launch_bounds__(COPY_BLOCK) void k_bgzf_copy(const int64_t *__restr
             wd &= wd - 1;
             sp[r++] = (uint16_t)(((c0 + lane) << 6) + k);
         }
+        // 64 matches at a time.  Everything below `frontier` is final: first the place of the batch's first match, then, round
+        // by round, the place of its first match that is still to do (the bytes before it are literals or matches already
+        // made).  A match whose source ends below the frontier is ready; the ready matches of a round do not depend on each
+        // other: the short ones are made by their own lanes, all at once (source words first, then the stores), the long
+        // ones one after the other by the whole wave.  The first pending match is always ready, so a batch takes as many
+        // rounds as its longest chain of matches feeding matches -- one or two -- instead of one step per dependent match.
+        uint32_t tk_next = total > 0 && lane < total ? (uint32_t)ld_u64(data, ub + sp[lane]) : 0u;
         for (int b0 = 0; b0 < total; b0 += 64) {
             const int i = b0 + lane;
             const bool have = i < total;
             const int64_t dst = have ? sp[i] : 0;
-            const uint32_t tk = have ? (uint32_t)ld_u64(data, ub + dst) : 0u;       // 8 + 15 bits in the first three bytes of the match's place
+            const uint32_t tk = tk_next;                       // 8 + 15 bits in the first three bytes of the match's place
+            tk_next = i + 64 < total ? (uint32_t)ld_u64(data, ub + sp[i + 64]) : 0u;     // the next batch's: no match of this one writes there
             const int len = (int)(tk & 0xFFu) + 3;
             const int64_t dist = (int64_t)((tk >> 8) & 0x7FFFu) + 1;
             const int64_t src = dst - dist;
             const int64_t need = dist < len ? dist : len;      // source bytes that must be final: [src, src + need)
-            const int64_t D0 = sp[b0];                         // first output byte of the batch (same address for all lanes)
-            const bool indep = have && src + need <= D0;
-            if (indep) {                                       // copied by its own lane
-                if (dist >= len) copy_plain(data, ub + dst, ub + src, len);
-                else for (int j = 0; j < len; ++j) data[ub + dst + j] = ld_byte(data, ub + src + j % dist);   // run replication
+            int64_t frontier = sp[b0];
+            bool pending = have;
+            for (;;) {
+                const bool ready = pending && src + need <= frontier;
+                const bool wide = ready && len > 32;
+                if (ready && !wide) {
+                    if (dist >= len) {                         // the 32 bytes at the source in two loads, then the stores
+                        uint64_t w[4];
+                        ld32_l2(data + ub + src, w);
+                        uint8_t *o = data + ub + dst;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int left = len - 8 * k;
+                            if (left >= 8) *reinterpret_cast<uint64_u *>(o + 8 * k) = w[k];
+                            else if (left > 0) {
+                                uint64_t t = w[k];
+                                int q = 8 * k;
+                                if (left & 4) { *reinterpret_cast<uint32_u *>(o + q) = (uint32_t)t; t >>= 32; q += 4; }
+                                if (left & 2) { o[q] = (uint8_t)t; o[q + 1] = (uint8_t)(t >> 8); t >>= 16; q += 2; }
+                                if (left & 1) o[q] = (uint8_t)t;
+                            }
+                        }
+                    } else for (int j = 0; j < len; ++j) data[ub + dst + j] = ld_byte(data, ub + src + j % dist);   // run replication
+                }
+                unsigned long long wb = __ballot(wide);
+                while (wb) {                                   // each one as a wave-wide gather
+                    const int l = __ffsll(wb) - 1;
+                    wb &= wb - 1;
+                    const int64_t d_l = __shfl((int)dst, l, 64), k_l = __shfl((int)dist, l, 64);
+                    const int n_l = __shfl(len, l, 64);
+                    for (int j = lane; j < n_l; j += 64) data[ub + d_l + j] = ld_byte(data, ub + d_l - k_l + (k_l < n_l ? j % k_l : j));
+                }
+                pending = pending && !ready;
+                __threadfence_block();                         // this wave's stores are at the L2 before the next round's (or batch's) loads
+                const unsigned long long pb = __ballot(pending);
+                if (!pb) break;
+                frontier = __shfl((int)dst, __ffsll(pb) - 1, 64);
             }
-            unsigned long long dep = __ballot(have && !indep);
-            while (dep) {                                      // in order, each one as a wave-wide gather
-                __threadfence_block();                         // this wave's earlier stores are at the L2 before these loads
-                const int l = __ffsll(dep) - 1;
-                dep &= dep - 1;
-                const int64_t d_l = __shfl((int)dst, l, 64), k_l = __shfl((int)dist, l, 64);
-                const int n_l = __shfl(len, l, 64);
-                for (int j = lane; j < n_l; j += 64) data[ub + d_l + j] = ld_byte(data, ub + d_l - k_l + (k_l < n_l ? j % k_l : j));
-            }
-            __threadfence_block();                             // the next batch may read what this one wrote
         }
     }
 }
