@@ -9,18 +9,20 @@
 // zran_seek/zran_read random access (index.c:685-686): the inflated stream
 // becomes the resident blob the other kernels work on.
 //
-// Two kernels.  DEFLATE decoding is bit-serial, but only the DECODING is: what a match copies does not
+// Three kernels.  DEFLATE decoding is bit-serial, but only the DECODING is: what a match copies does not
 // influence how the following bits are parsed.  So
 //   k_bgzf_decode   one work-item per member parses the bit stream: literals are stored straight to
-//                   their final position, matches become tokens (dst, len, dist) in a side buffer.  No
-//                   load of previously written output, so the only memory latency on the critical path
-//                   is the input, and that is read one 8-byte word ahead of use.
-//   k_bgzf_copy     one WAVE per member resolves the tokens, 64 at a time: a token whose source lies
-//                   before the batch's first output byte is independent of the rest of the batch (the
-//                   common case: distances are long against 64 tokens' worth of output) and is copied
-//                   by its own lane; the others follow in order, each as one wave-wide gather --
-//                   out[dst + j] = out[src + j % dist] has no dependency inside a token, run
-//                   replication (dist < len) included.
+//                   their final position; a match leaves a 3-byte token (length, distance) in the first
+//                   bytes of the place it will fill and one bit in the member's match map (one bit per
+//                   output byte).  No load of previously written output, so the only memory latency on
+//                   the critical path is the input, and that is read one 8-byte word ahead of use.
+//   k_bgzf_copy     one WAVE per member walks the map, 64 matches at a time, in rounds: everything below
+//                   the first match still to do is final, so a match whose source ends there is ready;
+//                   the ready matches of a round are independent of each other -- short ones are made by
+//                   their own lanes, long ones by the whole wave (out[dst + j] = out[src + j % dist] has
+//                   no dependency inside a match, run replication (dist < len) included).  Distances are
+//                   long against 64 matches' worth of output: one or two rounds per batch.
+//   k_bgzf_crc      the CRC-32 of every member against its trailer.
 // This replaces the serial gzread() inflate that feeds the reference's scan (kseq.c:70) and the
 // zran_seek/zran_read random access (index.c:685-686).  The decoder reads a symbol with one or two LDS look-ups (8-bit
 // literal/length and 6-bit distance root tables + sub-tables per work-item, 52 KiB per 64-lane workgroup); codes in no
