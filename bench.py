@@ -127,7 +127,7 @@ def e2e_fasta(path, plan, q, out):
                open_file_GBps=round(os.path.getsize(path) / _median(t_open) / 1e9, 1),
                index_ready_s=round(_median(t_ready), 4), fxi_durable_s=round(_median(t_ctor), 4),
                fetch_many_1M_host_to_host_s=round(_median(t_fetch), 4), n_queries=int(len(ids)),
-               note="medians of 3; file in the page cache; open = pread into pinned 8 MiB pieces + hipMemcpyAsync (PCIe-bound); "
+               note="medians of 3; file in the page cache; open = pread into pinned 8 MiB pieces + hipMemcpyAsync (bound by the copy out of the page cache: a plain pinned copy runs at 57 GB/s here); "
                     "fxi_durable = pyfastx_amd.Fasta(path) with no .fxi present; fetch = Fasta.fetch_many(names, starts, stops, strand)")
     ours_rows = _tables(path + ".fxi", ("seq", "stat"))
     del fa
