@@ -416,6 +416,15 @@ class Fasta:
         except _lib.FxError:
             return None
 
+    def _cache_stat(self, sql, args):
+        """The reference ignores the result of the sqlite3_step that caches a statistic in `stat` (fasta.c:651-659,
+        770-782, 827-839): an index file that cannot be written (read-only mount, shared directory) still answers."""
+        import sqlite3
+        try:
+            self._db.execute(sql, args)
+        except sqlite3.Error:
+            pass
+
     def count(self, n):
         st = self._dev_stats(count_min=int(n))
         if st is not None:
@@ -446,7 +455,7 @@ class Fasta:
             raise RuntimeError("can not calculate N50 and L50")
         # fasta.c:651-659 stores the pair in n50 / l50 WHATEVER p was (so nl(90) followed by nl(50) answers nl(90)'s pair
         # from the cache there): mirrored, the columns are part of the index file
-        self._db.execute("UPDATE stat SET n50=?, l50=?", (int(j), int(i)))
+        self._cache_stat("UPDATE stat SET n50=?, l50=?", (int(j), int(i)))
         return (int(j), int(i))
 
     @property
@@ -477,7 +486,7 @@ class Fasta:
                 m = float(self._db.execute("SELECT AVG(slen) FROM seq").fetchone()[0] or 0.0)
         if not m:
             raise RuntimeError("could not calculate average length")        # fasta.c:770-782: a mean of 0 is an error there
-        self._db.execute("UPDATE stat SET avglen=?", (m,))
+        self._cache_stat("UPDATE stat SET avglen=?", (m,))
         return m
 
     @property
@@ -497,7 +506,7 @@ class Fasta:
                 m = float(self._db.execute(sql).fetchone()[0] or 0.0)
         if not m:
             raise RuntimeError("could not calculate median length")         # fasta.c:827-839: so is a median of 0
-        self._db.execute("UPDATE stat SET medlen=?", (m,))
+        self._cache_stat("UPDATE stat SET medlen=?", (m,))
         return m
 
     @property

@@ -235,13 +235,13 @@ int sort_names(const uint8_t *data, int64_t gbase, const int64_t *name_off, cons
     if (n <= 0) return 0;
     const size_t N = (size_t)n;
     for (int k = 0; k < 2; ++k) {
-        SORTCHK(hipMalloc((void **)&keys[k], N * 8), "hipMalloc(sort keys)");
-        SORTCHK(hipMalloc((void **)&vals[k], N * 4), "hipMalloc(sort values)");
+        SORTCHK(pool_malloc((void **)&keys[k], N * 8), "hipMalloc(sort keys)");
+        SORTCHK(pool_malloc((void **)&vals[k], N * 4), "hipMalloc(sort values)");
     }
     sc.nblk = (n + RS_TILE - 1) / RS_TILE;
-    SORTCHK(hipMalloc((void **)&sc.hist, (size_t)sc.nblk * 256 * 4), "hipMalloc(sort histograms)");
-    SORTCHK(hipMalloc((void **)&sc.totals, 256 * 4), "hipMalloc");
-    SORTCHK(hipMalloc((void **)&d_max, 4), "hipMalloc");
+    SORTCHK(pool_malloc((void **)&sc.hist, (size_t)sc.nblk * 256 * 4), "hipMalloc(sort histograms)");
+    SORTCHK(pool_malloc((void **)&sc.totals, 256 * 4), "hipMalloc");
+    SORTCHK(pool_malloc((void **)&d_max, 4), "hipMalloc");
     SORTCHK(hipMemsetAsync(d_max, 0, 4, s), "memset");
     const unsigned nb = (unsigned)((n + SB - 1) / SB);
     hipLaunchKernelGGL(k_sort_init, dim3(nb < 4096u ? nb : 4096u), dim3(SB), 0, s, name_len, n, keys[0], vals[0], d_max);
@@ -362,16 +362,16 @@ int len_stats(const int64_t *d_slen, int64_t n, int64_t count_min, double half, 
     if (n >= 0xFFFFFFFFll) { *where = "too many records for the 32-bit sort index"; return (int)hipErrorInvalidValue; }
     const size_t N = (size_t)n;
     for (int k = 0; k < 2; ++k) {
-        SORTCHK(hipMalloc((void **)&keys[k], N * 8), "hipMalloc(sort keys)");
-        SORTCHK(hipMalloc((void **)&vals[k], N * 4), "hipMalloc(sort values)");
+        SORTCHK(pool_malloc((void **)&keys[k], N * 8), "hipMalloc(sort keys)");
+        SORTCHK(pool_malloc((void **)&vals[k], N * 4), "hipMalloc(sort values)");
     }
     sc.nblk = (n + RS_TILE - 1) / RS_TILE;
     const int64_t nchunks = (n + LS_CHUNK - 1) / LS_CHUNK;
-    SORTCHK(hipMalloc((void **)&sc.hist, (size_t)sc.nblk * 256 * 4), "hipMalloc(sort histograms)");
-    SORTCHK(hipMalloc((void **)&sc.totals, 256 * 4), "hipMalloc");
-    SORTCHK(hipMalloc((void **)&d_max, 8), "hipMalloc");
-    SORTCHK(hipMalloc((void **)&d_sums, (size_t)(nchunks + 1) * 8), "hipMalloc");
-    SORTCHK(hipMalloc((void **)&d_out, sizeof(LenStats)), "hipMalloc");
+    SORTCHK(pool_malloc((void **)&sc.hist, (size_t)sc.nblk * 256 * 4), "hipMalloc(sort histograms)");
+    SORTCHK(pool_malloc((void **)&sc.totals, 256 * 4), "hipMalloc");
+    SORTCHK(pool_malloc((void **)&d_max, 8), "hipMalloc");
+    SORTCHK(pool_malloc((void **)&d_sums, (size_t)(nchunks + 1) * 8), "hipMalloc");
+    SORTCHK(pool_malloc((void **)&d_out, sizeof(LenStats)), "hipMalloc");
     SORTCHK(hipMemsetAsync(d_max, 0, 8, s), "memset");
     SORTCHK(hipMemsetAsync(d_out, 0, sizeof(LenStats), s), "memset");
     const unsigned nb = (unsigned)((n + SB - 1) / SB);

@@ -5,6 +5,9 @@
 
 namespace fx {
 
+// hipMalloc that empties the library's idle scratch pool and tries again when memory is short (fxgpu.hip)
+hipError_t pool_malloc(void **p, size_t bytes);
+
 // Sorted order of n names that live in the resident stream (name i = name_len[i] bytes at data + name_off[i] - gbase)
 // in SQLite's BINARY collation: memcmp over the common length, the shorter name first on a tie.  d_order[i] (device,
 // int64) = 0-based index of the i-th smallest name, equal names in index order; *d_ndup (device) = number of

@@ -72,6 +72,8 @@ static hipError_t dev_malloc(void **p, size_t bytes) {     // hipMalloc; when me
     return e;
 }
 
+namespace fx { hipError_t pool_malloc(void **p, size_t bytes) { return dev_malloc(p, bytes); } }   // fx_sort.hip allocates through it
+
 template <class T> struct DevBuf {      // grow-only device array: rebuilds reuse the allocation
     T *p = nullptr;
     int64_t n = 0, cap = 0;
@@ -444,7 +446,16 @@ struct PinPool {
         if (hipHostMalloc((void **)&p, (size_t)PIECE_BYTES, hipHostMallocDefault) != hipSuccess) return nullptr;
         return p;
     }
-    void put(uint8_t *p) { std::lock_guard<std::mutex> g(mu); bufs.push_back(p); }
+    // at most PIN_KEEP idle buffers stay pinned for the life of the process (256 MiB at the default piece size: what the
+    // 8 staging threads + 8 read-back threads use); the rest goes back to the system
+    static const size_t PIN_KEEP = 32;
+    void put(uint8_t *p) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (bufs.size() < PIN_KEEP) { bufs.push_back(p); return; }
+        }
+        (void)hipHostFree(p);
+    }
 };
 static PinPool g_pins;
 
@@ -745,7 +756,15 @@ static int gzip_indexed_to_blob(fx_handle *h, const uint8_t *in, int64_t nin, in
     int rc = alloc_blob(h, usize);
     if (rc) return rc;
     if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(FX_EDEVICE, "stream sync failed");
-    const int T = (int)std::min<int64_t>(std::max(8u, std::min(64u, std::thread::hardware_concurrency() / 2)), npts);
+    // (each thread holds two pinned pieces: 32 threads = 512 MiB pinned while the open runs, PinPool keeps 256 MiB of them)
+    const int T = (int)std::min<int64_t>(std::max(8u, std::min(32u, std::thread::hardware_concurrency() / 4)), npts);
+    // What the serial path gets from zlib's gzip wrapper has to be checked by hand here (raw inflate, -15): the CRC-32 of
+    // every segment's output (folded in order with crc32_combine) against the trailer, ISIZE, and that the deflate stream
+    // ENDS where the last segment does.  A file with several gzip members: the members after the first are inflated with
+    // the wrapper (zlib checks them); the folded CRC then describes no single trailer and only the end of the stream is checked.
+    std::vector<uint32_t> seg_crc((size_t)npts, 0);
+    std::atomic<int> members_seen(0);
+    std::atomic<int64_t> trailer_at(-1);
     std::atomic<int64_t> next(0);
     std::atomic<int> err(0);                                   // 1: data does not match the index, 2: device
     std::vector<std::thread> th;
@@ -796,11 +815,29 @@ static int gzip_indexed_to_blob(fx_handle *h, const uint8_t *in, int64_t nin, in
                         else if (ret == Z_BUF_ERROR && z.avail_in == 0 && ipos >= nin) bad = true;
                     }
                     if (bad) break;
+                    seg_crc[(size_t)i] = (uint32_t)crc32(seg_crc[(size_t)i], pin[slot], (uInt)got);
                     if (hipMemcpyAsync(h->d_data + done, pin[slot], (size_t)got, hipMemcpyHostToDevice, st) != hipSuccess ||
                         hipEventRecord(ev[slot], st) != hipSuccess) { err.store(2); bad = true; break; }
                     used[slot] = true;
                     slot ^= 1;
                     done += got;
+                }
+                if (wrapped) members_seen.store(1);
+                if (!bad && i == npts - 1) {                                  // the stream has to end here: Z_STREAM_END with no byte more
+                    uint8_t extra[8];
+                    int ret = Z_OK;
+                    for (int tries = 0; tries < 4 && ret == Z_OK; ++tries) {
+                        if (z.avail_in == 0) {
+                            const int64_t c = std::min<int64_t>(nin - ipos, 1 << 26);
+                            if (c <= 0) break;
+                            z.next_in = const_cast<Bytef *>(in + ipos); z.avail_in = (uInt)c; ipos += c;
+                        }
+                        z.next_out = extra; z.avail_out = sizeof extra;
+                        ret = inflate(&z, Z_NO_FLUSH);
+                        if (z.avail_out != sizeof extra) { ret = Z_DATA_ERROR; break; }
+                    }
+                    if (ret != Z_STREAM_END) bad = true;
+                    else if (!wrapped) trailer_at.store(ipos - (int64_t)z.avail_in);
                 }
                 inflateEnd(&z);
                 if (bad && !err.load()) err.store(1);
@@ -811,6 +848,18 @@ static int gzip_indexed_to_blob(fx_handle *h, const uint8_t *in, int64_t nin, in
         });
     for (auto &x : th) x.join();
     if (err.load() == 2) return fail(FX_EDEVICE, "staging the inflated segments failed");
+    if (!err.load() && !members_seen.load()) {                 // one member: its trailer describes the whole output
+        const int64_t tp = trailer_at.load();
+        if (tp < 0 || tp + 8 > nin) err.store(1);
+        else {
+            uint32_t crc = seg_crc[0];
+            for (int64_t i = 1; i < npts; ++i) crc = (uint32_t)crc32_combine(crc, seg_crc[(size_t)i], (z_off_t)((i + 1 < npts ? cout[i + 1] : usize) - cout[i]));
+            const uint8_t *t8 = in + tp;
+            const uint32_t want = t8[0] | (t8[1] << 8) | (t8[2] << 16) | ((uint32_t)t8[3] << 24);
+            const uint32_t isz = t8[4] | (t8[5] << 8) | (t8[6] << 16) | ((uint32_t)t8[7] << 24);
+            if (crc != want || isz != (uint32_t)usize) err.store(1);
+        }
+    }
     if (err.load() == 1) {                                     // the index does not describe this file: inflate it serially instead
         (void)hipFree(h->d_data);
         h->d_data = nullptr; h->owns = false; h->n = 0;
@@ -833,6 +882,9 @@ extern "C" int fx_open_file_indexed(const char *path, int device, int64_t n_poin
                                     const uint8_t *bits, const uint8_t *has_data, const uint8_t *windows, int64_t uncompressed_size,
                                     fx_handle **out) {
     if (n_points > 0 && (!cmp_off || !uncmp_off || !bits || !has_data)) return fail(FX_EINVAL, "null argument");
+    if (!windows)                                            // windows holds GZ_WINDOW bytes for every point whose has_data is set
+        for (int64_t i = 0; i < n_points; ++i)
+            if (has_data[i]) return fail(FX_EINVAL, "restart point %lld has window data but no windows were passed", (long long)i);
     return open_file_impl(path, device, out, n_points, cmp_off, uncmp_off, bits, has_data, windows, uncompressed_size);
 }
 
@@ -1042,7 +1094,14 @@ extern "C" int fx_open_file_range(const char *path, int64_t off, int64_t len, in
             if (e == hipSuccess && h->n > n) e = hipMemset(h->d_data + n, 0, (size_t)std::min<int64_t>(h->n - n, 2 * TILE));
             (void)hipFree(tmp);
             if (e != hipSuccess) return bail(fail(FX_EDEVICE, "device copy failed: %s", hipGetErrorString(e)));
-        } else h->d_data += skip;
+        } else {
+            // the blob is the inflated members from `skip` on: what follows the range is live stream data, not the zero pad
+            // alloc_blob leaves behind a blob -- make it one (kernels may look at the pad, never past the allocation)
+            const int64_t after = h->n - (skip + n);
+            if (after > 0 && hipMemset(h->d_data + skip + n, 0, (size_t)std::min<int64_t>(after, 2 * TILE)) != hipSuccess)
+                return bail(fail(FX_EDEVICE, "memset failed"));
+            h->d_data += skip;
+        }
         h->n = n;
         h->gz = true;
     }
@@ -1622,8 +1681,16 @@ extern "C" int fx_fastq_comp(fx_handle *h, int64_t base[5], int64_t meta[5]) {
     HIPCHK(hipStreamSynchronize(h->stream));
     // reset the counters so a second call does not double count
     FastqAcc keep = acc;
-    keep.a = keep.c = keep.g = keep.t = keep.n = 0; keep.minqs = 104; keep.maxqs = 33;
+    keep.a = keep.c = keep.g = keep.t = keep.n = 0; keep.minqs = 104; keep.maxqs = 33; keep.qfix = 0;
+    if (acc.qfix) { keep.maxlen = 0; keep.minlen = 10000000000LL; }        // rows with a '\r' inside the quality line got the reference's line.l:
     HIPCHK(hipMemcpyAsync(h->fq_acc.p, &keep, sizeof keep, hipMemcpyHostToDevice, h->stream));
+    if (acc.qfix) {                                                        // ... meta.maxlen / minlen over the table once more (fastq.c:747-751)
+        hipLaunchKernelGGL(k_fastq_qlen_range, dim3((unsigned)std::min<int64_t>(nblocks(h->n_reads, BLOCK), 1024)), dim3(BLOCK), 0, h->stream, t, h->n_reads, h->fq_acc.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&keep, h->fq_acc.p, sizeof keep, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->fq_maxlen = keep.maxlen; h->fq_minlen = keep.minlen;
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     base[0] = (int64_t)acc.a; base[1] = (int64_t)acc.c; base[2] = (int64_t)acc.g; base[3] = (int64_t)acc.t; base[4] = (int64_t)acc.n;
     int phred = 0;

@@ -64,6 +64,12 @@ FASTQ_EDGE = {
     "lowercase_and_n": "@r\nacgtNnACGT\n+\nhhhhhhhhhh\n",
     "phred64": "@r\nACGT\n+\nhgfe\n@s\nAAAA\n+\nefgh\n",
     "tab_in_name": "@r\t1 2\nAC\n+\nII\n",
+    # a '\r' INSIDE a quality line: the reference's loop shrinks line.l as it goes (fastq.c:733-737), so the last bytes of the
+    # line are never examined ('!' and '~' below stay out of minqs / maxqs) and meta.minlen / maxlen are the shrunken lengths
+    "cr_in_quality_short": "@r\nACGT\n+\nI\rI!\n@s\nAC\n+\n\r~\n",
+    "cr_in_quality_long": "@r1\nACGTACGTACGTACGTACGT\n+\nIIII\rIIIIIIIIIIIII#!\n@r2\nACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIII\n"
+                          "@r3\nACGTACGTACGTACGTACGTAC\n+\nJJJJJJJJJJJJJJJJJJ\r\rJ~\n",
+    "cr_in_quality_crlf": "@r1\r\nACGTACGTACGTACGTACGT\r\n+\r\nIIIIIIIIII\rIIIIIII5!\r\n@r2\r\nACGTA\rCGTACGTACGTACGT\r\n+\r\nHHHHHHHHHHHHHHHHHHHH\r\n",
 }
 
 

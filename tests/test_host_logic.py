@@ -101,6 +101,29 @@ def test_existing_index_is_loaded_without_gpu(oracle, tmp_path):
     assert fa[1][5:30].name == "JZ822578.1:6-30" and fa.count(200) > 0
 
 
+def test_statistics_answer_from_a_read_only_index(oracle, tmp_path):
+    """The reference ignores the result of the write that caches nl / mean / median in `stat` (fasta.c:651-659, 770-782,
+    827-839), so an index the user cannot write still answers.  `PRAGMA query_only` makes every write fail the way a
+    read-only file does (the tests run as root, for whom a chmod means nothing)."""
+    import sqlite3
+    import pyfastx_amd as fx
+    from pyfastx_amd import fxi
+    p = str(tmp_path / "ro.fa")
+    raw = fixture_bytes("test.fa")
+    open(p, "wb").write(raw)
+    recs, tot = oracle.fasta_index(raw)
+    names = [raw[r["name_off"]:r["name_off"] + r["name_len"]].decode() for r in recs]
+    db = fxi.connect(p + ".fxi")
+    fxi.write_fasta(db, names, {k: recs[k] for k in ("boff", "blen", "slen", "llen", "elen", "norm", "dlen")}, tot)
+    db.close()
+    fa = fx.Fasta(p)
+    fa._db.execute("PRAGMA query_only=ON")
+    with pytest.raises(sqlite3.Error):
+        fa._db.execute("UPDATE stat SET medlen=1")
+    assert fa.nl(50) == (516, 66) and fa.median == 386.0 and abs(fa.mean - 408.82464454976304) < 1e-9
+    assert fa._db.execute("SELECT avglen, medlen, n50, l50 FROM stat").fetchone()[1:] in ((None, None, None), (0, 0, 0), (0.0, 0, 0))
+
+
 def _reg_of(raw, r):
     """The line-regular bit of one oracle row: shard.line_regular_rule with the whole stream in view."""
     from pyfastx_amd.shard import line_regular_rule
