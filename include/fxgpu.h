@@ -301,7 +301,8 @@ int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mode);
  * stream is serial).  fx_gz_points lists restart points for the .fxi `gzindex`
  * table (pyfastx_build_gzip_index / pyfastx_gzip_index_export, util.c:442-540,
  * 728-742): for BGZF, member boundaries about `spacing` uncompressed bytes apart
- * (bit offset 0, no 32 KiB window needed).  Call with cap = 0 to get the count.
+ * (cmp_off = the first byte of the member's deflate data, where zran_seek starts a raw
+ * inflate; bit offset 0, no 32 KiB window needed).  Call with cap = 0 to get the count.
  * Non-BGZF inputs report 0 points here: see fx_gz_checkpoints.                 */
 int fx_gz_points(fx_handle *h, int64_t spacing, int64_t *cmp_off, int64_t *uncmp_off, int64_t cap,
                  int64_t *n_out, int64_t *compressed_size);
@@ -314,8 +315,10 @@ int fx_gz_points(fx_handle *h, int64_t spacing, int64_t *cmp_off, int64_t *uncmp
  * (windows: 32768 bytes per point with has_data, in order; call with cap = 0 for the counts);  fx_open_file_indexed is
  * fx_open_file with the points of an existing index: the segments between them are inflated by many host threads at
  * once, each a raw inflate primed with its bits and window (zran_seek + zran_read of index.c:685-686, for every
- * segment at the same time).  Points that do not describe the file: the serial inflate, silently.  The checkpoint
- * layout itself is parity-unpinned: indexed_gzip is not part of the reference tree. */
+ * segment at the same time).  Points that do not describe the file: the serial inflate, silently.  indexed_gzip is
+ * not part of the reference tree; the compiled reference of the tests imports these rows (util.c:542-726) and serves
+ * its reads from them through a zran work-alike (oracle/refshim): offsets, bits and windows are pinned
+ * that way, only the PLACEMENT real zran would choose for its points is not. */
 int fx_gz_checkpoints(fx_handle *h, int64_t cap, int64_t *cmp_off, int64_t *uncmp_off, uint8_t *bits, uint8_t *has_data,
                       uint8_t *windows, int64_t *n_out, int64_t *n_windows);
 int fx_open_file_indexed(const char *path, int device, int64_t n_points, const int64_t *cmp_off, const int64_t *uncmp_off,

@@ -9,10 +9,12 @@
  * src/sequence.c:40-41,169,206), so that the reference's own C files can be
  * compiled *where they lie* into oracle/_ref/ and used as the parity oracle.
  *
- * Random access is served by zlib's gzseek/gzread on a dup'd descriptor:
- * the BYTES returned are exactly what real zran would return (gzip inflate is
- * deterministic); the checkpoint list itself is NOT reproduced ("parity
- * unpinned" for the gzindex blob layout -- no reference test asserts it).
+ * Random access works the way zran's does (see zran.c): restart points at deflate
+ * block boundaries (bit offset + 32 KiB window), raw inflate from the last point at
+ * or before the wanted offset -- so a gzindex table imported through
+ * pyfastx_gzip_index_import (util.c:542-726), e.g. one the product wrote, is what
+ * serves the reads.  The PLACEMENT of the points real indexed_gzip would choose is
+ * not reproduced (no reference test asserts it; any block boundary is valid).
  */
 #ifndef FX_ORACLE_ZRAN_SHIM_H
 #define FX_ORACLE_ZRAN_SHIM_H
@@ -40,8 +42,8 @@ typedef struct _zran_index {
     uint32_t      size;
     zran_point_t *list;
     uint16_t      flags;
-    /* shim state */
-    gzFile        gz;
+    /* shim state (zran.c: shim_t) */
+    void         *shim;
 } zran_index_t;
 
 enum { ZRAN_AUTO_BUILD = 1, ZRAN_SKIP_CRC_CHECK = 2 };
@@ -62,5 +64,12 @@ void    zran_free(zran_index_t *index);
 int     zran_build_index(zran_index_t *index, uint64_t from, uint64_t until);
 int     zran_seek(zran_index_t *index, int64_t offset, uint8_t whence, zran_point_t **point);
 int64_t zran_read(zran_index_t *index, void *buf, uint64_t len);
+
+/* how the seeks of this process were served (tests read these through ctypes from the compiled module):
+ * out = {seeks, started at a point, started at the head of the file, continued from the current position,
+ *        points created by zran_build_index, inflate / header errors} */
+void fxshim_stats(uint64_t out[6]);
+void fxshim_reset(void);
+void fxshim_point_hits(uint32_t *out, uint32_t n);
 
 #endif

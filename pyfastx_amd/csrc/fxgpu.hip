@@ -289,7 +289,7 @@ struct fx_handle {
     int64_t arena_used = 0;
     int64_t halo = 0;          // trailing bytes of the blob that belong to the next shard's core
     // BGZF member table (compressed offset of each member, offset of its data in the inflated stream)
-    std::vector<int64_t> gz_moff, gz_uoff;
+    std::vector<int64_t> gz_moff, gz_coff, gz_uoff;          // member start, start of its deflate data (behind the header), offset of its bytes in the inflated stream
     int64_t gz_csize = 0;
     bool bgzf = false;
     // restart points of a single gzip stream (captured while it is inflated: GzSerial below)
@@ -662,7 +662,7 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
                                                        : "BGZF member %lld of %s (offset %lld) failed to inflate: code %d",
                         (long long)m, path, (long long)t.moff[m], status[m]);
     h->bgzf = true;
-    h->gz_moff = full.moff; h->gz_uoff = full.uoff; h->gz_csize = fsize_all;
+    h->gz_moff = full.moff; h->gz_coff = full.coff; h->gz_uoff = full.uoff; h->gz_csize = fsize_all;
     return FX_OK;
 }
 
@@ -2301,7 +2301,9 @@ extern "C" int fx_gz_points(fx_handle *h, int64_t spacing, int64_t *cmp_off, int
         if (spacing <= 0) spacing = 1048576;                 // zran spacing used by the reference (index.c:70)
         for (size_t m = 0; m < h->gz_moff.size(); ++m) {
             if (h->gz_uoff[m] < next && m != 0) continue;
-            if (cmp_off && uncmp_off && n < cap) { cmp_off[n] = h->gz_moff[m]; uncmp_off[n] = h->gz_uoff[m]; }
+            // a zran point is where a RAW inflate can start (zran_seek: inflateInit2(-15) at cmp_offset): the first byte of the
+            // member's deflate data, behind its 18-byte BGZF header -- bits 0, no window (nothing before a member's first block)
+            if (cmp_off && uncmp_off && n < cap) { cmp_off[n] = h->gz_coff[m]; uncmp_off[n] = h->gz_uoff[m]; }
             ++n;
             next = h->gz_uoff[m] + spacing;
         }

@@ -41,10 +41,11 @@ def test_inflate_matches_zlib(L, tmp_path, level, block):
     got = b.read_bytes(0, len(raw))
     assert got == raw
     c, u, cs = b.gz_points(spacing=100_000)
-    assert cs == len(bg) and c[0] == 0 and u[0] == 0 and len(c) >= 2
-    for co, uo in zip(c, u):                              # each point really is a member start
-        assert bg[co:co + 4] == b"\x1f\x8b\x08\x04"
-        assert gzip.decompress(bg[co:])[:64] == raw[uo:uo + 64]
+    import zlib
+    assert cs == len(bg) and c[0] == 18 and u[0] == 0 and len(c) >= 2
+    for co, uo in zip(c, u):                              # each point is the first deflate byte of a member: what a raw inflate
+        assert bg[co - 18:co - 14] == b"\x1f\x8b\x08\x04"  # (zran_seek: inflateInit2(-15) at cmp_offset) starts from
+        assert zlib.decompressobj(-15).decompress(bg[co:co + 70_000], 64) == raw[uo:uo + 64]
 
 
 def test_fixed_huffman_and_stored_members(L, tmp_path):
@@ -218,24 +219,101 @@ def test_single_stream_gzip_checkpoints(L, tmp_path, shape):
     assert bb.read_bytes(0, len(raw)) == raw and bb.gz_checkpoints()["windows"].size == (n - 1) * 32768
 
 
-def test_reference_opens_a_gz_index_with_checkpoints(tmp_path):
-    """The compiled reference imports our gzindex rows (pyfastx_gzip_index_import, util.c:542-726: id, version, sizes,
-    window >= 32768, spacing >= window) and returns the same sequences.  (Its zran is the gzseek stand-in: the checkpoint
-    layout itself stays parity-unpinned.)"""
+def _shim(pyfastx):
+    """The counters of the compiled reference's zran work-alike (oracle/refshim/zran.c), through ctypes."""
+    import ctypes
+    so = ctypes.CDLL(pyfastx.__file__)
+    so.fxshim_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    so.fxshim_point_hits.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32]
+
+    def stats():
+        a = (ctypes.c_uint64 * 6)()
+        so.fxshim_stats(a)
+        return dict(zip(("seeks", "from_point", "from_start", "continued", "built_points", "errors"), (int(x) for x in a)))
+
+    def hits(n):
+        a = (ctypes.c_uint32 * n)()
+        so.fxshim_point_hits(a, n)
+        return [int(x) for x in a]
+    return so, stats, hits
+
+
+@pytest.mark.parametrize("shape", ["zlib6", "pigz_style", "two_members", "stored_then_deflate", "bgzf"])
+def test_reference_reads_through_our_restart_points(tmp_path, shape):
+    """SURVEY a13 pinned THROUGH the reference: the compiled reference opens an index file the PRODUCT wrote, imports its
+    gzindex rows (pyfastx_gzip_index_import, util.c:542-726: id, version, sizes, window >= 32768, spacing >= window, the
+    points and their windows) and answers 1 000 random slices by zran_seek / zran_read (index.c:685-686) -- served by the
+    zran work-alike of oracle/refshim FROM THE IMPORTED POINTS: last point at or before the offset, raw inflate primed
+    with the point's bits and window.  The shim's counters prove it: no point was built in this process, every imported
+    point started at least one seek, no inflate error -- and every answer equals the product's and the plain bytes."""
     import glob
     import sys
     from conftest import ROOT
+    from pyfastx_amd import synth
     if not glob.glob(os.path.join(ROOT, "oracle", "_ref", "pyfastx*.so")):
         pytest.fail("oracle/_ref is missing")
     sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
     import pyfastx
     import pyfastx_amd as fx
     rng = np.random.default_rng(3)
-    raw = _big_fasta(rng, nrec=12)
-    p = _write(tmp_path, "r.fa.gz", gzip.compress(raw, 6))
-    fa = fx.Fasta(p)
-    assert struct.unpack("<I", bytes(sqlite3.connect(p + ".fxi").execute("SELECT content FROM gzindex WHERE ID=8").fetchone()[0]))[0] >= 2
-    rf = pyfastx.Fasta(p)                                      # loads OUR index file
-    assert len(rf) == len(fa) == 12
-    for i in (0, 5, 11):
-        assert rf[i].seq == fa[i].seq and rf[i][100:220].antisense == fa[i][100:220].antisense
+    N = 40
+    raw = _big_fasta(rng, nrec=N)
+    if shape == "zlib6":
+        gz = gzip.compress(raw, 6)
+    elif shape == "pigz_style":
+        gz = synth.gzip_single_stream(raw, piece=1 << 20)
+    elif shape == "two_members":
+        gz = gzip.compress(raw[:len(raw) // 3], 6) + gzip.compress(raw[len(raw) // 3:], 1)
+    elif shape == "stored_then_deflate":
+        gz = gzip.compress(raw[:3_000_000], 0) + gzip.compress(raw[3_000_000:], 6)
+    else:
+        gz = synth.bgzf_compress(raw)
+    p = _write(tmp_path, "r.fa.gz", gz)
+    fa = fx.Fasta(p)                                           # the product writes the index file, gzindex included
+    db = sqlite3.connect(p + ".fxi")
+    npts = struct.unpack("<I", bytes(db.execute("SELECT content FROM gzindex WHERE ID=8").fetchone()[0]))[0]
+    pts = fxi_points(db)
+    db.close()
+    assert npts >= 5 and len(pts) == npts
+    if shape != "bgzf":
+        assert any(b for _, _, b, _ in pts) or shape == "stored_then_deflate"      # points in the middle of a byte are in play
+    so, stats, hits = _shim(pyfastx)
+    so.fxshim_reset()
+    rf = pyfastx.Fasta(p)                                      # loads OUR index file: import, no build
+    assert len(rf) == len(fa) == N and stats()["built_points"] == 0
+    # slices: two that start just behind every point's offset (so that each point has to serve a seek), the rest random
+    recs = [(s.name, len(s)) for s in fa]
+    tab = sqlite3.connect(p + ".fxi").execute("SELECT boff, blen, slen FROM seq ORDER BY ID").fetchall()
+    q = []
+    for (_, u, _, _) in pts:
+        for k, (boff, blen, slen) in enumerate(tab):
+            if boff <= u + 200 < boff + blen - 400:
+                a = ((u + 200 - boff) * 70) // 71                # a base whose byte lies a little behind the point
+                q.append((k, a, min(a + 120, slen)))
+                break
+    while len(q) < 1000:
+        k = int(rng.integers(0, N))
+        a = int(rng.integers(0, recs[k][1] - 1))
+        q.append((k, a, min(recs[k][1], a + int(rng.integers(1, 400)))))
+    order = rng.permutation(len(q))                            # random order: every seek starts over
+    for j in order.tolist():
+        k, a, b = q[j]
+        want = fa[k][a:b]
+        got = rf[recs[k][0]][a:b]
+        assert got.seq == want.seq and got.antisense == want.antisense, (shape, k, a, b)
+    assert rf[7].seq == fa[7].seq and rf[N - 1].raw == fa[N - 1].raw
+    st = stats()
+    h = hits(npts)
+    assert st["errors"] == 0 and st["built_points"] == 0 and st["from_start"] == 0
+    assert st["from_point"] >= 1000 * 0.5 and all(x >= 1 for x in h), (st, h)
+
+
+def fxi_points(db):
+    """(cmp, uncmp, bits, has_data) of every point of a gzindex table, straight from its rows (util.c:461-529)."""
+    rows = [bytes(r[0]) for r in db.execute("SELECT content FROM gzindex ORDER BY ID")]
+    n = struct.unpack("<I", rows[7])[0]
+    out = []
+    for i in range(n):
+        c, u, b, f = rows[8 + 4 * i:12 + 4 * i]
+        out.append((struct.unpack("<Q", c)[0], struct.unpack("<Q", u)[0], b[0], f[0]))
+    return out
