@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gbp", type=float, default=3.0, help="Gbp of FASTA per GPU (3.0 = BASELINE config)")
     ap.add_argument("--queries", type=int, default=1_000_000)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = --gbp per GPU, the pieces of all ranks form ONE file (configs[4]: 24 Gbp at 8 GPUs), with the strong leg "
+                         "reported beside it; strong = ONE --gbp file (the metric's 3 Gbp FASTA) split by byte range over the N GPUs")
     ap.add_argument("--c3-reads", type=float, default=1e8, help="reads of the FASTQ leg resident in HBM (1e8 = BASELINE configs[2])")
     ap.add_argument("--c3-sample", type=float, default=2e6, help="reads of the FASTQ file that the reference also indexes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -692,6 +695,240 @@ def main_sharded(a, dev, rank, world, backend):
     }
 
 
+# ------------------------------------------------------------------------------------------ strong scaling: ONE file over N GPUs
+def strong_leg(a, dev, rank, world, backend, collective):
+    """BASELINE.json's metric as it is worded -- ONE 3 Gbp FASTA on 1/2/4/8 GPUs: the file is cut into `world` byte ranges
+    (the cuts fall inside contigs and lines), rank r stages only ITS range over its own PCIe link, builds its part of the
+    index, ONE all-gather of the 28-word summaries stitches the record across every cut, rank 0 writes ONE .fxi, and the
+    SAME 1 M queries of the single-GPU run are answered over the whole stream: each by the rank that holds its first byte
+    (fx_shard_route), queries that cross a cut put together from their pieces.  Reported: (i) the step with everything
+    resident in HBM -- build + all-gather + stitch + this rank's routed share of the queries, K timed steps between barriers
+    -- and (ii) the same job END TO END, file to answers in host memory, every phase max over ranks.
+    collective: a process group exists (world > 1, or the forced single-rank RCCL run)."""
+    import torch
+    import torch.distributed as dist
+    from pyfastx_amd import _lib, synth, shard
+    total_bp = int(a.gbp * 1e9)
+    comm = dev if backend == "nccl" else torch.device("cpu")
+
+    def barrier():
+        if collective:
+            dist.barrier()
+
+    def allmax(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device=comm if collective else "cpu")
+        if collective:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t.cpu()]
+
+    def allsum(vals):
+        t = torch.tensor(vals, dtype=torch.int64, device=comm if collective else "cpu")
+        if collective:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [int(x) for x in t.cpu()]
+
+    plan = synth.fasta_plan(total_bp=total_bp, seed=20260612)          # the single-GPU run's file and queries (configs[1])
+    nb = int(plan["n_bytes"])
+    ids, st, sp, strand = synth.fasta_queries(plan, n=a.queries, seed=12345)
+    qfl = (strand * 6).astype(np.uint8)
+    qlen = int(sp[0] - st[0])
+    box = [None]
+    if rank == 0:
+        box[0] = os.path.join(_scratch_dir(nb), "c2.fa")
+        piece, _, _ = synth.fasta_generate(plan, dev, keep_flat=False)
+        piece[:nb].cpu().numpy().tofile(box[0])
+        del piece
+        torch.cuda.empty_cache()
+    if collective:
+        dist.broadcast_object_list(box, src=0)
+    path = box[0]
+    barrier()
+    try:
+        _lib.Blob.from_file_range(path, nb * rank // world, min(1 << 20, nb // world), 0, device=dev.index).close()   # first touch: HIP context, pinned pool
+        barrier()
+        # ---------------- (ii) end to end, once per phase (the phases are seconds-scale host work; max over ranks)
+        t0 = time.perf_counter()
+        job = shard.ShardedFasta.from_file(path, dev, rank, world, force_collective=collective and world == 1)
+        t_open = time.perf_counter() - t0
+        barrier()
+        t0 = time.perf_counter()
+        job.build()
+        t_build = time.perf_counter() - t0
+        barrier()
+        t0 = time.perf_counter()
+        table = job.write_index(path + ".fxi")                            # gather of the rows + rank 0 writes ONE .fxi
+        t_fxi = time.perf_counter() - t0
+        fetcher = job.fetcher(table)
+        fetcher.fetch(ids[:1000], st[:1000], sp[:1000], flags_per_query=qfl[:1000])
+        barrier()
+        t0 = time.perf_counter()
+        qidx, fbuf, foffs = fetcher.fetch(ids, st, sp, flags_per_query=qfl)   # host arrays -> host buffer, this rank's share
+        barrier()
+        t_fetch = time.perf_counter() - t0
+        # ---------------- parity: the merged index against the plan's analytic rows, every query answered once, the bytes
+        ok_rows = ok_bytes = None
+        off_, bl_, _, _ = shard.slice_ranges(table, ids, st, sp)
+        route = shard.route_ranges(table["bases"], table["ends"], off_, bl_)
+        n_cross = int((route["cnt"] > 1).sum())
+        if not a.no_verify:
+            if rank == 0:
+                import sqlite3
+                db = sqlite3.connect(path + ".fxi")
+                got = db.execute("SELECT chrom,boff,blen,slen,llen,elen,norm,dlen FROM seq ORDER BY ID").fetchall()
+                tot = db.execute("SELECT seqnum, seqlen FROM stat").fetchone()
+                db.close()
+                ok_rows = len(got) == len(plan["names"]) and tuple(tot) == (len(got), int(plan["slen"].sum())) and all(
+                    tuple(r) == (plan["names"][i], int(plan["boff"][i]), int(plan["blen"][i]), int(plan["slen"][i]), int(plan["llen"][i]), 1, 1, int(plan["dlen"][i]))
+                    for i, r in enumerate(got))
+                if not ok_rows:
+                    raise SystemExit("PARITY FAILURE (strong scaling): the merged .fxi differs from the analytic rows of the file")
+            mm = np.memmap(path, dtype=np.uint8, mode="r")
+            G = {"boff": plan["boff"]}
+            pos = np.full(a.queries, -1, dtype=np.int64)
+            pos[qidx] = np.arange(qidx.size)
+            crossing = np.nonzero(route["cnt"] > 1)[0]
+            sample = np.unique(np.concatenate([qidx[::max(qidx.size // 4000, 1)], crossing[pos[crossing] >= 0]]))
+            good = True
+            for qi in sample.tolist():
+                j = int(pos[qi])
+                good = good and fbuf[foffs[j]:foffs[j + 1]].tobytes() == _host_truth(mm, G, int(ids[qi]), int(st[qi]), int(sp[qi]), bool(strand[qi]))
+            del mm
+            n_ans, n_good = allsum([qidx.size, int(good)])
+            ok_bytes = bool(n_ans == a.queries and n_good == world)
+            if not ok_bytes:
+                raise SystemExit("PARITY FAILURE (strong scaling): fetches over the byte-range shards")
+        del fbuf
+        # ---------------- (i) the step, HBM-resident: this rank's routed share of the batch as device arrays (routing is
+        # setup here -- it is inside the end-to-end fetch above), pieces of cut-crossing queries of other ranks included
+        R = _lib.shard_route(ids, st, sp, fetcher._cols, fetcher.bases, fetcher.ends, 0, qfl)
+        lo_, hi_ = int(R["shard_start"][rank]), int(R["shard_start"][rank + 1])
+        r_off, r_len, r_take, r_fl = R["off"][lo_:hi_], R["len"][lo_:hi_], R["take"][lo_:hi_], R["fl"][lo_:hi_]
+        other = (route["r"] == rank) & (route["first"][route["q"]] != rank)   # pieces I hold of queries another rank answers
+        if other.any():
+            r_off = np.concatenate([r_off, route["poff"][other]]); r_len = np.concatenate([r_len, route["plen"][other]])
+            r_take = np.concatenate([r_take, route["plen"][other]]); r_fl = np.concatenate([r_fl, qfl[route["q"][other]]])
+        n_mine = int(r_off.size)
+        d_off = torch.from_numpy(np.ascontiguousarray(r_off)).to(dev); d_bl = torch.from_numpy(np.ascontiguousarray(r_len)).to(dev)
+        d_tk = torch.from_numpy(np.ascontiguousarray(r_take)).to(dev); d_fl = torch.from_numpy(np.ascontiguousarray(r_fl)).to(dev)
+        dst_off = np.zeros(n_mine + 1, dtype=np.int64)
+        np.cumsum(np.maximum(r_take, 0), out=dst_off[1:])
+        d_do = torch.from_numpy(dst_off[:-1].copy()).to(dev)
+        d_out = torch.zeros(max(int(dst_off[-1]), 16), dtype=torch.uint8, device=dev)
+        d_len = torch.zeros(max(n_mine, 1), dtype=torch.int64, device=dev)
+        L = _lib.lib()
+        torch.cuda.synchronize()
+
+        def step():
+            job.build_async()                                 # scan + tables + summary -> all-gather -> stitch, enqueued
+            if n_mine:
+                _lib.check(L.fx_fetch_ranges(job.blob._h, _lib.FX_DEVICE, n_mine, d_off.data_ptr(), d_bl.data_ptr(), d_tk.data_ptr(), 0,
+                                             d_fl.data_ptr(), d_out.data_ptr(), d_do.data_ptr(), d_len.data_ptr()))
+            job.finish()
+            job.sync()
+
+        for _ in range(a.warmup):
+            step()
+        job.blob.prof_enable(2)
+        job.blob.prof_reset()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        el = time.perf_counter() - t0                         # exactly a.steps steps between barriers
+        prof = job.blob.prof_read()
+        job.blob.prof_enable(1)
+        job.blob.prof_reset()
+        for _ in range(5):
+            step()
+        prof_all = job.blob.prof_read()
+        job.blob.prof_enable(0)
+        t_index = 0.0
+        for _ in range(a.steps):
+            ts = time.perf_counter()
+            job.build()
+            t_index += time.perf_counter() - ts
+        step_ok = None
+        if not a.no_verify:                                   # the device step's answers: whole queries against the file
+            out_h, len_h = d_out.cpu().numpy(), d_len.cpu().numpy()
+            mm = np.memmap(path, dtype=np.uint8, mode="r")
+            G = {"boff": plan["boff"]}
+            order = R["order"][lo_:hi_]
+            good = True
+            for k in range(0, hi_ - lo_, max((hi_ - lo_) // 2000, 1)):
+                if R["cnt"][lo_ + k] != 1:
+                    continue
+                qi = int(order[k])
+                good = good and int(len_h[k]) == qlen and out_h[dst_off[k]:dst_off[k] + qlen].tobytes() == _host_truth(mm, G, int(ids[qi]), int(st[qi]), int(sp[qi]), bool(strand[qi]))
+            del mm
+            step_ok = bool(allsum([int(good)])[0] == world)
+            if not step_ok:
+                raise SystemExit("PARITY FAILURE (strong scaling): the device-resident routed fetch")
+        el, t_index, t_open, t_build, t_fxi, t_fetch = allmax([el, t_index, t_open, t_build, t_fxi, t_fetch])
+        n_max = allmax([float(n_mine)])[0]
+    finally:
+        barrier()
+        if rank == 0:
+            shutil.rmtree(os.path.dirname(path), ignore_errors=True)
+    if rank != 0:
+        return None
+    ms = el / a.steps * 1e3
+    scan_ms, scan_n = prof.get("k_span_scan", (0.0, 0))
+    scan_avg = scan_ms / max(scan_n, 1)
+    achieved = job.n_bytes / (scan_avg * 1e-3) / 1e9 if scan_avg > 0 else 0.0
+    e2e_total = t_open + t_build + t_fxi + t_fetch
+    return {
+        "workload": "configs[1] on %d GPU(s): ONE synthetic %.1f Gbp hg38-shaped plain FASTA (%d contigs, %.2f GB) cut into %d byte ranges; index build "
+                    "(scan of the range + all-gather of the boundary summaries + stitch) + the SAME %d random %d bp intervals (50%% '-' strand) over the "
+                    "whole stream, routed to the rank that holds their first byte" % (world, a.gbp, len(plan["names"]), nb / 1e9, world, a.queries, qlen),
+        "Gbp_per_s": round(a.gbp / (el / a.steps), 3), "ms_per_step": round(ms, 4), "index_build_s": round(t_index / a.steps, 6),
+        "file_bytes": nb, "file_bytes_per_gpu": int(job.n_bytes), "queries_per_gpu_max": int(n_max), "queries_crossing_a_cut": n_cross,
+        "kernels_ms_avg": {k: round(v[0] / v[1], 4) for k, v in prof_all.items()},
+        "roofline": {"kernel": "fx::k_span_scan<0>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": int(job.n_bytes),
+                     "avg_launch_ms": round(scan_avg, 4)},
+        "e2e": {"open_range_s": round(t_open, 4), "open_GBps_aggregate": round(nb / max(t_open, 1e-9) / 1e9, 1), "build_s": round(t_build, 4),
+                "merged_fxi_s": round(t_fxi, 4), "fetch_1M_host_to_host_s": round(t_fetch, 4), "total_s": round(e2e_total, 4),
+                "note": "one pass per phase, max over ranks, barriers between phases: every rank stages only its byte range of the one file (page "
+                        "cache -> pinned -> HBM over its own PCIe link); build = scan + all-gather (%s) + stitch + totals; merged_fxi = gather of "
+                        "the rows + rank 0 writes ONE .fxi; fetch = the whole batch through fx_shard_route on every rank, its share through the "
+                        "fetch kernel and back to host memory, pieces of cut-crossing queries exchanged" % backend},
+        "parity": {"merged_fxi_rows_equal_plan": ok_rows, "every_query_answered_once_and_sample_equals_file": ok_bytes,
+                   "device_step_sample_equals_file": step_ok},
+    }
+
+
+def main_strong(a, dev, rank, world, backend, collective):
+    """--scaling strong: the strong leg IS the line."""
+    s = strong_leg(a, dev, rank, world, backend, collective)
+    if rank != 0:
+        return None
+    return {
+        "metric": "FASTA index build + 1M random 100bp subseq fetches on ONE 3 Gbp plain FASTA split by byte range over the GPUs (throughput of the whole step, stream resident in HBM)",
+        "value": s["Gbp_per_s"], "unit": "Gbp/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": s["ms_per_step"],
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": s["workload"], "file_bytes": s["file_bytes"], "file_bytes_per_gpu": s["file_bytes_per_gpu"],
+                   "parallelism": "byte-range shards of one file x%d (each rank reads only its range), 1 all-gather (%s)" % (world, backend)},
+        "index_build_s": s["index_build_s"], "parity_verified_full_size": all(v is not False for v in s["parity"].values()) and None not in s["parity"].values(),
+        "kernels_ms_avg": s["kernels_ms_avg"], "roofline": s["roofline"], "strong": s,
+    }
+
+
+def _self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (torch.distributed.run, one process per GPU)."""
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+
+
 # ------------------------------------------------------------------------------------------ main
 def main():
     a = parse()
@@ -699,41 +936,58 @@ def main():
     import torch.distributed as dist
     from pyfastx_amd import _lib, synth, shard
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(a)                                     # does not return: the N ranks run this file again under torch.distributed.run
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
-    backend = os.environ.get("FX_BENCH_BACKEND", "nccl")    # "nccl" IS RCCL on ROCm; "gloo" only for the 1-GPU plumbing test
-    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    ndev = max(torch.cuda.device_count(), 1)
+    # "nccl" IS RCCL on ROCm.  RCCL refuses two ranks on one device, so a box with fewer GPUs than ranks (the 1-GPU test box)
+    # runs the same code over gloo with the ranks sharing the devices -- a plumbing run, and the line says so.
+    backend = os.environ.get("FX_BENCH_BACKEND", "nccl" if ndev >= world else "gloo")
+    local = local % ndev if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # FX_BENCH_FORCE_SHARDED=1: the N > 1 code path with a process group of ONE rank (how the 1-GPU test box runs every
     # collective of that path over RCCL; needs MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE like any torch.distributed run)
-    if world > 1 or os.environ.get("FX_BENCH_FORCE_SHARDED"):
+    forced = bool(os.environ.get("FX_BENCH_FORCE_SHARDED"))
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-        line = main_sharded(a, dev, rank, world, backend)
+        if a.scaling == "strong":
+            line = main_strong(a, dev, rank, world, backend, True)
+        else:
+            line = main_sharded(a, dev, rank, world, backend)
+            if not os.environ.get("FX_BENCH_NO_STRONG"):
+                # the metric as BASELINE.json words it (ONE 3 Gbp file on N GPUs), beside the weak line: a 3 Gbp file whatever --gbp says
+                # for the weak pieces -- unless the run is a small one (tests), which keeps its size
+                b = argparse.Namespace(**vars(a))
+                b.gbp = 3.0 if a.gbp >= 3.0 else a.gbp
+                st_ = strong_leg(b, dev, rank, world, backend, True)
+                if rank == 0:
+                    line["strong"] = st_
         if rank == 0:
             print(json.dumps(line), flush=True)
         dist.destroy_process_group()
         return
+    if a.scaling == "strong":
+        print(json.dumps(main_strong(a, dev, 0, 1, "none", False)), flush=True)
+        return
 
     # ---------------- workload: the whole stream, resident in HBM
     total_bp = int(a.gbp * 1e9)
-    plan = synth.fasta_plan(total_bp=total_bp, seed=20260612 + rank, tag=("p%d_" % rank) if world > 1 else "")
+    plan = synth.fasta_plan(total_bp=total_bp, seed=20260612)      # (N > 1 never gets here: main_sharded / main_strong above)
     blob, flat, flat_start = synth.fasta_generate(plan, dev, keep_flat=not a.no_verify)
-    # world > 1: the first contig of every piece crosses a shard cut, so queries (answered from
-    # the local shard only -- no collective on the fetch path) use the other contigs
-    q = synth.fasta_queries(plan, n=a.queries, seed=12345 + rank, skip_first=world > 1)
+    q = synth.fasta_queries(plan, n=a.queries, seed=12345)
     ids, st, sp, strand = q
     qlen = int(sp[0] - st[0])
-    job = shard.ShardedFasta(blob, int(plan["n_bytes"]), dev, rank, world)     # moves the shard cut off the piece boundary
-    id_shift = 1 if (world > 1 and rank > 0) else 0       # local row index of piece contig i is i - id_shift
-    d_ids = torch.from_numpy(ids - id_shift).to(dev); d_st = torch.from_numpy(st).to(dev); d_sp = torch.from_numpy(sp).to(dev)
+    job = shard.ShardedFasta(blob, int(plan["n_bytes"]), dev, 0, 1)
+    d_ids = torch.from_numpy(ids).to(dev); d_st = torch.from_numpy(st).to(dev); d_sp = torch.from_numpy(sp).to(dev)
     d_fl = torch.from_numpy((strand * 6).astype(np.uint8)).to(dev)               # '-' = reverse|complement
     d_off = torch.arange(a.queries, device=dev, dtype=torch.int64) * qlen
     d_out = torch.zeros(a.queries * qlen, dtype=torch.uint8, device=dev)
@@ -741,7 +995,7 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        job.build_async()                                 # scan + tables (+ all-gather & stitch when world > 1), enqueued
+        job.build_async()                                 # scan + tables, enqueued
         job.fetch_local(a.queries, d_ids, d_st, d_sp, d_fl, d_out, d_off, d_len)      # reads the record count on the device
         job.finish()                                      # the step's one host synchronisation: totals of the build
         job.sync()
@@ -755,22 +1009,15 @@ def main():
         step()
     job.blob.prof_enable(2)                               # events around the dominant kernel only (k_span_scan)
     job.blob.prof_reset()
-    if world > 1:
-        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
     t1 = time.perf_counter()
     # the index build on its own (its own synchronisation), outside the timed region: the first half of the metric
     t_index = sum(build_only() for _ in range(a.steps))
-    elapsed = torch.tensor([t1 - t0, t_index], dtype=torch.float64, device=job.comm_dev)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    el, ti = float(elapsed[0]), float(elapsed[1])
+    el, ti = t1 - t0, t_index
     prof = job.blob.prof_read()
     # per-kernel table from a separate, untimed pass (timing every kernel costs ~20 events per step)
     job.blob.prof_enable(1)
@@ -784,8 +1031,7 @@ def main():
     verified = None
     if not a.no_verify:
         rows = job.local_rows()                           # records that START in this shard, as host arrays
-        nxt = synth.fasta_plan(total_bp=total_bp, seed=20260612 + rank + 1, tag="p%d_" % (rank + 1)) if rank < world - 1 else None
-        verified = bool(job.check_against_plan(plan, rows, nxt))
+        verified = bool(job.check_against_plan(plan, rows, None))
         exp = synth.expected_fetch(flat, flat_start, ids, st, qlen, strand, dev)
         verified = verified and bool((d_out.view(a.queries, qlen) == exp).all()) and bool((d_len == qlen).all())
         del exp
@@ -793,7 +1039,7 @@ def main():
             raise SystemExit("PARITY FAILURE at full size: refusing to report a speed-up")
     comp_ms = None
     full_index = None
-    if world == 1 and not a.no_verify:
+    if not a.no_verify:
         # per-record composition (fasta.c:901-950) at full size vs torch.bincount of the un-wrapped bases
         # (extra information, outside the timed region: full_index is lazy in the reference too)
         nrec = len(plan["slen"])
@@ -837,34 +1083,6 @@ def main():
                       "rows_equal": True}
         del d_comp2
 
-    if world > 1 and not a.no_verify:
-        # composition across the cuts (shard.ShardedFasta.composition: local counting + two small all-gathers):
-        # the contigs that lie wholly in this rank's piece row by row, and -- for the contig that crosses each cut,
-        # whose bases sit on two ranks -- the sum of all rows of all ranks against the sum of all bincounts
-        tc = time.perf_counter()
-        comp = job.composition()
-        comp_ms = (time.perf_counter() - tc) * 1e3
-        first = 1 if rank > 0 else 0
-        okc = True
-        for i in range(first, len(plan["slen"])):
-            L = int(plan["slen"][i])
-            seg = flat[int(flat_start[i]):int(flat_start[i]) + L]
-            okc &= bool((torch.bincount(seg.long(), minlength=128)[:128].cpu() == torch.from_numpy(comp[i - first])).all())
-        tot = torch.from_numpy(comp.sum(axis=0)).to(dev)
-        want = torch.zeros(128, dtype=torch.int64, device=dev)
-        for i in range(len(plan["slen"])):
-            L = int(plan["slen"][i])
-            want += torch.bincount(flat[int(flat_start[i]):int(flat_start[i]) + L].long(), minlength=128)[:128]
-        both = torch.stack([tot, want]).to(job.comm_dev)
-        dist.all_reduce(both, op=dist.ReduceOp.SUM)
-        okc &= bool((both[0] == both[1]).all())
-        if not okc:
-            raise SystemExit("PARITY FAILURE (composition across shards) at full size")
-
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
     ms = el / a.steps * 1e3
     shard_bytes = job.n_bytes
     fetch_ms = prof_all.get("k_fetch", (0.0, 1))[0] / max(prof_all.get("k_fetch", (0.0, 1))[1], 1)   # kernel time of one batch
@@ -879,7 +1097,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "configs[1]: synthetic %.1f Gbp hg38-shaped plain FASTA per GPU (200 contigs, 60-col LF, soft-masked, N runs), "
                                "index build + %d random %d bp intervals (50%% '-' strand)" % (a.gbp, a.queries, qlen),
-                   "file_bytes_per_gpu": int(plan["n_bytes"]), "parallelism": "byte-range shards x%d, 1 all-gather" % world},
+                   "file_bytes_per_gpu": int(plan["n_bytes"]), "parallelism": "one GPU, the whole stream resident in its HBM"},
         "index_build_s": round(ti / a.steps, 6),
         "fetch_M_per_s": round(world * a.queries / max(fetch_ms * 1e-3, 1e-9) / 1e6, 2),
         "parity_verified_full_size": verified,
@@ -895,7 +1113,7 @@ def main():
                            "avg_launch_ms": round(fetch_ms, 4),
                            "frac": round(fetch_alg / max(fetch_ms * 1e-3, 1e-9) / 1e9 / HBM_PEAK_GBS, 4)},
     }
-    if world == 1:
+    if True:
         # release the device-resident copies before the file legs (the same bytes go to a file first)
         host = None
         tmpdir = tempfile.mkdtemp(prefix="fxbench")
@@ -950,8 +1168,6 @@ def main():
         finally:
             shutil.rmtree(tmpdir, ignore_errors=True)
     print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

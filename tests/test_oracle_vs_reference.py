@@ -141,3 +141,46 @@ def test_fastq_rows_equal_the_reference(oracle, ref, tmp_path, seed):
         assert fq[i].seq.encode("latin-1") == raw[int(r["soff"]):int(r["soff"]) + int(r["rlen"])]
         assert fq[i].qual.encode("latin-1") == raw[int(r["qoff"]):int(r["qoff"]) + int(r["rlen"])]
     db.close()
+
+
+@pytest.mark.parametrize("members", [1, 3])
+def test_refshim_serves_reads_from_imported_points(ref, tmp_path, members):
+    """The zran work-alike under the compiled reference (oracle/refshim/zran.c; indexed_gzip is not part of the reference
+    tree): points built at deflate block boundaries, exported by the reference's own util.c:442-540, imported again by
+    util.c:542-726 on the next open, and every read served by a raw inflate from the last point at or before the offset
+    (bits primed, window as dictionary) -- the bytes equal the plain text, the counters say how the seeks were served."""
+    import ctypes
+    import gzip
+    so = ctypes.CDLL(ref.__file__)
+    so.fxshim_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    so.fxshim_point_hits.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32]
+    rng = np.random.default_rng(11 + members)
+    recs = [("c%d" % i, bytes(rng.choice(list(b"ACGTNacgt"), int(rng.integers(60_000, 300_000))).astype(np.uint8)).decode()) for i in range(24)]
+    text = "".join(">%s d\n%s\n" % (n, "\n".join(s[k:k + 60] for k in range(0, len(s), 60))) for n, s in recs).encode()
+    cut = [len(text) * k // members for k in range(members + 1)]
+    p = str(tmp_path / "s.fa.gz")
+    open(p, "wb").write(b"".join(gzip.compress(text[cut[k]:cut[k + 1]], 6) for k in range(members)))
+
+    def stats():
+        a = (ctypes.c_uint64 * 6)()
+        so.fxshim_stats(a)
+        return [int(x) for x in a]
+    so.fxshim_reset()
+    fa = ref.Fasta(p)                                          # scan + zran_build_index + export
+    built = stats()[4]
+    assert built >= 3 and stats()[5] == 0
+    del fa
+    so.fxshim_reset()
+    fa = ref.Fasta(p)                                          # load_index: import, nothing is built
+    assert stats()[4] == 0
+    for _ in range(600):
+        k = int(rng.integers(0, len(recs)))
+        n, s = recs[k]
+        a = int(rng.integers(0, len(s) - 1))
+        b = min(len(s), a + int(rng.integers(1, 300)))
+        assert fa[n][a:b].seq == s[a:b]
+    assert fa[recs[-1][0]].seq == recs[-1][1]
+    seeks, from_point, from_start, continued, built2, errors = stats()
+    hits = (ctypes.c_uint32 * built)()
+    so.fxshim_point_hits(hits, built)
+    assert errors == 0 and built2 == 0 and from_start == 0 and from_point >= 300 and sum(1 for x in hits if x) >= built - 1
