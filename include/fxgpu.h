@@ -428,6 +428,38 @@ int fx_shard_route(int64_t n, const int64_t *ids, const int64_t *starts, const i
                    int64_t *order, int64_t *shard_start, int64_t *off, int64_t *len, int64_t *skip, int64_t *take,
                    uint8_t *fl, int32_t *cnt);
 
+/* ------------------------------------------------- the collective under the C ABI
+ * pyfastx_create_index (index.c:109-388) and pyfastx_fastq_create_index (fastq.c:8-182) scan one file in one
+ * thread; the reference's only parallel story is "re-open per process" (docs/advance.rst:1-40).  Here a whole-file
+ * build shards by byte range over the GPUs of a node, ONE process per GPU, and the ONE exchange it needs -- the
+ * all-gather of the 28-word boundary summaries (RCCL over xGMI) -- lives in this library, so that a C caller
+ * (multi-GPU) needs no Python and no torch:
+ *
+ *     rank 0: fx_comm_unique_id(id);  ... id reaches every rank (file, pipe, MPI_Bcast, env) ...
+ *     all:    fx_comm_init(rank, world, id, device, &c);
+ *             fx_open_file_range(path, size * rank / world, size * (rank + 1) / world - size * rank / world, 0, device, &h);
+ *             fx_fasta_build_sharded(h, c, full_name, &summary);      rows of the records that START in this range,
+ *             fx_fasta_table(h, FX_HOST, ...);                        the one that crosses the cut completed
+ *
+ * RCCL is loaded at run time (dlopen librccl.so.1, or the copy the process already carries; FX_RCCL_LIB overrides):
+ * a single-GPU user never loads it; without it these entries return FX_EDEVICE.                               */
+typedef struct fx_comm fx_comm;
+int fx_comm_unique_id(uint8_t id[128]);                       /* ncclGetUniqueId: once, on one rank */
+int fx_comm_init(int rank, int world, const uint8_t id[128], int device, fx_comm **out);   /* ncclCommInitRank: all ranks */
+int fx_comm_destroy(fx_comm *c);
+int fx_comm_rank(const fx_comm *c);
+int fx_comm_world(const fx_comm *c);
+/* nbytes (<= 65536) of every rank to every rank, host buffers (recv: world x nbytes) */
+int fx_comm_allgather(fx_comm *c, const void *send, void *recv, int64_t nbytes);
+/* scan + tables + boundary summary + ncclAllGather + stitch, all enqueued on the handle's stream; _begin returns at
+ * once (device-side consumers may follow), fx_fasta_build_end reads the totals; full_name as in fx_fasta_build.    */
+int fx_fasta_build_sharded_begin(fx_handle *h, fx_comm *c, int full_name);
+int fx_fasta_build_sharded(fx_handle *h, fx_comm *c, int full_name, fx_fasta_summary *out);
+int fx_comm_summaries(fx_comm *c, fx_handle *h, fx_shard_summary *out);    /* world entries, as the all-gather delivered them */
+/* FASTQ: count pass, all-gather of (newlines of the core, last newline) per rank, rows with the global line numbering
+ * (fx_set_halo first: a record that begins in the core is finished from the halo) */
+int fx_fastq_build_sharded(fx_handle *h, fx_comm *c, fx_fastq_summary *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,8 @@ SYMBOLS = [
     "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_line_regular", "fx_fasta_len_stats", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
     "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
+    "fx_comm_unique_id", "fx_comm_init", "fx_comm_destroy", "fx_comm_rank", "fx_comm_world", "fx_comm_allgather", "fx_fasta_build_sharded_begin",
+    "fx_fasta_build_sharded", "fx_comm_summaries", "fx_fastq_build_sharded",
 ]
 
 
@@ -173,6 +175,16 @@ def lib():
     L.fx_prof_name.restype = C.c_char_p
     L.fx_prof_name.argtypes = [i32]
     L.fx_prof_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64)]
+    L.fx_comm_unique_id.argtypes = [vp]
+    L.fx_comm_init.argtypes = [i32, i32, vp, i32, C.POINTER(vp)]
+    L.fx_comm_destroy.argtypes = [vp]
+    L.fx_comm_rank.argtypes = [vp]
+    L.fx_comm_world.argtypes = [vp]
+    L.fx_comm_allgather.argtypes = [vp, vp, vp, i64]
+    L.fx_fasta_build_sharded_begin.argtypes = [vp, vp, i32]
+    L.fx_fasta_build_sharded.argtypes = [vp, vp, i32, vp]
+    L.fx_comm_summaries.argtypes = [vp, vp, vp]
+    L.fx_fastq_build_sharded.argtypes = [vp, vp, vp]
     for s in SYMBOLS:
         if getattr(L, s).restype is C.c_int:
             pass
@@ -212,6 +224,56 @@ def check(rc):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data
+
+
+class Comm:
+    """The library's own communicator (fx_comm: RCCL bound at run time) -- one per process, one process per GPU.
+    The 128-byte id comes from rank 0 (Comm.unique_id()) over whatever channel the launcher offers; share_id() uses the
+    torch.distributed process group when there is one."""
+
+    def __init__(self, rank, world, uid, device=0):
+        h = C.c_void_p()
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(uid))
+        check(lib().fx_comm_init(int(rank), int(world), buf, int(device), C.byref(h)))
+        self._c, self.rank, self.world, self.device = h, int(rank), int(world), int(device)
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * 128)()
+        check(lib().fx_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def from_process_group(cls, device):
+        """rank / world of torch.distributed's default group; the id travels over it (one broadcast at setup)."""
+        import torch.distributed as dist
+        box = [cls.unique_id() if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(dist.get_rank(), dist.get_world_size(), box[0], device)
+
+    def allgather(self, arr):
+        """A small host array of every rank to every rank -> [world, ...] (fx_comm_allgather)."""
+        a = np.ascontiguousarray(arr)
+        out = np.empty((self.world,) + a.shape, dtype=a.dtype)
+        check(lib().fx_comm_allgather(self._c, a.ctypes.data, out.ctypes.data, a.nbytes))
+        return out
+
+    def summaries(self, blob):
+        from .shard import Summary, NWORDS
+        out = np.zeros((self.world, NWORDS), dtype=np.int64)
+        check(lib().fx_comm_summaries(self._c, blob._h, out.ctypes.data))
+        return [Summary.from_array(r) for r in out]
+
+    def close(self):
+        if self._c:
+            lib().fx_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Blob:
@@ -391,6 +453,17 @@ class Blob:
         self._table_ready = True
         self._n_fasta = None
         check(lib().fx_fasta_build_begin(self._h, int(bool(full_name)) | (2 if comp else 0)))
+
+    def fasta_build_sharded_begin(self, comm, full_name=False, comp=False):
+        """fx_fasta_build_sharded_begin: scan + tables + summary + ncclAllGather + stitch, enqueued on the handle's stream."""
+        self._table_ready = True
+        self._n_fasta = None
+        check(lib().fx_fasta_build_sharded_begin(self._h, comm._c, int(bool(full_name)) | (2 if comp else 0)))
+
+    def fastq_build_sharded(self, comm):
+        s = FastqSummary()
+        check(lib().fx_fastq_build_sharded(self._h, comm._c, C.byref(s)))
+        return s
 
     def fasta_build_end(self):
         s = FastaSummary()

@@ -2464,3 +2464,162 @@ extern "C" int fx_fxi_bulk_index_int(const char *path, int rootpage, int64_t n, 
     if (rc) return fail(FX_EINVAL, "%s is not a SQLite database this loader can extend", path);
     return FX_OK;
 }
+
+// ------------------------------------------------------------------ the collective under the C ABI
+// One process per GPU; the sharded build needs ONE all-gather of 28 words per rank.  RCCL is bound at run time
+// (dlopen: a single-GPU user never loads it, and a process that already carries an RCCL -- torch's -- shares that one
+// instead of getting a second copy of the library), through the function types of <rccl/rccl.h>.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string why;
+    bool ok() const { return lib != nullptr; }
+};
+Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *env = getenv("FX_RCCL_LIB");
+        const char *names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void *lib = nullptr;
+        for (const char *n : {"librccl.so.1", "librccl.so"})           // already in the process (torch)?
+            if (!lib && !env) lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        for (const char *n : names)
+            if (!lib && n) lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) { const char *e = dlerror(); r.why = e ? e : "librccl.so.1 not found"; return; }
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(lib, "ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(lib, "ncclCommDestroy");
+        r.AllGather = (decltype(r.AllGather))dlsym(lib, "ncclAllGather");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString) { r.why = "RCCL symbols missing"; return; }
+        r.lib = lib;
+    });
+    return r;
+}
+}  // namespace
+
+struct fx_comm {
+    int rank = 0, world = 1, device = 0;
+    ncclComm_t comm = nullptr;
+    int64_t *d_send = nullptr, *d_recv = nullptr;          // 28 words; world x 28 words
+    uint8_t *d_buf = nullptr;                              // staging of fx_comm_allgather: (world + 1) x COMM_SLOT bytes
+    hipStream_t stream = nullptr;                          // for collectives that belong to no handle
+};
+static const int64_t COMM_SLOT = 64 << 10;
+#define RCCLCHK(expr)                                                                                          \
+    do {                                                                                                       \
+        ncclResult_t r__ = (expr);                                                                             \
+        if (r__ != ncclSuccess) return fail(FX_EDEVICE, "%s: %s", #expr, rccl().GetErrorString(r__));          \
+    } while (0)
+
+extern "C" int fx_comm_unique_id(uint8_t id[128]) {
+    if (!id) return fail(FX_EINVAL, "null argument");
+    if (!rccl().ok()) return fail(FX_EDEVICE, "RCCL is not available: %s", rccl().why.c_str());
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId u;
+    RCCLCHK(rccl().GetUniqueId(&u));
+    memcpy(id, &u, 128);
+    return FX_OK;
+}
+
+extern "C" int fx_comm_destroy(fx_comm *c) {
+    if (!c) return FX_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    if (c->comm) (void)rccl().CommDestroy(c->comm);
+    if (c->d_send) (void)hipFree(c->d_send);
+    if (c->d_recv) (void)hipFree(c->d_recv);
+    if (c->d_buf) (void)hipFree(c->d_buf);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return FX_OK;
+}
+
+extern "C" int fx_comm_init(int rank, int world, const uint8_t id[128], int device, fx_comm **out) {
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) return fail(FX_EINVAL, "bad argument");
+    if (!rccl().ok()) return fail(FX_EDEVICE, "RCCL is not available: %s", rccl().why.c_str());
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(FX_EDEVICE, "device %d out of range (have %d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    fx_comm *c = new fx_comm();
+    c->rank = rank; c->world = world; c->device = device;
+    ncclUniqueId u;
+    memcpy(&u, id, 128);
+    ncclResult_t r = rccl().CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) { c->comm = nullptr; fx_comm_destroy(c); return fail(FX_EDEVICE, "ncclCommInitRank: %s", rccl().GetErrorString(r)); }
+    hipError_t e = hipMalloc((void **)&c->d_send, sizeof(fx_shard_summary));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_recv, sizeof(fx_shard_summary) * (size_t)world);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_buf, (size_t)COMM_SLOT * (size_t)(world + 1));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { fx_comm_destroy(c); return fail(FX_ENOMEM, "fx_comm_init: %s", hipGetErrorString(e)); }
+    *out = c;
+    return FX_OK;
+}
+
+extern "C" int fx_comm_rank(const fx_comm *c) { return c ? c->rank : -1; }
+extern "C" int fx_comm_world(const fx_comm *c) { return c ? c->world : 0; }
+
+// nbytes (<= 64 KiB) of every rank to every rank, host buffers: the small exchanges around the build that have no kernel of
+// their own (FASTQ: newline count and last newline of every shard's core; composition: the 128 counts of a shard's lead).
+extern "C" int fx_comm_allgather(fx_comm *c, const void *send, void *recv, int64_t nbytes) {
+    if (!c || !send || !recv || nbytes <= 0 || nbytes > COMM_SLOT) return fail(FX_EINVAL, "bad argument (at most %lld bytes per rank)", (long long)COMM_SLOT);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->d_buf, send, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    RCCLCHK(rccl().AllGather(c->d_buf, c->d_buf + COMM_SLOT, (size_t)nbytes, ncclInt8, c->comm, c->stream));
+    HIPCHK(hipMemcpyAsync(recv, c->d_buf + COMM_SLOT, (size_t)nbytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return FX_OK;
+}
+
+// pyfastx_create_index (index.c:109-388) for ONE rank's byte range of the stream: everything enqueued on the handle's
+// stream -- scan + tables (fx_fasta_build_begin), this shard's boundary summary into the send buffer, THE all-gather
+// (ncclAllGather, RCCL over xGMI: 28 x int64 per rank), completion of the record that crosses the cut (k_stitch_tail).
+// fx_fasta_build_end (or fx_fasta_build_sharded) reads the totals.  Device-side consumers may follow at once.
+extern "C" int fx_fasta_build_sharded_begin(fx_handle *h, fx_comm *c, int full_name) {
+    if (!h || !c) return fail(FX_EINVAL, "null argument");
+    if (h->device != c->device) return fail(FX_EINVAL, "handle on device %d, communicator on device %d", h->device, c->device);
+    int rc = fx_fasta_build_begin(h, full_name);
+    if (rc) return rc;
+    if ((rc = fx_shard_summary_dev(h, c->d_send))) return rc;
+    RCCLCHK(rccl().AllGather(c->d_send, c->d_recv, sizeof(fx_shard_summary) / 8, ncclInt64, c->comm, h->stream));
+    return fx_fasta_stitch_dev(h, c->d_recv, c->world, c->rank, full_name & 1);
+}
+
+extern "C" int fx_fasta_build_sharded(fx_handle *h, fx_comm *c, int full_name, fx_fasta_summary *out) {
+    int rc = fx_fasta_build_sharded_begin(h, c, full_name);
+    if (rc) return rc;
+    return fx_fasta_build_end(h, out);
+}
+
+// every rank's summary as the all-gather delivered it (host copy; world x 28 words), e.g. for a caller that merges tables
+extern "C" int fx_comm_summaries(fx_comm *c, fx_handle *h, fx_shard_summary *out) {
+    if (!c || !h || !out) return fail(FX_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(out, c->d_recv, sizeof(fx_shard_summary) * (size_t)c->world, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FX_OK;
+}
+
+// pyfastx_fastq_create_index (fastq.c:8-182) for one rank's byte range (fx_set_shard + fx_set_halo done): count pass, ONE
+// all-gather of two integers per rank (newlines of the core, offset of the last one), then the rows with the global
+// line numbering.
+extern "C" int fx_fastq_build_sharded(fx_handle *h, fx_comm *c, fx_fastq_summary *out) {
+    if (!h || !c) return fail(FX_EINVAL, "null argument");
+    int64_t mine[2] = {0, -1};
+    int rc = fx_fastq_scan(h, &mine[0], &mine[1]);
+    if (rc) return rc;
+    std::vector<int64_t> all((size_t)c->world * 2);
+    if ((rc = fx_comm_allgather(c, mine, all.data(), sizeof mine))) return rc;
+    int64_t loff = 0, prev = -1;
+    for (int r = 0; r < c->rank; ++r) { loff += all[(size_t)r * 2]; if (all[(size_t)r * 2] > 0) prev = all[(size_t)r * 2 + 1]; }
+    return fx_fastq_build_ctx(h, loff, prev, out);
+}

@@ -263,6 +263,22 @@ class ShardedFasta:
         self.n_local = 0
         self._ext = self._mine = self._all = None
         self.force_collective = getattr(self, "force_collective", False)
+        self.fxcomm = None
+
+    def _collective(self):
+        return self.world > 1 or self.force_collective
+
+    def _use_fxcomm(self):
+        """On GPUs the all-gather of the build is the LIBRARY's (fx_comm: ncclAllGather on the handle's own stream, the
+        whole build one call, fx_fasta_build_sharded_begin) -- the same entry a C caller uses; torch's
+        process group only carries the communicator's id at setup.  FX_COMM=torch keeps the all-gather in
+        torch.distributed (all_gather_into_tensor on torch's stream, ordered against the handle's with stream events)."""
+        if not self._collective() or self.comm_dev.type != "cuda" or os.environ.get("FX_COMM", "fx") == "torch":
+            return False
+        if self.fxcomm is None:
+            from . import _lib
+            self.fxcomm = _lib.Comm.from_process_group(self.dev.index)
+        return True
 
     @classmethod
     def from_file(cls, path, dev, rank, world, full_name=False, force_collective=False):
@@ -316,6 +332,8 @@ class ShardedFasta:
         round trip; finish() is the one synchronisation.  (gloo, i.e. the CPU tests: the host path, synchronous.)"""
         if (self.world > 1 or self.force_collective) and self.comm_dev.type != "cuda":
             return self.build()
+        if self._use_fxcomm():
+            return self.blob.fasta_build_sharded_begin(self.fxcomm, self.full_name)       # the ONE collective, under the C ABI
         self.build_begin()
         if self.world > 1 or self.force_collective:
             cur = self._torch.cuda.current_stream(self.dev)

@@ -90,8 +90,11 @@ def test_bench_over_rccl_two_gpus():
     assert all(v is True for v in line["strong"]["parity"].values())
 
 
-def test_nccl_collective_path_on_one_gpu(tmp_path):
-    """the `nccl` (= RCCL) branch of the sharded build -- fx_shard_summary_dev into the send buffer,
+@pytest.mark.parametrize("flavour", ["fx", "torch"])
+def test_nccl_collective_path_on_one_gpu(tmp_path, flavour):
+    """flavour fx: the all-gather is the library's own (fx_comm_init + fx_fasta_build_sharded_begin: ncclAllGather on the
+    handle's stream, the entry a C caller uses); torch: all_gather_into_tensor of the process group.
+    VERDICT r1 #5: the `nccl` (= RCCL) branch of the sharded build -- fx_shard_summary_dev into the send buffer,
     all_gather_into_tensor on torch's stream ordered against the library's stream with ExternalStream events,
     fx_fasta_stitch_dev (k_stitch_tail) -- executed on an MI355X with a process group of ONE rank (force_collective):
     the rows must equal the plain single-handle build of the same file, fetches enqueued behind it included."""
@@ -130,17 +133,64 @@ assert s.n_seq == rs.n_seq == len(plan["slen"])
 for k in want:
     assert (rows[k] == want[k]).all(), k
 assert (job.blob.fasta_line_regular(s.n_seq) == ref.fasta_line_regular(rs.n_seq)).all()
-gathered = job._all.cpu().numpy()
+if %r == "fx":
+    assert job.fxcomm is not None and job._all is None     # the library's communicator did the all-gather
+    gathered = job.fxcomm.summaries(job.blob)[0].to_array()
+else:
+    assert job.fxcomm is None
+    gathered = job._all.cpu().numpy()
 mine = job.blob.shard_summary().to_array()
 assert (gathered == mine).all()                            # what the all-gather delivered is this shard's summary
 exp = synth.expected_fetch(flat, fs, ids, st, 100, strand, dev)
 assert bool((d_out.view(50000, 100) == exp).all()) and bool((d_len == 100).all())
 dist.destroy_process_group()
 print("NCCL_PATH_OK")
-''' % (ROOT, _free_port(), str(tmp_path / "one.fa")))
+''' % (ROOT, _free_port(), str(tmp_path / "one.fa"), flavour))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FX_COMM=flavour))
+    assert out.returncode == 0 and "NCCL_PATH_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+
+
+def test_fx_comm_without_torch(tmp_path):
+    """The collective under the C ABI with NOTHING but the library in the process (no torch, no process group): RCCL is
+    loaded by fx_comm_unique_id, a communicator of one rank builds a FASTA and a FASTQ shard through
+    fx_fasta_build_sharded / fx_fastq_build_sharded, fx_comm_allgather moves a host array -- rows equal the plain build."""
+    script = tmp_path / "comm_one.py"
+    script.write_text('''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from pyfastx_amd import _lib
+assert "torch" not in sys.modules
+raw = open(os.path.join(%r, "tests", "data", "test.fa"), "rb").read()
+rawq = open(os.path.join(%r, "tests", "data", "test.fq"), "rb").read()
+c = _lib.Comm(0, 1, _lib.Comm.unique_id(), 0)
+assert "torch" not in sys.modules
+b = _lib.Blob.from_bytes(raw)
+b.set_shard(0, 10, True)
+b.fasta_build_sharded_begin(c)
+s = b.fasta_build_end()
+ref = _lib.Blob.from_bytes(raw); rs = ref.fasta_build()
+assert s.n_seq == rs.n_seq == 211
+t, w = b.fasta_table(211), ref.fasta_table(211)
+assert all((t[k] == w[k]).all() for k in w)
+S = c.summaries(b)
+assert len(S) == 1 and S[0].n_hdr == 211 and S[0].to_array().tolist() == b.shard_summary().to_array().tolist()
+q = _lib.Blob.from_bytes(rawq)
+q.set_shard(0, 10, True)
+sq = q.fastq_build_sharded(c)
+rq = _lib.Blob.from_bytes(rawq); rsq = rq.fastq_build()
+assert (sq.n_reads, sq.size) == (rsq.n_reads, rsq.size) == (800, 120000)
+tq, wq = q.fastq_table(800), rq.fastq_table(800)
+assert all((tq[k] == wq[k]).all() for k in wq)
+got = c.allgather(np.arange(7, dtype=np.int64) * 3)
+assert got.shape == (1, 7) and got[0].tolist() == [0, 3, 6, 9, 12, 15, 18]
+c.close()
+print("FX_COMM_OK")
+''' % (ROOT, ROOT, ROOT))
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
-    assert out.returncode == 0 and "NCCL_PATH_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+    assert out.returncode == 0 and "FX_COMM_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
 
 
 def test_bench_single_small():
