@@ -105,10 +105,11 @@ def lib():
         raise ImportError(
             "pyfastx_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C pyfastx_amd/csrc`.  There is no CPU fallback." % _SO)
-    try:
-        import torch  # noqa: F401  (loads torch's bundled libamdhip64 first; ours then binds to the same runtime)
-    except Exception:
-        pass
+    if not os.environ.get("FX_NO_TORCH"):                  # FX_NO_TORCH=1: the library alone, on the system's ROCm (no torch in the process)
+        try:
+            import torch  # noqa: F401  (loads torch's bundled libamdhip64 first; ours then binds to the same runtime)
+        except Exception:
+            pass
     L = C.CDLL(_SO, mode=C.RTLD_GLOBAL)
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
     L.fx_last_error.restype = C.c_char_p

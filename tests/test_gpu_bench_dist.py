@@ -189,7 +189,7 @@ c.close()
 print("FX_COMM_OK")
 ''' % (ROOT, ROOT, ROOT))
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FX_NO_TORCH="1"))
     assert out.returncode == 0 and "FX_COMM_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
 
 
