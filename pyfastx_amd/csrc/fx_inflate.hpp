@@ -360,11 +360,12 @@ __global__ __launch_bounds__(INFL_BLOCK) void k_bgzf_decode(const uint8_t *__res
                                                            const int64_t *__restrict__ uoff,
                                                            const int32_t *__restrict__ isize, int64_t nmem,
                                                            uint8_t *__restrict__ data, int32_t *__restrict__ status,
-                                                           uint64_t *__restrict__ match_map, uint16_t *__restrict__ gsym) {
+                                                           uint64_t *__restrict__ match_map, uint16_t *__restrict__ gsym, int only_status) {
     __shared__ uint16_t t_llut[(1 << LBITS) * INFL_BLOCK], t_dlut[(1 << DBITS) * INFL_BLOCK], t_pool[POOL * INFL_BLOCK];
     const int lane = threadIdx.x;
     const int64_t m = (int64_t)blockIdx.x * INFL_BLOCK + lane;
     if (m >= nmem) return;
+    if (only_status >= 0 && status[m] < only_status) return;          // behind k_bgzf_decode_par: only the members it handed over
     uint16_t *gs = gsym + m * GSYM;                          // 288 + 32 symbols, 16 + 16 counts
     Huff lc{t_llut + lane, t_pool + lane, gs, gs + 320, LBITS}, dc{t_dlut + lane, t_pool + lane, gs + FIXLCODES, gs + 336, DBITS};
     int pool_used = 0;

@@ -31,6 +31,7 @@
 #include "fx_scancomp.hpp"
 #include "fx_names.hpp"
 #include "fx_inflate.hpp"
+#include "fx_inflate_par.hpp"
 #include "fx_fxi.hpp"
 #include "fx_sort.hpp"
 
@@ -183,10 +184,10 @@ static void crc_tables(CrcTables *T) {
 }
 
 enum KernelId { K_SPAN_SCAN = 0, K_GRAN_REDUCE, K_GRAN_PREFIX, K_HDR_REC, K_GRAN_LINES, K_GRAN_EXACT, K_FASTA_FINALIZE, K_FETCH,
-                K_FASTA_COMP, K_FASTA_COMP_EDGE, K_FASTA_COMP_SMALL, K_FASTQ_LINES, K_FASTQ_ROWS, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_BGZF_CRC, K_SCAN_COMP, K_COMP_ATTRIBUTE, K_NKERN };
+                K_FASTA_COMP, K_FASTA_COMP_EDGE, K_FASTA_COMP_SMALL, K_FASTQ_LINES, K_FASTQ_ROWS, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_BGZF_CRC, K_SCAN_COMP, K_COMP_ATTRIBUTE, K_BGZF_SERIAL, K_NKERN };
 static const char *const kKernelNames[K_NKERN] = {
     "k_span_scan", "k_gran_reduce", "k_gran_prefix", "k_hdr_rec", "k_gran_lines", "k_gran_exact", "k_fasta_finalize", "k_fetch",
-    "k_fasta_comp", "k_fasta_comp_edge", "k_fasta_comp_small", "k_fastq_lines", "k_fastq_rows", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy", "k_bgzf_crc", "k_scan_comp", "k_comp_attribute"};
+    "k_fasta_comp", "k_fasta_comp_edge", "k_fasta_comp_small", "k_fastq_lines", "k_fastq_rows", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy", "k_bgzf_crc", "k_scan_comp", "k_comp_attribute", "k_bgzf_decode_serial"};
 
 struct Prof {
     bool on = false;
@@ -639,8 +640,52 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
     HIPCHK(hipMemsetAsync(d_map.p, 0, (size_t)nmem * BM_WORDS * 8, h->stream));
     if ((rc = alloc_blob(h, t.total))) return rc;
     lap("allocations");
-    FX_LAUNCH(h, K_BGZF_INFLATE, k_bgzf_decode, dim3(nblocks(nmem, INFL_BLOCK)), dim3(INFL_BLOCK), d_c.p, d_coff.p,
-              d_clen.p, d_uoff.p, d_isize.p, nmem, h->d_data, d_status.p, d_map.p, d_gsym.p);
+    // one wave per member, the lanes at 64 bit positions of it (fx_inflate_par.hpp); members it hands over (status INFL_RETRY:
+    // anything out of the ordinary, damaged members included) are decoded by one lane each, as in round 2.  FX_BGZF_SERIAL=1: only that.
+    static const bool serial_only = [] { const char *e = getenv("FX_BGZF_SERIAL"); return e && atoi(e) != 0; }();
+    static const int dbg_par = [] { const char *e = getenv("FX_BGZF_DBG"); return e ? atoi(e) : 0; }();
+    // LDS of a wave: the tables + the member's payload (sized for the largest member of the file, at most 64 KiB of the 160 per CU)
+    int32_t clen_max = 0;
+    for (int32_t c : t.clen) clen_max = std::max(clen_max, c);
+    const int lds_payload = (int)std::min<int64_t>(((int64_t)clen_max + 16 + 255) & ~255ll, 65536);
+    static const bool stage = [] { const char *e = getenv("FX_BGZF_STAGE"); return e && atoi(e) != 0; }();   // the payload through LDS (experiment)
+    const size_t par_lds = ((sizeof(PTab) + 15) & ~(size_t)15) + (stage ? (size_t)lds_payload : 0);
+    const auto par_kernel = stage ? k_bgzf_decode_par<true> : k_bgzf_decode_par<false>;
+    static bool par_attr = false;
+    if (!par_attr) {
+        (void)hipFuncSetAttribute((const void *)k_bgzf_decode_par<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        par_attr = true;
+    }
+    if (!serial_only) {
+        h->prof.begin(K_BGZF_INFLATE, h->stream);
+        hipLaunchKernelGGL(par_kernel, dim3((unsigned)nmem), dim3(64), par_lds, h->stream, d_c.p, d_coff.p, d_clen.p, d_uoff.p, d_isize.p, nmem,
+                           h->d_data, d_status.p, d_map.p, dbg_par, lds_payload);
+        h->prof.end(h->stream);
+        if (trace) {                                         // how many members the wave-per-member kernel handed over, and why
+            std::vector<int32_t> stv((size_t)nmem);
+            HIPCHK(hipMemcpyAsync(stv.data(), d_status.p, (size_t)nmem * 4, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            int64_t hist[64] = {0};
+            for (int32_t v : stv) if (v >= INFL_RETRY) hist[std::min(v - INFL_RETRY, 63)]++;
+            for (int i = 0; i < 64; ++i) if (hist[i]) fprintf(stderr, "[fxgpu] bgzf handed over: reason %d x %lld\n", i, (long long)hist[i]);
+        }
+    }
+    if (dbg_par && !serial_only) {                          // timing probe of the kernel's phases: wrong answers, so nothing after it runs
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipEventRecord(e0, h->stream);
+        hipLaunchKernelGGL(par_kernel, dim3((unsigned)nmem), dim3(64), par_lds, h->stream, d_c.p, d_coff.p, d_clen.p, d_uoff.p, d_isize.p, nmem,
+                           h->d_data, d_status.p, d_map.p, dbg_par, lds_payload);
+        (void)hipEventRecord(e1, h->stream);
+        (void)hipStreamSynchronize(h->stream);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        fprintf(stderr, "[fxgpu] k_bgzf_decode_par dbg=%d: %.3f ms for %lld members\n", dbg_par, ms, (long long)nmem);
+        return fail(FX_EIO, "FX_BGZF_DBG is a timing probe");
+    }
+    FX_LAUNCH(h, K_BGZF_SERIAL, k_bgzf_decode, dim3(nblocks(nmem, INFL_BLOCK)), dim3(INFL_BLOCK), d_c.p, d_coff.p,
+              d_clen.p, d_uoff.p, d_isize.p, nmem, h->d_data, d_status.p, d_map.p, d_gsym.p, serial_only ? -1 : (int)INFL_RETRY);
     FX_LAUNCH(h, K_BGZF_COPY, k_bgzf_copy, dim3(nblocks(nmem, COPY_BLOCK / 64)), dim3(COPY_BLOCK), d_uoff.p, d_isize.p, nmem, h->d_data, d_map.p);
     static const bool no_crc = [] { const char *e = getenv("FX_BGZF_NO_CRC"); return e && atoi(e) != 0; }();
     DevBuf<CrcTables> d_crc;
