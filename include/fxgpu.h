@@ -307,6 +307,12 @@ int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mode);
 int fx_gz_points(fx_handle *h, int64_t spacing, int64_t *cmp_off, int64_t *uncmp_off, int64_t cap,
                  int64_t *n_out, int64_t *compressed_size);
 
+/* How the members of a BGZF file were inflated by the open that made this handle: out = {members, members the
+ * wave-per-member decoder handed over to the serial one, INFL_RETRY + reason of the first of those} (fx_inflate_par.hpp:
+ * the lanes of a wave start at 64 bit positions of a member and fall into step by Huffman self-synchronisation; anything
+ * out of the ordinary, damaged members included, is decoded by one lane).  Diagnostics; replaces nothing in the reference. */
+int fx_bgzf_counts(fx_handle *h, int64_t out[3]);
+
 /* Single-stream gzip (not BGZF): the restart points zran would build (pyfastx_build_gzip_index, util.c:728-742; spacing
  * 1 MiB, window 32 KiB, index.c:70) are captured while fx_open_file inflates the stream on the host -- at deflate block
  * boundaries at least 1 MiB of output apart: offset of the next compressed byte, number of bits of the byte before it

@@ -51,7 +51,7 @@ SYMBOLS = [
     "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
     "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
     "fx_comm_unique_id", "fx_comm_init", "fx_comm_destroy", "fx_comm_rank", "fx_comm_world", "fx_comm_allgather", "fx_fasta_build_sharded_begin",
-    "fx_fasta_build_sharded", "fx_comm_summaries", "fx_fastq_build_sharded",
+    "fx_fasta_build_sharded", "fx_comm_summaries", "fx_fastq_build_sharded", "fx_bgzf_counts",
 ]
 
 
@@ -186,6 +186,7 @@ def lib():
     L.fx_fasta_build_sharded.argtypes = [vp, vp, i32, vp]
     L.fx_comm_summaries.argtypes = [vp, vp, vp]
     L.fx_fastq_build_sharded.argtypes = [vp, vp, vp]
+    L.fx_bgzf_counts.argtypes = [vp, vp]
     for s in SYMBOLS:
         if getattr(L, s).restype is C.c_int:
             pass
@@ -371,6 +372,12 @@ class Blob:
         if n.value:
             check(lib().fx_gz_points(self._h, spacing, a.ctypes.data, b.ctypes.data, n.value, C.byref(n), C.byref(cs)))
         return a, b, cs.value
+
+    def bgzf_counts(self):
+        """(members, members handed over to the serial decoder, reason of the first) of the open that made this blob."""
+        a = (C.c_int64 * 3)()
+        check(lib().fx_bgzf_counts(self._h, a))
+        return int(a[0]), int(a[1]), int(a[2])
 
     def gz_checkpoints(self):
         """Restart points captured while a single gzip stream was inflated (fx_gz_checkpoints) -> dict cmp, uncmp (int64),

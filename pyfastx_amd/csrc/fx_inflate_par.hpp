@@ -303,7 +303,8 @@ template <bool STAGE>
 __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restrict__ cbuf, const int64_t *__restrict__ cdata_off,
                                                          const int32_t *__restrict__ cdata_len, const int64_t *__restrict__ uoff,
                                                          const int32_t *__restrict__ isize, int64_t nmem, uint8_t *__restrict__ data,
-                                                         int32_t *__restrict__ status, uint64_t *__restrict__ match_map, int dbg, int lds_payload) {
+                                                         int32_t *__restrict__ status, uint64_t *__restrict__ match_map, int dbg, int lds_payload,
+                                                         int32_t *__restrict__ par_status) {
     extern __shared__ __attribute__((aligned(16))) uint8_t p_smem[];
     PTab &T = *reinterpret_cast<PTab *>(p_smem);
     const int lane = threadIdx.x;
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
         uint8_t *const sb = p_smem + ((sizeof(PTab) + 15) & ~(size_t)15);
         if ((int)(pend >> 3) + 16 > lds_payload) {           // larger than the launch provided for
             for (int i = lane; i < BM_WORDS; i += 64) match_map[m * BM_WORDS + i] = 0ull;
-            if (lane == 0) status[m] = INFL_RETRY + 9;
+            if (lane == 0) { status[m] = INFL_RETRY + 9; par_status[m] = INFL_RETRY + 9; }
             return;
         }
         for (uint32_t i = (uint32_t)lane * 16u; i < (pend >> 3) + 16u; i += 1024u)
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
         for (int i = lane; i < BM_WORDS; i += 64) bm[i] = 0ull;
         if (st < INFL_RETRY) st = INFL_RETRY + 16 + st;
     }
-    if (lane == 0) status[m] = st;
+    if (lane == 0) { status[m] = st; par_status[m] = st; }              // par_status: what THIS kernel made of the member (the serial one overwrites status)
 }
 
 }  // namespace fx

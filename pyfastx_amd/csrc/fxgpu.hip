@@ -293,6 +293,8 @@ struct fx_handle {
     std::vector<int64_t> gz_moff, gz_coff, gz_uoff;          // member start, start of its deflate data (behind the header), offset of its bytes in the inflated stream
     int64_t gz_csize = 0;
     bool bgzf = false;
+    int64_t bgzf_members = 0, bgzf_handed_over = 0;    // members inflated by this open; of them, decoded by the serial kernel
+    int bgzf_reason = 0;                               // INFL_RETRY + reason of the first member handed over (fx_inflate_par.hpp)
     // restart points of a single gzip stream (captured while it is inflated: GzSerial below)
     std::vector<int64_t> gzp_cin, gzp_cout;
     std::vector<uint8_t> gzp_bits, gzp_has, gzp_win;          // gzp_win: GZ_WINDOW bytes per point that has data, in order
@@ -620,7 +622,7 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
     }
     const int64_t fsize = c1 - c0;
     DevBuf<int64_t> d_coff, d_uoff;
-    DevBuf<int32_t> d_clen, d_isize, d_status;
+    DevBuf<int32_t> d_clen, d_isize, d_status, d_pstatus;
     if ((rc = d_c.alloc(h->device, fsize + 48, h->stream))) return rc;          // the bit reader looks three 8-byte words ahead
     HIPCHK(hipMemsetAsync(d_c.p + fsize, 0, 48, h->stream));
     lap("alloc compressed");
@@ -633,10 +635,11 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
     // where the matches of a member begin: one bit per output byte (k_bgzf_decode sets them, k_bgzf_copy walks them)
     ScratchBuf<uint64_t> d_map;
     if ((rc = d_map.alloc(h->device, nmem * BM_WORDS, h->stream))) return rc;
-    if ((rc = d_status.alloc(nmem))) return rc;
+    if ((rc = d_status.alloc(nmem)) || (rc = d_pstatus.alloc(nmem))) return rc;
     ScratchBuf<uint16_t> d_gsym;                             // canonical symbol order of every member's tables (slow path of the decoder)
     if ((rc = d_gsym.alloc(h->device, nmem * GSYM, h->stream))) return rc;
     HIPCHK(hipMemsetAsync(d_status.p, 0xFF, (size_t)nmem * 4, h->stream));
+    HIPCHK(hipMemsetAsync(d_pstatus.p, 0, (size_t)nmem * 4, h->stream));
     HIPCHK(hipMemsetAsync(d_map.p, 0, (size_t)nmem * BM_WORDS * 8, h->stream));
     if ((rc = alloc_blob(h, t.total))) return rc;
     lap("allocations");
@@ -659,7 +662,7 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
     if (!serial_only) {
         h->prof.begin(K_BGZF_INFLATE, h->stream);
         hipLaunchKernelGGL(par_kernel, dim3((unsigned)nmem), dim3(64), par_lds, h->stream, d_c.p, d_coff.p, d_clen.p, d_uoff.p, d_isize.p, nmem,
-                           h->d_data, d_status.p, d_map.p, dbg_par, lds_payload);
+                           h->d_data, d_status.p, d_map.p, dbg_par, lds_payload, d_pstatus.p);
         h->prof.end(h->stream);
         if (trace) {                                         // how many members the wave-per-member kernel handed over, and why
             std::vector<int32_t> stv((size_t)nmem);
@@ -676,7 +679,7 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
         (void)hipStreamSynchronize(h->stream);
         (void)hipEventRecord(e0, h->stream);
         hipLaunchKernelGGL(par_kernel, dim3((unsigned)nmem), dim3(64), par_lds, h->stream, d_c.p, d_coff.p, d_clen.p, d_uoff.p, d_isize.p, nmem,
-                           h->d_data, d_status.p, d_map.p, dbg_par, lds_payload);
+                           h->d_data, d_status.p, d_map.p, dbg_par, lds_payload, d_pstatus.p);
         (void)hipEventRecord(e1, h->stream);
         (void)hipStreamSynchronize(h->stream);
         float ms = 0.f;
@@ -697,9 +700,13 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
                   nmem, d_crc.p, d_status.p);
     }
     HIPCHK(hipGetLastError());
-    std::vector<int32_t> status((size_t)nmem);
+    std::vector<int32_t> status((size_t)nmem), pstatus((size_t)nmem);
     HIPCHK(hipMemcpyAsync(status.data(), d_status.p, (size_t)nmem * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(pstatus.data(), d_pstatus.p, (size_t)nmem * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->bgzf_members = nmem; h->bgzf_handed_over = 0; h->bgzf_reason = 0;
+    for (int64_t m = 0; m < nmem; ++m)
+        if (serial_only || pstatus[(size_t)m] >= INFL_RETRY) { if (!h->bgzf_handed_over++) h->bgzf_reason = pstatus[(size_t)m]; }
     lap("kernels done");
     for (int64_t m = 0; m < nmem; ++m)
         if (status[m] != INFL_OK)
@@ -2354,6 +2361,12 @@ extern "C" int fx_gz_points(fx_handle *h, int64_t spacing, int64_t *cmp_off, int
         }
     }
     *n_out = n;
+    return FX_OK;
+}
+
+extern "C" int fx_bgzf_counts(fx_handle *h, int64_t out[3]) {
+    if (!h || !out) return fail(FX_EINVAL, "null argument");
+    out[0] = h->bgzf_members; out[1] = h->bgzf_handed_over; out[2] = h->bgzf_reason;
     return FX_OK;
 }
 

@@ -48,6 +48,55 @@ def test_inflate_matches_zlib(L, tmp_path, level, block):
         assert zlib.decompressobj(-15).decompress(bg[co:co + 70_000], 64) == raw[uo:uo + 64]
 
 
+def _genome_like(rng, n):
+    """Soft-masked four-letter text in 60-column lines with runs of N: what a FASTA member looks like to a compressor."""
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.choice(4, n, p=[.295, .205, .205, .295])]
+    low = np.repeat(rng.random(n // 5000 + 1) < 0.4, 5000)[:n]
+    letters = np.where(low, letters + 32, letters).astype(np.uint8)
+    for _ in range(max(1, n // 400_000)):
+        a = int(rng.integers(0, n - 1))
+        letters[a:a + int(rng.integers(1000, 120_000))] = ord("N")
+    rows = letters[:n - n % 60].reshape(-1, 60)
+    return b"\n".join(r.tobytes() for r in rows) + b"\n"
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_members_are_decoded_by_the_wave_kernel(L, tmp_path, level):
+    """k_bgzf_decode_par (one wave per member, the lanes at 64 bit positions of a block, hand-over by Huffman
+    self-synchronisation) decodes ordinary members ITSELF -- genome text at three compression levels (level 1: two or three
+    deflate blocks per member; N runs: members of a few hundred symbols that use a handful of lanes), FASTQ, protein --
+    and hands nothing to the serial kernel; the bytes equal the input and every member passes its CRC-32."""
+    from pyfastx_amd import synth
+    rng = np.random.default_rng(level)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    raw = b"".join([_genome_like(rng, 3_000_000), fixture_bytes("test.fq") * 3, b">p\n" + aa[rng.integers(0, 20, 700_000)].tobytes() + b"\n"])
+    bg = synth.bgzf_compress(raw, level=level)
+    p = _write(tmp_path, "w.gz", bg)
+    b = L.Blob.from_file(p)
+    assert b.size == len(raw) and b.read_bytes(0, len(raw)) == raw
+    members, handed, reason = b.bgzf_counts()
+    assert members == (len(raw) + 65279) // 65280 + 1 and handed == 0, (members, handed, reason)
+
+
+def test_damaged_and_odd_members_go_to_the_serial_kernel(L, tmp_path):
+    """What the wave kernel does not take on -- here: a payload that ends in the middle of a block -- is handed over, and the
+    serial kernel names the error."""
+    from pyfastx_amd import synth
+    raw = _genome_like(np.random.default_rng(5), 400_000)
+    bg = bytearray(synth.bgzf_compress(raw))
+    good = bytes(bg)
+    # cut 40 bytes out of the second member's deflate data and fix its BSIZE: the stream ends early
+    import struct as st
+    m0 = st.unpack("<H", good[16:18])[0] + 1
+    m1 = st.unpack("<H", good[m0 + 16:m0 + 18])[0] + 1
+    bad = good[:m0 + 16] + st.pack("<H", m1 - 40 - 1) + good[m0 + 18:m0 + m1 - 48] + good[m0 + m1 - 8:]
+    p = _write(tmp_path, "bad.gz", bad)
+    with pytest.raises(L.FxError):
+        L.Blob.from_file(p)
+    b = L.Blob.from_file(_write(tmp_path, "good.gz", good))
+    assert b.read_bytes(0, len(raw)) == raw and b.bgzf_counts()[1] == 0
+
+
 def test_fixed_huffman_and_stored_members(L, tmp_path):
     import zlib
     raws = [b"hello hello hello hello\n", bytes(range(256)) * 3, b""]
