@@ -14,6 +14,7 @@ import os
 import numpy as np
 
 from . import _lib, fxi
+from . import _fxobj          # C base types of Fasta / Sequence: the per-object getter path (csrc/fxobj.c)
 
 VERSION = "2.3.1"          # API level mirrored (reference src/version.h:1)
 
@@ -73,6 +74,7 @@ class _Staged:
     def __init__(self, path, device):
         self.path, self.device, self._blob = path, device, None
         self.gzindex = None          # callable -> restart points of the index file (fxi.read_gzindex), set by the owner
+        self.on_stage = None         # callable(blob): the owner learns the handle of the staged stream (the getters' fast path)
 
     @property
     def blob(self):
@@ -90,6 +92,8 @@ class _Staged:
                 self._blob = _lib.Blob.from_file(self.path, self.device, gzindex=pts)
             except _lib.FxError as e:
                 raise _fx_to_py(e)
+            if self.on_stage is not None:
+                self.on_stage(self._blob)
         return self._blob
 
     def write_gzindex(self, db):
@@ -163,8 +167,9 @@ def _bulk_index(path, blob, kind, n, name_off, name_len, write):
         return None
 
 
-class Fasta:
-    """pyfastx.Fasta (fasta.c:39-135, 1156-1210)."""
+class Fasta(_fxobj.FastaCore):
+    """pyfastx.Fasta (fasta.c:39-135, 1156-1210).  fa[name] for a name met before is answered by the C base type
+    (csrc/fxobj.c); every other subscript comes through _getitem_slow."""
 
     def __init__(self, file_name, index_file=None, uppercase=False, build_index=True, full_index=False,
                  full_name=False, memory_index=False, key_func=None, device=0, devices=None):
@@ -187,6 +192,16 @@ class Fasta:
             self._st = _ShardedStaged(file_name, devices, bool(full_name))
         else:
             self._st = _Staged(file_name, devices[0] if devices else device)
+            import weakref
+            me = weakref.ref(self)
+
+            def staged(blob, me=me):                           # the C getters talk to the resident kernel through this handle
+                fa = me()
+                if fa is not None:
+                    _bind_fxobj()
+                    fa._core_handle = int(blob._h.value or 0)
+            self._st.on_stage = staged
+        self._core_upper = 1 if uppercase else 0
         self._index_file = ":memory:" if memory_index else (index_file or file_name + ".fxi")   # index.c:45-61
         self._db = None
         self._full_index = False
@@ -315,10 +330,10 @@ class Fasta:
         return "<Fasta> %s" % self.file_name
 
     def _make(self, row):
-        return Sequence(self, *row)
+        return Sequence(self, *row[:9])
 
-    def __getitem__(self, item):
-        """pyfastx_fasta_subscript (fasta.c:521-546)."""
+    def _getitem_slow(self, item):
+        """pyfastx_fasta_subscript (fasta.c:521-546); names whose row is cached never get here (FastaCore.__getitem__)."""
         self._need_index()
         if isinstance(item, (int, np.integer)) and not isinstance(item, bool):
             i = int(item)
@@ -331,7 +346,7 @@ class Fasta:
                 raise IndexError("Index Error")
             return self._make(row)
         if type(item) is str:
-            cache = self.__dict__.setdefault("_rows_by_name", {})     # the B-tree probe (index.c:527-566) once per name: a genome has few
+            cache = self._rows_by_name                                # the B-tree probe (index.c:527-566) once per name: a genome has few
             row = cache.get(item)
             if row is None:
                 row = self._db.execute("SELECT * FROM seq WHERE chrom=? LIMIT 1", (item,)).fetchone()
@@ -874,8 +889,10 @@ class FastqKeys:
         return self._owner._db.execute("SELECT 1 FROM read WHERE name=? LIMIT 1", (name,)).fetchone() is not None
 
 
-class Sequence:
-    """pyfastx.Sequence (sequence.c:755-807).  start/end are 1-based inclusive."""
+class Sequence(_fxobj.SeqCore):
+    """pyfastx.Sequence (sequence.c:755-807).  start/end are 1-based inclusive.  The fields, slicing and the four sequence
+    getters live in the C base type (csrc/fxobj.c): a slice of a line-regular record goes from there straight to the
+    resident kernel; everything else lands in _get / _subscript_slow below."""
 
     def __init__(self, fasta, sid, name, boff, blen, slen, llen, elen, norm, dlen, start=1, end=None, complete=True):
         self._fa = fasta
@@ -952,22 +969,6 @@ class Sequence:
         return self._name if self._complete else "%s:%d-%d" % (self._name, self.start, self.end)    # sequence.c:291-297
 
     @property
-    def seq(self):
-        return self._get()
-
-    @property
-    def reverse(self):
-        return self._get(_F_REV)
-
-    @property
-    def complement(self):
-        return self._get(_F_COMP)
-
-    @property
-    def antisense(self):
-        return self._get(_F_REV | _F_COMP)
-
-    @property
     def description(self):
         return _text(self._fa._st.raw(self._offset - self._desc_len - self._end_len, self._desc_len))   # sequence.c:299-313
 
@@ -1038,25 +1039,30 @@ class Sequence:
             if ln:
                 yield _decode(ln)
 
-    def __getitem__(self, item):
-        """pyfastx_sequence_subscript (sequence.c:412-517) from ABSOLUTE coordinates (the
-        reference's nested slicing is cache-history dependent)."""
-        if isinstance(item, slice):
-            a, b, step = item.indices(self._seq_len)
-            if step != 1:
-                raise ValueError("slice step cannot > 1")
-            if b < a:
-                b = a
-            sub = Sequence(self._fa, self.id, self._name, self._offset, self._byte_len, self._full_len, self._line_len,
-                           self._end_len, self._normal, self._desc_len, start=self.start + a, end=self.start + b - 1,
-                           complete=self._complete and (b - a) == self._seq_len)
-            return sub
+    def _subscript_slow(self, item):
+        """pyfastx_sequence_subscript (sequence.c:412-517) for an integer (slices: SeqCore.__getitem__, from ABSOLUTE
+        coordinates -- the reference's nested slicing is cache-history dependent)."""
         i = int(item)
         if i < 0:
             i += self._seq_len
         if i < 0 or i >= self._seq_len:
             raise IndexError("index out of range")
         return _decode(self._fetch_many([self.start - 1 + i], [self.start + i])[0])
+
+
+_FXOBJ_BOUND = False
+
+
+def _bind_fxobj():
+    """Give the C types the address of fx_fetch_one (once the library is loaded: the first staged stream)."""
+    global _FXOBJ_BOUND
+    if not _FXOBJ_BOUND:
+        import ctypes
+        _fxobj.set_api(ctypes.cast(_lib.lib().fx_fetch_one, ctypes.c_void_p).value, Sequence)
+        _FXOBJ_BOUND = True
+
+
+_fxobj.set_api(0, Sequence)          # the types first; the entry point follows with the first staged stream
 
 
 # =========================================================================== FASTQ

@@ -808,8 +808,8 @@ static int gzip_indexed_to_blob(fx_handle *h, const uint8_t *in, int64_t nin, in
     int rc = alloc_blob(h, usize);
     if (rc) return rc;
     if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(FX_EDEVICE, "stream sync failed");
-    // (each thread holds two pinned pieces: 32 threads = 512 MiB pinned while the open runs, PinPool keeps 256 MiB of them)
-    const int T = (int)std::min<int64_t>(std::max(8u, std::min(32u, std::thread::hardware_concurrency() / 4)), npts);
+    // (each thread holds two pinned pieces: 64 threads = 1 GiB pinned while the open runs; PinPool keeps 256 MiB of them afterwards)
+    const int T = (int)std::min<int64_t>(std::max(8u, std::min(64u, std::thread::hardware_concurrency() / 2)), npts);
     // What the serial path gets from zlib's gzip wrapper has to be checked by hand here (raw inflate, -15): the CRC-32 of
     // every segment's output (folded in order with crc32_combine) against the trailer, ISIZE, and that the deflate stream
     // ENDS where the last segment does.  A file with several gzip members: the members after the first are inflated with

@@ -202,12 +202,13 @@ def test_reference_opens_our_gz_fxi(oracle, tmp_path):
         db = fxi.connect(p + ".fxi")
         fxi.write_fasta(db, names, {k: recs[k] for k in ("boff", "blen", "slen", "llen", "elen", "norm", "dlen")}, tot)
         if pts:
-            # member starts as restart points, as fx_gz_points reports them
+            # the first deflate byte of every fourth member as restart points (bits 0, no window), as fx_gz_points reports
+            # them: the reference's zran (here: the work-alike of oracle/refshim) starts a raw inflate there
             offs, uoffs, q, u = [], [], 0, 0
             while q < len(payload):
                 bsize = payload[q + 16] | (payload[q + 17] << 8)
                 isz = int.from_bytes(payload[q + bsize - 3:q + bsize + 1], "little")
-                offs.append(q); uoffs.append(u)
+                offs.append(q + 18); uoffs.append(u)
                 q += bsize + 1; u += isz
             fxi.write_gzindex(db, len(payload), len(raw), offs[::4], uoffs[::4])
         db.close()

@@ -51,6 +51,10 @@ def main():
     out["blob_fetch_one_us"] = rate(lambda j: b.fetch_one(rows[j][0], rows[j][1], 100), N)
     L = _lib.lib()
     out["ctypes_trivial_call_us"] = rate(lambda j: L.fx_size(b._h), N)
+    # the floor under ANY single getter: fx_fetch_one called from C in a loop (request line -> resident kernel -> answer
+    # through pinned memory: the PCIe round trips and the gather, no interpreter, no object)
+    from pyfastx_amd import _fxobj
+    out["fetch_one_from_C_floor_us"] = _fxobj.bench_fetch_one(int(b._h.value), rows[0][0], rows[0][1], 100, N)
     out["getters_per_s"] = round(1e6 / out["full_getter_us"])
     try:
         sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
