@@ -55,7 +55,7 @@ struct FastqAcc {            // device accumulators
     unsigned long long a, c, g, t, n;
     long long maxlen, minlen;
     int minqs, maxqs;
-    int qfix, pad1;          // qfix: rows whose qlen k_fastq_comp rewrote (a '\r' inside a quality line, fastq.c:733-737)
+    int qfix, pad1;          // qfix: waves of k_fastq_comp that met a '\r' inside a quality line (fastq.c:733-737: k_fastq_qual_walk then redoes that half)
 };
 
 constexpr int FQ_POSCAP = 512;           // newline positions per wave per round (more only for lines < 8 bytes on average)
@@ -657,35 +657,15 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp(const uint8_t *__restrict_
         if (left < 16) fq_keep_first(x, (int)left, 0x0D0D0D0Du);
         seq_count(x);
     };
-    // fastq.c:733-737 byte by byte into (mn_, mx_); true when the piece holds a '\r'.  The table's qlen leaves out a '\r'
-    // in front of the newline, so a '\r' met here sits INSIDE the line, and the reference's loop then shrinks line.l as it
-    // goes -- the last bytes of the line are never looked at and meta.minlen / maxlen see the shrunken length.  Such a row
-    // is walked whole by one lane (qual_walk) and nothing else of it is counted.
-    auto qual_exact = [&](const uint4 &v, int keep, int &mn_, int &mx_) -> bool {
+    bool saw_cr = false;                                   // a '\r' INSIDE a quality line (the table's qlen leaves a trailing one out)
+    auto qual_exact = [&](const uint4 &v, int keep) {      // fastq.c:733-737, byte by byte
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        bool cr = false;
         for (int j = 0; j < keep; ++j) {
             const int q = (int)(signed char)(w[j >> 2] >> ((j & 3) * 8));
-            if (q == 13) { cr = true; continue; }
-            mn_ = q < mn_ ? q : mn_; mx_ = q > mx_ ? q : mx_;
-        }
-        return cr;
-    };
-    // the reference's loop over one quality line as it stands in the stream (from qoff to the newline): line.l shrinks by one
-    // at every '\r' met, bytes at or past the bound are not examined; what is left of line.l becomes the row's qlen (with
-    // it the straight path counts exactly the examined bytes the next time, and k_fastq_qlen_range the reference's lengths)
-    auto qual_walk = [&](int64_t i) {
-        const int64_t q0 = t.qoff[i] - gbase;
-        int64_t l = 0;
-        while (q0 + l < n_bytes && data[q0 + l] != 10) ++l;
-        for (int64_t k = 0; k < l; ++k) {
-            const int q = (int)(signed char)data[q0 + k];
-            if (q == 13) { --l; continue; }
+            if (q == 13) { saw_cr = true; continue; }
             qmin = q < qmin ? q : qmin; qmax = q > qmax ? q : qmax;
         }
-        if (t.qlen[i] != (int32_t)l) { t.qlen[i] = (int32_t)l; atomicAdd(&acc->qfix, 1); }
     };
-    const unsigned long long gmask = (lpr >= 64 ? ~0ull : ((1ull << lpr) - 1ull)) << (live ? grp * lpr : 0);
     // even / odd bytes of the four words, zero-extended to 16 bits (one v_perm each), into packed minima and maxima
     auto qual_minmax = [&](const uint32_t (&lo)[4], const uint32_t (&hi)[4], uint32_t &mn, uint32_t &mx) {
 #pragma unroll
@@ -694,15 +674,15 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp(const uint8_t *__restrict_
             mx = pk_max_u16(mx, pk_max_u16(__builtin_amdgcn_perm(0u, hi[k], 0x0C020C00u), __builtin_amdgcn_perm(0u, hi[k], 0x0C030C01u)));
         }
     };
-    auto qual_piece = [&](const uint4 &v, int64_t left, int &mn_, int &mx_) -> bool {  // general path; true: a '\r' inside the line
+    auto qual_piece = [&](const uint4 &v, int64_t left) {  // general path
         uint32_t lo[4] = {v.x, v.y, v.z, v.w}, hi[4] = {v.x, v.y, v.z, v.w};
         const int keep = left < 16 ? (int)left : 16;
         if (keep < 16) { fq_keep_first(lo, keep, 0xFFFFFFFFu); fq_keep_first(hi, keep, 0u); }
         uint32_t mn = 0x00FF00FFu, mx = 0u;
         qual_minmax(lo, hi, mn, mx);
         const int cmin = (int)min(mn & 0xFFFFu, mn >> 16), cmax = (int)max(mx & 0xFFFFu, mx >> 16);
-        if (cmin >= 33 && cmax < 128) { mn_ = cmin < mn_ ? cmin : mn_; mx_ = cmax > mx_ ? cmax : mx_; return false; }
-        return qual_exact(v, keep, mn_, mx_);              // '\r' or bytes outside the printable range
+        if (cmin >= 33 && cmax < 128) { qmin = cmin < qmin ? cmin : qmin; qmax = cmax > qmax ? cmax : qmax; }
+        else qual_exact(v, keep);                          // '\r' (skipped) or bytes outside the printable range
     };
 
     // A wave takes FQ_RPW = ngrp * FQ_U consecutive records per iteration (FQ_U per group of lpr lanes) and runs three
@@ -792,18 +772,10 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp(const uint8_t *__restrict_
                 qual_minmax(q, q, mn, mx);
             }
             const int cmin = (int)min(mn & 0xFFFFu, mn >> 16), cmax = (int)max(mx & 0xFFFFu, mx >> 16);
-            const bool odd = !(cmin >= 33 && cmax < 128);  // a '\r', or bytes the reference reads as negative chars
-            if (__builtin_expect(__ballot(odd) == 0ull, 1)) { qmin = cmin < qmin ? cmin : qmin; qmax = cmax > qmax ? cmax : qmax; }
-            else {                                         // somewhere in the wave: every row decides with its whole group
-#pragma unroll 1
-                for (int u = 0; u < FQ_U; ++u) {
-                    int lmn = 0x7FFFFFFF, lmx = -0x7FFFFFFF - 1;
-                    const bool cr = qual_exact(vq[u], 16, lmn, lmx) && live;
-                    const unsigned long long b = __ballot(cr) & gmask;
-                    if (!live) continue;                   // (idle lanes hold copies of group 0's pieces)
-                    if (b) { if (sub == 0) { const int64_t i = ic + u; qual_walk(i < last_row ? i : last_row); } }
-                    else { qmin = lmn < qmin ? lmn : qmin; qmax = lmx > qmax ? lmx : qmax; }
-                }
+            if (cmin >= 33 && cmax < 128) { qmin = cmin < qmin ? cmin : qmin; qmax = cmax > qmax ? cmax : qmax; }
+            else {
+#pragma unroll
+                for (int u = 0; u < FQ_U; ++u) qual_exact(vq[u], 16);
             }
         } else {
             // the general path: the rows again, then piece by piece
@@ -816,11 +788,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp(const uint8_t *__restrict_
                 }
                 if (live && i < n_rows) {
                     const int64_t q_ = t.qoff[i] - gbase, e = q_ + t.qlen[i];
-                    int lmn = 0x7FFFFFFF, lmx = -0x7FFFFFFF - 1;
-                    bool cr = false;
-                    for (int64_t p = q_ + sub * 16; p < e; p += step) cr |= qual_piece(fq_load16(data, p, n_bytes), e - p, lmn, lmx);
-                    if (__ballot(cr) & gmask) { if (sub == 0) qual_walk(i); }
-                    else { qmin = lmn < qmin ? lmn : qmin; qmax = lmx > qmax ? lmx : qmax; }
+                    for (int64_t p = q_ + sub * 16; p < e; p += step) qual_piece(fq_load16(data, p, n_bytes), e - p);
                 }
             }
         }
@@ -849,6 +817,38 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp(const uint8_t *__restrict_
         if (tn) atomicAdd(&acc->n, (unsigned long long)tn);
         atomicMin(&acc->minqs, qmin); atomicMax(&acc->maxqs, qmax);
     }
+    // With a '\r' inside a quality line the reference's loop shrinks line.l as it goes (fastq.c:733-737): the last bytes of
+    // the line are never looked at and meta.minlen / maxlen see the shrunken length.  That does not belong in this loop
+    // (it costs registers and a wave-wide test per iteration for something no real file has): the kernel only says that it
+    // met one, and the host then lets k_fastq_qual_walk redo the quality half exactly.
+    if (__ballot(saw_cr) && lane == 0) atomicAdd(&acc->qfix, 1);
+}
+
+// The quality half of the composition for a file with a '\r' inside some quality line, exactly as the reference's loop
+// runs (fastq.c:733-745): one lane per read walks its quality line as it stands in the stream, from qoff to the newline --
+// line.l shrinks by one at every '\r' met, bytes at or past the bound are not examined -- and leaves what is left of line.l
+// in the row's qlen (k_fastq_qlen_range then gives the reference's minlen / maxlen).  Slow (byte loads, one lane per line)
+// and only ever launched for such files; acc->minqs / maxqs reset by the host before.
+__global__ __launch_bounds__(BLOCK) void k_fastq_qual_walk(const uint8_t *__restrict__ data, int64_t gbase, int64_t n_bytes, FqTab t,
+                                                          int64_t n_rows, FastqAcc *acc) {
+    int qmin = 104, qmax = 33;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * BLOCK) {
+        const int64_t q0 = t.qoff[i] - gbase;
+        int64_t l = 0;
+        while (q0 + l < n_bytes && data[q0 + l] != 10) ++l;
+        for (int64_t k = 0; k < l; ++k) {
+            const int q = (int)(signed char)data[q0 + k];
+            if (q == 13) { --l; continue; }
+            qmin = q < qmin ? q : qmin; qmax = q > qmax ? q : qmax;
+        }
+        t.qlen[i] = (int32_t)l;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const int a = __shfl_xor(qmin, d, 64), b = __shfl_xor(qmax, d, 64);
+        qmin = a < qmin ? a : qmin; qmax = b > qmax ? b : qmax;
+    }
+    if (lane_id() == 0) { atomicMin(&acc->minqs, qmin); atomicMax(&acc->maxqs, qmax); }
 }
 
 }  // namespace fx

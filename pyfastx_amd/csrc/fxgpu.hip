@@ -1731,18 +1731,26 @@ extern "C" int fx_fastq_comp(fx_handle *h, int64_t base[5], int64_t meta[5]) {
     FastqAcc acc;
     HIPCHK(hipMemcpyAsync(&acc, h->fq_acc.p, sizeof acc, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (acc.qfix) {
+        // a '\r' INSIDE a quality line somewhere (fastq.c:733-737 then shrinks line.l as it goes): the quality half once more,
+        // line by line exactly as the reference's loop runs, the rows' qlen rewritten, meta.maxlen / minlen from them
+        FastqAcc again = acc;
+        again.minqs = 104; again.maxqs = 33; again.maxlen = 0; again.minlen = 10000000000LL; again.qfix = 0;
+        HIPCHK(hipMemcpyAsync(h->fq_acc.p, &again, sizeof again, hipMemcpyHostToDevice, h->stream));
+        const unsigned g = (unsigned)std::min<int64_t>(nblocks(h->n_reads, BLOCK), 4096);
+        hipLaunchKernelGGL(k_fastq_qual_walk, dim3(g), dim3(BLOCK), 0, h->stream, h->d_data, h->base, h->n, t, h->n_reads, h->fq_acc.p);
+        hipLaunchKernelGGL(k_fastq_qlen_range, dim3((unsigned)std::min<int64_t>(nblocks(h->n_reads, BLOCK), 1024)), dim3(BLOCK), 0, h->stream, t, h->n_reads, h->fq_acc.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&again, h->fq_acc.p, sizeof again, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        acc.minqs = again.minqs; acc.maxqs = again.maxqs;
+        if (h->n_reads > 0) { h->fq_maxlen = again.maxlen; h->fq_minlen = again.minlen; }
+    }
     // reset the counters so a second call does not double count
     FastqAcc keep = acc;
     keep.a = keep.c = keep.g = keep.t = keep.n = 0; keep.minqs = 104; keep.maxqs = 33; keep.qfix = 0;
-    if (acc.qfix) { keep.maxlen = 0; keep.minlen = 10000000000LL; }        // rows with a '\r' inside the quality line got the reference's line.l:
+    keep.maxlen = h->fq_maxlen; keep.minlen = h->fq_minlen;
     HIPCHK(hipMemcpyAsync(h->fq_acc.p, &keep, sizeof keep, hipMemcpyHostToDevice, h->stream));
-    if (acc.qfix) {                                                        // ... meta.maxlen / minlen over the table once more (fastq.c:747-751)
-        hipLaunchKernelGGL(k_fastq_qlen_range, dim3((unsigned)std::min<int64_t>(nblocks(h->n_reads, BLOCK), 1024)), dim3(BLOCK), 0, h->stream, t, h->n_reads, h->fq_acc.p);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&keep, h->fq_acc.p, sizeof keep, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        h->fq_maxlen = keep.maxlen; h->fq_minlen = keep.minlen;
-    }
     HIPCHK(hipStreamSynchronize(h->stream));
     base[0] = (int64_t)acc.a; base[1] = (int64_t)acc.c; base[2] = (int64_t)acc.g; base[3] = (int64_t)acc.t; base[4] = (int64_t)acc.n;
     int phred = 0;
