@@ -270,6 +270,10 @@ int fx_names_sort(fx_handle *h, int kind, int where, int64_t *order, int64_t *n_
  * that is already in HBM: dst[name_off[i] .. name_off[i+1]) = name of record i, name_off: n + 1 host words, *total =
  * name_off[n].  FX_ERANGE when total > cap (only *total is valid then; n * longest name is a safe cap).  Host buffers. */
 int fx_names_pack(fx_handle *h, int kind, uint8_t *dst, int64_t cap, int64_t *name_off, int64_t *total);
+/* The same order for names that come from SEVERAL handles (the shards of one file): packed host buffer, n + 1 offsets;
+ * order[i] = 0-based index of the i-th smallest name, *n_dup = adjacent equal pairs.  For the index b-tree of a merged
+ * .fxi (fx_fxi_bulk_index) without CREATE UNIQUE INDEX's sort (index.c:363, fastq.c:155). */
+int fx_sort_packed_names(int device, const uint8_t *names, const int64_t *name_off, int64_t n, int64_t *order, int64_t *n_dup);
 
 /* ------------------------------------------------------------ statistics
  * Fasta.count(n), nl(p), longest, shortest, mean, median (fasta.c:573-849) ask SQLite to scan or sort the seq table, one
@@ -382,7 +386,7 @@ typedef struct {
     int64_t n_hdr;             /* FASTA header lines that START in the shard                        */
     int64_t first_hdr, last_hdr;
     int64_t lead_nl;           /* newlines before first_hdr (all of them if n_hdr == 0)             */
-    int64_t lead_ws;           /* first ' ' or '\t' in [base, min(first_nl, base+65536)), -1 if none */
+    int64_t lead_ws;           /* first ' ' or '\t' in [base, first_nl) (the whole shard if it has no newline), -1 if none */
     int64_t lead_v1, lead_c1;  /* lead lines with both newlines in the shard: the first two ...     */
     int64_t lead_v2, lead_c2;  /* ... distinct (len+1) values and how many lines have them          */
     /* the last record that starts in this shard, as far as the shard can tell */
@@ -404,8 +408,7 @@ int fx_shard_summary_get(fx_handle *h, fx_shard_summary *out);
  * fx_fasta_stitch_dev ENQUEUES the completion of this rank's last record from the gathered summaries
  * d_all[world][28] (device) -- the integer logic of index.c:234-353 across shard cuts -- and rewrites
  * that row of the resident table.  Both run on the handle's stream: order them against the collective's
- * stream with fx_stream() (an opaque hipStream_t) and stream events.  A header line whose name does not
- * end within 64 KiB of a cut is reported by the next fx_fasta_table (FX_ERANGE).                      */
+ * stream with fx_stream() (an opaque hipStream_t) and stream events.                                    */
 int fx_shard_summary_dev(fx_handle *h, int64_t *d_out);
 int fx_fasta_stitch_dev(fx_handle *h, const int64_t *d_all, int world, int rank, int full_name);
 void *fx_stream(fx_handle *h);

@@ -51,7 +51,7 @@ SYMBOLS = [
     "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
     "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
     "fx_comm_unique_id", "fx_comm_init", "fx_comm_destroy", "fx_comm_rank", "fx_comm_world", "fx_comm_allgather", "fx_fasta_build_sharded_begin",
-    "fx_fasta_build_sharded", "fx_comm_summaries", "fx_fastq_build_sharded", "fx_bgzf_counts",
+    "fx_fasta_build_sharded", "fx_comm_summaries", "fx_fastq_build_sharded", "fx_bgzf_counts", "fx_sort_packed_names",
 ]
 
 
@@ -187,11 +187,23 @@ def lib():
     L.fx_comm_summaries.argtypes = [vp, vp, vp]
     L.fx_fastq_build_sharded.argtypes = [vp, vp, vp]
     L.fx_bgzf_counts.argtypes = [vp, vp]
+    L.fx_sort_packed_names.argtypes = [i32, vp, vp, i64, vp, C.POINTER(i64)]
     for s in SYMBOLS:
         if getattr(L, s).restype is C.c_int:
             pass
     _LIB = L
     return L
+
+
+def sort_packed_names(packed, name_off, device=0):
+    """fx_sort_packed_names: BINARY-collation order of names from several handles -> (order int64[n], duplicates)."""
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    name_off = np.ascontiguousarray(name_off, dtype=np.int64)
+    n = name_off.size - 1
+    order = np.empty(max(n, 0), dtype=np.int64)
+    nd = C.c_int64(0)
+    check(lib().fx_sort_packed_names(int(device), _ptr(packed) if packed.size else None, _ptr(name_off), n, _ptr(order) if n > 0 else None, C.byref(nd)))
+    return order, int(nd.value)
 
 
 def stream_size(path):

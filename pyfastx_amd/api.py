@@ -175,8 +175,7 @@ class Fasta(_fxobj.FastaCore):
                  full_name=False, memory_index=False, key_func=None, device=0, devices=None):
         """devices: several GPUs for ONE file (extension): the stream is cut into len(devices) byte ranges,
         each device stages and scans only its own, the boundary summaries stitch the records that cross the cuts and ONE
-        index file is written; batched fetches are answered by the device that holds the bytes.  Plain and BGZF files.
-        One limit: a header line that crosses a cut must end its NAME within 64 KiB of the cut (ValueError otherwise)."""
+        index file is written; batched fetches are answered by the device that holds the bytes.  Plain and BGZF files."""
         if key_func is not None and not callable(key_func):
             raise TypeError("key_func must be a callable function")                       # fasta.c:71-74
         if not os.path.isfile(file_name):

@@ -927,10 +927,13 @@ __global__ __launch_bounds__(SUMM_BLOCK) void k_shard_summary2(ScanCtx x, int is
     const int64_t first_nl = next_nl(x, x.gbase - 1);
     const int64_t first_hdr = n_hdr ? hdr[0] : -1;
     // whitespace in the bytes before the first newline (a header line cut by the shard boundary)
-    int64_t lim = first_nl >= 0 ? first_nl - x.gbase : x.n;
-    if (lim > 65536) lim = 65536;
-    for (int64_t j = tid; j < lim; j += SUMM_BLOCK)
+    // (all of them, however long the line: a name that ends a megabyte behind the cut is found like any other; a thread stops
+    // once somebody has found white space in front of it)
+    const int64_t lim = first_nl >= 0 ? first_nl - x.gbase : x.n;
+    for (int64_t j = tid; j < lim; j += SUMM_BLOCK) {
+        if ((j & (64 * SUMM_BLOCK - 1)) < SUMM_BLOCK && *(volatile unsigned long long *)&ws < (unsigned long long)j) break;
         if (x.data[j] == ' ' || x.data[j] == '\t') { atomicMin(&ws, (unsigned long long)j); break; }
+    }
     // lead: whole granules before the first header's granule, four independent loads per thread per step
     const int64_t g_first = n_hdr ? (first_hdr - x.gbase) / GRAN : x.ngran;
     DiffSet ds;
@@ -1077,7 +1080,6 @@ __global__ void k_stitch_tail(const int64_t *__restrict__ S, int world, int r, i
                 dlen = (e - h) - elen;                    // index.c:271
                 if (full_name) name_len = dlen;
                 else if (name_len < 0) {
-                    if (u[SS_FIRSTNL] - u[SS_BASE] > 65536 && ws < 0) *err = 1;   // name end further than 64 KiB past the cut
                     name_len = (ws >= 0 && ws < e) ? ws - (h + 1) : dlen;
                 }
                 if (name_len > dlen) name_len = dlen;

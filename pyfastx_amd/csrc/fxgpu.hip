@@ -2317,6 +2317,41 @@ extern "C" int fx_names_sort(fx_handle *h, int kind, int where, int64_t *order, 
     return FX_OK;
 }
 
+// SQLite's BINARY order of n names given as one packed host buffer (name i = names[name_off[i], name_off[i + 1])): what
+// fx_names_sort computes from a handle's own table, for names that come from SEVERAL handles -- the shards of one file,
+// whose packed names rank 0 has concatenated -- so that the merged .fxi gets its index b-tree from the same GPU sort
+// instead of CREATE UNIQUE INDEX's (index.c:363, fastq.c:155).  order[i] = 0-based index of the i-th smallest name.
+extern "C" int fx_sort_packed_names(int device, const uint8_t *names, const int64_t *name_off, int64_t n, int64_t *order, int64_t *n_dup) {
+    if (!n_dup || n < 0 || (n > 0 && (!name_off || !order || (!names && name_off[n] > 0)))) return fail(FX_EINVAL, "bad argument");
+    *n_dup = 0;
+    if (n == 0) return FX_OK;
+    if (n >= 0xFFFFFFFFll) return fail(FX_ERANGE, "too many records for the 32-bit sort index");
+    fx_handle *h = nullptr;
+    int rc = new_handle(device, &h);
+    if (rc) return rc;
+    const int64_t total = name_off[n];
+    DevBuf<uint8_t> d_names;
+    DevBuf<int64_t> d_off, d_order, d_ndup;
+    DevBuf<int32_t> d_len;
+    std::vector<int32_t> len((size_t)n);
+    for (int64_t i = 0; i < n; ++i) len[(size_t)i] = (int32_t)(name_off[i + 1] - name_off[i]);
+    auto done = [&](int code) { fx_close(h); return code; };
+    if ((rc = d_names.alloc(total + 64)) || (rc = d_off.alloc(n)) || (rc = d_len.alloc(n)) || (rc = d_order.alloc(n)) || (rc = d_ndup.alloc(1))) return done(rc);
+    hipError_t e = hipMemsetAsync(d_names.p + total, 0, 64, h->stream);
+    if (e == hipSuccess && total) e = hipMemcpyAsync(d_names.p, names, (size_t)total, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off.p, name_off, (size_t)n * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_len.p, len.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) return done(fail(FX_EDEVICE, "H2D: %s", hipGetErrorString(e)));
+    const char *what = "";
+    const int se = sort_names(d_names.p, 0, d_off.p, d_len.p, n, d_order.p, d_ndup.p, h->stream, &what);
+    if (se) return done(fail(se == (int)hipErrorOutOfMemory ? FX_ENOMEM : FX_EDEVICE, "name sort, %s: %s", what, hipGetErrorString((hipError_t)se)));
+    e = hipMemcpyAsync(n_dup, d_ndup.p, 8, hipMemcpyDeviceToHost, h->stream);
+    if (e != hipSuccess) return done(fail(FX_EDEVICE, "D2H: %s", hipGetErrorString(e)));
+    if ((rc = to_host(h, order, d_order.p, n * 8))) return done(rc);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return done(fail(FX_EDEVICE, "stream sync failed"));
+    return done(FX_OK);
+}
+
 extern "C" int fx_fasta_len_stats(fx_handle *h, int64_t count_min, double half, fx_len_stats *out) {
     static_assert(sizeof(fx_len_stats) == sizeof(LenStats), "statistics layout");
     if (!h || !out) return fail(FX_EINVAL, "null argument");

@@ -104,8 +104,6 @@ def stitch_tail(S, r, full_name=False):
                 if full_name:
                     name_len = dlen
                 elif name_len < 0:
-                    if u.first_nl - u.base > 65536 and ws < 0:
-                        raise ValueError("header line crossing a shard cut continues for more than 64 KiB")
                     name_len = (ws - (h + 1)) if (0 <= ws < e) else dlen
                 name_len = min(name_len, dlen)
                 have_e = True
@@ -463,7 +461,8 @@ class ShardedFasta:
 
 
 # ------------------------------------------------------------------ one index file from many shards
-HEAD_BYTES = 65536 + 4096          # what a rank shows of its first bytes: a name cut by a shard boundary ends within 64 KiB of it
+HEAD_BYTES = 4096                  # what a rank shows of its first bytes at least (a name cut by a shard boundary runs on in them)
+HEAD_MAX = 64 << 20                # ... and at most: it shows them up to its first newline, where such a name ends at the latest
 
 
 def local_index_part(blob, n_local, base, n_bytes):
@@ -477,7 +476,9 @@ def local_index_part(blob, n_local, base, n_bytes):
         nb, no, ol = blob.fetch_ranges(rows["hoff"] + 1, ln, ln, flags=8)       # FX_RAW; clamped to the bytes held
         raw, o, l = nb.tobytes(), no.tolist(), ol.tolist()
         names = [raw[o[i]:o[i] + l[i]] for i in range(n_local)]
-    head = blob.read_bytes(base, min(HEAD_BYTES, n_bytes))
+    S = blob.shard_summary()
+    first_line = (S.first_nl - base + 1) if S.first_nl >= 0 else n_bytes
+    head = blob.read_bytes(base, min(max(HEAD_BYTES, min(first_line, HEAD_MAX)), n_bytes))
     return (int(base), int(n_bytes), {k: np.asarray(v) for k, v in rows.items()}, names, head)
 
 
@@ -723,3 +724,98 @@ def allgather_pieces(pieces):
     outs = [None] * dist.get_world_size()
     dist.all_gather_object(outs, pieces)
     return [p for o in outs for p in o]
+
+
+# ------------------------------------------------------------------ FASTQ: one file over several ranks (SURVEY 8e "FASTQ")
+class ShardedFastq:
+    """One rank's share of a sharded FASTQ index build (pyfastx_fastq_create_index, fastq.c:8-182, one process per GPU).
+
+    Rank r stages bytes [size r / R, size (r + 1) / R) of the uncompressed stream plus a halo behind them: a record
+    belongs to the rank its HEADER line begins in and is finished from the halo.  The only exchange of the build is the
+    line numbering -- one all-gather of two integers per rank (newlines in the core, offset of the last one).  A halo
+    that turns out too small for a record of this shard (FX_ERANGE from fx_fastq_build_ctx: a read of a megabyte) is no
+    error: the range is opened again with a larger one, the numbering from the all-gather stays valid (it only counts
+    the cores).  gather: callable(np.int64[2]) -> int64[world, 2]; default: torch.distributed's all_gather (gloo in the
+    CPU tests, RCCL on GPUs) -- or fx_comm (Comm.allgather), the library's own."""
+
+    HALO0 = 1 << 16
+
+    def __init__(self, path, rank, world, device=0, halo=None, gather=None):
+        from . import _lib
+        size, kind = _lib.stream_size(path)
+        if kind == 2:
+            raise ValueError("%s is a single gzip stream: it does not shard by byte range (replicas only)" % path)
+        self.path, self.rank, self.world, self.device, self.stream_bytes = path, rank, world, device, size
+        self.base, self.end = size * rank // world, size * (rank + 1) // world
+        self.halo = int(self.HALO0 if halo is None else halo)
+        self.reopened = 0
+        ctx = None
+        while True:
+            h = min(self.halo, size - self.end)
+            blob = _lib.Blob.from_file_range(path, self.base, self.end - self.base, h, device=device)
+            core = blob.fastq_scan()
+            if ctx is None:
+                mine = np.array(core, dtype=np.int64)
+                if gather is None:
+                    allc = allgather_fastq_cores(tuple(int(x) for x in mine), world, "cpu") if world > 1 else [tuple(int(x) for x in mine)]
+                else:
+                    allc = [tuple(int(v) for v in row) for row in np.asarray(gather(mine)).reshape(world, 2)]
+                ctx = fastq_contexts(allc)[rank]
+            try:
+                self.summary = blob.fastq_build_ctx(*ctx)
+                break
+            except _lib.FxError as e:
+                if e.code != _lib.FX_ERANGE or h >= size - self.end:
+                    raise
+                blob.close()
+                self.halo *= 8
+                self.reopened += 1
+        self.blob = blob
+        self.n_local, self.first_id, self.size = int(self.summary.n_reads), int(self.summary.first_id), int(self.summary.size)
+
+    def local_part(self):
+        """This shard's rows (global offsets) and names, as plain arrays."""
+        t = self.blob.fastq_table(self.n_local)
+        packed, offs = self.blob.names_pack(1, self.n_local, guess=int(np.maximum(t["name_len"], 0).sum()))
+        return {"dlen": np.asarray(t["dlen"], np.int64), "rlen": np.asarray(t["rlen"], np.int64), "soff": np.asarray(t["soff"], np.int64),
+                "qoff": np.asarray(t["qoff"], np.int64), "names": np.asarray(packed, np.uint8), "name_off": np.asarray(offs, np.int64),
+                "size": np.array([self.size, self.n_local], np.int64)}
+
+    def write_index(self, index_file, scratch_dir, barrier=None):
+        """ONE .fxi for the whole file.  The tables of a sequencing run are gigabytes (10^8 rows x 40 bytes + the names):
+        they go to rank 0 as RAW ARRAYS through files in scratch_dir (a directory every rank sees: /dev/shm on one node),
+        not pickled through the process group; rank 0 maps them, gets the order of all names from ONE GPU sort
+        (fx_sort_packed_names) and writes the b-trees as pages (fxi.write_fastq_bulk).  barrier: callable that returns when
+        every rank has called it (default: torch.distributed.barrier when world > 1).  -> rows written (rank 0), else None."""
+        from . import _lib, fxi
+        part = self.local_part()
+        for k, v in part.items():
+            np.save(os.path.join(scratch_dir, "fq_%s_%d.npy" % (k, self.rank)), v)
+        if barrier is None and self.world > 1:
+            import torch.distributed as dist
+            barrier = dist.barrier
+        if barrier is not None:
+            barrier()
+        n_total = None
+        if self.rank == 0:
+            def col(k):
+                return [np.load(os.path.join(scratch_dir, "fq_%s_%d.npy" % (k, r)), mmap_mode="r") for r in range(self.world)]
+            cols = {k: np.concatenate(col(k)) for k in ("dlen", "rlen", "soff", "qoff")}
+            names = np.concatenate(col("names"))
+            offs_r = col("name_off")
+            shift = np.concatenate([[0], np.cumsum([int(o[-1]) for o in offs_r])]).astype(np.int64)
+            name_off = np.concatenate([np.asarray(o[:-1]) + shift[r] for r, o in enumerate(offs_r)] + [shift[-1:]])
+            sizes = np.stack(col("size"))
+            order, ndup = _lib.sort_packed_names(names, name_off, self.device)
+            if os.path.exists(index_file):
+                os.remove(index_file)
+            db = fxi.write_fastq_bulk(index_file, names, name_off, cols, int(sizes[:, 0].sum()), None if ndup else order)
+            db.commit() if hasattr(db, "commit") else None
+            db.close()
+            n_total = int(sizes[:, 1].sum())
+            for r in range(self.world):
+                for k in part:
+                    os.remove(os.path.join(scratch_dir, "fq_%s_%d.npy" % (k, r)))
+        if barrier is not None:
+            barrier()
+        return n_total

@@ -79,7 +79,7 @@ def local_scan(raw, lo, hi, full_name=False):
             v2 = rest[0]
             c2 = sum(1 for x in d if x == v2)
     first_nl = nl[0] if nl else -1
-    lim = min((first_nl - lo) if first_nl >= 0 else n, 65536)
+    lim = (first_nl - lo) if first_nl >= 0 else n
     ws = -1
     for j in range(lim):
         if a[j] in (32, 9):

@@ -107,6 +107,29 @@ def test_long_lines_across_many_shards(oracle, L):
     check(oracle, L, raw, [5, 11, 30, 40000, 40010, n - 3])
 
 
+def _long_header_fasta():
+    """A header line of ~100 KiB: the name is 70 000 bytes long, the first white space sits 70 001 bytes behind the '>'."""
+    name = ("N" + "x" * 69_999).encode()
+    return b">a d\nACGTAC\nGT\n>" + name + b" " + b"d" * 30_000 + b"\nACGTACGT\nACGTACGT\nAC\n>" + b"y" * 100_000 + b"\nGG\n>z\nA\n"
+
+
+def test_header_lines_of_100_kib_across_cuts(oracle, L):
+    """No limit on how far behind a cut a name may end (round 2: 64 KiB, ValueError beyond): cuts at every kind of place of two
+    ~100 KiB header lines -- inside the name, at its last byte, at the white space, inside the description, around the line end
+    --, two and three shards, with and without full_name; a third shard that holds nothing but a middle piece of the line."""
+    raw = _long_header_fasta()
+    h1 = raw.index(b">N")
+    h2 = raw.index(b">y")
+    places = [h1 + 1, h1 + 2, h1 + 35_000, h1 + 69_999, h1 + 70_000, h1 + 70_001, h1 + 70_002, h1 + 85_000, h1 + 100_001, h1 + 100_002,
+              h1 + 100_003, h2 + 1, h2 + 50_000, h2 + 100_000, h2 + 100_001, h2 + 100_002]
+    for c in places:
+        check(oracle, L, raw, [c])
+        check(oracle, L, raw, [c], full_name=True)
+    for a, b in ((h1 + 10, h1 + 66_000), (h1 + 10, h1 + 70_001), (h1 + 69_000, h1 + 99_000), (h2 + 5, h2 + 99_999), (h1 - 3, h2 + 70_000)):
+        check(oracle, L, raw, [a, b])
+        check(oracle, L, raw, [a, (a + b) // 2, b], full_name=True)
+
+
 # ------------------------------------------------------------------ FASTQ shards (halo + line numbering)
 def _rand_fastq(rng, n, crlf=False, trailing=True):
     eol = b"\r\n" if crlf else b"\n"
@@ -363,3 +386,68 @@ def test_line_regular_across_cuts(oracle, L, crlf):
     for g in (2, 3, 7, 12):
         for _ in range(6):
             check(oracle, L, raw, sorted(set(int(x) for x in rng.integers(1, len(raw), g - 1))))
+
+
+def _logical_ranks(path, world, halo=None):
+    """ShardedFastq for every rank of a `world`, in one process: the all-gather is the list of every range's core counts."""
+    from pyfastx_amd import _lib, shard
+    size, _ = _lib.stream_size(path)
+    cores = []
+    for r in range(world):
+        lo, hi = size * r // world, size * (r + 1) // world
+        b = _lib.Blob.from_file_range(path, lo, hi - lo, 0)
+        cores.append(b.fastq_scan())
+        b.close()
+    table = np.array(cores, dtype=np.int64)
+    return [shard.ShardedFastq(path, r, world, halo=halo, gather=lambda mine, t=table: t) for r in range(world)]
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_sharded_fastq_with_a_read_of_a_megabyte(oracle, L, tmp_path, world):
+    """shard.ShardedFastq on a FILE: a halo too small for a record of the shard is no error any more (round 2: FX_ERANGE) --
+    the range is opened again with a larger one.  One read of 1 MiB among ordinary ones, placed so that it begins just in
+    front of a cut; the rows of all ranks, concatenated, are the oracle's; ONE .fxi is written from raw arrays passed
+    through files (no pickle), its name index from one GPU sort of all ranks' names."""
+    import sqlite3
+    rng = np.random.default_rng(world)
+    big = bytes(rng.choice(list(b"ACGT"), 1 << 20).astype(np.uint8))
+    head = _rand_fastq(rng, 400)
+    tail = _rand_fastq(rng, 300).replace(b"@r", b"@t")
+    # the big read begins ~100 bytes in front of the first cut of the file
+    raw0 = head + b"@big one\n" + big + b"\n+\n" + bytes(rng.integers(35, 71, 1 << 20).astype(np.uint8)) + b"\n" + tail
+    want_cut = len(raw0) // world
+    pad = want_cut - len(head) - 100
+    filler = b""
+    i = 0
+    while len(filler) < max(pad, 0):
+        filler += b"@f%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i
+        i += 1
+    raw = head + filler + raw0[len(head):]
+    p = tmp_path / "big.fq"
+    p.write_bytes(raw)
+    recs, size, ln = oracle.fastq_index(raw)
+    ranks = _logical_ranks(str(p), world)
+    assert sum(r.reopened for r in ranks) >= 1                    # somebody's 64 KiB halo was too small
+    assert sum(r.n_local for r in ranks) == len(recs) and sum(r.size for r in ranks) == size
+    nxt = 0
+    for r in ranks:
+        assert r.n_local == 0 or r.first_id == nxt
+        nxt += r.n_local
+    for k in ("name_off", "name_len", "dlen", "rlen", "soff", "qoff"):
+        got = np.concatenate([r.blob.fastq_table(r.n_local)[k] for r in ranks])
+        np.testing.assert_array_equal(got, recs[k].astype(got.dtype), err_msg=k)
+    fxi_path = str(tmp_path / "big.fq.fxi")
+    scratch = tmp_path / "scratch"
+    scratch.mkdir()
+    for r in ranks[1:] + ranks[:1]:                               # rank 0 last: the others' arrays are there by then
+        n = r.write_index(fxi_path, str(scratch), barrier=lambda: None)
+    assert n == len(recs) and not list(scratch.iterdir())
+    db = sqlite3.connect(fxi_path)
+    assert db.execute("PRAGMA integrity_check").fetchone()[0] == "ok"
+    rows = db.execute("SELECT name, dlen, rlen, soff, qoff FROM read ORDER BY ID").fetchall()
+    names = [raw[int(r["name_off"]):int(r["name_off"]) + int(r["name_len"])].decode() for r in recs]
+    assert rows == [(names[i], int(recs["dlen"][i]), int(recs["rlen"][i]), int(recs["soff"][i]), int(recs["qoff"][i])) for i in range(len(recs))]
+    assert db.execute("SELECT counts, size FROM stat").fetchone() == (len(recs), size)
+    for nm in ("big", names[3], names[-1]):
+        assert db.execute("SELECT ID FROM read WHERE name=?", (nm,)).fetchone()[0] == names.index(nm) + 1
+    db.close()

@@ -178,6 +178,20 @@ def test_stitch_random(oracle, seed):
             assert shard_ref.stitched_rows(raw, cuts) == want, (seed, cuts)
 
 
+def test_stitch_header_lines_of_100_kib(oracle):
+    """The host statement of the stitch (shard_ref: summaries computed in Python, shard.stitch_tail) with header lines of
+    ~100 KiB across the cuts: the name may end any distance behind a cut."""
+    name = ("N" + "x" * 69_999).encode()
+    raw = b">a d\nACGTAC\nGT\n>" + name + b" " + b"d" * 30_000 + b"\nACGTACGT\nACGTACGT\nAC\n>" + b"y" * 100_000 + b"\nGG\n>z\nA\n"
+    h1, h2 = raw.index(b">N"), raw.index(b">y")
+    want, want_full = _expect(oracle, raw), _expect(oracle, raw, True)
+    for c in (h1 + 1, h1 + 35_000, h1 + 70_000, h1 + 70_001, h1 + 70_002, h1 + 85_000, h1 + 100_002, h2 + 50_000, h2 + 100_001):
+        assert shard_ref.stitched_rows(raw, [c]) == want, c
+        assert shard_ref.stitched_rows(raw, [c], full_name=True) == want_full, c
+    for a, b in ((h1 + 10, h1 + 66_000), (h1 + 69_000, h1 + 99_000), (h2 + 5, h2 + 99_999)):
+        assert shard_ref.stitched_rows(raw, [a, (a + b) // 2, b]) == want, (a, b)
+
+
 def test_reference_opens_our_gz_fxi(oracle, tmp_path):
     """The .fxi contract in the other direction: an index written by fxi.py for a gzip input --
     including BGZF-style gzindex points without windows -- is accepted by the REAL reference's
