@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-c3", action="store_true")
     ap.add_argument("--no-c4", action="store_true")
     ap.add_argument("--no-gz-stream", action="store_true", help="skip the single-stream gzip sub-leg of c4")
+    ap.add_argument("--no-c3-file", action="store_true", help="skip the full-size FASTQ file leg (35 GB file + 10 GB index in /dev/shm)")
     return ap.parse_args()
 
 
@@ -275,6 +276,19 @@ def leg_c3(a, dev, tmpdir):
     m = int(min(a.c3_sample, n))
     path = os.path.join(tmpdir, "c3.fq")
     blob_t[:m * rec].cpu().numpy().tofile(path)
+    # ---- (iii) the WHOLE configuration as a file (space permitting): written here, while the bytes are at hand
+    full_dir = full_path = None
+    if not a.no_c3_file and n > m:
+        try:
+            need = nb + n * 110 + (8 << 30)                   # the file, its index file (~100 B per read), slack
+            if shutil.disk_usage("/dev/shm").free > need * 1.15:
+                full_dir = tempfile.mkdtemp(prefix="fxc3", dir="/dev/shm")
+                full_path = os.path.join(full_dir, "c3_full.fq")
+                with open(full_path, "wb") as f:
+                    for x in range(0, nb, 1 << 30):
+                        f.write(memoryview(blob_t[x:min(x + (1 << 30), nb)].cpu().numpy()))
+        except OSError:
+            full_path = None
     b.close()
     del b, blob_t, v, seqs, quals, o_seq, o_q, o_qi
     torch.cuda.empty_cache()
@@ -317,7 +331,75 @@ def leg_c3(a, dev, tmpdir):
             raise SystemExit("PARITY FAILURE (C3 file leg vs the reference)")
     _rm(path, path + ".fxi")
     out["file_sample"] = smp
+    if full_path is not None:
+        try:
+            out["e2e_full"] = c3_full_file(a, full_path, n, cols, theirs_rows=(theirs["read"] if ref is not None else None), m=m)
+        finally:
+            shutil.rmtree(full_dir, ignore_errors=True)
+    else:
+        out["e2e_full"] = None if a.no_c3_file or n <= m else "skipped: /dev/shm has no room for the %.0f GB file and its index" % (nb / 1e9)
     return out
+
+
+def c3_full_file(a, path, n, cols, theirs_rows, m):
+    """configs[2] at FULL size from a FILE, the job of pyfastx_fastq_create_index (fastq.c:8-182) end to end: the 35 GB file
+    (page cache) -> Fastq(path): staging, scan, rows, names, GPU sort, the 10 GB .fxi durable on disk -> 1 M reads (seq +
+    qual + int8 quali) into host memory.  Checked: SQLite's own integrity check of the index file (page structure, every
+    index entry against its row, order, uniqueness), the rows of the first `m` reads against the rows the REFERENCE wrote
+    for that prefix (offsets are from the start of the file: the same rows), rows and fetched bytes of a sample all over
+    the file against the file's own bytes."""
+    import sqlite3
+    import pyfastx_amd as fx
+    from pyfastx_amd import _lib
+    nb = os.path.getsize(path)
+    _lib.Blob.from_file_range(path, 0, 1 << 24, 0).close()
+    t0 = time.perf_counter()
+    fq = fx.Fastq(path)                                      # stage + scan + rows + names + sort + b-tree pages
+    t1 = time.perf_counter()
+    nq = a.queries
+    ids = np.random.default_rng(99).integers(0, n, nq)
+    fq.fetch_many(ids[:1000], want=("seq", "qual", "quali"))
+    t2 = time.perf_counter()
+    got = fq.fetch_many(ids, want=("seq", "qual", "quali"))
+    t3 = time.perf_counter()
+    rec = int(cols["rec"])
+    so, qo = int(cols["soff"][0]), int(cols["qoff"][0])
+    mm = np.memmap(path, dtype=np.uint8, mode="r")
+    pick = np.arange(0, nq, max(nq // 20000, 1))
+    o = got["offsets"]
+    ok = bool((np.diff(o) == 150).all())
+    base = ids[pick].astype(np.int64) * rec
+    idx = base[:, None] + np.arange(150)[None, :]
+    want_s, want_q = mm[idx + so], mm[idx + qo]
+    gs = got["seq"][:int(o[-1])].reshape(nq, 150)[pick]
+    gq = got["qual"][:int(o[-1])].reshape(nq, 150)[pick]
+    gi = got["quali"][:int(o[-1])].reshape(nq, 150)[pick]
+    ok = ok and bool((gs == want_s).all()) and bool((gq == want_q).all()) and bool((gi == (want_q.astype(np.int16) - 33).astype(np.int8)).all())
+    del mm, fq
+    t4 = time.perf_counter()
+    db = sqlite3.connect(path + ".fxi")
+    integrity = db.execute("PRAGMA integrity_check").fetchone()[0]
+    t5 = time.perf_counter()
+    cnt = db.execute("SELECT counts, size FROM stat").fetchone()
+    samp = np.unique(np.concatenate([np.arange(1, 6), np.random.default_rng(5).integers(1, n + 1, 2000), [n]]))
+    rows_ok = cnt == (n, n * 150)
+    for i in samp.tolist():
+        r = db.execute("SELECT dlen, rlen, soff, qoff FROM read WHERE ID=?", (i,)).fetchone()
+        rows_ok = rows_ok and r == (int(cols["dlen"][i - 1]), 150, int(cols["soff"][i - 1]), int(cols["qoff"][i - 1]))
+    prefix_equal = None
+    if theirs_rows is not None:
+        mine = db.execute("SELECT * FROM read WHERE ID<=? ORDER BY ID", (m,)).fetchall()
+        prefix_equal = mine == theirs_rows
+    by_name = db.execute("SELECT ID FROM read WHERE name=(SELECT name FROM read WHERE ID=?)", (n // 2,)).fetchone()[0] == n // 2
+    db.close()
+    res = {"workload": "configs[2] from a FILE: %d x 150 bp FASTQ (%.1f GB, page cache) -> pyfastx_amd.Fastq(path) with no .fxi present -> the index "
+                       "file durable on disk (%.1f GB) -> %d random reads (seq + qual + int8 quali) into host memory" % (n, nb / 1e9, os.path.getsize(path + ".fxi") / 1e9, nq),
+           "Fastq_ctor_s": round(t1 - t0, 3), "M_rows_per_s": round(n / (t1 - t0) / 1e6, 2), "fetch_many_1M_s": round(t3 - t2, 4),
+           "sqlite_integrity_check": integrity, "integrity_check_s": round(t5 - t4, 1), "rows_sample_equal_generator": bool(rows_ok),
+           "rows_of_the_first_%d_reads_equal_reference" % m: prefix_equal, "name_probe_ok": bool(by_name), "fetch_sample_equal_file_bytes": bool(ok)}
+    if integrity != "ok" or not rows_ok or not ok or prefix_equal is False or not by_name:
+        raise SystemExit("PARITY FAILURE (C3 at full size from a file): %r" % (res,))
+    return res
 
 
 # ------------------------------------------------------------------------------------------ C4: BGZF
