@@ -220,8 +220,10 @@ __device__ __forceinline__ void store_low_bytes(uint8_t *p, uint4 v, int len) {
 template <bool BY_ID, int G, int V>
 __global__ __launch_bounds__(BLOCK) void k_fetch(const uint8_t *__restrict__ data, int64_t gbase, int64_t n_bytes,
                                                 FetchQ q, FastaTab tab, int64_t nq, int flags_all,
-                                                uint8_t *__restrict__ dst) {
+                                                uint8_t *__restrict__ dst, const int32_t *__restrict__ list = nullptr,
+                                                const int *__restrict__ list_n = nullptr) {
     __shared__ uint8_t lut[256];
+    if (list) nq = *list_n;                                    // list mode: only the queries k_fetch_lines left over
     // BY_ID: the record table of a genome (a few hundred rows) is copied to LDS once per workgroup, so
     // resolving a query costs one LDS read instead of a second dependent trip to memory
     constexpr int TABCAP = BY_ID ? 512 : 1;
@@ -246,8 +248,11 @@ __global__ __launch_bounds__(BLOCK) void k_fetch(const uint8_t *__restrict__ dat
     // trips: descriptor -> table -> sequence bytes; this takes the first one off the critical path)
     int64_t d_a0 = 0, d_a1 = 0, d_a2 = 0, d_a3 = 0, d_off = 0;
     int d_fl = flags_all;
-    auto fetch_desc = [&](int64_t i) {
-        if (i >= nq) return;
+    int64_t d_i = 0;                                           // the query the descriptor belongs to
+    auto fetch_desc = [&](int64_t k) {
+        if (k >= nq) return;
+        const int64_t i = list ? (int64_t)list[k] : k;
+        d_i = i;
         if (BY_ID) { d_a0 = q.seq_id[i]; d_a1 = q.start[i]; d_a2 = q.stop[i]; }
         else       { d_a0 = q.off[i]; d_a1 = q.blen[i]; d_a2 = q.take[i]; d_a3 = q.skip ? q.skip[i] : 0; }
         d_off = q.dst_off[i];
@@ -255,11 +260,12 @@ __global__ __launch_bounds__(BLOCK) void k_fetch(const uint8_t *__restrict__ dat
     };
     fetch_desc(wave * QPW + grp);
     for (int64_t i0 = wave * QPW; i0 < nq; i0 += nwaves * QPW) {
-        const int64_t i = i0 + grp;
-        bool ok = i < nq;
+        const int64_t kq = i0 + grp;
+        bool ok = kq < nq;
+        const int64_t i = d_i;
         const int64_t c_a0 = d_a0, c_a1 = d_a1, c_a2 = d_a2, c_a3 = d_a3, c_off = d_off;
         const int fl = d_fl;
-        fetch_desc(i + nwaves * QPW);
+        fetch_desc(kq + nwaves * QPW);
         int64_t off = 0, blen = 0, skip = 0, take = 0;
         int64_t r_boff = 0, r_el = 0, r_bpl = 0;
         bool r_norm = false;
@@ -309,41 +315,73 @@ __global__ __launch_bounds__(BLOCK) void k_fetch(const uint8_t *__restrict__ dat
                 const uint32_t r0 = (uint32_t)a % bpl32;          // column of base `a` in its line
                 const bool rev = (fl & 2) != 0;
                 bool irregular = false;
-                for (int64_t s0 = 0; s0 < take; s0 += G * 16) {
-                    const int64_t oc = s0 + 16 * sub;             // this lane writes out[oc, oc + len)
-                    const int len = (int)(take - oc < 16 ? take - oc : 16);
-                    if (len <= 0) continue;
-                    // forward indices [f0, f0 + len) of the query; `lead` unused bytes in front of them in the
-                    // lane's 16-byte window (reverse strand: the partial chunk is the head of the query)
-                    const int64_t f0 = rev ? take - oc - len : oc;
-                    const int lead = rev ? 16 - len : 0;
-                    const uint32_t xx = r0 + (uint32_t)f0;
-                    const uint32_t k = xx / bpl32, t = bpl32 - (xx - k * bpl32);   // line of f0 (relative), bases to its end
-                    const uint8_t *p1 = data + in_a + f0 + el * (int64_t)k - lead;
-                    uint4 v = *reinterpret_cast<const uint4_u *>(p1);
-                    if (t < (uint32_t)len) {                      // a line ends inside: bytes from index lead + t on come from el further
-                        const uint4 w = *reinterpret_cast<const uint4_u *>(p1 + el);
-                        const int T = lead + (int)t;
-                        const uint32_t m0 = lowbytes_word(T, 0), m1 = lowbytes_word(T, 1), m2 = lowbytes_word(T, 2), m3 = lowbytes_word(T, 3);
-                        v.x = (v.x & m0) | (w.x & ~m0); v.y = (v.y & m1) | (w.y & ~m1);
-                        v.z = (v.z & m2) | (w.z & ~m2); v.w = (v.w & m3) | (w.w & ~m3);
+                // Two pieces per lane and step (a 100-base query is ONE round of loads for its four lanes, not two): the
+                // addresses of both first, then their loads -- the 16 bytes at the piece and, where a line ends inside or right
+                // behind it, the 16 bytes `el` further -- and only then the byte work and the stores.  The terminator bytes a
+                // piece skips are looked up in the registers it has loaded (byte loads of their own were two more gathers).
+                for (int64_t s0 = 0; s0 < take; s0 += 2 * G * 16) {
+                    int64_t oc[2], f0[2];
+                    int len[2], lead[2];
+                    uint32_t tt[2];
+                    const uint8_t *p1[2];
+                    bool need_w[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        oc[u] = s0 + u * (G * 16) + 16 * sub;         // this lane writes out[oc, oc + len)
+                        int l = (int)(take - oc[u] < 16 ? take - oc[u] : 16);
+                        len[u] = l < 0 ? 0 : l;
+                        // forward indices [f0, f0 + len) of the query; `lead` unused bytes in front of them in the
+                        // lane's 16-byte window (reverse strand: the partial chunk is the head of the query)
+                        f0[u] = len[u] ? (rev ? take - oc[u] - len[u] : oc[u]) : 0;
+                        lead[u] = len[u] && rev ? 16 - len[u] : 0;
+                        const uint32_t xx = r0 + (uint32_t)f0[u];
+                        const uint32_t k = xx / bpl32;
+                        tt[u] = bpl32 - (xx - k * bpl32);               // bases to the end of f0's line
+                        p1[u] = data + in_a + f0[u] + el * (int64_t)k - lead[u];
+                        need_w[u] = len[u] > 0 && tt[u] <= (uint32_t)len[u];
                     }
-                    if (t < (uint32_t)len || (t == (uint32_t)len && f0 + len < take)) {   // the terminator after base f0 + t - 1 is skipped
-                        const uint8_t *gp = p1 + lead + t;
-                        irregular |= !is_space3(gp[0]) || (el == 2 && !is_space3(gp[1]));
+                    uint4 v[2], w[2];
+                    v[0] = *reinterpret_cast<const uint4_u *>(p1[0]);
+                    v[1] = *reinterpret_cast<const uint4_u *>(p1[1]);
+                    w[0] = w[1] = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+                    if (need_w[0]) w[0] = *reinterpret_cast<const uint4_u *>(p1[0] + el);
+                    if (need_w[1]) w[1] = *reinterpret_cast<const uint4_u *>(p1[1] + el);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (len[u] <= 0) continue;
+                        uint4 x = v[u];
+                        const uint4 y = w[u];
+                        const int ln = len[u], ld = lead[u];
+                        const uint32_t t = tt[u];
+                        const int T = ld + (int)t;                      // index in the window of the first byte behind the line's bases
+                        if (t < (uint32_t)ln || (t == (uint32_t)ln && f0[u] + ln < take)) {   // the terminator after base f0 + t - 1 is skipped
+                            // window byte i is byte i of x (i < 16) or byte i - el of y: T <= 16, T + 1 <= 17
+                            const int i0 = T < 16 ? T : T - (int)el, i1 = T + 1 < 16 ? T + 1 : T + 1 - (int)el;
+                            const uint4 &s0v = T < 16 ? x : y, &s1v = T + 1 < 16 ? x : y;
+                            const uint32_t a01 = (i0 & 4) ? s0v.y : s0v.x, a23 = (i0 & 4) ? s0v.w : s0v.z;
+                            const uint32_t g0 = (((i0 & 8) ? a23 : a01) >> ((i0 & 3) * 8)) & 0xFFu;
+                            const uint32_t b01 = (i1 & 4) ? s1v.y : s1v.x, b23 = (i1 & 4) ? s1v.w : s1v.z;
+                            const uint32_t g1 = (((i1 & 8) ? b23 : b01) >> ((i1 & 3) * 8)) & 0xFFu;
+                            irregular |= !is_space3(g0) || (el == 2 && !is_space3(g1));
+                        }
+                        if (t < (uint32_t)ln) {                         // a line ends inside: bytes from index T on come from el further
+                            const uint32_t m0 = lowbytes_word(T, 0), m1 = lowbytes_word(T, 1), m2 = lowbytes_word(T, 2), m3 = lowbytes_word(T, 3);
+                            x.x = (x.x & m0) | (y.x & ~m0); x.y = (x.y & m1) | (y.y & ~m1);
+                            x.z = (x.z & m2) | (y.z & ~m2); x.w = (x.w & m3) | (y.w & ~m3);
+                        }
+                        {   // no white space among the bases taken
+                            const int lo_b = ld, hi_b = ld + ln;
+                            uint32_t f = le20_bytes(x.x) & lowbytes_word(hi_b, 0) & ~lowbytes_word(lo_b, 0);
+                            f |= le20_bytes(x.y) & lowbytes_word(hi_b, 1) & ~lowbytes_word(lo_b, 1);
+                            f |= le20_bytes(x.z) & lowbytes_word(hi_b, 2) & ~lowbytes_word(lo_b, 2);
+                            f |= le20_bytes(x.w) & lowbytes_word(hi_b, 3) & ~lowbytes_word(lo_b, 3);
+                            irregular |= f != 0;
+                        }
+                        if (fl & 1) { x.x = upper4(x.x); x.y = upper4(x.y); x.z = upper4(x.z); x.w = upper4(x.w); }
+                        if (fl & 4) { x.x = lut4(lut, x.x); x.y = lut4(lut, x.y); x.z = lut4(lut, x.z); x.w = lut4(lut, x.w); }
+                        if (rev) x = make_uint4(__builtin_bswap32(x.w), __builtin_bswap32(x.z), __builtin_bswap32(x.y), __builtin_bswap32(x.x));
+                        store_low_bytes(out + oc[u], x, ln);
                     }
-                    {   // no white space among the bases taken
-                        const int lo_b = lead, hi_b = lead + len;
-                        uint32_t f = le20_bytes(v.x) & lowbytes_word(hi_b, 0) & ~lowbytes_word(lo_b, 0);
-                        f |= le20_bytes(v.y) & lowbytes_word(hi_b, 1) & ~lowbytes_word(lo_b, 1);
-                        f |= le20_bytes(v.z) & lowbytes_word(hi_b, 2) & ~lowbytes_word(lo_b, 2);
-                        f |= le20_bytes(v.w) & lowbytes_word(hi_b, 3) & ~lowbytes_word(lo_b, 3);
-                        irregular |= f != 0;
-                    }
-                    if (fl & 1) { v.x = upper4(v.x); v.y = upper4(v.y); v.z = upper4(v.z); v.w = upper4(v.w); }
-                    if (fl & 4) { v.x = lut4(lut, v.x); v.y = lut4(lut, v.y); v.z = lut4(lut, v.z); v.w = lut4(lut, v.w); }
-                    if (rev) v = make_uint4(__builtin_bswap32(v.w), __builtin_bswap32(v.z), __builtin_bswap32(v.y), __builtin_bswap32(v.x));
-                    store_low_bytes(out + oc, v, len);
                 }
                 const unsigned long long ib = __ballot(irregular);
                 constexpr unsigned long long gmask = G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
@@ -421,6 +459,147 @@ __global__ __launch_bounds__(BLOCK) void k_fetch(const uint8_t *__restrict__ dat
                 }
             }
             if (sub == 0 && q.out_len) q.out_len[i] = got;
+        }
+    }
+}
+
+// The line-arithmetic path ALONE, for batches of short intervals by record id (the benchmark's 1 M x 100 bases): k_fetch
+// carries the general path with it -- keep masks, ranks, per-byte stores, the mirror fix-up -- and with it 100 registers,
+// four waves per SIMD.  The kernel is bound by how many random reads it keeps in flight, so here is the same arithmetic
+// with nothing else: a query that it cannot answer exactly (a record that is not line-regular, lines shorter than 16
+// bases, the edge of the stream, FX_RAW, a terminator that is not where the arithmetic says, white space among the bases,
+// an invalid id) goes on a list, and k_fetch runs over that list afterwards (for a genome: empty).
+template <int G, int NP>
+__global__ __launch_bounds__(BLOCK) void k_fetch_lines(const uint8_t *__restrict__ data, int64_t gbase, int64_t n_bytes, FetchQ q, FastaTab tab,
+                                                      int64_t nq, int flags_all, uint8_t *__restrict__ dst, int32_t *__restrict__ list,
+                                                      int *__restrict__ list_n) {
+    __shared__ uint8_t lut[256];
+    constexpr int TABCAP = 512;
+    __shared__ int64_t s_boff[TABCAP], s_slen[TABCAP];
+    __shared__ int32_t s_llen[TABCAP], s_en[TABCAP];           // s_en = elen | line-regular << 8
+    const int64_t n_seq = tab.n_seq_dev ? (*tab.n_seq_dev < tab.n_seq ? (int64_t)*tab.n_seq_dev : tab.n_seq) : tab.n_seq;
+    const bool tab_lds = n_seq <= TABCAP && n_seq > 0;
+    build_comp_lut(lut);
+    if (tab_lds)
+        for (int r = threadIdx.x; r < (int)n_seq; r += BLOCK) {
+            s_boff[r] = tab.boff[r]; s_slen[r] = tab.slen[r];
+            const int64_t ll = tab.llen[r];
+            s_llen[r] = ll > 0x7FFFFFFFll ? 0x7FFFFFFF : (int32_t)ll;
+            s_en[r] = tab.elen[r] | (tab.norm[r] << 8);
+        }
+    __syncthreads();
+    constexpr int QPW = 64 / G;
+    const int lane = lane_id(), sub = lane & (G - 1), grp = lane / G;
+    const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
+    int64_t d_id = 0, d_a = 0, d_b = 0, d_off = 0;
+    int d_fl = flags_all;
+    auto fetch_desc = [&](int64_t i) {
+        if (i >= nq) return;
+        d_id = q.seq_id[i]; d_a = q.start[i]; d_b = q.stop[i];
+        d_off = q.dst_off[i];
+        d_fl = q.qflags ? q.qflags[i] : flags_all;
+    };
+    fetch_desc(wave * QPW + grp);
+    for (int64_t i0 = wave * QPW; i0 < nq; i0 += nwaves * QPW) {
+        const int64_t i = i0 + grp;
+        const bool live = i < nq;
+        const int64_t id = d_id, a = d_a, b = d_b;
+        uint8_t *out = dst + (live ? d_off : 0);
+        const int fl = d_fl;
+        fetch_desc(i + nwaves * QPW);
+        bool fast = false, irregular = false;
+        int64_t take = 0, in_a = 0, el = 0;
+        uint32_t bpl32 = 1, r0 = 0;
+        if (live && id >= 0 && id < n_seq) {
+            int64_t r_boff, r_slen, llen;
+            int en;
+            if (tab_lds) { r_boff = s_boff[id]; r_slen = s_slen[id]; en = s_en[id]; llen = s_llen[id] == 0x7FFFFFFF ? tab.llen[id] : (int64_t)s_llen[id]; }
+            else         { r_boff = tab.boff[id]; r_slen = tab.slen[id]; en = tab.elen[id] | (tab.norm[id] << 8); llen = tab.llen[id]; }
+            el = en & 0xFF;
+            const int64_t bpl = llen - el;
+            take = b - a;
+            if (a >= 0 && take > 0 && b <= r_slen && (en >> 8) != 0 && bpl >= 16 && bpl < (1ll << 31) && a + take < (1ll << 31) && !(fl & 8)) {
+                bpl32 = (uint32_t)bpl;
+                const uint32_t bs = (uint32_t)a / bpl32, be = (uint32_t)b / bpl32;
+                in_a = r_boff + a + el * (int64_t)bs - gbase;                          // sequence.c:498-510
+                const int64_t blen = take + (int64_t)(be - bs) * el;
+                r0 = (uint32_t)a - bs * bpl32;
+                fast = in_a >= 16 && in_a + blen + 32 <= n_bytes;
+            }
+        }
+        if (fast) {
+            const bool rev = (fl & 2) != 0;
+            for (int64_t s0 = 0; s0 < take; s0 += NP * G * 16) {      // NP pieces per lane and step, all their loads first (see k_fetch)
+                int64_t oc[NP], f0[NP];
+                int len[NP], lead[NP];
+                uint32_t tt[NP];
+                const uint8_t *p1[NP];
+                bool need_w[NP];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    oc[u] = s0 + u * (G * 16) + 16 * sub;
+                    const int l = (int)(take - oc[u] < 16 ? take - oc[u] : 16);
+                    len[u] = l < 0 ? 0 : l;
+                    f0[u] = len[u] ? (rev ? take - oc[u] - len[u] : oc[u]) : 0;
+                    lead[u] = len[u] && rev ? 16 - len[u] : 0;
+                    const uint32_t xx = r0 + (uint32_t)f0[u];
+                    const uint32_t k = xx / bpl32;
+                    tt[u] = bpl32 - (xx - k * bpl32);
+                    p1[u] = data + in_a + f0[u] + el * (int64_t)k - lead[u];
+                    need_w[u] = len[u] > 0 && tt[u] <= (uint32_t)len[u];
+                }
+                uint4 v[NP], w[NP];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) v[u] = *reinterpret_cast<const uint4_u *>(p1[u]);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    w[u] = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+                    if (need_w[u]) w[u] = *reinterpret_cast<const uint4_u *>(p1[u] + el);
+                }
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    if (len[u] <= 0) continue;
+                    uint4 x = v[u];
+                    const uint4 y = w[u];
+                    const int ln = len[u], ld = lead[u];
+                    const uint32_t t = tt[u];
+                    const int T = ld + (int)t;
+                    if (t < (uint32_t)ln || (t == (uint32_t)ln && f0[u] + ln < take)) {
+                        const int i0b = T < 16 ? T : T - (int)el, i1b = T + 1 < 16 ? T + 1 : T + 1 - (int)el;
+                        const uint4 &s0v = T < 16 ? x : y, &s1v = T + 1 < 16 ? x : y;
+                        const uint32_t a01 = (i0b & 4) ? s0v.y : s0v.x, a23 = (i0b & 4) ? s0v.w : s0v.z;
+                        const uint32_t g0 = (((i0b & 8) ? a23 : a01) >> ((i0b & 3) * 8)) & 0xFFu;
+                        const uint32_t b01 = (i1b & 4) ? s1v.y : s1v.x, b23 = (i1b & 4) ? s1v.w : s1v.z;
+                        const uint32_t g1 = (((i1b & 8) ? b23 : b01) >> ((i1b & 3) * 8)) & 0xFFu;
+                        irregular |= !is_space3(g0) || (el == 2 && !is_space3(g1));
+                    }
+                    if (t < (uint32_t)ln) {
+                        const uint32_t m0 = lowbytes_word(T, 0), m1 = lowbytes_word(T, 1), m2 = lowbytes_word(T, 2), m3 = lowbytes_word(T, 3);
+                        x.x = (x.x & m0) | (y.x & ~m0); x.y = (x.y & m1) | (y.y & ~m1);
+                        x.z = (x.z & m2) | (y.z & ~m2); x.w = (x.w & m3) | (y.w & ~m3);
+                    }
+                    {
+                        const int lo_b = ld, hi_b = ld + ln;
+                        uint32_t f = le20_bytes(x.x) & lowbytes_word(hi_b, 0) & ~lowbytes_word(lo_b, 0);
+                        f |= le20_bytes(x.y) & lowbytes_word(hi_b, 1) & ~lowbytes_word(lo_b, 1);
+                        f |= le20_bytes(x.z) & lowbytes_word(hi_b, 2) & ~lowbytes_word(lo_b, 2);
+                        f |= le20_bytes(x.w) & lowbytes_word(hi_b, 3) & ~lowbytes_word(lo_b, 3);
+                        irregular |= f != 0;
+                    }
+                    if (fl & 1) { x.x = upper4(x.x); x.y = upper4(x.y); x.z = upper4(x.z); x.w = upper4(x.w); }
+                    if (fl & 4) { x.x = lut4(lut, x.x); x.y = lut4(lut, x.y); x.z = lut4(lut, x.z); x.w = lut4(lut, x.w); }
+                    if (rev) x = make_uint4(__builtin_bswap32(x.w), __builtin_bswap32(x.z), __builtin_bswap32(x.y), __builtin_bswap32(x.x));
+                    store_low_bytes(out + oc[u], x, ln);
+                }
+            }
+        }
+        const unsigned long long ib = __ballot(irregular);
+        constexpr unsigned long long gmask = G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
+        const bool redo = live && (!fast || ((ib >> (grp * G)) & gmask) != 0);
+        if (sub == 0 && live) {
+            if (redo) list[atomicAdd(list_n, 1)] = (int32_t)i;       // (the general kernel writes its answer and out_len)
+            else if (q.out_len) q.out_len[i] = take;
         }
     }
 }

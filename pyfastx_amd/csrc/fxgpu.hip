@@ -1870,7 +1870,21 @@ static int fetch_common(fx_handle *h, int where, int64_t n, bool by_id, const in
     // are only 3-6 % faster -- so what counts is how many queries a wave keeps in flight: 4 lanes (16 queries per wave, a 100-base
     // query in two steps of 64 bytes) 0.117 ms per 1 M, 8 lanes 0.134, 2 lanes 0.160, 16 lanes 0.225.
     static const int fetch_g = [] { const char *e = getenv("FX_FETCH_G"); return e ? atoi(e) : 4; }();
-    if (!longq && by_id && fetch_g == 4) {
+    static const bool lean = [] { const char *e = getenv("FX_FETCH_LEAN"); return !e || atoi(e) != 0; }();
+    if (!longq && by_id && fetch_g == 4 && lean && n < 0x7FFFFFFFll) {
+        // the line arithmetic alone (k_fetch_lines: few registers, many waves), then the general kernel over what it left over
+        int32_t *d_list = nullptr;
+        int *d_cnt = nullptr;
+        if ((rc = st.scratch<int32_t>(n, &d_list)) || (rc = st.scratch<int>(1, &d_cnt))) return rc;
+        HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(int), h->stream));
+        // (pieces of 16 bytes a lane has in flight: 1 -> 71 registers, 7 waves per SIMD, 0.104 ms per 1 M; 2 -> 85, 5 waves, 0.106;
+        // the general kernel alone, 102 registers: 0.113-0.121.  FX_FETCH_NP: experiments)
+        static const int np = [] { const char *e = getenv("FX_FETCH_NP"); return e ? atoi(e) : 1; }();
+        if (np == 1) FX_LAUNCH(h, K_FETCH, (k_fetch_lines<4, 1>), dim3(fetch_grid((n + 15) / 16)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst, d_list, d_cnt);
+        else         FX_LAUNCH(h, K_FETCH, (k_fetch_lines<4, 2>), dim3(fetch_grid((n + 15) / 16)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst, d_list, d_cnt);
+        hipLaunchKernelGGL((k_fetch<true, 4, 16>), dim3(std::min(fetch_grid((n + 15) / 16), 1024u)), dim3(BLOCK), 0, h->stream, h->d_data, h->base, h->n, q, tab, n, flags,
+                           d_dst, (const int32_t *)d_list, (const int *)d_cnt);
+    } else if (!longq && by_id && fetch_g == 4) {
         FX_LAUNCH(h, K_FETCH, (k_fetch<true, 4, 16>), dim3(fetch_grid((n + 15) / 16)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
     } else if (!longq && by_id && fetch_g == 2) {
         FX_LAUNCH(h, K_FETCH, (k_fetch<true, 2, 16>), dim3(fetch_grid((n + 31) / 32)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
