@@ -261,7 +261,7 @@ def write_gzindex(db, compressed_size, uncompressed_size, cmp_off=(), uncmp_off=
     (has-data = 0, which version-1 importers accept, util.c:621-651).  Single-stream gzip: the
     points captured while the stream was inflated (fx_gz_checkpoints) with their bits and windows --
     what the next open inflates in parallel from (read_gzindex -> fx_open_file_indexed).  Checkpoint
-    placement is not asserted by any reference test ("parity unpinned")."""
+    placement is not asserted by any reference test; offsets, bits and windows are: the compiled reference reads through them)."""
     n = len(cmp_off)
     bits = [0] * n if bits is None else [int(x) for x in bits]
     has_data = [0] * n if has_data is None else [int(x) for x in has_data]

@@ -7,7 +7,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 ( time timeout 900 python bench.py ) > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
-( time timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace -- python bench.py ) > $OUT/prof_bench.json 2> $OUT/prof.err
+( time timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace -- python bench.py --no-c3-file ) > $OUT/prof_bench.json 2> $OUT/prof.err
 DB=$(find $OUT/prof -name '*.db' | head -1)
 [ -n "$DB" ] && python tools/rocprof_summary.py $DB $OUT/kernel_stats.txt && grep 'fx::' $OUT/kernel_stats.txt
 rm -rf $OUT/prof
