@@ -564,6 +564,14 @@ def _host_truth(mm, G, g, a, b, neg):
 _COMP = bytes.maketrans(b"ACGTacgtMKRYVBHDmkryvbhdUu", b"TGCAtgcaKMYRBVDHkmyrbvdhAa")
 
 
+def _collective_name(job, backend):
+    if getattr(job, "fxcomm", None) is not None:
+        return "fx_comm: ncclAllGather (RCCL) on the library's own stream, under the C ABI (fx_fasta_build_sharded_begin)"
+    if backend == "nccl":
+        return "torch.distributed all_gather_into_tensor (RCCL)" + ("; fx_comm unavailable: %s" % job.fxcomm_error if getattr(job, "fxcomm_error", None) else "")
+    return "torch.distributed all_gather over %s (host path: the ranks share devices)" % backend
+
+
 def main_sharded(a, dev, rank, world, backend):
     """configs[4] shape: the pieces of all ranks form ONE file; rank r opens only bytes [size*r/N, size*(r+1)/N) of it
     (fx_open_file_range), scans them, and ONE all-gather of the 28-word summaries stitches the records that cross the cuts."""
@@ -758,7 +766,8 @@ def main_sharded(a, dev, rank, world, backend):
                                "range over %d GPUs; per GPU and step: index build of its range + all-gather of the boundary summaries + stitch + "
                                "%d random %d bp intervals (50%% '-' strand) on contigs it holds" % (world * a.gbp, world, a.gbp, len(gnames), world, a.queries, qlen),
                    "file_bytes": total, "file_bytes_per_gpu": int(job.n_bytes),
-                   "parallelism": "byte-range shards of one file x%d (each rank reads only its range), 1 all-gather (%s)" % (world, backend)},
+                   "parallelism": "byte-range shards of one file x%d (each rank reads only its range), 1 all-gather (%s)" % (world, backend),
+                   "collective": _collective_name(job, backend)},
         "index_build_s": round(t_index / a.steps, 6),
         "fetch_M_per_s": round(world * a.queries / max(fetch_ms * 1e-3, 1e-9) / 1e6, 2),
         "parity_verified_full_size": verified,
@@ -967,6 +976,7 @@ def strong_leg(a, dev, rank, world, backend, collective):
                     "whole stream, routed to the rank that holds their first byte" % (world, a.gbp, len(plan["names"]), nb / 1e9, world, a.queries, qlen),
         "Gbp_per_s": round(a.gbp / (el / a.steps), 3), "ms_per_step": round(ms, 4), "index_build_s": round(t_index / a.steps, 6),
         "file_bytes": nb, "file_bytes_per_gpu": int(job.n_bytes), "queries_per_gpu_max": int(n_max), "queries_crossing_a_cut": n_cross,
+        "collective": _collective_name(job, backend),
         "kernels_ms_avg": {k: round(v[0] / v[1], 4) for k, v in prof_all.items()},
         "roofline": {"kernel": "fx::k_span_scan<0>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": int(job.n_bytes),

@@ -2023,6 +2023,7 @@ extern "C" int fx_fetch_one(fx_handle *h, int64_t off, int64_t blen, int64_t ski
     if (!h->one_box) {
         HIPCHK(hipHostMalloc((void **)&h->one_box, sizeof(*h->one_box), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void **)&h->one_out, (size_t)ONE_CAP + 64, hipHostMallocDefault));
+        memset(h->one_out, 0, (size_t)ONE_CAP + 64);         // tags of the mailbox's answer pieces start out dead
     }
     // ---- the resident kernel: post the request in pinned memory, spin on the acknowledgement
     static const bool mb_env_off = [] { const char *e = getenv("FX_NO_MAILBOX"); return e && atoi(e) != 0; }();
@@ -2049,16 +2050,47 @@ extern "C" int fx_fetch_one(fx_handle *h, int64_t off, int64_t blen, int64_t ski
             // (a kernel that has left wrote state = 0 as its last act: the next one queues behind it on the same stream)
             bool ok = (h->mb_running && __atomic_load_n(&mb->state, __ATOMIC_ACQUIRE) != 0) || launch();
             const auto t0 = std::chrono::steady_clock::now();
+            // short answers come as a header piece + tagged 16-byte pieces, no acknowledgement word (fx_kernels.hpp: MB_TAGGED)
+            const bool tagged = take <= MB_TAGGED;
+            const uint8_t tag = (uint8_t)(n % 255ull + 1ull);
+            volatile uint8_t *const o = h->one_out;
+            int64_t tgot = -1;
+            auto answered = [&]() {
+                if (!tagged) return (__atomic_load_n(&mb->ack, __ATOMIC_ACQUIRE) >> 20) == n;
+                if (o[15] != tag) return false;
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                uint64_t seq;
+                uint32_t g;
+                memcpy(&g, (const void *)o, 4); memcpy(&seq, (const void *)(o + 4), 8);
+                if (seq != n || g > (uint32_t)take) return false;
+                const int np = (int)((g + 14u) / 15u);
+                for (int j = 1; j <= np; ++j) if (o[16 * j + 15] != tag) return false;       // a piece still on its way
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                tgot = (int64_t)g;
+                return true;
+            };
             for (unsigned spins = 0; ok; ++spins) {
-                if ((__atomic_load_n(&mb->ack, __ATOMIC_ACQUIRE) >> 20) == n) break;
+                if (answered()) break;
                 if ((spins & 63) == 63) {
                     // the kernel may have left between two requests: its stream is idle then, and the request unanswered
                     if (__atomic_load_n(&mb->state, __ATOMIC_ACQUIRE) != 1 && hipStreamQuery(h->mb_stream) == hipSuccess) {
-                        if ((__atomic_load_n(&mb->ack, __ATOMIC_ACQUIRE) >> 20) == n) break;
+                        if (answered()) break;
                         ok = launch();
                     }
                     if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2000)) ok = false;
                 }
+            }
+            if (ok && tagged) {
+                const int64_t got = tgot;
+                const int np = (int)((got + 14) / 15);
+                for (int j = 1; j <= np; ++j) {
+                    const int64_t b0 = 15ll * (j - 1);
+                    memcpy(dst + b0, (const void *)(o + 16 * j), (size_t)std::min<int64_t>(15, got - b0));
+                    o[16 * j + 15] = 0;                      // consumed: a stale piece never carries a live tag
+                }
+                o[15] = 0;
+                *out_len = got;
+                return FX_OK;
             }
             if (ok) {
                 const int64_t got = (int64_t)(mb->ack & 0xFFFFFull);

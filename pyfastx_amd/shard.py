@@ -273,10 +273,24 @@ class ShardedFasta:
         torch.distributed (all_gather_into_tensor on torch's stream, ordered against the handle's with stream events)."""
         if not self._collective() or self.comm_dev.type != "cuda" or os.environ.get("FX_COMM", "fx") == "torch":
             return False
-        if self.fxcomm is None:
+        if self.fxcomm is None and not getattr(self, "_fxcomm_failed", False):
             from . import _lib
-            self.fxcomm = _lib.Comm.from_process_group(self.dev.index)
-        return True
+            comm, err = None, ""
+            try:
+                comm = _lib.Comm.from_process_group(self.dev.index)
+            except Exception as e:                            # noqa: BLE001  (no RCCL to bind, ncclCommInitRank failed, ...)
+                err = str(e)
+            # all ranks take the same path: the library's communicator only if EVERY rank got one
+            ok = self._torch.tensor([1 if comm is not None else 0], dtype=self._torch.int32, device=self.comm_dev)
+            self._dist.all_reduce(ok, op=self._dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                self.fxcomm = comm
+            else:
+                if comm is not None:
+                    comm.close()
+                self._fxcomm_failed = True
+                self.fxcomm_error = err or "another rank could not create its communicator"
+        return self.fxcomm is not None
 
     @classmethod
     def from_file(cls, path, dev, rank, world, full_name=False, force_collective=False):
