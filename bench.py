@@ -1201,7 +1201,7 @@ def main():
                      "traffic_source": "profiles/pmc_k_span_scan.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this "
                                        "workload (counters cannot be read inside the run); null when the committed pass was on another size",
                      "algorithmic_bytes_per_launch": int(shard_bytes), "avg_launch_ms": round(scan_avg, 4)},
-        "roofline_fetch": {"kernel": "fx::k_fetch<true,4,16>", "bound": "hbm", "algorithmic_bytes_per_launch": fetch_alg,
+        "roofline_fetch": {"kernel": "fx::k_fetch_lines<4,1> (+ fx::k_fetch<true,4,16> over what it leaves over)", "bound": "hbm", "algorithmic_bytes_per_launch": fetch_alg,
                            "avg_launch_ms": round(fetch_ms, 4),
                            "frac": round(fetch_alg / max(fetch_ms * 1e-3, 1e-9) / 1e9 / HBM_PEAK_GBS, 4)},
     }
