@@ -753,7 +753,7 @@ def main_sharded(a, dev, rank, world, backend):
     if rank != 0:
         return None
     ms = el / a.steps * 1e3
-    fetch_ms = prof_all.get("k_fetch", (0.0, 1))[0] / max(prof_all.get("k_fetch", (0.0, 1))[1], 1)
+    fetch_ms = sum(prof_all.get(k, (0.0, 1))[0] / max(prof_all.get(k, (0.0, 1))[1], 1) for k in ("k_fetch", "k_fetch_rest"))
     scan_ms, scan_n = prof.get("k_span_scan", (0.0, 0))
     scan_avg = scan_ms / max(scan_n, 1)
     achieved = job.n_bytes / (scan_avg * 1e-3) / 1e9 if scan_avg > 0 else 0.0
@@ -1177,7 +1177,7 @@ def main():
 
     ms = el / a.steps * 1e3
     shard_bytes = job.n_bytes
-    fetch_ms = prof_all.get("k_fetch", (0.0, 1))[0] / max(prof_all.get("k_fetch", (0.0, 1))[1], 1)   # kernel time of one batch
+    fetch_ms = sum(prof_all.get(k, (0.0, 1))[0] / max(prof_all.get(k, (0.0, 1))[1], 1) for k in ("k_fetch", "k_fetch_rest"))   # kernel time of one batch: the line-arithmetic kernel + the general one over its leftovers
     scan_ms, scan_n = prof.get("k_span_scan", (0.0, 0))
     scan_avg = scan_ms / max(scan_n, 1)
     achieved = shard_bytes / (scan_avg * 1e-3) / 1e9 if scan_avg > 0 else 0.0

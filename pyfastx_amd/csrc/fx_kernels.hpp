@@ -626,13 +626,6 @@ struct Mailbox {
     unsigned int pad1[13];
 };
 constexpr int MB_OUT = 65536;        // longest answer the resident kernel stages (longer ones take the launch path)
-// Short answers (take <= MB_TAGGED: every getter of a few hundred bases) travel WITHOUT the acknowledgement word and the system
-// fence in front of it: the answer is cut into 16-byte pieces of 15 data bytes + 1 tag byte (the request number mod 255, + 1),
-// behind a 16-byte header piece {bytes of the answer, request number, tag}; the header and all pieces leave in ONE store
-// instruction of the wave, and the host takes the answer when the header carries its request number and EVERY piece it needs
-// carries the tag (pieces may arrive in any order; the host zeroes the tags it has consumed, so a stale piece never matches).
-// That removes one dependent trip over the bus per getter (data, fence, THEN the count).
-constexpr int MB_TAGGED = 15 * 63;
 
 // (relaxed: the request's fields arrive in the same load, and everything else the kernel reads is the immutable blob --
 // an acquire here would invalidate caches under every poll, for every kernel that runs beside this one)
@@ -713,22 +706,6 @@ __global__ __launch_bounds__(64) void k_mailbox(const uint8_t *__restrict__ data
         got = got < 0 ? 0 : (got > take ? take : got);
         __syncthreads();
         const int64_t delta = ((fl & 2) && got < take) ? take - got : 0;       // a reversed answer shorter than asked for sits too high
-        if (f[3] <= MB_TAGGED) {                             // header + tagged pieces, one store, no fence, no acknowledgement word
-            const uint32_t tag = (uint32_t)(r % 255ull) + 1u;
-            uint4 v = make_uint4((uint32_t)got, (uint32_t)r, (uint32_t)(r >> 32), tag << 24);
-            if (lane > 0) {
-                uint32_t w[4] = {0, 0, 0, tag << 24};
-                const int64_t b0 = 15 * (int64_t)(lane - 1);
-                for (int k = 0; k < 15; ++k)
-                    if (b0 + k < got) w[k >> 2] |= (uint32_t)s_out[delta + b0 + k] << ((k & 3) * 8);
-                v = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-            if ((int64_t)lane * 15 < got + 15) *reinterpret_cast<uint4 *>(out_host + 16 * lane) = v;
-            __syncthreads();
-            served = r;
-            idle = 0;
-            continue;
-        }
         for (int64_t j = (int64_t)lane * 16; j < got; j += 64 * 16) {
             uint4 v;
             if (delta == 0) v = *reinterpret_cast<const uint4 *>(s_out + j);

@@ -184,10 +184,10 @@ static void crc_tables(CrcTables *T) {
 }
 
 enum KernelId { K_SPAN_SCAN = 0, K_GRAN_REDUCE, K_GRAN_PREFIX, K_HDR_REC, K_GRAN_LINES, K_GRAN_EXACT, K_FASTA_FINALIZE, K_FETCH,
-                K_FASTA_COMP, K_FASTA_COMP_EDGE, K_FASTA_COMP_SMALL, K_FASTQ_LINES, K_FASTQ_ROWS, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_BGZF_CRC, K_SCAN_COMP, K_COMP_ATTRIBUTE, K_BGZF_SERIAL, K_NKERN };
+                K_FASTA_COMP, K_FASTA_COMP_EDGE, K_FASTA_COMP_SMALL, K_FASTQ_LINES, K_FASTQ_ROWS, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_BGZF_CRC, K_SCAN_COMP, K_COMP_ATTRIBUTE, K_BGZF_SERIAL, K_FETCH_REST, K_NKERN };
 static const char *const kKernelNames[K_NKERN] = {
     "k_span_scan", "k_gran_reduce", "k_gran_prefix", "k_hdr_rec", "k_gran_lines", "k_gran_exact", "k_fasta_finalize", "k_fetch",
-    "k_fasta_comp", "k_fasta_comp_edge", "k_fasta_comp_small", "k_fastq_lines", "k_fastq_rows", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy", "k_bgzf_crc", "k_scan_comp", "k_comp_attribute", "k_bgzf_decode_serial"};
+    "k_fasta_comp", "k_fasta_comp_edge", "k_fasta_comp_small", "k_fastq_lines", "k_fastq_rows", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy", "k_bgzf_crc", "k_scan_comp", "k_comp_attribute", "k_bgzf_decode_serial", "k_fetch_rest"};
 
 struct Prof {
     bool on = false;
@@ -1882,8 +1882,8 @@ static int fetch_common(fx_handle *h, int where, int64_t n, bool by_id, const in
         static const int np = [] { const char *e = getenv("FX_FETCH_NP"); return e ? atoi(e) : 1; }();
         if (np == 1) FX_LAUNCH(h, K_FETCH, (k_fetch_lines<4, 1>), dim3(fetch_grid((n + 15) / 16)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst, d_list, d_cnt);
         else         FX_LAUNCH(h, K_FETCH, (k_fetch_lines<4, 2>), dim3(fetch_grid((n + 15) / 16)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst, d_list, d_cnt);
-        hipLaunchKernelGGL((k_fetch<true, 4, 16>), dim3(std::min(fetch_grid((n + 15) / 16), 1024u)), dim3(BLOCK), 0, h->stream, h->d_data, h->base, h->n, q, tab, n, flags,
-                           d_dst, (const int32_t *)d_list, (const int *)d_cnt);
+        FX_LAUNCH(h, K_FETCH_REST, (k_fetch<true, 4, 16>), dim3(std::min(fetch_grid((n + 15) / 16), 1024u)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags,
+                  d_dst, (const int32_t *)d_list, (const int *)d_cnt);
     } else if (!longq && by_id && fetch_g == 4) {
         FX_LAUNCH(h, K_FETCH, (k_fetch<true, 4, 16>), dim3(fetch_grid((n + 15) / 16)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
     } else if (!longq && by_id && fetch_g == 2) {
@@ -2023,7 +2023,6 @@ extern "C" int fx_fetch_one(fx_handle *h, int64_t off, int64_t blen, int64_t ski
     if (!h->one_box) {
         HIPCHK(hipHostMalloc((void **)&h->one_box, sizeof(*h->one_box), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void **)&h->one_out, (size_t)ONE_CAP + 64, hipHostMallocDefault));
-        memset(h->one_out, 0, (size_t)ONE_CAP + 64);         // tags of the mailbox's answer pieces start out dead
     }
     // ---- the resident kernel: post the request in pinned memory, spin on the acknowledgement
     static const bool mb_env_off = [] { const char *e = getenv("FX_NO_MAILBOX"); return e && atoi(e) != 0; }();
@@ -2050,25 +2049,7 @@ extern "C" int fx_fetch_one(fx_handle *h, int64_t off, int64_t blen, int64_t ski
             // (a kernel that has left wrote state = 0 as its last act: the next one queues behind it on the same stream)
             bool ok = (h->mb_running && __atomic_load_n(&mb->state, __ATOMIC_ACQUIRE) != 0) || launch();
             const auto t0 = std::chrono::steady_clock::now();
-            // short answers come as a header piece + tagged 16-byte pieces, no acknowledgement word (fx_kernels.hpp: MB_TAGGED)
-            const bool tagged = take <= MB_TAGGED;
-            const uint8_t tag = (uint8_t)(n % 255ull + 1ull);
-            volatile uint8_t *const o = h->one_out;
-            int64_t tgot = -1;
-            auto answered = [&]() {
-                if (!tagged) return (__atomic_load_n(&mb->ack, __ATOMIC_ACQUIRE) >> 20) == n;
-                if (o[15] != tag) return false;
-                __atomic_thread_fence(__ATOMIC_ACQUIRE);
-                uint64_t seq;
-                uint32_t g;
-                memcpy(&g, (const void *)o, 4); memcpy(&seq, (const void *)(o + 4), 8);
-                if (seq != n || g > (uint32_t)take) return false;
-                const int np = (int)((g + 14u) / 15u);
-                for (int j = 1; j <= np; ++j) if (o[16 * j + 15] != tag) return false;       // a piece still on its way
-                __atomic_thread_fence(__ATOMIC_ACQUIRE);
-                tgot = (int64_t)g;
-                return true;
-            };
+            auto answered = [&]() { return (__atomic_load_n(&mb->ack, __ATOMIC_ACQUIRE) >> 20) == n; };
             for (unsigned spins = 0; ok; ++spins) {
                 if (answered()) break;
                 if ((spins & 63) == 63) {
@@ -2079,18 +2060,6 @@ extern "C" int fx_fetch_one(fx_handle *h, int64_t off, int64_t blen, int64_t ski
                     }
                     if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2000)) ok = false;
                 }
-            }
-            if (ok && tagged) {
-                const int64_t got = tgot;
-                const int np = (int)((got + 14) / 15);
-                for (int j = 1; j <= np; ++j) {
-                    const int64_t b0 = 15ll * (j - 1);
-                    memcpy(dst + b0, (const void *)(o + 16 * j), (size_t)std::min<int64_t>(15, got - b0));
-                    o[16 * j + 15] = 0;                      // consumed: a stale piece never carries a live tag
-                }
-                o[15] = 0;
-                *out_len = got;
-                return FX_OK;
             }
             if (ok) {
                 const int64_t got = (int64_t)(mb->ack & 0xFFFFFull);
