@@ -311,6 +311,17 @@ int fx_revcomp(int device, int where, uint8_t *buf, int64_t n, int mode);
 int fx_gz_points(fx_handle *h, int64_t spacing, int64_t *cmp_off, int64_t *uncmp_off, int64_t cap,
                  int64_t *n_out, int64_t *compressed_size);
 
+/* The first open of a single gzip stream runs on all cores of the host (fx_pgzip.hpp: block starts searched behind T cuts
+ * of the compressed bytes, the pieces decoded with markers for the 32 KiB in front of them, resolved in order; CRC-32 and
+ * ISIZE checked; restart points captured) -- zran_build_index's serial pass (util.c:728-742, index.c:383) in parallel.
+ * fx_open_file uses it by itself (FX_GZIP_SERIAL=1: zlib on one core, as before); this entry is the same code without
+ * a device: 0 done, 1 not a case for it (small file, several members, nothing it is sure of: inflate serially),
+ * FX_ERANGE when `out` is too small (*out_n then says how much is needed). */
+int fx_gunzip_parallel(const uint8_t *in, int64_t n, int threads, uint8_t *out, int64_t cap, int64_t *out_n, int64_t *n_points);
+/* how the open that made this handle inflated a gzip input: 0 plain, 1 BGZF on the device, 2 one stream serially (zlib),
+ * 3 one stream on all host cores, 4 from the restart points of its index file (diagnostics) */
+int fx_gz_open_mode(const fx_handle *h);
+
 /* How the members of a BGZF file were inflated by the open that made this handle: out = {members, members the
  * wave-per-member decoder handed over to the serial one, INFL_RETRY + reason of the first of those} (fx_inflate_par.hpp:
  * the lanes of a wave start at 64 bit positions of a member and fall into step by Huffman self-synchronisation; anything

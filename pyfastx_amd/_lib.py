@@ -51,7 +51,7 @@ SYMBOLS = [
     "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
     "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
     "fx_comm_unique_id", "fx_comm_init", "fx_comm_destroy", "fx_comm_rank", "fx_comm_world", "fx_comm_allgather", "fx_fasta_build_sharded_begin",
-    "fx_fasta_build_sharded", "fx_comm_summaries", "fx_fastq_build_sharded", "fx_bgzf_counts", "fx_sort_packed_names",
+    "fx_fasta_build_sharded", "fx_comm_summaries", "fx_fastq_build_sharded", "fx_bgzf_counts", "fx_sort_packed_names", "fx_gunzip_parallel", "fx_gz_open_mode",
 ]
 
 
@@ -187,6 +187,8 @@ def lib():
     L.fx_comm_summaries.argtypes = [vp, vp, vp]
     L.fx_fastq_build_sharded.argtypes = [vp, vp, vp]
     L.fx_bgzf_counts.argtypes = [vp, vp]
+    L.fx_gz_open_mode.argtypes = [vp]
+    L.fx_gunzip_parallel.argtypes = [vp, i64, i32, vp, i64, C.POINTER(i64), C.POINTER(i64)]
     L.fx_sort_packed_names.argtypes = [i32, vp, vp, i64, vp, C.POINTER(i64)]
     for s in SYMBOLS:
         if getattr(L, s).restype is C.c_int:
@@ -204,6 +206,25 @@ def sort_packed_names(packed, name_off, device=0):
     nd = C.c_int64(0)
     check(lib().fx_sort_packed_names(int(device), _ptr(packed) if packed.size else None, _ptr(name_off), n, _ptr(order) if n > 0 else None, C.byref(nd)))
     return order, int(nd.value)
+
+
+def gunzip_parallel(gz, threads=8):
+    """fx_gunzip_parallel (host only): the inflated bytes of ONE gzip member and the number of restart points it found, or
+    None when the parallel decoder declines (small input, several members, anything it is not sure of)."""
+    src = np.frombuffer(gz, dtype=np.uint8)
+    n, npts = C.c_int64(0), C.c_int64(0)
+    cap = max(len(gz) * 8, 1 << 20)
+    for _ in range(2):
+        out = np.empty(cap, dtype=np.uint8)
+        rc = lib().fx_gunzip_parallel(src.ctypes.data, src.size, int(threads), out.ctypes.data, cap, C.byref(n), C.byref(npts))
+        if rc == 1:
+            return None
+        if rc == FX_ERANGE and n.value > cap:
+            cap = int(n.value)
+            continue
+        check(rc)
+        return out[:n.value].tobytes(), int(npts.value)
+    raise FxError(FX_ERANGE, "output did not fit twice")
 
 
 def stream_size(path):
@@ -384,6 +405,11 @@ class Blob:
         if n.value:
             check(lib().fx_gz_points(self._h, spacing, a.ctypes.data, b.ctypes.data, n.value, C.byref(n), C.byref(cs)))
         return a, b, cs.value
+
+    @property
+    def gz_open_mode(self):
+        """0 plain, 1 BGZF on the device, 2 one gzip stream serially, 3 one stream on all host cores, 4 from restart points."""
+        return int(lib().fx_gz_open_mode(self._h))
 
     def bgzf_counts(self):
         """(members, members handed over to the serial decoder, reason of the first) of the open that made this blob."""

@@ -33,6 +33,7 @@
 #include "fx_inflate.hpp"
 #include "fx_inflate_par.hpp"
 #include "fx_fxi.hpp"
+#include "fx_pgzip.hpp"
 #include "fx_sort.hpp"
 
 using namespace fx;
@@ -295,6 +296,7 @@ struct fx_handle {
     bool bgzf = false;
     int64_t bgzf_members = 0, bgzf_handed_over = 0;    // members inflated by this open; of them, decoded by the serial kernel
     int bgzf_reason = 0;                               // INFL_RETRY + reason of the first member handed over (fx_inflate_par.hpp)
+    int gz_mode = 0;                                   // how a gzip input was inflated: 1 BGZF on the device, 2 one stream serially (zlib), 3 one stream on all host cores (fx_pgzip.hpp), 4 from the restart points of its index
     // restart points of a single gzip stream (captured while it is inflated: GzSerial below)
     std::vector<int64_t> gzp_cin, gzp_cout;
     std::vector<uint8_t> gzp_bits, gzp_has, gzp_win;          // gzp_win: GZ_WINDOW bytes per point that has data, in order
@@ -714,6 +716,7 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
                                                        : "BGZF member %lld of %s (offset %lld) failed to inflate: code %d",
                         (long long)m, path, (long long)t.moff[m], status[m]);
     h->bgzf = true;
+    h->gz_mode = 1;
     h->gz_moff = full.moff; h->gz_coff = full.coff; h->gz_uoff = full.uoff; h->gz_csize = fsize_all;
     return FX_OK;
 }
@@ -1007,6 +1010,7 @@ static int open_file_impl(const char *path, int device, fx_handle **out, int64_t
                 (void)munmap(mp, (size_t)fsize);
                 h->gzp_cin.assign(p_cin, p_cin + npts); h->gzp_cout.assign(p_cout, p_cout + npts);
                 h->gzp_bits.assign(p_bits, p_bits + npts); h->gzp_has.assign(p_has, p_has + npts);
+                h->gz_mode = 4;
                 close(fd);
                 if (hipStreamSynchronize(h->stream) != hipSuccess) { fx_close(h); return fail(FX_EDEVICE, "stream sync failed"); }
                 *out = h;
@@ -1014,7 +1018,60 @@ static int open_file_impl(const char *path, int device, fx_handle **out, int64_t
             }
             if (prc < 0) { (void)munmap(mp, (size_t)fsize); return bail(prc); }
         }
-        // ... without (or with points that do not fit): serial (zlib on the host), the inflated bytes stream through a
+        // ... without: the first open on all cores of the host (fx_pgzip.hpp: block starts searched behind T cuts, the pieces
+        // decoded with markers for what lies in front of them, resolved in order) straight into pinned pieces and HBM, with the
+        // restart points for the index file; anything it is not sure of -> the serial path below.
+        static const bool no_par = [] { const char *e = getenv("FX_GZIP_SERIAL"); return e && atoi(e) != 0; }();
+        if (npts <= 0 && !no_par && fsize >= (32ll << 20) && fsize <= (6ll << 30)) {
+            struct Wk { uint8_t *pin[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool used[2] = {false, false}; hipStream_t st = nullptr; int slot = 0; };
+            std::vector<Wk> wk;
+            std::atomic<int> dev_err(0);
+            auto alloc = [&](uint64_t total, int workers) {
+                if (alloc_blob(h, (int64_t)total) || hipStreamSynchronize(h->stream) != hipSuccess) return false;
+                wk.resize((size_t)workers);
+                return true;
+            };
+            auto sink = [&](int w, uint64_t off, const uint8_t *data, size_t len) {
+                Wk &k = wk[(size_t)w];
+                if (!k.st) {                                  // first piece of this worker thread: its stream, events, pinned pieces
+                    if (hipSetDevice(h->device) != hipSuccess) { dev_err.store(1); return false; }
+                    k.pin[0] = g_pins.get(); k.pin[1] = g_pins.get();
+                    if (!k.pin[0] || !k.pin[1] || hipStreamCreateWithFlags(&k.st, hipStreamNonBlocking) != hipSuccess ||
+                        hipEventCreateWithFlags(&k.ev[0], hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&k.ev[1], hipEventDisableTiming) != hipSuccess) { dev_err.store(1); return false; }
+                }
+                for (size_t a = 0; a < len; a += (size_t)PIECE_BYTES) {
+                    const size_t m = std::min<size_t>((size_t)PIECE_BYTES, len - a);
+                    if (k.used[k.slot] && hipEventSynchronize(k.ev[k.slot]) != hipSuccess) { dev_err.store(1); return false; }
+                    memcpy(k.pin[k.slot], data + a, m);
+                    if (hipMemcpyAsync(h->d_data + off + a, k.pin[k.slot], m, hipMemcpyHostToDevice, k.st) != hipSuccess ||
+                        hipEventRecord(k.ev[k.slot], k.st) != hipSuccess) { dev_err.store(1); return false; }
+                    k.used[k.slot] = true;
+                    k.slot ^= 1;
+                }
+                return true;
+            };
+            pgz::Result res;
+            const int T = (int)std::max(2u, std::min(128u, std::thread::hardware_concurrency() / 2));
+            const bool ok = pgz::inflate_parallel((const uint8_t *)mp, (uint64_t)fsize, T, (uint64_t)GZ_SPACING, alloc, sink, res);
+            for (Wk &k : wk) {
+                if (k.st) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(k.st); (void)hipStreamDestroy(k.st); }
+                for (int i = 0; i < 2; ++i) { if (k.ev[i]) (void)hipEventDestroy(k.ev[i]); if (k.pin[i]) g_pins.put(k.pin[i]); }
+            }
+            if (dev_err.load()) { (void)munmap(mp, (size_t)fsize); return bail(fail(FX_EDEVICE, "staging the inflated pieces of %s failed", path)); }
+            if (ok) {
+                (void)munmap(mp, (size_t)fsize);
+                h->gzp_cin.assign(res.pt_cin.begin(), res.pt_cin.end()); h->gzp_cout.assign(res.pt_cout.begin(), res.pt_cout.end());
+                h->gzp_bits = res.pt_bits; h->gzp_has = res.pt_has; h->gzp_win = std::move(res.pt_win);
+                h->gz_mode = 3;
+                close(fd);
+                if (hipStreamSynchronize(h->stream) != hipSuccess) { fx_close(h); return fail(FX_EDEVICE, "stream sync failed"); }
+                *out = h;
+                return FX_OK;
+            }
+            if (h->d_data && h->owns) { (void)hipFree(h->d_data); h->d_data = nullptr; h->owns = false; h->n = 0; }   // (it had got as far as the blob)
+        }
+        // ... else (or with points that do not fit): serial (zlib on the host), the inflated bytes stream through a
         // pinned ring into a growing blob and the restart points are captured on the way.
         rc = st_.init();
         if (rc) { (void)munmap(mp, (size_t)fsize); return bail(rc); }
@@ -1051,6 +1108,7 @@ static int open_file_impl(const char *path, int device, fx_handle **out, int64_t
         }
         (void)munmap(mp, (size_t)fsize);
         h->d_data = d; h->owns = true; h->n = n;
+        h->gz_mode = 2;
         e = hipMemsetAsync(d + n, 0, (size_t)(cap + 2 * TILE - n), h->stream);
         if (e != hipSuccess) return bail(fail(FX_EDEVICE, "memset: %s", hipGetErrorString(e)));
     }
@@ -2421,6 +2479,25 @@ extern "C" int fx_gz_points(fx_handle *h, int64_t spacing, int64_t *cmp_off, int
     *n_out = n;
     return FX_OK;
 }
+
+// fx_pgzip.hpp without a device (tests, tools): the whole gzip file `in` -> `out` (cap bytes); 0 done, 1 "not a case for it"
+// (too small, several members, no block start found, ...: the caller inflates serially), FX_ERANGE when out is too small.
+extern "C" int fx_gunzip_parallel(const uint8_t *in, int64_t n, int threads, uint8_t *out, int64_t cap, int64_t *out_n, int64_t *n_points) {
+    if (!in || n < 0 || !out_n) return fail(FX_EINVAL, "bad argument");
+    std::vector<uint8_t> padded((size_t)n + 16, 0);           // (the decoder looks 8 bytes past the positions it reads)
+    memcpy(padded.data(), in, (size_t)n);
+    pgz::Result res;
+    bool small = false;
+    const bool ok = pgz::inflate_parallel(padded.data(), (uint64_t)n, threads > 1 ? threads : 2, (uint64_t)GZ_SPACING,
+        [&](uint64_t total, int) { *out_n = (int64_t)total; small = (int64_t)total > cap || !out; return !small; },
+        [&](int, uint64_t off, const uint8_t *d, size_t len) { memcpy(out + off, d, len); return true; }, res);
+    if (small) return fail(FX_ERANGE, "the stream inflates to %lld bytes", (long long)*out_n);
+    if (!ok) return 1;
+    if (n_points) *n_points = (int64_t)res.pt_cin.size();
+    return FX_OK;
+}
+
+extern "C" int fx_gz_open_mode(const fx_handle *h) { return h ? h->gz_mode : 0; }
 
 extern "C" int fx_bgzf_counts(fx_handle *h, int64_t out[3]) {
     if (!h || !out) return fail(FX_EINVAL, "null argument");

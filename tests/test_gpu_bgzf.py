@@ -268,6 +268,69 @@ def test_single_stream_gzip_checkpoints(L, tmp_path, shape):
     assert bb.read_bytes(0, len(raw)) == raw and bb.gz_checkpoints()["windows"].size == (n - 1) * 32768
 
 
+def test_first_open_of_a_large_single_stream_runs_on_all_cores(L, tmp_path):
+    """A single gzip stream of >= 32 MiB is inflated by fx_pgzip.hpp on its FIRST open (mode 3; the serial zlib pass of round 2
+    is mode 2): the bytes are the input's, the restart points it captured on the way are valid zran points -- the second open
+    inflates from them in parallel (mode 4) and sees the same stream, and the compiled reference reads its slices THROUGH them."""
+    import glob
+    import sys
+    import zlib
+    from conftest import ROOT
+    rng = np.random.default_rng(77)
+    parts = []
+    for i in range(24):
+        parts.append(b">rec%d some description\n" % i)
+        s = bytes(rng.choice(list(b"ACGTNacgtn"), int(rng.integers(3_000_000, 6_000_000))).astype(np.uint8))
+        parts.append(b"\n".join(s[p:p + 70] for p in range(0, len(s), 70)) + b"\n")
+    raw = b"".join(parts)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    gz = co.compress(raw) + co.flush()
+    assert len(gz) >= 32 << 20
+    p = _write(tmp_path, "large.fa.gz", gz)
+    b = L.Blob.from_file(p)
+    assert b.gz_open_mode == 3 and b.size == len(raw)
+    for a in (0, len(raw) // 3, len(raw) - 5_000_000):
+        assert b.read_bytes(a, 5_000_000) == raw[a:a + 5_000_000]
+    pts = b.gz_checkpoints()
+    n = pts["cmp"].size
+    assert n >= len(raw) // (2 << 20) and pts["uncmp"][0] == 0 and pts["has"][0] == 0 and int(pts["has"].sum()) == n - 1
+    assert (np.diff(pts["uncmp"]) >= 1048576).all() and pts["windows"].size == (n - 1) * 32768
+    k = 0
+    for i in range(n):                                         # every point the way zran uses it (those on a byte boundary: python has no inflatePrime)
+        c, u, bits = int(pts["cmp"][i]), int(pts["uncmp"][i]), int(pts["bits"][i])
+        d = zlib.decompressobj(-15)
+        if pts["has"][i]:
+            win = pts["windows"][k * 32768:(k + 1) * 32768].tobytes()
+            k += 1
+            assert win == raw[u - 32768:u]
+            d = zlib.decompressobj(-15, zdict=win)
+        if bits == 0:
+            got = d.decompress(gz[c:c + 200_000], 50_000)
+            assert got == raw[u:u + len(got)] and len(got) > 0
+    del b
+    import pyfastx_amd as fx
+    fa = fx.Fasta(p)                                           # first open again (no index yet): parallel, writes the points
+    assert fa._st.blob.gz_open_mode == 3
+    del fa
+    fb = fx.Fasta(p)
+    some = [fb[5][1000:1400].seq, fb[23][-300:].antisense, fb[0][:80].seq]
+    assert fb._st.blob.gz_open_mode == 4 and fb._st.blob.read_bytes(len(raw) - 1000, 1000) == raw[-1000:]
+    if not glob.glob(os.path.join(ROOT, "oracle", "_ref", "pyfastx*.so")):
+        pytest.fail("oracle/_ref is missing")
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
+    import pyfastx
+    so, stats, hits = _shim(pyfastx)
+    so.fxshim_reset()
+    rf = pyfastx.Fasta(p)
+    assert [rf[5][1000:1400].seq, rf[23][-300:].antisense, rf[0][:80].seq] == some
+    for _ in range(300):
+        kk = int(rng.integers(0, 24))
+        a = int(rng.integers(0, len(rf[kk]) - 500))
+        assert rf[kk][a:a + 300].seq == fb[kk][a:a + 300].seq
+    st = stats()
+    assert st["errors"] == 0 and st["built_points"] == 0 and st["from_point"] >= 200
+
+
 def _shim(pyfastx):
     """The counters of the compiled reference's zran work-alike (oracle/refshim/zran.c), through ctypes."""
     import ctypes

@@ -1082,3 +1082,64 @@ def test_shard_route_equals_the_vectorised_statement(seed):
     ids[n // 2] = nrec
     with pytest.raises(_lib.FxError):
         _lib.shard_route(ids, a, b, cols, bases, ends)
+
+
+def _gz_text(rng, n):
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.choice(4, n, p=[.295, .205, .205, .295])]
+    low = np.repeat(rng.random(n // 5000 + 1) < 0.4, 5000)[:n]
+    letters = np.where(low, letters + 32, letters).astype(np.uint8)
+    letters[n // 3:n // 3 + 200_000] = ord("N")
+    rows = letters[:n - n % 60].reshape(-1, 60)
+    return b">chr1 first\n" + b"\n".join(r.tobytes() for r in rows) + b"\n"
+
+
+@pytest.mark.parametrize("shape", ["level6", "level1", "level9", "stored_inside", "fastq"])
+def test_parallel_gunzip_equals_zlib(shape):
+    """fx_pgzip.hpp (the first open of a single gzip stream on all cores; host code, no device): block starts searched behind
+    the cuts, pieces decoded with markers for the 32 KiB in front of them, resolved in order -- the bytes are zlib's, for
+    three compression levels, a stream with stored blocks in the middle (the pieces decode through them), FASTQ text."""
+    import zlib
+    from pyfastx_amd import _lib
+    rng = np.random.default_rng(len(shape))
+    if shape == "fastq":
+        n = 150_000
+        seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (n, 150))]
+        qual = rng.integers(35, 71, (n, 150)).astype(np.uint8)
+        nl = np.full((n, 1), 10, dtype=np.uint8)
+        hdr = np.frombuffer(b"".join(b"@SYN:1:FC:%07d 1:N:0\n" % i for i in range(n)), dtype=np.uint8).reshape(n, -1)
+        plus = np.tile(np.frombuffer(b"+\n", dtype=np.uint8), (n, 1))
+        raw = np.concatenate([hdr, seq, nl, plus, qual, nl], axis=1).tobytes()
+    else:
+        raw = _gz_text(rng, 36_000_000)
+    if shape == "stored_inside":                              # incompressible bytes in the middle: zlib emits stored blocks
+        raw = raw[:9_000_000] + bytes(rng.integers(0, 256, 3_000_000, dtype=np.uint8)) + raw[9_000_000:]
+    level = {"level1": 1, "level9": 9}.get(shape, 6)
+    co = zlib.compressobj(level, zlib.DEFLATED, 31)
+    gz = co.compress(raw) + co.flush()
+    assert len(gz) > 8 << 20                                  # several pieces of >= 4 MiB
+    got = _lib.gunzip_parallel(gz, threads=6)
+    assert got is not None, shape
+    out, npts = got
+    assert out == raw and npts >= 1 + len(raw) // (4 << 20)
+
+
+def test_parallel_gunzip_declines_what_it_is_not_sure_of():
+    """Small inputs, several members, a damaged trailer or a flipped bit: None (the caller inflates serially, and zlib names
+    the error), never wrong bytes."""
+    import zlib
+    from pyfastx_amd import _lib
+    rng = np.random.default_rng(9)
+    raw = _gz_text(rng, 30_000_000)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    gz = co.compress(raw) + co.flush()
+    assert _lib.gunzip_parallel(gz[:3 << 20] + gz[-8:], 4) is None           # too small / cut short
+    two = zlib.compressobj(6, zlib.DEFLATED, 31)
+    second = two.compress(b">x\nACGT\n") + two.flush()
+    assert _lib.gunzip_parallel(gz + second, 4) is None                     # two members: gzread semantics are the serial path's
+    bad = bytearray(gz)
+    bad[-6] ^= 0x40                                                          # the CRC-32 of the trailer
+    assert _lib.gunzip_parallel(bytes(bad), 4) is None
+    bad = bytearray(gz)
+    bad[len(gz) // 2] ^= 0x10                                                # a bit of the deflate data
+    got = _lib.gunzip_parallel(bytes(bad), 4)
+    assert got is None or got[0] == raw                                      # (only if the flipped bit happened to change nothing)
