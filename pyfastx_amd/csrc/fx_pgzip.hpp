@@ -469,33 +469,51 @@ static bool inflate_parallel(const uint8_t *in, uint64_t n, int threads, uint64_
     uint32_t crc = pc[(size_t)live[0]].crc;
     for (size_t k = 1; k < live.size(); ++k) crc = (uint32_t)crc32_combine(crc, pc[(size_t)live[k]].crc, (z_off_t)pc[(size_t)live[k]].sym.size());
     if (crc != want_crc) return false;
-    // ---- restart points: the start of the deflate data, every piece start, the marks inside the pieces
+    // ---- restart points: the start of the deflate data, piece starts and the block boundaries marked inside the pieces, at
+    // least `spacing` bytes of output apart (which ones: in order; their 32 KiB windows: in parallel)
     res.out_bytes = total;
-    auto add_point = [&](uint64_t bit, uint64_t out, const uint8_t *w32k) {
-        res.pt_cin.push_back((bit + 7) >> 3);
-        res.pt_bits.push_back((uint8_t)((8 - (bit & 7)) & 7));
-        res.pt_cout.push_back(out);
-        res.pt_has.push_back(w32k ? 1 : 0);
-        if (w32k) res.pt_win.insert(res.pt_win.end(), w32k, w32k + WIN);
-    };
-    // windows of points inside a piece need that piece's bytes: resolve the 32 KiB in front of each mark
-    for (size_t k = 0; k < live.size(); ++k) {
-        const Piece &P = pc[(size_t)live[k]];
-        const std::vector<uint8_t> &Wn = win[k];
-        const size_t base = WIN - Wn.size();
-        auto byte_at = [&](int64_t i) -> uint8_t {            // byte i of the piece's output (i < 0: the window in front of it)
-            if (i < 0) { const int64_t j = (int64_t)Wn.size() + i; return j >= 0 ? Wn[(size_t)j] : 0; }
-            const uint16_t s = P.sym[(size_t)i];
-            return (s & 0x8000u) ? Wn[(s & 0x7FFFu) - base] : (uint8_t)s;
-        };
-        if (k == 0) add_point(P.start_bit, 0, nullptr);
-        else if (P.out_base - res.pt_cout.back() >= spacing && Wn.size() == (size_t)WIN) add_point(P.start_bit, P.out_base, Wn.data());
-        std::vector<uint8_t> w((size_t)WIN);
-        for (const Point &mk : P.marks) {
-            if (P.out_base + mk.out - res.pt_cout.back() < spacing || P.out_base + mk.out < (uint64_t)WIN) continue;
-            for (int i = 0; i < WIN; ++i) w[(size_t)i] = byte_at((int64_t)mk.out - WIN + i);
-            add_point(mk.bit, P.out_base + mk.out, w.data());
+    struct Acc { size_t k; uint64_t bit, out_rel; bool at_start; };
+    std::vector<Acc> acc;
+    {
+        uint64_t last_out = 0;
+        for (size_t k = 0; k < live.size(); ++k) {
+            const Piece &P = pc[(size_t)live[k]];
+            if (k == 0) acc.push_back(Acc{0, P.start_bit, 0, true});
+            else if (P.out_base - last_out >= spacing && win[k].size() == (size_t)WIN) { acc.push_back(Acc{k, P.start_bit, 0, true}); last_out = P.out_base; }
+            for (const Point &mk : P.marks) {
+                if (P.out_base + mk.out - last_out < spacing || P.out_base + mk.out < (uint64_t)WIN) continue;
+                acc.push_back(Acc{k, mk.bit, mk.out, false});
+                last_out = P.out_base + mk.out;
+            }
         }
+    }
+    const size_t np = acc.size();
+    res.pt_cin.resize(np); res.pt_cout.resize(np); res.pt_bits.resize(np); res.pt_has.resize(np);
+    res.pt_win.resize((np - 1) * (size_t)WIN);
+    {
+        std::atomic<size_t> nextp(0);
+        std::vector<std::thread> th;
+        for (int wkr = 0; wkr < W; ++wkr)
+            th.emplace_back([&]() {
+                for (size_t i; (i = nextp.fetch_add(1)) < np;) {
+                    const Acc &A = acc[i];
+                    const Piece &P = pc[(size_t)live[A.k]];
+                    const std::vector<uint8_t> &Wn = win[A.k];
+                    const size_t base = WIN - Wn.size();
+                    res.pt_cin[i] = (A.bit + 7) >> 3;
+                    res.pt_bits[i] = (uint8_t)((8 - (A.bit & 7)) & 7);
+                    res.pt_cout[i] = P.out_base + A.out_rel;
+                    res.pt_has[i] = i ? 1 : 0;
+                    if (!i) continue;
+                    uint8_t *w = res.pt_win.data() + (i - 1) * (size_t)WIN;
+                    for (int j = 0; j < WIN; ++j) {           // byte out_rel - WIN + j of the piece's output (< 0: the window in front of it)
+                        const int64_t q = (int64_t)A.out_rel - WIN + j;
+                        if (q < 0) { const int64_t jj = (int64_t)Wn.size() + q; w[j] = jj >= 0 ? Wn[(size_t)jj] : 0; }
+                        else { const uint16_t sy = P.sym[(size_t)q]; w[j] = (sy & 0x8000u) ? Wn[(sy & 0x7FFFu) - base] : (uint8_t)sy; }
+                    }
+                }
+            });
+        for (auto &x : th) x.join();
     }
     lap("restart points");
     return true;
