@@ -47,8 +47,9 @@ struct PTab {
     int cnt[16];
     int tmp[32];                                                        // p_header's small arrays (private arrays would be selected out of ~40 registers)
     int hdr[8];                                                         // lane 0 -> wave: status, nlen, ndist, position behind the header, type, last
-    uint32_t hY[64], hc[64], oY[64], oc[64];                           // hand-over: what lane k found for its target / what lane t was given
+    uint32_t hY[64], hc[64], oY[64], oc[64], hn[64], on[64];          // hand-over: what lane k found for its target / what lane t was given (position, bytes, symbols)
     int htgt[64], own[64];
+    uint32_t map[2048];                                                // the member's match map (one bit per output byte), flushed once
 };
 
 // >= 57 bits of the payload from bit position bitpos on.  STAGE: the payload sits in LDS (three aligned words and two
@@ -299,39 +300,43 @@ template <bool STAGE> __device__ __forceinline__ void p_header(PTab &T, const ui
     T.hdr[0] = st; T.hdr[1] = nlen; T.hdr[2] = ndist; T.hdr[3] = (int)hp; T.hdr[4] = type; T.hdr[5] = last;
 }
 
-template <bool STAGE>
+// REPLAY: phases A and A2 leave every symbol they decode in a scratch row (row i of a wave = the i-th symbol of each of its
+// 64 lanes: one coalesced 256-byte store per step), and phase B does not decode again -- it replays its own rows.  The
+// scratch belongs to the WAVE, not to the member (the grid is as many waves as the device holds at once, every wave takes
+// members m, m + grid, ...): sym_rows rows of 64 words each, a member with a lane that needs more is handed over.
+template <bool STAGE, bool REPLAY>
 __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restrict__ cbuf, const int64_t *__restrict__ cdata_off,
                                                          const int32_t *__restrict__ cdata_len, const int64_t *__restrict__ uoff,
                                                          const int32_t *__restrict__ isize, int64_t nmem, uint8_t *__restrict__ data,
                                                          int32_t *__restrict__ status, uint64_t *__restrict__ match_map, int dbg, int lds_payload,
-                                                         int32_t *__restrict__ par_status) {
+                                                         int32_t *__restrict__ par_status, uint32_t *__restrict__ symbuf, int sym_rows) {
     extern __shared__ __attribute__((aligned(16))) uint8_t p_smem[];
     PTab &T = *reinterpret_cast<PTab *>(p_smem);
     const int lane = threadIdx.x;
-    const int64_t m = blockIdx.x;
-    if (m >= nmem) return;
+    uint32_t *const sb = REPLAY ? symbuf + (size_t)blockIdx.x * (size_t)sym_rows * 64u + (uint32_t)lane : nullptr;   // this lane's column
+  for (int64_t m = blockIdx.x; m < nmem; m += gridDim.x) {
+    __syncthreads();                                         // (the tables of the member before are done with)
+    for (int i = lane; i < 2048; i += 64) T.map[i] = 0;
     const uint8_t *gbase = cbuf + cdata_off[m];
     const uint32_t pend = (uint32_t)cdata_len[m] * 8u;       // the payload in bits (< 2^19)
     const uint8_t *base = gbase;
+    bool too_big = false;
     if (STAGE) {
         // the payload through the texture path ONCE, coalesced, into LDS; the symbol loops then peek from there
-        uint8_t *const sb = p_smem + ((sizeof(PTab) + 15) & ~(size_t)15);
-        if ((int)(pend >> 3) + 16 > lds_payload) {           // larger than the launch provided for
-            for (int i = lane; i < BM_WORDS; i += 64) match_map[m * BM_WORDS + i] = 0ull;
-            if (lane == 0) { status[m] = INFL_RETRY + 9; par_status[m] = INFL_RETRY + 9; }
-            return;
-        }
-        for (uint32_t i = (uint32_t)lane * 16u; i < (pend >> 3) + 16u; i += 1024u)
-            *reinterpret_cast<uint4 *>(sb + i) = *reinterpret_cast<const uint4_u *>(gbase + i);
-        base = sb;
+        uint8_t *const sbuf = p_smem + ((sizeof(PTab) + 15) & ~(size_t)15);
+        too_big = (int)(pend >> 3) + 16 > lds_payload;       // larger than the launch provided for
+        if (!too_big)
+            for (uint32_t i = (uint32_t)lane * 16u; i < (pend >> 3) + 16u; i += 1024u)
+                *reinterpret_cast<uint4 *>(sbuf + i) = *reinterpret_cast<const uint4_u *>(gbase + i);
+        base = sbuf;
         __syncthreads();
     }
     uint8_t *out = data + uoff[m];
     unsigned long long *bm = reinterpret_cast<unsigned long long *>(match_map + m * BM_WORDS);
     const uint32_t cap = (uint32_t)isize[m];
     uint32_t obase = 0, hp = 0;                              // output bytes so far, bit position of the next block header
-    int st = INFL_OK;
-    for (;;) {
+    int st = too_big ? INFL_RETRY + 9 : INFL_OK;
+    for (; !too_big;) {
         if (lane == 0) p_header<STAGE>(T, base, hp, pend);
         __syncthreads();
         st = T.hdr[0];
@@ -380,28 +385,30 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
         ch = ch < P_MINCH ? P_MINCH : ch;
         const uint32_t S = p0 + (uint32_t)lane * ch, Sn = S + ch;          // this lane's stretch [S, Sn)
         const bool active = S < pend;
-        if (dbg == 8) { if (lane == 63) status[m] = 0; break; }
+        if (dbg == 8) break;
         // phase A
-        uint32_t pos = S, T_k = 0;
-        uint32_t e1p = ~0u, e1a = 0, e1b = 0, e2p = ~0u, e2a = 0, e2b = 0;   // end-of-block codes met: position, position behind, bytes before
+        uint32_t pos = S, T_k = 0, ns = 0;                                    // ns: symbols this lane has decoded (= rows it has written)
+        uint32_t e1p = ~0u, e1a = 0, e1b = 0, e1i = 0, e2p = ~0u, e2a = 0, e2b = 0, e2i = 0;   // end-of-block codes met: position, position behind, bytes before, row
         int neob = 0;
         if (active) {
             const uint32_t lim = Sn < pend ? Sn : pend;
             while (pos < lim) {
-                const PSym s = p_symbol<false>(T, p_peek<STAGE>(base, pos));
+                const PSym s = p_symbol<REPLAY>(T, p_peek<STAGE>(base, pos));
+                if (REPLAY) { if (ns < (uint32_t)sym_rows) sb[(size_t)ns * 64u] = (s.kind << 30) | s.val; }
                 if (s.kind == 2) {
-                    if (neob == 0) { e1p = pos; e1a = pos + s.nbits; e1b = T_k; }
-                    else if (neob == 1) { e2p = pos; e2a = pos + s.nbits; e2b = T_k; }
+                    if (neob == 0) { e1p = pos; e1a = pos + s.nbits; e1b = T_k; e1i = ns; }
+                    else if (neob == 1) { e2p = pos; e2a = pos + s.nbits; e2b = T_k; e2i = ns; }
                     ++neob;
                 }
-                pos += s.nbits; T_k += s.out;
+                pos += s.nbits; T_k += s.out; ++ns;
             }
         }
         const uint32_t E = pos;
-        if (dbg == 1) { if (lane == 63) status[m] = (int)(E + T_k + neob); break; }      // timing probes (FX_BGZF_DBG): wrong answers
+        if (dbg == 1) { if (E + T_k + neob == 0xFFFFFFFFu) T.hdr[7] = 1; break; }      // timing probes (FX_BGZF_DBG): wrong answers
         // phase A2: walk on from E side by side with the next lane's path from its start until they meet.  A walk that crosses
         // the whole next stretch without meeting its lane's path leaves that lane out (it owns nothing) and tries the one behind.
-        uint32_t p = E, ovb = 0, cq = 0, oep = ~0u, oea = 0, oeb = 0;            // oe*: the first end-of-block code on the walk from E
+        uint32_t p = E, ovb = 0, cq = 0, oep = ~0u, oea = 0, oeb = 0, oei = 0;   // oe*: the first end-of-block code on the walk from E
+        uint32_t pn = 0, qn = 0;                                                 // symbols of the walk from E / of the other lane's path up to the meeting point
         int tgt = 64;                                                            // the lane this one hands over to
         if (active) {
             int t = lane + 1;
@@ -409,56 +416,57 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
             for (int skipped = 0; t < 64 && St < pend && skipped <= P_MAXSKIP && oep == ~0u; ++t, St += ch, ++skipped) {
                 const uint32_t lim = (St + ch) < pend ? St + ch : pend;          // the meeting point must lie inside lane t's stretch
                 uint32_t q = St;
-                cq = 0;
+                cq = 0; qn = 0;
                 while (p != q && p < lim && oep == ~0u) {
                     const bool adv_p = p < q || q >= lim;                        // (the other path has left the stretch: only an end-of-block code on this one still matters)
                     const uint32_t at = adv_p ? p : q;
-                    const PSym s = p_symbol<false>(T, p_peek<STAGE>(base, at));
+                    const PSym s = p_symbol<REPLAY>(T, p_peek<STAGE>(base, at));
                     if (adv_p) {
-                        if (s.kind == 2) { oep = p; oea = p + s.nbits; oeb = ovb; }
-                        p += s.nbits; ovb += s.out;
-                    } else { q += s.nbits; cq += s.out; }
+                        if (REPLAY) { if (ns + pn < (uint32_t)sym_rows) sb[(size_t)(ns + pn) * 64u] = (s.kind << 30) | s.val; }
+                        if (s.kind == 2) { oep = p; oea = p + s.nbits; oeb = ovb; oei = ns + pn; }
+                        p += s.nbits; ovb += s.out; ++pn;
+                    } else { q += s.nbits; cq += s.out; ++qn; }
                 }
                 if (p == q && oep == ~0u) { tgt = t; break; }
             }
         }
-        if (dbg == 2) { if (lane == 63) status[m] = (int)(p + ovb + cq); break; }
+        if (dbg == 2) { if (p + ovb + cq == 0xFFFFFFFFu) T.hdr[7] = 1; break; }
         // hand-over: the chain of owners from lane 0 on (lane 0 follows it through LDS: a few dozen steps), every owner learns
         // where its own stretch begins (Y) and what it counted before that (c)
-        T.htgt[lane] = tgt; T.hY[lane] = p; T.hc[lane] = cq; T.own[lane] = 0;
+        T.htgt[lane] = tgt; T.hY[lane] = p; T.hc[lane] = cq; T.hn[lane] = qn; T.own[lane] = 0;
         __syncthreads();
         if (lane == 0) {
             int k = 0;
-            T.oY[0] = p0; T.oc[0] = 0;
+            T.oY[0] = p0; T.oc[0] = 0; T.on[0] = 0;
             for (int guard = 0; guard < 64; ++guard) {
                 T.own[k] = 1;
                 const int t = T.htgt[k];
                 if (t >= 64) break;
-                T.oY[t] = T.hY[k]; T.oc[t] = T.hc[k];
+                T.oY[t] = T.hY[k]; T.oc[t] = T.hc[k]; T.on[t] = T.hn[k];
                 k = t;
             }
         }
         __syncthreads();
         const bool owner = active && T.own[lane] != 0;
-        const uint32_t Y = T.oY[lane], c = T.oc[lane], Yn = p;
+        const uint32_t Y = T.oY[lane], c = T.oc[lane], Yn = p, skipn = T.on[lane];      // skipn: rows of this lane that lie in front of Y
         // the first end-of-block code at or behind Y on this lane's own path, else on its walk beyond E
-        uint32_t eob_after = 0, eob_bytes = 0;
+        uint32_t eob_after = 0, eob_bytes = 0, eob_row = 0;
         bool has_eob = false, ambiguous = false;
         if (owner) {
-            if (e1p != ~0u && e1p >= Y) { has_eob = true; eob_after = e1a; eob_bytes = e1b - c; }
-            else if (e2p != ~0u && e2p >= Y) { has_eob = true; eob_after = e2a; eob_bytes = e2b - c; }
+            if (e1p != ~0u && e1p >= Y) { has_eob = true; eob_after = e1a; eob_bytes = e1b - c; eob_row = e1i; }
+            else if (e2p != ~0u && e2p >= Y) { has_eob = true; eob_after = e2a; eob_bytes = e2b - c; eob_row = e2i; }
             else if (neob > 2) ambiguous = true;
-            else if (oep != ~0u) { has_eob = true; eob_after = oea; eob_bytes = (T_k - c) + oeb; }
+            else if (oep != ~0u) { has_eob = true; eob_after = oea; eob_bytes = (T_k - c) + oeb; eob_row = oei; }
         }
         if (__ballot(ambiguous)) {                           // more end-of-block codes on the way than were remembered: the own stretch once more, from Y
             if (ambiguous) {
-                uint32_t bp = Y, nb = 0;
+                uint32_t bp = Y, nb = 0, nr = skipn;
                 while (bp < E) {
                     const PSym s = p_symbol<false>(T, p_peek<STAGE>(base, bp));
-                    if (s.kind == 2) { has_eob = true; eob_after = bp + s.nbits; eob_bytes = nb; break; }
-                    bp += s.nbits; nb += s.out;
+                    if (s.kind == 2) { has_eob = true; eob_after = bp + s.nbits; eob_bytes = nb; eob_row = nr; break; }
+                    bp += s.nbits; nb += s.out; ++nr;
                 }
-                if (!has_eob && oep != ~0u) { has_eob = true; eob_after = oea; eob_bytes = (T_k - c) + oeb; }
+                if (!has_eob && oep != ~0u) { has_eob = true; eob_after = oea; eob_bytes = (T_k - c) + oeb; eob_row = oei; }
             }
         }
         const unsigned long long eb = __ballot(has_eob);
@@ -468,6 +476,7 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
         const uint32_t incl = wave_incl_scan(n_k);
         const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
         if (obase + total > cap) { st = INFL_EOUTPUT; break; }
+        if (REPLAY && __ballot(owner && lane <= j && ns + pn > (uint32_t)sym_rows)) { st = INFL_RETRY + 6; break; }   // a lane with more symbols than rows
         // phase B: the own stretch again, stored this time.  Every byte of the stretch's output is written, 8 at a time from a
         // register (the bytes of a match behind its token are k_bgzf_copy's to fill: zeros here) -- whole words instead of one
         // partial store per symbol, and no line of the output is left half-written for the copy kernel to merge.
@@ -477,13 +486,43 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
             const uint32_t o_end = o + n_k;
             const uint32_t stop = lane < j ? Yn : eob_after;                     // (lane j stops AT its end-of-block code, see below)
             uint32_t bp = Y;
-            unsigned long long bmw = 0;
-            uint32_t bwin = o >> 6;
             uint64_t acc = 0;                                                    // the bytes [o - fill, o)
             uint32_t fill = 0;
+            if (REPLAY) {
+                // the rows [skipn, r1) of this lane's column, four at a time (their loads together, then the byte work and the stores)
+                const uint32_t r1 = lane < j ? ns + pn : eob_row;
+                for (uint32_t i = skipn; i < r1 && !bad; i += 4) {
+                    uint32_t e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) e[u] = i + u < r1 ? sb[(size_t)(i + u) * 64u] : (2u << 30);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t kind = e[u] >> 30, val = e[u] & 0x3FFFFFFFu;
+                        if (kind == 2u) continue;                                // (past the end of the column; an end-of-block row is never inside [skipn, r1))
+                        if (kind == 3u) { bad = INFL_EINPUT; break; }
+                        const uint32_t outn = kind ? (val & 0xFFu) + 3u : 1u;
+                        if (o + outn > o_end) { bad = INFL_ESIZE; break; }
+                        if (kind) {
+                            if ((val >> 8) + 1u > o) { bad = INFL_EDIST; break; }
+                            atomicOr(&T.map[o >> 5], 1u << (o & 31u));
+                        }
+                        const uint64_t v = kind ? (uint64_t)(val & 0xFFFFFFu) : (uint64_t)(val & 0xFFu);
+                        acc |= v << (8u * fill);
+                        const uint64_t spill = fill > 5u ? v >> (8u * (8u - fill)) : 0ull;
+                        fill += outn;
+                        o += outn;
+                        if (fill >= 8u) {
+                            *reinterpret_cast<uint64_u *>(out + (o - fill)) = acc;
+                            acc = spill; fill -= 8u;
+                            while (fill >= 8u) { *reinterpret_cast<uint64_u *>(out + (o - fill)) = acc; acc = 0; fill -= 8u; }
+                        }
+                    }
+                }
+                bp = stop;
+            }
             PRd r;
-            if (!STAGE) pr_init(r, base, Y);
-            for (;;) {
+            if (!STAGE && !REPLAY) pr_init(r, base, Y);
+            for (; !REPLAY;) {
                 if (lane < j && bp >= stop) break;
                 const PSym s = STAGE ? p_symbol<true>(T, p_peek<STAGE>(base, bp)) : p_next<true>(T, r);
                 if (s.kind == 2) { bp += s.nbits; break; }
@@ -492,11 +531,9 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
                 if (o + s.out > o_end) { bad = INFL_ESIZE; break; }
                 if (s.kind == 1) {
                     if ((s.val >> 8) + 1u > o) { bad = INFL_EDIST; break; }      // BGZF members never reference outside themselves
-                    const uint32_t w = o >> 6;
-                    if (w != bwin) { if (bmw) atomicOr(&bm[bwin], bmw); bmw = 0; bwin = w; }
-                    bmw |= 1ull << (o & 63u);
+                    atomicOr(&T.map[o >> 5], 1u << (o & 31u));
                 }
-                if (dbg == 4) { bmw += s.val; o += s.out; bp += s.nbits; continue; }
+                if (dbg == 4) { acc += s.val; o += s.out; bp += s.nbits; continue; }
                 // literal: one byte; match: the 3-byte token, then out - 3 bytes of nothing
                 const uint64_t v = s.kind == 0 ? (uint64_t)(s.val & 0xFFu) : (uint64_t)(s.val & 0xFFFFFFu);
                 acc |= v << (8u * fill);
@@ -509,7 +546,6 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
                     while (fill >= 8u) { *reinterpret_cast<uint64_u *>(out + (o - fill)) = acc; acc = 0; fill -= 8u; }   // a long match
                 }
             }
-            if (bmw) atomicOr(&bm[bwin], bmw);
             for (uint32_t i = 0; i < fill; ++i) out[o - fill + i] = (uint8_t)(acc >> (8u * i));      // the last few bytes
             if (!bad && (o != o_end || bp != stop)) bad = INFL_ESIZE;            // the second walk must land where the first one did
         }
@@ -521,6 +557,11 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
         if (last) break;
     }
     if (st == INFL_OK && obase != cap) st = INFL_ESIZE;
+    __syncthreads();
+    if (st == INFL_OK) {                                     // the map out of LDS: whole words, coalesced (the buffer was cleared by the host)
+        const uint32_t nw = (cap + 63u) >> 6;
+        for (uint32_t i = lane; i < nw; i += 64) bm[i] = (unsigned long long)T.map[2 * i] | ((unsigned long long)T.map[2 * i + 1] << 32);
+    }
     if (st != INFL_OK) {
         // whatever went wrong, the serial kernel decodes the member again (and names the error if there is one): it wants a
         // clean match map.  The status keeps the reason: INFL_RETRY + 1 / 2 sub-table pool, 3 end-of-block codes, 4 no meeting
@@ -529,6 +570,7 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
         if (st < INFL_RETRY) st = INFL_RETRY + 16 + st;
     }
     if (lane == 0) { status[m] = st; par_status[m] = st; }              // par_status: what THIS kernel made of the member (the serial one overwrites status)
+  }
 }
 
 }  // namespace fx

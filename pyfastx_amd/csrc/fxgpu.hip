@@ -654,17 +654,28 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
     for (int32_t c : t.clen) clen_max = std::max(clen_max, c);
     const int lds_payload = (int)std::min<int64_t>(((int64_t)clen_max + 16 + 255) & ~255ll, 65536);
     static const bool stage = [] { const char *e = getenv("FX_BGZF_STAGE"); return e && atoi(e) != 0; }();   // the payload through LDS (experiment)
+    static const bool replay = [] { const char *e = getenv("FX_BGZF_REPLAY"); return e && atoi(e) != 0; }();   // phase B replays the symbols phase A left behind (experiment: no faster -- what B costs is its stores)
     const size_t par_lds = ((sizeof(PTab) + 15) & ~(size_t)15) + (stage ? (size_t)lds_payload : 0);
-    const auto par_kernel = stage ? k_bgzf_decode_par<true> : k_bgzf_decode_par<false>;
+    const auto par_kernel = stage ? (replay ? k_bgzf_decode_par<true, true> : k_bgzf_decode_par<true, false>)
+                                  : (replay ? k_bgzf_decode_par<false, true> : k_bgzf_decode_par<false, false>);
     static bool par_attr = false;
     if (!par_attr) {
-        (void)hipFuncSetAttribute((const void *)k_bgzf_decode_par<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute((const void *)k_bgzf_decode_par<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute((const void *)k_bgzf_decode_par<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         par_attr = true;
     }
+    // a grid of as many waves as the device holds at once; every wave owns SYM_ROWS rows of 64 symbols of scratch
+    constexpr int SYM_ROWS = 2048;
+    int per_cu = 0, n_cu = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, par_kernel, 64, par_lds) != hipSuccess || per_cu <= 0) per_cu = 8;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+    const unsigned par_grid = (unsigned)std::min<int64_t>(nmem, (int64_t)per_cu * n_cu);
+    ScratchBuf<uint32_t> d_sym;
+    if (replay && !serial_only && (rc = d_sym.alloc(h->device, (int64_t)par_grid * SYM_ROWS * 64, h->stream))) return rc;
     if (!serial_only) {
         h->prof.begin(K_BGZF_INFLATE, h->stream);
-        hipLaunchKernelGGL(par_kernel, dim3((unsigned)nmem), dim3(64), par_lds, h->stream, d_c.p, d_coff.p, d_clen.p, d_uoff.p, d_isize.p, nmem,
-                           h->d_data, d_status.p, d_map.p, dbg_par, lds_payload, d_pstatus.p);
+        hipLaunchKernelGGL(par_kernel, dim3(par_grid), dim3(64), par_lds, h->stream, d_c.p, d_coff.p, d_clen.p, d_uoff.p, d_isize.p, nmem,
+                           h->d_data, d_status.p, d_map.p, dbg_par, lds_payload, d_pstatus.p, d_sym.p, SYM_ROWS);
         h->prof.end(h->stream);
         if (trace) {                                         // how many members the wave-per-member kernel handed over, and why
             std::vector<int32_t> stv((size_t)nmem);
@@ -680,8 +691,8 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipStreamSynchronize(h->stream);
         (void)hipEventRecord(e0, h->stream);
-        hipLaunchKernelGGL(par_kernel, dim3((unsigned)nmem), dim3(64), par_lds, h->stream, d_c.p, d_coff.p, d_clen.p, d_uoff.p, d_isize.p, nmem,
-                           h->d_data, d_status.p, d_map.p, dbg_par, lds_payload, d_pstatus.p);
+        hipLaunchKernelGGL(par_kernel, dim3(par_grid), dim3(64), par_lds, h->stream, d_c.p, d_coff.p, d_clen.p, d_uoff.p, d_isize.p, nmem,
+                           h->d_data, d_status.p, d_map.p, dbg_par, lds_payload, d_pstatus.p, d_sym.p, SYM_ROWS);
         (void)hipEventRecord(e1, h->stream);
         (void)hipStreamSynchronize(h->stream);
         float ms = 0.f;
