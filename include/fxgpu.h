@@ -241,6 +241,35 @@ int fx_fastq_fetch(fx_handle *h, int where, int64_t n, const int64_t *read_id,
                    int phred, int seq_flags,
                    uint8_t *seq, uint8_t *qual, int8_t *quali, const int64_t *dst_off);
 
+/* ------------------------------------------------------------------ Fastx
+ * Replaces kseq_read (kseq.c:138-179) as pyfastx_fastx_next drives it (fastx.c:124-130): index-free iteration over a
+ * file with kseq's own record rules -- FASTA and FASTQ records mixed, sequence / quality over any number of lines,
+ * text between records skipped, white space kept inside the lines, a trailing CR dropped per ks_getuntil2 call
+ * (kseq.c:106).  One record per kseq_read that returned >= 0. */
+typedef struct {
+    int64_t hdr_off;    /* first byte behind the '>' / '@'; name and comment are cut from these bytes (kseq.c:148-149)  */
+    int64_t hdr_line;   /* number of the line that holds it                                                            */
+    int64_t seq_len;    /* seq.l; qual.l of a FASTQ record is the same (kseq.c:176)                                    */
+    int64_t seq_cum;    /* sum of seq_len over the records before this one                                             */
+    uint32_t hdr_len;   /* bytes to the end of the line, '\n' excluded                                                  */
+    uint32_t s_n;       /* lines between the header line and the line that ended the sequence                          */
+    uint32_t q_n;       /* quality lines read                                                                          */
+    uint32_t flags;     /* 1: FASTQ record (kseq_read went through kseq.c:167-177); 2: its quality read met the end of
+                           the stream at once (the reference's buffer keeps its old content); 4: the header line has
+                           no '\n' behind it                                                                           */
+} fx_kseq_rec;
+/* The walk over the whole resident stream.  *end_code = the negative value that ended the reference's iteration:
+ * -1 end of file, -2 truncated quality string (kseq.c:131-136). */
+int fx_kseq_scan(fx_handle *h, int64_t *n_records, int64_t *n_lines, int64_t *seq_bytes, int *end_code);
+/* Records [first, first + count) of the table, to host memory. */
+int fx_kseq_records(fx_handle *h, int64_t first, int64_t count, fx_kseq_rec *out);
+/* Their sequence strings, one behind the other (record k at seq_cum[k] - seq_cum[first]), and their quality strings at
+ * the same offsets (zero bytes where a record has none); either destination may be NULL.  flags: FX_UPPER (sequence
+ * only, fastx.c:14-22).  *n_bytes = bytes per destination. */
+int fx_kseq_fetch(fx_handle *h, int where, int64_t first, int64_t count, int flags, uint8_t *seq_dst, uint8_t *qual_dst,
+                  int64_t *n_bytes);
+
+
 /* The same with explicit per-read offsets (the reference's call shape:
  * pyfastx_read_random_reader(read, buff, offset, bytes), read.c:37-45), for
  * callers that hold .fxi rows (soff, qoff, rlen) rather than ids. */

@@ -256,3 +256,82 @@ void fxo_quali(const uint8_t *data, int64_t qoff, int64_t rlen, int phred, int8_
     if (!phred) phred = 33;                                 /* read.c:268 */
     for (i = 0; i < rlen; ++i) out[i] = (int8_t)((int)(signed char)data[qoff + i] - phred);
 }
+
+/* ------------------------------------------------------------------ kseq_read (Fastx)
+ * ks_getuntil2 in line mode with append = 1 (kseq.c:59-109): the bytes up to the next '\n' (or the end of the
+ * stream) are appended to dst[0..*l); -1 when nothing at all is left; a trailing '\r' goes only from a string that
+ * is longer than one byte (kseq.c:106). */
+static int64_t kq_line(const uint8_t *d, int64_t n, int64_t *p, uint8_t *dst, int64_t *l) {
+    if (*p >= n) return -1;
+    const uint8_t *e = memchr(d + *p, '\n', (size_t)(n - *p));
+    const int64_t end = e ? (int64_t)(e - d) : n;
+    memcpy(dst + *l, d + *p, (size_t)(end - *p));
+    *l += end - *p;
+    *p = e ? end + 1 : n;
+    if (*l > 1 && dst[*l - 1] == '\r') --*l;
+    return *l;
+}
+static int kq_space(int c) { return c == ' ' || (c >= 9 && c <= 13); }   /* isspace() in the C locale */
+
+int64_t fxo_kseq(const uint8_t *d, int64_t n, fxo_kseq_rec *out, int64_t cap, uint8_t *seqbuf, uint8_t *qualbuf,
+                 int *end_code) {
+    int64_t p = 0, nrec = 0, so = 0, qo = 0;
+    int last = 0, code = -1;
+    for (;;) {
+        fxo_kseq_rec r;
+        if (last == 0) {                                   /* kseq.c:142-146: jump to the next header character */
+            while (p < n && d[p] != '>' && d[p] != '@') ++p;
+            if (p >= n) { code = -1; break; }
+            last = d[p++];
+        }
+        if (p >= n) { code = -1; break; }                  /* kseq.c:148: nothing behind the header character */
+        int64_t q = p;
+        while (q < n && !kq_space(d[q])) ++q;
+        const int delim = q < n ? d[q] : 0;
+        r.name_off = p; r.name_len = q - p;
+        p = q < n ? q + 1 : n;
+        r.com_off = p; r.com_len = -1;
+        if (delim != '\n' && p < n) {                      /* kseq.c:149 */
+            const uint8_t *e = memchr(d + p, '\n', (size_t)(n - p));
+            const int64_t end = e ? (int64_t)(e - d) : n;
+            r.com_len = end - p;
+            if (r.com_len > 1 && d[end - 1] == '\r') --r.com_len;
+            p = e ? end + 1 : n;
+        }
+        uint8_t *s = seqbuf + so;                          /* kseq.c:154-158 */
+        int64_t sl = 0;
+        int c = -1;
+        for (;;) {
+            if (p >= n) { c = -1; break; }
+            c = d[p++];
+            if (c == '>' || c == '+' || c == '@') break;
+            if (c == '\n') continue;
+            s[sl++] = (uint8_t)c;
+            (void)kq_line(d, n, &p, s, &sl);
+        }
+        if (c == '>' || c == '@') last = c;                /* kseq.c:159 */
+        r.seq_off = so; r.seq_len = sl; r.qual_off = qo; r.qual_len = -1;
+        so += sl;
+        if (c != '+') {                                    /* kseq.c:166: FASTA */
+            if (nrec < cap && out) out[nrec] = r;
+            ++nrec;
+            continue;
+        }
+        while (p < n && d[p] != '\n') ++p;                 /* kseq.c:171-172: the rest of the '+' line */
+        if (p >= n) { code = -2; break; }
+        ++p;
+        uint8_t *ql = qualbuf + qo;
+        int64_t qlen = 0, got, calls = 0;
+        do { got = kq_line(d, n, &p, ql, &qlen); ++calls; } while (got >= 0 && qlen < sl);   /* kseq.c:173 */
+        last = 0;                                          /* kseq.c:175 */
+        if (sl != qlen) { code = -2; break; }              /* kseq.c:176 */
+        /* the stream ended behind the '+' line of a record without bases: ks_getuntil2 returned -1 before it touched
+         * the quality buffer, which still holds the previous record's string (or nothing defined at all) */
+        r.qual_len = (calls == 1 && got < 0) ? -2 : qlen;
+        qo += qlen;
+        if (nrec < cap && out) out[nrec] = r;
+        ++nrec;
+    }
+    if (end_code) *end_code = code;
+    return nrec;
+}

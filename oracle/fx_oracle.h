@@ -81,4 +81,22 @@ int64_t fxo_fetch(const uint8_t *data, int64_t n, int64_t off, int64_t blen,
 /* read.c:251-278: quali[i] = qual[i] - phred. */
 void fxo_quali(const uint8_t *data, int64_t qoff, int64_t rlen, int phred, int8_t *out);
 
+/* kseq_read over a memory buffer (kseq.c:138-179 with ks_getuntil2, kseq.c:59-109): what pyfastx.Fastx iterates
+ * (fastx.c:124-130).  One record per successful kseq_read; the sequence / quality strings are written one after the
+ * other into seqbuf / qualbuf (each at least n bytes).  *end_code = kseq_read's last (negative) return value:
+ * -1 end of file, -2 truncated quality.  Returns the number of records (at most cap are written to out). */
+typedef struct {
+    int64_t name_off;  /* first byte after the '>' / '@'                                        */
+    int64_t name_len;  /* up to the first isspace() byte (ks_getuntil, delimiter 0)             */
+    int64_t com_off;   /* comment: the rest of the header line ...                              */
+    int64_t com_len;   /* ... -1 when ks_getuntil2 was not called for it or returned -1 (the comment buffer is untouched) */
+    int64_t seq_off;   /* into seqbuf                                                           */
+    int64_t seq_len;
+    int64_t qual_off;  /* into qualbuf                                                          */
+    int64_t qual_len;  /* -1: a FASTA-style record (kseq_read returned before the quality part); -2: a FASTQ record
+                          whose quality read met the end of the stream at once -- the buffer keeps its old content */
+} fxo_kseq_rec;
+int64_t fxo_kseq(const uint8_t *data, int64_t n, fxo_kseq_rec *out, int64_t cap, uint8_t *seqbuf, uint8_t *qualbuf,
+                 int *end_code);
+
 #endif

@@ -59,6 +59,8 @@ def lib():
         L.fxo_slice_range.argtypes = [i64, i64, C.c_int32, i64, i64, C.POINTER(i64), C.POINTER(i64)]
         L.fxo_fetch.restype = i64
         L.fxo_fetch.argtypes = [vp, i64, i64, i64, i64, i32, vp]
+        L.fxo_kseq.restype = i64
+        L.fxo_kseq.argtypes = [vp, i64, vp, i64, vp, vp, C.POINTER(C.c_int)]
         L.fxo_quali.restype = None
         L.fxo_quali.argtypes = [vp, i64, i64, i32, vp]
         _LIB = L
@@ -153,4 +155,68 @@ def quali(data, qoff, rlen, phred=0):
     a, p, n = _buf(data)
     out = np.zeros(int(rlen), dtype=np.int8)
     lib().fxo_quali(p, int(qoff), int(rlen), int(phred), out.ctypes.data)
+    return out
+
+
+KSEQ_REC = np.dtype([("name_off", "<i8"), ("name_len", "<i8"), ("com_off", "<i8"), ("com_len", "<i8"),
+                     ("seq_off", "<i8"), ("seq_len", "<i8"), ("qual_off", "<i8"), ("qual_len", "<i8")])
+
+
+def kseq(data):
+    """kseq_read over the whole buffer -> (records, seq bytes, qual bytes, end code)."""
+    a, p, n = _buf(data)
+    cap = int(np.count_nonzero((a == 62) | (a == 64))) + 1
+    recs = np.zeros(cap, dtype=KSEQ_REC)
+    seq = np.zeros(n + 1, dtype=np.uint8)
+    qual = np.zeros(n + 1, dtype=np.uint8)
+    code = C.c_int(0)
+    k = lib().fxo_kseq(p, n, recs.ctypes.data, cap, seq.ctypes.data, qual.ctypes.data, C.byref(code))
+    return recs[:k], seq, qual, code.value
+
+
+def kseq_undefined(data):
+    """Does the reference read a quality buffer it never wrote on this input (see fastx_tuples)?"""
+    seen = False
+    for r in kseq(data)[0]:
+        if r["qual_len"] >= 0:
+            seen = True
+        elif r["qual_len"] == -2 and not seen:
+            return True
+    return False
+
+
+def _cstr(b):
+    """Py_BuildValue "s": the bytes up to the first NUL, as text."""
+    b = bytes(b)
+    z = b.find(b"\0")
+    return (b if z < 0 else b[:z]).decode("utf-8", "surrogateescape")
+
+
+def fastx_tuples(data, fmt, uppercase=False, comment=False):
+    """What iterating pyfastx.Fastx over a file of these bytes yields (fastx.c:6-30, 124-130): the tuples of the
+    builder fmt ("fasta" / "fastq") selects, whatever kind of record kseq_read found -- a FASTA-style record seen
+    through the FASTQ builder carries whatever the quality buffer still holds (None before the first quality string,
+    kseq.c:147 resets only its length) and so does a record whose quality read met the end of the stream at once; a
+    comment is None until the comment buffer exists.  (Where the reference reads a buffer it never wrote -- such a
+    record before any quality string -- the value here is None; the reference's is not defined.)"""
+    a, _, _ = _buf(data)
+    raw = a.tobytes()
+    recs, seq, qual, _ = kseq(a)
+    out, have_comment, last_qual = [], False, None
+    for r in recs:
+        name = _cstr(raw[r["name_off"]:r["name_off"] + r["name_len"]])
+        s = seq[r["seq_off"]:r["seq_off"] + r["seq_len"]].tobytes()
+        if r["com_len"] >= 0:
+            have_comment = True
+        com = None
+        if have_comment:
+            com = raw[r["com_off"]:r["com_off"] + max(int(r["com_len"]), 0)].decode("utf-8", "surrogateescape")
+        if r["qual_len"] >= 0:
+            last_qual = _cstr(qual[r["qual_off"]:r["qual_off"] + r["qual_len"]].tobytes())
+        if fmt == "fasta":
+            if uppercase:
+                s = s.upper()
+            out.append((name, _cstr(s), com) if comment else (name, _cstr(s)))
+        else:
+            out.append((name, _cstr(s), last_qual, com) if comment else (name, _cstr(s), last_qual))
     return out

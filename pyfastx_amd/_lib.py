@@ -51,7 +51,7 @@ SYMBOLS = [
     "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
     "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
     "fx_comm_unique_id", "fx_comm_init", "fx_comm_destroy", "fx_comm_rank", "fx_comm_world", "fx_comm_allgather", "fx_fasta_build_sharded_begin",
-    "fx_fasta_build_sharded", "fx_comm_summaries", "fx_fastq_build_sharded", "fx_bgzf_counts", "fx_sort_packed_names", "fx_gunzip_parallel", "fx_gz_open_mode",
+    "fx_fasta_build_sharded", "fx_comm_summaries", "fx_fastq_build_sharded", "fx_bgzf_counts", "fx_sort_packed_names", "fx_gunzip_parallel", "fx_gz_open_mode", "fx_kseq_scan", "fx_kseq_records", "fx_kseq_fetch",
 ]
 
 
@@ -188,6 +188,9 @@ def lib():
     L.fx_fastq_build_sharded.argtypes = [vp, vp, vp]
     L.fx_bgzf_counts.argtypes = [vp, vp]
     L.fx_gz_open_mode.argtypes = [vp]
+    L.fx_kseq_scan.argtypes = [vp, vp, vp, vp, vp]
+    L.fx_kseq_records.argtypes = [vp, i64, i64, vp]
+    L.fx_kseq_fetch.argtypes = [vp, i32, i64, i64, i32, vp, vp, vp]
     L.fx_gunzip_parallel.argtypes = [vp, i64, i32, vp, i64, C.POINTER(i64), C.POINTER(i64)]
     L.fx_sort_packed_names.argtypes = [i32, vp, vp, i64, vp, C.POINTER(i64)]
     for s in SYMBOLS:
@@ -311,6 +314,10 @@ class Comm:
             pass
 
 
+KSEQ_REC = np.dtype([("hdr_off", "<i8"), ("hdr_line", "<i8"), ("seq_len", "<i8"), ("seq_cum", "<i8"),
+                     ("hdr_len", "<u4"), ("s_n", "<u4"), ("q_n", "<u4"), ("flags", "<u4")])
+
+
 class Blob:
     """Owning wrapper of an fx_handle: one staged stream resident in HBM."""
 
@@ -410,6 +417,31 @@ class Blob:
     def gz_open_mode(self):
         """0 plain, 1 BGZF on the device, 2 one gzip stream serially, 3 one stream on all host cores, 4 from restart points."""
         return int(lib().fx_gz_open_mode(self._h))
+
+    # -- Fastx: the kseq walk -------------------------------------------------
+    def kseq_scan(self):
+        """kseq_read over the whole stream (fx_kseq_scan) -> (records, lines, sequence bytes, end code -1 / -2)."""
+        nr, nl, sb, code = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int(0)
+        check(lib().fx_kseq_scan(self._h, C.byref(nr), C.byref(nl), C.byref(sb), C.byref(code)))
+        return int(nr.value), int(nl.value), int(sb.value), int(code.value)
+
+    def kseq_records(self, first, count):
+        """Records [first, first + count) of the walk as a structured array (fx_kseq_rec)."""
+        out = np.zeros(int(count), dtype=KSEQ_REC)
+        if count:
+            check(lib().fx_kseq_records(self._h, int(first), int(count), _ptr(out)))
+        return out
+
+    def kseq_fetch(self, first, count, nbytes, upper=False, want_qual=True):
+        """The sequence (and quality) strings of records [first, first + count), one behind the other: nbytes =
+        seq_cum + seq_len of the last minus seq_cum of the first."""
+        seq = np.empty(max(int(nbytes), 1), dtype=np.uint8)
+        qual = np.empty(max(int(nbytes), 1), dtype=np.uint8) if want_qual else None
+        got = C.c_int64(0)
+        check(lib().fx_kseq_fetch(self._h, FX_HOST, int(first), int(count), FX_UPPER if upper else 0, _ptr(seq), _ptr(qual), C.byref(got)))
+        if got.value != int(nbytes):
+            raise RuntimeError("fx_kseq_fetch: %d bytes, expected %d" % (got.value, int(nbytes)))
+        return seq[:int(nbytes)], (qual[:int(nbytes)] if want_qual else None)
 
     def bgzf_counts(self):
         """(members, members handed over to the serial decoder, reason of the first) of the open that made this blob."""

@@ -402,10 +402,7 @@ class Fasta(_fxobj.FastaCore):
             want = np.maximum(t["slen"][a:b], 0)
             buf, offs, ol = blob.fetch_ranges(t["boff"][a:b], t["blen"][a:b], want, flags=fl)
             for k in range(b - a):
-                if getattr(self, "_with_cr", False):                      # Fastx: did the header line end with CR?
-                    yield names[a + k], _decode(buf[offs[k]:offs[k] + ol[k]]), bool(t["elen"][a + k] == 2)
-                else:
-                    yield names[a + k], _decode(buf[offs[k]:offs[k] + ol[k]])
+                yield names[a + k], _decode(buf[offs[k]:offs[k] + ol[k]])
 
     def _need_index(self):
         if self._db is None:
@@ -1222,10 +1219,7 @@ class Fastq:
             for k in range(b - a):
                 full = _text(nb[no[k]:no[k + 1]])
                 nm = full.rstrip("\r")
-                if getattr(self, "_with_cr", False):                      # Fastx: did the header line end with CR?
-                    yield nm, _decode(seq[offs[k]:offs[k + 1]]), _decode(qual[offs[k]:offs[k + 1]]), len(nm) != len(full)
-                else:
-                    yield nm, _decode(seq[offs[k]:offs[k + 1]]), _decode(qual[offs[k]:offs[k + 1]])
+                yield nm, _decode(seq[offs[k]:offs[k + 1]]), _decode(qual[offs[k]:offs[k + 1]])
 
     def keys(self):
         return FastqKeys(self, self._counts)                                                   # fastq.c:555-557
@@ -1421,26 +1415,45 @@ class Read:
 
 
 # ============================================================== Fastx
-_SPACE = frozenset(" \t\n\r\x0b\x0c")                       # isspace(): what ends a name in kseq (KS_SEP_SPACE, kseq.h:9)
+def _kseq_header(raw, unterminated):
+    """kseq_read's cut of a header line (kseq.c:148-149): the name runs to the first isspace() byte; when that byte is not
+    the line's '\n', ks_getuntil2 reads the rest of the line into the comment buffer -- and drops a trailing CR only from
+    a string longer than one byte (kseq.c:106).  raw = the bytes behind the '>' / '@' up to the '\n'.
+    -> (name bytes, comment bytes -- None when the comment buffer was not written: nothing follows the name, or the
+    stream ends right behind the delimiter)."""
+    for i, c in enumerate(raw):
+        if c in _SPACE_BYTES:
+            rest = raw[i + 1:]
+            if unterminated and not rest:
+                return raw[:i], None
+            if len(rest) > 1 and rest[-1] == 13:
+                rest = rest[:-1]
+            return raw[:i], rest
+    return raw, None
 
 
-def _name_comment(header):
-    """kseq_read (kseq.c:145-146): the name runs to the first isspace() character, the comment is the rest of the line
-    after that one character (ks_getuntil2 in line mode drops a trailing CR only from a string longer than one).
-    -> (name, comment or None when nothing follows the name)."""
-    for i, c in enumerate(header):
-        if c in _SPACE:
-            return header[:i], header[i + 1:]
-    return header, None
+_SPACE_BYTES = frozenset(b" \t\n\r\x0b\x0c")            # isspace() in the C locale: what ends a name (KS_SEP_SPACE, kseq.h:9)
+
+
+def _cstr(b):
+    """Py_BuildValue "s" (fastx.c:6-30): the bytes up to the first NUL, as text."""
+    b = bytes(b)
+    z = b.find(b"\0")
+    return _text(b if z < 0 else b[:z])
 
 
 class Fastx:
     """pyfastx.Fastx (fastx.c:32-147): iteration over a FASTA or FASTQ file WITHOUT an index file -- tuples
-    (name, seq[, comment]) or (name, seq, qual[, comment]).  The reference walks the file with kseq_read; here the
-    records come from the same GPU scan as everything else, kept in memory only, and whole records are fetched in batches
-    (Fasta / Fastq with build_index=False).  Well-formed files give the same tuples; kseq's tolerance of multi-line
-    FASTQ records and of white space inside sequence lines is not reproduced (the index-building parsers, which this
-    engine restates, do not have it either)."""
+    (name, seq[, comment]) or (name, seq, qual[, comment]).  The reference walks the file with kseq_read (kseq.c:138-179);
+    here the stream is staged in HBM, ONE pass finds its lines, one workgroup walks the line table with kseq_read's own
+    rules (fx_kseq_scan: FASTA and FASTQ records mixed, sequence and quality over any number of lines, text between
+    records skipped, white space kept inside the lines, one trailing CR dropped per line read) and the strings of a batch
+    of records are gathered by one kernel (fx_kseq_fetch).  `format` only selects the tuple builder, as in the reference
+    (fastx.c:86-106): a FASTA-style record seen through the FASTQ builder carries what the reference's quality buffer
+    still holds -- the previous quality string, None before the first."""
+
+    BATCH_RECORDS = 65536
+    BATCH_BYTES = 64 << 20
 
     def __init__(self, file_name, format="auto", uppercase=False, comment=False, device=0):
         if not os.path.isfile(file_name):
@@ -1453,35 +1466,50 @@ class Fastx:
             self._format = {"fasta": 1, "fastq": 2}.get(format, 0)
         if self._format == 0:
             raise RuntimeError("%s is not fasta or fastq sequence file" % file_name)           # fastx.c:71-74
+        self.end_code = None                      # after an iteration: what ended it in the reference (-1 end of file, -2 truncated quality)
 
     def __repr__(self):
         return "<Fastx> %s %s" % ("fasta" if self._format == 1 else "fastq", self.file_name)    # fastx.c:126-132
 
     def __iter__(self):
-        # whole header lines from the scan, cut here: kseq ends a name at ANY isspace() character, the index builders at a
-        # space or tab (FASTA) / a space (FASTQ)
-        # A record without a comment: the reference hands out None until its comment buffer exists -- from the first
-        # header whose name is followed by anything but the newline, a CR included -- and "" afterwards (kseq.c:146 with
-        # Py_BuildValue "s#" on a NULL pointer, fastx.c:10-12, 28-30).
-        buffered = False
-        if self._format == 1:
-            src = Fasta(self.file_name, build_index=False, uppercase=self._uppercase, full_name=True, device=self._device)
-            src._with_cr = True
-            for header, seq, cr in src:
-                nm, cm = _name_comment(header)
-                buffered = buffered or cm is not None or cr
-                if cm is None and buffered:
-                    cm = ""
-                yield (nm, seq, cm) if self._comment else (nm, seq)
-        else:
-            src = Fastq(self.file_name, build_index=False, full_name=True, device=self._device)
-            src._with_cr = True
-            for header, seq, qual, cr in src:                                                    # (uppercase is not applied to FASTQ: fastx.c:97-103)
-                nm, cm = _name_comment(header)
-                buffered = buffered or cm is not None or cr
-                if cm is None and buffered:
-                    cm = ""
-                yield (nm, seq, qual, cm) if self._comment else (nm, seq, qual)
+        fastq, with_comment = self._format == 2, self._comment
+        blob = _lib.Blob.from_file(self.file_name, device=self._device)
+        try:
+            n_rec, _, _, self.end_code = blob.kseq_scan()
+            # A record without a comment: the reference hands out None until its comment buffer exists -- from the first
+            # header whose name is followed by anything but the newline, a CR included -- and "" afterwards (kseq.c:146
+            # with Py_BuildValue "s#" on a NULL pointer, fastx.c:10-12, 28-30).
+            buffered, last_qual = False, None
+            for a in range(0, n_rec, self.BATCH_RECORDS):
+                recs = blob.kseq_records(a, min(self.BATCH_RECORDS, n_rec - a))
+                cum, slen, flags = recs["seq_cum"], recs["seq_len"], recs["flags"]
+                i = 0
+                while i < recs.size:
+                    ends = cum[i:] + slen[i:] - cum[i]
+                    k = i + max(1, int(np.searchsorted(ends, self.BATCH_BYTES, side="right")))
+                    nbytes = int(ends[k - i - 1])
+                    seq, qual = blob.kseq_fetch(a + i, k - i, nbytes, upper=self._uppercase and not fastq, want_qual=fastq)  # fastx.c:14-22, 97-103
+                    hl = recs["hdr_len"][i:k].astype(np.int64)
+                    hdr, ho, _ = blob.fetch_ranges(recs["hdr_off"][i:k], hl, hl, flags=_lib.FX_RAW)
+                    base = int(cum[i])
+                    for r in range(i, k):
+                        nm, cm = _kseq_header(bytes(hdr[ho[r - i]:ho[r - i + 1]]), bool(flags[r] & 4))
+                        if cm is not None:
+                            buffered = True
+                        o = int(cum[r]) - base
+                        s = _cstr(seq[o:o + int(slen[r])])
+                        if not fastq:
+                            yield (_cstr(nm), s, _text(cm) if cm is not None else ("" if buffered else None)) if with_comment else (_cstr(nm), s)
+                            continue
+                        if (flags[r] & 3) == 1:                      # a FASTQ record whose quality was read
+                            last_qual = _cstr(qual[o:o + int(slen[r])])
+                        if with_comment:
+                            yield (_cstr(nm), s, last_qual, _text(cm) if cm is not None else ("" if buffered else None))
+                        else:
+                            yield (_cstr(nm), s, last_qual)
+                    i = k
+        finally:
+            blob.close()
 
 
 # ============================================================== module functions

@@ -1,0 +1,411 @@
+// fx_kseq.hpp -- Fastx: kseq_read (kseq.c:138-179, ks_getuntil2 kseq.c:59-109) over the resident stream.
+//
+// pyfastx.Fastx (fastx.c:124-130) hands out whatever kseq_read finds: FASTA and FASTQ records in one file, sequence
+// and quality strings over any number of lines, junk between records, white space kept inside the lines.  That parser
+// is a byte-at-a-time state machine whose quality part depends on the LENGTH of the sequence part, so its records
+// cannot be found from local evidence the way the index builders' records can (fx_spanscan.hpp, fx_fastq.hpp).  Here:
+//
+//   k_kq_count / k_kq_lines   one read of the stream: the offsets of all line ends (a line table)
+//   k_kq_desc                 per line: start, length, first and last byte
+//   k_kq_walk                 ONE workgroup walks the line table: three waves stream the descriptors into an LDS ring, one
+//                             wave runs the state machine over them -- 64 lines per step where the lines allow it (16
+//                             four-line FASTQ records, or a run of FASTA header / sequence lines: ballots and one wave
+//                             scan), one line per step otherwise.  It writes the record table and, per line, where its
+//                             bytes go in the concatenated sequence / quality strings.
+//   k_kq_gather               records [first, first + count) -> their strings, one 16-lane group per line
+//
+// The walk is sequential in the number of 64-line steps, not in bytes: 10^8 lines take a few tenths of a second.
+// tools/kseq_line_model.py is the executable model k_kq_walk transliterates (fuzzed against oracle/fx_oracle.c: fxo_kseq).
+#pragma once
+#include "fx_kernels.hpp"
+
+namespace fx {
+
+constexpr int KQ_TILE = 4096;                 // bytes per wave step of the count / lines kernels
+constexpr int KQ_RING = 4096;                 // line descriptors in the LDS ring (64 KiB)
+constexpr int KQ_BATCH = 512;                 // lines per producer batch
+constexpr int KQ_SLOTS = KQ_RING / KQ_BATCH;
+constexpr int KQ_PRODUCERS = 3;
+constexpr uint32_t KQ_BIG = 1u << 25;         // a window with a line this long takes the one-line steps (32-bit wave scans)
+constexpr int64_t KQ_POS = (1ll << 62) - 1;   // ldst: position in the low 62 bits, class above
+constexpr int KQ_LONG = 1 << 16;              // lines longer than this are copied by k_kq_gather_long
+
+enum { KQ_SEEK = 0, KQ_HDR = 1, KQ_SEQ = 2, KQ_QUAL = 3 };
+enum { KQ_C_SEQ = 1, KQ_C_QUAL = 2 };
+enum { KQ_F_FASTQ = 1, KQ_F_UNTOUCHED = 2, KQ_F_HDR_UNTERM = 4 };
+
+struct alignas(16) KqRec {                    // one kseq_read that returned >= 0
+    int64_t hdr_off;                          // first byte after the '>' / '@'
+    int64_t hdr_line;                         // line that holds it; the sequence lines follow
+    int64_t seq_len;                          // seq.l (= qual.l of a FASTQ record)
+    int64_t seq_cum;                          // sum of seq_len over the records before this one
+    uint32_t hdr_len;                         // to the end of the line ('\n' excluded, a '\r' included)
+    uint32_t s_n;                             // lines between the header line and the one that ended the sequence
+    uint32_t q_n;                             // quality lines read (FASTQ records)
+    uint32_t flags;                           // KQ_F_*
+};
+static_assert(sizeof(KqRec) == 48, "KqRec layout");
+
+// ------------------------------------------------------------------ line table
+__global__ __launch_bounds__(BLOCK) void k_kq_count(const uint8_t *__restrict__ data, int64_t n, int64_t ntiles, int32_t *__restrict__ cnt,
+                                                   unsigned long long *__restrict__ hdrchars) {
+    const int lane = lane_id();
+    const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
+    uint32_t hc = 0;
+    for (int64_t t = wave; t < ntiles; t += nwaves) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int r = 0; r < KQ_TILE / 1024; ++r) {
+            const uint4 v = load16(data, t * KQ_TILE + r * 1024 + lane * CHUNK, n);
+            c += __popc(eq_mask16(v, 0x0A0A0A0Au));
+            hc += __popc(eq_mask16(v, 0x3E3E3E3Eu)) + __popc(eq_mask16(v, 0x40404040u));
+        }
+        c = wave_sum(c);
+        if (lane == 0) cnt[t] = (int32_t)c;
+    }
+    hc = wave_sum(hc);
+    if (lane == 0 && hc) atomicAdd(hdrchars, (unsigned long long)hc);
+}
+
+// nl[k] = offset of the k-th '\n'; the caller appends the end of the stream when the last line has none
+__global__ __launch_bounds__(BLOCK) void k_kq_lines(const uint8_t *__restrict__ data, int64_t n, int64_t ntiles, const int64_t *__restrict__ off,
+                                                   int64_t *__restrict__ nl, int64_t virt_at) {
+    const int lane = lane_id();
+    const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
+    if (virt_at >= 0 && blockIdx.x == 0 && threadIdx.x == 0) nl[virt_at] = n;
+    for (int64_t t = wave; t < ntiles; t += nwaves) {
+        int64_t base = off[t];
+#pragma unroll
+        for (int r = 0; r < KQ_TILE / 1024; ++r) {
+            const int64_t p = t * KQ_TILE + r * 1024 + lane * CHUNK;
+            uint32_t m = eq_mask16(load16(data, p, n), 0x0A0A0A0Au);
+            const uint32_t c = __popc(m), inc = wave_incl_scan(c);
+            int64_t o = base + inc - c;
+            while (m) {
+                const int k = __ffs(m) - 1;
+                m &= m - 1;
+                nl[o++] = p + k;
+            }
+            base += (int64_t)__shfl((int)inc, 63, 64);
+        }
+    }
+}
+
+// desc[i] = { start (64 bit), length, first byte | last byte << 8 | (no '\n' behind it) << 16 }
+__global__ __launch_bounds__(BLOCK) void k_kq_desc(const uint8_t *__restrict__ data, int64_t n, const int64_t *__restrict__ nl, int64_t L,
+                                                  uint4 *__restrict__ desc, uint32_t *__restrict__ err) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < L; i += (int64_t)gridDim.x * BLOCK) {
+        const int64_t start = i ? nl[i - 1] + 1 : 0, end = nl[i], len = end - start;
+        if (len > 0xFFFFFFF0ll) atomicOr(err, 1u);
+        uint32_t info = end == n ? 1u << 16 : 0u;
+        if (len > 0) info |= (uint32_t)data[start] | ((uint32_t)data[end - 1] << 8);
+        desc[i] = make_uint4((uint32_t)(start & 0xFFFFFFFFll), (uint32_t)(start >> 32), (uint32_t)len, info);
+    }
+}
+
+// ------------------------------------------------------------------ the walk
+struct KqOut { long long n_rec, code, seq_bytes, pad; };
+
+__device__ __forceinline__ uint32_t kq_ld(const volatile uint32_t *p) { return *p; }
+__device__ __forceinline__ void kq_rec_store(KqRec *__restrict__ r, int64_t hdr_off, int64_t hdr_line, int64_t seq_len, int64_t seq_cum,
+                                             uint32_t hdr_len, uint32_t s_n, uint32_t q_n, uint32_t flags) {
+    KqRec t;
+    t.hdr_off = hdr_off; t.hdr_line = hdr_line; t.seq_len = seq_len; t.seq_cum = seq_cum;
+    t.hdr_len = hdr_len; t.s_n = s_n; t.q_n = q_n; t.flags = flags;
+    *r = t;
+}
+__device__ __forceinline__ int64_t kq_bcast64(int64_t v, int src) {
+    const int lo = __shfl((int)(v & 0xFFFFFFFFll), src, 64), hi = __shfl((int)(v >> 32), src, 64);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_kq_walk(const uint8_t *__restrict__ data, int64_t n, const uint4 *__restrict__ desc, int64_t L,
+                                                  KqRec *__restrict__ recs, int64_t cap, int64_t *__restrict__ ldst,
+                                                  uint32_t *__restrict__ lcon, KqOut *__restrict__ out) {
+    __shared__ uint4 ring[KQ_RING];
+    __shared__ volatile uint32_t ready[KQ_SLOTS];         // batch number + 1 that a slot holds
+    __shared__ volatile uint32_t cons_batch, stop;
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    if (threadIdx.x < KQ_SLOTS) ready[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { cons_batch = 0; stop = 0; }
+    __syncthreads();
+    const int64_t nb = (L + KQ_BATCH - 1) / KQ_BATCH;
+
+    if (w > 0) {
+        // ---------------- producers: batch b -> slot b % KQ_SLOTS, once the walker has left batch b - KQ_SLOTS
+        for (int64_t b = w - 1; b < nb; b += KQ_PRODUCERS) {
+            uint4 v[KQ_BATCH / 64];
+#pragma unroll
+            for (int r = 0; r < KQ_BATCH / 64; ++r) {
+                const int64_t i = b * KQ_BATCH + r * 64 + lane;
+                v[r] = i < L ? desc[i] : make_uint4(0, 0, 0, 0);
+            }
+            if (b >= KQ_SLOTS)
+                while ((int64_t)kq_ld(&cons_batch) < b - (KQ_SLOTS - 1) && !kq_ld(&stop)) __builtin_amdgcn_s_sleep(2);
+            if (kq_ld(&stop)) return;
+            const int slot = (int)(b % KQ_SLOTS);
+#pragma unroll
+            for (int r = 0; r < KQ_BATCH / 64; ++r) ring[slot * KQ_BATCH + r * 64 + lane] = v[r];
+            __threadfence_block();
+            if (lane == 0) ready[slot] = (uint32_t)(b + 1);
+        }
+        return;
+    }
+
+    // ---------------- the walker (wave 0).  Everything but the per-lane window values is wave-uniform.
+    int st = KQ_SEEK, code = 0;
+    int64_t j = 0, S = 0, nrec = 0;
+    int64_t cur_off = 0, cur_line = 0, acc = 0, qacc = 0, tcr = 0, lastc = 0;
+    uint32_t cur_len = 0, cur_flags = 0, qn = 0, sn = 0;
+    int64_t have = -1;                                      // batches [0, have] are known to be in the ring
+    uint32_t pub = 0;
+    const uint64_t lt = (1ull << lane) - 1ull;
+
+    while (j < L && !code) {
+        // the window: lines j .. j + 63
+        const int64_t lastline = j + 63 < L ? j + 63 : L - 1, bneed = lastline / KQ_BATCH;
+        while (have < bneed) {
+            const int64_t b = have + 1;
+            while (kq_ld(&ready[b % KQ_SLOTS]) != (uint32_t)(b + 1)) __builtin_amdgcn_s_sleep(1);
+            have = b;
+        }
+        __threadfence_block();
+        const uint32_t jb = (uint32_t)(j / KQ_BATCH);
+        if (jb != pub) { pub = jb; if (lane == 0) cons_batch = jb; }
+        const bool ex = j + lane < L;
+        const uint4 d = ex ? ring[(j + lane) & (KQ_RING - 1)] : make_uint4(0, 0, 0, 0);
+        const int64_t start = (int64_t)(((uint64_t)d.y << 32) | d.x);
+        const uint32_t len = d.z, first = d.w & 0xFF, last = (d.w >> 8) & 0xFF;
+        const bool un = (d.w >> 16) & 1;
+        const bool ishdr = ex && len >= 1 && (first == '>' || first == '@');
+        const bool big = __ballot(ex && len >= KQ_BIG) != 0;
+
+        if (st == KQ_SEEK && !big) {
+            // ---- 16 four-line records at once (the lines of a well-formed FASTQ file)
+            const int role = lane & 3;
+            const uint32_t con = len - ((last == 13 && len > 1) ? 1u : 0u);
+            const uint32_t con2 = (uint32_t)__shfl((int)con, (lane + 62) & 63, 64);      // of the line two above
+            bool ok;
+            if (role == 0) ok = ishdr;
+            else if (role == 1) ok = ex && len >= 1 && first != '>' && first != '@' && first != '+';
+            else if (role == 2) ok = ex && len >= 1 && first == '+' && !un;
+            else ok = ex && con == con2;
+            const uint64_t m = __ballot(ok);
+            const uint64_t g = m & (m >> 1) & (m >> 2) & (m >> 3) & 0x1111111111111111ull;
+            const uint64_t bad = ~g & 0x1111111111111111ull;
+            const int R = bad ? (__builtin_ctzll(bad) >> 2) : 16;
+            if (R > 0) {
+                const bool mine = (lane >> 2) < R;
+                const uint32_t pin = wave_incl_scan((role == 1 && mine) ? con : 0u);
+                const uint32_t total = (uint32_t)__shfl((int)pin, 63, 64);
+                const uint32_t seqlen = (uint32_t)__shfl((int)con, (lane + 1) & 63, 64);
+                if (mine) {
+                    if (role == 0) {
+                        const int64_t ri = nrec + (lane >> 2);
+                        if (ri < cap) kq_rec_store(&recs[ri], start + 1, j + lane, seqlen, S + pin, len - 1, 1, 1, KQ_F_FASTQ);
+                    } else if (role != 2) {
+                        ldst[j + lane] = (S + pin - con) | ((int64_t)(role == 1 ? KQ_C_SEQ : KQ_C_QUAL) << 62);
+                        lcon[j + lane] = con;
+                    }
+                }
+                nrec += R; S += total; j += 4 * R;
+                continue;
+            }
+        }
+        // lane 0 holds line j
+        const int64_t s0 = kq_bcast64(start, 0);
+        const uint32_t len0 = (uint32_t)__shfl((int)len, 0, 64), info0 = (uint32_t)__shfl((int)d.w, 0, 64);
+        const uint32_t f0 = info0 & 0xFF, la0 = (info0 >> 8) & 0xFF;
+        const bool un0 = (info0 >> 16) & 1;
+
+        if (st == KQ_SEEK) {
+            if (len0 >= 1 && (f0 == '>' || f0 == '@')) { st = KQ_HDR; continue; }
+            // kseq.c:142-146: the next '>' or '@' wherever it stands
+            int64_t p = -1;
+            for (int64_t q = 0; q < (int64_t)len0 && p < 0; q += 64) {
+                const bool hit = q + lane < (int64_t)len0 && (data[s0 + q + lane] == '>' || data[s0 + q + lane] == '@');
+                const uint64_t hm = __ballot(hit);
+                if (hm) p = s0 + q + __builtin_ctzll(hm);
+            }
+            if (p >= 0) {
+                if (p + 1 >= n) { code = -1; break; }
+                cur_off = p + 1; cur_len = (uint32_t)(s0 + len0 - (p + 1)); cur_line = j; cur_flags = un0 ? KQ_F_HDR_UNTERM : 0;
+                st = KQ_SEQ; acc = 0;
+            }
+            ++j;
+            continue;
+        }
+        if ((st == KQ_HDR || st == KQ_SEQ) && !big) {
+            // ---- a run of header / sequence lines at once, up to the first line that needs a closer look
+            const bool stopper = !ex || (len >= 1 && first == '+') || (len == 1 && first == 13) || un;
+            const uint64_t sm = __ballot(stopper);
+            const int m = sm ? __builtin_ctzll(sm) : 64;
+            if (m > 0) {
+                const bool inr = lane < m;
+                const bool H = inr && ishdr;
+                const uint32_t con = (inr && !H && len > 0) ? len - (last == 13 ? 1u : 0u) : 0u;
+                const uint32_t pin = wave_incl_scan(con), pex = pin - con;
+                const uint64_t hm = __ballot(H);
+                const bool carried = st == KQ_SEQ;
+                const int64_t carry = carried ? acc : 0;
+                if (inr && !H && len > 0) {
+                    ldst[j + lane] = (S + carry + pex) | ((int64_t)KQ_C_SEQ << 62);
+                    lcon[j + lane] = con;
+                }
+                const uint32_t pin_end = (uint32_t)__shfl((int)pin, m - 1, 64);
+                if (hm) {
+                    const int h0 = __builtin_ctzll(hm), hl = 63 - __builtin_clzll(hm), nh = __popcll(hm);
+                    const uint32_t pex_h0 = (uint32_t)__shfl((int)pex, h0, 64);
+                    if (carried) {
+                        if (lane == 0 && nrec < cap)
+                            kq_rec_store(&recs[nrec], cur_off, cur_line, acc + pex_h0, S, cur_len, (uint32_t)(j + h0 - cur_line - 1), 0, cur_flags);
+                        ++nrec;
+                    }
+                    const uint64_t above = lane < 63 ? hm >> (lane + 1) : 0ull;
+                    const int h2 = above ? lane + 1 + __builtin_ctzll(above) : lane;
+                    const uint32_t pex_h2 = (uint32_t)__shfl((int)pex, h2, 64);
+                    if (H && above) {
+                        const int64_t ri = nrec + __popcll(hm & lt);
+                        if (ri < cap) kq_rec_store(&recs[ri], start + 1, j + lane, pex_h2 - pin, S + carry + pin, len - 1, (uint32_t)(h2 - lane - 1), 0, 0);
+                    }
+                    nrec += nh - 1;
+                    const uint32_t pin_hl = (uint32_t)__shfl((int)pin, hl, 64);
+                    cur_off = kq_bcast64(start, hl) + 1; cur_len = (uint32_t)__shfl((int)len, hl, 64) - 1; cur_line = j + hl; cur_flags = 0;
+                    S += carry + pin_hl;
+                    acc = pin_end - pin_hl;
+                } else {
+                    acc += pin_end;
+                }
+                st = KQ_SEQ;
+                j += m;
+                continue;
+            }
+        }
+        // ---- one line
+        if (st == KQ_HDR) {
+            if (un0 && len0 == 1) { code = -1; break; }
+            cur_off = s0 + 1; cur_len = len0 - 1; cur_line = j; cur_flags = un0 ? KQ_F_HDR_UNTERM : 0;
+            st = KQ_SEQ; acc = 0;
+            ++j;
+        } else if (st == KQ_SEQ) {
+            if (len0 == 0) {
+                ++j;
+            } else if (f0 == '>' || f0 == '@') {
+                if (lane == 0 && nrec < cap) kq_rec_store(&recs[nrec], cur_off, cur_line, acc, S, cur_len, (uint32_t)(j - cur_line - 1), 0, cur_flags);
+                ++nrec; S += acc;
+                st = KQ_HDR;
+            } else if (f0 == '+') {
+                if (un0) { code = -2; break; }
+                sn = (uint32_t)(j - cur_line - 1);
+                st = KQ_QUAL; qacc = 0; qn = 0; tcr = 0; lastc = j;
+                ++j;
+            } else {
+                // the first byte goes in by itself (kseq.c:156); the strip belongs to the call for the rest of the line,
+                // which returns early when nothing at all is left: a lone CR as the last byte of the stream stays
+                const uint32_t con = len0 - ((la0 == 13 && acc + len0 > 1 && !(un0 && len0 == 1)) ? 1u : 0u);
+                if (lane == 0) { ldst[j] = (S + acc) | ((int64_t)KQ_C_SEQ << 62); lcon[j] = con; }
+                acc += con;
+                ++j;
+            }
+        } else {
+            // KQ_QUAL.  ks_getuntil2 strips ONE trailing CR per call from a string longer than one byte (kseq.c:106), also
+            // in a call that appends nothing: tcr = the run of CRs the quality string ends with, lastc = the last line that
+            // holds bytes of it.
+            int64_t tr = 0;
+            if (la0 == 13) while (tr < (int64_t)len0 && data[s0 + len0 - 1 - tr] == 13) ++tr;
+            uint32_t con = len0;
+            qacc += len0;
+            tcr = tr == (int64_t)len0 ? tcr + len0 : tr;
+            if (tcr >= 1 && qacc > 1) {
+                --qacc; --tcr;
+                if (len0) --con;
+                else if (lane == 0) {
+                    while (lcon[lastc] == 0) --lastc;
+                    lcon[lastc] -= 1;
+                }
+            }
+            lastc = __shfl((int)(lastc & 0xFFFFFFFFll), 0, 64) | (lastc & ~0xFFFFFFFFll);   // (lane 0 may have walked back within 4 G lines)
+            if (lane == 0) { ldst[j] = (S + qacc - con) | ((int64_t)KQ_C_QUAL << 62); lcon[j] = con; }
+            if (con) lastc = j;
+            ++qn; ++j;
+            if (qacc >= acc) {
+                if (qacc != acc) { code = -2; break; }
+                if (lane == 0 && nrec < cap) kq_rec_store(&recs[nrec], cur_off, cur_line, acc, S, cur_len, sn, qn, cur_flags | KQ_F_FASTQ);
+                ++nrec; S += acc;
+                st = KQ_SEEK;
+            }
+        }
+    }
+    if (!code) {
+        if (st == KQ_SEQ) {
+            if (lane == 0 && nrec < cap) kq_rec_store(&recs[nrec], cur_off, cur_line, acc, S, cur_len, (uint32_t)(L - cur_line - 1), 0, cur_flags);
+            ++nrec; S += acc;
+            code = -1;
+        } else if (st == KQ_QUAL) {
+            if (qn == 0 && acc == 0) {
+                if (lane == 0 && nrec < cap) kq_rec_store(&recs[nrec], cur_off, cur_line, 0, S, cur_len, sn, 0, cur_flags | KQ_F_FASTQ | KQ_F_UNTOUCHED);
+                ++nrec;
+                code = -1;
+            } else code = -2;
+        } else code = -1;
+    }
+    if (lane == 0) {
+        stop = 1;
+        out->n_rec = nrec; out->code = code; out->seq_bytes = S; out->pad = nrec > cap ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------ gather
+// Lines [l0, l1] of the table -> seq_dst / qual_dst at (position - cum0): one 16-lane group per line, 16 bytes per lane
+// and step.  Lines longer than KQ_LONG go on a list (k_kq_gather_long: the whole grid on each of them).
+struct KqLong { int64_t src, dst; uint32_t len, cls; };
+__device__ __forceinline__ void kq_copy16(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int64_t o, int64_t len, bool upper) {
+    if (o + 16 <= len) {
+        uint4 v = *reinterpret_cast<const uint4_u *>(src + o);
+        if (upper) { v.x = upper4(v.x); v.y = upper4(v.y); v.z = upper4(v.z); v.w = upper4(v.w); }
+        *reinterpret_cast<uint4_u *>(dst + o) = v;
+    } else {
+        for (int64_t k = o; k < len; ++k) {
+            uint8_t c = src[k];
+            if (upper && c >= 'a' && c <= 'z') c -= 32;
+            dst[k] = c;
+        }
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_kq_gather(const uint8_t *__restrict__ data, const int64_t *__restrict__ nl, const int64_t *__restrict__ ldst,
+                                                    const uint32_t *__restrict__ lcon, int64_t l0, int64_t l1, int64_t cum0, uint8_t *__restrict__ seq_dst,
+                                                    uint8_t *__restrict__ qual_dst, int upper, KqLong *__restrict__ longs, uint32_t *__restrict__ n_long,
+                                                    uint32_t long_cap) {
+    const int gl = threadIdx.x & 15;
+    const int64_t grp = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 4, ngrp = ((int64_t)gridDim.x * BLOCK) >> 4;
+    for (int64_t i = l0 + grp; i <= l1; i += ngrp) {
+        const int64_t e = ldst[i];
+        const int cls = (int)((uint64_t)e >> 62);
+        if (!cls) continue;
+        uint8_t *base = cls == KQ_C_SEQ ? seq_dst : qual_dst;
+        const uint32_t con = lcon[i];
+        if (!base || !con) continue;
+        const int64_t src = i ? nl[i - 1] + 1 : 0, dpos = (e & KQ_POS) - cum0;
+        if (con > (uint32_t)KQ_LONG) {
+            if (gl == 0) {
+                const uint32_t k = atomicAdd(n_long, 1u);
+                if (k < long_cap) longs[k] = KqLong{src, dpos, con, (uint32_t)cls};
+            }
+            continue;
+        }
+        const bool up = upper && cls == KQ_C_SEQ;
+        for (int64_t o = gl * 16; o < (int64_t)con; o += 256) kq_copy16(base + dpos, data + src, o, con, up);
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_kq_gather_long(const uint8_t *__restrict__ data, const KqLong *__restrict__ longs, uint32_t n_long,
+                                                         uint8_t *__restrict__ seq_dst, uint8_t *__restrict__ qual_dst, int upper) {
+    for (uint32_t e = 0; e < n_long; ++e) {
+        const KqLong q = longs[e];
+        uint8_t *base = q.cls == KQ_C_SEQ ? seq_dst : qual_dst;
+        const bool up = upper && q.cls == KQ_C_SEQ;
+        for (int64_t o = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * 16; o < (int64_t)q.len; o += (int64_t)gridDim.x * BLOCK * 16)
+            kq_copy16(base + q.dst, data + q.src, o, q.len, up);
+    }
+}
+
+}  // namespace fx

@@ -35,6 +35,7 @@
 #include "fx_fxi.hpp"
 #include "fx_pgzip.hpp"
 #include "fx_sort.hpp"
+#include "fx_kseq.hpp"
 
 using namespace fx;
 
@@ -185,10 +186,10 @@ static void crc_tables(CrcTables *T) {
 }
 
 enum KernelId { K_SPAN_SCAN = 0, K_GRAN_REDUCE, K_GRAN_PREFIX, K_HDR_REC, K_GRAN_LINES, K_GRAN_EXACT, K_FASTA_FINALIZE, K_FETCH,
-                K_FASTA_COMP, K_FASTA_COMP_EDGE, K_FASTA_COMP_SMALL, K_FASTQ_LINES, K_FASTQ_ROWS, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_BGZF_CRC, K_SCAN_COMP, K_COMP_ATTRIBUTE, K_BGZF_SERIAL, K_FETCH_REST, K_NKERN };
+                K_FASTA_COMP, K_FASTA_COMP_EDGE, K_FASTA_COMP_SMALL, K_FASTQ_LINES, K_FASTQ_ROWS, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_BGZF_CRC, K_SCAN_COMP, K_COMP_ATTRIBUTE, K_BGZF_SERIAL, K_FETCH_REST, K_KQ_LINES, K_KQ_WALK, K_KQ_GATHER, K_NKERN };
 static const char *const kKernelNames[K_NKERN] = {
     "k_span_scan", "k_gran_reduce", "k_gran_prefix", "k_hdr_rec", "k_gran_lines", "k_gran_exact", "k_fasta_finalize", "k_fetch",
-    "k_fasta_comp", "k_fasta_comp_edge", "k_fasta_comp_small", "k_fastq_lines", "k_fastq_rows", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy", "k_bgzf_crc", "k_scan_comp", "k_comp_attribute", "k_bgzf_decode_serial", "k_fetch_rest"};
+    "k_fasta_comp", "k_fasta_comp_edge", "k_fasta_comp_small", "k_fastq_lines", "k_fastq_rows", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy", "k_bgzf_crc", "k_scan_comp", "k_comp_attribute", "k_bgzf_decode_serial", "k_fetch_rest", "k_kq_lines", "k_kq_walk", "k_kq_gather"};
 
 struct Prof {
     bool on = false;
@@ -287,6 +288,12 @@ struct fx_handle {
     int64_t fq_c2 = 0;         // newlines of the shard below core_end - 1 (ownership of records, fx_fastq_scan)
     long long fq_maxlen = 0, fq_minlen = 0;
     bool fastq_built = false;
+    // Fastx (fx_kseq.hpp): the line table, where each line's bytes go, the records of the kseq walk
+    DevBuf<int64_t> kq_nl, kq_ldst;
+    DevBuf<uint32_t> kq_lcon;
+    DevBuf<KqRec> kq_recs;
+    int64_t kq_nrec = -1, kq_lines = 0, kq_seq_bytes = 0;
+    int kq_code = 0;
     DevBuf<uint8_t> arena;     // scratch for host-array calls (Staged)
     int64_t arena_used = 0;
     int64_t halo = 0;          // trailing bytes of the blob that belong to the next shard's core
@@ -1826,6 +1833,133 @@ extern "C" int fx_fastq_comp(fx_handle *h, int64_t base[5], int64_t meta[5]) {
     if (acc.maxqs > 74) phred = 64;                        // fastq.c:768-774
     if (acc.minqs < 59) phred = 33;
     meta[0] = h->fq_maxlen; meta[1] = h->fq_minlen; meta[2] = acc.minqs; meta[3] = acc.maxqs; meta[4] = phred;
+    return FX_OK;
+}
+
+
+// ------------------------------------------------------------------- Fastx: the kseq walk (fx_kseq.hpp)
+extern "C" int fx_kseq_scan(fx_handle *h, int64_t *n_records, int64_t *n_lines, int64_t *seq_bytes, int *end_code) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    if (h->base != 0 || h->halo != 0) return fail(FX_ESTATE, "fx_kseq_scan works on a whole stream, not on a shard");
+    int rc = use_device(h);
+    if (rc) return rc;
+    h->kq_nrec = -1;
+    const int64_t n = h->n;
+    KqOut res{0, -1, 0, 0};
+    int64_t L = 0;
+    if (n > 0) {
+        const int64_t ntiles = (n + KQ_TILE - 1) / KQ_TILE, nchunks = (ntiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        ScratchBuf<int32_t> cnt;
+        ScratchBuf<int64_t> sums, off;
+        ScratchBuf<unsigned long long> ctl;                  // [0] '>' and '@' bytes, [1] error bits, [2..5] KqOut
+        if ((rc = cnt.alloc(h->device, ntiles, h->stream)) || (rc = sums.alloc(h->device, nchunks + 1, h->stream)) ||
+            (rc = off.alloc(h->device, ntiles + 1, h->stream)) || (rc = ctl.alloc(h->device, 8, h->stream)))
+            return rc;
+        HIPCHK(hipMemsetAsync(ctl.p, 0, 8 * sizeof(unsigned long long), h->stream));
+        const unsigned wide = (unsigned)std::min<int64_t>(nblocks(ntiles, BLOCK / 64), 256 * 8);
+        FX_LAUNCH(h, K_KQ_LINES, k_kq_count, dim3(wide), dim3(BLOCK), h->d_data, n, ntiles, cnt.p, ctl.p);
+        hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, cnt.p, ntiles, sums.p);
+        hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, sums.p, nchunks);
+        hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, cnt.p, ntiles, sums.p, off.p);
+        HIPCHK(hipGetLastError());
+        int64_t n_nl = 0;
+        unsigned long long hdrchars = 0;
+        uint8_t tail = 0;
+        HIPCHK(hipMemcpyAsync(&n_nl, off.p + ntiles, sizeof n_nl, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(&hdrchars, ctl.p, sizeof hdrchars, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(&tail, h->d_data + (n - 1), 1, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const bool virt = tail != '\n';                      // the last line has no '\n': it ends where the stream ends
+        L = n_nl + (virt ? 1 : 0);
+        const int64_t cap = std::min<int64_t>(L, (int64_t)hdrchars) + 1;
+        ScratchBuf<uint4> desc;
+        if ((rc = h->kq_nl.alloc(L)) || (rc = h->kq_ldst.alloc(L)) || (rc = h->kq_lcon.alloc(L)) || (rc = h->kq_recs.alloc(cap)) ||
+            (rc = desc.alloc(h->device, L, h->stream)))
+            return rc;
+        HIPCHK(hipMemsetAsync(h->kq_ldst.p, 0, (size_t)L * sizeof(int64_t), h->stream));
+        HIPCHK(hipMemsetAsync(h->kq_lcon.p, 0, (size_t)L * sizeof(uint32_t), h->stream));
+        FX_LAUNCH(h, K_KQ_LINES, k_kq_lines, dim3(wide), dim3(BLOCK), h->d_data, n, ntiles, off.p, h->kq_nl.p, virt ? L - 1 : (int64_t)-1);
+        hipLaunchKernelGGL(k_kq_desc, dim3((unsigned)std::min<int64_t>(nblocks(L, BLOCK), 256 * 16)), dim3(BLOCK), 0, h->stream, h->d_data, n,
+                           h->kq_nl.p, L, desc.p, (uint32_t *)(ctl.p + 1));
+        FX_LAUNCH(h, K_KQ_WALK, k_kq_walk, dim3(1), dim3(BLOCK), h->d_data, n, desc.p, L, h->kq_recs.p, cap, h->kq_ldst.p, h->kq_lcon.p,
+                  (KqOut *)(ctl.p + 2));
+        HIPCHK(hipGetLastError());
+        unsigned long long back[6];
+        HIPCHK(hipMemcpyAsync(back, ctl.p, sizeof back, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (back[1]) return fail(FX_ERANGE, "a line of 4 GiB or more");
+        memcpy(&res, back + 2, sizeof res);
+        if (res.pad) return fail(FX_EDEVICE, "kseq walk: record table overflow (%lld records, room for %lld)", res.n_rec, (long long)cap);
+    }
+    h->kq_nrec = res.n_rec; h->kq_lines = L; h->kq_seq_bytes = res.seq_bytes; h->kq_code = (int)res.code;
+    if (n_records) *n_records = res.n_rec;
+    if (n_lines) *n_lines = L;
+    if (seq_bytes) *seq_bytes = res.seq_bytes;
+    if (end_code) *end_code = (int)res.code;
+    return FX_OK;
+}
+
+extern "C" int fx_kseq_records(fx_handle *h, int64_t first, int64_t count, fx_kseq_rec *out) {
+    if (!h || (count > 0 && !out)) return fail(FX_EINVAL, "null argument");
+    if (h->kq_nrec < 0) return fail(FX_ESTATE, "fx_kseq_scan has not run");
+    if (first < 0 || count < 0 || first + count > h->kq_nrec) return fail(FX_ERANGE, "records [%lld, %lld) of %lld", (long long)first, (long long)(first + count), (long long)h->kq_nrec);
+    if (!count) return FX_OK;
+    int rc = use_device(h);
+    if (rc) return rc;
+    static_assert(sizeof(fx_kseq_rec) == sizeof(KqRec), "fx_kseq_rec mirrors KqRec");
+    HIPCHK(hipMemcpyAsync(out, h->kq_recs.p + first, (size_t)count * sizeof(KqRec), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FX_OK;
+}
+
+extern "C" int fx_kseq_fetch(fx_handle *h, int where, int64_t first, int64_t count, int flags, uint8_t *seq_dst, uint8_t *qual_dst,
+                             int64_t *n_bytes) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    if (h->kq_nrec < 0) return fail(FX_ESTATE, "fx_kseq_scan has not run");
+    if (first < 0 || count < 0 || first + count > h->kq_nrec) return fail(FX_ERANGE, "records [%lld, %lld) of %lld", (long long)first, (long long)(first + count), (long long)h->kq_nrec);
+    if (n_bytes) *n_bytes = 0;
+    if (!count) return FX_OK;
+    int rc = use_device(h);
+    if (rc) return rc;
+    KqRec a, b;
+    HIPCHK(hipMemcpyAsync(&a, h->kq_recs.p + first, sizeof a, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&b, h->kq_recs.p + first + count - 1, sizeof b, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int64_t total = b.seq_cum + b.seq_len - a.seq_cum;
+    if (n_bytes) *n_bytes = total;
+    if (total <= 0 || (!seq_dst && !qual_dst)) return FX_OK;
+    const int64_t l0 = a.hdr_line, l1 = std::min<int64_t>(b.hdr_line + b.s_n + ((b.flags & KQ_F_FASTQ) ? 1 + (int64_t)b.q_n : 0), h->kq_lines - 1);
+    ScratchBuf<uint8_t> d_seq, d_qual;
+    uint8_t *ds = seq_dst, *dq = qual_dst;
+    if (where == FX_HOST) {
+        if (seq_dst) { if ((rc = d_seq.alloc(h->device, total, h->stream))) return rc; ds = d_seq.p; }
+        if (qual_dst) { if ((rc = d_qual.alloc(h->device, total, h->stream))) return rc; dq = d_qual.p; }
+    }
+    // a FASTA-style record has no quality: those stretches of the quality string read as zero bytes
+    if (dq) HIPCHK(hipMemsetAsync(dq, 0, (size_t)total, h->stream));
+    const uint32_t long_cap = (uint32_t)std::min<int64_t>(2 * (total / KQ_LONG + 2), 1 << 24);
+    ScratchBuf<KqLong> longs;
+    ScratchBuf<uint32_t> n_long;
+    if ((rc = longs.alloc(h->device, long_cap, h->stream)) || (rc = n_long.alloc(h->device, 1, h->stream))) return rc;
+    HIPCHK(hipMemsetAsync(n_long.p, 0, sizeof(uint32_t), h->stream));
+    const unsigned g = (unsigned)std::min<int64_t>(nblocks(l1 - l0 + 1, BLOCK / 16), 256 * 16);
+    FX_LAUNCH(h, K_KQ_GATHER, k_kq_gather, dim3(g), dim3(BLOCK), h->d_data, h->kq_nl.p, h->kq_ldst.p, h->kq_lcon.p, l0, l1, a.seq_cum, ds, dq,
+              (flags & FX_UPPER) ? 1 : 0, longs.p, n_long.p, long_cap);
+    HIPCHK(hipGetLastError());
+    uint32_t nl_host = 0;
+    HIPCHK(hipMemcpyAsync(&nl_host, n_long.p, sizeof nl_host, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (nl_host > long_cap) return fail(FX_EDEVICE, "kseq gather: long-line list overflow");
+    if (nl_host) {
+        hipLaunchKernelGGL(k_kq_gather_long, dim3(256 * 4), dim3(BLOCK), 0, h->stream, h->d_data, longs.p, nl_host, ds, dq, (flags & FX_UPPER) ? 1 : 0);
+        HIPCHK(hipGetLastError());
+    }
+    if (where == FX_HOST) {
+        if (seq_dst) HIPCHK(hipMemcpyAsync(seq_dst, ds, (size_t)total, hipMemcpyDeviceToHost, h->stream));
+        if (qual_dst) HIPCHK(hipMemcpyAsync(qual_dst, dq, (size_t)total, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->prof.drain();
     return FX_OK;
 }
 

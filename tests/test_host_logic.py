@@ -891,33 +891,51 @@ def test_line_regular_rule(oracle):
     assert int(recs[0]["norm"]) == 1 and _reg_of(b">c\nAAAA\nCC\nGGGG\n", recs[0]) == 0
 
 
-def test_fastx_name_comment_rule(tmp_path):
-    """Fastx's cut of a header line into (name, comment) and its None-then-"" rule for records without a comment
-    (api._name_comment + the `buffered` flag of Fastx.__iter__), replayed on header lines taken from the bytes and
-    compared with what the compiled reference's Fastx returns for the same files."""
-    from pyfastx_amd.api import _name_comment
-    from test_oracle_vs_reference import _FASTA_STYLES, _fasta_text, _fastq_text
-    assert _name_comment("abc def  ghi") == ("abc", "def  ghi") and _name_comment("abc") == ("abc", None)
-    assert _name_comment("a\tb c") == ("a", "b c") and _name_comment("a\x0bb") == ("a", "b") and _name_comment("") == ("", None)
-    ref = _ref_pyfastx()
-    if ref is None:
-        pytest.skip("oracle/_ref not built here")
-    for seed in range(60):
-        rng = np.random.default_rng(8900 + seed)
-        raw = _fasta_text(rng, dict(_FASTA_STYLES[seed % 2]))
-        rawq = _fastq_text(rng, 50, 150, crlf=bool(seed & 1), plus_name=bool(seed & 2), trailing=(seed % 8 != 4), qlo=33, qhi=74)
-        for kind, data in (("fa", raw), ("fq", rawq)):
-            p = str(tmp_path / ("x." + kind))
-            open(p, "wb").write(data)
-            theirs = [(t[0], t[-1]) for t in ref.Fastx(p, comment=True)]
-            lines = data.split(b"\n")
-            heads = [l for l in lines if l.startswith(b">")] if kind == "fa" else lines[0::4][:len(theirs)]
-            buffered, mine = False, []
-            for l in heads:
-                nm, cm = _name_comment(l[1:].rstrip(b"\r").decode())
-                buffered = buffered or cm is not None or l.endswith(b"\r")
-                mine.append((nm, "" if cm is None and buffered else cm))
-            assert mine == theirs, (seed, kind)
+def test_fastx_header_cut(oracle):
+    """Fastx's cut of a header line into (name, comment) (api._kseq_header: kseq.c:148-149 with the one-CR rule of
+    kseq.c:106) against the oracle's records, on the headers of the kseq test inputs."""
+    import random
+    from kseq_cases import FIXED, gen
+    from pyfastx_amd.api import _kseq_header
+    assert _kseq_header(b"abc def  ghi", False) == (b"abc", b"def  ghi") and _kseq_header(b"abc", False) == (b"abc", None)
+    assert _kseq_header(b"a\tb c\r", False) == (b"a", b"b c") and _kseq_header(b"a\x0bb", False) == (b"a", b"b")
+    assert _kseq_header(b"", False) == (b"", None) and _kseq_header(b"a \r", False) == (b"a", b"\r") and _kseq_header(b"a\r", False) == (b"a", b"")
+    assert _kseq_header(b"a ", True) == (b"a", None) and _kseq_header(b"a ", False) == (b"a", b"")
+    rng = random.Random(77)
+    seen = 0
+    for data in list(FIXED) + [gen(rng) for _ in range(200)]:
+        for r in oracle.kseq(data)[0]:
+            e = data.find(b"\n", int(r["name_off"]))
+            raw = data[int(r["name_off"]):e if e >= 0 else len(data)]
+            nm, cm = _kseq_header(raw, e < 0)
+            want_c = None if r["com_len"] < 0 else data[int(r["com_off"]):int(r["com_off"] + r["com_len"])]
+            assert (nm, cm) == (data[int(r["name_off"]):int(r["name_off"] + r["name_len"])], want_c), (data, raw)
+            seen += 1
+    assert seen > 1000
+
+
+def test_kseq_line_model_equals_the_oracle(oracle):
+    """tools/kseq_line_model.py -- the executable model k_kq_walk (fx_kseq.hpp) transliterates: kseq_read over a line
+    table with its two 64-line steps -- against the byte-level oracle, with and without the wide steps."""
+    import random
+    import sys
+    from conftest import ROOT
+    from kseq_cases import FIXED, gen
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kseq_line_model as M
+    rng = random.Random(505)
+    for data in list(FIXED) + [gen(rng) for _ in range(250)]:
+        recs, seq, qual, code = oracle.kseq(data)
+        want = []
+        for r in recs:
+            com = None if r["com_len"] < 0 else data[int(r["com_off"]):int(r["com_off"] + r["com_len"])]
+            q = None if r["qual_len"] == -1 else bytes(qual[int(r["qual_off"]):int(r["qual_off"]) + max(int(r["qual_len"]), 0)])
+            want.append((data[int(r["name_off"]):int(r["name_off"] + r["name_len"])], com, bytes(seq[int(r["seq_off"]):int(r["seq_off"] + r["seq_len"])]), q,
+                         bool(r["qual_len"] == -2)))
+        for fast in (True, False):
+            got, gcode = M.materialise(data, fast)
+            have = [M.header_parts(hdr, bool(fl & M.F_HDR_UNTERM)) + (s, q, bool(fl & M.F_UNTOUCHED)) for hdr, fl, s, q in got]
+            assert have == want and gcode == code, (data, fast)
 
 
 def test_shard_fetcher_degenerate_batches(oracle):

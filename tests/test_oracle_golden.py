@@ -86,6 +86,18 @@ def test_fastq_edge(oracle):
         assert [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"], c["phred"]] == case["meta"], name
 
 
+def test_fastx_golden(oracle):
+    """fxo_kseq + fxoracle.fastx_tuples against what the reference's Fastx yielded (tests/golden/make_golden_fastx.py)."""
+    cases = load_golden("fastx")
+    assert len(cases) > 100
+    for case in cases:
+        raw = case["text"].encode("latin-1")
+        for key, want in case["out"].items():
+            fmt, up, com = key.split(":")
+            got = [list(t) for t in oracle.fastx_tuples(raw, fmt, uppercase=bool(int(up)), comment=bool(int(com)))]
+            assert got == want, (raw, key)
+
+
 def test_revcomp(oracle):
     for s, want in load_golden("misc")["reverse_complement"]:
         assert oracle.revcomp(s.encode(), 3).decode() == want

@@ -143,6 +143,24 @@ def test_fastq_rows_equal_the_reference(oracle, ref, tmp_path, seed):
     db.close()
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FX_FUZZ", "8"))))
+def test_kseq_oracle_equals_the_reference_fastx(oracle, ref, tmp_path, seed):
+    """fxo_kseq (kseq.c:138-179 restated) + the tuple builders of fastx.c against the compiled reference's Fastx, on files
+    in which everything kseq tolerates happens (tests/kseq_cases.py), both builders, comment and uppercase options."""
+    import random
+    from kseq_cases import FIXED, gen
+    rng = random.Random(4100 + seed)
+    p = str(tmp_path / "t.fx")
+    for data in (FIXED if seed == 0 else []) + [gen(rng) for _ in range(150)]:
+        if oracle.kseq_undefined(data):          # the reference reads a buffer it never wrote: nothing to compare with
+            continue
+        with open(p, "wb") as f:
+            f.write(data)
+        for fmt in ("fasta", "fastq"):
+            for kw in (dict(), dict(comment=True), dict(uppercase=True, comment=True)):
+                assert list(ref.Fastx(p, format=fmt, **kw)) == oracle.fastx_tuples(data, fmt, **kw), (data, fmt, kw)
+
+
 @pytest.mark.parametrize("members", [1, 3])
 def test_refshim_serves_reads_from_imported_points(ref, tmp_path, members):
     """The zran work-alike under the compiled reference (oracle/refshim/zran.c; indexed_gzip is not part of the reference
