@@ -261,6 +261,10 @@ typedef struct {
 /* The walk over the whole resident stream.  *end_code = the negative value that ended the reference's iteration:
  * -1 end of file, -2 truncated quality string (kseq.c:131-136). */
 int fx_kseq_scan(fx_handle *h, int64_t *n_records, int64_t *n_lines, int64_t *seq_bytes, int *end_code);
+/* How many lines of the last scan the parallel passes took (a file of four-line FASTQ records, or of plain FASTA header /
+ * sequence lines, up to the first line that is neither); the sequential walk did the rest.  FX_KSEQ_WALK_ONLY=1 in the
+ * environment sends everything through the walk. */
+int64_t fx_kseq_prefix_lines(const fx_handle *h);
 /* Records [first, first + count) of the table, to host memory. */
 int fx_kseq_records(fx_handle *h, int64_t first, int64_t count, fx_kseq_rec *out);
 /* Their sequence strings, one behind the other (record k at seq_cum[k] - seq_cum[first]), and their quality strings at

@@ -51,7 +51,7 @@ SYMBOLS = [
     "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
     "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
     "fx_comm_unique_id", "fx_comm_init", "fx_comm_destroy", "fx_comm_rank", "fx_comm_world", "fx_comm_allgather", "fx_fasta_build_sharded_begin",
-    "fx_fasta_build_sharded", "fx_comm_summaries", "fx_fastq_build_sharded", "fx_bgzf_counts", "fx_sort_packed_names", "fx_gunzip_parallel", "fx_gz_open_mode", "fx_kseq_scan", "fx_kseq_records", "fx_kseq_fetch",
+    "fx_fasta_build_sharded", "fx_comm_summaries", "fx_fastq_build_sharded", "fx_bgzf_counts", "fx_sort_packed_names", "fx_gunzip_parallel", "fx_gz_open_mode", "fx_kseq_scan", "fx_kseq_records", "fx_kseq_fetch", "fx_kseq_prefix_lines",
 ]
 
 
@@ -190,6 +190,8 @@ def lib():
     L.fx_gz_open_mode.argtypes = [vp]
     L.fx_kseq_scan.argtypes = [vp, vp, vp, vp, vp]
     L.fx_kseq_records.argtypes = [vp, i64, i64, vp]
+    L.fx_kseq_prefix_lines.argtypes = [vp]
+    L.fx_kseq_prefix_lines.restype = i64
     L.fx_kseq_fetch.argtypes = [vp, i32, i64, i64, i32, vp, vp, vp]
     L.fx_gunzip_parallel.argtypes = [vp, i64, i32, vp, i64, C.POINTER(i64), C.POINTER(i64)]
     L.fx_sort_packed_names.argtypes = [i32, vp, vp, i64, vp, C.POINTER(i64)]
@@ -424,6 +426,10 @@ class Blob:
         nr, nl, sb, code = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int(0)
         check(lib().fx_kseq_scan(self._h, C.byref(nr), C.byref(nl), C.byref(sb), C.byref(code)))
         return int(nr.value), int(nl.value), int(sb.value), int(code.value)
+
+    def kseq_prefix_lines(self):
+        """Lines of the last kseq_scan that the parallel passes took (the walk did the rest)."""
+        return int(lib().fx_kseq_prefix_lines(self._h))
 
     def kseq_records(self, first, count):
         """Records [first, first + count) of the walk as a structured array (fx_kseq_rec)."""

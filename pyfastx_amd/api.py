@@ -1471,18 +1471,15 @@ class Fastx:
     def __repr__(self):
         return "<Fastx> %s %s" % ("fasta" if self._format == 1 else "fastq", self.file_name)    # fastx.c:126-132
 
-    def __iter__(self):
-        fastq, with_comment = self._format == 2, self._comment
+    def _batches(self):
+        """(hdr bytes, their offsets, seq bytes, qual bytes | None, record table) per batch of records, None at the end."""
+        fastq = self._format == 2
         blob = _lib.Blob.from_file(self.file_name, device=self._device)
         try:
             n_rec, _, _, self.end_code = blob.kseq_scan()
-            # A record without a comment: the reference hands out None until its comment buffer exists -- from the first
-            # header whose name is followed by anything but the newline, a CR included -- and "" afterwards (kseq.c:146
-            # with Py_BuildValue "s#" on a NULL pointer, fastx.c:10-12, 28-30).
-            buffered, last_qual = False, None
             for a in range(0, n_rec, self.BATCH_RECORDS):
                 recs = blob.kseq_records(a, min(self.BATCH_RECORDS, n_rec - a))
-                cum, slen, flags = recs["seq_cum"], recs["seq_len"], recs["flags"]
+                cum, slen = recs["seq_cum"], recs["seq_len"]
                 i = 0
                 while i < recs.size:
                     ends = cum[i:] + slen[i:] - cum[i]
@@ -1491,25 +1488,20 @@ class Fastx:
                     seq, qual = blob.kseq_fetch(a + i, k - i, nbytes, upper=self._uppercase and not fastq, want_qual=fastq)  # fastx.c:14-22, 97-103
                     hl = recs["hdr_len"][i:k].astype(np.int64)
                     hdr, ho, _ = blob.fetch_ranges(recs["hdr_off"][i:k], hl, hl, flags=_lib.FX_RAW)
-                    base = int(cum[i])
-                    for r in range(i, k):
-                        nm, cm = _kseq_header(bytes(hdr[ho[r - i]:ho[r - i + 1]]), bool(flags[r] & 4))
-                        if cm is not None:
-                            buffered = True
-                        o = int(cum[r]) - base
-                        s = _cstr(seq[o:o + int(slen[r])])
-                        if not fastq:
-                            yield (_cstr(nm), s, _text(cm) if cm is not None else ("" if buffered else None)) if with_comment else (_cstr(nm), s)
-                            continue
-                        if (flags[r] & 3) == 1:                      # a FASTQ record whose quality was read
-                            last_qual = _cstr(qual[o:o + int(slen[r])])
-                        if with_comment:
-                            yield (_cstr(nm), s, last_qual, _text(cm) if cm is not None else ("" if buffered else None))
-                        else:
-                            yield (_cstr(nm), s, last_qual)
+                    yield hdr, ho, seq, qual, recs[i:k]
                     i = k
         finally:
             blob.close()
+        yield None
+
+    def __iter__(self):
+        # The tuples of fastx.c:6-30 come out of a C iterator (_fxobj.FastxIter, the counterpart of pyfastx_fastx_next): per
+        # record the header cut of kseq.c:148-149 (_kseq_header), "s" strings (_cstr), and the buffer rules -- a record
+        # without a comment yields None until the reference's comment buffer exists (from the first header whose name is
+        # followed by anything but the newline, a CR included) and "" afterwards (kseq.c:146 with Py_BuildValue "s#" on a
+        # NULL pointer, fastx.c:10-12, 28-30); a FASTA-style record seen through the FASTQ builder carries the last
+        # quality string.
+        return _fxobj.FastxIter(self._batches().__next__, self._format == 2, self._comment)
 
 
 # ============================================================== module functions

@@ -18,14 +18,19 @@
 // tools/kseq_line_model.py is the executable model k_kq_walk transliterates (fuzzed against oracle/fx_oracle.c: fxo_kseq).
 #pragma once
 #include "fx_kernels.hpp"
+#include "fx_spanscan.hpp"
 
 namespace fx {
+
+#define KQ_LD(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define KQ_ST(x, v) __hip_atomic_store(&(x), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 
 constexpr int KQ_TILE = 4096;                 // bytes per wave step of the count / lines kernels
 constexpr int KQ_RING = 4096;                 // line descriptors in the LDS ring (64 KiB)
 constexpr int KQ_BATCH = 512;                 // lines per producer batch
 constexpr int KQ_SLOTS = KQ_RING / KQ_BATCH;
-constexpr int KQ_PRODUCERS = 3;
+constexpr int KQ_PRODUCERS = 3;              // (7 made the walk slower: the walker wave shares its SIMD with them)
+constexpr int KQ_WALK_BLOCK = 64 * (1 + KQ_PRODUCERS);
 constexpr uint32_t KQ_BIG = 1u << 25;         // a window with a line this long takes the one-line steps (32-bit wave scans)
 constexpr int64_t KQ_POS = (1ll << 62) - 1;   // ldst: position in the low 62 bits, class above
 constexpr int KQ_LONG = 1 << 16;              // lines longer than this are copied by k_kq_gather_long
@@ -103,10 +108,114 @@ __global__ __launch_bounds__(BLOCK) void k_kq_desc(const uint8_t *__restrict__ d
     }
 }
 
+// ------------------------------------------------------------------ the regular prefix, in parallel
+// A file of four-line FASTQ records, or of FASTA records whose lines hold nothing kseq treats specially, needs no state
+// machine: every line can be judged by itself, the records and string positions are prefix sums.  These passes take the
+// file up to the first line that breaks the pattern (usually: all of it); k_kq_walk starts there with the state they
+// leave behind (KqInit) -- at the end of the stream it only closes the last record.
+constexpr uint32_t KQ_REG_MAX = 1u << 20;     // longer lines end the regular prefix (32-bit partial sums of the scans)
+struct KqInit { long long j0, nrec, S, cur_off, cur_line, acc; uint32_t st, cur_len, cur_flags, pad; };
+
+__device__ __forceinline__ uint32_t kq_len(const uint4 &d) { return d.z; }
+__device__ __forceinline__ uint32_t kq_first(const uint4 &d) { return d.w & 0xFF; }
+__device__ __forceinline__ uint32_t kq_last(const uint4 &d) { return (d.w >> 8) & 0xFF; }
+__device__ __forceinline__ bool kq_unterm(const uint4 &d) { return (d.w >> 16) & 1; }
+__device__ __forceinline__ bool kq_is_hdr(const uint4 &d) { return d.z >= 1 && (kq_first(d) == '>' || kq_first(d) == '@'); }
+// what a line adds to an EMPTY string (ks_getuntil2, kseq.c:106: a trailing CR goes from a string longer than one byte)
+__device__ __forceinline__ uint32_t kq_con0(const uint4 &d) { return d.z - ((kq_last(d) == 13 && d.z > 1) ? 1u : 0u); }
+
+// first[0] = first line that is not what its place in a four-line record asks for; first[1] = first line a FASTA run
+// stops at ('+' in front, a lone CR, no '\n' behind it).  Both preset to L by the caller.
+__global__ __launch_bounds__(BLOCK) void k_kq_classify(const uint4 *__restrict__ desc, int64_t L, unsigned long long *__restrict__ first) {
+    unsigned long long mq = ~0ull, ma = ~0ull;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < L; i += (int64_t)gridDim.x * BLOCK) {
+        const uint4 d = desc[i];
+        const uint32_t f = kq_first(d), len = d.z;
+        const int role = (int)(i & 3);
+        bool ok;
+        if (role == 0) ok = kq_is_hdr(d);
+        else if (role == 1) ok = len >= 1 && f != '>' && f != '@' && f != '+';
+        else if (role == 2) ok = len >= 1 && f == '+' && !kq_unterm(d);
+        else ok = kq_con0(d) == kq_con0(desc[i - 2]);
+        if (len >= KQ_REG_MAX) ok = false;
+        if (!ok && (unsigned long long)i < mq) mq = (unsigned long long)i;
+        const bool stopper = (len >= 1 && f == '+') || (len == 1 && f == 13) || kq_unterm(d) || len >= KQ_REG_MAX;
+        if (stopper && (unsigned long long)i < ma) ma = (unsigned long long)i;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned long long oq = (unsigned long long)shfl64((long long)mq, lane_id() ^ d), oa = (unsigned long long)shfl64((long long)ma, lane_id() ^ d);
+        mq = oq < mq ? oq : mq; ma = oa < ma ? oa : ma;
+    }
+    if (lane_id() == 0) {
+        if (mq != ~0ull) atomicMin(&first[0], mq);
+        if (ma != ~0ull) atomicMin(&first[1], ma);
+    }
+}
+
+// ---- FASTQ: records 0 .. R - 1 are lines 4r .. 4r + 3
+__global__ __launch_bounds__(BLOCK) void k_kq_fq_cnt(const uint4 *__restrict__ desc, int64_t R, int32_t *__restrict__ cnt) {
+    for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < R; r += (int64_t)gridDim.x * BLOCK) cnt[r] = (int32_t)kq_con0(desc[4 * r + 1]);
+}
+__global__ __launch_bounds__(BLOCK) void k_kq_fq_emit(const uint4 *__restrict__ desc, int64_t R, const int64_t *__restrict__ off, KqRec *__restrict__ recs,
+                                                     int64_t *__restrict__ ldst, uint32_t *__restrict__ lcon, KqInit *__restrict__ init) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        KqInit t{4 * R, R, off[R], 0, 0, 0, (uint32_t)KQ_SEEK, 0, 0, 0};
+        *init = t;
+    }
+    for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < R; r += (int64_t)gridDim.x * BLOCK) {
+        const uint4 h = desc[4 * r];
+        const uint32_t con = kq_con0(desc[4 * r + 1]);
+        const int64_t cum = off[r];
+        KqRec t;
+        t.hdr_off = (int64_t)(((uint64_t)h.y << 32) | h.x) + 1; t.hdr_line = 4 * r; t.seq_len = con; t.seq_cum = cum;
+        t.hdr_len = h.z - 1; t.s_n = 1; t.q_n = 1; t.flags = KQ_F_FASTQ;
+        recs[r] = t;
+        ldst[4 * r + 1] = cum | ((int64_t)KQ_C_SEQ << 62); lcon[4 * r + 1] = con;
+        ldst[4 * r + 3] = cum | ((int64_t)KQ_C_QUAL << 62); lcon[4 * r + 3] = con;
+    }
+}
+
+// ---- FASTA: lines 0 .. n - 1, line 0 a header; a record = a header line and the lines up to the next one
+__global__ __launch_bounds__(BLOCK) void k_kq_fa_cnt(const uint4 *__restrict__ desc, int64_t n, int32_t *__restrict__ hflag, int32_t *__restrict__ con) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const uint4 d = desc[i];
+        const bool H = kq_is_hdr(d);
+        hflag[i] = H ? 1 : 0;
+        con[i] = (H || d.z == 0) ? 0 : (int32_t)(d.z - (kq_last(d) == 13 ? 1u : 0u));
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_kq_fa_lines(const uint4 *__restrict__ desc, int64_t n, const int64_t *__restrict__ hoff, const int64_t *__restrict__ coff,
+                                                      const int32_t *__restrict__ con, int64_t *__restrict__ hpos, int64_t *__restrict__ ldst,
+                                                      uint32_t *__restrict__ lcon) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const uint4 d = desc[i];
+        if (kq_is_hdr(d)) hpos[hoff[i]] = i;
+        else if (d.z > 0) { ldst[i] = coff[i] | ((int64_t)KQ_C_SEQ << 62); lcon[i] = (uint32_t)con[i]; }
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_kq_fa_recs(const uint4 *__restrict__ desc, int64_t n, int64_t nh, const int64_t *__restrict__ hpos,
+                                                     const int64_t *__restrict__ coff, KqRec *__restrict__ recs, KqInit *__restrict__ init) {
+    for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < nh; r += (int64_t)gridDim.x * BLOCK) {
+        const int64_t i = hpos[r];
+        const uint4 d = desc[i];
+        const int64_t off = (int64_t)(((uint64_t)d.y << 32) | d.x) + 1;
+        if (r + 1 < nh) {
+            const int64_t i2 = hpos[r + 1];
+            KqRec t;
+            t.hdr_off = off; t.hdr_line = i; t.seq_len = coff[i2] - coff[i]; t.seq_cum = coff[i];
+            t.hdr_len = d.z - 1; t.s_n = (uint32_t)(i2 - i - 1); t.q_n = 0; t.flags = 0;
+            recs[r] = t;
+        } else {                                            // the last header's record is still open: the walk closes it
+            KqInit t{n, nh - 1, coff[i], off, i, coff[n] - coff[i], (uint32_t)KQ_SEQ, d.z - 1, 0, 0};
+            *init = t;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ the walk
 struct KqOut { long long n_rec, code, seq_bytes, pad; };
 
-__device__ __forceinline__ uint32_t kq_ld(const volatile uint32_t *p) { return *p; }
 __device__ __forceinline__ void kq_rec_store(KqRec *__restrict__ r, int64_t hdr_off, int64_t hdr_line, int64_t seq_len, int64_t seq_cum,
                                              uint32_t hdr_len, uint32_t s_n, uint32_t q_n, uint32_t flags) {
     KqRec t;
@@ -114,64 +223,80 @@ __device__ __forceinline__ void kq_rec_store(KqRec *__restrict__ r, int64_t hdr_
     t.hdr_len = hdr_len; t.s_n = s_n; t.q_n = q_n; t.flags = flags;
     *r = t;
 }
+// wave-uniform values the compiler cannot prove uniform: through readfirstlane they live in scalar registers, and the
+// walker's bookkeeping and branches run on the scalar unit
+__device__ __forceinline__ int kq_u32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t kq_u64(int64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v & 0xFFFFFFFFll)), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
 __device__ __forceinline__ int64_t kq_bcast64(int64_t v, int src) {
     const int lo = __shfl((int)(v & 0xFFFFFFFFll), src, 64), hi = __shfl((int)(v >> 32), src, 64);
     return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_kq_walk(const uint8_t *__restrict__ data, int64_t n, const uint4 *__restrict__ desc, int64_t L,
+__global__ __launch_bounds__(KQ_WALK_BLOCK) void k_kq_walk(const uint8_t *__restrict__ data, int64_t n, const uint4 *__restrict__ desc, int64_t L,
                                                   KqRec *__restrict__ recs, int64_t cap, int64_t *__restrict__ ldst,
-                                                  uint32_t *__restrict__ lcon, KqOut *__restrict__ out) {
+                                                  uint32_t *__restrict__ lcon, const KqInit *__restrict__ init, KqOut *__restrict__ out) {
     __shared__ uint4 ring[KQ_RING];
-    __shared__ volatile uint32_t ready[KQ_SLOTS];         // batch number + 1 that a slot holds
-    __shared__ volatile uint32_t cons_batch, stop;
+    // flags between the waves: relaxed workgroup-scope atomics, which stay LDS instructions (volatile accesses become flat
+    // ones, and those also wait for the wave's outstanding global stores)
+    __shared__ uint32_t ready[KQ_SLOTS];                  // batch number + 1 that a slot holds
+    __shared__ uint32_t cons_batch, stop;
     const int lane = lane_id(), w = threadIdx.x >> 6;
     if (threadIdx.x < KQ_SLOTS) ready[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { cons_batch = 0; stop = 0; }
+    const KqInit in = *init;                               // where the parallel prefix passes left off (all zero: the start)
+    const int64_t b0 = in.j0 / KQ_BATCH;
+    if (threadIdx.x == 0) { cons_batch = (uint32_t)b0; stop = 0; }
     __syncthreads();
     const int64_t nb = (L + KQ_BATCH - 1) / KQ_BATCH;
 
     if (w > 0) {
         // ---------------- producers: batch b -> slot b % KQ_SLOTS, once the walker has left batch b - KQ_SLOTS
-        for (int64_t b = w - 1; b < nb; b += KQ_PRODUCERS) {
+        for (int64_t b = b0 + w - 1; b < nb; b += KQ_PRODUCERS) {
             uint4 v[KQ_BATCH / 64];
 #pragma unroll
             for (int r = 0; r < KQ_BATCH / 64; ++r) {
                 const int64_t i = b * KQ_BATCH + r * 64 + lane;
                 v[r] = i < L ? desc[i] : make_uint4(0, 0, 0, 0);
             }
-            if (b >= KQ_SLOTS)
-                while ((int64_t)kq_ld(&cons_batch) < b - (KQ_SLOTS - 1) && !kq_ld(&stop)) __builtin_amdgcn_s_sleep(2);
-            if (kq_ld(&stop)) return;
+            if (b >= b0 + KQ_SLOTS)
+                while ((int64_t)KQ_LD(cons_batch) < b - (KQ_SLOTS - 1) && !KQ_LD(stop)) __builtin_amdgcn_s_sleep(2);
+            if (KQ_LD(stop)) return;
             const int slot = (int)(b % KQ_SLOTS);
 #pragma unroll
             for (int r = 0; r < KQ_BATCH / 64; ++r) ring[slot * KQ_BATCH + r * 64 + lane] = v[r];
-            __threadfence_block();
-            if (lane == 0) ready[slot] = (uint32_t)(b + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the batch is in LDS before its flag
+            if (lane == 0) KQ_ST(ready[slot], (uint32_t)(b + 1));
         }
         return;
     }
 
     // ---------------- the walker (wave 0).  Everything but the per-lane window values is wave-uniform.
-    int st = KQ_SEEK, code = 0;
-    int64_t j = 0, S = 0, nrec = 0;
-    int64_t cur_off = 0, cur_line = 0, acc = 0, qacc = 0, tcr = 0, lastc = 0;
-    uint32_t cur_len = 0, cur_flags = 0, qn = 0, sn = 0;
-    int64_t have = -1;                                      // batches [0, have] are known to be in the ring
-    uint32_t pub = 0;
+    int st = (int)in.st, code = 0;
+    int64_t j = in.j0, S = in.S, nrec = in.nrec;
+    int64_t cur_off = in.cur_off, cur_line = in.cur_line, acc = in.acc, qacc = 0, tcr = 0, lastc = 0;
+    uint32_t cur_len = in.cur_len, cur_flags = in.cur_flags, qn = 0, sn = 0;
+    int64_t have = b0 - 1;                                  // batches [b0, have] are known to be in the ring
+    uint32_t pub = (uint32_t)b0;
     const uint64_t lt = (1ull << lane) - 1ull;
 
     while (j < L && !code) {
+        st = kq_u32(st); j = kq_u64(j); S = kq_u64(S); nrec = kq_u64(nrec); acc = kq_u64(acc); have = kq_u64(have); pub = (uint32_t)kq_u32((int)pub);
+        cur_off = kq_u64(cur_off); cur_line = kq_u64(cur_line); cur_len = (uint32_t)kq_u32((int)cur_len); cur_flags = (uint32_t)kq_u32((int)cur_flags);
         // the window: lines j .. j + 63
         const int64_t lastline = j + 63 < L ? j + 63 : L - 1, bneed = lastline / KQ_BATCH;
         while (have < bneed) {
             const int64_t b = have + 1;
-            while (kq_ld(&ready[b % KQ_SLOTS]) != (uint32_t)(b + 1)) __builtin_amdgcn_s_sleep(1);
+            while (KQ_LD(ready[b % KQ_SLOTS]) != (uint32_t)(b + 1)) __builtin_amdgcn_s_sleep(1);
             have = b;
         }
-        __threadfence_block();
+        // The ring is read behind the flag in program order and LDS serves a wave in order: only the compiler has to be kept
+        // from moving the reads up.  (A workgroup fence here would also wait for this wave's global stores of the step
+        // before -- once per 64 lines, it was most of the walk's time.)
+        asm volatile("" ::: "memory");
         const uint32_t jb = (uint32_t)(j / KQ_BATCH);
-        if (jb != pub) { pub = jb; if (lane == 0) cons_batch = jb; }
+        if (jb != pub) { pub = jb; if (lane == 0) KQ_ST(cons_batch, jb); }
         const bool ex = j + lane < L;
         const uint4 d = ex ? ring[(j + lane) & (KQ_RING - 1)] : make_uint4(0, 0, 0, 0);
         const int64_t start = (int64_t)(((uint64_t)d.y << 32) | d.x);
@@ -193,11 +318,11 @@ __global__ __launch_bounds__(BLOCK) void k_kq_walk(const uint8_t *__restrict__ d
             const uint64_t m = __ballot(ok);
             const uint64_t g = m & (m >> 1) & (m >> 2) & (m >> 3) & 0x1111111111111111ull;
             const uint64_t bad = ~g & 0x1111111111111111ull;
-            const int R = bad ? (__builtin_ctzll(bad) >> 2) : 16;
+            const int R = kq_u32(bad ? (__builtin_ctzll(bad) >> 2) : 16);
             if (R > 0) {
                 const bool mine = (lane >> 2) < R;
                 const uint32_t pin = wave_incl_scan((role == 1 && mine) ? con : 0u);
-                const uint32_t total = (uint32_t)__shfl((int)pin, 63, 64);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)pin, 63);
                 const uint32_t seqlen = (uint32_t)__shfl((int)con, (lane + 1) & 63, 64);
                 if (mine) {
                     if (role == 0) {
@@ -239,7 +364,7 @@ __global__ __launch_bounds__(BLOCK) void k_kq_walk(const uint8_t *__restrict__ d
             // ---- a run of header / sequence lines at once, up to the first line that needs a closer look
             const bool stopper = !ex || (len >= 1 && first == '+') || (len == 1 && first == 13) || un;
             const uint64_t sm = __ballot(stopper);
-            const int m = sm ? __builtin_ctzll(sm) : 64;
+            const int m = kq_u32(sm ? __builtin_ctzll(sm) : 64);
             if (m > 0) {
                 const bool inr = lane < m;
                 const bool H = inr && ishdr;
@@ -350,7 +475,7 @@ __global__ __launch_bounds__(BLOCK) void k_kq_walk(const uint8_t *__restrict__ d
         } else code = -1;
     }
     if (lane == 0) {
-        stop = 1;
+        KQ_ST(stop, 1u);
         out->n_rec = nrec; out->code = code; out->seq_bytes = S; out->pad = nrec > cap ? 1 : 0;
     }
 }

@@ -186,10 +186,10 @@ static void crc_tables(CrcTables *T) {
 }
 
 enum KernelId { K_SPAN_SCAN = 0, K_GRAN_REDUCE, K_GRAN_PREFIX, K_HDR_REC, K_GRAN_LINES, K_GRAN_EXACT, K_FASTA_FINALIZE, K_FETCH,
-                K_FASTA_COMP, K_FASTA_COMP_EDGE, K_FASTA_COMP_SMALL, K_FASTQ_LINES, K_FASTQ_ROWS, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_BGZF_CRC, K_SCAN_COMP, K_COMP_ATTRIBUTE, K_BGZF_SERIAL, K_FETCH_REST, K_KQ_LINES, K_KQ_WALK, K_KQ_GATHER, K_NKERN };
+                K_FASTA_COMP, K_FASTA_COMP_EDGE, K_FASTA_COMP_SMALL, K_FASTQ_LINES, K_FASTQ_ROWS, K_FASTQ_EMIT, K_FASTQ_STATS, K_FASTQ_COMP, K_FASTQ_FETCH, K_BGZF_INFLATE, K_BGZF_COPY, K_BGZF_CRC, K_SCAN_COMP, K_COMP_ATTRIBUTE, K_BGZF_SERIAL, K_FETCH_REST, K_KQ_LINES, K_KQ_PREFIX, K_KQ_WALK, K_KQ_GATHER, K_NKERN };
 static const char *const kKernelNames[K_NKERN] = {
     "k_span_scan", "k_gran_reduce", "k_gran_prefix", "k_hdr_rec", "k_gran_lines", "k_gran_exact", "k_fasta_finalize", "k_fetch",
-    "k_fasta_comp", "k_fasta_comp_edge", "k_fasta_comp_small", "k_fastq_lines", "k_fastq_rows", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy", "k_bgzf_crc", "k_scan_comp", "k_comp_attribute", "k_bgzf_decode_serial", "k_fetch_rest", "k_kq_lines", "k_kq_walk", "k_kq_gather"};
+    "k_fasta_comp", "k_fasta_comp_edge", "k_fasta_comp_small", "k_fastq_lines", "k_fastq_rows", "k_fastq_emit", "k_fastq_stats", "k_fastq_comp", "k_fastq_fetch", "k_bgzf_decode", "k_bgzf_copy", "k_bgzf_crc", "k_scan_comp", "k_comp_attribute", "k_bgzf_decode_serial", "k_fetch_rest", "k_kq_lines", "k_kq_prefix", "k_kq_walk", "k_kq_gather"};
 
 struct Prof {
     bool on = false;
@@ -292,7 +292,7 @@ struct fx_handle {
     DevBuf<int64_t> kq_nl, kq_ldst;
     DevBuf<uint32_t> kq_lcon;
     DevBuf<KqRec> kq_recs;
-    int64_t kq_nrec = -1, kq_lines = 0, kq_seq_bytes = 0;
+    int64_t kq_nrec = -1, kq_lines = 0, kq_seq_bytes = 0, kq_prefix_lines = 0;   // kq_prefix_lines: lines the parallel prefix passes took
     int kq_code = 0;
     DevBuf<uint8_t> arena;     // scratch for host-array calls (Staged)
     int64_t arena_used = 0;
@@ -1851,16 +1851,21 @@ extern "C" int fx_kseq_scan(fx_handle *h, int64_t *n_records, int64_t *n_lines, 
         const int64_t ntiles = (n + KQ_TILE - 1) / KQ_TILE, nchunks = (ntiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
         ScratchBuf<int32_t> cnt;
         ScratchBuf<int64_t> sums, off;
-        ScratchBuf<unsigned long long> ctl;                  // [0] '>' and '@' bytes, [1] error bits, [2..5] KqOut
+        ScratchBuf<unsigned long long> ctl;                  // [0] '>' and '@' bytes, [1] error bits, [2..5] KqOut, [6..7] k_kq_classify, [8..15] KqInit
         if ((rc = cnt.alloc(h->device, ntiles, h->stream)) || (rc = sums.alloc(h->device, nchunks + 1, h->stream)) ||
-            (rc = off.alloc(h->device, ntiles + 1, h->stream)) || (rc = ctl.alloc(h->device, 8, h->stream)))
+            (rc = off.alloc(h->device, ntiles + 1, h->stream)) || (rc = ctl.alloc(h->device, 16, h->stream)))
             return rc;
-        HIPCHK(hipMemsetAsync(ctl.p, 0, 8 * sizeof(unsigned long long), h->stream));
+        HIPCHK(hipMemsetAsync(ctl.p, 0, 16 * sizeof(unsigned long long), h->stream));
         const unsigned wide = (unsigned)std::min<int64_t>(nblocks(ntiles, BLOCK / 64), 256 * 8);
+        // exclusive prefix sums of a column of counts (fx_comp.hpp: three small kernels)
+        auto scan = [&](const int32_t *c, int64_t m, int64_t *sums_p, int64_t *o) {
+            const int64_t nch = (m + SCAN_CHUNK - 1) / SCAN_CHUNK;
+            hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)nch), dim3(BLOCK), 0, h->stream, c, m, sums_p);
+            hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, sums_p, nch);
+            hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)nch), dim3(BLOCK), 0, h->stream, c, m, sums_p, o);
+        };
         FX_LAUNCH(h, K_KQ_LINES, k_kq_count, dim3(wide), dim3(BLOCK), h->d_data, n, ntiles, cnt.p, ctl.p);
-        hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, cnt.p, ntiles, sums.p);
-        hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, sums.p, nchunks);
-        hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, cnt.p, ntiles, sums.p, off.p);
+        scan(cnt.p, ntiles, sums.p, off.p);
         HIPCHK(hipGetLastError());
         int64_t n_nl = 0;
         unsigned long long hdrchars = 0;
@@ -1878,11 +1883,67 @@ extern "C" int fx_kseq_scan(fx_handle *h, int64_t *n_records, int64_t *n_lines, 
             return rc;
         HIPCHK(hipMemsetAsync(h->kq_ldst.p, 0, (size_t)L * sizeof(int64_t), h->stream));
         HIPCHK(hipMemsetAsync(h->kq_lcon.p, 0, (size_t)L * sizeof(uint32_t), h->stream));
+        const unsigned per_line = (unsigned)std::min<int64_t>(nblocks(L, BLOCK), 256 * 16);
         FX_LAUNCH(h, K_KQ_LINES, k_kq_lines, dim3(wide), dim3(BLOCK), h->d_data, n, ntiles, off.p, h->kq_nl.p, virt ? L - 1 : (int64_t)-1);
-        hipLaunchKernelGGL(k_kq_desc, dim3((unsigned)std::min<int64_t>(nblocks(L, BLOCK), 256 * 16)), dim3(BLOCK), 0, h->stream, h->d_data, n,
-                           h->kq_nl.p, L, desc.p, (uint32_t *)(ctl.p + 1));
-        FX_LAUNCH(h, K_KQ_WALK, k_kq_walk, dim3(1), dim3(BLOCK), h->d_data, n, desc.p, L, h->kq_recs.p, cap, h->kq_ldst.p, h->kq_lcon.p,
-                  (KqOut *)(ctl.p + 2));
+        hipLaunchKernelGGL(k_kq_desc, dim3(per_line), dim3(BLOCK), 0, h->stream, h->d_data, n, h->kq_nl.p, L, desc.p, (uint32_t *)(ctl.p + 1));
+        // ---- the regular prefix in parallel (FX_KSEQ_WALK_ONLY=1: everything through the walk -- tests, experiments)
+        static const bool walk_only = [] { const char *e = getenv("FX_KSEQ_WALK_ONLY"); return e && atoi(e) != 0; }();
+        KqInit *init = (KqInit *)(ctl.p + 8);
+        h->kq_prefix_lines = 0;
+        if (!walk_only) {
+            const unsigned long long preset[2] = {(unsigned long long)L, (unsigned long long)L};
+            unsigned long long first[2];
+            uint4 d0;
+            HIPCHK(hipMemcpyAsync(ctl.p + 6, preset, sizeof preset, hipMemcpyHostToDevice, h->stream));
+            FX_LAUNCH(h, K_KQ_PREFIX, k_kq_classify, dim3(per_line), dim3(BLOCK), desc.p, L, ctl.p + 6);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(first, ctl.p + 6, sizeof first, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(&d0, desc.p, sizeof d0, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            const int64_t R = (int64_t)first[0] / 4, na = (int64_t)first[1];
+            const bool hdr0 = d0.z >= 1 && ((d0.w & 0xFF) == '>' || (d0.w & 0xFF) == '@');
+            if (R >= 1) {                                     // four-line FASTQ records up to line 4 R
+                ScratchBuf<int32_t> c;
+                ScratchBuf<int64_t> sm, o;
+                if ((rc = c.alloc(h->device, R, h->stream)) || (rc = sm.alloc(h->device, R / SCAN_CHUNK + 2, h->stream)) || (rc = o.alloc(h->device, R + 1, h->stream))) return rc;
+                const unsigned g = (unsigned)std::min<int64_t>(nblocks(R, BLOCK), 256 * 16);
+                h->prof.begin(K_KQ_PREFIX, h->stream);
+                hipLaunchKernelGGL(k_kq_fq_cnt, dim3(g), dim3(BLOCK), 0, h->stream, desc.p, R, c.p);
+                scan(c.p, R, sm.p, o.p);
+                hipLaunchKernelGGL(k_kq_fq_emit, dim3(g), dim3(BLOCK), 0, h->stream, desc.p, R, o.p, h->kq_recs.p, h->kq_ldst.p, h->kq_lcon.p, init);
+                h->prof.end(h->stream);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(h->stream));      // the scratch goes back to the pool
+                h->kq_prefix_lines = 4 * R;
+            } else if (hdr0 && na >= 1) {                     // FASTA header / sequence lines up to line na
+                ScratchBuf<int32_t> hf, cn;
+                ScratchBuf<int64_t> sm, ho, co, hp;
+                if ((rc = hf.alloc(h->device, na, h->stream)) || (rc = cn.alloc(h->device, na, h->stream)) || (rc = sm.alloc(h->device, na / SCAN_CHUNK + 2, h->stream)) ||
+                    (rc = ho.alloc(h->device, na + 1, h->stream)) || (rc = co.alloc(h->device, na + 1, h->stream)))
+                    return rc;
+                const unsigned g = (unsigned)std::min<int64_t>(nblocks(na, BLOCK), 256 * 16);
+                h->prof.begin(K_KQ_PREFIX, h->stream);
+                hipLaunchKernelGGL(k_kq_fa_cnt, dim3(g), dim3(BLOCK), 0, h->stream, desc.p, na, hf.p, cn.p);
+                scan(hf.p, na, sm.p, ho.p);
+                scan(cn.p, na, sm.p, co.p);
+                h->prof.end(h->stream);
+                HIPCHK(hipGetLastError());
+                int64_t nh = 0;
+                HIPCHK(hipMemcpyAsync(&nh, ho.p + na, sizeof nh, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                if ((rc = hp.alloc(h->device, nh, h->stream))) return rc;
+                h->prof.begin(K_KQ_PREFIX, h->stream);
+                hipLaunchKernelGGL(k_kq_fa_lines, dim3(g), dim3(BLOCK), 0, h->stream, desc.p, na, ho.p, co.p, cn.p, hp.p, h->kq_ldst.p, h->kq_lcon.p);
+                hipLaunchKernelGGL(k_kq_fa_recs, dim3((unsigned)std::min<int64_t>(nblocks(nh, BLOCK), 256 * 16)), dim3(BLOCK), 0, h->stream, desc.p, na, nh, hp.p,
+                                   co.p, h->kq_recs.p, init);
+                h->prof.end(h->stream);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(h->stream));
+                h->kq_prefix_lines = na;
+            }
+        }
+        FX_LAUNCH(h, K_KQ_WALK, k_kq_walk, dim3(1), dim3(KQ_WALK_BLOCK), h->d_data, n, desc.p, L, h->kq_recs.p, cap, h->kq_ldst.p, h->kq_lcon.p,
+                  init, (KqOut *)(ctl.p + 2));
         HIPCHK(hipGetLastError());
         unsigned long long back[6];
         HIPCHK(hipMemcpyAsync(back, ctl.p, sizeof back, hipMemcpyDeviceToHost, h->stream));
@@ -1898,6 +1959,8 @@ extern "C" int fx_kseq_scan(fx_handle *h, int64_t *n_records, int64_t *n_lines, 
     if (end_code) *end_code = (int)res.code;
     return FX_OK;
 }
+
+extern "C" int64_t fx_kseq_prefix_lines(const fx_handle *h) { return h ? h->kq_prefix_lines : 0; }
 
 extern "C" int fx_kseq_records(fx_handle *h, int64_t first, int64_t count, fx_kseq_rec *out) {
     if (!h || (count > 0 && !out)) return fail(FX_EINVAL, "null argument");

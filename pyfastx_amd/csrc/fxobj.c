@@ -252,7 +252,180 @@ static PyObject *mod_bench(PyObject *m, PyObject *args)
     return PyFloat_FromDouble(((double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec)) / 1e3 / (double)n);
 }
 
+/* ------------------------------------------------------------------ Fastx: the tuples of one gathered batch
+ * What pyfastx_fastx_fasta* / pyfastx_fastx_fastq* build per record (fastx.c:6-30), for the k records of a batch in one
+ * call: fastx_batch(hdr, hdr_off int64[k+1], seq, qual | None, recs (fx_kseq_rec[k]), fastq, with_comment, state) -> list.
+ * state = [comment buffer exists (bool), the reference's quality buffer (str | None)] carries over between batches. */
+typedef struct { int64_t hdr_off, hdr_line, seq_len, seq_cum; uint32_t hdr_len, s_n, q_n, flags; } kq_rec;
+
+static PyObject *cstr_text(const uint8_t *p, int64_t n)          /* Py_BuildValue "s": up to the first NUL */
+{
+    const uint8_t *z = (const uint8_t *)memchr(p, 0, (size_t)n);
+    return PyUnicode_DecodeUTF8((const char *)p, z ? (Py_ssize_t)(z - p) : (Py_ssize_t)n, "surrogateescape");
+}
+static int kq_isspace(int c) { return c == ' ' || (c >= 9 && c <= 13); }
+
+/* one record -> its tuple; *buffered / *last_qual carry the reference's comment / quality buffer state */
+static PyObject *kq_tuple(const uint8_t *h, int64_t hl, const uint8_t *s_ptr, const uint8_t *q_ptr, const kq_rec *r, int fastq, int with_comment,
+                          int *buffered, PyObject **last_qual)
+{
+    int64_t nl = 0, cl = -1;                                     /* name length; comment length, -1: buffer not written */
+    PyObject *name, *s, *com = NULL, *t;
+    while (nl < hl && !kq_isspace(h[nl])) ++nl;                  /* kseq.c:148: the name ends at the first isspace() byte */
+    if (nl < hl) {                                               /* kseq.c:149: the rest of the line is the comment ... */
+        cl = hl - nl - 1;
+        if ((r->flags & 4) && cl == 0) cl = -1;                  /* ... unless the stream ends right behind the delimiter */
+        else if (cl > 1 && h[hl - 1] == '\r') --cl;              /* kseq.c:106 */
+    }
+    if (cl >= 0) *buffered = 1;
+    if (fastq && (r->flags & 3) == 1 && q_ptr) {                 /* a FASTQ record whose quality string was read */
+        PyObject *q = cstr_text(q_ptr, r->seq_len);
+        if (!q) return NULL;
+        Py_SETREF(*last_qual, q);
+    }
+    name = cstr_text(h, nl);
+    s = cstr_text(s_ptr, r->seq_len);
+    if (with_comment) {
+        if (cl >= 0) com = PyUnicode_DecodeUTF8((const char *)h + nl + 1, (Py_ssize_t)cl, "surrogateescape");
+        else if (*buffered) com = PyUnicode_FromStringAndSize("", 0);
+        else com = Py_NewRef(Py_None);
+    }
+    if (!name || !s || (with_comment && !com)) t = NULL;
+    else if (fastq) t = with_comment ? PyTuple_Pack(4, name, s, *last_qual, com) : PyTuple_Pack(3, name, s, *last_qual);
+    else t = with_comment ? PyTuple_Pack(3, name, s, com) : PyTuple_Pack(2, name, s);
+    Py_XDECREF(name); Py_XDECREF(s); Py_XDECREF(com);
+    return t;
+}
+
+static PyObject *mod_fastx_batch(PyObject *m, PyObject *args)
+{
+    Py_buffer hdr, ho, seq, qual, recs;
+    PyObject *qual_obj, *state, *out = NULL, *last_qual;
+    int fastq = 0, with_comment = 0, buffered, has_qual;
+    Py_ssize_t k, i;
+    (void)m;
+    if (!PyArg_ParseTuple(args, "y*y*y*Oy*ppO!", &hdr, &ho, &seq, &qual_obj, &recs, &fastq, &with_comment, &PyList_Type, &state)) return NULL;
+    has_qual = qual_obj != Py_None;
+    if (has_qual && PyObject_GetBuffer(qual_obj, &qual, PyBUF_SIMPLE) < 0) { has_qual = 0; goto done; }
+    k = recs.len / (Py_ssize_t)sizeof(kq_rec);
+    if (PyList_GET_SIZE(state) != 2 || ho.len < (k + 1) * 8) { PyErr_SetString(PyExc_ValueError, "bad argument"); goto done; }
+    buffered = PyObject_IsTrue(PyList_GET_ITEM(state, 0));
+    last_qual = Py_NewRef(PyList_GET_ITEM(state, 1));
+    out = PyList_New(k);
+    if (out) {
+        const kq_rec *r = (const kq_rec *)recs.buf;
+        const int64_t *o = (const int64_t *)ho.buf;
+        const uint8_t *hb = (const uint8_t *)hdr.buf, *sb = (const uint8_t *)seq.buf, *qb = has_qual ? (const uint8_t *)qual.buf : NULL;
+        const int64_t base = k ? r[0].seq_cum : 0;
+        for (i = 0; i < k; ++i) {
+            const int64_t so = r[i].seq_cum - base;
+            PyObject *t;
+            if (o[i + 1] > hdr.len || so + r[i].seq_len > seq.len) { PyErr_SetString(PyExc_ValueError, "batch buffers too short"); Py_CLEAR(out); break; }
+            t = kq_tuple(hb + o[i], o[i + 1] - o[i], sb + so, qb ? qb + so : NULL, &r[i], fastq, with_comment, &buffered, &last_qual);
+            if (!t) { Py_CLEAR(out); break; }
+            PyList_SET_ITEM(out, i, t);
+        }
+    }
+    if (out) {
+        PyList_SetItem(state, 0, PyBool_FromLong(buffered));
+        PyList_SetItem(state, 1, last_qual);                     /* steals the reference */
+    } else Py_DECREF(last_qual);
+done:
+    PyBuffer_Release(&hdr); PyBuffer_Release(&ho); PyBuffer_Release(&seq); PyBuffer_Release(&recs);
+    if (has_qual) PyBuffer_Release(&qual);
+    return out;
+}
+
+/* The iterator behind Fastx.__iter__ (pyfastx_fastx_next, fastx.c:124-130): one tuple per call out of the current batch;
+ * next_batch() -- a Python callable -- brings the next one as (hdr, hdr_off, seq, qual | None, recs), or None at the end. */
+typedef struct {
+    PyObject_HEAD
+    PyObject *next_batch, *last_qual;
+    Py_buffer hdr, ho, seq, qual, recs;
+    int held, has_qual, fastq, with_comment, buffered;
+    Py_ssize_t i, k;
+    int64_t base;
+} FastxIter;
+
+static void fxi_release(FastxIter *it)
+{
+    if (it->held) {
+        PyBuffer_Release(&it->hdr); PyBuffer_Release(&it->ho); PyBuffer_Release(&it->seq); PyBuffer_Release(&it->recs);
+        if (it->has_qual) PyBuffer_Release(&it->qual);
+        it->held = 0; it->has_qual = 0;
+    }
+    it->i = it->k = 0;
+}
+static void fxi_dealloc(FastxIter *it)
+{
+    fxi_release(it);
+    Py_XDECREF(it->next_batch); Py_XDECREF(it->last_qual);
+    Py_TYPE(it)->tp_free((PyObject *)it);
+}
+static PyObject *fxi_new(PyTypeObject *type, PyObject *args, PyObject *kw)
+{
+    PyObject *fn;
+    int fastq = 0, with_comment = 0;
+    FastxIter *it;
+    (void)kw;
+    if (!PyArg_ParseTuple(args, "Opp", &fn, &fastq, &with_comment)) return NULL;
+    if (!PyCallable_Check(fn)) { PyErr_SetString(PyExc_TypeError, "next_batch must be callable"); return NULL; }
+    it = (FastxIter *)type->tp_alloc(type, 0);
+    if (!it) return NULL;
+    it->next_batch = Py_NewRef(fn); it->last_qual = Py_NewRef(Py_None);
+    it->held = it->has_qual = it->buffered = 0; it->fastq = fastq; it->with_comment = with_comment;
+    it->i = it->k = 0; it->base = 0;
+    return (PyObject *)it;
+}
+static PyObject *fxi_next(FastxIter *it)
+{
+    const kq_rec *r;
+    const int64_t *o;
+    int64_t so;
+    while (it->i >= it->k) {                                     /* the next batch that holds records */
+        PyObject *b, *q;
+        fxi_release(it);
+        if (!it->next_batch) return NULL;
+        b = PyObject_CallNoArgs(it->next_batch);
+        if (!b) return NULL;
+        if (b == Py_None) { Py_DECREF(b); Py_CLEAR(it->next_batch); return NULL; }     /* StopIteration */
+        if (!PyTuple_Check(b) || PyTuple_GET_SIZE(b) != 5) { Py_DECREF(b); PyErr_SetString(PyExc_TypeError, "next_batch() must return a 5-tuple or None"); return NULL; }
+        q = PyTuple_GET_ITEM(b, 3);
+        if (PyObject_GetBuffer(PyTuple_GET_ITEM(b, 0), &it->hdr, PyBUF_SIMPLE) < 0) { Py_DECREF(b); return NULL; }
+        if (PyObject_GetBuffer(PyTuple_GET_ITEM(b, 1), &it->ho, PyBUF_SIMPLE) < 0) { PyBuffer_Release(&it->hdr); Py_DECREF(b); return NULL; }
+        if (PyObject_GetBuffer(PyTuple_GET_ITEM(b, 2), &it->seq, PyBUF_SIMPLE) < 0) { PyBuffer_Release(&it->hdr); PyBuffer_Release(&it->ho); Py_DECREF(b); return NULL; }
+        if (PyObject_GetBuffer(PyTuple_GET_ITEM(b, 4), &it->recs, PyBUF_SIMPLE) < 0) { PyBuffer_Release(&it->hdr); PyBuffer_Release(&it->ho); PyBuffer_Release(&it->seq); Py_DECREF(b); return NULL; }
+        it->held = 1;
+        if (q != Py_None) {
+            if (PyObject_GetBuffer(q, &it->qual, PyBUF_SIMPLE) < 0) { fxi_release(it); Py_DECREF(b); return NULL; }
+            it->has_qual = 1;
+        }
+        Py_DECREF(b);                                            /* the buffers keep their exporters alive */
+        it->k = it->recs.len / (Py_ssize_t)sizeof(kq_rec);
+        if (it->ho.len < (it->k + 1) * 8) { fxi_release(it); PyErr_SetString(PyExc_ValueError, "bad batch"); return NULL; }
+        it->base = it->k ? ((const kq_rec *)it->recs.buf)[0].seq_cum : 0;
+    }
+    r = (const kq_rec *)it->recs.buf + it->i;
+    o = (const int64_t *)it->ho.buf + it->i;
+    so = r->seq_cum - it->base;
+    if (o[1] > it->hdr.len || so + r->seq_len > it->seq.len) { PyErr_SetString(PyExc_ValueError, "batch buffers too short"); return NULL; }
+    ++it->i;
+    return kq_tuple((const uint8_t *)it->hdr.buf + o[0], o[1] - o[0], (const uint8_t *)it->seq.buf + so,
+                    it->has_qual ? (const uint8_t *)it->qual.buf + so : NULL, r, it->fastq, it->with_comment, &it->buffered, &it->last_qual);
+}
+static PyTypeObject FastxIterType = {
+    PyVarObject_HEAD_INIT(NULL, 0)
+    .tp_name = "pyfastx_amd._fxobj.FastxIter",
+    .tp_basicsize = sizeof(FastxIter),
+    .tp_dealloc = (destructor)fxi_dealloc,
+    .tp_flags = Py_TPFLAGS_DEFAULT,
+    .tp_iter = PyObject_SelfIter,
+    .tp_iternext = (iternextfunc)fxi_next,
+    .tp_new = fxi_new,
+};
+
 static PyMethodDef mod_methods[] = {
+    {"fastx_batch", mod_fastx_batch, METH_VARARGS, "fastx_batch(hdr, hdr_off, seq, qual, recs, fastq, with_comment, state) -> list of tuples"},
     {"set_api", mod_set_api, METH_VARARGS, "set_api(address of fx_fetch_one, Sequence type)"},
     {"bench_fetch_one", mod_bench, METH_VARARGS, "bench_fetch_one(handle, off, blen, take, n) -> us per fx_fetch_one call from C"},
     {NULL, NULL, 0, NULL}};
@@ -261,11 +434,13 @@ static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_fxobj", "C base typ
 PyMODINIT_FUNC PyInit__fxobj(void)
 {
     PyObject *m;
-    if (PyType_Ready(&SeqCoreType) < 0 || PyType_Ready(&FastaCoreType) < 0) return NULL;
+    if (PyType_Ready(&SeqCoreType) < 0 || PyType_Ready(&FastaCoreType) < 0 || PyType_Ready(&FastxIterType) < 0) return NULL;
     m = PyModule_Create(&moddef);
     if (!m) return NULL;
     Py_INCREF(&SeqCoreType); Py_INCREF(&FastaCoreType);
     PyModule_AddObject(m, "SeqCore", (PyObject *)&SeqCoreType);
     PyModule_AddObject(m, "FastaCore", (PyObject *)&FastaCoreType);
+    Py_INCREF(&FastxIterType);
+    PyModule_AddObject(m, "FastxIter", (PyObject *)&FastxIterType);
     return m;
 }

@@ -6,6 +6,7 @@ import glob
 import gzip
 import os
 import random
+import subprocess
 import sys
 
 import numpy as np
@@ -97,6 +98,30 @@ def test_kseq_records_through_the_c_abi(fx, oracle):
                 assert bytes(s2) == bytes(seq[int(t["seq_cum"][a]):int(t["seq_cum"][a]) + nb])
         blob.close()
     assert codes == {-1, -2}
+
+
+def test_regular_files_need_no_walk(fx):
+    """A file of four-line records, or of plain FASTA lines, is taken by the parallel passes alone (fx_kseq_prefix_lines);
+    the first line that is neither hands over to the walk."""
+    from pyfastx_amd import _lib
+    fq = b"".join(b"@r%d\nACGTN\n+\nIIIII\n" % i for i in range(5000))
+    for data, want in ((fq, 20000), (fq[:-1], 20000), (fq + b"@x\nAC\nGT\n+\nIIII\n" + fq, 20000), (b"junk\n" + fq, 0),
+                       (b">a\nAC\nGT\n\n>b\nTT\n", 6), (b">a\nAC\nGT\n+\nIIII\n>b\nTT\n", 3), (b">a\nAC\nGT", 2)):
+        blob = _lib.Blob.from_bytes(data)
+        blob.kseq_scan()
+        assert blob.kseq_prefix_lines() == want, data[:40]
+        blob.close()
+
+
+@pytest.mark.skipif(os.environ.get("FX_KSEQ_WALK_ONLY") == "1", reason="already the walk-only run")
+def test_everything_through_the_walk():
+    """The same comparisons with the parallel prefix passes switched off (FX_KSEQ_WALK_ONLY=1): every line goes through
+    k_kq_walk, whose 64-line steps the default path reaches only behind a file's first irregular line."""
+    env = dict(os.environ, FX_KSEQ_WALK_ONLY="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "golden or equals_the_oracle or c_abi or large_fastq_side_by_side or large_fasta"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def _big_fastq(rng, n, crlf, odd_every):

@@ -914,9 +914,51 @@ def test_fastx_header_cut(oracle):
     assert seen > 1000
 
 
+def test_fastx_batch_builds_the_reference_tuples(oracle):
+    """_fxobj.fastx_batch (the C loop behind Fastx.__iter__: header cut, "s" strings, comment / quality buffer rules of
+    fastx.c:6-30) fed with record tables made from the oracle's records, in batches, against fxoracle.fastx_tuples."""
+    import random
+    from kseq_cases import FIXED, gen
+    from pyfastx_amd import _fxobj
+    from pyfastx_amd._lib import KSEQ_REC
+    rng = random.Random(909)
+    for data in list(FIXED) + [gen(rng) for _ in range(200)]:
+        recs, seq, qual, _ = oracle.kseq(data)
+        t = np.zeros(len(recs), dtype=KSEQ_REC)
+        hdrs = []
+        for k, r in enumerate(recs):
+            e = data.find(b"\n", int(r["name_off"]))
+            hdrs.append(data[int(r["name_off"]):e if e >= 0 else len(data)])
+            t[k] = (r["name_off"], 0, r["seq_len"], r["seq_off"], len(hdrs[-1]), 0, 0,
+                    (1 if r["qual_len"] != -1 else 0) | (2 if r["qual_len"] == -2 else 0) | (4 if e < 0 else 0))
+        # the quality strings at the sequence offsets, as fx_kseq_fetch lays them out
+        qbuf = np.zeros(max(int(seq.size), 1), dtype=np.uint8)
+        for r in recs:
+            if r["qual_len"] > 0:
+                qbuf[int(r["seq_off"]):int(r["seq_off"] + r["qual_len"])] = qual[int(r["qual_off"]):int(r["qual_off"] + r["qual_len"])]
+        for fmt, com in (("fasta", False), ("fasta", True), ("fastq", False), ("fastq", True)):
+            state, got, batches = [False, None], [], []
+            for a in range(0, len(recs), 3):
+                b = min(len(recs), a + 3)
+                ho = np.zeros(b - a + 1, dtype=np.int64)
+                np.cumsum([len(h) for h in hdrs[a:b]], out=ho[1:])
+                base = int(t["seq_cum"][a])
+                end = int(t["seq_cum"][b - 1] + t["seq_len"][b - 1])
+                batches.append((np.frombuffer(b"".join(hdrs[a:b]), dtype=np.uint8), ho, seq[base:end].copy(),
+                                qbuf[base:end].copy() if fmt == "fastq" else None, t[a:b]))
+                got += _fxobj.fastx_batch(*batches[-1], fmt == "fastq", com, state)
+            want = oracle.fastx_tuples(data, fmt, comment=com)
+            assert got == want, (data, fmt, com)
+            # the iterator type Fastx.__iter__ returns, fed with the same batches (and an empty one in between)
+            feed = iter(batches[:1] + [(np.zeros(0, np.uint8), np.zeros(1, np.int64), np.zeros(0, np.uint8), None, t[:0])] + batches[1:] + [None])
+            it = _fxobj.FastxIter(feed.__next__, fmt == "fastq", com)
+            assert iter(it) is it and list(it) == want and list(it) == []
+
+
 def test_kseq_line_model_equals_the_oracle(oracle):
     """tools/kseq_line_model.py -- the executable model k_kq_walk (fx_kseq.hpp) transliterates: kseq_read over a line
-    table with its two 64-line steps -- against the byte-level oracle, with and without the wide steps."""
+    table with its two 64-line steps and the parallel passes over the regular prefix -- against the byte-level oracle, with and
+    without them."""
     import random
     import sys
     from conftest import ROOT
@@ -932,10 +974,10 @@ def test_kseq_line_model_equals_the_oracle(oracle):
             q = None if r["qual_len"] == -1 else bytes(qual[int(r["qual_off"]):int(r["qual_off"]) + max(int(r["qual_len"]), 0)])
             want.append((data[int(r["name_off"]):int(r["name_off"] + r["name_len"])], com, bytes(seq[int(r["seq_off"]):int(r["seq_off"] + r["seq_len"])]), q,
                          bool(r["qual_len"] == -2)))
-        for fast in (True, False):
-            got, gcode = M.materialise(data, fast)
+        for fast, pre in ((True, True), (True, False), (False, False)):
+            got, gcode = M.materialise(data, fast, pre)
             have = [M.header_parts(hdr, bool(fl & M.F_HDR_UNTERM)) + (s, q, bool(fl & M.F_UNTOUCHED)) for hdr, fl, s, q in got]
-            assert have == want and gcode == code, (data, fast)
+            assert have == want and gcode == code, (data, fast, pre)
 
 
 def test_shard_fetcher_degenerate_batches(oracle):

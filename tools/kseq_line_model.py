@@ -1,6 +1,7 @@
 """Executable model of k_kseq_walk (pyfastx_amd/csrc/fx_kseq.hpp): kseq_read (kseq.c:138-179) restated over a LINE
 TABLE instead of a byte stream, with the two 64-line window steps the kernel takes -- 16 four-line FASTQ records at
-once, a run of FASTA header / sequence lines at once -- and the one-line-at-a-time step for everything else.
+once, a run of FASTA header / sequence lines at once -- and the one-line-at-a-time step for everything else; in front of
+it the passes that take a file's regular prefix with every line judged by itself (prefix()).
 
 A development tool: the kernel is a transliteration of walk() below, and `python tools/kseq_line_model.py [seed] [n]`
 fuzzes the model against the byte-level oracle (oracle/fx_oracle.c: fxo_kseq, itself pinned against the compiled
@@ -14,6 +15,7 @@ SEEK, HDR, SEQ, QUAL = 0, 1, 2, 3
 C_SEQ, C_QUAL = 1, 2
 F_FASTQ, F_UNTOUCHED, F_HDR_UNTERM = 1, 2, 4
 BIG = 1 << 25
+REG_MAX = 1 << 20
 W = 64
 
 
@@ -30,7 +32,66 @@ def line_table(data):
     return lines
 
 
-def walk(data, fast=True):
+def con0(t):
+    return t[1] - (1 if (t[3] == 13 and t[1] > 1) else 0)
+
+
+def is_hdr(t):
+    return t[1] >= 1 and t[2] in (62, 64)
+
+
+def prefix(T, recs, ldst, lcls, lcon):
+    """The regular prefix, every line judged by itself (k_kq_classify, k_kq_fq_*, k_kq_fa_*): -> the walker's entry state
+    (j, st, S, cur, acc), records and line entries filled in."""
+    L = len(T)
+    firstq = firsta = L
+    for i, t in enumerate(T):
+        s, ln, f, la, un = t
+        role = i & 3
+        if role == 0:
+            ok = is_hdr(t)
+        elif role == 1:
+            ok = ln >= 1 and f not in (62, 64, 43)
+        elif role == 2:
+            ok = ln >= 1 and f == 43 and not un
+        else:
+            ok = con0(t) == con0(T[i - 2])
+        if ln >= REG_MAX:
+            ok = False
+        if not ok:
+            firstq = min(firstq, i)
+        if (ln >= 1 and f == 43) or (ln == 1 and f == 13) or un or ln >= REG_MAX:
+            firsta = min(firsta, i)
+    R = firstq // 4
+    if R >= 1:
+        S = 0
+        for r in range(R):
+            h, c = T[4 * r], con0(T[4 * r + 1])
+            recs.append(dict(hdr_off=h[0] + 1, hdr_len=h[1] - 1, hdr_line=4 * r, flags=F_FASTQ, seq_len=c, s_n=1, q_n=1, seq_cum=S))
+            ldst[4 * r + 1], lcls[4 * r + 1], lcon[4 * r + 1] = S, C_SEQ, c
+            ldst[4 * r + 3], lcls[4 * r + 3], lcon[4 * r + 3] = S, C_QUAL, c
+            S += c
+        return 4 * R, SEEK, S, None, 0
+    if L and is_hdr(T[0]) and firsta >= 1:
+        n = firsta
+        H = [is_hdr(T[i]) for i in range(n)]
+        con = [0 if (H[i] or T[i][1] == 0) else T[i][1] - (1 if T[i][3] == 13 else 0) for i in range(n)]
+        coff = [0]
+        for c in con:
+            coff.append(coff[-1] + c)
+        hpos = [i for i in range(n) if H[i]]
+        for i in range(n):
+            if not H[i] and T[i][1] > 0:
+                ldst[i], lcls[i], lcon[i] = coff[i], C_SEQ, con[i]
+        for r, i in enumerate(hpos[:-1]):
+            i2 = hpos[r + 1]
+            recs.append(dict(hdr_off=T[i][0] + 1, hdr_len=T[i][1] - 1, hdr_line=i, flags=0, seq_len=coff[i2] - coff[i], s_n=i2 - i - 1, q_n=0, seq_cum=coff[i]))
+        i = hpos[-1]
+        return n, SEQ, coff[i], dict(hdr_off=T[i][0] + 1, hdr_len=T[i][1] - 1, hdr_line=i, flags=0), coff[n] - coff[i]
+    return 0, SEEK, 0, None, 0
+
+
+def walk(data, fast=True, use_prefix=True):
     n = len(data)
     T = line_table(data)
     L = len(T)
@@ -39,6 +100,8 @@ def walk(data, fast=True):
     st, j, S, code = SEEK, 0, 0, None
     cur = None                                           # open record: dict(hdr_off, hdr_len, hdr_line, flags)
     acc = qacc = qn = sn = tcr = lastc = 0
+    if use_prefix:
+        j, st, S, cur, acc = prefix(T, recs, ldst, lcls, lcon)
 
     def emit(seq_len, s_n, q_n, flags, seq_cum):
         r = dict(cur)
@@ -205,10 +268,10 @@ def walk(data, fast=True):
     return T, recs, ldst, lcls, lcon, S, code
 
 
-def materialise(data, fast=True):
+def materialise(data, fast=True, use_prefix=True):
     """-> list of (header bytes, flags, seq bytes, qual bytes or None), end code: through the per-line arrays, as
     k_kseq_gather copies."""
-    T, recs, ldst, lcls, lcon, S, code = walk(data, fast)
+    T, recs, ldst, lcls, lcon, S, code = walk(data, fast, use_prefix)
     out = []
     for r in recs:
         seq, qual = bytearray(r["seq_len"]), bytearray(r["seq_len"])
@@ -256,8 +319,8 @@ def main():
             q = None if r["qual_len"] == -1 else bytes(qual[r["qual_off"]:r["qual_off"] + max(int(r["qual_len"]), 0)])
             want.append((b[r["name_off"]:r["name_off"] + r["name_len"]], com, bytes(seq[r["seq_off"]:r["seq_off"] + r["seq_len"]]), q,
                          r["qual_len"] == -2))
-        for fast in (True, False):
-            got, gcode = materialise(b, fast)
+        for fast, pre in ((True, True), (True, False), (False, False)):
+            got, gcode = materialise(b, fast, pre)
             have = []
             for hdr, fl, s, q in got:
                 nm, cm = header_parts(hdr, bool(fl & F_HDR_UNTERM))
