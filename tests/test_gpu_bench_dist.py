@@ -211,6 +211,10 @@ def test_bench_single_small():
         assert line["c4"]["rows_equal_reference"] is True and line["c4"]["fetch_sample_equal_reference"] is True
     assert line["c3"]["full"]["rows_base_meta_fetch_equal_generator"] is True
     assert line["c4"]["inflated_size_ok"] is True and line["c4"]["roofline"]["achieved"] > 0
+    # the dominant kernel's HBM traffic comes from the counters of THIS run (two rocprofv3 --pmc passes over a child)
+    r = line["roofline"]
+    assert r["traffic_source"].startswith("measured in this run"), r["traffic_source"]
+    assert 0.5 * r["algorithmic_bytes_per_launch"] < r["traffic"] < 2.0 * r["algorithmic_bytes_per_launch"]
 
 
 def test_bench_sharded_path_over_nccl_with_one_rank():

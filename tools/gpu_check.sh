@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 tail -3 $OUT/pytest.log
 timeout 600 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace -- python bench.py --no-pmc --steps 20 --warmup 3 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err
 DB=$(find $OUT/prof -name '*.db' | head -1)
 [ -n "$DB" ] && python tools/rocprof_summary.py $DB $OUT/kernel_stats.txt && grep 'fx::' $OUT/kernel_stats.txt
 find $OUT/prof -name '*.db' -size +20M -delete
