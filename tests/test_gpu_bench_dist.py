@@ -202,7 +202,7 @@ def test_bench_single_small():
     assert line["parity_verified_full_size"] is True and line["roofline"]["achieved"] > 0
     assert line["cpu_baseline"]["kind"] in ("reference", "port")
     e = line["e2e"]                                       # file -> .fxi and host -> host answers, in the same run
-    assert e["open_file_s"] > 0 and e["fxi_durable_s"] >= e["open_file_s"] * 0.5 and e["fetch_many_1M_host_to_host_s"] > 0
+    assert e["open_file_s"] > 0 and e["fxi_durable_s"] > 0 and e["fetch_many_1M_host_to_host_s"] > 0     # (medians of 3 at 50 MB: no order between them)
     if line["cpu_baseline"]["kind"] == "reference":
         assert line["cpu_baseline"]["rows_equal_gpu"] is True and line["cpu_baseline"]["fetch_bytes_equal_gpu"] is True
         assert e["fetch_bytes_equal_reference"] is True and line["speedup_vs_cpu"] > 0
