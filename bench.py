@@ -331,6 +331,23 @@ def leg_c3(a, dev, tmpdir):
         del rq
         if not (smp["rows_equal_reference"] and eq):
             raise SystemExit("PARITY FAILURE (C3 file leg vs the reference)")
+    # Fastx (fastx.c + kseq.c:138-179): index-free iteration over the same file -- stage, line table, parallel prefix passes /
+    # walk, gather, tuples built by the C iterator -- beside the reference's kseq loop; every tuple compared
+    _rm(path + ".fxi")
+    t0 = time.perf_counter()
+    mine = list(fx.Fastx(path))
+    t1 = time.perf_counter()
+    smp["fastx"] = {"tuples": len(mine), "iterate_s": round(t1 - t0, 3)}
+    if ref is not None:
+        t2 = time.perf_counter()
+        theirs_x = list(ref.Fastx(path))
+        t3 = time.perf_counter()
+        smp["fastx"].update(reference_iterate_s=round(t3 - t2, 3), tuples_equal_reference=bool(mine == theirs_x),
+                            note="list(Fastx(path)): both sides create one (name, seq, qual) tuple of str per read, which is most of either time")
+        if mine != theirs_x:
+            raise SystemExit("PARITY FAILURE (Fastx vs the reference)")
+        del theirs_x
+    del mine
     _rm(path, path + ".fxi")
     out["file_sample"] = smp
     if full_path is not None:

@@ -208,6 +208,7 @@ def test_bench_single_small():
         assert e["fetch_bytes_equal_reference"] is True and line["speedup_vs_cpu"] > 0
         assert line["c3"]["file_sample"]["rows_equal_reference"] is True
         assert line["c3"]["file_sample"]["fetch_bytes_equal_reference"] is True
+        assert line["c3"]["file_sample"]["fastx"]["tuples_equal_reference"] is True
         assert line["c4"]["rows_equal_reference"] is True and line["c4"]["fetch_sample_equal_reference"] is True
     assert line["c3"]["full"]["rows_base_meta_fetch_equal_generator"] is True
     assert line["c4"]["inflated_size_ok"] is True and line["c4"]["roofline"]["achieved"] > 0
