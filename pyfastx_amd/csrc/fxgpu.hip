@@ -1041,23 +1041,34 @@ static int open_file_impl(const char *path, int device, fx_handle **out, int64_t
         // restart points for the index file; anything it is not sure of -> the serial path below.
         static const bool no_par = [] { const char *e = getenv("FX_GZIP_SERIAL"); return e && atoi(e) != 0; }();
         if (npts <= 0 && !no_par && fsize >= (32ll << 20) && fsize <= (6ll << 30)) {
-            struct Wk { uint8_t *pin[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool used[2] = {false, false}; hipStream_t st = nullptr; int slot = 0; };
-            std::vector<Wk> wk;
+            // The pieces leave through a FEW staging lanes (a stream, two pinned 8 MiB buffers, a mutex each) shared by all
+            // worker threads: PCIe is one link, and a stream + two pinned buffers per thread meant ~200 hipHostMalloc /
+            // hipHostFree calls and ~100 streams per open -- more time than the inflate itself (0.5 of 0.9 s for 1.5 GB).
+            constexpr int N_LANES = 8;
+            struct Lane { std::mutex mu; uint8_t *pin[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool used[2] = {false, false}; hipStream_t st = nullptr; int slot = 0; };
+            std::vector<Lane> lanes(N_LANES);
             std::atomic<int> dev_err(0);
-            auto alloc = [&](uint64_t total, int workers) {
-                if (alloc_blob(h, (int64_t)total) || hipStreamSynchronize(h->stream) != hipSuccess) return false;
-                wk.resize((size_t)workers);
-                return true;
+            static const bool trace_o = [] { const char *e = getenv("FX_TRACE"), *b = getenv("FX_TRACE_PGZ"); return (e && atoi(e) != 0) || (b && atoi(b) != 0); }();
+            const auto o0 = std::chrono::steady_clock::now();
+            auto olap = [&](const char *what) {
+                if (trace_o) fprintf(stderr, "[fxgpu] gzip open %-24s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - o0).count());
             };
-            auto sink = [&](int w, uint64_t off, const uint8_t *data, size_t len) {
-                Wk &k = wk[(size_t)w];
-                if (!k.st) {                                  // first piece of this worker thread: its stream, events, pinned pieces
-                    if (hipSetDevice(h->device) != hipSuccess) { dev_err.store(1); return false; }
+            auto alloc = [&](uint64_t total, int workers) {
+                (void)workers;
+                if (alloc_blob(h, (int64_t)total) || hipStreamSynchronize(h->stream) != hipSuccess) return false;
+                for (Lane &k : lanes) {
                     k.pin[0] = g_pins.get(); k.pin[1] = g_pins.get();
                     if (!k.pin[0] || !k.pin[1] || hipStreamCreateWithFlags(&k.st, hipStreamNonBlocking) != hipSuccess ||
                         hipEventCreateWithFlags(&k.ev[0], hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&k.ev[1], hipEventDisableTiming) != hipSuccess) { dev_err.store(1); return false; }
+                        hipEventCreateWithFlags(&k.ev[1], hipEventDisableTiming) != hipSuccess) return false;
                 }
+                olap("blob + lanes");
+                return true;
+            };
+            auto sink = [&](int w, uint64_t off, const uint8_t *data, size_t len) {
+                Lane &k = lanes[(size_t)w % N_LANES];
+                std::lock_guard<std::mutex> lk(k.mu);
+                if (hipSetDevice(h->device) != hipSuccess) { dev_err.store(1); return false; }
                 for (size_t a = 0; a < len; a += (size_t)PIECE_BYTES) {
                     const size_t m = std::min<size_t>((size_t)PIECE_BYTES, len - a);
                     if (k.used[k.slot] && hipEventSynchronize(k.ev[k.slot]) != hipSuccess) { dev_err.store(1); return false; }
@@ -1072,10 +1083,13 @@ static int open_file_impl(const char *path, int device, fx_handle **out, int64_t
             pgz::Result res;
             const int T = (int)std::max(2u, std::min(128u, std::thread::hardware_concurrency() / 2));
             const bool ok = pgz::inflate_parallel((const uint8_t *)mp, (uint64_t)fsize, T, (uint64_t)GZ_SPACING, alloc, sink, res);
-            for (Wk &k : wk) {
+            olap("inflate_parallel");
+            for (Lane &k : lanes) {
                 if (k.st) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(k.st); (void)hipStreamDestroy(k.st); }
                 for (int i = 0; i < 2; ++i) { if (k.ev[i]) (void)hipEventDestroy(k.ev[i]); if (k.pin[i]) g_pins.put(k.pin[i]); }
             }
+            olap("lanes drained");
+            if (res.release_later) { res.release_later(); res.release_later = nullptr; }     // the pieces' buffers: unmapped behind our back from here on
             if (dev_err.load()) { (void)munmap(mp, (size_t)fsize); return bail(fail(FX_EDEVICE, "staging the inflated pieces of %s failed", path)); }
             if (ok) {
                 (void)munmap(mp, (size_t)fsize);
