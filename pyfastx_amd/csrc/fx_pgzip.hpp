@@ -47,14 +47,14 @@ constexpr uint32_t LINKB = 1u << 15;
 // Its pages come straight from mmap, 2 MiB-aligned and advised as huge pages: a piece's output is tens of MB written once
 // by one thread while a hundred others do the same -- with 4 KiB pages the first touches queue up behind the process's
 // mmap lock, and giving 3 GB of them back took longer than inflating them (0.34 of 0.62 s).
-struct Buf16 {
-    uint16_t *p = nullptr;
+template <class E> struct BufT {
+    E *p = nullptr;
     size_t n = 0, cap = 0;
-    Buf16() = default;
-    Buf16(const Buf16 &) = delete;
-    Buf16 &operator=(const Buf16 &) = delete;
-    ~Buf16() { release(); }
-    static size_t bytes_of(size_t c) { return (c * 2 + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1); }
+    BufT() = default;
+    BufT(const BufT &) = delete;
+    BufT &operator=(const BufT &) = delete;
+    ~BufT() { release(); }
+    static size_t bytes_of(size_t c) { return (c * sizeof(E) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1); }
     bool reserve(size_t c) {
         if (c <= cap) return true;
         if (p) c = std::max(c, cap + cap / 2);             // (a buffer that has to grow grows by half)
@@ -62,13 +62,15 @@ struct Buf16 {
         void *q = p ? mremap(p, bytes_of(cap), nb, MREMAP_MAYMOVE) : mmap(nullptr, nb, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (q == MAP_FAILED) return false;
         (void)madvise(q, nb, MADV_HUGEPAGE);
-        p = (uint16_t *)q; cap = nb / 2;
+        p = (E *)q; cap = nb / sizeof(E);
         return true;
     }
     void release() { if (p) (void)munmap(p, bytes_of(cap)); p = nullptr; n = cap = 0; }
     size_t size() const { return n; }
-    uint16_t operator[](size_t i) const { return p[i]; }
+    E operator[](size_t i) const { return p[i]; }
 };
+using Buf16 = BufT<uint16_t>;
+using Buf8 = BufT<uint8_t>;
 
 struct Bits {                      // LSB-first bit reader over a buffer readable 8 bytes past `n`
     const uint8_t *p;
@@ -279,6 +281,62 @@ static bool block_codes(Bits &b, const Tables &T, Buf16 *out16, uint64_t &have, 
     return ok;
 }
 
+// The same for a piece whose last 32 KiB hold no marker any more: from there on nothing it produces can depend on the unknown
+// window, so the symbols are plain BYTES (half the memory, and nothing to resolve later).  out8 holds those 32 KiB at its start;
+// every distance reaches at most that far back.
+static bool block_codes8(Bits &b, const Tables &T, Buf8 *out8, uint64_t &have) {
+    uint8_t *p = out8->p;
+    size_t o = out8->n, cap = out8->cap;
+    const uint8_t *in = b.p;
+    uint64_t pos = b.pos;
+    const uint64_t n_bits = b.n_bits;
+    const uint32_t *lt = T.l, *dt = T.d;
+    const uint32_t *lp = T.lp.data(), *dp = T.dp.data();
+    bool ok = false;
+    for (;;) {
+        if (pos >= n_bits) break;
+        if (o + 264 + 16 > cap) {
+            if (!out8->reserve(cap * 2)) break;
+            p = out8->p; cap = out8->cap;
+        }
+        uint64_t w;
+        memcpy(&w, in + (pos >> 3), 8);
+        w >>= (pos & 7);
+        const uint32_t w32 = (uint32_t)w;
+        uint32_t e = lt[w32 & ((1u << LROOT) - 1u)];
+        if (e & LINKB) e = lp[(e >> 16) + ((w32 >> LROOT) & ((1u << (e & 15u)) - 1u))];
+        const uint32_t L = e & 15u, kind = (e >> 8) & 3u;
+        if (kind == 0) {
+            pos += L;
+            p[o++] = (uint8_t)(e >> 16);
+            ++have;
+            continue;
+        }
+        if (kind == 2) { pos += L; ok = pos <= n_bits; break; }
+        if (kind == 3) break;
+        const uint32_t le = (e >> 4) & 15u;
+        const uint32_t mlen = (e >> 16) + ((w32 >> L) & ((1u << le) - 1u));
+        const uint32_t v = (uint32_t)(w >> (L + le));
+        uint32_t d = dt[v & ((1u << DROOT) - 1u)];
+        if (d & LINKB) d = dp[(d >> 16) + ((v >> DROOT) & ((1u << (d & 15u)) - 1u))];
+        if (d & 0x100u) break;
+        const uint32_t dl = d & 15u, de = (d >> 4) & 15u;
+        const uint32_t dist = (d >> 16) + ((v >> dl) & ((1u << de) - 1u));
+        pos += L + le + dl + de;
+        if (pos > n_bits) break;
+        if (dist > o) break;                                  // (o >= WIN here: never true for a valid stream)
+        const uint8_t *src = p + o - dist;
+        uint8_t *dst = p + o;
+        if (dist >= 16) { for (uint32_t i = 0; i < mlen; i += 16) memcpy(dst + i, src + i, 16); }       // (room behind the match: 264 + 16 bytes)
+        else for (uint32_t i = 0; i < mlen; ++i) dst[i] = src[i];
+        o += mlen;
+        have += mlen;
+    }
+    b.pos = pos;
+    out8->n = o;
+    return ok;
+}
+
 // first bit position >= from (and < until) at which a dynamic block begins that decodes to its end and is followed by a
 // plausible header; ~0 when there is none
 static uint64_t find_block(const uint8_t *in, uint64_t n_bits, uint64_t from, uint64_t until) {
@@ -305,7 +363,23 @@ static uint64_t find_block(const uint8_t *in, uint64_t n_bits, uint64_t from, ui
 struct Point { uint64_t bit, out; };                          // a block boundary: bit position, output offset (of the whole stream)
 struct Piece {
     uint64_t start_bit = ~0ull, end_bit = 0;                   // [start, end): where this piece's decode began and stopped
-    Buf16 sym;                                                 // its output, markers included
+    Buf16 sym;                                                 // its output, markers included ...
+    Buf8 byt;                                                  // ... until its last 32 KiB held none: those 32 KiB again, then plain bytes
+    size_t out_len() const { return sym.n + (byt.n ? byt.n - (size_t)WIN : 0); }
+    // outputs [a, a + len) with the markers looked up in Wn (the window in front of the piece, base = WIN - Wn.size());
+    // false when a marker points in front of what exists
+    bool resolve(const std::vector<uint8_t> &Wn, size_t a, size_t len, uint8_t *dst) const {
+        const size_t base = (size_t)WIN - Wn.size();
+        size_t i = 0;
+        for (; i < len && a + i < sym.n; ++i) {
+            const uint16_t s = sym.p[a + i];
+            if (s & 0x8000u) { const uint32_t idx = s & 0x7FFFu; if (idx < base) return false; dst[i] = Wn[idx - base]; }
+            else dst[i] = (uint8_t)s;
+        }
+        if (i < len) memcpy(dst + i, byt.p + WIN + (a + i - sym.n), len - i);
+        return true;
+    }
+    void release() { sym.release(); byt.release(); }
     std::vector<Point> marks;                                  // block boundaries inside it (out: relative to the piece)
     bool dropped = false, failed = false, reached_end = false;
     uint32_t crc = 0;
@@ -374,12 +448,27 @@ static bool inflate_parallel(const uint8_t *in, uint64_t n, int threads, uint64_
                 Tables Tb;
                 Bits b{in, dend, P.start_bit};
                 uint64_t have = 0, last_mark = 0;
-                if (!P.sym.reserve((size_t)(total_bits / 8 / (uint64_t)T * 4) + 1024)) { P.failed = true; return; }
+                bool mode8 = false;                                         // the piece has left its markers behind: plain bytes from here on
+                const size_t est = (size_t)(total_bits / 8 / (uint64_t)T * 4) + ((size_t)1 << 20);    // bytes this piece is likely to produce
+                if (!P.sym.reserve(std::min<size_t>(est, (size_t)4 << 20))) { P.failed = true; return; }
                 int nxt = t + 1;
                 for (;;) {
                     while (nxt < T && (starts[(size_t)nxt] == ~0ull || starts[(size_t)nxt] < b.pos)) ++nxt;
                     if (nxt < T && starts[(size_t)nxt] == b.pos) break;         // exactly at a later piece's block: hand over
                     if (have - last_mark >= spacing && have > 0) { P.marks.push_back(Point{b.pos, have}); last_mark = have; }
+                    if (!mode8 && P.sym.n >= (size_t)WIN) {
+                        // Does anything in the last 32 KiB still stand for a byte of the unknown window?  If not, nothing
+                        // produced from here on can (every distance stays within those 32 KiB): on with bytes.
+                        const uint16_t *tl = P.sym.p + P.sym.n - WIN;
+                        uint16_t any = 0;
+                        for (int i = 0; i < WIN; ++i) any |= tl[i];
+                        if (!(any & 0x8000u)) {
+                            if (!P.byt.reserve(est + (size_t)WIN + 1024)) { P.failed = true; break; }
+                            for (int i = 0; i < WIN; ++i) P.byt.p[i] = (uint8_t)tl[i];
+                            P.byt.n = (size_t)WIN;
+                            mode8 = true;
+                        }
+                    }
                     int last = 0;
                     const int type = header(b, Tb, last);
                     if (type == H_BAD) { P.failed = true; break; }
@@ -388,13 +477,20 @@ static bool inflate_parallel(const uint8_t *in, uint64_t n, int threads, uint64_
                         if ((bp + 4) * 8 > dend) { P.failed = true; break; }
                         const uint32_t len = in[bp] | ((uint32_t)in[bp + 1] << 8), nl = in[bp + 2] | ((uint32_t)in[bp + 3] << 8);
                         if ((len ^ 0xFFFFu) != nl || (bp + 4 + len) * 8 > dend) { P.failed = true; break; }
-                        const size_t o = P.sym.n;
-                        if (!P.sym.reserve(std::max(P.sym.cap, o + len + 264))) { P.failed = true; break; }
-                        for (uint32_t i = 0; i < len; ++i) P.sym.p[o + i] = in[bp + 4 + i];
-                        P.sym.n = o + len;
+                        if (mode8) {
+                            const size_t o = P.byt.n;
+                            if (!P.byt.reserve(o + len + 264 + 16)) { P.failed = true; break; }
+                            memcpy(P.byt.p + o, in + bp + 4, len);
+                            P.byt.n = o + len;
+                        } else {
+                            const size_t o = P.sym.n;
+                            if (!P.sym.reserve(o + len + 264)) { P.failed = true; break; }
+                            for (uint32_t i = 0; i < len; ++i) P.sym.p[o + i] = in[bp + 4 + i];
+                            P.sym.n = o + len;
+                        }
                         have += len;
                         b.pos = (bp + 4 + len) * 8;
-                    } else if (!block_codes(b, Tb, &P.sym, have, false)) { P.failed = true; break; }
+                    } else if (mode8 ? !block_codes8(b, Tb, &P.byt, have) : !block_codes(b, Tb, &P.sym, have, false)) { P.failed = true; break; }
                     if (last) { P.reached_end = true; break; }
                 }
                 P.end_bit = b.pos;
@@ -402,6 +498,11 @@ static bool inflate_parallel(const uint8_t *in, uint64_t n, int threads, uint64_
         for (auto &x : th) x.join();
     }
     lap("pieces decoded");
+    if (trace) {
+        uint64_t s16 = 0, s8 = 0;
+        for (const Piece &P : pc) { s16 += P.sym.n; s8 += P.byt.n; }
+        fprintf(stderr, "[fxgpu] pgzip symbols kept with markers: %.1f MB of output, as plain bytes: %.1f MB\n", s16 / 1e6, s8 / 1e6);
+    }
     // ---- the chain from piece 0: every piece hands over to the piece whose start it stopped at; the others are dropped
     std::vector<int> live;
     uint64_t total = 0;
@@ -410,7 +511,7 @@ static bool inflate_parallel(const uint8_t *in, uint64_t n, int threads, uint64_
         if (P.failed) return false;
         live.push_back(t);
         P.out_base = total;
-        total += P.sym.size();
+        total += P.out_len();
         if (P.reached_end) break;
         int j = t + 1;
         while (j < T && starts[(size_t)j] != P.end_bit) ++j;
@@ -418,7 +519,7 @@ static bool inflate_parallel(const uint8_t *in, uint64_t n, int threads, uint64_
         t = j;
     }
     for (int t = 0; t < T; ++t)
-        if (std::find(live.begin(), live.end(), t) == live.end()) { pc[(size_t)t].sym.release(); pc[(size_t)t].dropped = true; }
+        if (std::find(live.begin(), live.end(), t) == live.end()) { pc[(size_t)t].release(); pc[(size_t)t].dropped = true; }
     // the stream must end at the trailer (up to 7 bits of padding) and ISIZE must agree
     const Piece &Lp = pc[(size_t)live.back()];
     if (((Lp.end_bit + 7) >> 3) != n - 8) return false;
@@ -435,16 +536,9 @@ static bool inflate_parallel(const uint8_t *in, uint64_t n, int threads, uint64_
         for (size_t k = 0; k < live.size(); ++k) {
             const Piece &P = pc[(size_t)live[k]];
             win[k] = cur;
-            const size_t m = P.sym.size(), take = std::min<size_t>(m, WIN), base = WIN - cur.size();
+            const size_t m = P.out_len(), take = std::min<size_t>(m, WIN);
             std::vector<uint8_t> tail(take);
-            for (size_t i = 0; i < take; ++i) {
-                const uint16_t s = P.sym[m - take + i];
-                if (s & 0x8000u) {                             // byte idx of the 32 KiB window that ENDS where the piece begins
-                    const size_t idx = s & 0x7FFFu;
-                    if (idx < base) return false;              // reaches back before the start of the stream
-                    tail[i] = cur[idx - base];
-                } else tail[i] = (uint8_t)s;
-            }
+            if (!P.resolve(cur, m - take, take, tail.data())) return false;      // a marker that reaches back before the start of the stream
             if (take == (size_t)WIN) cur.swap(tail);
             else {
                 std::vector<uint8_t> nc;
@@ -466,19 +560,20 @@ static bool inflate_parallel(const uint8_t *in, uint64_t n, int threads, uint64_
                 for (size_t k; (k = next_piece.fetch_add(1)) < live.size() && !bad.load();) {
                     Piece &P = pc[(size_t)live[k]];
                     const std::vector<uint8_t> &Wn = win[k];
-                    const size_t m = P.sym.size(), base = WIN - Wn.size();
+                    const size_t m = P.out_len();
                     uint32_t crc = 0;
                     const size_t STEP = 8u << 20;
                     for (size_t a = 0; a < m && !bad.load(); a += STEP) {
                         const size_t len = std::min(STEP, m - a);
-                        buf.resize(len);
-                        for (size_t i = 0; i < len; ++i) {
-                            const uint16_t s = P.sym[a + i];
-                            if (s & 0x8000u) { const uint32_t idx = s & 0x7FFFu; if (idx < base) { bad.store(1); break; } buf[i] = Wn[idx - base]; }
-                            else buf[i] = (uint8_t)s;
+                        const uint8_t *data;
+                        if (a >= P.sym.n) data = P.byt.p + WIN + (a - P.sym.n);        // plain bytes already: nothing to resolve, nothing to copy
+                        else {
+                            buf.resize(len);
+                            if (!P.resolve(Wn, a, len, buf.data())) { bad.store(1); break; }
+                            data = buf.data();
                         }
-                        crc = (uint32_t)crc32(crc, buf.data(), (uInt)len);
-                        if (!sink(wkr, P.out_base + a, buf.data(), len)) { bad.store(2); break; }
+                        crc = (uint32_t)crc32(crc, data, (uInt)len);
+                        if (!sink(wkr, P.out_base + a, data, len)) { bad.store(2); break; }
                     }
                     P.crc = crc;
                 }
@@ -488,7 +583,7 @@ static bool inflate_parallel(const uint8_t *in, uint64_t n, int threads, uint64_
     lap("bodies resolved, sunk");
     if (bad.load()) return false;
     uint32_t crc = pc[(size_t)live[0]].crc;
-    for (size_t k = 1; k < live.size(); ++k) crc = (uint32_t)crc32_combine(crc, pc[(size_t)live[k]].crc, (z_off_t)pc[(size_t)live[k]].sym.size());
+    for (size_t k = 1; k < live.size(); ++k) crc = (uint32_t)crc32_combine(crc, pc[(size_t)live[k]].crc, (z_off_t)pc[(size_t)live[k]].out_len());
     if (crc != want_crc) return false;
     // ---- restart points: the start of the deflate data, piece starts and the block boundaries marked inside the pieces, at
     // least `spacing` bytes of output apart (which ones: in order; their 32 KiB windows: in parallel)
@@ -520,18 +615,17 @@ static bool inflate_parallel(const uint8_t *in, uint64_t n, int threads, uint64_
                     const Acc &A = acc[i];
                     const Piece &P = pc[(size_t)live[A.k]];
                     const std::vector<uint8_t> &Wn = win[A.k];
-                    const size_t base = WIN - Wn.size();
                     res.pt_cin[i] = (A.bit + 7) >> 3;
                     res.pt_bits[i] = (uint8_t)((8 - (A.bit & 7)) & 7);
                     res.pt_cout[i] = P.out_base + A.out_rel;
                     res.pt_has[i] = i ? 1 : 0;
                     if (!i) continue;
                     uint8_t *w = res.pt_win.data() + (i - 1) * (size_t)WIN;
-                    for (int j = 0; j < WIN; ++j) {           // byte out_rel - WIN + j of the piece's output (< 0: the window in front of it)
-                        const int64_t q = (int64_t)A.out_rel - WIN + j;
-                        if (q < 0) { const int64_t jj = (int64_t)Wn.size() + q; w[j] = jj >= 0 ? Wn[(size_t)jj] : 0; }
-                        else { const uint16_t sy = P.sym[(size_t)q]; w[j] = (sy & 0x8000u) ? Wn[(sy & 0x7FFFu) - base] : (uint8_t)sy; }
-                    }
+                    // bytes out_rel - WIN .. out_rel - 1 of the piece's output (< 0: the window in front of it)
+                    const int64_t q0 = (int64_t)A.out_rel - WIN;
+                    int j = 0;
+                    for (; j < WIN && q0 + j < 0; ++j) { const int64_t jj = (int64_t)Wn.size() + q0 + j; w[j] = jj >= 0 ? Wn[(size_t)jj] : 0; }
+                    if (j < WIN) (void)P.resolve(Wn, (size_t)(q0 + j), (size_t)(WIN - j), w + j);
                 }
             });
         for (auto &x : th) x.join();
@@ -541,7 +635,7 @@ static bool inflate_parallel(const uint8_t *in, uint64_t n, int threads, uint64_
         auto *junk = new std::vector<Piece>(std::move(pc));
         res.release_later = [junk]() {
             std::thread([junk]() {
-                for (Piece &P : *junk) P.sym.release();
+                for (Piece &P : *junk) P.release();
                 delete junk;
             }).detach();
         };
