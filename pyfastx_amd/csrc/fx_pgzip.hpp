@@ -635,6 +635,11 @@ static bool inflate_parallel(const uint8_t *in, uint64_t n, int threads, uint64_
         auto *junk = new std::vector<Piece>(std::move(pc));
         res.release_later = [junk]() {
             std::thread([junk]() {
+                // ... and not at once: unmapping GBs keeps the process's mmap lock busy, and what the caller does next -- device
+                // allocations for the scan of the bytes it has just got -- needs that lock (measured: fx_fasta_build 177 ms
+                // instead of 1 ms).  The pages are idle memory for that long (FX_PGZ_RELEASE_DELAY_MS, default 1500).
+                static const int delay_ms = [] { const char *e = getenv("FX_PGZ_RELEASE_DELAY_MS"); return e ? atoi(e) : 1500; }();
+                if (delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(delay_ms));
                 for (Piece &P : *junk) P.release();
                 delete junk;
             }).detach();

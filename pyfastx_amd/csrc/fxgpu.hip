@@ -1089,7 +1089,7 @@ static int open_file_impl(const char *path, int device, fx_handle **out, int64_t
                 for (int i = 0; i < 2; ++i) { if (k.ev[i]) (void)hipEventDestroy(k.ev[i]); if (k.pin[i]) g_pins.put(k.pin[i]); }
             }
             olap("lanes drained");
-            if (res.release_later) { res.release_later(); res.release_later = nullptr; }     // the pieces' buffers: unmapped behind our back from here on
+            // (res goes out of scope at the end of this block: only then are the pieces' buffers handed to the thread that unmaps them)
             if (dev_err.load()) { (void)munmap(mp, (size_t)fsize); return bail(fail(FX_EDEVICE, "staging the inflated pieces of %s failed", path)); }
             if (ok) {
                 (void)munmap(mp, (size_t)fsize);
@@ -1097,7 +1097,9 @@ static int open_file_impl(const char *path, int device, fx_handle **out, int64_t
                 h->gzp_bits = res.pt_bits; h->gzp_has = res.pt_has; h->gzp_win = std::move(res.pt_win);
                 h->gz_mode = 3;
                 close(fd);
+                olap("unmapped, points kept");
                 if (hipStreamSynchronize(h->stream) != hipSuccess) { fx_close(h); return fail(FX_EDEVICE, "stream sync failed"); }
+                olap("done");
                 *out = h;
                 return FX_OK;
             }
