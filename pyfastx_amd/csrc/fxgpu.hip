@@ -1081,7 +1081,8 @@ static int open_file_impl(const char *path, int device, fx_handle **out, int64_t
                 return true;
             };
             pgz::Result res;
-            const int T = (int)std::max(2u, std::min(128u, std::thread::hardware_concurrency() / 2));
+            const char *te = getenv("FX_PGZ_THREADS");                     // (experiments; read at every open)
+            const int T = te && atoi(te) > 1 ? atoi(te) : (int)std::max(2u, std::min(128u, std::thread::hardware_concurrency() / 2));
             const bool ok = pgz::inflate_parallel((const uint8_t *)mp, (uint64_t)fsize, T, (uint64_t)GZ_SPACING, alloc, sink, res);
             olap("inflate_parallel");
             for (Lane &k : lanes) {

@@ -33,7 +33,14 @@ def main():
         f.write(gz)
     print("file: %.2f GB compressed, %.2f GB inflated" % (len(gz) / 1e9, host.size / 1e9), flush=True)
     del gz
-    for rep in range(2):
+    settings = [None] + [int(x) for x in os.environ.get("FX_PROBE_THREADS", "").split(",") if x]
+    for rep in range(2 * len(settings)):
+        th = settings[rep // 2]
+        if th is None:
+            os.environ.pop("FX_PGZ_THREADS", None)
+        else:
+            os.environ["FX_PGZ_THREADS"] = str(th)
+        print("threads:", th or "default", flush=True)
         if os.path.exists(p + ".fxi"):
             os.remove(p + ".fxi")
         pr = cProfile.Profile()
@@ -44,7 +51,7 @@ def main():
         t1 = time.perf_counter()
         print("Fasta(path) %.3f s" % (t1 - t0), flush=True)
         del fa
-        if rep == 1:
+        if rep == 2 * len(settings) - 1 and not os.environ.get('FX_PROBE_THREADS'):
             pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
     os.remove(p); os.remove(p + ".fxi"); os.rmdir(d)
 
