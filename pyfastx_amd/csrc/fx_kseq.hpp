@@ -275,7 +275,7 @@ __global__ __launch_bounds__(KQ_WALK_BLOCK) void k_kq_walk(const uint8_t *__rest
     // ---------------- the walker (wave 0).  Everything but the per-lane window values is wave-uniform.
     int st = (int)in.st, code = 0;
     int64_t j = in.j0, S = in.S, nrec = in.nrec;
-    int64_t cur_off = in.cur_off, cur_line = in.cur_line, acc = in.acc, qacc = 0, tcr = 0, lastc = 0;
+    int64_t cur_off = in.cur_off, cur_line = in.cur_line, acc = in.acc, qacc = 0, tcr = 0, lastc = 0, qfirst = 0;
     uint32_t cur_len = in.cur_len, cur_flags = in.cur_flags, qn = 0, sn = 0;
     int64_t have = b0 - 1;                                  // batches [b0, have] are known to be in the ring
     uint32_t pub = (uint32_t)b0;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(KQ_WALK_BLOCK) void k_kq_walk(const uint8_t *__rest
             } else if (f0 == '+') {
                 if (un0) { code = -2; break; }
                 sn = (uint32_t)(j - cur_line - 1);
-                st = KQ_QUAL; qacc = 0; qn = 0; tcr = 0; lastc = j;
+                st = KQ_QUAL; qacc = 0; qn = 0; tcr = 0; lastc = j; qfirst = j;
                 ++j;
             } else {
                 // the first byte goes in by itself (kseq.c:156); the strip belongs to the call for the rest of the line,
@@ -444,12 +444,12 @@ __global__ __launch_bounds__(KQ_WALK_BLOCK) void k_kq_walk(const uint8_t *__rest
             if (tcr >= 1 && qacc > 1) {
                 --qacc; --tcr;
                 if (len0) --con;
-                else if (lane == 0) {
-                    while (lcon[lastc] == 0) --lastc;
-                    lcon[lastc] -= 1;
+                else if (lane == 0) {                     // the CR belongs to an earlier line: the last one that still holds bytes
+                    while (lastc > qfirst && lcon[lastc] == 0) --lastc;       // (there is one: the lines' counts add up to qacc)
+                    if (lcon[lastc]) lcon[lastc] -= 1;
                 }
             }
-            lastc = __shfl((int)(lastc & 0xFFFFFFFFll), 0, 64) | (lastc & ~0xFFFFFFFFll);   // (lane 0 may have walked back within 4 G lines)
+            lastc = kq_u64(lastc);                         // lane 0's
             if (lane == 0) { ldst[j] = (S + qacc - con) | ((int64_t)KQ_C_QUAL << 62); lcon[j] = con; }
             if (con) lastc = j;
             ++qn; ++j;
