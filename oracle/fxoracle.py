@@ -220,3 +220,25 @@ def fastx_tuples(data, fmt, uppercase=False, comment=False):
         else:
             out.append((name, _cstr(s), last_qual, com) if comment else (name, _cstr(s), last_qual))
     return out
+
+
+def index_free_tuples(data, kind, full_name=False, uppercase=False):
+    """What iterating pyfastx.Fasta(path, build_index=False) (kind "fasta": index.c:609-664) or pyfastx.Fastq(path,
+    build_index=False) (kind "fastq": fastq.c:598-622) yields: kseq_read's records as (name, seq) / (name, seq, qual); with
+    full_name a non-empty comment is joined to the name with one space ("%s %s"), whatever the delimiter was."""
+    a, _, _ = _buf(data)
+    raw = a.tobytes()
+    recs, seq, qual, _ = kseq(a)
+    out, last_qual = [], None
+    for r in recs:
+        name = _cstr(raw[r["name_off"]:r["name_off"] + r["name_len"]])
+        if full_name and r["com_len"] > 0:
+            name = name + " " + _cstr(raw[r["com_off"]:r["com_off"] + r["com_len"]])
+        s = seq[r["seq_off"]:r["seq_off"] + r["seq_len"]].tobytes()
+        if r["qual_len"] >= 0:
+            last_qual = _cstr(qual[r["qual_off"]:r["qual_off"] + r["qual_len"]].tobytes())
+        if kind == "fasta":
+            out.append((name, _cstr(s.upper() if uppercase else s)))
+        else:
+            out.append((name, _cstr(s), last_qual))
+    return out

@@ -362,7 +362,15 @@ class Fasta(_fxobj.FastaCore):
         return self._db.execute("SELECT 1 FROM seq WHERE chrom=? LIMIT 1", (key,)).fetchone() is not None
 
     def __iter__(self):
-        if self._has_index:                                   # fasta.c:146-172 -> Sequence objects in file order
+        if not self._has_index:
+            # build_index=False: (name, seq) tuples from kseq_read (index.c:609-664) -- the same device path as Fastx (fx_kseq.hpp)
+            # over the staged stream, a C iterator building the tuples; full_name joins a non-empty comment to the name with
+            # one space ("%s %s"), whatever the delimiter was
+            return _kseq_iter(lambda: self._st.blob, False, fastq=False, upper=self._uppercase, comment_mode=2 if self._full_name else 0)
+        return self._iter_indexed()
+
+    def _iter_indexed(self):
+        if True:                                              # fasta.c:146-172 -> Sequence objects in file order
             self._need_index()
             # the sequences of the records ahead come off the GPU in batches (one gather per ~64 MB of
             # bases or 4096 records) and ride along in the Sequence objects; `.seq` of an object taken from the iterator
@@ -389,20 +397,7 @@ class Fasta(_fxobj.FastaCore):
                     yield sq
                 i = j
             return
-        # build_index=False: (name, seq) tuples (index.c:604-664); records come from the same GPU scan,
-        # kept in memory only, and whole sequences are fetched in batches
-        blob = self._st.blob
-        s = blob.fasta_build(self._full_name)
-        t = blob.fasta_table(s.n_seq)
-        names = [_text(x) for x in self._gather(t["hoff"] + 1, t["name_len"])]
-        fl = _F_UP if self._uppercase else 0
-        step = 256
-        for a in range(0, s.n_seq, step):
-            b = min(s.n_seq, a + step)
-            want = np.maximum(t["slen"][a:b], 0)
-            buf, offs, ol = blob.fetch_ranges(t["boff"][a:b], t["blen"][a:b], want, flags=fl)
-            for k in range(b - a):
-                yield names[a + k], _decode(buf[offs[k]:offs[k] + ol[k]])
+        # (build_index=False is answered by __iter__ itself)
 
     def _need_index(self):
         if self._db is None:
@@ -1191,7 +1186,13 @@ class Fastq:
         return self._db.execute("SELECT 1 FROM read WHERE name=? LIMIT 1", (key,)).fetchone() is not None
 
     def __iter__(self):
-        if self._has_index:
+        if not self._has_index:
+            # build_index=False: (name, seq, qual) tuples from kseq_read (fastq.c:598-622): the device path of Fastx
+            return _kseq_iter(lambda: self._st.blob, False, fastq=True, upper=False, comment_mode=2 if self._full_name else 0)
+        return self._iter_indexed()
+
+    def _iter_indexed(self):
+        if True:
             # sequence and quality lines of 16384 reads per gather ride along in the Read objects
             cur = self._db.execute("SELECT * FROM read ORDER BY ID")
             while True:
@@ -1205,21 +1206,6 @@ class Fastq:
                     rd = Read(self, *row)
                     rd._pre = (sall[o[m]:o[m + 1]], qall[o[m]:o[m + 1]])
                     yield rd
-        # build_index=False: (name, seq, qual) tuples, from an in-memory GPU scan + batched gathers
-        blob = self._st.blob
-        s = blob.fastq_build()
-        t = blob.fastq_table(s.n_reads)
-        step = 1 << 16
-        for a in range(0, s.n_reads, step):
-            b = min(s.n_reads, a + step)
-            ids = np.arange(a, b, dtype=np.int64)
-            seq, qual, _, offs = blob.fastq_fetch(ids, t["rlen"][a:b], want=("seq", "qual"))
-            ln = (t["dlen"][a:b] - 1).astype(np.int64) if self._full_name else t["name_len"][a:b].astype(np.int64)
-            nb, no, _ = blob.fetch_ranges(t["name_off"][a:b], ln, ln, flags=_F_RAW)
-            for k in range(b - a):
-                full = _text(nb[no[k]:no[k + 1]])
-                nm = full.rstrip("\r")
-                yield nm, _decode(seq[offs[k]:offs[k + 1]]), _decode(qual[offs[k]:offs[k + 1]])
 
     def keys(self):
         return FastqKeys(self, self._counts)                                                   # fastq.c:555-557
@@ -1471,29 +1457,6 @@ class Fastx:
     def __repr__(self):
         return "<Fastx> %s %s" % ("fasta" if self._format == 1 else "fastq", self.file_name)    # fastx.c:126-132
 
-    def _batches(self):
-        """(hdr bytes, their offsets, seq bytes, qual bytes | None, record table) per batch of records, None at the end."""
-        fastq = self._format == 2
-        blob = _lib.Blob.from_file(self.file_name, device=self._device)
-        try:
-            n_rec, _, _, self.end_code = blob.kseq_scan()
-            for a in range(0, n_rec, self.BATCH_RECORDS):
-                recs = blob.kseq_records(a, min(self.BATCH_RECORDS, n_rec - a))
-                cum, slen = recs["seq_cum"], recs["seq_len"]
-                i = 0
-                while i < recs.size:
-                    ends = cum[i:] + slen[i:] - cum[i]
-                    k = i + max(1, int(np.searchsorted(ends, self.BATCH_BYTES, side="right")))
-                    nbytes = int(ends[k - i - 1])
-                    seq, qual = blob.kseq_fetch(a + i, k - i, nbytes, upper=self._uppercase and not fastq, want_qual=fastq)  # fastx.c:14-22, 97-103
-                    hl = recs["hdr_len"][i:k].astype(np.int64)
-                    hdr, ho, _ = blob.fetch_ranges(recs["hdr_off"][i:k], hl, hl, flags=_lib.FX_RAW)
-                    yield hdr, ho, seq, qual, recs[i:k]
-                    i = k
-        finally:
-            blob.close()
-        yield None
-
     def __iter__(self):
         # The tuples of fastx.c:6-30 come out of a C iterator (_fxobj.FastxIter, the counterpart of pyfastx_fastx_next): per
         # record the header cut of kseq.c:148-149 (_kseq_header), "s" strings (_cstr), and the buffer rules -- a record
@@ -1501,7 +1464,41 @@ class Fastx:
         # followed by anything but the newline, a CR included) and "" afterwards (kseq.c:146 with Py_BuildValue "s#" on a
         # NULL pointer, fastx.c:10-12, 28-30); a FASTA-style record seen through the FASTQ builder carries the last
         # quality string.
-        return _fxobj.FastxIter(self._batches().__next__, self._format == 2, self._comment)
+        fastq = self._format == 2
+        return _kseq_iter(lambda: _lib.Blob.from_file(self.file_name, device=self._device), True, fastq=fastq,
+                          upper=self._uppercase and not fastq, comment_mode=1 if self._comment else 0, owner=self)   # fastx.c:14-22, 97-103
+
+
+def _kseq_batches(get_blob, close_blob, fastq, upper, owner=None):
+    """(hdr bytes, their offsets, seq bytes, qual bytes | None, record table) per batch of kseq_read's records over a staged
+    stream (fx_kseq_scan / _records / _fetch), None at the end."""
+    blob = get_blob()
+    try:
+        n_rec, _, _, code = blob.kseq_scan()
+        if owner is not None:
+            owner.end_code = code
+        for a in range(0, n_rec, Fastx.BATCH_RECORDS):
+            recs = blob.kseq_records(a, min(Fastx.BATCH_RECORDS, n_rec - a))
+            cum, slen = recs["seq_cum"], recs["seq_len"]
+            i = 0
+            while i < recs.size:
+                ends = cum[i:] + slen[i:] - cum[i]
+                k = i + max(1, int(np.searchsorted(ends, Fastx.BATCH_BYTES, side="right")))
+                nbytes = int(ends[k - i - 1])
+                seq, qual = blob.kseq_fetch(a + i, k - i, nbytes, upper=upper, want_qual=fastq)
+                hl = recs["hdr_len"][i:k].astype(np.int64)
+                hdr, ho, _ = blob.fetch_ranges(recs["hdr_off"][i:k], hl, hl, flags=_lib.FX_RAW)
+                yield hdr, ho, seq, qual, recs[i:k]
+                i = k
+    finally:
+        if close_blob:
+            blob.close()
+    yield None
+
+
+def _kseq_iter(get_blob, close_blob, fastq, upper, comment_mode, owner=None):
+    """The C iterator over kseq_read's records (comment_mode: 0 none, 1 the comment as last element, 2 joined to the name)."""
+    return _fxobj.FastxIter(_kseq_batches(get_blob, close_blob, fastq, upper, owner).__next__, fastq, comment_mode)
 
 
 # ============================================================== module functions

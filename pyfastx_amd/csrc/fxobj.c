@@ -266,6 +266,9 @@ static PyObject *cstr_text(const uint8_t *p, int64_t n)          /* Py_BuildValu
 static int kq_isspace(int c) { return c == ' ' || (c >= 9 && c <= 13); }
 
 /* one record -> its tuple; *buffered / *last_qual carry the reference's comment / quality buffer state */
+/* with_comment: 0 no comment element; 1 the comment as the last element (Fastx, fastx.c:10-12, 28-30); 2 no element, but a
+ * non-empty comment is joined to the name with ONE SPACE, whatever the delimiter was (the index-free iteration of Fasta /
+ * Fastq with full_name: PyUnicode_FromFormat("%s %s", name, comment), index.c:624-664, fastq.c:607-622) */
 static PyObject *kq_tuple(const uint8_t *h, int64_t hl, const uint8_t *s_ptr, const uint8_t *q_ptr, const kq_rec *r, int fastq, int with_comment,
                           int *buffered, PyObject **last_qual)
 {
@@ -285,6 +288,14 @@ static PyObject *kq_tuple(const uint8_t *h, int64_t hl, const uint8_t *s_ptr, co
     }
     name = cstr_text(h, nl);
     s = cstr_text(s_ptr, r->seq_len);
+    if (with_comment == 2) {
+        if (cl > 0 && name) {
+            PyObject *c = cstr_text(h + nl + 1, cl), *j = c ? PyUnicode_FromFormat("%U %U", name, c) : NULL;
+            Py_XDECREF(c);
+            Py_SETREF(name, j);
+        }
+        with_comment = 0;
+    }
     if (with_comment) {
         if (cl >= 0) com = PyUnicode_DecodeUTF8((const char *)h + nl + 1, (Py_ssize_t)cl, "surrogateescape");
         else if (*buffered) com = PyUnicode_FromStringAndSize("", 0);
@@ -304,7 +315,7 @@ static PyObject *mod_fastx_batch(PyObject *m, PyObject *args)
     int fastq = 0, with_comment = 0, buffered, has_qual;
     Py_ssize_t k, i;
     (void)m;
-    if (!PyArg_ParseTuple(args, "y*y*y*Oy*ppO!", &hdr, &ho, &seq, &qual_obj, &recs, &fastq, &with_comment, &PyList_Type, &state)) return NULL;
+    if (!PyArg_ParseTuple(args, "y*y*y*Oy*piO!", &hdr, &ho, &seq, &qual_obj, &recs, &fastq, &with_comment, &PyList_Type, &state)) return NULL;
     has_qual = qual_obj != Py_None;
     if (has_qual && PyObject_GetBuffer(qual_obj, &qual, PyBUF_SIMPLE) < 0) { has_qual = 0; goto done; }
     k = recs.len / (Py_ssize_t)sizeof(kq_rec);
@@ -368,7 +379,7 @@ static PyObject *fxi_new(PyTypeObject *type, PyObject *args, PyObject *kw)
     int fastq = 0, with_comment = 0;
     FastxIter *it;
     (void)kw;
-    if (!PyArg_ParseTuple(args, "Opp", &fn, &fastq, &with_comment)) return NULL;
+    if (!PyArg_ParseTuple(args, "Opi", &fn, &fastq, &with_comment)) return NULL;
     if (!PyCallable_Check(fn)) { PyErr_SetString(PyExc_TypeError, "next_batch must be callable"); return NULL; }
     it = (FastxIter *)type->tp_alloc(type, 0);
     if (!it) return NULL;

@@ -100,6 +100,34 @@ def test_kseq_records_through_the_c_abi(fx, oracle):
     assert codes == {-1, -2}
 
 
+def test_index_free_iteration_of_fasta_and_fastq(fx, oracle, ref, tmp_path):
+    """Fasta(path, build_index=False) and Fastq(path, build_index=False) iterate with kseq_read as well (index.c:609-664,
+    fastq.c:598-622): the same device path, names joined with the comment by one space under full_name -- against the oracle
+    on the kseq inputs whose first character lets the constructor through, and side by side with the reference."""
+    rng = random.Random(77)
+    seen = 0
+    for data in list(FIXED) + [gen(rng) for _ in range(150)]:
+        if oracle.kseq_undefined(data):
+            continue
+        first = data.lstrip()[:1]
+        for kind, lead, ext in (("fasta", b">", "fa"), ("fastq", b"@", "fq")):
+            if first != lead:
+                continue
+            p = _put(tmp_path, "i." + ext, data)
+            for full_name in (False, True):
+                for up in ((False, True) if kind == "fasta" else (False,)):
+                    if kind == "fasta":
+                        got = list(fx.Fasta(p, build_index=False, full_name=full_name, uppercase=up))
+                        theirs = list(ref.Fasta(p, build_index=False, full_name=full_name, uppercase=up))
+                    else:
+                        got = list(fx.Fastq(p, build_index=False, full_name=full_name))
+                        theirs = list(ref.Fastq(p, build_index=False, full_name=full_name))
+                    assert got == oracle.index_free_tuples(data, kind, full_name, up) == theirs, (data, kind, full_name, up)
+                    seen += 1
+            assert not os.path.exists(p + ".fxi")
+    assert seen > 200
+
+
 def test_regular_files_need_no_walk(fx):
     """A file of four-line records, or of plain FASTA lines, is taken by the parallel passes alone (fx_kseq_prefix_lines);
     the first line that is neither hands over to the walk."""

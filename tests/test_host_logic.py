@@ -936,7 +936,7 @@ def test_fastx_batch_builds_the_reference_tuples(oracle):
         for r in recs:
             if r["qual_len"] > 0:
                 qbuf[int(r["seq_off"]):int(r["seq_off"] + r["qual_len"])] = qual[int(r["qual_off"]):int(r["qual_off"] + r["qual_len"])]
-        for fmt, com in (("fasta", False), ("fasta", True), ("fastq", False), ("fastq", True)):
+        for fmt, com in (("fasta", 0), ("fasta", 1), ("fastq", 0), ("fastq", 1), ("fasta", 2), ("fastq", 2)):
             state, got, batches = [False, None], [], []
             for a in range(0, len(recs), 3):
                 b = min(len(recs), a + 3)
@@ -947,7 +947,8 @@ def test_fastx_batch_builds_the_reference_tuples(oracle):
                 batches.append((np.frombuffer(b"".join(hdrs[a:b]), dtype=np.uint8), ho, seq[base:end].copy(),
                                 qbuf[base:end].copy() if fmt == "fastq" else None, t[a:b]))
                 got += _fxobj.fastx_batch(*batches[-1], fmt == "fastq", com, state)
-            want = oracle.fastx_tuples(data, fmt, comment=com)
+            # (2: no comment element, a non-empty comment joined to the name -- the index-free iteration of Fasta / Fastq with full_name)
+            want = oracle.index_free_tuples(data, fmt, True) if com == 2 else oracle.fastx_tuples(data, fmt, comment=bool(com))
             assert got == want, (data, fmt, com)
             # the iterator type Fastx.__iter__ returns, fed with the same batches (and an empty one in between)
             feed = iter(batches[:1] + [(np.zeros(0, np.uint8), np.zeros(1, np.int64), np.zeros(0, np.uint8), None, t[:0])] + batches[1:] + [None])

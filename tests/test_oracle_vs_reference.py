@@ -161,6 +161,34 @@ def test_kseq_oracle_equals_the_reference_fastx(oracle, ref, tmp_path, seed):
                 assert list(ref.Fastx(p, format=fmt, **kw)) == oracle.fastx_tuples(data, fmt, **kw), (data, fmt, kw)
 
 
+def test_index_free_iteration_oracle_equals_the_reference(oracle, ref, tmp_path):
+    """fxoracle.index_free_tuples (kseq_read's records as Fasta / Fastq hand them out without an index, index.c:609-664 and
+    fastq.c:598-622, full_name joining name and comment with one space) against the compiled reference."""
+    import random
+    from kseq_cases import FIXED, gen
+    rng = random.Random(6100)
+    seen = 0
+    for data in list(FIXED) + [gen(rng) for _ in range(400)]:
+        if oracle.kseq_undefined(data):
+            continue
+        first = data.lstrip()[:1]
+        for kind, lead, ext in (("fasta", b">", "fa"), ("fastq", b"@", "fq")):
+            if first != lead:                              # the constructors refuse anything else (fasta.c:107-110, fastq.c)
+                continue
+            p = str(tmp_path / ("t." + ext))
+            with open(p, "wb") as f:
+                f.write(data)
+            for full_name in (False, True):
+                if kind == "fasta":
+                    for up in (False, True):
+                        assert list(ref.Fasta(p, build_index=False, full_name=full_name, uppercase=up)) == \
+                            oracle.index_free_tuples(data, kind, full_name, up), (data, full_name, up)
+                else:
+                    assert list(ref.Fastq(p, build_index=False, full_name=full_name)) == oracle.index_free_tuples(data, kind, full_name), (data, full_name)
+                seen += 1
+    assert seen > 300
+
+
 @pytest.mark.parametrize("members", [1, 3])
 def test_refshim_serves_reads_from_imported_points(ref, tmp_path, members):
     """The zran work-alike under the compiled reference (oracle/refshim/zran.c; indexed_gzip is not part of the reference
