@@ -1201,11 +1201,7 @@ class Fastq:
                     return
                 seq, qual, _, offs = self._st.blob.read_fetch([r[4] for r in rows], [r[5] for r in rows], [r[3] for r in rows],
                                                               want=("seq", "qual"))
-                sall, qall, o = _decode(seq[:int(offs[-1])]), _decode(qual[:int(offs[-1])]), offs.tolist()   # one decode per batch
-                for m, row in enumerate(rows):
-                    rd = Read(self, *row)
-                    rd._pre = (sall[o[m]:o[m + 1]], qall[o[m]:o[m + 1]])
-                    yield rd
+                yield from _fxobj.read_batch(Read, self, rows, seq, qual, offs)          # the batch's objects made in C, strings included
 
     def keys(self):
         return FastqKeys(self, self._counts)                                                   # fastq.c:555-557
@@ -1325,13 +1321,10 @@ class Fastq:
         return buf[sel], out_offs
 
 
-class Read:
-    """pyfastx.Read (read.c:288-323)."""
-
-    def __init__(self, fq, rid, name, dlen, rlen, soff, qoff):
-        self._fq = fq
-        self.id, self.name = int(rid), name
-        self._desc_len, self._read_len, self._soff, self._qoff = int(dlen), int(rlen), int(soff), int(qoff)
+class Read(_fxobj.ReadCore):
+    """pyfastx.Read (read.c:288-323).  The row's fields (id, name, _desc_len, _read_len, _soff, _qoff) live in the C base type
+    (csrc/fxobj.c: ReadCore, constructed as Read(fq, id, name, dlen, rlen, soff, qoff)); the objects of Fastq's iterator are
+    made a batch at a time by _fxobj.read_batch and carry their sequence and quality strings (_pre_seq / _pre_qual)."""
 
     def __len__(self):
         return self._read_len
@@ -1347,14 +1340,14 @@ class Read:
 
     @property
     def seq(self):
-        if getattr(self, "_pre", None) is not None:
-            return self._pre[0]                                                                # came with the iterator's batch
+        if self._pre_seq is not None:
+            return self._pre_seq                                                               # came with the iterator's batch
         return _decode(self._bytes(self._soff, self._read_len))                                # read.c:152-167
 
     @property
     def qual(self):
-        if getattr(self, "_pre", None) is not None:
-            return self._pre[1]
+        if self._pre_qual is not None:
+            return self._pre_qual
         return _decode(self._bytes(self._qoff, self._read_len))                                # read.c:237-249
 
     @property

@@ -435,7 +435,98 @@ static PyTypeObject FastxIterType = {
     .tp_new = fxi_new,
 };
 
+/* ------------------------------------------------------------------ Read: the C base of pyfastx_amd.Read (read.c:288-323)
+ * The fields of a row of the `read` table and, for objects that come out of Fastq's iterator, the sequence and quality
+ * strings that came with the iterator's batch.  read_batch() makes the objects of a whole batch in one call. */
+typedef struct {
+    PyObject_HEAD
+    PyObject *fq, *name, *pre_seq, *pre_qual;
+    long long id, desc_len, read_len, soff, qoff;
+} ReadCore;
+
+static void read_dealloc(ReadCore *r)
+{
+    Py_XDECREF(r->fq); Py_XDECREF(r->name); Py_XDECREF(r->pre_seq); Py_XDECREF(r->pre_qual);
+    Py_TYPE(r)->tp_free((PyObject *)r);
+}
+static int read_init(ReadCore *r, PyObject *args, PyObject *kw)
+{
+    PyObject *fq, *name;
+    long long id, dlen, rlen, soff, qoff;
+    (void)kw;
+    if (!PyArg_ParseTuple(args, "OLOLLLL", &fq, &id, &name, &dlen, &rlen, &soff, &qoff)) return -1;
+    Py_XSETREF(r->fq, Py_NewRef(fq));
+    Py_XSETREF(r->name, Py_NewRef(name));
+    r->id = id; r->desc_len = dlen; r->read_len = rlen; r->soff = soff; r->qoff = qoff;
+    return 0;
+}
+static PyMemberDef read_members[] = {
+    {"_fq", T_OBJECT_EX, offsetof(ReadCore, fq), READONLY, "the Fastq object"},
+    {"name", T_OBJECT_EX, offsetof(ReadCore, name), 0, "read name"},
+    {"id", T_LONGLONG, offsetof(ReadCore, id), 0, "1-based id"},
+    {"_desc_len", T_LONGLONG, offsetof(ReadCore, desc_len), READONLY, NULL},
+    {"_read_len", T_LONGLONG, offsetof(ReadCore, read_len), READONLY, NULL},
+    {"_soff", T_LONGLONG, offsetof(ReadCore, soff), READONLY, NULL},
+    {"_qoff", T_LONGLONG, offsetof(ReadCore, qoff), READONLY, NULL},
+    {"_pre_seq", T_OBJECT, offsetof(ReadCore, pre_seq), READONLY, "the sequence, when it came with the iterator's batch (else None)"},
+    {"_pre_qual", T_OBJECT, offsetof(ReadCore, pre_qual), READONLY, "the quality string, likewise"},
+    {NULL, 0, 0, 0, NULL}};
+static PyTypeObject ReadCoreType = {
+    PyVarObject_HEAD_INIT(NULL, 0)
+    .tp_name = "pyfastx_amd._fxobj.ReadCore",
+    .tp_basicsize = sizeof(ReadCore),
+    .tp_dealloc = (destructor)read_dealloc,
+    .tp_flags = Py_TPFLAGS_DEFAULT | Py_TPFLAGS_BASETYPE,
+    .tp_members = read_members,
+    .tp_init = (initproc)read_init,
+    .tp_new = PyType_GenericNew,
+};
+
+/* read_batch(ReadType, fq, rows, seq, qual, offs) -> list: rows = the (ID, name, dlen, rlen, soff, qoff) tuples of the batch,
+ * seq / qual = the bytes of their sequence / quality lines one behind the other, offs = int64[k + 1] */
+static PyObject *mod_read_batch(PyObject *m, PyObject *args)
+{
+    PyObject *type, *fq, *rows, *out = NULL;
+    Py_buffer seq, qual, offs;
+    Py_ssize_t k, i;
+    (void)m;
+    if (!PyArg_ParseTuple(args, "OOO!y*y*y*", &type, &fq, &PyList_Type, &rows, &seq, &qual, &offs)) return NULL;
+    k = PyList_GET_SIZE(rows);
+    if (!PyType_Check(type) || !PyType_IsSubtype((PyTypeObject *)type, &ReadCoreType) || offs.len < (k + 1) * 8) {
+        PyErr_SetString(PyExc_TypeError, "read_batch(ReadCore subtype, fq, rows, seq, qual, int64 offsets[k + 1])");
+        goto done;
+    }
+    out = PyList_New(k);
+    for (i = 0; out && i < k; ++i) {
+        PyObject *row = PyList_GET_ITEM(rows, i);
+        const int64_t *o = (const int64_t *)offs.buf;
+        ReadCore *r;
+        if (!PyTuple_Check(row) || PyTuple_GET_SIZE(row) < 6 || o[i] < 0 || o[i + 1] < o[i] || o[i + 1] > seq.len || o[i + 1] > qual.len) {
+            PyErr_SetString(PyExc_ValueError, "bad row or offsets");
+            Py_CLEAR(out);
+            break;
+        }
+        r = (ReadCore *)((PyTypeObject *)type)->tp_alloc((PyTypeObject *)type, 0);
+        if (!r) { Py_CLEAR(out); break; }
+        PyList_SET_ITEM(out, i, (PyObject *)r);
+        r->fq = Py_NewRef(fq);
+        r->name = Py_NewRef(PyTuple_GET_ITEM(row, 1));
+        r->id = PyLong_AsLongLong(PyTuple_GET_ITEM(row, 0));
+        r->desc_len = PyLong_AsLongLong(PyTuple_GET_ITEM(row, 2));
+        r->read_len = PyLong_AsLongLong(PyTuple_GET_ITEM(row, 3));
+        r->soff = PyLong_AsLongLong(PyTuple_GET_ITEM(row, 4));
+        r->qoff = PyLong_AsLongLong(PyTuple_GET_ITEM(row, 5));
+        r->pre_seq = PyUnicode_DecodeLatin1((const char *)seq.buf + o[i], (Py_ssize_t)(o[i + 1] - o[i]), NULL);
+        r->pre_qual = PyUnicode_DecodeLatin1((const char *)qual.buf + o[i], (Py_ssize_t)(o[i + 1] - o[i]), NULL);
+        if (PyErr_Occurred() || !r->pre_seq || !r->pre_qual) { Py_CLEAR(out); break; }
+    }
+done:
+    PyBuffer_Release(&seq); PyBuffer_Release(&qual); PyBuffer_Release(&offs);
+    return out;
+}
+
 static PyMethodDef mod_methods[] = {
+    {"read_batch", mod_read_batch, METH_VARARGS, "read_batch(ReadType, fq, rows, seq, qual, offs) -> list of Read objects with their strings"},
     {"fastx_batch", mod_fastx_batch, METH_VARARGS, "fastx_batch(hdr, hdr_off, seq, qual, recs, fastq, with_comment, state) -> list of tuples"},
     {"set_api", mod_set_api, METH_VARARGS, "set_api(address of fx_fetch_one, Sequence type)"},
     {"bench_fetch_one", mod_bench, METH_VARARGS, "bench_fetch_one(handle, off, blen, take, n) -> us per fx_fetch_one call from C"},
@@ -445,7 +536,7 @@ static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_fxobj", "C base typ
 PyMODINIT_FUNC PyInit__fxobj(void)
 {
     PyObject *m;
-    if (PyType_Ready(&SeqCoreType) < 0 || PyType_Ready(&FastaCoreType) < 0 || PyType_Ready(&FastxIterType) < 0) return NULL;
+    if (PyType_Ready(&SeqCoreType) < 0 || PyType_Ready(&FastaCoreType) < 0 || PyType_Ready(&FastxIterType) < 0 || PyType_Ready(&ReadCoreType) < 0) return NULL;
     m = PyModule_Create(&moddef);
     if (!m) return NULL;
     Py_INCREF(&SeqCoreType); Py_INCREF(&FastaCoreType);
@@ -453,5 +544,7 @@ PyMODINIT_FUNC PyInit__fxobj(void)
     PyModule_AddObject(m, "FastaCore", (PyObject *)&FastaCoreType);
     Py_INCREF(&FastxIterType);
     PyModule_AddObject(m, "FastxIter", (PyObject *)&FastxIterType);
+    Py_INCREF(&ReadCoreType);
+    PyModule_AddObject(m, "ReadCore", (PyObject *)&ReadCoreType);
     return m;
 }
