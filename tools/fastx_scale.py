@@ -56,6 +56,15 @@ def main():
     b = _lib.Blob.from_device(blob_t.data_ptr(), cols["n_bytes"], device=0, keepalive=blob_t)
     r, first = leg(b, "fastq 150-base reads", n)
     assert (first["hdr_off"] == cols["name_off"][:first.size]).all() and (first["seq_len"] == 150).all() and (first["flags"] == 1).all()
+    # the END of the stream as well (offsets beyond 4 GiB when n is large): record table and gathered strings against the blob
+    k = min(n, 65536)
+    lastr = b.kseq_records(n - k, k)
+    assert (lastr["hdr_off"] == cols["name_off"][n - k:]).all() and (lastr["seq_cum"] == 150 * np.arange(n - k, n)).all()
+    sq, ql = b.kseq_fetch(n - k, k, 150 * k)
+    so, qo, rec = int(cols["soff"][0]), int(cols["qoff"][0]), cols["rec"]
+    v = blob_t[:cols["n_bytes"]].view(n, rec)[n - k:]
+    assert bytes(sq) == v[:, so:so + 150].contiguous().cpu().numpy().tobytes() and bytes(ql) == v[:, qo:qo + 150].contiguous().cpu().numpy().tobytes()
+    r["tail_records_and_strings_equal_the_blob"] = True
     res.append(r)
     b.close(); del blob_t
     torch.cuda.empty_cache()
