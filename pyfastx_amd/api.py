@@ -1326,8 +1326,7 @@ class Read(_fxobj.ReadCore):
     (csrc/fxobj.c: ReadCore, constructed as Read(fq, id, name, dlen, rlen, soff, qoff)); the objects of Fastq's iterator are
     made a batch at a time by _fxobj.read_batch and carry their sequence and quality strings (_pre_seq / _pre_qual)."""
 
-    def __len__(self):
-        return self._read_len
+    __slots__ = ()                                            # no instance dict: the objects stay out of the cyclic GC's lists
 
     def __repr__(self):
         return "<Read> %s with length of %d" % (self.name, self._read_len)                     # read.c:280-282
@@ -1338,16 +1337,11 @@ class Read(_fxobj.ReadCore):
     def _bytes(self, off, n):
         return self._fq._st.raw(off, n)
 
-    @property
-    def seq(self):
-        if self._pre_seq is not None:
-            return self._pre_seq                                                               # came with the iterator's batch
+    # .seq, .qual and len() are the C base type's: the strings that came with the iterator's batch, else these
+    def _seq_slow(self):
         return _decode(self._bytes(self._soff, self._read_len))                                # read.c:152-167
 
-    @property
-    def qual(self):
-        if self._pre_qual is not None:
-            return self._pre_qual
+    def _qual_slow(self):
         return _decode(self._bytes(self._qoff, self._read_len))                                # read.c:237-249
 
     @property

@@ -471,9 +471,20 @@ static PyMemberDef read_members[] = {
     {"_pre_seq", T_OBJECT, offsetof(ReadCore, pre_seq), READONLY, "the sequence, when it came with the iterator's batch (else None)"},
     {"_pre_qual", T_OBJECT, offsetof(ReadCore, pre_qual), READONLY, "the quality string, likewise"},
     {NULL, 0, 0, 0, NULL}};
+/* .seq / .qual: the string that came with the iterator's batch, else the subclass's _seq_slow() / _qual_slow() (one fetch) */
+static PyObject *read_get_seq(ReadCore *r, void *c) { (void)c; return r->pre_seq ? Py_NewRef(r->pre_seq) : PyObject_CallMethod((PyObject *)r, "_seq_slow", NULL); }
+static PyObject *read_get_qual(ReadCore *r, void *c) { (void)c; return r->pre_qual ? Py_NewRef(r->pre_qual) : PyObject_CallMethod((PyObject *)r, "_qual_slow", NULL); }
+static PyGetSetDef read_getset[] = {
+    {"seq", (getter)read_get_seq, NULL, "read.c:152-167", NULL},
+    {"qual", (getter)read_get_qual, NULL, "read.c:237-249", NULL},
+    {NULL, NULL, NULL, NULL, NULL}};
+static Py_ssize_t read_length(ReadCore *r) { return (Py_ssize_t)r->read_len; }
+static PySequenceMethods read_as_sequence = {.sq_length = (lenfunc)read_length};
 static PyTypeObject ReadCoreType = {
     PyVarObject_HEAD_INIT(NULL, 0)
     .tp_name = "pyfastx_amd._fxobj.ReadCore",
+    .tp_getset = read_getset,
+    .tp_as_sequence = &read_as_sequence,
     .tp_basicsize = sizeof(ReadCore),
     .tp_dealloc = (destructor)read_dealloc,
     .tp_flags = Py_TPFLAGS_DEFAULT | Py_TPFLAGS_BASETYPE,
@@ -510,7 +521,10 @@ static PyObject *mod_read_batch(PyObject *m, PyObject *args)
         if (!r) { Py_CLEAR(out); break; }
         PyList_SET_ITEM(out, i, (PyObject *)r);
         r->fq = Py_NewRef(fq);
-        r->name = Py_NewRef(PyTuple_GET_ITEM(row, 1));
+        {   /* the name: a str, or the column's bytes (SELECT CAST(name AS BLOB): no text_factory call per row) decoded as fxi.connect does */
+            PyObject *nm = PyTuple_GET_ITEM(row, 1);
+            r->name = PyBytes_Check(nm) ? PyUnicode_DecodeUTF8(PyBytes_AS_STRING(nm), PyBytes_GET_SIZE(nm), "surrogateescape") : Py_NewRef(nm);
+        }
         r->id = PyLong_AsLongLong(PyTuple_GET_ITEM(row, 0));
         r->desc_len = PyLong_AsLongLong(PyTuple_GET_ITEM(row, 2));
         r->read_len = PyLong_AsLongLong(PyTuple_GET_ITEM(row, 3));
@@ -518,7 +532,7 @@ static PyObject *mod_read_batch(PyObject *m, PyObject *args)
         r->qoff = PyLong_AsLongLong(PyTuple_GET_ITEM(row, 5));
         r->pre_seq = PyUnicode_DecodeLatin1((const char *)seq.buf + o[i], (Py_ssize_t)(o[i + 1] - o[i]), NULL);
         r->pre_qual = PyUnicode_DecodeLatin1((const char *)qual.buf + o[i], (Py_ssize_t)(o[i + 1] - o[i]), NULL);
-        if (PyErr_Occurred() || !r->pre_seq || !r->pre_qual) { Py_CLEAR(out); break; }
+        if (PyErr_Occurred() || !r->name || !r->pre_seq || !r->pre_qual) { Py_CLEAR(out); break; }
     }
 done:
     PyBuffer_Release(&seq); PyBuffer_Release(&qual); PyBuffer_Release(&offs);
