@@ -1192,8 +1192,26 @@ class Fastq:
         return self._iter_indexed()
 
     def _iter_indexed(self):
+        # sequence and quality lines of 16384 reads per gather ride along in the Read objects.  The rows of the
+        # `read` table are stepped from C (_fxobj.RowCursor: sqlite3_step / sqlite3_column_* as fastq.c:566-596 does, a
+        # read-only connection of its own through the library the sqlite3 module has loaded) and the objects of a batch made
+        # by one call; when that connection cannot be had (an index another connection holds exclusively), the sqlite3
+        # module's rows do the same, more slowly.
+        batch = None
+        try:
+            cur = _fxobj.RowCursor(self._index_file, "SELECT ID, name, dlen, rlen, soff, qoff FROM read ORDER BY ID")
+            batch = cur.fetch(16384)
+        except RuntimeError:
+            cur = None
+        if cur is not None:
+            while batch is not None:
+                k, names, raw = batch
+                cols = np.frombuffer(raw, dtype=np.int64).reshape(5, k)                     # ID, dlen, rlen, soff, qoff
+                seq, qual, _, offs = self._st.blob.read_fetch(cols[3], cols[4], cols[2], want=("seq", "qual"))
+                yield from _fxobj.read_batch_cols(Read, self, names, raw, seq, qual, offs)
+                batch = cur.fetch(16384)
+            return
         if True:
-            # sequence and quality lines of 16384 reads per gather ride along in the Read objects
             cur = self._db.execute("SELECT * FROM read ORDER BY ID")
             while True:
                 rows = cur.fetchmany(16384)

@@ -24,6 +24,8 @@
 #include <structmember.h>
 #include <stdint.h>
 #include <time.h>
+#include <dlfcn.h>
+#include <string.h>
 
 typedef int (*fetch_one_fn)(void *h, int64_t off, int64_t blen, int64_t skip, int64_t take, int flags, uint8_t *dst, int64_t *out_len);
 static fetch_one_fn g_fetch_one = NULL;
@@ -539,7 +541,166 @@ done:
     return out;
 }
 
+/* ------------------------------------------------------------------ RowCursor: a table of the index file stepped from C
+ * The reference iterates an indexed file with sqlite3_step + sqlite3_column_* per record (fastq.c:566-596, index.c:525-560);
+ * through Python's sqlite3 module every row becomes a tuple of Python objects first (0.5-0.9 us per row).  This cursor opens
+ * its own READ-ONLY connection to the index file through the SAME library the sqlite3 module has loaded (dlopen: no build
+ * dependency) and hands out a batch of rows as one list of names + one block of int64 columns.
+ *   RowCursor(path, sql)   sql: first column an integer, second a TEXT, the others integers
+ *   .fetch(n) -> None at the end, else (k, names, cols): cols = bytes of (ncol - 1) x k int64, column after column  */
+typedef struct sqlite3 sqlite3;
+typedef struct sqlite3_stmt sqlite3_stmt;
+static struct {
+    int state;                                                   /* 0 not tried, 1 loaded, -1 not there */
+    int (*open_v2)(const char *, sqlite3 **, int, const char *);
+    int (*close_v2)(sqlite3 *);
+    int (*prepare_v2)(sqlite3 *, const char *, int, sqlite3_stmt **, const char **);
+    int (*step)(sqlite3_stmt *);
+    int (*finalize)(sqlite3_stmt *);
+    int (*column_count)(sqlite3_stmt *);
+    long long (*column_int64)(sqlite3_stmt *, int);
+    const unsigned char *(*column_text)(sqlite3_stmt *, int);
+    int (*column_bytes)(sqlite3_stmt *, int);
+    const char *(*errmsg)(sqlite3 *);
+    int (*busy_timeout)(sqlite3 *, int);
+} SQ;
+static int sq_load(void)
+{
+    void *h;
+    if (SQ.state) return SQ.state > 0;
+    SQ.state = -1;
+    h = dlopen("libsqlite3.so.0", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libsqlite3.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return 0;
+#define SQ_SYM(field, name) do { *(void **)&SQ.field = dlsym(h, name); if (!SQ.field) return 0; } while (0)
+    SQ_SYM(open_v2, "sqlite3_open_v2"); SQ_SYM(close_v2, "sqlite3_close_v2"); SQ_SYM(prepare_v2, "sqlite3_prepare_v2");
+    SQ_SYM(step, "sqlite3_step"); SQ_SYM(finalize, "sqlite3_finalize"); SQ_SYM(column_count, "sqlite3_column_count");
+    SQ_SYM(column_int64, "sqlite3_column_int64"); SQ_SYM(column_text, "sqlite3_column_text"); SQ_SYM(column_bytes, "sqlite3_column_bytes");
+    SQ_SYM(errmsg, "sqlite3_errmsg"); SQ_SYM(busy_timeout, "sqlite3_busy_timeout");
+#undef SQ_SYM
+    SQ.state = 1;
+    return 1;
+}
+typedef struct { PyObject_HEAD sqlite3 *db; sqlite3_stmt *st; int ncol, done; } RowCursor;
+static void rc_close(RowCursor *c)
+{
+    if (c->st) { SQ.finalize(c->st); c->st = NULL; }
+    if (c->db) { SQ.close_v2(c->db); c->db = NULL; }
+}
+static void rc_dealloc(RowCursor *c) { rc_close(c); Py_TYPE(c)->tp_free((PyObject *)c); }
+static PyObject *rc_new(PyTypeObject *type, PyObject *args, PyObject *kw)
+{
+    const char *path, *sql;
+    RowCursor *c;
+    (void)kw;
+    if (!PyArg_ParseTuple(args, "ss", &path, &sql)) return NULL;
+    if (!sq_load()) { PyErr_SetString(PyExc_RuntimeError, "libsqlite3 could not be loaded"); return NULL; }
+    c = (RowCursor *)type->tp_alloc(type, 0);
+    if (!c) return NULL;
+    c->db = NULL; c->st = NULL; c->done = 0;
+    if (SQ.open_v2(path, &c->db, 1 /* SQLITE_OPEN_READONLY */, NULL) != 0 || SQ.prepare_v2(c->db, sql, -1, &c->st, NULL) != 0) {
+        PyErr_Format(PyExc_RuntimeError, "RowCursor: %s", c->db ? SQ.errmsg(c->db) : "cannot open the index file");
+        rc_close(c);
+        Py_DECREF(c);
+        return NULL;
+    }
+    c->ncol = SQ.column_count(c->st);
+    if (c->ncol < 2) { PyErr_SetString(PyExc_ValueError, "RowCursor: the statement must yield an integer, a text and integers"); rc_close(c); Py_DECREF(c); return NULL; }
+    return (PyObject *)c;
+}
+static PyObject *rc_fetch(RowCursor *c, PyObject *arg)
+{
+    Py_ssize_t n = PyLong_AsSsize_t(arg), k = 0;
+    const int ni = c->ncol - 1;
+    PyObject *names, *cols, *out;
+    long long *v;
+    int j;
+    if (n <= 0) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "fetch(n): n > 0"); return NULL; }
+    if (c->done || !c->st) Py_RETURN_NONE;
+    names = PyList_New(n);
+    cols = PyBytes_FromStringAndSize(NULL, (Py_ssize_t)ni * n * 8);
+    if (!names || !cols) { Py_XDECREF(names); Py_XDECREF(cols); return NULL; }
+    v = (long long *)PyBytes_AS_STRING(cols);
+    while (k < n) {
+        const int rc = SQ.step(c->st);
+        PyObject *nm;
+        if (rc == 101 /* SQLITE_DONE */) { c->done = 1; break; }
+        if (rc != 100 /* SQLITE_ROW */) {
+            PyErr_Format(PyExc_RuntimeError, "RowCursor: %s (code %d)", SQ.errmsg(c->db), rc);
+            Py_DECREF(names); Py_DECREF(cols);
+            return NULL;
+        }
+        v[k] = SQ.column_int64(c->st, 0);
+        for (j = 2; j < c->ncol; ++j) v[(Py_ssize_t)(j - 1) * n + k] = SQ.column_int64(c->st, j);
+        {
+            const unsigned char *t = SQ.column_text(c->st, 1);
+            nm = PyUnicode_DecodeUTF8(t ? (const char *)t : "", t ? SQ.column_bytes(c->st, 1) : 0, "surrogateescape");   /* as fxi.connect's text_factory */
+        }
+        if (!nm) { Py_DECREF(names); Py_DECREF(cols); return NULL; }
+        PyList_SET_ITEM(names, k, nm);
+        ++k;
+    }
+    if (k == 0) { Py_DECREF(names); Py_DECREF(cols); Py_RETURN_NONE; }
+    if (k < n) {                                                 /* the last, short batch: the columns move together */
+        PyObject *c2 = PyBytes_FromStringAndSize(NULL, (Py_ssize_t)ni * k * 8);
+        if (!c2 || PyList_SetSlice(names, k, n, NULL) < 0) { Py_XDECREF(c2); Py_DECREF(names); Py_DECREF(cols); return NULL; }
+        for (j = 0; j < ni; ++j) memcpy(PyBytes_AS_STRING(c2) + (Py_ssize_t)j * k * 8, v + (Py_ssize_t)j * n, (size_t)k * 8);
+        Py_DECREF(cols);
+        cols = c2;
+    }
+    out = Py_BuildValue("(nNN)", k, names, cols);
+    return out;
+}
+static PyMethodDef rc_methods[] = {
+    {"fetch", (PyCFunction)rc_fetch, METH_O, "fetch(n) -> None | (k, names, int64 columns as bytes)"},
+    {NULL, NULL, 0, NULL}};
+static PyTypeObject RowCursorType = {
+    PyVarObject_HEAD_INIT(NULL, 0)
+    .tp_name = "pyfastx_amd._fxobj.RowCursor",
+    .tp_basicsize = sizeof(RowCursor),
+    .tp_dealloc = (destructor)rc_dealloc,
+    .tp_flags = Py_TPFLAGS_DEFAULT,
+    .tp_methods = rc_methods,
+    .tp_new = rc_new,
+};
+
+/* read_batch_cols(ReadType, fq, names, cols, seq, qual, offs) -> list: the same objects as read_batch from a RowCursor batch of
+ * "SELECT ID, name, dlen, rlen, soff, qoff FROM read" (cols: ID, dlen, rlen, soff, qoff -- k int64 each) */
+static PyObject *mod_read_batch_cols(PyObject *m, PyObject *args)
+{
+    PyObject *type, *fq, *names, *out = NULL;
+    Py_buffer cols, seq, qual, offs;
+    Py_ssize_t k, i;
+    (void)m;
+    if (!PyArg_ParseTuple(args, "OOO!y*y*y*y*", &type, &fq, &PyList_Type, &names, &cols, &seq, &qual, &offs)) return NULL;
+    k = PyList_GET_SIZE(names);
+    if (!PyType_Check(type) || !PyType_IsSubtype((PyTypeObject *)type, &ReadCoreType) || cols.len < 5 * k * 8 || offs.len < (k + 1) * 8) {
+        PyErr_SetString(PyExc_TypeError, "read_batch_cols(ReadCore subtype, fq, names, 5 x k int64, seq, qual, int64 offsets[k + 1])");
+        goto done;
+    }
+    out = PyList_New(k);
+    for (i = 0; out && i < k; ++i) {
+        const long long *v = (const long long *)cols.buf;
+        const int64_t *o = (const int64_t *)offs.buf;
+        ReadCore *r;
+        if (o[i] < 0 || o[i + 1] < o[i] || o[i + 1] > seq.len || o[i + 1] > qual.len) { PyErr_SetString(PyExc_ValueError, "bad offsets"); Py_CLEAR(out); break; }
+        r = (ReadCore *)((PyTypeObject *)type)->tp_alloc((PyTypeObject *)type, 0);
+        if (!r) { Py_CLEAR(out); break; }
+        PyList_SET_ITEM(out, i, (PyObject *)r);
+        r->fq = Py_NewRef(fq);
+        r->name = Py_NewRef(PyList_GET_ITEM(names, i));
+        r->id = v[i]; r->desc_len = v[k + i]; r->read_len = v[2 * k + i]; r->soff = v[3 * k + i]; r->qoff = v[4 * k + i];
+        r->pre_seq = PyUnicode_DecodeLatin1((const char *)seq.buf + o[i], (Py_ssize_t)(o[i + 1] - o[i]), NULL);
+        r->pre_qual = PyUnicode_DecodeLatin1((const char *)qual.buf + o[i], (Py_ssize_t)(o[i + 1] - o[i]), NULL);
+        if (!r->pre_seq || !r->pre_qual) { Py_CLEAR(out); break; }
+    }
+done:
+    PyBuffer_Release(&cols); PyBuffer_Release(&seq); PyBuffer_Release(&qual); PyBuffer_Release(&offs);
+    return out;
+}
+
 static PyMethodDef mod_methods[] = {
+    {"read_batch_cols", mod_read_batch_cols, METH_VARARGS, "read_batch_cols(ReadType, fq, names, cols, seq, qual, offs) -> list of Read objects"},
     {"read_batch", mod_read_batch, METH_VARARGS, "read_batch(ReadType, fq, rows, seq, qual, offs) -> list of Read objects with their strings"},
     {"fastx_batch", mod_fastx_batch, METH_VARARGS, "fastx_batch(hdr, hdr_off, seq, qual, recs, fastq, with_comment, state) -> list of tuples"},
     {"set_api", mod_set_api, METH_VARARGS, "set_api(address of fx_fetch_one, Sequence type)"},
@@ -550,7 +711,7 @@ static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_fxobj", "C base typ
 PyMODINIT_FUNC PyInit__fxobj(void)
 {
     PyObject *m;
-    if (PyType_Ready(&SeqCoreType) < 0 || PyType_Ready(&FastaCoreType) < 0 || PyType_Ready(&FastxIterType) < 0 || PyType_Ready(&ReadCoreType) < 0) return NULL;
+    if (PyType_Ready(&SeqCoreType) < 0 || PyType_Ready(&FastaCoreType) < 0 || PyType_Ready(&FastxIterType) < 0 || PyType_Ready(&ReadCoreType) < 0 || PyType_Ready(&RowCursorType) < 0) return NULL;
     m = PyModule_Create(&moddef);
     if (!m) return NULL;
     Py_INCREF(&SeqCoreType); Py_INCREF(&FastaCoreType);
@@ -560,5 +721,7 @@ PyMODINIT_FUNC PyInit__fxobj(void)
     PyModule_AddObject(m, "FastxIter", (PyObject *)&FastxIterType);
     Py_INCREF(&ReadCoreType);
     PyModule_AddObject(m, "ReadCore", (PyObject *)&ReadCoreType);
+    Py_INCREF(&RowCursorType);
+    PyModule_AddObject(m, "RowCursor", (PyObject *)&RowCursorType);
     return m;
 }

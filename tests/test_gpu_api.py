@@ -403,6 +403,28 @@ def test_iteration_rides_on_batched_fetches(fx, files, tmp_path, oracle):
             assert r.quali == [c - 33 for c in rawq[qo:qo + m]] and r.antisense == oracle.revcomp(rawq[so:so + m], 3).decode()
         n += 1
     assert n == len(rq)
+    # the rows come from a cursor stepped in C (_fxobj.RowCursor); when it cannot have its connection -- here: another
+    # connection holds the index file exclusively -- the sqlite3 module's rows give the same objects
+    import sqlite3
+    first = [(r.id, r.name, r.seq, r.qual, r.description, len(r)) for r in fq]
+    lock = sqlite3.connect(files["test.fq"] + ".fxi", isolation_level=None)
+    lock.execute("PRAGMA locking_mode=EXCLUSIVE")
+    lock.execute("BEGIN EXCLUSIVE")
+    try:
+        from pyfastx_amd import _fxobj
+        with pytest.raises(RuntimeError):
+            _fxobj.RowCursor(files["test.fq"] + ".fxi", "SELECT ID, name, dlen, rlen, soff, qoff FROM read ORDER BY ID").fetch(10)
+    finally:
+        lock.execute("COMMIT")
+        lock.close()
+    real = _fxobj.RowCursor
+    try:
+        def refuse(*a):
+            raise RuntimeError("no connection")
+        _fxobj.RowCursor = refuse
+        assert [(r.id, r.name, r.seq, r.qual, r.description, len(r)) for r in fq] == first
+    finally:
+        _fxobj.RowCursor = real
 
 
 def test_fetch_many_equals_slices_on_odd_line_records(fx, tmp_path):

@@ -956,6 +956,47 @@ def test_fastx_batch_builds_the_reference_tuples(oracle):
             assert iter(it) is it and list(it) == want and list(it) == []
 
 
+def test_row_cursor_and_read_batch_cols(tmp_path):
+    """_fxobj.RowCursor (the `read` table stepped from C through the library the sqlite3 module has loaded) against the
+    sqlite3 module's rows: batches, the short last batch, names that are not valid UTF-8, an exclusive lock held by another
+    connection (RuntimeError: the caller falls back); read_batch_cols makes the same objects as read_batch."""
+    import sqlite3
+    from pyfastx_amd import _fxobj, api, fxi
+    p = str(tmp_path / "t.fxi")
+    db = fxi.connect(p)
+    db.execute("CREATE TABLE read (ID INTEGER PRIMARY KEY, name TEXT, dlen INTEGER, rlen INTEGER, soff INTEGER, qoff INTEGER)")
+    n = 2500
+    names = [b"r%d" % i if i % 7 else b"bad\xff\xfe%d" % i for i in range(n)]
+    db.executemany("INSERT INTO read VALUES (?, CAST(? AS TEXT), ?, ?, ?, ?)",
+                   [(i + 1, names[i], 10 + i % 3, 3, (1 << 33) + 40 * i, (1 << 33) + 40 * i + 20) for i in range(n)])
+    want = db.execute("SELECT * FROM read ORDER BY ID").fetchall()
+    sql = "SELECT ID, name, dlen, rlen, soff, qoff FROM read ORDER BY ID"
+    cur = _fxobj.RowCursor(p, sql)
+    got, objs = [], []
+    seq = np.frombuffer(b"ACG" * 1024, dtype=np.uint8)
+    while True:
+        b = cur.fetch(1024)
+        if b is None:
+            break
+        k, nm, raw = b
+        cols = np.frombuffer(raw, dtype=np.int64).reshape(5, k)
+        got += [(int(cols[0, i]), nm[i]) + tuple(int(cols[j, i]) for j in range(1, 5)) for i in range(k)]
+        offs = np.arange(k + 1, dtype=np.int64) * 3
+        a = _fxobj.read_batch_cols(api.Read, "fq", nm, raw, seq, seq, offs)
+        b2 = _fxobj.read_batch(api.Read, "fq", want[len(objs):len(objs) + k], seq, seq, offs)
+        assert [(x.id, x.name, x._desc_len, x._read_len, x._soff, x._qoff, x.seq, x.qual, len(x)) for x in a] == \
+               [(x.id, x.name, x._desc_len, x._read_len, x._soff, x._qoff, x.seq, x.qual, len(x)) for x in b2]
+        objs += a
+    assert got == want and len(objs) == n and cur.fetch(5) is None
+    lock = sqlite3.connect(p, isolation_level=None)
+    lock.execute("BEGIN EXCLUSIVE")
+    with pytest.raises(RuntimeError):
+        _fxobj.RowCursor(p, sql).fetch(1)
+    lock.execute("COMMIT")
+    with pytest.raises(RuntimeError):
+        _fxobj.RowCursor(str(tmp_path / "none" / "x.fxi"), sql)
+
+
 def test_kseq_line_model_equals_the_oracle(oracle):
     """tools/kseq_line_model.py -- the executable model k_kq_walk (fx_kseq.hpp) transliterates: kseq_read over a line
     table with its two 64-line steps and the parallel passes over the regular prefix -- against the byte-level oracle, with and
