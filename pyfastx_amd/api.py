@@ -370,13 +370,41 @@ class Fasta(_fxobj.FastaCore):
         return self._iter_indexed()
 
     def _iter_indexed(self):
-        if True:                                              # fasta.c:146-172 -> Sequence objects in file order
-            self._need_index()
-            # the sequences of the records ahead come off the GPU in batches (one gather per ~64 MB of
-            # bases or 4096 records) and ride along in the Sequence objects; `.seq` of an object taken from the iterator
-            # costs nothing more.  A record larger than a batch is fetched when (and if) it is asked for.
+        # fasta.c:146-172 -> Sequence objects in file order.  SURVEY 8f-3: the sequences of the records ahead come off the GPU
+        # in batches (one gather per ~64 MB of bases or 4096 records) and ride along in the Sequence objects; `.seq` of an
+        # object taken from the iterator costs nothing more.  A record larger than a batch is fetched when (and if) it is
+        # asked for.  The rows of the `seq` table are stepped from C (_fxobj.RowCursor, as index.c:525-560 steps them) and the
+        # objects of a batch made by one call; without that connection (a memory index, a locked file) the sqlite3 module's
+        # rows do the same, more slowly.
+        self._need_index()
+        fl = _F_UP if self._uppercase else 0
+        batch = None
+        try:
+            cur = _fxobj.RowCursor(self._index_file, "SELECT ID, chrom, boff, blen, slen, llen, elen, norm, dlen FROM seq ORDER BY ID")
+            batch = cur.fetch(4096)
+        except RuntimeError:
+            cur = None
+        if cur is not None:
+            none8, none64 = np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.int64)
+            while batch is not None:
+                k, names, raw = batch
+                cols = np.frombuffer(raw, dtype=np.int64).reshape(8, k)                     # ID, boff, blen, slen, llen, elen, norm, dlen
+                slen = np.maximum(cols[3], 0)
+                i = 0
+                while i < k:
+                    j = i + max(1, int(np.searchsorted(np.cumsum(slen[i:]), _ITER_BATCH_BASES, side="right")))
+                    sel = np.nonzero((slen[i:j] > 0) & (slen[i:j] <= _ITER_BATCH_BASES))[0].astype(np.int64)
+                    if sel.size:
+                        buf, offs, ol = self._st.blob.fetch_ranges(cols[1, i:j][sel], cols[2, i:j][sel], slen[i:j][sel], flags=fl)
+                    else:
+                        buf, offs, ol = none8, none64, none64
+                    yield from _fxobj.seq_batch_cols(Sequence, self, names[i:j], np.ascontiguousarray(cols[:, i:j]), buf,
+                                                     np.ascontiguousarray(offs[:sel.size]), np.ascontiguousarray(ol), sel)
+                    i = j
+                batch = cur.fetch(4096)
+            return
+        if True:
             rows = self._db.execute("SELECT * FROM seq ORDER BY ID").fetchall()
-            fl = _F_UP if self._uppercase else 0
             i, n = 0, len(rows)
             while i < n:
                 j, tot = i, 0

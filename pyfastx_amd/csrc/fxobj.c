@@ -43,6 +43,7 @@ typedef struct {
 typedef struct {
     PyObject_HEAD
     PyObject *fa, *name;
+    PyObject *pre;                               /* the whole sequence, when it came with the iterator's batch (Fasta.__iter__) */
     long long id, offset, byte_len, full_len, line_len, end_len, normal, desc_len, start, end, seq_len;
     char complete;
     signed char reg;                             /* line-regular: -1 not known yet, 0, 1 */
@@ -55,6 +56,7 @@ static void seq_dealloc(SeqCore *s)
 {
     Py_XDECREF(s->fa);
     Py_XDECREF(s->name);
+    Py_XDECREF(s->pre);
     Py_TYPE(s)->tp_free((PyObject *)s);
 }
 
@@ -119,6 +121,7 @@ static PyObject *seq_fast(SeqCore *s, int flags)
 static PyObject *seq_get(SeqCore *s, int flags)
 {
     PyObject *r;
+    if (flags == 0 && s->complete && s->pre) return Py_NewRef(s->pre);     /* came with the iterator's batch */
     if (s->reg < 0 && !s->complete && s->seq_len > 0) {                   /* ask the Python side once per object (it caches per record) */
         PyObject *v = PyObject_CallMethod((PyObject *)s, "_line_regular", NULL);
         if (!v) return NULL;
@@ -156,7 +159,7 @@ static PyMemberDef seq_members[] = {
     {"_normal", T_LONGLONG, offsetof(SeqCore, normal), 0, NULL}, {"_desc_len", T_LONGLONG, offsetof(SeqCore, desc_len), 0, NULL},
     {"start", T_LONGLONG, offsetof(SeqCore, start), 0, NULL}, {"end", T_LONGLONG, offsetof(SeqCore, end), 0, NULL},
     {"_seq_len", T_LONGLONG, offsetof(SeqCore, seq_len), 0, NULL}, {"_complete", T_BOOL, offsetof(SeqCore, complete), 0, NULL},
-    {"_reg", T_BYTE, offsetof(SeqCore, reg), 0, NULL}, {NULL, 0, 0, 0, NULL}};
+    {"_reg", T_BYTE, offsetof(SeqCore, reg), 0, NULL}, {"_prefetched", T_OBJECT, offsetof(SeqCore, pre), 0, NULL}, {NULL, 0, 0, 0, NULL}};
 static PyGetSetDef seq_getset[] = {
     {"seq", (getter)seq_seq, NULL, NULL, NULL}, {"reverse", (getter)seq_reverse, NULL, NULL, NULL},
     {"complement", (getter)seq_complement, NULL, NULL, NULL}, {"antisense", (getter)seq_antisense, NULL, NULL, NULL},
@@ -699,7 +702,50 @@ done:
     return out;
 }
 
+/* seq_batch_cols(SeqType, fa, names, cols, buf, offs, lens, sel) -> list of Sequence objects: a RowCursor batch of
+ * "SELECT ID, chrom, boff, blen, slen, llen, elen, norm, dlen FROM seq" (cols: those 8 integers, k each); the whole sequences
+ * of the records sel[t] lie at buf[offs[t] : offs[t] + lens[t]] (one gather for the batch) and ride along in the objects */
+static PyObject *mod_seq_batch_cols(PyObject *m, PyObject *args)
+{
+    PyObject *type, *fa, *names, *out = NULL;
+    Py_buffer cols, buf, offs, lens, sel;
+    Py_ssize_t k, i, nsel;
+    (void)m;
+    if (!PyArg_ParseTuple(args, "OOO!y*y*y*y*y*", &type, &fa, &PyList_Type, &names, &cols, &buf, &offs, &lens, &sel)) return NULL;
+    k = PyList_GET_SIZE(names);
+    nsel = sel.len / 8;
+    if (!PyType_Check(type) || !PyType_IsSubtype((PyTypeObject *)type, &SeqCoreType) || cols.len < 8 * k * 8 || offs.len < nsel * 8 || lens.len < nsel * 8) {
+        PyErr_SetString(PyExc_TypeError, "seq_batch_cols(SeqCore subtype, fa, names, 8 x k int64, buf, offs, lens, sel)");
+        goto done;
+    }
+    out = PyList_New(k);
+    for (i = 0; out && i < k; ++i) {
+        const long long *v = (const long long *)cols.buf;
+        SeqCore *q = (SeqCore *)((PyTypeObject *)type)->tp_alloc((PyTypeObject *)type, 0);
+        if (!q) { Py_CLEAR(out); break; }
+        PyList_SET_ITEM(out, i, (PyObject *)q);
+        q->fa = Py_NewRef(fa);
+        q->name = Py_NewRef(PyList_GET_ITEM(names, i));
+        q->pre = NULL;
+        q->id = v[i]; q->offset = v[k + i]; q->byte_len = v[2 * k + i]; q->full_len = v[3 * k + i];
+        q->line_len = v[4 * k + i]; q->end_len = v[5 * k + i]; q->normal = v[6 * k + i]; q->desc_len = v[7 * k + i];
+        q->start = 1; q->end = q->full_len; q->seq_len = q->full_len; q->complete = 1; q->reg = -1;
+    }
+    for (i = 0; out && i < nsel; ++i) {
+        const int64_t t = ((const int64_t *)sel.buf)[i], o = ((const int64_t *)offs.buf)[i], l = ((const int64_t *)lens.buf)[i];
+        SeqCore *q;
+        if (t < 0 || t >= k || o < 0 || l < 0 || o + l > buf.len) { PyErr_SetString(PyExc_ValueError, "bad selection or offsets"); Py_CLEAR(out); break; }
+        q = (SeqCore *)PyList_GET_ITEM(out, t);
+        q->pre = PyUnicode_DecodeLatin1((const char *)buf.buf + o, (Py_ssize_t)l, NULL);
+        if (!q->pre) { Py_CLEAR(out); break; }
+    }
+done:
+    PyBuffer_Release(&cols); PyBuffer_Release(&buf); PyBuffer_Release(&offs); PyBuffer_Release(&lens); PyBuffer_Release(&sel);
+    return out;
+}
+
 static PyMethodDef mod_methods[] = {
+    {"seq_batch_cols", mod_seq_batch_cols, METH_VARARGS, "seq_batch_cols(SeqType, fa, names, cols, buf, offs, lens, sel) -> list of Sequence objects"},
     {"read_batch_cols", mod_read_batch_cols, METH_VARARGS, "read_batch_cols(ReadType, fq, names, cols, seq, qual, offs) -> list of Read objects"},
     {"read_batch", mod_read_batch, METH_VARARGS, "read_batch(ReadType, fq, rows, seq, qual, offs) -> list of Read objects with their strings"},
     {"fastx_batch", mod_fastx_batch, METH_VARARGS, "fastx_batch(hdr, hdr_off, seq, qual, recs, fastq, with_comment, state) -> list of tuples"},

@@ -364,6 +364,10 @@ def test_iteration_rides_on_batched_fetches(fx, files, tmp_path, oracle):
     assert seen == len(recs)
     up = fx.Fasta(files["test.fa"], uppercase=True)
     assert [s.seq for s in up][:5] == [fa[i].seq.upper() for i in range(5)]
+    # the rows of an index file are stepped from C (_fxobj.RowCursor) and the objects of a batch made by one call; a memory
+    # index has no file to open a second connection to: the sqlite3 module's rows give the same objects
+    mem = fx.Fasta(files["test.fa"], index_file=files["test.fa"] + ".unused", memory_index=True)
+    assert [(s.id, s.name, s.seq, s.start, s.end, len(s)) for s in mem] == [(s.id, s.name, s.seq, s.start, s.end, len(s)) for s in fa]
     # one odd line in the middle, one long last line, an empty record, a record with no trailing newline
     odd = tmp_path / "odd.fa"
     text = b">a\nACGTACGT\nAC\nGGGGTTTT\nCCCCAAAA\n>b\nACGT\nACGTACGTAC\n>e\n>c\nTTTTGGGG\nTTTTGG"
