@@ -92,6 +92,16 @@ int fx_close(fx_handle *h);
  * in a per-process pool for the next open (FX_SCRATCH_CACHE_MB, default 4096; the library empties it by itself before a
  * device allocation fails).  This gives the idle blocks back to the driver now. */
 int fx_release_scratch(void);
+/* Pinned (page-locked) host memory out of a per-process pool, for the arrays a caller hands to the batched entry
+ * points with FX_HOST: answers land in it by DMA -- no bounce buffer, no first-touch page faults of a fresh buffer
+ * (what the copy out of pyfastx_index_fill_cache's cache costs the reference per getter, sequence.c:346-347, is paid
+ * here once per batch) -- and query arrays in it go up without a staging copy.  Released blocks stay pinned for the
+ * next request of a similar size (FX_PINNED_CACHE_MB, default 2048; fx_pinned_trim gives them back).
+ * fx_pinned_holds: does [p, p + bytes) lie inside one block that is handed out? */
+void *fx_pinned_alloc(int64_t bytes);
+void fx_pinned_free(void *p);
+int fx_pinned_holds(const void *p, int64_t bytes);
+int fx_pinned_trim(void);
 int64_t fx_size(const fx_handle *h);          /* uncompressed bytes held          */
 int fx_is_gzip(const fx_handle *h);           /* is_gzip_format, util.c:307-325   */
 const void *fx_device_ptr(const fx_handle *h);/* device address of the blob       */
@@ -234,12 +244,30 @@ int fx_fasta_fetch(fx_handle *h, int where, int64_t n,
                    int flags, const uint8_t *flags_per_query,
                    uint8_t *dst, const int64_t *dst_off, int64_t *out_len);
 
+/* The same batch from host arrays with the layout left to the library -- the loop of the reference's benchmark
+ * (benchmark/pyfastx_fasta_extract_subsequences.py:8-12: fa[name][s:e].seq per interval; pyfastx_sequence_subscript
+ * sequence.c:412-517 + pyfastx_sequence_get_subseq sequence.c:76-125 per call) as ONE call: the intervals are checked on
+ * the device against the resident table (first invalid one -> *first_bad, FX_ERANGE), the answers are laid out back to
+ * back (offsets by a device scan) and come home by DMA into pinned memory of fx_pinned_alloc: *dst (the bytes) and
+ * *dst_off (n + 1 offsets) belong to the caller, who gives them back with fx_pinned_free. */
+int fx_fasta_fetch_alloc(fx_handle *h, int64_t n, const int64_t *seq_id, const int64_t *start, const int64_t *stop,
+                         int flags, const uint8_t *flags_per_query, uint8_t **dst, int64_t **dst_off, int64_t *first_bad);
+/* Where the last fx_*_fetch_alloc call of this thread spent its time on the host, in milliseconds (measurement aid): ms[0]
+ * query arrays staged + uploads enqueued, [1] counts, scan, offsets back (first wait), [2] pinned blocks, [3] kernels
+ * enqueued, [4] answers back (second wait), [5] the whole call. */
+int fx_fetch_phases(double *ms, int cap);
+
 /* FASTQ reads by 0-based id (read.c:37-45, 152-167, 237-278): seq and qual
  * are rlen bytes each at dst_off[i]; quali = qual - phred as int8
  * (phred 0 -> 33, read.c:268).  Any of seq/qual/quali may be NULL. */
 int fx_fastq_fetch(fx_handle *h, int where, int64_t n, const int64_t *read_id,
                    int phred, int seq_flags,
                    uint8_t *seq, uint8_t *qual, int8_t *quali, const int64_t *dst_off);
+/* ... with the layout left to the library (fq[i].seq / .qual / .quali for many i, read.c:152-167, 237-278): read lengths
+ * are gathered and scanned on the device, the wanted outputs (want: bit 0 seq, 1 qual, 2 quali) and *dst_off (n + 1)
+ * come back in pinned memory of fx_pinned_alloc (fx_pinned_free each); an id outside the table -> *first_bad, FX_ERANGE. */
+int fx_fastq_fetch_alloc(fx_handle *h, int64_t n, const int64_t *read_id, int phred, int seq_flags, int want,
+                         uint8_t **seq, uint8_t **qual, int8_t **quali, int64_t **dst_off, int64_t *first_bad);
 
 /* ------------------------------------------------------------------ Fastx
  * Replaces kseq_read (kseq.c:138-179) as pyfastx_fastx_next drives it (fastx.c:124-130): index-free iteration over a

@@ -46,9 +46,9 @@ class ShardSummary(C.Structure):
 
 SYMBOLS = [
     "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_file_indexed", "fx_gz_checkpoints", "fx_stream_size", "fx_open_file_range", "fx_open_host", "fx_open_device",
-    "fx_set_shard", "fx_close", "fx_release_scratch", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
+    "fx_set_shard", "fx_close", "fx_release_scratch", "fx_pinned_alloc", "fx_pinned_free", "fx_pinned_holds", "fx_pinned_trim", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
     "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_line_regular", "fx_fasta_len_stats", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
-    "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fastq_fetch", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
+    "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fasta_fetch_alloc", "fx_fetch_phases", "fx_fastq_fetch", "fx_fastq_fetch_alloc", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
     "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
     "fx_comm_unique_id", "fx_comm_init", "fx_comm_destroy", "fx_comm_rank", "fx_comm_world", "fx_comm_allgather", "fx_fasta_build_sharded_begin",
     "fx_fasta_build_sharded", "fx_comm_summaries", "fx_fastq_build_sharded", "fx_bgzf_counts", "fx_sort_packed_names", "fx_gunzip_parallel", "fx_gz_open_mode", "fx_kseq_scan", "fx_kseq_records", "fx_kseq_fetch", "fx_kseq_prefix_lines",
@@ -153,6 +153,14 @@ def lib():
     L.fx_fasta_fetch.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, vp, vp]
     L.fx_fetch_slices.argtypes = [vp, i32, i64, vp, vp, vp, vp, i32, vp, vp, vp, vp]
     L.fx_fastq_fetch.argtypes = [vp, i32, i64, vp, i32, i32, vp, vp, vp, vp]
+    L.fx_pinned_alloc.restype = vp
+    L.fx_pinned_alloc.argtypes = [i64]
+    L.fx_pinned_free.restype = None
+    L.fx_pinned_free.argtypes = [vp]
+    L.fx_pinned_holds.argtypes = [vp, i64]
+    L.fx_fasta_fetch_alloc.argtypes = [vp, i64, vp, vp, vp, i32, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
+    L.fx_fastq_fetch_alloc.argtypes = [vp, i64, vp, i32, i32, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
+    L.fx_fetch_phases.argtypes = [C.POINTER(C.c_double), i32]
     L.fx_names_build.argtypes = [vp, i32]
     L.fx_names_lookup.argtypes = [vp, i32, i64, vp, vp, vp]
     L.fx_revcomp.argtypes = [i32, i32, vp, i64, i32]
@@ -255,6 +263,33 @@ def shard_route(ids, starts, stops, cols, bases, ends, flags=0, flags_per_query=
                                int(flags), _ptr(fpq), _ptr(out["order"]), _ptr(out["shard_start"]), _ptr(out["off"]),
                                _ptr(out["len"]), _ptr(out["skip"]), _ptr(out["take"]), _ptr(out["fl"]), _ptr(out["cnt"])))
     return out
+
+
+def pinned_array(ptr, count, dtype=np.uint8):
+    """A numpy array over `count` items of pinned memory that fx_pinned_alloc (or an fx_*_alloc entry) handed out; the
+    block goes back to the library's pool when the last view of the array is gone (_fxobj.PinnedBuf owns it)."""
+    from . import _fxobj
+    L = lib()
+    dt = np.dtype(dtype)
+    owner = _fxobj.PinnedBuf(int(ptr), int(count) * dt.itemsize, C.cast(L.fx_pinned_free, C.c_void_p).value)
+    return np.frombuffer(owner, dtype=dt, count=int(count))
+
+
+def pinned_empty(count, dtype=np.uint8):
+    """numpy array of `count` items in pinned host memory (fx_pinned_alloc): query arrays built in it go to the device
+    without a staging copy, answers written into it arrive by DMA."""
+    dt = np.dtype(dtype)
+    p = lib().fx_pinned_alloc(max(int(count) * dt.itemsize, 1))
+    if not p:
+        raise FxError(FX_ENOMEM, lib().fx_last_error().decode())
+    return pinned_array(p, count, dt)
+
+
+def fetch_phases():
+    """Host-side phases of this thread's last fx_*_fetch_alloc call, ms: (stage + upload, offsets, pinned blocks, launch, answers back, total)."""
+    v = (C.c_double * 6)()
+    check(lib().fx_fetch_phases(v, 6))
+    return dict(zip(("stage_upload_ms", "offsets_wait_ms", "pinned_blocks_ms", "launch_ms", "answers_wait_ms", "call_ms"), [round(x, 3) for x in v]))
 
 
 def check(rc):
@@ -665,26 +700,33 @@ class Blob:
         check(lib().fx_names_build(self._h, int(kind)))
 
     def names_lookup(self, names):
-        """list of str / bytes -> int64 ids (0-based, -1 when absent), one kernel launch."""
+        """list of str / bytes -- or the names pre-packed as a (bytes, int64 offsets[n + 1]) pair -- -> int64 ids (0-based,
+        -1 when absent), one kernel launch."""
+        if isinstance(names, tuple) and len(names) == 2 and not isinstance(names[1], (str, int)) and \
+                isinstance(names[0], (bytes, bytearray, memoryview, np.ndarray)):
+            offs = np.ascontiguousarray(np.frombuffer(names[1], dtype=np.int64) if not isinstance(names[1], np.ndarray) else names[1], dtype=np.int64)
+            n = offs.size - 1
+            out = np.empty(max(n, 0), dtype=np.int64)
+            if n <= 0:
+                return out
+            raw = np.frombuffer(names[0], dtype=np.uint8) if not isinstance(names[0], np.ndarray) else names[0]
+            total = int(offs[n])
+            packed = raw if raw.size >= total + 8 else np.concatenate([raw[:total], np.zeros(16, dtype=np.uint8)])
+            check(lib().fx_names_lookup(self._h, FX_HOST, n, _ptr(packed), _ptr(offs), _ptr(out)))
+            return out
         n = len(names)
         out = np.empty(n, dtype=np.int64)
         if not n:
             return out
-        if isinstance(names[0], str):
-            # one join + one encode for the whole batch (a list comprehension of a million .encode() calls and a Python sum
-            # of their lengths cost more than the kernel and both copies together); a name cannot hold a newline
-            buf = np.frombuffer(("\n".join(names) + "\n").encode("utf-8", "surrogateescape"), dtype=np.uint8)
-            nl = np.flatnonzero(buf == 10)
-            if nl.size == n:
-                offs = np.zeros(n + 1, dtype=np.int64)
-                offs[1:] = nl - np.arange(n, dtype=np.int64)          # end of name i once the separators are gone
-                packed = np.concatenate([buf[buf != 10], np.zeros(16, dtype=np.uint8)])
-                check(lib().fx_names_lookup(self._h, FX_HOST, n, _ptr(packed), _ptr(offs), _ptr(out)))
-                return out
-        enc = [x if isinstance(x, bytes) else x.encode("utf-8", "surrogateescape") for x in names]
-        offs = np.zeros(n + 1, dtype=np.int64)
-        np.cumsum(np.fromiter(map(len, enc), dtype=np.int64, count=n), out=offs[1:])
-        packed = np.frombuffer(b"".join(enc) + b"\0" * 16, dtype=np.uint8)
+        from . import _fxobj
+        try:                                                    # one C pass over the list: sizes, then the bytes back to back (+ 16 zero bytes)
+            pb, po = _fxobj.pack_names(names)
+            packed, offs = np.frombuffer(pb, dtype=np.uint8), np.frombuffer(po, dtype=np.int64)
+        except ValueError:                                      # a name with surrogate escapes: encode one by one
+            enc = [x if isinstance(x, bytes) else x.encode("utf-8", "surrogateescape") for x in names]
+            offs = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(np.fromiter(map(len, enc), dtype=np.int64, count=n), out=offs[1:])
+            packed = np.frombuffer(b"".join(enc) + b"\0" * 16, dtype=np.uint8)
         check(lib().fx_names_lookup(self._h, FX_HOST, n, _ptr(packed), _ptr(offs), _ptr(out)))
         return out
 
@@ -762,6 +804,44 @@ class Blob:
             check(lib().fx_fasta_fetch(self._h, FX_HOST, n, _ptr(seq_id), _ptr(start), _ptr(stop), int(flags),
                                        _ptr(fpq), _ptr(dst), _ptr(offs), _ptr(out_len)))
         return dst[:int(offs[-1])], offs, out_len
+
+    def fasta_fetch_alloc(self, seq_id, start, stop, flags=0, flags_per_query=None):
+        """(record id, start, stop) batches with the layout left to the library (fx_fasta_fetch_alloc): intervals checked on the
+        device, answers and offsets in pinned memory -> (uint8 buffer, int64 offsets[n+1]); an invalid query raises
+        FxError(FX_ERANGE) whose .first_bad is its index."""
+        seq_id, start, stop = self._i64(seq_id), self._i64(start), self._i64(stop)
+        n = seq_id.size
+        if start.size != n or stop.size != n:
+            raise ValueError("ids, starts and stops differ in length")
+        fpq = None if flags_per_query is None else np.ascontiguousarray(flags_per_query, dtype=np.uint8)
+        dst, offs, bad = C.c_void_p(), C.c_void_p(), C.c_int64(-1)
+        rc = lib().fx_fasta_fetch_alloc(self._h, n, _ptr(seq_id), _ptr(start), _ptr(stop), int(flags), _ptr(fpq),
+                                        C.byref(dst), C.byref(offs), C.byref(bad))
+        if rc:
+            e = FxError(rc, lib().fx_last_error().decode())
+            e.first_bad = int(bad.value)
+            raise e
+        o = pinned_array(offs.value, n + 2, np.int64)[:n + 1]
+        return pinned_array(dst.value, max(int(o[n]), 1))[:int(o[n])], o
+
+    def fastq_fetch_alloc(self, read_id, phred=0, seq_flags=0, want=("seq", "qual", "quali")):
+        """Reads by id with the layout left to the library (fx_fastq_fetch_alloc) -> (seq, qual, quali, offsets), pinned."""
+        read_id = self._i64(read_id)
+        n = read_id.size
+        w = (1 if "seq" in want else 0) | (2 if "qual" in want else 0) | (4 if "quali" in want else 0)
+        ps, pq, pi, po, bad = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64(-1)
+        rc = lib().fx_fastq_fetch_alloc(self._h, n, _ptr(read_id), int(phred), int(seq_flags), w, C.byref(ps), C.byref(pq),
+                                        C.byref(pi), C.byref(po), C.byref(bad))
+        if rc:
+            e = FxError(rc, lib().fx_last_error().decode())
+            e.first_bad = int(bad.value)
+            raise e
+        o = pinned_array(po.value, n + 2, np.int64)[:n + 1]
+        tot = int(o[n])
+        seq = pinned_array(ps.value, max(tot, 1))[:tot] if ps.value else None
+        qual = pinned_array(pq.value, max(tot, 1))[:tot] if pq.value else None
+        qi = pinned_array(pi.value, max(tot, 1), np.int8)[:tot] if pi.value else None
+        return seq, qual, qi, o
 
     def fastq_fetch(self, read_id, rlen, phred=0, seq_flags=0, want=("seq", "qual", "quali")):
         read_id = self._i64(read_id)

@@ -646,7 +646,10 @@ class Fasta(_fxobj.FastaCore):
         """The seq table as numpy columns (cached): what the batched calls index into."""
         if getattr(self, "_tab", None) is None:
             rows = self._db.execute("SELECT chrom,boff,blen,slen,llen,elen,norm FROM seq ORDER BY ID").fetchall()
-            self._tab = {"index": {r[0]: i for i, r in enumerate(rows)},
+            index = {}
+            for i in range(len(rows) - 1, -1, -1):          # the FIRST record of a name wins, as `SELECT ... LIMIT 1` does (index.c:527-566)
+                index[rows[i][0]] = i
+            self._tab = {"index": index,
                          "boff": np.array([r[1] for r in rows], np.int64), "blen": np.array([r[2] for r in rows], np.int64),
                          "slen": np.array([r[3] for r in rows], np.int64), "llen": np.array([r[4] for r in rows], np.int64),
                          "elen": np.array([r[5] for r in rows], np.int64), "norm": np.array([r[6] for r in rows], np.int64)}
@@ -655,43 +658,37 @@ class Fasta(_fxobj.FastaCore):
     def fetch_many(self, names_or_ids, starts, stops, strand=None):
         """Batched extension: 0-based half-open (start, stop) on many sequences in ONE
         kernel launch -> (uint8 buffer, int64 offsets[n+1]).  names_or_ids: sequence names or 0-based
-        ids; strand: optional per-query '+'/'-' (or 0/1)."""
+        ids; strand: optional per-query '+'/'-' (or 0/1).
+        Host to host the call is a handful of milliseconds for a million intervals: names become ids in one C pass
+        (_fxobj.ids_of_names), the intervals are checked on the device against the resident table, the answers are laid
+        out by a device scan and arrive by DMA in pinned memory (fx_fasta_fetch_alloc) -- the arrays returned are views
+        of pinned blocks that go back to the library's pool when they are garbage-collected."""
         self._need_index()
         t = self._table()
+        n = len(names_or_ids)
         starts = np.asarray(starts, dtype=np.int64)
         stops = np.asarray(stops, dtype=np.int64)
-        first = names_or_ids[0] if len(names_or_ids) else 0
+        first = names_or_ids[0] if n else 0
         if isinstance(first, str):
-            ids = None
-            if getattr(self, "_scanned_here", False) and self._key_func is None:
-                try:                                          # name table in HBM (fx_names_lookup)
-                    if not getattr(self, "_names_ready", False):
-                        self._st.blob.names_build(0)
-                        self._names_ready = True
-                    ids = self._st.blob.names_lookup(names_or_ids)
-                    if (ids < 0).any():
-                        raise KeyError("%s does not exist in fasta file" % names_or_ids[int(np.nonzero(ids < 0)[0][0])])
-                except _lib.FxError:
-                    ids = None
-            if ids is None:
-                ix = t["index"]
-                try:
-                    ids = np.fromiter((ix[k] for k in names_or_ids), dtype=np.int64, count=len(names_or_ids))
-                except KeyError as e:
-                    raise KeyError("%s does not exist in fasta file" % e.args[0])
+            ids = np.empty(n, dtype=np.int64)
+            if not isinstance(names_or_ids, (list, tuple)):
+                names_or_ids = list(names_or_ids)
+            bad = _fxobj.ids_of_names(names_or_ids, t["index"], ids)
+            if bad >= 0:
+                raise KeyError("%s does not exist in fasta file" % names_or_ids[bad])
         else:
             ids = np.asarray(names_or_ids, dtype=np.int64)
-            if ids.size and (ids.min() < 0 or ids.max() >= self._seq_counts):
-                raise IndexError("index out of range")
-        if starts.size and (starts.min() < 0 or (stops < starts).any() or (stops > t["slen"][ids]).any()):
-            raise ValueError("interval outside the sequence")
         fl = (_F_UP if self._uppercase else 0)
         fpq = None
         if strand is not None:
             neg = np.array([s in ("-", 1, True) for s in strand], dtype=bool) if not isinstance(strand, np.ndarray) \
                 else (strand != 0) & (strand != ord("+"))
-            fpq = np.where(neg, fl | _F_REV | _F_COMP, fl).astype(np.uint8)
+            fpq = neg.view(np.uint8) * np.uint8(_F_REV | _F_COMP) | np.uint8(fl)
         if self._sharded:                                   # routed to the devices that hold the bytes (shard.ShardFetcher)
+            if ids.size and (ids.min() < 0 or ids.max() >= self._seq_counts):
+                raise IndexError("index out of range")
+            if starts.size and (starts.min() < 0 or (stops < starts).any() or (stops > t["slen"][ids]).any()):
+                raise ValueError("interval outside the sequence")
             qidx, sbuf, soffs = self._st.md.fetcher().fetch(ids, starts, stops, flags=fl, flags_per_query=fpq)
             offs = np.zeros(ids.size + 1, dtype=np.int64)
             np.cumsum(stops - starts, out=offs[1:])
@@ -704,9 +701,16 @@ class Fasta(_fxobj.FastaCore):
         if not getattr(blob, "_table_ready", False):       # index loaded from an existing .fxi: install its rows once
             blob.fasta_set_table(t["boff"], t["blen"], t["slen"], t["llen"], t["elen"], t["norm"])
         # (record id, start, stop) resolved on the GPU with the sequence.c:498-510 arithmetic (line-regular
-        # records) or despace-then-slice (sequence.c:100-110)
-        buf, offs, ol = blob.fasta_fetch(ids, starts, stops, flags=fl, flags_per_query=fpq)
-        return buf, offs
+        # records) or despace-then-slice (sequence.c:100-110); ids and intervals are checked there too
+        try:
+            return blob.fasta_fetch_alloc(ids, starts, stops, flags=fl, flags_per_query=fpq)
+        except _lib.FxError as e:
+            k = getattr(e, "first_bad", -1)
+            if e.code != _lib.FX_ERANGE or k < 0:
+                raise
+            if not 0 <= int(ids[k]) < self._seq_counts:
+                raise IndexError("index out of range")
+            raise ValueError("interval outside the sequence")
 
 
     def _ids_of(self, names_or_ids):
@@ -1324,17 +1328,30 @@ class Fastq:
         return blob
 
     def fetch_many(self, ids_or_names, want=("seq", "qual", "quali")):
-        """Batched extension: reads by 0-based id (or by name) in one launch -> dict of buffers + offsets."""
+        """Batched extension: reads by 0-based id (or by name; or names pre-packed as a (bytes, int64 offsets[n + 1]) pair)
+        in one launch -> dict of buffers + offsets.  Read lengths are gathered and laid out on the device, the outputs
+        arrive by DMA in pinned memory (fx_fastq_fetch_alloc)."""
         blob = self._dev()
-        if len(ids_or_names) and isinstance(ids_or_names[0], str):
+        packed = isinstance(ids_or_names, tuple) and len(ids_or_names) == 2 and isinstance(ids_or_names[0], (bytes, bytearray, memoryview, np.ndarray)) \
+            and not isinstance(ids_or_names[1], (str, int))
+        if packed or (len(ids_or_names) and isinstance(ids_or_names[0], str)):
             ids = self.ids_of(ids_or_names)
             if (ids < 0).any():
-                raise KeyError("%s does not exist in fastq file" % ids_or_names[int(np.nonzero(ids < 0)[0][0])])
+                k = int(np.nonzero(ids < 0)[0][0])
+                if packed:
+                    o = np.frombuffer(ids_or_names[1], dtype=np.int64) if not isinstance(ids_or_names[1], np.ndarray) else ids_or_names[1]
+                    nm = bytes(memoryview(ids_or_names[0])[int(o[k]):int(o[k + 1])]).decode("utf-8", "surrogateescape")
+                else:
+                    nm = ids_or_names[k]
+                raise KeyError("%s does not exist in fastq file" % nm)
         else:
             ids = np.asarray(ids_or_names, dtype=np.int64)
-            if ids.size and (ids.min() < 0 or ids.max() >= self._rlen_host.size):
+        try:
+            seq, qual, qi, offs = blob.fastq_fetch_alloc(ids, phred=self._phred, want=want)
+        except _lib.FxError as e:
+            if e.code == _lib.FX_ERANGE and getattr(e, "first_bad", -1) >= 0:
                 raise IndexError("index out of range")
-        seq, qual, qi, offs = blob.fastq_fetch(ids, self._rlen_host[ids], phred=self._phred, want=want)
+            raise
         return {"seq": seq, "qual": qual, "quali": qi, "offsets": offs}
 
 

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <map>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -296,6 +297,8 @@ struct fx_handle {
     int kq_code = 0;
     DevBuf<uint8_t> arena;     // scratch for host-array calls (Staged)
     int64_t arena_used = 0;
+    uint8_t *pin_in = nullptr; // pinned staging for the query arrays of host-array calls: pageable source -> here (threads) -> one DMA each
+    int64_t pin_in_cap = 0, pin_in_used = 0;
     int64_t halo = 0;          // trailing bytes of the blob that belong to the next shard's core
     // BGZF member table (compressed offset of each member, offset of its data in the inflated stream)
     std::vector<int64_t> gz_moff, gz_coff, gz_uoff;          // member start, start of its deflate data (behind the header), offset of its bytes in the inflated stream
@@ -358,6 +361,7 @@ extern "C" int fx_close(fx_handle *h) {
     if (h->pin_tot) (void)hipHostFree(h->pin_tot);
     if (h->one_box) (void)hipHostFree(h->one_box);
     if (h->one_out) (void)hipHostFree(h->one_out);
+    if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return FX_OK;
@@ -471,6 +475,100 @@ struct PinPool {
 };
 static PinPool g_pins;
 
+// Pinned host memory for CALLERS (fx_pinned_alloc / fx_pinned_free): answers of a batch land in it by DMA, with no bounce
+// buffer and no first-touch page faults (a fresh 100 MB numpy array costs more to fault in than the 1 M answers cost to
+// fetch), and query arrays that live in it go up without a staging copy.  Pinning is expensive (hipHostMalloc of 100 MB:
+// milliseconds), so released blocks are kept -- up to FX_PINNED_CACHE_MB (default 2048) -- and handed to the next request
+// they fit; every live block is in a registry so that the library can tell a pinned pointer from a pageable one.
+struct HostPool {
+    struct Block { uint8_t *p; size_t cap; };
+    std::mutex mu;
+    std::vector<Block> idle;
+    std::map<const uint8_t *, size_t> live;                   // base -> capacity of the blocks handed out (and of the idle ones: they stay pinned)
+    size_t held = 0;
+    const size_t limit = [] { const char *e = getenv("FX_PINNED_CACHE_MB"); return (size_t)(e ? std::max(0, atoi(e)) : 2048) << 20; }();
+    static size_t round_up(size_t b) {                        // few distinct sizes: 4 KiB steps up to 1 MiB, then 1/8 of the next power of two
+        if (b <= (1u << 20)) return (b + 4095) & ~(size_t)4095;
+        size_t step = 1;
+        while ((step << 4) <= b) step <<= 1;
+        return (b + step - 1) & ~(step - 1);
+    }
+    void *get(size_t bytes) {
+        const size_t want = round_up(std::max<size_t>(bytes, 1));
+        {
+            std::lock_guard<std::mutex> g(mu);
+            int best = -1;
+            for (int i = 0; i < (int)idle.size(); ++i)
+                if (idle[i].cap >= want && idle[i].cap <= 2 * want && (best < 0 || idle[i].cap < idle[best].cap)) best = i;
+            if (best >= 0) {
+                Block b = idle[best];
+                idle.erase(idle.begin() + best);
+                held -= b.cap;
+                live[b.p] = b.cap;
+                return b.p;
+            }
+        }
+        uint8_t *p = nullptr;
+        if (hipHostMalloc((void **)&p, want, hipHostMallocDefault) != hipSuccess) {
+            trim();
+            if (hipHostMalloc((void **)&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+        }
+        std::lock_guard<std::mutex> g(mu);
+        live[p] = want;
+        return p;
+    }
+    bool put(void *ptr) {
+        uint8_t *p = (uint8_t *)ptr;
+        size_t cap = 0;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto it = live.find(p);
+            if (it == live.end()) return false;
+            cap = it->second;
+            live.erase(it);
+            if (held + cap <= limit) { idle.push_back(Block{p, cap}); held += cap; return true; }
+        }
+        (void)hipHostFree(p);
+        return true;
+    }
+    // is [p, p + bytes) inside one block that was handed out?
+    bool holds(const void *ptr, size_t bytes) {
+        const uint8_t *p = (const uint8_t *)ptr;
+        std::lock_guard<std::mutex> g(mu);
+        auto it = live.upper_bound(p);
+        if (it == live.begin()) return false;
+        --it;
+        return p >= it->first && p + bytes <= it->first + it->second;
+    }
+    void trim() {
+        std::vector<Block> v;
+        { std::lock_guard<std::mutex> g(mu); v.swap(idle); held = 0; }
+        for (auto &b : v) (void)hipHostFree(b.p);
+    }
+};
+static HostPool g_hostpool;
+extern "C" void *fx_pinned_alloc(int64_t bytes) {
+    if (bytes < 0) { (void)fail(FX_EINVAL, "fx_pinned_alloc: negative size"); return nullptr; }
+    void *p = g_hostpool.get((size_t)bytes);
+    if (!p) (void)fail(FX_ENOMEM, "hipHostMalloc(%lld B) failed", (long long)bytes);
+    return p;
+}
+extern "C" void fx_pinned_free(void *p) { if (p) (void)g_hostpool.put(p); }
+extern "C" int fx_pinned_holds(const void *p, int64_t bytes) { return p && bytes >= 0 && g_hostpool.holds(p, (size_t)bytes) ? 1 : 0; }
+extern "C" int fx_pinned_trim(void) { g_hostpool.trim(); return FX_OK; }
+
+// memcpy with a few threads once it is worth their start (query arrays of a million entries: 8 MB each)
+static void par_memcpy(void *dst, const void *src, size_t bytes) {
+    const size_t PIECE = 2u << 20;
+    if (bytes < 2 * PIECE) { memcpy(dst, src, bytes); return; }
+    const int T = (int)std::min<size_t>(6, bytes / PIECE);
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t)
+        th.emplace_back([=]() { const size_t a = bytes * t / T, b = bytes * (t + 1) / T; memcpy((uint8_t *)dst + a, (const uint8_t *)src + a, b - a); });
+    memcpy(dst, src, bytes / T);
+    for (auto &x : th) x.join();
+}
+
 static int stage_plain_file(fx_handle *h, int fd, int64_t n, const char *path, uint8_t *d_dst, int64_t file_off = 0) {
     const int T = (int)std::min<int64_t>(stage_threads(), std::max<int64_t>(1, (n + PIECE_BYTES - 1) / PIECE_BYTES));
     std::atomic<int> err(0);                 // 1: read error, 2: device error
@@ -565,6 +663,16 @@ static int to_host(fx_handle *h, void *dst, const void *d_src, int64_t bytes) {
     if (bytes >= D2H_LARGE) return d2h_large(h, dst, d_src, bytes);
     HIPCHK(hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, h->stream));
     return FX_OK;
+}
+
+// ... and straight by DMA when the destination is pinned memory of fx_pinned_alloc (no bounce buffer, no threads)
+static int to_host_any(fx_handle *h, void *dst, const void *d_src, int64_t bytes) {
+    if (bytes <= 0) return FX_OK;
+    if (bytes >= D2H_LARGE && g_hostpool.holds(dst, (size_t)bytes)) {
+        HIPCHK(hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, h->stream));
+        return FX_OK;
+    }
+    return to_host(h, dst, d_src, bytes);
 }
 
 static inline unsigned nblocks(int64_t n, int per) { return (unsigned)std::max<int64_t>(1, (n + per - 1) / per); }
@@ -2052,7 +2160,20 @@ struct Staged {
     fx_handle *h;
     std::vector<void *> spill;
     int64_t want = 0;
-    explicit Staged(fx_handle *hh) : h(hh) { h->arena_used = 0; }
+    explicit Staged(fx_handle *hh) : h(hh) { h->arena_used = 0; h->pin_in_used = 0; }
+    // room for `bytes` of query arrays in the handle's pinned staging buffer (kept from call to call, grown by half more
+    // than asked): a pageable source goes through it -- copied by a few threads, then ONE DMA -- instead of through the
+    // runtime's own bounce buffer, which moves a pageable 8 MB array at a fraction of the link's rate
+    void reserve_pin(int64_t bytes) {
+        bytes += 4096;
+        if (bytes <= h->pin_in_cap || bytes < (1 << 16)) return;
+        (void)hipStreamSynchronize(h->stream);
+        if (h->pin_in) (void)hipHostFree(h->pin_in);
+        h->pin_in = nullptr; h->pin_in_cap = 0;
+        const int64_t cap = bytes + bytes / 2;
+        if (hipHostMalloc((void **)&h->pin_in, (size_t)cap, hipHostMallocDefault) == hipSuccess) h->pin_in_cap = cap;
+        else h->pin_in = nullptr;
+    }
     ~Staged() {
         for (void *p : spill) (void)hipFree(p);
         if (want > h->arena.cap) {                       // only reached after the call's final sync
@@ -2078,7 +2199,14 @@ struct Staged {
         if (!src || n <= 0) return FX_OK;
         void *d = take(n * (int64_t)sizeof(T));
         if (!d) return fail(FX_ENOMEM, "device scratch allocation failed");
-        hipError_t e = hipMemcpyAsync(d, src, (size_t)n * sizeof(T), hipMemcpyHostToDevice, h->stream);
+        const int64_t bytes = n * (int64_t)sizeof(T), padded = (bytes + 255) & ~255ll;
+        const void *from = src;
+        if (bytes >= (1 << 16) && h->pin_in && h->pin_in_used + padded <= h->pin_in_cap && !g_hostpool.holds(src, (size_t)bytes)) {
+            par_memcpy(h->pin_in + h->pin_in_used, src, (size_t)bytes);
+            from = h->pin_in + h->pin_in_used;
+            h->pin_in_used += padded;
+        }
+        hipError_t e = hipMemcpyAsync(d, from, (size_t)bytes, hipMemcpyHostToDevice, h->stream);
         if (e != hipSuccess) return fail(FX_EDEVICE, "H2D: %s", hipGetErrorString(e));
         *dst = (const T *)d;
         return FX_OK;
@@ -2097,56 +2225,15 @@ static unsigned fetch_grid(int64_t nq) {
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>((nq + 3) / 4, cap));
 }
 
-static int fetch_common(fx_handle *h, int where, int64_t n, bool by_id, const int64_t *a0, const int64_t *a1,
-                        const int64_t *a2, const int64_t *skip, int flags, const uint8_t *qflags, uint8_t *dst,
-                        const int64_t *dst_off, int64_t *out_len, int64_t dst_bytes_hint) {
-    if (!h) return fail(FX_EINVAL, "null handle");
-    if (n < 0 || (n > 0 && (!a0 || !a1 || !a2 || !dst || !dst_off))) return fail(FX_EINVAL, "null query array");
-    if (by_id && !h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build has not run");
-    if (n == 0) return FX_OK;
-    int rc = use_device(h);
-    if (rc) return rc;
-    Staged st(h);
-    FetchQ q;
-    memset(&q, 0, sizeof q);
-    const int64_t *host_blen = (where == FX_HOST && !by_id) ? a1 : nullptr;
-    uint8_t *d_dst = dst;
-    int64_t *d_len = out_len;
-    int64_t total = dst_bytes_hint;
-    if (where == FX_HOST) {
-        const int64_t *d0, *d1, *d2, *d3 = nullptr, *doff;
-        const uint8_t *dfl = nullptr;
-        if ((rc = st.up(h, a0, n, &d0)) || (rc = st.up(h, a1, n, &d1)) || (rc = st.up(h, a2, n, &d2)) ||
-            (rc = st.up(h, skip, n, &d3)) || (rc = st.up(h, dst_off, n, &doff)) || (rc = st.up(h, qflags, n, &dfl)))
-            return rc;
-        a0 = d0; a1 = d1; a2 = d2; skip = d3; qflags = dfl;
-        q.dst_off = doff;
-        if ((rc = st.scratch<int64_t>(n, &d_len))) return rc;
-    } else {
-        q.dst_off = dst_off;
-    }
-    if (by_id) { q.seq_id = a0; q.start = a1; q.stop = a2; }
-    else       { q.off = a0; q.blen = a1; q.take = a2; q.skip = skip; }
-    q.qflags = qflags;
-    q.out_len = d_len;
-    if (where == FX_HOST) {
-        if (total <= 0) return fail(FX_EINVAL, "internal: host fetch needs dst size");
-        if ((rc = st.scratch<uint8_t>(total, &d_dst))) return rc;
-    }
+// the kernels of one batch, enqueued on the handle's stream: q's arrays and d_dst are device pointers
+static int fetch_launch(fx_handle *h, Staged &st, const FetchQ &q, bool by_id, bool longq, int64_t n, int flags, uint8_t *d_dst) {
+    int rc;
     FastaTab tab;
     memset(&tab, 0, sizeof tab);
     if (h->fasta_built) {
         tab.boff = h->fa_boff.p; tab.blen = h->fa_blen.p; tab.slen = h->fa_slen.p; tab.llen = h->fa_llen.p;
         tab.elen = h->fa_elen.p; tab.norm = h->fa_reg.p; tab.n_seq = h->n_hdr;     // slices go by the line-regular column
         if (h->build_pending) { tab.n_seq_dev = (const long long *)&ctl_totals(h)->n_hdr; tab.n_seq = h->hdr.cap; }
-    }
-    // lanes per query: 16 (128-byte window, 4 queries per wave) for short random access,
-    // 64 (1 KiB window) when the caller says the ranges are long (FX_LONG) or host arrays show it
-    bool longq = (flags & 16) != 0;
-    if (where == FX_HOST && !by_id && host_blen) {
-        double sum = 0;
-        for (int64_t i = 0; i < n; ++i) sum += (double)host_blen[i];
-        longq = longq || sum / (double)n > 512.0;
     }
     // lanes per query for intervals by record id (FX_FETCH_G: tuning).  The kernel is latency-bound -- PMC (profiles/r02_pmc_fetch.txt):
     // 57 % of the wave cycles parked in s_waitcnt, 22 % issuing; queries sorted by offset, which share DRAM pages and even lines,
@@ -2183,9 +2270,58 @@ static int fetch_common(fx_handle *h, int where, int64_t n, bool by_id, const in
         else       FX_LAUNCH(h, K_FETCH, (k_fetch<false, 64, 16>), dim3(grid), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst);
     }
     HIPCHK(hipGetLastError());
+    return FX_OK;
+}
+
+static int fetch_common(fx_handle *h, int where, int64_t n, bool by_id, const int64_t *a0, const int64_t *a1,
+                        const int64_t *a2, const int64_t *skip, int flags, const uint8_t *qflags, uint8_t *dst,
+                        const int64_t *dst_off, int64_t *out_len, int64_t dst_bytes_hint) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    if (n < 0 || (n > 0 && (!a0 || !a1 || !a2 || !dst || !dst_off))) return fail(FX_EINVAL, "null query array");
+    if (by_id && !h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build has not run");
+    if (n == 0) return FX_OK;
+    int rc = use_device(h);
+    if (rc) return rc;
+    Staged st(h);
+    FetchQ q;
+    memset(&q, 0, sizeof q);
+    const int64_t *host_blen = (where == FX_HOST && !by_id) ? a1 : nullptr;
+    uint8_t *d_dst = dst;
+    int64_t *d_len = out_len;
+    int64_t total = dst_bytes_hint;
     if (where == FX_HOST) {
-        if ((rc = to_host(h, dst, d_dst, total))) return rc;
-        if (out_len && (rc = to_host(h, out_len, d_len, n * 8))) return rc;
+        const int64_t *d0, *d1, *d2, *d3 = nullptr, *doff;
+        const uint8_t *dfl = nullptr;
+        st.reserve_pin(n * 8 * (4 + (skip ? 1 : 0)) + (qflags ? n : 0) + 6 * 256);
+        if ((rc = st.up(h, a0, n, &d0)) || (rc = st.up(h, a1, n, &d1)) || (rc = st.up(h, a2, n, &d2)) ||
+            (rc = st.up(h, skip, n, &d3)) || (rc = st.up(h, dst_off, n, &doff)) || (rc = st.up(h, qflags, n, &dfl)))
+            return rc;
+        a0 = d0; a1 = d1; a2 = d2; skip = d3; qflags = dfl;
+        q.dst_off = doff;
+        if ((rc = st.scratch<int64_t>(n, &d_len))) return rc;
+    } else {
+        q.dst_off = dst_off;
+    }
+    if (by_id) { q.seq_id = a0; q.start = a1; q.stop = a2; }
+    else       { q.off = a0; q.blen = a1; q.take = a2; q.skip = skip; }
+    q.qflags = qflags;
+    q.out_len = d_len;
+    if (where == FX_HOST) {
+        if (total <= 0) return fail(FX_EINVAL, "internal: host fetch needs dst size");
+        if ((rc = st.scratch<uint8_t>(total, &d_dst))) return rc;
+    }
+    // lanes per query: 16 (128-byte window, 4 queries per wave) for short random access,
+    // 64 (1 KiB window) when the caller says the ranges are long (FX_LONG) or host arrays show it
+    bool longq = (flags & 16) != 0;
+    if (where == FX_HOST && !by_id && host_blen) {
+        double sum = 0;
+        for (int64_t i = 0; i < n; ++i) sum += (double)host_blen[i];
+        longq = longq || sum / (double)n > 512.0;
+    }
+    if ((rc = fetch_launch(h, st, q, by_id, longq, n, flags, d_dst))) return rc;
+    if (where == FX_HOST) {
+        if ((rc = to_host_any(h, dst, d_dst, total))) return rc;
+        if (out_len && (rc = to_host_any(h, out_len, d_len, n * 8))) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     return FX_OK;
@@ -2382,6 +2518,185 @@ extern "C" int fx_fasta_fetch(fx_handle *h, int where, int64_t n, const int64_t 
     int64_t ext = 0;
     if (where == FX_HOST && n > 0 && dst_off && start && stop) ext = std::max<int64_t>(1, host_extent(n, dst_off, nullptr, start, stop));
     return fetch_common(h, where, n, true, seq_id, start, stop, nullptr, flags, flags_per_query, dst, dst_off, out_len, ext);
+}
+
+// ---- batches whose answers the library lays out itself (fx_*_fetch_alloc)
+// Host-side phases of the last fx_*_fetch_alloc call of this thread, in milliseconds: 0 query arrays staged and their
+// copies enqueued, 1 counts + scan + offsets back (first wait), 2 pinned blocks for the answers, 3 kernels enqueued,
+// 4 answers back (second wait), 5 the whole call
+static thread_local double g_fetch_phase[6] = {0, 0, 0, 0, 0, 0};
+extern "C" int fx_fetch_phases(double *ms, int cap) {
+    if (!ms || cap <= 0) return fail(FX_EINVAL, "null argument");
+    for (int i = 0; i < cap && i < 6; ++i) ms[i] = g_fetch_phase[i];
+    return FX_OK;
+}
+struct PhaseClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    void lap(int i) { const auto now = std::chrono::steady_clock::now(); g_fetch_phase[i] = std::chrono::duration<double, std::milli>(now - last).count(); last = now; }
+    void done() { g_fetch_phase[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+// cnt[i] = bytes query i will write (0 for a query that is not valid; *bad = index of the first such query)
+__global__ __launch_bounds__(BLOCK) void k_q_counts_fasta(const int64_t *__restrict__ slen, int64_t n_seq, const int64_t *__restrict__ id,
+                                                         const int64_t *__restrict__ a, const int64_t *__restrict__ b, int64_t n,
+                                                         int32_t *__restrict__ cnt, unsigned long long *__restrict__ bad) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = id[i], x = a[i], y = b[i];
+    const bool ok = r >= 0 && r < n_seq && x >= 0 && y >= x && y - x <= 0x7FFFFFFFll && y <= slen[r];
+    cnt[i] = ok ? (int32_t)(y - x) : 0;
+    if (!ok) atomicMin(bad, (unsigned long long)i);
+}
+__global__ __launch_bounds__(BLOCK) void k_q_counts_fastq(const int64_t *__restrict__ rlen, int64_t n_reads, const int64_t *__restrict__ id, int64_t n,
+                                                         int32_t *__restrict__ cnt, unsigned long long *__restrict__ bad) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = id[i];
+    const bool ok = r >= 0 && r < n_reads && rlen[r] >= 0 && rlen[r] <= 0x7FFFFFFFll;
+    cnt[i] = ok ? (int32_t)rlen[r] : 0;
+    if (!ok) atomicMin(bad, (unsigned long long)i);
+}
+
+// cnt[0..n) on the device -> exclusive offsets d_off[0..n] on the device, and in *offs_out a pinned host copy (fx_pinned_free)
+// with the index of the first invalid query in *first_bad (-1: none); one wait
+static int offsets_of_counts(fx_handle *h, Staged &st, const int32_t *d_cnt, unsigned long long *d_bad, int64_t n, int64_t **d_off_out,
+                             int64_t **offs_out, int64_t *first_bad) {
+    int rc;
+    const int64_t nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    int64_t *d_sums = nullptr, *d_off = nullptr;
+    if ((rc = st.scratch<int64_t>(nchunks + 1, &d_sums)) || (rc = st.scratch<int64_t>(n + 1, &d_off))) return rc;
+    hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, d_cnt, n, d_sums);
+    hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, d_sums, nchunks);
+    hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, d_cnt, n, (const int64_t *)d_sums, d_off);
+    HIPCHK(hipGetLastError());
+    int64_t *offs = (int64_t *)fx_pinned_alloc((n + 2) * 8);            // one more word: the first invalid query
+    if (!offs) return FX_ENOMEM;
+    hipError_t e = hipMemcpyAsync(offs, d_off, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(offs + n + 1, d_bad, 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { fx_pinned_free(offs); return fail(FX_EDEVICE, "offsets of a batch: %s", hipGetErrorString(e)); }
+    const unsigned long long bad = (unsigned long long)offs[n + 1];
+    *first_bad = bad == ~0ull ? -1 : (int64_t)bad;
+    *d_off_out = d_off;
+    *offs_out = offs;
+    return FX_OK;
+}
+
+extern "C" int fx_fasta_fetch_alloc(fx_handle *h, int64_t n, const int64_t *seq_id, const int64_t *start, const int64_t *stop, int flags,
+                                    const uint8_t *flags_per_query, uint8_t **dst, int64_t **dst_off, int64_t *first_bad) {
+    if (!h || !dst || !dst_off || !first_bad) return fail(FX_EINVAL, "null argument");
+    *dst = nullptr; *dst_off = nullptr; *first_bad = -1;
+    if (n < 0 || (n > 0 && (!seq_id || !start || !stop))) return fail(FX_EINVAL, "null query array");
+    if (!h->fasta_built) return fail(FX_ESTATE, "fx_fasta_build has not run");
+    int rc = use_device(h);
+    if (!rc) rc = finish_build(h);
+    if (rc) return rc;
+    if (n >= 0x7FFFFFFFll * (int64_t)SCAN_CHUNK) return fail(FX_ERANGE, "too many queries in one batch");
+    Staged st(h);
+    PhaseClock pc;
+    FetchQ q;
+    memset(&q, 0, sizeof q);
+    int64_t *offs = nullptr;
+    if (n == 0) {
+        if (!(offs = (int64_t *)fx_pinned_alloc(16)) || !(*dst = (uint8_t *)fx_pinned_alloc(1))) { fx_pinned_free(offs); return FX_ENOMEM; }
+        offs[0] = 0; *dst_off = offs;
+        return FX_OK;
+    }
+    st.reserve_pin(n * 8 * 3 + (flags_per_query ? n : 0) + 5 * 256);
+    if ((rc = st.up(h, seq_id, n, &q.seq_id)) || (rc = st.up(h, start, n, &q.start)) || (rc = st.up(h, stop, n, &q.stop)) ||
+        (rc = st.up(h, flags_per_query, n, &q.qflags)))
+        return rc;
+    int32_t *d_cnt = nullptr;
+    unsigned long long *d_bad = nullptr;
+    if ((rc = st.scratch<int32_t>(n, &d_cnt)) || (rc = st.scratch<unsigned long long>(1, &d_bad))) return rc;
+    HIPCHK(hipMemsetAsync(d_bad, 0xFF, 8, h->stream));
+    hipLaunchKernelGGL(k_q_counts_fasta, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, (const int64_t *)h->fa_slen.p, h->n_hdr, q.seq_id, q.start,
+                       q.stop, n, d_cnt, d_bad);
+    pc.lap(0);
+    int64_t *d_off = nullptr;
+    if ((rc = offsets_of_counts(h, st, d_cnt, d_bad, n, &d_off, &offs, first_bad))) return rc;
+    pc.lap(1);
+    if (*first_bad >= 0) { fx_pinned_free(offs); return fail(FX_ERANGE, "query %lld: record id or interval outside the sequence", (long long)*first_bad); }
+    const int64_t total = offs[n];
+    uint8_t *out = (uint8_t *)fx_pinned_alloc(std::max<int64_t>(total, 1));
+    uint8_t *d_dst = nullptr;
+    if (!out) { fx_pinned_free(offs); return FX_ENOMEM; }
+    auto bail = [&](int code) { fx_pinned_free(offs); fx_pinned_free(out); return code; };
+    if ((rc = st.scratch<uint8_t>(std::max<int64_t>(total, 1), &d_dst))) return bail(rc);
+    pc.lap(2);
+    q.dst_off = d_off;
+    if (total > 0) {
+        if ((rc = fetch_launch(h, st, q, true, (flags & 16) != 0 || total / n > 512, n, flags, d_dst))) return bail(rc);
+        if (hipMemcpyAsync(out, d_dst, (size_t)total, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return bail(fail(FX_EDEVICE, "D2H failed"));
+    }
+    pc.lap(3);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(fail(FX_EDEVICE, "stream synchronisation failed"));
+    pc.lap(4);
+    h->prof.drain();
+    *dst = out; *dst_off = offs;
+    pc.done();
+    return FX_OK;
+}
+
+extern "C" int fx_fastq_fetch_alloc(fx_handle *h, int64_t n, const int64_t *read_id, int phred, int seq_flags, int want, uint8_t **seq,
+                                    uint8_t **qual, int8_t **quali, int64_t **dst_off, int64_t *first_bad) {
+    if (!h || !dst_off || !first_bad) return fail(FX_EINVAL, "null argument");
+    if (seq) *seq = nullptr; if (qual) *qual = nullptr; if (quali) *quali = nullptr;
+    *dst_off = nullptr; *first_bad = -1;
+    if (!h->fastq_built) return fail(FX_ESTATE, "fx_fastq_build has not run");
+    if (n < 0 || (n > 0 && !read_id)) return fail(FX_EINVAL, "null query array");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!phred) phred = 33;                                // read.c:268
+    const bool w_seq = (want & 1) && seq, w_qual = (want & 2) && qual, w_qi = (want & 4) && quali;
+    Staged st(h);
+    PhaseClock pc;
+    int64_t *offs = nullptr;
+    void *outs[3] = {nullptr, nullptr, nullptr};
+    auto bail = [&](int code) { fx_pinned_free(offs); for (void *p : outs) fx_pinned_free(p); return code; };
+    if (n == 0) {
+        if (!(offs = (int64_t *)fx_pinned_alloc(16))) return FX_ENOMEM;
+        offs[0] = 0;
+    } else {
+        st.reserve_pin(n * 8 + 512);
+        const int64_t *d_ids = nullptr;
+        if ((rc = st.up(h, read_id, n, &d_ids))) return rc;
+        int32_t *d_cnt = nullptr;
+        unsigned long long *d_bad = nullptr;
+        if ((rc = st.scratch<int32_t>(n, &d_cnt)) || (rc = st.scratch<unsigned long long>(1, &d_bad))) return rc;
+        HIPCHK(hipMemsetAsync(d_bad, 0xFF, 8, h->stream));
+        hipLaunchKernelGGL(k_q_counts_fastq, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, (const int64_t *)h->fq_rlen.p, h->n_reads, d_ids, n, d_cnt, d_bad);
+        pc.lap(0);
+        int64_t *d_off = nullptr;
+        if ((rc = offsets_of_counts(h, st, d_cnt, d_bad, n, &d_off, &offs, first_bad))) return rc;
+        pc.lap(1);
+        if (*first_bad >= 0) return bail(fail(FX_ERANGE, "read id %lld out of range", (long long)read_id[*first_bad]));
+        const int64_t total = std::max<int64_t>(offs[n], 1);
+        uint8_t *d_out[3] = {nullptr, nullptr, nullptr};
+        const bool w[3] = {w_seq, w_qual, w_qi};
+        for (int k = 0; k < 3; ++k)
+            if (w[k]) {
+                if (!(outs[k] = fx_pinned_alloc(total))) return bail(FX_ENOMEM);
+                if ((rc = st.scratch<uint8_t>(total, &d_out[k]))) return bail(rc);
+            }
+        pc.lap(2);
+        FX_LAUNCH(h, K_FASTQ_FETCH, k_fastq_fetch, dim3(fetch_grid((n + 3) / 4)), dim3(BLOCK), h->d_data, h->base, h->n, h->fq_rlen.p,
+                  h->fq_soff.p, h->fq_qoff.p, h->n_reads, d_ids, n, phred, seq_flags, d_out[0], d_out[1], (int8_t *)d_out[2], (const int64_t *)d_off);
+        if (hipGetLastError() != hipSuccess) return bail(fail(FX_EDEVICE, "launch failed"));
+        for (int k = 0; k < 3; ++k)
+            if (w[k] && hipMemcpyAsync(outs[k], d_out[k], (size_t)offs[n], hipMemcpyDeviceToHost, h->stream) != hipSuccess) return bail(fail(FX_EDEVICE, "D2H failed"));
+        pc.lap(3);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(fail(FX_EDEVICE, "stream synchronisation failed"));
+        pc.lap(4);
+        h->prof.drain();
+    }
+    if (n == 0) for (int k = 0; k < 3; ++k) { const bool w[3] = {w_seq, w_qual, w_qi}; if (w[k] && !(outs[k] = fx_pinned_alloc(1))) return bail(FX_ENOMEM); }
+    if (w_seq) *seq = (uint8_t *)outs[0];
+    if (w_qual) *qual = (uint8_t *)outs[1];
+    if (w_qi) *quali = (int8_t *)outs[2];
+    *dst_off = offs;
+    pc.done();
+    return FX_OK;
 }
 
 extern "C" int fx_fastq_fetch(fx_handle *h, int where, int64_t n, const int64_t *read_id, int phred, int seq_flags,

@@ -223,6 +223,75 @@ def test_batched_fetch_many(fx, files):
         assert buf[offs[i]:offs[i + 1]].tobytes().decode() == want
 
 
+def test_fetch_many_layout_by_the_library(fx, files):
+    """Round 4: the batched calls leave the layout to the library (fx_fasta_fetch_alloc / fx_fastq_fetch_alloc: intervals
+    checked on the device, offsets by a device scan, answers by DMA into pinned blocks of fx_pinned_alloc).  Same bytes as the
+    caller-allocated entry points, the reference's exception classes, blocks back in the pool when the arrays die."""
+    from pyfastx_amd import _lib
+    L = _lib.lib()
+    fa = fx.Fasta(files["test.fa"])
+    n = len(fa)
+    rng = np.random.default_rng(5)
+    ids = rng.integers(0, n, 5000)
+    slen = np.array([len(fa[int(i)]) for i in range(n)], dtype=np.int64)
+    st = (rng.random(5000) * slen[ids]).astype(np.int64)
+    sp = np.minimum(slen[ids], st + rng.integers(0, 200, 5000))
+    strand = rng.integers(0, 2, 5000).astype(np.uint8)
+    buf, offs = fa.fetch_many(ids, st, sp, strand=strand)
+    assert L.fx_pinned_holds(buf.ctypes.data, buf.nbytes) == 1 and L.fx_pinned_holds(offs.ctypes.data, offs.nbytes) == 1
+    rb, ro, _ = fa._st.blob.fasta_fetch(ids, st, sp, flags_per_query=np.where(strand != 0, 6, 0).astype(np.uint8))
+    assert np.array_equal(ro, offs) and np.array_equal(rb, buf)
+    names = [fa[int(i)].name for i in range(n)]
+    b2, o2 = fa.fetch_many([names[i] for i in ids], st, sp, strand=strand)            # names: one C pass, most of them the same objects
+    assert np.array_equal(b2, buf) and np.array_equal(o2, offs)
+    b3, o3 = fa.fetch_many(tuple(str(names[i]) for i in ids[:100]), st[:100], sp[:100])
+    assert np.array_equal(np.diff(o3), (sp - st)[:100]) and b3.size == int(o3[-1])
+    addr = buf.ctypes.data
+    view = buf[10:20]
+    del buf, b2
+    assert L.fx_pinned_holds(addr, 1) == 1                       # a view keeps the block
+    del view
+    assert L.fx_pinned_holds(addr, 1) == 0                       # ... the last one gives it back to the pool
+    e0, o0 = fa.fetch_many([], [], [])
+    assert e0.size == 0 and o0.tolist() == [0]
+    with pytest.raises(IndexError):
+        fa.fetch_many([0, n], [0, 0], [1, 1])
+    with pytest.raises(ValueError):
+        fa.fetch_many([0, 1], [0, 5], [1, 4])
+    with pytest.raises(ValueError):
+        fa.fetch_many([0], [0], [int(slen[0]) + 1])
+    with pytest.raises(KeyError):
+        fa.fetch_many([names[0], "no such sequence"], [0, 0], [1, 1])
+    # FASTQ: by id, by name list, by pre-packed names
+    fq = fx.Fastq(files["test.fq"])
+    m = len(fq)
+    rid = rng.integers(0, m, 3000)
+    out = fq.fetch_many(rid)
+    t = fq._tab_host
+    rs, rq, ri, rof = fq._st.blob.fastq_fetch(rid, t["rlen"][rid], phred=fq._phred)
+    assert np.array_equal(out["offsets"], rof) and np.array_equal(out["seq"], rs) and np.array_equal(out["qual"], rq) and np.array_equal(out["quali"], ri)
+    only = fq.fetch_many(rid, want=("qual",))
+    assert only["seq"] is None and only["quali"] is None and np.array_equal(only["qual"], rq)
+    rnames = [fq[int(i)].name for i in rid[:300]]
+    byname = fq.fetch_many(rnames)
+    assert np.array_equal(byname["seq"], rs[:int(rof[300])])
+    enc = [x.encode() for x in rnames]
+    po = np.zeros(len(enc) + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in enc], out=po[1:])
+    packed = fq.fetch_many((b"".join(enc), po))
+    assert np.array_equal(packed["seq"], byname["seq"]) and np.array_equal(packed["offsets"], byname["offsets"])
+    with pytest.raises(KeyError, match="no such read"):
+        fq.fetch_many((b"no such read", np.array([0, 12], dtype=np.int64)))
+    with pytest.raises(IndexError):
+        fq.fetch_many([0, m])
+    assert fq.fetch_many([])["offsets"].tolist() == [0]
+    # query arrays that already live in pinned memory go up without a staging copy: same answers
+    pid = _lib.pinned_empty(rid.size, np.int64)
+    pid[:] = rid
+    again = fq.fetch_many(pid)
+    assert np.array_equal(again["seq"], rs)
+
+
 def test_fetch_many_on_loaded_index(fx, files):
     """An index that already exists on disk is LOADED (no scan, index.c:391-429); fetch_many installs its rows
     in HBM (fx_fasta_set_table) and answers by (id, start, stop) exactly like a freshly built one."""
