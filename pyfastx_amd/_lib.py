@@ -359,6 +359,7 @@ class Blob:
     """Owning wrapper of an fx_handle: one staged stream resident in HBM."""
 
     def __init__(self, handle):
+        self.on_close = []
         self._h = handle
 
     # -- constructors -------------------------------------------------------
@@ -404,6 +405,11 @@ class Blob:
 
     def close(self):
         if self._h:
+            for f in self.__dict__.get("on_close", ()):          # owners that cached the raw handle (the C getters of api.Fasta / Fastq) let go of it first
+                try:
+                    f()
+                except Exception:                                # noqa: BLE001
+                    pass
             lib().fx_close(self._h)
             self._h = None
 

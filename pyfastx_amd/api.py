@@ -198,7 +198,14 @@ class Fasta(_fxobj.FastaCore):
                 fa = me()
                 if fa is not None:
                     _bind_fxobj()
-                    fa._core_handle = int(blob._h.value or 0)
+                    # ... and, for a plain file, read single small answers from the page cache (csrc/fxobj.c: seq_fast)
+                    fa._core_stage(int(blob._h.value or 0), None if fa.is_gzip or os.environ.get("FX_NO_HOST_GETTERS") else fa.file_name)
+
+                    def closed(me=me):                          # Blob.close(): the C getters must not keep the freed handle
+                        f2 = me()
+                        if f2 is not None:
+                            f2._core_stage(0)
+                    blob.on_close.append(closed)
             self._st.on_stage = staged
         self._core_upper = 1 if uppercase else 0
         self._index_file = ":memory:" if memory_index else (index_file or file_name + ".fxi")   # index.c:45-61
@@ -1089,8 +1096,9 @@ _fxobj.set_api(0, Sequence)          # the types first; the entry point follows 
 
 
 # =========================================================================== FASTQ
-class Fastq:
-    """pyfastx.Fastq (fastq.c:257-380, 1057-1107)."""
+class Fastq(_fxobj.FastqCore):
+    """pyfastx.Fastq (fastq.c:257-380, 1057-1107).  The subscript -- fq[i], fq[name] -- is the C base type's (csrc/fxobj.c:
+    prepared statements on a read-only connection of its own, fastq.c:454-545); `_counts` and `_phred` are its members."""
 
     def __init__(self, file_name, index_file=None, phred=0, build_index=True, full_index=False, full_name=False,
                  device=0):
@@ -1101,6 +1109,20 @@ class Fastq:
         if _first_nonspace(file_name, self.is_gzip) != ord("@"):                              # fastq.c:300-304
             raise RuntimeError("%s is not plain or gzip compressed fastq formatted file" % file_name)
         self._st = _Staged(file_name, device)
+        import weakref
+        me = weakref.ref(self)
+
+        def staged(blob, me=me):                               # single getters of a plain file: from the page cache (csrc/fxobj.c: read_get_seq)
+            fq = me()
+            if fq is not None:
+                fq._core_stage(int(blob._h.value or 0), None if fq.is_gzip or os.environ.get("FX_NO_HOST_GETTERS") else fq.file_name)
+
+                def closed(me=me):
+                    f2 = me()
+                    if f2 is not None:
+                        f2._core_stage(0)
+                blob.on_close.append(closed)
+        self._st.on_stage = staged
         self._index_file = index_file or file_name + ".fxi"
         self._phred = int(phred)
         self._has_index = bool(build_index)
@@ -1114,6 +1136,12 @@ class Fastq:
             self._create_index()
         if build_index and full_index:
             self._calc_composition()
+        self._bind_core()
+
+    def _bind_core(self):
+        """fq[i] / fq[name] from C once the index is a file on disk (csrc/fxobj.c: FastqCore)."""
+        ok = self._db is not None and self._index_file != ":memory:" and os.path.isfile(self._index_file) and not os.environ.get("FX_NO_C_SUBSCRIPT")
+        self._core_open(self._index_file if ok else None)
 
     def build_index(self):
         if self._db is None:
@@ -1121,6 +1149,7 @@ class Fastq:
                 self._load_index()
             else:
                 self._create_index()
+            self._bind_core()
         self._has_index = True
         return True
 
@@ -1193,8 +1222,9 @@ class Fastq:
             return "<Fastq> %s contains %d reads" % (self.file_name, self._counts)             # fastq.c:547-553
         return "<Fastq> %s" % self.file_name
 
-    def __getitem__(self, item):
-        """pyfastx_fastq_subscript (fastq.c:521-545)."""
+    def _getitem_slow(self, item):
+        """pyfastx_fastq_subscript (fastq.c:521-545) through the sqlite3 module: what the C base type does not take (an
+        index in memory, numpy integers, a library it could not bind)."""
         if isinstance(item, str):
             row = self._db.execute("SELECT * FROM read WHERE name=? LIMIT 1", (item,)).fetchone()
             if row is None:
@@ -1407,8 +1437,7 @@ class Read(_fxobj.ReadCore):
     def _qual_slow(self):
         return _decode(self._bytes(self._qoff, self._read_len))                                # read.c:237-249
 
-    @property
-    def quali(self):
+    def _quali_slow(self):
         """read.c:251-278 -- `qual - phred` (phred 0 -> 33) computed by the read-fetch kernel."""
         _, _, qi, _ = self._fq._st.blob.read_fetch([self._soff], [self._qoff], [self._read_len],
                                                     phred=self._fq._phred, want=("quali",))
@@ -1567,3 +1596,6 @@ def gzip_check(file_name):
 def reverse_complement(seq, device=0):
     """module.c:44-59 -> reverse_complement_seq (util.c:239-249) on the GPU."""
     return _decode(_lib.revcomp_bytes(seq.encode("latin-1"), _F_REV | _F_COMP, device))
+
+
+_fxobj.set_read_type(Read)          # what the C subscript of Fastq makes (csrc/fxobj.c: fqc_subscript)

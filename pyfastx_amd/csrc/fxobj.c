@@ -14,6 +14,10 @@
  *   SeqCore.seq                  line-regular record, a slice: the byte range of sequence.c:498-510, fx_fetch_one straight
  *                                into a stack buffer, PyUnicode_DecodeLatin1
  *
+ *   (round 4) on a PLAIN file whose stream is staged, a getter of at most 64 KiB is answered from the page cache -- pread,
+ *   despace / upper-case / complement / reverse in C (util.c:157-269) -- as the reference answers it (index.c:683-707); the
+ *   resident kernel keeps the gzip inputs, and the GPU everything batched (hard part 7: "a host fast-path")
+ *
  * -- and hand everything else (integer subscripts, whole records, records with an odd line, the first touch that stages the
  * file, ...) to the methods of the Python subclasses (api.Fasta / api.Sequence: `_getitem_slow`, `_subscript_slow`, `_get`),
  * which keep all the behaviour they had.  libfxgpu.so is not linked: the address of fx_fetch_one comes from the ctypes
@@ -26,6 +30,8 @@
 #include <time.h>
 #include <dlfcn.h>
 #include <string.h>
+#include <unistd.h>
+#include <fcntl.h>
 
 typedef int (*fetch_one_fn)(void *h, int64_t off, int64_t blen, int64_t skip, int64_t take, int flags, uint8_t *dst, int64_t *out_len);
 static fetch_one_fn g_fetch_one = NULL;
@@ -38,6 +44,7 @@ typedef struct {
     PyObject *rows;                              /* dict: name -> (ID, chrom, boff, blen, slen, llen, elen, norm, dlen[, reg]) */
     unsigned long long handle;                   /* fx_handle* of the staged stream, 0 until it is staged */
     int upper;                                   /* Fasta(uppercase=True) */
+    int fd;                                      /* the plain file, for single getters from the page cache; -1: none (gzip input, not staged yet) */
 } FastaCore;
 
 typedef struct {
@@ -97,6 +104,64 @@ static PyObject *seq_subscript(SeqCore *s, PyObject *item)
 
 static Py_ssize_t seq_length(SeqCore *s) { return (Py_ssize_t)(s->seq_len > 0 ? s->seq_len : 0); }
 
+/* ---- the byte work of ONE getter on the host: remove_space / remove_space_uppercase (util.c:157-194: bytes 10, 13 and 32
+ * go, nothing else), complement_seq / reverse_seq / reverse_complement_seq (util.c:228-269: IUPAC, case kept, U -> A; bytes
+ * of 128 and more stay as they are) */
+static const uint8_t *comp_table(void)
+{
+    static uint8_t t[256];
+    static int ready = 0;
+    if (!ready) {
+        int i;
+        for (i = 0; i < 256; ++i) {
+            uint8_t c = (uint8_t)i, u = (uint8_t)(c & 0xDF), r = c;
+            if (c < 128 && u >= 'A' && u <= 'Z') {
+                uint8_t m = u;
+                switch (u) {
+                case 'A': m = 'T'; break; case 'T': m = 'A'; break; case 'U': m = 'A'; break;
+                case 'C': m = 'G'; break; case 'G': m = 'C'; break;
+                case 'M': m = 'K'; break; case 'K': m = 'M'; break;
+                case 'R': m = 'Y'; break; case 'Y': m = 'R'; break;
+                case 'V': m = 'B'; break; case 'B': m = 'V'; break;
+                case 'H': m = 'D'; break; case 'D': m = 'H'; break;
+                default: break;
+                }
+                r = (uint8_t)(m | (c & 0x20));
+            }
+            t[i] = r;
+        }
+        ready = 1;
+    }
+    return t;
+}
+/* n raw bytes in b -> at most `take` kept bytes in place, flags as in fxgpu.h (1 upper, 2 reverse, 4 complement, 8 raw) */
+static Py_ssize_t host_bytes(uint8_t *b, Py_ssize_t n, Py_ssize_t take, int flags)
+{
+    Py_ssize_t i, k = 0;
+    if (flags & 8) k = n < take ? n : take;
+    else
+        for (i = 0; i < n && k < take; ++i) {
+            const uint8_t c = b[i];
+            if (c == 10 || c == 13 || c == 32) continue;
+            b[k++] = (flags & 1) && c >= 'a' && c <= 'z' ? (uint8_t)(c - 32) : c;
+        }
+    if (flags & 4) { const uint8_t *t = comp_table(); for (i = 0; i < k; ++i) b[i] = t[b[i]]; }
+    if (flags & 2) for (i = 0; i < k / 2; ++i) { const uint8_t x = b[i]; b[i] = b[k - 1 - i]; b[k - 1 - i] = x; }
+    return k;
+}
+/* n bytes at `off` of the plain file -> bytes read (short at the end of the file), -1 on an error */
+static Py_ssize_t host_read(int fd, uint8_t *b, Py_ssize_t n, long long off)
+{
+    Py_ssize_t got = 0;
+    while (got < n) {
+        const ssize_t r = pread(fd, b + got, (size_t)(n - got), (off_t)(off + got));
+        if (r < 0) return -1;
+        if (r == 0) break;
+        got += r;
+    }
+    return got;
+}
+
 /* the bytes of a slice of a line-regular record, flags as in fxgpu.h (1 upper, 2 reverse, 4 complement); NULL + no error
  * set: not a case for the fast path */
 static PyObject *seq_fast(SeqCore *s, int flags)
@@ -105,7 +170,7 @@ static PyObject *seq_fast(SeqCore *s, int flags)
     long long bpl, a, b, off, bl;
     int64_t got = 0;
     uint8_t buf[FX_GETTER_CAP];
-    if (s->complete || s->reg != 1 || s->seq_len <= 0 || s->seq_len > FX_GETTER_CAP || !g_fetch_one) return NULL;
+    if (s->complete || s->reg != 1 || s->seq_len <= 0 || s->seq_len > FX_GETTER_CAP || !s->fa) return NULL;
     if (!PyObject_TypeCheck(s->fa, &FastaCoreType)) return NULL;
     fa = (FastaCore *)s->fa;
     if (!fa->handle) return NULL;
@@ -114,6 +179,11 @@ static PyObject *seq_fast(SeqCore *s, int flags)
     a = s->start - 1; b = s->end;
     off = s->offset + a + s->end_len * (a / bpl);                         /* sequence.c:498-510 */
     bl = (b - a) + (b / bpl - a / bpl) * s->end_len;
+    if (fa->fd >= 0 && bl <= FX_GETTER_CAP) {                             /* a plain file: the page cache answers (index.c:683-707) */
+        const Py_ssize_t n = host_read(fa->fd, buf, (Py_ssize_t)bl, off);
+        if (n >= 0) return PyUnicode_DecodeLatin1((const char *)buf, host_bytes(buf, n, (Py_ssize_t)s->seq_len, flags | (fa->upper ? 1 : 0)), NULL);
+    }
+    if (!g_fetch_one) return NULL;
     if (g_fetch_one((void *)(uintptr_t)fa->handle, off, bl, 0, s->seq_len, flags | (fa->upper ? 1 : 0), buf, &got) != 0) return NULL;
     return PyUnicode_DecodeLatin1((const char *)buf, (Py_ssize_t)got, NULL);
 }
@@ -127,7 +197,7 @@ static PyObject *seq_get(SeqCore *s, int flags)
         if (!v) return NULL;
         s->reg = (signed char)(PyObject_IsTrue(v) ? 1 : 0);
         Py_DECREF(v);
-        if (PyObject_TypeCheck(s->fa, &FastaCoreType)) {                  /* ... and keep it with the row, for the next fa[name] */
+        if (s->fa && s->name && PyObject_TypeCheck(s->fa, &FastaCoreType)) {  /* ... and keep it with the row, for the next fa[name] */
             FastaCore *fa = (FastaCore *)s->fa;
             PyObject *row = fa->rows ? PyDict_GetItem(fa->rows, s->name) : NULL;
             if (row && PyTuple_Check(row) && PyTuple_GET_SIZE(row) == 9) {
@@ -152,7 +222,6 @@ static PyObject *seq_complement(SeqCore *s, void *c) { (void)c; return seq_get(s
 static PyObject *seq_antisense(SeqCore *s, void *c) { (void)c; return seq_get(s, 6); }
 
 static PyMemberDef seq_members[] = {
-    {"_fa", T_OBJECT_EX, offsetof(SeqCore, fa), 0, NULL}, {"_name", T_OBJECT_EX, offsetof(SeqCore, name), 0, NULL},
     {"id", T_LONGLONG, offsetof(SeqCore, id), 0, NULL}, {"_offset", T_LONGLONG, offsetof(SeqCore, offset), 0, NULL},
     {"_byte_len", T_LONGLONG, offsetof(SeqCore, byte_len), 0, NULL}, {"_full_len", T_LONGLONG, offsetof(SeqCore, full_len), 0, NULL},
     {"_line_len", T_LONGLONG, offsetof(SeqCore, line_len), 0, NULL}, {"_end_len", T_LONGLONG, offsetof(SeqCore, end_len), 0, NULL},
@@ -160,7 +229,25 @@ static PyMemberDef seq_members[] = {
     {"start", T_LONGLONG, offsetof(SeqCore, start), 0, NULL}, {"end", T_LONGLONG, offsetof(SeqCore, end), 0, NULL},
     {"_seq_len", T_LONGLONG, offsetof(SeqCore, seq_len), 0, NULL}, {"_complete", T_BOOL, offsetof(SeqCore, complete), 0, NULL},
     {"_reg", T_BYTE, offsetof(SeqCore, reg), 0, NULL}, {"_prefetched", T_OBJECT, offsetof(SeqCore, pre), 0, NULL}, {NULL, 0, 0, 0, NULL}};
+/* _fa / _name: plain attributes, except that they cannot be deleted (the C paths read them without asking) */
+static PyObject *seq_get_fa(SeqCore *s, void *c) { (void)c; return Py_NewRef(s->fa ? s->fa : Py_None); }
+static PyObject *seq_get_name(SeqCore *s, void *c) { (void)c; return Py_NewRef(s->name ? s->name : Py_None); }
+static int seq_set_fa(SeqCore *s, PyObject *v, void *c)
+{
+    (void)c;
+    if (!v) { PyErr_SetString(PyExc_TypeError, "_fa cannot be deleted"); return -1; }
+    Py_XSETREF(s->fa, Py_NewRef(v));
+    return 0;
+}
+static int seq_set_name(SeqCore *s, PyObject *v, void *c)
+{
+    (void)c;
+    if (!v) { PyErr_SetString(PyExc_TypeError, "_name cannot be deleted"); return -1; }
+    Py_XSETREF(s->name, Py_NewRef(v));
+    return 0;
+}
 static PyGetSetDef seq_getset[] = {
+    {"_fa", (getter)seq_get_fa, (setter)seq_set_fa, NULL, NULL}, {"_name", (getter)seq_get_name, (setter)seq_set_name, NULL, NULL},
     {"seq", (getter)seq_seq, NULL, NULL, NULL}, {"reverse", (getter)seq_reverse, NULL, NULL, NULL},
     {"complement", (getter)seq_complement, NULL, NULL, NULL}, {"antisense", (getter)seq_antisense, NULL, NULL, NULL},
     {NULL, NULL, NULL, NULL, NULL}};
@@ -174,6 +261,7 @@ static PyTypeObject SeqCoreType = {
 /* ---------------------------------------------------------------- FastaCore */
 static void fasta_dealloc(FastaCore *f)
 {
+    if (f->fd >= 0) close(f->fd);
     Py_XDECREF(f->rows);
     Py_TYPE(f)->tp_free((PyObject *)f);
 }
@@ -182,7 +270,7 @@ static PyObject *fasta_new(PyTypeObject *type, PyObject *args, PyObject *kw)
 {
     FastaCore *f = (FastaCore *)type->tp_alloc(type, 0);
     (void)args; (void)kw;
-    if (f) { f->rows = PyDict_New(); if (!f->rows) { Py_DECREF(f); return NULL; } }
+    if (f) { f->fd = -1; f->rows = PyDict_New(); if (!f->rows) { Py_DECREF(f); return NULL; } }
     return (PyObject *)f;
 }
 
@@ -211,15 +299,35 @@ static PyObject *fasta_subscript(FastaCore *f, PyObject *key)
 }
 
 static PyObject *fasta_tag(FastaCore *f, void *c) { (void)f; (void)c; Py_RETURN_TRUE; }
+/* _core_stage(handle, path | None): the stream is staged under this fx_handle (0: it is gone -- Blob.close -- and the C
+ * getters stop using it); path: the PLAIN file behind it, opened here for the getters that the page cache answers */
+static PyObject *fasta_stage(FastaCore *f, PyObject *args)
+{
+    unsigned long long h = 0;
+    PyObject *path = Py_None;
+    if (!PyArg_ParseTuple(args, "K|O", &h, &path)) return NULL;
+    if (f->fd >= 0) { close(f->fd); f->fd = -1; }
+    f->handle = h;
+    if (h && path != Py_None) {
+        PyObject *b = NULL;
+        if (!PyUnicode_FSConverter(path, &b)) return NULL;
+        f->fd = open(PyBytes_AS_STRING(b), O_RDONLY | O_CLOEXEC);         /* -1: the resident kernel answers */
+        Py_DECREF(b);
+    }
+    Py_RETURN_NONE;
+}
+static PyMethodDef fasta_methods[] = {
+    {"_core_stage", (PyCFunction)fasta_stage, METH_VARARGS, "_core_stage(handle, plain path | None)"}, {NULL, NULL, 0, NULL}};
 static PyMemberDef fasta_members[] = {
-    {"_rows_by_name", T_OBJECT_EX, offsetof(FastaCore, rows), 0, NULL}, {"_core_handle", T_ULONGLONG, offsetof(FastaCore, handle), 0, NULL},
+    {"_rows_by_name", T_OBJECT_EX, offsetof(FastaCore, rows), READONLY, NULL}, {"_core_handle", T_ULONGLONG, offsetof(FastaCore, handle), READONLY, NULL},
+    {"_core_fd", T_INT, offsetof(FastaCore, fd), READONLY, NULL},
     {"_core_upper", T_INT, offsetof(FastaCore, upper), 0, NULL}, {NULL, 0, 0, 0, NULL}};
 static PyGetSetDef fasta_getset[] = {{"_core_tag", (getter)fasta_tag, NULL, NULL, NULL}, {NULL, NULL, NULL, NULL, NULL}};
 static PyMappingMethods fasta_mapping = {NULL, (binaryfunc)fasta_subscript, NULL};     /* (__len__ stays with the Python class) */
 static PyTypeObject FastaCoreType = {
     PyVarObject_HEAD_INIT(NULL, 0).tp_name = "pyfastx_amd._fxobj.FastaCore", .tp_basicsize = sizeof(FastaCore),
     .tp_dealloc = (destructor)fasta_dealloc, .tp_flags = Py_TPFLAGS_DEFAULT | Py_TPFLAGS_BASETYPE, .tp_new = fasta_new,
-    .tp_members = fasta_members, .tp_getset = fasta_getset, .tp_as_mapping = &fasta_mapping,
+    .tp_members = fasta_members, .tp_methods = fasta_methods, .tp_getset = fasta_getset, .tp_as_mapping = &fasta_mapping,
     .tp_doc = "name -> row cache and subscript fast path of pyfastx_amd.Fasta"};
 
 /* ------------------------------------------------------------------- module */
@@ -440,6 +548,72 @@ static PyTypeObject FastxIterType = {
     .tp_new = fxi_new,
 };
 
+/* ------------------------------------------------------------------ RowCursor: a table of the index file stepped from C
+ * The reference iterates an indexed file with sqlite3_step + sqlite3_column_* per record (fastq.c:566-596, index.c:525-560);
+ * through Python's sqlite3 module every row becomes a tuple of Python objects first (0.5-0.9 us per row).  This cursor opens
+ * its own READ-ONLY connection to the index file through the SAME library the sqlite3 module has loaded (dlopen: no build
+ * dependency) and hands out a batch of rows as one list of names + one block of int64 columns.
+ *   RowCursor(path, sql)   sql: first column an integer, second a TEXT, the others integers
+ *   .fetch(n) -> None at the end, else (k, names, cols): cols = bytes of (ncol - 1) x k int64, column after column  */
+typedef struct sqlite3 sqlite3;
+typedef struct sqlite3_stmt sqlite3_stmt;
+static struct {
+    int state;                                                   /* 0 not tried, 1 loaded, -1 not there */
+    int (*open_v2)(const char *, sqlite3 **, int, const char *);
+    int (*close_v2)(sqlite3 *);
+    int (*prepare_v2)(sqlite3 *, const char *, int, sqlite3_stmt **, const char **);
+    int (*step)(sqlite3_stmt *);
+    int (*finalize)(sqlite3_stmt *);
+    int (*column_count)(sqlite3_stmt *);
+    long long (*column_int64)(sqlite3_stmt *, int);
+    const unsigned char *(*column_text)(sqlite3_stmt *, int);
+    int (*column_bytes)(sqlite3_stmt *, int);
+    const char *(*errmsg)(sqlite3 *);
+    int (*busy_timeout)(sqlite3 *, int);
+    int (*bind_int64)(sqlite3_stmt *, int, long long);
+    int (*bind_text)(sqlite3_stmt *, int, const char *, int, void (*)(void *));
+    int (*reset)(sqlite3_stmt *);
+} SQ;
+static int sq_load(void)
+{
+    void *h;
+    if (SQ.state) return SQ.state > 0;
+    SQ.state = -1;
+    /* ONLY the copy the sqlite3 module of this process already uses (RTLD_NOLOAD): a second copy of SQLite on the same index
+     * file would drop the first one's POSIX locks when it closes its descriptor (SQLite "how to corrupt", 2.2).  An
+     * interpreter whose _sqlite3 carries SQLite inside itself has no such library: the callers then keep to the module's rows. */
+    h = dlopen("libsqlite3.so.0", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (!h) h = dlopen("libsqlite3.so", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (!h) return 0;
+#define SQ_SYM(field, name) do { *(void **)&SQ.field = dlsym(h, name); if (!SQ.field) return 0; } while (0)
+    SQ_SYM(open_v2, "sqlite3_open_v2"); SQ_SYM(close_v2, "sqlite3_close_v2"); SQ_SYM(prepare_v2, "sqlite3_prepare_v2");
+    SQ_SYM(step, "sqlite3_step"); SQ_SYM(finalize, "sqlite3_finalize"); SQ_SYM(column_count, "sqlite3_column_count");
+    SQ_SYM(column_int64, "sqlite3_column_int64"); SQ_SYM(column_text, "sqlite3_column_text"); SQ_SYM(column_bytes, "sqlite3_column_bytes");
+    SQ_SYM(errmsg, "sqlite3_errmsg"); SQ_SYM(busy_timeout, "sqlite3_busy_timeout");
+    SQ_SYM(bind_int64, "sqlite3_bind_int64"); SQ_SYM(bind_text, "sqlite3_bind_text"); SQ_SYM(reset, "sqlite3_reset");
+#undef SQ_SYM
+    SQ.state = 1;
+    return 1;
+}
+/* ------------------------------------------------------------------ FastqCore: the C base of pyfastx_amd.Fastq
+ * pyfastx_fastq_subscript (fastq.c:521-545) is C in the reference: a prepared statement stepped once (fastq.c:454-519) and a
+ * Read filled from its columns.  Here the same, on a read-only connection of its own to the index file (through the SQLite
+ * library the sqlite3 module has loaded): fq[i] / fq[name] make the Read without entering the interpreter; the Read's
+ * .seq / .qual / .quali of a PLAIN file come from the page cache (pread, read.c:37-45, 152-167, 237-278), of a gzip file
+ * from the resident kernel through the Python methods as before.  Anything the C side cannot do (an index in memory, a
+ * library it cannot bind, keys of other types) goes to the subclass's _getitem_slow. */
+typedef struct {
+    PyObject_HEAD
+    sqlite3 *db;
+    sqlite3_stmt *by_id, *by_name;
+    unsigned long long handle;                   /* fx_handle* of the staged stream, 0 until it is staged */
+    int fd;                                      /* the plain file (-1: none) */
+    int phred;                                   /* Fastq(phred=) or meta.phred; 0: 33 (read.c:268) */
+    long long counts;
+} FastqCore;
+static PyTypeObject FastqCoreType;
+static PyTypeObject *g_read_type = NULL;         /* api.Read (subclass of ReadCore) */
+
 /* ------------------------------------------------------------------ Read: the C base of pyfastx_amd.Read (read.c:288-323)
  * The fields of a row of the `read` table and, for objects that come out of Fastq's iterator, the sequence and quality
  * strings that came with the iterator's batch.  read_batch() makes the objects of a whole batch in one call. */
@@ -476,12 +650,56 @@ static PyMemberDef read_members[] = {
     {"_pre_seq", T_OBJECT, offsetof(ReadCore, pre_seq), READONLY, "the sequence, when it came with the iterator's batch (else None)"},
     {"_pre_qual", T_OBJECT, offsetof(ReadCore, pre_qual), READONLY, "the quality string, likewise"},
     {NULL, 0, 0, 0, NULL}};
-/* .seq / .qual: the string that came with the iterator's batch, else the subclass's _seq_slow() / _qual_slow() (one fetch) */
-static PyObject *read_get_seq(ReadCore *r, void *c) { (void)c; return r->pre_seq ? Py_NewRef(r->pre_seq) : PyObject_CallMethod((PyObject *)r, "_seq_slow", NULL); }
-static PyObject *read_get_qual(ReadCore *r, void *c) { (void)c; return r->pre_qual ? Py_NewRef(r->pre_qual) : PyObject_CallMethod((PyObject *)r, "_qual_slow", NULL); }
+/* read_len bytes at `off` of the plain file behind the read's Fastq into buf (FX_GETTER_CAP bytes) -> 1; 0: not a case
+ * for the host path (gzip input, stream not staged, a long read, a short file) */
+static int read_host_bytes(ReadCore *r, long long off, uint8_t *buf)
+{
+    FastqCore *fq;
+    if (!r->fq || !PyObject_TypeCheck(r->fq, &FastqCoreType)) return 0;
+    fq = (FastqCore *)r->fq;
+    if (fq->fd < 0 || !fq->handle || r->read_len <= 0 || r->read_len > FX_GETTER_CAP) return 0;
+    return host_read(fq->fd, buf, (Py_ssize_t)r->read_len, off) == (Py_ssize_t)r->read_len;
+}
+/* .seq / .qual: the string that came with the iterator's batch, else the page cache (a plain file), else the subclass's
+ * _seq_slow() / _qual_slow() (one fetch through the resident kernel) */
+static PyObject *read_get_seq(ReadCore *r, void *c)
+{
+    uint8_t buf[FX_GETTER_CAP];
+    (void)c;
+    if (r->pre_seq) return Py_NewRef(r->pre_seq);
+    if (read_host_bytes(r, r->soff, buf)) return PyUnicode_DecodeLatin1((const char *)buf, (Py_ssize_t)r->read_len, NULL);      /* read.c:152-167 */
+    return PyObject_CallMethod((PyObject *)r, "_seq_slow", NULL);
+}
+static PyObject *read_get_qual(ReadCore *r, void *c)
+{
+    uint8_t buf[FX_GETTER_CAP];
+    (void)c;
+    if (r->pre_qual) return Py_NewRef(r->pre_qual);
+    if (read_host_bytes(r, r->qoff, buf)) return PyUnicode_DecodeLatin1((const char *)buf, (Py_ssize_t)r->read_len, NULL);      /* read.c:237-249 */
+    return PyObject_CallMethod((PyObject *)r, "_qual_slow", NULL);
+}
+/* .quali: qual - phred, a list of ints (read.c:251-278; the bytes are C chars there: signed) */
+static PyObject *read_get_quali(ReadCore *r, void *c)
+{
+    uint8_t buf[FX_GETTER_CAP];
+    (void)c;
+    if (read_host_bytes(r, r->qoff, buf)) {
+        const int phred = ((FastqCore *)r->fq)->phred ? ((FastqCore *)r->fq)->phred : 33;                 /* read.c:268 */
+        PyObject *l = PyList_New((Py_ssize_t)r->read_len);
+        Py_ssize_t i;
+        for (i = 0; l && i < (Py_ssize_t)r->read_len; ++i) {
+            PyObject *v = PyLong_FromLong((long)(signed char)buf[i] - phred);
+            if (!v) { Py_CLEAR(l); break; }
+            PyList_SET_ITEM(l, i, v);
+        }
+        return l;
+    }
+    return PyObject_CallMethod((PyObject *)r, "_quali_slow", NULL);
+}
 static PyGetSetDef read_getset[] = {
     {"seq", (getter)read_get_seq, NULL, "read.c:152-167", NULL},
     {"qual", (getter)read_get_qual, NULL, "read.c:237-249", NULL},
+    {"quali", (getter)read_get_quali, NULL, "read.c:251-278", NULL},
     {NULL, NULL, NULL, NULL, NULL}};
 static Py_ssize_t read_length(ReadCore *r) { return (Py_ssize_t)r->read_len; }
 static PySequenceMethods read_as_sequence = {.sq_length = (lenfunc)read_length};
@@ -497,6 +715,132 @@ static PyTypeObject ReadCoreType = {
     .tp_init = (initproc)read_init,
     .tp_new = PyType_GenericNew,
 };
+
+/* ---- FastqCore methods */
+static void fqc_close_db(FastqCore *f)
+{
+    if (f->by_id) { SQ.finalize(f->by_id); f->by_id = NULL; }
+    if (f->by_name) { SQ.finalize(f->by_name); f->by_name = NULL; }
+    if (f->db) { SQ.close_v2(f->db); f->db = NULL; }
+}
+static void fqc_dealloc(FastqCore *f)
+{
+    fqc_close_db(f);
+    if (f->fd >= 0) close(f->fd);
+    Py_TYPE(f)->tp_free((PyObject *)f);
+}
+static PyObject *fqc_new(PyTypeObject *type, PyObject *args, PyObject *kw)
+{
+    FastqCore *f = (FastqCore *)type->tp_alloc(type, 0);
+    (void)args; (void)kw;
+    if (f) f->fd = -1;
+    return (PyObject *)f;
+}
+/* _core_open(index file | None) -> True when fq[i] / fq[name] are served from C */
+static PyObject *fqc_open(FastqCore *f, PyObject *arg)
+{
+    PyObject *b = NULL;
+    int ok;
+    if (f->db || f->by_id || f->by_name) fqc_close_db(f);
+    if (arg == Py_None || !sq_load()) Py_RETURN_FALSE;
+    if (!PyUnicode_FSConverter(arg, &b)) return NULL;
+    ok = SQ.open_v2(PyBytes_AS_STRING(b), &f->db, 1 /* SQLITE_OPEN_READONLY */, NULL) == 0 &&
+         SQ.prepare_v2(f->db, "SELECT ID, name, dlen, rlen, soff, qoff FROM read WHERE ID=? LIMIT 1", -1, &f->by_id, NULL) == 0 &&      /* fastq.c:454-484 */
+         SQ.prepare_v2(f->db, "SELECT ID, name, dlen, rlen, soff, qoff FROM read WHERE name=? LIMIT 1", -1, &f->by_name, NULL) == 0;   /* fastq.c:486-519 */
+    Py_DECREF(b);
+    if (!ok) { fqc_close_db(f); Py_RETURN_FALSE; }
+    SQ.busy_timeout(f->db, 5000);
+    Py_RETURN_TRUE;
+}
+static PyObject *fqc_stage(FastqCore *f, PyObject *args)
+{
+    unsigned long long h = 0;
+    PyObject *path = Py_None;
+    if (!PyArg_ParseTuple(args, "K|O", &h, &path)) return NULL;
+    if (f->fd >= 0) { close(f->fd); f->fd = -1; }
+    f->handle = h;
+    if (h && path != Py_None) {
+        PyObject *b = NULL;
+        if (!PyUnicode_FSConverter(path, &b)) return NULL;
+        f->fd = open(PyBytes_AS_STRING(b), O_RDONLY | O_CLOEXEC);
+        Py_DECREF(b);
+    }
+    Py_RETURN_NONE;
+}
+/* the row the statement stands on -> a Read (name: the key itself when the caller asked by name) */
+static PyObject *fqc_read_of_row(FastqCore *f, sqlite3_stmt *st, PyObject *name)
+{
+    ReadCore *r = (ReadCore *)g_read_type->tp_alloc(g_read_type, 0);
+    if (!r) return NULL;
+    r->fq = Py_NewRef((PyObject *)f);
+    r->id = SQ.column_int64(st, 0);
+    if (name) r->name = Py_NewRef(name);
+    else {
+        const unsigned char *t = SQ.column_text(st, 1);
+        r->name = PyUnicode_DecodeUTF8(t ? (const char *)t : "", t ? SQ.column_bytes(st, 1) : 0, "surrogateescape");
+    }
+    r->desc_len = SQ.column_int64(st, 2); r->read_len = SQ.column_int64(st, 3);
+    r->soff = SQ.column_int64(st, 4); r->qoff = SQ.column_int64(st, 5);
+    if (!r->name) { Py_DECREF(r); return NULL; }
+    return (PyObject *)r;
+}
+static PyObject *fqc_subscript(FastqCore *f, PyObject *key)
+{
+    if (f->by_id && g_read_type && PyLong_CheckExact(key)) {                     /* fastq.c:527-534 */
+        int ovf = 0;
+        long long i = PyLong_AsLongLongAndOverflow(key, &ovf);
+        if (!ovf) {
+            PyObject *r = NULL;
+            int rc;
+            if (i < 0) i += f->counts;
+            if (i >= f->counts) { PyErr_SetString(PyExc_IndexError, "index out of range"); return NULL; }
+            SQ.bind_int64(f->by_id, 1, i + 1);
+            rc = SQ.step(f->by_id);
+            if (rc == 100) r = fqc_read_of_row(f, f->by_id, NULL);
+            else if (rc == 101) PyErr_SetString(PyExc_IndexError, "Index Error");
+            SQ.reset(f->by_id);
+            if (r || PyErr_Occurred()) return r;                                   /* (another code: the slow path reports it) */
+        }
+    } else if (f->by_name && g_read_type && PyUnicode_CheckExact(key)) {         /* fastq.c:535-541 */
+        Py_ssize_t l = 0;
+        const char *t = PyUnicode_AsUTF8AndSize(key, &l);
+        if (t) {
+            PyObject *r = NULL;
+            int rc;
+            SQ.bind_text(f->by_name, 1, t, (int)l, NULL /* SQLITE_STATIC: the key outlives the step */);
+            rc = SQ.step(f->by_name);
+            if (rc == 100) r = fqc_read_of_row(f, f->by_name, key);
+            else if (rc == 101) PyErr_Format(PyExc_KeyError, "%U does not exist in fastq file", key);
+            SQ.reset(f->by_name);
+            if (r || PyErr_Occurred()) return r;
+        } else PyErr_Clear();                                                      /* lone surrogates: the slow path encodes them its way */
+    }
+    return PyObject_CallMethod((PyObject *)f, "_getitem_slow", "O", key);
+}
+static PyMethodDef fqc_methods[] = {
+    {"_core_open", (PyCFunction)fqc_open, METH_O, "_core_open(index file | None) -> bool"},
+    {"_core_stage", (PyCFunction)fqc_stage, METH_VARARGS, "_core_stage(handle, plain path | None)"},
+    {NULL, NULL, 0, NULL}};
+static PyMemberDef fqc_members[] = {
+    {"_counts", T_LONGLONG, offsetof(FastqCore, counts), 0, "reads in the index"},
+    {"_phred", T_INT, offsetof(FastqCore, phred), 0, "quality offset (0: 33)"},
+    {"_core_handle", T_ULONGLONG, offsetof(FastqCore, handle), READONLY, NULL},
+    {"_core_fd", T_INT, offsetof(FastqCore, fd), READONLY, NULL},
+    {NULL, 0, 0, 0, NULL}};
+static PyMappingMethods fqc_mapping = {NULL, (binaryfunc)fqc_subscript, NULL};      /* (__len__ stays with the Python class) */
+static PyTypeObject FastqCoreType = {
+    PyVarObject_HEAD_INIT(NULL, 0).tp_name = "pyfastx_amd._fxobj.FastqCore", .tp_basicsize = sizeof(FastqCore),
+    .tp_dealloc = (destructor)fqc_dealloc, .tp_flags = Py_TPFLAGS_DEFAULT | Py_TPFLAGS_BASETYPE, .tp_new = fqc_new,
+    .tp_members = fqc_members, .tp_methods = fqc_methods, .tp_as_mapping = &fqc_mapping,
+    .tp_doc = "prepared statements and subscript fast path of pyfastx_amd.Fastq"};
+static PyObject *mod_set_read_type(PyObject *m, PyObject *t)
+{
+    (void)m;
+    if (!PyType_Check(t) || !PyType_IsSubtype((PyTypeObject *)t, &ReadCoreType)) { PyErr_SetString(PyExc_TypeError, "the read type must derive from ReadCore"); return NULL; }
+    Py_XDECREF(g_read_type);
+    g_read_type = (PyTypeObject *)Py_NewRef(t);
+    Py_RETURN_NONE;
+}
 
 /* read_batch(ReadType, fq, rows, seq, qual, offs) -> list: rows = the (ID, name, dlen, rlen, soff, qoff) tuples of the batch,
  * seq / qual = the bytes of their sequence / quality lines one behind the other, offs = int64[k + 1] */
@@ -544,46 +888,6 @@ done:
     return out;
 }
 
-/* ------------------------------------------------------------------ RowCursor: a table of the index file stepped from C
- * The reference iterates an indexed file with sqlite3_step + sqlite3_column_* per record (fastq.c:566-596, index.c:525-560);
- * through Python's sqlite3 module every row becomes a tuple of Python objects first (0.5-0.9 us per row).  This cursor opens
- * its own READ-ONLY connection to the index file through the SAME library the sqlite3 module has loaded (dlopen: no build
- * dependency) and hands out a batch of rows as one list of names + one block of int64 columns.
- *   RowCursor(path, sql)   sql: first column an integer, second a TEXT, the others integers
- *   .fetch(n) -> None at the end, else (k, names, cols): cols = bytes of (ncol - 1) x k int64, column after column  */
-typedef struct sqlite3 sqlite3;
-typedef struct sqlite3_stmt sqlite3_stmt;
-static struct {
-    int state;                                                   /* 0 not tried, 1 loaded, -1 not there */
-    int (*open_v2)(const char *, sqlite3 **, int, const char *);
-    int (*close_v2)(sqlite3 *);
-    int (*prepare_v2)(sqlite3 *, const char *, int, sqlite3_stmt **, const char **);
-    int (*step)(sqlite3_stmt *);
-    int (*finalize)(sqlite3_stmt *);
-    int (*column_count)(sqlite3_stmt *);
-    long long (*column_int64)(sqlite3_stmt *, int);
-    const unsigned char *(*column_text)(sqlite3_stmt *, int);
-    int (*column_bytes)(sqlite3_stmt *, int);
-    const char *(*errmsg)(sqlite3 *);
-    int (*busy_timeout)(sqlite3 *, int);
-} SQ;
-static int sq_load(void)
-{
-    void *h;
-    if (SQ.state) return SQ.state > 0;
-    SQ.state = -1;
-    h = dlopen("libsqlite3.so.0", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("libsqlite3.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) return 0;
-#define SQ_SYM(field, name) do { *(void **)&SQ.field = dlsym(h, name); if (!SQ.field) return 0; } while (0)
-    SQ_SYM(open_v2, "sqlite3_open_v2"); SQ_SYM(close_v2, "sqlite3_close_v2"); SQ_SYM(prepare_v2, "sqlite3_prepare_v2");
-    SQ_SYM(step, "sqlite3_step"); SQ_SYM(finalize, "sqlite3_finalize"); SQ_SYM(column_count, "sqlite3_column_count");
-    SQ_SYM(column_int64, "sqlite3_column_int64"); SQ_SYM(column_text, "sqlite3_column_text"); SQ_SYM(column_bytes, "sqlite3_column_bytes");
-    SQ_SYM(errmsg, "sqlite3_errmsg"); SQ_SYM(busy_timeout, "sqlite3_busy_timeout");
-#undef SQ_SYM
-    SQ.state = 1;
-    return 1;
-}
 typedef struct { PyObject_HEAD sqlite3 *db; sqlite3_stmt *st; int ncol, done; } RowCursor;
 static void rc_close(RowCursor *c)
 {
@@ -607,6 +911,7 @@ static PyObject *rc_new(PyTypeObject *type, PyObject *args, PyObject *kw)
         Py_DECREF(c);
         return NULL;
     }
+    SQ.busy_timeout(c->db, 5000);                                /* a writer in another process: wait, do not fail the iteration */
     c->ncol = SQ.column_count(c->st);
     if (c->ncol < 2) { PyErr_SetString(PyExc_ValueError, "RowCursor: the statement must yield an integer, a text and integers"); rc_close(c); Py_DECREF(c); return NULL; }
     return (PyObject *)c;
@@ -864,6 +1169,7 @@ fail:
 }
 
 static PyMethodDef mod_methods[] = {
+    {"set_read_type", mod_set_read_type, METH_O, "set_read_type(Read type): what fq[i] / fq[name] make"},
     {"ids_of_names", mod_ids_of_names, METH_VARARGS, "ids_of_names(names, index dict, out int64 buffer) -> -1 | position of the first unknown name"},
     {"pack_names", mod_pack_names, METH_O, "pack_names(names) -> (bytes + 16 zero bytes, int64 offsets[n + 1] as bytes)"},
     {"seq_batch_cols", mod_seq_batch_cols, METH_VARARGS, "seq_batch_cols(SeqType, fa, names, cols, buf, offs, lens, sel) -> list of Sequence objects"},
@@ -878,7 +1184,7 @@ static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_fxobj", "C base typ
 PyMODINIT_FUNC PyInit__fxobj(void)
 {
     PyObject *m;
-    if (PyType_Ready(&SeqCoreType) < 0 || PyType_Ready(&FastaCoreType) < 0 || PyType_Ready(&FastxIterType) < 0 || PyType_Ready(&ReadCoreType) < 0 || PyType_Ready(&RowCursorType) < 0 || PyType_Ready(&PinnedBufType) < 0) return NULL;
+    if (PyType_Ready(&SeqCoreType) < 0 || PyType_Ready(&FastaCoreType) < 0 || PyType_Ready(&FastxIterType) < 0 || PyType_Ready(&ReadCoreType) < 0 || PyType_Ready(&RowCursorType) < 0 || PyType_Ready(&PinnedBufType) < 0 || PyType_Ready(&FastqCoreType) < 0) return NULL;
     m = PyModule_Create(&moddef);
     if (!m) return NULL;
     Py_INCREF(&SeqCoreType); Py_INCREF(&FastaCoreType);
@@ -890,6 +1196,8 @@ PyMODINIT_FUNC PyInit__fxobj(void)
     PyModule_AddObject(m, "ReadCore", (PyObject *)&ReadCoreType);
     Py_INCREF(&RowCursorType);
     PyModule_AddObject(m, "RowCursor", (PyObject *)&RowCursorType);
+    Py_INCREF(&FastqCoreType);
+    PyModule_AddObject(m, "FastqCore", (PyObject *)&FastqCoreType);
     Py_INCREF(&PinnedBufType);
     PyModule_AddObject(m, "PinnedBuf", (PyObject *)&PinnedBufType);
     return m;

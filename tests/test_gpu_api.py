@@ -292,6 +292,41 @@ def test_fetch_many_layout_by_the_library(fx, files):
     assert np.array_equal(again["seq"], rs)
 
 
+def test_single_getters_page_cache_and_resident_kernel_agree(fx, files, monkeypatch):
+    """Round 4: on a plain file a single small getter is answered from the page cache by the C object layer (csrc/fxobj.c);
+    with FX_NO_HOST_GETTERS=1 (and for every gzip input) the same getter goes to the resident kernel (fx_fetch_one).  Same
+    strings either way, and both equal the goldens' (which come from the compiled reference)."""
+    g = load_golden("fasta_fixture")["test.fa"]
+    fa = fx.Fasta(files["test.fa"])
+    fa[0][0:5].seq
+    assert fa._core_fd >= 0 and fa._core_handle != 0
+    monkeypatch.setenv("FX_NO_HOST_GETTERS", "1")
+    fb = fx.Fasta(files["test.fa"])
+    fb[0][0:5].seq
+    assert fb._core_fd == -1 and fb._core_handle != 0
+    for x in g["fetches"]:
+        a, b = fa[x["id"] - 1][x["start"]:x["stop"]], fb[x["id"] - 1][x["start"]:x["stop"]]
+        assert a.seq == b.seq == x["seq"] and a.antisense == b.antisense == x["antisense"]
+        assert a.reverse == b.reverse and a.complement == b.complement
+    gq = load_golden("fastq_fixture")["test.fq"]
+    fq = fx.Fastq(files["test.fq"])
+    monkeypatch.delenv("FX_NO_HOST_GETTERS")
+    fr = fx.Fastq(files["test.fq"])
+    fr[0].seq, fq[0].seq
+    assert fr._core_fd >= 0 and fq._core_fd == -1
+    for r in gq["reads"]:
+        a, b = fr[r["i"]], fq[r["i"]]
+        assert (a.seq, a.qual, a.quali) == (b.seq, b.qual, b.quali) == (r["seq"], r["qual"], r["quali"])
+        assert fr[r["name"]].id == a.id == fq[r["name"]].id
+    monkeypatch.setenv("FX_NO_C_SUBSCRIPT", "1")                # ... and the subscript through the sqlite3 module gives the same Reads
+    fs = fx.Fastq(files["test.fq"])
+    for r in gq["reads"][:20]:
+        a = fs[r["i"]]
+        assert (a.name, a.seq, a.id) == (r["name"], r["seq"], fr[r["i"]].id)
+    fa._st.blob.close()                                          # ADVICE r3: a closed blob takes the C getters' handle with it
+    assert fa._core_handle == 0 and fa._core_fd == -1
+
+
 def test_fetch_many_on_loaded_index(fx, files):
     """An index that already exists on disk is LOADED (no scan, index.c:391-429); fetch_many installs its rows
     in HBM (fx_fasta_set_table) and answers by (id, start, stop) exactly like a freshly built one."""

@@ -1245,3 +1245,147 @@ def test_parallel_gunzip_declines_what_it_is_not_sure_of():
     bad[len(gz) // 2] ^= 0x10                                                # a bit of the deflate data
     got = _lib.gunzip_parallel(bytes(bad), 4)
     assert got is None or got[0] == raw                                      # (only if the flipped bit happened to change nothing)
+
+
+# ---------------------------------------------------------------------------------- round 4: the object layer's C paths
+def _tiny_fastq(tmp_path, crlf=False):
+    import sqlite3
+    nl = "\r\n" if crlf else "\n"
+    recs = [("r%d" % i, "ACGTN" * 3 + "A" * i, "".join(chr(40 + ((i + j) % 30)) for j in range(15 + i))) for i in range(7)]
+    path = str(tmp_path / "t.fq")
+    rows, off = [], 0
+    with open(path, "w", newline="") as f:
+        for i, (n, s, q) in enumerate(recs):
+            h = "@%s some words" % n
+            f.write(h + nl + s + nl + "+" + nl + q + nl)
+            soff = off + len(h) + len(nl)
+            qoff = soff + len(s) + len(nl) + 1 + len(nl)
+            rows.append((i + 1, n, len(h) + len(nl) - 1, len(s), soff, qoff))
+            off = qoff + len(q) + len(nl)
+    db = sqlite3.connect(path + ".fxi")
+    db.execute("CREATE TABLE read (ID INTEGER PRIMARY KEY, name TEXT, dlen INTEGER, rlen INTEGER, soff INTEGER, qoff INTEGER)")
+    db.executemany("INSERT INTO read VALUES (?,?,?,?,?,?)", rows)
+    db.execute("CREATE UNIQUE INDEX readidx ON read (name)")
+    db.commit()
+    db.close()
+    return path, recs
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+def test_fastq_subscript_and_read_getters_in_c(tmp_path, crlf):
+    """csrc/fxobj.c FastqCore: fq[i] / fq[name] from prepared statements (fastq.c:454-545), Read.seq / .qual / .quali of a
+    plain file from the page cache (read.c:152-167, 237-278) -- no device needed for either, so they are checked here."""
+    import pyfastx_amd  # noqa: F401  (binds the Read type)
+    from pyfastx_amd import _fxobj
+    path, recs = _tiny_fastq(tmp_path, crlf)
+
+    class FQ(_fxobj.FastqCore):
+        def _getitem_slow(self, key):
+            return ("slow", key)
+
+    fq = FQ()
+    fq._counts, fq._phred = len(recs), 0
+    assert fq[0] == ("slow", 0)                                  # nothing bound yet: the subclass answers
+    assert fq._core_open(path + ".fxi") is True
+    for i, (n, s, q) in enumerate(recs):
+        r = fq[i]
+        assert (r.id, r.name, len(r)) == (i + 1, n, len(s)) and type(r).__name__ == "Read"
+        assert fq[n].id == i + 1 and fq[i - len(recs)].name == n
+    with pytest.raises(IndexError, match="index out of range"):
+        fq[len(recs)]
+    with pytest.raises(IndexError):
+        fq[-len(recs) - 1]
+    with pytest.raises(KeyError, match="nope does not exist in fastq file"):
+        fq["nope"]
+    assert fq[2.0] == ("slow", 2.0) and fq[np.int64(3)] == ("slow", np.int64(3))
+    # the getters stay with the Python methods until the stream is staged (no device here: a made-up handle)
+    r = fq[3]
+    with pytest.raises(AttributeError):
+        r.seq                                                    # _seq_slow -> the Fastq's staged stream, which FQ does not have
+    fq._core_stage(1, path)
+    for i, (n, s, q) in enumerate(recs):
+        r = fq[n]
+        assert r.seq == s and r.qual == q and r.quali == [ord(c) - 33 for c in q]
+    fq._phred = 64
+    assert fq[1].quali == [ord(c) - 64 for c in recs[1][2]]
+    fq._core_stage(0)                                            # Blob.close(): back to the Python methods
+    with pytest.raises(AttributeError):
+        fq[0].seq
+    assert fq._core_open(None) is False and fq[0] == ("slow", 0)
+
+
+def test_sequence_getters_from_the_page_cache(tmp_path):
+    """csrc/fxobj.c seq_fast on a plain file: pread + despace / upper / complement / reverse in C (util.c:157-269), equal to
+    the oracle's getters for every slice of a line-regular record -- LF and CRLF, lower case, IUPAC codes, a byte of 200."""
+    import pyfastx_amd
+    from pyfastx_amd import _fxobj, api
+    import fxoracle
+    fxoracle.lib()
+    oracle_rc = fxoracle.revcomp                              # mode: 1 reverse, 2 complement (oracle/fx_oracle.c: fxo_revcomp)
+    rng = np.random.default_rng(3)
+    for el, nl in ((1, b"\n"), (2, b"\r\n")):
+        bases = bytes(rng.choice(list(b"ACGTacgtNnRYKMBDHVUu\xc8"), 333).astype(np.uint8))
+        bpl = 50
+        lines = [bases[i:i + bpl] for i in range(0, len(bases), bpl)]
+        hdr = b">s1 test" + nl
+        path = str(tmp_path / ("t%d.fa" % el))
+        with open(path, "wb") as f:
+            f.write(hdr + nl.join(lines) + nl)
+
+        class FA(_fxobj.FastaCore):
+            pass
+
+        for upper in (0, 1):
+            fa = FA()
+            fa._core_upper = upper
+            s = api.Sequence(fa, 1, "s1", len(hdr), len(bases) + len(lines) * el, len(bases), bpl + el, el, 1, len(hdr) - 1 - el)
+            s._reg = 1
+            fa._core_stage(1, path)
+            assert fa._core_fd >= 0
+            want = bases.upper() if upper else bases
+            # (bytes.upper leaves 0xC8 alone, as remove_space_uppercase leaves bytes >= 128 alone here)
+            for a, b in [(0, 1), (0, 50), (49, 51), (3, 333), (100, 250), (332, 333), (17, 18)] + [tuple(sorted(rng.integers(0, 334, 2))) for _ in range(60)]:
+                if a == b or (a == 0 and b == 333):
+                    continue
+                sl = s[a:b]
+                w = want[a:b]
+                assert sl.seq.encode("latin-1") == w
+                assert sl.reverse.encode("latin-1") == w[::-1]
+                assert sl.complement.encode("latin-1") == oracle_rc(w, 2)
+                assert sl.antisense.encode("latin-1") == oracle_rc(w, 3)
+            with pytest.raises(TypeError):
+                del s._fa
+            fa._core_stage(0)
+            assert fa._core_fd == -1 and fa._core_handle == 0
+
+
+def test_pinned_buffer_owner_and_name_helpers():
+    """csrc/fxobj.c: PinnedBuf gives its block back when the last view dies; ids_of_names resolves names through a dict with
+    an identity cache in front; pack_names packs a list for fx_names_lookup."""
+    import ctypes as C
+    from pyfastx_amd import _fxobj
+    freed = []
+    FREE = C.CFUNCTYPE(None, C.c_void_p)
+    cb = FREE(lambda p: freed.append(p))
+    raw = C.create_string_buffer(64)
+    pb = _fxobj.PinnedBuf(C.addressof(raw), 64, C.cast(cb, C.c_void_p).value)
+    a = np.frombuffer(pb, dtype=np.uint8)
+    a[:] = np.arange(64)
+    v = a[10:20]
+    del a, pb
+    assert not freed and v.tolist() == list(range(10, 20))
+    del v
+    assert freed == [C.addressof(raw)]
+    names = ["chr%d" % i for i in range(50)]
+    index = {n: i for i, n in enumerate(names)}
+    ids = np.random.default_rng(0).integers(0, 50, 10_000)
+    q = [names[i] for i in ids] + ["".join(["chr", "7"])]         # same objects again and again, and one equal but distinct
+    out = np.empty(len(q), dtype=np.int64)
+    assert _fxobj.ids_of_names(q, index, out) == -1 and out[:-1].tolist() == ids.tolist() and out[-1] == 7
+    assert _fxobj.ids_of_names(q[:5] + ["nope"] + q[5:], index, np.empty(len(q) + 1, dtype=np.int64)) == 5
+    with pytest.raises(ValueError):
+        _fxobj.ids_of_names(q, index, np.empty(3, dtype=np.int64))
+    b, o = _fxobj.pack_names(["ab", b"cde", "", "é"])
+    assert b == b"abcde\xc3\xa9" + b"\0" * 16 and np.frombuffer(o, dtype=np.int64).tolist() == [0, 2, 5, 5, 7]
+    with pytest.raises(ValueError):
+        _fxobj.pack_names(["ok", "\udcff"])

@@ -56,13 +56,24 @@ def main():
     from pyfastx_amd import _fxobj
     out["fetch_one_from_C_floor_us"] = _fxobj.bench_fetch_one(int(b._h.value), rows[0][0], rows[0][1], 100, N)
     out["getters_per_s"] = round(1e6 / out["full_getter_us"])
+    out["answered_by"] = "page cache (plain file: pread + byte work in csrc/fxobj.c)" if fa._core_fd >= 0 else "resident kernel (fx_fetch_one)"
+    out["antisense_getter_us"] = rate(lambda j: fa[names[ii[j]]][ss[j]:ee[j]].antisense, N)
+    # the same getters with the host path switched off: everything through the resident kernel (what a gzip input gets)
+    fa._core_stage(int(b._h.value), None)
+    out["full_getter_through_the_resident_kernel_us"] = rate(lambda j: fa[names[ii[j]]][ss[j]:ee[j]].seq, N)
+    fa._core_stage(int(b._h.value), path)
     try:
         sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
         import pyfastx
         os.unlink(path + ".fxi")
         rf = pyfastx.Fasta(path)
         out["reference_full_getter_us"] = rate(lambda j: rf[names[ii[j]]][ss[j]:ee[j]].seq, N)
-        assert rf[names[ii[5]]][ss[5]:ee[5]].seq == fa[names[ii[5]]][ss[5]:ee[5]].seq
+        out["reference_antisense_getter_us"] = rate(lambda j: rf[names[ii[j]]][ss[j]:ee[j]].antisense, N)
+        out["reference_subscript_by_name_us"] = rate(lambda j: rf[names[ii[j]]], N)
+        same = all(rf[names[ii[j]]][ss[j]:ee[j]].seq == fa[names[ii[j]]][ss[j]:ee[j]].seq and
+                   rf[names[ii[j]]][ss[j]:ee[j]].antisense == fa[names[ii[j]]][ss[j]:ee[j]].antisense for j in range(2000))
+        out["answers_equal_reference_2000"] = bool(same)
+        assert same
     except Exception as e:  # noqa: BLE001
         out["reference"] = str(e)[:100]
     print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v) for k, v in out.items()}))

@@ -35,10 +35,57 @@ def main():
     assert tot == 2 * 150 * n
     k = 20000
     ids = np.random.default_rng(1).integers(0, n, k).tolist()
+    fq[0].seq
     t3 = time.perf_counter()
     for i in ids:
         fq[i].seq
     t4 = time.perf_counter()
+    for i in ids:
+        r = fq[i]
+        r.seq, r.qual, r.quali
+    t4b = time.perf_counter()
+    rnames = [fq[i].name for i in ids]
+    t4c = time.perf_counter()
+    for nm in rnames:
+        fq[nm].seq
+    t4d = time.perf_counter()
+    ours = {"one_by_one_reads_per_s": round(k / (t4 - t3)), "one_by_one_seq_qual_quali_reads_per_s": round(k / (t4b - t4)),
+            "one_by_one_by_name_reads_per_s": round(k / (t4d - t4c)),
+            "single_getters_answered_by": "page cache (csrc/fxobj.c)" if fq._core_fd >= 0 else "resident kernel"}
+    # the compiled reference on the same file, same box (its own index file)
+    ref = {}
+    try:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref"))
+        import pyfastx
+        rix = pq + ".ref.fxi"
+        if os.path.exists(rix):
+            os.remove(rix)
+        r0 = time.perf_counter()
+        rq = pyfastx.Fastq(pq, index_file=rix)
+        r1 = time.perf_counter()
+        tot = 0
+        for r in rq:
+            tot += len(r.seq) + len(r.qual)
+        r2 = time.perf_counter()
+        assert tot == 2 * 150 * n
+        for i in ids:
+            rq[i].seq
+        r3 = time.perf_counter()
+        for i in ids:
+            r = rq[i]
+            r.seq, r.qual, r.quali
+        r4 = time.perf_counter()
+        for nm in rnames:
+            rq[nm].seq
+        r5 = time.perf_counter()
+        same = all(rq[i].seq == fq[i].seq and rq[i].qual == fq[i].qual and rq[i].quali == fq[i].quali and rq[i].name == fq[i].name for i in ids[:2000])
+        ref = {"reference_Fastq_ctor_s": round(r1 - r0, 2), "reference_iterate_seq_qual_M_reads_per_s": round(n / (r2 - r1) / 1e6, 3),
+               "reference_one_by_one_reads_per_s": round(k / (r3 - r2)), "reference_one_by_one_seq_qual_quali_reads_per_s": round(k / (r4 - r3)),
+               "reference_one_by_one_by_name_reads_per_s": round(k / (r5 - r4)), "answers_equal_reference_2000": bool(same)}
+        del rq
+        os.remove(rix)
+    except Exception as e:  # noqa: BLE001
+        ref = {"reference": str(e)[:120]}
     # FASTA: many short records
     rng = np.random.default_rng(2)
     m = n // 4
@@ -61,9 +108,31 @@ def main():
         tot += len(s.seq)
     t7 = time.perf_counter()
     assert tot == 300 * m and len(fa) == m
-    print(json.dumps({"fastq_reads": n, "Fastq_ctor_incl_fxi_s": round(t1 - t0, 2), "iterate_seq_qual_M_reads_per_s": round(n / (t2 - t1) / 1e6, 3),
-                      "one_by_one_reads_per_s": round(k / (t4 - t3)), "fasta_records": m, "Fasta_ctor_incl_fxi_s": round(t6 - t5, 2),
-                      "iterate_seq_M_records_per_s": round(m / (t7 - t6) / 1e6, 3)}))
+    refa = {}
+    try:
+        import pyfastx
+        rix = pa + ".ref.fxi"
+        if os.path.exists(rix):
+            os.remove(rix)
+        r0 = time.perf_counter()
+        ra = pyfastx.Fasta(pa, index_file=rix)
+        r1 = time.perf_counter()
+        tot = 0
+        for s in ra:
+            tot += len(s.seq)
+        r2 = time.perf_counter()
+        assert tot == 300 * m
+        refa = {"reference_Fasta_ctor_s": round(r1 - r0, 2), "reference_iterate_seq_M_records_per_s": round(m / (r2 - r1) / 1e6, 3)}
+        del ra
+        os.remove(rix)
+    except Exception as e:  # noqa: BLE001
+        refa = {"reference_fasta": str(e)[:120]}
+    out = {"fastq_reads": n, "Fastq_ctor_incl_fxi_s": round(t1 - t0, 2), "iterate_seq_qual_M_reads_per_s": round(n / (t2 - t1) / 1e6, 3)}
+    out.update(ours)
+    out.update(ref)
+    out.update({"fasta_records": m, "Fasta_ctor_incl_fxi_s": round(t6 - t5, 2), "iterate_seq_M_records_per_s": round(m / (t7 - t6) / 1e6, 3)})
+    out.update(refa)
+    print(json.dumps(out))
     for p in (pq, pq + ".fxi", pa, pa + ".fxi"):
         if os.path.exists(p):
             os.remove(p)
