@@ -103,6 +103,10 @@ void fx_pinned_free(void *p);
 int fx_pinned_holds(const void *p, int64_t bytes);
 int fx_pinned_trim(void);
 int64_t fx_size(const fx_handle *h);          /* uncompressed bytes held          */
+/* Free and total HBM of a device, now.  The reference streams files of any size through a 1 MiB buffer (kseq.h:13,
+ * index.c:229-230); here a stream larger than what is free is built and served in byte-range WINDOWS that take turns in HBM
+ * (pyfastx_amd/windows.py, fx_open_file_range): this is the number that decides. */
+int fx_device_memory(int device, int64_t *free_bytes, int64_t *total_bytes);
 int fx_is_gzip(const fx_handle *h);           /* is_gzip_format, util.c:307-325   */
 const void *fx_device_ptr(const fx_handle *h);/* device address of the blob       */
 /* Raw bytes [off, off+n) of the stream -> dst (host).  Serves names,

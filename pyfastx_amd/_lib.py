@@ -46,7 +46,7 @@ class ShardSummary(C.Structure):
 
 SYMBOLS = [
     "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_file_indexed", "fx_gz_checkpoints", "fx_stream_size", "fx_open_file_range", "fx_open_host", "fx_open_device",
-    "fx_set_shard", "fx_close", "fx_release_scratch", "fx_pinned_alloc", "fx_pinned_free", "fx_pinned_holds", "fx_pinned_trim", "fx_size", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
+    "fx_set_shard", "fx_close", "fx_release_scratch", "fx_pinned_alloc", "fx_pinned_free", "fx_pinned_holds", "fx_pinned_trim", "fx_size", "fx_device_memory", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
     "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_line_regular", "fx_fasta_len_stats", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fasta_fetch_alloc", "fx_fetch_phases", "fx_fastq_fetch", "fx_fastq_fetch_alloc", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
     "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
@@ -128,6 +128,7 @@ def lib():
     L.fx_size.restype = i64
     L.fx_size.argtypes = [vp]
     L.fx_is_gzip.argtypes = [vp]
+    L.fx_device_memory.argtypes = [i32, C.POINTER(i64), C.POINTER(i64)]
     L.fx_device_ptr.restype = vp
     L.fx_device_ptr.argtypes = [vp]
     L.fx_read_bytes.argtypes = [vp, i64, i64, vp]
@@ -240,6 +241,13 @@ def gunzip_parallel(gz, threads=8):
     raise FxError(FX_ERANGE, "output did not fit twice")
 
 
+def device_memory(device=0):
+    """-> (free, total) bytes of the device's HBM now."""
+    f, t = C.c_int64(0), C.c_int64(0)
+    check(lib().fx_device_memory(int(device), C.byref(f), C.byref(t)))
+    return f.value, t.value
+
+
 def stream_size(path):
     """-> (bytes of the uncompressed stream or -1, kind): kind 0 plain, 1 BGZF, 2 single-stream gzip (fx_stream_size)."""
     n, k = C.c_int64(0), C.c_int(0)
@@ -322,8 +330,19 @@ class Comm:
     def from_process_group(cls, device):
         """rank / world of torch.distributed's default group; the id travels over it (one broadcast at setup)."""
         import torch.distributed as dist
-        box = [cls.unique_id() if dist.get_rank() == 0 else None]
+        # Every collective below is entered by EVERY rank whatever happens on one of them (a rank that failed early and went on
+        # to the next collective while the others still sat in this one hung the job): rank 0 always broadcasts something --
+        # the id, or None when it could not make one -- and ncclCommInitRank, itself collective, is only reached when an id exists.
+        uid = None
+        if dist.get_rank() == 0:
+            try:
+                uid = cls.unique_id()
+            except Exception:                                   # noqa: BLE001  (no RCCL to bind)
+                uid = None
+        box = [uid]
         dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            raise FxError(FX_EDEVICE, "rank 0 could not create a communicator id (RCCL not bound)")
         return cls(dist.get_rank(), dist.get_world_size(), box[0], device)
 
     def allgather(self, arr):

@@ -75,9 +75,34 @@ class _Staged:
         self.path, self.device, self._blob = path, device, None
         self.gzindex = None          # callable -> restart points of the index file (fxi.read_gzindex), set by the owner
         self.on_stage = None         # callable(blob): the owner learns the handle of the staged stream (the getters' fast path)
+        self.windowed = None         # callable(plan) -> windows.WindowedFasta / WindowedFastq: set by an owner that can work out of core
+        self.forced = None           # callable() -> the same kind of object whatever the size: Fastq(path, devices=[...])
+        self.win_factor = 1.15       # what a build needs in HBM beside the stream itself, as a factor of its size
+        self._md = None              # the windowed build, once the stream turned out not to fit (pyfastx_amd/windows.py)
+
+    @property
+    def md(self):
+        """The windowed build when the stream does not fit the HBM it may use, else None (decided at the first touch)."""
+        self.blob
+        return self._md
 
     @property
     def blob(self):
+        if self._blob is None and self.forced is not None:
+            try:
+                self._md = self.forced()
+            except _lib.FxError as e:
+                raise _fx_to_py(e)
+            self._blob = self._md.blob
+        if self._blob is None and self.windowed is not None:
+            from . import windows
+            try:
+                plan = windows.plan(self.path, self.device, self.win_factor)
+                if plan is not None:                          # larger than the budget: windows that take turns on the device
+                    self._md = self.windowed(plan)
+                    self._blob = self._md.blob
+            except _lib.FxError as e:
+                raise _fx_to_py(e)
         if self._blob is None:
             pts = None
             if self.gzindex is not None:                     # a gzip file with an index: inflate the segments in parallel
@@ -131,6 +156,7 @@ class _ShardedStaged(_Staged):
     def __init__(self, path, devices, full_name):
         super().__init__(path, devices[0])
         self.devices, self.full_name, self._md = list(devices), full_name, None
+        self.windowed = None
 
     @property
     def md(self):
@@ -184,13 +210,20 @@ class Fasta(_fxobj.FastaCore):
         self._uppercase, self._full_name, self._key_func = bool(uppercase), bool(full_name), key_func
         self._has_index = bool(build_index)
         self.is_gzip = _is_gzip(file_name)
-        self._sharded = devices is not None and len(devices) > 1
-        if self._sharded:
+        self._explicit_shards = devices is not None and len(devices) > 1
+        if self._explicit_shards:
             if key_func is not None or not build_index:
                 raise ValueError("devices=[...] builds a plain index: no key_func, build_index must stay on")
             self._st = _ShardedStaged(file_name, devices, bool(full_name))
         else:
             self._st = _Staged(file_name, devices[0] if devices else device)
+            if key_func is None and build_index:
+                # a stream larger than the HBM it may use (FX_HBM_BUDGET / what is free): built and served in windows that take
+                # turns on the device -- the multi-GPU machinery on one GPU (pyfastx_amd/windows.py); decided at the first touch
+                def windowed(plan, path=file_name, dev=self._st.device, fn=bool(full_name)):
+                    from .windows import WindowedFasta
+                    return WindowedFasta(path, dev, fn, window=plan[2], capacity=plan[3])
+                self._st.windowed = windowed
             import weakref
             me = weakref.ref(self)
 
@@ -222,6 +255,12 @@ class Fasta(_fxobj.FastaCore):
             if full_index:
                 self._calc_composition()
 
+    @property
+    def _sharded(self):
+        """Is the stream held as byte-range shards -- over several devices (devices=[...]) or as windows of one (out of core)?
+        Asking stages the stream (or runs the windowed build): every caller is about to need it."""
+        return self._explicit_shards or self._st.md is not None
+
     # ---------------------------------------------------------------- index
     def build_index(self):
         """pyfastx_build_index (index.c:418-429): load the .fxi if present else create it."""
@@ -231,7 +270,7 @@ class Fasta(_fxobj.FastaCore):
             self._db = fxi.connect(self._index_file)
             if not fxi.has_fasta_index(self._db):                                         # index.c:402-411
                 raise RuntimeError("the index file %s was damaged" % self._index_file)
-            if self.is_gzip and not self._sharded:           # pyfastx_load_index imports the zran points (index.c:433): so do we
+            if self.is_gzip and not self._explicit_shards:   # pyfastx_load_index imports the zran points (index.c:433): so do we
                 self._st.gzindex = lambda: fxi.read_gzindex(self._db)
         else:
             self._create_index()
@@ -924,6 +963,8 @@ class Sequence(_fxobj.SeqCore):
     getters live in the C base type (csrc/fxobj.c): a slice of a line-regular record goes from there straight to the
     resident kernel; everything else lands in _get / _subscript_slow below."""
 
+    __slots__ = ()                                            # every field is the base type's: no instance dict, the objects stay out of the cyclic GC
+
     def __init__(self, fasta, sid, name, boff, blen, slen, llen, elen, norm, dlen, start=1, end=None, complete=True):
         self._fa = fasta
         self.id, self._name = int(sid), name
@@ -1101,9 +1142,15 @@ class Fastq(_fxobj.FastqCore):
     prepared statements on a read-only connection of its own, fastq.c:454-545); `_counts` and `_phred` are its members."""
 
     def __init__(self, file_name, index_file=None, phred=0, build_index=True, full_index=False, full_name=False,
-                 device=0):
+                 device=0, devices=None):
+        """devices=[0, 1, ...] (extension): the stream over several GPUs by byte range, one host thread per device,
+        ONE index file, batches routed by read id (windows.WindowedFastq)."""
         if not os.path.isfile(file_name):
             raise FileExistsError("input fastq file %s does not exists" % file_name)          # fastq.c:278-281
+        if devices is not None and len(devices) > 1 and not build_index:
+            raise ValueError("devices=[...] builds an index: build_index must stay on")
+        if devices:
+            device = devices[0]
         self.file_name = file_name
         self.is_gzip = _is_gzip(file_name)
         if _first_nonspace(file_name, self.is_gzip) != ord("@"):                              # fastq.c:300-304
@@ -1123,6 +1170,21 @@ class Fastq(_fxobj.FastqCore):
                         f2._core_stage(0)
                 blob.on_close.append(closed)
         self._st.on_stage = staged
+        self._want_comp = bool(build_index and full_index)
+        if build_index:
+            self._st.win_factor = 1.7                          # line records + read table beside the stream
+
+            def windowed(plan, me=me, path=file_name, dev=device):
+                from .windows import WindowedFastq
+                fq = me()
+                return WindowedFastq(path, dev, window=plan[2], capacity=plan[3], want_comp=bool(fq is not None and fq._want_comp))
+            self._st.windowed = windowed
+            if devices is not None and len(devices) > 1:
+                def forced(me=me, path=file_name, devs=list(devices)):
+                    from .windows import WindowedFastq
+                    fq = me()
+                    return WindowedFastq(path, devices=devs, want_comp=bool(fq is not None and fq._want_comp))
+                self._st.forced = forced
         self._index_file = index_file or file_name + ".fxi"
         self._phred = int(phred)
         self._has_index = bool(build_index)
@@ -1170,6 +1232,24 @@ class Fastq(_fxobj.FastqCore):
 
     def _create_index(self):
         """pyfastx_fastq_create_index (fastq.c:8-182) with the scan on the GPU."""
+        wq = self._st.md
+        if wq is not None:                                    # larger than the HBM it may use: built window after window (windows.WindowedFastq)
+            self._db = None
+            if wq.n_reads and self._index_file != ":memory:" and not os.path.exists(self._index_file):
+                try:
+                    self._db = wq.write_index(self._index_file)
+                except _lib.FxError:
+                    self._db = None
+            if self._db is None:
+                nm, no = wq.names.tobytes(), wq.name_off.tolist()
+                self._db = fxi.connect(self._index_file)
+                fxi.write_fastq(self._db, [nm[no[i]:no[i + 1]] for i in range(wq.n_reads)], wq.table, wq.size)
+            if self.is_gzip:
+                c, u, _ = wq.blobs[0].gz_points()
+                fxi.write_gzindex(self._db, os.path.getsize(self.file_name), wq.stream_bytes, c, u)
+            self._counts, self.size = int(wq.n_reads), int(wq.size)
+            self.avglen = self.size * 1.0 / self._counts if self._counts else float("nan")
+            return
         blob = self._st.blob
         try:
             s = blob.fastq_build()
@@ -1203,9 +1283,12 @@ class Fastq(_fxobj.FastqCore):
             return
         row = self._db.execute("SELECT * FROM meta LIMIT 1").fetchone()
         if row is None:
-            blob = self._st.blob
-            blob.fastq_build()
-            base, meta = blob.fastq_comp()
+            if self._st.md is not None:                       # windows: five sums, two minima, two maxima over them
+                base, meta = self._st.md.composition()
+            else:
+                blob = self._st.blob
+                blob.fastq_build()
+                base, meta = blob.fastq_comp()
             fxi.write_fastq_comp(self._db, base, meta)
             row = tuple(int(x) for x in meta)
         self._meta = {"maxlen": int(row[0]), "minlen": int(row[1]), "minqs": int(row[2]), "maxqs": int(row[3]),
@@ -1259,6 +1342,20 @@ class Fastq(_fxobj.FastqCore):
         # read-only connection of its own through the library the sqlite3 module has loaded) and the objects of a batch made
         # by one call; when that connection cannot be had (an index another connection holds exclusively), the sqlite3
         # module's rows do the same, more slowly.
+        if self._st.md is None and not os.environ.get("FX_ITER_SQLITE"):
+            # the rows from the read table of the DEVICE (one copy to the host, fx_fastq_table), the names gathered with the
+            # sequence and quality lines: no statement stepped per read (0.19 of the 0.9 us a read cost in round 3)
+            blob = self._dev()
+            tab, n, B = self._tab_host, int(self._counts), 16384
+            if n == tab["rlen"].size:
+                for a in range(0, n, B):
+                    b = min(n, a + B)
+                    seq, qual, _, offs = blob.read_fetch(tab["soff"][a:b], tab["qoff"][a:b], tab["rlen"][a:b], want=("seq", "qual"))
+                    ln = np.maximum(tab["name_len"][a:b].astype(np.int64), 0)
+                    nbuf, noffs, _ = blob.fetch_ranges(tab["name_off"][a:b], ln, ln, flags=_F_RAW)
+                    yield from _fxobj.read_batch_arrays(Read, self, a + 1, nbuf, noffs, tab["dlen"][a:b].astype(np.int64), tab["rlen"][a:b],
+                                                        tab["soff"][a:b], tab["qoff"][a:b], seq, qual, offs)
+                return
         batch = None
         try:
             cur = _fxobj.RowCursor(self._index_file, "SELECT ID, name, dlen, rlen, soff, qoff FROM read ORDER BY ID")
@@ -1343,6 +1440,17 @@ class Fastq(_fxobj.FastqCore):
         """Batched `fq[name].id - 1`: read names -> 0-based ids (-1 when absent) through the name table in HBM
         (fx_names_lookup) instead of one SQLite probe per name (fastq.c:486-519)."""
         blob = self._dev()
+        if self._st.md is not None:                           # windows: no name table in HBM -- one probe of the index file per name (fastq.c:486-519)
+            if isinstance(names, tuple) and len(names) == 2 and not isinstance(names[1], (str, int)):
+                o = np.frombuffer(names[1], dtype=np.int64) if not isinstance(names[1], np.ndarray) else names[1]
+                raw = bytes(memoryview(names[0]))
+                names = [raw[int(o[i]):int(o[i + 1])].decode("utf-8", "surrogateescape") for i in range(len(o) - 1)]
+            out = np.full(len(names), -1, dtype=np.int64)
+            for i, nm in enumerate(names):
+                row = self._db.execute("SELECT ID FROM read WHERE name=? LIMIT 1", (nm if isinstance(nm, str) else nm.decode("utf-8", "surrogateescape"),)).fetchone()
+                if row is not None:
+                    out[i] = int(row[0]) - 1
+            return out
         if not getattr(self, "_names_ready", False):
             blob.names_build(1)
             self._names_ready = True
@@ -1350,6 +1458,12 @@ class Fastq(_fxobj.FastqCore):
 
     def _dev(self):
         blob = self._st.blob
+        if self._st.md is not None:                           # windows: the merged table lives on the host, the windows answer by byte range
+            if not getattr(self, "_dev_table", False):
+                self._tab_host = self._st.md.table
+                self._rlen_host = self._tab_host["rlen"]
+                self._dev_table = True
+            return blob
         if not getattr(self, "_dev_table", False):
             s = blob.fastq_build()
             self._tab_host = blob.fastq_table(s.n_reads)       # host copy of the read table: what batches index into
@@ -1376,6 +1490,9 @@ class Fastq(_fxobj.FastqCore):
                 raise KeyError("%s does not exist in fastq file" % nm)
         else:
             ids = np.asarray(ids_or_names, dtype=np.int64)
+        if self._st.md is not None:                           # windows: routed by read id, staged on demand
+            seq, qual, qi, offs = self._st.md.fetch(ids, phred=self._phred, want=want)
+            return {"seq": seq, "qual": qual, "quali": qi, "offsets": offs}
         try:
             seq, qual, qi, offs = blob.fastq_fetch_alloc(ids, phred=self._phred, want=want)
         except _lib.FxError as e:

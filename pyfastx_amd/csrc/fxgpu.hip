@@ -368,6 +368,19 @@ extern "C" int fx_close(fx_handle *h) {
 }
 
 extern "C" int64_t fx_size(const fx_handle *h) { return h ? h->n : 0; }
+// free / total bytes of a device's HBM as the runtime sees them now (idle blocks of the library's scratch pool count as used:
+// fx_release_scratch first, for the figure a new open can really have)
+extern "C" int fx_device_memory(int device, int64_t *free_bytes, int64_t *total_bytes) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(FX_EDEVICE, "no HIP device available; libfxgpu has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(FX_EDEVICE, "device %d out of range (have %d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return FX_OK;
+}
 extern "C" int fx_is_gzip(const fx_handle *h) { return h && h->gz; }
 extern "C" const void *fx_device_ptr(const fx_handle *h) { return h ? h->d_data : nullptr; }
 

@@ -58,6 +58,14 @@ typedef struct {
 
 static PyTypeObject FastaCoreType;
 
+/* api.Sequence is a heap type and so a GC type, but a Sequence refers to its Fasta, its name and a string -- nothing that can
+ * lead back to it (the subclass has __slots__ = (): no instance dict): it stays out of the cyclic collector's lists, and its
+ * allocations out of the collector's counts (see read_untrack) */
+static void seq_untrack(PyObject *o)
+{
+    if (PyType_HasFeature(Py_TYPE(o), Py_TPFLAGS_HAVE_GC) && PyObject_GC_IsTracked(o)) PyObject_GC_UnTrack(o);
+}
+
 /* ------------------------------------------------------------------ SeqCore */
 static void seq_dealloc(SeqCore *s)
 {
@@ -71,7 +79,7 @@ static PyObject *seq_new(PyTypeObject *type, PyObject *args, PyObject *kw)
 {
     SeqCore *s = (SeqCore *)type->tp_alloc(type, 0);
     (void)args; (void)kw;
-    if (s) { s->fa = Py_NewRef(Py_None); s->name = Py_NewRef(Py_None); s->reg = -1; s->start = 1; }
+    if (s) { if (type->tp_dictoffset == 0) seq_untrack((PyObject *)s); s->fa = Py_NewRef(Py_None); s->name = Py_NewRef(Py_None); s->reg = -1; s->start = 1; }
     return (PyObject *)s;
 }
 
@@ -80,6 +88,7 @@ static SeqCore *seq_like(SeqCore *p, long long start, long long end, int complet
     PyTypeObject *tp = Py_TYPE(p);
     SeqCore *s = (SeqCore *)tp->tp_alloc(tp, 0);
     if (!s) return NULL;
+    if (tp->tp_dictoffset == 0) seq_untrack((PyObject *)s);
     s->fa = Py_NewRef(p->fa); s->name = Py_NewRef(p->name);
     s->id = p->id; s->offset = p->offset; s->byte_len = p->byte_len; s->full_len = p->full_len; s->line_len = p->line_len;
     s->end_len = p->end_len; s->normal = p->normal; s->desc_len = p->desc_len; s->reg = p->reg;
@@ -285,6 +294,7 @@ static PyObject *fasta_subscript(FastaCore *f, PyObject *key)
         if (row && PyTuple_Check(row) && PyTuple_GET_SIZE(row) >= 9) {
             SeqCore *s = (SeqCore *)g_seq_type->tp_alloc(g_seq_type, 0);
             if (!s) return NULL;
+            if (g_seq_type->tp_dictoffset == 0) seq_untrack((PyObject *)s);
             s->fa = Py_NewRef((PyObject *)f);
             s->name = Py_NewRef(PyTuple_GET_ITEM(row, 1));
             s->id = tup_ll(row, 0); s->offset = tup_ll(row, 2); s->byte_len = tup_ll(row, 3); s->full_len = tup_ll(row, 4);
@@ -623,6 +633,15 @@ typedef struct {
     long long id, desc_len, read_len, soff, qoff;
 } ReadCore;
 
+/* A Read refers to its Fastq, its name and two strings: none of them can lead back to it, so it has no business in the cyclic
+ * collector's lists -- but api.Read is a heap type, CPython makes those GC types, and every allocation of a tracked object
+ * counts towards the next collection: 16 384 reads per batch were 23 young collections and, with a large process around
+ * them (torch: half a million tracked objects), now and then a full one.  Untracked right after the allocation, as tuples
+ * of atoms are. */
+static void read_untrack(ReadCore *r)
+{
+    if (PyType_HasFeature(Py_TYPE(r), Py_TPFLAGS_HAVE_GC) && PyObject_GC_IsTracked((PyObject *)r)) PyObject_GC_UnTrack((PyObject *)r);
+}
 static void read_dealloc(ReadCore *r)
 {
     Py_XDECREF(r->fq); Py_XDECREF(r->name); Py_XDECREF(r->pre_seq); Py_XDECREF(r->pre_qual);
@@ -772,6 +791,7 @@ static PyObject *fqc_read_of_row(FastqCore *f, sqlite3_stmt *st, PyObject *name)
 {
     ReadCore *r = (ReadCore *)g_read_type->tp_alloc(g_read_type, 0);
     if (!r) return NULL;
+    read_untrack(r);
     r->fq = Py_NewRef((PyObject *)f);
     r->id = SQ.column_int64(st, 0);
     if (name) r->name = Py_NewRef(name);
@@ -868,6 +888,7 @@ static PyObject *mod_read_batch(PyObject *m, PyObject *args)
         }
         r = (ReadCore *)((PyTypeObject *)type)->tp_alloc((PyTypeObject *)type, 0);
         if (!r) { Py_CLEAR(out); break; }
+        read_untrack(r);
         PyList_SET_ITEM(out, i, (PyObject *)r);
         r->fq = Py_NewRef(fq);
         {   /* the name: a str, or the column's bytes (SELECT CAST(name AS BLOB): no text_factory call per row) decoded as fxi.connect does */
@@ -994,6 +1015,7 @@ static PyObject *mod_read_batch_cols(PyObject *m, PyObject *args)
         if (o[i] < 0 || o[i + 1] < o[i] || o[i + 1] > seq.len || o[i + 1] > qual.len) { PyErr_SetString(PyExc_ValueError, "bad offsets"); Py_CLEAR(out); break; }
         r = (ReadCore *)((PyTypeObject *)type)->tp_alloc((PyTypeObject *)type, 0);
         if (!r) { Py_CLEAR(out); break; }
+        read_untrack(r);
         PyList_SET_ITEM(out, i, (PyObject *)r);
         r->fq = Py_NewRef(fq);
         r->name = Py_NewRef(PyList_GET_ITEM(names, i));
@@ -1004,6 +1026,52 @@ static PyObject *mod_read_batch_cols(PyObject *m, PyObject *args)
     }
 done:
     PyBuffer_Release(&cols); PyBuffer_Release(&seq); PyBuffer_Release(&qual); PyBuffer_Release(&offs);
+    return out;
+}
+
+/* read_batch_arrays(ReadType, fq, first_id, names, name_offs, dlen, rlen, soff, qoff, seq, qual, offs) -> list: the Read objects of
+ * reads first_id .. first_id + k - 1 (1-based ids) from slices of the read table as it stands in host memory (int64 each, k
+ * entries; name_offs and offs k + 1) and three gathered buffers -- names, sequence lines, quality lines.  No SQLite in the loop:
+ * the table came off the device once (fx_fastq_table), where the reference steps a statement per read (fastq.c:566-596). */
+static PyObject *mod_read_batch_arrays(PyObject *m, PyObject *args)
+{
+    PyObject *type, *fq, *out = NULL;
+    long long first;
+    Py_buffer nb, no, dl, rl, so, qo, seq, qual, offs;
+    Py_ssize_t k, i;
+    (void)m;
+    if (!PyArg_ParseTuple(args, "OOLy*y*y*y*y*y*y*y*y*", &type, &fq, &first, &nb, &no, &dl, &rl, &so, &qo, &seq, &qual, &offs)) return NULL;
+    k = rl.len / 8;
+    if (!PyType_Check(type) || !PyType_IsSubtype((PyTypeObject *)type, &ReadCoreType) || no.len < (k + 1) * 8 || dl.len < k * 8 || so.len < k * 8 ||
+        qo.len < k * 8 || offs.len < (k + 1) * 8) {
+        PyErr_SetString(PyExc_TypeError, "read_batch_arrays(ReadCore subtype, fq, first id, names, int64 name offsets[k + 1], dlen, rlen, soff, qoff (int64[k]), seq, qual, int64 offsets[k + 1])");
+        goto done;
+    }
+    out = PyList_New(k);
+    for (i = 0; out && i < k; ++i) {
+        const int64_t *o = (const int64_t *)offs.buf, *n0 = (const int64_t *)no.buf;
+        ReadCore *r;
+        if (o[i] < 0 || o[i + 1] < o[i] || o[i + 1] > seq.len || o[i + 1] > qual.len || n0[i] < 0 || n0[i + 1] < n0[i] || n0[i + 1] > nb.len) {
+            PyErr_SetString(PyExc_ValueError, "bad offsets");
+            Py_CLEAR(out);
+            break;
+        }
+        r = (ReadCore *)((PyTypeObject *)type)->tp_alloc((PyTypeObject *)type, 0);
+        if (!r) { Py_CLEAR(out); break; }
+        read_untrack(r);
+        PyList_SET_ITEM(out, i, (PyObject *)r);
+        r->fq = Py_NewRef(fq);
+        r->name = PyUnicode_DecodeUTF8((const char *)nb.buf + n0[i], (Py_ssize_t)(n0[i + 1] - n0[i]), "surrogateescape");      /* as fxi.connect's text_factory */
+        r->id = first + i;
+        r->desc_len = ((const int64_t *)dl.buf)[i]; r->read_len = ((const int64_t *)rl.buf)[i];
+        r->soff = ((const int64_t *)so.buf)[i]; r->qoff = ((const int64_t *)qo.buf)[i];
+        r->pre_seq = PyUnicode_DecodeLatin1((const char *)seq.buf + o[i], (Py_ssize_t)(o[i + 1] - o[i]), NULL);
+        r->pre_qual = PyUnicode_DecodeLatin1((const char *)qual.buf + o[i], (Py_ssize_t)(o[i + 1] - o[i]), NULL);
+        if (!r->name || !r->pre_seq || !r->pre_qual) { Py_CLEAR(out); break; }
+    }
+done:
+    PyBuffer_Release(&nb); PyBuffer_Release(&no); PyBuffer_Release(&dl); PyBuffer_Release(&rl); PyBuffer_Release(&so); PyBuffer_Release(&qo);
+    PyBuffer_Release(&seq); PyBuffer_Release(&qual); PyBuffer_Release(&offs);
     return out;
 }
 
@@ -1028,6 +1096,7 @@ static PyObject *mod_seq_batch_cols(PyObject *m, PyObject *args)
         const long long *v = (const long long *)cols.buf;
         SeqCore *q = (SeqCore *)((PyTypeObject *)type)->tp_alloc((PyTypeObject *)type, 0);
         if (!q) { Py_CLEAR(out); break; }
+        if (((PyTypeObject *)type)->tp_dictoffset == 0) seq_untrack((PyObject *)q);
         PyList_SET_ITEM(out, i, (PyObject *)q);
         q->fa = Py_NewRef(fa);
         q->name = Py_NewRef(PyList_GET_ITEM(names, i));
@@ -1173,6 +1242,7 @@ static PyMethodDef mod_methods[] = {
     {"ids_of_names", mod_ids_of_names, METH_VARARGS, "ids_of_names(names, index dict, out int64 buffer) -> -1 | position of the first unknown name"},
     {"pack_names", mod_pack_names, METH_O, "pack_names(names) -> (bytes + 16 zero bytes, int64 offsets[n + 1] as bytes)"},
     {"seq_batch_cols", mod_seq_batch_cols, METH_VARARGS, "seq_batch_cols(SeqType, fa, names, cols, buf, offs, lens, sel) -> list of Sequence objects"},
+    {"read_batch_arrays", mod_read_batch_arrays, METH_VARARGS, "read_batch_arrays(ReadType, fq, first_id, names, name_offs, dlen, rlen, soff, qoff, seq, qual, offs) -> list of Read objects"},
     {"read_batch_cols", mod_read_batch_cols, METH_VARARGS, "read_batch_cols(ReadType, fq, names, cols, seq, qual, offs) -> list of Read objects"},
     {"read_batch", mod_read_batch, METH_VARARGS, "read_batch(ReadType, fq, rows, seq, qual, offs) -> list of Read objects with their strings"},
     {"fastx_batch", mod_fastx_batch, METH_VARARGS, "fastx_batch(hdr, hdr_off, seq, qual, recs, fastq, with_comment, state) -> list of tuples"},

@@ -802,6 +802,13 @@ class ShardedFastq:
         (fx_sort_packed_names) and writes the b-trees as pages (fxi.write_fastq_bulk).  barrier: callable that returns when
         every rank has called it (default: torch.distributed.barrier when world > 1).  -> rows written (rank 0), else None."""
         from . import _lib, fxi
+        import hashlib
+        # the arrays of THIS build in a directory of their own: two builds that share scratch_dir (or the leftovers of one that
+        # crashed) must not read each other's files -- the name is the same on every rank (file, its size and date, world)
+        st = os.stat(self.path)
+        tag = hashlib.blake2b(("%s|%d|%d|%d" % (os.path.abspath(self.path), st.st_size, st.st_mtime_ns, self.world)).encode(), digest_size=8).hexdigest()
+        scratch_dir = os.path.join(scratch_dir, "fxq_" + tag)
+        os.makedirs(scratch_dir, exist_ok=True)
         part = self.local_part()
         for k, v in part.items():
             np.save(os.path.join(scratch_dir, "fq_%s_%d.npy" % (k, self.rank)), v)
@@ -827,9 +834,58 @@ class ShardedFastq:
             db.commit() if hasattr(db, "commit") else None
             db.close()
             n_total = int(sizes[:, 1].sum())
+            if int(name_off[-1]) != names.size or n_total != name_off.size - 1:
+                raise RuntimeError("the parts of the sharded FASTQ index do not fit together (a stale file in %s?)" % scratch_dir)
             for r in range(self.world):
                 for k in part:
                     os.remove(os.path.join(scratch_dir, "fq_%s_%d.npy" % (k, r)))
+            try:
+                os.rmdir(scratch_dir)
+            except OSError:
+                pass
         if barrier is not None:
             barrier()
         return n_total
+
+    def composition(self, gather=None):
+        """base / meta of the WHOLE file on every rank (pyfastx_fastq_calc_composition, fastq.c:663-795): every rank counts the
+        reads it owns, one more latency-bound all-gather carries five sums, two minima and two maxima per rank (ten words), and
+        the phred rule (fastq.c:768-774) is applied to the merged extremes.  gather: as for the constructor (callable(int64[10])
+        -> int64[world, 10]); default torch.distributed, fx_comm through Comm.allgather."""
+        from .windows import merge_fastq_meta, finish_fastq_comp
+        mine = np.zeros(10, dtype=np.int64)
+        mine[5:] = (0, 1 << 62, 104, 33, 0)                                # no read: neutral for max / min / min / max
+        if self.n_local:
+            bs, mt = self.blob.fastq_comp()
+            mine[:5], mine[5:] = bs, mt
+        if gather is not None:
+            allc = np.asarray(gather(mine)).reshape(self.world, 10)
+        elif self.world > 1:
+            import torch
+            import torch.distributed as dist
+            t = torch.from_numpy(mine.copy())
+            outs = [torch.empty_like(t) for _ in range(self.world)]
+            dist.all_gather(outs, t)
+            allc = np.stack([o.numpy() for o in outs])
+        else:
+            allc = mine.reshape(1, 10)
+        base, meta = np.zeros(5, dtype=np.int64), None
+        for row in allc:
+            base += row[:5]
+            if row[6] != (1 << 62):                                          # a rank that owns reads
+                meta = merge_fastq_meta(meta, row[5:])
+        return finish_fastq_comp(base, meta)
+
+    def fetch(self, ids, first_ids, phred=0, seq_flags=0, want=("seq", "qual", "quali")):
+        """The reads of a batch (0-based GLOBAL ids, the same batch on every rank) that THIS rank owns -- read.c:37-45, 152-167,
+        237-278 -- -> (positions of those reads in the batch, seq, qual, quali, offsets): every read is answered exactly once
+        over the ranks, by the rank whose shard its header line begins in; no bytes move between GPUs.  first_ids: global id of
+        every rank's first read (cumulative n_local: what the build's all-gather already told everybody)."""
+        ids = np.asarray(ids, dtype=np.int64)
+        lo = int(first_ids[self.rank])
+        mine = np.nonzero((ids >= lo) & (ids < lo + self.n_local))[0]
+        if not mine.size:
+            z = np.zeros(0, dtype=np.uint8)
+            return mine, (z if "seq" in want else None), (z if "qual" in want else None), (z.view(np.int8) if "quali" in want else None), np.zeros(1, dtype=np.int64)
+        seq, qual, qi, offs = self.blob.fastq_fetch_alloc(ids[mine] - lo, phred=phred, seq_flags=seq_flags, want=want)
+        return mine, seq, qual, qi, offs

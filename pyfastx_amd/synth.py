@@ -237,55 +237,33 @@ def gzip_single_stream(raw, pool=None, piece=8 << 20, level=6):
 
 
 # --------------------------------------------------------------------------- the same two, over all cores of the host (setup speed only)
-# The bytes are handed to the worker processes by fork (a module global set before the pool starts), not through pipes:
-# pickling 3 GB into 96 workers was most of the 20 s a bench run spent compressing its C4 input.
-_SHARED = None
-
-
-def _bgzf_range(ab):
-    a, b = ab
-    return bgzf_compress(_SHARED[a:b].tobytes())[:-28]                      # without the EOF member of the piece
-
-
-def _deflate_range(args):
-    a, b, last, level = args
-    return _deflate_piece((_SHARED[a:b].tobytes(), last, level))
-
-
-def _pool(procs):
+# Threads, not processes: zlib releases the GIL while it deflates, so a thread pool compresses on all cores without a fork of
+# the bench process (96 forks of a process with a HIP context and tens of GB mapped: 10 s of page-table copies) and without
+# 3 GB going through pipes.
+def _threads(n=None):
     import os
-    from multiprocessing import get_context
-    return get_context("fork").Pool(procs or min(96, os.cpu_count() or 8))
+    from multiprocessing.pool import ThreadPool
+    return ThreadPool(n or min(128, os.cpu_count() or 8))
 
 
-def bgzf_compress_parallel(raw, procs=None, step=65280 * 64):
+def bgzf_compress_parallel(raw, procs=None, step=65280 * 16):
     """`raw` (numpy uint8) BGZF-framed as bgzf_compress would frame it, in pieces of whole members -> bytes."""
-    global _SHARED
-    _SHARED = raw
-    try:
-        with _pool(procs) as pool:
-            parts = pool.map(_bgzf_range, [(a, min(a + step, len(raw))) for a in range(0, len(raw), step)], chunksize=2)
-    finally:
-        _SHARED = None
+    mv = memoryview(raw)
+    with _threads(procs) as pool:
+        parts = pool.map(lambda ab: bgzf_compress(mv[ab[0]:ab[1]])[:-28], [(a, min(a + step, len(raw))) for a in range(0, len(raw), step)], chunksize=1)
     return b"".join(parts) + bgzf_compress(b"")
 
 
 def gzip_single_stream_parallel(raw, procs=None, piece=8 << 20, level=6):
-    """gzip_single_stream of `raw` (numpy uint8) with the pieces deflated by a pool that shares the bytes by fork; the
-    CRC-32 of the trailer is computed here while the pool works."""
+    """gzip_single_stream of `raw` (numpy uint8), the pieces deflated and the CRC-32 of the trailer folded by a thread pool."""
     import struct
     import zlib
-    global _SHARED
-    _SHARED = raw
+    mv = memoryview(raw)
     n = len(raw)
-    try:
-        with _pool(procs) as pool:
-            res = pool.map_async(_deflate_range, [(a, min(a + piece, n), a + piece >= n, level) for a in range(0, max(n, 1), piece)], chunksize=1)
-            mv = memoryview(raw)
-            crc = 0
-            for a in range(0, n, 64 << 20):
-                crc = zlib.crc32(mv[a:a + (64 << 20)], crc)
-            parts = res.get()
-    finally:
-        _SHARED = None
+    with _threads(procs) as pool:
+        res = pool.map_async(lambda a: _deflate_piece((mv[a:a + piece], a + piece >= n, level)), list(range(0, max(n, 1), piece)), chunksize=1)
+        crc = 0
+        for a in range(0, n, 64 << 20):
+            crc = zlib.crc32(mv[a:a + (64 << 20)], crc)
+        parts = res.get()
     return b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\xff" + b"".join(parts) + struct.pack("<II", crc & 0xFFFFFFFF, n & 0xFFFFFFFF)

@@ -1389,3 +1389,93 @@ def test_pinned_buffer_owner_and_name_helpers():
     assert b == b"abcde\xc3\xa9" + b"\0" * 16 and np.frombuffer(o, dtype=np.int64).tolist() == [0, 2, 5, 5, 7]
     with pytest.raises(ValueError):
         _fxobj.pack_names(["ok", "\udcff"])
+
+
+# ---------------------------------------------------------------------------------- round 4: windows of one device (out of core)
+class _FakeWindow:
+    """What windows.WindowedFasta asks of a staged window, answered by the numpy restatement of the shard kernels
+    (shard_ref.local_scan) over the bytes [lo, hi) of `raw`: the host logic of the windowed build on the CPU."""
+
+    staged = []
+
+    def __init__(self, raw, lo, hi):
+        self.raw, self.lo, self.hi = raw, lo, hi
+        _FakeWindow.staged.append((lo, hi))
+
+    def fasta_build(self, full_name=False):
+        self.rows, self.S = shard_ref.local_scan(self.raw, self.lo, self.hi, bool(full_name))
+        self._n_fasta = len(self.rows["hoff"])
+
+        class R:
+            n_seq = self._n_fasta
+        return R
+
+    def shard_summary(self):
+        return self.S
+
+    def fasta_table(self, n):
+        return {k: np.array(v[:n], dtype=np.int64) for k, v in self.rows.items() if k != "reg"}
+
+    def fasta_line_regular(self, n):
+        return np.array(self.rows["reg"][:n], dtype=np.int32)
+
+    def read_bytes(self, off, n):
+        a, b = max(int(off), self.lo), min(int(off) + int(n), self.hi)
+        got = self.raw[a:b] if b > a else b""
+        return got + b"\0" * (max(int(n), 0) - len(got)) if int(off) >= self.lo else got
+
+    def fetch_ranges(self, off, blen, slen, flags=0, **kw):
+        assert flags == 8
+        outs = [self.raw[max(int(o), self.lo):min(int(o) + int(l), self.hi)] for o, l in zip(off, blen)]
+        offs = np.zeros(len(outs) + 1, dtype=np.int64)
+        np.cumsum([int(x) for x in slen], out=offs[1:])
+        buf = np.zeros(max(int(offs[-1]), 1), dtype=np.uint8)
+        for i, b in enumerate(outs):
+            buf[offs[i]:offs[i] + len(b)] = np.frombuffer(b, dtype=np.uint8)
+        return buf, offs, np.array([len(b) for b in outs], dtype=np.int64)
+
+    def close(self):
+        pass
+
+
+def test_windowed_fasta_build_equals_the_whole_file(oracle, tmp_path, monkeypatch):
+    """pyfastx_amd/windows.py: a FASTA file built window after window -- summaries kept, every window's last record finished
+    from the windows behind it, names that cross a cut put together -- gives the rows and names of the whole-file build, for
+    every edge input at every number of windows (the kernels' part played by shard_ref on the CPU)."""
+    from pyfastx_amd import _lib, windows
+    cases = [(k, v["text"].encode()) for k, v in load_golden("fasta_edge").items() if not k.endswith(":upper")]
+    rng = np.random.default_rng(11)
+    long_hdr = b">" + bytes(rng.choice(list(b"abcdefgh"), 300).astype(np.uint8)) + b" d\nACGT\nAC\n>z\nA\n"
+    cases += [("long_name", long_hdr), ("long_name_full", long_hdr)]
+    for name, raw in cases:
+        if len(raw) < 8:
+            continue
+        p = str(tmp_path / "w.fa")
+        open(p, "wb").write(raw)
+        full = name.endswith("_full")
+        want = _expect(oracle, raw, full)
+        recs, _ = oracle.fasta_index(raw, full_name=full)
+        want_names = [raw[r["name_off"]:r["name_off"] + r["name_len"]] for r in recs]
+        monkeypatch.setattr(_lib.Blob, "from_file_range", classmethod(lambda cls, path, off, length, halo=0, device=0: _FakeWindow(raw, off, off + length)))
+        for nwin in (1, 2, 3, 5, 9, 17):
+            if nwin > len(raw):
+                continue
+            _FakeWindow.staged = []
+            wf = windows.WindowedFasta(p, device=0, full_name=full, window=-(-len(raw) // nwin), capacity=2)
+            got = {k: [int(x) for x in wf.table[k]] for k in want}
+            assert got == want, (name, nwin)
+            assert [bytes(x) for x in wf.table["names"]] == want_names, (name, nwin)
+            assert len(_FakeWindow.staged) == wf.windows and len(wf.cache.lru) <= 2      # one pass, two windows resident at most
+
+
+def test_window_plan_and_budget(monkeypatch, tmp_path):
+    from pyfastx_amd import windows
+    assert windows.parse_size("64M") == 64 << 20 and windows.parse_size("1.5G") == int(1.5 * (1 << 30)) and windows.parse_size("4096") == 4096
+    assert windows.parse_size("200GiB") == 200 << 30 and windows.parse_size("8k") == 8192
+    p = str(tmp_path / "f.fa")
+    open(p, "wb").write(b">a\n" + b"ACGT\n" * 100000)
+    monkeypatch.setenv("FX_HBM_BUDGET", "1G")
+    assert windows.plan(p, 0, 1.15) is None                     # fits
+    monkeypatch.setenv("FX_HBM_BUDGET", "256K")
+    size, kind, win, cap = windows.plan(p, 0, 1.0)
+    assert size == 500003 and kind == 0 and win == 65536 and cap == 4

@@ -33,6 +33,38 @@ def main():
         tot += len(r.seq) + len(r.qual)
     t2 = time.perf_counter()
     assert tot == 2 * 150 * n
+    # where the iteration's time goes: the three stages of a batch, each over the whole file on its own
+    from pyfastx_amd import _fxobj
+    bd = {}
+    try:
+        cur = _fxobj.RowCursor(fq._index_file, "SELECT ID, name, dlen, rlen, soff, qoff FROM read ORDER BY ID")
+        b0 = time.perf_counter()
+        batches = []
+        while True:
+            b = cur.fetch(16384)
+            if b is None:
+                break
+            batches.append(b)
+        b1 = time.perf_counter()
+        fetched = []
+        for kk, names, raw in batches:
+            cols = np.frombuffer(raw, dtype=np.int64).reshape(5, kk)
+            fetched.append(fq._st.blob.read_fetch(cols[3], cols[4], cols[2], want=("seq", "qual")))
+        b2 = time.perf_counter()
+        objs = []
+        for (kk, names, raw), (sq, ql, _, of) in zip(batches, fetched):
+            objs.append(_fxobj.read_batch_cols(fx.Read, fq, names, raw, sq, ql, of))
+        b3 = time.perf_counter()
+        tot = 0
+        for ob in objs:
+            for r in ob:
+                tot += len(r.seq) + len(r.qual)
+        b4 = time.perf_counter()
+        bd = {"rows_from_sqlite_us_per_read": round((b1 - b0) / n * 1e6, 3), "gather_seq_qual_us_per_read": round((b2 - b1) / n * 1e6, 3),
+              "objects_us_per_read": round((b3 - b2) / n * 1e6, 3), "python_loop_two_getters_us_per_read": round((b4 - b3) / n * 1e6, 3)}
+        del batches, fetched, objs
+    except Exception as e:  # noqa: BLE001
+        bd = {"breakdown": str(e)[:100]}
     k = 20000
     ids = np.random.default_rng(1).integers(0, n, k).tolist()
     fq[0].seq
@@ -128,6 +160,7 @@ def main():
     except Exception as e:  # noqa: BLE001
         refa = {"reference_fasta": str(e)[:120]}
     out = {"fastq_reads": n, "Fastq_ctor_incl_fxi_s": round(t1 - t0, 2), "iterate_seq_qual_M_reads_per_s": round(n / (t2 - t1) / 1e6, 3)}
+    out["iteration_breakdown"] = bd
     out.update(ours)
     out.update(ref)
     out.update({"fasta_records": m, "Fasta_ctor_incl_fxi_s": round(t6 - t5, 2), "iterate_seq_M_records_per_s": round(m / (t7 - t6) / 1e6, 3)})
