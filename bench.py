@@ -51,6 +51,7 @@ def parse():
                          "reported beside it; strong = ONE --gbp file (the metric's 3 Gbp FASTA) split by byte range over the N GPUs")
     ap.add_argument("--c3-reads", type=float, default=1e8, help="reads of the FASTQ leg resident in HBM (1e8 = BASELINE configs[2])")
     ap.add_argument("--c3-sample", type=float, default=2e6, help="reads of the FASTQ file that the reference also indexes")
+    ap.add_argument("--fastq-reads", type=float, default=2e7, help="reads of the ONE FASTQ file that an N > 1 run shards over its ranks (fastq_strong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -1087,6 +1088,106 @@ def strong_leg(a, dev, rank, world, backend, collective):
     }
 
 
+def fastq_strong_leg(a, dev, rank, world, backend, collective):
+    """configs[2]'s job on N GPUs (round 4: what was left of multi-GPU FASTQ): ONE FASTQ file cut into `world` byte ranges, rank r
+    stages its range + a halo, ONE all-gather of two words numbers the lines, every rank builds the rows of the reads it owns,
+    ONE more all-gather of ten words gives base / meta of the whole file on every rank, rank 0 writes ONE .fxi, and a batch of
+    random reads (the same on every rank) is answered by the ranks that own them -- no bytes between GPUs.  Every phase max
+    over ranks; rows, base / meta and fetched bytes against the generator's analytic truth."""
+    import torch
+    import torch.distributed as dist
+    from pyfastx_amd import _lib, synth, shard
+    n = int(min(a.c3_reads, a.fastq_reads))
+    comm = dev if backend == "nccl" else torch.device("cpu")
+
+    def barrier():
+        if collective:
+            dist.barrier()
+
+    def allmax(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device=comm if collective else "cpu")
+        if collective:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t.cpu()]
+
+    def allgather_i64(v):
+        t = torch.from_numpy(np.asarray(v, dtype=np.int64).copy()).to(comm if collective else "cpu")
+        if not collective:
+            return t.cpu().numpy().reshape(1, -1)
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        return np.stack([o.cpu().numpy() for o in outs])
+
+    box = [None]
+    rec = so = qo = hl = None
+    if rank == 0:
+        blob, cols = synth.fastq_generate(n, dev)
+        nb = int(cols["n_bytes"])
+        box[0] = (os.path.join(_scratch_dir(nb * 1.4), "c3s.fq"), nb, int(cols["rec"]), int(cols["soff"][0]), int(cols["qoff"][0]), int(cols["dlen"][0]))
+        blob[:nb].cpu().numpy().tofile(box[0][0])
+        del blob, cols
+        torch.cuda.empty_cache()
+    if collective:
+        dist.broadcast_object_list(box, src=0)
+    path, nb, rec, so, qo, dl = box[0]
+    barrier()
+    try:
+        _lib.Blob.from_file_range(path, nb * rank // world, min(1 << 20, nb // world), 0, device=dev.index).close()
+        barrier()
+        t0 = time.perf_counter()
+        sq = shard.ShardedFastq(path, rank, world, device=dev.index, gather=(lambda m: allgather_i64(m)))     # stage + scan + all-gather + rows
+        t_build = time.perf_counter() - t0
+        barrier()
+        t0 = time.perf_counter()
+        base, meta = sq.composition(gather=(lambda m: allgather_i64(m)))
+        t_comp = time.perf_counter() - t0
+        barrier()
+        t0 = time.perf_counter()
+        n_total = sq.write_index(path + ".fxi", os.path.dirname(path), barrier=barrier if collective else (lambda: None))
+        t_fxi = time.perf_counter() - t0
+        first = np.concatenate([[0], np.cumsum(allgather_i64([sq.n_local])[:, 0])])
+        nq = int(min(a.queries, 1_000_000))
+        ids = np.random.default_rng(99).integers(0, n, nq)
+        sq.fetch(ids[:1000], first, phred=int(meta[4]))
+        barrier()
+        t0 = time.perf_counter()
+        pos, seq, qual, qi, offs = sq.fetch(ids, first, phred=int(meta[4]))
+        barrier()
+        t_fetch = time.perf_counter() - t0
+        ok = None
+        if not a.no_verify:
+            # rows: the generator's records are `rec` bytes apart; this rank owns ids [first_id, first_id + n_local)
+            t = sq.blob.fastq_table(sq.n_local)
+            gid = sq.first_id + np.arange(sq.n_local, dtype=np.int64)
+            ok = bool((t["soff"] == gid * rec + so).all() and (t["qoff"] == gid * rec + qo).all() and (t["rlen"] == 150).all() and (t["dlen"] == dl).all())
+            mm = np.memmap(path, dtype=np.uint8, mode="r")
+            pick = np.arange(0, pos.size, max(pos.size // 5000, 1))
+            g = ids[pos[pick]].astype(np.int64) * rec
+            idx = g[:, None] + np.arange(150)[None, :]
+            sv = np.asarray(seq).reshape(-1, 150)[pick] if pos.size else np.zeros((0, 150), np.uint8)
+            qv = np.asarray(qual).reshape(-1, 150)[pick] if pos.size else np.zeros((0, 150), np.uint8)
+            ok = ok and bool((sv == mm[idx + so]).all()) and bool((qv == mm[idx + qo]).all())
+            del mm
+            answered = int(allgather_i64([pos.size])[:, 0].sum())
+            ok = ok and answered == nq and int(first[-1]) == n and int(base.sum()) == n * 150 and int(meta[0]) == 150 and int(meta[4]) == 33
+            if collective:
+                t_ok = torch.tensor([1 if ok else 0], dtype=torch.int32, device=comm)
+                dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+                ok = bool(int(t_ok.item()))
+            if not ok:
+                raise SystemExit("PARITY FAILURE (sharded FASTQ, rank %d)" % rank)
+        tb, tc, tf, tq = allmax([t_build, t_comp, t_fxi, t_fetch])
+        return {"workload": "ONE %d x 150 bp FASTQ file (%.2f GB) over %d ranks by byte range: build (stage + scan + one all-gather of 2 words + rows), "
+                            "composition (one all-gather of 10 words), ONE .fxi, %d random reads routed to the ranks that own them" % (n, nb / 1e9, world, nq),
+                "build_s": round(tb, 4), "composition_s": round(tc, 4), "fxi_written_s": round(tf, 3), "fetch_routed_s": round(tq, 4),
+                "reads_indexed": int(n_total) if n_total is not None else int(first[-1]), "halo_reopened": int(sq.reopened),
+                "rows_base_meta_fetch_equal_generator": ok, "M_reads_per_s_build": round(n / max(tb, 1e-9) / 1e6, 1)}
+    finally:
+        barrier()
+        if rank == 0:
+            _rm(path, path + ".fxi")
+
+
 def main_strong(a, dev, rank, world, backend, collective):
     """--scaling strong: the strong leg IS the line."""
     s = strong_leg(a, dev, rank, world, backend, collective)
@@ -1167,6 +1268,10 @@ def main():
                 st_ = strong_leg(b, dev, rank, world, backend, True)
                 if rank == 0:
                     line["strong"] = st_
+                if not a.no_c3:
+                    fq_ = fastq_strong_leg(a, dev, rank, world, backend, True)      # configs[2]'s job over the same ranks
+                    if rank == 0:
+                        line["fastq_strong"] = fq_
         if rank == 0:
             print(json.dumps(line), flush=True)
         dist.destroy_process_group()

@@ -152,3 +152,113 @@ def test_sharded_fetch_over_gloo(oracle, world, seed):
         for j, qi in enumerate(qidx.tolist()):
             assert buf[offs[j]:offs[j + 1]].tobytes() == _expected_fetch(oracle, raw, recs, int(ids[qi]), int(st[qi]), int(sp[qi]), int(fl[qi]))
     assert (seen == 1).all()
+
+
+# ---------------------------------------------------------------------------------- FASTQ over ranks (round 4)
+class _OracleFastqShard:
+    """What shard.ShardedFastq asks of its staged byte range, answered by the CPU oracle over the whole stream (the kernels'
+    part; the collective, the merge of the compositions and the routing are what runs here)."""
+
+    def __init__(self, oracle, raw, lo, hi):
+        self.o, self.raw, self.lo, self.hi = oracle, raw, lo, hi
+        recs, _, _ = oracle.fastq_index(raw)
+        hdr = recs["name_off"] - 1
+        self.own = np.nonzero((hdr >= lo) & (hdr < hi))[0]
+        self.recs = recs
+
+    def fastq_scan(self):
+        core = np.frombuffer(self.raw, dtype=np.uint8)[self.lo:self.hi]
+        nl = np.flatnonzero(core == 10)
+        return int(nl.size), int(nl[-1] + self.lo) if nl.size else -1
+
+    def fastq_build_ctx(self, line_offset, prev_nl):
+        assert line_offset == self.raw[:self.lo].count(b"\n")          # the running line count of the ranks before this one
+
+        class S:
+            n_reads = int(self.own.size)
+            first_id = int(self.own[0]) if self.own.size else 0
+            size = int(self.recs["rlen"][self.own].sum())
+        return S
+
+    def fastq_comp(self):
+        a = int(self.recs["name_off"][self.own[0]]) - 1
+        last = self.own[-1]
+        b = int(self.recs["qoff"][last] + self.recs["rlen"][last]) + 2
+        c = self.o.fastq_composition(self.raw[a:min(b, len(self.raw))])
+        return (np.array([c[k] for k in ("a", "c", "g", "t", "n")], dtype=np.int64),
+                np.array([c[k] for k in ("maxlen", "minlen", "minqs", "maxqs", "phred")], dtype=np.int64))
+
+    def fastq_fetch_alloc(self, local_ids, phred=0, seq_flags=0, want=("seq", "qual", "quali")):
+        ids = self.own[np.asarray(local_ids, dtype=np.int64)]
+        seq = b"".join(self.raw[int(self.recs["soff"][i]):int(self.recs["soff"][i] + self.recs["rlen"][i])] for i in ids)
+        qual = b"".join(self.raw[int(self.recs["qoff"][i]):int(self.recs["qoff"][i] + self.recs["rlen"][i])] for i in ids)
+        offs = np.zeros(ids.size + 1, dtype=np.int64)
+        np.cumsum(self.recs["rlen"][ids], out=offs[1:])
+        q = np.frombuffer(qual, dtype=np.uint8)
+        return np.frombuffer(seq, dtype=np.uint8), q, (q.astype(np.int16) - (phred or 33)).astype(np.int8), offs
+
+    def close(self):
+        pass
+
+
+def _fastq_worker(rank, world, port, raw, path, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    import fxoracle as oracle
+    from pyfastx_amd import _lib, shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _lib.Blob.from_file_range = classmethod(lambda cls, p, off, length, halo=0, device=0: _OracleFastqShard(oracle, raw, off, off + length))
+    sq = shard.ShardedFastq(path, rank, world)                          # one all-gather: the cores' line counts
+    base, meta = sq.composition()                                        # one more: ten words per rank
+    t = torch.tensor([sq.n_local], dtype=torch.int64)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    first = np.concatenate([[0], np.cumsum([int(o) for o in outs])])
+    ids = np.random.default_rng(5).integers(0, int(first[-1]), 300)      # the same batch on every rank
+    pos, seq, qual, qi, offs = sq.fetch(ids, first, phred=int(meta[4]))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (sq.n_local, sq.first_id, base.tolist(), meta.tolist(), pos, seq.tobytes(), qual.tobytes(), offs))
+    if rank == 0:
+        q.put((ids, gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_fastq_composition_and_fetch_over_gloo(oracle, tmp_path, world):
+    """One process per shard of a FASTQ file: the build's all-gather (line counts), the composition's all-gather (five sums, two
+    minima, two maxima per rank -> base / meta of the whole file on every rank) and the routed fetch (every read of a batch
+    answered by exactly one rank, no bytes between ranks)."""
+    rng = np.random.default_rng(world)
+    recs_txt = []
+    for i in range(400):
+        ln = int(rng.integers(1, 120))
+        recs_txt.append(b"@r%d some text\n%s\n+\n%s\n" % (i, bytes(rng.choice(list(b"ACGTN"), ln).astype(np.uint8)), bytes(rng.integers(40, 75, ln).astype(np.uint8))))
+    raw = b"".join(recs_txt)
+    path = str(tmp_path / "g.fq")
+    open(path, "wb").write(raw)
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fastq_worker, args=(r, world, port, raw, path, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ids, gathered = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    recs, size, _ = oracle.fastq_index(raw)
+    oc = oracle.fastq_composition(raw)
+    assert sum(g[0] for g in gathered) == len(recs)
+    seen = np.zeros(ids.size, dtype=np.int64)
+    for n_local, first_id, base, meta, pos, seq, qual, offs in gathered:
+        assert base == [oc[k] for k in ("a", "c", "g", "t", "n")] and meta == [oc[k] for k in ("maxlen", "minlen", "minqs", "maxqs", "phred")]
+        seen[pos] += 1
+        for j, k in enumerate(pos.tolist()):
+            i = int(ids[k])
+            s0, q0, l = int(recs["soff"][i]), int(recs["qoff"][i]), int(recs["rlen"][i])
+            assert seq[offs[j]:offs[j + 1]] == raw[s0:s0 + l] and qual[offs[j]:offs[j + 1]] == raw[q0:q0 + l]
+    assert (seen == 1).all()

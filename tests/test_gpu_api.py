@@ -605,3 +605,50 @@ def test_fasta_over_several_devices(fx, tmp_path, oracle, kind):
                 assert b[i][3:11].antisense == a[i][3:11].antisense and b[i].raw == a[i].raw
         assert [s.name for s in b][:10] == [s.name for s in a][:10]
         del b
+
+
+@pytest.mark.parametrize("kind", ["lf", "crlf", "bgzf"])
+def test_fastq_over_several_devices(fx, tmp_path, oracle, kind):
+    """Fastq(path, devices=[...]) (round 4, SURVEY 8e in one process): byte-range shards -- logical ones on the one GPU of the
+    test box -- staged and scanned at the same time, the line numbering from the shards' counts, ONE .fxi: the same index file,
+    base / meta and answers as the single-device build; reads that cross the cuts included."""
+    from test_gpu_shards import _rand_fastq
+    from pyfastx_amd import synth
+    rng = np.random.default_rng(23)
+    raw = _rand_fastq(rng, 900, crlf=(kind == "crlf"), trailing=(kind != "crlf"))
+    one, many = str(tmp_path / "one.fq"), str(tmp_path / "many.fq")
+    if kind == "bgzf":
+        one, many = one + ".gz", many + ".gz"
+        data = synth.bgzf_compress(raw, block=3000)
+    else:
+        data = raw
+    for p in (one, many):
+        open(p, "wb").write(data)
+    a = fx.Fastq(one, full_index=True)
+    for devs in ([0, 0, 0], [0] * 7):
+        if os.path.exists(many + ".fxi"):
+            os.unlink(many + ".fxi")
+        b = fx.Fastq(many, full_index=True, devices=devs)
+        assert b._st.md is not None and b._st.md.windows == len(devs) and len(b._st.md.cache.lru) == len(devs)
+        ta, tb = (sqlite3.connect(p + ".fxi") for p in (one, many))
+        for tab in ("read", "base", "meta", "gzindex"):
+            assert ta.execute("SELECT * FROM %s" % tab).fetchall() == tb.execute("SELECT * FROM %s" % tab).fetchall(), (tab, devs)
+        assert ta.execute("SELECT counts, size FROM stat").fetchall() == tb.execute("SELECT counts, size FROM stat").fetchall()
+        assert tb.execute("PRAGMA integrity_check").fetchone()[0] == "ok"
+        n = len(a)
+        assert len(b) == n and b.size == a.size and b.phred == a.phred and b.composition == a.composition
+        ids = rng.integers(0, n, 600)
+        ga, gb = a.fetch_many(ids), b.fetch_many(ids)
+        for k in ("seq", "qual", "quali", "offsets"):
+            assert np.array_equal(ga[k], gb[k]), (k, devs)
+        for i in range(0, n, 37):
+            ra, rb = a[i], b[i]
+            assert (rb.name, rb.seq, rb.qual, rb.quali, rb.raw) == (ra.name, ra.seq, ra.qual, ra.quali, ra.raw)
+            assert b[ra.name].id == ra.id and rb.antisense == ra.antisense
+        assert [(r.name, r.seq, r.qual) for r in b] == [(r.name, r.seq, r.qual) for r in a]
+        ra_, rb_ = a.raw_many(ids[:50]), b.raw_many(ids[:50])
+        assert np.array_equal(ra_[1], rb_[1]) and ra_[0].tobytes() == rb_[0].tobytes()
+        with pytest.raises(IndexError):
+            b.fetch_many([n])
+        del b
+

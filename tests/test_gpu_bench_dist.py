@@ -38,12 +38,14 @@ def test_bench_two_ranks_one_gpu(world):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(FX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
-           "--gbp", "0.05", "--queries", "20000"]
+           "--gbp", "0.05", "--queries", "20000", "--fastq-reads", "3e5"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     line = _last_json(out)
     assert line["n_gpus"] == world and line["parity_verified_full_size"] is True
     assert line["value"] > 0 and line["scaling"] == "weak"
+    fqs = line["fastq_strong"]                                # round 4: ONE FASTQ file over the same ranks -- build, base / meta, ONE .fxi, routed fetch
+    assert fqs["rows_base_meta_fetch_equal_generator"] is True and fqs["reads_indexed"] == 300000 and fqs["build_s"] > 0 and fqs["fetch_routed_s"] > 0
     sf = line["sharded_file"]
     assert sf["merged_fxi_rows_equal_plan"] is True and sf["every_query_answered_once_and_sample_equals_file"] is True
     assert sf["open_range_s"] > 0 and sf["queries_crossing_a_cut"] >= 0

@@ -196,11 +196,15 @@ def test_fastq_shards(oracle, L, seed):
 def test_fastq_every_cut_small(oracle, L):
     raw = b"@r1 d1\r\nACGT\r\n+\r\nIIII\r\n@r2\r\nGGCCA\r\n+r2\r\n#!5AB\r\n@r3 x y\r\nA\r\n+\r\nI\r\n"
     recs, size, ln = oracle.fastq_index(raw)
+    oc = oracle.fastq_composition(raw)
     for c in range(1, len(raw)):
         got, gsize, n, base, meta = fastq_sharded(L, raw, [c], halo=64)
         assert n == len(recs) and gsize == size, c
         for k in got:
             np.testing.assert_array_equal(got[k], recs[k].astype(got[k].dtype), err_msg="%s cut=%d" % (k, c))
+        # composition across every cut (round 4): five sums, two minima, two maxima -- each read counted by the shard that owns it
+        assert base.tolist() == [oc["a"], oc["c"], oc["g"], oc["t"], oc["n"]], c
+        assert meta[:4].tolist() == [oc["maxlen"], oc["minlen"], oc["minqs"], oc["maxqs"]], c
 
 
 def test_fastq_halo_too_small_is_an_error(L):
@@ -451,3 +455,40 @@ def test_sharded_fastq_with_a_read_of_a_megabyte(oracle, L, tmp_path, world):
     for nm in ("big", names[3], names[-1]):
         assert db.execute("SELECT ID FROM read WHERE name=?", (nm,)).fetchone()[0] == names.index(nm) + 1
     db.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_sharded_fastq_composition_and_routed_fetch(oracle, L, tmp_path, world):
+    """Round 4: what was left of multi-GPU FASTQ.  ShardedFastq.composition -- every rank counts the reads it owns, ONE more
+    all-gather of ten words, the phred rule on the merged extremes -- gives the base / meta rows of the whole file on every
+    rank; ShardedFastq.fetch answers the reads of a batch that the rank owns, every read exactly once over the ranks."""
+    rng = np.random.default_rng(40 + world)
+    raw = _rand_fastq(rng, 700, crlf=bool(world & 1))
+    p = tmp_path / "s.fq"
+    p.write_bytes(raw)
+    recs, size, ln = oracle.fastq_index(raw)
+    oc = oracle.fastq_composition(raw)
+    ranks = _logical_ranks(str(p), world)
+    mine = []
+    for r in ranks:                                               # what each rank would put into the all-gather
+        box = []
+        r.composition(gather=lambda m, box=box: (box.append(m.copy()), np.tile(m, (world, 1)))[1])
+        mine.append(box[0])
+    table = np.stack(mine)
+    for r in ranks:
+        base, meta = r.composition(gather=lambda m, t=table: t)
+        assert base.tolist() == [oc["a"], oc["c"], oc["g"], oc["t"], oc["n"]]
+        assert meta.tolist() == [oc["maxlen"], oc["minlen"], oc["minqs"], oc["maxqs"], oc["phred"]]
+    first = np.concatenate([[0], np.cumsum([r.n_local for r in ranks])])
+    ids = rng.integers(0, len(recs), 2000)
+    seen = np.zeros(ids.size, dtype=np.int64)
+    for r in ranks:
+        pos, seq, qual, qi, offs = r.fetch(ids, first, phred=int(oc["phred"]))
+        seen[pos] += 1
+        for j, k in enumerate(pos.tolist()):
+            i = int(ids[k])
+            s0, q0, l = int(recs["soff"][i]), int(recs["qoff"][i]), int(recs["rlen"][i])
+            assert seq[offs[j]:offs[j + 1]].tobytes() == raw[s0:s0 + l] and qual[offs[j]:offs[j + 1]].tobytes() == raw[q0:q0 + l]
+            assert (qi[offs[j]:offs[j + 1]] == oracle.quali(raw, q0, l, int(oc["phred"]))).all()
+    assert (seen == 1).all()
+
