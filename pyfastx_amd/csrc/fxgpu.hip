@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <functional>
 #include <map>
 #include <cstdarg>
 #include <cstdio>
@@ -33,6 +34,7 @@
 #include "fx_names.hpp"
 #include "fx_inflate.hpp"
 #include "fx_inflate_par.hpp"
+#include "fx_bgzf_walk.hpp"
 #include "fx_fxi.hpp"
 #include "fx_pgzip.hpp"
 #include "fx_sort.hpp"
@@ -730,56 +732,33 @@ template <class T> static int upload(fx_handle *h, DevBuf<T> &d, const std::vect
     return FX_OK;
 }
 
-// compressed bytes (file -> pinned pieces -> HBM, stage_plain_file) -> k_bgzf_inflate -> resident blob.
-// [m0, m1): the members to inflate (all of them for a whole file; the ones that cover a byte range of the inflated
-// stream for fx_open_file_range -- only their compressed bytes are read and staged).
-static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable &full, const char *path, int64_t m0 = 0, int64_t m1 = -1) {
-    ScratchBuf<uint8_t> d_c;
+// The kernels of a BGZF open over members whose table is ON THE DEVICE already (d_coff: first deflate byte of each member in
+// d_cp, d_clen: deflate bytes, d_uoff: offset of its bytes in the inflated stream, d_isize), the compressed bytes staged:
+// decode (one wave per member) -> what it handed over, serially -> copy (matches) -> crc -> the blob.  moff_of(m): file offset
+// of member m, for an error message.
+template <class MoffOf>
+static int bgzf_inflate_staged(fx_handle *h, const uint8_t *d_cp, const int64_t *d_coff, const int32_t *d_clen, const int64_t *d_uoff,
+                               const int32_t *d_isize, int64_t nmem, int64_t total, int32_t clen_max, const char *path, MoffOf moff_of,
+                               const std::function<void(const char *)> &lap) {
     int rc;
     static const bool trace = [] { const char *e = getenv("FX_TRACE"), *b = getenv("FX_TRACE_BGZF"); return (e && atoi(e) != 0) || (b && atoi(b) != 0); }();
-    const auto T0 = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (trace) fprintf(stderr, "[fxgpu] bgzf %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
-    };
-    if (m1 < 0) m1 = (int64_t)full.moff.size();
-    BgzfTable t;                                           // the range, offsets relative to its first member
-    const int64_t c0 = full.moff[(size_t)m0], u0 = full.uoff[(size_t)m0];
-    const int64_t c1 = m1 < (int64_t)full.moff.size() ? full.moff[(size_t)m1] : fsize_all;
-    for (int64_t m = m0; m < m1; ++m) {
-        t.moff.push_back(full.moff[(size_t)m]); t.coff.push_back(full.coff[(size_t)m] - c0); t.uoff.push_back(full.uoff[(size_t)m] - u0);
-        t.clen.push_back(full.clen[(size_t)m]); t.isize.push_back(full.isize[(size_t)m]);
-        t.total += full.isize[(size_t)m];
-    }
-    const int64_t fsize = c1 - c0;
-    DevBuf<int64_t> d_coff, d_uoff;
-    DevBuf<int32_t> d_clen, d_isize, d_status, d_pstatus;
-    if ((rc = d_c.alloc(h->device, fsize + 48, h->stream))) return rc;          // the bit reader looks three 8-byte words ahead
-    HIPCHK(hipMemsetAsync(d_c.p + fsize, 0, 48, h->stream));
-    lap("alloc compressed");
-    if ((rc = stage_plain_file(h, fd, fsize, path, d_c.p, c0))) return rc;
-    lap("staged");
-    if ((rc = upload(h, d_coff, t.coff)) || (rc = upload(h, d_uoff, t.uoff)) || (rc = upload(h, d_clen, t.clen)) ||
-        (rc = upload(h, d_isize, t.isize)))
-        return rc;
-    const int64_t nmem = (int64_t)t.moff.size();
+    ScratchBuf<int32_t> d_status, d_pstatus;
     // where the matches of a member begin: one bit per output byte (k_bgzf_decode sets them, k_bgzf_copy walks them)
     ScratchBuf<uint64_t> d_map;
     if ((rc = d_map.alloc(h->device, nmem * BM_WORDS, h->stream))) return rc;
-    if ((rc = d_status.alloc(nmem)) || (rc = d_pstatus.alloc(nmem))) return rc;
+    if ((rc = d_status.alloc(h->device, nmem, h->stream)) || (rc = d_pstatus.alloc(h->device, nmem, h->stream))) return rc;
     ScratchBuf<uint16_t> d_gsym;                             // canonical symbol order of every member's tables (slow path of the decoder)
     if ((rc = d_gsym.alloc(h->device, nmem * GSYM, h->stream))) return rc;
     HIPCHK(hipMemsetAsync(d_status.p, 0xFF, (size_t)nmem * 4, h->stream));
     HIPCHK(hipMemsetAsync(d_pstatus.p, 0, (size_t)nmem * 4, h->stream));
     HIPCHK(hipMemsetAsync(d_map.p, 0, (size_t)nmem * BM_WORDS * 8, h->stream));
-    if ((rc = alloc_blob(h, t.total))) return rc;
+    if ((rc = alloc_blob(h, total))) return rc;
     lap("allocations");
     // one wave per member, the lanes at 64 bit positions of it (fx_inflate_par.hpp); members it hands over (status INFL_RETRY:
     // anything out of the ordinary, damaged members included) are decoded by one lane each, as in round 2.  FX_BGZF_SERIAL=1: only that.
     static const bool serial_only = [] { const char *e = getenv("FX_BGZF_SERIAL"); return e && atoi(e) != 0; }();
     static const int dbg_par = [] { const char *e = getenv("FX_BGZF_DBG"); return e ? atoi(e) : 0; }();
     // LDS of a wave: the tables + the member's payload (sized for the largest member of the file, at most 64 KiB of the 160 per CU)
-    int32_t clen_max = 0;
-    for (int32_t c : t.clen) clen_max = std::max(clen_max, c);
     const int lds_payload = (int)std::min<int64_t>(((int64_t)clen_max + 16 + 255) & ~255ll, 65536);
     static const bool stage = [] { const char *e = getenv("FX_BGZF_STAGE"); return e && atoi(e) != 0; }();   // the payload through LDS (experiment)
     static const bool replay = [] { const char *e = getenv("FX_BGZF_REPLAY"); return e && atoi(e) != 0; }();   // phase B replays the symbols phase A left behind (experiment: no faster -- what B costs is its stores)
@@ -802,7 +781,7 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
     if (replay && !serial_only && (rc = d_sym.alloc(h->device, (int64_t)par_grid * SYM_ROWS * 64, h->stream))) return rc;
     if (!serial_only) {
         h->prof.begin(K_BGZF_INFLATE, h->stream);
-        hipLaunchKernelGGL(par_kernel, dim3(par_grid), dim3(64), par_lds, h->stream, d_c.p, d_coff.p, d_clen.p, d_uoff.p, d_isize.p, nmem,
+        hipLaunchKernelGGL(par_kernel, dim3(par_grid), dim3(64), par_lds, h->stream, d_cp, d_coff, d_clen, d_uoff, d_isize, nmem,
                            h->d_data, d_status.p, d_map.p, dbg_par, lds_payload, d_pstatus.p, d_sym.p, SYM_ROWS);
         h->prof.end(h->stream);
         if (trace) {                                         // how many members the wave-per-member kernel handed over, and why
@@ -819,7 +798,7 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipStreamSynchronize(h->stream);
         (void)hipEventRecord(e0, h->stream);
-        hipLaunchKernelGGL(par_kernel, dim3(par_grid), dim3(64), par_lds, h->stream, d_c.p, d_coff.p, d_clen.p, d_uoff.p, d_isize.p, nmem,
+        hipLaunchKernelGGL(par_kernel, dim3(par_grid), dim3(64), par_lds, h->stream, d_cp, d_coff, d_clen, d_uoff, d_isize, nmem,
                            h->d_data, d_status.p, d_map.p, dbg_par, lds_payload, d_pstatus.p, d_sym.p, SYM_ROWS);
         (void)hipEventRecord(e1, h->stream);
         (void)hipStreamSynchronize(h->stream);
@@ -828,16 +807,16 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
         fprintf(stderr, "[fxgpu] k_bgzf_decode_par dbg=%d: %.3f ms for %lld members\n", dbg_par, ms, (long long)nmem);
         return fail(FX_EIO, "FX_BGZF_DBG is a timing probe");
     }
-    FX_LAUNCH(h, K_BGZF_SERIAL, k_bgzf_decode, dim3(nblocks(nmem, INFL_BLOCK)), dim3(INFL_BLOCK), d_c.p, d_coff.p,
-              d_clen.p, d_uoff.p, d_isize.p, nmem, h->d_data, d_status.p, d_map.p, d_gsym.p, serial_only ? -1 : (int)INFL_RETRY);
-    FX_LAUNCH(h, K_BGZF_COPY, k_bgzf_copy, dim3(nblocks(nmem, COPY_BLOCK / 64)), dim3(COPY_BLOCK), d_uoff.p, d_isize.p, nmem, h->d_data, d_map.p);
+    FX_LAUNCH(h, K_BGZF_SERIAL, k_bgzf_decode, dim3(nblocks(nmem, INFL_BLOCK)), dim3(INFL_BLOCK), d_cp, d_coff,
+              d_clen, d_uoff, d_isize, nmem, h->d_data, d_status.p, d_map.p, d_gsym.p, serial_only ? -1 : (int)INFL_RETRY);
+    FX_LAUNCH(h, K_BGZF_COPY, k_bgzf_copy, dim3(nblocks(nmem, COPY_BLOCK / 64)), dim3(COPY_BLOCK), d_uoff, d_isize, nmem, h->d_data, d_map.p);
     static const bool no_crc = [] { const char *e = getenv("FX_BGZF_NO_CRC"); return e && atoi(e) != 0; }();
-    DevBuf<CrcTables> d_crc;
+    ScratchBuf<CrcTables> d_crc;
     if (!no_crc) {                                           // every member against the CRC-32 of its trailer, as zlib does in gzread
         static const CrcTables *tabs = [] { CrcTables *t = new CrcTables; crc_tables(t); return t; }();
-        if ((rc = d_crc.alloc(1))) return rc;
+        if ((rc = d_crc.alloc(h->device, 1, h->stream))) return rc;
         HIPCHK(hipMemcpyAsync(d_crc.p, tabs, sizeof(CrcTables), hipMemcpyHostToDevice, h->stream));
-        FX_LAUNCH(h, K_BGZF_CRC, k_bgzf_crc, dim3(nblocks(nmem, 4)), dim3(256), h->d_data, d_uoff.p, d_isize.p, d_c.p, d_coff.p, d_clen.p,
+        FX_LAUNCH(h, K_BGZF_CRC, k_bgzf_crc, dim3(nblocks(nmem, 4)), dim3(256), h->d_data, d_uoff, d_isize, d_cp, d_coff, d_clen,
                   nmem, d_crc.p, d_status.p);
     }
     HIPCHK(hipGetLastError());
@@ -853,10 +832,123 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
         if (status[m] != INFL_OK)
             return fail(FX_EIO, status[m] == INFL_ECRC ? "BGZF member %lld of %s (offset %lld): CRC-32 of the inflated bytes differs from the trailer (code %d)"
                                                        : "BGZF member %lld of %s (offset %lld) failed to inflate: code %d",
-                        (long long)m, path, (long long)t.moff[m], status[m]);
+                        (long long)m, path, (long long)moff_of(m), status[m]);
+    return FX_OK;
+}
+
+// compressed bytes (file -> pinned pieces -> HBM, stage_plain_file) -> k_bgzf_inflate -> resident blob.
+// [m0, m1): the members to inflate (all of them for a whole file; the ones that cover a byte range of the inflated
+// stream for fx_open_file_range -- only their compressed bytes are read and staged).
+static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable &full, const char *path, int64_t m0 = 0, int64_t m1 = -1) {
+    ScratchBuf<uint8_t> d_c;
+    int rc;
+    static const bool trace = [] { const char *e = getenv("FX_TRACE"), *b = getenv("FX_TRACE_BGZF"); return (e && atoi(e) != 0) || (b && atoi(b) != 0); }();
+    const auto T0 = std::chrono::steady_clock::now();
+    const std::function<void(const char *)> lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "[fxgpu] bgzf %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
+    };
+    if (m1 < 0) m1 = (int64_t)full.moff.size();
+    BgzfTable t;                                           // the range, offsets relative to its first member
+    const int64_t c0 = full.moff[(size_t)m0], u0 = full.uoff[(size_t)m0];
+    const int64_t c1 = m1 < (int64_t)full.moff.size() ? full.moff[(size_t)m1] : fsize_all;
+    for (int64_t m = m0; m < m1; ++m) {
+        t.moff.push_back(full.moff[(size_t)m]); t.coff.push_back(full.coff[(size_t)m] - c0); t.uoff.push_back(full.uoff[(size_t)m] - u0);
+        t.clen.push_back(full.clen[(size_t)m]); t.isize.push_back(full.isize[(size_t)m]);
+        t.total += full.isize[(size_t)m];
+    }
+    const int64_t fsize = c1 - c0;
+    DevBuf<int64_t> d_coff, d_uoff;
+    DevBuf<int32_t> d_clen, d_isize;
+    if ((rc = d_c.alloc(h->device, fsize + 48, h->stream))) return rc;          // the bit reader looks three 8-byte words ahead
+    HIPCHK(hipMemsetAsync(d_c.p + fsize, 0, 48, h->stream));
+    lap("alloc compressed");
+    if ((rc = stage_plain_file(h, fd, fsize, path, d_c.p, c0))) return rc;
+    lap("staged");
+    if ((rc = upload(h, d_coff, t.coff)) || (rc = upload(h, d_uoff, t.uoff)) || (rc = upload(h, d_clen, t.clen)) ||
+        (rc = upload(h, d_isize, t.isize)))
+        return rc;
+    const int64_t nmem = (int64_t)t.moff.size();
+    int32_t clen_max = 0;
+    for (int32_t c : t.clen) clen_max = std::max(clen_max, c);
+    if ((rc = bgzf_inflate_staged(h, d_c.p, d_coff.p, d_clen.p, d_uoff.p, d_isize.p, nmem, t.total, clen_max, path,
+                                  [&](int64_t m) { return t.moff[(size_t)m]; }, lap)))
+        return rc;
     h->bgzf = true;
     h->gz_mode = 1;
     h->gz_moff = full.moff; h->gz_coff = full.coff; h->gz_uoff = full.uoff; h->gz_csize = fsize_all;
+    return FX_OK;
+}
+
+// A whole BGZF file with the member table made on the device (fx_bgzf_walk.hpp): stage the compressed bytes, find the members
+// in HBM, inflate.  -> FX_OK; 1: not a file this path takes (another header layout, a chain that does not tile the file: the
+// host walk decides); < 0: an error.
+static int bgzf_open_on_device(fx_handle *h, int fd, int64_t fsize, const char *path) {
+    static const bool off = [] { const char *e = getenv("FX_BGZF_HOST_WALK"); return e && atoi(e) != 0; }();
+    if (off || fsize < BGZF_HDR + 8) return 1;
+    uint8_t head[16];
+    static const uint8_t sig[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 'B', 'C', 0x02, 0x00};
+    if (pread(fd, head, 16, 0) != 16 || memcmp(head, sig, 16) != 0) return 1;
+    static const bool trace = [] { const char *e = getenv("FX_TRACE"), *b = getenv("FX_TRACE_BGZF"); return (e && atoi(e) != 0) || (b && atoi(b) != 0); }();
+    const auto T0 = std::chrono::steady_clock::now();
+    const std::function<void(const char *)> lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "[fxgpu] bgzf %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
+    };
+    int rc;
+    ScratchBuf<uint8_t> d_c;
+    if ((rc = d_c.alloc(h->device, fsize + 48, h->stream))) return rc;
+    HIPCHK(hipMemsetAsync(d_c.p + fsize, 0, 48, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));                  // the staging lanes copy on streams of their own
+    if ((rc = stage_plain_file(h, fd, fsize, path, d_c.p, 0))) return rc;
+    lap("staged");
+    const int64_t ngran = (fsize + 4095) / 4096;
+    const int64_t nchunks = (ngran + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    ScratchBuf<int64_t> d_i64;                                // off[ngran + 1] | sums[nchunks + 1]
+    ScratchBuf<int32_t> d_cnt;
+    if ((rc = d_i64.alloc(h->device, ngran + 1 + nchunks + 1, h->stream)) || (rc = d_cnt.alloc(h->device, ngran, h->stream))) return rc;
+    int64_t *d_off = d_i64.p, *d_sums = d_i64.p + ngran + 1;
+    hipLaunchKernelGGL(k_bgzf_sig_count, dim3(nblocks(ngran, BLOCK / 64)), dim3(BLOCK), 0, h->stream, (const uint8_t *)d_c.p, fsize, ngran, d_cnt.p);
+    hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, (const int32_t *)d_cnt.p, ngran, d_sums);
+    hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, d_sums, nchunks);
+    hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, (const int32_t *)d_cnt.p, ngran, (const int64_t *)d_sums, d_off);
+    int64_t nmem = 0;
+    HIPCHK(hipMemcpyAsync(&nmem, d_off + ngran, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (nmem <= 0 || nmem > fsize / (BGZF_HDR + 8)) return 1;
+    // the member table: mstart | coff | uoff[nmem + 1] | scan sums, then clen | isize | flags
+    const int64_t mchunks = (nmem + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    ScratchBuf<int64_t> d_t64;
+    ScratchBuf<int32_t> d_t32;
+    if ((rc = d_t64.alloc(h->device, 3 * nmem + 1 + mchunks + 1, h->stream)) || (rc = d_t32.alloc(h->device, 2 * nmem + 2, h->stream))) return rc;
+    int64_t *d_mstart = d_t64.p, *d_coff = d_t64.p + nmem, *d_uoff = d_t64.p + 2 * nmem, *d_msums = d_t64.p + 3 * nmem + 1;
+    int32_t *d_clen = d_t32.p, *d_isize = d_t32.p + nmem, *d_flags = d_t32.p + 2 * nmem;      // flags: [0] bad, [1] longest deflate payload
+    HIPCHK(hipMemsetAsync(d_flags, 0, 8, h->stream));
+    hipLaunchKernelGGL(k_bgzf_sig_emit, dim3(nblocks(ngran, BLOCK / 64)), dim3(BLOCK), 0, h->stream, (const uint8_t *)d_c.p, fsize, ngran, (const int64_t *)d_off, d_mstart);
+    hipLaunchKernelGGL(k_bgzf_member_rows, dim3(nblocks(nmem, BLOCK)), dim3(BLOCK), 0, h->stream, (const uint8_t *)d_c.p, fsize, (const int64_t *)d_mstart, nmem,
+                       d_coff, d_clen, d_isize, (int *)d_flags, d_flags + 1);
+    hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)mchunks), dim3(BLOCK), 0, h->stream, (const int32_t *)d_isize, nmem, d_msums);
+    hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, d_msums, mchunks);
+    hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)mchunks), dim3(BLOCK), 0, h->stream, (const int32_t *)d_isize, nmem, (const int64_t *)d_msums, d_uoff);
+    HIPCHK(hipGetLastError());
+    int32_t flags[2] = {0, 0};
+    int64_t total = 0;
+    HIPCHK(hipMemcpyAsync(flags, d_flags, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&total, d_uoff + nmem, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    lap("member table (device)");
+    if (flags[0] || total <= 0) return 1;                     // the chain does not tile the file: the host walk decides what this file is
+    // the host's copy of the table (restart points, fx_gz_points; an error message): on its way while the members inflate
+    h->gz_moff.resize((size_t)nmem); h->gz_coff.resize((size_t)nmem); h->gz_uoff.resize((size_t)nmem);
+    HIPCHK(hipMemcpyAsync(h->gz_moff.data(), d_mstart, (size_t)nmem * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->gz_coff.data(), d_coff, (size_t)nmem * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->gz_uoff.data(), d_uoff, (size_t)nmem * 8, hipMemcpyDeviceToHost, h->stream));
+    if ((rc = bgzf_inflate_staged(h, d_c.p, d_coff, d_clen, d_uoff, d_isize, nmem, total, flags[1], path,
+                                  [&](int64_t m) { return h->gz_moff[(size_t)m]; }, lap))) {
+        h->gz_moff.clear(); h->gz_coff.clear(); h->gz_uoff.clear();
+        return rc;
+    }
+    h->bgzf = true;
+    h->gz_mode = 1;
+    h->gz_csize = fsize;
     return FX_OK;
 }
 
@@ -1120,9 +1212,16 @@ static int open_file_impl(const char *path, int device, fx_handle **out, int64_t
             auto lap = [&](const char *what) {
                 if (trace) fprintf(stderr, "[fxgpu] open %-27s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
             };
+            int brc = bgzf_open_on_device(h, fd, fsize, path);      // the member table found in HBM (fx_bgzf_walk.hpp); 1: not that kind of file
+            lap("open (device walk)");
+            if (brc == FX_OK) { close(fd); *out = h; return FX_OK; }
+            if (brc < 0) return bail(brc);
+            if (h->d_data || h->d_alloc) {                            // (a blob the attempt allocated: none on the ways it gives up)
+                (void)hipFree(h->d_alloc ? h->d_alloc : h->d_data); h->d_data = nullptr; h->d_alloc = nullptr; h->n = 0;
+            }
             void *mp = mmap(nullptr, (size_t)fsize, PROT_READ, MAP_PRIVATE, fd, 0);
             BgzfTable tab;
-            int brc = 1;
+            brc = 1;
             if (mp != MAP_FAILED) {
                 // (the walk touches 47 k pages of the mapping: 16-20 ms for C4.  Run in a thread of its own beside the staging
                 // of the compressed bytes it made the staging four times slower -- page faults on the mapping against the

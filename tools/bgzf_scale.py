@@ -27,17 +27,22 @@ def main():
     blob_t, flat, fs = synth.fasta_generate(plan, dev, keep_flat=False)
     nb = int(plan["n_bytes"])
     host = blob_t[:nb].cpu().numpy().tobytes()
-    step = 65280 * 64
     t0 = time.perf_counter()
-    with Pool(min(64, os.cpu_count() or 8)) as pool:
-        parts = pool.map(_comp, [host[a:a + step] for a in range(0, nb, step)])
-    bg = b"".join(parts) + synth.bgzf_compress(b"")
+    bg = synth.bgzf_compress_parallel(np.frombuffer(host, dtype=np.uint8))
     t1 = time.perf_counter()
     d = tempfile.mkdtemp(prefix="fxbgzf")
     path = os.path.join(d, "c4.fa.gz")
     open(path, "wb").write(bg)
     _lib.lib().fx_prof_default(1)
     _lib.Blob.from_file(path).close()                   # warm page cache / first-touch
+    opens = []
+    for _ in range(3):
+        t2 = time.perf_counter()
+        b = _lib.Blob.from_file(path)
+        t3 = time.perf_counter()
+        opens.append(t3 - t2)
+        b.close()
+    os.environ["FX_BGZF_HOST_WALK_PROBE"] = "1"
     t2 = time.perf_counter()
     b = _lib.Blob.from_file(path)
     t3 = time.perf_counter()
@@ -64,7 +69,7 @@ def main():
     print(json.dumps({"workload": "C4: %.1f Gbp FASTA, BGZF (%d members, %.2f GB compressed, %.2f GB inflated)" % (
                           gbp, (nb + 65279) // 65280, len(bg) / 1e9, nb / 1e9),
                       "host_compress_s_setup_only": round(t1 - t0, 1),
-                      "open_file_total_s": round(t3 - t2, 3), "k_bgzf_inflate_ms": round(infl_ms, 2), "decode_ms": round(dec_ms, 2), "copy_ms": round(cp_ms, 2),
+                      "open_file_total_s": round(sorted(opens)[1], 4), "open_file_all_s": [round(x, 4) for x in opens], "k_bgzf_inflate_ms": round(infl_ms, 2), "decode_ms": round(dec_ms, 2), "copy_ms": round(cp_ms, 2),
                       "kernels_ms": {k: round(v, 3) for k, v in avg.items()}, "inflate_GBps_out": round(nb / (infl_ms * 1e-3) / 1e9, 1), "inflated_equals_original": same,
                       "index_rows_equal_plan": ok, "gzindex_points": int(c.size)}))
     os.unlink(path)
