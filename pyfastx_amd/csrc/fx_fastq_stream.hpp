@@ -1,0 +1,222 @@
+// fx_fastq_stream.hpp -- FASTQ composition as a STREAM over the bytes (gfx950, round 4).
+//
+// pyfastx_fastq_calc_composition (fastq.c:663-795) is a `line_num % 4` loop over the lines of the file: the bases of every
+// second line of four are counted (A C G T upper case; everything else but '\r' is N), the bytes of every fourth line give the
+// smallest and largest quality.  k_fastq_comp (fx_fastq.hpp) goes at it from the READ TABLE: ten lanes per read, 16 bytes per
+// lane at whatever address the table says -- and is bound by exactly that: unaligned 16-byte gathers cost 40 L1 tag look-ups
+// per instruction (7.2 ms for C3, 4.8 TB/s of a stream that is read whole anyway).
+//
+// This kernel reads the stream the way the scans do -- a wave per run of granules, 64 lanes x 16 contiguous bytes per load,
+// non-temporal -- and decides per BYTE which line of four it belongs to from what the index build left behind: nl_prefix[g] is
+// the global number of the first newline of granule g, so the line a byte belongs to is nl_prefix[g] + (newlines of the
+// granule in front of it), a wave scan of the popcounts of the newline masks.  A 16-byte chunk then has ONE part that counts
+// (its bytes in front of its newline, or behind it) of ONE kind (bases or qualities), picked by a mask looked up in LDS:
+//   bases      x & 7 is distinct for ' ' A \n C T \r N G, so one v_perm_b32 makes a one-hot class byte of every byte and a second
+//              one the byte that class stands for (x ^ expected != 0: a byte that is none of them -- lower case, IUPAC codes --
+//              fixed up byte by byte: N for the reference); the one-hot words go into bit planes (fx_comp.hpp);
+//   qualities  packed 16-bit min / max on the bytes and on the bytes shifted by one (no unpacking: the high byte of a half
+//              decides), bytes that do not count filled with 0x00 / 0xFF.
+// Chunks with three newlines or more (lines shorter than ~7 bytes) are walked byte by byte.  A quality byte below '!' or above
+// 127 -- a '\r', which the reference skips with its line.l quirk (fastq.c:733-737), or bytes it reads as negative chars -- only
+// raises a flag: the host then runs k_fastq_comp, which knows those cases, instead.  Whole streams only (a shard counts the
+// reads it OWNS: k_fastq_comp, from its table).
+#pragma once
+#include "fx_fastq.hpp"
+#include "fx_comp.hpp"
+
+namespace fx {
+
+// by x & 7:                     0 (' ')  1 A     2 \n    3 C   |  4 T     5 \r    6 N     7 G
+constexpr uint32_t FS_OH_LO = 0x02000100u, FS_OH_HI = 0x04100008u;     // one-hot: A 1, C 2, G 4, T 8, N 16
+constexpr uint32_t FS_EX_LO = 0x430A4180u, FS_EX_HI = 0x474E0D54u;     // the byte the code stands for (0x80: none)
+constexpr int FS_GPW = 8;                                              // granules per wave
+constexpr int FS_NONE = 34 + 17 * 17, FS_NMASK = FS_NONE + 1;
+
+__device__ __forceinline__ uint32_t fs_orn(uint32_t a, uint32_t b) { return a | ~b; }
+
+struct FsAcc { CompPlanes pl; uint32_t mn, mn2, mx, mx2; uint32_t extra[5]; bool qodd; };
+
+// the bytes of `x` (one word of a chunk) that are bases (ms) / qualities (mq) into the accumulators; -> x ^ expected where a
+// base is none of A C G T N \r (0: none)
+__device__ __forceinline__ uint32_t fs_word(uint32_t x, uint32_t ms, uint32_t mq, uint32_t &h, FsAcc &a) {
+    const uint32_t xs = (uint32_t)__builtin_amdgcn_bitop3_b32(ms, x, 0x0D0D0D0Du, 0xCA);     // ms ? x : '\r'
+    const uint32_t code = xs & 0x07070707u;
+    h = __builtin_amdgcn_perm(FS_OH_HI, FS_OH_LO, code);
+    const uint32_t d = xs ^ __builtin_amdgcn_perm(FS_EX_HI, FS_EX_LO, code);
+    const uint32_t hi = x & mq, lo = fs_orn(x, mq);
+    a.mx = pk_max_u16(a.mx, hi); a.mx2 = pk_max_u16(a.mx2, hi << 8);
+    a.mn = pk_min_u16(a.mn, lo); a.mn2 = pk_min_u16(a.mn2, (lo << 8) | 0xFFu);
+    return d;
+}
+
+// byte b (0..15, any value at run time) of a chunk held in four words: selects, not an indexed array (which would live in scratch)
+__device__ __forceinline__ uint32_t fs_byte(const uint4 &v, int b) {
+    const uint32_t lo = (b & 4) ? v.y : v.x, hi = (b & 4) ? v.w : v.z;
+    return (((b & 8) ? hi : lo) >> ((b & 3) * 8)) & 0xFFu;
+}
+// one byte of line-of-four p as the reference's loop takes it (fastq.c:720-745)
+__device__ __forceinline__ void fs_one(uint32_t c, uint32_t p, FsAcc &a) {
+    if (p == 1u) {
+        if (c == 13u) return;
+        const int cls = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) a.extra[k] += cls == k ? 1u : 0u;
+    } else if (p == 3u) {
+        if (c < 33u || c > 127u) a.qodd = true;
+        else { a.mn = pk_min_u16(a.mn, (c << 8) | 0xFFFF00FFu); a.mx = pk_max_u16(a.mx, c << 8); }
+    }
+}
+
+// ngran_full granules that lie entirely inside the stream go through the fast path; the ragged end of the stream ([tail0, n),
+// less than a granule) is walked by the last wave, 64 bytes per lane.
+__global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__restrict__ data, int64_t n, int64_t nfull,
+                                                            const int64_t *__restrict__ nl_prefix, int64_t line0, FastqAcc *acc) {
+    // masks of a chunk's bytes: [k] bytes [0, k); [17 + k] bytes (k, 16); [34 + 17 k1 + k2] bytes (k1, k2); [FS_NONE] none
+    __shared__ uint4 s_mask[FS_NMASK];
+    __shared__ int s_fix[BLOCK / 64][8];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < FS_NMASK; e += BLOCK) {
+        int lo, hi;                                        // the bytes lo < p < hi
+        if (e < 17) { lo = -1; hi = e; }
+        else if (e < 34) { lo = e - 17; hi = 16; }
+        else if (e < FS_NONE) { lo = (e - 34) / 17; hi = (e - 34) % 17; }
+        else { lo = 16; hi = 16; }
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t m = 0;
+            for (int b = 0; b < 4; ++b) { const int p = 4 * i + b; if (p > lo && p < hi) m |= 0xFFu << (8 * b); }
+            w[i] = m;
+        }
+        s_mask[e] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    if (lane < 8) s_fix[wv][lane] = 0;
+    __syncthreads();
+    int *fix = s_fix[wv];
+    FsAcc a;
+#pragma unroll
+    for (int k = 0; k < COMP_NPL; ++k) a.pl.p[k] = 0;
+    a.mn = a.mn2 = 0xFFFFFFFFu; a.mx = a.mx2 = 0u; a.qodd = false;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) a.extra[c] = 0;
+    // A grid of as many waves as the device holds at once; wave w takes the runs w, w + nwaves, ... (one set of atomics per
+    // WAVE at the end: a million waves adding to the same seven words would take longer than the stream takes to read).
+    const int64_t wave = (int64_t)blockIdx.x * (BLOCK / 64) + wv, nwaves = (int64_t)gridDim.x * (BLOCK / 64);
+    unsigned long long tot[5] = {0, 0, 0, 0, 0};
+    int runs_in_planes = 0;
+    uint4 v[GR_ROWS], nx[GR_ROWS];
+  for (int64_t g0 = wave * FS_GPW; g0 < nfull; g0 += nwaves * FS_GPW) {
+    granule_load<true>(v, data, n, 0, g0);
+#pragma unroll 1
+    for (int kk = 0; kk < FS_GPW; ++kk) {
+        const int64_t g = g0 + kk;
+        if (g >= nfull) break;
+        const bool more = kk + 1 < FS_GPW && g + 1 < nfull;
+        if (more) granule_load<true>(nx, data, n, 0, g + 1);
+        // ---- the line every chunk begins in
+        uint32_t nlm[GR_ROWS], ex[GR_ROWS];
+        uint32_t run = 0;
+#pragma unroll
+        for (int j = 0; j < GR_ROWS; ++j) {
+            nlm[j] = eq_mask16(v[j], 0x0A0A0A0Au);
+            const uint32_t c = (uint32_t)__popc(nlm[j]);
+            const uint32_t inc = wave_incl_scan(c);
+            ex[j] = run + inc - c;
+            run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        }
+        const uint32_t L0 = (uint32_t)((line0 + nl_prefix[g]) & 3);
+        CompCarry cy;
+#pragma unroll
+        for (int j = 0; j < GR_ROWS; ++j) {
+            const uint32_t pA = (L0 + ex[j]) & 3u;         // which line of four the chunk's first byte belongs to
+            // Up to two line ends in a chunk ('+' lines are two bytes long: nearly every record has such a chunk): three stretches --
+            // in front of the first newline (line pA), between the two (pA + 1), behind the second (pA + 2) -- of which at most one
+            // holds bases (its line is 1 of four) and at most one qualities (3): each picked by ONE look-up whose address is made
+            // from pA and the two positions
+            const uint32_t cnt = (uint32_t)__popc(nlm[j]);
+            const uint32_t m1 = nlm[j] & (nlm[j] - 1u);
+            const int k1 = cnt ? __ffs(nlm[j]) - 1 : 16, k2 = m1 ? __ffs(m1) - 1 : 16;
+            const int i0 = k1, i1 = 34 + 17 * k1 + k2, i2 = 17 + k2;
+            const bool slow = cnt >= 3u;                                       // three line ends in 16 bytes: byte by byte below
+            const int is = slow ? FS_NONE : pA == 1u ? i0 : pA == 0u ? i1 : pA == 3u ? i2 : FS_NONE;
+            const int iq = slow ? FS_NONE : pA == 3u ? i0 : pA == 2u ? i1 : pA == 1u ? i2 : FS_NONE;
+            const uint4 ms = s_mask[is], mq = s_mask[iq];
+            uint32_t h0, h1, h2, h3;
+            const uint32_t d0 = fs_word(v[j].x, ms.x, mq.x, h0, a), d1 = fs_word(v[j].y, ms.y, mq.y, h1, a);
+            const uint32_t d2 = fs_word(v[j].z, ms.z, mq.z, h2, a), d3 = fs_word(v[j].w, ms.w, mq.w, h3, a);
+            planes_add4(a.pl, cy, j, h0, h1, h2, h3);
+            if (__builtin_expect((d0 | d1 | d2 | d3) != 0, 0)) {   // a base that is none of A C G T N \r: N for the reference; take the aliased class back out
+#pragma unroll 1
+                for (int b = 0; b < 16; ++b) {
+                    const uint32_t dw = (b & 8) ? ((b & 4) ? d3 : d2) : ((b & 4) ? d1 : d0);
+                    if (!((dw >> ((b & 3) * 8)) & 0xFFu)) continue;
+                    const uint32_t hw = (b & 8) ? ((b & 4) ? h3 : h2) : ((b & 4) ? h1 : h0);
+                    const uint32_t hk = (hw >> ((b & 3) * 8)) & 0xFFu;
+                    if (hk) atomicSub(&fix[__ffs(hk) - 1], 1);
+                    atomicAdd(&fix[4], 1);
+                }
+            }
+            if (__builtin_expect(slow, 0)) {
+                uint32_t p = pA;
+#pragma unroll 1
+                for (int b = 0; b < CHUNK; ++b) {
+                    const uint32_t c = fs_byte(v[j], b);
+                    if (c == 10u) { p = (p + 1u) & 3u; continue; }
+                    fs_one(c, p, a);
+                }
+            }
+        }
+        planes_finish16(a.pl, cy);
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < GR_ROWS; ++j) v[j] = nx[j];
+        }
+    }
+    if (++runs_in_planes == 6) {                           // 6 x 8 granules x 16 words: the planes count to 1023
+#pragma unroll
+        for (int c = 0; c < 5; ++c) tot[c] += planes_count(a.pl, c);
+#pragma unroll
+        for (int k = 0; k < COMP_NPL; ++k) a.pl.p[k] = 0;
+        runs_in_planes = 0;
+    }
+  }
+    // ---- the ragged end of the stream: wave 0 walks its bytes, 64 per lane
+    const int64_t tail0 = nfull * (int64_t)GRAN;
+    if (tail0 < n && wave == 0) {
+        const int64_t lo = tail0 + (int64_t)lane * 64, hi = lo + 64 < n ? lo + 64 : n;
+        uint32_t c = 0;
+        for (int64_t p = lo; p < hi; ++p) c += data[p] == 10;
+        const uint32_t inc = wave_incl_scan(c);
+        uint32_t ph = (uint32_t)((line0 + nl_prefix[nfull] + (int64_t)(inc - c)) & 3);
+        for (int64_t p = lo; p < hi; ++p) {
+            const uint32_t b = data[p];
+            if (b == 10u) { ph = (ph + 1u) & 3u; continue; }
+            fs_one(b, ph, a);
+        }
+    }
+    // ---- the lane's counts, the wave's, the accumulators
+#pragma unroll
+    for (int c = 0; c < 5; ++c) tot[c] = (unsigned long long)wave_sum64((long long)(tot[c] + planes_count(a.pl, c) + a.extra[c]));
+    uint32_t mn = pk_min_u16(a.mn, a.mn2), mx = pk_max_u16(a.mx, a.mx2);
+    int qmin = (int)min(mn >> 24, (mn >> 8) & 0xFFu), qmax = (int)max(mx >> 24, (mx >> 8) & 0xFFu);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const int x = __shfl_xor(qmin, d, 64), y = __shfl_xor(qmax, d, 64);
+        qmin = x < qmin ? x : qmin; qmax = y > qmax ? y : qmax;
+    }
+    const bool have = qmin < 255 || qmax > 0;             // a quality byte was seen
+    const bool odd = __ballot(a.qodd) != 0ull || (have && (qmin < 33 || qmax > 127));
+    if (lane == 0) {
+        const long long ta = (long long)tot[0] + fix[0], tc = (long long)tot[1] + fix[1], tg = (long long)tot[2] + fix[2],
+                        tt = (long long)tot[3] + fix[3], tn = (long long)tot[4] + fix[4];
+        if (ta) atomicAdd(&acc->a, (unsigned long long)ta);
+        if (tc) atomicAdd(&acc->c, (unsigned long long)tc);
+        if (tg) atomicAdd(&acc->g, (unsigned long long)tg);
+        if (tt) atomicAdd(&acc->t, (unsigned long long)tt);
+        if (tn) atomicAdd(&acc->n, (unsigned long long)tn);
+        if (have) { atomicMin(&acc->minqs, qmin); atomicMax(&acc->maxqs, qmax); }
+        if (odd) atomicAdd(&acc->qfix, 1);
+    }
+}
+
+}  // namespace fx

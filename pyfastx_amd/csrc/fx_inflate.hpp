@@ -487,6 +487,17 @@ __device__ __forceinline__ void ld32_l2(const uint8_t *p, uint64_t (&w)[4]) {
     w[2] = b.x | ((uint64_t)b.y << 32); w[3] = b.z | ((uint64_t)b.w << 32);
 }
 
+// the token of a match: the word at its place, any alignment, ONE request to the L2 (ld_u64 above is three)
+__device__ __forceinline__ uint32_t ld_tok(const uint8_t *base, int64_t byte_off) {
+    return __hip_atomic_load(reinterpret_cast<const uint32_t *>(base + byte_off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ld16_l2(const uint8_t *p, uint64_t (&w)[4]) {
+    uint4 a;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(a) : "v"(p) : "memory");
+    w[0] = a.x | ((uint64_t)a.y << 32); w[1] = a.z | ((uint64_t)a.w << 32);
+    w[2] = 0; w[3] = 0;
+}
+
 constexpr int COPY_BLOCK = 256, COPY_POS = 4096 / 3 + 2;
 __global__ __launch_bounds__(COPY_BLOCK) void k_bgzf_copy(const int64_t *__restrict__ uoff, const int32_t *__restrict__ isize, int64_t nmem,
                                                          uint8_t *__restrict__ data,          // 4-byte aligned, readable 12 bytes past the end
@@ -517,13 +528,13 @@ __global__ __launch_bounds__(COPY_BLOCK) void k_bgzf_copy(const int64_t *__restr
         // other: the short ones are made by their own lanes, all at once (source words first, then the stores), the long
         // ones one after the other by the whole wave.  The first pending match is always ready, so a batch takes as many
         // rounds as its longest chain of matches feeding matches -- one or two -- instead of one step per dependent match.
-        uint32_t tk_next = total > 0 && lane < total ? (uint32_t)ld_u64(data, ub + sp[lane]) : 0u;
+        uint32_t tk_next = total > 0 && lane < total ? ld_tok(data, ub + sp[lane]) : 0u;
         for (int b0 = 0; b0 < total; b0 += 64) {
             const int i = b0 + lane;
             const bool have = i < total;
             const int64_t dst = have ? sp[i] : 0;
             const uint32_t tk = tk_next;                       // 8 + 15 bits in the first three bytes of the match's place
-            tk_next = i + 64 < total ? (uint32_t)ld_u64(data, ub + sp[i + 64]) : 0u;     // the next batch's: no match of this one writes there
+            tk_next = i + 64 < total ? ld_tok(data, ub + sp[i + 64]) : 0u;     // the next batch's: no match of this one writes there
             const int len = (int)(tk & 0xFFu) + 3;
             const int64_t dist = (int64_t)((tk >> 8) & 0x7FFFu) + 1;
             const int64_t src = dst - dist;
@@ -534,21 +545,32 @@ __global__ __launch_bounds__(COPY_BLOCK) void k_bgzf_copy(const int64_t *__restr
                 const bool ready = pending && src + need <= frontier;
                 const bool wide = ready && len > 32;
                 if (ready && !wide) {
-                    if (dist >= len) {                         // the 32 bytes at the source in two loads, then the stores
-                        uint64_t w[4];
-                        ld32_l2(data + ub + src, w);
+                    if (dist >= len) {                         // the bytes at the source -- 16 in one load when that is all the match takes
+                        uint64_t w[4];                         // (most matches of genome text are short; the kernel is bound by the requests it
+                        if (len <= 16) ld16_l2(data + ub + src, w);      // sends to the L2, one per lane and load), else 32 in two -- then the stores
+                        else ld32_l2(data + ub + src, w);
                         uint8_t *o = data + ub + dst;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int left = len - 8 * k;
-                            if (left >= 8) *reinterpret_cast<uint64_u *>(o + 8 * k) = w[k];
-                            else if (left > 0) {
-                                uint64_t t = w[k];
-                                int q = 8 * k;
-                                if (left & 4) { *reinterpret_cast<uint32_u *>(o + q) = (uint32_t)t; t >>= 32; q += 4; }
-                                if (left & 2) { o[q] = (uint8_t)t; o[q + 1] = (uint8_t)(t >> 8); t >>= 16; q += 2; }
-                                if (left & 1) o[q] = (uint8_t)t;
+                        // as few stores as the length allows (the kernel is bound by its requests to the L2): the head of the match,
+                        // then its LAST 16 / 8 / 4 bytes once more, overlapping the head where they must
+                        if (len >= 16) {
+                            *reinterpret_cast<uint4_u *>(o) = make_uint4((uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32));
+                            if (len > 16) {
+                                const int sh = len - 16;                       // 1 .. 16: the 16 bytes from byte sh on
+                                const int q = sh >> 3, r = (sh & 7) * 8;
+                                const uint64_t a0 = q == 0 ? w[0] : q == 1 ? w[1] : w[2], a1 = q == 0 ? w[1] : q == 1 ? w[2] : w[3],
+                                               a2 = q == 0 ? w[2] : q == 1 ? w[3] : 0ull;           // (selects: an indexed array would live in scratch)
+                                const uint64_t t0 = r ? (a0 >> r) | (a1 << (64 - r)) : a0, t1 = r ? (a1 >> r) | (a2 << (64 - r)) : a1;
+                                *reinterpret_cast<uint4_u *>(o + sh) = make_uint4((uint32_t)t0, (uint32_t)(t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32));
                             }
+                        } else if (len >= 8) {
+                            *reinterpret_cast<uint64_u *>(o) = w[0];
+                            if (len > 8) { const int r = (len - 8) * 8; *reinterpret_cast<uint64_u *>(o + len - 8) = (w[0] >> r) | (w[1] << (64 - r)); }
+                        } else if (len >= 4) {
+                            *reinterpret_cast<uint32_u *>(o) = (uint32_t)w[0];
+                            if (len > 4) *reinterpret_cast<uint32_u *>(o + len - 4) = (uint32_t)(w[0] >> ((len - 4) * 8));
+                        } else {                                               // 3 bytes: a match is never shorter
+                            *reinterpret_cast<uint16_u *>(o) = (uint16_t)w[0];
+                            o[2] = (uint8_t)(w[0] >> 16);
                         }
                     } else for (int j = 0; j < len; ++j) data[ub + dst + j] = ld_byte(data, ub + src + j % dist);   // run replication
                 }

@@ -223,7 +223,10 @@ __global__ __launch_bounds__(BLOCK) void k_fetch(const uint8_t *__restrict__ dat
                                                 uint8_t *__restrict__ dst, const int32_t *__restrict__ list = nullptr,
                                                 const int *__restrict__ list_n = nullptr) {
     __shared__ uint8_t lut[256];
-    if (list) nq = *list_n;                                    // list mode: only the queries k_fetch_lines left over
+    if (list) {                                                // list mode: only the queries k_fetch_lines left over
+        nq = *list_n;
+        if (nq == 0) return;                                   // (for a genome: none -- leave before the tables are set up, the launch is all this costs)
+    }
     // BY_ID: the record table of a genome (a few hundred rows) is copied to LDS once per workgroup, so
     // resolving a query costs one LDS read instead of a second dependent trip to memory
     constexpr int TABCAP = BY_ID ? 512 : 1;
@@ -469,11 +472,17 @@ __global__ __launch_bounds__(BLOCK) void k_fetch(const uint8_t *__restrict__ dat
 // with nothing else: a query that it cannot answer exactly (a record that is not line-regular, lines shorter than 16
 // bases, the edge of the stream, FX_RAW, a terminator that is not where the arithmetic says, white space among the bases,
 // an invalid id) goes on a list, and k_fetch runs over that list afterwards (for a genome: empty).
-template <int G, int NP>
+template <int G, int NP, bool COAL = false>
 __global__ __launch_bounds__(BLOCK) void k_fetch_lines(const uint8_t *__restrict__ data, int64_t gbase, int64_t n_bytes, FetchQ q, FastaTab tab,
                                                       int64_t nq, int flags_all, uint8_t *__restrict__ dst, int32_t *__restrict__ list,
                                                       int *__restrict__ list_n) {
     __shared__ uint8_t lut[256];
+    // COAL: the answers of a wave's 16 queries are put together in LDS when they lie back to back in the output (dst_off[i + 1]
+    // = dst_off[i] + take: what every caller that lets the library lay the answers out gets) and leave as ALIGNED 16-byte
+    // stores that cover whole lines -- 100-byte answers at a 100-byte stride are otherwise unaligned stores that leave both
+    // ends of most 128-byte lines partly written (PMC WRITE_SIZE 1.45 x the answers' bytes, profiles/pmc_k_span_scan.json)
+    constexpr int CO_CAP = 2048;                               // bytes of answers per wave and step that the LDS path takes
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[COAL ? BLOCK / 64 : 1][COAL ? (CO_CAP + 32) / 4 : 1];
     constexpr int TABCAP = 512;
     __shared__ int64_t s_boff[TABCAP], s_slen[TABCAP];
     __shared__ int32_t s_llen[TABCAP], s_en[TABCAP];           // s_en = elen | line-regular << 8
@@ -528,6 +537,29 @@ __global__ __launch_bounds__(BLOCK) void k_fetch_lines(const uint8_t *__restrict
                 fast = in_a >= 16 && in_a + blen + 32 <= n_bytes;
             }
         }
+        // ---- COAL: do the 16 answers of this step lie back to back, dword-aligned, and fit the LDS buffer?
+        bool co = false;
+        uint32_t co_rel = 0, co_span = 0, co_sh = 0;           // this query's place in the wave's span; the span; (first byte of the span) & 15
+        uint8_t *co_base = nullptr;
+        if (COAL) {
+            const uint32_t lo32 = (uint32_t)(uintptr_t)out, tk = (uint32_t)take;
+            const uint32_t nxt = (uint32_t)__shfl((int)lo32, (lane + G) & 63, 64);
+            const bool chain = grp == QPW - 1 || nxt == lo32 + tk;                 // the next query's answer begins where this one ends
+            const bool okq = live && fast && take > 0 && take <= CO_CAP && (tk & 3u) == 0 && (lo32 & 3u) == 0 && chain;
+            if (__ballot(okq) == ~0ull) {
+                const uint32_t first = (uint32_t)__shfl((int)lo32, 0, 64), last = (uint32_t)__shfl((int)lo32, 63, 64), ltk = (uint32_t)__shfl((int)tk, 63, 64);
+                co_span = last + ltk - first;
+                if (co_span <= (uint32_t)CO_CAP) {
+                    co = true;
+                    co_rel = lo32 - first;
+                    co_sh = first & 15u;
+                    const uint64_t b0 = (uint64_t)(uintptr_t)out - co_rel;       // address of the span's first byte (lane-uniform)
+                    co_base = reinterpret_cast<uint8_t *>(((uint64_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b0 >> 32)) << 32) |
+                                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b0));
+                }
+            }
+        }
+        uint32_t *const so = COAL ? s_out[threadIdx.x >> 6] : nullptr;
         if (fast) {
             const bool rev = (fl & 2) != 0;
             for (int64_t s0 = 0; s0 < take; s0 += NP * G * 16) {      // NP pieces per lane and step, all their loads first (see k_fetch)
@@ -590,9 +622,33 @@ __global__ __launch_bounds__(BLOCK) void k_fetch_lines(const uint8_t *__restrict
                     if (fl & 1) { x.x = upper4(x.x); x.y = upper4(x.y); x.z = upper4(x.z); x.w = upper4(x.w); }
                     if (fl & 4) { x.x = lut4(lut, x.x); x.y = lut4(lut, x.y); x.z = lut4(lut, x.z); x.w = lut4(lut, x.w); }
                     if (rev) x = make_uint4(__builtin_bswap32(x.w), __builtin_bswap32(x.z), __builtin_bswap32(x.y), __builtin_bswap32(x.x));
-                    store_low_bytes(out + oc[u], x, ln);
+                    if (COAL && co) {                            // into the wave's span in LDS: ln is a multiple of four here
+                        uint32_t *w = so + ((co_sh + co_rel + (uint32_t)oc[u]) >> 2);
+                        w[0] = x.x;
+                        if (ln > 4) w[1] = x.y;
+                        if (ln > 8) w[2] = x.z;
+                        if (ln > 12) w[3] = x.w;
+                    } else store_low_bytes(out + oc[u], x, ln);
                 }
             }
+        }
+        if (COAL && co) {
+            // the span leaves as aligned 16-byte pieces: piece c covers bytes [16 c, 16 c + 16) of the buffer, whose byte co_sh is
+            // the span's first; the two ends are stored dword by dword
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            uint8_t *const ab = co_base - co_sh;                // 16-byte aligned
+            const uint32_t lo_b = co_sh, hi_b = co_sh + co_span;
+            for (uint32_t c = (uint32_t)lane; c * 16u < hi_b; c += 64u) {
+                const uint32_t a0 = c * 16u;
+                const uint4 v = *reinterpret_cast<const uint4 *>(so + (a0 >> 2));
+                if (a0 >= lo_b && a0 + 16u <= hi_b) *reinterpret_cast<uint4 *>(ab + a0) = v;
+                else {
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (a0 + 4u * k >= lo_b && a0 + 4u * k + 4u <= hi_b) *reinterpret_cast<uint32_t *>(ab + a0 + 4u * k) = w[k];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (the buffer is written again in the next step)
         }
         const unsigned long long ib = __ballot(irregular);
         constexpr unsigned long long gmask = G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);

@@ -30,6 +30,7 @@
 #include "fx_spanscan.hpp"
 #include "fx_fastq.hpp"
 #include "fx_comp.hpp"
+#include "fx_fastq_stream.hpp"
 #include "fx_scancomp.hpp"
 #include "fx_names.hpp"
 #include "fx_inflate.hpp"
@@ -2027,6 +2028,37 @@ extern "C" int fx_fastq_comp(fx_handle *h, int64_t base[5], int64_t meta[5]) {
     int rc = use_device(h);
     if (rc) return rc;
     const FqTab t{h->fq_name_off.p, h->fq_rlen.p, h->fq_soff.p, h->fq_qoff.p, h->fq_name_len.p, h->fq_dlen.p, h->fq_qlen.p};
+    // A whole stream: the composition as a stream over the bytes (k_fastq_comp_stream: coalesced loads, the line of four of
+    // every byte from the build's newline prefixes) -- 5.x ms for C3 where the gather from the read table takes 7.2.  It only
+    // flags what it does not do itself (a '\r' or a byte outside '!'..127 in a quality line): then, and for shards (which count
+    // the reads they OWN), the table kernel below runs.  FX_FQ_COMP_TABLE=1: always that one.
+    static const bool table_only = [] { const char *e = getenv("FX_FQ_COMP_TABLE"); return e && atoi(e) != 0; }();
+    if (!table_only && h->base == 0 && h->halo == 0 && h->is_last && h->nl_prefix.p && h->ngran > 0) {
+        const int64_t nfull = h->n / GRAN, waves = nfull / FS_GPW + 1;
+        static int s_per_cu = 0, s_n_cu = 256;               // as many workgroups as are resident at once
+        if (!s_per_cu) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&s_per_cu, k_fastq_comp_stream, BLOCK, 0) != hipSuccess || s_per_cu <= 0) s_per_cu = 4;
+            (void)hipDeviceGetAttribute(&s_n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+        }
+        FX_LAUNCH(h, K_FASTQ_COMP, k_fastq_comp_stream, dim3((unsigned)std::min<int64_t>(nblocks(waves, BLOCK / 64), (int64_t)s_per_cu * s_n_cu)), dim3(BLOCK), h->d_data, h->n, nfull,
+                  (const int64_t *)h->nl_prefix.p, (int64_t)0, h->fq_acc.p);
+        HIPCHK(hipGetLastError());
+        FastqAcc acc;
+        HIPCHK(hipMemcpyAsync(&acc, h->fq_acc.p, sizeof acc, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        FastqAcc keep = acc;                                 // the counters back to their start values, whichever way this goes on
+        keep.a = keep.c = keep.g = keep.t = keep.n = 0; keep.minqs = 104; keep.maxqs = 33; keep.qfix = 0;
+        HIPCHK(hipMemcpyAsync(h->fq_acc.p, &keep, sizeof keep, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (!acc.qfix) {
+            base[0] = (int64_t)acc.a; base[1] = (int64_t)acc.c; base[2] = (int64_t)acc.g; base[3] = (int64_t)acc.t; base[4] = (int64_t)acc.n;
+            int phred = 0;
+            if (acc.maxqs > 74) phred = 64;                  // fastq.c:768-774
+            if (acc.minqs < 59) phred = 33;
+            meta[0] = h->fq_maxlen; meta[1] = h->fq_minlen; meta[2] = acc.minqs; meta[3] = acc.maxqs; meta[4] = phred;
+            return FX_OK;
+        }
+    }
     // a grid-stride kernel: exactly as many workgroups as are resident at once (no partial last round)
     static int per_cu = 0, n_cu = 256;                      // asked once
     if (!per_cu) {
@@ -2362,7 +2394,9 @@ static int fetch_launch(fx_handle *h, Staged &st, const FetchQ &q, bool by_id, b
         // (pieces of 16 bytes a lane has in flight: 1 -> 71 registers, 7 waves per SIMD, 0.104 ms per 1 M; 2 -> 85, 5 waves, 0.106;
         // the general kernel alone, 102 registers: 0.113-0.121.  FX_FETCH_NP: experiments)
         static const int np = [] { const char *e = getenv("FX_FETCH_NP"); return e ? atoi(e) : 1; }();
-        if (np == 1) FX_LAUNCH(h, K_FETCH, (k_fetch_lines<4, 1>), dim3(fetch_grid((n + 15) / 16)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst, d_list, d_cnt);
+        static const bool coal = [] { const char *e = getenv("FX_FETCH_COAL"); return e && atoi(e) != 0; }();
+        if (np == 1 && coal) FX_LAUNCH(h, K_FETCH, (k_fetch_lines<4, 1, true>), dim3(fetch_grid((n + 15) / 16)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst, d_list, d_cnt);
+        else if (np == 1) FX_LAUNCH(h, K_FETCH, (k_fetch_lines<4, 1>), dim3(fetch_grid((n + 15) / 16)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst, d_list, d_cnt);
         else         FX_LAUNCH(h, K_FETCH, (k_fetch_lines<4, 2>), dim3(fetch_grid((n + 15) / 16)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags, d_dst, d_list, d_cnt);
         FX_LAUNCH(h, K_FETCH_REST, (k_fetch<true, 4, 16>), dim3(std::min(fetch_grid((n + 15) / 16), 1024u)), dim3(BLOCK), h->d_data, h->base, h->n, q, tab, n, flags,
                   d_dst, (const int32_t *)d_list, (const int *)d_cnt);
