@@ -498,43 +498,77 @@ __device__ __forceinline__ void ld16_l2(const uint8_t *p, uint64_t (&w)[4]) {
     w[2] = 0; w[3] = 0;
 }
 
-constexpr int COPY_BLOCK = 256, COPY_POS = 4096 / 3 + 2;
+#ifndef FX_COPY_SW
+#define FX_COPY_SW 32
+#endif
+constexpr int COPY_SW = FX_COPY_SW;                        // map words per stretch: 32 = 2 KiB of output (64: 4 KiB -- 27 KB of LDS per workgroup, five waves per SIMD instead of eight)
+constexpr int COPY_SB = COPY_SW * 64;                      // bytes of a stretch
+constexpr int COPY_BLOCK = 256, COPY_POS = COPY_SB / 3 + 2;
 __global__ __launch_bounds__(COPY_BLOCK) void k_bgzf_copy(const int64_t *__restrict__ uoff, const int32_t *__restrict__ isize, int64_t nmem,
-                                                         uint8_t *__restrict__ data,          // 4-byte aligned, readable 12 bytes past the end
+                                                         uint8_t *__restrict__ data,          // 4-byte aligned, readable a tile past the end
                                                          const uint64_t *__restrict__ match_map) {
     __shared__ uint16_t s_pos[COPY_BLOCK / 64][COPY_POS];
+    // The stretch as the decode kernel left it -- literals, tokens, zeros -- is read ONCE, coalesced, before any of its matches is
+    // made: the tokens then come out of LDS.  (One load per token, at 64 places per instruction, was a quarter of the requests
+    // this kernel sends to the L2, and those are what bound it.)
+    __shared__ __attribute__((aligned(16))) uint32_t s_tok[COPY_BLOCK / 64][COPY_SB / 4 + 4];
     const int lane = threadIdx.x & 63;
     const int64_t m = ((int64_t)blockIdx.x * COPY_BLOCK + threadIdx.x) >> 6;
     if (m >= nmem) return;                                 // waves are independent: no workgroup barrier below
     uint16_t *sp = s_pos[threadIdx.x >> 6];
+    uint32_t *stok = s_tok[threadIdx.x >> 6];
     const uint64_t *B = match_map + m * BM_WORDS;
     const int64_t ub = uoff[m];                            // member's offset in the stream
     const int nwords = (isize[m] + 63) >> 6;
-    uint64_t wnext = lane < nwords ? B[lane] : 0ull;       // the map of a stretch is requested while the stretch before is resolved
-    for (int c0 = 0; c0 < nwords; c0 += 64) {
+    uint64_t wnext = lane < COPY_SW && lane < nwords ? B[lane] : 0ull;       // the map of a stretch is requested while the stretch before is resolved
+    for (int c0 = 0; c0 < nwords; c0 += COPY_SW) {
         uint64_t wd = wnext;
-        wnext = c0 + 64 + lane < nwords ? B[c0 + 64 + lane] : 0ull;
+        wnext = lane < COPY_SW && c0 + COPY_SW + lane < nwords ? B[c0 + COPY_SW + lane] : 0ull;
         const uint32_t cnt = (uint32_t)__popcll(wd), incl = wave_incl_scan(cnt);
         const int total = __shfl((int)incl, 63, 64);
+        if (total == 0) continue;
+        {
+            const uint8_t *sb = data + ub + ((int64_t)c0 << 6);
+            // COPY_SB / 1024 x 1 KiB coalesced + the 16 bytes behind the stretch (every lane the same: one request)
+            uint4 t[COPY_SB / 1024], t4;
+            const uint8_t *pl = sb + lane * 16, *pt = sb + COPY_SB;
+            if (COPY_SB == 4096)
+                asm volatile("global_load_dwordx4 %0, %5, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off offset:1024 sc0 sc1\n\t"
+                             "global_load_dwordx4 %2, %5, off offset:2048 sc0 sc1\n\tglobal_load_dwordx4 %3, %5, off offset:3072 sc0 sc1\n\t"
+                             "global_load_dwordx4 %4, %6, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[COPY_SB / 1024 - 2]), "=&v"(t[COPY_SB / 1024 - 1]), "=&v"(t4) : "v"(pl), "v"(pt) : "memory");
+            else
+                asm volatile("global_load_dwordx4 %0, %3, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off offset:1024 sc0 sc1\n\t"
+                             "global_load_dwordx4 %2, %4, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t4) : "v"(pl), "v"(pt) : "memory");
+            uint4 *st4 = reinterpret_cast<uint4 *>(stok);
+#pragma unroll
+            for (int k = 0; k < COPY_SB / 1024; ++k) st4[k * 64 + lane] = t[k];
+            if (lane == 0) st4[COPY_SB / 16] = t4;
+        }
         uint32_t r = incl - cnt;
         while (wd) {
             const int k = __ffsll((long long)wd) - 1;
             wd &= wd - 1;
             sp[r++] = (uint16_t)(((c0 + lane) << 6) + k);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         // 64 matches at a time.  Everything below `frontier` is final: first the place of the batch's first match, then, round
         // by round, the place of its first match that is still to do (the bytes before it are literals or matches already
         // made).  A match whose source ends below the frontier is ready; the ready matches of a round do not depend on each
         // other: the short ones are made by their own lanes, all at once (source words first, then the stores), the long
         // ones one after the other by the whole wave.  The first pending match is always ready, so a batch takes as many
         // rounds as its longest chain of matches feeding matches -- one or two -- instead of one step per dependent match.
-        uint32_t tk_next = total > 0 && lane < total ? ld_tok(data, ub + sp[lane]) : 0u;
         for (int b0 = 0; b0 < total; b0 += 64) {
             const int i = b0 + lane;
             const bool have = i < total;
             const int64_t dst = have ? sp[i] : 0;
-            const uint32_t tk = tk_next;                       // 8 + 15 bits in the first three bytes of the match's place
-            tk_next = i + 64 < total ? ld_tok(data, ub + sp[i + 64]) : 0u;     // the next batch's: no match of this one writes there
+            uint32_t tk = 0;                                   // 8 + 15 bits in the first three bytes of the match's place
+            if (have) {
+                const uint32_t rel = (uint32_t)dst - ((uint32_t)c0 << 6);
+                const uint32_t wq = rel >> 2, sh = (rel & 3u) * 8u;
+                tk = sh ? __funnelshift_r(stok[wq], stok[wq + 1], sh) : stok[wq];
+            }
             const int len = (int)(tk & 0xFFu) + 3;
             const int64_t dist = (int64_t)((tk >> 8) & 0x7FFFu) + 1;
             const int64_t src = dst - dist;
@@ -545,26 +579,29 @@ __global__ __launch_bounds__(COPY_BLOCK) void k_bgzf_copy(const int64_t *__restr
                 const bool ready = pending && src + need <= frontier;
                 const bool wide = ready && len > 32;
                 if (ready && !wide) {
-                    if (dist >= len) {                         // the bytes at the source -- 16 in one load when that is all the match takes
-                        uint64_t w[4];                         // (most matches of genome text are short; the kernel is bound by the requests it
-                        if (len <= 16) ld16_l2(data + ub + src, w);      // sends to the L2, one per lane and load), else 32 in two -- then the stores
+                    uint8_t *o = data + ub + dst;
+                    if (dist >= len || dist == 1) {
+                        // the bytes at the source -- 16 in one load when that is all the match takes (most matches of genome text are
+                        // short), else 32 in two; a run of ONE byte (dist 1: N runs, poly-A) is that byte sixteen times
+                        uint64_t w[4];
+                        if (dist == 1) { const uint64_t v = (uint64_t)ld_byte(data, ub + src) * 0x0101010101010101ull; w[0] = w[1] = w[2] = w[3] = v; }
+                        else if (len <= 16) ld16_l2(data + ub + src, w);
                         else ld32_l2(data + ub + src, w);
-                        uint8_t *o = data + ub + dst;
-                        // as few stores as the length allows (the kernel is bound by its requests to the L2): the head of the match,
-                        // then its LAST 16 / 8 / 4 bytes once more, overlapping the head where they must
+                        // as few stores as the length allows: the head of the match, then its LAST 16 / 8 / 4 bytes once more,
+                        // overlapping the head where they must
                         if (len >= 16) {
                             *reinterpret_cast<uint4_u *>(o) = make_uint4((uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32));
                             if (len > 16) {
                                 const int sh = len - 16;                       // 1 .. 16: the 16 bytes from byte sh on
-                                const int q = sh >> 3, r = (sh & 7) * 8;
+                                const int q = sh >> 3, rr = (sh & 7) * 8;
                                 const uint64_t a0 = q == 0 ? w[0] : q == 1 ? w[1] : w[2], a1 = q == 0 ? w[1] : q == 1 ? w[2] : w[3],
                                                a2 = q == 0 ? w[2] : q == 1 ? w[3] : 0ull;           // (selects: an indexed array would live in scratch)
-                                const uint64_t t0 = r ? (a0 >> r) | (a1 << (64 - r)) : a0, t1 = r ? (a1 >> r) | (a2 << (64 - r)) : a1;
+                                const uint64_t t0 = rr ? (a0 >> rr) | (a1 << (64 - rr)) : a0, t1 = rr ? (a1 >> rr) | (a2 << (64 - rr)) : a1;
                                 *reinterpret_cast<uint4_u *>(o + sh) = make_uint4((uint32_t)t0, (uint32_t)(t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32));
                             }
                         } else if (len >= 8) {
                             *reinterpret_cast<uint64_u *>(o) = w[0];
-                            if (len > 8) { const int r = (len - 8) * 8; *reinterpret_cast<uint64_u *>(o + len - 8) = (w[0] >> r) | (w[1] << (64 - r)); }
+                            if (len > 8) { const int rr = (len - 8) * 8; *reinterpret_cast<uint64_u *>(o + len - 8) = (w[0] >> rr) | (w[1] << (64 - rr)); }
                         } else if (len >= 4) {
                             *reinterpret_cast<uint32_u *>(o) = (uint32_t)w[0];
                             if (len > 4) *reinterpret_cast<uint32_u *>(o + len - 4) = (uint32_t)(w[0] >> ((len - 4) * 8));
@@ -572,15 +609,25 @@ __global__ __launch_bounds__(COPY_BLOCK) void k_bgzf_copy(const int64_t *__restr
                             *reinterpret_cast<uint16_u *>(o) = (uint16_t)w[0];
                             o[2] = (uint8_t)(w[0] >> 16);
                         }
-                    } else for (int j = 0; j < len; ++j) data[ub + dst + j] = ld_byte(data, ub + src + j % dist);   // run replication
+                    } else for (int j = 0; j < len; ++j) o[j] = ld_byte(data, ub + src + j % dist);   // a short period: byte by byte
                 }
                 unsigned long long wb = __ballot(wide);
-                while (wb) {                                   // each one as a wave-wide gather
+                while (wb) {                                   // each long one by the whole wave, 16 bytes per lane where the source allows
                     const int l = __ffsll(wb) - 1;
                     wb &= wb - 1;
                     const int64_t d_l = __shfl((int)dst, l, 64), k_l = __shfl((int)dist, l, 64);
                     const int n_l = __shfl(len, l, 64);
-                    for (int j = lane; j < n_l; j += 64) data[ub + d_l + j] = ld_byte(data, ub + d_l - k_l + (k_l < n_l ? j % k_l : j));
+                    uint8_t *o = data + ub + d_l;
+                    if (k_l == 1 || k_l >= n_l) {              // one byte repeated, or a source that ends in front of the place
+                        int j = lane * 16;
+                        if (j < n_l) {
+                            if (j + 16 > n_l) j = n_l - 16;    // the last piece once more, overlapping (n_l > 32)
+                            uint4 v;
+                            if (k_l == 1) { const uint32_t c = (uint32_t)ld_byte(data, ub + d_l - 1) * 0x01010101u; v = make_uint4(c, c, c, c); }
+                            else { uint64_t w[4]; ld16_l2(o - k_l + j, w); v = make_uint4((uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32)); }
+                            *reinterpret_cast<uint4_u *>(o + j) = v;
+                        }
+                    } else for (int j = lane; j < n_l; j += 64) o[j] = ld_byte(data, ub + d_l - k_l + j % k_l);
                 }
                 pending = pending && !ready;
                 __threadfence_block();                         // this wave's stores are at the L2 before the next round's (or batch's) loads

@@ -25,6 +25,10 @@
 #pragma once
 #include "fx_inflate.hpp"
 
+#ifndef FX_BGZF_GLOBAL_MAP
+#define FX_BGZF_LDS_MAP 1                                               // the match map of a member in LDS (see P_MAP_SET)
+#endif
+
 namespace fx {
 
 constexpr int P_LB = 10, P_DB = 8, P_LPOOL = 512, P_DPOOL = 384;        // root bits; sub-table entries (an overflow hands the member over)
@@ -49,7 +53,9 @@ struct PTab {
     int hdr[8];                                                         // lane 0 -> wave: status, nlen, ndist, position behind the header, type, last
     uint32_t hY[64], hc[64], oY[64], oc[64], hn[64], on[64];          // hand-over: what lane k found for its target / what lane t was given (position, bytes, symbols)
     int htgt[64], own[64];
+#ifdef FX_BGZF_LDS_MAP
     uint32_t map[2048];                                                // the member's match map (one bit per output byte), flushed once
+#endif
 };
 
 // >= 57 bits of the payload from bit position bitpos on.  STAGE: the payload sits in LDS (three aligned words and two
@@ -304,6 +310,14 @@ template <bool STAGE> __device__ __forceinline__ void p_header(PTab &T, const ui
 // 64 lanes: one coalesced 256-byte store per step), and phase B does not decode again -- it replays its own rows.  The
 // scratch belongs to the WAVE, not to the member (the grid is as many waves as the device holds at once, every wave takes
 // members m, m + grid, ...): sym_rows rows of 64 words each, a member with a lane that needs more is handed over.
+// the bit of output byte o in the member's match map: in LDS and flushed once per member (8 KiB of the wave's 21: seven waves
+// per CU), or -- FX_BGZF_GLOBAL_MAP, measured in round 4 -- straight in memory (13 KiB, twelve waves per CU, but 460 M atomics
+// on memory for C4: decode 12.4 -> 20.3 ms)
+#ifdef FX_BGZF_LDS_MAP
+#define P_MAP_SET(o) atomicOr(&T.map[(o) >> 5], 1u << ((o) & 31u))
+#else
+#define P_MAP_SET(o) atomicOr(reinterpret_cast<unsigned int *>(bm) + ((o) >> 5), 1u << ((o) & 31u))
+#endif
 template <bool STAGE, bool REPLAY>
 __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restrict__ cbuf, const int64_t *__restrict__ cdata_off,
                                                          const int32_t *__restrict__ cdata_len, const int64_t *__restrict__ uoff,
@@ -316,7 +330,9 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
     uint32_t *const sb = REPLAY ? symbuf + (size_t)blockIdx.x * (size_t)sym_rows * 64u + (uint32_t)lane : nullptr;   // this lane's column
   for (int64_t m = blockIdx.x; m < nmem; m += gridDim.x) {
     __syncthreads();                                         // (the tables of the member before are done with)
+#ifdef FX_BGZF_LDS_MAP
     for (int i = lane; i < 2048; i += 64) T.map[i] = 0;
+#endif
     const uint8_t *gbase = cbuf + cdata_off[m];
     const uint32_t pend = (uint32_t)cdata_len[m] * 8u;       // the payload in bits (< 2^19)
     const uint8_t *base = gbase;
@@ -504,7 +520,7 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
                         if (o + outn > o_end) { bad = INFL_ESIZE; break; }
                         if (kind) {
                             if ((val >> 8) + 1u > o) { bad = INFL_EDIST; break; }
-                            atomicOr(&T.map[o >> 5], 1u << (o & 31u));
+                            P_MAP_SET(o);
                         }
                         const uint64_t v = kind ? (uint64_t)(val & 0xFFFFFFu) : (uint64_t)(val & 0xFFu);
                         acc |= v << (8u * fill);
@@ -531,7 +547,7 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
                 if (o + s.out > o_end) { bad = INFL_ESIZE; break; }
                 if (s.kind == 1) {
                     if ((s.val >> 8) + 1u > o) { bad = INFL_EDIST; break; }      // BGZF members never reference outside themselves
-                    atomicOr(&T.map[o >> 5], 1u << (o & 31u));
+                    P_MAP_SET(o);
                 }
                 if (dbg == 4) { acc += s.val; o += s.out; bp += s.nbits; continue; }
                 // literal: one byte; match: the 3-byte token, then out - 3 bytes of nothing
@@ -558,10 +574,12 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
     }
     if (st == INFL_OK && obase != cap) st = INFL_ESIZE;
     __syncthreads();
+#ifdef FX_BGZF_LDS_MAP
     if (st == INFL_OK) {                                     // the map out of LDS: whole words, coalesced (the buffer was cleared by the host)
         const uint32_t nw = (cap + 63u) >> 6;
         for (uint32_t i = lane; i < nw; i += 64) bm[i] = (unsigned long long)T.map[2 * i] | ((unsigned long long)T.map[2 * i + 1] << 32);
     }
+#endif
     if (st != INFL_OK) {
         // whatever went wrong, the serial kernel decodes the member again (and names the error if there is one): it wants a
         // clean match map.  The status keeps the reason: INFL_RETRY + 1 / 2 sub-table pool, 3 end-of-block codes, 4 no meeting
