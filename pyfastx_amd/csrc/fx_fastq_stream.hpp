@@ -30,23 +30,41 @@ namespace fx {
 constexpr uint32_t FS_OH_LO = 0x02000100u, FS_OH_HI = 0x04100008u;     // one-hot: A 1, C 2, G 4, T 8, N 16
 constexpr uint32_t FS_EX_LO = 0x430A4180u, FS_EX_HI = 0x474E0D54u;     // the byte the code stands for (0x80: none)
 constexpr int FS_GPW = 8;                                              // granules per wave
-constexpr int FS_NONE = 34 + 17 * 17, FS_NMASK = FS_NONE + 1;
+// masks of a chunk's bytes, s_mask[(r * 17 + k1) * 17 + k2] with k1 <= k2 the positions of its first two newlines (16: none):
+// r = 0 the bytes in front of k1, r = 1 those between k1 and k2, r = 2 those behind k2, r = 3 none
+constexpr int FS_NMASK = 4 * 17 * 17;
 
 __device__ __forceinline__ uint32_t fs_orn(uint32_t a, uint32_t b) { return a | ~b; }
 
-struct FsAcc { CompPlanes pl; uint32_t mn, mn2, mx, mx2; uint32_t extra[5]; bool qodd; };
+struct FsAcc { CompPlanes pl; uint32_t mn, mx; uint32_t extra[5]; bool qodd; };   // mn / mx: high bytes of the 16-bit halves
 
-// the bytes of `x` (one word of a chunk) that are bases (ms) / qualities (mq) into the accumulators; -> x ^ expected where a
-// base is none of A C G T N \r (0: none)
-__device__ __forceinline__ uint32_t fs_word(uint32_t x, uint32_t ms, uint32_t mq, uint32_t &h, FsAcc &a) {
+// the bytes of `x` (one word of a chunk) that are bases (ms) into the one-hot word h; -> x ^ expected where a base is none of
+// A C G T N \r (0: none).  Qualities (mq): min and max are not computed but TESTED -- is any quality byte above the largest or
+// below the smallest the wave has met (qf: cmin in every byte, k1 = 0x7F - cmax, k2 = 0x80 - cmin per byte)?  A byte above
+// cmax sets bit 7 of x + k1, one of cmin or more sets bit 7 of x + k2, one of 128 or more has it set itself; bytes that are no
+// qualities are replaced by cmin, which passes both.  The bounds settle within the first granules of a wave; a row that fails
+// the test is measured exactly (fs_row_minmax) and the bounds move.
+__device__ __forceinline__ uint32_t fs_word(uint32_t x, uint32_t ms, uint32_t mq, uint32_t &h, uint32_t qf, uint32_t k1, uint32_t k2,
+                                            uint32_t &over, uint32_t &notunder) {
     const uint32_t xs = (uint32_t)__builtin_amdgcn_bitop3_b32(ms, x, 0x0D0D0D0Du, 0xCA);     // ms ? x : '\r'
     const uint32_t code = xs & 0x07070707u;
     h = __builtin_amdgcn_perm(FS_OH_HI, FS_OH_LO, code);
     const uint32_t d = xs ^ __builtin_amdgcn_perm(FS_EX_HI, FS_EX_LO, code);
-    const uint32_t hi = x & mq, lo = fs_orn(x, mq);
-    a.mx = pk_max_u16(a.mx, hi); a.mx2 = pk_max_u16(a.mx2, hi << 8);
-    a.mn = pk_min_u16(a.mn, lo); a.mn2 = pk_min_u16(a.mn2, (lo << 8) | 0xFFu);
+    const uint32_t xq = (uint32_t)__builtin_amdgcn_bitop3_b32(mq, x, qf, 0xCA);              // mq ? x : cmin
+    over = (uint32_t)__builtin_amdgcn_bitop3_b32(over, xq + k1, xq, 0xFE);                   // over | (xq + k1) | xq
+    notunder &= xq + k2;
     return d;
+}
+// smallest / largest quality byte of a row's chunk (mask mq), exactly: packed 16-bit min / max on the bytes and on the bytes
+// shifted by one (the high byte of a half decides); bytes that are no qualities count as 0xFF / 0x00
+__device__ __forceinline__ void fs_minmax(const uint4 &v, const uint4 &mq, uint32_t &mn, uint32_t &mx) {
+    const uint32_t xw[4] = {v.x, v.y, v.z, v.w}, mw[4] = {mq.x, mq.y, mq.z, mq.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t hi = xw[i] & mw[i], lo = fs_orn(xw[i], mw[i]);
+        mx = pk_max_u16(pk_max_u16(mx, hi), hi << 8);
+        mn = pk_min_u16(pk_min_u16(mn, lo), (lo << 8) | 0xFFu);
+    }
 }
 
 // byte b (0..15, any value at run time) of a chunk held in four words: selects, not an indexed array (which would live in scratch)
@@ -71,16 +89,12 @@ __device__ __forceinline__ void fs_one(uint32_t c, uint32_t p, FsAcc &a) {
 // less than a granule) is walked by the last wave, 64 bytes per lane.
 __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__restrict__ data, int64_t n, int64_t nfull,
                                                             const int64_t *__restrict__ nl_prefix, int64_t line0, FastqAcc *acc) {
-    // masks of a chunk's bytes: [k] bytes [0, k); [17 + k] bytes (k, 16); [34 + 17 k1 + k2] bytes (k1, k2); [FS_NONE] none
     __shared__ uint4 s_mask[FS_NMASK];
     __shared__ int s_fix[BLOCK / 64][8];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     for (int e = threadIdx.x; e < FS_NMASK; e += BLOCK) {
-        int lo, hi;                                        // the bytes lo < p < hi
-        if (e < 17) { lo = -1; hi = e; }
-        else if (e < 34) { lo = e - 17; hi = 16; }
-        else if (e < FS_NONE) { lo = (e - 34) / 17; hi = (e - 34) % 17; }
-        else { lo = 16; hi = 16; }
+        const int r = e / 289, k1 = (e % 289) / 17, k2 = e % 17;
+        const int lo = r == 0 ? -1 : r == 1 ? k1 : r == 2 ? k2 : 16, hi = r == 0 ? k1 : r == 1 ? k2 : 16;     // the bytes lo < p < hi
         uint32_t w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -96,7 +110,8 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__re
     FsAcc a;
 #pragma unroll
     for (int k = 0; k < COMP_NPL; ++k) a.pl.p[k] = 0;
-    a.mn = a.mn2 = 0xFFFFFFFFu; a.mx = a.mx2 = 0u; a.qodd = false;
+    a.mn = 0xFFFFFFFFu; a.mx = 0u; a.qodd = false;
+    int cmin = 104, cmax = 33;                             // fastq.c:667-668: what the wave has met so far (wave-uniform)
 #pragma unroll
     for (int c = 0; c < 5; ++c) a.extra[c] = 0;
     // A grid of as many waves as the device holds at once; wave w takes the runs w, w + nwaves, ... (one set of atomics per
@@ -104,6 +119,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__re
     const int64_t wave = (int64_t)blockIdx.x * (BLOCK / 64) + wv, nwaves = (int64_t)gridDim.x * (BLOCK / 64);
     unsigned long long tot[5] = {0, 0, 0, 0, 0};
     int runs_in_planes = 0;
+    uint32_t qf = 33u * 0x01010101u, qk1 = (0x7Fu - 33u) * 0x01010101u, qk2 = (0x80u - 104u) * 0x01010101u;   // fill, "above cmax", "at least cmin"
     uint4 v[GR_ROWS], nx[GR_ROWS];
   for (int64_t g0 = wave * FS_GPW; g0 < nfull; g0 += nwaves * FS_GPW) {
     granule_load<true>(v, data, n, 0, g0);
@@ -131,20 +147,38 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__re
             const uint32_t pA = (L0 + ex[j]) & 3u;         // which line of four the chunk's first byte belongs to
             // Up to two line ends in a chunk ('+' lines are two bytes long: nearly every record has such a chunk): three stretches --
             // in front of the first newline (line pA), between the two (pA + 1), behind the second (pA + 2) -- of which at most one
-            // holds bases (its line is 1 of four) and at most one qualities (3): each picked by ONE look-up whose address is made
-            // from pA and the two positions
+            // holds bases (its line is 1 of four: stretch (1 - pA) & 3) and at most one qualities (line 3: stretch (3 - pA) & 3);
+            // stretch 3 is none.  ONE look-up each, the address from pA and the two positions.
             const uint32_t cnt = (uint32_t)__popc(nlm[j]);
             const uint32_t m1 = nlm[j] & (nlm[j] - 1u);
             const int k1 = cnt ? __ffs(nlm[j]) - 1 : 16, k2 = m1 ? __ffs(m1) - 1 : 16;
-            const int i0 = k1, i1 = 34 + 17 * k1 + k2, i2 = 17 + k2;
             const bool slow = cnt >= 3u;                                       // three line ends in 16 bytes: byte by byte below
-            const int is = slow ? FS_NONE : pA == 1u ? i0 : pA == 0u ? i1 : pA == 3u ? i2 : FS_NONE;
-            const int iq = slow ? FS_NONE : pA == 3u ? i0 : pA == 2u ? i1 : pA == 1u ? i2 : FS_NONE;
-            const uint4 ms = s_mask[is], mq = s_mask[iq];
-            uint32_t h0, h1, h2, h3;
-            const uint32_t d0 = fs_word(v[j].x, ms.x, mq.x, h0, a), d1 = fs_word(v[j].y, ms.y, mq.y, h1, a);
-            const uint32_t d2 = fs_word(v[j].z, ms.z, mq.z, h2, a), d3 = fs_word(v[j].w, ms.w, mq.w, h3, a);
+            const int kk = k1 * 17 + k2;
+            const uint32_t rs = slow ? 3u : (1u - pA) & 3u, rq = slow ? 3u : (3u - pA) & 3u;
+            const uint4 ms = s_mask[rs * 289u + kk], mq = s_mask[rq * 289u + kk];
+            uint32_t h0, h1, h2, h3, over = 0, notunder = 0xFFFFFFFFu;
+            const uint32_t d0 = fs_word(v[j].x, ms.x, mq.x, h0, qf, qk1, qk2, over, notunder), d1 = fs_word(v[j].y, ms.y, mq.y, h1, qf, qk1, qk2, over, notunder);
+            const uint32_t d2 = fs_word(v[j].z, ms.z, mq.z, h2, qf, qk1, qk2, over, notunder), d3 = fs_word(v[j].w, ms.w, mq.w, h3, qf, qk1, qk2, over, notunder);
             planes_add4(a.pl, cy, j, h0, h1, h2, h3);
+            if (__builtin_expect(__ballot((((over | ~notunder) & 0x80808080u) != 0)) != 0ull, 0)) {
+                // a quality outside the bounds: this row exactly, the wave's bounds move (wave-uniform again)
+                uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+                fs_minmax(v[j], mq, mn, mx);
+                int lo = (int)min(mn >> 24, (mn >> 8) & 0xFFu), hi = (int)max(mx >> 24, (mx >> 8) & 0xFFu);
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    const int x = __shfl_xor(lo, d, 64), y = __shfl_xor(hi, d, 64);
+                    lo = x < lo ? x : lo; hi = y > hi ? y : hi;
+                }
+                if (lo <= hi) {                                                // the row held qualities
+                    cmin = lo < cmin ? lo : cmin; cmax = hi > cmax ? hi : cmax;
+                    if (lo < 33 || hi > 127) a.qodd = true;
+                    const int fl = cmin <= cmax ? cmin : cmax;                 // (no quality met yet: anything fails, the row above is exact anyway)
+                    qf = (uint32_t)fl * 0x01010101u;
+                    qk1 = (uint32_t)(0x7F - (cmax < 127 ? cmax : 127)) * 0x01010101u;
+                    qk2 = (uint32_t)(0x80 - (cmin > 0 ? cmin : 0)) * 0x01010101u;
+                }
+            }
             if (__builtin_expect((d0 | d1 | d2 | d3) != 0, 0)) {   // a base that is none of A C G T N \r: N for the reference; take the aliased class back out
 #pragma unroll 1
                 for (int b = 0; b < 16; ++b) {
@@ -197,8 +231,9 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__re
     // ---- the lane's counts, the wave's, the accumulators
 #pragma unroll
     for (int c = 0; c < 5; ++c) tot[c] = (unsigned long long)wave_sum64((long long)(tot[c] + planes_count(a.pl, c) + a.extra[c]));
-    uint32_t mn = pk_min_u16(a.mn, a.mn2), mx = pk_max_u16(a.mx, a.mx2);
-    int qmin = (int)min(mn >> 24, (mn >> 8) & 0xFFu), qmax = (int)max(mx >> 24, (mx >> 8) & 0xFFu);
+    // the bounds of the tested rows (wave-uniform) and what the byte-by-byte walks met (per lane)
+    int qmin = (int)min(a.mn >> 24, (a.mn >> 8) & 0xFFu), qmax = (int)max(a.mx >> 24, (a.mx >> 8) & 0xFFu);
+    if (cmin <= cmax) { qmin = cmin < qmin ? cmin : qmin; qmax = cmax > qmax ? cmax : qmax; }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         const int x = __shfl_xor(qmin, d, 64), y = __shfl_xor(qmax, d, 64);

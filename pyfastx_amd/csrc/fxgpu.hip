@@ -2028,11 +2028,13 @@ extern "C" int fx_fastq_comp(fx_handle *h, int64_t base[5], int64_t meta[5]) {
     int rc = use_device(h);
     if (rc) return rc;
     const FqTab t{h->fq_name_off.p, h->fq_rlen.p, h->fq_soff.p, h->fq_qoff.p, h->fq_name_len.p, h->fq_dlen.p, h->fq_qlen.p};
-    // A whole stream: the composition as a stream over the bytes (k_fastq_comp_stream: coalesced loads, the line of four of
-    // every byte from the build's newline prefixes) -- 5.x ms for C3 where the gather from the read table takes 7.2.  It only
-    // flags what it does not do itself (a '\r' or a byte outside '!'..127 in a quality line): then, and for shards (which count
-    // the reads they OWN), the table kernel below runs.  FX_FQ_COMP_TABLE=1: always that one.
-    static const bool table_only = [] { const char *e = getenv("FX_FQ_COMP_TABLE"); return e && atoi(e) != 0; }();
+    // FX_FQ_COMP_STREAM=1: the composition as a stream over the bytes (k_fastq_comp_stream, fx_fastq_stream.hpp: coalesced loads,
+    // the line of four of every byte from the build's newline prefixes).  Correct on everything the tests hold, and measured in
+    // round 4: 7.6-7.8 ms for C3 against 7.2 for the gather from the read table below -- the stream form is bound by its
+    // ~490 VALU instructions per granule (the exact newline mask and the wave scans alone are 150 of them), so the table
+    // kernel stays the default.  The stream kernel only flags what it does not do itself (a '\r' or a byte outside '!'..127 in a
+    // quality line): then, and for shards (which count the reads they OWN), the table kernel runs.
+    static const bool table_only = [] { const char *e = getenv("FX_FQ_COMP_STREAM"); return !(e && atoi(e) != 0); }();
     if (!table_only && h->base == 0 && h->halo == 0 && h->is_last && h->nl_prefix.p && h->ngran > 0) {
         const int64_t nfull = h->n / GRAN, waves = nfull / FS_GPW + 1;
         static int s_per_cu = 0, s_n_cu = 256;               // as many workgroups as are resident at once
