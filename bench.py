@@ -238,7 +238,21 @@ def leg_c3(a, dev, tmpdir):
     for _ in range(R):
         base, meta = b.fastq_comp()
     t2 = time.perf_counter()
-    ok = (s.n_reads, s.size) == (n, n * 150)
+    prof_two = {k: v[0] / v[1] for k, v in b.prof_read().items()}
+    b.prof_reset()
+    # Fastq(path, full_index=True) since round 4: index AND composition in one read of the stream (fx_fastq_build_comp)
+    b.fastq_build(comp=True); b.fastq_comp()
+    t3a = time.perf_counter()
+    for _ in range(R):
+        b.fastq_build(comp=True)
+        base1, meta1 = b.fastq_comp()
+    t3b = time.perf_counter()
+    one_read_ms = (t3b - t3a) / R * 1e3
+    same_one_read = bool((base1 == base).all() and (meta1 == meta).all())
+    prof_one = {k: v[0] / v[1] for k, v in b.prof_read().items()}     # (the slots k_fastq_lines / k_fastq_comp hold the fused kernels here)
+    b.prof_reset()
+    s = b.fastq_build()
+    ok = (s.n_reads, s.size) == (n, n * 150) and same_one_read
     t = b.fastq_table(n)
     for k in ("name_off", "name_len", "dlen", "rlen", "soff", "qoff"):
         ok = ok and bool((t[k] == cols[k]).all())
@@ -269,6 +283,7 @@ def leg_c3(a, dev, tmpdir):
     ok = ok and bool((o_seq.view(nq, 150) == seqs[ids]).all()) and bool((o_q.view(nq, 150) == quals[ids]).all())
     ok = ok and bool((o_qi.view(nq, 150) == (quals[ids].to(torch.int16) - 33).to(torch.int8)).all())
     prof = {k: v[0] / v[1] for k, v in b.prof_read().items()}
+    prof.update({k: v for k, v in prof_two.items() if k in ("k_fastq_lines", "k_fastq_comp")})   # the two-read timings of these slots
     b.prof_enable(0)
     n_lines = 4 * n
     build_alg = nb + 4 * n_lines + 44 * n                 # stream once + one 4-byte line record per line + the 44-byte row
@@ -279,6 +294,9 @@ def leg_c3(a, dev, tmpdir):
         "workload": "configs[2]: synthetic FASTQ %d x 150 bp (%.2f GB) resident in HBM, index build + composition + %d random reads "
                     "(seq + qual + int8 quali)" % (n, nb / 1e9, nq),
         "index_build_ms": round((t1 - t0) / R * 1e3, 3), "composition_ms": round((t2 - t1) / R * 1e3, 3),
+        "full_index_one_read_ms": round(one_read_ms, 3), "full_index_two_reads_ms": round((t2 - t0) / R * 1e3, 3),
+        "kernels_one_read_ms_avg": {"k_fastq_lines_comp": round(prof_one.get("k_fastq_lines", 0.0), 4),
+                                    "k_fastq_comp_reduce": round(prof_one.get("k_fastq_comp", 0.0), 4)},
         "fetch_1M_ms": round((t4 - t3) / R * 1e3, 3), "M_reads_per_s": round(nq / ((t4 - t3) / R) / 1e6, 1),
         "kernels_ms_avg": {k: round(v, 4) for k, v in prof.items()},
         "rows_base_meta_fetch_equal_generator": bool(ok),

@@ -194,6 +194,13 @@ typedef struct {
 } fx_fastq_summary;
 
 int fx_fastq_build(fx_handle *h, fx_fastq_summary *out);
+/* The same with the composition counted ON THE WAY -- pyfastx_fastq_create_index (fastq.c:8-182) and
+ * pyfastx_fastq_calc_composition (fastq.c:663-795), the reference's two passes over the file, in ONE read of the stream: the
+ * count pass of the build classifies the bytes it holds in registers anyway; which line of four a byte belongs to is guessed
+ * per run of granules from the '+' lines and checked against the newline prefixes afterwards.  A later fx_fastq_comp then
+ * only hands the counts out; when any guess was wrong (or the file has what the stream form does not do: CRLF, bytes outside
+ * '!'..127 in a quality line) it counts from the read table as if this had been fx_fastq_build.  Whole streams only. */
+int fx_fastq_build_comp(fx_handle *h, fx_fastq_summary *out);
 
 /* Sharded FASTQ: records are short, so a shard carries a HALO -- the first
  * bytes of the next shard appended to its own range (fx_set_halo) -- and owns every record

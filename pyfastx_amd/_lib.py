@@ -47,7 +47,7 @@ class ShardSummary(C.Structure):
 SYMBOLS = [
     "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_file_indexed", "fx_gz_checkpoints", "fx_stream_size", "fx_open_file_range", "fx_open_host", "fx_open_device",
     "fx_set_shard", "fx_close", "fx_release_scratch", "fx_pinned_alloc", "fx_pinned_free", "fx_pinned_holds", "fx_pinned_trim", "fx_size", "fx_device_memory", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
-    "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_line_regular", "fx_fasta_len_stats", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
+    "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_line_regular", "fx_fasta_len_stats", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_fastq_build_comp", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fasta_fetch_alloc", "fx_fetch_phases", "fx_fastq_fetch", "fx_fastq_fetch_alloc", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
     "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
     "fx_comm_unique_id", "fx_comm_init", "fx_comm_destroy", "fx_comm_rank", "fx_comm_world", "fx_comm_allgather", "fx_fasta_build_sharded_begin",
@@ -144,6 +144,7 @@ def lib():
     L.fx_fasta_comp_shard.argtypes = [vp, i32, vp, i64, vp]
     L.fx_fasta_comp_sparse.argtypes = [vp, i32, i64, vp, vp, vp, C.POINTER(i64), vp]
     L.fx_fastq_build.argtypes = [vp, C.POINTER(FastqSummary)]
+    L.fx_fastq_build_comp.argtypes = [vp, C.POINTER(FastqSummary)]
     L.fx_fastq_table.argtypes = [vp, i32] + [vp] * 6
     L.fx_set_halo.argtypes = [vp, i64]
     L.fx_fastq_scan.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
@@ -684,9 +685,10 @@ class Blob:
         return comp[:n], lead
 
     # -- FASTQ --------------------------------------------------------------
-    def fastq_build(self):
+    def fastq_build(self, comp=False):
+        """comp: count the composition on the way (fx_fastq_build_comp: index and base / meta in one read of the stream)."""
         s = FastqSummary()
-        check(lib().fx_fastq_build(self._h, C.byref(s)))
+        check((lib().fx_fastq_build_comp if comp else lib().fx_fastq_build)(self._h, C.byref(s)))
         self._n_fastq = int(s.n_reads)
         return s
 

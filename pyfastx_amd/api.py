@@ -1252,7 +1252,7 @@ class Fastq(_fxobj.FastqCore):
             return
         blob = self._st.blob
         try:
-            s = blob.fastq_build()
+            s = blob.fastq_build(comp=self._want_comp)        # full_index: base / meta are counted on the way, one read of the stream for both
         except _lib.FxError as e:
             raise _fx_to_py(e)
         t = blob.fastq_table(s.n_reads)
@@ -1287,7 +1287,8 @@ class Fastq(_fxobj.FastqCore):
                 base, meta = self._st.md.composition()
             else:
                 blob = self._st.blob
-                blob.fastq_build()
+                if getattr(blob, "_n_fastq", None) is None:       # (an index that was loaded: the stream has not been scanned yet)
+                    blob.fastq_build(comp=True)
                 base, meta = blob.fastq_comp()
             fxi.write_fastq_comp(self._db, base, meta)
             row = tuple(int(x) for x in meta)

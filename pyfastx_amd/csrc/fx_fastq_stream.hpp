@@ -254,4 +254,289 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__re
     }
 }
 
+// =================================================================================== index AND composition in ONE read
+// k_fastq_lines_comp = k_fastq_lines (the count pass of the one-read build: granule summaries + line records) with the
+// composition of the same granules counted from the same registers -- fastq.c:8-182 and fastq.c:663-795 in one pass over the
+// stream, where the reference makes two (and this engine made two: 7 + 7 ms for C3).
+//
+// Which line of four a byte belongs to is not known while the stream is read -- the newline prefixes come later in the
+// build.  A wave takes FQL_G consecutive granules; for the first one it GUESSES: a line of exactly one byte is the '+' line
+// (two newlines two bytes apart; every candidate of the granule must agree), which fixes the number-of-four of the granule's
+// first line, and the granules behind it follow by counting.  The counts of a run -- A C G T N, smallest / largest quality,
+// the guess -- go to an 8-word record; k_fastq_comp_reduce, after the prefixes, compares every guess with the truth
+// ((line offset + nl_prefix[first granule]) & 3) and adds the records up.  ONE wrong or missing guess (a file whose '+' lines
+// repeat the name, 1-base reads, CRLF) and the result is not used: fx_fastq_comp then counts from the read table as before.
+struct FqRun { uint32_t cnt[5]; uint32_t q; uint32_t guess; uint32_t pad; };   // q: min | max << 8 | have << 16 | odd << 17; guess: 0..3, 0xFF none
+static_assert(sizeof(FqRun) == 32, "one run record is 32 bytes");
+
+__global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__restrict__ data, int64_t n, int prev_byte, int64_t g_end,
+                                                           GranPk *__restrict__ out, uint32_t *__restrict__ recs, GranList ovl,
+                                                           FqRun *__restrict__ runs, int64_t nruns) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_sp[BLOCK / 64][GRAN / CHUNK], s_cr[BLOCK / 64][GRAN / CHUNK];   // bit k of word c <-> byte 16 c + k
+    __shared__ uint16_t s_pos[BLOCK / 64][FQL_CAP];
+    __shared__ uint4 s_mask[FS_NMASK];
+    __shared__ int s_fix[BLOCK / 64][8];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < FS_NMASK; e += BLOCK) {
+        const int r = e / 289, k1 = (e % 289) / 17, k2 = e % 17;
+        const int lo = r == 0 ? -1 : r == 1 ? k1 : r == 2 ? k2 : 16, hi = r == 0 ? k1 : r == 1 ? k2 : 16;
+        uint32_t m4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t m = 0;
+            for (int b = 0; b < 4; ++b) { const int p = 4 * i + b; if (p > lo && p < hi) m |= 0xFFu << (8 * b); }
+            m4[i] = m;
+        }
+        s_mask[e] = make_uint4(m4[0], m4[1], m4[2], m4[3]);
+    }
+    if (lane < 8) s_fix[w][lane] = 0;
+    __syncthreads();
+    int *fix = s_fix[w];
+    // a workgroup makes its mask table once and then takes run after run (a table per 64 KiB of stream was an eighth of the work)
+    for (int64_t run = (int64_t)blockIdx.x * (BLOCK / 64) + w; run < nruns; run += (int64_t)gridDim.x * (BLOCK / 64)) {
+    const int64_t gw = run * FQL_G;
+    FsAcc a;
+#pragma unroll
+    for (int k = 0; k < COMP_NPL; ++k) a.pl.p[k] = 0;
+    a.mn = 0xFFFFFFFFu; a.mx = 0u; a.qodd = false;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) a.extra[c] = 0;
+    int cmin = 104, cmax = 33;
+    uint32_t qf = 33u * 0x01010101u, qk1 = (0x7Fu - 33u) * 0x01010101u, qk2 = (0x80u - 104u) * 0x01010101u;
+    uint32_t guess = 0xFFu, lines_before = 0;              // number-of-four of the run's first line (0xFF: not known), newlines of the run so far
+    uint4 v[GR_ROWS];
+    if (gw < g_end) granule_load<true>(v, data, n, 0, gw);
+    for (int kk = 0; kk < FQL_G; ++kk) {
+        const int64_t g = gw + kk;
+        if (g >= g_end) break;
+        const int64_t sbase = g * (int64_t)GRAN;
+        uint32_t nlm[GR_ROWS], ex[GR_ROWS], c = 0, run_n = 0;
+        int first = GRAN, last = -1;
+#pragma unroll
+        for (int j = 0; j < GR_ROWS; ++j) {
+            nlm[j] = eq_mask16(v[j], 0x0A0A0A0Au);
+            s_sp[w][j * 64 + lane] = (uint16_t)eq_mask16(v[j], 0x20202020u);
+            uint32_t any_cr = 0;
+            {
+                const uint32_t y0 = v[j].x ^ 0x0D0D0D0Du, y1 = v[j].y ^ 0x0D0D0D0Du, y2 = v[j].z ^ 0x0D0D0D0Du, y3 = v[j].w ^ 0x0D0D0D0Du;
+                any_cr = (y0 - 0x01010101u) & ~y0;
+                any_cr = (uint32_t)__builtin_amdgcn_bitop3_b32(any_cr, y1 - 0x01010101u, y1, 0xF4);
+                any_cr = (uint32_t)__builtin_amdgcn_bitop3_b32(any_cr, y2 - 0x01010101u, y2, 0xF4);
+                any_cr = (uint32_t)__builtin_amdgcn_bitop3_b32(any_cr, y3 - 0x01010101u, y3, 0xF4);
+            }
+            s_cr[w][j * 64 + lane] = __ballot((any_cr & 0x80808080u) != 0) ? (uint16_t)eq_mask16(v[j], 0x0D0D0D0Du) : (uint16_t)0;
+            const uint32_t cj = (uint32_t)__popc(nlm[j]);
+            c += cj;
+            const uint32_t inc = wave_incl_scan(cj);
+            ex[j] = run_n + inc - cj;                      // newlines of the granule in front of this chunk
+            run_n += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            if (nlm[j]) {
+                const int cb = j * 1024 + lane * CHUNK;
+                if (first == GRAN) first = cb + __ffs(nlm[j]) - 1;
+                last = cb + 31 - __clz(nlm[j]);
+            }
+        }
+        const uint32_t M = run_n;
+        // ---- the guess, once per run: a '+' line of one byte ends at a newline that has another one two bytes in front of it
+        if (kk == 0) {
+            uint32_t mine = 0xFFu;
+            bool clash = false;
+#pragma unroll
+            for (int j = 0; j < GR_ROWS; ++j) {
+                const uint32_t cand = nlm[j] & (nlm[j] << 2) & ~(nlm[j] << 1) & 0xFFFFu;     // second newline of a pair inside the chunk
+                if (cand) {
+                    const uint32_t b = (uint32_t)__ffs(cand) - 1u;
+                    const uint32_t i = ex[j] + (uint32_t)__popc(nlm[j] & ((1u << b) - 1u));   // that newline is the granule's i-th: line i is line 2 of four
+                    const uint32_t p0 = (2u - i) & 3u;
+                    if (mine == 0xFFu) mine = p0; else clash |= mine != p0;
+                }
+            }
+            const unsigned long long hv = __ballot(mine != 0xFFu);
+            if (hv) {
+                guess = (uint32_t)__builtin_amdgcn_readlane((int)mine, __ffsll((long long)hv) - 1);
+                if (__ballot(clash || (mine != 0xFFu && mine != guess))) guess = 0xFFu;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const int f = __shfl_xor(first, d, 64), l = __shfl_xor(last, d, 64);
+            first = f < first ? f : first; last = l > last ? l : last;
+        }
+        if (lane == 0) {
+            GranOut o;
+            o.n = M; o.h = 0; o.first = (uint32_t)first; o.last = (uint32_t)last;
+            o.v1 = o.c1 = o.v2 = o.c2 = o.ovf = 0;
+            out[g] = gran_pack(o);
+        }
+        // ---- composition of this granule (only with a guess: without one the run's record says so and nothing is used)
+        if (guess != 0xFFu) {
+            const uint32_t L0 = (guess + lines_before) & 3u;
+            CompCarry cy;
+#pragma unroll
+            for (int j = 0; j < GR_ROWS; ++j) {
+                const uint32_t pA = (L0 + ex[j]) & 3u;
+                const uint32_t cnt = (uint32_t)__popc(nlm[j]);
+                const uint32_t m1 = nlm[j] & (nlm[j] - 1u);
+                const int k1 = cnt ? __ffs(nlm[j]) - 1 : 16, k2 = m1 ? __ffs(m1) - 1 : 16;
+                const bool slow = cnt >= 3u;
+                const int kx = k1 * 17 + k2;
+                const uint32_t rs = slow ? 3u : (1u - pA) & 3u, rq = slow ? 3u : (3u - pA) & 3u;
+                const uint4 ms = s_mask[rs * 289u + kx], mq = s_mask[rq * 289u + kx];
+                uint32_t h0, h1, h2, h3, over = 0, notunder = 0xFFFFFFFFu;
+                const uint32_t d0 = fs_word(v[j].x, ms.x, mq.x, h0, qf, qk1, qk2, over, notunder), d1 = fs_word(v[j].y, ms.y, mq.y, h1, qf, qk1, qk2, over, notunder);
+                const uint32_t d2 = fs_word(v[j].z, ms.z, mq.z, h2, qf, qk1, qk2, over, notunder), d3 = fs_word(v[j].w, ms.w, mq.w, h3, qf, qk1, qk2, over, notunder);
+                planes_add4(a.pl, cy, j, h0, h1, h2, h3);
+                if (__builtin_expect(__ballot((((over | ~notunder) & 0x80808080u) != 0)) != 0ull, 0)) {
+                    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+                    fs_minmax(v[j], mq, mn, mx);
+                    int lo = (int)min(mn >> 24, (mn >> 8) & 0xFFu), hi = (int)max(mx >> 24, (mx >> 8) & 0xFFu);
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) {
+                        const int x = __shfl_xor(lo, d, 64), y = __shfl_xor(hi, d, 64);
+                        lo = x < lo ? x : lo; hi = y > hi ? y : hi;
+                    }
+                    if (lo <= hi) {
+                        cmin = lo < cmin ? lo : cmin; cmax = hi > cmax ? hi : cmax;
+                        if (lo < 33 || hi > 127) a.qodd = true;
+                        const int fl = cmin <= cmax ? cmin : cmax;
+                        qf = (uint32_t)fl * 0x01010101u;
+                        qk1 = (uint32_t)(0x7F - (cmax < 127 ? cmax : 127)) * 0x01010101u;
+                        qk2 = (uint32_t)(0x80 - (cmin > 0 ? cmin : 0)) * 0x01010101u;
+                    }
+                }
+                if (__builtin_expect((d0 | d1 | d2 | d3) != 0, 0)) {
+#pragma unroll 1
+                    for (int b = 0; b < 16; ++b) {
+                        const uint32_t dw = (b & 8) ? ((b & 4) ? d3 : d2) : ((b & 4) ? d1 : d0);
+                        if (!((dw >> ((b & 3) * 8)) & 0xFFu)) continue;
+                        const uint32_t hw = (b & 8) ? ((b & 4) ? h3 : h2) : ((b & 4) ? h1 : h0);
+                        const uint32_t hk = (hw >> ((b & 3) * 8)) & 0xFFu;
+                        if (hk) atomicSub(&fix[__ffs(hk) - 1], 1);
+                        atomicAdd(&fix[4], 1);
+                    }
+                }
+                if (__builtin_expect(slow, 0)) {
+                    uint32_t p = pA;
+#pragma unroll 1
+                    for (int b = 0; b < CHUNK; ++b) {
+                        const uint32_t cc = fs_byte(v[j], b);
+                        if (cc == 10u) { p = (p + 1u) & 3u; continue; }
+                        fs_one(cc, p, a);
+                    }
+                }
+            }
+            planes_finish16(a.pl, cy);
+        }
+        lines_before += M;
+        if (kk + 1 < FQL_G && g + 1 < g_end) granule_load<true>(v, data, n, 0, g + 1);       // the next granule is on its way
+        if (M > (uint32_t)FQL_CAP) {                          // more lines than a slot holds: k_fastq_emit reads the granule again
+            if (lane == 0) ovl.g[atomicAdd(ovl.count, 1u)] = (uint32_t)g;
+            continue;
+        }
+        if (!M) continue;
+        // ---- compact the newline positions, one line record per newline (as k_fastq_lines)
+#pragma unroll
+        for (int j = 0; j < GR_ROWS; ++j) {
+            uint32_t m = nlm[j], r = ex[j];
+            while (m) {
+                const int k = __ffs(m) - 1;
+                m &= m - 1;
+                s_pos[w][r++] = (uint16_t)(j * 1024 + lane * CHUNK + k);
+            }
+        }
+        const uint64_t *spm = reinterpret_cast<const uint64_t *>(&s_sp[w][0]);
+        uint32_t *slot = recs + g * (int64_t)FQL_CAP;
+        for (uint32_t i = lane; i < M; i += 64) {
+            const int lp = s_pos[w][i];
+            const int ql = i ? (int)s_pos[w][i - 1] : -1;
+            int cr;
+            if (lp) cr = (s_cr[w][(lp - 1) >> 4] >> ((lp - 1) & 15)) & 1;
+            else    cr = (sbase ? data[sbase - 1] : prev_byte) == '\r';
+            const int from = i ? ql + 2 : 0;
+            const int sp = from < lp ? fq_first_bit(spm, from, lp) : -1;
+            slot[i] = (uint32_t)lp | (cr ? FQL_CR : 0u) | (sp >= 0 ? FQL_HAS | ((uint32_t)sp << 14) : 0u);
+        }
+    }
+    // ---- the run's record
+    {
+        uint32_t tot[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) tot[c] = wave_sum(planes_count(a.pl, c) + a.extra[c]);
+        int qmin = (int)min(a.mn >> 24, (a.mn >> 8) & 0xFFu), qmax = (int)max(a.mx >> 24, (a.mx >> 8) & 0xFFu);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const int x = __shfl_xor(qmin, d, 64), y = __shfl_xor(qmax, d, 64);
+            qmin = x < qmin ? x : qmin; qmax = y > qmax ? y : qmax;
+        }
+        if (cmin <= cmax) { qmin = cmin < qmin ? cmin : qmin; qmax = cmax > qmax ? cmax : qmax; }
+        const bool have = qmin < 255 || qmax > 0;
+        const bool odd = __ballot(a.qodd) != 0ull || (have && (qmin < 33 || qmax > 127));
+        if (lane == 0) {
+            FqRun r;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) { r.cnt[c] = (uint32_t)((int)tot[c] + fix[c]); fix[c] = 0; }
+            r.q = (uint32_t)(qmin & 0xFF) | ((uint32_t)(qmax & 0xFF) << 8) | (have ? 1u << 16 : 0u) | (odd ? 1u << 17 : 0u);
+            r.guess = guess; r.pad = 0;
+            runs[run] = r;
+        }
+    }
+    }
+}
+
+// after the prefixes: every run's guess against the truth, the records added up; the ragged end of the stream (less than a
+// granule, no run) walked by the first wave.  res: FastqAcc (a c g t n, minqs, maxqs; qfix = runs that cannot be used + odd bytes).
+__global__ __launch_bounds__(BLOCK) void k_fastq_comp_reduce(const FqRun *__restrict__ runs, int64_t nruns, const int64_t *__restrict__ nl_prefix,
+                                                            int64_t line0, const uint8_t *__restrict__ data, int64_t n, int64_t nfull,
+                                                            FastqAcc *res) {
+    unsigned long long tot[5] = {0, 0, 0, 0, 0};
+    int qmin = 255, qmax = 0, bad = 0;
+    for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < nruns; r += (int64_t)gridDim.x * BLOCK) {
+        const FqRun x = runs[r];
+        const uint32_t truth = (uint32_t)((line0 + nl_prefix[r * FQL_G]) & 3);
+        if (x.guess != truth || (x.q >> 17) & 1u) { ++bad; continue; }
+#pragma unroll
+        for (int c = 0; c < 5; ++c) tot[c] += x.cnt[c];
+        if ((x.q >> 16) & 1u) { const int lo = (int)(x.q & 0xFFu), hi = (int)((x.q >> 8) & 0xFFu); qmin = lo < qmin ? lo : qmin; qmax = hi > qmax ? hi : qmax; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64 && nfull * (int64_t)GRAN < n) {        // the ragged end
+        FsAcc a;
+        a.mn = 0xFFFFFFFFu; a.mx = 0u; a.qodd = false;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) a.extra[c] = 0;
+        const int lane = lane_id();
+        const int64_t tail0 = nfull * (int64_t)GRAN, lo = tail0 + (int64_t)lane * 64, hi = lo + 64 < n ? lo + 64 : n;
+        uint32_t c = 0;
+        for (int64_t p = lo; p < hi; ++p) c += data[p] == 10;
+        const uint32_t inc = wave_incl_scan(c);
+        uint32_t ph = (uint32_t)((line0 + nl_prefix[nfull] + (int64_t)(inc - c)) & 3);
+        for (int64_t p = lo; p < hi; ++p) {
+            const uint32_t b = data[p];
+            if (b == 10u) { ph = (ph + 1u) & 3u; continue; }
+            fs_one(b, ph, a);
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) tot[k] += a.extra[k];
+        const int l2 = (int)min(a.mn >> 24, (a.mn >> 8) & 0xFFu), h2 = (int)max(a.mx >> 24, (a.mx >> 8) & 0xFFu);
+        if (l2 < 255 || h2 > 0) { qmin = l2 < qmin ? l2 : qmin; qmax = h2 > qmax ? h2 : qmax; }
+        if (a.qodd) ++bad;
+    }
+#pragma unroll
+    for (int c = 0; c < 5; ++c) tot[c] = (unsigned long long)wave_sum64((long long)tot[c]);
+    bad = (int)wave_sum((uint32_t)bad);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const int x = __shfl_xor(qmin, d, 64), y = __shfl_xor(qmax, d, 64);
+        qmin = x < qmin ? x : qmin; qmax = y > qmax ? y : qmax;
+    }
+    if (lane_id() == 0) {
+        if (tot[0]) atomicAdd(&res->a, tot[0]);
+        if (tot[1]) atomicAdd(&res->c, tot[1]);
+        if (tot[2]) atomicAdd(&res->g, tot[2]);
+        if (tot[3]) atomicAdd(&res->t, tot[3]);
+        if (tot[4]) atomicAdd(&res->n, tot[4]);
+        if (qmin < 255 || qmax > 0) { atomicMin(&res->minqs, qmin); atomicMax(&res->maxqs, qmax); }
+        if (bad) atomicAdd(&res->qfix, bad);
+    }
+}
+
 }  // namespace fx

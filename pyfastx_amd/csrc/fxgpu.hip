@@ -285,6 +285,11 @@ struct fx_handle {
     DevBuf<int64_t> fq_name_off, fq_rlen, fq_soff, fq_qoff;
     DevBuf<int32_t> fq_name_len, fq_dlen, fq_qlen;
     DevBuf<FastqAcc> fq_acc;
+    DevBuf<FqRun> fq_runs;                    // k_fastq_lines_comp: one record per run of FQL_G granules (composition counted on the scan)
+    DevBuf<FastqAcc> fq_acc_build;            // ... added up by k_fastq_comp_reduce
+    bool fq_comp_valid = false;               // the build counted the composition and every run's guess was right
+    int64_t fq_comp_base[5] = {0, 0, 0, 0, 0};
+    int fq_comp_minqs = 104, fq_comp_maxqs = 33;
     DevBuf<uint32_t> fq_lines;                // k_fastq_lines: FQL_CAP line records per granule
     bool fq_by_lines = false;                 // the last count pass wrote line records (else: counts only)
     int64_t fq_nlist = 0;                     // granules k_fastq_emit has to read again (overflowing ones + the partial last)
@@ -1599,6 +1604,13 @@ static int granule_pass(fx_handle *h, bool fq_lines = false, bool with_comp = fa
     const int SCAN_WG = 512;                                  // 8 waves = 8 granules per workgroup (tools/scanbench2.hip)
     if (nfull > 0 && MODE == 1 && fq_lines) {                 // FASTQ, one-read build: the count pass also writes the line records
         if ((rc = h->fq_lines.alloc(nfull * FQL_CAP))) return rc;
+        if (with_comp) {                                      // index and composition in one read of the stream (fx_fastq_stream.hpp)
+            const int64_t nruns = (nfull + FQL_G - 1) / FQL_G;
+            if ((rc = h->fq_runs.alloc(nruns)) || (rc = h->fq_acc_build.alloc(1))) return rc;
+            static const int64_t grid_cap = [] { const char *e = getenv("FX_FQ_FUSED_GRID"); return e && atoll(e) > 0 ? atoll(e) : 6144ll; }();
+            FX_LAUNCH(h, K_FASTQ_LINES, k_fastq_lines_comp, dim3((unsigned)std::min<int64_t>(nblocks(nruns, BLOCK / 64), grid_cap)), dim3(BLOCK), h->d_data,
+                      h->n, h->prev_byte, nfull, h->gran.p, h->fq_lines.p, hgl, h->fq_runs.p, nruns);
+        } else
         FX_LAUNCH(h, K_FASTQ_LINES, k_fastq_lines, dim3(nblocks(nfull, (BLOCK / 64) * FQL_G)), dim3(BLOCK), h->d_data, h->n, h->prev_byte, nfull,
                   h->gran.p, h->fq_lines.p, hgl);
     } else if (nfull > 0 && MODE == 0 && with_comp) {         // the scan and the composition counters in one read (fx_scancomp.hpp)
@@ -1623,6 +1635,15 @@ static int granule_pass(fx_handle *h, bool fq_lines = false, bool with_comp = fa
                   (int)h->is_last, hgl, h->gran.p, ngran, h->base, h->chunks.p);
         FX_LAUNCH(h, K_GRAN_PREFIX, (k_gran_prefix<1024>), dim3((unsigned)nchunks), dim3(1024), h->gran.p, ngran, h->base,
                   h->chunks.p, ctl_totals(h), h->nl_prefix.p, h->hdr_prefix.p, h->prevnl.p);
+    }
+    if (MODE == 1 && fq_lines && with_comp && nfull > 0) {   // every run's guess against the prefixes, the runs' counts added up
+        FastqAcc init;
+        memset(&init, 0, sizeof init);
+        init.minqs = 104; init.maxqs = 33;                    // fastq.c:667-668
+        HIPCHK(hipMemcpyAsync(h->fq_acc_build.p, &init, sizeof init, hipMemcpyHostToDevice, h->stream));
+        const int64_t nruns = (nfull + FQL_G - 1) / FQL_G;
+        FX_LAUNCH(h, K_FASTQ_COMP, k_fastq_comp_reduce, dim3((unsigned)std::min<int64_t>(nblocks(nruns, BLOCK), 1024)), dim3(BLOCK), (const FqRun *)h->fq_runs.p,
+                  nruns, (const int64_t *)h->nl_prefix.p, (int64_t)0, h->d_data, h->n, nfull, h->fq_acc_build.p);
     }
     HIPCHK(hipGetLastError());
     return FX_OK;
@@ -1864,11 +1885,12 @@ extern "C" int fx_fasta_comp_shard(fx_handle *h, int where, int64_t *comp, int64
 // ------------------------------------------------------------- FASTQ build
 // Count pass (fx_fastq.hpp): granule newline counts + prefixes, and the newlines of the shard's core
 // (what the next shards need to number their lines).
-static int fastq_count(fx_handle *h, int64_t *n_nl_core, int64_t *last_nl_core) {
+static int fastq_count(fx_handle *h, int64_t *n_nl_core, int64_t *last_nl_core, bool want_comp = false) {
     int rc = use_device(h);
     if (rc) return rc;
     if (h->n <= 0) return fail(FX_EFORMAT, "empty input");
     h->fasta_built = h->fastq_built = h->comp_runs_valid = false;
+    h->fq_comp_valid = false;
     // One read or two?  Line records pay when most granules fit their slot: ask three windows of the stream.
     static const int force = [] { const char *e = getenv("FX_FQ_LINES"); return e ? atoi(e) : -1; }();   // 0 / 1: experiments
     bool by_lines = force > 0;
@@ -1882,7 +1904,10 @@ static int fastq_count(fx_handle *h, int64_t *n_nl_core, int64_t *last_nl_core) 
         HIPCHK(hipStreamSynchronize(h->stream));
         by_lines = smp[1] > 0 && (double)smp[0] / (double)smp[1] * GRAN <= 0.7 * FQL_CAP;
     }
-    if ((rc = granule_pass<1>(h, by_lines))) return rc;
+    // the composition on the way (fx_fastq_build_comp): whole streams with line records only -- a shard counts the reads it OWNS
+    static const bool no_fuse = [] { const char *e = getenv("FX_FQ_NO_FUSED_COMP"); return e && atoi(e) != 0; }();
+    const bool with_comp = want_comp && by_lines && !no_fuse && h->base == 0 && h->halo == 0 && h->is_last && h->n >= GRAN;
+    if ((rc = granule_pass<1>(h, by_lines, with_comp))) return rc;
     int64_t *res = (int64_t *)(h->ctl.p + 48);                // 3 words of the control block
     hipLaunchKernelGGL(k_core_count, dim3(1), dim3(64), 0, h->stream, scan_ctx(h), (int)h->is_last, h->n - h->halo, res);
     HIPCHK(hipGetLastError());
@@ -1891,7 +1916,16 @@ static int fastq_count(fx_handle *h, int64_t *n_nl_core, int64_t *last_nl_core) 
     HIPCHK(hipMemcpyAsync(host, res, sizeof host, hipMemcpyDeviceToHost, h->stream));
     uint32_t n_over = 0;
     if (by_lines) HIPCHK(hipMemcpyAsync(&n_over, ctl_counter(h, 0), sizeof n_over, hipMemcpyDeviceToHost, h->stream));
+    FastqAcc built;
+    memset(&built, 0, sizeof built);
+    if (with_comp) HIPCHK(hipMemcpyAsync(&built, h->fq_acc_build.p, sizeof built, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (with_comp && built.qfix == 0) {                       // every guess was right, no byte the stream form leaves to the table kernel
+        h->fq_comp_valid = true;
+        h->fq_comp_base[0] = (int64_t)built.a; h->fq_comp_base[1] = (int64_t)built.c; h->fq_comp_base[2] = (int64_t)built.g;
+        h->fq_comp_base[3] = (int64_t)built.t; h->fq_comp_base[4] = (int64_t)built.n;
+        h->fq_comp_minqs = built.minqs; h->fq_comp_maxqs = built.maxqs;
+    }
     h->fq_by_lines = by_lines;
     if (by_lines) {                                           // the partial last granule goes on the list as well
         const uint32_t tail = (uint32_t)(h->ngran - 1);
@@ -2007,6 +2041,13 @@ extern "C" int fx_fastq_build(fx_handle *h, fx_fastq_summary *out) {
     return fastq_records(h, 0, -1, out);
 }
 
+extern "C" int fx_fastq_build_comp(fx_handle *h, fx_fastq_summary *out) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    int rc = fastq_count(h, nullptr, nullptr, true);
+    if (rc) return rc;
+    return fastq_records(h, 0, -1, out);
+}
+
 extern "C" int fx_fastq_table(fx_handle *h, int where, int64_t *name_off, int32_t *name_len, int32_t *dlen,
                               int64_t *rlen, int64_t *soff, int64_t *qoff) {
     if (!h) return fail(FX_EINVAL, "null handle");
@@ -2027,6 +2068,14 @@ extern "C" int fx_fastq_comp(fx_handle *h, int64_t base[5], int64_t meta[5]) {
     if (!h->fastq_built) return fail(FX_ESTATE, "fx_fastq_build has not run");
     int rc = use_device(h);
     if (rc) return rc;
+    if (h->fq_comp_valid) {                                  // counted while the index was built (fx_fastq_build_comp): nothing is read again
+        for (int i = 0; i < 5; ++i) base[i] = h->fq_comp_base[i];
+        int phred = 0;
+        if (h->fq_comp_maxqs > 74) phred = 64;                // fastq.c:768-774
+        if (h->fq_comp_minqs < 59) phred = 33;
+        meta[0] = h->fq_maxlen; meta[1] = h->fq_minlen; meta[2] = h->fq_comp_minqs; meta[3] = h->fq_comp_maxqs; meta[4] = phred;
+        return FX_OK;
+    }
     const FqTab t{h->fq_name_off.p, h->fq_rlen.p, h->fq_soff.p, h->fq_qoff.p, h->fq_name_len.p, h->fq_dlen.p, h->fq_qlen.p};
     // FX_FQ_COMP_STREAM=1: the composition as a stream over the bytes (k_fastq_comp_stream, fx_fastq_stream.hpp: coalesced loads,
     // the line of four of every byte from the build's newline prefixes).  Correct on everything the tests hold, and measured in

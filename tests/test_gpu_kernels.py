@@ -88,6 +88,21 @@ def test_fasta_edge_cases(oracle, L):
                 assert buf[:ol[0]].tobytes().decode("latin-1") == fx["antisense"], (key, fx)
 
 
+def _comp_both_ways(b):
+    """base / meta of an indexed FASTQ stream: counted from the read table in a second pass (k_fastq_comp) AND counted while
+    the index is built, in the one read of the stream (fx_fastq_build_comp: k_fastq_lines_comp + k_fastq_comp_reduce, the
+    line-of-four guessed per run and verified against the prefix; fastq.c:715-774 is one loop over the reads) -- equal."""
+    base, meta = b.fastq_comp()
+    s0 = b.fastq_build(comp=True)
+    base1, meta1 = b.fastq_comp()
+    assert base1.tolist() == base.tolist() and meta1.tolist() == meta.tolist(), (base1, base, meta1, meta)
+    s1 = b.fastq_build()                                     # ... and the plain build after it forgets the stored counts
+    assert (s0.n_reads, s0.size, s0.n_lines) == (s1.n_reads, s1.size, s1.n_lines)
+    base2, meta2 = b.fastq_comp()
+    assert base2.tolist() == base.tolist() and meta2.tolist() == meta.tolist()
+    return base, meta
+
+
 @pytest.mark.parametrize("fn", ["test.fq", "test.fq.gz"])
 def test_fastq_fixture(oracle, L, fn):
     raw = fixture_bytes(fn)
@@ -98,7 +113,7 @@ def test_fastq_fixture(oracle, L, fn):
     t = b.fastq_table(s.n_reads)
     for col in ("name_off", "name_len", "dlen", "rlen", "soff", "qoff"):
         np.testing.assert_array_equal(t[col], recs[col].astype(t[col].dtype), err_msg=col)
-    base, meta = b.fastq_comp()
+    base, meta = _comp_both_ways(b)
     c = oracle.fastq_composition(raw)
     assert base.tolist() == [c["a"], c["c"], c["g"], c["t"], c["n"]]
     assert meta.tolist() == [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"], c["phred"]]
@@ -124,7 +139,7 @@ def test_fastq_edge_cases(oracle, L):
             nm = raw[t["name_off"][i]: t["name_off"][i] + t["name_len"][i]].decode()
             got = [nm, int(t["dlen"][i]), int(t["rlen"][i]), int(t["soff"][i]), int(t["qoff"][i])]
             assert got == row[1:], (name, got, row)
-        base, meta = b.fastq_comp()
+        base, meta = _comp_both_ways(b)
         assert base.tolist() == case["base"], name
         assert meta.tolist() == case["meta"], name
 
@@ -278,7 +293,7 @@ def test_fastq_random(oracle, L, seed):
     t = b.fastq_table(s.n_reads)
     for col in ("name_off", "name_len", "dlen", "rlen", "soff", "qoff"):
         np.testing.assert_array_equal(t[col], recs[col].astype(t[col].dtype), err_msg=col)
-    base, meta = b.fastq_comp()
+    base, meta = _comp_both_ways(b)
     c = oracle.fastq_composition(raw)
     assert base.tolist() == [c["a"], c["c"], c["g"], c["t"], c["n"]]
     assert meta.tolist() == [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"], c["phred"]]
@@ -447,7 +462,7 @@ def test_fastq_comp_letters(oracle, L):
         b = L.Blob.from_bytes(raw)
         s = b.fastq_build()
         assert s.n_reads == 3000
-        base, meta = b.fastq_comp()
+        base, meta = _comp_both_ways(b)
         assert base.tolist() == [c["a"], c["c"], c["g"], c["t"], c["n"]], eol
         assert meta.tolist() == [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"], c["phred"]], eol
         base2, meta2 = b.fastq_comp()                        # a second call starts from clean accumulators
@@ -615,7 +630,7 @@ def test_fastq_mixed_shapes_40mb(oracle, L):
     t = b.fastq_table(s.n_reads)
     for col in ("name_off", "name_len", "dlen", "rlen", "soff", "qoff"):
         np.testing.assert_array_equal(t[col], recs[col].astype(t[col].dtype), err_msg=col)
-    base, meta = b.fastq_comp()
+    base, meta = _comp_both_ways(b)
     c = oracle.fastq_composition(raw)
     assert base.tolist() == [c["a"], c["c"], c["g"], c["t"], c["n"]]
     assert meta.tolist() == [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"], c["phred"]]
@@ -702,7 +717,7 @@ def test_fastq_line_records(oracle, L, crlf):
     t = b.fastq_table(s.n_reads)
     for col in ("name_off", "name_len", "dlen", "rlen", "soff", "qoff"):
         np.testing.assert_array_equal(t[col], recs[col].astype(t[col].dtype), err_msg=col)
-    base, meta = b.fastq_comp()
+    base, meta = _comp_both_ways(b)
     c = oracle.fastq_composition(raw)
     assert base.tolist() == [c["a"], c["c"], c["g"], c["t"], c["n"]]
     assert meta.tolist() == [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"], c["phred"]]
