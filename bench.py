@@ -67,6 +67,18 @@ def parse():
     return ap.parse_args()
 
 
+_T0 = time.perf_counter()
+_LAPS = []
+
+
+def _lap(name):
+    """wall time of the bench's own legs (set-up included), for the line's `bench_wall_s`: the default run has a budget of minutes"""
+    global _T0
+    t = time.perf_counter()
+    _LAPS.append((name, round(t - _T0, 2)))
+    _T0 = t
+
+
 def _median(xs):
     return float(np.median(np.asarray(xs, dtype=np.float64)))
 
@@ -1437,6 +1449,7 @@ def main():
                            "avg_launch_ms": round(fetch_ms, 4),
                            "frac": round(fetch_alg / max(fetch_ms * 1e-3, 1e-9) / 1e9 / HBM_PEAK_GBS, 4)},
     }
+    _lap("generate + timed steps + parity at full size")
     if True:
         # release the device-resident copies before the file legs (the same bytes go to a file first)
         host = None
@@ -1455,6 +1468,7 @@ def main():
                 e2e = {}
                 gbuf, goffs, ours_rows = e2e_fasta(path, plan, q, e2e)
                 line["e2e"] = e2e
+            _lap("e2e from a file")
             if not a.no_cpu_baseline:
                 cb = {}
                 if ours_rows is None:
@@ -1482,6 +1496,7 @@ def main():
                     line["speedup_vs_cpu"] = round(cpu_s / gpu_s, 1)          # like for like: file -> .fxi + host -> host answers
                     line["speedup_definition"] = "(cpu index_s + fetch_s) / (e2e fxi_durable_s + fetch_many_1M_host_to_host_s), same file, same host"
                 line["hbm_resident_step_vs_cpu_file_run"] = round(line["value"] / cb["value"], 1)   # NOT like for like: kept for continuity with round 1
+            _lap("cpu_baseline (reference on the whole file)")
             plain_digest = None
             if gbuf is not None:
                 import hashlib
@@ -1497,11 +1512,14 @@ def main():
                     line["roofline"]["traffic_source"] += "; a live measurement was tried and failed: " + src
                 a.no_pmc = True
             _rm(path)
+            _lap("pmc passes")
             if not a.no_c4:
                 line["c4"] = leg_c4(a, host, plan, q, tmpdir, plain_digest)
             del host
+            _lap("c4")
             if not a.no_c3:
                 line["c3"] = leg_c3(a, dev, tmpdir)
+            _lap("c3")
         finally:
             shutil.rmtree(tmpdir, ignore_errors=True)
     if not a.no_pmc:
@@ -1512,6 +1530,7 @@ def main():
             line["roofline"]["traffic"], line["roofline"]["traffic_source"] = tr, src
         else:
             line["roofline"]["traffic_source"] += "; a live measurement was tried and failed: " + src
+    line["bench_wall_s"] = dict(_LAPS)
     print(json.dumps(line), flush=True)
 
 

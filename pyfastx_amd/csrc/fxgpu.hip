@@ -1219,7 +1219,7 @@ static int open_file_impl(const char *path, int device, fx_handle **out, int64_t
                 if (trace) fprintf(stderr, "[fxgpu] open %-27s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
             };
             int brc = bgzf_open_on_device(h, fd, fsize, path);      // the member table found in HBM (fx_bgzf_walk.hpp); 1: not that kind of file
-            lap("open (device walk)");
+            lap("(device walk)");
             if (brc == FX_OK) { close(fd); *out = h; return FX_OK; }
             if (brc < 0) return bail(brc);
             if (h->d_data || h->d_alloc) {                            // (a blob the attempt allocated: none on the ways it gives up)

@@ -246,11 +246,47 @@ def _threads(n=None):
     return ThreadPool(n or min(128, os.cpu_count() or 8))
 
 
-def bgzf_compress_parallel(raw, procs=None, step=65280 * 16):
-    """`raw` (numpy uint8) BGZF-framed as bgzf_compress would frame it, in pieces of whole members -> bytes."""
+_NATIVE = None
+
+
+def _native():
+    """csrc/libfxsynth.so (fxsynth.c: the same zlib calls from plain threads) or None when it has not been built."""
+    global _NATIVE
+    if _NATIVE is None:
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libfxsynth.so")
+        try:
+            L = C.CDLL(path)
+            i64, vp, i32 = C.c_int64, C.c_void_p, C.c_int
+            L.fxs_bgzf_bound.restype = i64; L.fxs_bgzf_bound.argtypes = [i64, i32]
+            L.fxs_gzip_bound.restype = i64; L.fxs_gzip_bound.argtypes = [i64, i64]
+            L.fxs_bgzf_compress.restype = i64; L.fxs_bgzf_compress.argtypes = [vp, i64, vp, i64, i32, i32, i32]
+            L.fxs_gzip_stream.restype = i64; L.fxs_gzip_stream.argtypes = [vp, i64, vp, i64, i64, i32, i32]
+            _NATIVE = L
+        except OSError:
+            _NATIVE = False
+    return _NATIVE or None
+
+
+def _ncpu(procs):
+    import os
+    return int(procs or min(192, os.cpu_count() or 8))
+
+
+def bgzf_compress_parallel(raw, procs=None, step=65280 * 16, block=65280, level=6):
+    """`raw` (numpy uint8) BGZF-framed as bgzf_compress would frame it -> bytes-like (numpy uint8 from the native helper)."""
+    L = _native()
+    if L is not None:
+        src = np.ascontiguousarray(np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else raw)
+        dst = np.empty(int(L.fxs_bgzf_bound(src.size, block)), dtype=np.uint8)
+        w = int(L.fxs_bgzf_compress(src.ctypes.data, src.size, dst.ctypes.data, dst.size, block, level, _ncpu(procs)))
+        if w < 0:
+            raise RuntimeError("fxs_bgzf_compress: %d" % w)
+        return dst[:w]
     mv = memoryview(raw)
     with _threads(procs) as pool:
-        parts = pool.map(lambda ab: bgzf_compress(mv[ab[0]:ab[1]])[:-28], [(a, min(a + step, len(raw))) for a in range(0, len(raw), step)], chunksize=1)
+        parts = pool.map(lambda ab: bgzf_compress(mv[ab[0]:ab[1]], block, level)[:-28], [(a, min(a + step, len(raw))) for a in range(0, len(raw), step)], chunksize=1)
     return b"".join(parts) + bgzf_compress(b"")
 
 
@@ -258,6 +294,14 @@ def gzip_single_stream_parallel(raw, procs=None, piece=8 << 20, level=6):
     """gzip_single_stream of `raw` (numpy uint8), the pieces deflated and the CRC-32 of the trailer folded by a thread pool."""
     import struct
     import zlib
+    L = _native()
+    if L is not None:
+        src = np.ascontiguousarray(np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else raw)
+        dst = np.empty(int(L.fxs_gzip_bound(src.size, piece)), dtype=np.uint8)
+        w = int(L.fxs_gzip_stream(src.ctypes.data, src.size, dst.ctypes.data, dst.size, piece, level, _ncpu(procs)))
+        if w < 0:
+            raise RuntimeError("fxs_gzip_stream: %d" % w)
+        return dst[:w]
     mv = memoryview(raw)
     n = len(raw)
     with _threads(procs) as pool:

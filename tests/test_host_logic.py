@@ -1479,3 +1479,20 @@ def test_window_plan_and_budget(monkeypatch, tmp_path):
     monkeypatch.setenv("FX_HBM_BUDGET", "256K")
     size, kind, win, cap = windows.plan(p, 0, 1.0)
     assert size == 500003 and kind == 0 and win == 65536 and cap == 4
+
+
+def test_native_framing_helpers_write_the_bytes_of_the_python_ones():
+    """csrc/libfxsynth.so (set-up of the C4 inputs: BGZF members / one gzip stream deflated by plain threads) against
+    synth.bgzf_compress / synth.gzip_single_stream, byte for byte, and against gzip itself."""
+    import gzip
+    from pyfastx_amd import synth
+    if synth._native() is None:
+        pytest.skip("libfxsynth.so not built")
+    rng = np.random.default_rng(3)
+    raw = np.frombuffer(b"ACGTNacgt\n", dtype=np.uint8)[rng.integers(0, 10, 700_000)]
+    for n in (0, 1, 65279, 65280, 65281, 700_000):
+        r = raw[:n]
+        a = bytes(synth.bgzf_compress_parallel(r))
+        assert a == synth.bgzf_compress(r.tobytes()) and gzip.decompress(a) == r.tobytes(), n
+        g = bytes(synth.gzip_single_stream_parallel(r, piece=1 << 18))
+        assert g == bytes(synth.gzip_single_stream(r, piece=1 << 18)) and gzip.decompress(g) == r.tobytes(), n
