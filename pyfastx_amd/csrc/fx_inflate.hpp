@@ -649,10 +649,13 @@ __global__ __launch_bounds__(COPY_BLOCK) void k_bgzf_copy(const int64_t *__restr
 // nothing) and the all-ones start value is shifted by the member's length once, at the end.  "Shift by 2^k bytes" is a
 // 32 x 32 matrix over GF(2) (computed on the host by repeated squaring, as zlib's crc32_combine does); the seven the hot
 // loop uses are expanded into 4 x 256-entry tables (one LDS look-up per byte of the operand).
-constexpr int CRC_ROW = 1024, CRC_NSH = 7;                   // shifts by 16 << k bytes, k = 0 .. 6 (6 = one row)
+// Round 4: 64 bytes per lane and row (4 KiB rows) instead of 16: the butterfly of six steps -- 24 of the 40 table look-ups a
+// lane made per 16 bytes -- is paid once per 64, and a lane's own bytes go through four tables at a time ("slicing by 4":
+// four independent look-ups per word instead of a chain of four): 1.26 -> see DESIGN.md for C4.
+constexpr int CRC_LB = 64, CRC_ROW = 64 * CRC_LB, CRC_NSH = 7, CRC_SH0 = 6;   // shifts by CRC_LB << k bytes, k = 0 .. 6 (6 = one row); 2^CRC_SH0 = CRC_LB
 struct CrcTables {
-    uint32_t crc[256];                                       // the byte table of the reflected polynomial 0xEDB88320
-    uint32_t sh[CRC_NSH][4][256];                            // sh[k][b][v] = shift_{16 << k}(v << 8 b)
+    uint32_t crc[4][256];                                    // crc[0]: the byte table of the reflected polynomial 0xEDB88320; crc[j]: the same j bytes further on
+    uint32_t sh[CRC_NSH][4][256];                            // sh[k][b][v] = shift_{CRC_LB << k}(v << 8 b)
     uint32_t pow2[17][32];                                   // matrix of "shift by 2^j bytes", j = 0 .. 16 (column i = image of bit i)
 };
 __device__ __forceinline__ uint32_t crc_shift(const uint32_t (*t)[256], uint32_t v) {
@@ -662,8 +665,8 @@ __global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t *__restrict__ da
                                                  const int32_t *__restrict__ isize, const uint8_t *__restrict__ cbuf,
                                                  const int64_t *__restrict__ cdata_off, const int32_t *__restrict__ cdata_len,
                                                  int64_t nmem, const CrcTables *__restrict__ T, int32_t *__restrict__ status) {
-    __shared__ uint32_t tab[256], sh[CRC_NSH][4][256];
-    for (int i = threadIdx.x; i < 256; i += 256) tab[i] = T->crc[i];
+    __shared__ uint32_t tab[4][256], sh[CRC_NSH][4][256];
+    for (int i = threadIdx.x; i < 4 * 256; i += 256) (&tab[0][0])[i] = (&T->crc[0][0])[i];
     for (int i = threadIdx.x; i < CRC_NSH * 4 * 256; i += 256) (&sh[0][0][0])[i] = (&T->sh[0][0][0])[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -674,15 +677,23 @@ __global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t *__restrict__ da
     const int64_t nrows = (n + CRC_ROW - 1) / CRC_ROW;
     uint32_t acc = 0;                                        // crc_0 of the rows so far (wave-uniform)
     for (int64_t r = 0; r < nrows; ++r) {
-        const int64_t a = n - (nrows - r) * CRC_ROW + lane * 16;   // member-relative offset of this lane's 16 bytes (< 0 in the first row: nothing there)
-        uint32_t w[4] = {0, 0, 0, 0};
-        if (a >= 0) { const uint4 v = *reinterpret_cast<const uint4_u *>(p + a); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
-        else if (a > -16) for (int k = (int)-a; k < 16; ++k) w[k >> 2] |= (uint32_t)p[a + k] << ((k & 3) * 8);
+        const int64_t a = n - (nrows - r) * CRC_ROW + lane * CRC_LB;   // member-relative offset of this lane's 64 bytes (< 0 in the first row: nothing there)
         uint32_t c = 0;
+        if (a >= 0) {
+            uint4 v[CRC_LB / 16];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            c ^= w[k];
-            c = tab[c & 0xFFu] ^ (c >> 8); c = tab[c & 0xFFu] ^ (c >> 8); c = tab[c & 0xFFu] ^ (c >> 8); c = tab[c & 0xFFu] ^ (c >> 8);
+            for (int q = 0; q < CRC_LB / 16; ++q) v[q] = *reinterpret_cast<const uint4_u *>(p + a + 16 * q);
+#pragma unroll
+            for (int q = 0; q < CRC_LB / 16; ++q) {
+                const uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    c ^= w[k];
+                    c = tab[3][c & 0xFFu] ^ tab[2][(c >> 8) & 0xFFu] ^ tab[1][(c >> 16) & 0xFFu] ^ tab[0][c >> 24];
+                }
+            }
+        } else if (a > -CRC_LB) {                            // the member begins inside this lane's piece: its bytes one by one
+            for (int k = (int)-a; k < CRC_LB; ++k) c = tab[0][(c ^ p[a + k]) & 0xFFu] ^ (c >> 8);
         }
 #pragma unroll
         for (int l = 0; l < 6; ++l) {                        // butterfly: after step l every lane holds the crc_0 of its block of 2^(l+1) lanes

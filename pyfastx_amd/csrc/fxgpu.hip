@@ -173,7 +173,9 @@ template <class T> struct ScratchBuf {                      // device array out 
 // bytes" (column b = image of bit b; squared up from the one-zero-bit operator, as zlib's crc32_combine does), and the
 // seven the kernel's hot loop uses expanded into byte-indexed tables.
 static void crc_tables(CrcTables *T) {
-    for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; T->crc[i] = c; }
+    for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; T->crc[0][i] = c; }
+    for (int j = 1; j < 4; ++j)                              // slicing: crc[j][i] = crc[0] applied to i followed by j zero bytes
+        for (uint32_t i = 0; i < 256; ++i) T->crc[j][i] = (T->crc[j - 1][i] >> 8) ^ T->crc[0][T->crc[j - 1][i] & 0xFFu];
     uint32_t a[32], b[32];
     a[0] = 0xEDB88320u;                                      // one zero bit
     for (int n = 1; n < 32; ++n) a[n] = 1u << (n - 1);
@@ -184,9 +186,9 @@ static void crc_tables(CrcTables *T) {
         for (int n = 0; n < 32; ++n) b[n] = times(a, a[n]);
         memcpy(a, b, sizeof a);
     }
-    for (int k = 0; k < CRC_NSH; ++k)                        // shift by 16 << k bytes = 2^(4 + k)
+    for (int k = 0; k < CRC_NSH; ++k)                        // shift by CRC_LB << k bytes = 2^(CRC_SH0 + k)
         for (int byte = 0; byte < 4; ++byte)
-            for (uint32_t v = 0; v < 256; ++v) T->sh[k][byte][v] = times(T->pow2[4 + k], v << (8 * byte));
+            for (uint32_t v = 0; v < 256; ++v) T->sh[k][byte][v] = times(T->pow2[CRC_SH0 + k], v << (8 * byte));
 }
 
 enum KernelId { K_SPAN_SCAN = 0, K_GRAN_REDUCE, K_GRAN_PREFIX, K_HDR_REC, K_GRAN_LINES, K_GRAN_EXACT, K_FASTA_FINALIZE, K_FETCH,

@@ -42,15 +42,10 @@ def main():
     blob, _, _ = synth.fasta_generate(plan, dev, keep_flat=False)
     host = blob[:int(plan["n_bytes"])].cpu().numpy()
     del blob
-    step = 65280 * 64
-    with get_context("fork").Pool(min(96, os.cpu_count() or 8)) as pool:
-        parts = pool.map(_part, [host[x:x + step].tobytes() for x in range(0, len(host), step)], chunksize=4)
     d = tempfile.mkdtemp(prefix="fxprobe")
     path = os.path.join(d, "c4.fa.gz")
     with open(path, "wb") as f:
-        for p in parts:
-            f.write(p)
-        f.write(synth.bgzf_compress(b""))
+        f.write(synth.bgzf_compress_parallel(host))
     if not libs:                                            # in this process (what a profiler attached to it sees)
         from pyfastx_amd import _lib
         _lib.lib().fx_prof_default(1)
