@@ -58,22 +58,23 @@ __device__ __forceinline__ unsigned long long bgzf_lane_hits(const uint8_t *__re
     return m;
 }
 
-// one wave per 4 KiB granule: how many members begin in it
-__global__ __launch_bounds__(BLOCK) void k_bgzf_sig_count(const uint8_t *__restrict__ c, int64_t n, int64_t ngran, int32_t *__restrict__ cnt) {
+// one wave per 4 KiB granule: how many members begin in it.  The granules [g0, g0 + ngran) of the file (a file whose bytes are
+// still arriving is searched group by group, bgzf_open_pipelined); cnt / off are indexed from 0
+__global__ __launch_bounds__(BLOCK) void k_bgzf_sig_count(const uint8_t *__restrict__ c, int64_t n, int64_t g0, int64_t ngran, int32_t *__restrict__ cnt) {
     const int64_t g = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     if (g >= ngran) return;
-    const unsigned long long m = bgzf_lane_hits(c, n, g * 4096 + (int64_t)lane_id() * 64);
+    const unsigned long long m = bgzf_lane_hits(c, n, (g0 + g) * 4096 + (int64_t)lane_id() * 64);
     const uint32_t tot = wave_sum((uint32_t)__popcll(m));
     if (lane_id() == 0) cnt[g] = (int32_t)tot;
 }
 
 // ... and where, in file order: off[g] = members before granule g
-__global__ __launch_bounds__(BLOCK) void k_bgzf_sig_emit(const uint8_t *__restrict__ c, int64_t n, int64_t ngran, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(BLOCK) void k_bgzf_sig_emit(const uint8_t *__restrict__ c, int64_t n, int64_t g0, int64_t ngran, const int64_t *__restrict__ off,
                                                         int64_t *__restrict__ mstart) {
     const int64_t g = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     if (g >= ngran) return;
     if (off[g + 1] == off[g]) return;                                // (wave-uniform: most granules hold no header)
-    const int64_t p0 = g * 4096 + (int64_t)lane_id() * 64;
+    const int64_t p0 = (g0 + g) * 4096 + (int64_t)lane_id() * 64;
     unsigned long long m = bgzf_lane_hits(c, n, p0);
     const uint32_t k = (uint32_t)__popcll(m);
     int64_t at = off[g] + (wave_incl_scan(k) - k);
@@ -84,15 +85,18 @@ __global__ __launch_bounds__(BLOCK) void k_bgzf_sig_emit(const uint8_t *__restri
     }
 }
 
-// one thread per member: BSIZE must lead to the next member exactly; the row of the member table
+// one thread per member: BSIZE must lead to the next member exactly; the row of the member table.  mstart holds nstarts
+// positions (>= nmem: a group of a file that is still arriving leaves its last member to the next group, which knows where
+// it ends); first: where the first of them must begin (0, or where the chain of the group before led)
 __global__ __launch_bounds__(BLOCK) void k_bgzf_member_rows(const uint8_t *__restrict__ c, int64_t n, const int64_t *__restrict__ mstart, int64_t nmem,
+                                                           int64_t nstarts, int64_t first,
                                                            int64_t *__restrict__ coff, int32_t *__restrict__ clen, int32_t *__restrict__ isize,
                                                            int *__restrict__ bad, int32_t *__restrict__ clen_max) {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= nmem) return;
-    const int64_t s = mstart[i], next = i + 1 < nmem ? mstart[i + 1] : n;
+    const int64_t s = mstart[i], next = i + 1 < nstarts ? mstart[i + 1] : n;
     const int64_t msize = (int64_t)(c[s + 16] | (c[s + 17] << 8)) + 1;
-    bool ok = s + msize == next && msize >= BGZF_HDR + 8 && (i > 0 || s == 0);
+    bool ok = s + msize == next && msize >= BGZF_HDR + 8 && (i > 0 || s == first);
     uint32_t isz = 0;
     if (ok) {
         const uint8_t *tr = c + next - 4;
@@ -104,6 +108,12 @@ __global__ __launch_bounds__(BLOCK) void k_bgzf_member_rows(const uint8_t *__res
     isize[i] = ok ? (int32_t)isz : 0;
     if (!ok) atomicOr(bad, 1);
     else atomicMax(clen_max, (int32_t)(msize - BGZF_HDR - 8));
+}
+
+// off[i] += base (the offsets of a group's members in the inflated stream: the scan of their ISIZE began at 0)
+__global__ __launch_bounds__(BLOCK) void k_add_base(int64_t *__restrict__ off, int64_t n, int64_t base) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) off[i] += base;
 }
 
 }  // namespace fx

@@ -16,6 +16,7 @@
 #include <chrono>
 #include <functional>
 #include <map>
+#include <memory>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -122,10 +123,13 @@ struct ScratchPool {
             }
         }
         void *p = nullptr;
+        static const bool trace = [] { const char *e = getenv("FX_TRACE_ALLOC"); return e && atoi(e) != 0; }();
+        const auto t0 = std::chrono::steady_clock::now();
         if (hipMalloc(&p, bytes) != hipSuccess) {            // make room: give the idle blocks back and try once more
             trim();
             if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
         }
+        if (trace) fprintf(stderr, "[fxgpu] scratch miss: hipMalloc(%zu) %.2f ms\n", bytes, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         *cap = bytes;
         return p;
     }
@@ -134,6 +138,7 @@ struct ScratchPool {
             std::lock_guard<std::mutex> g(mu);
             if (held + cap <= limit) { idle.push_back(Block{p, cap, dev}); held += cap; return; }
         }
+        if (getenv("FX_TRACE_ALLOC")) fprintf(stderr, "[fxgpu] scratch full: hipFree(%zu)\n", cap);
         (void)hipFree(p);
     }
     void trim() {
@@ -348,7 +353,9 @@ static int new_handle(int device, fx_handle **out) {
 static int alloc_blob(fx_handle *h, int64_t n) {
     // pad to a whole tile so vector loads of the last chunk stay inside the allocation
     const int64_t padded = ((n + TILE - 1) / TILE) * TILE + TILE;
+    const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(dev_malloc((void **)&h->d_data, (size_t)padded));
+    if (getenv("FX_TRACE_ALLOC")) fprintf(stderr, "[fxgpu] blob: hipMalloc(%lld) %.2f ms\n", (long long)padded, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     h->owns = true;
     h->n = n;
     if (padded > n) HIPCHK(hipMemsetAsync(h->d_data + n, 0, (size_t)(padded - n), h->stream));
@@ -747,7 +754,9 @@ template <class T> static int upload(fx_handle *h, DevBuf<T> &d, const std::vect
 template <class MoffOf>
 static int bgzf_inflate_staged(fx_handle *h, const uint8_t *d_cp, const int64_t *d_coff, const int32_t *d_clen, const int64_t *d_uoff,
                                const int32_t *d_isize, int64_t nmem, int64_t total, int32_t clen_max, const char *path, MoffOf moff_of,
-                               const std::function<void(const char *)> &lap) {
+                               const std::function<void(const char *)> &lap, int64_t m_first = -1) {
+    // m_first >= 0: members [m_first, m_first + nmem) of a file that is inflated group by group (bgzf_open_pipelined): the blob
+    // exists already (d_uoff are offsets into it) and the counts of the handle are added to
     int rc;
     static const bool trace = [] { const char *e = getenv("FX_TRACE"), *b = getenv("FX_TRACE_BGZF"); return (e && atoi(e) != 0) || (b && atoi(b) != 0); }();
     ScratchBuf<int32_t> d_status, d_pstatus;
@@ -760,7 +769,7 @@ static int bgzf_inflate_staged(fx_handle *h, const uint8_t *d_cp, const int64_t 
     HIPCHK(hipMemsetAsync(d_status.p, 0xFF, (size_t)nmem * 4, h->stream));
     HIPCHK(hipMemsetAsync(d_pstatus.p, 0, (size_t)nmem * 4, h->stream));
     HIPCHK(hipMemsetAsync(d_map.p, 0, (size_t)nmem * BM_WORDS * 8, h->stream));
-    if ((rc = alloc_blob(h, total))) return rc;
+    if (m_first < 0 && (rc = alloc_blob(h, total))) return rc;
     lap("allocations");
     // one wave per member, the lanes at 64 bit positions of it (fx_inflate_par.hpp); members it hands over (status INFL_RETRY:
     // anything out of the ordinary, damaged members included) are decoded by one lane each, as in round 2.  FX_BGZF_SERIAL=1: only that.
@@ -832,7 +841,8 @@ static int bgzf_inflate_staged(fx_handle *h, const uint8_t *d_cp, const int64_t 
     HIPCHK(hipMemcpyAsync(status.data(), d_status.p, (size_t)nmem * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(pstatus.data(), d_pstatus.p, (size_t)nmem * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->bgzf_members = nmem; h->bgzf_handed_over = 0; h->bgzf_reason = 0;
+    if (m_first <= 0) { h->bgzf_members = 0; h->bgzf_handed_over = 0; h->bgzf_reason = 0; }
+    h->bgzf_members += nmem;
     for (int64_t m = 0; m < nmem; ++m)
         if (serial_only || pstatus[(size_t)m] >= INFL_RETRY) { if (!h->bgzf_handed_over++) h->bgzf_reason = pstatus[(size_t)m]; }
     lap("kernels done");
@@ -840,7 +850,7 @@ static int bgzf_inflate_staged(fx_handle *h, const uint8_t *d_cp, const int64_t 
         if (status[m] != INFL_OK)
             return fail(FX_EIO, status[m] == INFL_ECRC ? "BGZF member %lld of %s (offset %lld): CRC-32 of the inflated bytes differs from the trailer (code %d)"
                                                        : "BGZF member %lld of %s (offset %lld) failed to inflate: code %d",
-                        (long long)m, path, (long long)moff_of(m), status[m]);
+                        (long long)(m + (m_first > 0 ? m_first : 0)), path, (long long)moff_of(m), status[m]);
     return FX_OK;
 }
 
@@ -887,6 +897,233 @@ static int bgzf_to_blob(fx_handle *h, int fd, int64_t fsize_all, const BgzfTable
     return FX_OK;
 }
 
+// stage_plain_file with the caller free to go on: the same lanes (threads, own streams, two pinned pieces each), every piece
+// with an event of its own that another stream can wait for -- wait_until() makes `s` wait for the pieces that cover the
+// first `upto` bytes (the pieces are handed out in file order, so a prefix of the file is complete long before its end).
+struct StageAsync {
+    fx_handle *h = nullptr;
+    int fd = -1;
+    int64_t n = 0, piece = 0, npieces = 0;
+    uint8_t *d_dst = nullptr;
+    int T = 0;
+    std::atomic<int> err{0};                                  // 1: read error, 2: device error
+    std::vector<std::thread> th;
+    std::vector<hipEvent_t> ev;                               // one per piece
+    std::unique_ptr<std::atomic<int>[]> issued;               // 1: the piece's copy and its event are in the lane's stream
+    int64_t waited = 0;                                       // pieces `wait_until` has been through
+    int start(fx_handle *hh, int fd_, int64_t n_, uint8_t *dst, int64_t piece_bytes) {
+        h = hh; fd = fd_; n = n_; d_dst = dst; piece = std::min<int64_t>(PIECE_BYTES, piece_bytes);
+        npieces = (n + piece - 1) / piece;
+        T = (int)std::min<int64_t>(stage_threads(), std::max<int64_t>(1, npieces));
+        ev.assign((size_t)npieces, nullptr);
+        issued.reset(new std::atomic<int>[(size_t)npieces]);
+        for (int64_t i = 0; i < npieces; ++i) {
+            issued[(size_t)i].store(0);
+            if (hipEventCreateWithFlags(&ev[(size_t)i], hipEventDisableTiming) != hipSuccess) { err.store(2); return fail(FX_EDEVICE, "hipEventCreate failed"); }
+        }
+        static cpu_set_t near_cpus;
+        const bool bind = device_cpus(h->device, &near_cpus);
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([this, t, bind]() {
+                if (bind) (void)pthread_setaffinity_np(pthread_self(), sizeof near_cpus, &near_cpus);
+                if (hipSetDevice(h->device) != hipSuccess) { err.store(2); return; }
+                uint8_t *pin[2] = {g_pins.get(), g_pins.get()};
+                hipStream_t st = nullptr;
+                int64_t last[2] = {-1, -1};                  // the piece whose copy reads the slot
+                bool ok = pin[0] && pin[1] && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+                if (!ok) err.store(2);
+                int slot = 0;
+                for (int64_t k = t; ok && k < npieces && !err.load(); k += T, slot ^= 1) {
+                    const int64_t off = k * piece, len = std::min(piece, n - off);
+                    if (last[slot] >= 0 && hipEventSynchronize(ev[(size_t)last[slot]]) != hipSuccess) { err.store(2); break; }
+                    int64_t done = 0;
+                    while (done < len) {
+                        const ssize_t r = pread(fd, pin[slot] + done, (size_t)(len - done), (off_t)(off + done));
+                        if (r <= 0) { err.store(1); break; }
+                        done += r;
+                    }
+                    if (done < len) break;
+                    if (hipMemcpyAsync(d_dst + off, pin[slot], (size_t)len, hipMemcpyHostToDevice, st) != hipSuccess ||
+                        hipEventRecord(ev[(size_t)k], st) != hipSuccess) { err.store(2); break; }
+                    last[slot] = k;
+                    issued[(size_t)k].store(1, std::memory_order_release);
+                }
+                if (st) (void)hipStreamSynchronize(st);
+                for (int i = 0; i < 2; ++i) if (pin[i]) g_pins.put(pin[i]);
+                if (st) (void)hipStreamDestroy(st);
+            });
+        return FX_OK;
+    }
+    // the HOST waits until the first `upto` bytes of the file are on the device; -> 0, or the error of a lane.  (Not
+    // hipStreamWaitEvent: the lanes' streams and the stream of the kernels share a handful of hardware queues, and a kernel
+    // queued behind the markers of copies that are still to come starts when THOSE have landed -- measured: the first group's
+    // kernels began when the whole file was there.  The kernels run on a stream of another priority, which has queues of its own.)
+    int wait_until(int64_t upto) {
+        const int64_t pe = std::min(npieces, (upto + piece - 1) / piece);
+        for (; waited < pe; ++waited) {
+            while (!issued[(size_t)waited].load(std::memory_order_acquire)) {
+                if (err.load()) return err.load();
+                usleep(20);
+            }
+            if (hipEventSynchronize(ev[(size_t)waited]) != hipSuccess) return 2;
+        }
+        return err.load();
+    }
+    int finish() {
+        for (auto &x : th) x.join();
+        th.clear();
+        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+        ev.clear();
+        return err.load();
+    }
+    ~StageAsync() { (void)finish(); }
+};
+
+// A large BGZF file, the inflate running BEHIND the staging instead of after it (round 4).  The compressed bytes reach the
+// device at what the copy out of the page cache gives (~46 GB/s: 21 ms for C4's 0.97 GB) and the kernels of the whole file take
+// about as long again (18 ms); neither needs the other's engine.  The file is taken in groups of FX_BGZF_GROUP bytes (256 MiB; the first ones smaller):
+// as soon as a group has landed, its members are found (the signature search of fx_bgzf_walk.hpp over the group's granules --
+// all but the last one, whose hits may need bytes of the next group; the last member found waits for the next group too, which
+// knows where it ends), their ISIZE scanned on from the running total, and they are inflated -- decode, copy, CRC -- while the
+// next groups arrive.  The size of the inflated stream is not known before the last group: the blob is allocated after the
+// first group for that group's ratio + 10 % (a file whose later groups inflate further than that takes the one-shot path:
+// -> 1, as for any file this path does not take; what is left over at the end stays with the blob).
+static int bgzf_open_pipelined(fx_handle *h, int fd, int64_t fsize, const char *path, int64_t group) {
+    static const bool trace = [] { const char *e = getenv("FX_TRACE"), *b = getenv("FX_TRACE_BGZF"); return (e && atoi(e) != 0) || (b && atoi(b) != 0); }();
+    const auto T0 = std::chrono::steady_clock::now();
+    const std::function<void(const char *)> lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "[fxgpu] bgzf/p %-20s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
+    };
+    const std::function<void(const char *)> quiet = [](const char *) {};
+    int rc;
+    // the kernels on a stream of the highest priority for the length of this open: hardware queues of its own (see wait_until)
+    struct PrioStream {
+        fx_handle *h; hipStream_t saved, mine = nullptr;
+        explicit PrioStream(fx_handle *hh) : h(hh), saved(hh->stream) {
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo &&
+                hipStreamCreateWithPriority(&mine, hipStreamNonBlocking, hi) == hipSuccess) { (void)hipStreamSynchronize(saved); h->stream = mine; }
+            else mine = nullptr;
+        }
+        ~PrioStream() { if (mine) { (void)hipStreamSynchronize(mine); h->stream = saved; (void)hipStreamDestroy(mine); } }
+    } prio(h);
+    ScratchBuf<uint8_t> d_c;
+    if ((rc = d_c.alloc(h->device, fsize + 48, h->stream))) return rc;
+    HIPCHK(hipMemsetAsync(d_c.p + fsize, 0, 48, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    StageAsync stg;
+    if ((rc = stg.start(h, fd, fsize, d_c.p, group))) return rc;
+    // whatever happens below, the lanes are joined before the staging buffer goes back to the pool (d_c is declared first)
+    const int64_t ngran_all = (fsize + 4095) / 4096;
+    // where the groups end: the first ones are smaller (a quarter, a quarter, a half of `group`), so that the kernels begin
+    // when the first few pieces are there and not after the first 128 MiB
+    std::vector<int64_t> edge;
+    for (int64_t at = 0, k = 0; at < fsize; ++k) {
+        const int64_t step = std::max<int64_t>(4096, (k < 2 ? group / 4 : k == 2 ? group / 2 : group) & ~4095ll);
+        at = std::min(fsize, at + step);
+        if (fsize - at < step / 2) at = fsize;                 // no sliver at the end
+        edge.push_back(at);
+    }
+    const int64_t ngroups = (int64_t)edge.size();
+    int64_t carry = -1;                                        // start of the member the group before left over
+    int64_t U = 0, M = 0, cap = 0;                             // inflated bytes / members so far; bytes the blob can take
+    h->gz_moff.clear(); h->gz_coff.clear(); h->gz_uoff.clear();
+    auto give_up = [&](int code) {                             // 1: the one-shot path decides; < 0: an error
+        (void)stg.finish();
+        if (h->owns && h->d_data) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->d_data); h->d_data = nullptr; h->owns = false; h->n = 0; }
+        h->gz_moff.clear(); h->gz_coff.clear(); h->gz_uoff.clear();
+        return code;
+    };
+    for (int64_t g = 0; g < ngroups; ++g) {
+        const bool last = g + 1 == ngroups;
+        const int64_t upto = edge[(size_t)g];
+        const int e = stg.wait_until(upto);
+        if (e) { (void)give_up(0); return e == 1 ? fail(FX_EIO, "read error on %s", path) : fail(FX_EDEVICE, "staging %s to the device failed", path); }
+        if (trace && g < 2) lap("  bytes of the group there");
+        const int64_t ga = g == 0 ? 0 : edge[(size_t)g - 1] / 4096 - 1, gb = last ? ngran_all : upto / 4096 - 1, ng = gb - ga;
+        if (ng <= 0) continue;
+        const int64_t nchunks = (ng + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        ScratchBuf<int64_t> d_i64;
+        ScratchBuf<int32_t> d_cnt;
+        if ((rc = d_i64.alloc(h->device, ng + 1 + nchunks + 1, h->stream)) || (rc = d_cnt.alloc(h->device, ng, h->stream))) return give_up(rc);
+        int64_t *d_off = d_i64.p, *d_sums = d_i64.p + ng + 1;
+        hipLaunchKernelGGL(k_bgzf_sig_count, dim3(nblocks(ng, BLOCK / 64)), dim3(BLOCK), 0, h->stream, (const uint8_t *)d_c.p, fsize, ga, ng, d_cnt.p);
+        hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, (const int32_t *)d_cnt.p, ng, d_sums);
+        hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, d_sums, nchunks);
+        hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, (const int32_t *)d_cnt.p, ng, (const int64_t *)d_sums, d_off);
+        int64_t found = 0;
+        if (hipMemcpyAsync(&found, d_off + ng, 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+            return give_up(fail(FX_EDEVICE, "BGZF member search failed on the device"));
+        if (found < 0 || found > (gb - ga) * 4096 / (BGZF_HDR + 8)) return give_up(1);
+        if (g == 0 && found == 0) return give_up(1);
+        const int64_t nstarts = found + (carry >= 0 ? 1 : 0);
+        const int64_t nmem = last ? nstarts : nstarts - 1;     // the last start of a group waits for the next one
+        if (nstarts == 0) continue;
+        const int64_t mchunks = (std::max<int64_t>(nmem, 1) + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        ScratchBuf<int64_t> d_t64;
+        ScratchBuf<int32_t> d_t32;
+        if ((rc = d_t64.alloc(h->device, nstarts + 2 * nmem + 2 + mchunks + 1, h->stream)) || (rc = d_t32.alloc(h->device, 2 * nmem + 4, h->stream))) return give_up(rc);
+        int64_t *d_mstart = d_t64.p, *d_coff = d_t64.p + nstarts, *d_uoff = d_coff + nmem, *d_msums = d_uoff + nmem + 1;
+        int32_t *d_clen = d_t32.p, *d_isize = d_t32.p + nmem, *d_flags = d_t32.p + 2 * nmem;
+        HIPCHK(hipMemsetAsync(d_flags, 0, 8, h->stream));
+        if (carry >= 0) HIPCHK(hipMemcpyAsync(d_mstart, &carry, 8, hipMemcpyHostToDevice, h->stream));
+        if (found) hipLaunchKernelGGL(k_bgzf_sig_emit, dim3(nblocks(ng, BLOCK / 64)), dim3(BLOCK), 0, h->stream, (const uint8_t *)d_c.p, fsize, ga, ng,
+                                      (const int64_t *)d_off, d_mstart + (carry >= 0 ? 1 : 0));
+        const int64_t first_start = carry >= 0 ? carry : 0;
+        int64_t next_carry = -1;
+        if (!last) HIPCHK(hipMemcpyAsync(&next_carry, d_mstart + nstarts - 1, 8, hipMemcpyDeviceToHost, h->stream));
+        if (nmem == 0) {                                       // one start only: it waits
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (g == 0 && next_carry != 0) return give_up(1);
+            carry = next_carry;
+            continue;
+        }
+        hipLaunchKernelGGL(k_bgzf_member_rows, dim3(nblocks(nmem, BLOCK)), dim3(BLOCK), 0, h->stream, (const uint8_t *)d_c.p, fsize, (const int64_t *)d_mstart, nmem,
+                           nstarts, first_start, d_coff, d_clen, d_isize, (int *)d_flags, d_flags + 1);
+        hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)mchunks), dim3(BLOCK), 0, h->stream, (const int32_t *)d_isize, nmem, d_msums);
+        hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, d_msums, mchunks);
+        hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)mchunks), dim3(BLOCK), 0, h->stream, (const int32_t *)d_isize, nmem, (const int64_t *)d_msums, d_uoff);
+        if (U) hipLaunchKernelGGL(k_add_base, dim3(nblocks(nmem + 1, BLOCK)), dim3(BLOCK), 0, h->stream, d_uoff, nmem + 1, U);
+        int32_t flags[2] = {0, 0};
+        int64_t u_end = 0;
+        HIPCHK(hipMemcpyAsync(flags, d_flags, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(&u_end, d_uoff + nmem, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (flags[0] || u_end < U) return give_up(1);          // the chain does not tile the file
+        if (!last && (next_carry <= first_start)) return give_up(1);
+        if (!cap) {                                            // the blob, from the ratio of the first members
+            const int64_t cbytes = (last ? fsize : next_carry) - first_start;
+            if (u_end <= 0 || cbytes <= 0) return give_up(1);
+            const double ratio = (double)u_end / (double)cbytes;
+            cap = last ? u_end : (int64_t)((double)fsize * ratio * 1.10) + (16ll << 20);
+            if ((rc = alloc_blob(h, cap))) return give_up(rc);
+        }
+        if (u_end > cap) return give_up(1);                    // later groups inflate further than the first ones promised
+        if (trace && g < 2) lap("  members found, blob");
+        const size_t at = h->gz_moff.size();
+        h->gz_moff.resize(at + (size_t)nmem); h->gz_coff.resize(at + (size_t)nmem); h->gz_uoff.resize(at + (size_t)nmem);
+        HIPCHK(hipMemcpyAsync(h->gz_moff.data() + at, d_mstart, (size_t)nmem * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->gz_coff.data() + at, d_coff, (size_t)nmem * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->gz_uoff.data() + at, d_uoff, (size_t)nmem * 8, hipMemcpyDeviceToHost, h->stream));
+        if ((rc = bgzf_inflate_staged(h, d_c.p, d_coff, d_clen, d_uoff, d_isize, nmem, (int64_t)-1, flags[1], path,
+                                      [&](int64_t m) { return h->gz_moff[at + (size_t)m]; }, M == 0 ? lap : quiet, M)))
+            return give_up(rc);
+        U = u_end; M += nmem;
+        carry = next_carry;
+        if (trace) { char what[64]; snprintf(what, sizeof what, "group %lld (%lld members)", (long long)g, (long long)nmem); lap(what); }
+    }
+    if ((rc = stg.finish())) { (void)give_up(0); return rc == 1 ? fail(FX_EIO, "read error on %s", path) : fail(FX_EDEVICE, "staging %s to the device failed", path); }
+    if (M == 0 || U <= 0) return give_up(1);
+    h->n = U;                                                  // what the blob holds (its allocation is a little larger)
+    HIPCHK(hipMemsetAsync(h->d_data + U, 0, (size_t)std::min<int64_t>(2 * TILE, ((cap + TILE - 1) / TILE) * TILE + TILE - U), h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->bgzf = true;
+    h->gz_mode = 1;
+    h->gz_csize = fsize;
+    lap("done");
+    return FX_OK;
+}
+
 // A whole BGZF file with the member table made on the device (fx_bgzf_walk.hpp): stage the compressed bytes, find the members
 // in HBM, inflate.  -> FX_OK; 1: not a file this path takes (another header layout, a chain that does not tile the file: the
 // host walk decides); < 0: an error.
@@ -902,6 +1139,15 @@ static int bgzf_open_on_device(fx_handle *h, int fd, int64_t fsize, const char *
         if (trace) fprintf(stderr, "[fxgpu] bgzf %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
     };
     int rc;
+    {   // large files: the inflate behind the staging, group by group (FX_BGZF_GROUP bytes, a multiple of 4096; 0: never)
+        const char *e = getenv("FX_BGZF_GROUP");
+        int64_t group = e ? atoll(e) : (256ll << 20);       // tools/bgzf_group_probe.py: C4 opens in 37 ms (median) with 256 MiB, 40 with 128, 54 with 64, 49 all at once
+        group &= ~4095ll;
+        if (group >= 8192 && fsize >= 2 * group) {
+            rc = bgzf_open_pipelined(h, fd, fsize, path, group);
+            if (rc != 1) return rc;                           // 1: not for that path (a ratio that grew, a chain that breaks): all at once, below
+        }
+    }
     ScratchBuf<uint8_t> d_c;
     if ((rc = d_c.alloc(h->device, fsize + 48, h->stream))) return rc;
     HIPCHK(hipMemsetAsync(d_c.p + fsize, 0, 48, h->stream));
@@ -914,7 +1160,7 @@ static int bgzf_open_on_device(fx_handle *h, int fd, int64_t fsize, const char *
     ScratchBuf<int32_t> d_cnt;
     if ((rc = d_i64.alloc(h->device, ngran + 1 + nchunks + 1, h->stream)) || (rc = d_cnt.alloc(h->device, ngran, h->stream))) return rc;
     int64_t *d_off = d_i64.p, *d_sums = d_i64.p + ngran + 1;
-    hipLaunchKernelGGL(k_bgzf_sig_count, dim3(nblocks(ngran, BLOCK / 64)), dim3(BLOCK), 0, h->stream, (const uint8_t *)d_c.p, fsize, ngran, d_cnt.p);
+    hipLaunchKernelGGL(k_bgzf_sig_count, dim3(nblocks(ngran, BLOCK / 64)), dim3(BLOCK), 0, h->stream, (const uint8_t *)d_c.p, fsize, (int64_t)0, ngran, d_cnt.p);
     hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, (const int32_t *)d_cnt.p, ngran, d_sums);
     hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, d_sums, nchunks);
     hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, (const int32_t *)d_cnt.p, ngran, (const int64_t *)d_sums, d_off);
@@ -930,9 +1176,9 @@ static int bgzf_open_on_device(fx_handle *h, int fd, int64_t fsize, const char *
     int64_t *d_mstart = d_t64.p, *d_coff = d_t64.p + nmem, *d_uoff = d_t64.p + 2 * nmem, *d_msums = d_t64.p + 3 * nmem + 1;
     int32_t *d_clen = d_t32.p, *d_isize = d_t32.p + nmem, *d_flags = d_t32.p + 2 * nmem;      // flags: [0] bad, [1] longest deflate payload
     HIPCHK(hipMemsetAsync(d_flags, 0, 8, h->stream));
-    hipLaunchKernelGGL(k_bgzf_sig_emit, dim3(nblocks(ngran, BLOCK / 64)), dim3(BLOCK), 0, h->stream, (const uint8_t *)d_c.p, fsize, ngran, (const int64_t *)d_off, d_mstart);
+    hipLaunchKernelGGL(k_bgzf_sig_emit, dim3(nblocks(ngran, BLOCK / 64)), dim3(BLOCK), 0, h->stream, (const uint8_t *)d_c.p, fsize, (int64_t)0, ngran, (const int64_t *)d_off, d_mstart);
     hipLaunchKernelGGL(k_bgzf_member_rows, dim3(nblocks(nmem, BLOCK)), dim3(BLOCK), 0, h->stream, (const uint8_t *)d_c.p, fsize, (const int64_t *)d_mstart, nmem,
-                       d_coff, d_clen, d_isize, (int *)d_flags, d_flags + 1);
+                       nmem, (int64_t)0, d_coff, d_clen, d_isize, (int *)d_flags, d_flags + 1);
     hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)mchunks), dim3(BLOCK), 0, h->stream, (const int32_t *)d_isize, nmem, d_msums);
     hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, d_msums, mchunks);
     hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)mchunks), dim3(BLOCK), 0, h->stream, (const int32_t *)d_isize, nmem, (const int64_t *)d_msums, d_uoff);

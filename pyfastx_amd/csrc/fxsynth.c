@@ -23,33 +23,35 @@ typedef struct {
     volatile int err;
 } job_t;
 
-static int deflate_raw(const uint8_t *in, int64_t n, uint8_t *out, int64_t cap, int level, int flush, int64_t *got) {
-    z_stream z;
-    memset(&z, 0, sizeof z);
-    if (deflateInit2(&z, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return -1;
+/* one z_stream per thread, reset for every item: deflateInit2 allocates ~260 KiB, and 192 threads doing that per 64 KiB
+ * member spend their time in mmap / munmap (3 GB took 15 s that way, whatever the language above) */
+static int deflate_raw(z_stream *z, const uint8_t *in, int64_t n, uint8_t *out, int64_t cap, int flush, int64_t *got) {
+    if (deflateReset(z) != Z_OK) return -1;
     int64_t ip = 0, op = 0;
     int rc = Z_OK;
     do {                                  /* avail_in / avail_out are 32-bit: feed at most 1 GiB at a time */
         const int64_t in_now = n - ip > (1 << 30) ? (1 << 30) : n - ip;
         const int last = ip + in_now == n;
-        z.next_in = (Bytef *)(in + ip); z.avail_in = (uInt)in_now;
+        z->next_in = (Bytef *)(in + ip); z->avail_in = (uInt)in_now;
         do {
             const int64_t room = cap - op > (1 << 30) ? (1 << 30) : cap - op;
-            if (room <= 0) { deflateEnd(&z); return -2; }
-            z.next_out = out + op; z.avail_out = (uInt)room;
-            rc = deflate(&z, last ? flush : Z_NO_FLUSH);
-            op += room - z.avail_out;
-            if (rc == Z_STREAM_ERROR) { deflateEnd(&z); return -3; }
-        } while (z.avail_out == 0);
+            if (room <= 0) return -2;
+            z->next_out = out + op; z->avail_out = (uInt)room;
+            rc = deflate(z, last ? flush : Z_NO_FLUSH);
+            op += room - z->avail_out;
+            if (rc == Z_STREAM_ERROR) return -3;
+        } while (z->avail_out == 0);
         ip += in_now;
     } while (ip < n);
-    deflateEnd(&z);
     *got = op;
     return 0;
 }
 
 static void *worker(void *arg) {
     job_t *j = (job_t *)arg;
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (deflateInit2(&z, j->level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { j->err = 3; return 0; }
     for (;;) {
         const int64_t i = __sync_fetch_and_add(&j->next, 1);
         if (i >= j->nitem || j->err) break;
@@ -58,7 +60,7 @@ static void *worker(void *arg) {
         int64_t got = 0;
         if (j->bgzf) {                    /* SAM spec 4.1: 18-byte header with the 'BC' subfield, deflate, CRC-32, ISIZE */
             static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
-            if (deflate_raw(j->src + a, m, o + 18, j->slot - 26, j->level, Z_FINISH, &got)) { j->err = 1; break; }
+            if (deflate_raw(&z, j->src + a, m, o + 18, j->slot - 26, Z_FINISH, &got)) { j->err = 1; break; }
             if (got + 25 > 65535) { j->err = 2; break; }
             memcpy(o, hdr, 16);
             const uint32_t bsize = (uint32_t)(got + 25), c = (uint32_t)crc32(crc32(0L, Z_NULL, 0), j->src + a, (uInt)m), isz = (uint32_t)m;
@@ -67,13 +69,14 @@ static void *worker(void *arg) {
             j->len[i] = got + 26;
         } else {                          /* one piece of a single stream, pigz-style: a full flush ends all but the last */
             const int last = i + 1 == j->nitem;
-            if (deflate_raw(j->src + a, m, o, j->slot, j->level, last ? Z_FINISH : Z_FULL_FLUSH, &got)) { j->err = 1; break; }
+            if (deflate_raw(&z, j->src + a, m, o, j->slot, last ? Z_FINISH : Z_FULL_FLUSH, &got)) { j->err = 1; break; }
             uint32_t c = (uint32_t)crc32(0L, Z_NULL, 0);
             for (int64_t p = 0; p < m; p += 1 << 30) c = (uint32_t)crc32(c, j->src + a + p, (uInt)(m - p > (1 << 30) ? (1 << 30) : m - p));
             j->crc[i] = c;
             j->len[i] = got;
         }
     }
+    deflateEnd(&z);
     return 0;
 }
 

@@ -429,3 +429,54 @@ def fxi_points(db):
         c, u, b, f = rows[8 + 4 * i:12 + 4 * i]
         out.append((struct.unpack("<Q", c)[0], struct.unpack("<Q", u)[0], b[0], f[0]))
     return out
+
+
+@pytest.mark.parametrize("group", [8192, 65536, 1 << 20])
+def test_open_in_groups_behind_the_staging(L, tmp_path, monkeypatch, group):
+    """Round 4: a large BGZF file is inflated group by group while its later bytes are still on their way to the device
+    (bgzf_open_pipelined; FX_BGZF_GROUP makes a few MB "large").  Members that straddle two groups, groups that hold no
+    complete member, the 28-byte EOF member alone in the last group: the bytes, the restart points and the counts are the
+    one-shot open's."""
+    from pyfastx_amd import synth
+    rng = np.random.default_rng(group)
+    raw = b">chr1 six million\n" + _genome_like(rng, 6_000_000) + b">fixture\n" + fixture_bytes("test.fa")[:200_000]
+    bg = synth.bgzf_compress(raw, block=65280 if group > 8192 else 30000)
+    p = _write(tmp_path, "g.fa.gz", bg)
+    monkeypatch.setenv("FX_BGZF_GROUP", "0")
+    one = L.Blob.from_file(p)
+    want_pts = one.gz_points(spacing=100_000)
+    want_counts = one.bgzf_counts()
+    monkeypatch.setenv("FX_BGZF_GROUP", str(group))
+    monkeypatch.setenv("FX_TRACE_BGZF", "1")
+    b = L.Blob.from_file(p)
+    assert b.is_gzip and b.size == len(raw) == one.size
+    assert b.read_bytes(0, len(raw)) == raw
+    got_pts = b.gz_points(spacing=100_000)
+    for x, y in zip(got_pts, want_pts):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    assert b.bgzf_counts() == want_counts
+    s = b.fasta_build()                                    # the blob is a stream like any other (its allocation is a little larger than it)
+    s1 = one.fasta_build()
+    assert (s.n_seq, s.seq_len) == (s1.n_seq, s1.seq_len) and s.n_seq == 2 + fixture_bytes("test.fa")[:200_000].count(b">")
+
+
+def test_groups_give_way_when_the_file_inflates_further_than_its_head_promised(L, tmp_path, monkeypatch):
+    """The blob of a pipelined open is allocated from the ratio of the first group (+ 10 %): a file whose tail is a run of N
+    (ratio ~1000) outgrows it and is opened all at once instead -- same bytes; a member damaged in a LATER group is reported
+    with its number in the file."""
+    from pyfastx_amd import synth
+    rng = np.random.default_rng(5)
+    raw = _genome_like(rng, 1_500_000) + b"N" * 30_000_000
+    bg = synth.bgzf_compress(raw)
+    monkeypatch.setenv("FX_BGZF_GROUP", "65536")
+    b = L.Blob.from_file(_write(tmp_path, "n.fa.gz", bg))
+    assert b.size == len(raw) and b.read_bytes(1_400_000, 200_000) == raw[1_400_000:1_600_000] and b.read_bytes(len(raw) - 70_000, 70_000) == raw[-70_000:]
+    raw2 = _genome_like(rng, 3_000_000)
+    bg2 = bytearray(synth.bgzf_compress(raw2, level=0))   # stored members: a flipped payload byte only shows in the CRC
+    member = 2_000_000 // 65280                          # a stored member: 18 bytes of header, 5 of block header, 65280 of payload, 8 of trailer
+    pos = member * (65280 + 31) + 23 + (2_000_000 - member * 65280)
+    assert bg2[pos] == raw2[2_000_000]
+    bg2[pos] ^= 0x20
+    with pytest.raises(L.FxError) as e:
+        L.Blob.from_file(_write(tmp_path, "flip2.fa.gz", bytes(bg2)))
+    assert e.value.code == L.FX_EIO and "CRC-32" in str(e.value) and ("member %d " % member) in str(e.value)
