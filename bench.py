@@ -57,7 +57,9 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-c3", action="store_true")
     ap.add_argument("--no-c4", action="store_true")
-    ap.add_argument("--no-gz-stream", action="store_true", help="skip the single-stream gzip sub-leg of c4")
+    ap.add_argument("--gz-stream", action="store_true", help="also the single-stream gzip sub-leg of c4 (the C2 bytes as ONE gzip member: 17 s of deflate on this box's "
+                                                               "16-CPU quota to make it + 3 s; its numbers of the round are in profiles/r04_single_stream_gzip.json)")
+    ap.add_argument("--no-gz-stream", action="store_true", help=argparse.SUPPRESS)      # (the default now)
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure the scan kernel's HBM traffic (about a minute)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # the workload of one counter pass: generate, build three times, exit
     ap.add_argument("--no-c3-file", action="store_true", help="skip the full-size FASTQ file leg (35 GB file + 10 GB index in /dev/shm)")
@@ -598,7 +600,7 @@ def leg_c4(a, host, plan, q, tmpdir, plain_digest=None):
     _rm(path, path + ".fxi")
     # ---- the same bytes as ONE gzip stream (no member boundaries): zran-style restart points.  First open:
     # serial inflate on the host, points captured; every later open: the segments between the points inflated in parallel
-    if not a.no_gz_stream:
+    if a.gz_stream and not a.no_gz_stream:
         t0 = time.perf_counter()
         gz = synth.gzip_single_stream_parallel(host)
         p2 = os.path.join(tmpdir, "c4s.fa.gz")
