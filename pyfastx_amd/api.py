@@ -14,7 +14,13 @@ import os
 import numpy as np
 
 from . import _lib, fxi
-from . import _fxobj          # C base types of Fasta / Sequence: the per-object getter path (csrc/fxobj.c)
+try:
+    from . import _fxobj      # C base types of Fasta / Sequence / Fastq / Read: the per-object getter path (csrc/fxobj.c)
+except ImportError as _e:     # not built, or built for another interpreter (the ABI tag of the file name is the builder's)
+    import sys as _sys
+    raise ImportError("pyfastx_amd._fxobj (csrc/fxobj.c) is missing or was built for another Python than %s: build it with "
+                      "`make -C pyfastx_amd/csrc PYTHON=%s` (or `python -c 'import __graft_entry__ as g; g.build()'`): %s"
+                      % (_sys.version.split()[0], _sys.executable, _e)) from _e
 
 VERSION = "2.3.1"          # API level mirrored (reference src/version.h:1)
 

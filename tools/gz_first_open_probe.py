@@ -25,8 +25,7 @@ def main():
     blob, _, _ = synth.fasta_generate(plan, dev, keep_flat=False)
     host = blob[:int(plan["n_bytes"])].cpu().numpy()
     del blob
-    with get_context("fork").Pool(min(96, os.cpu_count() or 8)) as pool:
-        gz = synth.gzip_single_stream(host, pool)
+    gz = synth.gzip_single_stream_parallel(host, procs=32)
     d = tempfile.mkdtemp(prefix="fxgz", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     p = os.path.join(d, "s.fa.gz")
     with open(p, "wb") as f:
