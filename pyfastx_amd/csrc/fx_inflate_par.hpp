@@ -25,8 +25,8 @@
 #pragma once
 #include "fx_inflate.hpp"
 
-#ifndef FX_BGZF_GLOBAL_MAP
-#define FX_BGZF_LDS_MAP 1                                               // the match map of a member in LDS (see P_MAP_SET)
+#if !defined(FX_BGZF_GLOBAL_MAP) && !defined(FX_BGZF_LDS_MAP)
+#define FX_BGZF_REG_MAP 1                                               // the word of the match map a lane is in waits in a register (see P_MAP_SET)
 #endif
 
 namespace fx {
@@ -310,10 +310,25 @@ template <bool STAGE> __device__ __forceinline__ void p_header(PTab &T, const ui
 // 64 lanes: one coalesced 256-byte store per step), and phase B does not decode again -- it replays its own rows.  The
 // scratch belongs to the WAVE, not to the member (the grid is as many waves as the device holds at once, every wave takes
 // members m, m + grid, ...): sym_rows rows of 64 words each, a member with a lane that needs more is handed over.
-// the bit of output byte o in the member's match map: in LDS and flushed once per member (8 KiB of the wave's 21: seven waves
-// per CU), or -- FX_BGZF_GLOBAL_MAP, measured in round 4 -- straight in memory (13 KiB, twelve waves per CU, but 460 M atomics
-// on memory for C4: decode 12.4 -> 20.3 ms)
-#ifdef FX_BGZF_LDS_MAP
+// the bit of output byte o in the member's match map.  Round 3-4: in LDS and flushed once per member (FX_BGZF_LDS_MAP: 8 KiB of the
+// wave's 21, seven waves per CU, 12.45 ms for C4); straight in memory (FX_BGZF_GLOBAL_MAP: 13 KiB, twelve waves per CU, but 460 M
+// atomics on memory: 20.3 ms); now in a register of the lane that writes that stretch of output (13 KiB, twelve waves per CU,
+// one store per map word: 11.3-12.1 ms; capped at 6 / 8 / 10 waves per CU, FX_BGZF_WAVES_PER_CU: 15.2 / 12.6 / 11.6 -- the
+// kernel stops gaining at ten: from there it is bound by the instructions it issues)
+#if defined(FX_BGZF_REG_MAP)
+// FX_BGZF_REG_MAP: a lane's matches come in rising order of their place, so the 64-bit word of the map it is in can wait in a
+// register and go out when the lane moves on to the next one -- a plain store for a word that lies inside the lane's own
+// stretch of output (nobody else has bits in it; the host cleared the map), an atomic for the word at either end of it
+__device__ __forceinline__ void p_map_flush(unsigned long long *bm, uint32_t wi, unsigned long long mw, uint32_t o_start, uint32_t o_end) {
+    if (wi == ~0u || !mw) return;
+#ifndef FX_BGZF_REG_MAP_ATOMIC                                           // (an atomic for every word: 11.4-12.7 ms for C4 against 11.3-12.1)
+    if (wi * 64u >= o_start && wi * 64u + 64u <= o_end) bm[wi] = mw;
+    else
+#endif
+    atomicOr(&bm[wi], mw);
+}
+#define P_MAP_SET(o) do { const uint32_t w_ = (o) >> 6; if (w_ != mw_i) { p_map_flush(bm, mw_i, mw, o_first, o_end); mw = 0; mw_i = w_; } mw |= 1ull << ((o) & 63u); } while (0)
+#elif defined(FX_BGZF_LDS_MAP)
 #define P_MAP_SET(o) atomicOr(&T.map[(o) >> 5], 1u << ((o) & 31u))
 #else
 #define P_MAP_SET(o) atomicOr(reinterpret_cast<unsigned int *>(bm) + ((o) >> 5), 1u << ((o) & 31u))
@@ -500,6 +515,11 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
         if (owner && lane <= j) {
             uint32_t o = obase + incl - n_k;
             const uint32_t o_end = o + n_k;
+#ifdef FX_BGZF_REG_MAP
+            const uint32_t o_first = o;
+            unsigned long long mw = 0;
+            uint32_t mw_i = ~0u;
+#endif
             const uint32_t stop = lane < j ? Yn : eob_after;                     // (lane j stops AT its end-of-block code, see below)
             uint32_t bp = Y;
             uint64_t acc = 0;                                                    // the bytes [o - fill, o)
@@ -563,6 +583,9 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
                 }
             }
             for (uint32_t i = 0; i < fill; ++i) out[o - fill + i] = (uint8_t)(acc >> (8u * i));      // the last few bytes
+#ifdef FX_BGZF_REG_MAP
+            p_map_flush(bm, mw_i, mw, o_first, o_end);
+#endif
             if (!bad && (o != o_end || bp != stop)) bad = INFL_ESIZE;            // the second walk must land where the first one did
         }
         const unsigned long long bb = __ballot(bad != 0);
