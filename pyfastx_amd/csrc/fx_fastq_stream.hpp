@@ -180,23 +180,33 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__re
                 }
             }
             if (__builtin_expect((d0 | d1 | d2 | d3) != 0, 0)) {   // a base that is none of A C G T N \r: N for the reference; take the aliased class back out
+                // (word by word, the bytes of a word by shifting it: a byte picked by a run-time index makes the compiler keep the
+                // chunk in scratch memory -- 64 bytes per lane stored for every granule, on the straight path)
+                const uint32_t dsw[4] = {d0, d1, d2, d3}, hsw[4] = {h0, h1, h2, h3};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t dw = dsw[q], hw = hsw[q];
 #pragma unroll 1
-                for (int b = 0; b < 16; ++b) {
-                    const uint32_t dw = (b & 8) ? ((b & 4) ? d3 : d2) : ((b & 4) ? d1 : d0);
-                    if (!((dw >> ((b & 3) * 8)) & 0xFFu)) continue;
-                    const uint32_t hw = (b & 8) ? ((b & 4) ? h3 : h2) : ((b & 4) ? h1 : h0);
-                    const uint32_t hk = (hw >> ((b & 3) * 8)) & 0xFFu;
-                    if (hk) atomicSub(&fix[__ffs(hk) - 1], 1);
-                    atomicAdd(&fix[4], 1);
+                    for (int k = 0; k < 4 && dw; ++k, dw >>= 8, hw >>= 8) {
+                        if (!(dw & 0xFFu)) continue;
+                        const uint32_t hk = hw & 0xFFu;
+                        if (hk) atomicSub(&fix[__ffs(hk) - 1], 1);
+                        atomicAdd(&fix[4], 1);
+                    }
                 }
             }
             if (__builtin_expect(slow, 0)) {
                 uint32_t p = pA;
+                const uint32_t vsw[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t w = vsw[q];
 #pragma unroll 1
-                for (int b = 0; b < CHUNK; ++b) {
-                    const uint32_t c = fs_byte(v[j], b);
-                    if (c == 10u) { p = (p + 1u) & 3u; continue; }
-                    fs_one(c, p, a);
+                    for (int k = 0; k < 4; ++k, w >>= 8) {
+                        const uint32_t cc = w & 0xFFu;
+                        if (cc == 10u) { p = (p + 1u) & 3u; continue; }
+                        fs_one(cc, p, a);
+                    }
                 }
             }
         }
@@ -405,23 +415,33 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
                     }
                 }
                 if (__builtin_expect((d0 | d1 | d2 | d3) != 0, 0)) {
+                    // (word by word, the bytes of a word by shifting it: a byte picked by a run-time index makes the compiler keep the
+                    // chunk in scratch memory -- 64 bytes per lane stored for every granule, on the straight path)
+                    const uint32_t dsw[4] = {d0, d1, d2, d3}, hsw[4] = {h0, h1, h2, h3};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t dw = dsw[q], hw = hsw[q];
 #pragma unroll 1
-                    for (int b = 0; b < 16; ++b) {
-                        const uint32_t dw = (b & 8) ? ((b & 4) ? d3 : d2) : ((b & 4) ? d1 : d0);
-                        if (!((dw >> ((b & 3) * 8)) & 0xFFu)) continue;
-                        const uint32_t hw = (b & 8) ? ((b & 4) ? h3 : h2) : ((b & 4) ? h1 : h0);
-                        const uint32_t hk = (hw >> ((b & 3) * 8)) & 0xFFu;
-                        if (hk) atomicSub(&fix[__ffs(hk) - 1], 1);
-                        atomicAdd(&fix[4], 1);
+                        for (int k = 0; k < 4 && dw; ++k, dw >>= 8, hw >>= 8) {
+                            if (!(dw & 0xFFu)) continue;
+                            const uint32_t hk = hw & 0xFFu;
+                            if (hk) atomicSub(&fix[__ffs(hk) - 1], 1);
+                            atomicAdd(&fix[4], 1);
+                        }
                     }
                 }
                 if (__builtin_expect(slow, 0)) {
                     uint32_t p = pA;
+                    const uint32_t vsw[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t w = vsw[q];
 #pragma unroll 1
-                    for (int b = 0; b < CHUNK; ++b) {
-                        const uint32_t cc = fs_byte(v[j], b);
-                        if (cc == 10u) { p = (p + 1u) & 3u; continue; }
-                        fs_one(cc, p, a);
+                        for (int k = 0; k < 4; ++k, w >>= 8) {
+                            const uint32_t cc = w & 0xFFu;
+                            if (cc == 10u) { p = (p + 1u) & 3u; continue; }
+                            fs_one(cc, p, a);
+                        }
                     }
                 }
             }

@@ -829,17 +829,20 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_fetch(const uint8_t *__restrict
     int64_t i = wave * 4 + grp;
     auto get_id = [&](int64_t q) -> int64_t { return q < nq ? (ids ? ids[q] : q) : -1; };   // ids == null: the arrays are per query already
     int64_t id1 = get_id(i), id2 = get_id(i + stride);
-    int64_t r_n = 0, r_so = 0, r_qo = 0, r_d = 0;
-    auto get_row = [&](int64_t id, int64_t q) {
-        if (id >= 0 && id < n_reads) { r_n = rlen[id]; r_so = soff[id] - gbase; r_qo = qoff[id] - gbase; r_d = dst_off[q]; }
-        else r_n = -1;
+    // (the row by value: with the four fields as variables a lambda assigned through references, the compiler kept two of them
+    // in scratch memory -- a store and a load per query on the path that is all latency)
+    struct Row { int64_t n, so, qo, d; };
+    auto get_row = [=](int64_t id, int64_t q) -> Row {
+        Row r{-1, 0, 0, 0};
+        if (id >= 0 && id < n_reads) { r.n = rlen[id]; r.so = soff[id] - gbase; r.qo = qoff[id] - gbase; r.d = dst_off[q]; }
+        return r;
     };
-    get_row(id1, i);
+    Row row = get_row(id1, i);
     for (; i - grp < nq; i += stride) {                       // wave-uniform trip count
-        const int64_t n = r_n, so = r_so, qo = r_qo, d = r_d;
+        const int64_t n = row.n, so = row.so, qo = row.qo, d = row.d;
         id1 = id2;
         id2 = get_id(i + 2 * stride);
-        get_row(id1, i + stride);
+        row = get_row(id1, i + stride);
         if (n <= 0) continue;
         const bool inside = so >= 16 && qo >= 16 && so + n + 16 <= n_bytes && qo + n + 16 <= n_bytes;   // room for whole 16-byte accesses
         for (int64_t s0 = 0; s0 < n; s0 += 256) {
