@@ -227,6 +227,55 @@ __device__ __forceinline__ int fq_first_bit(const uint64_t *m, int a, int b) {
 #endif
 constexpr int FQL_G = FX_FQL_G;
 
+// The line records of a granule whose newline positions stand compacted in spos[0, M): one lane per line -- the CR bit from the
+// granule's map of '\r' bytes, the first space of the line by a word-wise bit search from the line's second byte.
+// (Round 4 tried to READ both from the stream instead -- one byte in front of every newline, the head of every header line, which
+// the one-read build can tell from its guess -- and drop the two maps from the path of every byte: 150 vector instructions less
+// per granule and 3.6 ms MORE for C3's 34.8 GB; the loads sit at the end of a granule's work with nothing to hide them behind.)
+__device__ __forceinline__ void fq_line_records(const uint8_t *__restrict__ data, int64_t sbase, int prev_byte, const uint16_t *spos, uint32_t M,
+                                                const uint64_t *spm, const uint16_t *crm, uint32_t *__restrict__ slot, int lane) {
+    for (uint32_t i = lane; i < M; i += 64) {
+        const int lp = spos[i];
+        const int ql = i ? (int)spos[i - 1] : -1;                    // previous newline of the granule
+        int cr;
+        if (lp) cr = (crm[(lp - 1) >> 4] >> ((lp - 1) & 15)) & 1;
+        else    cr = (sbase ? data[sbase - 1] : prev_byte) == '\r';
+        // a header's name ends at the first space from the line's SECOND byte on (fastq.c:112-117).  The first
+        // line of the granule may have begun earlier: every byte of it that lies here is searched, k_fastq_rows sorts it out
+        const int from = i ? ql + 2 : 0;
+        const int sp = from < lp ? fq_first_bit(spm, from, lp) : -1;
+        slot[i] = (uint32_t)lp | (cr ? FQL_CR : 0u) | (sp >= 0 ? FQL_HAS | ((uint32_t)sp << 14) : 0u);
+    }
+}
+
+// the exact map of the '\r' bytes of a row -- most files have none at all: computed only for a row in which some lane holds one
+// ((y - 0x01..) & ~y & 0x80.. is non-zero exactly when a byte of y is zero: 13 instructions instead of 27; the kernels are VALU-bound)
+__device__ __forceinline__ uint16_t fq_cr_mask(const uint4 &v) {
+    const uint32_t y0 = v.x ^ 0x0D0D0D0Du, y1 = v.y ^ 0x0D0D0D0Du, y2 = v.z ^ 0x0D0D0D0Du, y3 = v.w ^ 0x0D0D0D0Du;
+    uint32_t any_cr = (y0 - 0x01010101u) & ~y0;
+    any_cr = (uint32_t)__builtin_amdgcn_bitop3_b32(any_cr, y1 - 0x01010101u, y1, 0xF4);      // a | (b & ~c)
+    any_cr = (uint32_t)__builtin_amdgcn_bitop3_b32(any_cr, y2 - 0x01010101u, y2, 0xF4);
+    any_cr = (uint32_t)__builtin_amdgcn_bitop3_b32(any_cr, y3 - 0x01010101u, y3, 0xF4);
+    return __ballot((any_cr & 0x80808080u) != 0) ? (uint16_t)eq_mask16(v, 0x0D0D0D0Du) : (uint16_t)0;
+}
+
+// first / last newline of a granule with too many lines for its slot (the others read them from the compacted positions)
+__device__ __forceinline__ void fq_first_last(const uint32_t (&nlm)[GR_ROWS], int lane, int &first, int &last) {
+    first = GRAN; last = -1;
+#pragma unroll
+    for (int j = 0; j < GR_ROWS; ++j)
+        if (nlm[j]) {
+            const int cb = j * 1024 + lane * CHUNK;
+            if (first == GRAN) first = cb + __ffs(nlm[j]) - 1;
+            last = cb + 31 - __clz(nlm[j]);
+        }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const int f = __shfl_xor(first, d, 64), l = __shfl_xor(last, d, 64);
+        first = f < first ? f : first; last = l > last ? l : last;
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_fastq_lines(const uint8_t *__restrict__ data, int64_t n, int prev_byte, int64_t g_end,
                                                       GranPk *__restrict__ out, uint32_t *__restrict__ recs, GranList ovl) {
     __shared__ __attribute__((aligned(16))) uint16_t s_sp[BLOCK / 64][GRAN / CHUNK], s_cr[BLOCK / 64][GRAN / CHUNK];   // bit k of word c <-> byte 16 c + k
@@ -242,36 +291,35 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines(const uint8_t *__restrict
         const int64_t g = gw + kk;
         if (g >= g_end) break;
         const int64_t sbase = g * (int64_t)GRAN;
-        uint32_t nlm[GR_ROWS], c = 0;
-        int first = GRAN, last = -1;
+        uint32_t nlm[GR_ROWS], ex[GR_ROWS], M = 0;
 #pragma unroll
         for (int j = 0; j < GR_ROWS; ++j) {
             nlm[j] = eq_mask16(v[j], 0x0A0A0A0Au);
             s_sp[w][j * 64 + lane] = (uint16_t)eq_mask16(v[j], 0x20202020u);
-            // most files have no '\r' at all: the exact map only for a row in which some lane holds one ((y - 0x01..) & ~y &
-            // 0x80.. is non-zero exactly when a byte of y is zero: 13 instructions instead of 27; the kernel is VALU-bound)
-            uint32_t any_cr = 0;
-            {
-                const uint32_t y0 = v[j].x ^ 0x0D0D0D0Du, y1 = v[j].y ^ 0x0D0D0D0Du, y2 = v[j].z ^ 0x0D0D0D0Du, y3 = v[j].w ^ 0x0D0D0D0Du;
-                any_cr = (y0 - 0x01010101u) & ~y0;
-                any_cr = (uint32_t)__builtin_amdgcn_bitop3_b32(any_cr, y1 - 0x01010101u, y1, 0xF4);      // a | (b & ~c)
-                any_cr = (uint32_t)__builtin_amdgcn_bitop3_b32(any_cr, y2 - 0x01010101u, y2, 0xF4);
-                any_cr = (uint32_t)__builtin_amdgcn_bitop3_b32(any_cr, y3 - 0x01010101u, y3, 0xF4);
-            }
-            s_cr[w][j * 64 + lane] = __ballot((any_cr & 0x80808080u) != 0) ? (uint16_t)eq_mask16(v[j], 0x0D0D0D0Du) : (uint16_t)0;
-            c += __popc(nlm[j]);
-            if (nlm[j]) {
-                const int cb = j * 1024 + lane * CHUNK;
-                if (first == GRAN) first = cb + __ffs(nlm[j]) - 1;
-                last = cb + 31 - __clz(nlm[j]);
-            }
+            s_cr[w][j * 64 + lane] = fq_cr_mask(v[j]);
+            const uint32_t cj = (uint32_t)__popc(nlm[j]);
+            const uint32_t inc = wave_incl_scan(cj);
+            ex[j] = M + inc - cj;                              // newlines of the granule in front of this chunk
+            M += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
         if (kk + 1 < FQL_G && g + 1 < g_end) granule_load<true>(v, data, n, 0, g + 1);       // the next granule is on its way
-        const uint32_t M = wave_sum(c);
+        int first = GRAN, last = -1;
+        const bool over = M > (uint32_t)FQL_CAP;              // more lines than a slot holds: k_fastq_emit reads the granule again
+        if (over) {
+            fq_first_last(nlm, lane, first, last);
+            if (lane == 0) ov_g[atomicAdd(&ov_n, 1u)] = (uint32_t)g;
+        } else if (M) {
+            // ---- compact the newline positions: the first and the last of them are the granule's
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            const int f = __shfl_xor(first, d, 64), l = __shfl_xor(last, d, 64);
-            first = f < first ? f : first; last = l > last ? l : last;
+            for (int j = 0; j < GR_ROWS; ++j) {
+                uint32_t m = nlm[j], r = ex[j];
+                while (m) {
+                    const int k = __ffs(m) - 1;
+                    m &= m - 1;
+                    s_pos[w][r++] = (uint16_t)(j * 1024 + lane * CHUNK + k);
+                }
+            }
+            first = s_pos[w][0]; last = s_pos[w][M - 1];
         }
         if (lane == 0) {
             GranOut o;
@@ -279,39 +327,9 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines(const uint8_t *__restrict
             o.v1 = o.c1 = o.v2 = o.c2 = o.ovf = 0;
             out[g] = gran_pack(o);
         }
-        if (M > (uint32_t)FQL_CAP) {                          // more lines than a slot holds: k_fastq_emit reads the granule again
-            if (lane == 0) ov_g[atomicAdd(&ov_n, 1u)] = (uint32_t)g;
-            continue;
-        }
-        if (!M) continue;
-        // ---- compact the newline positions
-        uint32_t r0 = 0;
-#pragma unroll
-        for (int j = 0; j < GR_ROWS; ++j) {
-            const uint32_t cj = __popc(nlm[j]);
-            const uint32_t inc = wave_incl_scan(cj);
-            uint32_t m = nlm[j], r = r0 + inc - cj;
-            while (m) {
-                const int k = __ffs(m) - 1;
-                m &= m - 1;
-                s_pos[w][r++] = (uint16_t)(j * 1024 + lane * CHUNK + k);
-            }
-            r0 += (uint32_t)__shfl((int)inc, 63, 64);
-        }
-        const uint64_t *spm = reinterpret_cast<const uint64_t *>(&s_sp[w][0]);
-        uint32_t *slot = recs + g * (int64_t)FQL_CAP;
-        for (uint32_t i = lane; i < M; i += 64) {
-            const int lp = s_pos[w][i];
-            const int ql = i ? (int)s_pos[w][i - 1] : -1;                // previous newline of the granule
-            int cr;
-            if (lp) cr = (s_cr[w][(lp - 1) >> 4] >> ((lp - 1) & 15)) & 1;
-            else    cr = (sbase ? data[sbase - 1] : prev_byte) == '\r';
-            // a header's name ends at the first space from the line's SECOND byte on (fastq.c:112-117).  The first
-            // line of the granule may have begun earlier: every byte of it that lies here is searched, k_fastq_rows sorts it out
-            const int from = i ? ql + 2 : 0;
-            const int sp = from < lp ? fq_first_bit(spm, from, lp) : -1;
-            slot[i] = (uint32_t)lp | (cr ? FQL_CR : 0u) | (sp >= 0 ? FQL_HAS | ((uint32_t)sp << 14) : 0u);
-        }
+        if (over || !M) continue;
+        fq_line_records(data, sbase, prev_byte, s_pos[w], M, reinterpret_cast<const uint64_t *>(&s_sp[w][0]), &s_cr[w][0],
+                        recs + g * (int64_t)FQL_CAP, lane);
     }
     // ---- the overflowing granules of the workgroup: one append (the last wave to arrive does it)
     if (lane == 0) {

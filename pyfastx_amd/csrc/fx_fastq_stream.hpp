@@ -320,31 +320,16 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
         const int64_t g = gw + kk;
         if (g >= g_end) break;
         const int64_t sbase = g * (int64_t)GRAN;
-        uint32_t nlm[GR_ROWS], ex[GR_ROWS], c = 0, run_n = 0;
-        int first = GRAN, last = -1;
+        uint32_t nlm[GR_ROWS], ex[GR_ROWS], run_n = 0;
 #pragma unroll
         for (int j = 0; j < GR_ROWS; ++j) {
             nlm[j] = eq_mask16(v[j], 0x0A0A0A0Au);
             s_sp[w][j * 64 + lane] = (uint16_t)eq_mask16(v[j], 0x20202020u);
-            uint32_t any_cr = 0;
-            {
-                const uint32_t y0 = v[j].x ^ 0x0D0D0D0Du, y1 = v[j].y ^ 0x0D0D0D0Du, y2 = v[j].z ^ 0x0D0D0D0Du, y3 = v[j].w ^ 0x0D0D0D0Du;
-                any_cr = (y0 - 0x01010101u) & ~y0;
-                any_cr = (uint32_t)__builtin_amdgcn_bitop3_b32(any_cr, y1 - 0x01010101u, y1, 0xF4);
-                any_cr = (uint32_t)__builtin_amdgcn_bitop3_b32(any_cr, y2 - 0x01010101u, y2, 0xF4);
-                any_cr = (uint32_t)__builtin_amdgcn_bitop3_b32(any_cr, y3 - 0x01010101u, y3, 0xF4);
-            }
-            s_cr[w][j * 64 + lane] = __ballot((any_cr & 0x80808080u) != 0) ? (uint16_t)eq_mask16(v[j], 0x0D0D0D0Du) : (uint16_t)0;
+            s_cr[w][j * 64 + lane] = fq_cr_mask(v[j]);
             const uint32_t cj = (uint32_t)__popc(nlm[j]);
-            c += cj;
             const uint32_t inc = wave_incl_scan(cj);
             ex[j] = run_n + inc - cj;                      // newlines of the granule in front of this chunk
             run_n += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            if (nlm[j]) {
-                const int cb = j * 1024 + lane * CHUNK;
-                if (first == GRAN) first = cb + __ffs(nlm[j]) - 1;
-                last = cb + 31 - __clz(nlm[j]);
-            }
         }
         const uint32_t M = run_n;
         // ---- the guess, once per run: a '+' line of one byte ends at a newline that has another one two bytes in front of it
@@ -366,17 +351,6 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
                 guess = (uint32_t)__builtin_amdgcn_readlane((int)mine, __ffsll((long long)hv) - 1);
                 if (__ballot(clash || (mine != 0xFFu && mine != guess))) guess = 0xFFu;
             }
-        }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            const int f = __shfl_xor(first, d, 64), l = __shfl_xor(last, d, 64);
-            first = f < first ? f : first; last = l > last ? l : last;
-        }
-        if (lane == 0) {
-            GranOut o;
-            o.n = M; o.h = 0; o.first = (uint32_t)first; o.last = (uint32_t)last;
-            o.v1 = o.c1 = o.v2 = o.c2 = o.ovf = 0;
-            out[g] = gran_pack(o);
         }
         // ---- composition of this granule (only with a guess: without one the run's record says so and nothing is used)
         if (guess != 0xFFu) {
@@ -449,33 +423,33 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
         }
         lines_before += M;
         if (kk + 1 < FQL_G && g + 1 < g_end) granule_load<true>(v, data, n, 0, g + 1);       // the next granule is on its way
-        if (M > (uint32_t)FQL_CAP) {                          // more lines than a slot holds: k_fastq_emit reads the granule again
+        int first = GRAN, last = -1;
+        const bool over = M > (uint32_t)FQL_CAP;              // more lines than a slot holds: k_fastq_emit reads the granule again
+        if (over) {
+            fq_first_last(nlm, lane, first, last);
             if (lane == 0) ovl.g[atomicAdd(ovl.count, 1u)] = (uint32_t)g;
-            continue;
-        }
-        if (!M) continue;
-        // ---- compact the newline positions, one line record per newline (as k_fastq_lines)
+        } else if (M) {
+            // ---- compact the newline positions: the first and the last of them are the granule's
 #pragma unroll
-        for (int j = 0; j < GR_ROWS; ++j) {
-            uint32_t m = nlm[j], r = ex[j];
-            while (m) {
-                const int k = __ffs(m) - 1;
-                m &= m - 1;
-                s_pos[w][r++] = (uint16_t)(j * 1024 + lane * CHUNK + k);
+            for (int j = 0; j < GR_ROWS; ++j) {
+                uint32_t m = nlm[j], r = ex[j];
+                while (m) {
+                    const int k = __ffs(m) - 1;
+                    m &= m - 1;
+                    s_pos[w][r++] = (uint16_t)(j * 1024 + lane * CHUNK + k);
+                }
             }
+            first = s_pos[w][0]; last = s_pos[w][M - 1];
         }
-        const uint64_t *spm = reinterpret_cast<const uint64_t *>(&s_sp[w][0]);
-        uint32_t *slot = recs + g * (int64_t)FQL_CAP;
-        for (uint32_t i = lane; i < M; i += 64) {
-            const int lp = s_pos[w][i];
-            const int ql = i ? (int)s_pos[w][i - 1] : -1;
-            int cr;
-            if (lp) cr = (s_cr[w][(lp - 1) >> 4] >> ((lp - 1) & 15)) & 1;
-            else    cr = (sbase ? data[sbase - 1] : prev_byte) == '\r';
-            const int from = i ? ql + 2 : 0;
-            const int sp = from < lp ? fq_first_bit(spm, from, lp) : -1;
-            slot[i] = (uint32_t)lp | (cr ? FQL_CR : 0u) | (sp >= 0 ? FQL_HAS | ((uint32_t)sp << 14) : 0u);
+        if (lane == 0) {
+            GranOut o;
+            o.n = M; o.h = 0; o.first = (uint32_t)first; o.last = (uint32_t)last;
+            o.v1 = o.c1 = o.v2 = o.c2 = o.ovf = 0;
+            out[g] = gran_pack(o);
         }
+        if (over || !M) continue;
+        fq_line_records(data, sbase, prev_byte, s_pos[w], M, reinterpret_cast<const uint64_t *>(&s_sp[w][0]), &s_cr[w][0],
+                        recs + g * (int64_t)FQL_CAP, lane);
     }
     // ---- the run's record
     {

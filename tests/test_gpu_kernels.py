@@ -826,3 +826,27 @@ def test_len_stats(L, n):
                 if hit.size:
                     want = (int(desc[hit[0]]), int(hit[0]) + 1)
                 assert (st.nx_len, st.nx_count) == want, (n, shape, p)
+
+
+def test_fastq_one_read_build_on_a_file_that_misleads_its_guess(oracle, L):
+    """fx_fastq_build_comp guesses the line-of-four of every run of granules from its 1-byte lines (the '+' lines of a usual
+    file) and k_fastq_comp_reduce checks the guess against the newline prefixes.  Here the only 1-byte lines are SEQUENCE
+    lines (the '+' lines repeat the name, the quality lines hold two bytes -- the reference checks none of that,
+    fastq.c:89-171): every guess is wrong by one.  The composition must then come from the read table; the rows never
+    depended on the guess.  Rows, base and meta equal the oracle's."""
+    out = []
+    for i in range(30_000):
+        out += [b"@read%d some text here %d\n" % (i, i * 7), b"ACGTN"[i % 5:i % 5 + 1] + b"\n", b"+read%d\n" % i, b"I%c\n" % (40 + i % 50)]
+    raw = b"".join(out)
+    recs, size, ln = oracle.fastq_index(raw)
+    c = oracle.fastq_composition(raw)
+    b = L.Blob.from_bytes(raw)
+    for comp in (True, False):
+        s = b.fastq_build(comp=comp)
+        assert (s.n_reads, s.size, s.n_lines) == (len(recs), size, ln) == (30_000, 30_000, 120_000)
+        t = b.fastq_table(s.n_reads)
+        for col in ("name_off", "name_len", "dlen", "rlen", "soff", "qoff"):
+            np.testing.assert_array_equal(t[col], recs[col].astype(t[col].dtype), err_msg="%s comp=%s" % (col, comp))
+        base, meta = b.fastq_comp()
+        assert base.tolist() == [c["a"], c["c"], c["g"], c["t"], c["n"]]
+        assert meta.tolist() == [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"], c["phred"]]
