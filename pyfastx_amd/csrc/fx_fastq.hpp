@@ -287,6 +287,8 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines(const uint8_t *__restrict
     const int64_t gw = ((int64_t)blockIdx.x * (BLOCK / 64) + w) * FQL_G;
     uint4 v[GR_ROWS];
     if (gw < g_end) granule_load<true>(v, data, n, 0, gw);
+    uint32_t *const rslot = recs + (gw / FQL_G) * (int64_t)(FQL_G * FQL_CAP);      // the records of the run's granules, one after the other
+    uint32_t written = 0;
     for (int kk = 0; kk < FQL_G; ++kk) {
         const int64_t g = gw + kk;
         if (g >= g_end) break;
@@ -329,7 +331,8 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines(const uint8_t *__restrict
         }
         if (over || !M) continue;
         fq_line_records(data, sbase, prev_byte, s_pos[w], M, reinterpret_cast<const uint64_t *>(&s_sp[w][0]), &s_cr[w][0],
-                        recs + g * (int64_t)FQL_CAP, lane);
+                        rslot + written, lane);
+        written += M;
     }
     // ---- the overflowing granules of the workgroup: one append (the last wave to arrive does it)
     if (lane == 0) {
@@ -352,6 +355,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines(const uint8_t *__restrict
 #endif
 constexpr int FQR_G = FX_FQR_G;
 static_assert(FQR_G <= 8, "a staged line record has three bits for the granule of the wave it came from");
+static_assert(FQR_G == FQL_G, "k_fastq_rows reads the records of a run of granules from the slot the count pass filled for that run");
 
 // The fields the line record r of line idx determines (line i of its granule, which begins at global offset gs; q =
 // global offset of the newline before it), into row idx >> 2 of the table when the shard owns it.
@@ -399,23 +403,29 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_rows(ScanCtx x, FqOwn own, FqTa
     const int lane = lane_id();
     const int64_t g0 = ((int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * FQR_G;
     if (g0 >= g_end) return;                                               // waves are independent: no workgroup barrier below
-    uint32_t M[FQR_G], rr[FQR_G];
+    uint32_t M[FQR_G];
     int64_t I0[FQR_G], q0[FQR_G];
     bool whole = true;                                                     // no granule of the wave left to k_fastq_emit
-    // the first 64 records of every slot are asked for together with the summaries that say how many of them count:
-    // one round trip instead of two (a slot always has FQL_CAP entries; what lies past the granule's count is ignored)
-#pragma unroll
-    for (int k = 0; k < FQR_G; ++k) rr[k] = g0 + k < g_end ? recs[(g0 + k) * (int64_t)FQL_CAP + lane] : 0u;
+    // The line records of the wave's granules stand one after the other in the slot of their RUN (the count pass, whose waves take
+    // the same runs of FQL_G granules, appends them there): for reads of 150 bases that is ~47 records -- ONE 256-byte request
+    // (a slot per granule, round 3: four requests of 256 bytes at a stride of 512, a dozen records in each).  They are asked for
+    // together with the summaries that say how many there are: one round trip instead of two.
+    const uint32_t *rslot = recs + (g0 / FQR_G) * (int64_t)(FQR_G * FQL_CAP);
+    const uint32_t rr = rslot[lane];
 #pragma unroll
     for (int k = 0; k < FQR_G; ++k) {
         M[k] = 0; I0[k] = 0; q0[k] = -1;
         if (g0 + k < g_end) { M[k] = x.go[g0 + k].nh & 0xFFFFu; I0[k] = x.nl_prefix[g0 + k]; q0[k] = x.prevnl[g0 + k]; }
-        if (M[k] > (uint32_t)FQL_CAP) { M[k] = 0; whole = false; }        // overflowed: k_fastq_emit reads that granule again
+        if (M[k] > (uint32_t)FQL_CAP) { M[k] = 0; whole = false; }        // overflowed (no records of it in the slot): k_fastq_emit reads that granule again
     }
+    uint32_t cum[FQR_G + 1];
+    cum[0] = 0;
+#pragma unroll
+    for (int k = 0; k < FQR_G; ++k) cum[k + 1] = cum[k] + M[k];
     if (!whole) {                                                          // one lane per line, granule by granule
-#pragma unroll 1
+#pragma unroll
         for (int k = 0; k < FQR_G; ++k) {
-            const uint32_t *slot = recs + (g0 + k) * (int64_t)FQL_CAP;
+            const uint32_t *slot = rslot + cum[k];
             const int64_t gs = x.gbase + (g0 + k) * (int64_t)GRAN;
             const int64_t qq = q0[k] < 0 ? own.prev_nl : q0[k];
             for (uint32_t i = lane; i < M[k]; i += 64)
@@ -424,14 +434,12 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_rows(ScanCtx x, FqOwn own, FqTa
         return;
     }
     uint32_t *sr = s_rec[threadIdx.x >> 6];
-    uint32_t cum[FQR_G + 1];
-    cum[0] = 0;
+    for (uint32_t i = lane; i < cum[FQR_G]; i += 64) {                      // (bits 26-28 of a staged record: which of the wave's granules)
+        const uint32_t r = i < 64u ? rr : rslot[i];
+        uint32_t k = 0;
 #pragma unroll
-    for (int k = 0; k < FQR_G; ++k) {
-        cum[k + 1] = cum[k] + M[k];
-        const uint32_t *slot = recs + (g0 + k) * (int64_t)FQL_CAP;
-        if ((uint32_t)lane < M[k]) sr[cum[k] + lane] = rr[k] | ((uint32_t)k << 26);
-        if (64u + lane < M[k]) sr[cum[k] + 64u + lane] = slot[64u + lane] | ((uint32_t)k << 26);      // lines of less than 64 bytes on average
+        for (int kk = 1; kk < FQR_G; ++kk) k += i >= cum[kk] ? 1u : 0u;
+        sr[i] = r | (k << 26);
     }
     const uint32_t Mtot = cum[FQR_G];
     if (!Mtot) return;

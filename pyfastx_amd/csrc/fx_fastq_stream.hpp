@@ -313,6 +313,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
     for (int c = 0; c < 5; ++c) a.extra[c] = 0;
     int cmin = 104, cmax = 33;
     uint32_t qf = 33u * 0x01010101u, qk1 = (0x7Fu - 33u) * 0x01010101u, qk2 = (0x80u - 104u) * 0x01010101u;
+    uint32_t written = 0;                                  // line records of the run so far (they stand one after the other in the run's slot)
     uint32_t guess = 0xFFu, lines_before = 0;              // number-of-four of the run's first line (0xFF: not known), newlines of the run so far
     uint4 v[GR_ROWS];
     if (gw < g_end) granule_load<true>(v, data, n, 0, gw);
@@ -449,7 +450,8 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
         }
         if (over || !M) continue;
         fq_line_records(data, sbase, prev_byte, s_pos[w], M, reinterpret_cast<const uint64_t *>(&s_sp[w][0]), &s_cr[w][0],
-                        recs + g * (int64_t)FQL_CAP, lane);
+                        recs + run * (int64_t)(FQL_G * FQL_CAP) + written, lane);
+        written += M;
     }
     // ---- the run's record
     {

@@ -1852,7 +1852,7 @@ static int granule_pass(fx_handle *h, bool fq_lines = false, bool with_comp = fa
     GranList hgl{h->hdr_grans.p, ctl_counter(h, 0)};
     const int SCAN_WG = 512;                                  // 8 waves = 8 granules per workgroup (tools/scanbench2.hip)
     if (nfull > 0 && MODE == 1 && fq_lines) {                 // FASTQ, one-read build: the count pass also writes the line records
-        if ((rc = h->fq_lines.alloc(nfull * FQL_CAP))) return rc;
+        if ((rc = h->fq_lines.alloc((nfull + FQL_G - 1) / FQL_G * FQL_G * FQL_CAP))) return rc;      // a slot of FQL_G * FQL_CAP records per run of FQL_G granules
         if (with_comp) {                                      // index and composition in one read of the stream (fx_fastq_stream.hpp)
             const int64_t nruns = (nfull + FQL_G - 1) / FQL_G;
             if ((rc = h->fq_runs.alloc(nruns)) || (rc = h->fq_acc_build.alloc(1))) return rc;

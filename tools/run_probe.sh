@@ -1,3 +1,3 @@
-export FX_BGZF_GROUP=0
-python tools/bgzf_decode_probe.py 3.0 pyfastx_amd/csrc/libfxgpu.so 2>&1 | tail -1
-FX_BGZF_REPLAY=1 python tools/bgzf_decode_probe.py 3.0 pyfastx_amd/csrc/libfxgpu.so 2>&1 | tail -1
+python -m pytest tests/test_gpu_kernels.py tests/test_gpu_vs_reference.py tests/test_gpu_api.py tests/test_gpu_windows.py tests/test_gpu_shards.py -x -q -k "fastq or Fastq" 2>&1 | tail -3
+python tools/fq_one_probe.py 1e8 | tail -1
+python tools/fastq_scale.py 1e8 2>&1 | tail -1 | cut -c1-330
