@@ -100,14 +100,14 @@ template <class T> struct DevBuf {      // grow-only device array: rebuilds reus
 
 // Scratch of an open (the compressed bytes of a BGZF file, its match map, ...): hundreds of MB that live for tens of
 // milliseconds.  hipFree waits for the device and unmaps -- 20 ms for 1.4 GB -- and the hipMalloc of the next open maps
-// again, so released blocks are kept (per device, up to FX_SCRATCH_CACHE_MB, default 4096; 0 = off) and handed to the
+// again, so released blocks are kept (per device, up to FX_SCRATCH_CACHE_MB, default 8192; 0 = off) and handed to the
 // next request they fit (at most twice its size).
 struct ScratchPool {
     struct Block { void *p; size_t cap; int dev; };
     std::mutex mu;
     std::vector<Block> idle;
     size_t held = 0;
-    const size_t limit = [] { const char *e = getenv("FX_SCRATCH_CACHE_MB"); return (size_t)(e ? std::max(0, atoi(e)) : 4096) << 20; }();
+    const size_t limit = [] { const char *e = getenv("FX_SCRATCH_CACHE_MB"); return (size_t)(e ? std::max(0, atoi(e)) : 8192) << 20; }();
     void *get(int dev, size_t bytes, size_t *cap) {
         {
             std::lock_guard<std::mutex> g(mu);
@@ -248,6 +248,7 @@ struct fx_handle {
     // resident stream
     uint8_t *d_data = nullptr;
     uint8_t *d_alloc = nullptr;               // what is freed when owns (d_data points into it for a BGZF byte range)
+    size_t blob_cap = 0;                      // != 0: the blob is a block of the scratch pool of that capacity (alloc_blob) and goes back there
     bool owns = false;
     int64_t n = 0;
     bool gz = false;
@@ -350,16 +351,30 @@ static int new_handle(int device, fx_handle **out) {
     return FX_OK;
 }
 
+// The blob of an open comes out of the scratch pool too and goes back there when the handle is closed (round 4): the driver
+// clears device memory it hands out or takes back -- 3.3 GB: 20 ms on a copy engine, in the way of the next open's staging
+// (FX_TRACE_BGZF=1 showed the first 64 MiB of C4 arriving after 6 ms or after 22, depending on what had just been freed) --,
+// and a server that opens and closes files keeps asking for the same sizes.  fx_release_scratch gives everything idle back.
 static int alloc_blob(fx_handle *h, int64_t n) {
     // pad to a whole tile so vector loads of the last chunk stay inside the allocation
     const int64_t padded = ((n + TILE - 1) / TILE) * TILE + TILE;
-    const auto t0 = std::chrono::steady_clock::now();
-    HIPCHK(dev_malloc((void **)&h->d_data, (size_t)padded));
-    if (getenv("FX_TRACE_ALLOC")) fprintf(stderr, "[fxgpu] blob: hipMalloc(%lld) %.2f ms\n", (long long)padded, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    size_t cap = 0;
+    h->d_data = (uint8_t *)g_scratch.get(h->device, (size_t)padded, &cap);
+    if (!h->d_data) return fail(FX_ENOMEM, "hipMalloc(%lld B) failed", (long long)padded);
+    h->blob_cap = cap;
     h->owns = true;
     h->n = n;
     if (padded > n) HIPCHK(hipMemsetAsync(h->d_data + n, 0, (size_t)(padded - n), h->stream));
     return FX_OK;
+}
+// the blob the handle owns, back to where it came from (the caller has waited for whatever used it)
+static void free_blob(fx_handle *h) {
+    uint8_t *p = h->d_alloc ? h->d_alloc : h->d_data;
+    if (h->owns && p) {
+        if (h->blob_cap) g_scratch.put(h->device, p, h->blob_cap);
+        else (void)hipFree(p);
+    }
+    h->d_data = nullptr; h->d_alloc = nullptr; h->blob_cap = 0; h->owns = false; h->n = 0;
 }
 
 extern "C" int fx_close(fx_handle *h) {
@@ -374,7 +389,7 @@ extern "C" int fx_close(fx_handle *h) {
         (void)hipHostFree(h->mb);
     }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->owns && (h->d_alloc || h->d_data)) (void)hipFree(h->d_alloc ? h->d_alloc : h->d_data);
+    free_blob(h);
     if (h->pin_tot) (void)hipHostFree(h->pin_tot);
     if (h->one_box) (void)hipHostFree(h->one_box);
     if (h->one_out) (void)hipHostFree(h->one_out);
@@ -1031,7 +1046,7 @@ static int bgzf_open_pipelined(fx_handle *h, int fd, int64_t fsize, const char *
     h->gz_moff.clear(); h->gz_coff.clear(); h->gz_uoff.clear();
     auto give_up = [&](int code) {                             // 1: the one-shot path decides; < 0: an error
         (void)stg.finish();
-        if (h->owns && h->d_data) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->d_data); h->d_data = nullptr; h->owns = false; h->n = 0; }
+        if (h->owns && h->d_data) { (void)hipStreamSynchronize(h->stream); free_blob(h); }
         h->gz_moff.clear(); h->gz_coff.clear(); h->gz_uoff.clear();
         return code;
     };
@@ -1402,8 +1417,8 @@ static int gzip_indexed_to_blob(fx_handle *h, const uint8_t *in, int64_t nin, in
         }
     }
     if (err.load() == 1) {                                     // the index does not describe this file: inflate it serially instead
-        (void)hipFree(h->d_data);
-        h->d_data = nullptr; h->owns = false; h->n = 0;
+        (void)hipStreamSynchronize(h->stream);
+        free_blob(h);
         return 1;
     }
     return FX_OK;
@@ -1472,7 +1487,7 @@ static int open_file_impl(const char *path, int device, fx_handle **out, int64_t
             if (brc == FX_OK) { close(fd); *out = h; return FX_OK; }
             if (brc < 0) return bail(brc);
             if (h->d_data || h->d_alloc) {                            // (a blob the attempt allocated: none on the ways it gives up)
-                (void)hipFree(h->d_alloc ? h->d_alloc : h->d_data); h->d_data = nullptr; h->d_alloc = nullptr; h->n = 0;
+                (void)hipStreamSynchronize(h->stream); free_blob(h);
             }
             void *mp = mmap(nullptr, (size_t)fsize, PROT_READ, MAP_PRIVATE, fd, 0);
             BgzfTable tab;
@@ -1579,7 +1594,7 @@ static int open_file_impl(const char *path, int device, fx_handle **out, int64_t
                 *out = h;
                 return FX_OK;
             }
-            if (h->d_data && h->owns) { (void)hipFree(h->d_data); h->d_data = nullptr; h->owns = false; h->n = 0; }   // (it had got as far as the blob)
+            if (h->d_data && h->owns) { (void)hipStreamSynchronize(h->stream); free_blob(h); }   // (it had got as far as the blob)
         }
         // ... else (or with points that do not fit): serial (zlib on the host), the inflated bytes stream through a
         // pinned ring into a growing blob and the restart points are captured on the way.
