@@ -1210,6 +1210,11 @@ class Fastq(_fxobj.FastqCore):
         """fq[i] / fq[name] from C once the index is a file on disk (csrc/fxobj.c: FastqCore)."""
         ok = self._db is not None and self._index_file != ":memory:" and os.path.isfile(self._index_file) and not os.environ.get("FX_NO_C_SUBSCRIPT")
         self._core_open(self._index_file if ok else None)
+        t = getattr(self, "_host_tab", None)
+        if ok and t is not None and len(t["soff"]) == self._counts:
+            self._core_table(t["name_off"], t["name_len"], t["dlen"], t["rlen"], t["soff"], t["qoff"])
+        else:
+            self._core_table()
 
     def build_index(self):
         if self._db is None:
@@ -1262,6 +1267,9 @@ class Fastq(_fxobj.FastqCore):
         except _lib.FxError as e:
             raise _fx_to_py(e)
         t = blob.fastq_table(s.n_reads)
+        # the table the index file is written from stays with the object (up to FX_FQ_HOST_TABLE rows, 16 M = 640 MB; 0: never):
+        # fq[i] then is six array elements in C instead of a statement on the index file (csrc/fxobj.c: _core_table)
+        self._host_tab = t if 0 < s.n_reads <= int(os.environ.get("FX_FQ_HOST_TABLE", 16_000_000)) else None
         self._db = None
         if s.n_reads:
             self._db = _bulk_index(self._index_file, blob, 1, s.n_reads, t["name_off"], t["name_len"],
@@ -1555,6 +1563,10 @@ class Read(_fxobj.ReadCore):
         return self._fq._st.raw(off, n)
 
     # .seq, .qual and len() are the C base type's: the strings that came with the iterator's batch, else these
+    def _name_slow(self):
+        """the name of a read that came out of the host table (fq[i]) when the file is not a plain one: its bytes from the stream"""
+        return self._bytes(self._name_off, self._name_len).decode("utf-8", "surrogateescape")
+
     def _seq_slow(self):
         return _decode(self._bytes(self._soff, self._read_len))                                # read.c:152-167
 

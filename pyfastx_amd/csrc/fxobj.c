@@ -620,6 +620,10 @@ typedef struct {
     int fd;                                      /* the plain file (-1: none) */
     int phred;                                   /* Fastq(phred=) or meta.phred; 0: 33 (read.c:268) */
     long long counts;
+    /* the read table this process built (fx_fastq_table: the arrays the index file was written from), kept by _core_table():
+     * fq[i] then needs no statement at all -- the row is six array elements, the name is read from the file when asked for */
+    Py_buffer tab[6];                            /* name_off i64, name_len i32, dlen i32, rlen i64, soff i64, qoff i64 */
+    long long tab_n;                             /* rows of the table (0: none) */
 } FastqCore;
 static PyTypeObject FastqCoreType;
 static PyTypeObject *g_read_type = NULL;         /* api.Read (subclass of ReadCore) */
@@ -631,6 +635,8 @@ typedef struct {
     PyObject_HEAD
     PyObject *fq, *name, *pre_seq, *pre_qual;
     long long id, desc_len, read_len, soff, qoff;
+    long long name_off;                          /* lazy_name: where the name stands in the file ... */
+    int name_len, lazy_name;                     /* ... and its bytes; name == NULL until somebody asks */
 } ReadCore;
 
 /* A Read refers to its Fastq, its name and two strings: none of them can lead back to it, so it has no business in the cyclic
@@ -660,7 +666,8 @@ static int read_init(ReadCore *r, PyObject *args, PyObject *kw)
 }
 static PyMemberDef read_members[] = {
     {"_fq", T_OBJECT_EX, offsetof(ReadCore, fq), READONLY, "the Fastq object"},
-    {"name", T_OBJECT_EX, offsetof(ReadCore, name), 0, "read name"},
+    {"_name_off", T_LONGLONG, offsetof(ReadCore, name_off), READONLY, NULL},
+    {"_name_len", T_INT, offsetof(ReadCore, name_len), READONLY, NULL},
     {"id", T_LONGLONG, offsetof(ReadCore, id), 0, "1-based id"},
     {"_desc_len", T_LONGLONG, offsetof(ReadCore, desc_len), READONLY, NULL},
     {"_read_len", T_LONGLONG, offsetof(ReadCore, read_len), READONLY, NULL},
@@ -715,7 +722,32 @@ static PyObject *read_get_quali(ReadCore *r, void *c)
     }
     return PyObject_CallMethod((PyObject *)r, "_quali_slow", NULL);
 }
+/* .name: the str the row came with; for a read made from the host table (fq[i]) the bytes name_off .. + name_len of the file,
+ * read when first asked for (fastq.c:112-117 cut them out of the header line; the index file stores them verbatim) */
+static PyObject *read_get_name(ReadCore *r, void *c)
+{
+    (void)c;
+    if (!r->name && r->lazy_name) {
+        uint8_t buf[FX_GETTER_CAP];
+        FastqCore *fq = r->fq && PyObject_TypeCheck(r->fq, &FastqCoreType) ? (FastqCore *)r->fq : NULL;
+        if (fq && fq->fd >= 0 && r->name_len >= 0 && r->name_len <= FX_GETTER_CAP &&
+            host_read(fq->fd, buf, (Py_ssize_t)r->name_len, r->name_off) == (Py_ssize_t)r->name_len)
+            r->name = PyUnicode_DecodeUTF8((const char *)buf, (Py_ssize_t)r->name_len, "surrogateescape");
+        else r->name = PyObject_CallMethod((PyObject *)r, "_name_slow", NULL);        /* gzip input: through the resident stream */
+        if (!r->name) return NULL;
+    }
+    if (!r->name) { PyErr_SetString(PyExc_AttributeError, "name"); return NULL; }
+    return Py_NewRef(r->name);
+}
+static int read_set_name(ReadCore *r, PyObject *v, void *c)
+{
+    (void)c;
+    if (!v) { PyErr_SetString(PyExc_AttributeError, "name cannot be deleted"); return -1; }
+    Py_XSETREF(r->name, Py_NewRef(v));
+    return 0;
+}
 static PyGetSetDef read_getset[] = {
+    {"name", (getter)read_get_name, (setter)read_set_name, "read name", NULL},
     {"seq", (getter)read_get_seq, NULL, "read.c:152-167", NULL},
     {"qual", (getter)read_get_qual, NULL, "read.c:237-249", NULL},
     {"quali", (getter)read_get_quali, NULL, "read.c:251-278", NULL},
@@ -742,8 +774,15 @@ static void fqc_close_db(FastqCore *f)
     if (f->by_name) { SQ.finalize(f->by_name); f->by_name = NULL; }
     if (f->db) { SQ.close_v2(f->db); f->db = NULL; }
 }
+static void fqc_drop_table(FastqCore *f)
+{
+    int k;
+    f->tab_n = 0;
+    for (k = 0; k < 6; ++k) if (f->tab[k].obj) PyBuffer_Release(&f->tab[k]);
+}
 static void fqc_dealloc(FastqCore *f)
 {
+    fqc_drop_table(f);
     fqc_close_db(f);
     if (f->fd >= 0) close(f->fd);
     Py_TYPE(f)->tp_free((PyObject *)f);
@@ -786,6 +825,26 @@ static PyObject *fqc_stage(FastqCore *f, PyObject *args)
     }
     Py_RETURN_NONE;
 }
+/* _core_table(name_off, name_len, dlen, rlen, soff, qoff) keeps the six columns (any objects with the buffer protocol; the
+ * item sizes are checked, the row count is the shortest of them); _core_table() forgets them */
+static PyObject *fqc_table(FastqCore *f, PyObject *args)
+{
+    static const Py_ssize_t width[6] = {8, 4, 4, 8, 8, 8};
+    PyObject *o[6] = {NULL, NULL, NULL, NULL, NULL, NULL};
+    long long n = -1;
+    int k;
+    if (!PyArg_ParseTuple(args, "|OOOOOO", &o[0], &o[1], &o[2], &o[3], &o[4], &o[5])) return NULL;
+    fqc_drop_table(f);
+    if (!o[0]) Py_RETURN_NONE;
+    if (!o[5]) { PyErr_SetString(PyExc_TypeError, "_core_table(name_off, name_len, dlen, rlen, soff, qoff) or _core_table()"); return NULL; }
+    for (k = 0; k < 6; ++k) {
+        if (PyObject_GetBuffer(o[k], &f->tab[k], PyBUF_SIMPLE) != 0) { f->tab[k].obj = NULL; fqc_drop_table(f); return NULL; }
+        if (f->tab[k].len % width[k]) { fqc_drop_table(f); PyErr_SetString(PyExc_ValueError, "_core_table: int64, int32, int32, int64, int64, int64 columns"); return NULL; }
+        if (n < 0 || f->tab[k].len / width[k] < n) n = f->tab[k].len / width[k];
+    }
+    f->tab_n = n;
+    Py_RETURN_NONE;
+}
 /* the row the statement stands on -> a Read (name: the key itself when the caller asked by name) */
 static PyObject *fqc_read_of_row(FastqCore *f, sqlite3_stmt *st, PyObject *name)
 {
@@ -814,6 +873,18 @@ static PyObject *fqc_subscript(FastqCore *f, PyObject *key)
             int rc;
             if (i < 0) i += f->counts;
             if (i >= f->counts) { PyErr_SetString(PyExc_IndexError, "index out of range"); return NULL; }
+            if (i >= 0 && i < f->tab_n) {                                          /* the row from the table this process built */
+                ReadCore *rd = (ReadCore *)g_read_type->tp_alloc(g_read_type, 0);
+                if (!rd) return NULL;
+                read_untrack(rd);
+                rd->fq = Py_NewRef((PyObject *)f);
+                rd->id = i + 1;
+                rd->lazy_name = 1;
+                rd->name_off = ((const int64_t *)f->tab[0].buf)[i]; rd->name_len = ((const int32_t *)f->tab[1].buf)[i];
+                rd->desc_len = ((const int32_t *)f->tab[2].buf)[i]; rd->read_len = ((const int64_t *)f->tab[3].buf)[i];
+                rd->soff = ((const int64_t *)f->tab[4].buf)[i]; rd->qoff = ((const int64_t *)f->tab[5].buf)[i];
+                return (PyObject *)rd;
+            }
             SQ.bind_int64(f->by_id, 1, i + 1);
             rc = SQ.step(f->by_id);
             if (rc == 100) r = fqc_read_of_row(f, f->by_id, NULL);
@@ -840,12 +911,14 @@ static PyObject *fqc_subscript(FastqCore *f, PyObject *key)
 static PyMethodDef fqc_methods[] = {
     {"_core_open", (PyCFunction)fqc_open, METH_O, "_core_open(index file | None) -> bool"},
     {"_core_stage", (PyCFunction)fqc_stage, METH_VARARGS, "_core_stage(handle, plain path | None)"},
+    {"_core_table", (PyCFunction)fqc_table, METH_VARARGS, "_core_table(name_off, name_len, dlen, rlen, soff, qoff) | _core_table()"},
     {NULL, NULL, 0, NULL}};
 static PyMemberDef fqc_members[] = {
     {"_counts", T_LONGLONG, offsetof(FastqCore, counts), 0, "reads in the index"},
     {"_phred", T_INT, offsetof(FastqCore, phred), 0, "quality offset (0: 33)"},
     {"_core_handle", T_ULONGLONG, offsetof(FastqCore, handle), READONLY, NULL},
     {"_core_fd", T_INT, offsetof(FastqCore, fd), READONLY, NULL},
+    {"_core_table_rows", T_LONGLONG, offsetof(FastqCore, tab_n), READONLY, "rows of the host table fq[i] is served from (0: the index file)"},
     {NULL, 0, 0, 0, NULL}};
 static PyMappingMethods fqc_mapping = {NULL, (binaryfunc)fqc_subscript, NULL};      /* (__len__ stays with the Python class) */
 static PyTypeObject FastqCoreType = {

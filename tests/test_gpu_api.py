@@ -193,6 +193,14 @@ def test_fastq_and_reads(fx, files, fn):
         assert (rd.antisense, rd.complement, rd.reverse) == (r["antisense"], r["complement"], r["reverse"])
         assert rd.raw == r["raw"] and rd.description == r["desc"] and len(rd) == len(r["seq"])
         assert fq[rd.name].id == rd.id and rd.name in fq
+    # the object that BUILT the index answers fq[i] from the table it wrote the index from (csrc/fxobj.c: _core_table); one that
+    # loads the index file answers from the file's statements -- the same reads either way
+    fq2 = fx.Fastq(files[fn])
+    assert fq._core_table_rows == len(fq) and fq2._core_table_rows == 0
+    for r in g["reads"][:40]:
+        a, b = fq[r["i"]], fq2[r["i"]]
+        assert (a.id, a.name, a.seq, a.qual, a.raw, a.description, repr(a)) == (b.id, b.name, b.seq, b.qual, b.raw, b.description, repr(b))
+    assert fq[-1].name == fq2[-1].name == fq2[len(fq) - 1].name
     out = fq.fetch_many([r["i"] for r in g["reads"][:50]])
     for j, r in enumerate(g["reads"][:50]):
         a, b = out["offsets"][j], out["offsets"][j + 1]

@@ -1308,6 +1308,31 @@ def test_fastq_subscript_and_read_getters_in_c(tmp_path, crlf):
         assert r.seq == s and r.qual == q and r.quali == [ord(c) - 33 for c in q]
     fq._phred = 64
     assert fq[1].quali == [ord(c) - 64 for c in recs[1][2]]
+    # the table this process built, kept on the host (_core_table): fq[i] is six array elements, the name is read from the
+    # file when somebody asks -- same objects as the statements give
+    import sqlite3
+    rows = sqlite3.connect(path + ".fxi").execute("SELECT name, dlen, rlen, soff, qoff FROM read ORDER BY ID").fetchall()
+    raw = open(path, "rb").read()
+    name_off = np.array([raw.index(b"@" + r[0].encode() + b" ") + 1 for r in rows], dtype=np.int64)
+    cols = (name_off, np.array([len(r[0]) for r in rows], dtype=np.int32), np.array([r[1] for r in rows], dtype=np.int32),
+            np.array([r[2] for r in rows], dtype=np.int64), np.array([r[3] for r in rows], dtype=np.int64), np.array([r[4] for r in rows], dtype=np.int64))
+    with pytest.raises(ValueError):
+        fq._core_table(cols[0], cols[1].astype(np.int16)[:5], *cols[2:])   # a column of another width
+    assert fq._core_table_rows == 0
+    fq._phred = 0
+    fq._core_table(*cols)
+    assert fq._core_table_rows == len(recs)
+    for i, (n, s, q) in enumerate(recs):
+        r = fq[i - len(recs)] if i % 2 else fq[i]
+        assert type(r).__name__ == "Read" and (r.id, len(r), r._desc_len, r._soff, r._qoff) == (i + 1, len(s), rows[i][1], rows[i][3], rows[i][4])
+        assert r.seq == s and r.qual == q and r.quali == [ord(c) - 33 for c in q]
+        assert r.name == n and r.name is r.name and repr(r) == "<Read> %s with length of %d" % (n, len(s))
+        r.name = "other"
+        assert r.name == "other" and fq[n].id == i + 1                 # by name: still the statement
+    with pytest.raises(IndexError, match="index out of range"):
+        fq[len(recs)]
+    fq._core_table()
+    assert fq._core_table_rows == 0 and fq[1].name == recs[1][0]
     fq._core_stage(0)                                            # Blob.close(): back to the Python methods
     with pytest.raises(AttributeError):
         fq[0].seq
