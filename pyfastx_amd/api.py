@@ -1215,6 +1215,8 @@ class Fastq(_fxobj.FastqCore):
             self._core_table(t["name_off"], t["name_len"], t["dlen"], t["rlen"], t["soff"], t["qoff"])
         else:
             self._core_table()
+        # an object that loaded its index file reads the table from it once fq[i] has been asked for often enough (csrc/fxobj.c)
+        self._core_table_cap = int(os.environ.get("FX_FQ_HOST_TABLE", 16_000_000)) if ok else 0
 
     def build_index(self):
         if self._db is None:

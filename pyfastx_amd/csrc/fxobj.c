@@ -624,6 +624,14 @@ typedef struct {
      * fq[i] then needs no statement at all -- the row is six array elements, the name is read from the file when asked for */
     Py_buffer tab[6];                            /* name_off i64, name_len i32, dlen i32, rlen i64, soff i64, qoff i64 */
     long long tab_n;                             /* rows of the table (0: none) */
+    const int64_t *c_name_off, *c_rlen, *c_soff, *c_qoff;     /* the columns, wherever they live (c_name_off == NULL: names by statement) */
+    const int32_t *c_name_len, *c_dlen;
+    /* an object that LOADED its index file: once fq[i] has been asked for often enough to pay for it (hits * 22 > reads: a
+     * statement costs ~4 us more than an array element, stepping through the table ~0.1 us per row), the four integer columns
+     * are read from the file in one pass into arrays of its own; tab_cap = 0: never (set from FX_FQ_HOST_TABLE by the subclass) */
+    void *own[4];
+    long long tab_cap, int_hits;
+    int tab_tried;
 } FastqCore;
 static PyTypeObject FastqCoreType;
 static PyTypeObject *g_read_type = NULL;         /* api.Read (subclass of ReadCore) */
@@ -727,6 +735,18 @@ static PyObject *read_get_quali(ReadCore *r, void *c)
 static PyObject *read_get_name(ReadCore *r, void *c)
 {
     (void)c;
+    if (!r->name && r->lazy_name == 2) {                          /* a row of the table read from the index file: its name is there */
+        FastqCore *fq = r->fq && PyObject_TypeCheck(r->fq, &FastqCoreType) ? (FastqCore *)r->fq : NULL;
+        if (fq && fq->by_id) {
+            SQ.bind_int64(fq->by_id, 1, r->id);
+            if (SQ.step(fq->by_id) == 100) {
+                const unsigned char *t = SQ.column_text(fq->by_id, 1);
+                r->name = PyUnicode_DecodeUTF8(t ? (const char *)t : "", t ? SQ.column_bytes(fq->by_id, 1) : 0, "surrogateescape");
+            }
+            SQ.reset(fq->by_id);
+        }
+        if (!r->name) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_RuntimeError, "the index file no longer answers for this read"); return NULL; }
+    }
     if (!r->name && r->lazy_name) {
         uint8_t buf[FX_GETTER_CAP];
         FastqCore *fq = r->fq && PyObject_TypeCheck(r->fq, &FastqCoreType) ? (FastqCore *)r->fq : NULL;
@@ -778,7 +798,31 @@ static void fqc_drop_table(FastqCore *f)
 {
     int k;
     f->tab_n = 0;
+    f->c_name_off = f->c_rlen = f->c_soff = f->c_qoff = NULL; f->c_name_len = f->c_dlen = NULL;
     for (k = 0; k < 6; ++k) if (f->tab[k].obj) PyBuffer_Release(&f->tab[k]);
+    for (k = 0; k < 4; ++k) { free(f->own[k]); f->own[k] = NULL; }
+}
+/* dlen, rlen, soff, qoff of every row of the index file into arrays of the object's own (IDs must run 1 .. counts) */
+static void fqc_load_table(FastqCore *f)
+{
+    sqlite3_stmt *st = NULL;
+    const long long n = f->counts;
+    long long k = 0;
+    int32_t *dl; int64_t *rl, *so, *qo;
+    if (!f->db || n <= 0 || SQ.prepare_v2(f->db, "SELECT ID, dlen, rlen, soff, qoff FROM read ORDER BY ID", -1, &st, NULL) != 0) return;
+    fqc_drop_table(f);
+    f->own[0] = dl = (int32_t *)malloc((size_t)n * 4); f->own[1] = rl = (int64_t *)malloc((size_t)n * 8);
+    f->own[2] = so = (int64_t *)malloc((size_t)n * 8); f->own[3] = qo = (int64_t *)malloc((size_t)n * 8);
+    if (dl && rl && so && qo) {
+        while (k < n && SQ.step(st) == 100 && SQ.column_int64(st, 0) == k + 1) {
+            dl[k] = (int32_t)SQ.column_int64(st, 1); rl[k] = SQ.column_int64(st, 2); so[k] = SQ.column_int64(st, 3); qo[k] = SQ.column_int64(st, 4);
+            ++k;
+        }
+    }
+    SQ.finalize(st);
+    if (k != n) { fqc_drop_table(f); return; }                   /* not the table it says it is: the statements go on answering */
+    f->c_dlen = dl; f->c_rlen = rl; f->c_soff = so; f->c_qoff = qo;
+    f->tab_n = n;
 }
 static void fqc_dealloc(FastqCore *f)
 {
@@ -800,6 +844,7 @@ static PyObject *fqc_open(FastqCore *f, PyObject *arg)
     PyObject *b = NULL;
     int ok;
     if (f->db || f->by_id || f->by_name) fqc_close_db(f);
+    fqc_drop_table(f); f->tab_tried = 0; f->int_hits = 0;        /* another index file: whatever was known of the old one goes */
     if (arg == Py_None || !sq_load()) Py_RETURN_FALSE;
     if (!PyUnicode_FSConverter(arg, &b)) return NULL;
     ok = SQ.open_v2(PyBytes_AS_STRING(b), &f->db, 1 /* SQLITE_OPEN_READONLY */, NULL) == 0 &&
@@ -842,6 +887,8 @@ static PyObject *fqc_table(FastqCore *f, PyObject *args)
         if (f->tab[k].len % width[k]) { fqc_drop_table(f); PyErr_SetString(PyExc_ValueError, "_core_table: int64, int32, int32, int64, int64, int64 columns"); return NULL; }
         if (n < 0 || f->tab[k].len / width[k] < n) n = f->tab[k].len / width[k];
     }
+    f->c_name_off = (const int64_t *)f->tab[0].buf; f->c_name_len = (const int32_t *)f->tab[1].buf; f->c_dlen = (const int32_t *)f->tab[2].buf;
+    f->c_rlen = (const int64_t *)f->tab[3].buf; f->c_soff = (const int64_t *)f->tab[4].buf; f->c_qoff = (const int64_t *)f->tab[5].buf;
     f->tab_n = n;
     Py_RETURN_NONE;
 }
@@ -873,16 +920,20 @@ static PyObject *fqc_subscript(FastqCore *f, PyObject *key)
             int rc;
             if (i < 0) i += f->counts;
             if (i >= f->counts) { PyErr_SetString(PyExc_IndexError, "index out of range"); return NULL; }
-            if (i >= 0 && i < f->tab_n) {                                          /* the row from the table this process built */
+            if (!f->tab_n && !f->tab_tried && f->counts <= f->tab_cap && ++f->int_hits >= 64 && f->int_hits * 22 > f->counts) {
+                f->tab_tried = 1;                                                  /* asked often enough: the columns in one pass */
+                fqc_load_table(f);
+            }
+            if (i >= 0 && i < f->tab_n) {                                          /* the row from the table on the host */
                 ReadCore *rd = (ReadCore *)g_read_type->tp_alloc(g_read_type, 0);
                 if (!rd) return NULL;
                 read_untrack(rd);
                 rd->fq = Py_NewRef((PyObject *)f);
                 rd->id = i + 1;
-                rd->lazy_name = 1;
-                rd->name_off = ((const int64_t *)f->tab[0].buf)[i]; rd->name_len = ((const int32_t *)f->tab[1].buf)[i];
-                rd->desc_len = ((const int32_t *)f->tab[2].buf)[i]; rd->read_len = ((const int64_t *)f->tab[3].buf)[i];
-                rd->soff = ((const int64_t *)f->tab[4].buf)[i]; rd->qoff = ((const int64_t *)f->tab[5].buf)[i];
+                if (f->c_name_off) { rd->lazy_name = 1; rd->name_off = f->c_name_off[i]; rd->name_len = f->c_name_len[i]; }
+                else rd->lazy_name = 2;                                            /* the name by statement, when asked for */
+                rd->desc_len = f->c_dlen[i]; rd->read_len = f->c_rlen[i];
+                rd->soff = f->c_soff[i]; rd->qoff = f->c_qoff[i];
                 return (PyObject *)rd;
             }
             SQ.bind_int64(f->by_id, 1, i + 1);
@@ -919,6 +970,7 @@ static PyMemberDef fqc_members[] = {
     {"_core_handle", T_ULONGLONG, offsetof(FastqCore, handle), READONLY, NULL},
     {"_core_fd", T_INT, offsetof(FastqCore, fd), READONLY, NULL},
     {"_core_table_rows", T_LONGLONG, offsetof(FastqCore, tab_n), READONLY, "rows of the host table fq[i] is served from (0: the index file)"},
+    {"_core_table_cap", T_LONGLONG, offsetof(FastqCore, tab_cap), 0, "an object that loaded its index reads the table from it once fq[i] is used enough, up to this many reads (0: never)"},
     {NULL, 0, 0, 0, NULL}};
 static PyMappingMethods fqc_mapping = {NULL, (binaryfunc)fqc_subscript, NULL};      /* (__len__ stays with the Python class) */
 static PyTypeObject FastqCoreType = {

@@ -1333,6 +1333,18 @@ def test_fastq_subscript_and_read_getters_in_c(tmp_path, crlf):
         fq[len(recs)]
     fq._core_table()
     assert fq._core_table_rows == 0 and fq[1].name == recs[1][0]
+    # ... and an object that only has the index file reads the four integer columns from it in one pass once fq[i] has been
+    # asked for often enough (64 times and 1/22 of the reads); the name of such a read comes from the file's statement
+    fq._core_table_cap = 1000
+    for k in range(70):
+        assert fq[k % len(recs)].id == k % len(recs) + 1
+    assert fq._core_table_rows == len(recs)
+    for i, (n, s, q) in enumerate(recs):
+        r = fq[i]
+        assert (r.id, r._name_len, len(r), r._desc_len, r._soff, r._qoff) == (i + 1, 0, len(s), rows[i][1], rows[i][3], rows[i][4])
+        assert r.seq == s and r.qual == q and r.name == n and r.name is r.name
+    fq._core_open(path + ".fxi")                                 # bound again: what was known of the file goes
+    assert fq._core_table_rows == 0
     fq._core_stage(0)                                            # Blob.close(): back to the Python methods
     with pytest.raises(AttributeError):
         fq[0].seq
