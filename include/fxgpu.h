@@ -65,7 +65,11 @@ int fx_device_count(void);
  * (index.c:683-692) / pyfastx_read_random_reader (read.c:37-45): the whole
  * uncompressed stream becomes one resident blob in HBM.                        */
 
-/* Plain or gzip file -> pinned double buffers -> hipMemcpyAsync -> HBM. */
+/* Plain or gzip file -> pinned double buffers -> hipMemcpyAsync -> HBM.  A BGZF file is inflated on the device (one wave per
+ * member; every member checked against the CRC-32 of its trailer, as zlib's gzread does for the reference); a BGZF file of
+ * 512 MiB or more in groups of FX_BGZF_GROUP bytes (256 MiB; 0: all at once) BEHIND its staging, the blob sized from the ratio
+ * of the first group (what is left over stays with the blob: fx_size is what it holds).  A single gzip stream is inflated on
+ * the host cores. */
 int fx_open_file(const char *path, int device, fx_handle **out);
 /* What a file holds and how long its stream is once inflated -- kind 0: plain; 1: BGZF (*n_bytes = sum of the members'
  * ISIZE, from a walk over their headers); 2: a single gzip stream (*n_bytes = -1: unknown without inflating it). */
@@ -88,9 +92,10 @@ int fx_open_device(const void *dptr, int64_t nbytes, int device, fx_handle **out
 int fx_set_shard(fx_handle *h, int64_t base, int prev_byte, int is_last);
 
 int fx_close(fx_handle *h);
-/* Scratch of an open (compressed bytes of a BGZF file, its match map: hundreds of MB for tens of milliseconds) is kept
- * in a per-process pool for the next open (FX_SCRATCH_CACHE_MB, default 4096; the library empties it by itself before a
- * device allocation fails).  This gives the idle blocks back to the driver now. */
+/* Scratch of an open (compressed bytes of a BGZF file, its match map: hundreds of MB for tens of milliseconds) and, since
+ * round 4, the blob of a closed handle are kept in a per-process pool for the next open (FX_SCRATCH_CACHE_MB, default 8192:
+ * the driver clears memory it hands out or takes back, 20 ms per 3 GB in the way of the next open's copies; the library
+ * empties the pool by itself before a device allocation fails).  This gives the idle blocks back to the driver now. */
 int fx_release_scratch(void);
 /* Pinned (page-locked) host memory out of a per-process pool, for the arrays a caller hands to the batched entry
  * points with FX_HOST: answers land in it by DMA -- no bounce buffer, no first-touch page faults of a fresh buffer
