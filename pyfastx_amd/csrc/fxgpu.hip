@@ -927,6 +927,7 @@ struct StageAsync {
     std::vector<hipEvent_t> ev;                               // one per piece
     std::unique_ptr<std::atomic<int>[]> issued;               // 1: the piece's copy and its event are in the lane's stream
     int64_t waited = 0;                                       // pieces `wait_until` has been through
+    cpu_set_t near_cpus;                                      // the cores next to the device (the lanes are bound to them)
     int start(fx_handle *hh, int fd_, int64_t n_, uint8_t *dst, int64_t piece_bytes) {
         h = hh; fd = fd_; n = n_; d_dst = dst; piece = std::min<int64_t>(PIECE_BYTES, piece_bytes);
         npieces = (n + piece - 1) / piece;
@@ -937,7 +938,6 @@ struct StageAsync {
             issued[(size_t)i].store(0);
             if (hipEventCreateWithFlags(&ev[(size_t)i], hipEventDisableTiming) != hipSuccess) { err.store(2); return fail(FX_EDEVICE, "hipEventCreate failed"); }
         }
-        static cpu_set_t near_cpus;
         const bool bind = device_cpus(h->device, &near_cpus);
         for (int t = 0; t < T; ++t)
             th.emplace_back([this, t, bind]() {
