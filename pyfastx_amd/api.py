@@ -1215,6 +1215,11 @@ class Fastq(_fxobj.FastqCore):
             self._core_table(t["name_off"], t["name_len"], t["dlen"], t["rlen"], t["soff"], t["qoff"])
         else:
             self._core_table()
+        nm = getattr(self, "_host_names", None)
+        if ok and nm is not None and self._core_table_rows == self._counts == len(nm[1]) - 1:
+            self._core_names(nm[0], nm[1])
+        else:
+            self._core_names()
         # an object that loaded its index file reads the table from it once fq[i] has been asked for often enough (csrc/fxobj.c)
         self._core_table_cap = int(os.environ.get("FX_FQ_HOST_TABLE", 16_000_000)) if ok else 0
 
@@ -1274,8 +1279,13 @@ class Fastq(_fxobj.FastqCore):
         self._host_tab = t if 0 < s.n_reads <= int(os.environ.get("FX_FQ_HOST_TABLE", 16_000_000)) else None
         self._db = None
         if s.n_reads:
-            self._db = _bulk_index(self._index_file, blob, 1, s.n_reads, t["name_off"], t["name_len"],
-                                   lambda p, names, offs, order: fxi.write_fastq_bulk(p, names, offs, t, s.size, order))
+            def write(p, names, offs, order):
+                # the names as they were packed for the index file stay too (up to 1 GiB of them): fq[name] is a hash look-up in C
+                if self._host_tab is not None and names.nbytes <= (1 << 30):
+                    self._host_names = (np.ascontiguousarray(names), offs)
+                return fxi.write_fastq_bulk(p, names, offs, t, s.size, order)
+            self._host_names = None
+            self._db = _bulk_index(self._index_file, blob, 1, s.n_reads, t["name_off"], t["name_len"], write)
         if self._db is None:
             names = []
             step = 1 << 20

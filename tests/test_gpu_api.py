@@ -196,10 +196,12 @@ def test_fastq_and_reads(fx, files, fn):
     # the object that BUILT the index answers fq[i] from the table it wrote the index from (csrc/fxobj.c: _core_table); one that
     # loads the index file answers from the file's statements -- the same reads either way
     fq2 = fx.Fastq(files[fn])
-    assert fq._core_table_rows == len(fq) and fq2._core_table_rows == 0
+    assert fq._core_table_rows == len(fq) == fq._core_names_rows and fq2._core_table_rows == 0 == fq2._core_names_rows
     for r in g["reads"][:40]:
         a, b = fq[r["i"]], fq2[r["i"]]
         assert (a.id, a.name, a.seq, a.qual, a.raw, a.description, repr(a)) == (b.id, b.name, b.seq, b.qual, b.raw, b.description, repr(b))
+        a, b = fq[r["name"]], fq2[r["name"]]                    # by name: the builder's hash of the packed names / the file's statement
+        assert (a.id, a.name, a.seq, a.qual, a.raw, a.description) == (b.id, b.name, b.seq, b.qual, b.raw, b.description) and a.id == r["i"] + 1
     assert fq[-1].name == fq2[-1].name == fq2[len(fq) - 1].name
     out = fq.fetch_many([r["i"] for r in g["reads"][:50]])
     for j, r in enumerate(g["reads"][:50]):

@@ -1331,6 +1331,28 @@ def test_fastq_subscript_and_read_getters_in_c(tmp_path, crlf):
         assert r.name == "other" and fq[n].id == i + 1                 # by name: still the statement
     with pytest.raises(IndexError, match="index out of range"):
         fq[len(recs)]
+    # ... and with the names as they were packed for the index file (_core_names), fq[name] is a hash look-up into that table
+    packed = np.frombuffer("".join(n for n, _, _ in recs).encode(), dtype=np.uint8)
+    offs = np.cumsum([0] + [len(n) for n, _, _ in recs]).astype(np.int64)
+    with pytest.raises(ValueError):
+        fq._core_names(packed, offs[::-1].copy())
+    fq._core_names(packed, offs)
+    assert fq._core_names_rows == len(recs)
+    import sqlite3 as _sq
+    _sq.connect(path + ".fxi").execute("UPDATE read SET soff = -1").connection.commit()    # whoever asks the file now gets nonsense
+    for k in range(70):                                           # (the id table is made once fq[name] has been used 64 times and once per 90 reads)
+        fq[recs[k % len(recs)][0]]
+    for i, (n, s, q) in enumerate(recs):
+        key = "".join(n)                                          # (another str object than the one in recs)
+        r = fq[key]
+        assert (r.id, r.seq, r.qual, r._soff) == (i + 1, s, q, rows[i][3]) and r.name is key
+    with pytest.raises(KeyError, match="nope does not exist in fastq file"):
+        fq["nope"]
+    with pytest.raises(KeyError):
+        fq["r"]                                                  # a prefix of every name
+    _sq.connect(path + ".fxi").executemany("UPDATE read SET soff = ? WHERE ID = ?", [(rows[i][3], i + 1) for i in range(len(rows))]).connection.commit()
+    fq._core_names()
+    assert fq._core_names_rows == 0 and fq[recs[2][0]].seq == recs[2][1]
     fq._core_table()
     assert fq._core_table_rows == 0 and fq[1].name == recs[1][0]
     # ... and an object that only has the index file reads the four integer columns from it in one pass once fq[i] has been
