@@ -226,6 +226,13 @@ __device__ __forceinline__ int fq_first_bit(const uint64_t *m, int a, int b) {
 #define FX_FQL_G 4
 #endif
 constexpr int FQL_G = FX_FQL_G;
+// ... and k_fastq_rows takes FQR_G of them per wave: the count pass fills ONE record slot per FQR_G granules
+#ifndef FX_FQR_G
+#define FX_FQR_G 4
+#endif
+constexpr int FQR_G = FX_FQR_G;
+static_assert(FQR_G <= 8, "a staged line record has three bits for the granule of the wave it came from");
+static_assert(FQL_G % FQR_G == 0, "the count pass fills one record slot per FQR_G granules: a wave of k_fastq_rows reads one of them");
 
 // The line records of a granule whose newline positions stand compacted in spos[0, M): one lane per line -- the CR bit from the
 // granule's map of '\r' bytes, the first space of the line by a word-wise bit search from the line's second byte.
@@ -287,11 +294,12 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines(const uint8_t *__restrict
     const int64_t gw = ((int64_t)blockIdx.x * (BLOCK / 64) + w) * FQL_G;
     uint4 v[GR_ROWS];
     if (gw < g_end) granule_load<true>(v, data, n, 0, gw);
-    uint32_t *const rslot = recs + (gw / FQL_G) * (int64_t)(FQL_G * FQL_CAP);      // the records of the run's granules, one after the other
-    uint32_t written = 0;
+    uint32_t written = 0;                  // records of the slot so far (a slot per FQR_G granules, the records one after the other)
     for (int kk = 0; kk < FQL_G; ++kk) {
         const int64_t g = gw + kk;
         if (g >= g_end) break;
+        if (kk % FQR_G == 0) written = 0;
+        uint32_t *const rslot = recs + (g / FQR_G) * (int64_t)(FQR_G * FQL_CAP);
         const int64_t sbase = g * (int64_t)GRAN;
         uint32_t nlm[GR_ROWS], ex[GR_ROWS], M = 0;
 #pragma unroll
@@ -350,12 +358,6 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines(const uint8_t *__restrict
 // rows from the line records: granules [0, g_end) that did not overflow.  A wave takes FQR_G consecutive granules and
 // asks for their summaries, then for their records, before it computes anything: one wave per granule spent its time
 // waiting for two dependent round trips (0.73 ms for 1.7 M granules; the traffic is worth 0.25 ms).
-#ifndef FX_FQR_G
-#define FX_FQR_G 4
-#endif
-constexpr int FQR_G = FX_FQR_G;
-static_assert(FQR_G <= 8, "a staged line record has three bits for the granule of the wave it came from");
-static_assert(FQR_G == FQL_G, "k_fastq_rows reads the records of a run of granules from the slot the count pass filled for that run");
 
 // The fields the line record r of line idx determines (line i of its granule, which begins at global offset gs; q =
 // global offset of the newline before it), into row idx >> 2 of the table when the shard owns it.

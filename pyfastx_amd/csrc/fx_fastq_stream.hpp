@@ -270,12 +270,18 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__re
 // stream, where the reference makes two (and this engine made two: 7 + 7 ms for C3).
 //
 // Which line of four a byte belongs to is not known while the stream is read -- the newline prefixes come later in the
-// build.  A wave takes FQL_G consecutive granules; for the first one it GUESSES: a line of exactly one byte is the '+' line
+// build.  A wave takes FQLC_G consecutive granules (16: 64 KiB per guess, table look-up set-up and run record -- 11.9 ms for C3
+// with 4, 11.2 with 8, 11.0 with 16; the plain count pass is fastest with 4); for the first one it GUESSES: a line of exactly one byte is the '+' line
 // (two newlines two bytes apart; every candidate of the granule must agree), which fixes the number-of-four of the granule's
 // first line, and the granules behind it follow by counting.  The counts of a run -- A C G T N, smallest / largest quality,
 // the guess -- go to an 8-word record; k_fastq_comp_reduce, after the prefixes, compares every guess with the truth
 // ((line offset + nl_prefix[first granule]) & 3) and adds the records up.  ONE wrong or missing guess (a file whose '+' lines
 // repeat the name, 1-base reads, CRLF) and the result is not used: fx_fastq_comp then counts from the read table as before.
+#ifndef FX_FQLC_G
+#define FX_FQLC_G 16
+#endif
+constexpr int FQLC_G = FX_FQLC_G;                          // granules per run of k_fastq_lines_comp
+static_assert(FQLC_G % FQR_G == 0, "the count pass fills one record slot per FQR_G granules");
 struct FqRun { uint32_t cnt[5]; uint32_t q; uint32_t guess; uint32_t pad; };   // q: min | max << 8 | have << 16 | odd << 17; guess: 0..3, 0xFF none
 static_assert(sizeof(FqRun) == 32, "one run record is 32 bytes");
 
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
     int *fix = s_fix[w];
     // a workgroup makes its mask table once and then takes run after run (a table per 64 KiB of stream was an eighth of the work)
     for (int64_t run = (int64_t)blockIdx.x * (BLOCK / 64) + w; run < nruns; run += (int64_t)gridDim.x * (BLOCK / 64)) {
-    const int64_t gw = run * FQL_G;
+    const int64_t gw = run * FQLC_G;
     FsAcc a;
 #pragma unroll
     for (int k = 0; k < COMP_NPL; ++k) a.pl.p[k] = 0;
@@ -317,10 +323,11 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
     uint32_t guess = 0xFFu, lines_before = 0;              // number-of-four of the run's first line (0xFF: not known), newlines of the run so far
     uint4 v[GR_ROWS];
     if (gw < g_end) granule_load<true>(v, data, n, 0, gw);
-    for (int kk = 0; kk < FQL_G; ++kk) {
+    for (int kk = 0; kk < FQLC_G; ++kk) {
         const int64_t g = gw + kk;
         if (g >= g_end) break;
         const int64_t sbase = g * (int64_t)GRAN;
+        if (kk % FQR_G == 0) written = 0;                      // (a record slot per FQR_G granules: what k_fastq_rows reads in one request)
         uint32_t nlm[GR_ROWS], ex[GR_ROWS], run_n = 0;
 #pragma unroll
         for (int j = 0; j < GR_ROWS; ++j) {
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
             planes_finish16(a.pl, cy);
         }
         lines_before += M;
-        if (kk + 1 < FQL_G && g + 1 < g_end) granule_load<true>(v, data, n, 0, g + 1);       // the next granule is on its way
+        if (kk + 1 < FQLC_G && g + 1 < g_end) granule_load<true>(v, data, n, 0, g + 1);       // the next granule is on its way
         int first = GRAN, last = -1;
         const bool over = M > (uint32_t)FQL_CAP;              // more lines than a slot holds: k_fastq_emit reads the granule again
         if (over) {
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
         }
         if (over || !M) continue;
         fq_line_records(data, sbase, prev_byte, s_pos[w], M, reinterpret_cast<const uint64_t *>(&s_sp[w][0]), &s_cr[w][0],
-                        recs + run * (int64_t)(FQL_G * FQL_CAP) + written, lane);
+                        recs + (g / FQR_G) * (int64_t)(FQR_G * FQL_CAP) + written, lane);
         written += M;
     }
     // ---- the run's record
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_reduce(const FqRun *__rest
     int qmin = 255, qmax = 0, bad = 0;
     for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < nruns; r += (int64_t)gridDim.x * BLOCK) {
         const FqRun x = runs[r];
-        const uint32_t truth = (uint32_t)((line0 + nl_prefix[r * FQL_G]) & 3);
+        const uint32_t truth = (uint32_t)((line0 + nl_prefix[r * FQLC_G]) & 3);
         if (x.guess != truth || (x.q >> 17) & 1u) { ++bad; continue; }
 #pragma unroll
         for (int c = 0; c < 5; ++c) tot[c] += x.cnt[c];

@@ -293,7 +293,7 @@ struct fx_handle {
     DevBuf<int64_t> fq_name_off, fq_rlen, fq_soff, fq_qoff;
     DevBuf<int32_t> fq_name_len, fq_dlen, fq_qlen;
     DevBuf<FastqAcc> fq_acc;
-    DevBuf<FqRun> fq_runs;                    // k_fastq_lines_comp: one record per run of FQL_G granules (composition counted on the scan)
+    DevBuf<FqRun> fq_runs;                    // k_fastq_lines_comp: one record per run of FQLC_G granules (composition counted on the scan)
     DevBuf<FastqAcc> fq_acc_build;            // ... added up by k_fastq_comp_reduce
     bool fq_comp_valid = false;               // the build counted the composition and every run's guess was right
     int64_t fq_comp_base[5] = {0, 0, 0, 0, 0};
@@ -1867,9 +1867,9 @@ static int granule_pass(fx_handle *h, bool fq_lines = false, bool with_comp = fa
     GranList hgl{h->hdr_grans.p, ctl_counter(h, 0)};
     const int SCAN_WG = 512;                                  // 8 waves = 8 granules per workgroup (tools/scanbench2.hip)
     if (nfull > 0 && MODE == 1 && fq_lines) {                 // FASTQ, one-read build: the count pass also writes the line records
-        if ((rc = h->fq_lines.alloc((nfull + FQL_G - 1) / FQL_G * FQL_G * FQL_CAP))) return rc;      // a slot of FQL_G * FQL_CAP records per run of FQL_G granules
+        if ((rc = h->fq_lines.alloc((nfull + FQR_G - 1) / FQR_G * FQR_G * FQL_CAP))) return rc;      // a slot of FQR_G * FQL_CAP records per FQR_G granules
         if (with_comp) {                                      // index and composition in one read of the stream (fx_fastq_stream.hpp)
-            const int64_t nruns = (nfull + FQL_G - 1) / FQL_G;
+            const int64_t nruns = (nfull + FQLC_G - 1) / FQLC_G;
             if ((rc = h->fq_runs.alloc(nruns)) || (rc = h->fq_acc_build.alloc(1))) return rc;
             static const int64_t grid_cap = [] { const char *e = getenv("FX_FQ_FUSED_GRID"); return e && atoll(e) > 0 ? atoll(e) : 6144ll; }();
             FX_LAUNCH(h, K_FASTQ_LINES, k_fastq_lines_comp, dim3((unsigned)std::min<int64_t>(nblocks(nruns, BLOCK / 64), grid_cap)), dim3(BLOCK), h->d_data,
@@ -1905,7 +1905,7 @@ static int granule_pass(fx_handle *h, bool fq_lines = false, bool with_comp = fa
         memset(&init, 0, sizeof init);
         init.minqs = 104; init.maxqs = 33;                    // fastq.c:667-668
         HIPCHK(hipMemcpyAsync(h->fq_acc_build.p, &init, sizeof init, hipMemcpyHostToDevice, h->stream));
-        const int64_t nruns = (nfull + FQL_G - 1) / FQL_G;
+        const int64_t nruns = (nfull + FQLC_G - 1) / FQLC_G;
         FX_LAUNCH(h, K_FASTQ_COMP, k_fastq_comp_reduce, dim3((unsigned)std::min<int64_t>(nblocks(nruns, BLOCK), 1024)), dim3(BLOCK), (const FqRun *)h->fq_runs.p,
                   nruns, (const int64_t *)h->nl_prefix.p, (int64_t)0, h->d_data, h->n, nfull, h->fq_acc_build.p);
     }

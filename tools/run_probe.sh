@@ -1,3 +1,2 @@
-for l in pyfastx_amd/csrc/libfxgpu.so build/libfxgpu_FX_SC_WPE_6.so build/libfxgpu_FX_SC_WPE_4.so build/libfxgpu_FX_COMP_DEPTH_4.so pyfastx_amd/csrc/libfxgpu.so; do
-  echo $l; FX_LIBFXGPU=/root/repo/$l python tools/fullindex_probe.py 3.0 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['one_read']['wall_ms'], d['one_read']['kernels_ms_avg'].get('k_scan_comp'), d['rows_equal'])"
-done
+python -m pytest tests/test_gpu_kernels.py tests/test_gpu_vs_reference.py tests/test_gpu_api.py tests/test_gpu_windows.py tests/test_gpu_shards.py -x -q -k "fastq or Fastq" 2>&1 | tail -3
+python tools/fastq_scale.py 1e8 2>&1 | tail -1 | cut -c1-330
