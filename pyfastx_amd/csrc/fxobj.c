@@ -635,6 +635,10 @@ typedef struct {
     /* the names of the reads as the build packed them for the index file (one buffer + n + 1 offsets), kept by _core_names():
      * fq[name] is then a hash look-up into the host table (the table of ids is made at the first such subscript) */
     Py_buffer nm_buf, nm_off;
+    const unsigned char *nm_bytes;               /* the names and their n + 1 offsets, wherever they live: the two buffers above, or ... */
+    const int64_t *nm_offs;
+    void *own_names, *own_offs;                  /* ... arrays of the object's own, read from a LOADED index file in one pass (fqc_load_names) */
+    int nm_tried;
     long long nm_n, nm_hits;                     /* the id table costs ~0.06 us per read to make and saves ~5 us per look-up: made once hits * 90 > reads */
     uint32_t *nm_ht;                             /* open addressing, id + 1 (0: empty); the lowest id of equal names wins */
     uint64_t nm_mask;
@@ -803,6 +807,8 @@ static void fqc_close_db(FastqCore *f)
 static void fqc_drop_names(FastqCore *f)
 {
     f->nm_n = 0; f->nm_hits = 0;
+    f->nm_bytes = NULL; f->nm_offs = NULL;
+    free(f->own_names); free(f->own_offs); f->own_names = f->own_offs = NULL;
     free(f->nm_ht); f->nm_ht = NULL; f->nm_mask = 0;
     if (f->nm_buf.obj) PyBuffer_Release(&f->nm_buf);
     if (f->nm_off.obj) PyBuffer_Release(&f->nm_off);
@@ -818,8 +824,8 @@ static uint64_t fq_name_hash(const unsigned char *p, Py_ssize_t l)
 /* the id table of the packed names (at the first fq[name]); 0: no memory, the statements go on answering */
 static int fqc_build_ht(FastqCore *f)
 {
-    const unsigned char *nb = (const unsigned char *)f->nm_buf.buf;
-    const int64_t *no = (const int64_t *)f->nm_off.buf;
+    const unsigned char *nb = f->nm_bytes;
+    const int64_t *no = f->nm_offs;
     uint64_t cap = 16;
     long long i;
     while (cap < (uint64_t)f->nm_n * 2) cap <<= 1;
@@ -841,8 +847,8 @@ static int fqc_build_ht(FastqCore *f)
 /* id (0-based) of the read called t, -1: no such read */
 static long long fqc_find_name(FastqCore *f, const char *t, Py_ssize_t l)
 {
-    const unsigned char *nb = (const unsigned char *)f->nm_buf.buf;
-    const int64_t *no = (const int64_t *)f->nm_off.buf;
+    const unsigned char *nb = f->nm_bytes;
+    const int64_t *no = f->nm_offs;
     uint64_t at = fq_name_hash((const unsigned char *)t, l) & f->nm_mask;
     for (;;) {
         const uint32_t e = f->nm_ht[at];
@@ -903,7 +909,7 @@ static PyObject *fqc_open(FastqCore *f, PyObject *arg)
     int ok;
     if (f->db || f->by_id || f->by_name) fqc_close_db(f);
     fqc_drop_names(f);
-    fqc_drop_table(f); f->tab_tried = 0; f->int_hits = 0;        /* another index file: whatever was known of the old one goes */
+    fqc_drop_table(f); f->tab_tried = 0; f->int_hits = 0; f->nm_tried = 0;   /* another index file: whatever was known of the old one goes */
     if (arg == Py_None || !sq_load()) Py_RETURN_FALSE;
     if (!PyUnicode_FSConverter(arg, &b)) return NULL;
     ok = SQ.open_v2(PyBytes_AS_STRING(b), &f->db, 1 /* SQLITE_OPEN_READONLY */, NULL) == 0 &&
@@ -928,6 +934,46 @@ static PyObject *fqc_stage(FastqCore *f, PyObject *args)
         Py_DECREF(b);
     }
     Py_RETURN_NONE;
+}
+/* An object that loaded its index file and is asked by name often enough: the integer columns (fqc_load_table) and the names of
+ * every row, in one pass over the file each, into arrays of its own; fq[name] then is the same hash look-up as on the
+ * object that built the index. */
+static void fqc_load_names(FastqCore *f)
+{
+    sqlite3_stmt *st = NULL;
+    const long long n = f->counts;
+    long long k = 0;
+    size_t cap = 0, used = 0;
+    unsigned char *buf = NULL;
+    int64_t *off = NULL;
+    if (!f->tab_n) { f->tab_tried = 1; fqc_load_table(f); }
+    if (f->tab_n != n || n <= 0 || n >= 0xFFFFFFFFll || !f->db) return;
+    if (SQ.prepare_v2(f->db, "SELECT ID, name FROM read ORDER BY ID", -1, &st, NULL) != 0) return;
+    off = (int64_t *)malloc((size_t)(n + 1) * 8);
+    cap = (size_t)n * 24 + 64;
+    buf = (unsigned char *)malloc(cap);
+    if (off && buf) {
+        off[0] = 0;
+        while (k < n && SQ.step(st) == 100 && SQ.column_int64(st, 0) == k + 1) {
+            const unsigned char *t = SQ.column_text(st, 1);
+            const size_t l = t ? (size_t)SQ.column_bytes(st, 1) : 0;
+            if (used + l > cap) {
+                unsigned char *nb;
+                cap = (used + l) * 2;
+                nb = (unsigned char *)realloc(buf, cap);
+                if (!nb) break;
+                buf = nb;
+            }
+            if (l) memcpy(buf + used, t, l);
+            used += l;
+            off[++k] = (int64_t)used;
+        }
+    }
+    SQ.finalize(st);
+    if (k != n || !off || !buf) { free(off); free(buf); return; }
+    fqc_drop_names(f);
+    f->own_names = buf; f->own_offs = off;
+    f->nm_bytes = buf; f->nm_offs = off; f->nm_n = n;
 }
 /* _core_table(name_off, name_len, dlen, rlen, soff, qoff) keeps the six columns (any objects with the buffer protocol; the
  * item sizes are checked, the row count is the shortest of them); _core_table() forgets them */
@@ -974,6 +1020,7 @@ static PyObject *fqc_names(FastqCore *f, PyObject *args)
         long long i;
         for (i = 0; i < n; ++i) if (no[i + 1] < no[i]) { fqc_drop_names(f); PyErr_SetString(PyExc_ValueError, "_core_names: offsets must not fall"); return NULL; }
     }
+    f->nm_bytes = (const unsigned char *)f->nm_buf.buf; f->nm_offs = no;
     f->nm_n = n;
     Py_RETURN_NONE;
 }
@@ -1031,6 +1078,11 @@ static PyObject *fqc_subscript(FastqCore *f, PyObject *key)
     } else if (f->by_name && g_read_type && PyUnicode_CheckExact(key)) {         /* fastq.c:535-541 */
         Py_ssize_t l = 0;
         const char *t = PyUnicode_AsUTF8AndSize(key, &l);
+        if (t && !f->nm_n && !f->nm_tried && f->counts <= f->tab_cap && ++f->nm_hits >= 64 && f->nm_hits * 25 > f->counts) {
+            f->nm_tried = 1;                                                       /* a loaded index file, asked by name often enough */
+            fqc_load_names(f);
+            f->nm_hits = 1ll << 40;                                                /* (the id table at once: the look-ups have paid for it) */
+        }
         if (t && f->nm_n > 0 && f->nm_n == f->tab_n && (f->nm_ht || (++f->nm_hits >= 64 && f->nm_hits * 90 > f->nm_n && fqc_build_ht(f)))) {   /* the names this process packed: no statement */
             const long long i = fqc_find_name(f, t, l);
             ReadCore *rd;

@@ -1367,6 +1367,19 @@ def test_fastq_subscript_and_read_getters_in_c(tmp_path, crlf):
         assert r.seq == s and r.qual == q and r.name == n and r.name is r.name
     fq._core_open(path + ".fxi")                                 # bound again: what was known of the file goes
     assert fq._core_table_rows == 0
+    # ... and asked by NAME often enough, it reads the names too (one more pass) and answers from a table of ids of its own
+    for k in range(70):
+        assert fq[recs[k % len(recs)][0]].id == k % len(recs) + 1
+    assert fq._core_names_rows == len(recs) == fq._core_table_rows
+    _sq.connect(path + ".fxi").execute("UPDATE read SET rlen = 1").connection.commit()      # (the file is not asked any more)
+    for i, (n, s, q) in enumerate(recs):
+        r = fq["".join(n)]
+        assert (r.id, len(r), r.seq, r.qual) == (i + 1, len(s), s, q)
+    with pytest.raises(KeyError, match="zzz does not exist in fastq file"):
+        fq["zzz"]
+    _sq.connect(path + ".fxi").executemany("UPDATE read SET rlen = ? WHERE ID = ?", [(rows[i][2], i + 1) for i in range(len(rows))]).connection.commit()
+    fq._core_open(path + ".fxi")
+    assert fq._core_names_rows == 0 == fq._core_table_rows
     fq._core_stage(0)                                            # Blob.close(): back to the Python methods
     with pytest.raises(AttributeError):
         fq[0].seq
