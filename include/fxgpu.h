@@ -446,6 +446,33 @@ int fx_fxi_bulk_index(const char *path, int rootpage, int64_t n, const uint8_t *
  * TEXT column (`comp`: rowid, then cols[] as INTEGERs). */
 int fx_fxi_bulk_index_int(const char *path, int rootpage, int64_t n, const int64_t *key, const int64_t *order);
 
+/* The same two b-trees formatted ON THE DEVICE (round 5, csrc/fx_fxi_dev.hpp): the record table of the handle's last
+ * build, the names where they are in the resident stream and the sorted order never leave HBM -- only finished 4 KiB
+ * pages cross PCIe and go into the file (pinned pieces, several copy threads, fallocate running ahead of them).  Replaces
+ * the INSERT loop and CREATE UNIQUE INDEX of fastq.c:29-60, 136-171 (`read`, `readidx`) and index.c:178-207, 239-251, 363
+ * (`seq`, `chromidx`) for a NEW index file.
+ *   fx_fxi_dev_sort:  kind 0 = FASTA table, 1 = FASTQ table; the BINARY-collation order of the record names is computed
+ *                     and kept in the handle; *n_dup = adjacent equal pairs (> 0: the names are not distinct, SQLite's
+ *                     CREATE UNIQUE INDEX would fail and the reference ignores that: write the table only).
+ *   fx_fxi_dev_write: `path` = a database with the schema in place and NO open connection, 4 KiB pages;
+ *                     root_table / root_index = sqlite_master.rootpage of the empty table / of the empty UNIQUE INDEX on its
+ *                     name column (0: no index; else fx_fxi_dev_sort must have run).  laps (8 doubles, may be NULL), seconds:
+ *                     table shape, leaf kernels, pages to the file, interior pages; the same four for the index (shape
+ *                     includes the dividers for the upper levels).  FX_ERANGE: a row / entry needs an overflow page (or
+ *                     >= 2^32 records) -- nothing usable was written, use the host loaders or INSERTs; FX_EINVAL: not a
+ *                     database this loader can extend (other page size, reserved bytes, auto-vacuum). */
+int fx_fxi_dev_sort(fx_handle *h, int kind, int64_t *n_dup);
+int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int root_table, int root_index, double *laps);
+/* Room for those pages set aside while the stream is still being staged: `path` = the database SQLite has just created
+ * (schema in place, no open connection); a thread of the library grows the file to `bytes` with fallocate (on tmpfs the
+ * allocation of 10 GB takes 0.6 s and must not run beside the stores into the file; beside the staging it costs nothing).
+ * The database header keeps saying where the database ends; fx_fxi_dev_write uses the room and cuts the file to what it
+ * needed.  fx_fxi_presize_end waits for the thread (cancel != 0: stops it at the next 256 MiB step first).  An estimate
+ * that is too small only means the rest is allocated by fx_fxi_dev_write.  No counterpart in the reference: its index
+ * file grows one INSERT at a time (fastq.c:136-149). */
+int fx_fxi_presize_begin(const char *path, int64_t bytes, void **token);
+int fx_fxi_presize_end(void *token, int cancel);
+
 /* ------------------------------------------------------- sync and timing
  * Calls that take FX_DEVICE arrays return after ENQUEUEING work on the
  * handle's stream; fx_sync waits for it.  (FX_HOST calls are synchronous.)   */

@@ -49,7 +49,7 @@ SYMBOLS = [
     "fx_set_shard", "fx_close", "fx_release_scratch", "fx_pinned_alloc", "fx_pinned_free", "fx_pinned_holds", "fx_pinned_trim", "fx_size", "fx_device_memory", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
     "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_line_regular", "fx_fasta_len_stats", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_fastq_build_comp", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fasta_fetch_alloc", "fx_fetch_phases", "fx_fastq_fetch", "fx_fastq_fetch_alloc", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
-    "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
+    "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_fxi_dev_sort", "fx_fxi_dev_write", "fx_fxi_presize_begin", "fx_fxi_presize_end", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
     "fx_comm_unique_id", "fx_comm_init", "fx_comm_destroy", "fx_comm_rank", "fx_comm_world", "fx_comm_allgather", "fx_fasta_build_sharded_begin",
     "fx_fasta_build_sharded", "fx_comm_summaries", "fx_fastq_build_sharded", "fx_bgzf_counts", "fx_sort_packed_names", "fx_gunzip_parallel", "fx_gz_open_mode", "fx_kseq_scan", "fx_kseq_records", "fx_kseq_fetch", "fx_kseq_prefix_lines",
 ]
@@ -57,6 +57,19 @@ SYMBOLS = [
 
 def so_path():
     return _SO
+
+
+def fxi_presize_begin(path, nbytes):
+    """A library thread grows the (just created) index file to nbytes with fallocate -> token for fxi_presize_end."""
+    tok = C.c_void_p(None)
+    check(lib().fx_fxi_presize_begin(os.fsencode(path), int(nbytes), C.byref(tok)))
+    return tok
+
+
+def fxi_presize_end(token, cancel=False):
+    if token is not None and token.value:
+        lib().fx_fxi_presize_end(token, 1 if cancel else 0)
+        token.value = None
 
 
 def fxi_bulk_rows(path, rootpage, packed_names, name_off, cols):
@@ -179,6 +192,10 @@ def lib():
     L.fx_fxi_bulk_rows.argtypes = [C.c_char_p, i32, i64, vp, vp, i32, vp]
     L.fx_fxi_bulk_index.argtypes = [C.c_char_p, i32, i64, vp, vp, vp]
     L.fx_fxi_bulk_index_int.argtypes = [C.c_char_p, i32, i64, vp, vp]
+    L.fx_fxi_dev_sort.argtypes = [vp, i32, C.POINTER(C.c_int64)]
+    L.fx_fxi_dev_write.argtypes = [vp, i32, C.c_char_p, i32, i32, C.POINTER(C.c_double)]
+    L.fx_fxi_presize_begin.argtypes = [C.c_char_p, i64, C.POINTER(vp)]
+    L.fx_fxi_presize_end.argtypes = [vp, i32]
     L.fx_sync.argtypes = [vp]
     L.fx_prof_enable.argtypes = [vp, i32]
     L.fx_prof_default.argtypes = [i32]
@@ -771,6 +788,22 @@ class Blob:
             check(rc)
             return buf[:total.value], offs
         raise FxError(FX_ERANGE, "names did not fit twice")
+
+    def fxi_dev_sort(self, kind):
+        """The sorted order of the record names, computed and KEPT on the device for fxi_dev_write -> number of adjacent
+        equal pairs (0: the names are distinct and the UNIQUE INDEX may be written)."""
+        ndup = C.c_int64(0)
+        check(lib().fx_fxi_dev_sort(self._h, int(kind), C.byref(ndup)))
+        return int(ndup.value)
+
+    FXI_LAPS = ("table_shape", "table_kernels", "table_to_file", "file_grown", "index_shape", "index_kernels", "index_to_file", "host_levels_and_header")
+
+    def fxi_dev_write(self, kind, path, root_table, root_index=0):
+        """The big table of a new index file (and, root_index != 0, the UNIQUE INDEX on its name column) as b-tree pages
+        formatted on the device (fx_fxi_dev_write) -> dict of the phases in seconds."""
+        laps = (C.c_double * 8)()
+        check(lib().fx_fxi_dev_write(self._h, int(kind), os.fsencode(path), int(root_table), int(root_index), laps))
+        return dict(zip(self.FXI_LAPS, (float(x) for x in laps)))
 
     def names_sort(self, kind, n):
         """-> (order int64[n], n_dup): sorted order of the n record names (BINARY collation) computed on the GPU."""

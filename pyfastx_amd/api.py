@@ -10,6 +10,7 @@ MI355X; only pure SQLite metadata (len, size, names ...) works without one.
 """
 import gzip
 import os
+import time
 
 import numpy as np
 
@@ -181,6 +182,32 @@ class _ShardedStaged(_Staged):
 
 
 # =========================================================================== FASTA
+def _dev_index_applies(path):
+    return not (path == ":memory:" or os.path.exists(path) or os.environ.get("FX_FXI_HOST"))
+
+
+def _dev_index(path, blob, kind, n, total, presized=False):
+    """A NEW .fxi whose two big b-trees are formatted on the device (fxi._bulk_table_dev): from FX_FXI_DEV_MIN records
+    (default 200 000; below that the host loaders are as fast and keep their arrays for the getters).  presized: the file
+    is there already, schema in place, made by fxi.presize_fastq for this very build.  -> (connection, phases) or None when
+    this route does not apply: an existing file, an in-memory index, a row that needs an overflow page, a database without
+    4 KiB pages."""
+    if not presized and not _dev_index_applies(path):
+        return None
+    if n < int(os.environ.get("FX_FXI_DEV_MIN", 200_000)) or not hasattr(blob, "fxi_dev_write"):
+        if presized and os.path.exists(path):
+            os.remove(path)
+        return None
+    try:
+        if kind == 1:
+            return fxi.write_fastq_dev(path, blob, n, total, schema_done=presized)
+        return fxi.write_fasta_dev(path, blob, n, total)
+    except _lib.FxError as e:
+        if e.code not in (_lib.FX_ERANGE, _lib.FX_EINVAL):
+            raise
+        return None
+
+
 def _bulk_index(path, blob, kind, n, name_off, name_len, write):
     """The bulk route to a NEW .fxi (fxi._bulk_table): the names come off the GPU as one packed buffer (one gather),
     their sorted order from Blob.names_sort, and both b-trees are written as pages instead of n INSERTs + a CPU
@@ -306,7 +333,12 @@ class Fasta(_fxobj.FastaCore):
         self._scanned_here = True
         t = blob.fasta_table(s.n_seq)
         self._db = None
+        self.index_phases = None
         if self._key_func is None and s.n_seq:
+            dv = _dev_index(self._index_file, blob, 0, s.n_seq, s.seq_len)
+            if dv is not None:
+                self._db, self.index_phases = dv
+        if self._db is None and self._key_func is None and s.n_seq:
             self._db = _bulk_index(self._index_file, blob, 0, s.n_seq, t["hoff"] + 1, t["name_len"],
                                    lambda p, names, offs, order: fxi.write_fasta_bulk(p, names, offs, t, s.seq_len, order))
         if self._db is None:
@@ -1250,7 +1282,30 @@ class Fastq(_fxobj.FastqCore):
 
     def _create_index(self):
         """pyfastx_fastq_create_index (fastq.c:8-182) with the scan on the GPU."""
+        # a large plain file: the index file is created now and grows to its estimated size while the input is staged
+        # (fxi.presize_fastq; the pages that fill it are formatted on the device once the table exists)
+        tok = None
+        if not self.is_gzip and _dev_index_applies(self._index_file) and self._st.forced is None and not os.environ.get("FX_FXI_NO_PRESIZE"):
+            try:
+                tok = fxi.presize_fastq(self._index_file, self.file_name, self._full_name)
+            except Exception:                                 # noqa: BLE001  (no early file: the build makes it)
+                tok = None
+        try:
+            self._create_index_body(tok is not None, tok)
+        except BaseException:
+            _lib.fxi_presize_end(tok, cancel=True)
+            if tok is not None and os.path.exists(self._index_file):
+                os.remove(self._index_file)
+            raise
+
+    def _create_index_body(self, presized, tok):
+        t_begin = time.perf_counter()
+        self.build_phases = None
         wq = self._st.md
+        if presized and wq is not None:                       # (built in windows after all: that route writes its own file)
+            _lib.fxi_presize_end(tok, cancel=True)
+            os.remove(self._index_file)
+            presized = False
         if wq is not None:                                    # larger than the HBM it may use: built window after window (windows.WindowedFastq)
             self._db = None
             if wq.n_reads and self._index_file != ":memory:" and not os.path.exists(self._index_file):
@@ -1269,24 +1324,45 @@ class Fastq(_fxobj.FastqCore):
             self.avglen = self.size * 1.0 / self._counts if self._counts else float("nan")
             return
         blob = self._st.blob
+        t_staged = time.perf_counter()
         try:
             s = blob.fastq_build(comp=self._want_comp)        # full_index: base / meta are counted on the way, one read of the stream for both
         except _lib.FxError as e:
             raise _fx_to_py(e)
-        t = blob.fastq_table(s.n_reads)
+        t_ready = time.perf_counter()                         # the read table is in HBM: batches by read id can be served from here on
         # the table the index file is written from stays with the object (up to FX_FQ_HOST_TABLE rows, 16 M = 640 MB; 0: never):
         # fq[i] then is six array elements in C instead of a statement on the index file (csrc/fxobj.c: _core_table)
-        self._host_tab = t if 0 < s.n_reads <= int(os.environ.get("FX_FQ_HOST_TABLE", 16_000_000)) else None
+        keep = 0 < s.n_reads <= int(os.environ.get("FX_FQ_HOST_TABLE", 16_000_000))
+        t = None
+        self._host_tab = self._host_names = None
         self._db = None
-        if s.n_reads:
+        self.index_phases = None
+        if presized:
+            _lib.fxi_presize_end(tok)                         # (done long before the staging is)
+        if s.n_reads or presized:
+            dv = _dev_index(self._index_file, blob, 1, s.n_reads, s.size, presized) if s.n_reads else None     # pages formatted on the device: nothing but pages comes to the host
+            if dv is None and presized and os.path.exists(self._index_file):
+                os.remove(self._index_file)
+            if dv is not None:
+                self._db, self.index_phases = dv
+                if keep:
+                    t = self._host_tab = blob.fastq_table(s.n_reads)
+                    names, offs = blob.names_pack(1, s.n_reads, guess=int(np.maximum(t["name_len"], 0).astype(np.int64).sum()))
+                    if names.nbytes <= (1 << 30):
+                        self._host_names = (np.ascontiguousarray(names), offs)
+        if self._db is None and s.n_reads:
+            t = blob.fastq_table(s.n_reads)
+            self._host_tab = t if keep else None
+
             def write(p, names, offs, order):
                 # the names as they were packed for the index file stay too (up to 1 GiB of them): fq[name] is a hash look-up in C
                 if self._host_tab is not None and names.nbytes <= (1 << 30):
                     self._host_names = (np.ascontiguousarray(names), offs)
                 return fxi.write_fastq_bulk(p, names, offs, t, s.size, order)
-            self._host_names = None
             self._db = _bulk_index(self._index_file, blob, 1, s.n_reads, t["name_off"], t["name_len"], write)
         if self._db is None:
+            if t is None:
+                t = blob.fastq_table(s.n_reads)
             names = []
             step = 1 << 20
             for a in range(0, s.n_reads, step):
@@ -1300,6 +1376,11 @@ class Fastq(_fxobj.FastqCore):
             fxi.write_fastq(self._db, names, t, s.size)
         if self.is_gzip:
             self._st.write_gzindex(self._db)
+        t_done = time.perf_counter()
+        # where the constructor's time went (seconds): the stream to HBM, the index kernels ("index ready": the table is
+        # resident), the index file durable on disk; index_phases has the parts of the last step when the device wrote it
+        self.build_phases = {"staging_s": t_staged - t_begin, "scan_s": t_ready - t_staged, "index_ready_s": t_ready - t_begin,
+                             "fxi_s": t_done - t_ready, "fxi_durable_s": t_done - t_begin, "room_set_aside_early": bool(presized)}
         self._counts, self.size = int(s.n_reads), int(s.size)
         self.avglen = self.size * 1.0 / self._counts if self._counts else float("nan")
 

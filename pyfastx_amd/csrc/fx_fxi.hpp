@@ -197,6 +197,47 @@ struct PageSeq {
     }
 };
 
+
+// ---- the interior levels of a table b-tree over leaves that are (being) written elsewhere: leaf k sits on page
+// seq.at(k) and holds rows [leaf_first[k], leaf_first[k + 1]).  A cell is 4 + varint(rowid) <= 13 bytes, + 2 for its
+// pointer.  Children are spread evenly over the pages of a level, so no page ends up with a single child; the levels
+// follow the leaves in the page sequence, the top level lives in the root page.  (The host formatter below and the
+// device formatter, fx_fxi_dev.hpp, both end here.)
+static inline size_t table_fan(int usable) { return (size_t)((usable - 12) / 15) + 1; }             // children per interior page
+static inline uint64_t table_new_pages(size_t nleaf, size_t fan) {
+    uint64_t total = nleaf;
+    for (size_t K = nleaf; K > fan; K = (K + fan - 1) / fan) total += (K + fan - 1) / fan;
+    return total;
+}
+static bool table_interior(int fd, const FileMap &map, int pagesize, int usable, uint32_t rootpage, const PageSeq &seq,
+                           const int64_t *leaf_first, size_t nleaf, uint64_t total) {
+    std::vector<uint32_t> kids(nleaf);
+    std::vector<int64_t> maxkey(nleaf);
+    for (size_t k = 0; k < nleaf; ++k) { kids[k] = seq.at(k); maxkey[k] = leaf_first[k + 1]; }   // rowid = row + 1
+    uint64_t next_k = nleaf;
+    const size_t fan = table_fan(usable);
+    std::vector<uint8_t> page((size_t)pagesize);
+    bool ok = true;
+    while (ok && kids.size() > fan) {
+        const size_t K = kids.size(), groups = (K + fan - 1) / fan;
+        std::vector<uint32_t> up(groups);
+        std::vector<int64_t> upkey(groups);
+        for (size_t g = 0; g < groups && ok; ++g) {
+            const size_t a = K * g / groups, b = K * (g + 1) / groups;
+            format_interior(page.data(), pagesize, usable, kids, maxkey, a, b, 0);
+            up[g] = seq.at(next_k++);
+            ok = put_page(fd, map, page.data(), pagesize, up[g]);
+            upkey[g] = maxkey[b - 1];
+        }
+        kids.swap(up); maxkey.swap(upkey);
+    }
+    if (ok) {
+        format_interior(page.data(), pagesize, usable, kids, maxkey, 0, kids.size(), 0);
+        ok = put_page(fd, map, page.data(), pagesize, rootpage);
+    }
+    return ok && next_k == total;                            // the page count the file was sized for
+}
+
 static int bulk_load_table(const char *path, uint32_t rootpage, const Rows &r) {
     if (r.ncols < 0 || r.ncols > 16 || r.n < 0 || rootpage < 2) return E_INVAL;
     const int fd = open(path, O_RDWR);
@@ -248,14 +289,8 @@ static int bulk_load_table(const char *path, uint32_t rootpage, const Rows &r) {
         ok = pwrite_all(fd, page.data(), (size_t)pagesize, (off_t)(rootpage - 1) * pagesize);
     } else {
         // ---- page numbers: leaves first, then the interior levels; the top level lives in the root page
-        std::vector<uint32_t> kids(nleaf);
-        std::vector<int64_t> maxkey(nleaf);
         const PageSeq seq(npages + 1, pagesize);
-        for (size_t k = 0; k < nleaf; ++k) { kids[k] = seq.at(k); maxkey[k] = leaf_first[k + 1]; }   // rowid = row + 1
-        uint64_t next_k = nleaf;
-        const size_t fan = (size_t)((usable - 12) / 15) + 1;             // children per interior page
-        uint64_t total = nleaf;                                            // all new pages: the leaves + every interior level but the top
-        for (size_t K = nleaf; K > fan; K = (K + fan - 1) / fan) total += (K + fan - 1) / fan;
+        const uint64_t total = table_new_pages(nleaf, table_fan(usable));          // all new pages: the leaves + every interior level but the top
         FileMap map;
         map.open(fd, (size_t)seq.at(total - 1) * (size_t)pagesize);
         // leaves, in parallel, 256 pages per write
@@ -273,42 +308,23 @@ static int bulk_load_table(const char *path, uint32_t rootpage, const Rows &r) {
                         const size_t b = std::min(nleaf, a + 256);
                         if (map.p) {                         // in place
                             for (size_t k = a; k < b; ++k)
-                                format_leaf(map.p + (size_t)(kids[k] - 1) * (size_t)pagesize, pagesize, usable, r, leaf_first[k], leaf_first[k + 1]);
+                                format_leaf(map.p + (size_t)(seq.at(k) - 1) * (size_t)pagesize, pagesize, usable, r, leaf_first[k], leaf_first[k + 1]);
                             continue;
                         }
                         for (size_t k = a; k < b; ++k)
                             format_leaf(buf.data() + (k - a) * (size_t)pagesize, pagesize, usable, r, leaf_first[k], leaf_first[k + 1]);
                         size_t cut = a + 1;                  // pages a .. cut-1 are adjacent in the file (the skipped page splits a batch)
-                        while (cut < b && kids[cut] == kids[cut - 1] + 1) ++cut;
-                        if (!pwrite_all(fd, buf.data(), (cut - a) * (size_t)pagesize, (off_t)(kids[a] - 1) * pagesize)) err.store(1);
+                        while (cut < b && seq.at(cut) == seq.at(cut - 1) + 1) ++cut;
+                        if (!pwrite_all(fd, buf.data(), (cut - a) * (size_t)pagesize, (off_t)(seq.at(a) - 1) * pagesize)) err.store(1);
                         if (cut < b && !pwrite_all(fd, buf.data() + (cut - a) * (size_t)pagesize, (b - cut) * (size_t)pagesize,
-                                                   (off_t)(kids[cut] - 1) * pagesize)) err.store(1);
+                                                   (off_t)(seq.at(cut) - 1) * pagesize)) err.store(1);
                     }
                 });
             for (auto &x : th) x.join();
             ok = !err.load();
         }
-        // interior levels: a cell is 4 + varint(rowid) <= 13 bytes, + 2 for its pointer.  Children are spread evenly
-        // over the pages of a level, so no page ends up with a single child.
-        while (ok && kids.size() > fan) {
-            const size_t K = kids.size(), groups = (K + fan - 1) / fan;
-            std::vector<uint32_t> up(groups);
-            std::vector<int64_t> upkey(groups);
-            for (size_t g = 0; g < groups && ok; ++g) {
-                const size_t a = K * g / groups, b = K * (g + 1) / groups;
-                format_interior(page.data(), pagesize, usable, kids, maxkey, a, b, 0);
-                up[g] = seq.at(next_k++);
-                ok = put_page(fd, map, page.data(), pagesize, up[g]);
-                upkey[g] = maxkey[b - 1];
-            }
-            kids.swap(up); maxkey.swap(upkey);
-        }
-        if (ok) {
-            format_interior(page.data(), pagesize, usable, kids, maxkey, 0, kids.size(), 0);
-            ok = put_page(fd, map, page.data(), pagesize, rootpage);
-        }
-        if (ok && next_k != total) ok = false;               // the page count the file was sized for
-        npages = seq.at(next_k - 1);
+        if (ok) ok = table_interior(fd, map, pagesize, usable, rootpage, seq, leaf_first.data(), nleaf, total);
+        npages = seq.at(total - 1);
         map.close();
     }
     // ---- file header: size in pages, change counter, "version valid for"
@@ -338,19 +354,22 @@ struct Entries {
     const int64_t *name_off;          // ... n + 1 offsets
     const int64_t *ikey;              // or INTEGER key (names / name_off null): ikey[row]
     const int64_t *order;             // order[i] = 0-based row of the i-th smallest key; its rowid is order[i] + 1
+    const int64_t *rowid = nullptr;   // given (TEXT keys only): names are packed in ENTRY order and entry i carries rowid[i] (order unused)
 };
 static inline int entry_payload(const Entries &e, int64_t i) {
-    const int64_t r = e.order[i];
+    const int64_t r = e.rowid ? i : e.order[i];
+    const int64_t rid = e.rowid ? e.rowid[i] : r + 1;
     int nb, kb;
-    int_serial(r + 1, &nb);
+    int_serial(rid, &nb);
     if (e.ikey) { int_serial(e.ikey[r], &kb); return 1 + 1 + 1 + kb + nb; }
     const int64_t L = e.name_off[r + 1] - e.name_off[r];
     return 1 + varint_len((uint64_t)(13 + 2 * L)) + 1 + (int)L + nb;
 }
 static inline int put_entry(uint8_t *p, const Entries &e, int64_t i) {      // varint(payload) + record(key, rowid)
-    const int64_t r = e.order[i];
+    const int64_t r = e.rowid ? i : e.order[i];
+    const int64_t rid = e.rowid ? e.rowid[i] : r + 1;
     int nb;
-    const int st = int_serial(r + 1, &nb);
+    const int st = int_serial(rid, &nb);
     uint8_t *q = p;
     if (e.ikey) {
         int kb;
@@ -367,7 +386,7 @@ static inline int put_entry(uint8_t *p, const Entries &e, int64_t i) {      // v
         *q++ = (uint8_t)st;
         if (L) { memcpy(q, e.names + e.name_off[r], (size_t)L); q += L; }
     }
-    put_be(q, (uint64_t)(r + 1), nb); q += nb;
+    put_be(q, (uint64_t)rid, nb); q += nb;
     return (int)(q - p);
 }
 
@@ -541,5 +560,107 @@ static int bulk_load_index(const char *path, uint32_t rootpage, const Entries &e
     close(fd);
     return ok ? OK : E_IO;
 }
+
+// ------------------------------------------------------------------ for the device formatter (fx_fxi_dev.hpp)
+// An index-file database opened for appending pages: header checked, size known.
+struct DbFile {
+    int fd = -1;
+    uint8_t hdr[100];
+    int pagesize = 0, usable = 0;
+    uint32_t npages = 0;
+    off_t size0 = 0;
+    int open_rw(const char *path, uint32_t rootpage) {
+        fd = open(path, O_RDWR);
+        if (fd < 0) return E_IO;
+        if (pread(fd, hdr, 100, 0) != 100 || memcmp(hdr, "SQLite format 3", 16) != 0) return E_INVAL;
+        pagesize = (hdr[16] << 8) | hdr[17];
+        if (pagesize == 1) pagesize = 65536;
+        usable = pagesize - hdr[20];
+        struct stat st;
+        if (fstat(fd, &st) != 0) return E_IO;
+        size0 = st.st_size;
+        npages = (uint32_t)(st.st_size / pagesize);
+        // a file that was made longer than its database (room set aside for the pages to come): the header's own count,
+        // valid when "version valid for" equals the change counter (fileformat2 1.3.8), says where the database ends
+        const uint32_t in_hdr = ((uint32_t)hdr[28] << 24) | (hdr[29] << 16) | (hdr[30] << 8) | hdr[31];
+        if (in_hdr && in_hdr < npages && memcmp(hdr + 24, hdr + 92, 4) == 0) npages = in_hdr;
+        if (rootpage < 2 || rootpage > npages || hdr[18] > 1 || hdr[19] > 1 || (hdr[52] | hdr[53] | hdr[54] | hdr[55])) return E_INVAL;
+        return OK;
+    }
+    bool finish(uint32_t new_npages) {                       // file header: size in pages, change counter, "version valid for"
+        uint32_t change = ((uint32_t)hdr[24] << 24) | (hdr[25] << 16) | (hdr[26] << 8) | hdr[27];
+        ++change;
+        put_be(hdr + 24, change, 4);
+        put_be(hdr + 28, new_npages, 4);
+        put_be(hdr + 92, change, 4);
+        return pwrite_all(fd, hdr, 100, 0);
+    }
+    void give_back() { if (fd >= 0) (void)!ftruncate(fd, size0); }     // failure: no orphaned pages behind the database
+    ~DbFile() { if (fd >= 0) close(fd); }
+};
+
+// The levels of an index b-tree ABOVE leaves that are written elsewhere: leaf k sits on page seq.at(k); divider d -- the
+// entry between leaf d and leaf d + 1 -- is entry d of `dv` (names packed in that order, dv.rowid set).  plan() works out
+// the shape (so that the file can be sized before anything is written), write() formats the pages: level 1 follows the
+// leaves in the page sequence, ..., the single page of the top level is the root page.
+struct IndexUpper {
+    std::vector<Level> levels;                               // levels[0] = the level above the leaves
+    std::vector<std::vector<int64_t>> items;                 // items[l][j] = divider (entry of dv) that is item j of that level
+    uint64_t pages = 0;                                      // new pages: every level here but the top one
+    bool plan(size_t nleaf, const Entries &dv, int usable) {
+        levels.clear(); items.clear(); pages = 0;
+        if (nleaf < 2) return true;
+        auto cell = [&](int64_t i) { const int p = entry_payload(dv, i); return p + varint_len((uint64_t)p) + 2 + 4; };
+        std::vector<int64_t> it((size_t)nleaf - 1);
+        for (size_t j = 0; j < it.size(); ++j) it[j] = (int64_t)j;
+        for (;;) {
+            items.push_back(it);
+            const std::vector<int64_t> &cur = items.back();
+            levels.push_back(fill_level((int64_t)cur.size(), usable - 12, [&](int64_t j) { return cell(cur[(size_t)j]); }));
+            const Level &lv = levels.back();
+            if (lv.first.empty()) return false;
+            if (lv.first.size() - 1 <= 1) break;
+            pages += lv.first.size() - 1;
+            std::vector<int64_t> up;
+            for (int64_t d : lv.divider) up.push_back(cur[(size_t)d]);
+            it.swap(up);
+        }
+        return true;
+    }
+    bool write(int fd, const FileMap &map, int pagesize, int usable, uint32_t rootpage, const PageSeq &seq, size_t nleaf, const Entries &dv) const {
+        std::vector<uint8_t> pg((size_t)pagesize);
+        std::vector<uint8_t> tmp(8192);
+        uint64_t next_k = nleaf;
+        std::vector<uint32_t> below(nleaf), here;
+        for (size_t k = 0; k < nleaf; ++k) below[k] = seq.at(k);
+        for (size_t l = 0; l < levels.size(); ++l) {
+            const Level &lv = levels[l];
+            const std::vector<int64_t> &it = items[l];       // item j: divider it[j]; left child = page j of the level below
+            const size_t np = lv.first.size() - 1;
+            here.assign(np, 0);
+            for (size_t k = 0; k < np; ++k) here[k] = (l + 1 == levels.size()) ? rootpage : seq.at(next_k++);
+            for (size_t k = 0; k < np; ++k) {
+                memset(pg.data(), 0, (size_t)pagesize);
+                int64_t a = lv.first[k], b = lv.first[k + 1];
+                if (k + 1 < np) --b;                         // that item is promoted further up
+                int top = usable, c = 0;
+                for (int64_t j = a; j < b; ++j, ++c) {
+                    put_be(tmp.data(), below[(size_t)j], 4);
+                    const int len = 4 + put_entry(tmp.data() + 4, dv, it[(size_t)j]);
+                    top -= len;
+                    memcpy(pg.data() + top, tmp.data(), (size_t)len);
+                    put_be(pg.data() + 12 + 2 * c, (uint64_t)top, 2);
+                }
+                pg[0] = 0x02;
+                put_be(pg.data() + 3, (uint64_t)c, 2);
+                put_be(pg.data() + 5, (uint64_t)(top == 65536 ? 0 : top), 2);
+                put_be(pg.data() + 8, below[(size_t)b], 4);  // right-most child: the page after the last divider kept here
+                if (!put_page(fd, map, pg.data(), pagesize, here[k])) return false;
+            }
+            below.swap(here);
+        }
+        return next_k == nleaf + pages;
+    }
+};
 
 }  // namespace fxi

@@ -38,6 +38,7 @@
 #include "fx_inflate_par.hpp"
 #include "fx_bgzf_walk.hpp"
 #include "fx_fxi.hpp"
+#include "fx_fxi_dev.hpp"
 #include "fx_pgzip.hpp"
 #include "fx_sort.hpp"
 #include "fx_kseq.hpp"
@@ -311,6 +312,10 @@ struct fx_handle {
     DevBuf<KqRec> kq_recs;
     int64_t kq_nrec = -1, kq_lines = 0, kq_seq_bytes = 0, kq_prefix_lines = 0;   // kq_prefix_lines: lines the parallel prefix passes took
     int kq_code = 0;
+    // the sorted order of the record names, kept between fx_fxi_dev_sort and fx_fxi_dev_write (fx_fxi_dev.hpp)
+    DevBuf<int64_t> fxi_order;
+    int fxi_order_kind = -1;
+    int64_t fxi_order_n = 0;
     DevBuf<uint8_t> arena;     // scratch for host-array calls (Staged)
     int64_t arena_used = 0;
     uint8_t *pin_in = nullptr; // pinned staging for the query arrays of host-array calls: pageable source -> here (threads) -> one DMA each
@@ -3656,6 +3661,394 @@ extern "C" int fx_fxi_bulk_index_int(const char *path, int rootpage, int64_t n, 
     const int rc = fxi::bulk_load_index(path, (uint32_t)rootpage, e);
     if (rc == fxi::E_IO) return fail(FX_EIO, "cannot write %s", path);
     if (rc) return fail(FX_EINVAL, "%s is not a SQLite database this loader can extend", path);
+    return FX_OK;
+}
+
+// ------------------------------------------------------------------ the two big b-trees of a .fxi from the device (round 5)
+// fx_fxi_dev_sort + fx_fxi_dev_write: what fx_names_pack + fx_names_sort + fx_fxi_bulk_rows + fx_fxi_bulk_index do through
+// host arrays, with the pages formatted where the table and the names are (fx_fxi_dev.hpp).  Only finished pages cross
+// PCIe: pinned 8 MiB pieces, several threads, each piece copied into the mapping of the file -- grown to its final size
+// and allocated (fallocate) before the first store -- while the next one travels.
+static int fxi_cols(fx_handle *h, int kind, FxiCols *c) {
+    memset(c, 0, sizeof *c);
+    c->gbase = h->base;
+    if (kind == 1) {                                         // read: name, dlen, rlen, soff, qoff (fastq.c:29-36)
+        c->p[0] = h->fq_dlen.p; c->w[0] = 4;
+        c->p[1] = h->fq_rlen.p; c->w[1] = 8;
+        c->p[2] = h->fq_soff.p; c->w[2] = 8;
+        c->p[3] = h->fq_qoff.p; c->w[3] = 8;
+        c->ncols = 4;
+        c->name_off = h->fq_name_off.p; c->name_add = 0; c->name_len = h->fq_name_len.p;
+    } else {                                                 // seq: chrom, boff, blen, slen, llen, elen, norm, dlen (index.c:178-189)
+        c->p[0] = h->fa_boff.p; c->w[0] = 8;
+        c->p[1] = h->fa_blen.p; c->w[1] = 8;
+        c->p[2] = h->fa_slen.p; c->w[2] = 8;
+        c->p[3] = h->fa_llen.p; c->w[3] = 8;
+        c->p[4] = h->fa_elen.p; c->w[4] = 4;
+        c->p[5] = h->fa_norm.p; c->w[5] = 4;
+        c->p[6] = h->fa_dlen.p; c->w[6] = 4;
+        c->ncols = 7;
+        c->name_off = h->hdr.p; c->name_add = 1; c->name_len = h->fa_name_len.p;
+    }
+    return FX_OK;
+}
+
+static int fxi_copy_threads() {
+    static const int n = [] {
+        if (const char *e = getenv("FX_FXI_COPY_THREADS")) { const int v = atoi(e); if (v > 0) return std::min(v, 64); }
+        const unsigned hw = std::thread::hardware_concurrency();
+        return (int)std::min<unsigned>(16u, std::max<unsigned>(4u, hw / 4));
+    }();
+    return n;
+}
+
+// logical pages [k0, k1) of a tree, FXI_PAGE bytes each and back to back at d_img, to their places in the file
+static int fxi_image_out(fx_handle *h, const uint8_t *d_img, int64_t k0, int64_t k1, const fxi::PageSeq &seq, int fd, const fxi::FileMap &map) {
+    const int64_t ppp = PIECE_BYTES / FXI_PAGE, npieces = (k1 - k0 + ppp - 1) / ppp;
+    const int T = (int)std::min<int64_t>(fxi_copy_threads(), std::max<int64_t>(1, npieces));
+    std::atomic<int> err(0);                                 // 1: device, 2: file
+    std::vector<std::thread> th;
+    auto put = [&](const uint8_t *src, int64_t a, int64_t b) {          // pages [a, b) -- adjacent in the file unless the skipped page lies between
+        int64_t cut = b;
+        if ((int64_t)seq.at((uint64_t)(b - 1)) - (int64_t)seq.at((uint64_t)a) != b - 1 - a)
+            for (cut = a + 1; cut < b && seq.at((uint64_t)cut) == seq.at((uint64_t)(cut - 1)) + 1;) ++cut;
+        for (int part = 0; part < 2; ++part) {
+            const int64_t x = part ? cut : a, y = part ? b : cut;
+            if (x >= y) continue;
+            const size_t off = (size_t)(seq.at((uint64_t)x) - 1) * FXI_PAGE, len = (size_t)(y - x) * FXI_PAGE;
+            if (map.p) memcpy(map.p + off, src + (size_t)(x - a) * FXI_PAGE, len);
+            else if (!fxi::pwrite_all(fd, src + (size_t)(x - a) * FXI_PAGE, len, (off_t)off)) err.store(2);
+        }
+    };
+    for (int t = 0; t < T; ++t)
+        th.emplace_back([&, t]() {
+            if (hipSetDevice(h->device) != hipSuccess) { err.store(1); return; }
+            uint8_t *pin[2] = {g_pins.get(), g_pins.get()};
+            hipStream_t st = nullptr;
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            bool ok = pin[0] && pin[1] && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+                      hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+            if (!ok) err.store(1);
+            int64_t pa[2] = {-1, -1}, pb[2] = {0, 0};
+            auto drain = [&](int sl) {
+                if (pa[sl] < 0) return;
+                if (hipEventSynchronize(ev[sl]) != hipSuccess) { err.store(1); pa[sl] = -1; return; }
+                put(pin[sl], pa[sl], pb[sl]);
+                pa[sl] = -1;
+            };
+            int slot = 0;
+            for (int64_t pc = t; ok && pc < npieces && !err.load(); pc += T, slot ^= 1) {
+                const int64_t a = k0 + pc * ppp, b = std::min(k1, a + ppp);
+                drain(slot);
+                if (hipMemcpyAsync(pin[slot], d_img + (size_t)(a - k0) * FXI_PAGE, (size_t)(b - a) * FXI_PAGE, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipEventRecord(ev[slot], st) != hipSuccess) { err.store(1); break; }
+                pa[slot] = a; pb[slot] = b;
+                drain(slot ^ 1);
+            }
+            drain(0); drain(1);
+            if (st) (void)hipStreamSynchronize(st);
+            for (int i = 0; i < 2; ++i) { if (ev[i]) (void)hipEventDestroy(ev[i]); if (pin[i]) g_pins.put(pin[i]); }
+            if (st) (void)hipStreamDestroy(st);
+        });
+    for (auto &x : th) x.join();
+    if (err.load() == 1) return fail(FX_EDEVICE, "device to host copy of index pages failed");
+    if (err.load() == 2) return fail(FX_EIO, "cannot write the index file");
+    return FX_OK;
+}
+
+static int64_t fxi_slab_pages() {                          // pages formatted per kernel launch (HBM the image takes): FX_FXI_SLAB_MB, default 4096
+    const char *e = getenv("FX_FXI_SLAB_MB");
+    const int64_t mb = e ? atoll(e) : 0;
+    return ((mb > 0 ? mb : 4096) << 20) / FXI_PAGE;
+}
+
+static int fxi_check_kind(fx_handle *h, int kind) {
+    if (!h || (kind != 0 && kind != 1)) return fail(FX_EINVAL, "bad argument");
+    if (kind == 0 ? !h->fasta_built : !h->fastq_built) return fail(FX_ESTATE, "the index has not been built");
+    if (kind == 0 && !h->hdr.p) return fail(FX_ESTATE, "names need a scanned index (fx_fasta_build), not an installed table");
+    int rc = use_device(h);
+    if (!rc) rc = finish_build(h);
+    return rc;
+}
+
+extern "C" int fx_fxi_dev_sort(fx_handle *h, int kind, int64_t *n_dup) {
+    int rc = fxi_check_kind(h, kind);
+    if (rc) return rc;
+    if (!n_dup) return fail(FX_EINVAL, "null n_dup");
+    *n_dup = 0;
+    h->fxi_order_kind = -1;
+    const int64_t n = kind == 0 ? h->n_hdr : h->n_reads;
+    if (n == 0) { h->fxi_order_kind = kind; h->fxi_order_n = 0; return FX_OK; }
+    if (n >= 0xFFFFFFFFll) return fail(FX_ERANGE, "too many records for the 32-bit sort index");
+    FxiCols c;
+    fxi_cols(h, kind, &c);
+    const int64_t *noff = c.name_off;
+    if (kind == 0) {
+        if ((rc = h->nm_off.alloc(n))) return rc;
+        hipLaunchKernelGGL(k_add_i64, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, h->hdr.p, (int64_t)1, n, h->nm_off.p);
+        noff = h->nm_off.p;
+    }
+    if ((rc = h->fxi_order.alloc(n))) return rc;
+    DevBuf<int64_t> d_ndup;
+    if ((rc = d_ndup.alloc(1))) return rc;
+    const char *what = "";
+    const int e = sort_names(h->d_data, h->base, noff, c.name_len, n, h->fxi_order.p, d_ndup.p, h->stream, &what);
+    if (e) return fail(e == (int)hipErrorOutOfMemory ? FX_ENOMEM : FX_EDEVICE, "name sort, %s: %s", what, hipGetErrorString((hipError_t)e));
+    HIPCHK(hipMemcpyAsync(n_dup, d_ndup.p, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->fxi_order_kind = kind;
+    h->fxi_order_n = n;
+    return FX_OK;
+}
+
+extern "C" int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int root_table, int root_index, double *laps) {
+    int rc = fxi_check_kind(h, kind);
+    if (rc) return rc;
+    if (!path || root_table < 2 || (root_index != 0 && root_index < 2)) return fail(FX_EINVAL, "bad argument");
+    const int64_t n = kind == 0 ? h->n_hdr : h->n_reads;
+    if (root_index && (h->fxi_order_kind != kind || h->fxi_order_n != n)) return fail(FX_ESTATE, "fx_fxi_dev_sort has not been called for this table");
+    if (n >= 0xFFFFFFFFll) return fail(FX_ERANGE, "too many records");
+    double lap_buf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    static const bool trace = [] { const char *e = getenv("FX_TRACE"); return e && atoi(e) != 0; }();
+    FxiCols c;
+    fxi_cols(h, kind, &c);
+    const uint8_t *data = h->d_data;
+    const int64_t nchunks = (n + FXI_R - 1) / FXI_R;
+    const int64_t nsc = (nchunks + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    DevBuf<uint16_t> sz;
+    DevBuf<int32_t> pages, bad;
+    DevBuf<int64_t> sums, pbase, first_t, first_i;
+    ScratchBuf<uint8_t> slab;
+    auto done = [&](int code) {
+        (void)hipStreamSynchronize(h->stream);
+        h->fxi_order.release(); h->fxi_order_kind = -1;
+        if (laps) memcpy(laps, lap_buf, sizeof lap_buf);
+        return code;
+    };
+    if (n == 0) return done(FX_OK);
+    if ((rc = sz.alloc(n)) || (rc = pages.alloc(nchunks)) || (rc = bad.alloc(1)) || (rc = sums.alloc(nsc + 1)) || (rc = pbase.alloc(nchunks + 1))) return done(rc);
+
+    // shape of one tree's leaf level: sizes are in sz -> nleaf, first[0 .. nleaf]
+    auto leaf_level = [&](bool idx, DevBuf<int64_t> &first, int64_t *nleaf_out) -> int {
+        if (idx) hipLaunchKernelGGL((k_fxi_fill<true, false>), dim3((unsigned)nchunks), dim3(64), 0, h->stream, sz.p, n, FXI_PAGE - 8, pages.p, (const int64_t *)nullptr, (int64_t *)nullptr);
+        else hipLaunchKernelGGL((k_fxi_fill<false, false>), dim3((unsigned)nchunks), dim3(64), 0, h->stream, sz.p, n, FXI_PAGE - 8, pages.p, (const int64_t *)nullptr, (int64_t *)nullptr);
+        hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)nsc), dim3(BLOCK), 0, h->stream, pages.p, nchunks, sums.p);
+        hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, sums.p, nsc);
+        hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)nsc), dim3(BLOCK), 0, h->stream, pages.p, nchunks, sums.p, pbase.p);
+        HIPCHK(hipGetLastError());
+        int64_t nleaf = 0;
+        int isbad = 0;
+        HIPCHK(hipMemcpyAsync(&nleaf, pbase.p + nchunks, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(&isbad, bad.p, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (isbad) return fail(FX_ERANGE, idx ? "an index entry does not fit a b-tree page without overflow: use CREATE INDEX"
+                                              : "a row does not fit a b-tree page without overflow: use the INSERT path");
+        int r2 = first.alloc(nleaf + 1);
+        if (r2) return r2;
+        if (idx) hipLaunchKernelGGL((k_fxi_fill<true, true>), dim3((unsigned)nchunks), dim3(64), 0, h->stream, sz.p, n, FXI_PAGE - 8, (int32_t *)nullptr, pbase.p, first.p);
+        else hipLaunchKernelGGL((k_fxi_fill<false, true>), dim3((unsigned)nchunks), dim3(64), 0, h->stream, sz.p, n, FXI_PAGE - 8, (int32_t *)nullptr, pbase.p, first.p);
+        HIPCHK(hipGetLastError());
+        *nleaf_out = nleaf;
+        return FX_OK;
+    };
+    // the leaves [0, nleaf) of one tree to the file, slab by slab
+    auto leaves_out = [&](bool idx, int64_t nleaf, const int64_t *first, const fxi::PageSeq &seq, int fd, const fxi::FileMap &map, double *t_kern, double *t_copy) -> int {
+        const int64_t S = std::min(nleaf, fxi_slab_pages());
+        int r2 = slab.alloc(h->device, S * FXI_PAGE, h->stream);
+        if (r2) return r2;
+        for (int64_t k0 = 0; k0 < nleaf; k0 += S) {
+            const int64_t k1 = std::min(nleaf, k0 + S);
+            const auto t0 = now();
+            const unsigned grid = (unsigned)std::min<int64_t>((k1 - k0 + 3) / 4, 16384);
+            if (idx) hipLaunchKernelGGL(k_fxi_index_leaves, dim3(grid), dim3(BLOCK), 0, h->stream, c, data, (const int64_t *)h->fxi_order.p, first, nleaf, n, k0, k1, slab.p);
+            else hipLaunchKernelGGL(k_fxi_table_leaves, dim3(grid), dim3(BLOCK), 0, h->stream, c, data, first, k0, k1, slab.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(h->stream));
+            const auto t1 = now();
+            if ((r2 = fxi_image_out(h, slab.p, k0, k1, seq, fd, map))) return r2;
+            *t_kern += secs(t0, t1); *t_copy += secs(t1, now());
+        }
+        return FX_OK;
+    };
+    // a tree of ONE leaf lives in its root page
+    auto root_leaf = [&](bool idx, const int64_t *first, int fd, int rootpage) -> int {
+        int r2 = slab.alloc(h->device, FXI_PAGE, h->stream);
+        if (r2) return r2;
+        if (idx) hipLaunchKernelGGL(k_fxi_index_leaves, dim3(1), dim3(BLOCK), 0, h->stream, c, data, (const int64_t *)h->fxi_order.p, first, (int64_t)1, n, (int64_t)0, (int64_t)1, slab.p);
+        else hipLaunchKernelGGL(k_fxi_table_leaves, dim3(1), dim3(BLOCK), 0, h->stream, c, data, first, (int64_t)0, (int64_t)1, slab.p);
+        std::vector<uint8_t> pg(FXI_PAGE);
+        HIPCHK(hipMemcpyAsync(pg.data(), slab.p, FXI_PAGE, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (!fxi::pwrite_all(fd, pg.data(), FXI_PAGE, (off_t)(rootpage - 1) * FXI_PAGE)) return fail(FX_EIO, "cannot write %s", path);
+        return FX_OK;
+    };
+
+    const auto t0 = now();
+    fxi::DbFile db;
+    {
+        const int e = db.open_rw(path, (uint32_t)root_table);
+        if (e == fxi::E_IO) return done(fail(FX_EIO, "cannot open %s", path));
+        if (e || db.pagesize != FXI_PAGE || db.usable != FXI_PAGE || (root_index && (uint32_t)root_index > db.npages))
+            return done(fail(FX_EINVAL, "%s is not a SQLite database this loader can extend (4 KiB pages, no reserved bytes)", path));
+    }
+    // ================================================================ shapes: which row on which leaf of the table, which entry on which leaf of the index
+    int64_t nleaf_t = 0, nleaf_i = 0;
+    HIPCHK(hipMemsetAsync(bad.p, 0, 4, h->stream));
+    hipLaunchKernelGGL(k_fxi_cell_sizes, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, c, n, sz.p, bad.p);
+    if ((rc = leaf_level(false, first_t, &nleaf_t))) return done(rc);
+    std::vector<int64_t> lf((size_t)nleaf_t + 1);
+    HIPCHK(hipMemcpyAsync(lf.data(), first_t.p, (size_t)(nleaf_t + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const auto t1 = now();
+    lap_buf[0] = secs(t0, t1);
+    // the dividers of the index -- (name, rowid) of the entry between leaf d and leaf d + 1 -- for the levels the host writes
+    std::vector<int64_t> d_rowid(1), d_off(1, 0);
+    std::vector<uint8_t> d_names(1);
+    fxi::IndexUpper up;
+    int64_t nd = 0;
+    if (root_index) {
+        hipLaunchKernelGGL(k_fxi_entry_sizes, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, c, (const int64_t *)h->fxi_order.p, n, sz.p, bad.p);
+        if ((rc = leaf_level(true, first_i, &nleaf_i))) return done(rc);
+        nd = nleaf_i - 1;
+        d_rowid.assign((size_t)std::max<int64_t>(nd, 1), 0);
+        d_off.assign((size_t)nd + 1, 0);
+        if (nd > 0) {
+            DevBuf<int64_t> drow, doff, dsum;
+            DevBuf<int32_t> dlen;
+            DevBuf<uint8_t> dnm;
+            const int64_t ndc = (nd + SCAN_CHUNK - 1) / SCAN_CHUNK;
+            if ((rc = drow.alloc(nd)) || (rc = dlen.alloc(nd)) || (rc = doff.alloc(nd + 1)) || (rc = dsum.alloc(ndc + 1))) return done(rc);
+            hipLaunchKernelGGL(k_fxi_divider_rows, dim3(nblocks(nd, BLOCK)), dim3(BLOCK), 0, h->stream, c, (const int64_t *)h->fxi_order.p, (const int64_t *)first_i.p, nd, drow.p, dlen.p);
+            hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)ndc), dim3(BLOCK), 0, h->stream, dlen.p, nd, dsum.p);
+            hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, dsum.p, ndc);
+            hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)ndc), dim3(BLOCK), 0, h->stream, dlen.p, nd, dsum.p, doff.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(d_off.data(), doff.p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(d_rowid.data(), drow.p, (size_t)nd * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            const int64_t tot = d_off[(size_t)nd];
+            d_names.resize((size_t)std::max<int64_t>(tot, 1));
+            if (tot) {
+                if ((rc = dnm.alloc(tot))) return done(rc);
+                hipLaunchKernelGGL(k_fxi_divider_names, dim3(nblocks(nd, BLOCK)), dim3(BLOCK), 0, h->stream, c, data, (const int64_t *)drow.p, (const int64_t *)doff.p, nd, dnm.p);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(d_names.data(), dnm.p, (size_t)tot, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+            }
+            for (auto &r : d_rowid) r += 1;                  // row -> rowid
+        }
+    }
+    const fxi::Entries dv{nd, d_names.data(), d_off.data(), nullptr, nullptr, d_rowid.data()};
+    if (root_index && !up.plan((size_t)nleaf_i, dv, FXI_PAGE)) return done(fail(FX_ERANGE, "an index entry does not fit an interior page: use CREATE INDEX"));
+    const auto t2 = now();
+    lap_buf[4] = secs(t1, t2);
+
+    // ================================================================ the page sequence: table leaves, table interior levels, index leaves, index upper levels
+    const uint64_t tot_t = nleaf_t > 1 ? fxi::table_new_pages((size_t)nleaf_t, fxi::table_fan(FXI_PAGE)) : 0;
+    const uint64_t tot_i = nleaf_i > 1 ? (uint64_t)nleaf_i + up.pages : 0;
+    const uint64_t total = tot_t + tot_i;
+    const fxi::PageSeq seq(db.npages + 1, FXI_PAGE);
+    if (total && (uint64_t)seq.at(total - 1) >= 0xFFFFFFF0ull) return done(fail(FX_ERANGE, "the index file would exceed 2^32 pages"));
+    bool ok = true;
+    fxi::FileMap map;
+    uint32_t new_npages = db.npages;
+    if (total) {
+        // All new pages are allocated BEFORE anything is stored into them: on tmpfs fallocate alone runs at 16-18 GB/s and
+        // sixteen threads then copy into the mapping at 15 GB/s, while page allocation and faults running side by side
+        // (a fallocate thread ahead of the writers, or first touches through the mapping) reach 3-4 GB/s together
+        // (tools/filewrite_probe2.c: 10 GB in 1.3 s against 2.6-3.8 s).  A file that already has the room (pre-sized by the
+        // caller while the stream was staged) skips this.
+        new_npages = seq.at(total - 1);
+        const off_t end = (off_t)new_npages * FXI_PAGE, from = (off_t)db.npages * FXI_PAGE;
+        const bool presized = db.size0 >= end;
+        if (presized || map.open(db.fd, (size_t)end)) {
+            if (presized) { void *m = mmap(nullptr, (size_t)end, PROT_READ | PROT_WRITE, MAP_SHARED, db.fd, 0); if (m != MAP_FAILED) { map.p = (uint8_t *)m; map.len = (size_t)end; } }
+            // (only what a pre-sized file lacks: fallocate over pages that exist still visits every one of them, 0.2 us each)
+            const off_t have = std::max(from, db.size0 & ~(off_t)(FXI_PAGE - 1));
+            if (map.p && !presized && have < end && !getenv("FX_FXI_NO_FALLOCATE")) (void)fallocate(db.fd, 0, have, end - have);
+        }
+    }
+    const auto t3 = now();
+    lap_buf[3] = secs(t2, t3);                               // file grown and allocated
+    // the host's share -- interior levels of the table, upper levels of the index -- in two threads beside the copy-out
+    const fxi::PageSeq seq_i(total && tot_t ? seq.at(tot_t) : db.npages + 1, FXI_PAGE);     // (a sequence that starts behind the table's pages skips the same page)
+    std::atomic<int> host_bad(0);
+    std::thread th_t, th_i;
+    if (nleaf_t > 1)
+        th_t = std::thread([&]() { if (!fxi::table_interior(db.fd, map, FXI_PAGE, FXI_PAGE, (uint32_t)root_table, seq, lf.data(), (size_t)nleaf_t, tot_t)) host_bad.store(1); });
+    if (nleaf_i > 1)
+        th_i = std::thread([&]() { if (!up.write(db.fd, map, FXI_PAGE, FXI_PAGE, (uint32_t)root_index, seq_i, (size_t)nleaf_i, dv)) host_bad.store(1); });
+    if (nleaf_t == 1) rc = root_leaf(false, first_t.p, db.fd, root_table);
+    else rc = leaves_out(false, nleaf_t, first_t.p, seq, db.fd, map, &lap_buf[1], &lap_buf[2]);
+    if (!rc && root_index) {
+        if (nleaf_i == 1) rc = root_leaf(true, first_i.p, db.fd, root_index);
+        else rc = leaves_out(true, nleaf_i, first_i.p, seq_i, db.fd, map, &lap_buf[5], &lap_buf[6]);
+    }
+    const auto t4 = now();
+    if (th_t.joinable()) th_t.join();
+    if (th_i.joinable()) th_i.join();
+    if (host_bad.load()) ok = false;
+    const auto t5 = now();
+    // Taking the mapping down walks every page table entry of it (0.25 s for 10 GB of dirty shared pages) and nothing waits
+    // for the result: the pages are in the file's page cache either way.  It is left to a thread of its own.
+    if (map.p && !getenv("FX_FXI_SYNC_UNMAP")) {
+        uint8_t *mp = map.p;
+        const size_t ml = map.len;
+        map.p = nullptr;
+        std::thread([mp, ml]() { munmap(mp, ml); }).detach();
+    }
+    map.close();
+    const auto t6 = now();
+    if (trace) fprintf(stderr, "[fxgpu] fxi: host levels joined after %.1f ms, mapping released in %.1f ms\n", secs(t4, t5) * 1e3, secs(t5, t6) * 1e3);
+    if (!rc && ok) ok = db.finish(new_npages);
+    if (!rc && ok && db.size0 > (off_t)new_npages * FXI_PAGE) ok = ftruncate(db.fd, (off_t)new_npages * FXI_PAGE) == 0;     // a pre-sized file: cut to what was used
+    if (rc || !ok) db.give_back();
+    lap_buf[7] = secs(t4, now());
+    if (rc) return done(rc);
+    if (!ok) return done(fail(FX_EIO, "cannot write %s", path));
+    if (trace) fprintf(stderr, "[fxgpu] fxi pages from the device: %lld rows, %lld + %lld leaves, %llu pages: table shape %.1f ms, index shape + dividers %.1f ms, file grown %.1f ms, "
+                               "table kernels %.1f + copy-out %.1f ms, index kernels %.1f + copy-out %.1f ms, rest of the host levels + header %.1f ms\n",
+                       (long long)n, (long long)nleaf_t, (long long)nleaf_i, (unsigned long long)total, lap_buf[0] * 1e3, lap_buf[4] * 1e3, lap_buf[3] * 1e3,
+                       lap_buf[1] * 1e3, lap_buf[2] * 1e3, lap_buf[5] * 1e3, lap_buf[6] * 1e3, lap_buf[7] * 1e3);
+    return done(FX_OK);
+}
+
+// Room for the pages to come, set aside WHILE THE STREAM IS STAGED: the caller that knows roughly how large the index file
+// will be (an estimate from the head of the input) has SQLite create the database, then lets a thread of this library
+// fallocate the file to that size -- 0.6 s for 10 GB that fx_fxi_dev_write would otherwise spend between the kernels and
+// the first page it stores.  The database header still says where the database ends (fx_fxi.hpp: DbFile); fx_fxi_dev_write
+// cuts the file to what it used.  Best effort: a file system without fallocate, or no space, just leaves the file as it is.
+struct FxiPresize {
+    std::thread th;
+    std::atomic<bool> stop{false};
+};
+extern "C" int fx_fxi_presize_begin(const char *path, int64_t bytes, void **token) {
+    if (!path || !token || bytes < 0) return fail(FX_EINVAL, "bad argument");
+    *token = nullptr;
+    const int fd = open(path, O_RDWR);
+    if (fd < 0) return fail(FX_EIO, "cannot open %s", path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return fail(FX_EIO, "cannot stat %s", path); }
+    FxiPresize *p = new FxiPresize();
+    const off_t from = st.st_size, to = (off_t)bytes;
+    p->th = std::thread([p, fd, from, to]() {
+        const off_t step = 256ll << 20;
+        for (off_t o = from; o < to && !p->stop.load(); o += step)
+            if (fallocate(fd, 0, o, std::min(step, to - o)) != 0) break;
+        close(fd);
+    });
+    *token = p;
+    return FX_OK;
+}
+extern "C" int fx_fxi_presize_end(void *token, int cancel) {
+    FxiPresize *p = (FxiPresize *)token;
+    if (!p) return FX_OK;
+    if (cancel) p->stop.store(true);
+    if (p->th.joinable()) p->th.join();
+    delete p;
     return FX_OK;
 }
 

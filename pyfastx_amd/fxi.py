@@ -227,6 +227,176 @@ def _bulk_table(path, ddl, table, index_sql, index_name, packed_names, name_off,
     return db
 
 
+def _bulk_table_dev(path, blob, kind, ddl, table, index_sql, index_name, schema_done=False):
+    """_bulk_table with the pages formatted ON THE DEVICE (Blob.fxi_dev_sort / fxi_dev_write, csrc/fx_fxi_dev.hpp): the
+    record table, the names and their sorted order stay in HBM, only finished pages come to the file.  Duplicate names:
+    the table alone is written and SQLite is asked for the index, whose failure is ignored (index.c:363-366,
+    fastq.c:152-156).  schema_done: the file exists with the tables of `ddl` in it (presize_fastq).  Returns (open
+    connection, phases in seconds); on FX_ERANGE / FX_EINVAL (a row that needs an overflow page, a database that does not
+    have 4 KiB pages) the file is removed and the error re-raised -- the caller falls back to the host loaders."""
+    try:
+        ndup = blob.fxi_dev_sort(kind)
+        db = connect(path)
+        if not schema_done:
+            db.executescript(ddl)
+        if not ndup:
+            db.execute(index_sql)
+        root = dict(db.execute("SELECT name, rootpage FROM sqlite_master").fetchall())
+        db.close()
+        laps = blob.fxi_dev_write(kind, path, root[table], 0 if ndup else root[index_name])
+    except BaseException:
+        if os.path.exists(path):
+            os.remove(path)
+        raise
+    db = connect(path)
+    db.execute("PRAGMA synchronous = OFF")
+    if ndup:
+        try:
+            db.execute(index_sql)
+        except sqlite3.Error:
+            pass
+    return db, laps
+
+
+def _varint_len(v):
+    n = 1
+    while v > 0x7F and n < 9:
+        v >>= 7
+        n += 1
+    return n
+
+
+def _int_bytes(v):
+    """Bytes of the body of an INTEGER value in a record (fileformat2 2.1)."""
+    if v in (0, 1):
+        return 0
+    for lim, nb in ((127, 1), (32767, 2), (8388607, 3), (2147483647, 4), (140737488355327, 6)):
+        if v <= lim:
+            return nb
+    return 8
+
+
+def _fastq_window_shape(buf, at_start, full_name):
+    """Mean (bytes per record, name length, header-line length, read length) of the four-line records in a window of a
+    FASTQ file; the window may begin anywhere (at_start: at the first byte of the file).  None when no phase of four makes
+    every complete record of the window look like one ('@' line, then a '+' line two lines on)."""
+    import numpy as np
+    nl = np.flatnonzero(buf == 10)
+    if nl.size < 12:
+        return None
+    starts = nl[:-1] + 1                                      # starts[i] = first byte of the line that ends at nl[i + 1]
+    if at_start:
+        starts = np.concatenate([[0], starts])
+        ends = nl
+    else:
+        ends = nl[1:]
+    m = starts.size
+    first = buf[starts]
+    for ph in range(1 if at_start else 4):
+        k = (m - ph) // 4
+        if k < 2:
+            continue
+        h = starts[ph: ph + 4 * k: 4]
+        if (first[ph: ph + 4 * k: 4] == ord("@")).all() and (first[ph + 2: ph + 4 * k: 4] == ord("+")).all():
+            he = ends[ph: ph + 4 * k: 4]
+            ss, se = starts[ph + 1: ph + 4 * k: 4], ends[ph + 1: ph + 4 * k: 4]
+            per = float(ends[ph + 4 * k - 1] + 1 - h[0]) / k
+            kk = min(k, 1024)
+            L = dl = 0.0
+            for s0, e0 in zip(h[:kk].tolist(), he[:kk].tolist()):
+                line = bytes(buf[s0 + 1:e0])
+                if line.endswith(b"\r"):
+                    line = line[:-1]
+                dl += len(line)
+                if not full_name:
+                    for sep in (b" ", b"\t"):
+                        i = line.find(sep)
+                        if i >= 0:
+                            line = line[:i]
+                L += len(line)
+            cr = int(buf[se[0] - 1] == 13) if se[0] > 0 else 0
+            return per, L / kk, dl / kk, float((se[:kk] - ss[:kk]).mean()) - cr
+    return None
+
+
+def estimate_fastq_index_bytes(path, full_name=False, head=1 << 19, places=8):
+    """How large the index file of a plain FASTQ file will be, from `places` windows of `head` bytes spread over it:
+    reads are taken as four lines, the name ends at the first white space; cells and entries are sized as
+    fx_fxi_dev.hpp sizes them, with the offsets and rowids of each window's place in the file.  None when a window
+    does not look like four-line records.  (Only used to set room aside early -- presize_fastq; a wrong guess costs
+    time, never correctness.)"""
+    import numpy as np
+    size = os.path.getsize(path)
+    if size < 64:
+        return None
+    shapes = []
+    with open(path, "rb") as f:
+        for j in range(places):
+            off = 0 if j == 0 else min(int(size * j / places), max(size - head, 0))
+            f.seek(off)
+            sh = _fastq_window_shape(np.frombuffer(f.read(head), dtype=np.uint8), off == 0, full_name)
+            if sh is None:
+                return None
+            shapes.append((off, sh))
+            if size <= head:
+                break
+    per_mean = sum(sh[0] for _, sh in shapes) / len(shapes)
+    n = size / per_mean
+    pages = 0.0
+    for j, (off, (per, L, dl, rl)) in enumerate(shapes):
+        mid = int(off + min(size / len(shapes), size - off) / 2)
+        rid = max(int(n * mid / size), 1)
+        tl = _varint_len(13 + 2 * int(round(L)))
+        payload = 2 + tl + 4 + L + _int_bytes(int(dl)) + _int_bytes(int(rl)) + 2 * _int_bytes(mid)
+        cell = _varint_len(int(payload)) + _varint_len(rid) + payload + 2
+        ent_payload = 1 + tl + 1 + L + _int_bytes(rid)
+        ent = _varint_len(int(ent_payload)) + ent_payload + 2
+        rows = n / len(shapes)
+        pages += rows / int(4088 / cell) * 1.005 + rows / (int(4088 / ent) + 1) * 1.005
+    pages *= 1.0 + 1.0 / 250                                  # interior levels
+    return int(pages * 4096)
+
+
+def presize_fastq(path, input_path, full_name=False):
+    """The index file of a LARGE plain FASTQ input created early -- schema in place -- and grown in the background to
+    98.5 % of its estimated size while the input is staged (fx_fxi_presize_begin).  -> token for _lib.fxi_presize_end, or
+    None when nothing was done (a small input, no estimate).  The caller removes the file if the build fails."""
+    from . import _lib
+    if os.path.getsize(input_path) < int(os.environ.get("FX_FXI_PRESIZE_MIN", 1 << 30)):
+        return None
+    est = estimate_fastq_index_bytes(input_path, full_name)
+    if not est:
+        return None
+    try:
+        st = os.statvfs(os.path.dirname(os.path.abspath(path)) or ".")
+        if st.f_bavail * st.f_frsize < est * 1.1 + (64 << 20):
+            return None
+    except OSError:
+        return None
+    db = connect(path)
+    db.executescript(FASTQ_DDL)
+    db.close()
+    try:
+        return _lib.fxi_presize_begin(path, int(est * 0.985))
+    except _lib.FxError:
+        return None
+
+
+def write_fastq_dev(path, blob, n, size, schema_done=False):
+    """The result of write_fastq (fastq.c:76-171) through _bulk_table_dev: `read` and `readidx` from the device."""
+    db, laps = _bulk_table_dev(path, blob, 1, FASTQ_DDL, "read", "CREATE UNIQUE INDEX readidx ON read (name)", "readidx", schema_done)
+    avg = size * 1.0 / n if n else float("nan")              # fastq.c:161
+    db.execute("INSERT INTO stat VALUES (?,?,?)", (int(n), int(size), avg))
+    return db, laps
+
+
+def write_fasta_dev(path, blob, n, seqlen_total):
+    """The result of write_fasta (index.c:226-251, 342-372) through _bulk_table_dev: `seq` and `chromidx` from the device."""
+    db, laps = _bulk_table_dev(path, blob, 0, FASTA_DDL, "seq", "CREATE UNIQUE INDEX chromidx ON seq (chrom)", "chromidx")
+    db.execute("INSERT INTO stat (seqnum,seqlen) VALUES (?,?)", (int(n), int(seqlen_total)))
+    return db, laps
+
+
 def write_fastq_bulk(path, packed_names, name_off, cols, size, order=None, threads=8):
     """The result of write_fastq (fastq.c:76-171) through _bulk_table.  packed_names uint8 + name_off int64[n+1]:
     the read names back to back; cols as for write_fastq."""

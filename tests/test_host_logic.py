@@ -1568,3 +1568,49 @@ def test_native_framing_helpers_write_the_bytes_of_the_python_ones():
         assert a == synth.bgzf_compress(r.tobytes()) and gzip.decompress(a) == r.tobytes(), n
         g = bytes(synth.gzip_single_stream_parallel(r, piece=1 << 18))
         assert g == bytes(synth.gzip_single_stream(r, piece=1 << 18)) and gzip.decompress(g) == r.tobytes(), n
+
+
+@pytest.mark.parametrize("shape", ["illumina", "short_names", "crlf_long"])
+def test_fxi_size_estimate_from_the_head_of_a_fastq(tmp_path, shape):
+    """fxi.estimate_fastq_index_bytes (room set aside for the index file while the input is staged) against the size
+    of the index file the page loaders really write for the same records: within 3 %."""
+    from pyfastx_amd import fxi
+    rng = np.random.default_rng(4)
+    n = 120_000
+    if shape == "illumina":
+        recs = [b"@SYN:1:FC:1:%04d:%05d:%09d 1:N:0:ACGT\n%s\n+\n%s\n" % (i % 9999, (i * 7919) % 100000, i, b"A" * 150, b"I" * 150) for i in range(n)]
+    elif shape == "short_names":
+        recs = [b"@r%d\n%s\n+\n%s\n" % (i, b"ACGT" * 9, b"IIII" * 9) for i in range(n)]
+    else:
+        recs = [b"@%s/%d some comment here\r\n%s\r\n+\r\n%s\r\n" % (b"x" * 80, i, b"ACGT" * 60, b"IIII" * 60) for i in range(n)]
+    raw = b"".join(recs)
+    p = tmp_path / "e.fq"
+    p.write_bytes(raw)
+    est = fxi.estimate_fastq_index_bytes(str(p), head=1 << 20)
+    # the real thing: rows as the index builder gives them, written by the host page loaders
+    names, soff, qoff, dlen, rlen = [], [], [], [], []
+    pos = 0
+    eol = 2 if shape == "crlf_long" else 1
+    for r in recs:
+        h = r.index(b"\n")
+        line = r[1:h + 1 - eol]
+        names.append(line.split()[0])
+        dlen.append(len(line))
+        s2 = r.index(b"\n", h + 1)
+        rlen.append(s2 - h - eol)
+        soff.append(pos + h + 1)
+        q = r.index(b"\n", s2 + 1)
+        qoff.append(pos + q + 1)
+        pos += len(r)
+    cols = {k: np.asarray(v, dtype=np.int64) for k, v in (("dlen", dlen), ("rlen", rlen), ("soff", soff), ("qoff", qoff))}
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in names], out=offs[1:])
+    order = np.array(sorted(range(n), key=lambda i: names[i]), dtype=np.int64)
+    out = str(tmp_path / "e.fxi")
+    fxi.write_fastq_bulk(out, np.frombuffer(b"".join(names), dtype=np.uint8), offs, cols, int(cols["rlen"].sum()), order=order).close()
+    real = os.path.getsize(out)
+    assert abs(est - real) <= 0.03 * real, (est, real)
+    # a head that is not made of four-line records gives no estimate
+    q = tmp_path / "odd.fq"
+    q.write_bytes(b"@a\nAC\nGT\n+\nII\nII\n" * 1000)
+    assert fxi.estimate_fastq_index_bytes(str(q)) is None
