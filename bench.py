@@ -354,10 +354,13 @@ def leg_c3(a, dev, tmpdir):
     got = fq.fetch_many(sid, want=("seq", "qual", "quali"))
     t2 = time.perf_counter()
     ours = _tables(path + ".fxi", ("read", "stat", "base", "meta"))
+    ctor_ph = {k: round(v, 4) for d in (getattr(fq, "ctor_phases", None), getattr(fq, "build_phases", None)) if d for k, v in d.items() if isinstance(v, float)}
     del fq
     _rm(path + ".fxi")
     smp = {"reads": m, "file_bytes": os.path.getsize(path), "Fastq_ctor_full_index_s": round(t1 - t0, 3),
-           "fetch_many_%d_s" % nqs: round(t2 - t1, 4)}
+           "fetch_many_%d_s" % nqs: round(t2 - t1, 4),
+           # (one run of round 4 showed 5.9 s here against 0.17 s in all others: the parts are in the line since round 5)
+           "ctor_phases_s": ctor_ph}
     ref = None if a.no_cpu_baseline else _reference()
     if ref is not None:
         t0 = time.perf_counter()

@@ -206,6 +206,14 @@ int fx_fastq_build(fx_handle *h, fx_fastq_summary *out);
  * only hands the counts out; when any guess was wrong (or the file has what the stream form does not do: CRLF, bytes outside
  * '!'..127 in a quality line) it counts from the read table as if this had been fx_fastq_build.  Whole streams only. */
 int fx_fastq_build_comp(fx_handle *h, fx_fastq_summary *out);
+/* How the last fx_fastq_build_comp counted: *runs = runs of 64 KiB the stream was cut into, each counted on a GUESS of its line
+ * phase (a '+' line of one byte, or '+' and '\r'); *recounted = runs whose guess the newline prefixes proved wrong or that had
+ * none -- counted again from the prefixes (-1: too many of them, nothing of the one-read result was used); *one_read = 1 when
+ * fx_fastq_comp answers from the build's counters, 0 when it reads the stream again through the read table (a quality byte
+ * outside '!'..127, a '\r' that is not the end of its line: fastq.c:731-745's quirks are the table kernels').  The reference
+ * has no counterpart (its loop fastq.c:715-753 is one pass of its own over the file). */
+int fx_fastq_comp_info(fx_handle *h, int64_t *runs, int64_t *recounted, int *one_read);
+
 
 /* Sharded FASTQ: records are short, so a shard carries a HALO -- the first
  * bytes of the next shard appended to its own range (fx_set_halo) -- and owns every record

@@ -47,7 +47,7 @@ class ShardSummary(C.Structure):
 SYMBOLS = [
     "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_file_indexed", "fx_gz_checkpoints", "fx_stream_size", "fx_open_file_range", "fx_open_host", "fx_open_device",
     "fx_set_shard", "fx_close", "fx_release_scratch", "fx_pinned_alloc", "fx_pinned_free", "fx_pinned_holds", "fx_pinned_trim", "fx_size", "fx_device_memory", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
-    "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_line_regular", "fx_fasta_len_stats", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_fastq_build_comp", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
+    "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_line_regular", "fx_fasta_len_stats", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_fastq_build_comp", "fx_fastq_comp_info", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fasta_fetch_alloc", "fx_fetch_phases", "fx_fastq_fetch", "fx_fastq_fetch_alloc", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
     "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_fxi_dev_sort", "fx_fxi_dev_write", "fx_fxi_presize_begin", "fx_fxi_presize_end", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
     "fx_comm_unique_id", "fx_comm_init", "fx_comm_destroy", "fx_comm_rank", "fx_comm_world", "fx_comm_allgather", "fx_fasta_build_sharded_begin",
@@ -192,6 +192,7 @@ def lib():
     L.fx_fxi_bulk_rows.argtypes = [C.c_char_p, i32, i64, vp, vp, i32, vp]
     L.fx_fxi_bulk_index.argtypes = [C.c_char_p, i32, i64, vp, vp, vp]
     L.fx_fxi_bulk_index_int.argtypes = [C.c_char_p, i32, i64, vp, vp]
+    L.fx_fastq_comp_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
     L.fx_fxi_dev_sort.argtypes = [vp, i32, C.POINTER(C.c_int64)]
     L.fx_fxi_dev_write.argtypes = [vp, i32, C.c_char_p, i32, i32, C.POINTER(C.c_double)]
     L.fx_fxi_presize_begin.argtypes = [C.c_char_p, i64, C.POINTER(vp)]
@@ -788,6 +789,12 @@ class Blob:
             check(rc)
             return buf[:total.value], offs
         raise FxError(FX_ERANGE, "names did not fit twice")
+
+    def fastq_comp_info(self):
+        """How the last fastq_build(comp=True) counted -> (runs, runs counted again from the prefixes or -1, one-read result in use)."""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int(0)
+        check(lib().fx_fastq_comp_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), bool(c.value)
 
     def fxi_dev_sort(self, kind):
         """The sorted order of the record names, computed and KEPT on the device for fxi_dev_write -> number of adjacent

@@ -791,10 +791,16 @@ class Fasta(_fxobj.FastaCore):
         except _lib.FxError as e:
             k = getattr(e, "first_bad", -1)
             if e.code != _lib.FX_ERANGE or k < 0:
-                raise
-            if not 0 <= int(ids[k]) < self._seq_counts:
+                raise _fx_to_py(e)
+            # ids first, then intervals -- the order of the sharded path above
+            if ids.size and (ids.min() < 0 or ids.max() >= self._seq_counts):
                 raise IndexError("index out of range")
-            raise ValueError("interval outside the sequence")
+            if (starts < 0).any() or (stops < starts).any() or (stops > np.asarray(t["slen"])[ids]).any():
+                raise ValueError("interval outside the sequence")
+            # every query is valid: one of them is longer than the 2^31 - 1 bytes the device-side layout counts in (a whole
+            # chromosome of a 32 Gbp genome) -- the batch goes through the path that lays the answers out on the host in int64
+            buf, offs, _ = blob.fasta_fetch(ids, starts, stops, flags=fl, flags_per_query=fpq)
+            return buf, offs
 
 
     def _ids_of(self, names_or_ids):
@@ -1230,13 +1236,19 @@ class Fastq(_fxobj.FastqCore):
         self._db = None
         self._counts, self.size, self.avglen = 0, 0, 0.0
         self._meta = None
+        self.build_phases = self.index_phases = None
+        t0 = time.perf_counter()
         if fxi.exists(self._index_file):                                                      # fastq.c:347-351
             self._load_index()
         elif build_index:
             self._create_index()
+        t1 = time.perf_counter()
         if build_index and full_index:
             self._calc_composition()
+        t2 = time.perf_counter()
         self._bind_core()
+        # where the constructor's time went, in seconds (build_phases / index_phases: the parts of the first one)
+        self.ctor_phases = {"index_s": t1 - t0, "composition_s": t2 - t1, "bind_s": time.perf_counter() - t2}
 
     def _bind_core(self):
         """fq[i] / fq[name] from C once the index is a file on disk (csrc/fxobj.c: FastqCore)."""
@@ -1300,7 +1312,6 @@ class Fastq(_fxobj.FastqCore):
 
     def _create_index_body(self, presized, tok):
         t_begin = time.perf_counter()
-        self.build_phases = None
         wq = self._st.md
         if presized and wq is not None:                       # (built in windows after all: that route writes its own file)
             _lib.fxi_presize_end(tok, cancel=True)

@@ -361,6 +361,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines(const uint8_t *__restrict
 
 // The fields the line record r of line idx determines (line i of its granule, which begins at global offset gs; q =
 // global offset of the newline before it), into row idx >> 2 of the table when the shard owns it.
+template <bool NT = false>
 __device__ __forceinline__ void fq_row_of_line(const ScanCtx &x, const FqOwn &own, const FqTab &t, int64_t gs, bool first_of_granule, uint32_t r,
                                                int64_t q, int64_t idx) {
     const int64_t p = gs + (r & 0xFFFu);
@@ -382,13 +383,18 @@ __device__ __forceinline__ void fq_row_of_line(const ScanCtx &x, const FqOwn &ow
             sp = x.gbase + first_space(x.data, nb - x.gbase, ne - x.gbase);
         }
         const int64_t hit = sp < ne ? sp : ne;
+        if (NT) {                                                          // (the table is not read again by this kernel: past the caches)
+            __builtin_nontemporal_store(nb, &t.name_off[row]); __builtin_nontemporal_store((int32_t)(hit - nb), &t.name_len[row]);
+            __builtin_nontemporal_store((int32_t)len, &t.dlen[row]); __builtin_nontemporal_store(p + 1, &t.soff[row]);
+            break;
+        }
         t.name_off[row] = nb; t.name_len[row] = (int32_t)(hit - nb); t.dlen[row] = (int32_t)len;   // fastq.c:103: '@' and '\r' included
         t.soff[row] = p + 1;                                              // fastq.c:122
         break;
     }
-    case 1: t.rlen[row] = len - cr; break;                                // fastq.c:124-128
-    case 2: t.qoff[row] = p + 1; break;                                   // fastq.c:133
-    default: t.qlen[row] = (int32_t)(len - cr); break;                    // quality line, trailing CR dropped (fastq.c:734-737)
+    case 1: if (NT) __builtin_nontemporal_store(len - cr, &t.rlen[row]); else t.rlen[row] = len - cr; break;                                // fastq.c:124-128
+    case 2: if (NT) __builtin_nontemporal_store(p + 1, &t.qoff[row]); else t.qoff[row] = p + 1; break;                                   // fastq.c:133
+    default: if (NT) __builtin_nontemporal_store((int32_t)(len - cr), &t.qlen[row]); else t.qlen[row] = (int32_t)(len - cr); break;      // quality line, trailing CR dropped (fastq.c:734-737)
     }
 }
 
@@ -464,6 +470,96 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_rows(ScanCtx x, FqOwn own, FqTa
 #pragma unroll
             for (int kk = 0; kk < FQR_G; ++kk) first_of_granule |= k == (uint32_t)kk && j == cum[kk];
             fq_row_of_line(x, own, t, gs, first_of_granule, r & 0x03FFFFFFu, q, L0 + j);
+        }
+    }
+}
+
+// ONE LANE PER ROW, A WORKGROUP PER G GRANULES (round 5).  k_fastq_rows gives a wave FQR_G = 4 granules: ~47 lines, ~12 rows -- 12 of
+// its 64 lanes work in the row loop and every column store is a 48-96-byte piece of a 128-byte line (2.3-2.5 ms for C3 where the
+// traffic is worth 0.7).  Here the four waves of a workgroup stage the records of G / 4 runs side by side in LDS, then thread k
+// takes row (first row of the workgroup) + k: ~190 of 256 lanes busy for G = 64 and reads of 150 bases, column stores of 1.5 KB.
+// As in k_fastq_rows a wave asks for the first 64 records of its runs TOGETHER with the granule summaries that say how many of
+// them count (every wave reads all G summaries -- lane = granule -- and scans them itself: no barrier in front of the staging).
+// Bits 26-31 of a staged record: which of the workgroup's granules.  G is chosen by the launch from the stream's line density
+// (FQW_CAP staged records); a workgroup with more lines than that, or with an overflowed granule (its lines are k_fastq_emit's),
+// walks its granules one lane per line, as k_fastq_rows does.
+constexpr int FQW_CAP = 2048;
+template <int G, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_fastq_rows_wg(ScanCtx x, FqOwn own, FqTab t, const uint32_t *__restrict__ recs, int64_t g_end) {
+    static_assert(G % (FQR_G * (BLOCK / 64)) == 0 && G <= 64, "whole runs per wave; six bits for the granule a staged record came from");
+    constexpr int RPW = G / FQR_G / (BLOCK / 64);                          // runs per wave
+    __shared__ uint32_t s_rec[FQW_CAP];
+    __shared__ uint32_t s_cum[G];
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const int64_t g0 = (int64_t)blockIdx.x * G;
+    if (g0 >= g_end) return;
+    const int ng = (int)(g_end - g0 < G ? g_end - g0 : G);
+    uint32_t rr[RPW];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int k0 = (w * RPW + q) * FQR_G;
+        rr[q] = k0 < ng ? recs[((g0 + k0) / FQR_G) * (int64_t)(FQR_G * FQL_CAP) + lane] : 0u;
+    }
+    uint32_t M = 0;
+    bool over = false;
+    if (lane < ng) { M = x.go[g0 + lane].nh & 0xFFFFu; if (M > (uint32_t)FQL_CAP) { M = 0; over = true; } }
+    const int64_t L0 = own.loff + x.nl_prefix[g0];                         // global index of the workgroup's first line (asked for with the rest)
+    const int64_t qp = x.prevnl[g0];
+    const unsigned long long ob = __ballot(over);
+    const uint32_t incl = wave_incl_scan(M), excl = incl - M;              // lines of the workgroup's granules in front of granule `lane`
+    const uint32_t Mtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (ob || Mtot > (uint32_t)FQW_CAP) {                                  // one lane per line, granule by granule (the records of a run
+        for (int k = w; k < ng; k += BLOCK / 64) {                          // stand one after the other in its slot, overflowed granules left out)
+            const uint32_t Mk = (uint32_t)__shfl((int)M, k, 64);
+            if (!Mk) continue;
+            const int64_t g = g0 + k;
+            const uint32_t in_run = (uint32_t)__shfl((int)excl, k, 64) - (uint32_t)__shfl((int)excl, k - k % FQR_G, 64);
+            const uint32_t *slot = recs + (g / FQR_G) * (int64_t)(FQR_G * FQL_CAP) + in_run;
+            const int64_t gs = x.gbase + g * (int64_t)GRAN;
+            const int64_t q0 = x.prevnl[g], qq = q0 < 0 ? own.prev_nl : q0, I0 = x.nl_prefix[g];
+            for (uint32_t i = lane; i < Mk; i += 64)
+                fq_row_of_line(x, own, t, gs, i == 0, slot[i], i ? gs + (slot[i - 1] & 0xFFFu) : qq, own.loff + I0 + i);
+        }
+        return;
+    }
+    if (w == 0 && lane < G) s_cum[lane] = excl;
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {                                        // the records of a run: one after the other in the run's slot
+        const int k0 = (w * RPW + q) * FQR_G;
+        if (k0 >= ng) break;
+        const int k1 = k0 + FQR_G < ng ? k0 + FQR_G : ng;
+        const uint32_t base = (uint32_t)__shfl((int)excl, k0, 64), cnt = (uint32_t)__shfl((int)incl, k1 - 1, 64) - base;
+        uint32_t c1 = (uint32_t)__shfl((int)excl, k0 + 1 < ng ? k0 + 1 : k0, 64), c2 = (uint32_t)__shfl((int)excl, k0 + 2 < ng ? k0 + 2 : k0, 64),
+                 c3 = (uint32_t)__shfl((int)excl, k0 + 3 < ng ? k0 + 3 : k0, 64);
+        if (k0 + 1 >= ng) c1 = ~0u;
+        if (k0 + 2 >= ng) c2 = ~0u;
+        if (k0 + 3 >= ng) c3 = ~0u;
+        const uint32_t *rslot = recs + ((g0 + k0) / FQR_G) * (int64_t)(FQR_G * FQL_CAP);
+        for (uint32_t i = lane; i < cnt; i += 64) {
+            const uint32_t r = i < 64u ? rr[q] : rslot[i];
+            const uint32_t at = base + i;
+            const uint32_t k = (uint32_t)k0 + (at >= c1 ? 1u : 0u) + (at >= c2 ? 1u : 0u) + (at >= c3 ? 1u : 0u);
+            s_rec[at] = (r & 0x03FFFFFFu) | (k << 26);
+        }
+    }
+    static_assert(FQR_G == 4, "the staging above names the run's four granules");
+    __syncthreads();
+    if (!Mtot) return;
+    const int64_t gs0 = x.gbase + g0 * (int64_t)GRAN;
+    const int64_t qq0 = qp < 0 ? own.prev_nl : qp;                         // the newline before the workgroup's first line
+    const int64_t rb = L0 >> 2, re = (L0 + Mtot - 1) >> 2;                 // rows the workgroup's lines touch
+    for (int64_t row = rb + tid; row <= re; row += BLOCK) {
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const int64_t jj = 4 * row + ph - L0;
+            if (jj < 0 || jj >= (int64_t)Mtot) continue;
+            const uint32_t j = (uint32_t)jj;
+            const uint32_t r = s_rec[j];
+            const uint32_t k = r >> 26;
+            const int64_t gs = gs0 + (int64_t)k * GRAN;
+            int64_t q = qq0;
+            if (j) { const uint32_t rp = s_rec[j - 1]; q = gs0 + (int64_t)(rp >> 26) * GRAN + (rp & 0xFFFu); }
+            fq_row_of_line<NT>(x, own, t, gs, j == s_cum[k], r & 0x03FFFFFFu, q, L0 + j);
         }
     }
 }

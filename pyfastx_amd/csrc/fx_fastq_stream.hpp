@@ -36,7 +36,7 @@ constexpr int FS_NMASK = 4 * 17 * 17;
 
 __device__ __forceinline__ uint32_t fs_orn(uint32_t a, uint32_t b) { return a | ~b; }
 
-struct FsAcc { CompPlanes pl; uint32_t mn, mx; uint32_t extra[5]; bool qodd; };   // mn / mx: high bytes of the 16-bit halves
+struct FsAcc { CompPlanes pl; uint32_t mn, mx; uint32_t extra[5]; bool qodd, pend; };   // mn / mx: high bytes of the 16-bit halves; pend: lane 63 holds a '\r' as the granule's last byte
 
 // the bytes of `x` (one word of a chunk) that are bases (ms) into the one-hot word h; -> x ^ expected where a base is none of
 // A C G T N \r (0: none).  Qualities (mq): min and max are not computed but TESTED -- is any quality byte above the largest or
@@ -85,10 +85,139 @@ __device__ __forceinline__ void fs_one(uint32_t c, uint32_t p, FsAcc &a) {
     }
 }
 
+// ---- '\r' in front of a line's '\n' (CRLF files, round 5).  The reference's loop over a quality line (fastq.c:731-745) meets
+// the '\r' as the LAST byte of line.s: `--line.l; continue;` ends the loop -- the byte is skipped, nothing else happens.  A '\r'
+// anywhere else in a quality line makes that loop stop short of the line's end (k_fastq_qual_walk knows how); such a file is
+// left to the table kernels.  So: a '\r' that is followed by '\n' is taken out of the quality mask of its chunk, and a '\r'
+// that is NOT followed by '\n' -- anywhere, which is more than the rule asks for and costs nothing -- raises the run's odd
+// flag.  Rows without a '\r' (every row of an LF file: the test is wave-uniform and was made by fq_cr_mask already) pay one
+// scalar branch.  crb: 0xFF in the bytes of v that are '\r'.
+__device__ __forceinline__ uint4 fs_cr_bytes(const uint4 &v) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const uint32_t z = zero_bytes(w[i] ^ 0x0D0D0D0Du) >> 7; o[i] = (z << 8) - z; }     // 0x01 -> 0xFF per byte
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+// the exact map of the '\r' bytes of a row as fq_cr_mask gives it, and whether the row holds one at all (wave-uniform)
+__device__ __forceinline__ uint16_t fq_cr_mask2(const uint4 &v, bool &row_has) {
+    const uint32_t y0 = v.x ^ 0x0D0D0D0Du, y1 = v.y ^ 0x0D0D0D0Du, y2 = v.z ^ 0x0D0D0D0Du, y3 = v.w ^ 0x0D0D0D0Du;
+    uint32_t any_cr = (y0 - 0x01010101u) & ~y0;
+    any_cr = (uint32_t)__builtin_amdgcn_bitop3_b32(any_cr, y1 - 0x01010101u, y1, 0xF4);      // a | (b & ~c)
+    any_cr = (uint32_t)__builtin_amdgcn_bitop3_b32(any_cr, y2 - 0x01010101u, y2, 0xF4);
+    any_cr = (uint32_t)__builtin_amdgcn_bitop3_b32(any_cr, y3 - 0x01010101u, y3, 0xF4);
+    row_has = __ballot((any_cr & 0x80808080u) != 0) != 0ull;
+    return row_has ? (uint16_t)eq_mask16(v, 0x0D0D0D0Du) : (uint16_t)0;
+}
+
+struct FsQ { uint32_t qf, qk1, qk2; int cmin, cmax; };       // the wave's quality bounds so far and the constants of the test made from them
+__device__ __forceinline__ void fsq_init(FsQ &q) {
+    q.cmin = 104; q.cmax = 33;                               // fastq.c:667-668
+    q.qf = 33u * 0x01010101u; q.qk1 = (0x7Fu - 33u) * 0x01010101u; q.qk2 = (0x80u - 104u) * 0x01010101u;   // fill, "above cmax", "at least cmin"
+}
+
+// One row (1 KiB: a 16-byte chunk per lane) of a granule through the counters.  pA: which line of four the chunk's first byte
+// belongs to; nlm / crm: the chunk's newline and '\r' maps; row_cr: some lane of the row holds a '\r'; next_first: 1 / 0 = the
+// chunk behind lane 63's begins / does not begin with '\n', 2 = not known here (the caller settles a.pend).
+template <int J>
+__device__ __forceinline__ void fs_row(const uint4 &vj, uint32_t nlmj, uint32_t crmj, bool row_cr, uint32_t next_first, uint32_t pA,
+                                       const uint4 *s_mask, FsAcc &a, CompCarry &cy, FsQ &qs, int *fix, int lane) {
+    // Up to two line ends in a chunk ('+' lines are two bytes long: nearly every record has such a chunk): three stretches --
+    // in front of the first newline (line pA), between the two (pA + 1), behind the second (pA + 2) -- of which at most one
+    // holds bases (its line is 1 of four: stretch (1 - pA) & 3) and at most one qualities (line 3: stretch (3 - pA) & 3);
+    // stretch 3 is none.  ONE look-up each, the address from pA and the two positions.
+    const uint32_t cnt = (uint32_t)__popc(nlmj);
+    const uint32_t m1 = nlmj & (nlmj - 1u);
+    const int k1 = cnt ? __ffs(nlmj) - 1 : 16, k2 = m1 ? __ffs(m1) - 1 : 16;
+    const bool slow = cnt >= 3u;                                       // three line ends in 16 bytes: byte by byte below
+    const int kx = k1 * 17 + k2;
+    const uint32_t rs = slow ? 3u : (1u - pA) & 3u, rq = slow ? 3u : (3u - pA) & 3u;
+    const uint4 ms = s_mask[rs * 289u + kx];
+    uint4 mq = s_mask[rq * 289u + kx];
+    if (row_cr) {
+        const uint4 crb = fs_cr_bytes(vj);
+        mq.x &= ~crb.x; mq.y &= ~crb.y; mq.z &= ~crb.z; mq.w &= ~crb.w;
+        uint32_t lone = crmj & ~(nlmj >> 1) & 0x7FFFu;                 // a '\r' with something else than '\n' behind it
+        const uint32_t nb = (uint32_t)__shfl_down((int)(nlmj & 1u), 1, 64);
+        if (crmj & 0x8000u) {                                          // the chunk's last byte: the next chunk's first byte decides
+            const uint32_t nf = lane < 63 ? nb : next_first;
+            if (nf == 0u) lone |= 0x8000u;
+            else if (nf == 2u) a.pend = true;
+        }
+        if (lone) a.qodd = true;
+    }
+    uint32_t h0, h1, h2, h3, over = 0, notunder = 0xFFFFFFFFu;
+    const uint32_t d0 = fs_word(vj.x, ms.x, mq.x, h0, qs.qf, qs.qk1, qs.qk2, over, notunder), d1 = fs_word(vj.y, ms.y, mq.y, h1, qs.qf, qs.qk1, qs.qk2, over, notunder);
+    const uint32_t d2 = fs_word(vj.z, ms.z, mq.z, h2, qs.qf, qs.qk1, qs.qk2, over, notunder), d3 = fs_word(vj.w, ms.w, mq.w, h3, qs.qf, qs.qk1, qs.qk2, over, notunder);
+    planes_add4(a.pl, cy, J, h0, h1, h2, h3);
+    if (__builtin_expect(__ballot((((over | ~notunder) & 0x80808080u) != 0)) != 0ull, 0)) {
+        // a quality outside the bounds: this row exactly, the wave's bounds move (wave-uniform again)
+        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+        fs_minmax(vj, mq, mn, mx);
+        int lo = (int)min(mn >> 24, (mn >> 8) & 0xFFu), hi = (int)max(mx >> 24, (mx >> 8) & 0xFFu);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const int x = __shfl_xor(lo, d, 64), y = __shfl_xor(hi, d, 64);
+            lo = x < lo ? x : lo; hi = y > hi ? y : hi;
+        }
+        if (lo <= hi) {                                                // the row held qualities
+            qs.cmin = lo < qs.cmin ? lo : qs.cmin; qs.cmax = hi > qs.cmax ? hi : qs.cmax;
+            if (lo < 33 || hi > 127) a.qodd = true;
+            const int fl = qs.cmin <= qs.cmax ? qs.cmin : qs.cmax;     // (no quality met yet: anything fails, the row above is exact anyway)
+            qs.qf = (uint32_t)fl * 0x01010101u;
+            qs.qk1 = (uint32_t)(0x7F - (qs.cmax < 127 ? qs.cmax : 127)) * 0x01010101u;
+            qs.qk2 = (uint32_t)(0x80 - (qs.cmin > 0 ? qs.cmin : 0)) * 0x01010101u;
+        }
+    }
+    if (__builtin_expect((d0 | d1 | d2 | d3) != 0, 0)) {   // a base that is none of A C G T N \r: N for the reference; take the aliased class back out
+        // (word by word, the bytes of a word by shifting it: a byte picked by a run-time index makes the compiler keep the
+        // chunk in scratch memory -- 64 bytes per lane stored for every granule, on the straight path)
+        const uint32_t dsw[4] = {d0, d1, d2, d3}, hsw[4] = {h0, h1, h2, h3};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t dw = dsw[q], hw = hsw[q];
+#pragma unroll 1
+            for (int k = 0; k < 4 && dw; ++k, dw >>= 8, hw >>= 8) {
+                if (!(dw & 0xFFu)) continue;
+                const uint32_t hk = hw & 0xFFu;
+                if (hk) atomicSub(&fix[__ffs(hk) - 1], 1);
+                atomicAdd(&fix[4], 1);
+            }
+        }
+    }
+    if (__builtin_expect(slow, 0)) {
+        uint32_t p = pA;
+        bool cr_open = false;                                          // a '\r' of a quality line whose next byte has not been seen
+        const uint32_t vsw[4] = {vj.x, vj.y, vj.z, vj.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t w = vsw[q];
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k, w >>= 8) {
+                const uint32_t cc = w & 0xFFu;
+                if (cr_open && cc != 10u) a.qodd = true;
+                cr_open = false;
+                if (cc == 10u) { p = (p + 1u) & 3u; continue; }
+                if (cc == 13u && p == 3u) { cr_open = true; continue; }
+                fs_one(cc, p, a);
+            }
+        }
+        if (cr_open) a.qodd = true;                                    // (the chunk ends on it: left to the table kernels)
+    }
+}
+// the ragged end of the stream and other byte-by-byte walks: one byte of line-of-four ph with the byte behind it (10 at the end of the stream)
+__device__ __forceinline__ void fs_one_cr(uint32_t b, uint32_t next, uint32_t ph, FsAcc &a) {
+    if (b == 13u && ph == 3u) { if (next != 10u) a.qodd = true; return; }
+    fs_one(b, ph, a);
+}
+
 // ngran_full granules that lie entirely inside the stream go through the fast path; the ragged end of the stream ([tail0, n),
-// less than a granule) is walked by the last wave, 64 bytes per lane.
+// less than a granule) is walked by the last wave, 64 bytes per lane.  With a LIST (round 5: the runs of k_fastq_lines_comp whose
+// guess was wrong or missing, FQLC_G granules each) only those runs are counted -- the line-of-four of every chunk from the
+// prefixes, which exist by then -- and the ragged end is somebody else's.
 __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__restrict__ data, int64_t n, int64_t nfull,
-                                                            const int64_t *__restrict__ nl_prefix, int64_t line0, FastqAcc *acc) {
+                                                            const int64_t *__restrict__ nl_prefix, int64_t line0, FastqAcc *acc,
+                                                            const uint32_t *__restrict__ list, int64_t nlist, int list_gpr) {
     __shared__ uint4 s_mask[FS_NMASK];
     __shared__ int s_fix[BLOCK / 64][8];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
@@ -110,8 +239,9 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__re
     FsAcc a;
 #pragma unroll
     for (int k = 0; k < COMP_NPL; ++k) a.pl.p[k] = 0;
-    a.mn = 0xFFFFFFFFu; a.mx = 0u; a.qodd = false;
-    int cmin = 104, cmax = 33;                             // fastq.c:667-668: what the wave has met so far (wave-uniform)
+    a.mn = 0xFFFFFFFFu; a.mx = 0u; a.qodd = false; a.pend = false;
+    FsQ qs;
+    fsq_init(qs);                                            // what the wave has met so far (wave-uniform)
 #pragma unroll
     for (int c = 0; c < 5; ++c) a.extra[c] = 0;
     // A grid of as many waves as the device holds at once; wave w takes the runs w, w + nwaves, ... (one set of atomics per
@@ -119,9 +249,12 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__re
     const int64_t wave = (int64_t)blockIdx.x * (BLOCK / 64) + wv, nwaves = (int64_t)gridDim.x * (BLOCK / 64);
     unsigned long long tot[5] = {0, 0, 0, 0, 0};
     int runs_in_planes = 0;
-    uint32_t qf = 33u * 0x01010101u, qk1 = (0x7Fu - 33u) * 0x01010101u, qk2 = (0x80u - 104u) * 0x01010101u;   // fill, "above cmax", "at least cmin"
     uint4 v[GR_ROWS], nx[GR_ROWS];
-  for (int64_t g0 = wave * FS_GPW; g0 < nfull; g0 += nwaves * FS_GPW) {
+    const int per = list ? list_gpr / FS_GPW : 1;            // pieces of FS_GPW granules per listed run
+    const int64_t npieces = list ? nlist * per : (nfull + FS_GPW - 1) / FS_GPW;
+  for (int64_t pc = wave; pc < npieces; pc += nwaves) {
+    const int64_t g0 = list ? (int64_t)list[pc / per] * list_gpr + (pc % per) * FS_GPW : pc * FS_GPW;
+    if (g0 >= nfull) continue;
     granule_load<true>(v, data, n, 0, g0);
 #pragma unroll 1
     for (int kk = 0; kk < FS_GPW; ++kk) {
@@ -130,11 +263,13 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__re
         const bool more = kk + 1 < FS_GPW && g + 1 < nfull;
         if (more) granule_load<true>(nx, data, n, 0, g + 1);
         // ---- the line every chunk begins in
-        uint32_t nlm[GR_ROWS], ex[GR_ROWS];
+        uint32_t nlm[GR_ROWS], ex[GR_ROWS], crm[GR_ROWS];
+        bool rcr[GR_ROWS];
         uint32_t run = 0;
 #pragma unroll
         for (int j = 0; j < GR_ROWS; ++j) {
             nlm[j] = eq_mask16(v[j], 0x0A0A0A0Au);
+            crm[j] = fq_cr_mask2(v[j], rcr[j]);
             const uint32_t c = (uint32_t)__popc(nlm[j]);
             const uint32_t inc = wave_incl_scan(c);
             ex[j] = run + inc - c;
@@ -142,75 +277,17 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__re
         }
         const uint32_t L0 = (uint32_t)((line0 + nl_prefix[g]) & 3);
         CompCarry cy;
-#pragma unroll
-        for (int j = 0; j < GR_ROWS; ++j) {
-            const uint32_t pA = (L0 + ex[j]) & 3u;         // which line of four the chunk's first byte belongs to
-            // Up to two line ends in a chunk ('+' lines are two bytes long: nearly every record has such a chunk): three stretches --
-            // in front of the first newline (line pA), between the two (pA + 1), behind the second (pA + 2) -- of which at most one
-            // holds bases (its line is 1 of four: stretch (1 - pA) & 3) and at most one qualities (line 3: stretch (3 - pA) & 3);
-            // stretch 3 is none.  ONE look-up each, the address from pA and the two positions.
-            const uint32_t cnt = (uint32_t)__popc(nlm[j]);
-            const uint32_t m1 = nlm[j] & (nlm[j] - 1u);
-            const int k1 = cnt ? __ffs(nlm[j]) - 1 : 16, k2 = m1 ? __ffs(m1) - 1 : 16;
-            const bool slow = cnt >= 3u;                                       // three line ends in 16 bytes: byte by byte below
-            const int kk = k1 * 17 + k2;
-            const uint32_t rs = slow ? 3u : (1u - pA) & 3u, rq = slow ? 3u : (3u - pA) & 3u;
-            const uint4 ms = s_mask[rs * 289u + kk], mq = s_mask[rq * 289u + kk];
-            uint32_t h0, h1, h2, h3, over = 0, notunder = 0xFFFFFFFFu;
-            const uint32_t d0 = fs_word(v[j].x, ms.x, mq.x, h0, qf, qk1, qk2, over, notunder), d1 = fs_word(v[j].y, ms.y, mq.y, h1, qf, qk1, qk2, over, notunder);
-            const uint32_t d2 = fs_word(v[j].z, ms.z, mq.z, h2, qf, qk1, qk2, over, notunder), d3 = fs_word(v[j].w, ms.w, mq.w, h3, qf, qk1, qk2, over, notunder);
-            planes_add4(a.pl, cy, j, h0, h1, h2, h3);
-            if (__builtin_expect(__ballot((((over | ~notunder) & 0x80808080u) != 0)) != 0ull, 0)) {
-                // a quality outside the bounds: this row exactly, the wave's bounds move (wave-uniform again)
-                uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-                fs_minmax(v[j], mq, mn, mx);
-                int lo = (int)min(mn >> 24, (mn >> 8) & 0xFFu), hi = (int)max(mx >> 24, (mx >> 8) & 0xFFu);
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) {
-                    const int x = __shfl_xor(lo, d, 64), y = __shfl_xor(hi, d, 64);
-                    lo = x < lo ? x : lo; hi = y > hi ? y : hi;
-                }
-                if (lo <= hi) {                                                // the row held qualities
-                    cmin = lo < cmin ? lo : cmin; cmax = hi > cmax ? hi : cmax;
-                    if (lo < 33 || hi > 127) a.qodd = true;
-                    const int fl = cmin <= cmax ? cmin : cmax;                 // (no quality met yet: anything fails, the row above is exact anyway)
-                    qf = (uint32_t)fl * 0x01010101u;
-                    qk1 = (uint32_t)(0x7F - (cmax < 127 ? cmax : 127)) * 0x01010101u;
-                    qk2 = (uint32_t)(0x80 - (cmin > 0 ? cmin : 0)) * 0x01010101u;
-                }
-            }
-            if (__builtin_expect((d0 | d1 | d2 | d3) != 0, 0)) {   // a base that is none of A C G T N \r: N for the reference; take the aliased class back out
-                // (word by word, the bytes of a word by shifting it: a byte picked by a run-time index makes the compiler keep the
-                // chunk in scratch memory -- 64 bytes per lane stored for every granule, on the straight path)
-                const uint32_t dsw[4] = {d0, d1, d2, d3}, hsw[4] = {h0, h1, h2, h3};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    uint32_t dw = dsw[q], hw = hsw[q];
-#pragma unroll 1
-                    for (int k = 0; k < 4 && dw; ++k, dw >>= 8, hw >>= 8) {
-                        if (!(dw & 0xFFu)) continue;
-                        const uint32_t hk = hw & 0xFFu;
-                        if (hk) atomicSub(&fix[__ffs(hk) - 1], 1);
-                        atomicAdd(&fix[4], 1);
-                    }
-                }
-            }
-            if (__builtin_expect(slow, 0)) {
-                uint32_t p = pA;
-                const uint32_t vsw[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    uint32_t w = vsw[q];
-#pragma unroll 1
-                    for (int k = 0; k < 4; ++k, w >>= 8) {
-                        const uint32_t cc = w & 0xFFu;
-                        if (cc == 10u) { p = (p + 1u) & 3u; continue; }
-                        fs_one(cc, p, a);
-                    }
-                }
-            }
-        }
+        fs_row<0>(v[0], nlm[0], crm[0], rcr[0], (uint32_t)__builtin_amdgcn_readlane((int)nlm[1], 0) & 1u, (L0 + ex[0]) & 3u, s_mask, a, cy, qs, fix, lane);
+        fs_row<1>(v[1], nlm[1], crm[1], rcr[1], (uint32_t)__builtin_amdgcn_readlane((int)nlm[2], 0) & 1u, (L0 + ex[1]) & 3u, s_mask, a, cy, qs, fix, lane);
+        fs_row<2>(v[2], nlm[2], crm[2], rcr[2], (uint32_t)__builtin_amdgcn_readlane((int)nlm[3], 0) & 1u, (L0 + ex[2]) & 3u, s_mask, a, cy, qs, fix, lane);
+        fs_row<3>(v[3], nlm[3], crm[3], rcr[3], 2u, (L0 + ex[3]) & 3u, s_mask, a, cy, qs, fix, lane);
+        static_assert(GR_ROWS == 4, "four rows per granule");
         planes_finish16(a.pl, cy);
+        if (__ballot(a.pend)) {                              // a '\r' as the granule's last byte: the byte behind it (the end of the stream passes)
+            const int64_t q = (g + 1) * (int64_t)GRAN;
+            if (a.pend && q < n && data[q] != 10) a.qodd = true;
+            a.pend = false;
+        }
         if (more) {
 #pragma unroll
             for (int j = 0; j < GR_ROWS; ++j) v[j] = nx[j];
@@ -226,7 +303,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__re
   }
     // ---- the ragged end of the stream: wave 0 walks its bytes, 64 per lane
     const int64_t tail0 = nfull * (int64_t)GRAN;
-    if (tail0 < n && wave == 0) {
+    if (!list && tail0 < n && wave == 0) {
         const int64_t lo = tail0 + (int64_t)lane * 64, hi = lo + 64 < n ? lo + 64 : n;
         uint32_t c = 0;
         for (int64_t p = lo; p < hi; ++p) c += data[p] == 10;
@@ -235,7 +312,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__re
         for (int64_t p = lo; p < hi; ++p) {
             const uint32_t b = data[p];
             if (b == 10u) { ph = (ph + 1u) & 3u; continue; }
-            fs_one(b, ph, a);
+            fs_one_cr(b, p + 1 < n ? data[p + 1] : 10u, ph, a);
         }
     }
     // ---- the lane's counts, the wave's, the accumulators
@@ -243,7 +320,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__re
     for (int c = 0; c < 5; ++c) tot[c] = (unsigned long long)wave_sum64((long long)(tot[c] + planes_count(a.pl, c) + a.extra[c]));
     // the bounds of the tested rows (wave-uniform) and what the byte-by-byte walks met (per lane)
     int qmin = (int)min(a.mn >> 24, (a.mn >> 8) & 0xFFu), qmax = (int)max(a.mx >> 24, (a.mx >> 8) & 0xFFu);
-    if (cmin <= cmax) { qmin = cmin < qmin ? cmin : qmin; qmax = cmax > qmax ? cmax : qmax; }
+    if (qs.cmin <= qs.cmax) { qmin = qs.cmin < qmin ? qs.cmin : qmin; qmax = qs.cmax > qmax ? qs.cmax : qmax; }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         const int x = __shfl_xor(qmin, d, 64), y = __shfl_xor(qmax, d, 64);
@@ -275,8 +352,9 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__re
 // (two newlines two bytes apart; every candidate of the granule must agree), which fixes the number-of-four of the granule's
 // first line, and the granules behind it follow by counting.  The counts of a run -- A C G T N, smallest / largest quality,
 // the guess -- go to an 8-word record; k_fastq_comp_reduce, after the prefixes, compares every guess with the truth
-// ((line offset + nl_prefix[first granule]) & 3) and adds the records up.  ONE wrong or missing guess (a file whose '+' lines
-// repeat the name, 1-base reads, CRLF) and the result is not used: fx_fastq_comp then counts from the read table as before.
+// ((line offset + nl_prefix[first granule]) & 3) and adds the records up; the runs whose guess was wrong or missing (a granule
+// without a '+' line in it: reads longer than a granule; '+' lines that repeat the name; 1-base reads) are counted again by
+// k_fastq_comp_stream, from the prefixes, when they are few -- else fx_fastq_comp counts from the read table as before.
 #ifndef FX_FQLC_G
 #define FX_FQLC_G 16
 #endif
@@ -314,11 +392,11 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
     FsAcc a;
 #pragma unroll
     for (int k = 0; k < COMP_NPL; ++k) a.pl.p[k] = 0;
-    a.mn = 0xFFFFFFFFu; a.mx = 0u; a.qodd = false;
+    a.mn = 0xFFFFFFFFu; a.mx = 0u; a.qodd = false; a.pend = false;
 #pragma unroll
     for (int c = 0; c < 5; ++c) a.extra[c] = 0;
-    int cmin = 104, cmax = 33;
-    uint32_t qf = 33u * 0x01010101u, qk1 = (0x7Fu - 33u) * 0x01010101u, qk2 = (0x80u - 104u) * 0x01010101u;
+    FsQ qs;
+    fsq_init(qs);
     uint32_t written = 0;                                  // line records of the run so far (they stand one after the other in the run's slot)
     uint32_t guess = 0xFFu, lines_before = 0;              // number-of-four of the run's first line (0xFF: not known), newlines of the run so far
     uint4 v[GR_ROWS];
@@ -328,25 +406,35 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
         if (g >= g_end) break;
         const int64_t sbase = g * (int64_t)GRAN;
         if (kk % FQR_G == 0) written = 0;                      // (a record slot per FQR_G granules: what k_fastq_rows reads in one request)
-        uint32_t nlm[GR_ROWS], ex[GR_ROWS], run_n = 0;
+        uint32_t nlm[GR_ROWS], ex[GR_ROWS], crm[GR_ROWS], run_n = 0;
+        bool rcr[GR_ROWS];
 #pragma unroll
         for (int j = 0; j < GR_ROWS; ++j) {
             nlm[j] = eq_mask16(v[j], 0x0A0A0A0Au);
             s_sp[w][j * 64 + lane] = (uint16_t)eq_mask16(v[j], 0x20202020u);
-            s_cr[w][j * 64 + lane] = fq_cr_mask(v[j]);
+            crm[j] = fq_cr_mask2(v[j], rcr[j]);
+            s_cr[w][j * 64 + lane] = (uint16_t)crm[j];
             const uint32_t cj = (uint32_t)__popc(nlm[j]);
             const uint32_t inc = wave_incl_scan(cj);
             ex[j] = run_n + inc - cj;                      // newlines of the granule in front of this chunk
             run_n += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
         const uint32_t M = run_n;
-        // ---- the guess, once per run: a '+' line of one byte ends at a newline that has another one two bytes in front of it
+        if (__ballot(a.pend)) {                                // the granule before ended on a '\r': this one must begin with '\n'
+            if (a.pend && !(__builtin_amdgcn_readlane((int)nlm[0], 0) & 1)) a.qodd = true;
+            a.pend = false;
+        }
+        // ---- the guess, once per run: the '+' line.  One byte long in an LF file -- it ends at a newline that has another one two
+        // bytes in front of it --, '+' and '\r' in a CRLF file: a newline with a '\r' in front of it and the newline before three
+        // bytes back (round 5; the reference's own gzip fixture is such a file).  Which byte stands there is not looked at: every
+        // such place of the run's first granule must name the same phase, and k_fastq_comp_reduce checks the guess anyway.
         if (kk == 0) {
             uint32_t mine = 0xFFu;
             bool clash = false;
 #pragma unroll
             for (int j = 0; j < GR_ROWS; ++j) {
-                const uint32_t cand = nlm[j] & (nlm[j] << 2) & ~(nlm[j] << 1) & 0xFFFFu;     // second newline of a pair inside the chunk
+                uint32_t cand = nlm[j] & (nlm[j] << 2) & ~(nlm[j] << 1) & 0xFFFFu;     // second newline of a pair inside the chunk
+                if (rcr[j]) cand |= nlm[j] & (nlm[j] << 3) & ~(nlm[j] << 1) & ~(nlm[j] << 2) & (crm[j] << 1) & 0xFFFFu;
                 if (cand) {
                     const uint32_t b = (uint32_t)__ffs(cand) - 1u;
                     const uint32_t i = ex[j] + (uint32_t)__popc(nlm[j] & ((1u << b) - 1u));   // that newline is the granule's i-th: line i is line 2 of four
@@ -364,69 +452,10 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
         if (guess != 0xFFu) {
             const uint32_t L0 = (guess + lines_before) & 3u;
             CompCarry cy;
-#pragma unroll
-            for (int j = 0; j < GR_ROWS; ++j) {
-                const uint32_t pA = (L0 + ex[j]) & 3u;
-                const uint32_t cnt = (uint32_t)__popc(nlm[j]);
-                const uint32_t m1 = nlm[j] & (nlm[j] - 1u);
-                const int k1 = cnt ? __ffs(nlm[j]) - 1 : 16, k2 = m1 ? __ffs(m1) - 1 : 16;
-                const bool slow = cnt >= 3u;
-                const int kx = k1 * 17 + k2;
-                const uint32_t rs = slow ? 3u : (1u - pA) & 3u, rq = slow ? 3u : (3u - pA) & 3u;
-                const uint4 ms = s_mask[rs * 289u + kx], mq = s_mask[rq * 289u + kx];
-                uint32_t h0, h1, h2, h3, over = 0, notunder = 0xFFFFFFFFu;
-                const uint32_t d0 = fs_word(v[j].x, ms.x, mq.x, h0, qf, qk1, qk2, over, notunder), d1 = fs_word(v[j].y, ms.y, mq.y, h1, qf, qk1, qk2, over, notunder);
-                const uint32_t d2 = fs_word(v[j].z, ms.z, mq.z, h2, qf, qk1, qk2, over, notunder), d3 = fs_word(v[j].w, ms.w, mq.w, h3, qf, qk1, qk2, over, notunder);
-                planes_add4(a.pl, cy, j, h0, h1, h2, h3);
-                if (__builtin_expect(__ballot((((over | ~notunder) & 0x80808080u) != 0)) != 0ull, 0)) {
-                    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-                    fs_minmax(v[j], mq, mn, mx);
-                    int lo = (int)min(mn >> 24, (mn >> 8) & 0xFFu), hi = (int)max(mx >> 24, (mx >> 8) & 0xFFu);
-#pragma unroll
-                    for (int d = 32; d > 0; d >>= 1) {
-                        const int x = __shfl_xor(lo, d, 64), y = __shfl_xor(hi, d, 64);
-                        lo = x < lo ? x : lo; hi = y > hi ? y : hi;
-                    }
-                    if (lo <= hi) {
-                        cmin = lo < cmin ? lo : cmin; cmax = hi > cmax ? hi : cmax;
-                        if (lo < 33 || hi > 127) a.qodd = true;
-                        const int fl = cmin <= cmax ? cmin : cmax;
-                        qf = (uint32_t)fl * 0x01010101u;
-                        qk1 = (uint32_t)(0x7F - (cmax < 127 ? cmax : 127)) * 0x01010101u;
-                        qk2 = (uint32_t)(0x80 - (cmin > 0 ? cmin : 0)) * 0x01010101u;
-                    }
-                }
-                if (__builtin_expect((d0 | d1 | d2 | d3) != 0, 0)) {
-                    // (word by word, the bytes of a word by shifting it: a byte picked by a run-time index makes the compiler keep the
-                    // chunk in scratch memory -- 64 bytes per lane stored for every granule, on the straight path)
-                    const uint32_t dsw[4] = {d0, d1, d2, d3}, hsw[4] = {h0, h1, h2, h3};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint32_t dw = dsw[q], hw = hsw[q];
-#pragma unroll 1
-                        for (int k = 0; k < 4 && dw; ++k, dw >>= 8, hw >>= 8) {
-                            if (!(dw & 0xFFu)) continue;
-                            const uint32_t hk = hw & 0xFFu;
-                            if (hk) atomicSub(&fix[__ffs(hk) - 1], 1);
-                            atomicAdd(&fix[4], 1);
-                        }
-                    }
-                }
-                if (__builtin_expect(slow, 0)) {
-                    uint32_t p = pA;
-                    const uint32_t vsw[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint32_t w = vsw[q];
-#pragma unroll 1
-                        for (int k = 0; k < 4; ++k, w >>= 8) {
-                            const uint32_t cc = w & 0xFFu;
-                            if (cc == 10u) { p = (p + 1u) & 3u; continue; }
-                            fs_one(cc, p, a);
-                        }
-                    }
-                }
-            }
+            fs_row<0>(v[0], nlm[0], crm[0], rcr[0], (uint32_t)__builtin_amdgcn_readlane((int)nlm[1], 0) & 1u, (L0 + ex[0]) & 3u, s_mask, a, cy, qs, fix, lane);
+            fs_row<1>(v[1], nlm[1], crm[1], rcr[1], (uint32_t)__builtin_amdgcn_readlane((int)nlm[2], 0) & 1u, (L0 + ex[1]) & 3u, s_mask, a, cy, qs, fix, lane);
+            fs_row<2>(v[2], nlm[2], crm[2], rcr[2], (uint32_t)__builtin_amdgcn_readlane((int)nlm[3], 0) & 1u, (L0 + ex[2]) & 3u, s_mask, a, cy, qs, fix, lane);
+            fs_row<3>(v[3], nlm[3], crm[3], rcr[3], 2u, (L0 + ex[3]) & 3u, s_mask, a, cy, qs, fix, lane);
             planes_finish16(a.pl, cy);
         }
         lines_before += M;
@@ -462,6 +491,10 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
     }
     // ---- the run's record
     {
+        if (__ballot(a.pend)) {                                // the run's last byte is a '\r': the byte behind it, from memory (the end of the stream passes)
+            const int64_t q = (gw + FQLC_G < g_end ? gw + FQLC_G : g_end) * (int64_t)GRAN;
+            if (a.pend && q < n && data[q] != 10) a.qodd = true;
+        }
         uint32_t tot[5];
 #pragma unroll
         for (int c = 0; c < 5; ++c) tot[c] = wave_sum(planes_count(a.pl, c) + a.extra[c]);
@@ -471,7 +504,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
             const int x = __shfl_xor(qmin, d, 64), y = __shfl_xor(qmax, d, 64);
             qmin = x < qmin ? x : qmin; qmax = y > qmax ? y : qmax;
         }
-        if (cmin <= cmax) { qmin = cmin < qmin ? cmin : qmin; qmax = cmax > qmax ? cmax : qmax; }
+        if (qs.cmin <= qs.cmax) { qmin = qs.cmin < qmin ? qs.cmin : qmin; qmax = qs.cmax > qmax ? qs.cmax : qmax; }
         const bool have = qmin < 255 || qmax > 0;
         const bool odd = __ballot(a.qodd) != 0ull || (have && (qmin < 33 || qmax > 127));
         if (lane == 0) {
@@ -487,23 +520,26 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
 }
 
 // after the prefixes: every run's guess against the truth, the records added up; the ragged end of the stream (less than a
-// granule, no run) walked by the first wave.  res: FastqAcc (a c g t n, minqs, maxqs; qfix = runs that cannot be used + odd bytes).
+// granule, no run) walked by the first wave.  res: FastqAcc (a c g t n, minqs, maxqs; qfix = runs with bytes the stream form leaves
+// to the table kernels).  A run whose guess was wrong or missing goes on the list `rej` (rej[0] = how many, then the runs):
+// k_fastq_comp_stream counts those again with the line numbers the prefixes give (round 5; round 4 dropped the whole result).
 __global__ __launch_bounds__(BLOCK) void k_fastq_comp_reduce(const FqRun *__restrict__ runs, int64_t nruns, const int64_t *__restrict__ nl_prefix,
                                                             int64_t line0, const uint8_t *__restrict__ data, int64_t n, int64_t nfull,
-                                                            FastqAcc *res) {
+                                                            FastqAcc *res, uint32_t *__restrict__ rej) {
     unsigned long long tot[5] = {0, 0, 0, 0, 0};
     int qmin = 255, qmax = 0, bad = 0;
     for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < nruns; r += (int64_t)gridDim.x * BLOCK) {
         const FqRun x = runs[r];
         const uint32_t truth = (uint32_t)((line0 + nl_prefix[r * FQLC_G]) & 3);
-        if (x.guess != truth || (x.q >> 17) & 1u) { ++bad; continue; }
+        if (x.guess != truth) { rej[1u + atomicAdd(&rej[0], 1u)] = (uint32_t)r; continue; }
+        if ((x.q >> 17) & 1u) { ++bad; continue; }
 #pragma unroll
         for (int c = 0; c < 5; ++c) tot[c] += x.cnt[c];
         if ((x.q >> 16) & 1u) { const int lo = (int)(x.q & 0xFFu), hi = (int)((x.q >> 8) & 0xFFu); qmin = lo < qmin ? lo : qmin; qmax = hi > qmax ? hi : qmax; }
     }
     if (blockIdx.x == 0 && threadIdx.x < 64 && nfull * (int64_t)GRAN < n) {        // the ragged end
         FsAcc a;
-        a.mn = 0xFFFFFFFFu; a.mx = 0u; a.qodd = false;
+        a.mn = 0xFFFFFFFFu; a.mx = 0u; a.qodd = false; a.pend = false;
 #pragma unroll
         for (int c = 0; c < 5; ++c) a.extra[c] = 0;
         const int lane = lane_id();
@@ -515,7 +551,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_reduce(const FqRun *__rest
         for (int64_t p = lo; p < hi; ++p) {
             const uint32_t b = data[p];
             if (b == 10u) { ph = (ph + 1u) & 3u; continue; }
-            fs_one(b, ph, a);
+            fs_one_cr(b, p + 1 < n ? data[p + 1] : 10u, ph, a);
         }
 #pragma unroll
         for (int k = 0; k < 5; ++k) tot[k] += a.extra[k];

@@ -296,6 +296,8 @@ struct fx_handle {
     DevBuf<FastqAcc> fq_acc;
     DevBuf<FqRun> fq_runs;                    // k_fastq_lines_comp: one record per run of FQLC_G granules (composition counted on the scan)
     DevBuf<FastqAcc> fq_acc_build;            // ... added up by k_fastq_comp_reduce
+    DevBuf<uint32_t> fq_rej;                  // [0]: runs whose guess was wrong or missing, [1 ..]: which (counted again from the prefixes)
+    int64_t fq_comp_runs = 0, fq_comp_rejected = 0;   // of the last fx_fastq_build_comp: runs of the stream, runs counted again (-1: too many, the table kernel counts)
     bool fq_comp_valid = false;               // the build counted the composition and every run's guess was right
     int64_t fq_comp_base[5] = {0, 0, 0, 0, 0};
     int fq_comp_minqs = 104, fq_comp_maxqs = 33;
@@ -1875,7 +1877,7 @@ static int granule_pass(fx_handle *h, bool fq_lines = false, bool with_comp = fa
         if ((rc = h->fq_lines.alloc((nfull + FQR_G - 1) / FQR_G * FQR_G * FQL_CAP))) return rc;      // a slot of FQR_G * FQL_CAP records per FQR_G granules
         if (with_comp) {                                      // index and composition in one read of the stream (fx_fastq_stream.hpp)
             const int64_t nruns = (nfull + FQLC_G - 1) / FQLC_G;
-            if ((rc = h->fq_runs.alloc(nruns)) || (rc = h->fq_acc_build.alloc(1))) return rc;
+            if ((rc = h->fq_runs.alloc(nruns)) || (rc = h->fq_acc_build.alloc(1)) || (rc = h->fq_rej.alloc(nruns + 1))) return rc;
             static const int64_t grid_cap = [] { const char *e = getenv("FX_FQ_FUSED_GRID"); return e && atoll(e) > 0 ? atoll(e) : 6144ll; }();
             FX_LAUNCH(h, K_FASTQ_LINES, k_fastq_lines_comp, dim3((unsigned)std::min<int64_t>(nblocks(nruns, BLOCK / 64), grid_cap)), dim3(BLOCK), h->d_data,
                       h->n, h->prev_byte, nfull, h->gran.p, h->fq_lines.p, hgl, h->fq_runs.p, nruns);
@@ -1911,8 +1913,9 @@ static int granule_pass(fx_handle *h, bool fq_lines = false, bool with_comp = fa
         init.minqs = 104; init.maxqs = 33;                    // fastq.c:667-668
         HIPCHK(hipMemcpyAsync(h->fq_acc_build.p, &init, sizeof init, hipMemcpyHostToDevice, h->stream));
         const int64_t nruns = (nfull + FQLC_G - 1) / FQLC_G;
+        HIPCHK(hipMemsetAsync(h->fq_rej.p, 0, 4, h->stream));
         FX_LAUNCH(h, K_FASTQ_COMP, k_fastq_comp_reduce, dim3((unsigned)std::min<int64_t>(nblocks(nruns, BLOCK), 1024)), dim3(BLOCK), (const FqRun *)h->fq_runs.p,
-                  nruns, (const int64_t *)h->nl_prefix.p, (int64_t)0, h->d_data, h->n, nfull, h->fq_acc_build.p);
+                  nruns, (const int64_t *)h->nl_prefix.p, (int64_t)0, h->d_data, h->n, nfull, h->fq_acc_build.p, h->fq_rej.p);
     }
     HIPCHK(hipGetLastError());
     return FX_OK;
@@ -2187,9 +2190,34 @@ static int fastq_count(fx_handle *h, int64_t *n_nl_core, int64_t *last_nl_core, 
     if (by_lines) HIPCHK(hipMemcpyAsync(&n_over, ctl_counter(h, 0), sizeof n_over, hipMemcpyDeviceToHost, h->stream));
     FastqAcc built;
     memset(&built, 0, sizeof built);
-    if (with_comp) HIPCHK(hipMemcpyAsync(&built, h->fq_acc_build.p, sizeof built, hipMemcpyDeviceToHost, h->stream));
+    uint32_t n_rej = 0;
+    if (with_comp) {
+        HIPCHK(hipMemcpyAsync(&built, h->fq_acc_build.p, sizeof built, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(&n_rej, h->fq_rej.p, 4, hipMemcpyDeviceToHost, h->stream));
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (with_comp && built.qfix == 0) {                       // every guess was right, no byte the stream form leaves to the table kernel
+    if (with_comp) {
+        const int64_t nfull = h->n / GRAN, nruns = (nfull + FQLC_G - 1) / FQLC_G;
+        h->fq_comp_runs = nruns;
+        h->fq_comp_rejected = n_rej;
+        // runs whose guess was wrong or missing (no '+' line in the run's first granule, '+' lines that repeat the name, ...): counted
+        // again, with the line numbers the prefixes give, when they are few -- else the table kernel counts everything (fx_fastq_comp)
+        static const int64_t rej_div = [] { const char *e = getenv("FX_FQ_RECOUNT_DIV"); return e && atoll(e) > 0 ? atoll(e) : 8ll; }();
+        if (built.qfix == 0 && n_rej > 0) {
+            if ((int64_t)n_rej <= std::max<int64_t>(64, nruns / rej_div)) {
+                const int64_t pieces = (int64_t)n_rej * (FQLC_G / FS_GPW);
+                FX_LAUNCH(h, K_FASTQ_COMP, k_fastq_comp_stream, dim3((unsigned)std::min<int64_t>(nblocks(pieces, BLOCK / 64), 2048)), dim3(BLOCK), h->d_data, h->n, nfull,
+                          (const int64_t *)h->nl_prefix.p, (int64_t)0, h->fq_acc_build.p, (const uint32_t *)(h->fq_rej.p + 1), (int64_t)n_rej, (int)FQLC_G);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(&built, h->fq_acc_build.p, sizeof built, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+            } else {
+                built.qfix = 1;
+                h->fq_comp_rejected = -1;
+            }
+        }
+    }
+    if (with_comp && built.qfix == 0) {                       // every run counted (by its guess or from the prefixes), no byte the stream form leaves to the table kernel
         h->fq_comp_valid = true;
         h->fq_comp_base[0] = (int64_t)built.a; h->fq_comp_base[1] = (int64_t)built.c; h->fq_comp_base[2] = (int64_t)built.g;
         h->fq_comp_base[3] = (int64_t)built.t; h->fq_comp_base[4] = (int64_t)built.n;
@@ -2273,9 +2301,20 @@ static int fastq_records(fx_handle *h, int64_t loff, int64_t prev_nl, fx_fastq_s
     FqPlan pl;
     if ((rc = fastq_plan(h, loff, prev_nl, &pl)) || (rc = fastq_alloc(h, pl.own.nrows))) return rc;
     if (h->fq_by_lines) {
-        if (h->ngran > 1)
+        static const bool rows_wave = [] { const char *e = getenv("FX_FQ_ROWS_WAVE"); return e && atoi(e) != 0; }();   // the round-4 form, for comparison
+        if (h->ngran > 1 && rows_wave)
             FX_LAUNCH(h, K_FASTQ_ROWS, k_fastq_rows, dim3(nblocks(h->ngran - 1, (BLOCK / 64) * FQR_G)), dim3(BLOCK), scan_ctx(h), pl.own, fastq_tab(h),
                       h->fq_lines.p, h->ngran - 1);
+        else if (h->ngran > 1) {
+            // granules per workgroup: as many as leave the lines of a workgroup under FQW_CAP staged records with room to spare
+            const double lpg = (double)h->n_nl / (double)h->ngran;
+            static const bool nt = [] { const char *e = getenv("FX_FQ_ROWS_NT"); return e && atoi(e) != 0; }();
+#define FX_ROWS_WG(G, NT) FX_LAUNCH(h, K_FASTQ_ROWS, (k_fastq_rows_wg<G, NT>), dim3(nblocks(h->ngran - 1, G)), dim3(BLOCK), scan_ctx(h), pl.own, fastq_tab(h), h->fq_lines.p, h->ngran - 1)
+            if (lpg * 64 <= 0.75 * FQW_CAP) { if (nt) FX_ROWS_WG(64, true); else FX_ROWS_WG(64, false); }
+            else if (lpg * 32 <= 0.75 * FQW_CAP) { if (nt) FX_ROWS_WG(32, true); else FX_ROWS_WG(32, false); }
+            else { if (nt) FX_ROWS_WG(16, true); else FX_ROWS_WG(16, false); }
+#undef FX_ROWS_WG
+        }
         FX_LAUNCH(h, K_FASTQ_EMIT, k_fastq_emit, dim3(nblocks(h->fq_nlist, BLOCK / 64)), dim3(BLOCK), scan_ctx(h), h->prev_byte,
                   (int)h->is_last, pl.own, fastq_tab(h), (const uint32_t *)h->hdr_grans.p, h->fq_nlist);
     } else {
@@ -2315,6 +2354,14 @@ extern "C" int fx_fastq_build_comp(fx_handle *h, fx_fastq_summary *out) {
     int rc = fastq_count(h, nullptr, nullptr, true);
     if (rc) return rc;
     return fastq_records(h, 0, -1, out);
+}
+
+extern "C" int fx_fastq_comp_info(fx_handle *h, int64_t *runs, int64_t *recounted, int *one_read) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    if (runs) *runs = h->fq_comp_runs;
+    if (recounted) *recounted = h->fq_comp_rejected;
+    if (one_read) *one_read = h->fq_comp_valid ? 1 : 0;
+    return FX_OK;
 }
 
 extern "C" int fx_fastq_table(fx_handle *h, int where, int64_t *name_off, int32_t *name_len, int32_t *dlen,
@@ -2361,7 +2408,7 @@ extern "C" int fx_fastq_comp(fx_handle *h, int64_t base[5], int64_t meta[5]) {
             (void)hipDeviceGetAttribute(&s_n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
         }
         FX_LAUNCH(h, K_FASTQ_COMP, k_fastq_comp_stream, dim3((unsigned)std::min<int64_t>(nblocks(waves, BLOCK / 64), (int64_t)s_per_cu * s_n_cu)), dim3(BLOCK), h->d_data, h->n, nfull,
-                  (const int64_t *)h->nl_prefix.p, (int64_t)0, h->fq_acc.p);
+                  (const int64_t *)h->nl_prefix.p, (int64_t)0, h->fq_acc.p, (const uint32_t *)nullptr, (int64_t)0, 0);
         HIPCHK(hipGetLastError());
         FastqAcc acc;
         HIPCHK(hipMemcpyAsync(&acc, h->fq_acc.p, sizeof acc, hipMemcpyDeviceToHost, h->stream));
@@ -3087,7 +3134,8 @@ extern "C" int fx_fasta_fetch_alloc(fx_handle *h, int64_t n, const int64_t *seq_
     uint8_t *out = (uint8_t *)fx_pinned_alloc(std::max<int64_t>(total, 1));
     uint8_t *d_dst = nullptr;
     if (!out) { fx_pinned_free(offs); return FX_ENOMEM; }
-    auto bail = [&](int code) { fx_pinned_free(offs); fx_pinned_free(out); return code; };
+    // (a copy into these blocks may still be in flight when something fails: the stream is waited for before they go back to the pool)
+    auto bail = [&](int code) { (void)hipStreamSynchronize(h->stream); fx_pinned_free(offs); fx_pinned_free(out); return code; };
     if ((rc = st.scratch<uint8_t>(std::max<int64_t>(total, 1), &d_dst))) return bail(rc);
     pc.lap(2);
     q.dst_off = d_off;
@@ -3119,7 +3167,7 @@ extern "C" int fx_fastq_fetch_alloc(fx_handle *h, int64_t n, const int64_t *read
     PhaseClock pc;
     int64_t *offs = nullptr;
     void *outs[3] = {nullptr, nullptr, nullptr};
-    auto bail = [&](int code) { fx_pinned_free(offs); for (void *p : outs) fx_pinned_free(p); return code; };
+    auto bail = [&](int code) { (void)hipStreamSynchronize(h->stream); fx_pinned_free(offs); for (void *p : outs) fx_pinned_free(p); return code; };
     if (n == 0) {
         if (!(offs = (int64_t *)fx_pinned_alloc(16))) return FX_ENOMEM;
         offs[0] = 0;

@@ -664,6 +664,8 @@ typedef struct {
  * of atoms are. */
 static void read_untrack(ReadCore *r)
 {
+    /* (a subclass WITH an instance dict or weak references can be part of a cycle -- r.x = r -- and stays with the collector) */
+    if (Py_TYPE(r)->tp_dictoffset != 0 || Py_TYPE(r)->tp_weaklistoffset != 0) return;
     if (PyType_HasFeature(Py_TYPE(r), Py_TPFLAGS_HAVE_GC) && PyObject_GC_IsTracked((PyObject *)r)) PyObject_GC_UnTrack((PyObject *)r);
 }
 static void read_dealloc(ReadCore *r)

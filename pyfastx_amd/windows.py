@@ -42,6 +42,11 @@ def hbm_budget(device=0):
     if env:
         return max(parse_size(env), 1 << 16)
     free, _ = _lib.device_memory(device)
+    if free * 0.85 < (16 << 30):
+        # little room: blocks of closed streams that idle in the library's pool count as used (fx_device_memory) -- give
+        # them back and look again, before a stream that fits is sent through windows for nothing
+        _lib.lib().fx_release_scratch()
+        free, _ = _lib.device_memory(device)
     return int(free * 0.85)
 
 
@@ -54,6 +59,11 @@ def plan(path, device=0, factor=1.0):
     budget = hbm_budget(device)
     if size * factor <= budget:
         return None
+    if not os.environ.get("FX_HBM_BUDGET"):                     # does it fit once the idle blocks of the pool are back with the driver?
+        _lib.lib().fx_release_scratch()
+        budget = hbm_budget(device)
+        if size * factor <= budget:
+            return None
     win = max(int(budget / factor) // 4, 1 << 16)               # four windows' worth of stream within the budget
     return size, kind, win, max(2, int(budget / factor) // win)
 

@@ -850,3 +850,81 @@ def test_fastq_one_read_build_on_a_file_that_misleads_its_guess(oracle, L):
         base, meta = b.fastq_comp()
         assert base.tolist() == [c["a"], c["c"], c["g"], c["t"], c["n"]]
         assert meta.tolist() == [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"], c["phred"]]
+
+
+def _fq_file(n, eol, rng, rlen=150, plus_name=False, long_every=0):
+    alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    out = []
+    for i in range(n):
+        m = rlen if not long_every or i % long_every else 9000           # a read longer than two granules: runs without a '+' line in their first granule
+        s = alpha[rng.integers(0, 5, m)].tobytes()
+        q = rng.integers(35, 75, m).astype(np.uint8).tobytes()
+        out.append(b"@r%d len=%d%s%s%s+%s%s%s%s" % (i, m, eol, s, eol, (b"r%d" % i) if plus_name else b"", eol, q, eol))
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("shape", ["lf", "crlf", "crlf_fixture", "long_reads", "plus_name", "lone_cr", "cr_ends_granule"])
+def test_fastq_one_read_composition_is_used_where_it_can_be(oracle, L, shape):
+    """fx_fastq_build_comp on files of every shape (fastq.c:715-774 handles them all in its one loop): LF and CRLF files take the
+    counts of the scan itself for (nearly) every run of granules -- fx_fastq_comp_info says how many runs were counted again
+    from the prefixes --, a file whose '+' lines repeat the name has no guess at all and a '\\r' that is not the end of its line
+    sends everything through the table kernels; base / meta equal the oracle's in every case."""
+    rng = np.random.default_rng(77)
+    if shape == "crlf_fixture":
+        raw = fixture_bytes("test.fq.gz")                    # the reference's own gzip fixture is a CRLF file
+        assert raw.count(b"\r\n") == raw.count(b"\n") > 0
+        raw = raw * 6                                        # (several runs of 64 KiB)
+    elif shape == "lone_cr":
+        raw = bytearray(_fq_file(3000, b"\n", rng))
+        k = raw.index(b"\n+\n", len(raw) // 2) + 40          # a '\r' in the middle of a quality line
+        raw[k] = 13
+        raw = bytes(raw)
+    elif shape == "cr_ends_granule":                         # the '\r' of a quality line as the LAST byte of a granule / of a run of 16, its '\n' behind it
+        alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
+        parts, pos, i = [], 0, 0
+        while pos < 24 * 65536:
+            i += 1
+            name = b"@r%d" % i
+            rl = 150 + i % 5
+            if i % 6 == 0:                                   # this record ends one byte behind a multiple of 4 KiB (every third time: of 64 KiB)
+                unit = 65536 if i % 18 == 0 else 4096
+                need = (1 - pos - len(name) - 9) % unit      # a record is len(name) + 2 rl + 9 bytes: name CRLF seq CRLF + CRLF qual CRLF
+                if need % 2:
+                    name += b"x"
+                    need = (need - 1) % unit
+                rl = need // 2
+                if rl < 20:
+                    rl += unit // 2
+            rec = name + b"\r\n" + alpha[rng.integers(0, 5, rl)].tobytes() + b"\r\n+\r\n" + rng.integers(35, 75, rl).astype(np.uint8).tobytes() + b"\r\n"
+            parts.append(rec)
+            pos += len(rec)
+            if i % 6 == 0:
+                assert pos % 4096 == 1, (pos, len(rec))
+        raw = b"".join(parts)
+        ends = [k for k in range(4095, len(raw) - 1, 4096) if raw[k] == 13 and raw[k + 1] == 10]
+        assert len(ends) > 20 and any(k % 65536 == 65535 for k in ends)
+    else:
+        # (plus_name: more than 64 runs of 64 KiB, all of them without a guess -- a handful would simply be counted again)
+        raw = _fq_file(16000 if shape == "plus_name" else 4000, b"\r\n" if shape == "crlf" else b"\n", rng, plus_name=(shape == "plus_name"),
+                       long_every=(25 if shape == "long_reads" else 0))
+    recs, size, ln = oracle.fastq_index(raw)
+    c = oracle.fastq_composition(raw)
+    b = L.Blob.from_bytes(raw)
+    s = b.fastq_build(comp=True)
+    assert (s.n_reads, s.size, s.n_lines) == (len(recs), size, ln)
+    runs, recounted, one_read = b.fastq_comp_info()
+    base, meta = b.fastq_comp()
+    assert base.tolist() == [c["a"], c["c"], c["g"], c["t"], c["n"]], shape
+    assert meta.tolist() == [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"], c["phred"]], shape
+    assert runs == (len(raw) // 4096 + 15) // 16
+    if shape in ("lf", "crlf", "crlf_fixture", "cr_ends_granule"):
+        assert one_read and 0 <= recounted <= max(1, runs // 100), (runs, recounted)
+    elif shape == "long_reads":
+        assert one_read and 0 < recounted <= max(64, runs // 8), (runs, recounted)
+    elif shape == "plus_name":
+        assert not one_read and recounted == -1              # no run has a guess: the table kernel counts
+    else:
+        assert not one_read                                  # the quirk of fastq.c:733-737 is k_fastq_qual_walk's
+    t = b.fastq_table(s.n_reads)
+    for col in ("name_off", "name_len", "dlen", "rlen", "soff", "qoff"):
+        np.testing.assert_array_equal(t[col], recs[col].astype(t[col].dtype), err_msg=col)

@@ -58,18 +58,28 @@ def main():
     b.close()
     os.unlink(p)
     del tab, packed, offs, order
-    t0 = time.perf_counter()
-    fq = fx.Fastq(path)
-    t1 = time.perf_counter()
-    out["Fastq_ctor_s"] = round(t1 - t0, 3)
-    out["index_phases"] = None if fq.index_phases is None else {k: round(v, 4) for k, v in fq.index_phases.items()}
+    out["ctor_runs"] = []
+    for rep in range(int(os.environ.get("C3_REPS", 2))):
+        for mode in ("presize", "no_presize"):
+            if os.path.exists(p):
+                os.unlink(p)
+            if mode == "no_presize":
+                os.environ["FX_FXI_NO_PRESIZE"] = "1"
+            else:
+                os.environ.pop("FX_FXI_NO_PRESIZE", None)
+            t0 = time.perf_counter()
+            fq = fx.Fastq(path)
+            t1 = time.perf_counter()
+            out["ctor_runs"].append({"mode": mode, "Fastq_ctor_s": round(t1 - t0, 3),
+                                     "build_phases": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in (fq.build_phases or {}).items()},
+                                     "index_phases": None if fq.index_phases is None else {k: round(v, 4) for k, v in fq.index_phases.items()}})
+            del fq
     out["fxi_GB_dev"] = round(os.path.getsize(p) / 1e9, 2)
     import sqlite3
     db = sqlite3.connect(p)
     i = n // 3
     out["probe_ok"] = db.execute("SELECT ID FROM read WHERE name=(SELECT name FROM read WHERE ID=?)", (i,)).fetchone()[0] == i
     db.close()
-    del fq
     os.unlink(p)
     os.unlink(path)
     os.rmdir(d)
