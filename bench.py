@@ -97,6 +97,18 @@ def _reference():
         return None
 
 
+def _device_cpulist(dev):
+    """local_cpulist of the device's PCI function: where libfxgpu pins the staging threads of that device (FX_STAGE_NUMA=0: nowhere)."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(dev)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/local_cpulist" % bdf) as f:
+            return {"pci": bdf, "local_cpulist": f.read().strip()}
+    except Exception as e:                                    # noqa: BLE001
+        return {"error": str(e)[:80]}
+
+
 def _tables(path, names):
     import sqlite3
     db = sqlite3.connect(path)
@@ -182,27 +194,36 @@ def cpu_fasta(path, plan, q, out, gpu_buf, gpu_offs, ours_rows):
         return False
     ids, st, sp, strand = q
     names = plan["names"]
-    _rm(path + ".fxi")
-    t0 = time.perf_counter()
-    fa = ref.Fasta(path)                                  # benchmark/pyfastx_fasta_build_index.py idiom
-    t1 = time.perf_counter()
-    got = []
-    app = got.append
+    # three repeats, the median -- of the constructor (the index file removed in between) and of the query loop
+    t_index, t_loop = [], []
+    fa = None
+    for _ in range(3):
+        del fa
+        _rm(path + ".fxi")
+        t0 = time.perf_counter()
+        fa = ref.Fasta(path)                              # benchmark/pyfastx_fasta_build_index.py idiom
+        t_index.append(time.perf_counter() - t0)
     ii, ss, ee, neg = ids.tolist(), st.tolist(), sp.tolist(), strand.tolist()
-    t2 = time.perf_counter()
-    for j in range(len(ii)):                              # benchmark/pyfastx_fasta_extract_subsequences.py idiom
-        s = fa[names[ii[j]]][ss[j]:ee[j]]
-        app(s.antisense if neg[j] else s.seq)
-    t3 = time.perf_counter()
+    got = None
+    for _ in range(3):
+        got = []
+        app = got.append
+        t2 = time.perf_counter()
+        for j in range(len(ii)):                          # benchmark/pyfastx_fasta_extract_subsequences.py idiom
+            s = fa[names[ii[j]]][ss[j]:ee[j]]
+            app(s.antisense if neg[j] else s.seq)
+        t_loop.append(time.perf_counter() - t2)
+    t0, t1, t2, t3 = 0.0, _median(t_index), 0.0, _median(t_loop)
     theirs = _tables(path + ".fxi", ("seq", "stat"))
     rows_equal = theirs["seq"] == ours_rows["seq"] and theirs["stat"][0][:2] == ours_rows["stat"][0][:2]
     bytes_equal = None
     if gpu_buf is not None:
         theirs_b = "".join(got).encode("latin-1")
         bytes_equal = (len(theirs_b) == int(gpu_offs[-1])) and theirs_b == gpu_buf[:int(gpu_offs[-1])].tobytes()
-    out.update(kind="reference", cores=1, index_s=round(t1 - t0, 3), fetch_s=round(t3 - t2, 3),
+    out.update(kind="reference", cores=1, index_s=round(t1 - t0, 3), fetch_s=round(t3 - t2, 3), repeats=3,
+               index_runs_s=[round(x, 3) for x in t_index], fetch_runs_s=[round(x, 3) for x in t_loop],
                rows_equal_gpu=bool(rows_equal), fetch_bytes_equal_gpu=bytes_equal,
-               sample="full workload: pyfastx.Fasta() on the %.2f GB file (no .fxi present) + %d fa[name][s:e].seq/.antisense, "
+               sample="full workload, medians of 3 (BASELINE.md 3.3): pyfastx.Fasta() on the %.2f GB file (no .fxi present) + %d fa[name][s:e].seq/.antisense, "
                       "every returned string compared with the GPU batch" % (os.path.getsize(path) / 1e9, len(ii)))
     del fa
     _rm(path + ".fxi")
@@ -928,7 +949,9 @@ def main_sharded(a, dev, rank, world, backend):
                                "%d random %d bp intervals (50%% '-' strand) on contigs it holds" % (world * a.gbp, world, a.gbp, len(gnames), world, a.queries, qlen),
                    "file_bytes": total, "file_bytes_per_gpu": int(job.n_bytes),
                    "parallelism": "byte-range shards of one file x%d (each rank reads only its range), 1 all-gather (%s)" % (world, backend),
-                   "collective": _collective_name(job, backend)},
+                   "collective": _collective_name(job, backend),
+                   # the host threads that stage a rank's byte range run on the CPUs next to its device (csrc/fxgpu.hip: device_cpus)
+                   "staging_cpus_of_rank0_device": _device_cpulist(dev)},
         "index_build_s": round(t_index / a.steps, 6),
         "fetch_M_per_s": round(world * a.queries / max(fetch_ms * 1e-3, 1e-9) / 1e6, 2),
         "parity_verified_full_size": verified,

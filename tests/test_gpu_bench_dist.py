@@ -30,11 +30,12 @@ def _last_json(out):
     return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_bench_two_ranks_one_gpu(world):
     """`python bench.py --gpus N` with NO launcher around it (the way the driver runs --gpus 1): bench.py starts its N ranks
     itself; fewer devices than ranks -> gloo, the ranks share the device.  The weak line (configs[4] shape) carries the
-    strong leg (ONE file split over the ranks) beside it."""
+    strong leg (ONE file split over the ranks) beside it.  world = 8: the driver's multi-GPU command shape with small inputs (the
+    full default sizes on one device: profiles/r05_bench_8ranks_gloo_one_gpu.json, 25 s of wall)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(FX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
