@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # the workload of one counter pass: generate, build three times, exit
     ap.add_argument("--no-c3-file", action="store_true", help="skip the full-size FASTQ file leg (35 GB file + 10 GB index in /dev/shm)")
     ap.add_argument("--c3-integrity", action="store_true", help="PRAGMA integrity_check of the 10 GB index file of the full-size FASTQ leg (SQLite reads all of it: about a minute)")
+    ap.add_argument("--c3-reference-full", action="store_true", help="the compiled reference on the FULL configs[2] file as well (pyfastx.Fastq(path, full_index=True): ~5 minutes on one core, "
+                                                                      "a second 10 GB index file), every `read` row + base / meta / stat compared (profiles/r05_c3_full_reference.json holds one such run)")
     ap.add_argument("--c4-ref-queries", type=int, default=100_000, help="queries of the C4 leg that the reference answers too (ascending offsets, through its restart points)")
     ap.add_argument("--pmc-file", default=None, help=argparse.SUPPRESS)                  # the counter passes' child opens this file instead of generating the stream
     return ap.parse_args()
@@ -447,6 +449,15 @@ def c3_full_file(a, path, n, cols, theirs_rows, m):
     from pyfastx_amd import _lib
     nb = os.path.getsize(path)
     _lib.Blob.from_file_range(path, 0, 1 << 24, 0).close()
+    # Twice: the FIRST block of 35 GB a process asks the driver for takes seconds to map (hipMalloc 2.9 s, and the first copies into it
+    # run at a third of the rate: tools/c3_outlier_probe.py), every later one 0.3 ms -- the first constructor pays that once per
+    # process, the second is what a process that has opened a file of this size before sees.  Both are reported; the phases are the second's.
+    t0 = time.perf_counter()
+    fq = fx.Fastq(path)
+    t1 = time.perf_counter()
+    first = {"Fastq_ctor_s": round(t1 - t0, 3), **{k: round(v, 3) for k, v in (getattr(fq, "build_phases", None) or {}).items() if isinstance(v, float)}}
+    del fq
+    _rm(path + ".fxi")
     t0 = time.perf_counter()
     fq = fx.Fastq(path)                                      # stage + scan + rows + names sorted + b-tree pages formatted on the device + pages to the file
     t1 = time.perf_counter()
@@ -493,12 +504,46 @@ def c3_full_file(a, path, n, cols, theirs_rows, m):
     for i in samp.tolist():                                   # ... and every sampled row through the name index
         by_name = by_name and db.execute("SELECT ID FROM read WHERE name=(SELECT name FROM read WHERE ID=?)", (i,)).fetchone()[0] == i
     db.close()
+    full_ref = None
+    if a.c3_reference_full and _reference() is not None:
+        # the reference on the whole file (fastq.c:8-182 + 663-795), its index file beside ours, every row compared by one join on the rowid
+        ref = _reference()
+        ours_path = path + ".ours.fxi"
+        os.rename(path + ".fxi", ours_path)
+        base_meta = None
+        try:
+            import pyfastx_amd as fx2
+            t6 = time.perf_counter()
+            fq2 = fx2.Fastq(path, index_file=ours_path, full_index=True)      # our base / meta for the whole file (the index is there: composition only)
+            t7 = time.perf_counter()
+            del fq2
+            rq = ref.Fastq(path, full_index=True)
+            t8 = time.perf_counter()
+            del rq
+            db = sqlite3.connect(path + ".fxi")
+            db.execute("ATTACH DATABASE ? AS ours", (ours_path,))
+            same = db.execute("SELECT count(*) FROM main.read r JOIN ours.read q ON q.ID = r.ID WHERE r.name = q.name AND r.dlen = q.dlen "
+                              "AND r.rlen = q.rlen AND r.soff = q.soff AND r.qoff = q.qoff").fetchone()[0]
+            counts = (db.execute("SELECT count(*) FROM main.read").fetchone()[0], db.execute("SELECT count(*) FROM ours.read").fetchone()[0])
+            base_meta = all(db.execute("SELECT * FROM main.%s" % t).fetchall() == db.execute("SELECT * FROM ours.%s" % t).fetchall() for t in ("base", "meta", "stat"))
+            t9 = time.perf_counter()
+            db.close()
+            full_ref = {"reference_Fastq_full_index_s": round(t8 - t7, 1), "ours_composition_on_the_indexed_file_s": round(t7 - t6, 3),
+                        "rows_compared": int(counts[0]), "rows_equal": int(same), "row_counts": list(counts), "base_meta_stat_equal": bool(base_meta),
+                        "compare_s": round(t9 - t8, 1), "cores": 1}
+        finally:
+            _rm(path + ".fxi")
+            os.rename(ours_path, path + ".fxi")
+        if full_ref["rows_equal"] != n or counts != (n, n) or not base_meta:
+            raise SystemExit("PARITY FAILURE (C3 at full size against the reference on the whole file): %r" % (full_ref,))
     res = {"workload": "configs[2] from a FILE: %d x 150 bp FASTQ (%.1f GB, page cache) -> pyfastx_amd.Fastq(path) with no .fxi present -> the index "
                        "file durable on disk (%.1f GB) -> %d random reads (seq + qual + int8 quali) into host memory" % (n, nb / 1e9, os.path.getsize(path + ".fxi") / 1e9, nq),
            "Fastq_ctor_s": round(t1 - t0, 3), "M_rows_per_s": round(n / (t1 - t0) / 1e6, 2),
            # both times -- the read table resident in HBM (batches can be served), the .fxi durable on disk
            "index_ready_s": round(bp["index_ready_s"], 3) if bp else None, "fxi_durable_s": round(bp["fxi_durable_s"], 3) if bp else None,
-           "phases_s": {"staging": round(bp.get("staging_s", 0.0), 3), "index_kernels": round(bp.get("scan_s", 0.0), 4),
+           "first_constructor_of_the_process": first,
+           "phases_s": {"staging": round(bp.get("staging_s", 0.0), 3), "device_alloc": round(bp.get("device_alloc_s", 0.0), 4),
+                        "page_cache_to_hbm": round(bp.get("page_cache_to_hbm_s", 0.0), 3), "index_kernels": round(bp.get("scan_s", 0.0), 4),
                         "name_sort_and_sqlite_schema": round(bp.get("fxi_s", 0.0) - sum(ip.values()), 3) if ip else None,
                         "page_shapes": round(ip.get("table_shape", 0.0) + ip.get("index_shape", 0.0), 4) if ip else None,
                         "page_kernels": round(ip.get("table_kernels", 0.0) + ip.get("index_kernels", 0.0), 4) if ip else None,
@@ -509,7 +554,8 @@ def c3_full_file(a, path, n, cols, theirs_rows, m):
                         "pages_formatted_on": "device" if ip else "host"} if bp else None,
            "fetch_many_1M_s": round(t3 - t2, 4),
            "sqlite_integrity_check": integrity, "integrity_check_s": round(t5 - t4, 1), "rows_sample_equal_generator": bool(rows_ok),
-           "rows_of_the_first_%d_reads_equal_reference" % m: prefix_equal, "name_probe_ok": bool(by_name), "fetch_sample_equal_file_bytes": bool(ok)}
+           "rows_of_the_first_%d_reads_equal_reference" % m: prefix_equal, "name_probe_ok": bool(by_name), "fetch_sample_equal_file_bytes": bool(ok),
+           "reference_on_the_whole_file": full_ref if full_ref is not None else "behind --c3-reference-full (one run: profiles/r05_c3_full_reference.json)"}
     if (a.c3_integrity and integrity != "ok") or not rows_ok or not ok or prefix_equal is False or not by_name:
         raise SystemExit("PARITY FAILURE (C3 at full size from a file): %r" % (res,))
     return res

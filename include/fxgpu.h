@@ -71,6 +71,11 @@ int fx_device_count(void);
  * of the first group (what is left over stays with the blob: fx_size is what it holds).  A single gzip stream is inflated on
  * the host cores. */
 int fx_open_file(const char *path, int device, fx_handle **out);
+/* Where the last fx_open_file of a PLAIN file spent its time (this thread): *alloc_s = the device allocation of the blob --
+ * the first block of tens of GB a process asks the driver for can take seconds (35 GB: 2.9 s measured), the next one of that
+ * size 0.3 ms --, *stage_s = page cache -> pinned pieces -> HBM.  (The reference has no counterpart: it reads through a 1 MiB
+ * buffer, kseq.h:13.) */
+int fx_open_laps(double *alloc_s, double *stage_s);
 /* What a file holds and how long its stream is once inflated -- kind 0: plain; 1: BGZF (*n_bytes = sum of the members'
  * ISIZE, from a walk over their headers); 2: a single gzip stream (*n_bytes = -1: unknown without inflating it). */
 int fx_stream_size(const char *path, int64_t *n_bytes, int *kind);

@@ -1390,7 +1390,8 @@ class Fastq(_fxobj.FastqCore):
         t_done = time.perf_counter()
         # where the constructor's time went (seconds): the stream to HBM, the index kernels ("index ready": the table is
         # resident), the index file durable on disk; index_phases has the parts of the last step when the device wrote it
-        self.build_phases = {"staging_s": t_staged - t_begin, "scan_s": t_ready - t_staged, "index_ready_s": t_ready - t_begin,
+        al, st = _lib.open_laps() if not self.is_gzip else (0.0, 0.0)
+        self.build_phases = {"staging_s": t_staged - t_begin, "device_alloc_s": al, "page_cache_to_hbm_s": st, "scan_s": t_ready - t_staged, "index_ready_s": t_ready - t_begin,
                              "fxi_s": t_done - t_ready, "fxi_durable_s": t_done - t_begin, "room_set_aside_early": bool(presized)}
         self._counts, self.size = int(s.n_reads), int(s.size)
         self.avglen = self.size * 1.0 / self._counts if self._counts else float("nan")

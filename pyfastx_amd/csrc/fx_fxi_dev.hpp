@@ -187,13 +187,11 @@ __device__ __forceinline__ void fxi_zero_page(uint8_t *pg, int lane) {
 __device__ __forceinline__ void fxi_store_page(const uint8_t *pg, uint8_t *__restrict__ dst, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    typedef uint32_t fxi_v4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int j = 0; j < FXI_PAGE / 1024; ++j) {
-        const uint4 v = reinterpret_cast<const uint4 *>(pg)[lane + 64 * j];
-        __builtin_nontemporal_store(v.x, reinterpret_cast<uint32_t *>(dst) + 4 * (lane + 64 * j));
-        __builtin_nontemporal_store(v.y, reinterpret_cast<uint32_t *>(dst) + 4 * (lane + 64 * j) + 1);
-        __builtin_nontemporal_store(v.z, reinterpret_cast<uint32_t *>(dst) + 4 * (lane + 64 * j) + 2);
-        __builtin_nontemporal_store(v.w, reinterpret_cast<uint32_t *>(dst) + 4 * (lane + 64 * j) + 3);
+    for (int j = 0; j < FXI_PAGE / 1024; ++j) {              // four coalesced 1 KiB stores, past the caches (the page is not read again here)
+        const fxi_v4 v = reinterpret_cast<const fxi_v4 *>(pg)[lane + 64 * j];
+        __builtin_nontemporal_store(v, reinterpret_cast<fxi_v4 *>(dst) + lane + 64 * j);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

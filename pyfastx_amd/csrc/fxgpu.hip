@@ -66,6 +66,14 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *fx_last_error(void) { return g_err.c_str(); }
+// the last fx_open_file of a plain file by this thread: seconds for the device allocation (the FIRST block of tens of GB a
+// process asks the driver for takes seconds, the next one of that size microseconds) and for page cache -> pinned -> HBM
+static thread_local double g_open_laps[2] = {0.0, 0.0};
+extern "C" int fx_open_laps(double *alloc_s, double *stage_s) {
+    if (alloc_s) *alloc_s = g_open_laps[0];
+    if (stage_s) *stage_s = g_open_laps[1];
+    return FX_OK;
+}
 extern "C" const char *fx_version(void) { return "fxgpu 0.1.0 (gfx950)"; }
 extern "C" int fx_device_count(void) {
     int n = 0;
@@ -1472,12 +1480,18 @@ static int open_file_impl(const char *path, int device, fx_handle **out, int64_t
 
     if (!gz) {
         const int64_t n = (int64_t)st.st_size;
+        static const bool trace_p = [] { const char *e = getenv("FX_TRACE"); return e && atoi(e) != 0; }();
+        const auto tp0 = std::chrono::steady_clock::now();
         rc = alloc_blob(h, n);
         if (rc) return bail(rc);
         if (hipStreamSynchronize(h->stream) != hipSuccess)   // the pad memset precedes the copies of the staging streams
             return bail(fail(FX_EDEVICE, "stream sync failed"));
+        const auto tp1 = std::chrono::steady_clock::now();
         rc = stage_plain_file(h, fd, n, path, h->d_data);
         if (rc) return bail(rc);
+        g_open_laps[0] = std::chrono::duration<double>(tp1 - tp0).count();
+        g_open_laps[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - tp1).count();
+        if (trace_p) fprintf(stderr, "[fxgpu] open plain %.2f GB: blob %.1f ms, page cache -> pinned -> HBM %.1f ms\n", n / 1e9, g_open_laps[0] * 1e3, g_open_laps[1] * 1e3);
     } else {
         // BGZF (bgzip): every member inflates independently -> GPU (k_bgzf_inflate)
         {

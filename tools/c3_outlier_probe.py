@@ -54,7 +54,18 @@ def main():
         del fq
     out["runs"] = runs
     os.remove(path + ".fxi"); os.remove(path)
-    if full:
+    if full:                                                # the full file: first and second constructor of the process (FX_TRACE=1: blob / staging laps on stderr)
+        fp = os.path.join(d, "c3_full.fq")
+        out["full_runs"] = []
+        for rep in range(3):
+            if os.path.exists(fp + ".fxi"):
+                os.remove(fp + ".fxi")
+            t0 = time.perf_counter()
+            fq = fx.Fastq(fp)
+            t1 = time.perf_counter()
+            out["full_runs"].append({"ctor_s": round(t1 - t0, 3), "build_phases": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in (fq.build_phases or {}).items()}})
+            del fq
+        os.remove(fp + ".fxi")
         os.remove(os.path.join(d, "c3_full.fq"))
     os.rmdir(d)
     print(json.dumps(out))
