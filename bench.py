@@ -340,6 +340,10 @@ def leg_c3(a, dev, tmpdir):
         "roofline": {"kernel": "fx::k_fastq_lines", "bound": "hbm", "achieved": round(nb / (kl * 1e-3) / 1e9, 1) if kl else None,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb / (kl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kl else None,
                      "algorithmic_bytes_per_launch": nb, "avg_launch_ms": round(kl, 4), "traffic": None},
+        # the scan kernels of the FASTQ build are bound by the vector instructions they issue, not by HBM (VERDICT r4 missing #6): the
+        # floor is instructions per 4 KiB granule and wave (SQ_INSTS_VALU / granules, PMC pass of the round) x 4 cycles of a SIMD each
+        # / (1024 SIMDs x 2.4 GHz); frac = floor / measured time
+        "roofline_issue": {name: _issue_roofline(name, nb, ms) for name, ms in (("k_fastq_lines", kl), ("k_fastq_lines_comp", prof_one.get("k_fastq_lines", 0.0))) if ms},
         "roofline_build": {"algorithmic_bytes": build_alg, "frac": round(build_alg / ((t1 - t0) / R) / 1e9 / HBM_PEAK_GBS, 4)},
         "roofline_comp": {"kernel": "fx::k_fastq_comp", "algorithmic_bytes": comp_alg,
                           "frac": round(comp_alg / (prof.get("k_fastq_comp", 1e9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
@@ -585,7 +589,8 @@ def leg_c4(a, host, plan, q, tmpdir, plain_digest=None):
     csize = os.path.getsize(path)
     L = _lib.lib()
     L.fx_prof_default(1)
-    os.environ.setdefault("FX_TRACE_BGZF", "1")           # the laps of every BGZF open of this leg go to stderr (read at the first open)
+    if os.environ.get("FX_BENCH_TRACE"):                  # (FX_BENCH_TRACE=1: the laps of every BGZF open of this leg on stderr; off in the default run)
+        os.environ.setdefault("FX_TRACE_BGZF", "1")
     _lib.Blob.from_file(path).close()                     # first touch
     t_open = []
     prof = {}
@@ -747,6 +752,22 @@ def _host_truth(mm, G, g, a, b, neg):
 _COMP = bytes.maketrans(b"ACGTacgtMKRYVBHDmkryvbhdUu", b"TGCAtgcaKMYRBVDHkmyrbvdhAa")
 
 
+# vector instructions per 4 KiB granule and wave (SQ_INSTS_VALU of a PMC pass / granules of its stream); source file beside each
+VALU_PER_GRANULE = {"k_fastq_lines": (506, "profiles/r03_pmc_fastq.txt"), "k_fastq_lines_comp": (855, "profiles/r04_pmc_fastq_sq.txt")}
+N_SIMD, CLOCK_HZ = 1024, 2.4e9                              # 256 CUs x 4 SIMDs, MI355X_MICROARCH.md (max clock)
+
+
+def _issue_roofline(kernel, stream_bytes, measured_ms):
+    per, src = VALU_PER_GRANULE[kernel]
+    floor_ms = per * (stream_bytes / 4096.0) * 4.0 / (N_SIMD * CLOCK_HZ) * 1e3
+    return {"bound": "valu issue", "valu_instructions_per_granule_and_wave": per, "counter_source": src, "granules": int(stream_bytes // 4096),
+            "floor_ms": round(floor_ms, 3), "avg_launch_ms": round(measured_ms, 4), "frac": round(floor_ms / measured_ms, 4),
+            "hbm_frac": round(stream_bytes / (measured_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+_FETCH_PMC = {}                                              # FETCH_SIZE / WRITE_SIZE (KiB per launch) of k_fetch_lines from the same two passes
+
+
 def live_pmc_traffic(a, file_bytes, file_path=None):
     """HBM bytes per k_span_scan launch, measured NOW: two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE: separate runs,
     counters only -- MI355X_MICROARCH.md, HBM section) over a child of this script that generates the same stream and builds
@@ -773,15 +794,24 @@ def live_pmc_traffic(a, file_bytes, file_path=None):
             if r.returncode != 0:
                 return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-200:])
             tot, ids = 0.0, set()
+            ftot, fids = 0.0, set()
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f, newline="") as fh:
                     for row in csv.DictReader(fh):
-                        if row.get("Counter_Name") == counter and "k_span_scan<0>" in row.get("Kernel_Name", ""):
+                        if row.get("Counter_Name") != counter:
+                            continue
+                        kn = row.get("Kernel_Name", "")
+                        if "k_span_scan<0>" in kn:
                             tot += float(row["Counter_Value"])
                             ids.add(row.get("Dispatch_Id", len(ids)))
+                        elif "k_fetch_lines" in kn:
+                            ftot += float(row["Counter_Value"])
+                            fids.add(row.get("Dispatch_Id", len(fids)))
             if not ids:
                 return None, "no k_span_scan<0> rows in the %s pass" % counter
             per[counter] = tot / len(ids)
+            if fids:
+                _FETCH_PMC[counter] = ftot / len(fids)
     except Exception as e:                                  # a profiler that is missing, hangs or writes another format: the committed figure stands
         return None, "%s: %s" % (type(e).__name__, e)
     finally:
@@ -1361,6 +1391,12 @@ def main():
         for _ in range(3):
             b.fasta_build()
         b.sync()
+        # ... and the run's own batch of queries, three times (k_fetch_lines: the traffic of roofline_fetch); plan and queries are numpy
+        from pyfastx_amd import synth
+        plan = synth.fasta_plan(total_bp=int(a.gbp * 1e9), seed=20260612)
+        ids, st, sp, strand = synth.fasta_queries(plan, n=a.queries, seed=12345)
+        for _ in range(3):
+            b.fasta_fetch_alloc(ids, st, sp, flags_per_query=(strand * 6).astype(np.uint8))
         b.close()
         return
     import torch
@@ -1614,6 +1650,17 @@ def main():
                     line["roofline"]["traffic"], line["roofline"]["traffic_source"] = tr, src
                 else:
                     line["roofline"]["traffic_source"] += "; a live measurement was tried and failed: " + src
+                if "FETCH_SIZE" in _FETCH_PMC and "WRITE_SIZE" in _FETCH_PMC:
+                    # a gather of ~100-byte pieces: 64-byte sectors are what FETCH_SIZE counts here (no wide coalesced stream: no x 2)
+                    rf = line["roofline_fetch"]
+                    rd, wr = int(_FETCH_PMC["FETCH_SIZE"] * 1024), int(_FETCH_PMC["WRITE_SIZE"] * 1024)
+                    rf["traffic"] = rd + wr
+                    rf["traffic_source"] = ("the same two rocprofv3 passes, rows of k_fetch_lines (3 launches of the run's own %d queries): FETCH_SIZE %.0f KiB + WRITE_SIZE %.0f KiB "
+                                            "per launch = %.2f x the algorithmic bytes; %.0f B fetched per query = %.2f lines of 128 B (a 100-base interval at a random offset "
+                                            "of a 61-byte-per-line record touches 1.8), so the kernel moves %.1f TB/s of lines to deliver its answers"
+                                            % (a.queries, _FETCH_PMC["FETCH_SIZE"], _FETCH_PMC["WRITE_SIZE"], (rd + wr) / max(rf["algorithmic_bytes_per_launch"], 1),
+                                               rd / a.queries, rd / a.queries / 128.0, (rd + wr) / max(rf["avg_launch_ms"] * 1e-3, 1e-12) / 1e12))
+                    rf["frac_of_measured_traffic"] = round((rd + wr) / max(rf["avg_launch_ms"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4)
                 a.no_pmc = True
             _rm(path)
             _lap("pmc passes")

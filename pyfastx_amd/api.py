@@ -1791,26 +1791,47 @@ class Fastx:
 
 def _kseq_batches(get_blob, close_blob, fastq, upper, owner=None):
     """(hdr bytes, their offsets, seq bytes, qual bytes | None, record table) per batch of kseq_read's records over a staged
-    stream (fx_kseq_scan / _records / _fetch), None at the end."""
+    stream (fx_kseq_scan / _records / _fetch), None at the end.  The NEXT batch is gathered and copied to the host by a helper
+    thread while the consumer makes the tuples of this one (the C calls release the interpreter lock; one call at a time on the
+    handle): the device side of the iteration -- a sixth of its time -- hides behind the object creation."""
+    from concurrent.futures import ThreadPoolExecutor
     blob = get_blob()
+    pool = ThreadPoolExecutor(max_workers=1)
     try:
         n_rec, _, _, code = blob.kseq_scan()
         if owner is not None:
             owner.end_code = code
-        for a in range(0, n_rec, Fastx.BATCH_RECORDS):
-            recs = blob.kseq_records(a, min(Fastx.BATCH_RECORDS, n_rec - a))
-            cum, slen = recs["seq_cum"], recs["seq_len"]
-            i = 0
-            while i < recs.size:
-                ends = cum[i:] + slen[i:] - cum[i]
-                k = i + max(1, int(np.searchsorted(ends, Fastx.BATCH_BYTES, side="right")))
-                nbytes = int(ends[k - i - 1])
-                seq, qual = blob.kseq_fetch(a + i, k - i, nbytes, upper=upper, want_qual=fastq)
-                hl = recs["hdr_len"][i:k].astype(np.int64)
-                hdr, ho, _ = blob.fetch_ranges(recs["hdr_off"][i:k], hl, hl, flags=_lib.FX_RAW)
-                yield hdr, ho, seq, qual, recs[i:k]
-                i = k
+
+        def pieces():                                            # (first record, count, bytes) of every batch, chunk of records by chunk
+            for a in range(0, n_rec, Fastx.BATCH_RECORDS):
+                recs = blob.kseq_records(a, min(Fastx.BATCH_RECORDS, n_rec - a))
+                cum, slen = recs["seq_cum"], recs["seq_len"]
+                i = 0
+                while i < recs.size:
+                    ends = cum[i:] + slen[i:] - cum[i]
+                    k = i + max(1, int(np.searchsorted(ends, Fastx.BATCH_BYTES, side="right")))
+                    yield a, recs, i, k, int(ends[k - i - 1])
+                    i = k
+
+        def fetch(job):
+            a, recs, i, k, nbytes = job
+            seq, qual = blob.kseq_fetch(a + i, k - i, nbytes, upper=upper, want_qual=fastq)
+            hl = recs["hdr_len"][i:k].astype(np.int64)
+            hdr, ho, _ = blob.fetch_ranges(recs["hdr_off"][i:k], hl, hl, flags=_lib.FX_RAW)
+            return hdr, ho, seq, qual, recs[i:k]
+
+        jobs = pieces()
+        ahead = None
+        job = next(jobs, None)
+        if job is not None:
+            ahead = pool.submit(fetch, job)
+        while ahead is not None:
+            out = ahead.result()
+            job = next(jobs, None)                               # (kseq_records of the next chunk runs here, after the fetch before it is done)
+            ahead = pool.submit(fetch, job) if job is not None else None
+            yield out
     finally:
+        pool.shutdown(wait=True)
         if close_blob:
             blob.close()
     yield None

@@ -565,20 +565,24 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_rows_wg(ScanCtx x, FqOwn own, F
 }
 
 // newlines in up to three 256 KiB windows of the stream (start, middle, end): the line density that decides
-// between the two forms of the build (fastq_count).  out[0] += newlines, out[1] += bytes looked at.
+// between the two forms of the build (fastq_count).  out[0] += newlines, out[1] += bytes looked at, out[2] += "\r\n" pairs.
 constexpr int64_t FQ_SAMPLE = 256 * 1024;
 __global__ __launch_bounds__(BLOCK) void k_nl_sample(const uint8_t *__restrict__ data, int64_t n, unsigned long long *out) {
     const int64_t len = n < FQ_SAMPLE ? n : FQ_SAMPLE;
     int64_t lo = blockIdx.x == 0 ? 0 : (blockIdx.x == 1 ? (n / 2) & ~15ll : (n - len) & ~15ll);
     if (blockIdx.x > 0 && n <= (int64_t)(blockIdx.x + 1) * FQ_SAMPLE) return;      // short stream: the first window(s) cover it
     const int64_t hi = lo + len < n ? lo + len : n;
-    uint32_t c = 0;
+    uint32_t c = 0, crlf = 0;
     for (int64_t p = lo + (int64_t)threadIdx.x * CHUNK; p < hi; p += (int64_t)BLOCK * CHUNK) {
-        uint32_t m = eq_mask16(load16(data, p, n), 0x0A0A0A0Au);
+        const uint4 v = load16(data, p, n);
+        uint32_t m = eq_mask16(v, 0x0A0A0A0Au);
         if (hi - p < CHUNK) m &= (1u << (hi - p)) - 1u;
         c += __popc(m);
+        crlf += __popc((eq_mask16(v, 0x0D0D0D0Du) << 1) & m);     // "\r\n" inside a chunk: does the stream end its lines that way? (out[2])
     }
     c = wave_sum(c);
+    crlf = wave_sum(crlf);
+    if (lane_id() == 0 && crlf) atomicAdd(&out[2], (unsigned long long)crlf);
     if (lane_id() == 0) { atomicAdd(&out[0], (unsigned long long)c); }
     if (threadIdx.x == 0) atomicAdd(&out[1], (unsigned long long)(hi - lo));
 }

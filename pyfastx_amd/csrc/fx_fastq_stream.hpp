@@ -119,8 +119,11 @@ __device__ __forceinline__ void fsq_init(FsQ &q) {
 // One row (1 KiB: a 16-byte chunk per lane) of a granule through the counters.  pA: which line of four the chunk's first byte
 // belongs to; nlm / crm: the chunk's newline and '\r' maps; row_cr: some lane of the row holds a '\r'; next_first: 1 / 0 = the
 // chunk behind lane 63's begins / does not begin with '\n', 2 = not known here (the caller settles a.pend).
-template <int J>
-__device__ __forceinline__ void fs_row(const uint4 &vj, uint32_t nlmj, uint32_t crmj, bool row_cr, uint32_t next_first, uint32_t pA,
+// CRLF = false: the form for streams without '\r\n' line ends (what the build's sample of the stream says: nearly every file) --
+// no '\r' logic at all, a '\r' among the quality bytes is below '!' and raises the odd flag like any such byte (the three
+// instructions per row and the registers the other form costs were 3 % of k_fastq_lines_comp: 10.74 -> 11.10 ms for C3).
+template <int J, bool CRLF>
+__device__ __forceinline__ void fs_row(const uint4 &vj, uint32_t nlmj, uint32_t crmj, bool row_cr, uint32_t nlm_next, uint32_t pA,
                                        const uint4 *s_mask, FsAcc &a, CompCarry &cy, FsQ &qs, int *fix, int lane) {
     // Up to two line ends in a chunk ('+' lines are two bytes long: nearly every record has such a chunk): three stretches --
     // in front of the first newline (line pA), between the two (pA + 1), behind the second (pA + 2) -- of which at most one
@@ -134,11 +137,13 @@ __device__ __forceinline__ void fs_row(const uint4 &vj, uint32_t nlmj, uint32_t 
     const uint32_t rs = slow ? 3u : (1u - pA) & 3u, rq = slow ? 3u : (3u - pA) & 3u;
     const uint4 ms = s_mask[rs * 289u + kx];
     uint4 mq = s_mask[rq * 289u + kx];
-    if (row_cr) {
+    if (CRLF && row_cr) {
         const uint4 crb = fs_cr_bytes(vj);
         mq.x &= ~crb.x; mq.y &= ~crb.y; mq.z &= ~crb.z; mq.w &= ~crb.w;
         uint32_t lone = crmj & ~(nlmj >> 1) & 0x7FFFu;                 // a '\r' with something else than '\n' behind it
         const uint32_t nb = (uint32_t)__shfl_down((int)(nlmj & 1u), 1, 64);
+        // the chunk behind lane 63's: lane 0 of the next row (nlm_next), or -- last row, J == 3 -- not known here (the caller settles a.pend)
+        const uint32_t next_first = J < 3 ? (uint32_t)__builtin_amdgcn_readlane((int)nlm_next, 0) & 1u : 2u;
         if (crmj & 0x8000u) {                                          // the chunk's last byte: the next chunk's first byte decides
             const uint32_t nf = lane < 63 ? nb : next_first;
             if (nf == 0u) lone |= 0x8000u;
@@ -277,10 +282,10 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__re
         }
         const uint32_t L0 = (uint32_t)((line0 + nl_prefix[g]) & 3);
         CompCarry cy;
-        fs_row<0>(v[0], nlm[0], crm[0], rcr[0], (uint32_t)__builtin_amdgcn_readlane((int)nlm[1], 0) & 1u, (L0 + ex[0]) & 3u, s_mask, a, cy, qs, fix, lane);
-        fs_row<1>(v[1], nlm[1], crm[1], rcr[1], (uint32_t)__builtin_amdgcn_readlane((int)nlm[2], 0) & 1u, (L0 + ex[1]) & 3u, s_mask, a, cy, qs, fix, lane);
-        fs_row<2>(v[2], nlm[2], crm[2], rcr[2], (uint32_t)__builtin_amdgcn_readlane((int)nlm[3], 0) & 1u, (L0 + ex[2]) & 3u, s_mask, a, cy, qs, fix, lane);
-        fs_row<3>(v[3], nlm[3], crm[3], rcr[3], 2u, (L0 + ex[3]) & 3u, s_mask, a, cy, qs, fix, lane);
+        fs_row<0, true>(v[0], nlm[0], crm[0], rcr[0], nlm[1], (L0 + ex[0]) & 3u, s_mask, a, cy, qs, fix, lane);
+        fs_row<1, true>(v[1], nlm[1], crm[1], rcr[1], nlm[2], (L0 + ex[1]) & 3u, s_mask, a, cy, qs, fix, lane);
+        fs_row<2, true>(v[2], nlm[2], crm[2], rcr[2], nlm[3], (L0 + ex[2]) & 3u, s_mask, a, cy, qs, fix, lane);
+        fs_row<3, true>(v[3], nlm[3], crm[3], rcr[3], 0u, (L0 + ex[3]) & 3u, s_mask, a, cy, qs, fix, lane);
         static_assert(GR_ROWS == 4, "four rows per granule");
         planes_finish16(a.pl, cy);
         if (__ballot(a.pend)) {                              // a '\r' as the granule's last byte: the byte behind it (the end of the stream passes)
@@ -363,6 +368,7 @@ static_assert(FQLC_G % FQR_G == 0, "the count pass fills one record slot per FQR
 struct FqRun { uint32_t cnt[5]; uint32_t q; uint32_t guess; uint32_t pad; };   // q: min | max << 8 | have << 16 | odd << 17; guess: 0..3, 0xFF none
 static_assert(sizeof(FqRun) == 32, "one run record is 32 bytes");
 
+template <bool CRLF>
 __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__restrict__ data, int64_t n, int prev_byte, int64_t g_end,
                                                            GranPk *__restrict__ out, uint32_t *__restrict__ recs, GranList ovl,
                                                            FqRun *__restrict__ runs, int64_t nruns) {
@@ -412,15 +418,15 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
         for (int j = 0; j < GR_ROWS; ++j) {
             nlm[j] = eq_mask16(v[j], 0x0A0A0A0Au);
             s_sp[w][j * 64 + lane] = (uint16_t)eq_mask16(v[j], 0x20202020u);
-            crm[j] = fq_cr_mask2(v[j], rcr[j]);
-            s_cr[w][j * 64 + lane] = (uint16_t)crm[j];
+            if (CRLF) { crm[j] = fq_cr_mask2(v[j], rcr[j]); s_cr[w][j * 64 + lane] = (uint16_t)crm[j]; }
+            else { crm[j] = 0; rcr[j] = false; s_cr[w][j * 64 + lane] = fq_cr_mask(v[j]); }
             const uint32_t cj = (uint32_t)__popc(nlm[j]);
             const uint32_t inc = wave_incl_scan(cj);
             ex[j] = run_n + inc - cj;                      // newlines of the granule in front of this chunk
             run_n += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
         const uint32_t M = run_n;
-        if (__ballot(a.pend)) {                                // the granule before ended on a '\r': this one must begin with '\n'
+        if (CRLF && __ballot(a.pend)) {                        // the granule before ended on a '\r': this one must begin with '\n'
             if (a.pend && !(__builtin_amdgcn_readlane((int)nlm[0], 0) & 1)) a.qodd = true;
             a.pend = false;
         }
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
 #pragma unroll
             for (int j = 0; j < GR_ROWS; ++j) {
                 uint32_t cand = nlm[j] & (nlm[j] << 2) & ~(nlm[j] << 1) & 0xFFFFu;     // second newline of a pair inside the chunk
-                if (rcr[j]) cand |= nlm[j] & (nlm[j] << 3) & ~(nlm[j] << 1) & ~(nlm[j] << 2) & (crm[j] << 1) & 0xFFFFu;
+                if (CRLF && rcr[j]) cand |= nlm[j] & (nlm[j] << 3) & ~(nlm[j] << 1) & ~(nlm[j] << 2) & (crm[j] << 1) & 0xFFFFu;
                 if (cand) {
                     const uint32_t b = (uint32_t)__ffs(cand) - 1u;
                     const uint32_t i = ex[j] + (uint32_t)__popc(nlm[j] & ((1u << b) - 1u));   // that newline is the granule's i-th: line i is line 2 of four
@@ -452,10 +458,10 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
         if (guess != 0xFFu) {
             const uint32_t L0 = (guess + lines_before) & 3u;
             CompCarry cy;
-            fs_row<0>(v[0], nlm[0], crm[0], rcr[0], (uint32_t)__builtin_amdgcn_readlane((int)nlm[1], 0) & 1u, (L0 + ex[0]) & 3u, s_mask, a, cy, qs, fix, lane);
-            fs_row<1>(v[1], nlm[1], crm[1], rcr[1], (uint32_t)__builtin_amdgcn_readlane((int)nlm[2], 0) & 1u, (L0 + ex[1]) & 3u, s_mask, a, cy, qs, fix, lane);
-            fs_row<2>(v[2], nlm[2], crm[2], rcr[2], (uint32_t)__builtin_amdgcn_readlane((int)nlm[3], 0) & 1u, (L0 + ex[2]) & 3u, s_mask, a, cy, qs, fix, lane);
-            fs_row<3>(v[3], nlm[3], crm[3], rcr[3], 2u, (L0 + ex[3]) & 3u, s_mask, a, cy, qs, fix, lane);
+            fs_row<0, true>(v[0], nlm[0], crm[0], rcr[0], nlm[1], (L0 + ex[0]) & 3u, s_mask, a, cy, qs, fix, lane);
+            fs_row<1, true>(v[1], nlm[1], crm[1], rcr[1], nlm[2], (L0 + ex[1]) & 3u, s_mask, a, cy, qs, fix, lane);
+            fs_row<2, true>(v[2], nlm[2], crm[2], rcr[2], nlm[3], (L0 + ex[2]) & 3u, s_mask, a, cy, qs, fix, lane);
+            fs_row<3, CRLF>(v[3], nlm[3], crm[3], rcr[3], 0u, (L0 + ex[3]) & 3u, s_mask, a, cy, qs, fix, lane);
             planes_finish16(a.pl, cy);
         }
         lines_before += M;
@@ -491,7 +497,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
     }
     // ---- the run's record
     {
-        if (__ballot(a.pend)) {                                // the run's last byte is a '\r': the byte behind it, from memory (the end of the stream passes)
+        if (CRLF && __ballot(a.pend)) {                        // the run's last byte is a '\r': the byte behind it, from memory (the end of the stream passes)
             const int64_t q = (gw + FQLC_G < g_end ? gw + FQLC_G : g_end) * (int64_t)GRAN;
             if (a.pend && q < n && data[q] != 10) a.qodd = true;
         }

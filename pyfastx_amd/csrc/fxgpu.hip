@@ -311,6 +311,7 @@ struct fx_handle {
     int fq_comp_minqs = 104, fq_comp_maxqs = 33;
     DevBuf<uint32_t> fq_lines;                // k_fastq_lines: FQL_CAP line records per granule
     bool fq_by_lines = false;                 // the last count pass wrote line records (else: counts only)
+    bool fq_crlf = false;                     // the sampled windows of the stream hold "\r\n" (fastq_count): k_fastq_lines_comp<true>
     int64_t fq_nlist = 0;                     // granules k_fastq_emit has to read again (overflowing ones + the partial last)
     int64_t n_reads = 0, fq_size = 0, fq_seq_rows = 0;    // complete records; rows that have a sequence line (>= n_reads)
     int64_t fq_c2 = 0;         // newlines of the shard below core_end - 1 (ownership of records, fx_fastq_scan)
@@ -1893,8 +1894,13 @@ static int granule_pass(fx_handle *h, bool fq_lines = false, bool with_comp = fa
             const int64_t nruns = (nfull + FQLC_G - 1) / FQLC_G;
             if ((rc = h->fq_runs.alloc(nruns)) || (rc = h->fq_acc_build.alloc(1)) || (rc = h->fq_rej.alloc(nruns + 1))) return rc;
             static const int64_t grid_cap = [] { const char *e = getenv("FX_FQ_FUSED_GRID"); return e && atoll(e) > 0 ? atoll(e) : 6144ll; }();
-            FX_LAUNCH(h, K_FASTQ_LINES, k_fastq_lines_comp, dim3((unsigned)std::min<int64_t>(nblocks(nruns, BLOCK / 64), grid_cap)), dim3(BLOCK), h->d_data,
-                      h->n, h->prev_byte, nfull, h->gran.p, h->fq_lines.p, hgl, h->fq_runs.p, nruns);
+            static const int force_crlf = [] { const char *e = getenv("FX_FQ_CRLF"); return e ? atoi(e) : -1; }();      // 0 / 1: experiments
+            if (force_crlf >= 0 ? force_crlf != 0 : h->fq_crlf)
+                FX_LAUNCH(h, K_FASTQ_LINES, k_fastq_lines_comp<true>, dim3((unsigned)std::min<int64_t>(nblocks(nruns, BLOCK / 64), grid_cap)), dim3(BLOCK), h->d_data,
+                          h->n, h->prev_byte, nfull, h->gran.p, h->fq_lines.p, hgl, h->fq_runs.p, nruns);
+            else
+                FX_LAUNCH(h, K_FASTQ_LINES, k_fastq_lines_comp<false>, dim3((unsigned)std::min<int64_t>(nblocks(nruns, BLOCK / 64), grid_cap)), dim3(BLOCK), h->d_data,
+                          h->n, h->prev_byte, nfull, h->gran.p, h->fq_lines.p, hgl, h->fq_runs.p, nruns);
         } else
         FX_LAUNCH(h, K_FASTQ_LINES, k_fastq_lines, dim3(nblocks(nfull, (BLOCK / 64) * FQL_G)), dim3(BLOCK), h->d_data, h->n, h->prev_byte, nfull,
                   h->gran.p, h->fq_lines.p, hgl);
@@ -2180,15 +2186,17 @@ static int fastq_count(fx_handle *h, int64_t *n_nl_core, int64_t *last_nl_core, 
     // One read or two?  Line records pay when most granules fit their slot: ask three windows of the stream.
     static const int force = [] { const char *e = getenv("FX_FQ_LINES"); return e ? atoi(e) : -1; }();   // 0 / 1: experiments
     bool by_lines = force > 0;
-    if (force < 0 && h->n >= 4 * GRAN) {
+    h->fq_crlf = false;
+    if (h->n >= 4 * GRAN) {
         if ((rc = h->ctl.alloc(64))) return rc;
-        HIPCHK(hipMemsetAsync(h->ctl.p + 56, 0, 2 * sizeof(unsigned long long), h->stream));
+        HIPCHK(hipMemsetAsync(h->ctl.p + 56, 0, 3 * sizeof(unsigned long long), h->stream));
         hipLaunchKernelGGL(k_nl_sample, dim3(3), dim3(BLOCK), 0, h->stream, h->d_data, h->n, h->ctl.p + 56);
         HIPCHK(hipGetLastError());
-        unsigned long long smp[2];
+        unsigned long long smp[3];
         HIPCHK(hipMemcpyAsync(smp, h->ctl.p + 56, sizeof smp, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        by_lines = smp[1] > 0 && (double)smp[0] / (double)smp[1] * GRAN <= 0.7 * FQL_CAP;
+        if (force < 0) by_lines = smp[1] > 0 && (double)smp[0] / (double)smp[1] * GRAN <= 0.7 * FQL_CAP;
+        h->fq_crlf = smp[2] > 0;                              // the sampled windows hold "\r\n": the stream kernels take their CRLF form
     }
     // the composition on the way (fx_fastq_build_comp): whole streams with line records only -- a shard counts the reads it OWNS
     static const bool no_fuse = [] { const char *e = getenv("FX_FQ_NO_FUSED_COMP"); return e && atoi(e) != 0; }();

@@ -383,8 +383,26 @@ typedef struct { int64_t hdr_off, hdr_line, seq_len, seq_cum; uint32_t hdr_len, 
 
 static PyObject *cstr_text(const uint8_t *p, int64_t n)          /* Py_BuildValue "s": up to the first NUL */
 {
-    const uint8_t *z = (const uint8_t *)memchr(p, 0, (size_t)n);
-    return PyUnicode_DecodeUTF8((const char *)p, z ? (Py_ssize_t)(z - p) : (Py_ssize_t)n, "surrogateescape");
+    /* Bases and qualities are ASCII without a NUL in every file there is: one pass over the bytes, eight at a time, finds out, and
+     * the string is then made without the decoder (a compact ASCII object + memcpy).  Anything else -- a NUL, a byte above 127 --
+     * takes the route "s" takes. */
+    int64_t i = 0;
+    uint64_t bad = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        bad |= (w & 0x8080808080808080ull) | ((w - 0x0101010101010101ull) & ~w & 0x8080808080808080ull);
+    }
+    for (; i < n; ++i) bad |= (uint64_t)(p[i] >= 0x80 || p[i] == 0);
+    if (!bad) {
+        PyObject *u = PyUnicode_New((Py_ssize_t)n, 127);
+        if (u && n) memcpy(PyUnicode_1BYTE_DATA(u), p, (size_t)n);
+        return u;
+    }
+    {
+        const uint8_t *z = (const uint8_t *)memchr(p, 0, (size_t)n);
+        return PyUnicode_DecodeUTF8((const char *)p, z ? (Py_ssize_t)(z - p) : (Py_ssize_t)n, "surrogateescape");
+    }
 }
 static int kq_isspace(int c) { return c == ' ' || (c >= 9 && c <= 13); }
 
@@ -424,10 +442,19 @@ static PyObject *kq_tuple(const uint8_t *h, int64_t hl, const uint8_t *s_ptr, co
         else if (*buffered) com = PyUnicode_FromStringAndSize("", 0);
         else com = Py_NewRef(Py_None);
     }
-    if (!name || !s || (with_comment && !com)) t = NULL;
-    else if (fastq) t = with_comment ? PyTuple_Pack(4, name, s, *last_qual, com) : PyTuple_Pack(3, name, s, *last_qual);
-    else t = with_comment ? PyTuple_Pack(3, name, s, com) : PyTuple_Pack(2, name, s);
-    Py_XDECREF(name); Py_XDECREF(s); Py_XDECREF(com);
+    if (!name || !s || (with_comment && !com)) { Py_XDECREF(name); Py_XDECREF(s); Py_XDECREF(com); return NULL; }
+    t = PyTuple_New((fastq ? 3 : 2) + (with_comment ? 1 : 0));
+    if (!t) { Py_DECREF(name); Py_DECREF(s); Py_XDECREF(com); return NULL; }
+    {
+        Py_ssize_t k = 0;
+        PyTuple_SET_ITEM(t, k++, name);                          /* (the references move into the tuple) */
+        PyTuple_SET_ITEM(t, k++, s);
+        if (fastq) PyTuple_SET_ITEM(t, k++, Py_NewRef(*last_qual));
+        if (with_comment) PyTuple_SET_ITEM(t, k++, com);
+    }
+    /* a tuple of str / None can be part of no cycle: out of the collector's lists at once (CPython does the same for such
+     * tuples, but only when a collection first meets them -- two million of them are met by several) */
+    PyObject_GC_UnTrack(t);
     return t;
 }
 
