@@ -753,14 +753,19 @@ _COMP = bytes.maketrans(b"ACGTacgtMKRYVBHDmkryvbhdUu", b"TGCAtgcaKMYRBVDHkmyrbvd
 
 
 # vector instructions per 4 KiB granule and wave (SQ_INSTS_VALU of a PMC pass / granules of its stream); source file beside each
-VALU_PER_GRANULE = {"k_fastq_lines": (506, "profiles/r03_pmc_fastq.txt"), "k_fastq_lines_comp": (855, "profiles/r04_pmc_fastq_sq.txt")}
+VALU_PER_GRANULE = {"k_fastq_lines": (506, "profiles/r01_v7_pmc_fastq_build.txt: 860 586 961 / 1 699 219 granules (the kernel has not changed since)"),
+                    "k_fastq_lines_comp": (800, "profiles/r05_pmc_fastq_sq.txt: k_fastq_lines_comp<false> 1 358 541 574 / 1 699 219 granules (855 in round 4)")}
 N_SIMD, CLOCK_HZ = 1024, 2.4e9                              # 256 CUs x 4 SIMDs, MI355X_MICROARCH.md (max clock)
+# A wave64 integer / logic instruction -- what these kernels are made of -- occupies its SIMD for 4 cycles (16 lanes per cycle): the
+# instruction counts x 4 cycles reproduce the kernels' times within 3 % (profiles/r04_pmc_fastq_sq.txt, r05_pmc_fastq_sq.txt).  The
+# guide's "2 cycles" is the FP32 FMA rate (157 TFLOP/s); a frac slightly above 1 is the boost clock / the few cheaper instructions.
+VALU_CYCLES = 4.0
 
 
 def _issue_roofline(kernel, stream_bytes, measured_ms):
     per, src = VALU_PER_GRANULE[kernel]
-    floor_ms = per * (stream_bytes / 4096.0) * 4.0 / (N_SIMD * CLOCK_HZ) * 1e3
-    return {"bound": "valu issue", "valu_instructions_per_granule_and_wave": per, "counter_source": src, "granules": int(stream_bytes // 4096),
+    floor_ms = per * (stream_bytes / 4096.0) * VALU_CYCLES / (N_SIMD * CLOCK_HZ) * 1e3
+    return {"bound": "valu issue", "cycles_per_wave64_instruction": VALU_CYCLES, "valu_instructions_per_granule_and_wave": per, "counter_source": src, "granules": int(stream_bytes // 4096),
             "floor_ms": round(floor_ms, 3), "avg_launch_ms": round(measured_ms, 4), "frac": round(floor_ms / measured_ms, 4),
             "hbm_frac": round(stream_bytes / (measured_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 

@@ -483,7 +483,10 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_rows(ScanCtx x, FqOwn own, FqTa
 // Bits 26-31 of a staged record: which of the workgroup's granules.  G is chosen by the launch from the stream's line density
 // (FQW_CAP staged records); a workgroup with more lines than that, or with an overflowed granule (its lines are k_fastq_emit's),
 // walks its granules one lane per line, as k_fastq_rows does.
-constexpr int FQW_CAP = 2048;
+#ifndef FX_FQW_CAP
+#define FX_FQW_CAP 4096
+#endif
+constexpr int FQW_CAP = FX_FQW_CAP;
 template <int G, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_fastq_rows_wg(ScanCtx x, FqOwn own, FqTab t, const uint32_t *__restrict__ recs, int64_t g_end) {
     static_assert(G % (FQR_G * (BLOCK / 64)) == 0 && G <= 64, "whole runs per wave; six bits for the granule a staged record came from");
