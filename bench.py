@@ -647,8 +647,17 @@ def leg_c4(a, host, plan, q, tmpdir, plain_digest=None):
            "kernels_ms_per_open_in_groups": {k: round(v, 3) for k, v in prof.items()}, "launches_per_open_in_groups": launches,
            "fxi_durable_s": round(_median(t_ctor), 4), "fetch_many_1M_host_to_host_s": round(_median(t_fetch), 4),
            "gzindex_rows": npoints,
-           "roofline": {"kernel": "fx::k_bgzf_*", "bound": "hbm", "achieved": round(alg / (infl * 1e-3) / 1e9, 1) if infl else None,
+           # what bounds the inflate is NOT HBM (VERDICT r4 missing #6): the decode is one wave per member walking ~190 symbol steps
+           # three times (count, hand-over, store), every step two dependent LDS look-ups and the bit arithmetic between them, twelve waves
+           # per CU (13 KB of LDS each).  Its vector instructions alone (55 k per wave, profiles/r03_pmc_bgzf_par.txt) would take
+           # `valu_issue_floor_ms`; the rest is the latency of the chain.  hbm_frac is kept for continuity.
+           "roofline": {"kernel": "fx::k_bgzf_*", "bound": "latency of a per-member dependent chain (LDS look-ups, bit arithmetic) at 12 waves per CU; neither HBM nor vector issue",
+                        "achieved": round(alg / (infl * 1e-3) / 1e9, 1) if infl else None,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (infl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if infl else None,
+                        "hbm_frac": round(alg / (infl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if infl else None,
+                        "decode_valu_issue_floor_ms": round(55000.0 * ((nb + 65279) // 65280) * VALU_CYCLES / (N_SIMD * CLOCK_HZ) * 1e3, 2),
+                        "decode_avg_launch_ms": round(prof_one.get("k_bgzf_decode", 0.0), 3),
+                        "symbols": "11 863 per 65 280-byte member at zlib level 6: 73.7 % matches of 7.1 bytes, 26.3 % literals (tools/deflate_symbol_mix.c)",
                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(infl, 3), "traffic": None}}
     if plain_digest is not None:
         # all 1 M answers against the run on the plain file -- every string of which was compared with the reference's
@@ -753,7 +762,7 @@ _COMP = bytes.maketrans(b"ACGTacgtMKRYVBHDmkryvbhdUu", b"TGCAtgcaKMYRBVDHkmyrbvd
 
 
 # vector instructions per 4 KiB granule and wave (SQ_INSTS_VALU of a PMC pass / granules of its stream); source file beside each
-VALU_PER_GRANULE = {"k_fastq_lines": (506, "profiles/r01_v7_pmc_fastq_build.txt: 860 586 961 / 1 699 219 granules (the kernel has not changed since)"),
+VALU_PER_GRANULE = {"k_fastq_lines": (473, "profiles/r05_pmc_fastq_plain.txt: 803 238 357 / 1 699 219 granules (506 in round 1)"),
                     "k_fastq_lines_comp": (800, "profiles/r05_pmc_fastq_sq.txt: k_fastq_lines_comp<false> 1 358 541 574 / 1 699 219 granules (855 in round 4)")}
 N_SIMD, CLOCK_HZ = 1024, 2.4e9                              # 256 CUs x 4 SIMDs, MI355X_MICROARCH.md (max clock)
 # A wave64 integer / logic instruction -- what these kernels are made of -- occupies its SIMD for 4 cycles (16 lanes per cycle): the
@@ -766,7 +775,8 @@ def _issue_roofline(kernel, stream_bytes, measured_ms):
     per, src = VALU_PER_GRANULE[kernel]
     floor_ms = per * (stream_bytes / 4096.0) * VALU_CYCLES / (N_SIMD * CLOCK_HZ) * 1e3
     return {"bound": "valu issue", "cycles_per_wave64_instruction": VALU_CYCLES, "valu_instructions_per_granule_and_wave": per, "counter_source": src, "granules": int(stream_bytes // 4096),
-            "floor_ms": round(floor_ms, 3), "avg_launch_ms": round(measured_ms, 4), "frac": round(floor_ms / measured_ms, 4),
+            "floor_ms": round(floor_ms, 3), "avg_launch_ms": round(measured_ms, 4), "frac": round(min(floor_ms / measured_ms, 1.0), 4),
+            "floor_over_measured": round(floor_ms / measured_ms, 4),   # (above 1: part of the mix issues in fewer than 4 cycles; the kernel runs AT its issue rate)
             "hbm_frac": round(stream_bytes / (measured_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 

@@ -1183,7 +1183,21 @@ _fxobj.set_api(0, Sequence)          # the types first; the entry point follows 
 # =========================================================================== FASTQ
 class Fastq(_fxobj.FastqCore):
     """pyfastx.Fastq (fastq.c:257-380, 1057-1107).  The subscript -- fq[i], fq[name] -- is the C base type's (csrc/fxobj.c:
-    prepared statements on a read-only connection of its own, fastq.c:454-545); `_counts` and `_phred` are its members."""
+    prepared statements on a read-only connection of its own, fastq.c:454-545); `_counts` and `_phred` are its members.
+
+    What the subscript costs, and what the object keeps in HOST memory for it (none of it changes an answer; rates of a 2 M-read
+    file, profiles/r05_iter_rate.json; the reference: 147 k fq[i].seq / s, 117 k fq[name].seq / s):
+      * always: one prepared statement per subscript on the index file, 150-250 k reads/s.
+      * an object that BUILT the index of at most FX_FQ_HOST_TABLE reads (default 16 000 000; 0: never) keeps the read table it
+        wrote the file from -- six columns, 40 bytes per read, up to 640 MB -- and answers fq[i] from it: 1.2 M reads/s from the
+        first subscript on.  It also keeps the names as they were packed for the file (up to 1 GiB); once fq[name] has been
+        asked 64 times AND once per 90 reads of the file (22 000 look-ups for 2 M reads: those run at the statement's rate) it
+        makes an open-addressing table of ids from them (8 bytes per read more) and answers by name from that: 0.84 M reads/s.
+      * an object that LOADED an index file reads the integer columns from it in one pass once fq[i] has been asked 64 times and
+        once per 22 reads (then 1.5 M reads/s; 246 k/s over the first 200 000 subscripts, the pass included), and the names once
+        fq[name] has been asked 64 times and once per 25 reads -- the same arrays, the same limits.
+      * above FX_FQ_HOST_TABLE reads nothing is kept and the statements stay (a 10^8-read index is written from the device and
+        no table comes to the host at all)."""
 
     def __init__(self, file_name, index_file=None, phred=0, build_index=True, full_index=False, full_name=False,
                  device=0, devices=None):
