@@ -371,7 +371,9 @@ def leg_c3(a, dev, tmpdir):
             full_path = None
     b.close()
     del b, blob_t, v, seqs, quals, o_seq, o_q, o_qi
-    torch.cuda.empty_cache()
+    # (no torch.cuda.empty_cache() here: the 35 GB stay in torch's pool.  The driver takes freed device memory down in the
+    # background -- 35 GB: ~2.8 s -- and the next hipMalloc of ANY size may wait for it: tools/first_open_probe.py; that wait in
+    # front of the 0.7 GB file below was the 5.9 s "constructor" of one round-4 run.  288 GB hold both copies.)
     nqs = min(nq, 200_000)
     sid = np.random.default_rng(7).integers(0, m, nqs)
     _lib.Blob.from_file(path).close()

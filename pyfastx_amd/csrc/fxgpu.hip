@@ -115,6 +115,13 @@ struct ScratchPool {
     struct Block { void *p; size_t cap; int dev; };
     std::mutex mu;
     std::vector<Block> idle;
+    // ONE block per device that is larger than the whole limit may idle here as well (round 5): the blob of the last large
+    // stream.  hipFree of tens of GB returns at once, but the driver takes the block down in the background, and a hipMalloc
+    // of that size that comes before it is done WAITS for it -- 2.65 s for 34.8 GB, now and then (tools/first_open_probe.py:
+    // open / close / open of one file in a fresh process: 0.3 ms, 2.6 ms, 2 650 ms) -- what made a constructor on a 0.7 GB
+    // file take 5.9 s in one bench run of round 4.  Kept, the next open of a file of that size asks the driver for nothing;
+    // fx_release_scratch, a failed allocation and windows.hbm_budget give it back.
+    std::vector<Block> big;
     size_t held = 0;
     const size_t limit = [] { const char *e = getenv("FX_SCRATCH_CACHE_MB"); return (size_t)(e ? std::max(0, atoi(e)) : 8192) << 20; }();
     void *get(int dev, size_t bytes, size_t *cap) {
@@ -130,6 +137,13 @@ struct ScratchPool {
                 *cap = b.cap;
                 return b.p;
             }
+            for (int i = 0; i < (int)big.size(); ++i)
+                if (big[i].dev == dev && big[i].cap >= bytes && big[i].cap <= 2 * bytes + (1u << 20)) {
+                    Block b = big[i];
+                    big.erase(big.begin() + i);
+                    *cap = b.cap;
+                    return b.p;
+                }
         }
         void *p = nullptr;
         static const bool trace = [] { const char *e = getenv("FX_TRACE_ALLOC"); return e && atoi(e) != 0; }();
@@ -143,17 +157,27 @@ struct ScratchPool {
         return p;
     }
     void put(int dev, void *p, size_t cap) {
+        void *drop = nullptr;
+        size_t drop_cap = 0;
         {
             std::lock_guard<std::mutex> g(mu);
             if (held + cap <= limit) { idle.push_back(Block{p, cap, dev}); held += cap; return; }
+            if (limit && cap > limit) {                      // larger than the whole limit: the device's one large idle block (the larger of two stays)
+                int at = -1;
+                for (int i = 0; i < (int)big.size(); ++i) if (big[i].dev == dev) at = i;
+                if (at < 0) { big.push_back(Block{p, cap, dev}); return; }
+                if (big[at].cap < cap) { drop = big[at].p; drop_cap = big[at].cap; big[at] = Block{p, cap, dev}; }
+                else { drop = p; drop_cap = cap; }
+            } else { drop = p; drop_cap = cap; }
         }
-        if (getenv("FX_TRACE_ALLOC")) fprintf(stderr, "[fxgpu] scratch full: hipFree(%zu)\n", cap);
-        (void)hipFree(p);
+        if (getenv("FX_TRACE_ALLOC")) fprintf(stderr, "[fxgpu] scratch full: hipFree(%zu)\n", drop_cap);
+        (void)hipFree(drop);
     }
     void trim() {
-        std::vector<Block> v;
-        { std::lock_guard<std::mutex> g(mu); v.swap(idle); held = 0; }
+        std::vector<Block> v, w;
+        { std::lock_guard<std::mutex> g(mu); v.swap(idle); w.swap(big); held = 0; }
         for (auto &b : v) (void)hipFree(b.p);
+        for (auto &b : w) (void)hipFree(b.p);
     }
 };
 static ScratchPool g_scratch;
