@@ -348,7 +348,7 @@ struct fx_handle {
     int64_t kq_nrec = -1, kq_lines = 0, kq_seq_bytes = 0, kq_prefix_lines = 0;   // kq_prefix_lines: lines the parallel prefix passes took
     int kq_code = 0;
     // the sorted order of the record names, kept between fx_fxi_dev_sort and fx_fxi_dev_write (fx_fxi_dev.hpp)
-    DevBuf<int64_t> fxi_order;
+    ScratchBuf<int64_t> fxi_order;           // (a block of the scratch pool: 0.8 GB for 10^8 reads; hipFree of it would wait for the device)
     int fxi_order_kind = -1;
     int64_t fxi_order_n = 0;
     DevBuf<uint8_t> arena;     // scratch for host-array calls (Staged)
@@ -429,6 +429,7 @@ extern "C" int fx_close(fx_handle *h) {
         (void)hipHostFree(h->mb);
     }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->fxi_order.release();                                  // (back to the pool while the stream it names still exists)
     free_blob(h);
     if (h->pin_tot) (void)hipHostFree(h->pin_tot);
     if (h->one_box) (void)hipHostFree(h->one_box);
@@ -3883,7 +3884,7 @@ extern "C" int fx_fxi_dev_sort(fx_handle *h, int kind, int64_t *n_dup) {
         hipLaunchKernelGGL(k_add_i64, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, h->hdr.p, (int64_t)1, n, h->nm_off.p);
         noff = h->nm_off.p;
     }
-    if ((rc = h->fxi_order.alloc(n))) return rc;
+    if ((rc = h->fxi_order.alloc(h->device, n, h->stream))) return rc;
     DevBuf<int64_t> d_ndup;
     if ((rc = d_ndup.alloc(1))) return rc;
     const char *what = "";
@@ -3912,9 +3913,10 @@ extern "C" int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int ro
     const uint8_t *data = h->d_data;
     const int64_t nchunks = (n + FXI_R - 1) / FXI_R;
     const int64_t nsc = (nchunks + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    DevBuf<uint16_t> sz;
-    DevBuf<int32_t> pages, bad;
-    DevBuf<int64_t> sums, pbase, first_t, first_i;
+    // (all out of the scratch pool: the hipFree of these blocks at the end of the call -- 1 GB -- cost 0.12-0.23 s of waiting for the device)
+    ScratchBuf<uint16_t> sz;
+    ScratchBuf<int32_t> pages, bad;
+    ScratchBuf<int64_t> sums, pbase, first_t, first_i;
     ScratchBuf<uint8_t> slab;
     auto done = [&](int code) {
         (void)hipStreamSynchronize(h->stream);
@@ -3923,10 +3925,11 @@ extern "C" int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int ro
         return code;
     };
     if (n == 0) return done(FX_OK);
-    if ((rc = sz.alloc(n)) || (rc = pages.alloc(nchunks)) || (rc = bad.alloc(1)) || (rc = sums.alloc(nsc + 1)) || (rc = pbase.alloc(nchunks + 1))) return done(rc);
+    if ((rc = sz.alloc(h->device, n, h->stream)) || (rc = pages.alloc(h->device, nchunks, h->stream)) || (rc = bad.alloc(h->device, 1, h->stream)) ||
+        (rc = sums.alloc(h->device, nsc + 1, h->stream)) || (rc = pbase.alloc(h->device, nchunks + 1, h->stream))) return done(rc);
 
     // shape of one tree's leaf level: sizes are in sz -> nleaf, first[0 .. nleaf]
-    auto leaf_level = [&](bool idx, DevBuf<int64_t> &first, int64_t *nleaf_out) -> int {
+    auto leaf_level = [&](bool idx, ScratchBuf<int64_t> &first, int64_t *nleaf_out) -> int {
         if (idx) hipLaunchKernelGGL((k_fxi_fill<true, false>), dim3((unsigned)nchunks), dim3(64), 0, h->stream, sz.p, n, FXI_PAGE - 8, pages.p, (const int64_t *)nullptr, (int64_t *)nullptr);
         else hipLaunchKernelGGL((k_fxi_fill<false, false>), dim3((unsigned)nchunks), dim3(64), 0, h->stream, sz.p, n, FXI_PAGE - 8, pages.p, (const int64_t *)nullptr, (int64_t *)nullptr);
         hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)nsc), dim3(BLOCK), 0, h->stream, pages.p, nchunks, sums.p);
@@ -3940,7 +3943,7 @@ extern "C" int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int ro
         HIPCHK(hipStreamSynchronize(h->stream));
         if (isbad) return fail(FX_ERANGE, idx ? "an index entry does not fit a b-tree page without overflow: use CREATE INDEX"
                                               : "a row does not fit a b-tree page without overflow: use the INSERT path");
-        int r2 = first.alloc(nleaf + 1);
+        int r2 = first.alloc(h->device, nleaf + 1, h->stream);
         if (r2) return r2;
         if (idx) hipLaunchKernelGGL((k_fxi_fill<true, true>), dim3((unsigned)nchunks), dim3(64), 0, h->stream, sz.p, n, FXI_PAGE - 8, (int32_t *)nullptr, pbase.p, first.p);
         else hipLaunchKernelGGL((k_fxi_fill<false, true>), dim3((unsigned)nchunks), dim3(64), 0, h->stream, sz.p, n, FXI_PAGE - 8, (int32_t *)nullptr, pbase.p, first.p);
@@ -4010,11 +4013,12 @@ extern "C" int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int ro
         d_rowid.assign((size_t)std::max<int64_t>(nd, 1), 0);
         d_off.assign((size_t)nd + 1, 0);
         if (nd > 0) {
-            DevBuf<int64_t> drow, doff, dsum;
-            DevBuf<int32_t> dlen;
-            DevBuf<uint8_t> dnm;
+            ScratchBuf<int64_t> drow, doff, dsum;
+            ScratchBuf<int32_t> dlen;
+            ScratchBuf<uint8_t> dnm;
             const int64_t ndc = (nd + SCAN_CHUNK - 1) / SCAN_CHUNK;
-            if ((rc = drow.alloc(nd)) || (rc = dlen.alloc(nd)) || (rc = doff.alloc(nd + 1)) || (rc = dsum.alloc(ndc + 1))) return done(rc);
+            if ((rc = drow.alloc(h->device, nd, h->stream)) || (rc = dlen.alloc(h->device, nd, h->stream)) || (rc = doff.alloc(h->device, nd + 1, h->stream)) ||
+                (rc = dsum.alloc(h->device, ndc + 1, h->stream))) return done(rc);
             hipLaunchKernelGGL(k_fxi_divider_rows, dim3(nblocks(nd, BLOCK)), dim3(BLOCK), 0, h->stream, c, (const int64_t *)h->fxi_order.p, (const int64_t *)first_i.p, nd, drow.p, dlen.p);
             hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)ndc), dim3(BLOCK), 0, h->stream, dlen.p, nd, dsum.p);
             hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, dsum.p, ndc);
@@ -4026,7 +4030,7 @@ extern "C" int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int ro
             const int64_t tot = d_off[(size_t)nd];
             d_names.resize((size_t)std::max<int64_t>(tot, 1));
             if (tot) {
-                if ((rc = dnm.alloc(tot))) return done(rc);
+                if ((rc = dnm.alloc(h->device, tot, h->stream))) return done(rc);
                 hipLaunchKernelGGL(k_fxi_divider_names, dim3(nblocks(nd, BLOCK)), dim3(BLOCK), 0, h->stream, c, data, (const int64_t *)drow.p, (const int64_t *)doff.p, nd, dnm.p);
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipMemcpyAsync(d_names.data(), dnm.p, (size_t)tot, hipMemcpyDeviceToHost, h->stream));

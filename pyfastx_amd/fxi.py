@@ -234,8 +234,11 @@ def _bulk_table_dev(path, blob, kind, ddl, table, index_sql, index_name, schema_
     fastq.c:152-156).  schema_done: the file exists with the tables of `ddl` in it (presize_fastq).  Returns (open
     connection, phases in seconds); on FX_ERANGE / FX_EINVAL (a row that needs an overflow page, a database that does not
     have 4 KiB pages) the file is removed and the error re-raised -- the caller falls back to the host loaders."""
+    import time
+    t0 = time.perf_counter()
     try:
         ndup = blob.fxi_dev_sort(kind)
+        t1 = time.perf_counter()
         db = connect(path)
         if not schema_done:
             db.executescript(ddl)
@@ -243,7 +246,9 @@ def _bulk_table_dev(path, blob, kind, ddl, table, index_sql, index_name, schema_
             db.execute(index_sql)
         root = dict(db.execute("SELECT name, rootpage FROM sqlite_master").fetchall())
         db.close()
+        t2 = time.perf_counter()
         laps = blob.fxi_dev_write(kind, path, root[table], 0 if ndup else root[index_name])
+        t3 = time.perf_counter()
     except BaseException:
         if os.path.exists(path):
             os.remove(path)
@@ -255,6 +260,10 @@ def _bulk_table_dev(path, blob, kind, ddl, table, index_sql, index_name, schema_
             db.execute(index_sql)
         except sqlite3.Error:
             pass
+    laps["name_sort"] = t1 - t0
+    laps["sqlite_schema"] = t2 - t1
+    laps["write_call"] = t3 - t2
+    laps["sqlite_reopen"] = time.perf_counter() - t3
     return db, laps
 
 
