@@ -455,20 +455,30 @@ def c3_full_file(a, path, n, cols, theirs_rows, m):
     from pyfastx_amd import _lib
     nb = os.path.getsize(path)
     _lib.Blob.from_file_range(path, 0, 1 << 24, 0).close()
-    # Twice: the FIRST block of 35 GB a process asks the driver for takes seconds to map (hipMalloc 2.9 s, and the first copies into it
-    # run at a third of the rate: tools/c3_outlier_probe.py), every later one 0.3 ms -- the first constructor pays that once per
-    # process, the second is what a process that has opened a file of this size before sees.  Both are reported; the phases are the second's.
-    t0 = time.perf_counter()
-    fq = fx.Fastq(path)
-    t1 = time.perf_counter()
-    first = {"Fastq_ctor_s": round(t1 - t0, 3), **{k: round(v, 3) for k, v in (getattr(fq, "build_phases", None) or {}).items() if isinstance(v, float)}}
-    del fq
-    _rm(path + ".fxi")
-    t0 = time.perf_counter()
-    fq = fx.Fastq(path)                                      # stage + scan + rows + names sorted + b-tree pages formatted on the device + pages to the file
-    t1 = time.perf_counter()
-    bp = dict(getattr(fq, "build_phases", None) or {})
-    ip = dict(getattr(fq, "index_phases", None) or {})
+    # Three constructors, the MEDIAN reported (as every end-to-end figure of this file), all three listed: an allocation of tens of GB
+    # can wait seconds for the driver's background clean-up of memory freed just before -- by this process or the one before it --
+    # and the first copies into fresh device memory run at a third of the rate (tools/first_open_probe.py); the
+    # library's pool keeps the blob of the last large stream so that later opens ask the driver for nothing.
+    import gc
+    runs, fq = [], None
+    for rep in range(3):
+        if fq is not None:
+            st_ = getattr(fq, "_st", None)
+            if st_ is not None and getattr(st_, "_blob", None) is not None:
+                st_._blob.close()                             # (explicitly: the blob goes back to the library's pool now, not when the collector gets to it)
+            fq = None
+            gc.collect()
+            _rm(path + ".fxi")
+        t0 = time.perf_counter()
+        fq = fx.Fastq(path)                                  # stage + scan + rows + names sorted + b-tree pages formatted on the device + pages to the file
+        t1 = time.perf_counter()
+        runs.append((t1 - t0, dict(getattr(fq, "build_phases", None) or {}), dict(getattr(fq, "index_phases", None) or {})))
+    order = sorted(range(3), key=lambda i: runs[i][0])
+    t_ctor, bp, ip = runs[order[1]]                          # the median run: its phases are the ones reported
+    t0, t1 = 0.0, t_ctor
+    first = {"Fastq_ctor_s": round(runs[0][0], 3), **{k: round(v, 3) for k, v in runs[0][1].items() if isinstance(v, float)}}
+    all_runs = [{"Fastq_ctor_s": round(r[0], 3), "device_alloc_s": round(r[1].get("device_alloc_s", 0.0), 3), "page_cache_to_hbm_s": round(r[1].get("page_cache_to_hbm_s", 0.0), 3),
+                 "fxi_s": round(r[1].get("fxi_s", 0.0), 3)} for r in runs]
     nq = a.queries
     ids = np.random.default_rng(99).integers(0, n, nq)
     fq.fetch_many(ids[:1000], want=("seq", "qual", "quali"))
@@ -544,10 +554,11 @@ def c3_full_file(a, path, n, cols, theirs_rows, m):
             raise SystemExit("PARITY FAILURE (C3 at full size against the reference on the whole file): %r" % (full_ref,))
     res = {"workload": "configs[2] from a FILE: %d x 150 bp FASTQ (%.1f GB, page cache) -> pyfastx_amd.Fastq(path) with no .fxi present -> the index "
                        "file durable on disk (%.1f GB) -> %d random reads (seq + qual + int8 quali) into host memory" % (n, nb / 1e9, os.path.getsize(path + ".fxi") / 1e9, nq),
-           "Fastq_ctor_s": round(t1 - t0, 3), "M_rows_per_s": round(n / (t1 - t0) / 1e6, 2),
+           "Fastq_ctor_s": round(t1 - t0, 3), "Fastq_ctor_s_is": "the median of three constructors (constructor_runs lists them; phases_s are the median run's)",
+           "M_rows_per_s": round(n / (t1 - t0) / 1e6, 2),
            # both times -- the read table resident in HBM (batches can be served), the .fxi durable on disk
            "index_ready_s": round(bp["index_ready_s"], 3) if bp else None, "fxi_durable_s": round(bp["fxi_durable_s"], 3) if bp else None,
-           "first_constructor_of_the_process": first,
+           "first_constructor_of_the_process": first, "constructor_runs": all_runs,
            "phases_s": {"staging": round(bp.get("staging_s", 0.0), 3), "device_alloc": round(bp.get("device_alloc_s", 0.0), 4),
                         "page_cache_to_hbm": round(bp.get("page_cache_to_hbm_s", 0.0), 3), "index_kernels": round(bp.get("scan_s", 0.0), 4),
                         "name_sort": round(ip.get("name_sort", 0.0), 3) if ip else None,

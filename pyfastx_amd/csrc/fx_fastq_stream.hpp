@@ -359,7 +359,9 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_comp_stream(const uint8_t *__re
 // the guess -- go to an 8-word record; k_fastq_comp_reduce, after the prefixes, compares every guess with the truth
 // ((line offset + nl_prefix[first granule]) & 3) and adds the records up; the runs whose guess was wrong or missing (a granule
 // without a '+' line in it: reads longer than a granule; '+' lines that repeat the name; 1-base reads) are counted again by
-// k_fastq_comp_stream, from the prefixes, when they are few -- else fx_fastq_comp counts from the read table as before.
+// k_fastq_comp_stream, from the prefixes, when they are few -- else fx_fastq_comp counts from the read table as before.  A run
+// without a one-byte line makes a SECOND guess from the first bytes of its lines ('@' ... two lines on '+': files whose '+' lines
+// repeat the name).
 #ifndef FX_FQLC_G
 #define FX_FQLC_G 16
 #endif
@@ -454,13 +456,57 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_lines_comp(const uint8_t *__res
                 if (__ballot(clash || (mine != 0xFFu && mine != guess))) guess = 0xFFu;
             }
         }
+        // ---- no line of one byte in the run's first granule ('+' lines that repeat the name: what fastq-dump writes): the second
+        // guess, on this rare path only -- a line that begins with '@' whose next line but one begins with '+' is a header line.  (A
+        // quality line may begin with '@', but the line two behind it is then a sequence line; k_fastq_comp_reduce checks every
+        // guess anyway.)  The first byte of the line behind every newline goes to LDS, one slot per newline; lanes then look at
+        // slots i and i + 2.
+        if (kk == 0 && guess == 0xFFu && M >= 3u && M <= (uint32_t)FQL_CAP) {
+            uint16_t *cls = s_pos[w];                          // (free here: the compaction below fills it after the composition)
+            // (maps of the '@' and '+' bytes, not bytes picked out of the chunk by a run-time index: that would put every chunk of the
+            // straight path into scratch memory)
+            uint32_t at16[GR_ROWS], pl16[GR_ROWS];
+#pragma unroll
+            for (int j = 0; j < GR_ROWS; ++j) { at16[j] = eq_mask16(v[j], 0x40404040u); pl16[j] = eq_mask16(v[j], 0x2B2B2B2Bu); }
+#pragma unroll
+            for (int j = 0; j < GR_ROWS; ++j) {
+                // bit 16 of a chunk's maps: the first byte of the chunk behind it (the next lane's, the next row's first; none behind the granule)
+                const uint32_t fa = at16[j] & 1u, fp = pl16[j] & 1u;
+                const uint32_t na = (uint32_t)__shfl_down((int)fa, 1, 64), np = (uint32_t)__shfl_down((int)fp, 1, 64);
+                const uint32_t ra = j + 1 < GR_ROWS ? (uint32_t)__builtin_amdgcn_readlane((int)at16[j + 1 < GR_ROWS ? j + 1 : j], 0) & 1u : 0u;
+                const uint32_t rp = j + 1 < GR_ROWS ? (uint32_t)__builtin_amdgcn_readlane((int)pl16[j + 1 < GR_ROWS ? j + 1 : j], 0) & 1u : 0u;
+                const uint32_t am = at16[j] | ((lane < 63 ? na : ra) << 16), pm = pl16[j] | ((lane < 63 ? np : rp) << 16);
+                uint32_t m = nlm[j], r = ex[j];
+                while (m) {
+                    const int k = __ffs(m) - 1;
+                    m &= m - 1;
+                    cls[r++] = (uint16_t)(((am >> (k + 1)) & 1u) ? 1u : ((pm >> (k + 1)) & 1u) ? 2u : 0u);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t mine = 0xFFu;
+            bool clash = false;
+            for (uint32_t i = lane; i + 2u < M; i += 64u)
+                if (cls[i] == 1u && cls[i + 2u] == 2u) {       // the line behind newline i is a header line: it is line i + 1 of the granule
+                    const uint32_t p0 = (3u - i) & 3u;
+                    if (mine == 0xFFu) mine = p0; else clash |= mine != p0;
+                }
+            const unsigned long long hv = __ballot(mine != 0xFFu);
+            if (hv) {
+                guess = (uint32_t)__builtin_amdgcn_readlane((int)mine, __ffsll((long long)hv) - 1);
+                if (__ballot(clash || (mine != 0xFFu && mine != guess))) guess = 0xFFu;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         // ---- composition of this granule (only with a guess: without one the run's record says so and nothing is used)
         if (guess != 0xFFu) {
             const uint32_t L0 = (guess + lines_before) & 3u;
             CompCarry cy;
-            fs_row<0, true>(v[0], nlm[0], crm[0], rcr[0], nlm[1], (L0 + ex[0]) & 3u, s_mask, a, cy, qs, fix, lane);
-            fs_row<1, true>(v[1], nlm[1], crm[1], rcr[1], nlm[2], (L0 + ex[1]) & 3u, s_mask, a, cy, qs, fix, lane);
-            fs_row<2, true>(v[2], nlm[2], crm[2], rcr[2], nlm[3], (L0 + ex[2]) & 3u, s_mask, a, cy, qs, fix, lane);
+            fs_row<0, CRLF>(v[0], nlm[0], crm[0], rcr[0], nlm[1], (L0 + ex[0]) & 3u, s_mask, a, cy, qs, fix, lane);
+            fs_row<1, CRLF>(v[1], nlm[1], crm[1], rcr[1], nlm[2], (L0 + ex[1]) & 3u, s_mask, a, cy, qs, fix, lane);
+            fs_row<2, CRLF>(v[2], nlm[2], crm[2], rcr[2], nlm[3], (L0 + ex[2]) & 3u, s_mask, a, cy, qs, fix, lane);
             fs_row<3, CRLF>(v[3], nlm[3], crm[3], rcr[3], 0u, (L0 + ex[3]) & 3u, s_mask, a, cy, qs, fix, lane);
             planes_finish16(a.pl, cy);
         }

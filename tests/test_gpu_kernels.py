@@ -867,7 +867,7 @@ def _fq_file(n, eol, rng, rlen=150, plus_name=False, long_every=0):
 def test_fastq_one_read_composition_is_used_where_it_can_be(oracle, L, shape):
     """fx_fastq_build_comp on files of every shape (fastq.c:715-774 handles them all in its one loop): LF and CRLF files take the
     counts of the scan itself for (nearly) every run of granules -- fx_fastq_comp_info says how many runs were counted again
-    from the prefixes --, a file whose '+' lines repeat the name has no guess at all and a '\\r' that is not the end of its line
+    from the prefixes --, a file whose '+' lines repeat the name is guessed from the first bytes of its lines, and a '\\r' that is not the end of its line
     sends everything through the table kernels; base / meta equal the oracle's in every case."""
     rng = np.random.default_rng(77)
     if shape == "crlf_fixture":
@@ -917,12 +917,11 @@ def test_fastq_one_read_composition_is_used_where_it_can_be(oracle, L, shape):
     assert base.tolist() == [c["a"], c["c"], c["g"], c["t"], c["n"]], shape
     assert meta.tolist() == [c["maxlen"], c["minlen"], c["minqs"], c["maxqs"], c["phred"]], shape
     assert runs == (len(raw) // 4096 + 15) // 16
-    if shape in ("lf", "crlf", "crlf_fixture", "cr_ends_granule"):
+    if shape in ("lf", "crlf", "crlf_fixture", "cr_ends_granule", "plus_name"):
+        # (plus_name: no line of one byte anywhere -- the second guess: a line that begins with '@' whose next line but one begins with '+')
         assert one_read and 0 <= recounted <= max(1, runs // 100), (runs, recounted)
     elif shape == "long_reads":
         assert one_read and 0 < recounted <= max(64, runs // 8), (runs, recounted)
-    elif shape == "plus_name":
-        assert not one_read and recounted == -1              # no run has a guess: the table kernel counts
     else:
         assert not one_read                                  # the quirk of fastq.c:733-737 is k_fastq_qual_walk's
     t = b.fastq_table(s.n_reads)
