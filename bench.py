@@ -371,9 +371,11 @@ def leg_c3(a, dev, tmpdir):
             full_path = None
     b.close()
     del b, blob_t, v, seqs, quals, o_seq, o_q, o_qi
-    # (no torch.cuda.empty_cache() here: the 35 GB stay in torch's pool.  The driver takes freed device memory down in the
-    # background -- 35 GB: ~2.8 s -- and the next hipMalloc of ANY size may wait for it: tools/first_open_probe.py; that wait in
-    # front of the 0.7 GB file below was the 5.9 s "constructor" of one round-4 run.  288 GB hold both copies.)
+    # torch's 35 GB go back to the driver HERE, as early as possible: the driver takes freed device memory down in the background
+    # (35 GB: ~2.8 s) and a hipMalloc that comes before it is done may wait for it (tools/first_open_probe.py; that wait in front of
+    # the 0.7 GB file below was the 5.9 s "constructor" of one round-4 run).  The reference's leg below (5 s) gives it the time;
+    # keeping the memory in torch's pool instead made the full-size constructors further down erratic (2.2-3.6 s against 1.4).
+    torch.cuda.empty_cache()
     nqs = min(nq, 200_000)
     sid = np.random.default_rng(7).integers(0, m, nqs)
     _lib.Blob.from_file(path).close()

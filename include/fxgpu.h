@@ -478,12 +478,14 @@ int fx_fxi_dev_sort(fx_handle *h, int kind, int64_t *n_dup);
 int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int root_table, int root_index, double *laps);
 /* Room for those pages set aside while the stream is still being staged: `path` = the database SQLite has just created
  * (schema in place, no open connection); a thread of the library grows the file to `bytes` with fallocate (on tmpfs the
- * allocation of 10 GB takes 0.6 s and must not run beside the stores into the file; beside the staging it costs nothing).
+ * allocation of 10 GB takes 0.6 s and must not run beside the stores into the file; beside the staging it costs nothing);
+ * device >= 0: the thread runs on the CPUs next to that device, so that the pages lie in the memory the copy threads of
+ * fx_fxi_dev_write are next to (-1: wherever).
  * The database header keeps saying where the database ends; fx_fxi_dev_write uses the room and cuts the file to what it
  * needed.  fx_fxi_presize_end waits for the thread (cancel != 0: stops it at the next 256 MiB step first).  An estimate
  * that is too small only means the rest is allocated by fx_fxi_dev_write.  No counterpart in the reference: its index
  * file grows one INSERT at a time (fastq.c:136-149). */
-int fx_fxi_presize_begin(const char *path, int64_t bytes, void **token);
+int fx_fxi_presize_begin(const char *path, int64_t bytes, int device, void **token);
 int fx_fxi_presize_end(void *token, int cancel);
 
 /* ------------------------------------------------------- sync and timing

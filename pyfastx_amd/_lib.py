@@ -66,10 +66,11 @@ def open_laps():
     return float(a.value), float(b.value)
 
 
-def fxi_presize_begin(path, nbytes):
-    """A library thread grows the (just created) index file to nbytes with fallocate -> token for fxi_presize_end."""
+def fxi_presize_begin(path, nbytes, device=-1):
+    """A library thread (on the CPUs next to `device`) grows the (just created) index file to nbytes with fallocate -> token for
+    fxi_presize_end."""
     tok = C.c_void_p(None)
-    check(lib().fx_fxi_presize_begin(os.fsencode(path), int(nbytes), C.byref(tok)))
+    check(lib().fx_fxi_presize_begin(os.fsencode(path), int(nbytes), int(device), C.byref(tok)))
     return tok
 
 
@@ -203,7 +204,7 @@ def lib():
     L.fx_fastq_comp_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
     L.fx_fxi_dev_sort.argtypes = [vp, i32, C.POINTER(C.c_int64)]
     L.fx_fxi_dev_write.argtypes = [vp, i32, C.c_char_p, i32, i32, C.POINTER(C.c_double)]
-    L.fx_fxi_presize_begin.argtypes = [C.c_char_p, i64, C.POINTER(vp)]
+    L.fx_fxi_presize_begin.argtypes = [C.c_char_p, i64, i32, C.POINTER(vp)]
     L.fx_fxi_presize_end.argtypes = [vp, i32]
     L.fx_sync.argtypes = [vp]
     L.fx_prof_enable.argtypes = [vp, i32]

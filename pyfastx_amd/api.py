@@ -1313,7 +1313,7 @@ class Fastq(_fxobj.FastqCore):
         tok = None
         if not self.is_gzip and _dev_index_applies(self._index_file) and self._st.forced is None and not os.environ.get("FX_FXI_NO_PRESIZE"):
             try:
-                tok = fxi.presize_fastq(self._index_file, self.file_name)     # (the index holds names cut at the first white space whatever full_name says: fastq.c:112-117)
+                tok = fxi.presize_fastq(self._index_file, self.file_name, device=self._st.device)     # (the index holds names cut at the first white space whatever full_name says: fastq.c:112-117)
             except Exception:                                 # noqa: BLE001  (no early file: the build makes it)
                 tok = None
         try:

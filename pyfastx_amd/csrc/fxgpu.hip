@@ -109,7 +109,8 @@ template <class T> struct DevBuf {      // grow-only device array: rebuilds reus
 
 // Scratch of an open (the compressed bytes of a BGZF file, its match map, ...): hundreds of MB that live for tens of
 // milliseconds.  hipFree waits for the device and unmaps -- 20 ms for 1.4 GB -- and the hipMalloc of the next open maps
-// again, so released blocks are kept (per device, up to FX_SCRATCH_CACHE_MB, default 8192; 0 = off) and handed to the
+// again, so released blocks are kept (per device, up to FX_SCRATCH_CACHE_MB, default 16384 since round 5 -- the temporaries of a
+// 10^8-read index file are 5 GB on top of what the opens before left --; 0 = off) and handed to the
 // next request they fit (at most twice its size).
 struct ScratchPool {
     struct Block { void *p; size_t cap; int dev; };
@@ -123,7 +124,7 @@ struct ScratchPool {
     // fx_release_scratch, a failed allocation and windows.hbm_budget give it back.
     std::vector<Block> big;
     size_t held = 0;
-    const size_t limit = [] { const char *e = getenv("FX_SCRATCH_CACHE_MB"); return (size_t)(e ? std::max(0, atoi(e)) : 8192) << 20; }();
+    const size_t limit = [] { const char *e = getenv("FX_SCRATCH_CACHE_MB"); return (size_t)(e ? std::max(0, atoi(e)) : 16384) << 20; }();
     void *get(int dev, size_t bytes, size_t *cap) {
         {
             std::lock_guard<std::mutex> g(mu);
@@ -3815,8 +3816,12 @@ static int fxi_image_out(fx_handle *h, const uint8_t *d_img, int64_t k0, int64_t
             else if (!fxi::pwrite_all(fd, src + (size_t)(x - a) * FXI_PAGE, len, (off_t)off)) err.store(2);
         }
     };
+    cpu_set_t near_cpus;
+    static const bool no_bind = [] { const char *e = getenv("FX_FXI_NO_BIND"); return e && atoi(e) != 0; }();
+    const bool bind = !no_bind && device_cpus(h->device, &near_cpus);     // the copy threads on the CPUs next to the device, as the staging threads are
     for (int t = 0; t < T; ++t)
         th.emplace_back([&, t]() {
+            if (bind) (void)pthread_setaffinity_np(pthread_self(), sizeof near_cpus, &near_cpus);
             if (hipSetDevice(h->device) != hipSuccess) { err.store(1); return; }
             uint8_t *pin[2] = {g_pins.get(), g_pins.get()};
             hipStream_t st = nullptr;
@@ -4123,7 +4128,7 @@ struct FxiPresize {
     std::thread th;
     std::atomic<bool> stop{false};
 };
-extern "C" int fx_fxi_presize_begin(const char *path, int64_t bytes, void **token) {
+extern "C" int fx_fxi_presize_begin(const char *path, int64_t bytes, int device, void **token) {
     if (!path || !token || bytes < 0) return fail(FX_EINVAL, "bad argument");
     *token = nullptr;
     const int fd = open(path, O_RDWR);
@@ -4132,7 +4137,11 @@ extern "C" int fx_fxi_presize_begin(const char *path, int64_t bytes, void **toke
     if (fstat(fd, &st) != 0) { close(fd); return fail(FX_EIO, "cannot stat %s", path); }
     FxiPresize *p = new FxiPresize();
     const off_t from = st.st_size, to = (off_t)bytes;
-    p->th = std::thread([p, fd, from, to]() {
+    cpu_set_t near_cpus;
+    static const bool no_bind = [] { const char *e = getenv("FX_FXI_NO_BIND"); return e && atoi(e) != 0; }();
+    const bool bind = !no_bind && device >= 0 && device_cpus(device, &near_cpus);     // the pages on the memory next to the device that will fill them
+    p->th = std::thread([p, fd, from, to, bind, near_cpus]() {
+        if (bind) (void)pthread_setaffinity_np(pthread_self(), sizeof near_cpus, &near_cpus);
         const off_t step = 256ll << 20;
         for (off_t o = from; o < to && !p->stop.load(); o += step)
             if (fallocate(fd, 0, o, std::min(step, to - o)) != 0) break;

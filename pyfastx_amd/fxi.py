@@ -366,7 +366,7 @@ def estimate_fastq_index_bytes(path, full_name=False, head=1 << 19, places=8):
     return int(pages * 4096)
 
 
-def presize_fastq(path, input_path, full_name=False):
+def presize_fastq(path, input_path, full_name=False, device=-1):
     """The index file of a LARGE plain FASTQ input created early -- schema in place -- and grown in the background to
     98.5 % of its estimated size while the input is staged (fx_fxi_presize_begin).  -> token for _lib.fxi_presize_end, or
     None when nothing was done (a small input, no estimate).  The caller removes the file if the build fails."""
@@ -386,7 +386,7 @@ def presize_fastq(path, input_path, full_name=False):
     db.executescript(FASTQ_DDL)
     db.close()
     try:
-        return _lib.fxi_presize_begin(path, int(est * 0.985))
+        return _lib.fxi_presize_begin(path, int(est * 0.985), device)
     except _lib.FxError:
         return None
 
