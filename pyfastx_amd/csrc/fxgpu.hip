@@ -4071,7 +4071,16 @@ extern "C" int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int ro
             if (presized) { void *m = mmap(nullptr, (size_t)end, PROT_READ | PROT_WRITE, MAP_SHARED, db.fd, 0); if (m != MAP_FAILED) { map.p = (uint8_t *)m; map.len = (size_t)end; } }
             // (only what a pre-sized file lacks: fallocate over pages that exist still visits every one of them, 0.2 us each)
             const off_t have = std::max(from, db.size0 & ~(off_t)(FXI_PAGE - 1));
-            if (map.p && !presized && have < end && !getenv("FX_FXI_NO_FALLOCATE")) (void)fallocate(db.fd, 0, have, end - have);
+            if (map.p && !presized && have < end && !getenv("FX_FXI_NO_FALLOCATE")) {
+                // (in a thread on the CPUs next to the device: the pages then lie in the memory its copy threads are next to)
+                cpu_set_t near_cpus;
+                const bool bind = !getenv("FX_FXI_NO_BIND") && device_cpus(h->device, &near_cpus);
+                const int fd_ = db.fd;
+                std::thread([fd_, have, end, bind, near_cpus]() {
+                    if (bind) (void)pthread_setaffinity_np(pthread_self(), sizeof near_cpus, &near_cpus);
+                    (void)fallocate(fd_, 0, have, end - have);
+                }).join();
+            }
         }
     }
     const auto t3 = now();
