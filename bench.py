@@ -99,6 +99,23 @@ def _reference():
         return None
 
 
+def _settle_device_memory(dev, limit_s=12.0):
+    """Wait until the driver has finished taking down device memory that was freed just before: it does that in the background
+    (~12 GB/s) and ANY hipMalloc that comes before it is done may wait for it -- seconds after torch released tens of GB
+    (tools/first_open_probe.py).  A timed region must not begin in that state: small allocations are made and
+    released until three in a row come back at once.  -> seconds waited."""
+    import torch
+    t0 = time.perf_counter()
+    quick = 0
+    while quick < 3 and time.perf_counter() - t0 < limit_s:
+        t = time.perf_counter()
+        x = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+        del x
+        torch.cuda.empty_cache()
+        quick = quick + 1 if time.perf_counter() - t < 0.002 else 0
+    return round(time.perf_counter() - t0, 3)
+
+
 def _device_cpulist(dev):
     """local_cpulist of the device's PCI function: where libfxgpu pins the staging threads of that device (FX_STAGE_NUMA=0: nowhere)."""
     try:
@@ -376,6 +393,7 @@ def leg_c3(a, dev, tmpdir):
     # the 0.7 GB file below was the 5.9 s "constructor" of one round-4 run).  The reference's leg below (5 s) gives it the time;
     # keeping the memory in torch's pool instead made the full-size constructors further down erratic (2.2-3.6 s against 1.4).
     torch.cuda.empty_cache()
+    out["device_memory_settled_after_s"] = _settle_device_memory(dev)      # (not part of any timed region)
     nqs = min(nq, 200_000)
     sid = np.random.default_rng(7).integers(0, m, nqs)
     _lib.Blob.from_file(path).close()
@@ -1636,6 +1654,7 @@ def main():
             gbuf = goffs = ours_rows = None
             if want_file:
                 host.tofile(path)
+            line["device_memory_settled_after_s"] = _settle_device_memory(dev)     # (the timed opens below must not wait for the driver to take torch's tensors down)
             if not a.no_e2e:
                 e2e = {}
                 gbuf, goffs, ours_rows = e2e_fasta(path, plan, q, e2e)
