@@ -110,9 +110,12 @@ def _settle_device_memory(dev, limit_s=12.0):
     while quick < 3 and time.perf_counter() - t0 < limit_s:
         t = time.perf_counter()
         x = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
-        del x
+        x[:4096].zero_()                                      # (... and a kernel on it with its wait: the device itself may be busy with the take-down)
+        torch.cuda.synchronize(dev)
+        pin = torch.empty(4096, dtype=torch.uint8).pin_memory()      # (... and a small pinned host allocation, which every new handle makes)
+        del x, pin
         torch.cuda.empty_cache()
-        quick = quick + 1 if time.perf_counter() - t < 0.002 else 0
+        quick = quick + 1 if time.perf_counter() - t < 0.005 else 0
     return round(time.perf_counter() - t0, 3)
 
 
@@ -403,7 +406,8 @@ def leg_c3(a, dev, tmpdir):
     got = fq.fetch_many(sid, want=("seq", "qual", "quali"))
     t2 = time.perf_counter()
     ours = _tables(path + ".fxi", ("read", "stat", "base", "meta"))
-    ctor_ph = {k: round(v, 4) for d in (getattr(fq, "ctor_phases", None), getattr(fq, "build_phases", None)) if d for k, v in d.items() if isinstance(v, float)}
+    ctor_ph = {k: (round(v, 4) if isinstance(v, float) else v) for d in (getattr(fq, "ctor_phases", None), getattr(fq, "build_phases", None)) if d
+               for k, v in d.items() if isinstance(v, (float, dict))}
     del fq
     _rm(path + ".fxi")
     smp = {"reads": m, "file_bytes": os.path.getsize(path), "Fastq_ctor_full_index_s": round(t1 - t0, 3),

@@ -76,6 +76,10 @@ int fx_open_file(const char *path, int device, fx_handle **out);
  * size 0.3 ms --, *stage_s = page cache -> pinned pieces -> HBM.  (The reference has no counterpart: it reads through a 1 MiB
  * buffer, kseq.h:13.) */
 int fx_open_laps(double *alloc_s, double *stage_s);
+/* ... and the last fx_fastq_build / fx_fastq_build_comp (this thread), eight doubles, seconds: [0] the sample of the stream and its
+ * wait, [1] allocations + launches of the count pass, [2] the wait for it, [4] plan + allocation of the read table, [5] row kernels +
+ * their wait ([3], [6], [7]: unused).  Diagnostic: a build that takes seconds instead of milliseconds is waiting for the driver. */
+int fx_build_laps(double *out8);
 /* What a file holds and how long its stream is once inflated -- kind 0: plain; 1: BGZF (*n_bytes = sum of the members'
  * ISIZE, from a walk over their headers); 2: a single gzip stream (*n_bytes = -1: unknown without inflating it). */
 int fx_stream_size(const char *path, int64_t *n_bytes, int *kind);

@@ -45,7 +45,7 @@ class ShardSummary(C.Structure):
 
 
 SYMBOLS = [
-    "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_laps", "fx_open_file_indexed", "fx_gz_checkpoints", "fx_stream_size", "fx_open_file_range", "fx_open_host", "fx_open_device",
+    "fx_last_error", "fx_version", "fx_device_count", "fx_open_file", "fx_open_laps", "fx_build_laps", "fx_open_file_indexed", "fx_gz_checkpoints", "fx_stream_size", "fx_open_file_range", "fx_open_host", "fx_open_device",
     "fx_set_shard", "fx_close", "fx_release_scratch", "fx_pinned_alloc", "fx_pinned_free", "fx_pinned_holds", "fx_pinned_trim", "fx_size", "fx_device_memory", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
     "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_line_regular", "fx_fasta_len_stats", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_fastq_build_comp", "fx_fastq_comp_info", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fasta_fetch_alloc", "fx_fetch_phases", "fx_fastq_fetch", "fx_fastq_fetch_alloc", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
@@ -64,6 +64,13 @@ def open_laps():
     a, b = C.c_double(0.0), C.c_double(0.0)
     lib().fx_open_laps(C.byref(a), C.byref(b))
     return float(a.value), float(b.value)
+
+
+def build_laps():
+    """The parts of this thread's last fx_fastq_build, seconds (fx_build_laps)."""
+    a = (C.c_double * 8)()
+    lib().fx_build_laps(a)
+    return {"sample": float(a[0]), "count_pass_enqueue": float(a[1]), "count_pass_wait": float(a[2]), "table_alloc": float(a[4]), "rows": float(a[5])}
 
 
 def fxi_presize_begin(path, nbytes, device=-1):
@@ -201,6 +208,7 @@ def lib():
     L.fx_fxi_bulk_index.argtypes = [C.c_char_p, i32, i64, vp, vp, vp]
     L.fx_fxi_bulk_index_int.argtypes = [C.c_char_p, i32, i64, vp, vp]
     L.fx_open_laps.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.fx_build_laps.argtypes = [C.POINTER(C.c_double)]
     L.fx_fastq_comp_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
     L.fx_fxi_dev_sort.argtypes = [vp, i32, C.POINTER(C.c_int64)]
     L.fx_fxi_dev_write.argtypes = [vp, i32, C.c_char_p, i32, i32, C.POINTER(C.c_double)]

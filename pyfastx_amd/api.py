@@ -1355,6 +1355,7 @@ class Fastq(_fxobj.FastqCore):
         except _lib.FxError as e:
             raise _fx_to_py(e)
         t_ready = time.perf_counter()                         # the read table is in HBM: batches by read id can be served from here on
+        scan_laps = _lib.build_laps()
         # the table the index file is written from stays with the object (up to FX_FQ_HOST_TABLE rows, 16 M = 640 MB; 0: never):
         # fq[i] then is six array elements in C instead of a statement on the index file (csrc/fxobj.c: _core_table)
         keep = 0 < s.n_reads <= int(os.environ.get("FX_FQ_HOST_TABLE", 16_000_000))
@@ -1406,7 +1407,8 @@ class Fastq(_fxobj.FastqCore):
         # resident), the index file durable on disk; index_phases has the parts of the last step when the device wrote it
         al, st = _lib.open_laps() if not self.is_gzip else (0.0, 0.0)
         self.build_phases = {"staging_s": t_staged - t_begin, "device_alloc_s": al, "page_cache_to_hbm_s": st, "scan_s": t_ready - t_staged, "index_ready_s": t_ready - t_begin,
-                             "fxi_s": t_done - t_ready, "fxi_durable_s": t_done - t_begin, "room_set_aside_early": bool(presized)}
+                             "fxi_s": t_done - t_ready, "fxi_durable_s": t_done - t_begin, "room_set_aside_early": bool(presized),
+                             "scan_laps_s": {k: round(v, 4) for k, v in scan_laps.items()}}
         self._counts, self.size = int(s.n_reads), int(s.size)
         self.avglen = self.size * 1.0 / self._counts if self._counts else float("nan")
 

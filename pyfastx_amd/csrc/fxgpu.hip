@@ -69,6 +69,17 @@ extern "C" const char *fx_last_error(void) { return g_err.c_str(); }
 // the last fx_open_file of a plain file by this thread: seconds for the device allocation (the FIRST block of tens of GB a
 // process asks the driver for takes seconds, the next one of that size microseconds) and for page cache -> pinned -> HBM
 static thread_local double g_open_laps[2] = {0.0, 0.0};
+// ... and of the last FASTQ build by this thread (fx_fastq_build / _build_comp), seconds: the sample of the stream and its wait, the
+// allocations + launches of the count pass, the wait for it, the recount of rejected runs, plan + table allocation, row kernels + wait
+static thread_local double g_build_laps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+extern "C" int fx_build_laps(double *out8) {
+    if (out8) memcpy(out8, g_build_laps, sizeof g_build_laps);
+    return FX_OK;
+}
+struct LapClock {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(int i) { const auto n = std::chrono::steady_clock::now(); g_build_laps[i] = std::chrono::duration<double>(n - t).count(); t = n; }
+};
 extern "C" int fx_open_laps(double *alloc_s, double *stage_s) {
     if (alloc_s) *alloc_s = g_open_laps[0];
     if (stage_s) *stage_s = g_open_laps[1];
@@ -2213,6 +2224,8 @@ static int fastq_count(fx_handle *h, int64_t *n_nl_core, int64_t *last_nl_core, 
     static const int force = [] { const char *e = getenv("FX_FQ_LINES"); return e ? atoi(e) : -1; }();   // 0 / 1: experiments
     bool by_lines = force > 0;
     h->fq_crlf = false;
+    memset(g_build_laps, 0, sizeof g_build_laps);
+    LapClock lc;
     if (h->n >= 4 * GRAN) {
         if ((rc = h->ctl.alloc(64))) return rc;
         HIPCHK(hipMemsetAsync(h->ctl.p + 56, 0, 3 * sizeof(unsigned long long), h->stream));
@@ -2227,7 +2240,9 @@ static int fastq_count(fx_handle *h, int64_t *n_nl_core, int64_t *last_nl_core, 
     // the composition on the way (fx_fastq_build_comp): whole streams with line records only -- a shard counts the reads it OWNS
     static const bool no_fuse = [] { const char *e = getenv("FX_FQ_NO_FUSED_COMP"); return e && atoi(e) != 0; }();
     const bool with_comp = want_comp && by_lines && !no_fuse && h->base == 0 && h->halo == 0 && h->is_last && h->n >= GRAN;
+    lc.lap(0);
     if ((rc = granule_pass<1>(h, by_lines, with_comp))) return rc;
+    lc.lap(1);
     int64_t *res = (int64_t *)(h->ctl.p + 48);                // 3 words of the control block
     hipLaunchKernelGGL(k_core_count, dim3(1), dim3(64), 0, h->stream, scan_ctx(h), (int)h->is_last, h->n - h->halo, res);
     HIPCHK(hipGetLastError());
@@ -2244,6 +2259,7 @@ static int fastq_count(fx_handle *h, int64_t *n_nl_core, int64_t *last_nl_core, 
         HIPCHK(hipMemcpyAsync(&n_rej, h->fq_rej.p, 4, hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
+    lc.lap(2);
     if (with_comp) {
         const int64_t nfull = h->n / GRAN, nruns = (nfull + FQLC_G - 1) / FQLC_G;
         h->fq_comp_runs = nruns;
@@ -2347,7 +2363,10 @@ static int fastq_records(fx_handle *h, int64_t loff, int64_t prev_nl, fx_fastq_s
     int rc = use_device(h);
     if (rc) return rc;
     FqPlan pl;
+    LapClock lc;
     if ((rc = fastq_plan(h, loff, prev_nl, &pl)) || (rc = fastq_alloc(h, pl.own.nrows))) return rc;
+    lc.lap(4);
+    struct AtExit { LapClock &c; ~AtExit() { c.lap(5); } } at_exit{lc};
     if (h->fq_by_lines) {
         static const bool rows_wave = [] { const char *e = getenv("FX_FQ_ROWS_WAVE"); return e && atoi(e) != 0; }();   // the round-4 form, for comparison
         if (h->ngran > 1 && rows_wave)
