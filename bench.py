@@ -102,14 +102,15 @@ def _reference():
 def _settle_device_memory(dev, limit_s=12.0):
     """Wait until the driver has finished taking down device memory that was freed just before: it does that in the background
     (~12 GB/s) and ANY hipMalloc that comes before it is done may wait for it -- seconds after torch released tens of GB
-    (tools/first_open_probe.py).  A timed region must not begin in that state: small allocations are made and
-    released until three in a row come back at once.  -> seconds waited."""
+    (tools/first_open_probe.py; 5.7 s inside the allocations of the 0.7 GB sample's index build in about half of the
+    full runs of round 5).  A timed region must not begin in that state: a 2 GiB allocation, a kernel on it and a small pinned host
+    allocation are made and released until three rounds in a row come back at once.  -> seconds waited."""
     import torch
     t0 = time.perf_counter()
     quick = 0
     while quick < 3 and time.perf_counter() - t0 < limit_s:
         t = time.perf_counter()
-        x = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+        x = torch.empty(2 << 30, dtype=torch.uint8, device=dev)       # (large enough to be a request to the driver, not a piece of a cached chunk)
         x[:4096].zero_()                                      # (... and a kernel on it with its wait: the device itself may be busy with the take-down)
         torch.cuda.synchronize(dev)
         pin = torch.empty(4096, dtype=torch.uint8).pin_memory()      # (... and a small pinned host allocation, which every new handle makes)
