@@ -1436,6 +1436,34 @@ def _self_launch(a):
     os.execve(sys.executable, cmd, dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
 
 
+_LINE_FD = None
+
+
+def _stdout_for_the_line_only():
+    """stdout carries the ONE JSON line and nothing else: what libraries print there (gloo's "[Gloo] Rank 3 is connected to 7 peer
+    ranks" for every rank, RCCL's lines under NCCL_DEBUG) goes to stderr from here on."""
+    global _LINE_FD
+    try:
+        sys.stdout.flush()
+        fd = os.dup(1)
+        os.dup2(2, 1)
+        _LINE_FD = fd
+    except OSError:
+        _LINE_FD = None
+
+
+def _emit(line):
+    text = json.dumps(line) + "\n"
+    if _LINE_FD is None:
+        sys.stdout.write(text)
+        sys.stdout.flush()
+        return
+    sys.stdout.flush()
+    data = text.encode()
+    while data:
+        data = data[os.write(_LINE_FD, data):]
+
+
 # ------------------------------------------------------------------------------------------ main
 def main():
     a = parse()
@@ -1460,6 +1488,7 @@ def main():
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _self_launch(a)                                     # does not return: the N ranks run this file again under torch.distributed.run
+    _stdout_for_the_line_only()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1498,11 +1527,11 @@ def main():
                     if rank == 0:
                         line["fastq_strong"] = fq_
         if rank == 0:
-            print(json.dumps(line), flush=True)
+            _emit(line)
         dist.destroy_process_group()
         return
     if a.scaling == "strong":
-        print(json.dumps(main_strong(a, dev, 0, 1, "none", False)), flush=True)
+        _emit(main_strong(a, dev, 0, 1, "none", False))
         return
 
     # ---------------- workload: the whole stream, resident in HBM
@@ -1738,7 +1767,7 @@ def main():
         else:
             line["roofline"]["traffic_source"] += "; a live measurement was tried and failed: " + src
     line["bench_wall_s"] = dict(_LAPS)
-    print(json.dumps(line), flush=True)
+    _emit(line)
 
 
 if __name__ == "__main__":
