@@ -4095,10 +4095,14 @@ extern "C" int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int ro
                 cpu_set_t near_cpus;
                 const bool bind = !getenv("FX_FXI_NO_BIND") && device_cpus(h->device, &near_cpus);
                 const int fd_ = db.fd;
-                std::thread([fd_, have, end, bind, near_cpus]() {
+                int fa_errno = 0;
+                std::thread([fd_, have, end, bind, near_cpus, &fa_errno]() {
                     if (bind) (void)pthread_setaffinity_np(pthread_self(), sizeof near_cpus, &near_cpus);
-                    (void)fallocate(fd_, 0, have, end - have);
+                    if (fallocate(fd_, 0, have, end - have) != 0) fa_errno = errno;
                 }).join();
+                // no room after all (a quota, a race with another writer): a store into the mapping would be a SIGBUS where a
+                // pwrite returns an error -- the pages go through pwrite then.  (EOPNOTSUPP and the like: the mapping stays.)
+                if (fa_errno == ENOSPC || fa_errno == EDQUOT || fa_errno == EFBIG) map.close();
             }
         }
     }

@@ -74,7 +74,7 @@ def _many_fastq(n, seed, short=False):
     return ids, b"".join(b"@SRR8539271.%d len=%d\n%s\n+\n%s\n" % (i + 1, i % 97, b"ACGTNACGTA" * (1 + i % 3), b"IIIIIHHHHH" * (1 + i % 3)) for i in ids)
 
 
-@pytest.mark.parametrize("shape", ["usual", "short", "slabs"])
+@pytest.mark.parametrize("shape", ["usual", "short", "slabs", "pwrite"])
 def test_device_pages_equal_the_host_loader_row_for_row(fx, tmp_path, monkeypatch, shape):
     """The same file indexed through the device route and through the host page loaders: SQLite accepts both, every row
     of `read` is the same, the index gives the names in order, by-name access works."""
@@ -91,6 +91,8 @@ def test_device_pages_equal_the_host_loader_row_for_row(fx, tmp_path, monkeypatc
             monkeypatch.delenv("FX_FXI_HOST", raising=False)
         if shape == "slabs":
             monkeypatch.setenv("FX_FXI_SLAB_MB", "1")         # 256 pages per slab: dozens of slabs per tree
+        if shape == "pwrite":
+            monkeypatch.setenv("FX_FXI_NO_MMAP", "1")         # no mapping of the file (what a file system without room for it gets): every page through pwrite
         fq = fx.Fastq(str(p))
         assert (fq.index_phases is not None) == (route == "dev")
         assert len(fq) == n and _check(str(p) + ".fxi") == ([("ok",)], ["readidx"])
