@@ -1614,3 +1614,30 @@ def test_fxi_size_estimate_from_the_head_of_a_fastq(tmp_path, shape):
     q = tmp_path / "odd.fq"
     q.write_bytes(b"@a\nAC\nGT\n+\nII\nII\n" * 1000)
     assert fxi.estimate_fastq_index_bytes(str(q)) is None
+
+
+def test_bench_stdout_carries_the_json_line_only():
+    """bench.py's contract with the driver: ONE JSON line on stdout.  What libraries print there from C (gloo's "[Gloo] Rank r is
+    connected to 7 peer ranks" of every rank, RCCL under NCCL_DEBUG) and what children inherit goes to stderr once
+    _stdout_for_the_line_only() has run; _emit() writes the line to the real stdout.  Also the instruction-issue roofline's arithmetic."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); import bench\n"
+            "bench._stdout_for_the_line_only(); print('python noise'); os.system('echo child noise')\n"
+            "os.write(1, b'C-level noise\\n'); bench._emit({'metric': 'm', 'value': 1.5})\n") % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout == '{"metric": "m", "value": 1.5}\n'
+    for noise in ("python noise", "child noise", "C-level noise"):
+        assert noise in out.stderr
+    sys.path.insert(0, root)
+    try:
+        import bench
+        r = bench._issue_roofline("k_fastq_lines", 4096 * 1000, 1.0)
+        # instructions per granule x 4 cycles of a SIMD / (1024 SIMDs x 2.4 GHz): 1000 granules of 473 instructions = 0.77 us
+        assert r["granules"] == 1000 and r["bound"] == "valu issue"
+        assert abs(r["floor_ms"] - 1000 * 473 * 4 / (1024 * 2.4e9) * 1e3) < 1e-3
+        assert 0 < r["frac"] <= 1
+    finally:
+        sys.path.remove(root)
