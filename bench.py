@@ -1362,7 +1362,7 @@ def fastq_strong_leg(a, dev, rank, world, backend, collective):
         t_comp = time.perf_counter() - t0
         barrier()
         t0 = time.perf_counter()
-        n_total = sq.write_index(path + ".fxi", os.path.dirname(path), barrier=barrier if collective else (lambda: None))
+        n_total = sq.write_index(path + ".fxi", gather=allgather_i64)     # every rank formats its table leaves on its device; names to rank 0 (RCCL / gloo), one sort, the index
         t_fxi = time.perf_counter() - t0
         first = np.concatenate([[0], np.cumsum(allgather_i64([sq.n_local])[:, 0])])
         nq = int(min(a.queries, 1_000_000))

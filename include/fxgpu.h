@@ -104,8 +104,18 @@ int fx_close(fx_handle *h);
 /* Scratch of an open (compressed bytes of a BGZF file, its match map: hundreds of MB for tens of milliseconds) and, since
  * round 4, the blob of a closed handle are kept in a per-process pool for the next open (FX_SCRATCH_CACHE_MB, default 8192:
  * the driver clears memory it hands out or takes back, 20 ms per 3 GB in the way of the next open's copies; the library
- * empties the pool by itself before a device allocation fails).  This gives the idle blocks back to the driver now. */
+ * empties the pool by itself before a device allocation fails).  This gives the idle blocks back to the driver now.
+ * Blobs LARGER than that whole limit (the 35 GB of a sequencing run) are kept too when their handle closes -- freeing one
+ * makes the process's next large allocation wait seconds for the driver -- under a cap of their own: FX_SCRATCH_KEEP_BIG_MB
+ * per device (default half the device's memory; 0: none) and FX_SCRATCH_BIG_TTL_S (default 300 s idle, checked at the next
+ * call into the pool; 0: no limit).  A process that SHARES its GPU with others (several ranks on one device) should call
+ * fx_release_scratch after closing large files: nobody else can reclaim what idles here.  (index.c:431-474 frees
+ * synchronously; there is no device memory in the reference.) */
 int fx_release_scratch(void);
+/* The decision behind that cap, as a pure function (tests pin it): the device holds n large idle blocks of idle_caps[]
+ * bytes, one more of `cap` bytes comes back, keep_bytes are allowed in all.  -> 1: the new block is kept and the idle
+ * blocks with evict[i] = 1 (the smallest, as many as needed) are freed; 0: the new block is freed and nothing else. */
+int fx_scratch_policy(const int64_t *idle_caps, int n, int64_t cap, int64_t keep_bytes, int32_t *evict);
 /* Pinned (page-locked) host memory out of a per-process pool, for the arrays a caller hands to the batched entry
  * points with FX_HOST: answers land in it by DMA -- no bounce buffer, no first-touch page faults of a fresh buffer
  * (what the copy out of pyfastx_index_fill_cache's cache costs the reference per getter, sequence.c:346-347, is paid
@@ -474,8 +484,9 @@ int fx_fxi_bulk_index_int(const char *path, int rootpage, int64_t n, const int64
  *   fx_fxi_dev_write: `path` = a database with the schema in place and NO open connection, 4 KiB pages;
  *                     root_table / root_index = sqlite_master.rootpage of the empty table / of the empty UNIQUE INDEX on its
  *                     name column (0: no index; else fx_fxi_dev_sort must have run).  laps (8 doubles, may be NULL), seconds:
- *                     table shape, leaf kernels, pages to the file, interior pages; the same four for the index (shape
- *                     includes the dividers for the upper levels).  FX_ERANGE: a row / entry needs an overflow page (or
+ *                     [0] table shape, [1] table leaf kernels, [2] table leaves to the file, [3] file grown and allocated
+ *                     (fallocate), [4] index shape + the dividers for the upper levels, [5] index leaf kernels, [6] index
+ *                     leaves to the file, [7] rest of the host's levels + header; filled on every way out.  FX_ERANGE: a row / entry needs an overflow page (or
  *                     >= 2^32 records) -- nothing usable was written, use the host loaders or INSERTs; FX_EINVAL: not a
  *                     database this loader can extend (other page size, reserved bytes, auto-vacuum). */
 int fx_fxi_dev_sort(fx_handle *h, int kind, int64_t *n_dup);
@@ -491,6 +502,45 @@ int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int root_table, i
  * file grows one INSERT at a time (fastq.c:136-149). */
 int fx_fxi_presize_begin(const char *path, int64_t bytes, int device, void **token);
 int fx_fxi_presize_end(void *token, int cancel);
+
+/* ONE index file from SEVERAL handles (round 6): a file indexed by byte range -- one process per GPU, the
+ * devices of one process, or windows of one device that take turns -- has the rows of `read` / `seq` in several handles;
+ * part r holds rows [row_base_r, row_base_r + n_r), in order.  Every part formats ITS table leaves on its own device and
+ * copies them into its own page range of the one file; the index needs all names in one order, so every part hands its
+ * names to device memory the caller moves to the writing rank (the process group's gather: RCCL over xGMI), which sorts
+ * them once and formats the index leaves from that buffer.  Replaces, for a sharded build, the same reference loops as
+ * fx_fxi_dev_write (fastq.c:29-60, 136-171; index.c:178-207, 239-251, 363).  Order of the calls:
+ *   every part   fx_fxi_part_shape(h, kind, row_base, out3): out3 = rows, table leaves, bytes of names.  The caller adds up
+ *                the leaves over the parts (they travel with the build's all-gather).
+ *   writer       creates the database (schema + the empty UNIQUE INDEX), no open connection; fx_fxi_join_grow(path,
+ *                root_table, all parts' leaves, device, &first_new_page) makes room for the table's pages (best effort)
+ *                and says where the new pages begin -- every part needs that number.
+ *   every part   fx_fxi_part_leaves(h, kind, path, first_new_page, leaves of the parts before this one, laps2): kernels +
+ *                copy-out into the file (laps2: seconds in the kernels, in the copies).  The parts may run at the same
+ *                time, from different processes.  A table with ONE leaf in all: leaf_base = -root_table (it lives in
+ *                the root page).
+ *   every part   fx_fxi_part_names(h, kind, d_names, d_lens): DEVICE pointers on the handle's device, room for out3[2] + 64
+ *                bytes and out3[0] lengths; fx_fxi_part_firsts(h, first_rows): 0-based first row of each of its leaves
+ *                (host, out3[1] values) for the table's interior pages.
+ *   writer       fx_fxi_join_begin(device, all names back to back in part order, all lengths, n, &j, &n_dup): one sort;
+ *                n_dup > 0: the names are not distinct, write no index (fastq.c:152-156 ignores the failure of CREATE
+ *                UNIQUE INDEX) -- pass root_index = 0 below and drop the empty index from the schema.
+ *                fx_fxi_join_write(j, path, root_table, root_index, rows, table leaves, first_rows of all parts in order,
+ *                first_new_page, laps6) once every part's fx_fxi_part_leaves has returned: the table's interior levels,
+ *                the index (leaves on the device, upper levels on the host), the header; laps6: file grown, index shape +
+ *                dividers, index leaf kernels, index leaves to the file, host levels + header, table interior.
+ *                fx_fxi_join_end(j).
+ * FX_ERANGE from any of them: a row / entry needs an overflow page -- remove the file and use the host loaders. */
+typedef struct fx_fxi_join fx_fxi_join;
+int fx_fxi_part_shape(fx_handle *h, int kind, int64_t row_base, int64_t *out3);
+int fx_fxi_part_firsts(fx_handle *h, int64_t *first_rows);
+int fx_fxi_part_names(fx_handle *h, int kind, uint8_t *d_names, int32_t *d_lens);
+int fx_fxi_part_leaves(fx_handle *h, int kind, const char *path, int64_t first_new_page, int64_t leaf_base, double *laps);
+int fx_fxi_join_grow(const char *path, int root_table, int64_t nleaf_table, int device, int64_t *first_new_page);
+int fx_fxi_join_begin(int device, const uint8_t *d_names, const int32_t *d_lens, int64_t n, fx_fxi_join **out, int64_t *n_dup);
+int fx_fxi_join_write(fx_fxi_join *j, const char *path, int root_table, int root_index, int64_t n_rows, int64_t nleaf_table,
+                      const int64_t *first_rows, int64_t first_new_page, double *laps);
+void fx_fxi_join_end(fx_fxi_join *j);
 
 /* ------------------------------------------------------- sync and timing
  * Calls that take FX_DEVICE arrays return after ENQUEUEING work on the

@@ -49,7 +49,7 @@ SYMBOLS = [
     "fx_set_shard", "fx_close", "fx_release_scratch", "fx_pinned_alloc", "fx_pinned_free", "fx_pinned_holds", "fx_pinned_trim", "fx_size", "fx_device_memory", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
     "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_line_regular", "fx_fasta_len_stats", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_fastq_build_comp", "fx_fastq_comp_info", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fasta_fetch_alloc", "fx_fetch_phases", "fx_fastq_fetch", "fx_fastq_fetch_alloc", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
-    "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_fxi_dev_sort", "fx_fxi_dev_write", "fx_fxi_presize_begin", "fx_fxi_presize_end", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
+    "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_fxi_dev_sort", "fx_fxi_dev_write", "fx_fxi_presize_begin", "fx_fxi_presize_end", "fx_fxi_part_shape", "fx_fxi_part_firsts", "fx_fxi_part_names", "fx_fxi_part_leaves", "fx_fxi_join_grow", "fx_fxi_join_begin", "fx_fxi_join_write", "fx_fxi_join_end", "fx_scratch_policy", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
     "fx_comm_unique_id", "fx_comm_init", "fx_comm_destroy", "fx_comm_rank", "fx_comm_world", "fx_comm_allgather", "fx_fasta_build_sharded_begin",
     "fx_fasta_build_sharded", "fx_comm_summaries", "fx_fastq_build_sharded", "fx_bgzf_counts", "fx_sort_packed_names", "fx_gunzip_parallel", "fx_gz_open_mode", "fx_kseq_scan", "fx_kseq_records", "fx_kseq_fetch", "fx_kseq_prefix_lines",
 ]
@@ -79,6 +79,38 @@ def fxi_presize_begin(path, nbytes, device=-1):
     tok = C.c_void_p(None)
     check(lib().fx_fxi_presize_begin(os.fsencode(path), int(nbytes), int(device), C.byref(tok)))
     return tok
+
+
+def fxi_join_grow(path, root_table, nleaf_table, device):
+    """Room for the table's new pages (best effort) -> the page number the parts' leaves begin at."""
+    first = C.c_int64(0)
+    check(lib().fx_fxi_join_grow(os.fsencode(path), int(root_table), int(nleaf_table), int(device), C.byref(first)))
+    return int(first.value)
+
+
+class FxiJoin:
+    """The writer's side of an index file that several handles fill (fx_fxi_join_*): the names of all parts, in part order,
+    back to back in device memory (d_names, d_lens: pointers as integers), sorted once."""
+    LAPS = ("file_grown", "index_shape", "index_kernels", "index_to_file", "host_levels_and_header", "table_interior")
+
+    def __init__(self, device, d_names, d_lens, n):
+        self._j, nd = C.c_void_p(), C.c_int64(0)
+        check(lib().fx_fxi_join_begin(int(device), C.c_void_p(int(d_names or 0)), C.c_void_p(int(d_lens or 0)), int(n), C.byref(self._j), C.byref(nd)))
+        self.n_dup = int(nd.value)
+
+    def write(self, path, root_table, root_index, n_rows, first_rows, first_new_page):
+        first_rows = np.ascontiguousarray(first_rows, dtype=np.int64)
+        laps = (C.c_double * 6)()
+        check(lib().fx_fxi_join_write(self._j, os.fsencode(path), int(root_table), int(root_index), int(n_rows), int(first_rows.size),
+                                      _ptr(first_rows) if first_rows.size else None, int(first_new_page), laps))
+        return dict(zip(self.LAPS, (float(x) for x in laps)))
+
+    def close(self):
+        if self._j:
+            lib().fx_fxi_join_end(self._j)
+            self._j = C.c_void_p()
+
+    __del__ = close
 
 
 def fxi_presize_end(token, cancel=False):
@@ -214,6 +246,16 @@ def lib():
     L.fx_fxi_dev_write.argtypes = [vp, i32, C.c_char_p, i32, i32, C.POINTER(C.c_double)]
     L.fx_fxi_presize_begin.argtypes = [C.c_char_p, i64, i32, C.POINTER(vp)]
     L.fx_fxi_presize_end.argtypes = [vp, i32]
+    L.fx_fxi_part_shape.argtypes = [vp, i32, i64, C.POINTER(C.c_int64)]
+    L.fx_fxi_part_firsts.argtypes = [vp, vp]
+    L.fx_fxi_part_names.argtypes = [vp, i32, vp, vp]
+    L.fx_fxi_part_leaves.argtypes = [vp, i32, C.c_char_p, i64, i64, C.POINTER(C.c_double)]
+    L.fx_fxi_join_grow.argtypes = [C.c_char_p, i32, i64, i32, C.POINTER(C.c_int64)]
+    L.fx_fxi_join_begin.argtypes = [i32, vp, vp, i64, C.POINTER(vp), C.POINTER(C.c_int64)]
+    L.fx_fxi_join_write.argtypes = [vp, C.c_char_p, i32, i32, i64, i64, vp, i64, C.POINTER(C.c_double)]
+    L.fx_fxi_join_end.argtypes = [vp]
+    L.fx_fxi_join_end.restype = None
+    L.fx_scratch_policy.argtypes = [vp, i32, i64, i64, vp]
     L.fx_sync.argtypes = [vp]
     L.fx_prof_enable.argtypes = [vp, i32]
     L.fx_prof_default.argtypes = [i32]
@@ -828,6 +870,27 @@ class Blob:
         laps = (C.c_double * 8)()
         check(lib().fx_fxi_dev_write(self._h, int(kind), os.fsencode(path), int(root_table), int(root_index), laps))
         return dict(zip(self.FXI_LAPS, (float(x) for x in laps)))
+
+    # -- one index file from several handles (fx_fxi_part_*: this handle's part) --
+    def fxi_part_shape(self, kind, row_base):
+        """-> (rows, table leaves, bytes of names) of this handle's part of the table; rowids start at row_base + 1."""
+        out = (C.c_int64 * 3)()
+        check(lib().fx_fxi_part_shape(self._h, int(kind), int(row_base), out))
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def fxi_part_firsts(self, nleaf):
+        first = np.empty(int(nleaf), dtype=np.int64)
+        check(lib().fx_fxi_part_firsts(self._h, _ptr(first) if nleaf else None))
+        return first
+
+    def fxi_part_names(self, kind, d_names, d_lens):
+        """Names back to back + their lengths into DEVICE memory (pointers as integers: torch data_ptr())."""
+        check(lib().fx_fxi_part_names(self._h, int(kind), C.c_void_p(int(d_names)), C.c_void_p(int(d_lens))))
+
+    def fxi_part_leaves(self, kind, path, first_new_page, leaf_base):
+        laps = (C.c_double * 2)()
+        check(lib().fx_fxi_part_leaves(self._h, int(kind), os.fsencode(path), int(first_new_page), int(leaf_base), laps))
+        return {"table_kernels": float(laps[0]), "table_to_file": float(laps[1])}
 
     def names_sort(self, kind, n):
         """-> (order int64[n], n_dup): sorted order of the n record names (BINARY collation) computed on the GPU."""

@@ -203,8 +203,13 @@ def _dev_index(path, blob, kind, n, total, presized=False):
             return fxi.write_fastq_dev(path, blob, n, total, schema_done=presized)
         return fxi.write_fasta_dev(path, blob, n, total)
     except _lib.FxError as e:
-        if e.code not in (_lib.FX_ERANGE, _lib.FX_EINVAL):
+        # a row that needs an overflow page / a database without 4 KiB pages -- or no room on the device for the slab and the
+        # sort beside a stream close to the HBM budget (FX_ENOMEM, FX_EDEVICE; FX_EIO: the file could not be grown): the host
+        # loaders still produce the index (the half-written file is gone: fxi._bulk_table_dev removed it)
+        if e.code not in (_lib.FX_ERANGE, _lib.FX_EINVAL, _lib.FX_ENOMEM, _lib.FX_EDEVICE, _lib.FX_EIO):
             raise
+        if e.code in (_lib.FX_ENOMEM, _lib.FX_EDEVICE):
+            _lib.lib().fx_release_scratch()
         return None
 
 
@@ -1314,8 +1319,10 @@ class Fastq(_fxobj.FastqCore):
         if not self.is_gzip and _dev_index_applies(self._index_file) and self._st.forced is None and not os.environ.get("FX_FXI_NO_PRESIZE"):
             try:
                 tok = fxi.presize_fastq(self._index_file, self.file_name, device=self._st.device)     # (the index holds names cut at the first white space whatever full_name says: fastq.c:112-117)
-            except Exception:                                 # noqa: BLE001  (no early file: the build makes it)
+            except Exception:                                 # noqa: BLE001  (no early file: the build makes it -- and must find none)
                 tok = None
+                if os.path.exists(self._index_file):
+                    os.remove(self._index_file)
         try:
             self._create_index_body(tok is not None, tok)
         except BaseException:
@@ -1837,6 +1844,14 @@ def _kseq_batches(get_blob, close_blob, fastq, upper, owner=None):
             return hdr, ho, seq, qual, recs[i:k]
 
         jobs = pieces()
+        if not close_blob:
+            # the handle is shared (Fasta / Fastq(build_index=False).__iter__ hand out their own blob): a second live iterator on
+            # the same object would run fx_kseq_scan on the main thread while this one's helper is inside fx_kseq_fetch -- two
+            # calls at a time on one handle.  Only a generator that OWNS its blob gathers ahead; a shared one stays strictly serial.
+            for job in jobs:
+                yield fetch(job)
+            yield None
+            return
         ahead = None
         job = next(jobs, None)
         if job is not None:

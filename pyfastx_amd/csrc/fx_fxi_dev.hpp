@@ -38,6 +38,7 @@ struct FxiCols {
     const int64_t *name_off;                    // name of row i = stream[name_off[i] + name_add - gbase, + name_len[i])
     int64_t name_add, gbase;
     const int32_t *name_len;
+    int64_t row_base;                           // rowid of row i = row_base + i + 1 (a part of a table that several handles write)
 };
 
 __device__ __forceinline__ int64_t fxi_col(const FxiCols &c, int k, int64_t i) {
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(BLOCK) void k_fxi_cell_sizes(FxiCols c, int64_t n, 
         if (k < c.ncols) { int nb; (void)fxi_int_serial(fxi_col(c, k, i), &nb); body += nb; }
     const int payload = hdr + body;
     if (hdr > 127 || payload > FXI_PAGE - 35 || L > 3900) { atomicOr(bad, 1); sz[i] = 64; return; }
-    sz[i] = (uint16_t)(fxi_varint_len((uint64_t)payload) + fxi_varint_len((uint64_t)(i + 1)) + payload + 2);
+    sz[i] = (uint16_t)(fxi_varint_len((uint64_t)payload) + fxi_varint_len((uint64_t)(c.row_base + i + 1)) + payload + 2);
 }
 // index leaf cell of the e-th smallest name: varint(payload) | header: size, TEXT, integer | name | rowid
 __global__ __launch_bounds__(BLOCK) void k_fxi_entry_sizes(FxiCols c, const int64_t *__restrict__ order, int64_t n, uint16_t *__restrict__ sz,
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(BLOCK) void k_fxi_entry_sizes(FxiCols c, const int6
     const int64_t r = order[e];
     const int L = c.name_len[r] > 0 ? c.name_len[r] : 0;
     int nb;
-    (void)fxi_int_serial(r + 1, &nb);
+    (void)fxi_int_serial(c.row_base + r + 1, &nb);
     const int payload = 1 + fxi_varint_len((uint64_t)(13 + 2 * (int64_t)L)) + 1 + L + nb;
     if (payload > FXI_INDEX_MAX_LOCAL) { atomicOr(bad, 1); sz[e] = 64; return; }
     sz[e] = (uint16_t)(fxi_varint_len((uint64_t)payload) + payload + 2);
@@ -222,14 +223,14 @@ __global__ __launch_bounds__(BLOCK) void k_fxi_table_leaves(FxiCols c, const uin
 #pragma unroll
                 for (int q = 0; q < FXI_MAXCOL; ++q)
                     if (q < c.ncols) { val[q] = fxi_col(c, q, i); st[q] = fxi_int_serial(val[q], &nb[q]); body += nb[q]; }
-                len = (uint32_t)(fxi_varint_len((uint64_t)(hdr + body)) + fxi_varint_len((uint64_t)(i + 1)) + hdr + body);
+                len = (uint32_t)(fxi_varint_len((uint64_t)(hdr + body)) + fxi_varint_len((uint64_t)(c.row_base + i + 1)) + hdr + body);
             }
             const uint32_t incl = wave_incl_scan(len);
             if (valid) {
                 const uint32_t at = top - incl;
                 uint8_t *q = pg + at;
                 q = fxi_put_varint(q, (uint64_t)(hdr + body));
-                q = fxi_put_varint(q, (uint64_t)(i + 1));
+                q = fxi_put_varint(q, (uint64_t)(c.row_base + i + 1));
                 *q++ = (uint8_t)hdr;
                 *q++ = 0;                                    // INTEGER PRIMARY KEY: NULL, the rowid is the value
                 q = fxi_put_varint(q, (uint64_t)(13 + 2 * L));
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(BLOCK) void k_fxi_index_leaves(FxiCols c, const uin
                 r = order[e];
                 L = c.name_len[r] > 0 ? c.name_len[r] : 0;
                 tl = fxi_varint_len((uint64_t)(13 + 2 * L));
-                st = fxi_int_serial(r + 1, &nb);
+                st = fxi_int_serial(c.row_base + r + 1, &nb);
                 payload = 1 + tl + 1 + L + nb;
                 len = (uint32_t)(fxi_varint_len((uint64_t)payload) + payload);
             }
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(BLOCK) void k_fxi_index_leaves(FxiCols c, const uin
                 q = fxi_put_varint(q, (uint64_t)(13 + 2 * L));
                 *q++ = (uint8_t)st;
                 q = fxi_put_name(q, data + (c.name_off[r] + c.name_add - c.gbase), L);
-                q = fxi_put_be(q, (uint64_t)(r + 1), nb);
+                q = fxi_put_be(q, (uint64_t)(c.row_base + r + 1), nb);
                 const uint32_t slot = 8 + 2 * (uint32_t)(e - a);
                 pg[slot] = (uint8_t)(at >> 8); pg[slot + 1] = (uint8_t)at;
             }

@@ -31,7 +31,20 @@
 
 namespace fx {
 
-constexpr int P_LB = 10, P_DB = 8, P_LPOOL = 512, P_DPOOL = 384;        // root bits; sub-table entries (an overflow hands the member over)
+// root bits; sub-table entries (an overflow hands the member over).  Round 6: the pools sized for what zlib's trees need (genome
+// text: none at all; FASTQ quality strings, protein: under 200 entries) instead of the worst case -- 384 + 256 -- and the arrays
+// only the table construction uses share their bytes with the arrays only the hand-over uses: 12 784 -> 9 760 B per wave,
+// sixteen waves per CU instead of twelve (FX_BGZF_P_LB / _LPOOL / _DPOOL: experiment builds)
+#ifndef FX_BGZF_P_LB
+#define FX_BGZF_P_LB 10
+#endif
+#ifndef FX_BGZF_P_LPOOL
+#define FX_BGZF_P_LPOOL 384
+#endif
+#ifndef FX_BGZF_P_DPOOL
+#define FX_BGZF_P_DPOOL 256
+#endif
+constexpr int P_LB = FX_BGZF_P_LB, P_DB = 8, P_LPOOL = FX_BGZF_P_LPOOL, P_DPOOL = FX_BGZF_P_DPOOL;
 constexpr int INFL_RETRY = 100;
 constexpr uint32_t P_MINCH = 2048;                                     // bits per lane at least, ~150 symbols: a wrong start needs up to ~130 to fall into step (short blocks use fewer lanes)
 constexpr int P_MAXSKIP = 3;                                           // stretches a walk may cross without meeting their lane's path
@@ -44,19 +57,33 @@ constexpr int P_MAXSKIP = 3;                                           // stretc
 constexpr uint32_t P_LINK = 1u << 15, P_INV_L = 1u | (3u << 8), P_INV_D = 1u | (1u << 8);
 struct PTab {
     uint32_t llut[1 << P_LB], dlut[1 << P_DB], lpool[P_LPOOL], dpool[P_DPOOL];
-    uint16_t code[MAXLCODES + MAXDCODES + 4];                           // canonical code of every symbol, bit-reversed (table construction)
-    uint16_t longs[MAXLCODES + 4];                                      // symbols whose code is longer than the root index
-    uint16_t cl[128];                                                   // the code-length code: 7-bit root, complete
-    uint8_t lengths[MAXLCODES + MAXDCODES + 8];
-    int cnt[16];
-    int tmp[32];                                                        // p_header's small arrays (private arrays would be selected out of ~40 registers)
     int hdr[8];                                                         // lane 0 -> wave: status, nlen, ndist, position behind the header, type, last
-    uint32_t hY[64], hc[64], oY[64], oc[64], hn[64], on[64];          // hand-over: what lane k found for its target / what lane t was given (position, bytes, symbols)
-    int htgt[64], own[64];
+    union {
+        struct {                                                        // live from the block header to the end of the table construction
+            uint16_t code[MAXLCODES + MAXDCODES + 4];                   // canonical code of every symbol, bit-reversed
+            uint16_t longs[MAXLCODES + 4];                              // symbols whose code is longer than the root index
+            uint16_t cl[128];                                           // the code-length code: 7-bit root, complete
+            uint8_t lengths[MAXLCODES + MAXDCODES + 8];
+            int cnt[16];
+            int tmp[32];                                                // p_header's small arrays (private arrays would be selected out of ~40 registers)
+        };
+        struct {                                                        // live from the end of phase A2 to the start of phase B
+            uint32_t hY[64], hc[64], oY[64], oc[64], hn[64], on[64];  // hand-over: what lane k found for its target / what lane t was given (position, bytes, symbols)
+            int htgt[64], own[64];
+        };
+    };
 #ifdef FX_BGZF_LDS_MAP
     uint32_t map[2048];                                                // the member's match map (one bit per output byte), flushed once
 #endif
+#ifdef FX_BGZF_OUTBUF
+    unsigned long long ob[8 * 64];                                     // phase B: every lane's current 64-byte block of output, word s of lane l at [s * 64 + l]
+#endif
 };
+#ifdef FX_BGZF_WPE
+#define P_WPE __attribute__((amdgpu_waves_per_eu(FX_BGZF_WPE, FX_BGZF_WPE)))
+#else
+#define P_WPE
+#endif
 
 // >= 57 bits of the payload from bit position bitpos on.  STAGE: the payload sits in LDS (three aligned words and two
 // funnel shifts: an unaligned 8-byte LDS read is split into byte reads by the compiler); else in place, one unaligned load.
@@ -245,6 +272,8 @@ template <bool FULL> __device__ __forceinline__ PSym p_next(const PTab &T, PRd &
 
 // the block header at bit position hp, by lane 0: type, last, and for a dynamic block the code lengths into T.lengths.
 // T.hdr = {status, nlen, ndist, position behind the header, type, last}
+// (Round 6, tried: the header's bytes staged in LDS by the wave before lane 0 walks them -- 10.38 -> 10.55 ms for C4: the walk's loads
+// hit the L1, they follow each other through a few lines; the staging's own load and barrier per block cost more than they save.)
 template <bool STAGE> __device__ __forceinline__ void p_header(PTab &T, const uint8_t *base, uint32_t hp, uint32_t pend) {
     int st = INFL_OK, nlen = 0, ndist = 0;
     uint64_t w = p_peek<STAGE>(base, hp);
@@ -334,7 +363,7 @@ __device__ __forceinline__ void p_map_flush(unsigned long long *bm, uint32_t wi,
 #define P_MAP_SET(o) atomicOr(reinterpret_cast<unsigned int *>(bm) + ((o) >> 5), 1u << ((o) & 31u))
 #endif
 template <bool STAGE, bool REPLAY>
-__global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restrict__ cbuf, const int64_t *__restrict__ cdata_off,
+__global__ __launch_bounds__(64) P_WPE void k_bgzf_decode_par(const uint8_t *__restrict__ cbuf, const int64_t *__restrict__ cdata_off,
                                                          const int32_t *__restrict__ cdata_len, const int64_t *__restrict__ uoff,
                                                          const int32_t *__restrict__ isize, int64_t nmem, uint8_t *__restrict__ data,
                                                          int32_t *__restrict__ status, uint64_t *__restrict__ match_map, int dbg, int lds_payload,
@@ -423,8 +452,16 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
         int neob = 0;
         if (active) {
             const uint32_t lim = Sn < pend ? Sn : pend;
+#ifndef FX_BGZF_NO_A_CHUNK
+            PRd ra;
+            if (!STAGE) pr_init(ra, base, S);
+#endif
             while (pos < lim) {
+#ifndef FX_BGZF_NO_A_CHUNK
+                const PSym s = STAGE ? p_symbol<REPLAY>(T, p_peek<STAGE>(base, pos)) : p_next<REPLAY>(T, ra);
+#else
                 const PSym s = p_symbol<REPLAY>(T, p_peek<STAGE>(base, pos));
+#endif
                 if (REPLAY) { if (ns < (uint32_t)sym_rows) sb[(size_t)ns * 64u] = (s.kind << 30) | s.val; }
                 if (s.kind == 2) {
                     if (neob == 0) { e1p = pos; e1a = pos + s.nbits; e1b = T_k; e1i = ns; }
@@ -558,6 +595,36 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
             }
             PRd r;
             if (!STAGE && !REPLAY) pr_init(r, base, Y);
+#ifdef FX_BGZF_OUTBUF
+            // Round 6.  Words of output are 8-byte ALIGNED in memory and a lane's whole 64-byte blocks are put together in LDS and
+            // leave as four 16-byte stores back to back: a block is in the L2 for a moment and goes to memory whole.  (Before: one
+            // 8-byte store per ~1.5 symbols at 64 places of the member; a 128-byte line got its sixteen stores over the whole of
+            // phase B, ~40 us, was evicted in between -- 4096 members x 84 KiB are open at a time, the L2s hold 32 MiB -- and
+            // was read back and written again: WRITE_SIZE 18.5 GB for 3.4 GB of output and map, profiles/r06_pmc_bgzf_c4_before.txt.)
+            // Only the words of the first and the last, partly owned block of a stretch are stored as they come.
+            const uint32_t al = (uint32_t)(reinterpret_cast<uintptr_t>(out) & 63u);
+            uint8_t *const P = out - al;                                         // 64-byte aligned; place x of the member is P[x + al]
+            const uint32_t oa0 = o + al, oa_end = o_end + al;
+            const uint32_t lo_full = (oa0 + 63u) & ~63u, hi_full = oa_end & ~63u;   // the blocks [lo_full, hi_full) are this lane's alone
+            uint32_t wb = oa0 & ~7u;                                             // acc holds the bytes [wb, wb + fill)
+            if (!REPLAY) fill = oa0 & 7u;
+            auto emit = [&](uint64_t w) {
+                if (wb >= lo_full && wb < hi_full) {
+                    const uint32_t sl = (wb >> 3) & 7u;
+                    T.ob[sl * 64u + (uint32_t)lane] = w;
+                    if (sl == 7u) {
+                        typedef unsigned long long p_v2q __attribute__((ext_vector_type(2)));
+                        p_v2q *dst = reinterpret_cast<p_v2q *>(P + (wb & ~63u));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { p_v2q v; v.x = T.ob[(2 * i) * 64 + lane]; v.y = T.ob[(2 * i + 1) * 64 + lane]; dst[i] = v; }
+                    }
+                } else if (wb < oa0) {                                           // the word the stretch begins in: the bytes in front are the lane before's
+                    for (uint32_t i = oa0 - wb; i < 8u; ++i) P[wb + i] = (uint8_t)(w >> (8u * i));
+                } else
+                    *reinterpret_cast<uint64_t *>(P + wb) = w;
+                wb += 8u;
+            };
+#endif
             for (; !REPLAY;) {
                 if (lane < j && bp >= stop) break;
                 const PSym s = STAGE ? p_symbol<true>(T, p_peek<STAGE>(base, bp)) : p_next<true>(T, r);
@@ -577,11 +644,26 @@ __global__ __launch_bounds__(64) void k_bgzf_decode_par(const uint8_t *__restric
                 fill += s.out;
                 o += s.out; bp += s.nbits;
                 if (fill >= 8u) {
+#ifdef FX_BGZF_OUTBUF
+                    uint64_t nx = spill;
+                    do { emit(acc); acc = nx; nx = 0; fill -= 8u; } while (fill >= 8u);      // (more than once: a long match)
+#else
+                    if (dbg == 5) {                                              // timing probe: the same stores into 4 KiB per member (they stay in the L2)
+                        *reinterpret_cast<uint64_u *>(out + ((o - fill) & 0xFFFu)) = acc;
+                        acc = spill; fill -= 8u;
+                        while (fill >= 8u) { *reinterpret_cast<uint64_u *>(out + ((o - fill) & 0xFFFu)) = acc; acc = 0; fill -= 8u; }
+                        continue;
+                    }
                     *reinterpret_cast<uint64_u *>(out + (o - fill)) = acc;
                     acc = spill; fill -= 8u;
                     while (fill >= 8u) { *reinterpret_cast<uint64_u *>(out + (o - fill)) = acc; acc = 0; fill -= 8u; }   // a long match
+#endif
                 }
             }
+#ifdef FX_BGZF_OUTBUF
+            if (!REPLAY) { for (uint32_t i = (wb < oa0 ? oa0 - wb : 0u); i < fill; ++i) P[wb + i] = (uint8_t)(acc >> (8u * i)); }      // the last few bytes
+            else
+#endif
             for (uint32_t i = 0; i < fill; ++i) out[o - fill + i] = (uint8_t)(acc >> (8u * i));      // the last few bytes
 #ifdef FX_BGZF_REG_MAP
             p_map_flush(bm, mw_i, mw, o_first, o_end);

@@ -123,20 +123,74 @@ template <class T> struct DevBuf {      // grow-only device array: rebuilds reus
 // again, so released blocks are kept (per device, up to FX_SCRATCH_CACHE_MB, default 16384 since round 5 -- the temporaries of a
 // 10^8-read index file are 5 GB on top of what the opens before left --; 0 = off) and handed to the
 // next request they fit (at most twice its size).
+// Which of a device's LARGE idle blocks (each larger than the whole FX_SCRATCH_CACHE_MB limit: the blobs of closed streams)
+// stay when one more of `cap` bytes comes back, `keep` bytes of them allowed in all: the new block stays if it fits beside
+// the others; else the smallest ones go until it does -- a block smaller than all that would have to go is itself the
+// one that goes.  -> 1: keep the new block (evict[i] = 1: idle block i goes), 0: drop it.  Pure: tests pin it (fx_scratch_policy).
+static int big_block_policy(const int64_t *caps, int n, int64_t cap, int64_t keep, int32_t *evict) {
+    for (int i = 0; i < n; ++i) evict[i] = 0;
+    if (cap > keep) return 0;
+    int64_t held = 0;
+    for (int i = 0; i < n; ++i) held += caps[i];
+    while (held + cap > keep) {
+        int at = -1;
+        for (int i = 0; i < n; ++i) if (!evict[i] && (at < 0 || caps[i] < caps[at])) at = i;
+        if (at < 0 || caps[at] >= cap) { for (int i = 0; i < n; ++i) evict[i] = 0; return 0; }      // what would go is no smaller than the newcomer
+        evict[at] = 1;
+        held -= caps[at];
+    }
+    return 1;
+}
+extern "C" int fx_scratch_policy(const int64_t *idle_caps, int n, int64_t cap, int64_t keep_bytes, int32_t *evict) {
+    if (n < 0 || (n > 0 && (!idle_caps || !evict)) || cap < 0 || keep_bytes < 0) return fail(FX_EINVAL, "bad argument");
+    return big_block_policy(idle_caps, n, cap, keep_bytes, evict);
+}
+
 struct ScratchPool {
-    struct Block { void *p; size_t cap; int dev; };
+    struct Block { void *p; size_t cap; int dev; std::chrono::steady_clock::time_point since; };
     std::mutex mu;
     std::vector<Block> idle;
-    // ONE block per device that is larger than the whole limit may idle here as well (round 5): the blob of the last large
-    // stream.  hipFree of tens of GB returns at once, but the driver takes the block down in the background, and a hipMalloc
-    // of that size that comes before it is done WAITS for it -- 2.65 s for 34.8 GB, now and then (tools/first_open_probe.py:
-    // open / close / open of one file in a fresh process: 0.3 ms, 2.6 ms, 2 650 ms) -- what made a constructor on a 0.7 GB
-    // file take 5.9 s in one bench run of round 4.  Kept, the next open of a file of that size asks the driver for nothing;
-    // fx_release_scratch, a failed allocation and windows.hbm_budget give it back.
+    // Blocks LARGER than the whole limit idle here (round 5: one per device; round 6: several, under a cap and a time to live):
+    // the blobs of the last large streams.  hipFree of tens of GB returns at once, but the driver takes the block down in the
+    // background, and a hipMalloc that comes before it is done WAITS for it -- 2.65 s for 34.8 GB, now and then
+    // (tools/first_open_probe.py: open / close / open of one file in a fresh process: 0.3 ms, 2.6 ms, 2 650 ms; 5.9 s in front of
+    // a constructor on a 0.7 GB file in one bench run of round 4).  So a large block is not freed when its stream closes: the
+    // next open of that size class takes it (no driver call at all), and an open of ANOTHER size finds no free in flight to
+    // wait behind.  What bounds them: FX_SCRATCH_KEEP_BIG_MB per device (default: half the device's memory; 0: keep none),
+    // big_block_policy above; FX_SCRATCH_BIG_TTL_S (default 300; 0: no limit) -- a block idle for longer goes back at the next
+    // call into the pool, so a process that has moved on does not sit on tens of GB other tenants of the GPU could use --;
+    // fx_release_scratch, a failed allocation and windows.hbm_budget give everything back at once.  In a process that shares
+    // its GPU (several ranks on one device) call fx_release_scratch after closing large files, or set FX_SCRATCH_KEEP_BIG_MB=0.
     std::vector<Block> big;
     size_t held = 0;
     const size_t limit = [] { const char *e = getenv("FX_SCRATCH_CACHE_MB"); return (size_t)(e ? std::max(0, atoi(e)) : 16384) << 20; }();
+    const double big_ttl = [] { const char *e = getenv("FX_SCRATCH_BIG_TTL_S"); return e ? atof(e) : 300.0; }();
+    int64_t keep_big(int dev) {
+        if (const char *e = getenv("FX_SCRATCH_KEEP_BIG_MB")) return (int64_t)std::max(0ll, atoll(e)) << 20;
+        static std::mutex m;
+        static std::vector<int64_t> half;                    // per device: half its memory
+        std::lock_guard<std::mutex> g(m);
+        if ((int)half.size() <= dev) half.resize((size_t)dev + 1, -1);
+        if (half[(size_t)dev] < 0) {
+            size_t fr = 0, tot = 0;
+            int cur = 0;
+            (void)hipGetDevice(&cur);
+            if (hipSetDevice(dev) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess) half[(size_t)dev] = (int64_t)(tot / 2);
+            else half[(size_t)dev] = 0;
+            (void)hipSetDevice(cur);
+        }
+        return half[(size_t)dev];
+    }
+    // large blocks that have idled past their time to live -> out (freed by the caller, outside the lock)
+    void expire_locked(std::vector<Block> &out) {
+        if (big_ttl <= 0 || big.empty()) return;
+        const auto now = std::chrono::steady_clock::now();
+        for (size_t i = 0; i < big.size();)
+            if (std::chrono::duration<double>(now - big[i].since).count() > big_ttl) { out.push_back(big[i]); big.erase(big.begin() + (long)i); }
+            else ++i;
+    }
     void *get(int dev, size_t bytes, size_t *cap) {
+        std::vector<Block> old;
         {
             std::lock_guard<std::mutex> g(mu);
             int best = -1;
@@ -149,41 +203,59 @@ struct ScratchPool {
                 *cap = b.cap;
                 return b.p;
             }
+            best = -1;
             for (int i = 0; i < (int)big.size(); ++i)
-                if (big[i].dev == dev && big[i].cap >= bytes && big[i].cap <= 2 * bytes + (1u << 20)) {
-                    Block b = big[i];
-                    big.erase(big.begin() + i);
-                    *cap = b.cap;
-                    return b.p;
-                }
+                if (big[i].dev == dev && big[i].cap >= bytes && big[i].cap <= 2 * bytes + (1u << 20) && (best < 0 || big[i].cap < big[best].cap)) best = i;
+            if (best >= 0) {
+                Block b = big[best];
+                big.erase(big.begin() + best);
+                *cap = b.cap;
+                return b.p;
+            }
+            expire_locked(old);
         }
         void *p = nullptr;
         static const bool trace = [] { const char *e = getenv("FX_TRACE_ALLOC"); return e && atoi(e) != 0; }();
         const auto t0 = std::chrono::steady_clock::now();
+        // (the new block FIRST, what has expired afterwards: a hipMalloc behind a large hipFree waits for the driver)
         if (hipMalloc(&p, bytes) != hipSuccess) {            // make room: give the idle blocks back and try once more
+            (void)hipGetLastError();
+            for (auto &b : old) (void)hipFree(b.p);
+            old.clear();
             trim();
             if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
         }
+        for (auto &b : old) (void)hipFree(b.p);
         if (trace) fprintf(stderr, "[fxgpu] scratch miss: hipMalloc(%zu) %.2f ms\n", bytes, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         *cap = bytes;
         return p;
     }
     void put(int dev, void *p, size_t cap) {
-        void *drop = nullptr;
-        size_t drop_cap = 0;
+        std::vector<Block> drop;
         {
             std::lock_guard<std::mutex> g(mu);
-            if (held + cap <= limit) { idle.push_back(Block{p, cap, dev}); held += cap; return; }
-            if (limit && cap > limit) {                      // larger than the whole limit: the device's one large idle block (the larger of two stays)
-                int at = -1;
-                for (int i = 0; i < (int)big.size(); ++i) if (big[i].dev == dev) at = i;
-                if (at < 0) { big.push_back(Block{p, cap, dev}); return; }
-                if (big[at].cap < cap) { drop = big[at].p; drop_cap = big[at].cap; big[at] = Block{p, cap, dev}; }
-                else { drop = p; drop_cap = cap; }
-            } else { drop = p; drop_cap = cap; }
+            const auto now = std::chrono::steady_clock::now();
+            if (held + cap <= limit) { idle.push_back(Block{p, cap, dev, now}); held += cap; return; }
+            bool kept = false;
+            if (limit && cap > limit) {                      // larger than the whole limit: one of the device's large idle blocks, if the policy says so
+                std::vector<int64_t> caps;
+                std::vector<int> where;
+                for (int i = 0; i < (int)big.size(); ++i) if (big[i].dev == dev) { caps.push_back((int64_t)big[i].cap); where.push_back(i); }
+                std::vector<int32_t> ev(caps.size() + 1, 0);
+                kept = big_block_policy(caps.data(), (int)caps.size(), (int64_t)cap, keep_big(dev), ev.data()) != 0;
+                if (kept) {
+                    for (int k = (int)where.size() - 1; k >= 0; --k)
+                        if (ev[(size_t)k]) { drop.push_back(big[(size_t)where[(size_t)k]]); big.erase(big.begin() + where[(size_t)k]); }
+                    big.push_back(Block{p, cap, dev, now});
+                }
+            }
+            if (!kept) drop.push_back(Block{p, cap, dev, now});
+            expire_locked(drop);
         }
-        if (getenv("FX_TRACE_ALLOC")) fprintf(stderr, "[fxgpu] scratch full: hipFree(%zu)\n", drop_cap);
-        (void)hipFree(drop);
+        for (auto &b : drop) {
+            if (getenv("FX_TRACE_ALLOC")) fprintf(stderr, "[fxgpu] scratch full: hipFree(%zu)\n", b.cap);
+            (void)hipFree(b.p);
+        }
     }
     void trim() {
         std::vector<Block> v, w;
@@ -363,6 +435,10 @@ struct fx_handle {
     ScratchBuf<int64_t> fxi_order;           // (a block of the scratch pool: 0.8 GB for 10^8 reads; hipFree of it would wait for the device)
     int fxi_order_kind = -1;
     int64_t fxi_order_n = 0;
+    // this handle's part of a table that several handles write (fx_fxi_part_*): first row of each of its leaves
+    ScratchBuf<int64_t> fxi_part_first;
+    int64_t fxi_part_nleaf = 0, fxi_part_row_base = 0;
+    int fxi_part_kind = -1;
     DevBuf<uint8_t> arena;     // scratch for host-array calls (Staged)
     int64_t arena_used = 0;
     uint8_t *pin_in = nullptr; // pinned staging for the query arrays of host-array calls: pageable source -> here (threads) -> one DMA each
@@ -442,6 +518,7 @@ extern "C" int fx_close(fx_handle *h) {
     }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->fxi_order.release();                                  // (back to the pool while the stream it names still exists)
+    h->fxi_part_first.release();
     free_blob(h);
     if (h->pin_tot) (void)hipHostFree(h->pin_tot);
     if (h->one_box) (void)hipHostFree(h->one_box);
@@ -3817,31 +3894,32 @@ static int fxi_copy_threads() {
     return n;
 }
 
-// logical pages [k0, k1) of a tree, FXI_PAGE bytes each and back to back at d_img, to their places in the file
-static int fxi_image_out(fx_handle *h, const uint8_t *d_img, int64_t k0, int64_t k1, const fxi::PageSeq &seq, int fd, const fxi::FileMap &map) {
+// logical pages koff + [k0, k1) of a page sequence, FXI_PAGE bytes each and back to back at d_img, to their places in the file
+static int fxi_image_out(int device, const uint8_t *d_img, int64_t k0, int64_t k1, const fxi::PageSeq &seq, int64_t koff, int fd, const fxi::FileMap &map) {
     const int64_t ppp = PIECE_BYTES / FXI_PAGE, npieces = (k1 - k0 + ppp - 1) / ppp;
     const int T = (int)std::min<int64_t>(fxi_copy_threads(), std::max<int64_t>(1, npieces));
     std::atomic<int> err(0);                                 // 1: device, 2: file
     std::vector<std::thread> th;
+    auto pg = [&](int64_t k) { return (int64_t)seq.at((uint64_t)(koff + k)); };
     auto put = [&](const uint8_t *src, int64_t a, int64_t b) {          // pages [a, b) -- adjacent in the file unless the skipped page lies between
         int64_t cut = b;
-        if ((int64_t)seq.at((uint64_t)(b - 1)) - (int64_t)seq.at((uint64_t)a) != b - 1 - a)
-            for (cut = a + 1; cut < b && seq.at((uint64_t)cut) == seq.at((uint64_t)(cut - 1)) + 1;) ++cut;
+        if (pg(b - 1) - pg(a) != b - 1 - a)
+            for (cut = a + 1; cut < b && pg(cut) == pg(cut - 1) + 1;) ++cut;
         for (int part = 0; part < 2; ++part) {
             const int64_t x = part ? cut : a, y = part ? b : cut;
             if (x >= y) continue;
-            const size_t off = (size_t)(seq.at((uint64_t)x) - 1) * FXI_PAGE, len = (size_t)(y - x) * FXI_PAGE;
-            if (map.p) memcpy(map.p + off, src + (size_t)(x - a) * FXI_PAGE, len);
+            const size_t off = (size_t)(pg(x) - 1) * FXI_PAGE, len = (size_t)(y - x) * FXI_PAGE;
+            if (map.p && off + len <= map.len) memcpy(map.p + off, src + (size_t)(x - a) * FXI_PAGE, len);
             else if (!fxi::pwrite_all(fd, src + (size_t)(x - a) * FXI_PAGE, len, (off_t)off)) err.store(2);
         }
     };
     cpu_set_t near_cpus;
     static const bool no_bind = [] { const char *e = getenv("FX_FXI_NO_BIND"); return e && atoi(e) != 0; }();
-    const bool bind = !no_bind && device_cpus(h->device, &near_cpus);     // the copy threads on the CPUs next to the device, as the staging threads are
+    const bool bind = !no_bind && device_cpus(device, &near_cpus);     // the copy threads on the CPUs next to the device, as the staging threads are
     for (int t = 0; t < T; ++t)
         th.emplace_back([&, t]() {
             if (bind) (void)pthread_setaffinity_np(pthread_self(), sizeof near_cpus, &near_cpus);
-            if (hipSetDevice(h->device) != hipSuccess) { err.store(1); return; }
+            if (hipSetDevice(device) != hipSuccess) { err.store(1); return; }
             uint8_t *pin[2] = {g_pins.get(), g_pins.get()};
             hipStream_t st = nullptr;
             hipEvent_t ev[2] = {nullptr, nullptr};
@@ -3891,6 +3969,167 @@ static int fxi_check_kind(fx_handle *h, int kind) {
     return rc;
 }
 
+// What the kernels of fx_fxi_dev.hpp need, whoever owns the rows and the names: one handle's table and stream
+// (fx_fxi_dev_write), one part of a table that several handles share (fx_fxi_part_*), or the packed names of all parts on
+// the device that writes the index (fx_fxi_join_*).
+struct FxiJob {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    FxiCols c;
+    const uint8_t *data = nullptr;                         // what c.name_off points into
+    int64_t n = 0;                                           // rows / entries
+    const int64_t *order = nullptr;                          // the index: e-th smallest name = row order[e]
+    // (all out of the scratch pool: the hipFree of these blocks at the end of the call -- 1 GB -- cost 0.12-0.23 s of waiting for the device)
+    ScratchBuf<uint16_t> sz;
+    ScratchBuf<int32_t> pages, bad;
+    ScratchBuf<int64_t> sums, pbase;
+    ScratchBuf<uint8_t> slab;
+    int64_t nchunks = 0, nsc = 0;
+    int init() {
+        nchunks = (n + FXI_R - 1) / FXI_R;
+        nsc = (nchunks + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        int rc;
+        if ((rc = sz.alloc(device, n, stream)) || (rc = pages.alloc(device, nchunks, stream)) || (rc = bad.alloc(device, 1, stream)) ||
+            (rc = sums.alloc(device, nsc + 1, stream)) || (rc = pbase.alloc(device, nchunks + 1, stream))) return rc;
+        HIPCHK(hipMemsetAsync(bad.p, 0, 4, stream));
+        return FX_OK;
+    }
+    void table_sizes() { hipLaunchKernelGGL(k_fxi_cell_sizes, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, stream, c, n, sz.p, bad.p); }
+    void index_sizes() { hipLaunchKernelGGL(k_fxi_entry_sizes, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, stream, c, order, n, sz.p, bad.p); }
+    // shape of one tree's leaf level: sizes are in sz -> nleaf, first[0 .. nleaf]
+    int leaf_level(bool idx, ScratchBuf<int64_t> &first, int64_t *nleaf_out) {
+        if (idx) hipLaunchKernelGGL((k_fxi_fill<true, false>), dim3((unsigned)nchunks), dim3(64), 0, stream, sz.p, n, FXI_PAGE - 8, pages.p, (const int64_t *)nullptr, (int64_t *)nullptr);
+        else hipLaunchKernelGGL((k_fxi_fill<false, false>), dim3((unsigned)nchunks), dim3(64), 0, stream, sz.p, n, FXI_PAGE - 8, pages.p, (const int64_t *)nullptr, (int64_t *)nullptr);
+        hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)nsc), dim3(BLOCK), 0, stream, pages.p, nchunks, sums.p);
+        hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, stream, sums.p, nsc);
+        hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)nsc), dim3(BLOCK), 0, stream, pages.p, nchunks, sums.p, pbase.p);
+        HIPCHK(hipGetLastError());
+        int64_t nleaf = 0;
+        int isbad = 0;
+        HIPCHK(hipMemcpyAsync(&nleaf, pbase.p + nchunks, 8, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(&isbad, bad.p, 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (isbad) return fail(FX_ERANGE, idx ? "an index entry does not fit a b-tree page without overflow: use CREATE INDEX"
+                                              : "a row does not fit a b-tree page without overflow: use the INSERT path");
+        int r2 = first.alloc(device, nleaf + 1, stream);
+        if (r2) return r2;
+        if (idx) hipLaunchKernelGGL((k_fxi_fill<true, true>), dim3((unsigned)nchunks), dim3(64), 0, stream, sz.p, n, FXI_PAGE - 8, (int32_t *)nullptr, pbase.p, first.p);
+        else hipLaunchKernelGGL((k_fxi_fill<false, true>), dim3((unsigned)nchunks), dim3(64), 0, stream, sz.p, n, FXI_PAGE - 8, (int32_t *)nullptr, pbase.p, first.p);
+        HIPCHK(hipGetLastError());
+        *nleaf_out = nleaf;
+        return FX_OK;
+    }
+    // the leaves [0, nleaf) of one tree to the pages koff + [0, nleaf) of `seq`, slab by slab
+    int leaves_out(bool idx, int64_t nleaf, const int64_t *first, const fxi::PageSeq &seq, int64_t koff, int fd, const fxi::FileMap &map, double *t_kern, double *t_copy) {
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        const int64_t S = std::min(nleaf, fxi_slab_pages());
+        int r2 = slab.alloc(device, S * FXI_PAGE, stream);
+        if (r2) return r2;
+        for (int64_t k0 = 0; k0 < nleaf; k0 += S) {
+            const int64_t k1 = std::min(nleaf, k0 + S);
+            const auto t0 = now();
+            const unsigned grid = (unsigned)std::min<int64_t>((k1 - k0 + 3) / 4, 16384);
+            if (idx) hipLaunchKernelGGL(k_fxi_index_leaves, dim3(grid), dim3(BLOCK), 0, stream, c, data, order, first, nleaf, n, k0, k1, slab.p);
+            else hipLaunchKernelGGL(k_fxi_table_leaves, dim3(grid), dim3(BLOCK), 0, stream, c, data, first, k0, k1, slab.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(stream));
+            const auto t1 = now();
+            if ((r2 = fxi_image_out(device, slab.p, k0, k1, seq, koff, fd, map))) return r2;
+            *t_kern += secs(t0, t1); *t_copy += secs(t1, now());
+        }
+        return FX_OK;
+    }
+    // a tree of ONE leaf lives in its root page
+    int root_leaf(bool idx, const int64_t *first, int fd, int rootpage, const char *path) {
+        int r2 = slab.alloc(device, FXI_PAGE, stream);
+        if (r2) return r2;
+        if (idx) hipLaunchKernelGGL(k_fxi_index_leaves, dim3(1), dim3(BLOCK), 0, stream, c, data, order, first, (int64_t)1, n, (int64_t)0, (int64_t)1, slab.p);
+        else hipLaunchKernelGGL(k_fxi_table_leaves, dim3(1), dim3(BLOCK), 0, stream, c, data, first, (int64_t)0, (int64_t)1, slab.p);
+        std::vector<uint8_t> pg(FXI_PAGE);
+        HIPCHK(hipMemcpyAsync(pg.data(), slab.p, FXI_PAGE, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (!fxi::pwrite_all(fd, pg.data(), FXI_PAGE, (off_t)(rootpage - 1) * FXI_PAGE)) return fail(FX_EIO, "cannot write %s", path);
+        return FX_OK;
+    }
+    // the dividers of the index -- (name, rowid) of the entry between leaf d and leaf d + 1 -- for the levels the host writes
+    int dividers(const int64_t *first_i, int64_t nd, std::vector<int64_t> &d_rowid, std::vector<int64_t> &d_off, std::vector<uint8_t> &d_names) {
+        d_rowid.assign((size_t)std::max<int64_t>(nd, 1), 0);
+        d_off.assign((size_t)nd + 1, 0);
+        d_names.assign(1, 0);
+        if (nd <= 0) return FX_OK;
+        int rc;
+        ScratchBuf<int64_t> drow, doff, dsum;
+        ScratchBuf<int32_t> dlen;
+        ScratchBuf<uint8_t> dnm;
+        const int64_t ndc = (nd + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        if ((rc = drow.alloc(device, nd, stream)) || (rc = dlen.alloc(device, nd, stream)) || (rc = doff.alloc(device, nd + 1, stream)) ||
+            (rc = dsum.alloc(device, ndc + 1, stream))) return rc;
+        hipLaunchKernelGGL(k_fxi_divider_rows, dim3(nblocks(nd, BLOCK)), dim3(BLOCK), 0, stream, c, order, first_i, nd, drow.p, dlen.p);
+        hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)ndc), dim3(BLOCK), 0, stream, dlen.p, nd, dsum.p);
+        hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, stream, dsum.p, ndc);
+        hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)ndc), dim3(BLOCK), 0, stream, dlen.p, nd, dsum.p, doff.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(d_off.data(), doff.p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(d_rowid.data(), drow.p, (size_t)nd * 8, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        const int64_t tot = d_off[(size_t)nd];
+        d_names.resize((size_t)std::max<int64_t>(tot, 1));
+        if (tot) {
+            if ((rc = dnm.alloc(device, tot, stream))) return rc;
+            hipLaunchKernelGGL(k_fxi_divider_names, dim3(nblocks(nd, BLOCK)), dim3(BLOCK), 0, stream, c, data, (const int64_t *)drow.p, (const int64_t *)doff.p, nd, dnm.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(d_names.data(), dnm.p, (size_t)tot, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+        }
+        for (auto &r : d_rowid) r += c.row_base + 1;         // row -> rowid
+        return FX_OK;
+    }
+};
+
+// The pages of a database that exist + what is to come, mapped; grown and allocated first (see below).  -> map.p null: pwrite.
+static void fxi_grow_and_map(fxi::DbFile &db, uint32_t new_npages, int device, fxi::FileMap &map) {
+    // All new pages are allocated BEFORE anything is stored into them: on tmpfs fallocate alone runs at 16-18 GB/s and
+    // sixteen threads then copy into the mapping at 15 GB/s, while page allocation and faults running side by side
+    // (a fallocate thread ahead of the writers, or first touches through the mapping) reach 3-4 GB/s together
+    // (tools/filewrite_probe2.c: 10 GB in 1.3 s against 2.6-3.8 s).  A file that already has the room (pre-sized by the
+    // caller while the stream was staged) skips this.
+    const off_t end = (off_t)new_npages * FXI_PAGE, from = (off_t)db.npages * FXI_PAGE;
+    struct stat st;
+    const off_t size_now = fstat(db.fd, &st) == 0 ? st.st_size : db.size0;     // (other parts may have grown the file since it was opened)
+    const bool presized = size_now >= end;
+    if (presized || map.open(db.fd, (size_t)end)) {
+        if (presized) { void *m = mmap(nullptr, (size_t)end, PROT_READ | PROT_WRITE, MAP_SHARED, db.fd, 0); if (m != MAP_FAILED) { map.p = (uint8_t *)m; map.len = (size_t)end; } }
+        // (only what a pre-sized file lacks: fallocate over pages that exist still visits every one of them, 0.2 us each)
+        const off_t have = std::max(from, size_now & ~(off_t)(FXI_PAGE - 1));
+        if (map.p && !presized && have < end && !getenv("FX_FXI_NO_FALLOCATE")) {
+            // (in a thread on the CPUs next to the device: the pages then lie in the memory its copy threads are next to)
+            cpu_set_t near_cpus;
+            const bool bind = !getenv("FX_FXI_NO_BIND") && device_cpus(device, &near_cpus);
+            const int fd_ = db.fd;
+            int fa_errno = 0;
+            std::thread([fd_, have, end, bind, near_cpus, &fa_errno]() {
+                if (bind) (void)pthread_setaffinity_np(pthread_self(), sizeof near_cpus, &near_cpus);
+                if (fallocate(fd_, 0, have, end - have) != 0) fa_errno = errno;
+            }).join();
+            // no room after all (a quota, a race with another writer): a store into the mapping would be a SIGBUS where a
+            // pwrite returns an error -- the pages go through pwrite then.  (EOPNOTSUPP and the like: the mapping stays.)
+            if (fa_errno == ENOSPC || fa_errno == EDQUOT || fa_errno == EFBIG) map.close();
+        }
+    }
+}
+// Taking a mapping down walks every page table entry of it (0.25 s for 10 GB of dirty shared pages) and nothing waits
+// for the result: the pages are in the file's page cache either way.  It is left to a thread of its own.
+static void fxi_unmap_later(fxi::FileMap &map) {
+    if (map.p && !getenv("FX_FXI_SYNC_UNMAP")) {
+        uint8_t *mp = map.p;
+        const size_t ml = map.len;
+        map.p = nullptr;
+        std::thread([mp, ml]() { munmap(mp, ml); }).detach();
+    }
+    map.close();
+}
+
 extern "C" int fx_fxi_dev_sort(fx_handle *h, int kind, int64_t *n_dup) {
     int rc = fxi_check_kind(h, kind);
     if (rc) return rc;
@@ -3921,6 +4160,8 @@ extern "C" int fx_fxi_dev_sort(fx_handle *h, int kind, int64_t *n_dup) {
     return FX_OK;
 }
 
+// laps[8]: [0] table shape, [1] table leaf kernels, [2] table leaves to the file, [3] file grown and allocated (fallocate),
+// [4] index shape + dividers, [5] index leaf kernels, [6] index leaves to the file, [7] rest of the host levels + header
 extern "C" int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int root_table, int root_index, double *laps) {
     int rc = fxi_check_kind(h, kind);
     if (rc) return rc;
@@ -3932,80 +4173,19 @@ extern "C" int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int ro
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     static const bool trace = [] { const char *e = getenv("FX_TRACE"); return e && atoi(e) != 0; }();
-    FxiCols c;
-    fxi_cols(h, kind, &c);
-    const uint8_t *data = h->d_data;
-    const int64_t nchunks = (n + FXI_R - 1) / FXI_R;
-    const int64_t nsc = (nchunks + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    // (all out of the scratch pool: the hipFree of these blocks at the end of the call -- 1 GB -- cost 0.12-0.23 s of waiting for the device)
-    ScratchBuf<uint16_t> sz;
-    ScratchBuf<int32_t> pages, bad;
-    ScratchBuf<int64_t> sums, pbase, first_t, first_i;
-    ScratchBuf<uint8_t> slab;
-    auto done = [&](int code) {
+    FxiJob J;
+    J.device = h->device; J.stream = h->stream; J.data = h->d_data; J.n = n; J.order = h->fxi_order.p;
+    fxi_cols(h, kind, &J.c);
+    ScratchBuf<int64_t> first_t, first_i;
+    auto done = [&](int code) {                               // every way out: the order goes back to the pool, the laps to the caller
         (void)hipStreamSynchronize(h->stream);
         h->fxi_order.release(); h->fxi_order_kind = -1;
         if (laps) memcpy(laps, lap_buf, sizeof lap_buf);
         return code;
     };
+#define FXI_CHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return done(fail(FX_EDEVICE, "%s: %s", #expr, hipGetErrorString(e_))); } while (0)
     if (n == 0) return done(FX_OK);
-    if ((rc = sz.alloc(h->device, n, h->stream)) || (rc = pages.alloc(h->device, nchunks, h->stream)) || (rc = bad.alloc(h->device, 1, h->stream)) ||
-        (rc = sums.alloc(h->device, nsc + 1, h->stream)) || (rc = pbase.alloc(h->device, nchunks + 1, h->stream))) return done(rc);
-
-    // shape of one tree's leaf level: sizes are in sz -> nleaf, first[0 .. nleaf]
-    auto leaf_level = [&](bool idx, ScratchBuf<int64_t> &first, int64_t *nleaf_out) -> int {
-        if (idx) hipLaunchKernelGGL((k_fxi_fill<true, false>), dim3((unsigned)nchunks), dim3(64), 0, h->stream, sz.p, n, FXI_PAGE - 8, pages.p, (const int64_t *)nullptr, (int64_t *)nullptr);
-        else hipLaunchKernelGGL((k_fxi_fill<false, false>), dim3((unsigned)nchunks), dim3(64), 0, h->stream, sz.p, n, FXI_PAGE - 8, pages.p, (const int64_t *)nullptr, (int64_t *)nullptr);
-        hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)nsc), dim3(BLOCK), 0, h->stream, pages.p, nchunks, sums.p);
-        hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, sums.p, nsc);
-        hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)nsc), dim3(BLOCK), 0, h->stream, pages.p, nchunks, sums.p, pbase.p);
-        HIPCHK(hipGetLastError());
-        int64_t nleaf = 0;
-        int isbad = 0;
-        HIPCHK(hipMemcpyAsync(&nleaf, pbase.p + nchunks, 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(&isbad, bad.p, 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        if (isbad) return fail(FX_ERANGE, idx ? "an index entry does not fit a b-tree page without overflow: use CREATE INDEX"
-                                              : "a row does not fit a b-tree page without overflow: use the INSERT path");
-        int r2 = first.alloc(h->device, nleaf + 1, h->stream);
-        if (r2) return r2;
-        if (idx) hipLaunchKernelGGL((k_fxi_fill<true, true>), dim3((unsigned)nchunks), dim3(64), 0, h->stream, sz.p, n, FXI_PAGE - 8, (int32_t *)nullptr, pbase.p, first.p);
-        else hipLaunchKernelGGL((k_fxi_fill<false, true>), dim3((unsigned)nchunks), dim3(64), 0, h->stream, sz.p, n, FXI_PAGE - 8, (int32_t *)nullptr, pbase.p, first.p);
-        HIPCHK(hipGetLastError());
-        *nleaf_out = nleaf;
-        return FX_OK;
-    };
-    // the leaves [0, nleaf) of one tree to the file, slab by slab
-    auto leaves_out = [&](bool idx, int64_t nleaf, const int64_t *first, const fxi::PageSeq &seq, int fd, const fxi::FileMap &map, double *t_kern, double *t_copy) -> int {
-        const int64_t S = std::min(nleaf, fxi_slab_pages());
-        int r2 = slab.alloc(h->device, S * FXI_PAGE, h->stream);
-        if (r2) return r2;
-        for (int64_t k0 = 0; k0 < nleaf; k0 += S) {
-            const int64_t k1 = std::min(nleaf, k0 + S);
-            const auto t0 = now();
-            const unsigned grid = (unsigned)std::min<int64_t>((k1 - k0 + 3) / 4, 16384);
-            if (idx) hipLaunchKernelGGL(k_fxi_index_leaves, dim3(grid), dim3(BLOCK), 0, h->stream, c, data, (const int64_t *)h->fxi_order.p, first, nleaf, n, k0, k1, slab.p);
-            else hipLaunchKernelGGL(k_fxi_table_leaves, dim3(grid), dim3(BLOCK), 0, h->stream, c, data, first, k0, k1, slab.p);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(h->stream));
-            const auto t1 = now();
-            if ((r2 = fxi_image_out(h, slab.p, k0, k1, seq, fd, map))) return r2;
-            *t_kern += secs(t0, t1); *t_copy += secs(t1, now());
-        }
-        return FX_OK;
-    };
-    // a tree of ONE leaf lives in its root page
-    auto root_leaf = [&](bool idx, const int64_t *first, int fd, int rootpage) -> int {
-        int r2 = slab.alloc(h->device, FXI_PAGE, h->stream);
-        if (r2) return r2;
-        if (idx) hipLaunchKernelGGL(k_fxi_index_leaves, dim3(1), dim3(BLOCK), 0, h->stream, c, data, (const int64_t *)h->fxi_order.p, first, (int64_t)1, n, (int64_t)0, (int64_t)1, slab.p);
-        else hipLaunchKernelGGL(k_fxi_table_leaves, dim3(1), dim3(BLOCK), 0, h->stream, c, data, first, (int64_t)0, (int64_t)1, slab.p);
-        std::vector<uint8_t> pg(FXI_PAGE);
-        HIPCHK(hipMemcpyAsync(pg.data(), slab.p, FXI_PAGE, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        if (!fxi::pwrite_all(fd, pg.data(), FXI_PAGE, (off_t)(rootpage - 1) * FXI_PAGE)) return fail(FX_EIO, "cannot write %s", path);
-        return FX_OK;
-    };
+    if ((rc = J.init())) return done(rc);
 
     const auto t0 = now();
     fxi::DbFile db;
@@ -4017,51 +4197,22 @@ extern "C" int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int ro
     }
     // ================================================================ shapes: which row on which leaf of the table, which entry on which leaf of the index
     int64_t nleaf_t = 0, nleaf_i = 0;
-    HIPCHK(hipMemsetAsync(bad.p, 0, 4, h->stream));
-    hipLaunchKernelGGL(k_fxi_cell_sizes, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, c, n, sz.p, bad.p);
-    if ((rc = leaf_level(false, first_t, &nleaf_t))) return done(rc);
+    J.table_sizes();
+    if ((rc = J.leaf_level(false, first_t, &nleaf_t))) return done(rc);
     std::vector<int64_t> lf((size_t)nleaf_t + 1);
-    HIPCHK(hipMemcpyAsync(lf.data(), first_t.p, (size_t)(nleaf_t + 1) * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    FXI_CHK(hipMemcpyAsync(lf.data(), first_t.p, (size_t)(nleaf_t + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+    FXI_CHK(hipStreamSynchronize(h->stream));
     const auto t1 = now();
     lap_buf[0] = secs(t0, t1);
-    // the dividers of the index -- (name, rowid) of the entry between leaf d and leaf d + 1 -- for the levels the host writes
     std::vector<int64_t> d_rowid(1), d_off(1, 0);
     std::vector<uint8_t> d_names(1);
     fxi::IndexUpper up;
     int64_t nd = 0;
     if (root_index) {
-        hipLaunchKernelGGL(k_fxi_entry_sizes, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, c, (const int64_t *)h->fxi_order.p, n, sz.p, bad.p);
-        if ((rc = leaf_level(true, first_i, &nleaf_i))) return done(rc);
+        J.index_sizes();
+        if ((rc = J.leaf_level(true, first_i, &nleaf_i))) return done(rc);
         nd = nleaf_i - 1;
-        d_rowid.assign((size_t)std::max<int64_t>(nd, 1), 0);
-        d_off.assign((size_t)nd + 1, 0);
-        if (nd > 0) {
-            ScratchBuf<int64_t> drow, doff, dsum;
-            ScratchBuf<int32_t> dlen;
-            ScratchBuf<uint8_t> dnm;
-            const int64_t ndc = (nd + SCAN_CHUNK - 1) / SCAN_CHUNK;
-            if ((rc = drow.alloc(h->device, nd, h->stream)) || (rc = dlen.alloc(h->device, nd, h->stream)) || (rc = doff.alloc(h->device, nd + 1, h->stream)) ||
-                (rc = dsum.alloc(h->device, ndc + 1, h->stream))) return done(rc);
-            hipLaunchKernelGGL(k_fxi_divider_rows, dim3(nblocks(nd, BLOCK)), dim3(BLOCK), 0, h->stream, c, (const int64_t *)h->fxi_order.p, (const int64_t *)first_i.p, nd, drow.p, dlen.p);
-            hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)ndc), dim3(BLOCK), 0, h->stream, dlen.p, nd, dsum.p);
-            hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, dsum.p, ndc);
-            hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)ndc), dim3(BLOCK), 0, h->stream, dlen.p, nd, dsum.p, doff.p);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(d_off.data(), doff.p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipMemcpyAsync(d_rowid.data(), drow.p, (size_t)nd * 8, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
-            const int64_t tot = d_off[(size_t)nd];
-            d_names.resize((size_t)std::max<int64_t>(tot, 1));
-            if (tot) {
-                if ((rc = dnm.alloc(h->device, tot, h->stream))) return done(rc);
-                hipLaunchKernelGGL(k_fxi_divider_names, dim3(nblocks(nd, BLOCK)), dim3(BLOCK), 0, h->stream, c, data, (const int64_t *)drow.p, (const int64_t *)doff.p, nd, dnm.p);
-                HIPCHK(hipGetLastError());
-                HIPCHK(hipMemcpyAsync(d_names.data(), dnm.p, (size_t)tot, hipMemcpyDeviceToHost, h->stream));
-                HIPCHK(hipStreamSynchronize(h->stream));
-            }
-            for (auto &r : d_rowid) r += 1;                  // row -> rowid
-        }
+        if ((rc = J.dividers(first_i.p, nd, d_rowid, d_off, d_names))) return done(rc);
     }
     const fxi::Entries dv{nd, d_names.data(), d_off.data(), nullptr, nullptr, d_rowid.data()};
     if (root_index && !up.plan((size_t)nleaf_i, dv, FXI_PAGE)) return done(fail(FX_ERANGE, "an index entry does not fit an interior page: use CREATE INDEX"));
@@ -4078,33 +4229,8 @@ extern "C" int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int ro
     fxi::FileMap map;
     uint32_t new_npages = db.npages;
     if (total) {
-        // All new pages are allocated BEFORE anything is stored into them: on tmpfs fallocate alone runs at 16-18 GB/s and
-        // sixteen threads then copy into the mapping at 15 GB/s, while page allocation and faults running side by side
-        // (a fallocate thread ahead of the writers, or first touches through the mapping) reach 3-4 GB/s together
-        // (tools/filewrite_probe2.c: 10 GB in 1.3 s against 2.6-3.8 s).  A file that already has the room (pre-sized by the
-        // caller while the stream was staged) skips this.
         new_npages = seq.at(total - 1);
-        const off_t end = (off_t)new_npages * FXI_PAGE, from = (off_t)db.npages * FXI_PAGE;
-        const bool presized = db.size0 >= end;
-        if (presized || map.open(db.fd, (size_t)end)) {
-            if (presized) { void *m = mmap(nullptr, (size_t)end, PROT_READ | PROT_WRITE, MAP_SHARED, db.fd, 0); if (m != MAP_FAILED) { map.p = (uint8_t *)m; map.len = (size_t)end; } }
-            // (only what a pre-sized file lacks: fallocate over pages that exist still visits every one of them, 0.2 us each)
-            const off_t have = std::max(from, db.size0 & ~(off_t)(FXI_PAGE - 1));
-            if (map.p && !presized && have < end && !getenv("FX_FXI_NO_FALLOCATE")) {
-                // (in a thread on the CPUs next to the device: the pages then lie in the memory its copy threads are next to)
-                cpu_set_t near_cpus;
-                const bool bind = !getenv("FX_FXI_NO_BIND") && device_cpus(h->device, &near_cpus);
-                const int fd_ = db.fd;
-                int fa_errno = 0;
-                std::thread([fd_, have, end, bind, near_cpus, &fa_errno]() {
-                    if (bind) (void)pthread_setaffinity_np(pthread_self(), sizeof near_cpus, &near_cpus);
-                    if (fallocate(fd_, 0, have, end - have) != 0) fa_errno = errno;
-                }).join();
-                // no room after all (a quota, a race with another writer): a store into the mapping would be a SIGBUS where a
-                // pwrite returns an error -- the pages go through pwrite then.  (EOPNOTSUPP and the like: the mapping stays.)
-                if (fa_errno == ENOSPC || fa_errno == EDQUOT || fa_errno == EFBIG) map.close();
-            }
-        }
+        fxi_grow_and_map(db, new_npages, h->device, map);
     }
     const auto t3 = now();
     lap_buf[3] = secs(t2, t3);                               // file grown and allocated
@@ -4116,26 +4242,18 @@ extern "C" int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int ro
         th_t = std::thread([&]() { if (!fxi::table_interior(db.fd, map, FXI_PAGE, FXI_PAGE, (uint32_t)root_table, seq, lf.data(), (size_t)nleaf_t, tot_t)) host_bad.store(1); });
     if (nleaf_i > 1)
         th_i = std::thread([&]() { if (!up.write(db.fd, map, FXI_PAGE, FXI_PAGE, (uint32_t)root_index, seq_i, (size_t)nleaf_i, dv)) host_bad.store(1); });
-    if (nleaf_t == 1) rc = root_leaf(false, first_t.p, db.fd, root_table);
-    else rc = leaves_out(false, nleaf_t, first_t.p, seq, db.fd, map, &lap_buf[1], &lap_buf[2]);
+    if (nleaf_t == 1) rc = J.root_leaf(false, first_t.p, db.fd, root_table, path);
+    else rc = J.leaves_out(false, nleaf_t, first_t.p, seq, 0, db.fd, map, &lap_buf[1], &lap_buf[2]);
     if (!rc && root_index) {
-        if (nleaf_i == 1) rc = root_leaf(true, first_i.p, db.fd, root_index);
-        else rc = leaves_out(true, nleaf_i, first_i.p, seq_i, db.fd, map, &lap_buf[5], &lap_buf[6]);
+        if (nleaf_i == 1) rc = J.root_leaf(true, first_i.p, db.fd, root_index, path);
+        else rc = J.leaves_out(true, nleaf_i, first_i.p, seq_i, 0, db.fd, map, &lap_buf[5], &lap_buf[6]);
     }
     const auto t4 = now();
     if (th_t.joinable()) th_t.join();
     if (th_i.joinable()) th_i.join();
     if (host_bad.load()) ok = false;
     const auto t5 = now();
-    // Taking the mapping down walks every page table entry of it (0.25 s for 10 GB of dirty shared pages) and nothing waits
-    // for the result: the pages are in the file's page cache either way.  It is left to a thread of its own.
-    if (map.p && !getenv("FX_FXI_SYNC_UNMAP")) {
-        uint8_t *mp = map.p;
-        const size_t ml = map.len;
-        map.p = nullptr;
-        std::thread([mp, ml]() { munmap(mp, ml); }).detach();
-    }
-    map.close();
+    fxi_unmap_later(map);
     const auto t6 = now();
     if (trace) fprintf(stderr, "[fxgpu] fxi: host levels joined after %.1f ms, mapping released in %.1f ms\n", secs(t4, t5) * 1e3, secs(t5, t6) * 1e3);
     if (!rc && ok) ok = db.finish(new_npages);
@@ -4148,6 +4266,307 @@ extern "C" int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int ro
                                "table kernels %.1f + copy-out %.1f ms, index kernels %.1f + copy-out %.1f ms, rest of the host levels + header %.1f ms\n",
                        (long long)n, (long long)nleaf_t, (long long)nleaf_i, (unsigned long long)total, lap_buf[0] * 1e3, lap_buf[4] * 1e3, lap_buf[3] * 1e3,
                        lap_buf[1] * 1e3, lap_buf[2] * 1e3, lap_buf[5] * 1e3, lap_buf[6] * 1e3, lap_buf[7] * 1e3);
+    return done(FX_OK);
+#undef FXI_CHK
+}
+
+// ------------------------------------------------------------------ ONE .fxi from SEVERAL handles (round 6)
+// A file that is indexed by byte range -- one process per GPU (shard.ShardedFastq), the devices of one process, or windows
+// of one device that take turns (windows.WindowedFastq) -- has its rows in several handles: part r holds the rows
+// [row_base_r, row_base_r + n_r) of the table, in order.  Round 5 sent every part's table and names to one host and let
+// the host page loader (fx_fxi.hpp) format them: 15 M rows/s against the 220 M rows/s of fx_fxi_dev_write.  Here
+//   * every part formats ITS table leaves where its rows and names are (rowids are global; a part starts a fresh page,
+//     as a fill chunk does) and copies them into its own range of the ONE file: fx_fxi_part_shape -> the caller adds up
+//     the leaf counts (the build's all-gather carries them) -> fx_fxi_part_leaves(first page of the new pages, leaves
+//     of the parts before);
+//   * the index needs all names in one order: every part hands its names -- back to back, with their lengths -- to
+//     device memory of the caller's choosing (fx_fxi_part_names: a buffer the process group gathers on the writing
+//     rank, RCCL over xGMI; windows: one buffer that outlives the windows); the writer sorts them once
+//     (fx_fxi_join_begin), formats the index leaves from that buffer, and writes what the host writes anyway: the
+//     interior levels of both trees -- the table's from the first rows of all parts' leaves (fx_fxi_part_firsts, 8 bytes
+//     per leaf through the process group) -- and the header (fx_fxi_join_write).
+// Why gather + one sort and not a splitter exchange: the keys are the names themselves (3 GB for 10^8 reads), a gather
+// moves them once over seven xGMI links into one device that sorts 10^8 keys in 50 ms; a splitter exchange moves the
+// same bytes all-to-all, needs a second round for the splitters, and leaves eight ranks to write a third of the file
+// (the index leaves) that one PCIe link writes while the other seven are still writing table leaves.
+struct fx_fxi_join {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    const uint8_t *d_names = nullptr;
+    const int32_t *d_lens = nullptr;
+    int64_t n = 0, n_dup = 0;
+    ScratchBuf<int64_t> noff, order;
+};
+
+extern "C" int fx_fxi_part_shape(fx_handle *h, int kind, int64_t row_base, int64_t *out3) {
+    int rc = fxi_check_kind(h, kind);
+    if (rc) return rc;
+    if (!out3 || row_base < 0) return fail(FX_EINVAL, "bad argument");
+    const int64_t n = kind == 0 ? h->n_hdr : h->n_reads;
+    out3[0] = n; out3[1] = 0; out3[2] = 0;
+    h->fxi_part_first.release(); h->fxi_part_nleaf = 0; h->fxi_part_kind = -1;
+    if (n == 0) { h->fxi_part_kind = kind; h->fxi_part_row_base = row_base; return FX_OK; }
+    if (n + row_base >= 0xFFFFFFFFll) return fail(FX_ERANGE, "too many records");
+    FxiJob J;
+    J.device = h->device; J.stream = h->stream; J.data = h->d_data; J.n = n;
+    fxi_cols(h, kind, &J.c);
+    J.c.row_base = row_base;
+    if ((rc = J.init())) return rc;
+    J.table_sizes();
+    int64_t nleaf = 0;
+    if ((rc = J.leaf_level(false, h->fxi_part_first, &nleaf))) return rc;
+    // bytes of the names (what fx_fxi_part_names will write)
+    const int64_t nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    ScratchBuf<int32_t> l32;
+    ScratchBuf<int64_t> l64, sums, off;
+    if ((rc = l32.alloc(h->device, n, h->stream)) || (rc = l64.alloc(h->device, n, h->stream)) || (rc = sums.alloc(h->device, nchunks + 1, h->stream)) ||
+        (rc = off.alloc(h->device, n + 1, h->stream))) return rc;
+    hipLaunchKernelGGL(k_len_clamp, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, J.c.name_len, n, l32.p, l64.p);
+    hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, l32.p, n, sums.p);
+    hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, sums.p, nchunks);
+    hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, l32.p, n, sums.p, off.p);
+    HIPCHK(hipGetLastError());
+    int64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, off.p + n, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->fxi_part_nleaf = nleaf; h->fxi_part_row_base = row_base; h->fxi_part_kind = kind;
+    out3[1] = nleaf; out3[2] = total;
+    return FX_OK;
+}
+
+extern "C" int fx_fxi_part_firsts(fx_handle *h, int64_t *first_rows) {
+    if (!h || h->fxi_part_kind < 0) return fail(FX_ESTATE, "fx_fxi_part_shape has not been called");
+    if (h->fxi_part_nleaf == 0) return FX_OK;
+    if (!first_rows) return fail(FX_EINVAL, "null first_rows");
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(first_rows, h->fxi_part_first.p, (size_t)h->fxi_part_nleaf * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int64_t k = 0; k < h->fxi_part_nleaf; ++k) first_rows[k] += h->fxi_part_row_base;
+    return FX_OK;
+}
+
+extern "C" int fx_fxi_part_names(fx_handle *h, int kind, uint8_t *d_names, int32_t *d_lens) {
+    int rc = fxi_check_kind(h, kind);
+    if (rc) return rc;
+    const int64_t n = kind == 0 ? h->n_hdr : h->n_reads;
+    if (n == 0) return FX_OK;
+    if (!d_names || !d_lens) return fail(FX_EINVAL, "null destination");
+    FxiCols c;
+    fxi_cols(h, kind, &c);
+    const int64_t *noff = c.name_off;
+    if (kind == 0) {
+        if ((rc = h->nm_off.alloc(n))) return rc;
+        hipLaunchKernelGGL(k_add_i64, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, h->hdr.p, (int64_t)1, n, h->nm_off.p);
+        noff = h->nm_off.p;
+    }
+    const int64_t nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    ScratchBuf<int64_t> l64, sums, off;
+    if ((rc = l64.alloc(h->device, n, h->stream)) || (rc = sums.alloc(h->device, nchunks + 1, h->stream)) || (rc = off.alloc(h->device, n + 1, h->stream))) return rc;
+    hipLaunchKernelGGL(k_len_clamp, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, c.name_len, n, d_lens, l64.p);
+    hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, (const int32_t *)d_lens, n, sums.p);
+    hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, h->stream, sums.p, nchunks);
+    hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)nchunks), dim3(BLOCK), 0, h->stream, (const int32_t *)d_lens, n, sums.p, off.p);
+    HIPCHK(hipGetLastError());
+    if ((rc = fetch_common(h, FX_DEVICE, n, false, noff, l64.p, l64.p, nullptr, FX_RAW, nullptr, d_names, off.p, nullptr, 0))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FX_OK;
+}
+
+// laps[2]: leaf kernels, leaves to the file
+extern "C" int fx_fxi_part_leaves(fx_handle *h, int kind, const char *path, int64_t first_new_page, int64_t leaf_base, double *laps) {
+    int rc = fxi_check_kind(h, kind);
+    if (rc) return rc;
+    if (!path || first_new_page < 2) return fail(FX_EINVAL, "bad argument");
+    if (h->fxi_part_kind != kind) return fail(FX_ESTATE, "fx_fxi_part_shape has not been called for this table");
+    double lap_buf[2] = {0, 0};
+    const int64_t n = kind == 0 ? h->n_hdr : h->n_reads, nleaf = h->fxi_part_nleaf;
+    if (n == 0 || nleaf == 0) { if (laps) memcpy(laps, lap_buf, sizeof lap_buf); return FX_OK; }
+    FxiJob J;
+    J.device = h->device; J.stream = h->stream; J.data = h->d_data; J.n = n;
+    fxi_cols(h, kind, &J.c);
+    J.c.row_base = h->fxi_part_row_base;
+    const int fd = open(path, O_RDWR);
+    if (fd < 0) return fail(FX_EIO, "cannot open %s", path);
+    if (leaf_base < 0) {                                     // the table's only leaf: it lives in the root page, number -leaf_base
+        rc = nleaf == 1 ? J.root_leaf(false, h->fxi_part_first.p, fd, (int)-leaf_base, path) : fail(FX_EINVAL, "a root page takes one leaf, this part has %lld", (long long)nleaf);
+        close(fd);
+        return rc;
+    }
+    const fxi::PageSeq seq((uint32_t)first_new_page, FXI_PAGE);
+    if ((uint64_t)seq.at((uint64_t)(leaf_base + nleaf - 1)) >= 0xFFFFFFF0ull) { close(fd); return fail(FX_ERANGE, "the index file would exceed 2^32 pages"); }
+    // the writer has grown the file (fx_fxi_join_grow) or it has not: what of this part's range exists is written through a
+    // mapping, the rest with pwrite (which grows the file by itself; never ftruncate here -- the parts run side by side)
+    fxi::FileMap map;
+    struct stat st;
+    if (!getenv("FX_FXI_NO_MMAP") && fstat(fd, &st) == 0 && st.st_size >= (off_t)seq.at((uint64_t)leaf_base) * FXI_PAGE) {
+        const size_t len = (size_t)std::min<off_t>(st.st_size, (off_t)seq.at((uint64_t)(leaf_base + nleaf - 1)) * FXI_PAGE);
+        void *m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (m != MAP_FAILED) { map.p = (uint8_t *)m; map.len = len; }
+    }
+    rc = J.leaves_out(false, nleaf, h->fxi_part_first.p, seq, leaf_base, fd, map, &lap_buf[0], &lap_buf[1]);
+    fxi_unmap_later(map);
+    close(fd);
+    if (laps) memcpy(laps, lap_buf, sizeof lap_buf);
+    return rc;
+}
+
+// Room for the table's pages before the parts write them (they map what exists): pages [db pages + 1, ... + all of the
+// table's new pages) of `path`; first_new_page <- the page the first part's first leaf goes to.  Best effort, like
+// fx_fxi_presize_begin: parts that find no room use pwrite.
+extern "C" int fx_fxi_join_grow(const char *path, int root_table, int64_t nleaf_table, int device, int64_t *first_new_page) {
+    if (!path || root_table < 2 || nleaf_table < 0 || !first_new_page) return fail(FX_EINVAL, "bad argument");
+    fxi::DbFile db;
+    const int e = db.open_rw(path, (uint32_t)root_table);
+    if (e == fxi::E_IO) return fail(FX_EIO, "cannot open %s", path);
+    if (e || db.pagesize != FXI_PAGE || db.usable != FXI_PAGE) return fail(FX_EINVAL, "%s is not a SQLite database this loader can extend (4 KiB pages, no reserved bytes)", path);
+    *first_new_page = (int64_t)db.npages + 1;
+    const uint64_t tot_t = nleaf_table > 1 ? fxi::table_new_pages((size_t)nleaf_table, fxi::table_fan(FXI_PAGE)) : 0;
+    if (tot_t) {
+        const fxi::PageSeq seq(db.npages + 1, FXI_PAGE);
+        if ((uint64_t)seq.at(tot_t - 1) >= 0xFFFFFFF0ull) return fail(FX_ERANGE, "the index file would exceed 2^32 pages");
+        fxi::FileMap map;
+        fxi_grow_and_map(db, seq.at(tot_t - 1), device, map);
+        fxi_unmap_later(map);
+    }
+    return FX_OK;                                            // (the header still says db.npages: fx_fxi_join_write finishes it)
+}
+
+extern "C" int fx_fxi_join_begin(int device, const uint8_t *d_names, const int32_t *d_lens, int64_t n, fx_fxi_join **out, int64_t *n_dup) {
+    if (!out || !n_dup || n < 0 || (n > 0 && (!d_names || !d_lens))) return fail(FX_EINVAL, "bad argument");
+    *out = nullptr; *n_dup = 0;
+    if (n >= 0xFFFFFFFFll) return fail(FX_ERANGE, "too many records for the 32-bit sort index");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(FX_EDEVICE, "device %d is not available; libfxgpu has no CPU fallback", device);
+    HIPCHK(hipSetDevice(device));
+    std::unique_ptr<fx_fxi_join> j(new fx_fxi_join());
+    j->device = device; j->d_names = d_names; j->d_lens = d_lens; j->n = n;
+    HIPCHK(hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking));
+    auto bail = [&](int code) { (void)hipStreamSynchronize(j->stream); j->noff.release(); j->order.release(); (void)hipStreamDestroy(j->stream); return code; };
+    if (n) {
+        int rc;
+        const int64_t nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        ScratchBuf<int64_t> sums, ndup;
+        if ((rc = j->noff.alloc(device, n + 1, j->stream)) || (rc = j->order.alloc(device, n, j->stream)) || (rc = sums.alloc(device, nchunks + 1, j->stream)) ||
+            (rc = ndup.alloc(device, 1, j->stream))) return bail(rc);
+        hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)nchunks), dim3(BLOCK), 0, j->stream, d_lens, n, sums.p);
+        hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, j->stream, sums.p, nchunks);
+        hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)nchunks), dim3(BLOCK), 0, j->stream, d_lens, n, sums.p, j->noff.p);
+        if (hipGetLastError() != hipSuccess) return bail(fail(FX_EDEVICE, "offsets of the gathered names"));
+        const char *what = "";
+        const int e = sort_names(d_names, 0, j->noff.p, d_lens, n, j->order.p, ndup.p, j->stream, &what);
+        if (e) return bail(fail(e == (int)hipErrorOutOfMemory ? FX_ENOMEM : FX_EDEVICE, "name sort, %s: %s", what, hipGetErrorString((hipError_t)e)));
+        if (hipMemcpyAsync(&j->n_dup, ndup.p, 8, hipMemcpyDeviceToHost, j->stream) != hipSuccess || hipStreamSynchronize(j->stream) != hipSuccess)
+            return bail(fail(FX_EDEVICE, "the name sort failed"));
+    }
+    *n_dup = j->n_dup;
+    *out = j.release();
+    return FX_OK;
+}
+
+extern "C" void fx_fxi_join_end(fx_fxi_join *j) {
+    if (!j) return;
+    (void)hipSetDevice(j->device);
+    (void)hipStreamSynchronize(j->stream);
+    j->noff.release(); j->order.release();
+    (void)hipStreamDestroy(j->stream);
+    delete j;
+}
+
+// The writer's share once the parts' leaves are in the file (or on their way: nothing here touches their pages): the
+// interior levels of the table from first_rows[0 .. nleaf_table) (0-based first row of every leaf, parts in order), the
+// index from the joined names (j; root_index 0 or j null: none -- the caller lets SQLite build it, or not), the header.
+// laps[6]: [0] file grown, [1] index shape + dividers, [2] index leaf kernels, [3] index leaves to the file, [4] host levels + header, [5] table interior
+extern "C" int fx_fxi_join_write(fx_fxi_join *j, const char *path, int root_table, int root_index, int64_t n_rows, int64_t nleaf_table,
+                                 const int64_t *first_rows, int64_t first_new_page, double *laps) {
+    if (!path || root_table < 2 || (root_index != 0 && root_index < 2) || n_rows < 0 || nleaf_table < 0 || (nleaf_table > 0 && !first_rows))
+        return fail(FX_EINVAL, "bad argument");
+    if (root_index && (!j || j->n != n_rows || j->n_dup)) return fail(FX_ESTATE, "the index needs the joined names of all %lld rows, distinct", (long long)n_rows);
+    double lap_buf[6] = {0, 0, 0, 0, 0, 0};
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    auto done = [&](int code) { if (laps) memcpy(laps, lap_buf, sizeof lap_buf); return code; };
+    if (n_rows == 0) return done(FX_OK);
+    fxi::DbFile db;
+    {
+        const int e = db.open_rw(path, (uint32_t)root_table);
+        if (e == fxi::E_IO) return done(fail(FX_EIO, "cannot open %s", path));
+        if (e || db.pagesize != FXI_PAGE || db.usable != FXI_PAGE || (root_index && (uint32_t)root_index > db.npages))
+            return done(fail(FX_EINVAL, "%s is not a SQLite database this loader can extend (4 KiB pages, no reserved bytes)", path));
+    }
+    if ((int64_t)db.npages + 1 != first_new_page) return done(fail(FX_ESTATE, "%s has %u pages, the parts wrote their leaves from page %lld on", path, db.npages, (long long)first_new_page));
+    const auto t0 = now();
+    // ---- the index: shape and dividers
+    FxiJob J;
+    ScratchBuf<int64_t> first_i;
+    int64_t nleaf_i = 0, nd = 0;
+    std::vector<int64_t> d_rowid(1), d_off(1, 0);
+    std::vector<uint8_t> d_names(1);
+    fxi::IndexUpper up;
+    int rc = FX_OK;
+    if (root_index) {
+        HIPCHK(hipSetDevice(j->device));
+        J.device = j->device; J.stream = j->stream; J.data = j->d_names; J.n = n_rows; J.order = j->order.p;
+        memset(&J.c, 0, sizeof J.c);
+        J.c.name_off = j->noff.p; J.c.name_len = j->d_lens;
+        if ((rc = J.init())) return done(rc);
+        J.index_sizes();
+        if ((rc = J.leaf_level(true, first_i, &nleaf_i))) return done(rc);
+        nd = nleaf_i - 1;
+        if ((rc = J.dividers(first_i.p, nd, d_rowid, d_off, d_names))) return done(rc);
+    }
+    const fxi::Entries dv{nd, d_names.data(), d_off.data(), nullptr, nullptr, d_rowid.data()};
+    if (root_index && !up.plan((size_t)nleaf_i, dv, FXI_PAGE)) return done(fail(FX_ERANGE, "an index entry does not fit an interior page: use CREATE INDEX"));
+    const auto t1 = now();
+    lap_buf[1] = secs(t0, t1);
+    // ---- the page sequence: table leaves (the parts'), table interior levels, index leaves, index upper levels
+    const uint64_t tot_t = nleaf_table > 1 ? fxi::table_new_pages((size_t)nleaf_table, fxi::table_fan(FXI_PAGE)) : 0;
+    const uint64_t tot_i = nleaf_i > 1 ? (uint64_t)nleaf_i + up.pages : 0;
+    const uint64_t total = tot_t + tot_i;
+    const fxi::PageSeq seq(db.npages + 1, FXI_PAGE);
+    if (total && (uint64_t)seq.at(total - 1) >= 0xFFFFFFF0ull) return done(fail(FX_ERANGE, "the index file would exceed 2^32 pages"));
+    fxi::FileMap map;
+    uint32_t new_npages = db.npages;
+    if (total) {
+        new_npages = seq.at(total - 1);
+        fxi_grow_and_map(db, new_npages, j ? j->device : 0, map);
+    }
+    const auto t2 = now();
+    lap_buf[0] = secs(t1, t2);
+    const fxi::PageSeq seq_i(total && tot_t ? seq.at(tot_t) : db.npages + 1, FXI_PAGE);
+    std::vector<int64_t> lf((size_t)nleaf_table + 1);
+    if (nleaf_table) memcpy(lf.data(), first_rows, (size_t)nleaf_table * 8);
+    lf[(size_t)nleaf_table] = n_rows;
+    std::atomic<int> host_bad(0);
+    double t_interior = 0;
+    std::thread th_t, th_i;
+    if (nleaf_table > 1)
+        th_t = std::thread([&]() {
+            const auto a = now();
+            if (!fxi::table_interior(db.fd, map, FXI_PAGE, FXI_PAGE, (uint32_t)root_table, seq, lf.data(), (size_t)nleaf_table, tot_t)) host_bad.store(1);
+            t_interior = secs(a, now());
+        });
+    if (nleaf_i > 1)
+        th_i = std::thread([&]() { if (!up.write(db.fd, map, FXI_PAGE, FXI_PAGE, (uint32_t)root_index, seq_i, (size_t)nleaf_i, dv)) host_bad.store(1); });
+    if (root_index) {
+        if (nleaf_i == 1) rc = J.root_leaf(true, first_i.p, db.fd, root_index, path);
+        else rc = J.leaves_out(true, nleaf_i, first_i.p, seq_i, 0, db.fd, map, &lap_buf[2], &lap_buf[3]);
+    }
+    const auto t3 = now();
+    if (th_t.joinable()) th_t.join();
+    if (th_i.joinable()) th_i.join();
+    lap_buf[5] = t_interior;
+    bool ok = !host_bad.load();
+    fxi_unmap_later(map);
+    if (!rc && ok) ok = db.finish(new_npages);
+    if (!rc && ok) {
+        struct stat st;
+        if (fstat(db.fd, &st) == 0 && st.st_size > (off_t)new_npages * FXI_PAGE) ok = ftruncate(db.fd, (off_t)new_npages * FXI_PAGE) == 0;     // a pre-sized file: cut to what was used
+    }
+    if (rc || !ok) db.give_back();
+    lap_buf[4] = secs(t3, now());
+    if (rc) return done(rc);
+    if (!ok) return done(fail(FX_EIO, "cannot write %s", path));
     return done(FX_OK);
 }
 

@@ -8,6 +8,9 @@ written here opens in reference pyfastx and vice versa.
 import os
 import sqlite3
 import struct
+import time
+
+import numpy as np
 
 FASTA_DDL = """
 CREATE TABLE seq (
@@ -267,6 +270,131 @@ def _bulk_table_dev(path, blob, kind, ddl, table, index_sql, index_name, schema_
     return db, laps
 
 
+_KINDS = {1: (None, "read", "CREATE UNIQUE INDEX readidx ON read (name)", "readidx"),
+          0: (None, "seq", "CREATE UNIQUE INDEX chromidx ON seq (chrom)", "chromidx")}
+
+
+class PartsWriter:
+    """ONE index file whose big table is held by SEVERAL handles -- the byte-range shards of a multi-GPU build, the devices
+    of one process, the windows of a stream that does not fit -- with every page formatted on a device (fx_fxi_part_* /
+    fx_fxi_join_*, csrc/fxgpu.hip): each part writes the table leaves of ITS rows into its own page range of the file, the
+    names of all parts meet on the writer's device, are sorted once and become the index leaves there; the host writes
+    the interior levels and the header.  What _bulk_table_dev does for one handle (fastq.c:29-60, 136-171; index.c:178-207,
+    239-251, 363).  The parts are added IN ORDER: add_local(blob) for a handle of this process (its leaves are formatted and
+    written here and now -- the blob may be closed afterwards), add_remote(...) for a part whose rank wrote its own leaves.
+    finish() -> open connection (the caller adds the small tables).  Any FxError: the file is removed and the error
+    re-raised -- FX_ERANGE / FX_EINVAL mean the caller should use the host loaders."""
+
+    def __init__(self, path, kind, device, schema_done=False):
+        import torch
+        self._torch = torch
+        self.path, self.kind, self.device = path, int(kind), int(device)
+        ddl = FASTQ_DDL if self.kind == 1 else FASTA_DDL
+        _, self.table, self.index_sql, self.index_name = _KINDS[self.kind]
+        if os.path.exists(path) and not schema_done:
+            os.remove(path)
+        db = connect(path)
+        if not schema_done:
+            db.executescript(ddl)
+        db.execute(self.index_sql)                            # (dropped again at the end if the names turn out not to be distinct)
+        self.root = dict(db.execute("SELECT name, rootpage FROM sqlite_master").fetchall())
+        self.first_new_page = int(db.execute("PRAGMA page_count").fetchone()[0]) + 1
+        db.commit()
+        db.close()
+        self.rows = self.leaves = 0
+        self._firsts, self._names, self._lens = [], [], []
+        self.laps = {"table_kernels": 0.0, "table_to_file": 0.0}
+        self._slack = False
+
+    def reserve(self, leaves_total):
+        """Room for the table's pages before the parts write them (best effort; fx_fxi_join_grow)."""
+        from . import _lib
+        first = _lib.fxi_join_grow(self.path, self.root[self.table], int(leaves_total), self.device)
+        if first != self.first_new_page:
+            raise RuntimeError("the index file %s changed under its writer" % self.path)
+
+    def dev_buffers(self, n, name_bytes, device=None):
+        t = self._torch
+        d = t.device("cuda", self.device if device is None else int(device))
+        return t.empty(int(name_bytes) + 64, dtype=t.uint8, device=d), t.empty(max(int(n), 1), dtype=t.int32, device=d)
+
+    def add_local(self, blob, device=None):
+        """A part held by a handle of this process: shape, leaves to the file, names to the writer's device."""
+        try:
+            n, nleaf, nb = blob.fxi_part_shape(self.kind, self.rows)
+            if n == 0:
+                return 0
+            lp = blob.fxi_part_leaves(self.kind, self.path, self.first_new_page, self.leaves)
+            for k, v in lp.items():
+                self.laps[k] += v
+            names, lens = self.dev_buffers(n, nb, device)
+            blob.fxi_part_names(self.kind, names.data_ptr(), lens.data_ptr())
+            names[nb:].zero_()
+            self.add_remote(n, nleaf, blob.fxi_part_firsts(nleaf), names[:nb], lens[:n], slack=True)
+            return n
+        except BaseException:
+            self.abort()
+            raise
+
+    def add_remote(self, n, nleaf, firsts, names_dev, lens_dev, slack=False):
+        """A part whose own rank formatted and wrote its leaves (at leaf_base = self.leaves as it was before this call):
+        its first rows (global, 0-based), its names and their lengths as tensors on a device."""
+        if int(n) == 0:
+            return
+        self._firsts.append(np.asarray(firsts, dtype=np.int64))
+        self._slack = bool(slack)                             # (64 zero bytes lie behind names_dev in its own storage)
+        self._names.append(names_dev)
+        self._lens.append(lens_dev)
+        self.rows += int(n)
+        self.leaves += int(nleaf)
+
+    def abort(self):
+        self._names, self._lens = [], []
+        if os.path.exists(self.path):
+            os.remove(self.path)
+
+    def finish(self):
+        from . import _lib
+        t = self._torch
+        try:
+            dev = t.device("cuda", self.device)
+            root_table, root_index = self.root[self.table], self.root[self.index_name]
+            if self.leaves == 1:                              # a table of ONE leaf lives in its root page: the part wrote it as the first new page
+                fd = os.open(self.path, os.O_RDWR)
+                try:
+                    os.pwrite(fd, os.pread(fd, 4096, (self.first_new_page - 1) * 4096), (root_table - 1) * 4096)
+                finally:
+                    os.close(fd)
+            names = lens = None
+            if self.rows:
+                # (the sort reads whole words behind the last name: 64 zero bytes follow it -- a lone part's buffer has them, dev_buffers)
+                pad = t.zeros(64, dtype=t.uint8, device=dev)
+                names = self._names[0] if len(self._names) == 1 and self._names[0].device == dev and self._slack else t.cat([x.to(dev) for x in self._names] + [pad])
+                lens = self._lens[0].to(dev) if len(self._lens) == 1 else t.cat([x.to(dev) for x in self._lens])
+                self._names, self._lens = [], []
+                t.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            j = _lib.FxiJoin(self.device, names.data_ptr() if names is not None else 0, lens.data_ptr() if lens is not None else 0, self.rows)
+            t1 = time.perf_counter()
+            try:
+                firsts = np.concatenate(self._firsts) if self._firsts else np.zeros(0, dtype=np.int64)
+                lp = j.write(self.path, root_table, 0 if j.n_dup else root_index, self.rows, firsts, self.first_new_page)
+            finally:
+                j.close()
+            self.laps.update(lp)
+            self.laps["name_sort"] = t1 - t0
+            self.n_dup = j.n_dup
+            del names, lens
+        except BaseException:
+            self.abort()
+            raise
+        db = connect(self.path)
+        db.execute("PRAGMA synchronous = OFF")
+        if self.n_dup:                                        # CREATE UNIQUE INDEX would have failed, and the reference ignores that (fastq.c:152-156)
+            db.execute("DROP INDEX %s" % self.index_name)
+        return db
+
+
 def _varint_len(v):
     n = 1
     while v > 0x7F and n < 9:
@@ -388,6 +516,8 @@ def presize_fastq(path, input_path, full_name=False, device=-1):
     try:
         return _lib.fxi_presize_begin(path, int(est * 0.985), device)
     except _lib.FxError:
+        if os.path.exists(path):                              # (the build must find no file: it makes its own)
+            os.remove(path)
         return None
 
 

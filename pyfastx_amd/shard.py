@@ -740,6 +740,25 @@ def allgather_pieces(pieces):
     return [p for o in outs for p in o]
 
 
+def write_fastq_index_parts(parts, index_file, device=None):
+    """ONE .fxi from the ShardedFastq objects of ALL ranks of a build, held by one process (logical ranks on one or several
+    devices): the same pages as ShardedFastq.write_index writes over a process group, without one -- every part's leaves are
+    formatted on its own device, the names meet on the first part's.  -> rows written."""
+    from . import fxi
+    parts = sorted(parts, key=lambda p: p.rank)
+    w = fxi.PartsWriter(index_file, 1, parts[0].device if device is None else device)
+    shapes = []
+    for p in parts:
+        w.add_local(p.blob, device=p.device)
+        shapes.append(p.size)
+    db = w.finish()
+    n, size = w.rows, int(sum(shapes))
+    db.execute("INSERT INTO stat VALUES (?,?,?)", (n, size, size * 1.0 / n if n else float("nan")))     # fastq.c:161
+    db.commit()
+    db.close()
+    return n
+
+
 # ------------------------------------------------------------------ FASTQ: one file over several ranks (SURVEY 8e "FASTQ")
 class ShardedFastq:
     """One rank's share of a sharded FASTQ index build (pyfastx_fastq_create_index, fastq.c:8-182, one process per GPU).
@@ -788,63 +807,167 @@ class ShardedFastq:
         self.n_local, self.first_id, self.size = int(self.summary.n_reads), int(self.summary.first_id), int(self.summary.size)
 
     def local_part(self):
-        """This shard's rows (global offsets) and names, as plain arrays."""
+        """This shard's rows (global offsets) and names, as plain arrays (the host loaders' fall-back)."""
         t = self.blob.fastq_table(self.n_local)
         packed, offs = self.blob.names_pack(1, self.n_local, guess=int(np.maximum(t["name_len"], 0).sum()))
         return {"dlen": np.asarray(t["dlen"], np.int64), "rlen": np.asarray(t["rlen"], np.int64), "soff": np.asarray(t["soff"], np.int64),
                 "qoff": np.asarray(t["qoff"], np.int64), "names": np.asarray(packed, np.uint8), "name_off": np.asarray(offs, np.int64),
                 "size": np.array([self.size, self.n_local], np.int64)}
 
-    def write_index(self, index_file, scratch_dir, barrier=None):
-        """ONE .fxi for the whole file.  The tables of a sequencing run are gigabytes (10^8 rows x 40 bytes + the names):
-        they go to rank 0 as RAW ARRAYS through files in scratch_dir (a directory every rank sees: /dev/shm on one node),
-        not pickled through the process group; rank 0 maps them, gets the order of all names from ONE GPU sort
-        (fx_sort_packed_names) and writes the b-trees as pages (fxi.write_fastq_bulk).  barrier: callable that returns when
-        every rank has called it (default: torch.distributed.barrier when world > 1).  -> rows written (rank 0), else None."""
+    def write_index(self, index_file, gather=None, group=None):
+        """ONE .fxi for the whole file, every page of its two big b-trees formatted on a device (fxi.PartsWriter, round 6; round 5
+        sent every rank's table and names to rank 0 through files and let the host page loader format them: 15 M rows/s).
+        Collective over the ranks of the build:
+          1. fx_fxi_part_shape on every rank; ONE all-gather of three integers per rank (rows, table leaves, bytes of names);
+          2. rank 0 creates the database and makes room for the table's pages; an all-gather of three words tells
+             everybody where the new pages begin;
+          3. every rank hands its names to rank 0 (point to point: RCCL over xGMI on GPUs, gloo through the host in tests) --
+             rank 0 sorts while -- every rank formats ITS table leaves and copies them into its page range of the file;
+          4. the first rows of every rank's leaves follow (8 bytes per leaf; their arrival also says the leaves are in
+             the file), rank 0 writes the interior levels, the index and the header.
+        A row that needs an overflow page (FX_ERANGE on any rank): the host loaders instead, the arrays gathered as objects.
+        gather: callable(int64[k]) -> int64[world, k] (default: torch.distributed.all_gather).  -> rows written (rank 0), else None."""
         from . import _lib, fxi
-        import hashlib
-        # the arrays of THIS build in a directory of their own: two builds that share scratch_dir (or the leftovers of one that
-        # crashed) must not read each other's files -- the name is the same on every rank (file, its size and date, world)
-        st = os.stat(self.path)
-        tag = hashlib.blake2b(("%s|%d|%d|%d" % (os.path.abspath(self.path), st.st_size, st.st_mtime_ns, self.world)).encode(), digest_size=8).hexdigest()
-        scratch_dir = os.path.join(scratch_dir, "fxq_" + tag)
-        os.makedirs(scratch_dir, exist_ok=True)
-        part = self.local_part()
-        for k, v in part.items():
-            np.save(os.path.join(scratch_dir, "fq_%s_%d.npy" % (k, self.rank)), v)
-        if barrier is None and self.world > 1:
+        world, rank = self.world, self.rank
+        if world > 1:
+            import torch
             import torch.distributed as dist
-            barrier = dist.barrier
-        if barrier is not None:
-            barrier()
+            nccl = dist.get_backend(group) == "nccl"
+        if gather is None:
+            def gather(v):
+                if world == 1:
+                    return np.asarray(v, dtype=np.int64).reshape(1, -1)
+                t = torch.tensor([int(x) for x in v], dtype=torch.int64, device=("cuda:%d" % self.device) if nccl else "cpu")
+                outs = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(outs, t, group=group)
+                return np.stack([o.cpu().numpy() for o in outs])
+        # ---- 1. shapes
+        bad = 0
+        try:
+            n, nleaf, nb = self.blob.fxi_part_shape(1, self.first_id)
+        except _lib.FxError as e:
+            if e.code not in (_lib.FX_ERANGE, _lib.FX_ENOMEM):
+                raise
+            n, nleaf, nb, bad = self.n_local, 0, 0, 1
+        shapes = np.asarray(gather([n, nleaf, nb, bad, self.size]), dtype=np.int64).reshape(world, 5)
+        n_total, leaves_total = int(shapes[:, 0].sum()), int(shapes[:, 1].sum())
+        if shapes[:, 3].any():
+            return self._write_index_host(index_file, group)
+        # ---- 2. the database; where the new pages begin
+        w = None
+        head = [0, 0, 0]
+        if rank == 0:
+            try:
+                w = fxi.PartsWriter(index_file, 1, self.device)
+                w.reserve(leaves_total)
+                head = [w.first_new_page, w.root["read"], 1]
+            except (_lib.FxError, OSError):
+                w = None
+        head = np.asarray(gather(head), dtype=np.int64).reshape(world, 3)[0]
+        if not head[2]:
+            return self._write_index_host(index_file, group)
+        first_new_page = int(head[0])
+        leaf_base = int(shapes[:rank, 1].sum())               # (a table of one leaf in all: PartsWriter.finish moves it into the root page)
+        # ---- 3. names to rank 0, leaves to the file
+        names = lens = None
+        if n:
+            names = torch.empty(nb + 64, dtype=torch.uint8, device="cuda:%d" % self.device) if world > 1 else None
+            if world == 1:
+                names, lens = w.dev_buffers(n, nb)
+            else:
+                lens = torch.empty(n, dtype=torch.int32, device="cuda:%d" % self.device)
+            self.blob.fxi_part_names(1, names.data_ptr(), lens.data_ptr())
+            names[nb:].zero_()
+        reqs, parts = [], []
+        if world > 1:
+            def ship(t):                                      # what the backend can send: device memory (RCCL) or a host copy (gloo)
+                return t if nccl else t.cpu()
+            if rank == 0:
+                for r in range(1, world):
+                    nr, lr, br = int(shapes[r, 0]), int(shapes[r, 1]), int(shapes[r, 2])
+                    if nr == 0:
+                        parts.append(None)
+                        continue
+                    dev = "cuda:%d" % self.device if nccl else "cpu"
+                    bn = torch.empty(br, dtype=torch.uint8, device=dev, pin_memory=not nccl)
+                    bl = torch.empty(nr, dtype=torch.int32, device=dev, pin_memory=not nccl)
+                    bf = torch.empty(lr, dtype=torch.int64, device=dev, pin_memory=not nccl)
+                    reqs += [dist.irecv(bn, src=r, group=group), dist.irecv(bl, src=r, group=group)]
+                    parts.append((nr, lr, bn, bl, bf))
+            elif n:
+                reqs += [dist.isend(ship(names[:nb]), dst=0, group=group), dist.isend(ship(lens), dst=0, group=group)]
+        err = None
+        try:
+            if n:
+                self.index_laps = self.blob.fxi_part_leaves(1, index_file, first_new_page, leaf_base)
+        except _lib.FxError as e:                             # (said in step 4: nobody may be left waiting)
+            err = e
+        for q in reqs:
+            q.wait()
+        # ---- 4. first rows to rank 0 (their arrival: this rank's leaves are in the file), then the writer's share
+        firsts = self.blob.fxi_part_firsts(nleaf) if (n and err is None) else np.zeros(nleaf, dtype=np.int64)
+        flag = np.asarray(gather([0 if err is None else 1]), dtype=np.int64).reshape(world)
+        if flag.any():
+            if w is not None:
+                w.abort()
+            if err is not None:
+                raise err
+            raise _lib.FxError(_lib.FX_EIO, "another rank could not write its pages of %s" % index_file)
+        out = None
+        if world > 1 and rank != 0 and n:
+            tf = torch.from_numpy(firsts)
+            dist.send(tf.to("cuda:%d" % self.device) if nccl else tf, dst=0, group=group)
+        if rank == 0:
+            if n:
+                w.add_remote(n, nleaf, firsts, names[:nb], lens, slack=True)
+            for r in range(1, world):
+                pr = parts[r - 1] if world > 1 else None
+                if pr is None:
+                    continue
+                nr, lr, bn, bl, bf = pr
+                dist.recv(bf, src=r, group=group)
+                w.add_remote(nr, lr, bf.cpu().numpy(), bn, bl)
+            db = w.finish()
+            size = int(shapes[:, 4].sum())
+            db.execute("INSERT INTO stat VALUES (?,?,?)", (n_total, size, size * 1.0 / n_total if n_total else float("nan")))     # fastq.c:161
+            db.commit()
+            db.close()
+            self.index_laps = dict(getattr(self, "index_laps", {}), **w.laps)
+            out = n_total
+        if world > 1:
+            dist.barrier(group=group)
+        return out
+
+    def _write_index_host(self, index_file, group=None):
+        """The fall-back of write_index (a row that needs an overflow page, no room on a device): every rank's arrays to rank 0
+        as objects through the process group, the host page loader there (fxi.write_fastq_bulk; INSERTs when that declines too)."""
+        from . import _lib, fxi
+        part = self.local_part()
+        parts = [part]
+        if self.world > 1:
+            import torch.distributed as dist
+            parts = [None] * self.world
+            dist.all_gather_object(parts, part, group=group)
         n_total = None
         if self.rank == 0:
-            def col(k):
-                return [np.load(os.path.join(scratch_dir, "fq_%s_%d.npy" % (k, r)), mmap_mode="r") for r in range(self.world)]
-            cols = {k: np.concatenate(col(k)) for k in ("dlen", "rlen", "soff", "qoff")}
-            names = np.concatenate(col("names"))
-            offs_r = col("name_off")
-            shift = np.concatenate([[0], np.cumsum([int(o[-1]) for o in offs_r])]).astype(np.int64)
-            name_off = np.concatenate([np.asarray(o[:-1]) + shift[r] for r, o in enumerate(offs_r)] + [shift[-1:]])
-            sizes = np.stack(col("size"))
-            order, ndup = _lib.sort_packed_names(names, name_off, self.device)
+            cols = {k: np.concatenate([p[k] for p in parts]) for k in ("dlen", "rlen", "soff", "qoff")}
+            names = np.concatenate([p["names"] for p in parts])
+            shift = np.concatenate([[0], np.cumsum([int(p["name_off"][-1]) for p in parts])]).astype(np.int64)
+            name_off = np.concatenate([p["name_off"][:-1] + shift[r] for r, p in enumerate(parts)] + [shift[-1:]])
+            size, n_total = int(sum(int(p["size"][0]) for p in parts)), int(name_off.size - 1)
             if os.path.exists(index_file):
                 os.remove(index_file)
-            db = fxi.write_fastq_bulk(index_file, names, name_off, cols, int(sizes[:, 0].sum()), None if ndup else order)
-            db.commit() if hasattr(db, "commit") else None
-            db.close()
-            n_total = int(sizes[:, 1].sum())
-            if int(name_off[-1]) != names.size or n_total != name_off.size - 1:
-                raise RuntimeError("the parts of the sharded FASTQ index do not fit together (a stale file in %s?)" % scratch_dir)
-            for r in range(self.world):
-                for k in part:
-                    os.remove(os.path.join(scratch_dir, "fq_%s_%d.npy" % (k, r)))
+            order, ndup = _lib.sort_packed_names(names, name_off, self.device)
             try:
-                os.rmdir(scratch_dir)
-            except OSError:
-                pass
-        if barrier is not None:
-            barrier()
+                db = fxi.write_fastq_bulk(index_file, names, name_off, cols, size, None if ndup else order)
+            except _lib.FxError:
+                nm, no = names.tobytes(), name_off.tolist()
+                db = fxi.connect(index_file)
+                fxi.write_fastq(db, [nm[no[i]:no[i + 1]] for i in range(n_total)], cols, size)
+            db.commit()
+            db.close()
+        if self.world > 1:
+            dist.barrier(group=group)
         return n_total
 
     def composition(self, gather=None):

@@ -403,8 +403,24 @@ class WindowedFastq:
         return self.comp
 
     def write_index(self, index_file):
-        """ONE .fxi: the order of all names from one GPU sort, both b-trees as pages (fxi.write_fastq_bulk)."""
+        """ONE .fxi, every page of `read` and `readidx` formatted on a device (fxi.PartsWriter, round 6): range after range --
+        staged again if it has been evicted since the build -- formats the table leaves of its rows and hands over its names;
+        one sort, the index leaves, the host's levels.  FX_ERANGE / FX_EINVAL (a row that needs an overflow page, a database
+        without 4 KiB pages): the host page loader from the merged host arrays, as before."""
         from . import fxi
+        try:
+            w = fxi.PartsWriter(index_file, 1, self.device)
+            for r in range(self.windows):
+                if self.first_id[r + 1] > self.first_id[r]:
+                    w.add_local(self._built(r), device=self.cache.device_of(r))
+            db = w.finish()
+            self.index_laps = dict(w.laps)
+            n = int(self.n_reads)
+            db.execute("INSERT INTO stat VALUES (?,?,?)", (n, int(self.size), self.size * 1.0 / n if n else float("nan")))     # fastq.c:161
+            return db
+        except _lib.FxError as e:
+            if e.code not in (_lib.FX_ERANGE, _lib.FX_EINVAL, _lib.FX_ENOMEM):
+                raise
         order, ndup = _lib.sort_packed_names(self.names, self.name_off, self.device)
         return fxi.write_fastq_bulk(index_file, self.names, self.name_off, self.table, self.size, None if ndup else order)
 

@@ -1,0 +1,191 @@
+"""-m gpu: ONE `.fxi` from SEVERAL handles with every page formatted on a device (fx_fxi_part_* / fx_fxi_join_*, round 6):
+the byte-range shards of a FASTQ file as logical ranks of one process (shard.write_fastq_index_parts), as one process per
+rank over a gloo process group on one GPU (ShardedFastq.write_index: the shape the 8-GPU run has, RCCL in place of gloo),
+and as windows of a stream larger than its HBM budget (windows.WindowedFastq.write_index).  Every file must pass SQLite's
+integrity check and hold, row for row, what the single-device file of the same input holds (itself pinned against the
+host loader and the reference's golden rows in test_gpu_fxi_dev.py); the names come out of `readidx` in order.
+Replaces fastq.c:29-60, 136-171 for a sharded build."""
+import multiprocessing as mp
+import os
+import socket
+import sqlite3
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def fx():
+    import pyfastx_amd
+    from pyfastx_amd import _lib
+    assert _lib.lib().fx_device_count() >= 1
+    return pyfastx_amd
+
+
+def _fastq(n, seed, dup=False):
+    rng = np.random.default_rng(seed)
+    ids = rng.permutation(n).tolist()
+    if dup:
+        ids[n // 2] = ids[3]                                    # one name twice: no UNIQUE INDEX (fastq.c:152-156)
+    return b"".join(b"@SRR8539271.%d len=%d\n%s\n+\n%s\n" % (i + 1, i % 97, b"ACGTNACGTA" * (1 + i % 3), b"IIIIIHHHHH" * (1 + i % 3)) for i in ids)
+
+
+def _db(path):
+    db = sqlite3.connect(path)
+    db.text_factory = bytes
+    return db
+
+
+def _whole(path):
+    db = _db(path)
+    out = {"check": db.execute("PRAGMA integrity_check").fetchall(),
+           "index": sorted(r[0].decode() for r in db.execute("SELECT name FROM sqlite_master WHERE type='index'")),
+           "read": db.execute("SELECT * FROM read ORDER BY ID").fetchall(),
+           "stat": db.execute("SELECT * FROM stat").fetchall()}
+    if out["index"]:
+        out["by_name"] = [r[0] for r in db.execute("SELECT name FROM read INDEXED BY readidx ORDER BY name")]
+    db.close()
+    return out
+
+
+def _single(fx, tmp_path, raw, monkeypatch):
+    p = tmp_path / "single.fq"
+    p.write_bytes(raw)
+    monkeypatch.setenv("FX_FXI_DEV_MIN", "0")
+    fq = fx.Fastq(str(p))
+    assert fq.index_phases is not None
+    return _whole(str(p) + ".fxi")
+
+
+def _logical_ranks(path, world):
+    from pyfastx_amd import _lib, shard
+    size, _ = _lib.stream_size(path)
+    cores = []
+    for r in range(world):
+        lo, hi = size * r // world, size * (r + 1) // world
+        b = _lib.Blob.from_file_range(path, lo, hi - lo, 0)
+        cores.append(b.fastq_scan())
+        b.close()
+    table = np.array(cores, dtype=np.int64)
+    return [shard.ShardedFastq(path, r, world, gather=lambda mine, t=table: t) for r in range(world)]
+
+
+@pytest.mark.parametrize("world,n", [(2, 150_000), (3, 150_000), (3, 5), (7, 40), (4, 3000)])
+def test_logical_ranks_write_the_single_device_rows(fx, tmp_path, monkeypatch, world, n):
+    """n = 5 / 40: one leaf in all (it lives in the root page) and ranks without a read; 3000: a few leaves per rank."""
+    from pyfastx_amd import shard
+    raw = _fastq(n, world)
+    want = _single(fx, tmp_path, raw, monkeypatch)
+    p = tmp_path / "parts.fq"
+    p.write_bytes(raw)
+    ranks = _logical_ranks(str(p), world)
+    assert sum(r.n_local for r in ranks) == n
+    out = str(p) + ".fxi"
+    assert shard.write_fastq_index_parts(ranks[::-1], out) == n          # (any order of the list: the parts are taken by rank)
+    got = _whole(out)
+    assert got["check"] == [(b"ok",)] and got["index"] == ["readidx"]
+    assert got["read"] == want["read"] and got["stat"] == want["stat"]
+    assert got["by_name"] == sorted(r[1] for r in got["read"]) == want["by_name"]
+    db = _db(out)
+    for j in np.random.default_rng(1).integers(0, n, 20).tolist():
+        name = got["read"][j][1].decode()
+        assert db.execute("SELECT ID FROM read WHERE name=?", (name,)).fetchone()[0] == j + 1
+        assert b"readidx" in db.execute("EXPLAIN QUERY PLAN SELECT ID FROM read WHERE name=?", (name,)).fetchall()[0][-1]
+    db.close()
+    # the index file serves the object API like any other
+    fq = fx.Fastq(str(p))
+    assert len(fq) == n and fq[n // 2].name == got["read"][n // 2][1].decode()
+    for r in ranks:
+        r.blob.close()
+
+
+def test_duplicate_names_leave_no_index(fx, tmp_path, monkeypatch):
+    from pyfastx_amd import shard
+    raw = _fastq(20_000, 9, dup=True)
+    want = _single(fx, tmp_path, raw, monkeypatch)
+    assert want["index"] == []
+    p = tmp_path / "dup.fq"
+    p.write_bytes(raw)
+    ranks = _logical_ranks(str(p), 3)
+    shard.write_fastq_index_parts(ranks, str(p) + ".fxi")
+    got = _whole(str(p) + ".fxi")
+    assert got["check"] == [(b"ok",)] and got["index"] == [] and got["read"] == want["read"] and got["stat"] == want["stat"]
+
+
+def test_a_row_that_needs_an_overflow_page_is_refused(fx, tmp_path):
+    """A name of 5 000 bytes does not fit a leaf: FX_ERANGE, nothing left on disk (the callers then use the host loaders)."""
+    from pyfastx_amd import _lib, shard
+    raw = b"@a\nACGT\n+\nIIII\n@" + b"n" * 5000 + b"\nACGT\n+\nIIII\n" + _fastq(3000, 2)
+    p = tmp_path / "long.fq"
+    p.write_bytes(raw)
+    ranks = _logical_ranks(str(p), 2)
+    with pytest.raises(_lib.FxError) as e:
+        shard.write_fastq_index_parts(ranks, str(p) + ".fxi")
+    assert e.value.code == _lib.FX_ERANGE and not os.path.exists(str(p) + ".fxi")
+
+
+def test_windows_of_a_stream_larger_than_its_budget(fx, tmp_path, monkeypatch):
+    raw = _fastq(400_000, 4)
+    want = _single(fx, tmp_path, raw, monkeypatch)
+    p = tmp_path / "win.fq"
+    p.write_bytes(raw)
+    monkeypatch.setenv("FX_HBM_BUDGET", "16M")
+    fq = fx.Fastq(str(p))
+    wq = fq._st.md
+    assert wq is not None and wq.windows >= 4 and "index_kernels" in getattr(wq, "index_laps", {})      # in windows, pages from the device
+    got = _whole(str(p) + ".fxi")
+    assert got["check"] == [(b"ok",)] and got["index"] == ["readidx"]
+    assert got["read"] == want["read"] and got["stat"] == want["stat"] and got["by_name"] == want["by_name"]
+    assert fq[123_456].seq == fx.Fastq(str(tmp_path / "single.fq"))[123_456].seq
+
+
+# ---------------------------------------------------------------------------------- one process per rank, gloo, one GPU
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, path, out, q):
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from pyfastx_amd import shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sq = shard.ShardedFastq(path, rank, world, device=0)
+        n = sq.write_index(out)
+        q.put((rank, n, sq.n_local, getattr(sq, "index_laps", None)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 120_000), (3, 120_000), (4, 7)])
+def test_one_process_per_rank_over_gloo(fx, tmp_path, monkeypatch, world, n):
+    raw = _fastq(n, 10 + world)
+    want = _single(fx, tmp_path, raw, monkeypatch)
+    p = tmp_path / "ranks.fq"
+    p.write_bytes(raw)
+    out = str(p) + ".fxi"
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, str(p), out, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted(q.get() for _ in range(world))
+    for pr in procs:
+        pr.join(120)
+        assert pr.exitcode == 0
+    assert res[0][1] == n and all(r[1] is None for r in res[1:]) and sum(r[2] for r in res) == n
+    got = _whole(out)
+    assert got["check"] == [(b"ok",)] and got["index"] == ["readidx"]
+    assert got["read"] == want["read"] and got["stat"] == want["stat"] and got["by_name"] == want["by_name"]

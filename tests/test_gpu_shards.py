@@ -410,9 +410,10 @@ def _logical_ranks(path, world, halo=None):
 def test_sharded_fastq_with_a_read_of_a_megabyte(oracle, L, tmp_path, world):
     """shard.ShardedFastq on a FILE: a halo too small for a record of the shard is no error any more (round 2: FX_ERANGE) --
     the range is opened again with a larger one.  One read of 1 MiB among ordinary ones, placed so that it begins just in
-    front of a cut; the rows of all ranks, concatenated, are the oracle's; ONE .fxi is written from raw arrays passed
-    through files (no pickle), its name index from one GPU sort of all ranks' names."""
+    front of a cut; the rows of all ranks, concatenated, are the oracle's; ONE .fxi is written with every rank's
+    table leaves formatted from its own handle and the name index from one GPU sort of all ranks' names."""
     import sqlite3
+    from pyfastx_amd import shard
     rng = np.random.default_rng(world)
     big = bytes(rng.choice(list(b"ACGT"), 1 << 20).astype(np.uint8))
     head = _rand_fastq(rng, 400)
@@ -441,11 +442,8 @@ def test_sharded_fastq_with_a_read_of_a_megabyte(oracle, L, tmp_path, world):
         got = np.concatenate([r.blob.fastq_table(r.n_local)[k] for r in ranks])
         np.testing.assert_array_equal(got, recs[k].astype(got.dtype), err_msg=k)
     fxi_path = str(tmp_path / "big.fq.fxi")
-    scratch = tmp_path / "scratch"
-    scratch.mkdir()
-    for r in ranks[1:] + ranks[:1]:                               # rank 0 last: the others' arrays are there by then
-        n = r.write_index(fxi_path, str(scratch), barrier=lambda: None)
-    assert n == len(recs) and not list(scratch.iterdir())
+    n = shard.write_fastq_index_parts(ranks, fxi_path)             # every rank's leaves from its own handle, one sort of all names (round 6)
+    assert n == len(recs)
     db = sqlite3.connect(fxi_path)
     assert db.execute("PRAGMA integrity_check").fetchone()[0] == "ok"
     rows = db.execute("SELECT name, dlen, rlen, soff, qoff FROM read ORDER BY ID").fetchall()

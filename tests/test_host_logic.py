@@ -1641,3 +1641,27 @@ def test_bench_stdout_carries_the_json_line_only():
         assert 0 < r["frac"] <= 1
     finally:
         sys.path.remove(root)
+
+
+def test_large_idle_blocks_policy():
+    """ScratchPool's rule for the blobs of closed streams (fx_scratch_policy, csrc/fxgpu.hip): a block
+    stays if it fits under the cap beside the others; the smallest go first to make room; a newcomer smaller than everything
+    that would have to go is the one that goes; nothing stays with a cap of 0."""
+    import ctypes as C
+    from pyfastx_amd import _lib
+    L = _lib.lib()
+    G = 1 << 30
+
+    def ask(idle, cap, keep):
+        a = (C.c_int64 * max(len(idle), 1))(*idle)
+        ev = (C.c_int32 * max(len(idle), 1))()
+        r = L.fx_scratch_policy(a, len(idle), cap, keep, ev)
+        return r, [int(ev[i]) for i in range(len(idle))]
+    assert ask([], 35 * G, 144 * G) == (1, [])                                  # the first large blob of a process is kept
+    assert ask([35 * G], 40 * G, 144 * G) == (1, [0])                           # open / close / open of two 35 GB-class sizes: both stay, no hipFree at all
+    assert ask([35 * G, 40 * G, 45 * G], 50 * G, 144 * G) == (1, [1, 0, 0])     # over the cap: the smallest goes
+    assert ask([35 * G, 40 * G, 60 * G], 30 * G, 144 * G) == (0, [0, 0, 0])     # the newcomer is the smallest: it goes
+    assert ask([20 * G, 25 * G, 90 * G], 100 * G, 144 * G) == (1, [1, 1, 1])    # every idle block is smaller than the newcomer and all must go: they go
+    assert ask([20 * G, 25 * G, 120 * G], 100 * G, 144 * G) == (0, [0, 0, 0])   # the 120 GB block would have to go as well, and it is larger: the newcomer goes
+    assert ask([35 * G], 35 * G, 0) == (0, [0])                                 # FX_SCRATCH_KEEP_BIG_MB=0: nothing idles
+    assert ask([35 * G], 200 * G, 144 * G) == (0, [0])                          # larger than the cap itself

@@ -33,19 +33,25 @@ print(json.dumps([o.get('k_bgzf_decode') for o in out]), json.dumps(out[-1]))
 
 
 def main():
-    import torch
-    from pyfastx_amd import synth
     gbp = float(sys.argv[1])
     libs = sys.argv[2:]
-    dev = torch.device("cuda", 0)
-    plan = synth.fasta_plan(total_bp=int(gbp * 1e9))
-    blob, _, _ = synth.fasta_generate(plan, dev, keep_flat=False)
-    host = blob[:int(plan["n_bytes"])].cpu().numpy()
-    del blob
-    d = tempfile.mkdtemp(prefix="fxprobe")
-    path = os.path.join(d, "c4.fa.gz")
-    with open(path, "wb") as f:
-        f.write(synth.bgzf_compress_parallel(host))
+    keep = os.environ.get("FX_PROBE_FILE")                 # generate once, reuse across profiler passes
+    if keep and os.path.exists(keep):
+        path, d = keep, None
+    else:
+        import torch
+        from pyfastx_amd import synth
+        dev = torch.device("cuda", 0)
+        plan = synth.fasta_plan(total_bp=int(gbp * 1e9))
+        blob, _, _ = synth.fasta_generate(plan, dev, keep_flat=False)
+        host = blob[:int(plan["n_bytes"])].cpu().numpy()
+        del blob
+        torch.cuda.empty_cache()
+        d = None if keep else tempfile.mkdtemp(prefix="fxprobe")
+        path = keep or os.path.join(d, "c4.fa.gz")
+        with open(path, "wb") as f:
+            f.write(synth.bgzf_compress_parallel(host))
+        del host
     if not libs:                                            # in this process (what a profiler attached to it sees)
         from pyfastx_amd import _lib
         _lib.lib().fx_prof_default(1)
@@ -54,11 +60,17 @@ def main():
             print("in-process", json.dumps({k: round(v[0] / v[1], 3) for k, v in b.prof_read().items()}), flush=True)
             b.close()
     for lib in libs:
-        env = dict(os.environ, FX_LIBFXGPU=os.path.join(ROOT, lib))
+        env = dict(os.environ)
+        name = lib
+        if "@" in lib:                                      # lib.so@KEY=VAL,KEY=VAL: the same library under other settings
+            lib, kv = lib.split("@", 1)
+            env.update(dict(x.split("=", 1) for x in kv.split(",") if x))
+        env["FX_LIBFXGPU"] = os.path.join(ROOT, lib)
         r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, path, path)], env=env, capture_output=True, text=True)
-        print(lib, r.stdout.strip() or r.stderr[-500:], flush=True)
-    os.unlink(path)
-    os.rmdir(d)
+        print(name, r.stdout.strip() or r.stderr[-500:], flush=True)
+    if d:
+        os.unlink(path)
+        os.rmdir(d)
 
 
 if __name__ == "__main__":
