@@ -1354,7 +1354,7 @@ def fastq_strong_leg(a, dev, rank, world, backend, collective):
         _lib.Blob.from_file_range(path, nb * rank // world, min(1 << 20, nb // world), 0, device=dev.index).close()
         barrier()
         t0 = time.perf_counter()
-        sq = shard.ShardedFastq(path, rank, world, device=dev.index, gather=(lambda m: allgather_i64(m)))     # stage + scan + all-gather + rows
+        sq = shard.ShardedFastq(path, rank, world, device=dev.index, gather=(lambda m: allgather_i64(m)), index_file=path + ".fxi")     # stage + scan + all-gather + rows (rank 0: room for the .fxi set aside meanwhile)
         t_build = time.perf_counter() - t0
         barrier()
         t0 = time.perf_counter()
@@ -1399,6 +1399,7 @@ def fastq_strong_leg(a, dev, rank, world, backend, collective):
         return {"workload": "ONE %d x 150 bp FASTQ file (%.2f GB) over %d ranks by byte range: build (stage + scan + one all-gather of 2 words + rows), "
                             "composition (one all-gather of 10 words), ONE .fxi, %d random reads routed to the ranks that own them" % (n, nb / 1e9, world, nq),
                 "build_s": round(tb, 4), "composition_s": round(tc, 4), "fxi_written_s": round(tf, 3), "fetch_routed_s": round(tq, 4),
+                "fxi_steps_rank0_s": getattr(sq, "index_steps", None), "fxi_laps_rank0_s": {k: round(v, 4) for k, v in getattr(sq, "index_laps", {}).items()},
                 "reads_indexed": int(n_total) if n_total is not None else int(first[-1]), "halo_reopened": int(sq.reopened),
                 "rows_base_meta_fetch_equal_generator": ok, "M_reads_per_s_build": round(n / max(tb, 1e-9) / 1e6, 1)}
     finally:

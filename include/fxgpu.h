@@ -513,8 +513,9 @@ int fx_fxi_presize_end(void *token, int cancel);
  *   every part   fx_fxi_part_shape(h, kind, row_base, out3): out3 = rows, table leaves, bytes of names.  The caller adds up
  *                the leaves over the parts (they travel with the build's all-gather).
  *   writer       creates the database (schema + the empty UNIQUE INDEX), no open connection; fx_fxi_join_grow(path,
- *                root_table, all parts' leaves, device, &first_new_page) makes room for the table's pages (best effort)
- *                and says where the new pages begin -- every part needs that number.
+ *                root_table, all parts' leaves, extra_bytes, device, &first_new_page) makes room for the table's pages and
+ *                extra_bytes behind them (an estimate of the index; best effort) and says where the new pages begin --
+ *                every part needs that number.
  *   every part   fx_fxi_part_leaves(h, kind, path, first_new_page, leaves of the parts before this one, laps2): kernels +
  *                copy-out into the file (laps2: seconds in the kernels, in the copies).  The parts may run at the same
  *                time, from different processes.  A table with ONE leaf in all: leaf_base = -root_table (it lives in
@@ -536,7 +537,7 @@ int fx_fxi_part_shape(fx_handle *h, int kind, int64_t row_base, int64_t *out3);
 int fx_fxi_part_firsts(fx_handle *h, int64_t *first_rows);
 int fx_fxi_part_names(fx_handle *h, int kind, uint8_t *d_names, int32_t *d_lens);
 int fx_fxi_part_leaves(fx_handle *h, int kind, const char *path, int64_t first_new_page, int64_t leaf_base, double *laps);
-int fx_fxi_join_grow(const char *path, int root_table, int64_t nleaf_table, int device, int64_t *first_new_page);
+int fx_fxi_join_grow(const char *path, int root_table, int64_t nleaf_table, int64_t extra_bytes, int device, int64_t *first_new_page);
 int fx_fxi_join_begin(int device, const uint8_t *d_names, const int32_t *d_lens, int64_t n, fx_fxi_join **out, int64_t *n_dup);
 int fx_fxi_join_write(fx_fxi_join *j, const char *path, int root_table, int root_index, int64_t n_rows, int64_t nleaf_table,
                       const int64_t *first_rows, int64_t first_new_page, double *laps);

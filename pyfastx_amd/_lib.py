@@ -81,10 +81,10 @@ def fxi_presize_begin(path, nbytes, device=-1):
     return tok
 
 
-def fxi_join_grow(path, root_table, nleaf_table, device):
-    """Room for the table's new pages (best effort) -> the page number the parts' leaves begin at."""
+def fxi_join_grow(path, root_table, nleaf_table, device, extra_bytes=0):
+    """Room for the table's new pages and extra_bytes behind them (best effort) -> the page number the parts' leaves begin at."""
     first = C.c_int64(0)
-    check(lib().fx_fxi_join_grow(os.fsencode(path), int(root_table), int(nleaf_table), int(device), C.byref(first)))
+    check(lib().fx_fxi_join_grow(os.fsencode(path), int(root_table), int(nleaf_table), int(extra_bytes), int(device), C.byref(first)))
     return int(first.value)
 
 
@@ -250,7 +250,7 @@ def lib():
     L.fx_fxi_part_firsts.argtypes = [vp, vp]
     L.fx_fxi_part_names.argtypes = [vp, i32, vp, vp]
     L.fx_fxi_part_leaves.argtypes = [vp, i32, C.c_char_p, i64, i64, C.POINTER(C.c_double)]
-    L.fx_fxi_join_grow.argtypes = [C.c_char_p, i32, i64, i32, C.POINTER(C.c_int64)]
+    L.fx_fxi_join_grow.argtypes = [C.c_char_p, i32, i64, i64, i32, C.POINTER(C.c_int64)]
     L.fx_fxi_join_begin.argtypes = [i32, vp, vp, i64, C.POINTER(vp), C.POINTER(C.c_int64)]
     L.fx_fxi_join_write.argtypes = [vp, C.c_char_p, i32, i32, i64, i64, vp, i64, C.POINTER(C.c_double)]
     L.fx_fxi_join_end.argtypes = [vp]

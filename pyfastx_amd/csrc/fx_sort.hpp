@@ -7,14 +7,18 @@ namespace fx {
 
 // hipMalloc that empties the library's idle scratch pool and tries again when memory is short (fxgpu.hip)
 hipError_t pool_malloc(void **p, size_t bytes);
+// a block of the library's scratch pool (fxgpu.hip: ScratchPool) / back into it
+void *scratch_get(int device, size_t bytes, size_t *cap);
+void scratch_put(int device, void *p, size_t cap);
 
 // Sorted order of n names that live in the resident stream (name i = name_len[i] bytes at data + name_off[i] - gbase)
 // in SQLite's BINARY collation: memcmp over the common length, the shorter name first on a tie.  d_order[i] (device,
 // int64) = 0-based index of the i-th smallest name, equal names in index order; *d_ndup (device) = number of
-// adjacent equal pairs in that order (0 <=> all names distinct).  Enqueued on `s`; returns a hipError_t.
-// *where names the failing step.
+// adjacent equal pairs in that order (0 <=> all names distinct).  d_soff / d_slen (device, n each; both or neither): the
+// offset and the length of the i-th smallest name -- name_off / name_len through the order, so that what formats the index
+// from it gathers nothing but the names.  Enqueued on `s`; returns a hipError_t.  *where names the failing step.
 int sort_names(const uint8_t *data, int64_t gbase, const int64_t *name_off, const int32_t *name_len, int64_t n,
-               int64_t *d_order, int64_t *d_ndup, hipStream_t s, const char **where);
+               int64_t *d_order, int64_t *d_ndup, hipStream_t s, const char **where, int64_t *d_soff = nullptr, int32_t *d_slen = nullptr);
 
 // Statistics of the record lengths (fasta.c:573-849: count(n), nl(p), longest, shortest, mean, median --
 // the reference asks SQLite to sort / scan the seq table for each of them): ONE stable radix sort of (slen, id) on the

@@ -266,6 +266,10 @@ struct ScratchPool {
 };
 static ScratchPool g_scratch;
 static void scratch_trim() { g_scratch.trim(); }
+namespace fx {                                              // (fx_sort.hip takes its buffers from the pool)
+void *scratch_get(int device, size_t bytes, size_t *cap) { return g_scratch.get(device, bytes, cap); }
+void scratch_put(int device, void *p, size_t cap) { g_scratch.put(device, p, cap); }
+}
 extern "C" int fx_release_scratch(void) { g_scratch.trim(); return FX_OK; }
 template <class T> struct ScratchBuf {                      // device array out of the pool; returned to it when it goes out of scope
     T *p = nullptr;
@@ -433,6 +437,8 @@ struct fx_handle {
     int kq_code = 0;
     // the sorted order of the record names, kept between fx_fxi_dev_sort and fx_fxi_dev_write (fx_fxi_dev.hpp)
     ScratchBuf<int64_t> fxi_order;           // (a block of the scratch pool: 0.8 GB for 10^8 reads; hipFree of it would wait for the device)
+    ScratchBuf<int64_t> fxi_soff;            // offset and length of the i-th smallest name (sort_names: what the index kernels read instead of three gathers)
+    ScratchBuf<int32_t> fxi_slen;
     int fxi_order_kind = -1;
     int64_t fxi_order_n = 0;
     // this handle's part of a table that several handles write (fx_fxi_part_*): first row of each of its leaves
@@ -518,6 +524,7 @@ extern "C" int fx_close(fx_handle *h) {
     }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->fxi_order.release();                                  // (back to the pool while the stream it names still exists)
+    h->fxi_soff.release(); h->fxi_slen.release();
     h->fxi_part_first.release();
     free_blob(h);
     if (h->pin_tot) (void)hipHostFree(h->pin_tot);
@@ -4147,11 +4154,11 @@ extern "C" int fx_fxi_dev_sort(fx_handle *h, int kind, int64_t *n_dup) {
         hipLaunchKernelGGL(k_add_i64, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, h->stream, h->hdr.p, (int64_t)1, n, h->nm_off.p);
         noff = h->nm_off.p;
     }
-    if ((rc = h->fxi_order.alloc(h->device, n, h->stream))) return rc;
+    if ((rc = h->fxi_order.alloc(h->device, n, h->stream)) || (rc = h->fxi_soff.alloc(h->device, n, h->stream)) || (rc = h->fxi_slen.alloc(h->device, n, h->stream))) return rc;
     DevBuf<int64_t> d_ndup;
     if ((rc = d_ndup.alloc(1))) return rc;
     const char *what = "";
-    const int e = sort_names(h->d_data, h->base, noff, c.name_len, n, h->fxi_order.p, d_ndup.p, h->stream, &what);
+    const int e = sort_names(h->d_data, h->base, noff, c.name_len, n, h->fxi_order.p, d_ndup.p, h->stream, &what, h->fxi_soff.p, h->fxi_slen.p);
     if (e) return fail(e == (int)hipErrorOutOfMemory ? FX_ENOMEM : FX_EDEVICE, "name sort, %s: %s", what, hipGetErrorString((hipError_t)e));
     HIPCHK(hipMemcpyAsync(n_dup, d_ndup.p, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -4176,10 +4183,11 @@ extern "C" int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int ro
     FxiJob J;
     J.device = h->device; J.stream = h->stream; J.data = h->d_data; J.n = n; J.order = h->fxi_order.p;
     fxi_cols(h, kind, &J.c);
+    J.c.s_off = h->fxi_soff.p; J.c.s_len = h->fxi_slen.p;   // (offsets as the sort saw them: the FASTA '+ 1' is in them)
     ScratchBuf<int64_t> first_t, first_i;
     auto done = [&](int code) {                               // every way out: the order goes back to the pool, the laps to the caller
         (void)hipStreamSynchronize(h->stream);
-        h->fxi_order.release(); h->fxi_order_kind = -1;
+        h->fxi_order.release(); h->fxi_soff.release(); h->fxi_slen.release(); h->fxi_order_kind = -1;
         if (laps) memcpy(laps, lap_buf, sizeof lap_buf);
         return code;
     };
@@ -4295,7 +4303,8 @@ struct fx_fxi_join {
     const uint8_t *d_names = nullptr;
     const int32_t *d_lens = nullptr;
     int64_t n = 0, n_dup = 0;
-    ScratchBuf<int64_t> noff, order;
+    ScratchBuf<int64_t> noff, order, soff;
+    ScratchBuf<int32_t> slen;
 };
 
 extern "C" int fx_fxi_part_shape(fx_handle *h, int kind, int64_t row_base, int64_t *out3) {
@@ -4412,10 +4421,11 @@ extern "C" int fx_fxi_part_leaves(fx_handle *h, int kind, const char *path, int6
 }
 
 // Room for the table's pages before the parts write them (they map what exists): pages [db pages + 1, ... + all of the
-// table's new pages) of `path`; first_new_page <- the page the first part's first leaf goes to.  Best effort, like
+// table's new pages) of `path` and extra_bytes behind them (the index to come); first_new_page <- the page the first
+// part's first leaf goes to.  Best effort, like
 // fx_fxi_presize_begin: parts that find no room use pwrite.
-extern "C" int fx_fxi_join_grow(const char *path, int root_table, int64_t nleaf_table, int device, int64_t *first_new_page) {
-    if (!path || root_table < 2 || nleaf_table < 0 || !first_new_page) return fail(FX_EINVAL, "bad argument");
+extern "C" int fx_fxi_join_grow(const char *path, int root_table, int64_t nleaf_table, int64_t extra_bytes, int device, int64_t *first_new_page) {
+    if (!path || root_table < 2 || nleaf_table < 0 || extra_bytes < 0 || !first_new_page) return fail(FX_EINVAL, "bad argument");
     fxi::DbFile db;
     const int e = db.open_rw(path, (uint32_t)root_table);
     if (e == fxi::E_IO) return fail(FX_EIO, "cannot open %s", path);
@@ -4424,9 +4434,10 @@ extern "C" int fx_fxi_join_grow(const char *path, int root_table, int64_t nleaf_
     const uint64_t tot_t = nleaf_table > 1 ? fxi::table_new_pages((size_t)nleaf_table, fxi::table_fan(FXI_PAGE)) : 0;
     if (tot_t) {
         const fxi::PageSeq seq(db.npages + 1, FXI_PAGE);
-        if ((uint64_t)seq.at(tot_t - 1) >= 0xFFFFFFF0ull) return fail(FX_ERANGE, "the index file would exceed 2^32 pages");
+        const uint64_t more = (uint64_t)(extra_bytes / FXI_PAGE);          // room for the index as well (an estimate: fx_fxi_join_write allocates what is missing, cuts what is left over)
+        if ((uint64_t)seq.at(tot_t - 1) + more >= 0xFFFFFFF0ull) return fail(FX_ERANGE, "the index file would exceed 2^32 pages");
         fxi::FileMap map;
-        fxi_grow_and_map(db, seq.at(tot_t - 1), device, map);
+        fxi_grow_and_map(db, seq.at(tot_t - 1) + (uint32_t)more, device, map);
         fxi_unmap_later(map);
     }
     return FX_OK;                                            // (the header still says db.npages: fx_fxi_join_write finishes it)
@@ -4442,19 +4453,19 @@ extern "C" int fx_fxi_join_begin(int device, const uint8_t *d_names, const int32
     std::unique_ptr<fx_fxi_join> j(new fx_fxi_join());
     j->device = device; j->d_names = d_names; j->d_lens = d_lens; j->n = n;
     HIPCHK(hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking));
-    auto bail = [&](int code) { (void)hipStreamSynchronize(j->stream); j->noff.release(); j->order.release(); (void)hipStreamDestroy(j->stream); return code; };
+    auto bail = [&](int code) { (void)hipStreamSynchronize(j->stream); j->noff.release(); j->order.release(); j->soff.release(); j->slen.release(); (void)hipStreamDestroy(j->stream); return code; };
     if (n) {
         int rc;
         const int64_t nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
         ScratchBuf<int64_t> sums, ndup;
-        if ((rc = j->noff.alloc(device, n + 1, j->stream)) || (rc = j->order.alloc(device, n, j->stream)) || (rc = sums.alloc(device, nchunks + 1, j->stream)) ||
-            (rc = ndup.alloc(device, 1, j->stream))) return bail(rc);
+        if ((rc = j->noff.alloc(device, n + 1, j->stream)) || (rc = j->order.alloc(device, n, j->stream)) || (rc = j->soff.alloc(device, n, j->stream)) ||
+            (rc = j->slen.alloc(device, n, j->stream)) || (rc = sums.alloc(device, nchunks + 1, j->stream)) || (rc = ndup.alloc(device, 1, j->stream))) return bail(rc);
         hipLaunchKernelGGL(k_cnt_chunk_sums, dim3((unsigned)nchunks), dim3(BLOCK), 0, j->stream, d_lens, n, sums.p);
         hipLaunchKernelGGL(k_cnt_chunk_bases, dim3(1), dim3(BLOCK), 0, j->stream, sums.p, nchunks);
         hipLaunchKernelGGL(k_cnt_offsets, dim3((unsigned)nchunks), dim3(BLOCK), 0, j->stream, d_lens, n, sums.p, j->noff.p);
         if (hipGetLastError() != hipSuccess) return bail(fail(FX_EDEVICE, "offsets of the gathered names"));
         const char *what = "";
-        const int e = sort_names(d_names, 0, j->noff.p, d_lens, n, j->order.p, ndup.p, j->stream, &what);
+        const int e = sort_names(d_names, 0, j->noff.p, d_lens, n, j->order.p, ndup.p, j->stream, &what, j->soff.p, j->slen.p);
         if (e) return bail(fail(e == (int)hipErrorOutOfMemory ? FX_ENOMEM : FX_EDEVICE, "name sort, %s: %s", what, hipGetErrorString((hipError_t)e)));
         if (hipMemcpyAsync(&j->n_dup, ndup.p, 8, hipMemcpyDeviceToHost, j->stream) != hipSuccess || hipStreamSynchronize(j->stream) != hipSuccess)
             return bail(fail(FX_EDEVICE, "the name sort failed"));
@@ -4468,7 +4479,7 @@ extern "C" void fx_fxi_join_end(fx_fxi_join *j) {
     if (!j) return;
     (void)hipSetDevice(j->device);
     (void)hipStreamSynchronize(j->stream);
-    j->noff.release(); j->order.release();
+    j->noff.release(); j->order.release(); j->soff.release(); j->slen.release();
     (void)hipStreamDestroy(j->stream);
     delete j;
 }
@@ -4509,6 +4520,7 @@ extern "C" int fx_fxi_join_write(fx_fxi_join *j, const char *path, int root_tabl
         J.device = j->device; J.stream = j->stream; J.data = j->d_names; J.n = n_rows; J.order = j->order.p;
         memset(&J.c, 0, sizeof J.c);
         J.c.name_off = j->noff.p; J.c.name_len = j->d_lens;
+        J.c.s_off = j->soff.p; J.c.s_len = j->slen.p;
         if ((rc = J.init())) return done(rc);
         J.index_sizes();
         if ((rc = J.leaf_level(true, first_i, &nleaf_i))) return done(rc);

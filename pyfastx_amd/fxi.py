@@ -306,12 +306,38 @@ class PartsWriter:
         self.laps = {"table_kernels": 0.0, "table_to_file": 0.0}
         self._slack = False
 
-    def reserve(self, leaves_total):
-        """Room for the table's pages before the parts write them (best effort; fx_fxi_join_grow)."""
+    def reserve(self, leaves_total, rows_total=0, name_bytes_total=0, background=False):
+        """Room for the table's pages -- and for the index, estimated from the rows and the bytes of their names -- before the
+        parts write them (best effort; fx_fxi_join_grow: on tmpfs the pages are allocated at 16-18 GB/s when nothing else
+        writes into the file).  background: in a thread (the call releases the interpreter lock); reserved() waits for it."""
         from . import _lib
-        first = _lib.fxi_join_grow(self.path, self.root[self.table], int(leaves_total), self.device)
-        if first != self.first_new_page:
-            raise RuntimeError("the index file %s changed under its writer" % self.path)
+        # an index entry: payload size, header (3), the name, the rowid (<= 4 bytes below 2^31 rows), its 2-byte cell pointer
+        extra = int((int(name_bytes_total) + 11 * int(rows_total)) * 1.02) + (1 << 16) if rows_total else 0
+
+        def grow():
+            first = _lib.fxi_join_grow(self.path, self.root[self.table], int(leaves_total), self.device, extra)
+            if first != self.first_new_page:
+                raise RuntimeError("the index file %s changed under its writer" % self.path)
+        self._grow_err = None
+        if not background:
+            return grow()
+        import threading
+
+        def run():
+            try:
+                grow()
+            except BaseException as e:                        # noqa: BLE001
+                self._grow_err = e
+        self._grower = threading.Thread(target=run)
+        self._grower.start()
+
+    def reserved(self):
+        t = getattr(self, "_grower", None)
+        if t is not None:
+            t.join()
+            self._grower = None
+            if self._grow_err is not None:
+                raise self._grow_err
 
     def dev_buffers(self, n, name_bytes, device=None):
         t = self._torch
@@ -341,14 +367,47 @@ class PartsWriter:
         its first rows (global, 0-based), its names and their lengths as tensors on a device."""
         if int(n) == 0:
             return
-        self._firsts.append(np.asarray(firsts, dtype=np.int64))
+        self._firsts.append(None if firsts is None else np.asarray(firsts, dtype=np.int64))      # (None: set_firsts brings them later)
         self._slack = bool(slack)                             # (64 zero bytes lie behind names_dev in its own storage)
         self._names.append(names_dev)
         self._lens.append(lens_dev)
         self.rows += int(n)
         self.leaves += int(nleaf)
 
+    def set_firsts(self, k, firsts):
+        self._firsts[int(k)] = np.asarray(firsts, dtype=np.int64)
+
+    def join_names(self):
+        """All parts' names are here: onto the writer's device, back to back, sorted (fx_fxi_join_begin).  May run while the parts
+        still write their leaves; finish() does it if nobody has."""
+        from . import _lib
+        t = self._torch
+        try:
+            dev = t.device("cuda", self.device)
+            names = lens = None
+            t0 = time.perf_counter()
+            if self.rows:
+                # (the sort reads whole words behind the last name: 64 zero bytes follow it -- a lone part's buffer has them, dev_buffers)
+                pad = t.zeros(64, dtype=t.uint8, device=dev)
+                names = self._names[0] if len(self._names) == 1 and self._names[0].device == dev and self._slack else t.cat([x.to(dev, non_blocking=True) for x in self._names] + [pad])
+                lens = self._lens[0].to(dev) if len(self._lens) == 1 else t.cat([x.to(dev, non_blocking=True) for x in self._lens])
+                self._names, self._lens = [], []
+                t.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            self._joined = (names, lens)                      # (kept alive until the index leaves are formatted from them)
+            self._join = _lib.FxiJoin(self.device, names.data_ptr() if names is not None else 0, lens.data_ptr() if lens is not None else 0, self.rows)
+            self.laps["names_to_device"] = t1 - t0
+            self.laps["name_sort"] = time.perf_counter() - t1
+        except BaseException:
+            self.abort()
+            raise
+
     def abort(self):
+        j = getattr(self, "_join", None)
+        if j is not None:
+            j.close()
+            self._join = None
+        self._joined = None
         self._names, self._lens = [], []
         if os.path.exists(self.path):
             os.remove(self.path)
@@ -357,6 +416,7 @@ class PartsWriter:
         from . import _lib
         t = self._torch
         try:
+            self.reserved()
             dev = t.device("cuda", self.device)
             root_table, root_index = self.root[self.table], self.root[self.index_name]
             if self.leaves == 1:                              # a table of ONE leaf lives in its root page: the part wrote it as the first new page
@@ -365,26 +425,17 @@ class PartsWriter:
                     os.pwrite(fd, os.pread(fd, 4096, (self.first_new_page - 1) * 4096), (root_table - 1) * 4096)
                 finally:
                     os.close(fd)
-            names = lens = None
-            if self.rows:
-                # (the sort reads whole words behind the last name: 64 zero bytes follow it -- a lone part's buffer has them, dev_buffers)
-                pad = t.zeros(64, dtype=t.uint8, device=dev)
-                names = self._names[0] if len(self._names) == 1 and self._names[0].device == dev and self._slack else t.cat([x.to(dev) for x in self._names] + [pad])
-                lens = self._lens[0].to(dev) if len(self._lens) == 1 else t.cat([x.to(dev) for x in self._lens])
-                self._names, self._lens = [], []
-                t.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            j = _lib.FxiJoin(self.device, names.data_ptr() if names is not None else 0, lens.data_ptr() if lens is not None else 0, self.rows)
-            t1 = time.perf_counter()
+            if getattr(self, "_join", None) is None:
+                self.join_names()
+            j = self._join
             try:
                 firsts = np.concatenate(self._firsts) if self._firsts else np.zeros(0, dtype=np.int64)
                 lp = j.write(self.path, root_table, 0 if j.n_dup else root_index, self.rows, firsts, self.first_new_page)
             finally:
                 j.close()
+                self._join = self._joined = None
             self.laps.update(lp)
-            self.laps["name_sort"] = t1 - t0
             self.n_dup = j.n_dup
-            del names, lens
         except BaseException:
             self.abort()
             raise

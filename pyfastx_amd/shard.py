@@ -773,12 +773,25 @@ class ShardedFastq:
 
     HALO0 = 1 << 16
 
-    def __init__(self, path, rank, world, device=0, halo=None, gather=None):
+    def __init__(self, path, rank, world, device=0, halo=None, gather=None, index_file=None):
         from . import _lib
         size, kind = _lib.stream_size(path)
         if kind == 2:
             raise ValueError("%s is a single gzip stream: it does not shard by byte range (replicas only)" % path)
         self.path, self.rank, self.world, self.device, self.stream_bytes = path, rank, world, device, size
+        # index_file: where write_index will put the .fxi -- rank 0 creates it NOW and lets it grow to its estimated size in a
+        # thread of the library while the ranks stage and scan (fxi.presize_fastq, as api.Fastq does for one device): the
+        # pages are allocated by the time the first leaf is formatted.  Plain files of 1 GiB and more only; best effort.
+        self._presized = None
+        if index_file and rank == 0 and kind == 0 and not os.path.exists(index_file) and not os.environ.get("FX_FXI_NO_PRESIZE"):
+            from . import fxi
+            try:
+                tok = fxi.presize_fastq(index_file, path, device=device)
+                if tok is not None:
+                    self._presized = (index_file, tok)
+            except Exception:                                 # noqa: BLE001  (no early file: write_index makes it)
+                if os.path.exists(index_file):
+                    os.remove(index_file)
         self.base, self.end = size * rank // world, size * (rank + 1) // world
         self.halo = int(self.HALO0 if halo is None else halo)
         self.reopened = 0
@@ -819,16 +832,21 @@ class ShardedFastq:
         sent every rank's table and names to rank 0 through files and let the host page loader format them: 15 M rows/s).
         Collective over the ranks of the build:
           1. fx_fxi_part_shape on every rank; ONE all-gather of three integers per rank (rows, table leaves, bytes of names);
-          2. rank 0 creates the database and makes room for the table's pages; an all-gather of three words tells
-             everybody where the new pages begin;
-          3. every rank hands its names to rank 0 (point to point: RCCL over xGMI on GPUs, gloo through the host in tests) --
-             rank 0 sorts while -- every rank formats ITS table leaves and copies them into its page range of the file;
+          2. rank 0 creates the database and, in a thread, makes room for all its pages (table + estimated index);
+          3. every rank posts its names to rank 0 (point to point: RCCL over xGMI on GPUs, gloo through the host in tests);
+             an all-gather of three words tells everybody where the new pages begin, and every rank formats ITS table
+             leaves and copies them into its page range of the file while the names travel;
           4. the first rows of every rank's leaves follow (8 bytes per leaf; their arrival also says the leaves are in
              the file), rank 0 writes the interior levels, the index and the header.
         A row that needs an overflow page (FX_ERANGE on any rank): the host loaders instead, the arrays gathered as objects.
         gather: callable(int64[k]) -> int64[world, k] (default: torch.distributed.all_gather).  -> rows written (rank 0), else None."""
         from . import _lib, fxi
+        import time
         world, rank = self.world, self.rank
+        marks = [("start", time.perf_counter())]
+
+        def mark(what):
+            marks.append((what, time.perf_counter()))
         if world > 1:
             import torch
             import torch.distributed as dist
@@ -851,59 +869,120 @@ class ShardedFastq:
             n, nleaf, nb, bad = self.n_local, 0, 0, 1
         shapes = np.asarray(gather([n, nleaf, nb, bad, self.size]), dtype=np.int64).reshape(world, 5)
         n_total, leaves_total = int(shapes[:, 0].sum()), int(shapes[:, 1].sum())
+        mark("shapes_gathered")
         if shapes[:, 3].any():
             return self._write_index_host(index_file, group)
-        # ---- 2. the database; where the new pages begin
+        # ---- 2. the database (rank 0); room for all its pages is made in a thread while the names are packed and posted
         w = None
         head = [0, 0, 0]
         if rank == 0:
             try:
-                w = fxi.PartsWriter(index_file, 1, self.device)
-                w.reserve(leaves_total)
+                pre = False
+                if self._presized is not None:                # the file made while the ranks staged: schema in place, room allocated
+                    pf, tok = self._presized
+                    self._presized = None
+                    pre = pf == index_file
+                    _lib.fxi_presize_end(tok, cancel=not pre)
+                    if not pre and os.path.exists(pf):
+                        os.remove(pf)
+                w = fxi.PartsWriter(index_file, 1, self.device, schema_done=pre)
+                w.reserve(leaves_total, n_total, int(shapes[:, 2].sum()), background=True)
                 head = [w.first_new_page, w.root["read"], 1]
             except (_lib.FxError, OSError):
                 w = None
-        head = np.asarray(gather(head), dtype=np.int64).reshape(world, 3)[0]
-        if not head[2]:
-            return self._write_index_host(index_file, group)
-        first_new_page = int(head[0])
-        leaf_base = int(shapes[:rank, 1].sum())               # (a table of one leaf in all: PartsWriter.finish moves it into the root page)
-        # ---- 3. names to rank 0, leaves to the file
+        mark("database_made")
+        # ---- 3. names to rank 0 (posted now, travelling while the leaves are written)
         names = lens = None
         if n:
-            names = torch.empty(nb + 64, dtype=torch.uint8, device="cuda:%d" % self.device) if world > 1 else None
             if world == 1:
                 names, lens = w.dev_buffers(n, nb)
             else:
+                names = torch.empty(nb + 64, dtype=torch.uint8, device="cuda:%d" % self.device)
                 lens = torch.empty(n, dtype=torch.int32, device="cuda:%d" % self.device)
             self.blob.fxi_part_names(1, names.data_ptr(), lens.data_ptr())
             names[nb:].zero_()
+        mark("names_packed")
         reqs, parts = [], []
         if world > 1:
             def ship(t):                                      # what the backend can send: device memory (RCCL) or a host copy (gloo)
                 return t if nccl else t.cpu()
             if rank == 0:
+                # ONE receive buffer for everything the other ranks send (device memory for RCCL, one pinned block for gloo):
+                # per rank its names, then -- 8-byte aligned -- its lengths and the first rows of its leaves
+                def up8(x):
+                    return (int(x) + 7) & ~7
+                need = sum(up8(shapes[r, 2]) + up8(4 * shapes[r, 0]) + 8 * int(shapes[r, 1]) for r in range(1, world))
+                pool = torch.empty(max(need, 8), dtype=torch.uint8, device=("cuda:%d" % self.device) if nccl else "cpu", pin_memory=not nccl)
+                at = 0
                 for r in range(1, world):
                     nr, lr, br = int(shapes[r, 0]), int(shapes[r, 1]), int(shapes[r, 2])
                     if nr == 0:
                         parts.append(None)
                         continue
-                    dev = "cuda:%d" % self.device if nccl else "cpu"
-                    bn = torch.empty(br, dtype=torch.uint8, device=dev, pin_memory=not nccl)
-                    bl = torch.empty(nr, dtype=torch.int32, device=dev, pin_memory=not nccl)
-                    bf = torch.empty(lr, dtype=torch.int64, device=dev, pin_memory=not nccl)
+                    bn = pool[at:at + br]
+                    at += up8(br)
+                    bl = pool[at:at + 4 * nr].view(torch.int32)
+                    at += up8(4 * nr)
+                    bf = pool[at:at + 8 * lr].view(torch.int64)
+                    at += 8 * lr
                     reqs += [dist.irecv(bn, src=r, group=group), dist.irecv(bl, src=r, group=group)]
                     parts.append((nr, lr, bn, bl, bf))
             elif n:
                 reqs += [dist.isend(ship(names[:nb]), dst=0, group=group), dist.isend(ship(lens), dst=0, group=group)]
+        mark("names_posted")
+        # ---- where the new pages begin: three words from rank 0, once the room is there
+        if w is not None:
+            try:
+                w.reserved()
+            except (_lib.FxError, OSError, RuntimeError):
+                pass                                          # (best effort: the parts fall back to pwrite)
+        mark("room_made")
+        head = np.asarray(gather(head), dtype=np.int64).reshape(world, 3)[0]
+        if not head[2]:
+            for q in reqs:
+                q.wait()
+            return self._write_index_host(index_file, group)
+        first_new_page = int(head[0])
+        leaf_base = int(shapes[:rank, 1].sum())               # (a table of one leaf in all: PartsWriter.finish moves it into the root page)
+        mark("first_page_known")
         err = None
-        try:
-            if n:
-                self.index_laps = self.blob.fxi_part_leaves(1, index_file, first_new_page, leaf_base)
-        except _lib.FxError as e:                             # (said in step 4: nobody may be left waiting)
-            err = e
+        box = {}
+
+        def leaves():
+            try:
+                if n:
+                    box["laps"] = self.blob.fxi_part_leaves(1, index_file, first_new_page, leaf_base)
+            except _lib.FxError as e:                         # (said in step 4: nobody may be left waiting)
+                box["err"] = e
+        th = None
+        if rank == 0 and world > 1:
+            # the writer's own leaves go out in a thread (the copy-out is the host's work, the call releases the interpreter
+            # lock): the names of the others arrive and are sorted on the device meanwhile
+            import threading
+            th = threading.Thread(target=leaves)
+            th.start()
+        else:
+            leaves()
+            mark("own_leaves_in_the_file")
         for q in reqs:
             q.wait()
+        mark("names_arrived")
+        if th is not None:
+            try:
+                if n:
+                    w.add_remote(n, nleaf, None, names[:nb], lens, slack=True)
+                for pr in parts:
+                    if pr is not None:
+                        w.add_remote(pr[0], pr[1], None, pr[2], pr[3])
+                w.join_names()
+            except _lib.FxError as e:
+                box.setdefault("err", e)
+            mark("names_sorted")
+            th.join()
+            mark("own_leaves_in_the_file")
+        err = box.get("err")
+        if "laps" in box:
+            self.index_laps = box["laps"]
         # ---- 4. first rows to rank 0 (their arrival: this rank's leaves are in the file), then the writer's share
         firsts = self.blob.fxi_part_firsts(nleaf) if (n and err is None) else np.zeros(nleaf, dtype=np.int64)
         flag = np.asarray(gather([0 if err is None else 1]), dtype=np.int64).reshape(world)
@@ -918,24 +997,33 @@ class ShardedFastq:
             tf = torch.from_numpy(firsts)
             dist.send(tf.to("cuda:%d" % self.device) if nccl else tf, dst=0, group=group)
         if rank == 0:
-            if n:
-                w.add_remote(n, nleaf, firsts, names[:nb], lens, slack=True)
+            if world == 1:
+                if n:
+                    w.add_remote(n, nleaf, firsts, names[:nb], lens, slack=True)
+            elif n:
+                w.set_firsts(0, firsts)
+            k = 1 if n else 0
             for r in range(1, world):
                 pr = parts[r - 1] if world > 1 else None
                 if pr is None:
                     continue
-                nr, lr, bn, bl, bf = pr
-                dist.recv(bf, src=r, group=group)
-                w.add_remote(nr, lr, bf.cpu().numpy(), bn, bl)
+                dist.recv(pr[4], src=r, group=group)
+                w.set_firsts(k, pr[4].cpu().numpy())
+                k += 1
+            mark("first_rows_arrived")
             db = w.finish()
+            mark("index_and_levels_written")
             size = int(shapes[:, 4].sum())
             db.execute("INSERT INTO stat VALUES (?,?,?)", (n_total, size, size * 1.0 / n_total if n_total else float("nan")))     # fastq.c:161
             db.commit()
             db.close()
-            self.index_laps = dict(getattr(self, "index_laps", {}), **w.laps)
+            own = getattr(self, "index_laps", {})
+            self.index_laps = dict(w.laps, **{k: v for k, v in own.items() if v})
             out = n_total
         if world > 1:
             dist.barrier(group=group)
+        mark("done")
+        self.index_steps = {b[0]: round(b[1] - a[1], 4) for a, b in zip(marks[:-1], marks[1:])}
         return out
 
     def _write_index_host(self, index_file, group=None):

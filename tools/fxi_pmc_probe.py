@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One Fastq(path) of N synthetic reads with the index file written from the device (k_fxi_*): the process the PMC passes of
-tools/gpu_r05_r.sh run.  usage: python tools/fxi_pmc_probe.py [reads] [dir]"""
+tools/gpu.sh pmc_fxi run.  usage: python tools/fxi_pmc_probe.py [reads] [dir]"""
 import json
 import os
 import shutil
@@ -34,7 +34,8 @@ def main():
         fq = fx.Fastq(path)
         el = time.perf_counter() - t
         print(json.dumps({"reads": n, "file_bytes": nb, "fxi_bytes": os.path.getsize(path + ".fxi"), "Fastq_ctor_s": round(el, 4),
-                          "len": len(fq), "phases": getattr(fq, "build_phases", None)}))
+                          "len": len(fq), "phases": getattr(fq, "build_phases", None),
+                          "index_phases": {k: round(v, 4) for k, v in (getattr(fq, "index_phases", None) or {}).items()}}))
     finally:
         shutil.rmtree(d, ignore_errors=True)
 

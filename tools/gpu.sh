@@ -5,6 +5,7 @@
 #   pytest:<file>[:<file>...]  some test files (-m gpu)
 #   tests          pytest -m gpu                           smoke       __graft_entry__.smoke()
 #   bench          the driver's default bench line, timed  prof        the same command under rocprofv3 --kernel-trace --stats
+#   bench8         the driver's --gpus 8 command shape on this ONE device (gloo; all ranks share it)
 #   counters       rocprofv3 -L (the counter names of this box)
 #   valuprobe      tools/valuprobe.hip  (cycles per wave64 VALU instruction)
 #   gathercal      tools/gathercal.hip under FETCH_SIZE and the raw request counters (calibration of the gather traffic)
@@ -38,6 +39,7 @@ for STEP in "$@"; do
     DB=$(find $OUT/prof -name '*.db' | head -1)
     [ -n "$DB" ] && python tools/rocprof_summary.py $DB $OUT/kernel_stats.txt && grep 'fx::' $OUT/kernel_stats.txt | head -80
     rm -rf $OUT/prof ;;
+  bench8) ( time FX_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 > $OUT/bench8.json 2> $OUT/bench8.err ) 2> $OUT/bench8.time; cat $OUT/bench8.time; python -c "import json,sys; d=json.loads([l for l in open('$OUT/bench8.json') if l.startswith('{')][-1]); print(json.dumps(d.get('fastq_strong')))"; tail -3 $OUT/bench8.err ;;
   counters) rocprofv3 -L > $OUT/counters.txt 2>&1; grep -c . $OUT/counters.txt ;;
   valuprobe)
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/valuprobe tools/valuprobe.hip 2> /dev/null && /tmp/valuprobe > $OUT/valuprobe.txt 2>&1; cat $OUT/valuprobe.txt ;;
