@@ -26,6 +26,7 @@ summaries stitches the record that crosses each cut.
 import argparse
 import json
 import os
+import re
 import shutil
 import sys
 import tempfile
@@ -67,6 +68,7 @@ def parse():
     ap.add_argument("--c3-reference-full", action="store_true", help="the compiled reference on the FULL configs[2] file as well (pyfastx.Fastq(path, full_index=True): ~5 minutes on one core, "
                                                                       "a second 10 GB index file), every `read` row + base / meta / stat compared (profiles/r05_c3_full_reference.json holds one such run)")
     ap.add_argument("--c4-ref-queries", type=int, default=100_000, help="queries of the C4 leg that the reference answers too (ascending offsets, through its restart points)")
+    ap.add_argument("--c4-reference-full", action="store_true", help="ALL queries of the C4 leg through the reference (builder-run: profiles/r06_c4_full_reference.json; minutes of one core)")
     ap.add_argument("--pmc-file", default=None, help=argparse.SUPPRESS)                  # the counter passes' child opens this file instead of generating the stream
     return ap.parse_args()
 
@@ -687,15 +689,25 @@ def leg_c4(a, host, plan, q, tmpdir, plain_digest=None):
            "kernels_ms_per_open_in_groups": {k: round(v, 3) for k, v in prof.items()}, "launches_per_open_in_groups": launches,
            "fxi_durable_s": round(_median(t_ctor), 4), "fetch_many_1M_host_to_host_s": round(_median(t_fetch), 4),
            "gzindex_rows": npoints,
-           # what bounds the inflate is NOT HBM (VERDICT r4 missing #6): the decode is one wave per member walking ~190 symbol steps
-           # three times (count, hand-over, store), every step two dependent LDS look-ups and the bit arithmetic between them, twelve waves
-           # per CU (13 KB of LDS each).  Its vector instructions alone (55 k per wave, profiles/r03_pmc_bgzf_par.txt) would take
-           # `valu_issue_floor_ms`; the rest is the latency of the chain.  hbm_frac is kept for continuity.
-           "roofline": {"kernel": "fx::k_bgzf_*", "bound": "latency of a per-member dependent chain (LDS look-ups, bit arithmetic) at 12 waves per CU; neither HBM nor vector issue",
+           # what bounds the inflate (counters of profiles/r06_pmc_bgzf_c4.txt, whole file in one launch): the decode is one
+           # wave per member, 16 waves per CU; of a wave's cycles 71 % are spent parked at s_waitcnt for vector memory, 23 % issuing,
+           # 6 % in issue stalls.  What it waits for: the per-CU vL1D has requests outstanding at the L2 70 % of the kernel's time
+           # (TCP_PENDING_STALL_CYCLES) -- 170 M reads (16-byte chunks of the compressed bytes, one per ~8 symbols and lane) at 474 cycles
+           # each and 471 M 8-byte stores at 64 places of a member per instruction at 253; 41 % of the L2's requests miss (4096 members x
+           # 84 KiB are open at a time, the L2s hold 32 MiB: lines are evicted between their sixteen 8-byte stores and come back:
+           # 15 GB fetched + 17 GB written for 4 GB of compressed and inflated bytes).  Round 6 took the reads from 732 M to 170 M
+           # (phase A through the chunk reader: 12.6 -> 10.4 ms); whole 64-byte blocks put together in LDS, streaming stores, a second
+           # chunk ahead, the block header staged in LDS were measured and are slower.
+           "roofline": {"kernel": "fx::k_bgzf_*", "bound": "vector-memory latency of k_bgzf_decode_par (s_waitcnt on divergent 8-byte stores and 16-byte chunk loads: "
+                                 "the vL1D has L2 requests outstanding 70 % of the kernel); not HBM bandwidth, not vector issue",
+                        "stall_classes_of_wave_cycles": {"parked_at_s_waitcnt": 0.714, "issuing_instructions": 0.228, "issue_stalls": 0.058,
+                                                         "source": "profiles/r06_pmc_bgzf_c4.txt: SQ_WAIT_ANY, SQ_ACTIVE_INST_ANY, SQ_WAIT_INST_ANY over SQ_WAVE_CYCLES"},
                         "achieved": round(alg / (infl * 1e-3) / 1e9, 1) if infl else None,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (infl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if infl else None,
                         "hbm_frac": round(alg / (infl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if infl else None,
-                        "decode_valu_issue_floor_ms": round(55000.0 * ((nb + 65279) // 65280) * VALU_CYCLES / (N_SIMD * CLOCK_HZ) * 1e3, 2),
+                        "decode_traffic_measured": {"hbm_read_bytes": 15425574912, "hbm_written_bytes": 17345473536, "ratio_to_algorithmic": 8.1,
+                                                    "source": "profiles/r06_pmc_bgzf_c4.txt: FETCH_SIZE x 1024 x 2 (profiles/r06_gathercal.txt), WRITE_SIZE x 1024"},
+                        "decode_valu_issue_floor_ms": round(63900.0 * ((nb + 65279) // 65280) * 1.66e-9 / N_SIMD * 1e3, 2),
                         "decode_avg_launch_ms": round(prof_one.get("k_bgzf_decode", 0.0), 3),
                         "symbols": "11 863 per 65 280-byte member at zlib level 6: 73.7 % matches of 7.1 bytes, 26.3 % literals (tools/deflate_symbol_mix.c)",
                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(infl, 3), "traffic": None}}
@@ -715,8 +727,9 @@ def leg_c4(a, host, plan, q, tmpdir, plain_digest=None):
         # fetches: indexed_gzip (zran) is NOT vendored in the reference tree; oracle/refshim stands in for it with gzseek, which
         # only moves forward cheaply.  So: a sample of queries in ascending file order (one forward pass), every string compared.
         boff = np.array([x[2] for x in ours["seq"]], dtype=np.int64)
-        nref = max(1, min(int(a.c4_ref_queries), 200_000, len(ids)))
-        pick = np.argsort(boff[ids[:200_000]] + st[:200_000], kind="stable")[::max(1, min(200_000, len(ids)) // nref)]   # ascending offsets: one forward pass, a restart at every point it crosses
+        pool_n = len(ids) if a.c4_reference_full else min(200_000, len(ids))
+        nref = pool_n if a.c4_reference_full else max(1, min(int(a.c4_ref_queries), pool_n))
+        pick = np.argsort(boff[ids[:pool_n]] + st[:pool_n], kind="stable")[::max(1, pool_n // nref)]   # ascending offsets: one forward pass, a restart at every point it crosses
         t4 = time.perf_counter()
         eq = True
         for j in pick.tolist():
@@ -804,19 +817,49 @@ _COMP = bytes.maketrans(b"ACGTacgtMKRYVBHDmkryvbhdUu", b"TGCAtgcaKMYRBVDHkmyrbvd
 # vector instructions per 4 KiB granule and wave (SQ_INSTS_VALU of a PMC pass / granules of its stream); source file beside each
 VALU_PER_GRANULE = {"k_fastq_lines": (473, "profiles/r05_pmc_fastq_plain.txt: 803 238 357 / 1 699 219 granules (506 in round 1)"),
                     "k_fastq_lines_comp": (800, "profiles/r05_pmc_fastq_sq.txt: k_fastq_lines_comp<false> 1 358 541 574 / 1 699 219 granules (855 in round 4)")}
-N_SIMD, CLOCK_HZ = 1024, 2.4e9                              # 256 CUs x 4 SIMDs, MI355X_MICROARCH.md (max clock)
-# A wave64 integer / logic instruction -- what these kernels are made of -- occupies its SIMD for 4 cycles (16 lanes per cycle): the
-# instruction counts x 4 cycles reproduce the kernels' times within 3 % (profiles/r04_pmc_fastq_sq.txt, r05_pmc_fastq_sq.txt).  The
-# guide's "2 cycles" is the FP32 FMA rate (157 TFLOP/s); a frac slightly above 1 is the boost clock / the few cheaper instructions.
-VALU_CYCLES = 4.0
+N_SIMD = 1024                                               # 256 CUs x 4 SIMDs
+VALU_CAL = os.path.join("profiles", "r06_valuprobe.txt")    # tools/valuprobe.hip + tools/mixprobe.py on an MI355X (tools/gpu.sh valuprobe)
+
+
+def _valu_calibration():
+    """Measured issue times, from the committed calibration file: ns a wave64 instruction occupies a SIMD with the device full --
+    fast class (v_sub_u32), slow class (v_dot4_u32_u8: also v_perm, v_alignbit, v_bfe, v_mul_lo, v_bcnt, v_mbcnt, v_readlane, the
+    64-bit shifts), and per product kernel the time of ITS opcode mix as a probe kernel + the fraction of slow-class opcodes in it."""
+    out = {"mix": {}}
+    try:
+        for ln in open(os.path.join(ROOT, VALU_CAL)):
+            m = re.match(r"(v_sub_u32|v_dot4_u32_u8)\s+full:\s+([0-9.]+) ms", ln)
+            if m:                                           # 2000 iterations x 64 instructions x 8 waves per SIMD
+                out["fast_ns" if m.group(1) == "v_sub_u32" else "slow_ns"] = float(m.group(2)) * 1e6 / (2000 * 64 * 8)
+            m = re.match(r"MIX (\S+) ns_per_instr=([0-9.]+) slow_class_fraction=([0-9.]+)", ln)
+            if m:
+                out["mix"][m.group(1)] = (float(m.group(2)), float(m.group(3)))
+    except OSError:
+        pass
+    return out
 
 
 def _issue_roofline(kernel, stream_bytes, measured_ms):
+    """The vector-issue bound of a scan kernel, from MEASURED instruction times (VERDICT r5 #4a).  floor: the kernel's instruction
+    count (SQ_INSTS_VALU of a PMC pass) x the time of its mix if every opcode issued at the best rate measured for its class -- a
+    lower bound (opcodes not measured one by one count as fast).  mix_probe: the same count x the time its own opcode mix took as a
+    probe kernel (shuffled, no memory) -- an estimate, not a bound: the product kernels issue their mix a few per cent FASTER than the
+    shuffled probe (mix_probe_over_measured > 1), i.e. they run at the issue rate of their mix."""
     per, src = VALU_PER_GRANULE[kernel]
-    floor_ms = per * (stream_bytes / 4096.0) * VALU_CYCLES / (N_SIMD * CLOCK_HZ) * 1e3
-    return {"bound": "valu issue", "cycles_per_wave64_instruction": VALU_CYCLES, "valu_instructions_per_granule_and_wave": per, "counter_source": src, "granules": int(stream_bytes // 4096),
-            "floor_ms": round(floor_ms, 3), "avg_launch_ms": round(measured_ms, 4), "frac": round(min(floor_ms / measured_ms, 1.0), 4),
-            "floor_over_measured": round(floor_ms / measured_ms, 4),   # (above 1: part of the mix issues in fewer than 4 cycles; the kernel runs AT its issue rate)
+    cal = _valu_calibration()
+    key = {"k_fastq_lines": "k_fastq_linesE", "k_fastq_lines_comp": "k_fastq_lines_compILb0E"}[kernel]
+    if "fast_ns" not in cal or "slow_ns" not in cal or key not in cal["mix"]:
+        return {"bound": "valu issue", "calibration": None, "note": "no calibration file (%s)" % VALU_CAL}
+    mix_ns, slow = cal["mix"][key]
+    floor_ns = (1.0 - slow) * cal["fast_ns"] + slow * cal["slow_ns"]
+    n_instr = per * (stream_bytes / 4096.0)
+    floor_ms, probe_ms = n_instr * floor_ns / N_SIMD * 1e-6, n_instr * mix_ns / N_SIMD * 1e-6
+    return {"bound": "valu issue", "calibration": VALU_CAL, "valu_instructions_per_granule_and_wave": per, "counter_source": src, "granules": int(stream_bytes // 4096),
+            "ns_per_wave64_instruction": {"fast_class": round(cal["fast_ns"], 3), "slow_class": round(cal["slow_ns"], 3), "slow_class_fraction": slow,
+                                          "floor_of_this_mix": round(floor_ns, 3), "this_mix_as_a_probe_kernel": mix_ns},
+            "floor_ms": round(floor_ms, 3), "avg_launch_ms": round(measured_ms, 4), "frac": round(floor_ms / measured_ms, 4),
+            "floor_over_measured": round(floor_ms / measured_ms, 4),
+            "mix_probe_ms": round(probe_ms, 3), "mix_probe_over_measured": round(probe_ms / measured_ms, 4),
             "hbm_frac": round(stream_bytes / (measured_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
@@ -1737,13 +1780,17 @@ def main():
                 else:
                     line["roofline"]["traffic_source"] += "; a live measurement was tried and failed: " + src
                 if "FETCH_SIZE" in _FETCH_PMC and "WRITE_SIZE" in _FETCH_PMC:
-                    # a gather of ~100-byte pieces: 64-byte sectors are what FETCH_SIZE counts here (no wide coalesced stream: no x 2)
+                    # FETCH_SIZE tallies every request to memory at 64 bytes and every request fetches 128 -- streams AND gathers
+                    # (profiles/r06_gathercal.txt: 10^6 random aligned 128-byte lines = 128 MB known, 64 MB reported; 10^6 random
+                    # 64-byte half lines: the same 128 MB fetched) -- so the reads are FETCH_SIZE x 2 here as for the scan kernel
                     rf = line["roofline_fetch"]
-                    rd, wr = int(_FETCH_PMC["FETCH_SIZE"] * 1024), int(_FETCH_PMC["WRITE_SIZE"] * 1024)
+                    rd, wr = int(_FETCH_PMC["FETCH_SIZE"] * 1024 * 2), int(_FETCH_PMC["WRITE_SIZE"] * 1024)
                     rf["traffic"] = rd + wr
-                    rf["traffic_source"] = ("the same two rocprofv3 passes, rows of k_fetch_lines (3 launches of the run's own %d queries): FETCH_SIZE %.0f KiB + WRITE_SIZE %.0f KiB "
-                                            "per launch = %.2f x the algorithmic bytes; %.0f B fetched per query = %.2f lines of 128 B (a 100-base interval at a random offset "
-                                            "of a 61-byte-per-line record touches 1.8), so the kernel moves %.1f TB/s of lines to deliver its answers"
+                    rf["calibration"] = "profiles/r06_gathercal.txt (tools/gathercal.hip under --pmc FETCH_SIZE: factor 2.0 for a stream, for aligned 128-byte lines and for 64-byte half lines; 1.93 for unaligned 100-byte spans counted in 128-byte blocks)"
+                    rf["lines_of_128_bytes_fetched_per_query"] = round(rd / a.queries / 128.0, 2)
+                    rf["traffic_source"] = ("the same two rocprofv3 passes, rows of k_fetch_lines (3 launches of the run's own %d queries): FETCH_SIZE %.0f KiB x 2 + WRITE_SIZE %.0f KiB "
+                                            "per launch = %.2f x the algorithmic bytes; %.0f B fetched per query = %.2f lines of 128 B: the interval's own 1.8 lines (100 bases at a random "
+                                            "offset of a 61-byte-per-line record), its descriptor, its row of the record table; the kernel moves %.1f TB/s of lines to deliver its answers"
                                             % (a.queries, _FETCH_PMC["FETCH_SIZE"], _FETCH_PMC["WRITE_SIZE"], (rd + wr) / max(rf["algorithmic_bytes_per_launch"], 1),
                                                rd / a.queries, rd / a.queries / 128.0, (rd + wr) / max(rf["avg_launch_ms"] * 1e-3, 1e-12) / 1e12))
                     rf["frac_of_measured_traffic"] = round((rd + wr) / max(rf["avg_launch_ms"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4)

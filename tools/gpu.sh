@@ -5,6 +5,7 @@
 #   pytest:<file>[:<file>...]  some test files (-m gpu)
 #   tests          pytest -m gpu                           smoke       __graft_entry__.smoke()
 #   bench          the driver's default bench line, timed  prof        the same command under rocprofv3 --kernel-trace --stats
+#   bench_c4full   the bench with ALL 1 M queries of the C4 leg answered by the reference too (builder-run evidence)
 #   bench8         the driver's --gpus 8 command shape on this ONE device (gloo; all ranks share it)
 #   counters       rocprofv3 -L (the counter names of this box)
 #   valuprobe      tools/valuprobe.hip  (cycles per wave64 VALU instruction)
@@ -39,10 +40,12 @@ for STEP in "$@"; do
     DB=$(find $OUT/prof -name '*.db' | head -1)
     [ -n "$DB" ] && python tools/rocprof_summary.py $DB $OUT/kernel_stats.txt && grep 'fx::' $OUT/kernel_stats.txt | head -80
     rm -rf $OUT/prof ;;
+  bench_c4full) ( time timeout 2400 python bench.py --c4-reference-full --no-c3 > $OUT/bench_c4full.json 2> $OUT/bench_c4full.err ) 2> $OUT/bench_c4full.time; cat $OUT/bench_c4full.time; python -c "import json; d=json.loads([l for l in open('$OUT/bench_c4full.json') if l.startswith('{')][-1]); print(json.dumps(d['c4'])[:3000])" ;;
   bench8) ( time FX_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 > $OUT/bench8.json 2> $OUT/bench8.err ) 2> $OUT/bench8.time; cat $OUT/bench8.time; python -c "import json,sys; d=json.loads([l for l in open('$OUT/bench8.json') if l.startswith('{')][-1]); print(json.dumps(d.get('fastq_strong')))"; tail -3 $OUT/bench8.err ;;
   counters) rocprofv3 -L > $OUT/counters.txt 2>&1; grep -c . $OUT/counters.txt ;;
   valuprobe)
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/valuprobe tools/valuprobe.hip 2> /dev/null && /tmp/valuprobe > $OUT/valuprobe.txt 2>&1; cat $OUT/valuprobe.txt ;;
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/valuprobe tools/valuprobe.hip 2> /dev/null && /tmp/valuprobe > $OUT/valuprobe.txt 2>&1
+    python tools/mixprobe.py >> $OUT/valuprobe.txt 2>> $OUT/mixprobe.err; cat $OUT/valuprobe.txt ;;
   gathercal)
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-align-mismatch -o /tmp/gathercal tools/gathercal.hip 2> /dev/null
     /tmp/gathercal > $OUT/gathercal_known.txt 2>&1; cat $OUT/gathercal_known.txt

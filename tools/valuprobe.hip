@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void k_probe(uint32_t *out, uint32_t seed, int
 #pragma unroll
     for (int k = 0; k < 4; ++k) b[k] = ((uint64_t)a[k] << 32) | a[k + 4];
     uint32_t c1 = seed | 0x04080201u, c2 = seed ^ 0x10200000u;
+    const unsigned long long w0 = wall_clock64();                 // the constant 100 MHz clock (hipDeviceAttributeWallClockRate)
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -61,26 +62,27 @@ __global__ __launch_bounds__(256) void k_probe(uint32_t *out, uint32_t seed, int
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
+    const unsigned long long w1 = wall_clock64();
     uint32_t s = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s ^= a[k];
 #pragma unroll
     for (int k = 0; k < 4; ++k) s ^= (uint32_t)b[k] ^ (uint32_t)(b[k] >> 32);
     if (s == 0x12345678u) out[threadIdx.x] = s;
-    if (ticks && threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
+    if (ticks && threadIdx.x == 0) { ticks[blockIdx.x] = t1 - t0; ticks[4096 + blockIdx.x] = w1 - w0; }
 }
 
 static double g_mhz = 0;          // shader clock under load: s_memtime ticks per microsecond, from the full-device run of v_add_u32
 
 template <int OP> static int run(const char *name, int per_iter /* wave64 instructions the body compiles to, per a[k] */) {
     uint32_t *d; CK(hipMalloc((void **)&d, 4096));
-    unsigned long long *dt; CK(hipMalloc((void **)&dt, 8 * 4096));
+    unsigned long long *dt; CK(hipMalloc((void **)&dt, 8 * 8192));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int iters = 2000, blocks = 256 * 8;
     const int n_inner = OP < 100 ? 64 : 32;                   // a[k] updates per iteration
     float best = 1e9f;
-    std::vector<unsigned long long> h(blocks);
-    double ticks_full = 0;
+    std::vector<unsigned long long> h(blocks), hw(blocks);
+    double ticks_full = 0, wall_full = 0, wall_lone = 0;
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL(k_probe<OP>, dim3(blocks), dim3(256), 0, 0, d, 12345u + rep, iters, dt);
@@ -89,8 +91,9 @@ template <int OP> static int run(const char *name, int per_iter /* wave64 instru
         if (ms < best) {
             best = ms;
             CK(hipMemcpy(h.data(), dt, 8 * blocks, hipMemcpyDeviceToHost));
-            std::sort(h.begin(), h.end());
-            ticks_full = (double)h[blocks / 2];
+            CK(hipMemcpy(hw.data(), dt + 4096, 8 * blocks, hipMemcpyDeviceToHost));
+            std::sort(h.begin(), h.end()); std::sort(hw.begin(), hw.end());
+            ticks_full = (double)h[blocks / 2]; wall_full = (double)hw[blocks / 2];
         }
     }
     // a lone wave: 256 workgroups of 64 threads
@@ -104,15 +107,18 @@ template <int OP> static int run(const char *name, int per_iter /* wave64 instru
         if (ms < lone_ms) {
             lone_ms = ms;
             CK(hipMemcpy(h.data(), dt, 8 * 256, hipMemcpyDeviceToHost));
-            std::sort(h.begin(), h.begin() + 256);
-            ticks_lone = (double)h[128];
+            CK(hipMemcpy(hw.data(), dt + 4096, 8 * 256, hipMemcpyDeviceToHost));
+            std::sort(h.begin(), h.begin() + 256); std::sort(hw.begin(), hw.begin() + 256);
+            ticks_lone = (double)h[128]; wall_lone = (double)hw[128];
         }
     }
     const double upd = (double)iters * n_inner;                           // updates per wave
     const double lane_ops = (double)blocks * 256 * upd;
     // full device: 8 waves per SIMD; SIMD cycles per wave64 update = ticks of one wave / (updates x 8 waves sharing the SIMD) x (shader clock / memtime clock)
-    printf("%-34s full: %7.3f ms %6.2f T lane-upd/s, %5.2f memtime-ticks/upd/SIMD | lone wave: %6.2f ticks/upd (%d instr/upd)\n", name, best,
-           lane_ops / (best * 1e-3) / 1e12, ticks_full / (upd * 8.0), ticks_lone / upd, per_iter);
+    // wall_* are ticks of the 100 MHz clock over one wave's loop: 10 ns each
+    printf("%-34s full: %7.3f ms %6.2f T lane-upd/s, %5.2f ns/upd/SIMD (%.0f memtime ticks per us) | lone wave: %6.2f ns/upd, %5.2f ticks/upd (%.0f per us) (%d instr/upd)\n", name, best,
+           lane_ops / (best * 1e-3) / 1e12, wall_full * 10.0 / (upd * 8.0), ticks_full / (wall_full * 0.01), wall_lone * 10.0 / upd, ticks_lone / upd,
+           ticks_lone / (wall_lone * 0.01), per_iter);
     if (OP == 0) g_mhz = ticks_full / (best * 1e3);
     (void)hipFree(d); (void)hipFree(dt);
     return 0;
