@@ -370,8 +370,15 @@ def leg_c3(a, dev, tmpdir):
         "roofline_build": {"algorithmic_bytes": build_alg, "frac": round(build_alg / ((t1 - t0) / R) / 1e9 / HBM_PEAK_GBS, 4)},
         "roofline_comp": {"kernel": "fx::k_fastq_comp", "algorithmic_bytes": comp_alg,
                           "frac": round(comp_alg / (prof.get("k_fastq_comp", 1e9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        # traffic: from the builder's counter passes (profiles/r06_pmc_fetch.txt: 1 M random reads of 150 bases -> FETCH_SIZE 409 700 KB x 2 read,
+        # WRITE_SIZE 440 040 KB written per launch), scaled to this launch's reads; the factor 2 is the calibration of profiles/r06_gathercal.txt
         "roofline_fetch": {"kernel": "fx::k_fastq_fetch", "algorithmic_bytes": fetch_alg,
-                           "frac": round(fetch_alg / (prof.get("k_fastq_fetch", 1e9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                           "frac": round(fetch_alg / (prof.get("k_fastq_fetch", 1e9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "traffic": int(nq * (409700 * 1024 * 2 + 440040 * 1024) / 1e6),
+                           "traffic_source": "profiles/r06_pmc_fetch.txt (builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/fetch_probe.py, 1 M reads per launch), per read x this launch's reads",
+                           "calibration": "profiles/r06_gathercal.txt (FETCH_SIZE x 2 for gathers as for streams)",
+                           "lines_of_128_bytes_fetched_per_read": round(409700 * 1024 * 2 / 1e6 / 128.0, 2),
+                           "frac_of_measured_traffic": round(nq * (409700 * 1024 * 2 + 440040 * 1024) / 1e6 / (prof.get("k_fastq_fetch", 1e9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
     }
     if not ok:
         raise SystemExit("PARITY FAILURE (C3 at full size)")

@@ -76,6 +76,15 @@ int fx_open_file(const char *path, int device, fx_handle **out);
  * size 0.3 ms --, *stage_s = page cache -> pinned pieces -> HBM.  (The reference has no counterpart: it reads through a 1 MiB
  * buffer, kseq.h:13.) */
 int fx_open_laps(double *alloc_s, double *stage_s);
+/* A PLAIN file staged in the background (round 6): the handle comes back as soon as its blob is allocated, the staging lanes
+ * copy the file into it in file order.  fx_stage_wait(h, upto): returns when the first `upto` bytes are on the device
+ * (upto < 0: the whole file; the lanes are joined and the handle is an ordinary one from then on).  Until then the caller
+ * works on PREFIXES through views of the blob -- fx_open_device(fx_device_ptr(h) + off, len + halo), fx_set_shard,
+ * fx_set_halo: byte ranges as in the sharded build -- e.g. formats and ships the table leaves of an index file
+ * (fx_fxi_part_*) while the rest of the input still arrives; no other call on THIS handle before fx_stage_wait(h, -1).
+ * fx_close waits for the lanes.  gzip input: FX_EINVAL.  (The reference reads and indexes in one loop, fastq.c:8-182.) */
+int fx_open_file_async(const char *path, int device, fx_handle **out);
+int fx_stage_wait(fx_handle *h, int64_t upto);
 /* ... and the last fx_fastq_build / fx_fastq_build_comp (this thread), eight doubles, seconds: [0] the sample of the stream and its
  * wait, [1] allocations + launches of the count pass, [2] the wait for it, [4] plan + allocation of the read table, [5] row kernels +
  * their wait ([3], [6], [7]: unused).  Diagnostic: a build that takes seconds instead of milliseconds is waiting for the driver. */

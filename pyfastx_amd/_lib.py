@@ -49,7 +49,7 @@ SYMBOLS = [
     "fx_set_shard", "fx_close", "fx_release_scratch", "fx_pinned_alloc", "fx_pinned_free", "fx_pinned_holds", "fx_pinned_trim", "fx_size", "fx_device_memory", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
     "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_line_regular", "fx_fasta_len_stats", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_fastq_build_comp", "fx_fastq_comp_info", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fasta_fetch_alloc", "fx_fetch_phases", "fx_fastq_fetch", "fx_fastq_fetch_alloc", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
-    "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_fxi_dev_sort", "fx_fxi_dev_write", "fx_fxi_presize_begin", "fx_fxi_presize_end", "fx_fxi_part_shape", "fx_fxi_part_firsts", "fx_fxi_part_names", "fx_fxi_part_leaves", "fx_fxi_join_grow", "fx_fxi_join_begin", "fx_fxi_join_write", "fx_fxi_join_end", "fx_scratch_policy", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
+    "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_fxi_dev_sort", "fx_fxi_dev_write", "fx_fxi_presize_begin", "fx_fxi_presize_end", "fx_fxi_part_shape", "fx_fxi_part_firsts", "fx_fxi_part_names", "fx_fxi_part_leaves", "fx_fxi_join_grow", "fx_fxi_join_begin", "fx_fxi_join_write", "fx_fxi_join_end", "fx_scratch_policy", "fx_open_file_async", "fx_stage_wait", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
     "fx_comm_unique_id", "fx_comm_init", "fx_comm_destroy", "fx_comm_rank", "fx_comm_world", "fx_comm_allgather", "fx_fasta_build_sharded_begin",
     "fx_fasta_build_sharded", "fx_comm_summaries", "fx_fastq_build_sharded", "fx_bgzf_counts", "fx_sort_packed_names", "fx_gunzip_parallel", "fx_gz_open_mode", "fx_kseq_scan", "fx_kseq_records", "fx_kseq_fetch", "fx_kseq_prefix_lines",
 ]
@@ -256,6 +256,8 @@ def lib():
     L.fx_fxi_join_end.argtypes = [vp]
     L.fx_fxi_join_end.restype = None
     L.fx_scratch_policy.argtypes = [vp, i32, i64, i64, vp]
+    L.fx_open_file_async.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+    L.fx_stage_wait.argtypes = [vp, i64]
     L.fx_sync.argtypes = [vp]
     L.fx_prof_enable.argtypes = [vp, i32]
     L.fx_prof_default.argtypes = [i32]
@@ -491,6 +493,16 @@ class Blob:
         h = C.c_void_p()
         check(lib().fx_open_host(a.ctypes.data if a.size else None, a.size, device, C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def from_file_async(cls, path, device=0):
+        """A plain file staged in the background (fx_open_file_async): work on prefixes through views until stage_wait(-1)."""
+        h = C.c_void_p()
+        check(lib().fx_open_file_async(os.fsencode(path), device, C.byref(h)))
+        return cls(h)
+
+    def stage_wait(self, upto=-1):
+        check(lib().fx_stage_wait(self._h, int(upto)))
 
     @classmethod
     def from_device(cls, dptr, nbytes, device=0, keepalive=None):

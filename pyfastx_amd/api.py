@@ -1318,7 +1318,7 @@ class Fastq(_fxobj.FastqCore):
         tok = None
         if not self.is_gzip and _dev_index_applies(self._index_file) and self._st.forced is None and not os.environ.get("FX_FXI_NO_PRESIZE"):
             try:
-                tok = fxi.presize_fastq(self._index_file, self.file_name, device=self._st.device)     # (the index holds names cut at the first white space whatever full_name says: fastq.c:112-117)
+                tok = fxi.presize_fastq(self._index_file, self.file_name, device=self._st.device, with_index=True)     # (the index holds names cut at the first white space whatever full_name says: fastq.c:112-117)
             except Exception:                                 # noqa: BLE001  (no early file: the build makes it -- and must find none)
                 tok = None
                 if os.path.exists(self._index_file):
@@ -1331,8 +1331,114 @@ class Fastq(_fxobj.FastqCore):
                 os.remove(self._index_file)
             raise
 
+    def _create_index_pipelined(self, tok, t_begin):
+        """A large plain file whose index file has its room already (fxi.presize_fastq): the input is staged in the background
+        (Blob.from_file_async) and taken in byte ranges as they land -- scan + rows of the range through a VIEW of the blob (the
+        sharded build's machinery: line counts of the ranges before, a halo behind), its table leaves formatted on the device and
+        copied into the file (fxi.PartsWriter) while the next ranges are still arriving: host-to-device and device-to-host run at
+        the same time, the link is full duplex.  When everything has landed: one build over the whole blob (the object's table,
+        11 ms), one sort of all names, the index leaves.  -> True; False when this route does not apply (then nothing was done)."""
+        from . import shard, windows
+        st = self._st
+        if st._blob is not None or st.windowed is None or os.environ.get("FX_FQ_NO_PIPELINE"):
+            return False
+        size = os.path.getsize(self.file_name)
+        step = int(os.environ.get("FX_FQ_PIPELINE_RANGE", 4 << 30)) & ~4095
+        if step < (1 << 16) or size < 2 * step or windows.plan(self.file_name, st.device, st.win_factor) is not None:
+            return False
+        R = -(-size // step)
+        try:
+            blob = _lib.Blob.from_file_async(self.file_name, st.device)
+        except _lib.FxError:
+            return False
+        views, jobs, laps = [], [], {}
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1)                  # the parts go into the writer in order, one after the other
+        w = None
+        try:
+            wait_room = os.environ.get("FX_FQ_PIPELINE_WAIT_ROOM", "0") != "0"
+            if wait_room:                                         # (experiment: nothing is written before all the room is there)
+                _lib.fxi_presize_end(tok)
+                tok = None
+            w = fxi.PartsWriter(self._index_file, 1, st.device, schema_done=True)
+            ptr = blob.device_ptr()
+            cores, prev = [], 10
+            for r in range(R):
+                a, e = r * step, min(size, (r + 1) * step)
+                halo = min(1 << 16, size - e)
+                while True:
+                    blob.stage_wait(e + halo)
+                    v = _lib.Blob.from_device(ptr + a, (e - a) + halo, st.device)
+                    v.set_shard(a, prev, e + halo >= size and halo == size - e)
+                    v.set_halo(halo)
+                    core = v.fastq_scan()
+                    ctx = shard.fastq_contexts(cores + [core])[r]
+                    try:
+                        v.fastq_build_ctx(*ctx)
+                        break
+                    except _lib.FxError as ex:                    # a read longer than the halo: the range with a larger one
+                        v.close()
+                        if ex.code != _lib.FX_ERANGE or halo >= size - e:
+                            raise
+                        halo = min(halo * 8, size - e)
+                cores.append(core)
+                if e < size:
+                    prev = v.read_bytes(e - 1, 1)[0]
+                views.append(v)
+                jobs.append(pool.submit(w.add_local, v, st.device))
+            blob.stage_wait(-1)
+            t_staged = time.perf_counter()
+            s = blob.fastq_build(comp=self._want_comp)            # the object's own table: one pass over the whole blob
+            t_ready = time.perf_counter()
+            scan_laps = _lib.build_laps()
+            for j in jobs:
+                j.result()
+            t_leaves = time.perf_counter()
+            if w.rows != int(s.n_reads):
+                raise RuntimeError("the ranges hold %d reads, the whole stream %d" % (w.rows, int(s.n_reads)))
+            _lib.fxi_presize_end(tok)                             # (the thread that made the room: done long ago)
+            tok = None
+            self._db = w.finish()
+            n, size_b = int(s.n_reads), int(s.size)
+            self._db.execute("INSERT INTO stat VALUES (?,?,?)", (n, size_b, size_b * 1.0 / n if n else float("nan")))     # fastq.c:161
+        except BaseException:
+            pool.shutdown(wait=True)
+            _lib.fxi_presize_end(tok, cancel=True)
+            for v in views:
+                v.close()
+            blob.close()
+            if w is not None:
+                w.abort()
+            elif os.path.exists(self._index_file):
+                os.remove(self._index_file)
+            raise
+        pool.shutdown(wait=True)
+        for v in views:
+            v.close()
+        st._blob = blob
+        if st.on_stage is not None:
+            st.on_stage(blob)
+        t_done = time.perf_counter()
+        self._host_tab = self._host_names = None
+        self.index_phases = dict(w.laps, table_leaves_done_after_staging_s=t_leaves - t_ready)
+        al, _ = _lib.open_laps()
+        self.build_phases = {"staging_s": t_staged - t_begin, "device_alloc_s": al, "page_cache_to_hbm_s": t_staged - t_begin - al, "scan_s": t_ready - t_staged,
+                             "index_ready_s": t_ready - t_begin, "fxi_s": t_done - t_ready, "fxi_durable_s": t_done - t_begin, "room_set_aside_early": True,
+                             "pipelined_ranges": R, "scan_laps_s": {k: round(v, 4) for k, v in scan_laps.items()}}
+        self._counts, self.size = int(s.n_reads), int(s.size)
+        self.avglen = self.size * 1.0 / self._counts if self._counts else float("nan")
+        keep = 0 < s.n_reads <= int(os.environ.get("FX_FQ_HOST_TABLE", 16_000_000))
+        if keep:
+            t = self._host_tab = blob.fastq_table(s.n_reads)
+            names, offs = blob.names_pack(1, s.n_reads, guess=int(np.maximum(t["name_len"], 0).astype(np.int64).sum()))
+            if names.nbytes <= (1 << 30):
+                self._host_names = (np.ascontiguousarray(names), offs)
+        return True
+
     def _create_index_body(self, presized, tok):
         t_begin = time.perf_counter()
+        if presized and self._create_index_pipelined(tok, t_begin):
+            return
         wq = self._st.md
         if presized and wq is not None:                       # (built in windows after all: that route writes its own file)
             _lib.fxi_presize_end(tok, cancel=True)

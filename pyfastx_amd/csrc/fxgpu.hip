@@ -363,9 +363,13 @@ struct Prof {
         (h)->prof.end((h)->stream);                                               \
     } while (0)
 
+struct StageAsync;                                         // (a file on its way to the device in the background: fx_open_file_async)
+static void stage_drop(fx_handle *h);
 struct fx_handle {
     int device = 0;
     hipStream_t stream = nullptr;
+    StageAsync *stage = nullptr;              // fx_open_file_async: the lanes that are still copying the file into the blob
+    int stage_fd = -1;
     // resident stream
     uint8_t *d_data = nullptr;
     uint8_t *d_alloc = nullptr;               // what is freed when owns (d_data points into it for a BGZF byte range)
@@ -514,6 +518,7 @@ static void free_blob(fx_handle *h) {
 extern "C" int fx_close(fx_handle *h) {
     if (!h) return FX_OK;
     (void)hipSetDevice(h->device);
+    stage_drop(h);                                           // (lanes of fx_open_file_async still copying into the blob)
     if (h->mb) {                                             // send the resident kernel home
         if (h->mb_running) {
             const unsigned long long q = ++h->mb_seq;
@@ -1131,6 +1136,52 @@ struct StageAsync {
     }
     ~StageAsync() { (void)finish(); }
 };
+
+static void stage_drop(fx_handle *h) {
+    if (h->stage) { (void)h->stage->finish(); delete h->stage; h->stage = nullptr; }
+    if (h->stage_fd >= 0) { close(h->stage_fd); h->stage_fd = -1; }
+}
+
+// A PLAIN file on its way to the device while the caller already works on what has landed (round 6): the blob is allocated,
+// the staging lanes start, the handle comes back at once.  The pieces land in file order; fx_stage_wait(h, upto) returns when
+// the first `upto` bytes are there (upto < 0: all of them, the lanes joined) -- only then may anything read them: a caller
+// builds on PREFIXES through views (fx_open_device on fx_device_ptr(h) + offset, fx_set_shard, fx_set_halo), as the sharded
+// build does on byte ranges, and calls nothing else on THIS handle before fx_stage_wait(h, -1).  What it buys: the table
+// leaves of an index file leave for the host (fx_fxi_part_leaves of the views) while later parts of the input still arrive
+// -- the link is full duplex, the reference's loop (fastq.c:8-182) knows neither direction.  gzip input: FX_EINVAL (fx_open_file).
+extern "C" int fx_open_file_async(const char *path, int device, fx_handle **out) {
+    if (!path || !out) return fail(FX_EINVAL, "null argument");
+    struct stat st;
+    if (stat(path, &st) != 0 || !S_ISREG(st.st_mode)) return fail(FX_ENOENT, "the input file %s does not exists", path);
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(FX_ENOENT, "cannot open %s", path);
+    unsigned char magic[4] = {0, 0, 0, 0};
+    if (pread(fd, magic, 4, 0) == 4 && magic[0] == 0x1f && magic[1] == 0x8b) { close(fd); return fail(FX_EINVAL, "%s is gzip-compressed: fx_open_file", path); }
+    fx_handle *h = nullptr;
+    int rc = new_handle(device, &h);
+    if (rc) { close(fd); return rc; }
+    const int64_t n = (int64_t)st.st_size;
+    const auto t0 = std::chrono::steady_clock::now();
+    if ((rc = alloc_blob(h, n)) || hipStreamSynchronize(h->stream) != hipSuccess) { close(fd); fx_close(h); return rc ? rc : fail(FX_EDEVICE, "stream sync failed"); }
+    g_open_laps[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    g_open_laps[1] = 0;
+    h->stage_fd = fd;
+    if (n > 0) {
+        h->stage = new StageAsync();
+        if ((rc = h->stage->start(h, fd, n, h->d_data, PIECE_BYTES))) { fx_close(h); return rc; }
+    }
+    *out = h;
+    return FX_OK;
+}
+extern "C" int fx_stage_wait(fx_handle *h, int64_t upto) {
+    if (!h) return fail(FX_EINVAL, "null handle");
+    if (!h->stage) return FX_OK;                             // nothing in flight
+    const int e = upto < 0 ? h->stage->finish() : h->stage->wait_until(std::min<int64_t>(upto, h->n));
+    if (upto < 0) stage_drop(h);
+    if (e == 1) return fail(FX_EIO, "read error on the input file");
+    if (e) return fail(FX_EDEVICE, "staging the input file to the device failed");
+    return FX_OK;
+}
 
 // A large BGZF file, the inflate running BEHIND the staging instead of after it (round 4).  The compressed bytes reach the
 // device at what the copy out of the page cache gives (~46 GB/s: 21 ms for C4's 0.97 GB) and the kernels of the whole file take

@@ -245,8 +245,11 @@ def _bulk_table_dev(path, blob, kind, ddl, table, index_sql, index_name, schema_
         db = connect(path)
         if not schema_done:
             db.executescript(ddl)
-        if not ndup:
+        have = db.execute("SELECT count(*) FROM sqlite_master WHERE name=?", (index_name,)).fetchone()[0]
+        if not ndup and not have:
             db.execute(index_sql)
+        elif ndup and have:                                   # (made early by presize_fastq(with_index=True); the names turned out not to be distinct)
+            db.execute("DROP INDEX %s" % index_name)
         root = dict(db.execute("SELECT name, rootpage FROM sqlite_master").fetchall())
         db.close()
         t2 = time.perf_counter()
@@ -296,7 +299,8 @@ class PartsWriter:
         db = connect(path)
         if not schema_done:
             db.executescript(ddl)
-        db.execute(self.index_sql)                            # (dropped again at the end if the names turn out not to be distinct)
+        if not db.execute("SELECT count(*) FROM sqlite_master WHERE name=?", (self.index_name,)).fetchone()[0]:
+            db.execute(self.index_sql)                        # (dropped again at the end if the names turn out not to be distinct)
         self.root = dict(db.execute("SELECT name, rootpage FROM sqlite_master").fetchall())
         self.first_new_page = int(db.execute("PRAGMA page_count").fetchone()[0]) + 1
         db.commit()
@@ -545,7 +549,7 @@ def estimate_fastq_index_bytes(path, full_name=False, head=1 << 19, places=8):
     return int(pages * 4096)
 
 
-def presize_fastq(path, input_path, full_name=False, device=-1):
+def presize_fastq(path, input_path, full_name=False, device=-1, with_index=False):
     """The index file of a LARGE plain FASTQ input created early -- schema in place -- and grown in the background to
     98.5 % of its estimated size while the input is staged (fx_fxi_presize_begin).  -> token for _lib.fxi_presize_end, or
     None when nothing was done (a small input, no estimate).  The caller removes the file if the build fails."""
@@ -563,6 +567,8 @@ def presize_fastq(path, input_path, full_name=False, device=-1):
         return None
     db = connect(path)
     db.executescript(FASTQ_DDL)
+    if with_index:                                            # (the pipelined build: nothing but pages is written while the room is being made)
+        db.execute(_KINDS[1][2])
     db.close()
     try:
         return _lib.fxi_presize_begin(path, int(est * 0.985), device)

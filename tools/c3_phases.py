@@ -60,13 +60,20 @@ def main():
     del tab, packed, offs, order
     out["ctor_runs"] = []
     for rep in range(int(os.environ.get("C3_REPS", 2))):
-        for mode in ("presize", "no_presize"):
+        # pipelined: the ranges of the input are indexed and their table leaves shipped while the rest still arrives (round 6);
+        # pipelined_wait_room: the same, nothing written before the whole index file is allocated; presize: one blob, one build
+        # (round 5); no_presize: and the index file grown only when its size is known
+        for mode in os.environ.get("C3_MODES", "pipelined,pipelined_wait_room,presize,no_presize").split(","):
             if os.path.exists(p):
                 os.unlink(p)
+            for k in ("FX_FXI_NO_PRESIZE", "FX_FQ_NO_PIPELINE", "FX_FQ_PIPELINE_WAIT_ROOM"):
+                os.environ.pop(k, None)
             if mode == "no_presize":
                 os.environ["FX_FXI_NO_PRESIZE"] = "1"
-            else:
-                os.environ.pop("FX_FXI_NO_PRESIZE", None)
+            elif mode == "presize":
+                os.environ["FX_FQ_NO_PIPELINE"] = "1"
+            elif mode == "pipelined_wait_room":
+                os.environ["FX_FQ_PIPELINE_WAIT_ROOM"] = "1"
             t0 = time.perf_counter()
             fq = fx.Fastq(path)
             t1 = time.perf_counter()

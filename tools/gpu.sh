@@ -9,6 +9,7 @@
 #   bench8         the driver's --gpus 8 command shape on this ONE device (gloo; all ranks share it)
 #   counters       rocprofv3 -L (the counter names of this box)
 #   valuprobe      tools/valuprobe.hip  (cycles per wave64 VALU instruction)
+#   firsttouch[:GB] tools/firsttouch.hip (the first host-to-device copy into fresh device memory, with and without a touching kernel)
 #   gathercal      tools/gathercal.hip under FETCH_SIZE and the raw request counters (calibration of the gather traffic)
 #   bgzf_pmc[:gbp] counter passes over the BGZF kernels, whole file in ONE launch (FX_BGZF_GROUP=0)
 #   bgzf_libs:gbp:lib[@K=V,...]:...   k_bgzf_* times for experiment builds (build/libfxgpu_*.so; pyfastx_amd/csrc/libfxgpu.so = the product)
@@ -46,6 +47,7 @@ for STEP in "$@"; do
   valuprobe)
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/valuprobe tools/valuprobe.hip 2> /dev/null && /tmp/valuprobe > $OUT/valuprobe.txt 2>&1
     python tools/mixprobe.py >> $OUT/valuprobe.txt 2>> $OUT/mixprobe.err; cat $OUT/valuprobe.txt ;;
+  firsttouch) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/firsttouch tools/firsttouch.hip 2> /dev/null && /tmp/firsttouch ${A1:-16} > $OUT/firsttouch.txt 2>&1; cat $OUT/firsttouch.txt ;;
   gathercal)
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-align-mismatch -o /tmp/gathercal tools/gathercal.hip 2> /dev/null
     /tmp/gathercal > $OUT/gathercal_known.txt 2>&1; cat $OUT/gathercal_known.txt
