@@ -1340,7 +1340,11 @@ class Fastq(_fxobj.FastqCore):
         11 ms), one sort of all names, the index leaves.  -> True; False when this route does not apply (then nothing was done)."""
         from . import shard, windows
         st = self._st
-        if st._blob is not None or st.windowed is None or os.environ.get("FX_FQ_NO_PIPELINE"):
+        # Off unless FX_FQ_PIPELINE=1.  Measured for C3 (10^8 reads, tools/c3_phases.py, two constructors each on one box): 1.32 / 1.58 s
+        # this way, 1.32 / 1.35 when nothing is written before the index file's room is all there, 1.36 / 1.11 with one blob and one
+        # build (round 5's route, the default): on this host the copy-out, the staging and the allocation of the file's pages share
+        # the memory bandwidth of one socket -- the staging slows from 0.63 to 0.73-0.97 s while leaves are written beside it.
+        if st._blob is not None or st.windowed is None or os.environ.get("FX_FQ_NO_PIPELINE") or os.environ.get("FX_FQ_PIPELINE", "0") == "0":
             return False
         size = os.path.getsize(self.file_name)
         step = int(os.environ.get("FX_FQ_PIPELINE_RANGE", 4 << 30)) & ~4095
@@ -1361,7 +1365,7 @@ class Fastq(_fxobj.FastqCore):
                 _lib.fxi_presize_end(tok)
                 tok = None
             w = fxi.PartsWriter(self._index_file, 1, st.device, schema_done=True)
-            ptr = blob.device_ptr()
+            ptr = int(blob.device_ptr)
             cores, prev = [], 10
             for r in range(R):
                 a, e = r * step, min(size, (r + 1) * step)

@@ -487,29 +487,47 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_rows(ScanCtx x, FqOwn own, FqTa
 #define FX_FQW_CAP 4096
 #endif
 constexpr int FQW_CAP = FX_FQW_CAP;
-template <int G, bool NT>
-__global__ __launch_bounds__(BLOCK) void k_fastq_rows_wg(ScanCtx x, FqOwn own, FqTab t, const uint32_t *__restrict__ recs, int64_t g_end) {
-    static_assert(G % (FQR_G * (BLOCK / 64)) == 0 && G <= 64, "whole runs per wave; six bits for the granule a staged record came from");
-    constexpr int RPW = G / FQR_G / (BLOCK / 64);                          // runs per wave
-    __shared__ uint32_t s_rec[FQW_CAP];
-    __shared__ uint32_t s_cum[G];
-    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
-    const int64_t g0 = (int64_t)blockIdx.x * G;
-    if (g0 >= g_end) return;
-    const int ng = (int)(g_end - g0 < G ? g_end - g0 : G);
-    uint32_t rr[RPW];
+// Round 6, measured and left at ONE group: FX_FQW_GROUPS groups of G granules per workgroup, one after the other, the loads of ALL
+// its groups (summaries, first 64 records of every run) issued before the first group is staged, so that the second group's round
+// trip to memory runs under the first group's staging and rows; one barrier per group + one between groups (the
+// staged records of a group are overwritten by the next).  C3, same box, k_fastq_rows: 1 group 1.52 ms, 2 groups 2.27, 3 groups
+// 2.36 (tools/fq_build_bench.py 1e8): half as many workgroups, each living twice as long with a barrier more -- what the waves wait
+// for is not the round trip of their loads (the persistent-grid form of round 4 had said the same).
+#ifndef FX_FQW_GROUPS
+#define FX_FQW_GROUPS 1
+#endif
+template <int G> struct FqwPre {                                           // what a wave asks for up front, per group
+    uint32_t rr[G / FQR_G / (BLOCK / 64)];
+    uint32_t M;
+    bool over;
+    int64_t L0, qp;
+    int ng;
+};
+template <int G>
+__device__ __forceinline__ void fqw_load(const ScanCtx &x, const FqOwn &own, const uint32_t *__restrict__ recs, int64_t g_end, int64_t g0, int lane, int w, FqwPre<G> &p) {
+    constexpr int RPW = G / FQR_G / (BLOCK / 64);
+    p.ng = g0 < g_end ? (int)(g_end - g0 < G ? g_end - g0 : G) : 0;
+    p.M = 0; p.over = false; p.L0 = 0; p.qp = -1;
 #pragma unroll
     for (int q = 0; q < RPW; ++q) {
         const int k0 = (w * RPW + q) * FQR_G;
-        rr[q] = k0 < ng ? recs[((g0 + k0) / FQR_G) * (int64_t)(FQR_G * FQL_CAP) + lane] : 0u;
+        p.rr[q] = k0 < p.ng ? recs[((g0 + k0) / FQR_G) * (int64_t)(FQR_G * FQL_CAP) + lane] : 0u;
     }
-    uint32_t M = 0;
-    bool over = false;
-    if (lane < ng) { M = x.go[g0 + lane].nh & 0xFFFFu; if (M > (uint32_t)FQL_CAP) { M = 0; over = true; } }
-    const int64_t L0 = own.loff + x.nl_prefix[g0];                         // global index of the workgroup's first line (asked for with the rest)
-    const int64_t qp = x.prevnl[g0];
-    const unsigned long long ob = __ballot(over);
-    const uint32_t incl = wave_incl_scan(M), excl = incl - M;              // lines of the workgroup's granules in front of granule `lane`
+    if (p.ng == 0) return;
+    if (lane < p.ng) { p.M = x.go[g0 + lane].nh & 0xFFFFu; if (p.M > (uint32_t)FQL_CAP) { p.M = 0; p.over = true; } }
+    p.L0 = own.loff + x.nl_prefix[g0];                                     // global index of the group's first line (asked for with the rest)
+    p.qp = x.prevnl[g0];
+}
+template <int G, bool NT>
+__device__ __forceinline__ void fqw_group(const ScanCtx &x, const FqOwn &own, const FqTab &t, const uint32_t *__restrict__ recs, int64_t g0,
+                                          const FqwPre<G> &p, uint32_t *s_rec, uint32_t *s_cum, int tid, int lane, int w) {
+    constexpr int RPW = G / FQR_G / (BLOCK / 64);
+    const int ng = p.ng;
+    if (ng == 0) return;                                                   // (the same for every thread of the workgroup, as every branch below that leaves early)
+    const uint32_t M = p.M;
+    const int64_t L0 = p.L0, qp = p.qp;
+    const unsigned long long ob = __ballot(p.over);
+    const uint32_t incl = wave_incl_scan(M), excl = incl - M;              // lines of the group's granules in front of granule `lane`
     const uint32_t Mtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if (ob || Mtot > (uint32_t)FQW_CAP) {                                  // one lane per line, granule by granule (the records of a run
         for (int k = w; k < ng; k += BLOCK / 64) {                          // stand one after the other in its slot, overflowed granules left out)
@@ -539,7 +557,7 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_rows_wg(ScanCtx x, FqOwn own, F
         if (k0 + 3 >= ng) c3 = ~0u;
         const uint32_t *rslot = recs + ((g0 + k0) / FQR_G) * (int64_t)(FQR_G * FQL_CAP);
         for (uint32_t i = lane; i < cnt; i += 64) {
-            const uint32_t r = i < 64u ? rr[q] : rslot[i];
+            const uint32_t r = i < 64u ? p.rr[q] : rslot[i];
             const uint32_t at = base + i;
             const uint32_t k = (uint32_t)k0 + (at >= c1 ? 1u : 0u) + (at >= c2 ? 1u : 0u) + (at >= c3 ? 1u : 0u);
             s_rec[at] = (r & 0x03FFFFFFu) | (k << 26);
@@ -549,8 +567,8 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_rows_wg(ScanCtx x, FqOwn own, F
     __syncthreads();
     if (!Mtot) return;
     const int64_t gs0 = x.gbase + g0 * (int64_t)GRAN;
-    const int64_t qq0 = qp < 0 ? own.prev_nl : qp;                         // the newline before the workgroup's first line
-    const int64_t rb = L0 >> 2, re = (L0 + Mtot - 1) >> 2;                 // rows the workgroup's lines touch
+    const int64_t qq0 = qp < 0 ? own.prev_nl : qp;                         // the newline before the group's first line
+    const int64_t rb = L0 >> 2, re = (L0 + Mtot - 1) >> 2;                 // rows the group's lines touch
     for (int64_t row = rb + tid; row <= re; row += BLOCK) {
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) {
@@ -564,6 +582,23 @@ __global__ __launch_bounds__(BLOCK) void k_fastq_rows_wg(ScanCtx x, FqOwn own, F
             if (j) { const uint32_t rp = s_rec[j - 1]; q = gs0 + (int64_t)(rp >> 26) * GRAN + (rp & 0xFFFu); }
             fq_row_of_line<NT>(x, own, t, gs, j == s_cum[k], r & 0x03FFFFFFu, q, L0 + j);
         }
+    }
+}
+template <int G, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_fastq_rows_wg(ScanCtx x, FqOwn own, FqTab t, const uint32_t *__restrict__ recs, int64_t g_end) {
+    static_assert(G % (FQR_G * (BLOCK / 64)) == 0 && G <= 64, "whole runs per wave; six bits for the granule a staged record came from");
+    __shared__ uint32_t s_rec[FQW_CAP];
+    __shared__ uint32_t s_cum[G];
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const int64_t g0 = (int64_t)blockIdx.x * (G * FX_FQW_GROUPS);
+    if (g0 >= g_end) return;
+    FqwPre<G> pre[FX_FQW_GROUPS];
+#pragma unroll
+    for (int grp = 0; grp < FX_FQW_GROUPS; ++grp) fqw_load<G>(x, own, recs, g_end, g0 + (int64_t)grp * G, lane, w, pre[grp]);
+#pragma unroll
+    for (int grp = 0; grp < FX_FQW_GROUPS; ++grp) {
+        if (grp) __syncthreads();                                          // (the rows of the group before have read their staged records)
+        fqw_group<G, NT>(x, own, t, recs, g0 + (int64_t)grp * G, pre[grp], s_rec, s_cum, tid, lane, w);
     }
 }
 

@@ -2511,7 +2511,7 @@ static int fastq_records(fx_handle *h, int64_t loff, int64_t prev_nl, fx_fastq_s
             // granules per workgroup: as many as leave the lines of a workgroup under FQW_CAP staged records with room to spare
             const double lpg = (double)h->n_nl / (double)h->ngran;
             static const bool nt = [] { const char *e = getenv("FX_FQ_ROWS_NT"); return e && atoi(e) != 0; }();
-#define FX_ROWS_WG(G, NT) FX_LAUNCH(h, K_FASTQ_ROWS, (k_fastq_rows_wg<G, NT>), dim3(nblocks(h->ngran - 1, G)), dim3(BLOCK), scan_ctx(h), pl.own, fastq_tab(h), h->fq_lines.p, h->ngran - 1)
+#define FX_ROWS_WG(G, NT) FX_LAUNCH(h, K_FASTQ_ROWS, (k_fastq_rows_wg<G, NT>), dim3(nblocks(h->ngran - 1, G * FX_FQW_GROUPS)), dim3(BLOCK), scan_ctx(h), pl.own, fastq_tab(h), h->fq_lines.p, h->ngran - 1)
             if (lpg * 64 <= 0.75 * FQW_CAP) { if (nt) FX_ROWS_WG(64, true); else FX_ROWS_WG(64, false); }
             else if (lpg * 32 <= 0.75 * FQW_CAP) { if (nt) FX_ROWS_WG(32, true); else FX_ROWS_WG(32, false); }
             else { if (nt) FX_ROWS_WG(16, true); else FX_ROWS_WG(16, false); }

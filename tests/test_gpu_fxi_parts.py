@@ -143,6 +143,37 @@ def test_windows_of_a_stream_larger_than_its_budget(fx, tmp_path, monkeypatch):
     assert fq[123_456].seq == fx.Fastq(str(tmp_path / "single.fq"))[123_456].seq
 
 
+def test_ranges_of_a_file_that_is_still_being_staged(fx, tmp_path, monkeypatch):
+    """Fastq(path) of a large plain file: staged in the background (fx_open_file_async), indexed range by range through views of
+    the blob as the bytes land, the table leaves of a range on their way to the index file while the next ranges arrive.  Small
+    ranges here (1 MiB; 4 GiB by default) and one read of 300 KB, longer than the 64 KiB halo of a range: its range is taken
+    again with a larger one.  Rows, stat, names in order and reads equal the one-blob build's."""
+    big = b"@long one\n" + b"ACGT" * 75_000 + b"\n+\n" + b"I" * 300_000 + b"\n"
+    raw = _fastq(60_000, 21) + big + _fastq(60_000, 22).replace(b"@SRR8539271.", b"@SRR8539272.")
+    monkeypatch.setenv("FX_FXI_DEV_MIN", "0")
+    monkeypatch.setenv("FX_FXI_PRESIZE_MIN", "0")
+    p1 = tmp_path / "one.fq"
+    p1.write_bytes(raw)
+    monkeypatch.setenv("FX_FQ_NO_PIPELINE", "1")
+    one = fx.Fastq(str(p1))
+    assert "pipelined_ranges" not in one.build_phases
+    want = _whole(str(p1) + ".fxi")
+    monkeypatch.delenv("FX_FQ_NO_PIPELINE")
+    monkeypatch.setenv("FX_FQ_PIPELINE", "1")                   # (off by default: no gain on the bench host, DESIGN 6.1)
+    monkeypatch.setenv("FX_FQ_PIPELINE_RANGE", str(1 << 20))
+    p2 = tmp_path / "ranges.fq"
+    p2.write_bytes(raw)
+    fq = fx.Fastq(str(p2))
+    assert fq.build_phases.get("pipelined_ranges", 0) >= 8 and fq.index_phases is not None
+    got = _whole(str(p2) + ".fxi")
+    assert got["check"] == [(b"ok",)] and got["index"] == ["readidx"]
+    assert got["read"] == want["read"] and got["stat"] == want["stat"] and got["by_name"] == want["by_name"]
+    assert len(fq) == len(one) == 120_001
+    for i in (0, 59_999, 60_000, 60_001, 120_000):
+        assert fq[i].seq == one[i].seq and fq[i].qual == one[i].qual and fq[i].name == one[i].name
+    assert fq["long"].id == 60_001 and len(fq["long"].seq) == 300_000
+
+
 # ---------------------------------------------------------------------------------- one process per rank, gloo, one GPU
 def _free_port():
     s = socket.socket()

@@ -66,8 +66,10 @@ def main():
         for mode in os.environ.get("C3_MODES", "pipelined,pipelined_wait_room,presize,no_presize").split(","):
             if os.path.exists(p):
                 os.unlink(p)
-            for k in ("FX_FXI_NO_PRESIZE", "FX_FQ_NO_PIPELINE", "FX_FQ_PIPELINE_WAIT_ROOM"):
+            for k in ("FX_FXI_NO_PRESIZE", "FX_FQ_NO_PIPELINE", "FX_FQ_PIPELINE_WAIT_ROOM", "FX_FQ_PIPELINE"):
                 os.environ.pop(k, None)
+            if mode.startswith("pipelined"):
+                os.environ["FX_FQ_PIPELINE"] = "1"
             if mode == "no_presize":
                 os.environ["FX_FXI_NO_PRESIZE"] = "1"
             elif mode == "presize":
