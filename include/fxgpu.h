@@ -111,7 +111,7 @@ int fx_set_shard(fx_handle *h, int64_t base, int prev_byte, int is_last);
 
 int fx_close(fx_handle *h);
 /* Scratch of an open (compressed bytes of a BGZF file, its match map: hundreds of MB for tens of milliseconds) and, since
- * round 4, the blob of a closed handle are kept in a per-process pool for the next open (FX_SCRATCH_CACHE_MB, default 8192:
+ * round 4, the blob of a closed handle are kept in a per-process pool for the next open (FX_SCRATCH_CACHE_MB, default 24576:
  * the driver clears memory it hands out or takes back, 20 ms per 3 GB in the way of the next open's copies; the library
  * empties the pool by itself before a device allocation fails).  This gives the idle blocks back to the driver now.
  * Blobs LARGER than that whole limit (the 35 GB of a sequencing run) are kept too when their handle closes -- freeing one
@@ -500,6 +500,12 @@ int fx_fxi_bulk_index_int(const char *path, int rootpage, int64_t n, const int64
  *                     database this loader can extend (other page size, reserved bytes, auto-vacuum). */
 int fx_fxi_dev_sort(fx_handle *h, int kind, int64_t *n_dup);
 int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int root_table, int root_index, double *laps);
+/* Both in one call (round 6), the sort and the shape of the index computed BESIDE the copy-out of the table's leaves (a second
+ * stream, a second thread: the device is idle while 6 GB of pages cross PCIe).  The schema must hold the empty UNIQUE INDEX
+ * already (root_index >= 2) -- whether the names are distinct is only known when the sort is done: *n_dup > 0 means no index
+ * was written and the caller drops the empty one (fastq.c:152-156 / index.c:363-366 ignore the failed CREATE UNIQUE INDEX).
+ * laps as fx_fxi_dev_write, [4] = what of sort + index shape the table's copy-out did NOT hide. */
+int fx_fxi_dev_build(fx_handle *h, int kind, const char *path, int root_table, int root_index, int64_t *n_dup, double *laps);
 /* Room for those pages set aside while the stream is still being staged: `path` = the database SQLite has just created
  * (schema in place, no open connection); a thread of the library grows the file to `bytes` with fallocate (on tmpfs the
  * allocation of 10 GB takes 0.6 s and must not run beside the stores into the file; beside the staging it costs nothing);

@@ -49,7 +49,7 @@ SYMBOLS = [
     "fx_set_shard", "fx_close", "fx_release_scratch", "fx_pinned_alloc", "fx_pinned_free", "fx_pinned_holds", "fx_pinned_trim", "fx_size", "fx_device_memory", "fx_is_gzip", "fx_device_ptr", "fx_read_bytes", "fx_first_byte",
     "fx_fasta_build", "fx_fasta_build_begin", "fx_fasta_build_end", "fx_fasta_table", "fx_fasta_set_table", "fx_fasta_line_regular", "fx_fasta_len_stats", "fx_fasta_comp", "fx_fasta_comp_shard", "fx_fasta_comp_sparse", "fx_fastq_build", "fx_fastq_build_comp", "fx_fastq_comp_info", "fx_set_halo", "fx_fastq_scan", "fx_fastq_build_ctx", "fx_fastq_table", "fx_fastq_comp",
     "fx_fetch_ranges", "fx_fetch_slices", "fx_fetch_one", "fx_fasta_fetch", "fx_fasta_fetch_alloc", "fx_fetch_phases", "fx_fastq_fetch", "fx_fastq_fetch_alloc", "fx_names_build", "fx_names_lookup", "fx_names_sort", "fx_names_pack", "fx_revcomp", "fx_shard_summary_get",
-    "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_fxi_dev_sort", "fx_fxi_dev_write", "fx_fxi_presize_begin", "fx_fxi_presize_end", "fx_fxi_part_shape", "fx_fxi_part_firsts", "fx_fxi_part_names", "fx_fxi_part_leaves", "fx_fxi_join_grow", "fx_fxi_join_begin", "fx_fxi_join_write", "fx_fxi_join_end", "fx_scratch_policy", "fx_open_file_async", "fx_stage_wait", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
+    "fx_fasta_set_row", "fx_shard_route", "fx_shard_summary_dev", "fx_fasta_stitch_dev", "fx_stream", "fx_read_fetch", "fx_gz_points", "fx_fxi_bulk_rows", "fx_fxi_bulk_index", "fx_fxi_bulk_index_int", "fx_fxi_dev_sort", "fx_fxi_dev_write", "fx_fxi_dev_build", "fx_fxi_presize_begin", "fx_fxi_presize_end", "fx_fxi_part_shape", "fx_fxi_part_firsts", "fx_fxi_part_names", "fx_fxi_part_leaves", "fx_fxi_join_grow", "fx_fxi_join_begin", "fx_fxi_join_write", "fx_fxi_join_end", "fx_scratch_policy", "fx_open_file_async", "fx_stage_wait", "fx_sync", "fx_prof_default", "fx_prof_enable", "fx_prof_reset", "fx_prof_count", "fx_prof_name", "fx_prof_read",
     "fx_comm_unique_id", "fx_comm_init", "fx_comm_destroy", "fx_comm_rank", "fx_comm_world", "fx_comm_allgather", "fx_fasta_build_sharded_begin",
     "fx_fasta_build_sharded", "fx_comm_summaries", "fx_fastq_build_sharded", "fx_bgzf_counts", "fx_sort_packed_names", "fx_gunzip_parallel", "fx_gz_open_mode", "fx_kseq_scan", "fx_kseq_records", "fx_kseq_fetch", "fx_kseq_prefix_lines",
 ]
@@ -244,6 +244,7 @@ def lib():
     L.fx_fastq_comp_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
     L.fx_fxi_dev_sort.argtypes = [vp, i32, C.POINTER(C.c_int64)]
     L.fx_fxi_dev_write.argtypes = [vp, i32, C.c_char_p, i32, i32, C.POINTER(C.c_double)]
+    L.fx_fxi_dev_build.argtypes = [vp, i32, C.c_char_p, i32, i32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.fx_fxi_presize_begin.argtypes = [C.c_char_p, i64, i32, C.POINTER(vp)]
     L.fx_fxi_presize_end.argtypes = [vp, i32]
     L.fx_fxi_part_shape.argtypes = [vp, i32, i64, C.POINTER(C.c_int64)]
@@ -903,6 +904,16 @@ class Blob:
         laps = (C.c_double * 2)()
         check(lib().fx_fxi_part_leaves(self._h, int(kind), os.fsencode(path), int(first_new_page), int(leaf_base), laps))
         return {"table_kernels": float(laps[0]), "table_to_file": float(laps[1])}
+
+    def fxi_dev_build(self, kind, path, root_table, root_index):
+        """fxi_dev_sort + fxi_dev_write in one call, the sort and the index shape beside the table's copy-out (fx_fxi_dev_build)
+        -> (n_dup, phases in seconds); n_dup > 0: the table alone was written, drop the empty index."""
+        laps = (C.c_double * 8)()
+        nd = C.c_int64(0)
+        check(lib().fx_fxi_dev_build(self._h, int(kind), os.fsencode(path), int(root_table), int(root_index), C.byref(nd), laps))
+        d = dict(zip(self.FXI_LAPS, (float(x) for x in laps)))
+        d["sort_and_index_shape_not_hidden"] = d.pop("index_shape")
+        return int(nd.value), d
 
     def names_sort(self, kind, n):
         """-> (order int64[n], n_dup): sorted order of the n record names (BINARY collation) computed on the GPU."""

@@ -120,8 +120,8 @@ template <class T> struct DevBuf {      // grow-only device array: rebuilds reus
 
 // Scratch of an open (the compressed bytes of a BGZF file, its match map, ...): hundreds of MB that live for tens of
 // milliseconds.  hipFree waits for the device and unmaps -- 20 ms for 1.4 GB -- and the hipMalloc of the next open maps
-// again, so released blocks are kept (per device, up to FX_SCRATCH_CACHE_MB, default 16384 since round 5 -- the temporaries of a
-// 10^8-read index file are 5 GB on top of what the opens before left --; 0 = off) and handed to the
+// again, so released blocks are kept (per device, up to FX_SCRATCH_CACHE_MB, default 24576 since round 6 -- the temporaries of a
+// 10^8-read index file with its sort are 14 GB on top of what the opens before left --; 0 = off) and handed to the
 // next request they fit (at most twice its size).
 // Which of a device's LARGE idle blocks (each larger than the whole FX_SCRATCH_CACHE_MB limit: the blobs of closed streams)
 // stay when one more of `cap` bytes comes back, `keep` bytes of them allowed in all: the new block stays if it fits beside
@@ -163,7 +163,7 @@ struct ScratchPool {
     // its GPU (several ranks on one device) call fx_release_scratch after closing large files, or set FX_SCRATCH_KEEP_BIG_MB=0.
     std::vector<Block> big;
     size_t held = 0;
-    const size_t limit = [] { const char *e = getenv("FX_SCRATCH_CACHE_MB"); return (size_t)(e ? std::max(0, atoi(e)) : 16384) << 20; }();
+    const size_t limit = [] { const char *e = getenv("FX_SCRATCH_CACHE_MB"); return (size_t)(e ? std::max(0, atoi(e)) : 24576) << 20; }();
     const double big_ttl = [] { const char *e = getenv("FX_SCRATCH_BIG_TTL_S"); return e ? atof(e) : 300.0; }();
     int64_t keep_big(int dev) {
         if (const char *e = getenv("FX_SCRATCH_KEEP_BIG_MB")) return (int64_t)std::max(0ll, atoll(e)) << 20;
@@ -370,6 +370,8 @@ struct fx_handle {
     hipStream_t stream = nullptr;
     StageAsync *stage = nullptr;              // fx_open_file_async: the lanes that are still copying the file into the blob
     int stage_fd = -1;
+    hipStream_t stream2 = nullptr;            // a second stream for work beside the handle's own (fx_fxi_dev_build's sort); made on first use, kept:
+                                              // hipStreamDestroy behind the munmap of a 10 GB mapping waited 214 ms for the process's mm lock
     // resident stream
     uint8_t *d_data = nullptr;
     uint8_t *d_alloc = nullptr;               // what is freed when owns (d_data points into it for a BGZF byte range)
@@ -528,6 +530,7 @@ extern "C" int fx_close(fx_handle *h) {
         (void)hipHostFree(h->mb);
     }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); h->stream2 = nullptr; }
     h->fxi_order.release();                                  // (back to the pool while the stream it names still exists)
     h->fxi_soff.release(); h->fxi_slen.release();
     h->fxi_part_first.release();
@@ -4156,6 +4159,16 @@ static void fxi_grow_and_map(fxi::DbFile &db, uint32_t new_npages, int device, f
     struct stat st;
     const off_t size_now = fstat(db.fd, &st) == 0 ? st.st_size : db.size0;     // (other parts may have grown the file since it was opened)
     const bool presized = size_now >= end;
+    static const bool by_pwrite = [] { const char *e = getenv("FX_FXI_PWRITE"); return e && atoi(e) != 0; }();
+    if (by_pwrite) {
+        // (experiment, round 6) no mapping at all: the pages go into the file with pwrite -- the kernel copies into the page cache,
+        // no page-table entries are made for 2.5 M pages and none have to be taken down again (the munmap of a 10 GB mapping holds
+        // the process's mm lock for ~0.2 s, whoever needs it next waits: measured as a 214 ms hipStreamDestroy).  The room is
+        // allocated here all the same.
+        const off_t have = std::max(from, size_now & ~(off_t)(FXI_PAGE - 1));
+        if (!presized && have < end && !getenv("FX_FXI_NO_FALLOCATE")) (void)fallocate(db.fd, 0, have, end - have);
+        return;
+    }
     if (presized || map.open(db.fd, (size_t)end)) {
         if (presized) { void *m = mmap(nullptr, (size_t)end, PROT_READ | PROT_WRITE, MAP_SHARED, db.fd, 0); if (m != MAP_FAILED) { map.p = (uint8_t *)m; map.len = (size_t)end; } }
         // (only what a pre-sized file lacks: fallocate over pages that exist still visits every one of them, 0.2 us each)
@@ -4327,6 +4340,168 @@ extern "C" int fx_fxi_dev_write(fx_handle *h, int kind, const char *path, int ro
                        lap_buf[1] * 1e3, lap_buf[2] * 1e3, lap_buf[5] * 1e3, lap_buf[6] * 1e3, lap_buf[7] * 1e3);
     return done(FX_OK);
 #undef FXI_CHK
+}
+
+// fx_fxi_dev_sort + fx_fxi_dev_write in ONE call, with the sort and the shape of the index computed BESIDE the copy-out of the
+// table's leaves (round 6): the name sort (40 ms for 10^8 reads), the entry sizes, the fill and the dividers (17 ms) run on a
+// second stream in a second thread while the table's 6 GB of pages cross PCIe -- the device is idle then, the link is not.
+// The schema must hold the empty UNIQUE INDEX already (root_index): whether the names are distinct is only known when the
+// sort is done -- *n_dup > 0: no index was written, the caller drops the empty one (fastq.c:152-156 / index.c:363-366 ignore the
+// failure of CREATE UNIQUE INDEX).  laps[8] as fx_fxi_dev_write, [4] = what of sort + index shape was NOT hidden.
+extern "C" int fx_fxi_dev_build(fx_handle *h, int kind, const char *path, int root_table, int root_index, int64_t *n_dup, double *laps) {
+    int rc = fxi_check_kind(h, kind);
+    if (rc) return rc;
+    if (!path || !n_dup || root_table < 2 || root_index < 2) return fail(FX_EINVAL, "bad argument");
+    *n_dup = 0;
+    const int64_t n = kind == 0 ? h->n_hdr : h->n_reads;
+    if (n >= 0xFFFFFFFFll) return fail(FX_ERANGE, "too many records");
+    double lap_buf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    auto done = [&](int code) { (void)hipStreamSynchronize(h->stream); if (laps) memcpy(laps, lap_buf, sizeof lap_buf); return code; };
+    static const bool trace = [] { const char *e = getenv("FX_TRACE"); return e && atoi(e) != 0; }();
+    const auto T00 = now();
+    auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[fxgpu] fxi build %-34s %8.1f ms\n", what, secs(T00, now()) * 1e3); };
+    if (n == 0) return done(FX_OK);
+    FxiJob T;                                                // the table
+    T.device = h->device; T.stream = h->stream; T.data = h->d_data; T.n = n;
+    fxi_cols(h, kind, &T.c);
+    if ((rc = T.init())) return done(rc);
+    const auto t0 = now();
+    fxi::DbFile db;
+    {
+        const int e = db.open_rw(path, (uint32_t)root_table);
+        if (e == fxi::E_IO) return done(fail(FX_EIO, "cannot open %s", path));
+        if (e || db.pagesize != FXI_PAGE || db.usable != FXI_PAGE || (uint32_t)root_index > db.npages)
+            return done(fail(FX_EINVAL, "%s is not a SQLite database this loader can extend (4 KiB pages, no reserved bytes)", path));
+    }
+    // ---- the other thread: order of the names, shape of the index, dividers
+    FxiJob I;
+    I.device = h->device; I.data = h->d_data; I.n = n;
+    fxi_cols(h, kind, &I.c);
+    ScratchBuf<int64_t> order, soff, first_i, noff_fa;
+    ScratchBuf<int32_t> slen;
+    int64_t ndup = 0, nleaf_i = 0, nd = 0;
+    std::vector<int64_t> d_rowid(1), d_off(1, 0);
+    std::vector<uint8_t> d_names(1);
+    fxi::IndexUpper up;
+    int rc_i = FX_OK;
+    if (!h->stream2) HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    const hipStream_t s2 = h->stream2;
+    I.stream = s2;
+    double t_side = 0;
+    std::thread side([&]() {
+        const auto a = now();
+        auto work = [&]() -> int {
+            if (hipSetDevice(h->device) != hipSuccess) return fail(FX_EDEVICE, "hipSetDevice failed");
+            int r;
+            const int64_t *noff = I.c.name_off;
+            if (kind == 0) {                                 // FASTA: the names begin one byte behind the header offsets
+                if ((r = noff_fa.alloc(h->device, n, s2))) return r;
+                hipLaunchKernelGGL(k_add_i64, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, s2, h->hdr.p, (int64_t)1, n, noff_fa.p);
+                noff = noff_fa.p;
+            }
+            ScratchBuf<int64_t> d_nd;
+            if ((r = order.alloc(h->device, n, s2)) || (r = soff.alloc(h->device, n, s2)) || (r = slen.alloc(h->device, n, s2)) || (r = d_nd.alloc(h->device, 1, s2))) return r;
+            const char *what = "";
+            const int e = sort_names(h->d_data, h->base, noff, I.c.name_len, n, order.p, d_nd.p, s2, &what, soff.p, slen.p);
+            if (e) return fail(e == (int)hipErrorOutOfMemory ? FX_ENOMEM : FX_EDEVICE, "name sort, %s: %s", what, hipGetErrorString((hipError_t)e));
+            if (hipMemcpyAsync(&ndup, d_nd.p, 8, hipMemcpyDeviceToHost, s2) != hipSuccess || hipStreamSynchronize(s2) != hipSuccess) return fail(FX_EDEVICE, "the name sort failed");
+            if (ndup) return FX_OK;
+            I.order = order.p; I.c.s_off = soff.p; I.c.s_len = slen.p;
+            if ((r = I.init())) return r;
+            I.index_sizes();
+            if ((r = I.leaf_level(true, first_i, &nleaf_i))) return r;
+            nd = nleaf_i - 1;
+            if ((r = I.dividers(first_i.p, nd, d_rowid, d_off, d_names))) return r;
+            const fxi::Entries dv{nd, d_names.data(), d_off.data(), nullptr, nullptr, d_rowid.data()};
+            if (!up.plan((size_t)nleaf_i, dv, FXI_PAGE)) return fail(FX_ERANGE, "an index entry does not fit an interior page: use CREATE INDEX");
+            return FX_OK;
+        };
+        rc_i = work();
+        t_side = secs(a, now());
+    });
+    auto join_side = [&]() { if (side.joinable()) side.join(); };
+    auto bail = [&](int code) { join_side(); (void)hipStreamSynchronize(s2); return done(code); };
+    // ---- this thread: the table
+    ScratchBuf<int64_t> first_t;
+    int64_t nleaf_t = 0;
+    T.table_sizes();
+    if ((rc = T.leaf_level(false, first_t, &nleaf_t))) return bail(rc);
+    std::vector<int64_t> lf((size_t)nleaf_t + 1);
+    if (hipMemcpyAsync(lf.data(), first_t.p, (size_t)(nleaf_t + 1) * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+        return bail(fail(FX_EDEVICE, "the first rows of the table's leaves"));
+    const auto t1 = now();
+    lap_buf[0] = secs(t0, t1);
+    mark("table shape");
+    const uint64_t tot_t = nleaf_t > 1 ? fxi::table_new_pages((size_t)nleaf_t, fxi::table_fan(FXI_PAGE)) : 0;
+    const fxi::PageSeq seq(db.npages + 1, FXI_PAGE);
+    if (tot_t && (uint64_t)seq.at(tot_t - 1) >= 0xFFFFFFF0ull) return bail(fail(FX_ERANGE, "the index file would exceed 2^32 pages"));
+    fxi::FileMap map;
+    uint32_t new_npages = db.npages;
+    if (tot_t) { new_npages = seq.at(tot_t - 1); fxi_grow_and_map(db, new_npages, h->device, map); }
+    const auto t2 = now();
+    lap_buf[3] = secs(t1, t2);
+    mark("room for the table");
+    std::atomic<int> host_bad(0);
+    std::thread th_t;
+    if (nleaf_t > 1)
+        th_t = std::thread([&]() { if (!fxi::table_interior(db.fd, map, FXI_PAGE, FXI_PAGE, (uint32_t)root_table, seq, lf.data(), (size_t)nleaf_t, tot_t)) host_bad.store(1); });
+    if (nleaf_t == 1) rc = T.root_leaf(false, first_t.p, db.fd, root_table, path);
+    else rc = T.leaves_out(false, nleaf_t, first_t.p, seq, 0, db.fd, map, &lap_buf[1], &lap_buf[2]);
+    mark("table leaves out");
+    if (th_t.joinable()) th_t.join();
+    mark("table interior joined");
+    const auto t3 = now();
+    join_side();
+    lap_buf[4] = secs(t3, now());                            // what of the sort and the index shape the table's copy-out did not hide
+    if (!rc) rc = rc_i;
+    bool ok = !host_bad.load();
+    // ---- the index, if the names are distinct
+    *n_dup = ndup;
+    if (!rc && ok && !ndup) {
+        const uint64_t tot_i = nleaf_i > 1 ? (uint64_t)nleaf_i + up.pages : 0;
+        const fxi::Entries dv{nd, d_names.data(), d_off.data(), nullptr, nullptr, d_rowid.data()};
+        const fxi::PageSeq seq_i(tot_t ? seq.at(tot_t) : db.npages + 1, FXI_PAGE);
+        if (tot_i) {
+            if ((uint64_t)seq.at(tot_t + tot_i - 1) >= 0xFFFFFFF0ull) rc = fail(FX_ERANGE, "the index file would exceed 2^32 pages");
+            else {
+                const auto g0 = now();
+                new_npages = seq.at(tot_t + tot_i - 1);
+                fxi::FileMap map2;
+                fxi_grow_and_map(db, new_npages, h->device, map2);
+                lap_buf[3] += secs(g0, now());
+                std::thread th_i([&]() { if (!up.write(db.fd, map2, FXI_PAGE, FXI_PAGE, (uint32_t)root_index, seq_i, (size_t)nleaf_i, dv)) host_bad.store(1); });
+                std::swap(I.slab.p, T.slab.p); std::swap(I.slab.cap_bytes, T.slab.cap_bytes);      // (the table's slab is free: one 4 GiB block for both trees)
+                std::swap(I.slab.dev, T.slab.dev); I.slab.stream = s2;
+                mark("room for the index");
+                rc = I.leaves_out(true, nleaf_i, first_i.p, seq_i, 0, db.fd, map2, &lap_buf[5], &lap_buf[6]);
+                mark("index leaves out");
+                th_i.join();
+                mark("index upper levels joined");
+                fxi_unmap_later(map2);
+            }
+        } else if (nleaf_i == 1)
+            rc = I.root_leaf(true, first_i.p, db.fd, root_index, path);
+        if (host_bad.load()) ok = false;
+    }
+    const auto t4 = now();
+    fxi_unmap_later(map);
+    if (!rc && ok) ok = db.finish(new_npages);
+    if (!rc && ok && db.size0 > (off_t)new_npages * FXI_PAGE) ok = ftruncate(db.fd, (off_t)new_npages * FXI_PAGE) == 0;     // a pre-sized file: cut to what was used
+    if (rc || !ok) db.give_back();
+    lap_buf[7] = secs(t4, now());
+    mark("header, file cut");
+    (void)hipStreamSynchronize(s2);
+    mark("second stream idle");
+    order.release(); soff.release(); slen.release(); first_i.release(); noff_fa.release();
+    I.sz.release(); I.pages.release(); I.bad.release(); I.sums.release(); I.pbase.release(); I.slab.release();
+    mark("buffers back in the pool");
+    if (trace) fprintf(stderr, "[fxgpu] fxi build: %lld rows, %lld + %lld leaves; sort + index shape %.1f ms beside the table's copy-out, %.1f ms of it not hidden\n",
+                       (long long)n, (long long)nleaf_t, (long long)nleaf_i, t_side * 1e3, lap_buf[4] * 1e3);
+    if (rc) return done(rc);
+    if (!ok) return done(fail(FX_EIO, "cannot write %s", path));
+    return done(FX_OK);
 }
 
 // ------------------------------------------------------------------ ONE .fxi from SEVERAL handles (round 6)

@@ -231,45 +231,37 @@ def _bulk_table(path, ddl, table, index_sql, index_name, packed_names, name_off,
 
 
 def _bulk_table_dev(path, blob, kind, ddl, table, index_sql, index_name, schema_done=False):
-    """_bulk_table with the pages formatted ON THE DEVICE (Blob.fxi_dev_sort / fxi_dev_write, csrc/fx_fxi_dev.hpp): the
-    record table, the names and their sorted order stay in HBM, only finished pages come to the file.  Duplicate names:
-    the table alone is written and SQLite is asked for the index, whose failure is ignored (index.c:363-366,
-    fastq.c:152-156).  schema_done: the file exists with the tables of `ddl` in it (presize_fastq).  Returns (open
+    """_bulk_table with the pages formatted ON THE DEVICE (Blob.fxi_dev_build, csrc/fx_fxi_dev.hpp): the record table, the
+    names and their sorted order stay in HBM, only finished pages come to the file; the names are sorted while the table's
+    leaves cross PCIe.  Duplicate names: the table alone is written and the empty index dropped again -- the reference ignores
+    the failure of CREATE UNIQUE INDEX (index.c:363-366, fastq.c:152-156).  schema_done: the file exists with the tables of `ddl` in it (presize_fastq).  Returns (open
     connection, phases in seconds); on FX_ERANGE / FX_EINVAL (a row that needs an overflow page, a database that does not
     have 4 KiB pages) the file is removed and the error re-raised -- the caller falls back to the host loaders."""
     import time
     t0 = time.perf_counter()
     try:
-        ndup = blob.fxi_dev_sort(kind)
-        t1 = time.perf_counter()
         db = connect(path)
         if not schema_done:
             db.executescript(ddl)
-        have = db.execute("SELECT count(*) FROM sqlite_master WHERE name=?", (index_name,)).fetchone()[0]
-        if not ndup and not have:
-            db.execute(index_sql)
-        elif ndup and have:                                   # (made early by presize_fastq(with_index=True); the names turned out not to be distinct)
-            db.execute("DROP INDEX %s" % index_name)
+        if not db.execute("SELECT count(*) FROM sqlite_master WHERE name=?", (index_name,)).fetchone()[0]:
+            db.execute(index_sql)                             # (the empty index; dropped below if the names are not distinct)
         root = dict(db.execute("SELECT name, rootpage FROM sqlite_master").fetchall())
+        db.commit()
         db.close()
+        t1 = time.perf_counter()
+        ndup, laps = blob.fxi_dev_build(kind, path, root[table], root[index_name])      # the sort runs beside the table's copy-out
         t2 = time.perf_counter()
-        laps = blob.fxi_dev_write(kind, path, root[table], 0 if ndup else root[index_name])
-        t3 = time.perf_counter()
     except BaseException:
         if os.path.exists(path):
             os.remove(path)
         raise
     db = connect(path)
     db.execute("PRAGMA synchronous = OFF")
-    if ndup:
-        try:
-            db.execute(index_sql)
-        except sqlite3.Error:
-            pass
-    laps["name_sort"] = t1 - t0
-    laps["sqlite_schema"] = t2 - t1
-    laps["write_call"] = t3 - t2
-    laps["sqlite_reopen"] = time.perf_counter() - t3
+    if ndup:                                                  # CREATE UNIQUE INDEX would have failed, and the reference ignores that
+        db.execute("DROP INDEX %s" % index_name)
+    laps["sqlite_schema"] = t1 - t0
+    laps["write_call"] = t2 - t1
+    laps["sqlite_reopen"] = time.perf_counter() - t2
     return db, laps
 
 
