@@ -952,6 +952,9 @@ static int bgzf_inflate_staged(fx_handle *h, const uint8_t *d_cp, const int64_t 
     constexpr int SYM_ROWS = 2048;
     int per_cu = 0, n_cu = 256;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, par_kernel, 64, par_lds) != hipSuccess || per_cu <= 0) per_cu = 8;
+    // (the LDS of a workgroup is handed out in steps: 14 880 bytes were reported as 11 workgroups per CU and 10 were resident -- the
+    // persistent grid's eleventh wave per CU then ran alone after the others, doubling the kernel's time; round 6)
+    per_cu = std::min<int>(per_cu, (int)((160 * 1024) / ((par_lds + 1023) & ~(size_t)1023)));
     { const char *e = getenv("FX_BGZF_WAVES_PER_CU"); if (e && atoi(e) > 0) per_cu = std::min(per_cu, atoi(e)); }      // experiments: fewer members in flight than fit
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
     const unsigned par_grid = (unsigned)std::min<int64_t>(nmem, (int64_t)per_cu * n_cu);
