@@ -5,6 +5,7 @@
 #   pytest:<file>[:<file>...]  some test files (-m gpu)
 #   tests          pytest -m gpu                           smoke       __graft_entry__.smoke()
 #   bench          the driver's default bench line, timed  prof        the same command under rocprofv3 --kernel-trace --stats
+#   bench_c3full   the bench with the reference on the WHOLE configs[2] file (10^8 reads: ~3 minutes of one core)
 #   bench_c4full   the bench with ALL 1 M queries of the C4 leg answered by the reference too (builder-run evidence)
 #   bench8         the driver's --gpus 8 command shape on this ONE device (gloo; all ranks share it)
 #   counters       rocprofv3 -L (the counter names of this box)
@@ -14,7 +15,8 @@
 #   bgzf_pmc[:gbp] counter passes over the BGZF kernels, whole file in ONE launch (FX_BGZF_GROUP=0)
 #   bgzf_libs:gbp:lib[@K=V,...]:...   k_bgzf_* times for experiment builds (build/libfxgpu_*.so; pyfastx_amd/csrc/libfxgpu.so = the product)
 #   bgzf_dbg[:gbp] the phase probes of k_bgzf_decode_par (FX_BGZF_DBG=8 / 1 / 2 / 4: header+tables / +A / +A2 / +B without stores)
-#   pmc_fq[:n]     counters + traffic of the FASTQ build kernels    pmc_fxi[:n]  of the page formatter    pmc_fetch  of the gather kernels
+#   pmc_fq[:n] pmc_fq_one[:n] pmc_fqcomp[:n] pmc_comp[:filter] pmc_fetch pmc_fxi[:n]   the standing counter passes (traffic, SQ, TCC) of a probe
+#   prof_fastx     kernel trace of the kseq walk (tools/fastx_scale.py), default and walk-only
 #   py:<script>:args...   any tools/*.py probe, stdout to <script>.json
 TAG=${1:-run}; shift
 OUT=gpurun_out/$TAG
@@ -41,6 +43,7 @@ for STEP in "$@"; do
     DB=$(find $OUT/prof -name '*.db' | head -1)
     [ -n "$DB" ] && python tools/rocprof_summary.py $DB $OUT/kernel_stats.txt && grep 'fx::' $OUT/kernel_stats.txt | head -80
     rm -rf $OUT/prof ;;
+  bench_c3full) ( time timeout 2700 python bench.py --c3-reference-full --no-c4 > $OUT/bench_c3full.json 2> $OUT/bench_c3full.err ) 2> $OUT/bench_c3full.time; cat $OUT/bench_c3full.time; python -c "import json; d=json.loads([l for l in open('$OUT/bench_c3full.json') if l.startswith('{')][-1]); print(json.dumps(d['c3']['e2e_full'])[:3500])" ;;
   bench_c4full) ( time timeout 2400 python bench.py --c4-reference-full --no-c3 > $OUT/bench_c4full.json 2> $OUT/bench_c4full.err ) 2> $OUT/bench_c4full.time; cat $OUT/bench_c4full.time; python -c "import json; d=json.loads([l for l in open('$OUT/bench_c4full.json') if l.startswith('{')][-1]); print(json.dumps(d['c4'])[:3000])" ;;
   bench8) ( time FX_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 > $OUT/bench8.json 2> $OUT/bench8.err ) 2> $OUT/bench8.time; cat $OUT/bench8.time; python -c "import json,sys; d=json.loads([l for l in open('$OUT/bench8.json') if l.startswith('{')][-1]); print(json.dumps(d.get('fastq_strong')))"; tail -3 $OUT/bench8.err ;;
   counters) rocprofv3 -L > $OUT/counters.txt 2>&1; grep -c . $OUT/counters.txt ;;
@@ -78,14 +81,33 @@ for STEP in "$@"; do
     export FX_PROBE_FILE=/tmp/c4_probe.fa.gz FX_BGZF_GROUP=0
     for d in 8 1 2 4 5; do FX_BGZF_DBG=$d python tools/bgzf_decode_probe.py ${A1:-3.0} 2>&1 | grep "dbg=" | tail -1; done | tee $OUT/bgzf_dbg.txt
     unset FX_BGZF_GROUP ;;
-  pmc_fq) bash tools/gpu_pmc_fq_one.sh $TAG/pmc_fq_traffic ${A1:-2e7} > $OUT/pmc_fq_traffic.log 2>&1; bash tools/gpu_pmc_fq_one_sq.sh $TAG/pmc_fq_sq ${A1:-2e7} > $OUT/pmc_fq_sq.log 2>&1; tail -24 $OUT/pmc_fq_sq.log ;;
-  pmc_fxi)
-    P="python tools/fxi_pmc_probe.py ${A1:-2e7}"
-    pmc_pass fxi_fetch k_fxi $P -- FETCH_SIZE
-    pmc_pass fxi_write k_fxi $P -- WRITE_SIZE
-    pmc_pass fxi_sq k_fxi $P -- SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD
-    for n in fxi_fetch fxi_write fxi_sq; do echo "-- $n"; tail -6 $OUT/$n.txt; done ;;
-  pmc_fetch) bash tools/gpu_pmc_fetch.sh $TAG/pmc_fetch > $OUT/pmc_fetch.log 2>&1; tail -30 $OUT/pmc_fetch.log ;;
+  pmc_fq|pmc_fq_one|pmc_fqcomp|pmc_comp|pmc_fetch|pmc_fxi)
+    # the standing counter passes of a probe, one rocprofv3 run per set (counters in runs of their own, kernel trace only):
+    #   pmc_fq[:n]      tools/fq_build_bench.py   k_fastq        pmc_fq_one[:n]  tools/fq_one_probe.py  k_fastq (one-read build)
+    #   pmc_fqcomp[:n]  tools/fq_comp_probe.py    k_fastq_comp   pmc_comp        bench.py (2 steps)     k_fasta_comp / k_scan_comp / k_span_scan
+    #   pmc_fetch       tools/fetch_probe.py      fetch          pmc_fxi[:n]     tools/fxi_pmc_probe.py k_fxi
+    case $S in
+      pmc_fq) P="python tools/fq_build_bench.py ${A1:-2e7}"; F=k_fastq ;;
+      pmc_fq_one) P="python tools/fq_one_probe.py ${A1:-2e7}"; F=k_fastq ;;
+      pmc_fqcomp) P="python tools/fq_comp_probe.py ${A1:-1e7}"; F=k_fastq_comp ;;
+      pmc_comp) P="python bench.py --no-pmc --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-c3 --no-c4"; F=${A1:-k_} ;;
+      pmc_fetch) P="python tools/fetch_probe.py 3.0 2e7"; F=fetch ;;
+      pmc_fxi) P="python tools/fxi_pmc_probe.py ${A1:-2e7}"; F=k_fxi ;;
+    esac
+    pmc_pass ${S}_fetch $F $P -- FETCH_SIZE
+    pmc_pass ${S}_write $F $P -- WRITE_SIZE
+    pmc_pass ${S}_sq $F $P -- SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
+    pmc_pass ${S}_sq2 $F $P -- SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM
+    pmc_pass ${S}_tcc $F $P -- TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum
+    for n in fetch write sq sq2 tcc; do echo "-- $n"; awk 'NR%3==1' $OUT/${S}_$n.txt | tail -8 | cut -c1-400; done ;;
+  prof_fastx)
+    for MODE in default walk_only; do
+      if [ $MODE = walk_only ]; then export FX_KSEQ_WALK_ONLY=1; else unset FX_KSEQ_WALK_ONLY; fi
+      timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_$MODE -o trace -- python tools/fastx_scale.py > $OUT/$MODE.json 2> $OUT/$MODE.err
+      DB=$(find $OUT/prof_$MODE -name '*.db' | head -1)
+      [ -n "$DB" ] && python tools/rocprof_summary.py $DB $OUT/kernel_stats_$MODE.txt && grep 'k_kq\|^kernel' $OUT/kernel_stats_$MODE.txt
+      rm -rf $OUT/prof_$MODE
+    done ;;
   py) timeout 1200 python tools/$A1 $A2 $A3 $A4 $A5 $A6 > $OUT/${A1%.py}.json 2> $OUT/${A1%.py}.err; tail -3 $OUT/${A1%.py}.json | cut -c1-2500; tail -2 $OUT/${A1%.py}.err ;;
   *) echo "unknown step $S" ;;
   esac
