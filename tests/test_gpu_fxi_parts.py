@@ -103,6 +103,43 @@ def test_logical_ranks_write_the_single_device_rows(fx, tmp_path, monkeypatch, w
         r.blob.close()
 
 
+def test_fasta_table_through_the_parts_route(fx, tmp_path, monkeypatch):
+    """kind 0 (`seq`, `chromidx`; index.c:178-207, 239-251, 363): one handle as the only part of a PartsWriter writes what the
+    single-device route writes -- seven integer columns of every width, names one byte behind the header offsets."""
+    from pyfastx_amd import _lib, fxi
+    rng = np.random.default_rng(8)
+    lens = [0, 1, 127, 128, 40_000] + rng.integers(0, 600, 30_000).tolist()
+    raw = b"".join(b">rec%d some description %d\n" % (i, i) + b"\n".join(bytes(rng.choice(list(b"ACGTN"), min(60, L - a)).astype(np.uint8)) for a in range(0, L, 60)) + (b"\n" if L else b"")
+                   for i, L in enumerate(lens))
+    monkeypatch.setenv("FX_FXI_DEV_MIN", "0")
+    p1 = tmp_path / "one.fa"
+    p1.write_bytes(raw)
+    fa = fx.Fasta(str(p1))
+    assert fa.index_phases is not None
+    db = _db(str(p1) + ".fxi")
+    want = db.execute("SELECT * FROM seq ORDER BY ID").fetchall()
+    want_names = [r[0] for r in db.execute("SELECT chrom FROM seq INDEXED BY chromidx ORDER BY chrom")]
+    db.close()
+    p2 = tmp_path / "parts.fa"
+    p2.write_bytes(raw)
+    b = _lib.Blob.from_file(str(p2))
+    s = b.fasta_build()
+    w = fxi.PartsWriter(str(p2) + ".fxi", 0, 0)
+    assert w.add_local(b) == s.n_seq == len(lens)
+    out = w.finish()
+    out.execute("INSERT INTO stat (seqnum,seqlen) VALUES (?,?)", (int(s.n_seq), int(s.seq_len)))
+    out.commit()
+    out.close()
+    b.close()
+    db = _db(str(p2) + ".fxi")
+    assert db.execute("PRAGMA integrity_check").fetchall() == [(b"ok",)]
+    assert db.execute("SELECT * FROM seq ORDER BY ID").fetchall() == want
+    assert [r[0] for r in db.execute("SELECT chrom FROM seq INDEXED BY chromidx ORDER BY chrom")] == want_names
+    db.close()
+    fb = fx.Fasta(str(p2))
+    assert len(fb) == len(lens) and fb["rec4"].seq == fa["rec4"].seq and fb[len(lens) - 1].name == fa[len(lens) - 1].name
+
+
 def test_duplicate_names_leave_no_index(fx, tmp_path, monkeypatch):
     from pyfastx_amd import shard
     raw = _fastq(20_000, 9, dup=True)
