@@ -1240,7 +1240,8 @@ class Fastq(_fxobj.FastqCore):
             def windowed(plan, me=me, path=file_name, dev=device):
                 from .windows import WindowedFastq
                 fq = me()
-                return WindowedFastq(path, dev, window=plan[2], capacity=plan[3], want_comp=bool(fq is not None and fq._want_comp))
+                return WindowedFastq(path, dev, window=plan[2], capacity=plan[3], want_comp=bool(fq is not None and fq._want_comp),
+                                     index_file=(fq._index_file if fq is not None and _dev_index_applies(fq._index_file) else None))
             self._st.windowed = windowed
             if devices is not None and len(devices) > 1:
                 def forced(me=me, path=file_name, devs=list(devices)):
@@ -1316,7 +1317,14 @@ class Fastq(_fxobj.FastqCore):
         # a large plain file: the index file is created now and grows to its estimated size while the input is staged
         # (fxi.presize_fastq; the pages that fill it are formatted on the device once the table exists)
         tok = None
-        if not self.is_gzip and _dev_index_applies(self._index_file) and self._st.forced is None and not os.environ.get("FX_FXI_NO_PRESIZE"):
+        fits = True
+        if not self.is_gzip and self._st.windowed is not None and self._st._blob is None:
+            from . import windows
+            try:                                              # (a stream built in windows writes its own file, range by range: no early file)
+                fits = windows.plan(self.file_name, self._st.device, self._st.win_factor) is None
+            except _lib.FxError:
+                fits = True
+        if fits and not self.is_gzip and _dev_index_applies(self._index_file) and self._st.forced is None and not os.environ.get("FX_FXI_NO_PRESIZE"):
             try:
                 tok = fxi.presize_fastq(self._index_file, self.file_name, device=self._st.device, with_index=True)     # (the index holds names cut at the first white space whatever full_name says: fastq.c:112-117)
             except Exception:                                 # noqa: BLE001  (no early file: the build makes it -- and must find none)
@@ -1450,12 +1458,15 @@ class Fastq(_fxobj.FastqCore):
             presized = False
         if wq is not None:                                    # larger than the HBM it may use: built window after window (windows.WindowedFastq)
             self._db = None
-            if wq.n_reads and self._index_file != ":memory:" and not os.path.exists(self._index_file):
+            riding = getattr(wq, "_writer", None) is not None and wq._writer.path == self._index_file      # (the ranges' leaves are in that file already)
+            if wq.n_reads and self._index_file != ":memory:" and (riding or not os.path.exists(self._index_file)):
                 try:
                     self._db = wq.write_index(self._index_file)
                 except _lib.FxError:
                     self._db = None
             if self._db is None:
+                if riding and os.path.exists(self._index_file):   # (a writer that gave up removes its file; one that was never asked does not)
+                    os.remove(self._index_file)
                 nm, no = wq.names.tobytes(), wq.name_off.tolist()
                 self._db = fxi.connect(self._index_file)
                 fxi.write_fastq(self._db, [nm[no[i]:no[i + 1]] for i in range(wq.n_reads)], wq.table, wq.size)

@@ -266,7 +266,11 @@ class WindowedFastq:
 
     HALO0 = 1 << 16
 
-    def __init__(self, path, device=0, window=None, capacity=None, want_comp=False, devices=None):
+    def __init__(self, path, device=0, window=None, capacity=None, want_comp=False, devices=None, index_file=None):
+        """index_file: where the .fxi will go (a path that does not exist yet).  The table leaves of every range are then formatted
+        and written WHILE THE RANGE IS RESIDENT for its build (fxi.PartsWriter.add_local) -- a stream larger than its budget is
+        staged once, not once for the build and once more for the index file -- and write_index only has the names to sort and
+        the index to write."""
         size, kind = _lib.stream_size(path)
         if kind == 2:
             raise ValueError("%s is a single gzip stream: it cannot be staged by byte range" % path)
@@ -287,8 +291,17 @@ class WindowedFastq:
         self.ctx = [None] * W
         parts = [None] * W
         comps = [None] * W
+        self._writer = None
+        if index_file and index_file != ":memory:" and not os.path.exists(index_file) and not os.environ.get("FX_FXI_HOST"):
+            from . import fxi
+            try:
+                self._writer = fxi.PartsWriter(index_file, 1, devices[0])
+            except (_lib.FxError, OSError):
+                self._writer = None
         if len(devices) > 1 or (capacity or 2) >= W > 1:
             self._build_resident(bounds, parts, comps)
+            for w in range(W):                                  # (all ranges are resident: their leaves in order)
+                self._part_to_index(w, self.cache.lru[w])
         else:
             cores = []
             for w in range(W):                                  # one pass: a range needs only the counts of the ranges before it
@@ -296,6 +309,7 @@ class WindowedFastq:
                 cores.append(core)
                 self.ctx[w] = shard.fastq_contexts(cores)[w]
                 parts[w], comps[w] = self._build_range(w, b)
+                self._part_to_index(w, self.cache.get(w))       # (the range as _build_range left it: opened again if its halo had to grow)
         self.table = {k: np.concatenate([p[k] for p in parts]) for k in ("dlen", "rlen", "soff", "qoff")}
         self.names = np.concatenate([p["names"] for p in parts]) if parts else np.zeros(0, dtype=np.uint8)
         shift = np.concatenate([[0], np.cumsum([int(p["name_off"][-1]) for p in parts])]).astype(np.int64)
@@ -313,6 +327,17 @@ class WindowedFastq:
             self.comp = finish_fastq_comp(base_sum, meta)
         self.blobs = _LazyBlobs(self.cache, W)
         self.blob = WindowedBlob(self.blobs, self.bases, self.ends, np.zeros(0, dtype=np.int32))
+
+    def _part_to_index(self, w, blob):
+        """The table leaves of range w into the index file while the range is resident; its names to the writer's device."""
+        if self._writer is None:
+            return
+        try:
+            self._writer.add_local(blob, device=self.cache.device_of(w))
+        except _lib.FxError as e:                                # (the writer has removed its file: write_index takes the other routes)
+            self._writer = None
+            if e.code not in (_lib.FX_ERANGE, _lib.FX_EINVAL, _lib.FX_ENOMEM):
+                raise
 
     # ---- the steps of one range
     def _open_scan(self, w, halo):
@@ -409,10 +434,15 @@ class WindowedFastq:
         without 4 KiB pages): the host page loader from the merged host arrays, as before."""
         from . import fxi
         try:
-            w = fxi.PartsWriter(index_file, 1, self.device)
-            for r in range(self.windows):
-                if self.first_id[r + 1] > self.first_id[r]:
-                    w.add_local(self._built(r), device=self.cache.device_of(r))
+            w, self._writer = self._writer, None
+            if w is not None and (w.path != index_file or w.rows != int(self.n_reads)):
+                w.abort()
+                w = None
+            if w is None:                                         # (no writer rode along with the build: the ranges once more, staged again where they were evicted)
+                w = fxi.PartsWriter(index_file, 1, self.device)
+                for r in range(self.windows):
+                    if self.first_id[r + 1] > self.first_id[r]:
+                        w.add_local(self._built(r), device=self.cache.device_of(r))
             db = w.finish()
             self.index_laps = dict(w.laps)
             n = int(self.n_reads)

@@ -174,6 +174,7 @@ def test_windows_of_a_stream_larger_than_its_budget(fx, tmp_path, monkeypatch):
     fq = fx.Fastq(str(p))
     wq = fq._st.md
     assert wq is not None and wq.windows >= 4 and "index_kernels" in getattr(wq, "index_laps", {})      # in windows, pages from the device
+    assert wq.cache.staged == wq.windows                          # every range staged ONCE: its leaves were written while it was resident for the build
     got = _whole(str(p) + ".fxi")
     assert got["check"] == [(b"ok",)] and got["index"] == ["readidx"]
     assert got["read"] == want["read"] and got["stat"] == want["stat"] and got["by_name"] == want["by_name"]
