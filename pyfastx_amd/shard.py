@@ -831,7 +831,8 @@ class ShardedFastq:
         """ONE .fxi for the whole file, every page of its two big b-trees formatted on a device (fxi.PartsWriter, round 6; round 5
         sent every rank's table and names to rank 0 through files and let the host page loader format them: 15 M rows/s).
         Collective over the ranks of the build:
-          1. fx_fxi_part_shape on every rank; ONE all-gather of three integers per rank (rows, table leaves, bytes of names);
+          1. fx_fxi_part_shape on every rank; ONE all-gather of five integers per rank (rows, table leaves, bytes of names, an
+             overflow flag, bases);
           2. rank 0 creates the database and, in a thread, makes room for all its pages (table + estimated index);
           3. every rank posts its names to rank 0 (point to point: RCCL over xGMI on GPUs, gloo through the host in tests);
              an all-gather of three words tells everybody where the new pages begin, and every rank formats ITS table

@@ -258,3 +258,42 @@ def test_one_process_per_rank_over_gloo(fx, tmp_path, monkeypatch, world, n):
     got = _whole(out)
     assert got["check"] == [(b"ok",)] and got["index"] == ["readidx"]
     assert got["read"] == want["read"] and got["stat"] == want["stat"] and got["by_name"] == want["by_name"]
+
+
+def test_large_idle_blocks_come_and_go(tmp_path):
+    """The scratch pool's rule for the blobs of closed streams, on the device (csrc/fxgpu.hip: ScratchPool; the rule itself is pinned on
+    the CPU: test_large_idle_blocks_policy).  With a 1 MiB pool limit every blob of these files is "large": four sizes opened and
+    closed in turn under a cap of 64 MiB (the 48 MiB block pushes smaller ones out, a 100 MiB one is never kept), a time to live of
+    50 ms, then everything given back -- every byte read back equals the file's, before and after."""
+    import subprocess
+    code = r'''
+import os, sys, time
+sys.path.insert(0, %r)
+import numpy as np
+from pyfastx_amd import _lib
+rng = np.random.default_rng(3)
+files = []
+for k, mb in enumerate((8, 16, 48, 100, 12)):
+    p = os.path.join(%r, "f%%d.fa" %% k)
+    body = rng.integers(65, 91, mb << 20, dtype=np.uint8)
+    body[60::61] = 10
+    raw = b">r%%d\n" %% k + body.tobytes() + b"\n"
+    open(p, "wb").write(raw)
+    files.append((p, raw))
+for rnd in range(3):
+    for p, raw in files:
+        b = _lib.Blob.from_file(p)
+        n = len(raw)
+        assert b.size == n and b.read_bytes(0, 4096) == raw[:4096] and b.read_bytes(n - 5000, 5000) == raw[-5000:]
+        assert b.fasta_build().n_seq == 1
+        b.close()
+    if rnd == 1:
+        time.sleep(0.12)                                    # past the time to live: the next call into the pool gives the idle blocks back
+_lib.lib().fx_release_scratch()
+b = _lib.Blob.from_file(files[2][0]); assert b.read_bytes(100, 100) == files[2][1][100:200]; b.close()
+print("ok")
+''' % (os.path.dirname(HERE), str(tmp_path))
+    env = dict(os.environ, FX_SCRATCH_CACHE_MB="1", FX_SCRATCH_KEEP_BIG_MB="64", FX_SCRATCH_BIG_TTL_S="0.05", FX_TRACE_ALLOC="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+    assert "scratch full: hipFree" in out.stderr             # blocks did leave the pool (cap, time to live)
