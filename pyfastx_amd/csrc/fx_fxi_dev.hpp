@@ -85,6 +85,13 @@ __device__ __forceinline__ uint8_t *fxi_put_name(uint8_t *q, const uint8_t *__re
 #pragma unroll
         for (int j = 0; j < 16; ++j) q[k + j] = (uint8_t)(w[j >> 2] >> ((j & 3) * 8));
     }
+    if (k < L && L >= 16) {                                  // the last 1..15 bytes: the 16 bytes that END with the name, once more
+        const uint4 v = *reinterpret_cast<const uint4_u *>(src + L - 16);      // (one load; a loop of byte loads is a chain of
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};                             // up to fifteen round trips per lane)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) q[L - 16 + j] = (uint8_t)(w[j >> 2] >> ((j & 3) * 8));
+        return q + L;
+    }
     for (; k < L; ++k) q[k] = src[k];
     return q + L;
 }

@@ -6,11 +6,13 @@
 // the order is an LSD radix sort over them in place: the names are cut into 8-byte big-endian chunks (zero padded),
 // a permutation is stable-sorted by name length first and then by chunk  ceil(maxlen/8)-1, ..., 1, 0; after the last
 // pass it is ordered by (chunk 0, chunk 1, ..., length) = memcmp order with the shorter name first on a tie, which is
-// SQLite's BINARY collation.  Each chunk gathers one 8-byte key per name through the current permutation (a random
-// 8-byte read per name) and sorts the (key, index) pairs by it with up to eight stable 8-bit counting passes
-// (k_rs_hist / k_rs_scan / k_rs_scatter below); a pass whose digit is the same in every key -- the shared prefix of
-// sequencer read names -- is detected from its histogram and skipped.  A final kernel compares neighbours to count
-// duplicate names.  The permutation goes to fx_fxi_bulk_index, which writes the index b-tree from it.
+// SQLite's BINARY collation.  The chunks of all names are written once (k_sort_chunks), together with the OR and the AND of
+// every chunk over all names: the bits in which names DIFFER.  Only those are sorted by -- they are packed, up to 64 at a
+// time and across chunk borders, into the key of a round (k_sort_gather: a random 8-byte read per name and chunk touched),
+// and the (key, index) pairs are sorted with stable 8-bit counting passes (k_rs_hist / k_rs_scan / k_rs_scatter below).
+// The shared prefix of sequencer read names costs nothing and an ASCII digit four bits: the 31-byte names of C3 are
+// 72 bits = 9 passes where whole chunks took 18 (plus 14 histograms that found a constant digit).  A final kernel compares
+// neighbours to count duplicate names.  The permutation goes to the index kernels of fx_fxi_dev.hpp.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <vector>
@@ -47,24 +49,147 @@ __global__ __launch_bounds__(SB) void k_sort_init(const int32_t *__restrict__ na
 // other (a line per name whatever the number of chunks); the passes below then fetch ONE 8-byte key per name through the
 // permutation.  (Round 5 went to the stream in every pass: name_off[r], name_len[r] and the bytes, three dependent random
 // reads per name and chunk -- 6.9 ms per chunk for 10^8 names, 21 of the sort's 51 ms.)
+// OR and AND of every chunk over all names: a bit that is equal in both is the same in every name.  A workgroup keeps its own
+// pair of words per chunk in LDS (a lane goes to the LDS atomic only with a bit the words do not show yet: after the first few
+// names nobody does), walks over several tiles and leaves its words in part[workgroup][chunk][2]; k_sort_orand folds them.
+// (Global atomics on ONE pair of words per chunk, guarded by a load of them: 3 of the kernel's 6.5 ms for 10^8 names -- the
+// L2 of an XCD keeps the line as it first saw it, so the guard never learns; read coherently the words are a hot spot: 8.7 ms.)
+// Names of more than SORT_LDS_CHUNKS chunks (4 KiB) take the global atomics.
+constexpr int SORT_LDS_CHUNKS = 512;
 __global__ __launch_bounds__(SB) void k_sort_chunks(const uint8_t *__restrict__ data, int64_t gbase, const int64_t *__restrict__ name_off,
-                                                    const int32_t *__restrict__ name_len, int64_t n, int nchunk, uint64_t *__restrict__ kc) {
-    const int64_t i = (int64_t)blockIdx.x * SB + threadIdx.x;
-    if (i >= n) return;
-    const int len = name_len[i] > 0 ? name_len[i] : 0;
-    const uint8_t *p = data + (name_off[i] - gbase);
-    for (int c = 0; c < nchunk; ++c) {
+                                                    const int32_t *__restrict__ name_len, int64_t n, int nchunk, uint64_t *__restrict__ kc,
+                                                    unsigned long long *__restrict__ part, unsigned long long *orand) {
+    // one thread per (name, chunk), the chunks of a name in neighbouring lanes: one load instruction per wave reads 64 / nchunk
+    // names, a name's lanes share its line (a thread per name issued nchunk loads over 64 different lines each: 8.2 ms for 10^8 names)
+    __shared__ unsigned long long s_or[SORT_LDS_CHUNKS], s_and[SORT_LDS_CHUNKS];
+    const bool local = nchunk <= SORT_LDS_CHUNKS;
+    if (local) {
+        for (int x = threadIdx.x; x < nchunk; x += SB) { s_or[x] = 0ull; s_and[x] = ~0ull; }
+        __syncthreads();
+    }
+    const int64_t ntiles = (n * nchunk + SB - 1) / SB;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t t0 = tile * SB;                      // (the 64-bit division once per tile, on the scalar unit)
+        const int64_t i0 = t0 / nchunk;
+        const uint32_t x = (uint32_t)(t0 - i0 * nchunk) + threadIdx.x;
+        const int64_t i = i0 + x / (uint32_t)nchunk;
+        if (i >= n) continue;
+        const int c = (int)(x % (uint32_t)nchunk);
+        const int len = name_len[i] > 0 ? name_len[i] : 0;
+        const uint8_t *p = data + (name_off[i] - gbase);
         const int rest = len - 8 * c;
         uint64_t k = 0;
         if (rest >= 8) k = __builtin_bswap64(*reinterpret_cast<const u64_unal *>(p + 8 * c));
-        else if (rest > 0) for (int b = 0; b < rest; ++b) k |= (uint64_t)p[8 * c + b] << (56 - 8 * b);
+        else if (rest > 0 && len >= 8) k = __builtin_bswap64(*reinterpret_cast<const u64_unal *>(p + len - 8)) << (8 * (8 - rest));   // the 8 bytes that end with the name
+        else if (rest > 0) for (int b = 0; b < rest; ++b) k |= (uint64_t)p[b] << (56 - 8 * b);
         kc[(int64_t)c * n + i] = k;
+        if (local) {
+            if (k & ~s_or[c]) atomicOr(&s_or[c], (unsigned long long)k);
+            if (~k & s_and[c]) atomicAnd(&s_and[c], (unsigned long long)k);
+        } else {
+            if (k & ~orand[2 * c]) atomicOr(&orand[2 * c], (unsigned long long)k);
+            if (~k & orand[2 * c + 1]) atomicAnd(&orand[2 * c + 1], (unsigned long long)k);
+        }
+    }
+    if (local) {
+        __syncthreads();
+        unsigned long long *mine = part + (int64_t)blockIdx.x * nchunk * 2;
+        for (int x = threadIdx.x; x < nchunk; x += SB) { mine[2 * x] = s_or[x]; mine[2 * x + 1] = s_and[x]; }
     }
 }
-__global__ __launch_bounds__(SB) void k_sort_gather(const uint64_t *__restrict__ kc, const uint32_t *__restrict__ vals, int64_t n,
+// one workgroup per chunk: the words of all workgroups of k_sort_chunks -> orand[2c], orand[2c + 1]
+__global__ __launch_bounds__(SB) void k_sort_orand(const unsigned long long *__restrict__ part, int nblk, int nchunk, unsigned long long *__restrict__ orand) {
+    __shared__ unsigned long long w_or[SB / 64], w_and[SB / 64];
+    const int c = blockIdx.x;
+    unsigned long long o = 0ull, a = ~0ull;
+    for (int b = threadIdx.x; b < nblk; b += SB) { o |= part[((int64_t)b * nchunk + c) * 2]; a &= part[((int64_t)b * nchunk + c) * 2 + 1]; }
+    for (int d = 32; d; d >>= 1) { o |= __shfl_xor(o, d); a &= __shfl_xor(a, d); }
+    if ((threadIdx.x & 63) == 0) { w_or[threadIdx.x >> 6] = o; w_and[threadIdx.x >> 6] = a; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < SB / 64; ++q) { o |= w_or[q]; a &= w_and[q]; }
+        orand[2 * c] = o; orand[2 * c + 1] = a;
+    }
+}
+
+// The key of one round of passes: up to 64 of the bits that DIFFER between names, taken from one or more chunks and packed
+// without the bits every name shares (`SYN:1:FC:1:` costs nothing, an ASCII digit four bits instead of eight).  Dropping bits
+// that are equal everywhere keeps the order of any two keys, so sorting by the packed groups, least significant first, is
+// sorting by the chunks.  A run = `width` consecutive bits of chunk `chunk` from bit `lo`, placed at bit `dst` of the key.
+constexpr int SORT_RUNS = 64;                             // a run is at least one bit: a group is full by its bits before it is by its runs
+struct SortGroup { int n, bits; uint32_t run[SORT_RUNS]; };      // run: chunk (16 bits) | lo << 16 (6) | (width - 1) << 22 (6); dst = the widths before it
+constexpr int SORT_PACK_GROUPS = 32;                      // groups per launch of k_sort_pack (their descriptions lie in LDS)
+
+// The packed keys of ALL names, once, in record order and IN PLACE: the m-th most significant group goes where chunk m was
+// (its bits come from chunks >= m -- a chunk holds at most 64 differing bits --, and a thread has read them when it writes;
+// launches take the groups most significant first).  groups: least significant first, as the rounds take them; this launch
+// writes the slots [m0, m1).  A round then gathers one word per name (k_sort_gather), the first of them -- while the
+// permutation is still the identity or close to it -- nearly in order.
+__global__ __launch_bounds__(SB) void k_sort_pack(uint64_t *kc, int64_t N, int64_t n, const SortGroup *__restrict__ groups, int G, int m0, int m1) {
+    __shared__ SortGroup sg[SORT_PACK_GROUPS];            // (read from global memory run by run, every run was a round trip of every wave: 2.7 ms for 10^8 names)
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(groups + (G - m1));      // slots m0..m1-1 = groups G-1-m0 .. G-m1
+        uint32_t *dst = reinterpret_cast<uint32_t *>(sg);
+        const int words = (m1 - m0) * (int)(sizeof(SortGroup) / 4);
+        for (int x = threadIdx.x; x < words; x += SB) dst[x] = src[x];
+    }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * SB + threadIdx.x;
+    if (i >= n) return;
+    for (int m = m0; m < m1; ++m) {
+        const SortGroup &g = sg[m1 - 1 - m];
+        uint64_t key = 0, k = 0;
+        int cc = -1, dst = 0;
+        for (int r = 0; r < g.n; ++r) {
+            const uint32_t d = g.run[r];
+            const int c = (int)(d & 0xFFFFu), lo = (int)((d >> 16) & 63u), width = (int)((d >> 22) & 63u) + 1;
+            if (c != cc) { cc = c; k = kc[(int64_t)cc * N + i]; }
+            const uint64_t msk = width >= 64 ? ~0ull : (1ull << width) - 1ull;
+            key |= ((k >> lo) & msk) << dst;
+            dst += width;
+        }
+        kc[(int64_t)m * N + i] = key;
+    }
+}
+__global__ __launch_bounds__(SB) void k_sort_gather(const uint64_t *__restrict__ pk, const uint32_t *__restrict__ vals, int64_t n,
                                                     uint64_t *__restrict__ keys) {
     const int64_t i = (int64_t)blockIdx.x * SB + threadIdx.x;
-    if (i < n) keys[i] = kc[vals[i]];
+    if (i < n) keys[i] = pk[vals[i]];
+}
+
+// the groups, least significant first.  The FIRST one takes what is left over (total mod 64), so that the last -- whose keys
+// k_sort_finish compares neighbours by -- holds the 64 most significant differing bits.
+static std::vector<SortGroup> sort_groups(const uint64_t *orand, int nchunk) {
+    struct Run { int chunk, lo, width; };
+    std::vector<Run> runs;                                 // least significant first: last chunk, low bits
+    int total = 0;
+    for (int c = nchunk - 1; c >= 0; --c) {
+        const uint64_t vary = orand[2 * c] ^ orand[2 * c + 1];
+        for (int b = 0; b < 64;) {
+            if (!((vary >> b) & 1ull)) { ++b; continue; }
+            int e = b;
+            while (e < 64 && ((vary >> e) & 1ull)) ++e;
+            runs.push_back(Run{c, b, e - b});
+            total += e - b;
+            b = e;
+        }
+    }
+    std::vector<SortGroup> out;
+    if (!total) return out;
+    SortGroup g;
+    memset(&g, 0, sizeof g);
+    int room = total % 64 ? total % 64 : 64;
+    auto close = [&]() { out.push_back(g); memset(&g, 0, sizeof g); room = 64; };
+    for (size_t r = 0; r < runs.size();) {
+        const int w = runs[r].width < room ? runs[r].width : room;
+        g.run[g.n++] = (uint32_t)runs[r].chunk | ((uint32_t)runs[r].lo << 16) | ((uint32_t)(w - 1) << 22);
+        g.bits += w; room -= w;
+        if (w == runs[r].width) ++r;
+        else { runs[r].lo += w; runs[r].width -= w; }
+        if (room == 0) close();
+    }
+    if (g.n) close();
+    return out;
 }
 
 // ------------------------------------------------------------------ stable 8-bit counting pass over (key, value) pairs
@@ -131,24 +256,30 @@ __global__ __launch_bounds__(RS_BLOCK) void k_rs_scan(uint32_t *__restrict__ his
     if (tid == RS_BLOCK - 1) totals[blockIdx.x] = base;
 }
 
+// The tile is put in digit order in LDS first and leaves from there: neighbouring lanes then write neighbouring places of a
+// bucket (a tile holds 16 pairs per digit on average: runs of 128 + 64 bytes) where, straight from the registers, every
+// store instruction went to 64 different places (2.0 ms per pass for 10^8 pairs).
 __global__ __launch_bounds__(RS_BLOCK) void k_rs_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                          uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, int64_t n, int shift,
                                                          int64_t nblk, const uint32_t *__restrict__ offs, const uint32_t *__restrict__ totals) {
-    __shared__ uint32_t cnt[RS_BLOCK / 64][256];          // per wave: pairs seen so far per digit
-    __shared__ uint32_t base[256];                        // where this tile's pairs of a digit start in the output
-    __shared__ uint32_t wsum[RS_BLOCK / 64];
+    __shared__ uint64_t lk[RS_TILE];
+    __shared__ uint32_t lv[RS_TILE];
+    __shared__ uint32_t cnt[RS_BLOCK / 64][256];          // per wave: pairs seen so far per digit; then: pairs of the digit in the waves before
+    __shared__ uint32_t lbase[256];                       // where the digit starts in the tile once it is in digit order
+    __shared__ uint32_t gdelta[256];                      // place in the output - place in the ordered tile, per digit
+    __shared__ uint32_t wsum[RS_BLOCK / 64], wsum2[RS_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 #pragma unroll
     for (int k = 0; k < RS_BLOCK / 64; ++k) cnt[k][tid] = 0;
+    uint32_t gbase;
     {                                                     // bucket starts: exclusive scan of the 256 totals
         const uint32_t t = totals[tid], inc = rs_incl_scan64(t);
         if (lane == 63) wsum[w] = inc;
         __syncthreads();
         uint32_t b = inc - t;
         for (int k = 0; k < w; ++k) b += wsum[k];
-        base[tid] = b + offs[(int64_t)tid * nblk + blockIdx.x];
+        gbase = b + offs[(int64_t)tid * nblk + blockIdx.x];    // where this tile's pairs of digit `tid` start in the output
     }
-    __syncthreads();
     uint64_t k[RS_ROUNDS];
     uint32_t v[RS_ROUNDS], dr[RS_ROUNDS];                 // digit << 16 | rank among the wave's pairs of that digit
     const int64_t start = (int64_t)blockIdx.x * RS_TILE + w * (RS_TILE / 4);
@@ -166,22 +297,46 @@ __global__ __launch_bounds__(RS_BLOCK) void k_rs_scatter(const uint64_t *__restr
         dr[r] = (d << 16) | (prior + below);
     }
     __syncthreads();
+    {                                                     // thread `tid` = digit: the waves' counts become prefixes, the tile's total is scanned over the digits
+        uint32_t run = 0;
+#pragma unroll
+        for (int q = 0; q < RS_BLOCK / 64; ++q) { const uint32_t c = cnt[q][tid]; cnt[q][tid] = run; run += c; }
+        const uint32_t inc = rs_incl_scan64(run);
+        if (lane == 63) wsum2[w] = inc;
+        __syncthreads();
+        uint32_t b = inc - run;
+        for (int q = 0; q < w; ++q) b += wsum2[q];
+        lbase[tid] = b;
+        gdelta[tid] = gbase - b;
+    }
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; ++r) {
         const int64_t i = start + r * 64 + lane;
         if (i < n) {
             const uint32_t d = dr[r] >> 16;
-            uint32_t pos = base[d] + (dr[r] & 0xFFFFu);
-            for (int q = 0; q < w; ++q) pos += cnt[q][d];
-            kout[pos] = k[r];
-            vout[pos] = v[r];
+            const uint32_t lp = lbase[d] + cnt[w][d] + (dr[r] & 0xFFFFu);
+            lk[lp] = k[r];
+            lv[lp] = v[r];
         }
+    }
+    __syncthreads();
+    const int64_t left = n - (int64_t)blockIdx.x * RS_TILE;
+    const uint32_t count = left < RS_TILE ? (uint32_t)left : (uint32_t)RS_TILE;
+#pragma unroll 4
+    for (uint32_t j = tid; j < count; j += RS_BLOCK) {
+        const uint64_t key = lk[j];
+        const uint32_t pos = j + gdelta[(uint32_t)(key >> shift) & 255u];
+        kout[pos] = key;
+        vout[pos] = lv[j];
     }
 }
 
 // order[i] = row of the i-th smallest name; s_off / s_len (may be null): the offset and the length of that name, in sorted
 // order -- the index kernels of fx_fxi_dev.hpp then gather nothing but the name itself; *ndup += 1 per adjacent equal pair
-// (equal length, equal in every chunk: chunk 0 is what the last pass sorted by and lies in keys0, coalesced)
+// (equal length, equal in every packed group = equal in every bit that differs anywhere: keys0 = what the last round sorted
+// by -- the most significant group, or the lengths when no bit differs --, coalesced; only neighbours equal in it go to the
+// other groups, kc[1..nchunk) after k_sort_pack)
 __global__ __launch_bounds__(SB) void k_sort_finish(const uint64_t *__restrict__ kc, int nchunk, const uint64_t *__restrict__ keys0,
                                                     const int64_t *__restrict__ name_off, const int32_t *__restrict__ name_len,
                                                     const uint32_t *__restrict__ vals, int64_t n, int64_t *__restrict__ order,
@@ -193,7 +348,7 @@ __global__ __launch_bounds__(SB) void k_sort_finish(const uint64_t *__restrict__
     const int la = name_len[a] > 0 ? name_len[a] : 0;
     if (s_off) { s_off[i] = name_off[a]; s_len[i] = la; }
     if (i + 1 >= n) return;
-    if (nchunk > 0 && keys0[i] != keys0[i + 1]) return;
+    if (keys0[i] != keys0[i + 1]) return;
     const uint32_t b = vals[i + 1];
     const int lb = name_len[b] > 0 ? name_len[b] : 0;
     if (la != lb) return;
@@ -273,19 +428,40 @@ int sort_names(const uint8_t *data, int64_t gbase, const int64_t *name_off, cons
     SORTCHK(hipMemcpyAsync(&max_len, d_max, 4, hipMemcpyDeviceToHost, s), "memcpy");
     SORTCHK(hipStreamSynchronize(s), "k_sort_init");
     const int nchunk = (int)((max_len + 7) / 8);
+    if (nchunk > 0xFFFF) { *where = "a name of more than 512 KiB"; cleanup(); return (int)hipErrorInvalidValue; }
+    std::vector<uint64_t> orand((size_t)nchunk * 2);
     if (nchunk) {
+        unsigned long long *d_orand = nullptr;
         SORTCHK(take((void **)&kc, N * 8 * (size_t)nchunk), "hipMalloc(name chunks)");
-        hipLaunchKernelGGL(k_sort_chunks, dim3(nb), dim3(SB), 0, s, data, gbase, name_off, name_len, n, nchunk, kc);
+        SORTCHK(take((void **)&d_orand, orand.size() * 8), "hipMalloc");
+        for (int c = 0; c < nchunk; ++c) { orand[2 * c] = 0; orand[2 * c + 1] = ~0ull; }
+        SORTCHK(hipMemcpyAsync(d_orand, orand.data(), orand.size() * 8, hipMemcpyHostToDevice, s), "memcpy");
+        const int64_t ntiles = (n * nchunk + SB - 1) / SB;
+        const int nblk = (int)(ntiles < 8192 ? ntiles : 8192);
+        unsigned long long *d_part = nullptr;
+        if (nchunk <= SORT_LDS_CHUNKS) SORTCHK(take((void **)&d_part, (size_t)nblk * nchunk * 16), "hipMalloc");
+        hipLaunchKernelGGL(k_sort_chunks, dim3((unsigned)nblk), dim3(SB), 0, s, data, gbase, name_off, name_len, n, nchunk, kc, d_part, d_orand);
+        if (d_part) hipLaunchKernelGGL(k_sort_orand, dim3((unsigned)nchunk), dim3(SB), 0, s, d_part, nblk, nchunk, d_orand);
+        SORTCHK(hipMemcpyAsync(orand.data(), d_orand, orand.size() * 8, hipMemcpyDeviceToHost, s), "memcpy");
     }
     int cur = 0;
     int len_bits = 8;
     while (len_bits < 32 && (max_len >> len_bits)) len_bits += 8;
-    SORTCHK(radix_sort_pairs(keys, vals, cur, n, 0, len_bits, sc, s), "radix passes (length)");
-    for (int c = nchunk - 1; c >= 0; --c) {
-        hipLaunchKernelGGL(k_sort_gather, dim3(nb), dim3(SB), 0, s, kc + (size_t)c * N, vals[cur], n, keys[cur]);
-        SORTCHK(radix_sort_pairs(keys, vals, cur, n, 0, 64, sc, s), "radix passes (chunk)");
+    SORTCHK(radix_sort_pairs(keys, vals, cur, n, 0, len_bits, sc, s), "radix passes (length)");     // (synchronises: orand is on the host)
+    const std::vector<SortGroup> groups = sort_groups(orand.data(), nchunk);
+    const int G = (int)groups.size();                      // <= nchunk
+    if (G) {
+        SortGroup *d_groups = nullptr;
+        SORTCHK(take((void **)&d_groups, groups.size() * sizeof(SortGroup)), "hipMalloc");
+        SORTCHK(hipMemcpyAsync(d_groups, groups.data(), groups.size() * sizeof(SortGroup), hipMemcpyHostToDevice, s), "memcpy");
+        for (int m0 = 0; m0 < G; m0 += SORT_PACK_GROUPS)
+            hipLaunchKernelGGL(k_sort_pack, dim3(nb), dim3(SB), 0, s, kc, (int64_t)N, n, d_groups, G, m0, m0 + SORT_PACK_GROUPS < G ? m0 + SORT_PACK_GROUPS : G);
     }
-    hipLaunchKernelGGL(k_sort_finish, dim3(nb), dim3(SB), 0, s, kc, nchunk, keys[cur], name_off, name_len, vals[cur], n, d_order, d_soff, d_slen, d_ndup);
+    for (int g = 0; g < G; ++g) {
+        hipLaunchKernelGGL(k_sort_gather, dim3(nb), dim3(SB), 0, s, kc + (size_t)(G - 1 - g) * N, vals[cur], n, keys[cur]);
+        SORTCHK(radix_sort_pairs(keys, vals, cur, n, 0, groups[g].bits, sc, s), "radix passes (names)");
+    }
+    hipLaunchKernelGGL(k_sort_finish, dim3(nb), dim3(SB), 0, s, kc, G, keys[cur], name_off, name_len, vals[cur], n, d_order, d_soff, d_slen, d_ndup);
     SORTCHK(hipGetLastError(), "k_sort_finish");
     SORTCHK(hipStreamSynchronize(s), "sort");
     cleanup();

@@ -360,7 +360,8 @@ def test_names_sort(oracle, L):
     assert order.tolist() == _py_order(names) and ndup == 0
     # duplicates, the empty name, prefixes of each other, a NUL byte, lengths across several 8-byte chunks
     heads = [b"dup 1", b"x", b"dup 2", b"", b"L" * 300 + b" tail", b"dup", b"abcdefgh", b"abcdefghi", b"abcdefg",
-             b"abcdefgh\x01", b"ab\x00c", b"ab", b"\xff\xfe", b"L" * 300, b"L" * 299 + b"M", b"abcdefghabcdefgh", b"abcdefghabcdefg"]
+             b"abcdefgh\x01", b"ab\x00c", b"ab", b"\xff\xfe", b"L" * 300, b"L" * 299 + b"M", b"abcdefghabcdefgh", b"abcdefghabcdefg",
+             b"Z" * 2100 + b"b", b"Z" * 2100 + b"a", b"Z" * 2100]       # more than 256 chunks of 8 bytes
     raw = b"".join(b">" + h + b"\nACGT\n" for h in heads)
     for full in (False, True):
         b, s, t = fasta_rows(L.Blob, raw, full_name=full)
@@ -370,6 +371,12 @@ def test_names_sort(oracle, L):
         srt = [names[i] for i in order]
         assert ndup == sum(srt[i] == srt[i + 1] for i in range(len(srt) - 1))
         assert (ndup == 0) == full                          # first tokens: "dup" three times; whole headers: distinct
+    # names of more than 4 KiB (the sort then keeps the bits that differ in global words, not in a workgroup's LDS)
+    heads = [b"Q" * 5000 + b"x", b"short", b"Q" * 5000 + b"w", b"Q" * 4999, b"Q" * 5000 + b"x"]
+    raw = b"".join(b">" + h + b"\nACGT\n" for h in heads)
+    b, s, t = fasta_rows(L.Blob, raw)
+    order, ndup = b.names_sort(0, s.n_seq)
+    assert order.tolist() == _py_order(heads) and ndup == 1
     # FASTQ read names: random (duplicates likely with short names) and sequencer-style (long common prefix)
     for n, maxlen in ((5000, 6), (20000, 60)):
         raw = _rand_fastq(rng, n, maxlen, crlf=bool(n & 1), plus_name=True)
@@ -380,6 +387,19 @@ def test_names_sort(oracle, L):
         order, ndup = fq.names_sort(1, sq.n_reads)
         assert order.tolist() == _py_order(rn)
         assert ndup == len(rn) - len(set(rn))
+    # names that differ in ONE bit per byte over 400 bytes (the sort packs the differing bits of all chunks: 400 runs of one bit,
+    # more than a round's key takes), and names where every bit of every byte differs (whole chunks as keys), duplicates in both
+    for alphabet, ln_, n in ((b"ac", 400, 3000), (bytes(range(33, 256)), 21, 20000), (b"01", 9, 4000)):
+        a = np.frombuffer(alphabet, dtype=np.uint8)[rng.integers(0, len(alphabet), (n, ln_))]
+        a[n // 2] = a[n // 3]
+        rn = [a[i].tobytes() for i in range(n)]
+        raw = b"".join(b"@" + x + b"\nAC\n+\nII\n" for x in rn)
+        fq = L.Blob.from_bytes(raw)
+        sq = fq.fastq_build()
+        assert sq.n_reads == n
+        order, ndup = fq.names_sort(1, n)
+        assert order.tolist() == _py_order(rn), (alphabet[:4], ln_)
+        assert ndup == len(rn) - len(set(rn)) and ndup >= 1
     n = 30000
     ids = rng.permutation(n)
     raw = b"".join(b"@SRR8539271.%d %d/1\nACGTN\n+\nIIIII\n" % (i + 1, i) for i in ids.tolist())
