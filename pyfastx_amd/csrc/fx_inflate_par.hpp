@@ -75,9 +75,6 @@ struct PTab {
 #ifdef FX_BGZF_LDS_MAP
     uint32_t map[2048];                                                // the member's match map (one bit per output byte), flushed once
 #endif
-#ifdef FX_BGZF_OUTBUF
-    unsigned long long ob[8 * 64];                                     // phase B: every lane's current 64-byte block of output, word s of lane l at [s * 64 + l]
-#endif
 };
 #ifdef FX_BGZF_WPE
 #define P_WPE __attribute__((amdgpu_waves_per_eu(FX_BGZF_WPE, FX_BGZF_WPE)))
@@ -595,36 +592,6 @@ __global__ __launch_bounds__(64) P_WPE void k_bgzf_decode_par(const uint8_t *__r
             }
             PRd r;
             if (!STAGE && !REPLAY) pr_init(r, base, Y);
-#ifdef FX_BGZF_OUTBUF
-            // Round 6.  Words of output are 8-byte ALIGNED in memory and a lane's whole 64-byte blocks are put together in LDS and
-            // leave as four 16-byte stores back to back: a block is in the L2 for a moment and goes to memory whole.  (Before: one
-            // 8-byte store per ~1.5 symbols at 64 places of the member; a 128-byte line got its sixteen stores over the whole of
-            // phase B, ~40 us, was evicted in between -- 4096 members x 84 KiB are open at a time, the L2s hold 32 MiB -- and
-            // was read back and written again: WRITE_SIZE 18.5 GB for 3.4 GB of output and map, profiles/r06_pmc_bgzf_c4_before.txt.)
-            // Only the words of the first and the last, partly owned block of a stretch are stored as they come.
-            const uint32_t al = (uint32_t)(reinterpret_cast<uintptr_t>(out) & 63u);
-            uint8_t *const P = out - al;                                         // 64-byte aligned; place x of the member is P[x + al]
-            const uint32_t oa0 = o + al, oa_end = o_end + al;
-            const uint32_t lo_full = (oa0 + 63u) & ~63u, hi_full = oa_end & ~63u;   // the blocks [lo_full, hi_full) are this lane's alone
-            uint32_t wb = oa0 & ~7u;                                             // acc holds the bytes [wb, wb + fill)
-            if (!REPLAY) fill = oa0 & 7u;
-            auto emit = [&](uint64_t w) {
-                if (wb >= lo_full && wb < hi_full) {
-                    const uint32_t sl = (wb >> 3) & 7u;
-                    T.ob[sl * 64u + (uint32_t)lane] = w;
-                    if (sl == 7u) {
-                        typedef unsigned long long p_v2q __attribute__((ext_vector_type(2)));
-                        p_v2q *dst = reinterpret_cast<p_v2q *>(P + (wb & ~63u));
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) { p_v2q v; v.x = T.ob[(2 * i) * 64 + lane]; v.y = T.ob[(2 * i + 1) * 64 + lane]; dst[i] = v; }
-                    }
-                } else if (wb < oa0) {                                           // the word the stretch begins in: the bytes in front are the lane before's
-                    for (uint32_t i = oa0 - wb; i < 8u; ++i) P[wb + i] = (uint8_t)(w >> (8u * i));
-                } else
-                    *reinterpret_cast<uint64_t *>(P + wb) = w;
-                wb += 8u;
-            };
-#endif
             for (; !REPLAY;) {
                 if (lane < j && bp >= stop) break;
                 const PSym s = STAGE ? p_symbol<true>(T, p_peek<STAGE>(base, bp)) : p_next<true>(T, r);
@@ -644,10 +611,6 @@ __global__ __launch_bounds__(64) P_WPE void k_bgzf_decode_par(const uint8_t *__r
                 fill += s.out;
                 o += s.out; bp += s.nbits;
                 if (fill >= 8u) {
-#ifdef FX_BGZF_OUTBUF
-                    uint64_t nx = spill;
-                    do { emit(acc); acc = nx; nx = 0; fill -= 8u; } while (fill >= 8u);      // (more than once: a long match)
-#else
                     if (dbg == 5) {                                              // timing probe: the same stores into 4 KiB per member (they stay in the L2)
                         *reinterpret_cast<uint64_u *>(out + ((o - fill) & 0xFFFu)) = acc;
                         acc = spill; fill -= 8u;
@@ -657,13 +620,8 @@ __global__ __launch_bounds__(64) P_WPE void k_bgzf_decode_par(const uint8_t *__r
                     *reinterpret_cast<uint64_u *>(out + (o - fill)) = acc;
                     acc = spill; fill -= 8u;
                     while (fill >= 8u) { *reinterpret_cast<uint64_u *>(out + (o - fill)) = acc; acc = 0; fill -= 8u; }   // a long match
-#endif
                 }
             }
-#ifdef FX_BGZF_OUTBUF
-            if (!REPLAY) { for (uint32_t i = (wb < oa0 ? oa0 - wb : 0u); i < fill; ++i) P[wb + i] = (uint8_t)(acc >> (8u * i)); }      // the last few bytes
-            else
-#endif
             for (uint32_t i = 0; i < fill; ++i) out[o - fill + i] = (uint8_t)(acc >> (8u * i));      // the last few bytes
 #ifdef FX_BGZF_REG_MAP
             p_map_flush(bm, mw_i, mw, o_first, o_end);

@@ -25,7 +25,8 @@ __device__ __forceinline__ uint64_t name_hash(const uint8_t *p, int64_t n) {
     }
     if (i < n) {
         uint64_t w = 0;
-        for (int k = 0; i + k < n; ++k) w |= (uint64_t)p[i + k] << (8 * k);
+        if (n >= 8) w = *reinterpret_cast<const u64_any *>(p + n - 8) >> (8 * (8 - (n - i)));      // the 8 bytes that end with the name: one load, not a loop of byte loads
+        else for (int k = 0; i + k < n; ++k) w |= (uint64_t)p[i + k] << (8 * k);
         h ^= w;
         h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32;
     }
@@ -36,6 +37,7 @@ __device__ __forceinline__ bool bytes_equal(const uint8_t *a, const uint8_t *b, 
     int64_t i = 0;
     for (; i + 8 <= n; i += 8)
         if (*reinterpret_cast<const u64_any *>(a + i) != *reinterpret_cast<const u64_any *>(b + i)) return false;
+    if (i < n && n >= 8) return *reinterpret_cast<const u64_any *>(a + n - 8) == *reinterpret_cast<const u64_any *>(b + n - 8);   // the tail: the 8 bytes that end both
     for (; i < n; ++i) if (a[i] != b[i]) return false;
     return true;
 }
