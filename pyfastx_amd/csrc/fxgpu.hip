@@ -665,6 +665,32 @@ struct PinPool {
 };
 static PinPool g_pins;
 
+// The streams of the staging / copy-out lanes, kept between opens: hipStreamCreate takes ~0.4 ms and the runtime creates them one
+// after the other -- the eighth lane of an open had its stream after 3.8 ms and the first 64 MiB of a file were on the device
+// after 6 ms instead of 2.5 (FX_TRACE_STAGE=1).  A stream goes back idle (synchronised); at most 32 per device are kept.
+struct LaneStreams {
+    std::mutex mu;
+    std::map<int, std::vector<hipStream_t>> idle;
+    hipStream_t get(int device) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto &v = idle[device];
+            if (!v.empty()) { hipStream_t s = v.back(); v.pop_back(); return s; }
+        }
+        hipStream_t s = nullptr;
+        return hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess ? s : nullptr;      // (the caller has set the device)
+    }
+    void put(int device, hipStream_t s) {
+        if (hipStreamSynchronize(s) == hipSuccess) {
+            std::lock_guard<std::mutex> g(mu);
+            auto &v = idle[device];
+            if (v.size() < 32) { v.push_back(s); return; }
+        }
+        (void)hipStreamDestroy(s);
+    }
+};
+static LaneStreams g_lane_streams;
+
 // Pinned host memory for CALLERS (fx_pinned_alloc / fx_pinned_free): answers of a batch land in it by DMA, with no bounce
 // buffer and no first-touch page faults (a fresh 100 MB numpy array costs more to fault in than the 1 M answers cost to
 // fetch), and query arrays that live in it go up without a staging copy.  Pinning is expensive (hipHostMalloc of 100 MB:
@@ -773,7 +799,7 @@ static int stage_plain_file(fx_handle *h, int fd, int64_t n, const char *path, u
             hipStream_t st = nullptr;
             hipEvent_t ev[2] = {nullptr, nullptr};
             bool used[2] = {false, false};
-            bool ok = pin[0] && pin[1] && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+            bool ok = pin[0] && pin[1] && (st = g_lane_streams.get(h->device)) != nullptr &&
                       hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess &&
                       hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
             if (!ok) err.store(2);
@@ -794,7 +820,7 @@ static int stage_plain_file(fx_handle *h, int fd, int64_t n, const char *path, u
             }
             if (st) (void)hipStreamSynchronize(st);
             for (int i = 0; i < 2; ++i) { if (ev[i]) (void)hipEventDestroy(ev[i]); if (pin[i]) g_pins.put(pin[i]); }
-            if (st) (void)hipStreamDestroy(st);
+            if (st) g_lane_streams.put(h->device, st);
         });
     for (auto &x : th) x.join();
     if (err.load() == 1) return fail(FX_EIO, "read error on %s", path);
@@ -819,7 +845,7 @@ static int d2h_large(fx_handle *h, void *dst, const void *d_src, int64_t n) {
             uint8_t *pin[2] = {g_pins.get(), g_pins.get()};
             hipStream_t st = nullptr;
             hipEvent_t ev[2] = {nullptr, nullptr};
-            bool ok = pin[0] && pin[1] && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+            bool ok = pin[0] && pin[1] && (st = g_lane_streams.get(h->device)) != nullptr &&
                       hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess &&
                       hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
             if (!ok) err.store(1);
@@ -841,7 +867,7 @@ static int d2h_large(fx_handle *h, void *dst, const void *d_src, int64_t n) {
             }
             drain(0); drain(1);
             for (int i = 0; i < 2; ++i) { if (ev[i]) (void)hipEventDestroy(ev[i]); if (pin[i]) g_pins.put(pin[i]); }
-            if (st) (void)hipStreamDestroy(st);
+            if (st) g_lane_streams.put(h->device, st);
         });
     for (auto &x : th) x.join();
     if (err.load()) return fail(FX_EDEVICE, "device to host copy failed");
@@ -1076,7 +1102,9 @@ struct StageAsync {
     std::unique_ptr<std::atomic<int>[]> issued;               // 1: the piece's copy and its event are in the lane's stream
     int64_t waited = 0;                                       // pieces `wait_until` has been through
     cpu_set_t near_cpus;                                      // the cores next to the device (the lanes are bound to them)
+    std::chrono::steady_clock::time_point T_start;
     int start(fx_handle *hh, int fd_, int64_t n_, uint8_t *dst, int64_t piece_bytes) {
+        T_start = std::chrono::steady_clock::now();
         h = hh; fd = fd_; n = n_; d_dst = dst; piece = std::min<int64_t>(PIECE_BYTES, piece_bytes);
         npieces = (n + piece - 1) / piece;
         T = (int)std::min<int64_t>(stage_threads(), std::max<int64_t>(1, npieces));
@@ -1094,9 +1122,13 @@ struct StageAsync {
                 uint8_t *pin[2] = {g_pins.get(), g_pins.get()};
                 hipStream_t st = nullptr;
                 int64_t last[2] = {-1, -1};                  // the piece whose copy reads the slot
-                bool ok = pin[0] && pin[1] && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+                bool ok = pin[0] && pin[1] && (st = g_lane_streams.get(h->device)) != nullptr;
                 if (!ok) err.store(2);
                 int slot = 0;
+                static const bool trace = [] { const char *e = getenv("FX_TRACE_STAGE"); return e && atoi(e) != 0; }();
+                const auto L0 = std::chrono::steady_clock::now();
+                auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - L0).count(); };
+                if (trace) fprintf(stderr, "[fxgpu] lane %d: stream + pins after %.2f ms (since the lane began: %.2f)\n", t, std::chrono::duration<double, std::milli>(L0 - T_start).count(), 0.0);
                 for (int64_t k = t; ok && k < npieces && !err.load(); k += T, slot ^= 1) {
                     const int64_t off = k * piece, len = std::min(piece, n - off);
                     if (last[slot] >= 0 && hipEventSynchronize(ev[(size_t)last[slot]]) != hipSuccess) { err.store(2); break; }
@@ -1107,14 +1139,16 @@ struct StageAsync {
                         done += r;
                     }
                     if (done < len) break;
+                    if (trace && k == t) fprintf(stderr, "[fxgpu] lane %d: first piece read after %.2f ms\n", t, since());
                     if (hipMemcpyAsync(d_dst + off, pin[slot], (size_t)len, hipMemcpyHostToDevice, st) != hipSuccess ||
                         hipEventRecord(ev[(size_t)k], st) != hipSuccess) { err.store(2); break; }
+                    if (trace && k == t) fprintf(stderr, "[fxgpu] lane %d: first copy queued after %.2f ms\n", t, since());
                     last[slot] = k;
                     issued[(size_t)k].store(1, std::memory_order_release);
                 }
                 if (st) (void)hipStreamSynchronize(st);
                 for (int i = 0; i < 2; ++i) if (pin[i]) g_pins.put(pin[i]);
-                if (st) (void)hipStreamDestroy(st);
+                if (st) g_lane_streams.put(h->device, st);
             });
         return FX_OK;
     }
@@ -1221,8 +1255,10 @@ static int bgzf_open_pipelined(fx_handle *h, int fd, int64_t fsize, const char *
     if ((rc = d_c.alloc(h->device, fsize + 48, h->stream))) return rc;
     HIPCHK(hipMemsetAsync(d_c.p + fsize, 0, 48, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (trace) lap("  staging area, stream");
     StageAsync stg;
     if ((rc = stg.start(h, fd, fsize, d_c.p, group))) return rc;
+    if (trace) lap("  lanes started");
     // whatever happens below, the lanes are joined before the staging buffer goes back to the pool (d_c is declared first)
     const int64_t ngran_all = (fsize + 4095) / 4096;
     // where the groups end: the first ones are smaller (a quarter, a quarter, a half of `group`), so that the kernels begin
@@ -1249,7 +1285,7 @@ static int bgzf_open_pipelined(fx_handle *h, int fd, int64_t fsize, const char *
         const int64_t upto = edge[(size_t)g];
         const int e = stg.wait_until(upto);
         if (e) { (void)give_up(0); return e == 1 ? fail(FX_EIO, "read error on %s", path) : fail(FX_EDEVICE, "staging %s to the device failed", path); }
-        if (trace && g < 2) lap("  bytes of the group there");
+        if (trace) lap("  bytes of the group there");
         const int64_t ga = g == 0 ? 0 : edge[(size_t)g - 1] / 4096 - 1, gb = last ? ngran_all : upto / 4096 - 1, ng = gb - ga;
         if (ng <= 0) continue;
         const int64_t nchunks = (ng + SCAN_CHUNK - 1) / SCAN_CHUNK;
@@ -1309,7 +1345,7 @@ static int bgzf_open_pipelined(fx_handle *h, int fd, int64_t fsize, const char *
             if ((rc = alloc_blob(h, cap))) return give_up(rc);
         }
         if (u_end > cap) return give_up(1);                    // later groups inflate further than the first ones promised
-        if (trace && g < 2) lap("  members found, blob");
+        if (trace) lap("  members found, blob");
         const size_t at = h->gz_moff.size();
         h->gz_moff.resize(at + (size_t)nmem); h->gz_coff.resize(at + (size_t)nmem); h->gz_uoff.resize(at + (size_t)nmem);
         HIPCHK(hipMemcpyAsync(h->gz_moff.data() + at, d_mstart, (size_t)nmem * 8, hipMemcpyDeviceToHost, h->stream));
@@ -1525,7 +1561,7 @@ static int gzip_indexed_to_blob(fx_handle *h, const uint8_t *in, int64_t nin, in
             hipStream_t st = nullptr;
             hipEvent_t ev[2] = {nullptr, nullptr};
             bool used[2] = {false, false};
-            bool ok = pin[0] && pin[1] && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+            bool ok = pin[0] && pin[1] && (st = g_lane_streams.get(h->device)) != nullptr &&
                       hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess &&
                       hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
             if (!ok) err.store(2);
@@ -1594,7 +1630,7 @@ static int gzip_indexed_to_blob(fx_handle *h, const uint8_t *in, int64_t nin, in
             }
             if (st) (void)hipStreamSynchronize(st);
             for (int k = 0; k < 2; ++k) { if (ev[k]) (void)hipEventDestroy(ev[k]); if (pin[k]) g_pins.put(pin[k]); }
-            if (st) (void)hipStreamDestroy(st);
+            if (st) g_lane_streams.put(h->device, st);
         });
     for (auto &x : th) x.join();
     if (err.load() == 2) return fail(FX_EDEVICE, "staging the inflated segments failed");
@@ -3987,7 +4023,7 @@ static int fxi_image_out(int device, const uint8_t *d_img, int64_t k0, int64_t k
             uint8_t *pin[2] = {g_pins.get(), g_pins.get()};
             hipStream_t st = nullptr;
             hipEvent_t ev[2] = {nullptr, nullptr};
-            bool ok = pin[0] && pin[1] && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+            bool ok = pin[0] && pin[1] && (st = g_lane_streams.get(device)) != nullptr &&
                       hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess &&
                       hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
             if (!ok) err.store(1);
@@ -4010,7 +4046,7 @@ static int fxi_image_out(int device, const uint8_t *d_img, int64_t k0, int64_t k
             drain(0); drain(1);
             if (st) (void)hipStreamSynchronize(st);
             for (int i = 0; i < 2; ++i) { if (ev[i]) (void)hipEventDestroy(ev[i]); if (pin[i]) g_pins.put(pin[i]); }
-            if (st) (void)hipStreamDestroy(st);
+            if (st) g_lane_streams.put(device, st);
         });
     for (auto &x : th) x.join();
     if (err.load() == 1) return fail(FX_EDEVICE, "device to host copy of index pages failed");
