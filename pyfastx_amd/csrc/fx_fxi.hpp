@@ -156,9 +156,48 @@ static bool pwrite_all(int fd, const uint8_t *p, size_t n, off_t off) {
 // The file grown to its final size and mapped: the writer threads format their pages in place.  pwrite() takes the
 // inode lock for every call, so sixteen threads writing one file queue up behind each other; stores into a shared
 // mapping do not.  (No mapping -- a file system that refuses it -- and the pages go through pwrite as before.)
+// The file mapped for the writers -- in SEPARATE mappings of 8 MiB, a guard between them so that the kernel keeps them apart.
+// Every store into a page of a mapping that has no page-table entry yet is a write fault (tmpfs here has no huge pages: one
+// fault per 4 KiB), a fault takes the lock of ITS mapping, and with one mapping for the whole file that lock is one cache line
+// for all copy threads.  tools/filewrite_probe2.c (profiles/r06_filewrite_populate.txt): 16 threads store 10 GiB into ONE
+// mapping in 0.34 s (the copy alone, entries made beforehand: 0.05 s), into mappings of their own in 0.17 s.  In the product
+// the copy lanes also wait for their device-to-host pieces, so 16 of them gain little (4.3 GB: 105 against 105-129 ms) -- but
+// with one mapping more lanes made the copy-out SLOWER (24 / 32 lanes: 146 / 157 ms), with separate ones they wait for the
+// device instead (99 / 110 ms).  at(off): where byte `off` of the file is; a span is cut at the 8 MiB borders (put()).
 struct FileMap {
+    static constexpr size_t CHUNK = 8u << 20, STRIDE = CHUNK + 65536;    // (a page size of up to 64 KiB between the mappings)
     uint8_t *p = nullptr;
-    size_t len = 0;
+    size_t len = 0, area = 0;                              // bytes of the file covered; bytes of address space taken
+    bool one = false;                                      // ONE mapping (FX_FXI_ONE_MAPPING=1: the form before, for comparison)
+    uint8_t *at(size_t off) const { return one ? p + off : p + (off / CHUNK) * STRIDE + off % CHUNK; }
+    void put(size_t off, const uint8_t *src, size_t n) const {
+        while (n) {
+            const size_t m = one ? n : std::min(n, CHUNK - off % CHUNK);
+            memcpy(at(off), src, m);
+            off += m; src += m; n -= m;
+        }
+    }
+    // the first `newlen` bytes of a file that has them
+    bool map_existing(int fd, size_t newlen) {
+        close();
+        if (getenv("FX_FXI_NO_MMAP") || newlen == 0) return false;
+        static const bool single = [] { const char *e = getenv("FX_FXI_ONE_MAPPING"); return e && atoi(e) != 0; }();
+        if (single) {
+            void *m = mmap(nullptr, newlen, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            if (m == MAP_FAILED) return false;
+            p = (uint8_t *)m; len = newlen; area = newlen; one = true;
+            return true;
+        }
+        const size_t nch = (newlen + CHUNK - 1) / CHUNK;
+        void *r = mmap(nullptr, nch * STRIDE, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (r == MAP_FAILED) return false;
+        for (size_t k = 0; k < nch; ++k) {
+            const size_t off = k * CHUNK, n = std::min(CHUNK, newlen - off);
+            if (mmap((uint8_t *)r + k * STRIDE, n, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, fd, (off_t)off) == MAP_FAILED) { munmap(r, nch * STRIDE); return false; }
+        }
+        p = (uint8_t *)r; len = newlen; area = nch * STRIDE; one = false;
+        return true;
+    }
     bool open(int fd, size_t newlen) {
         if (getenv("FX_FXI_NO_MMAP")) return false;
         // a store into a mapping of a full file system is a SIGBUS, a pwrite an error return: map only when the space is there
@@ -168,18 +207,15 @@ struct FileMap {
         const uint64_t grow = newlen > (size_t)st.st_size ? newlen - (size_t)st.st_size : 0;
         if ((uint64_t)vfs.f_bavail * (uint64_t)vfs.f_frsize < grow + (64u << 20)) return false;
         if (ftruncate(fd, (off_t)newlen) != 0) return false;
-        void *m = mmap(nullptr, newlen, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        if (m == MAP_FAILED) return false;
-        p = (uint8_t *)m; len = newlen;
-        return true;
+        return map_existing(fd, newlen);
     }
-    void close() { if (p) munmap(p, len); p = nullptr; }
+    void close() { if (p) munmap(p, area); p = nullptr; len = area = 0; }
     ~FileMap() { close(); }
 };
 // one page into the mapping or through pwrite
 static bool put_page(int fd, const FileMap &m, const uint8_t *pg, int pagesize, uint32_t pageno) {
     const size_t off = (size_t)(pageno - 1) * (size_t)pagesize;
-    if (m.p) { memcpy(m.p + off, pg, (size_t)pagesize); return true; }
+    if (m.p) { memcpy(m.at(off), pg, (size_t)pagesize); return true; }
     return pwrite_all(fd, pg, (size_t)pagesize, (off_t)off);
 }
 
@@ -308,7 +344,7 @@ static int bulk_load_table(const char *path, uint32_t rootpage, const Rows &r) {
                         const size_t b = std::min(nleaf, a + 256);
                         if (map.p) {                         // in place
                             for (size_t k = a; k < b; ++k)
-                                format_leaf(map.p + (size_t)(seq.at(k) - 1) * (size_t)pagesize, pagesize, usable, r, leaf_first[k], leaf_first[k + 1]);
+                                format_leaf(map.at((size_t)(seq.at(k) - 1) * (size_t)pagesize), pagesize, usable, r, leaf_first[k], leaf_first[k + 1]);
                             continue;
                         }
                         for (size_t k = a; k < b; ++k)
@@ -496,7 +532,7 @@ static int bulk_load_index(const char *path, uint32_t rootpage, const Entries &e
                 for (;;) {
                     const size_t k = cursor.fetch_add(1);
                     if (k >= np || err.load()) return;
-                    uint8_t *const pg = map.p ? map.p + (size_t)(pageno[0][k] - 1) * (size_t)pagesize : own.data();   // in place when mapped
+                    uint8_t *const pg = map.p ? map.at((size_t)(pageno[0][k] - 1) * (size_t)pagesize) : own.data();   // in place when mapped
                     memset(pg, 0, (size_t)pagesize);
                     // items of page k: entries first[k] .. end, where the promoted one (if any) is excluded
                     int64_t a = lv.first[k], b = lv.first[k + 1];

@@ -4009,12 +4009,15 @@ static int fxi_image_out(int device, const uint8_t *d_img, int64_t k0, int64_t k
             const int64_t x = part ? cut : a, y = part ? b : cut;
             if (x >= y) continue;
             const size_t off = (size_t)(pg(x) - 1) * FXI_PAGE, len = (size_t)(y - x) * FXI_PAGE;
-            if (map.p && off + len <= map.len) memcpy(map.p + off, src + (size_t)(x - a) * FXI_PAGE, len);
+            if (map.p && off + len <= map.len) map.put(off, src + (size_t)(x - a) * FXI_PAGE, len);
             else if (!fxi::pwrite_all(fd, src + (size_t)(x - a) * FXI_PAGE, len, (off_t)off)) err.store(2);
         }
     };
     cpu_set_t near_cpus;
     static const bool no_bind = [] { const char *e = getenv("FX_FXI_NO_BIND"); return e && atoi(e) != 0; }();
+    static const bool trace_copy = [] { const char *e = getenv("FX_TRACE_FXI_COPY"); return e && atoi(e) != 0; }();   // per call: what the lanes waited for the device, what they spent storing into the file
+    std::atomic<long long> wait_us(0), put_us(0);
+    const auto C0 = std::chrono::steady_clock::now();
     const bool bind = !no_bind && device_cpus(device, &near_cpus);     // the copy threads on the CPUs next to the device, as the staging threads are
     for (int t = 0; t < T; ++t)
         th.emplace_back([&, t]() {
@@ -4030,8 +4033,14 @@ static int fxi_image_out(int device, const uint8_t *d_img, int64_t k0, int64_t k
             int64_t pa[2] = {-1, -1}, pb[2] = {0, 0};
             auto drain = [&](int sl) {
                 if (pa[sl] < 0) return;
+                const auto w0 = std::chrono::steady_clock::now();
                 if (hipEventSynchronize(ev[sl]) != hipSuccess) { err.store(1); pa[sl] = -1; return; }
+                const auto w1 = std::chrono::steady_clock::now();
                 put(pin[sl], pa[sl], pb[sl]);
+                if (trace_copy) {
+                    wait_us.fetch_add((long long)std::chrono::duration<double, std::micro>(w1 - w0).count());
+                    put_us.fetch_add((long long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w1).count());
+                }
                 pa[sl] = -1;
             };
             int slot = 0;
@@ -4049,6 +4058,9 @@ static int fxi_image_out(int device, const uint8_t *d_img, int64_t k0, int64_t k
             if (st) g_lane_streams.put(device, st);
         });
     for (auto &x : th) x.join();
+    if (trace_copy)
+        fprintf(stderr, "[fxgpu] fxi_image_out %.2f GB, %d lanes: %.1f ms; per lane waiting for the device %.1f ms, storing into the file %.1f ms\n", (double)(k1 - k0) * FXI_PAGE / 1e9, T,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - C0).count(), wait_us.load() / 1e3 / T, put_us.load() / 1e3 / T);
     if (err.load() == 1) return fail(FX_EDEVICE, "device to host copy of index pages failed");
     if (err.load() == 2) return fail(FX_EIO, "cannot write the index file");
     return FX_OK;
@@ -4209,7 +4221,7 @@ static void fxi_grow_and_map(fxi::DbFile &db, uint32_t new_npages, int device, f
         return;
     }
     if (presized || map.open(db.fd, (size_t)end)) {
-        if (presized) { void *m = mmap(nullptr, (size_t)end, PROT_READ | PROT_WRITE, MAP_SHARED, db.fd, 0); if (m != MAP_FAILED) { map.p = (uint8_t *)m; map.len = (size_t)end; } }
+        if (presized) (void)map.map_existing(db.fd, (size_t)end);
         // (only what a pre-sized file lacks: fallocate over pages that exist still visits every one of them, 0.2 us each)
         const off_t have = std::max(from, size_now & ~(off_t)(FXI_PAGE - 1));
         if (map.p && !presized && have < end && !getenv("FX_FXI_NO_FALLOCATE")) {
@@ -4233,7 +4245,7 @@ static void fxi_grow_and_map(fxi::DbFile &db, uint32_t new_npages, int device, f
 static void fxi_unmap_later(fxi::FileMap &map) {
     if (map.p && !getenv("FX_FXI_SYNC_UNMAP")) {
         uint8_t *mp = map.p;
-        const size_t ml = map.len;
+        const size_t ml = map.area;
         map.p = nullptr;
         std::thread([mp, ml]() { munmap(mp, ml); }).detach();
     }
@@ -4676,8 +4688,7 @@ extern "C" int fx_fxi_part_leaves(fx_handle *h, int kind, const char *path, int6
     struct stat st;
     if (!getenv("FX_FXI_NO_MMAP") && fstat(fd, &st) == 0 && st.st_size >= (off_t)seq.at((uint64_t)leaf_base) * FXI_PAGE) {
         const size_t len = (size_t)std::min<off_t>(st.st_size, (off_t)seq.at((uint64_t)(leaf_base + nleaf - 1)) * FXI_PAGE);
-        void *m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        if (m != MAP_FAILED) { map.p = (uint8_t *)m; map.len = len; }
+        (void)map.map_existing(fd, len);
     }
     rc = J.leaves_out(false, nleaf, h->fxi_part_first.p, seq, leaf_base, fd, map, &lap_buf[0], &lap_buf[1]);
     fxi_unmap_later(map);

@@ -8,7 +8,9 @@
 //      K threads on K shares of the mapping, then T mmap writers -- each stage timed (the copy alone = what is left of the
 //      copy-out when the entries were made while the input was still being staged)
 //   R  as Q without the fallocate: the populate allocates the pages as it maps them (one pass over the file instead of two)
-// usage: filewrite_probe2 <path> <MiB> <schedule A|B|E|F|P|Q|R> <T> [piece KiB = 8192] [falloc step MiB = 128] [K = 4] [first cpu, cpus: bind every thread to that range]
+//   V  as B, but the file is mapped in SEPARATE mappings of `step` MiB (a page between them, so that the kernel keeps them apart) and a
+//      writer takes a whole mapping at a time: no two threads fault on the same VMA (its lock is one cache line for all of them)
+// usage: filewrite_probe2 <path> <MiB> <schedule A|B|E|F|P|Q|R|V> <T> [piece KiB = 8192] [falloc step MiB = 128] [K = 4] [first cpu, cpus: bind every thread to that range]
 #define _GNU_SOURCE
 #include <sched.h>
 #include <fcntl.h>
@@ -37,6 +39,10 @@ static void *mmap_writer(void *a) {
 static int K = 4;
 static void *populate_share(void *a) { long t = (long)a; size_t lo = (N / K * t) & ~4095ul, hi = t == K - 1 ? N : (N / K * (t + 1)) & ~4095ul;
     if (madvise(map + lo, hi - lo, MADV_POPULATE_WRITE)) perror("madvise(MADV_POPULATE_WRITE)"); return 0; }
+static char **vmap; static size_t nvmap;
+static void *vma_writer(void *a) {
+    for (;;) { size_t k = atomic_fetch_add(&cursor, 1); if (k >= nvmap) return 0; size_t off = k * STEP, len = N - off < STEP ? N - off : STEP;
+        for (size_t o = 0; o < len; o += PIECE) { size_t l = len - o < PIECE ? len - o : PIECE; memcpy(vmap[k] + o, src + (off + o) % (SRC - PIECE), l); } } }
 static size_t split;   // E: pwrite thread takes [0, ...) upward, mmap writers take pieces downward from N; they meet
 static void *pw_front(void *a) {
     for (;;) { size_t off = atomic_fetch_add(&cursor, PIECE); if (off >= N || off + PIECE > N - atomic_load(&back_cursor)) { return 0; }
@@ -59,14 +65,24 @@ int main(int c, char **v) {
     pthread_t th[300]; int nt = 0; double tf = 0;
     if (sched == 'B') { falloc_thread(0); tf = now() - t0; }
     double tp = 0, tq0 = 0;
+    if (sched == 'V') {
+        falloc_thread(0); tf = now() - t0;
+        nvmap = (N + STEP - 1) / STEP; vmap = malloc(nvmap * sizeof *vmap);
+        char *area = mmap(0, nvmap * (STEP + 4096), PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0); if (area == MAP_FAILED) { perror("mmap area"); return 1; }
+        for (size_t k = 0; k < nvmap; ++k) { size_t off = k * STEP, len = N - off < STEP ? N - off : STEP;
+            vmap[k] = mmap(area + k * (STEP + 4096), len, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, fd, off); if (vmap[k] == MAP_FAILED) { perror("mmap piece"); return 1; } }
+        tq0 = now();
+        for (int t = 0; t < T; ++t) pthread_create(&th[nt++], 0, vma_writer, 0);
+    } else
     if (sched == 'Q' || sched == 'R') { if (sched == 'Q') falloc_thread(0); tf = now() - t0; double a = now(); pthread_t pt[64]; for (long t = 0; t < K; ++t) pthread_create(&pt[t], 0, populate_share, (void *)t);
         for (int t = 0; t < K; ++t) pthread_join(pt[t], 0); tp = now() - a; tq0 = now(); }
     if (sched == 'A' || sched == 'F') pthread_create(&th[nt++], 0, falloc_thread, 0);
     if (sched == 'E') { pthread_create(&th[nt++], 0, pw_front, 0); for (int t = 0; t < T; ++t) pthread_create(&th[nt++], 0, mmap_back, 0); }
     else if (sched == 'P') for (long t = 0; t < T; ++t) pthread_create(&th[nt++], 0, pw_share, (void *)t);
-    else for (int t = 0; t < T; ++t) pthread_create(&th[nt++], 0, mmap_writer, 0);
+    else if (sched != 'V') for (int t = 0; t < T; ++t) pthread_create(&th[nt++], 0, mmap_writer, 0);
     for (int t = 0; t < nt; ++t) pthread_join(th[t], 0);
     double t1 = now();
+    if (sched == 'V') printf("schedule V: fallocate %.3f s, %zu mappings of %zu MiB, copy with %d threads %.3f s = %.2f GB/s\n", tf, nvmap, STEP >> 20, T, t1 - tq0, N / 1e9 / (t1 - tq0));
     if (sched == 'Q' || sched == 'R') printf("schedule Q/R: fallocate %.3f s, populate with %d threads %.3f s, copy with %d threads %.3f s = %.2f GB/s\n", tf, K, tp, T, t1 - tq0, N / 1e9 / (t1 - tq0));
     printf("schedule %c T=%d piece=%zuK step=%zuM: %.3f s (fallocate first: %.3f) -> %.2f GB/s\n", sched, T, PIECE >> 10, STEP >> 20, t1 - t0, tf, N / 1e9 / (t1 - t0));
     munmap(map, N); close(fd); unlink(path); return 0; }
