@@ -4016,7 +4016,7 @@ static int fxi_image_out(int device, const uint8_t *d_img, int64_t k0, int64_t k
     cpu_set_t near_cpus;
     static const bool no_bind = [] { const char *e = getenv("FX_FXI_NO_BIND"); return e && atoi(e) != 0; }();
     static const bool trace_copy = [] { const char *e = getenv("FX_TRACE_FXI_COPY"); return e && atoi(e) != 0; }();   // per call: what the lanes waited for the device, what they spent storing into the file
-    std::atomic<long long> wait_us(0), put_us(0);
+    std::atomic<long long> wait_us(0), put_us(0), first_us(1ll << 60), last_us(0);
     const auto C0 = std::chrono::steady_clock::now();
     const bool bind = !no_bind && device_cpus(device, &near_cpus);     // the copy threads on the CPUs next to the device, as the staging threads are
     for (int t = 0; t < T; ++t)
@@ -4038,6 +4038,11 @@ static int fxi_image_out(int device, const uint8_t *d_img, int64_t k0, int64_t k
                 const auto w1 = std::chrono::steady_clock::now();
                 put(pin[sl], pa[sl], pb[sl]);
                 if (trace_copy) {
+                    const long long landed = (long long)std::chrono::duration<double, std::micro>(w1 - C0).count();
+                    long long cur = first_us.load();
+                    while (landed < cur && !first_us.compare_exchange_weak(cur, landed)) {}
+                    cur = last_us.load();
+                    while (landed > cur && !last_us.compare_exchange_weak(cur, landed)) {}
                     wait_us.fetch_add((long long)std::chrono::duration<double, std::micro>(w1 - w0).count());
                     put_us.fetch_add((long long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w1).count());
                 }
@@ -4059,8 +4064,8 @@ static int fxi_image_out(int device, const uint8_t *d_img, int64_t k0, int64_t k
         });
     for (auto &x : th) x.join();
     if (trace_copy)
-        fprintf(stderr, "[fxgpu] fxi_image_out %.2f GB, %d lanes: %.1f ms; per lane waiting for the device %.1f ms, storing into the file %.1f ms\n", (double)(k1 - k0) * FXI_PAGE / 1e9, T,
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - C0).count(), wait_us.load() / 1e3 / T, put_us.load() / 1e3 / T);
+        fprintf(stderr, "[fxgpu] fxi_image_out %.2f GB, %d lanes: %.1f ms; per lane waiting for the device %.1f ms, storing into the file %.1f ms; first piece seen on the host after %.1f ms, last after %.1f ms\n", (double)(k1 - k0) * FXI_PAGE / 1e9, T,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - C0).count(), wait_us.load() / 1e3 / T, put_us.load() / 1e3 / T, first_us.load() / 1e3, last_us.load() / 1e3);
     if (err.load() == 1) return fail(FX_EDEVICE, "device to host copy of index pages failed");
     if (err.load() == 2) return fail(FX_EIO, "cannot write the index file");
     return FX_OK;
@@ -4241,13 +4246,21 @@ static void fxi_grow_and_map(fxi::DbFile &db, uint32_t new_npages, int device, f
     }
 }
 // Taking a mapping down walks every page table entry of it (0.25 s for 10 GB of dirty shared pages) and nothing waits
-// for the result: the pages are in the file's page cache either way.  It is left to a thread of its own.
+// for the result: the pages are in the file's page cache either way.  It is left to a thread of its own -- which takes the
+// mapping down PIECE BY PIECE: a munmap holds the process's mm lock for as long as it runs, and behind one call for the whole
+// 10 GB everything else that needs the lock waited up to 0.2 s -- the free() of a large vector in this function's own epilogue,
+// SQLite's next open, a hipStreamDestroy (FX_TRACE: the call returned 0-130 ms after its last lap).
 static void fxi_unmap_later(fxi::FileMap &map) {
     if (map.p && !getenv("FX_FXI_SYNC_UNMAP")) {
         uint8_t *mp = map.p;
-        const size_t ml = map.area;
+        const size_t area = map.area, len = map.len;
+        const bool one = map.one;
         map.p = nullptr;
-        std::thread([mp, ml]() { munmap(mp, ml); }).detach();
+        std::thread([mp, area, len, one]() {
+            const size_t C = fxi::FileMap::CHUNK, S = one ? C : fxi::FileMap::STRIDE;
+            for (size_t k = 0; k * C < len; ++k) (void)munmap(mp + k * S, std::min(C, len - k * C));
+            if (!one) (void)munmap(mp, area);              // what is left: the guards
+        }).detach();
     }
     map.close();
 }

@@ -543,7 +543,8 @@ def estimate_fastq_index_bytes(path, full_name=False, head=1 << 19, places=8):
 
 def presize_fastq(path, input_path, full_name=False, device=-1, with_index=False):
     """The index file of a LARGE plain FASTQ input created early -- schema in place -- and grown in the background to
-    98.5 % of its estimated size while the input is staged (fx_fxi_presize_begin).  -> token for _lib.fxi_presize_end, or
+    101 % of its estimated size while the input is staged (fx_fxi_presize_begin; FX_FXI_PRESIZE_FRAC: with 98.5 % the
+    missing pages were allocated between the table and the index, 12 ms of C3's constructor; what is left over is cut off).  -> token for _lib.fxi_presize_end, or
     None when nothing was done (a small input, no estimate).  The caller removes the file if the build fails."""
     from . import _lib
     if os.path.getsize(input_path) < int(os.environ.get("FX_FXI_PRESIZE_MIN", 1 << 30)):
@@ -563,7 +564,7 @@ def presize_fastq(path, input_path, full_name=False, device=-1, with_index=False
         db.execute(_KINDS[1][2])
     db.close()
     try:
-        return _lib.fxi_presize_begin(path, int(est * 0.985), device)
+        return _lib.fxi_presize_begin(path, int(est * float(os.environ.get("FX_FXI_PRESIZE_FRAC", "1.01"))), device)
     except _lib.FxError:
         if os.path.exists(path):                              # (the build must find no file: it makes its own)
             os.remove(path)
