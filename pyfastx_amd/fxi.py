@@ -5,6 +5,7 @@ column order and pragmas the reference uses (index.c:178-224, 342-372;
 fasta.c:890-953; fastq.c:29-60, 136-171, 755-784; util.c:442-540), so an index
 written here opens in reference pyfastx and vice versa.
 """
+import math
 import os
 import sqlite3
 import struct
@@ -536,7 +537,8 @@ def estimate_fastq_index_bytes(path, full_name=False, head=1 << 19, places=8):
         ent_payload = 1 + tl + 1 + L + _int_bytes(rid)
         ent = _varint_len(int(ent_payload)) + ent_payload + 2
         rows = n / len(shapes)
-        pages += rows / int(4088 / cell) * 1.005 + rows / (int(4088 / ent) + 1) * 1.005
+        # (the leaves are filled in chunks of 2048 rows, each starting a fresh page -- k_fxi_fill: whole pages per chunk)
+        pages += rows / 2048.0 * (math.ceil(2048.0 / int(4088 / cell)) + math.ceil(2048.0 / (int(4088 / ent) + 1)))
     pages *= 1.0 + 1.0 / 250                                  # interior levels
     return int(pages * 4096)
 
