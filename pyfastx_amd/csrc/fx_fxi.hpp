@@ -163,16 +163,19 @@ static bool pwrite_all(int fd, const uint8_t *p, size_t n, off_t off) {
 // mapping in 0.34 s (the copy alone, entries made beforehand: 0.05 s), into mappings of their own in 0.17 s.  In the product
 // the copy lanes also wait for their device-to-host pieces, so 16 of them gain little (4.3 GB: 105 against 105-129 ms) -- but
 // with one mapping more lanes made the copy-out SLOWER (24 / 32 lanes: 146 / 157 ms), with separate ones they wait for the
-// device instead (99 / 110 ms).  at(off): where byte `off` of the file is; a span is cut at the 8 MiB borders (put()).
+// device instead (99 / 110 ms).  at(off): where byte `off` of the file is; a span is cut at the mappings' borders (put()).
 struct FileMap {
-    static constexpr size_t CHUNK = 8u << 20, STRIDE = CHUNK + 65536;    // (a page size of up to 64 KiB between the mappings)
+    static constexpr size_t MIN_CHUNK = 8u << 20, GUARD = 65536;         // (a page size of up to 64 KiB between the mappings)
     uint8_t *p = nullptr;
     size_t len = 0, area = 0;                              // bytes of the file covered; bytes of address space taken
+    size_t chunk = MIN_CHUNK;                              // bytes per mapping: 8 MiB, more for files of more than 16 GiB (at most ~2048 mappings:
+                                                           // a process may hold 65530 of them by default, and every guard is one more)
     bool one = false;                                      // ONE mapping (FX_FXI_ONE_MAPPING=1: the form before, for comparison)
-    uint8_t *at(size_t off) const { return one ? p + off : p + (off / CHUNK) * STRIDE + off % CHUNK; }
+    size_t stride() const { return chunk + GUARD; }
+    uint8_t *at(size_t off) const { return one ? p + off : p + (off / chunk) * stride() + off % chunk; }
     void put(size_t off, const uint8_t *src, size_t n) const {
         while (n) {
-            const size_t m = one ? n : std::min(n, CHUNK - off % CHUNK);
+            const size_t m = one ? n : std::min(n, chunk - off % chunk);
             memcpy(at(off), src, m);
             off += m; src += m; n -= m;
         }
@@ -188,14 +191,16 @@ struct FileMap {
             p = (uint8_t *)m; len = newlen; area = newlen; one = true;
             return true;
         }
-        const size_t nch = (newlen + CHUNK - 1) / CHUNK;
-        void *r = mmap(nullptr, nch * STRIDE, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        chunk = MIN_CHUNK;
+        while ((newlen + chunk - 1) / chunk > 2048) chunk <<= 1;
+        const size_t nch = (newlen + chunk - 1) / chunk;
+        void *r = mmap(nullptr, nch * stride(), PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
         if (r == MAP_FAILED) return false;
         for (size_t k = 0; k < nch; ++k) {
-            const size_t off = k * CHUNK, n = std::min(CHUNK, newlen - off);
-            if (mmap((uint8_t *)r + k * STRIDE, n, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, fd, (off_t)off) == MAP_FAILED) { munmap(r, nch * STRIDE); return false; }
+            const size_t off = k * chunk, n = std::min(chunk, newlen - off);
+            if (mmap((uint8_t *)r + k * stride(), n, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, fd, (off_t)off) == MAP_FAILED) { munmap(r, nch * stride()); return false; }
         }
-        p = (uint8_t *)r; len = newlen; area = nch * STRIDE; one = false;
+        p = (uint8_t *)r; len = newlen; area = nch * stride(); one = false;
         return true;
     }
     bool open(int fd, size_t newlen) {

@@ -4253,11 +4253,10 @@ static void fxi_grow_and_map(fxi::DbFile &db, uint32_t new_npages, int device, f
 static void fxi_unmap_later(fxi::FileMap &map) {
     if (map.p && !getenv("FX_FXI_SYNC_UNMAP")) {
         uint8_t *mp = map.p;
-        const size_t area = map.area, len = map.len;
+        const size_t area = map.area, len = map.len, C = map.one ? fxi::FileMap::MIN_CHUNK : map.chunk, S = map.one ? C : map.stride();
         const bool one = map.one;
         map.p = nullptr;
-        std::thread([mp, area, len, one]() {
-            const size_t C = fxi::FileMap::CHUNK, S = one ? C : fxi::FileMap::STRIDE;
+        std::thread([mp, area, len, one, C, S]() {
             for (size_t k = 0; k * C < len; ++k) (void)munmap(mp + k * S, std::min(C, len - k * C));
             if (!one) (void)munmap(mp, area);              // what is left: the guards
         }).detach();
