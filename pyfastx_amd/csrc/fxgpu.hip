@@ -654,8 +654,8 @@ struct PinPool {
     }
     // at most PIN_KEEP idle buffers stay pinned for the life of the process (256 MiB at the default piece size: what the
     // 8 staging threads + 8 read-back threads use); the rest goes back to the system
-    static const size_t PIN_KEEP = 32;
     void put(uint8_t *p) {
+        static const size_t PIN_KEEP = [] { const char *e = getenv("FX_PIN_KEEP"); const int v = e ? atoi(e) : 0; return (size_t)(v > 0 && v <= 1024 ? v : 32); }();
         {
             std::lock_guard<std::mutex> g(mu);
             if (bufs.size() < PIN_KEEP) { bufs.push_back(p); return; }
