@@ -4257,8 +4257,10 @@ static void fxi_unmap_later(fxi::FileMap &map) {
         const bool one = map.one;
         map.p = nullptr;
         std::thread([mp, area, len, one, C, S]() {
-            for (size_t k = 0; k * C < len; ++k) (void)munmap(mp + k * S, std::min(C, len - k * C));
-            if (!one) (void)munmap(mp, area);              // what is left: the guards
+            // (every piece with the guard behind it, each address once: a range that has been unmapped may belong to somebody
+            // else a moment later -- a second munmap over the whole area took a numpy array of the caller with it)
+            if (one) { for (size_t o = 0; o < len; o += C) (void)munmap(mp + o, std::min(C, len - o)); }
+            else for (size_t o = 0; o < area; o += S) (void)munmap(mp + o, std::min(S, area - o));
         }).detach();
     }
     map.close();
