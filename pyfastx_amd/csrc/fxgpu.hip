@@ -4259,8 +4259,9 @@ static void fxi_unmap_later(fxi::FileMap &map) {
         std::thread([mp, area, len, one, C, S]() {
             // (every piece with the guard behind it, each address once: a range that has been unmapped may belong to somebody
             // else a moment later -- a second munmap over the whole area took a numpy array of the caller with it)
-            if (one) { for (size_t o = 0; o < len; o += C) (void)munmap(mp + o, std::min(C, len - o)); }
-            else for (size_t o = 0; o < area; o += S) (void)munmap(mp + o, std::min(S, area - o));
+            static const int pause_us = [] { const char *e = getenv("FX_FXI_UNMAP_PAUSE_US"); return e ? atoi(e) : 0; }();   // (tests: a caller that maps memory meanwhile)
+            if (one) { for (size_t o = 0; o < len; o += C) { (void)munmap(mp + o, std::min(C, len - o)); if (pause_us > 0) usleep((useconds_t)pause_us); } }
+            else for (size_t o = 0; o < area; o += S) { (void)munmap(mp + o, std::min(S, area - o)); if (pause_us > 0) usleep((useconds_t)pause_us); }
         }).detach();
     }
     map.close();

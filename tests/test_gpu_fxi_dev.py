@@ -229,3 +229,32 @@ def test_room_set_aside_while_staging(fx, tmp_path, dev_route, monkeypatch):
     p.write_bytes(raw[: len(raw) // 2 + 7])
     fq = fx.Fastq(str(p))
     assert _check(str(p) + ".fxi")[0] == [("ok",)] and len(fq) > 0
+
+
+def test_memory_mapped_right_after_the_build_stays(fx, tmp_path, dev_route, monkeypatch):
+    """The index file's mappings are taken down by a thread of the library after the build has returned, piece by piece
+    (a munmap of the whole file at once holds the process's mm lock for as long as it runs).  Every address is given back
+    ONCE: arrays the caller maps while that thread is still at work -- the allocator hands out the addresses just
+    freed -- keep their pages.  (The first piecewise form went over the whole area once more at the end and took a numpy
+    array of bench.py with it: a SIGSEGV in the next copy into it.)"""
+    import mmap
+    import time
+    monkeypatch.setenv("FX_FXI_UNMAP_PAUSE_US", "3000")      # the library's thread pauses between its pieces: it is at work while the arrays below are made
+    n = 1_500_000                                            # an index file of ~150 MB: some twenty mappings of 8 MiB
+    ids, raw = _many_fastq(n, 8)
+    for rep in range(3):
+        p = tmp_path / ("unmap_%d.fq" % rep)
+        p.write_bytes(raw)
+        fq = fx.Fastq(str(p))
+        maps = []
+        for k in range(300):                                 # anonymous mappings of 2 MiB, made while the thread is at work: they fit the holes it leaves
+            m = mmap.mmap(-1, 2 << 20)
+            m[0:8] = m[-8:] = (rep * 1000 + k).to_bytes(8, "little")
+            maps.append(m)
+            time.sleep(0.0003)
+        assert fq.index_phases is not None and len(fq) == n
+        time.sleep(0.2)
+        assert [int.from_bytes(m[0:8], "little") + int.from_bytes(m[-8:], "little") for m in maps] == [2 * (rep * 1000 + k) for k in range(300)]
+        for m in maps:
+            m.close()
+        del fq
