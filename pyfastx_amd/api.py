@@ -123,6 +123,18 @@ class _Staged:
             try:
                 self._blob = _lib.Blob.from_file(self.path, self.device, gzindex=pts)
             except _lib.FxError as e:
+                # (a BGZF file that was taken to fit from the ratio of its first members and does not: the exact size, then windows)
+                if e.code == _lib.FX_ENOMEM and self.windowed is not None:
+                    from . import windows
+                    try:
+                        _lib.lib().fx_release_scratch()
+                        plan = windows.plan(self.path, self.device, self.win_factor, exact=True)
+                        if plan is not None:
+                            self._md = self.windowed(plan)
+                            self._blob = self._md.blob
+                            return self._blob
+                    except _lib.FxError as e2:
+                        raise _fx_to_py(e2)
                 raise _fx_to_py(e)
             if self.on_stage is not None:
                 self.on_stage(self._blob)

@@ -50,9 +50,35 @@ def hbm_budget(device=0):
     return int(free * 0.85)
 
 
-def plan(path, device=0, factor=1.0):
+def bgzf_head_ratio(path, head=1 << 18):
+    """Inflated / compressed bytes of the BGZF members in the first `head` bytes of a file, or None when the file does not
+    begin with BGZF members (header layout of fx_bgzf_walk.hpp: 1f 8b 08 04, XLEN 6, 'B' 'C' 2 0, BSIZE; ISIZE closes a member)."""
+    try:
+        with open(path, "rb") as f:
+            b = f.read(head)
+    except OSError:
+        return None
+    at = cin = cout = 0
+    while at + 18 <= len(b) and b[at:at + 4] == b"\x1f\x8b\x08\x04" and b[at + 10:at + 16] == b"\x06\x00BC\x02\x00":
+        size = int.from_bytes(b[at + 16:at + 18], "little") + 1
+        if size < 26 or at + size > len(b):
+            break
+        cout += int.from_bytes(b[at + size - 4:at + size], "little")
+        cin += size
+        at += size
+    return cout / cin if cin >= 4096 or (cin and at == len(b)) else None
+
+
+def plan(path, device=0, factor=1.0, exact=False):
     """-> None when the stream fits (size * factor <= budget; factor: what a build needs beside the stream itself), else
-    (size, kind, window bytes, windows resident at a time)."""
+    (size, kind, window bytes, windows resident at a time).  A BGZF file whose size -- estimated from the ratio of its first
+    members -- is under a quarter of the budget is taken to fit without the walk over all its members that the exact size
+    costs (20 ms for the 46 723 members of C4, a quarter of Fasta(path)); a caller whose open then fails for lack of memory
+    asks again with exact=True."""
+    if not exact:
+        r = bgzf_head_ratio(path)
+        if r is not None and os.path.getsize(path) * max(r, 1.0) * 4 * factor <= hbm_budget(device):
+            return None
     size, kind = _lib.stream_size(path)
     if kind == 2 or size <= 0:                                  # a single gzip stream does not shard by byte range
         return None

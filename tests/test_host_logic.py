@@ -1551,6 +1551,29 @@ def test_window_plan_and_budget(monkeypatch, tmp_path):
     monkeypatch.setenv("FX_HBM_BUDGET", "256K")
     size, kind, win, cap = windows.plan(p, 0, 1.0)
     assert size == 500003 and kind == 0 and win == 65536 and cap == 4
+    # a BGZF file: taken to fit from the ratio of its first members when that estimate is under a quarter of the budget
+    # (no walk over all members: _lib.stream_size is not asked); else, and for exact=True, the exact size decides
+    import gzip
+    from pyfastx_amd import _lib, synth
+    raw = b">a\n" + b"ACGTTGCA" * 40000 + b"\n>b\n" + bytes(np.random.default_rng(5).integers(65, 85, 300000, dtype=np.uint8)) + b"\n"
+    z = str(tmp_path / "f.fa.gz")
+    open(z, "wb").write(synth.bgzf_compress(raw))
+    r = windows.bgzf_head_ratio(z)
+    assert r is not None and abs(r - len(raw) / os.path.getsize(z)) < 0.35 * r
+    g = str(tmp_path / "g.fa.gz")
+    open(g, "wb").write(gzip.compress(raw))
+    assert windows.bgzf_head_ratio(g) is None and windows.bgzf_head_ratio(p) is None and windows.bgzf_head_ratio(str(tmp_path / "absent")) is None
+    asked = []
+    real = _lib.stream_size
+    monkeypatch.setattr(_lib, "stream_size", lambda path: (asked.append(path), real(path))[1])
+    monkeypatch.setenv("FX_HBM_BUDGET", "1G")
+    assert windows.plan(z, 0, 1.15) is None and asked == []     # estimate x 4 under the budget
+    assert windows.plan(z, 0, 1.15, exact=True) is None and asked == [z]
+    monkeypatch.setenv("FX_HBM_BUDGET", "2M")                   # estimate x 4 over the budget, the stream itself under it: the exact size is asked for
+    assert windows.plan(z, 0, 1.0) is None and asked == [z, z]
+    monkeypatch.setenv("FX_HBM_BUDGET", "256K")
+    size, kind, win, cap = windows.plan(z, 0, 1.0)
+    assert size == len(raw) and kind == 1 and win == 65536
 
 
 def test_native_framing_helpers_write_the_bytes_of_the_python_ones():
