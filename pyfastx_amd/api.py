@@ -1336,16 +1336,30 @@ class Fastq(_fxobj.FastqCore):
                 fits = windows.plan(self.file_name, self._st.device, self._st.win_factor) is None
             except _lib.FxError:
                 fits = True
+        early = None
         if fits and not self.is_gzip and _dev_index_applies(self._index_file) and self._st.forced is None and not os.environ.get("FX_FXI_NO_PRESIZE"):
-            try:
-                tok = fxi.presize_fastq(self._index_file, self.file_name, device=self._st.device, with_index=True)     # (the index holds names cut at the first white space whatever full_name says: fastq.c:112-117)
-            except Exception:                                 # noqa: BLE001  (no early file: the build makes it -- and must find none)
-                tok = None
-                if os.path.exists(self._index_file):
-                    os.remove(self._index_file)
+            def presize():
+                try:
+                    return fxi.presize_fastq(self._index_file, self.file_name, device=self._st.device, with_index=True)     # (the index holds names cut at the first white space whatever full_name says: fastq.c:112-117)
+                except Exception:                             # noqa: BLE001  (no early file: the build makes it -- and must find none)
+                    if os.path.exists(self._index_file):
+                        os.remove(self._index_file)
+                    return None
+            # in a thread of its own: the estimate reads eight windows of the input and sizes their records in Python (9 ms for
+            # C3) -- beside the first milliseconds of the staging instead of in front of it; the body asks for the token when it
+            # needs it (once the stream is staged)
+            import threading
+            box = {}
+            th = threading.Thread(target=lambda: box.__setitem__("tok", presize()))
+            th.start()
+
+            def early():
+                th.join()
+                return box.get("tok")
         try:
-            self._create_index_body(tok is not None, tok)
+            self._create_index_body(early)
         except BaseException:
+            tok = early() if early is not None else None
             _lib.fxi_presize_end(tok, cancel=True)
             if tok is not None and os.path.exists(self._index_file):
                 os.remove(self._index_file)
@@ -1459,11 +1473,20 @@ class Fastq(_fxobj.FastqCore):
                 self._host_names = (np.ascontiguousarray(names), offs)
         return True
 
-    def _create_index_body(self, presized, tok):
+    def _create_index_body(self, early):
+        """early: None, or a callable -> the token of the index file's room set aside in the background (fxi.presize_fastq), None
+        when nothing was set aside; asked once the stream is staged (the pipelined route, off by default, asks at once)."""
         t_begin = time.perf_counter()
-        if presized and self._create_index_pipelined(tok, t_begin):
-            return
+        tok = None
+        if early is not None and os.environ.get("FX_FQ_PIPELINE", "0") != "0":
+            tok = early()
+            early = None
+            if tok is not None and self._create_index_pipelined(tok, t_begin):
+                return
         wq = self._st.md
+        if early is not None:
+            tok = early()
+        presized = tok is not None
         if presized and wq is not None:                       # (built in windows after all: that route writes its own file)
             _lib.fxi_presize_end(tok, cancel=True)
             os.remove(self._index_file)
