@@ -10,7 +10,8 @@
 //   R  as Q without the fallocate: the populate allocates the pages as it maps them (one pass over the file instead of two)
 //   V  as B, but the file is mapped in SEPARATE mappings of `step` MiB (a page between them, so that the kernel keeps them apart) and a
 //      writer takes a whole mapping at a time: no two threads fault on the same VMA (its lock is one cache line for all of them)
-// usage: filewrite_probe2 <path> <MiB> <schedule A|B|E|F|P|Q|R|V> <T> [piece KiB = 8192] [falloc step MiB = 128] [K = 4] [first cpu, cpus: bind every thread to that range]
+//   W  V without the fallocate: the writers' first touches allocate the pages (in separate mappings: does the allocation spread over threads then?)
+// usage: filewrite_probe2 <path> <MiB> <schedule A|B|E|F|P|Q|R|V|W> <T> [piece KiB = 8192] [falloc step MiB = 128] [K = 4] [first cpu, cpus: bind every thread to that range]
 #define _GNU_SOURCE
 #include <sched.h>
 #include <fcntl.h>
@@ -65,8 +66,9 @@ int main(int c, char **v) {
     pthread_t th[300]; int nt = 0; double tf = 0;
     if (sched == 'B') { falloc_thread(0); tf = now() - t0; }
     double tp = 0, tq0 = 0;
-    if (sched == 'V') {
-        falloc_thread(0); tf = now() - t0;
+    if (sched == 'V' || sched == 'W') {
+        if (sched == 'V') falloc_thread(0);
+        tf = now() - t0;
         nvmap = (N + STEP - 1) / STEP; vmap = malloc(nvmap * sizeof *vmap);
         char *area = mmap(0, nvmap * (STEP + 4096), PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0); if (area == MAP_FAILED) { perror("mmap area"); return 1; }
         for (size_t k = 0; k < nvmap; ++k) { size_t off = k * STEP, len = N - off < STEP ? N - off : STEP;
@@ -79,10 +81,10 @@ int main(int c, char **v) {
     if (sched == 'A' || sched == 'F') pthread_create(&th[nt++], 0, falloc_thread, 0);
     if (sched == 'E') { pthread_create(&th[nt++], 0, pw_front, 0); for (int t = 0; t < T; ++t) pthread_create(&th[nt++], 0, mmap_back, 0); }
     else if (sched == 'P') for (long t = 0; t < T; ++t) pthread_create(&th[nt++], 0, pw_share, (void *)t);
-    else if (sched != 'V') for (int t = 0; t < T; ++t) pthread_create(&th[nt++], 0, mmap_writer, 0);
+    else if (sched != 'V' && sched != 'W') for (int t = 0; t < T; ++t) pthread_create(&th[nt++], 0, mmap_writer, 0);
     for (int t = 0; t < nt; ++t) pthread_join(th[t], 0);
     double t1 = now();
-    if (sched == 'V') printf("schedule V: fallocate %.3f s, %zu mappings of %zu MiB, copy with %d threads %.3f s = %.2f GB/s\n", tf, nvmap, STEP >> 20, T, t1 - tq0, N / 1e9 / (t1 - tq0));
+    if (sched == 'V' || sched == 'W') printf("schedule V/W: fallocate %.3f s, %zu mappings of %zu MiB, copy with %d threads %.3f s = %.2f GB/s\n", tf, nvmap, STEP >> 20, T, t1 - tq0, N / 1e9 / (t1 - tq0));
     if (sched == 'Q' || sched == 'R') printf("schedule Q/R: fallocate %.3f s, populate with %d threads %.3f s, copy with %d threads %.3f s = %.2f GB/s\n", tf, K, tp, T, t1 - tq0, N / 1e9 / (t1 - tq0));
     printf("schedule %c T=%d piece=%zuK step=%zuM: %.3f s (fallocate first: %.3f) -> %.2f GB/s\n", sched, T, PIECE >> 10, STEP >> 20, t1 - t0, tf, N / 1e9 / (t1 - t0));
     munmap(map, N); close(fd); unlink(path); return 0; }
