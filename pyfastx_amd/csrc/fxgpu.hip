@@ -631,10 +631,15 @@ static int stage_threads() {
     static const int forced = [] { const char *e = getenv("FX_STAGE_THREADS"); return e ? atoi(e) : 0; }();   // experiments
     if (forced > 0) return std::min(forced, 64);
     const unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::min<unsigned>(8u, std::max<unsigned>(4u, hw / 8));     // 3 GB from the page cache: 8 threads 47 GB/s, 16: 41, 32: 37 (tools/stage_probe.py)
+    // Round 6: 16 (it was 8: "3 GB from the page cache: 8 threads 47 GB/s, 16: 41, 32: 37" -- measured when every lane still created its
+    // stream at every open).  A file that has been read before comes out of the page cache as fast as the link takes it with 8 or 16
+    // threads (C3: 0.62-0.66 s either way); a file that has just been WRITTEN is read at 2.4 GB/s per thread the first time, with or
+    // without a device (tools/firstread_probe.c: 19 GB/s with 8 threads, 30 with 16, 26 with 32, then 160-270 GB/s) -- the first
+    // Fastq(path) of C3 after the bench wrote its input staged in 1.65-1.8 s with 8 threads and in 1.17-1.35 s with 16.
+    return (int)std::min<unsigned>(16u, std::max<unsigned>(4u, hw / 8));
 }
 
-// Plain files: T host threads (8: more of them copy out of the page cache more slowly, not faster), each with its own pair of
+// Plain files: T host threads (stage_threads()), each with its own pair of
 // pinned 8 MiB buffers and its own HIP stream,
 // walk the file in an interleaved pattern (thread t takes pieces t, t+T, ...): pread into pinned memory,
 // hipMemcpyAsync to the blob, double-buffered.  The pinned buffers are allocated once per process
