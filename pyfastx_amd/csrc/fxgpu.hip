@@ -631,17 +631,27 @@ static int stage_threads() {
     static const int forced = [] { const char *e = getenv("FX_STAGE_THREADS"); return e ? atoi(e) : 0; }();   // experiments
     if (forced > 0) return std::min(forced, 64);
     const unsigned hw = std::thread::hardware_concurrency();
-    // Round 6: 16 (it was 8: "3 GB from the page cache: 8 threads 47 GB/s, 16: 41, 32: 37" -- measured when every lane still created its
-    // stream at every open).  A file that has been read before comes out of the page cache as fast as the link takes it with 8 or 16
-    // threads (C3: 0.62-0.66 s either way); a file that has just been WRITTEN is read at 2.4 GB/s per thread the first time, with or
-    // without a device (tools/firstread_probe.c: 19 GB/s with 8 threads, 30 with 16, 26 with 32, then 160-270 GB/s) -- the first
-    // Fastq(path) of C3 after the bench wrote its input staged in 1.65-1.8 s with 8 threads and in 1.17-1.35 s with 16.
-    return (int)std::min<unsigned>(16u, std::max<unsigned>(4u, hw / 8));
+    return (int)std::min<unsigned>(8u, std::max<unsigned>(4u, hw / 8));     // 3 GB from the page cache: 8 threads 47 GB/s, 16: 41, 32: 37 (tools/stage_probe.py)
+}
+// Lanes that join in when the file turns out to be COLD.  A file that has just been written is read at 2.4 GB/s per thread the first
+// time, with or without a device (tools/firstread_probe.c: 19 GB/s with 8 threads, 30 with 16, no more with 24-64; later passes
+// 160-270 GB/s): the first Fastq(path) of C3 after the bench wrote its input staged in 1.65-1.8 s with 8 lanes, 1.17-1.35 s with 16.
+// A file that has been read before is link-bound with 8, and 16 lanes take memory bandwidth from the thread that sets the index
+// file's room aside beside them (it then finished 0.1-0.2 s after the staging).  So the extra lanes wait for a decision (below)
+// and leave at once when the file is not cold.
+// The decision: once piece STAGE_COLD_PROBE_PIECES is taken (0.8 GB into the file; the head of a file is no measure -- the size
+// estimate of an index file has just read it, and one thread alone reads a cold file at 4-10 GB/s), slower than 33 GB/s so far -> cold.
+// (A file in the page cache arrives at the link's 50-56 GB/s, a fresh one at 19.)  Files of less than 2 GiB: no extra lanes.
+constexpr int64_t STAGE_COLD_PROBE_PIECES = 96, STAGE_COLD_MIN_PIECES = 256;
+static bool stage_is_cold(double seconds, int64_t bytes) { return seconds * 33e9 > (double)bytes; }
+static int stage_extra_threads() {
+    static const int forced = [] { const char *e = getenv("FX_STAGE_EXTRA_THREADS"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return std::min(forced, 32);
+    return stage_threads();
 }
 
-// Plain files: T host threads (stage_threads()), each with its own pair of
-// pinned 8 MiB buffers and its own HIP stream,
-// walk the file in an interleaved pattern (thread t takes pieces t, t+T, ...): pread into pinned memory,
+// Plain files: T host threads (stage_threads(); more for a cold file: stage_extra_threads()), each with its own pair of
+// pinned 8 MiB buffers and its own HIP stream, take the pieces of the file in order, whoever is free: pread into pinned memory,
 // hipMemcpyAsync to the blob, double-buffered.  The pinned buffers are allocated once per process
 // (pinning 256 MiB costs about as much as moving 1 GB) and reused by later opens.
 static const int64_t PIECE_BYTES = [] { const char *e = getenv("FX_STAGE_PIECE_MB"); const int mb = e ? atoi(e) : 0; return (int64_t)(mb > 0 && mb <= 256 ? mb : 8) << 20; }();
@@ -791,14 +801,23 @@ static void par_memcpy(void *dst, const void *src, size_t bytes) {
 }
 
 static int stage_plain_file(fx_handle *h, int fd, int64_t n, const char *path, uint8_t *d_dst, int64_t file_off = 0) {
-    const int T = (int)std::min<int64_t>(stage_threads(), std::max<int64_t>(1, (n + PIECE_BYTES - 1) / PIECE_BYTES));
+    const int64_t npieces = (n + PIECE_BYTES - 1) / PIECE_BYTES;
+    const int T0 = (int)std::min<int64_t>(stage_threads(), std::max<int64_t>(1, npieces));
+    const int T = npieces >= STAGE_COLD_MIN_PIECES ? T0 + stage_extra_threads() : T0;       // lanes T0 .. T-1: only for a cold file (stage_extra_threads)
+    const auto S0 = std::chrono::steady_clock::now();
     std::atomic<int> err(0);                 // 1: read error, 2: device error
+    std::atomic<int64_t> next(0);            // the pieces are taken in file order by whoever is free
+    std::atomic<int> cold(T > T0 ? -1 : 0);  // -1: not known yet
     std::vector<std::thread> th;
     cpu_set_t near_cpus;
     const bool bind = device_cpus(h->device, &near_cpus);
     for (int t = 0; t < T; ++t)
         th.emplace_back([&, t]() {
             if (bind) (void)pthread_setaffinity_np(pthread_self(), sizeof near_cpus, &near_cpus);
+            if (t >= T0) {
+                while (cold.load() == -1 && !err.load()) usleep(100);
+                if (cold.load() != 1) return;
+            }
             if (hipSetDevice(h->device) != hipSuccess) { err.store(2); return; }
             uint8_t *pin[2] = {g_pins.get(), g_pins.get()};
             hipStream_t st = nullptr;
@@ -809,8 +828,10 @@ static int stage_plain_file(fx_handle *h, int fd, int64_t n, const char *path, u
                       hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
             if (!ok) err.store(2);
             int slot = 0;
-            for (int64_t off = (int64_t)t * PIECE_BYTES; ok && off < n && !err.load(); off += (int64_t)T * PIECE_BYTES, slot ^= 1) {
-                const int64_t len = std::min(PIECE_BYTES, n - off);
+            for (; ok && !err.load(); slot ^= 1) {
+                const int64_t k = next.fetch_add(1);
+                if (k >= npieces) break;
+                const int64_t off = k * PIECE_BYTES, len = std::min(PIECE_BYTES, n - off);
                 if (used[slot] && hipEventSynchronize(ev[slot]) != hipSuccess) { err.store(2); break; }
                 int64_t done = 0;
                 while (done < len) {
@@ -819,10 +840,17 @@ static int stage_plain_file(fx_handle *h, int fd, int64_t n, const char *path, u
                     done += r;
                 }
                 if (done < len) break;
+                if (k == STAGE_COLD_PROBE_PIECES && cold.load() == -1) {
+                    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - S0).count();
+                    cold.store(stage_is_cold(dt, k * PIECE_BYTES) ? 1 : 0);
+                    static const bool trace = [] { const char *e = getenv("FX_TRACE_STAGE"); return e && atoi(e) != 0; }();
+                    if (trace) fprintf(stderr, "[fxgpu] staging: the first %.0f MiB read in %.1f ms = %.1f GB/s -> %s\n", k * PIECE_BYTES / 1048576.0, dt * 1e3, k * PIECE_BYTES / dt / 1e9, cold.load() ? "a cold file: the extra lanes join in" : "no extra lanes");
+                }
                 if (hipMemcpyAsync(d_dst + off, pin[slot], (size_t)len, hipMemcpyHostToDevice, st) != hipSuccess ||
                     hipEventRecord(ev[slot], st) != hipSuccess) { err.store(2); break; }
                 used[slot] = true;
             }
+            { int e = -1; (void)cold.compare_exchange_strong(e, 0); }     // (a lane that is through before anybody decided: nothing is left for the others)
             if (st) (void)hipStreamSynchronize(st);
             for (int i = 0; i < 2; ++i) { if (ev[i]) (void)hipEventDestroy(ev[i]); if (pin[i]) g_pins.put(pin[i]); }
             if (st) g_lane_streams.put(h->device, st);
@@ -1102,6 +1130,8 @@ struct StageAsync {
     uint8_t *d_dst = nullptr;
     int T = 0;
     std::atomic<int> err{0};                                  // 1: read error, 2: device error
+    std::atomic<int64_t> next{0};                             // the next piece nobody has taken
+    std::atomic<int> cold{0};                                 // -1: not known yet; 1: the extra lanes join in (stage_extra_threads)
     std::vector<std::thread> th;
     std::vector<hipEvent_t> ev;                               // one per piece
     std::unique_ptr<std::atomic<int>[]> issued;               // 1: the piece's copy and its event are in the lane's stream
@@ -1112,7 +1142,9 @@ struct StageAsync {
         T_start = std::chrono::steady_clock::now();
         h = hh; fd = fd_; n = n_; d_dst = dst; piece = std::min<int64_t>(PIECE_BYTES, piece_bytes);
         npieces = (n + piece - 1) / piece;
-        T = (int)std::min<int64_t>(stage_threads(), std::max<int64_t>(1, npieces));
+        const int T0 = (int)std::min<int64_t>(stage_threads(), std::max<int64_t>(1, npieces));
+        T = npieces >= STAGE_COLD_MIN_PIECES && piece == PIECE_BYTES ? T0 + stage_extra_threads() : T0;    // lanes T0 .. T-1: only for a cold file (stage_extra_threads)
+        cold.store(T > T0 ? -1 : 0);
         ev.assign((size_t)npieces, nullptr);
         issued.reset(new std::atomic<int>[(size_t)npieces]);
         for (int64_t i = 0; i < npieces; ++i) {
@@ -1121,8 +1153,12 @@ struct StageAsync {
         }
         const bool bind = device_cpus(h->device, &near_cpus);
         for (int t = 0; t < T; ++t)
-            th.emplace_back([this, t, bind]() {
+            th.emplace_back([this, t, bind, T0]() {
                 if (bind) (void)pthread_setaffinity_np(pthread_self(), sizeof near_cpus, &near_cpus);
+                if (t >= T0) {
+                    while (cold.load() == -1 && !err.load()) usleep(100);
+                    if (cold.load() != 1) return;
+                }
                 if (hipSetDevice(h->device) != hipSuccess) { err.store(2); return; }
                 uint8_t *pin[2] = {g_pins.get(), g_pins.get()};
                 hipStream_t st = nullptr;
@@ -1134,7 +1170,10 @@ struct StageAsync {
                 const auto L0 = std::chrono::steady_clock::now();
                 auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - L0).count(); };
                 if (trace) fprintf(stderr, "[fxgpu] lane %d: stream + pins after %.2f ms (since the lane began: %.2f)\n", t, std::chrono::duration<double, std::milli>(L0 - T_start).count(), 0.0);
-                for (int64_t k = t; ok && k < npieces && !err.load(); k += T, slot ^= 1) {
+                bool first = true;
+                for (; ok && !err.load(); slot ^= 1) {
+                    const int64_t k = next.fetch_add(1);         // in file order, by whoever is free
+                    if (k >= npieces) break;
                     const int64_t off = k * piece, len = std::min(piece, n - off);
                     if (last[slot] >= 0 && hipEventSynchronize(ev[(size_t)last[slot]]) != hipSuccess) { err.store(2); break; }
                     int64_t done = 0;
@@ -1144,13 +1183,17 @@ struct StageAsync {
                         done += r;
                     }
                     if (done < len) break;
-                    if (trace && k == t) fprintf(stderr, "[fxgpu] lane %d: first piece read after %.2f ms\n", t, since());
+                    if (k == STAGE_COLD_PROBE_PIECES && cold.load() == -1)
+                        cold.store(stage_is_cold(std::chrono::duration<double>(std::chrono::steady_clock::now() - T_start).count(), k * piece) ? 1 : 0);
+                    if (trace && first) fprintf(stderr, "[fxgpu] lane %d: first piece read after %.2f ms\n", t, since());
                     if (hipMemcpyAsync(d_dst + off, pin[slot], (size_t)len, hipMemcpyHostToDevice, st) != hipSuccess ||
                         hipEventRecord(ev[(size_t)k], st) != hipSuccess) { err.store(2); break; }
-                    if (trace && k == t) fprintf(stderr, "[fxgpu] lane %d: first copy queued after %.2f ms\n", t, since());
+                    if (trace && first) fprintf(stderr, "[fxgpu] lane %d: first copy queued after %.2f ms\n", t, since());
+                    first = false;
                     last[slot] = k;
                     issued[(size_t)k].store(1, std::memory_order_release);
                 }
+                { int e = -1; (void)cold.compare_exchange_strong(e, 0); }
                 if (st) (void)hipStreamSynchronize(st);
                 for (int i = 0; i < 2; ++i) if (pin[i]) g_pins.put(pin[i]);
                 if (st) g_lane_streams.put(h->device, st);
