@@ -642,8 +642,10 @@ static int stage_threads() {
 // The decision: once piece STAGE_COLD_PROBE_PIECES is taken (0.8 GB into the file; the head of a file is no measure -- the size
 // estimate of an index file has just read it, and one thread alone reads a cold file at 4-10 GB/s), slower than 33 GB/s so far -> cold.
 // (A file in the page cache arrives at the link's 50-56 GB/s, a fresh one at 19.)  Files of less than 2 GiB: no extra lanes.
-constexpr int64_t STAGE_COLD_PROBE_PIECES = 96, STAGE_COLD_MIN_PIECES = 256;
-static bool stage_is_cold(double seconds, int64_t bytes) { return seconds * 33e9 > (double)bytes; }
+// FX_STAGE_COLD_FORCE=1 (tests): every file of at least two pieces counts as cold from its second piece on.
+static const bool STAGE_COLD_FORCE = [] { const char *e = getenv("FX_STAGE_COLD_FORCE"); return e && atoi(e) != 0; }();
+static const int64_t STAGE_COLD_PROBE_PIECES = STAGE_COLD_FORCE ? 1 : 96, STAGE_COLD_MIN_PIECES = STAGE_COLD_FORCE ? 2 : 256;
+static bool stage_is_cold(double seconds, int64_t bytes) { return STAGE_COLD_FORCE || seconds * 33e9 > (double)bytes; }
 static int stage_extra_threads() {
     static const int forced = [] { const char *e = getenv("FX_STAGE_EXTRA_THREADS"); return e ? atoi(e) : -1; }();
     if (forced >= 0) return std::min(forced, 32);
