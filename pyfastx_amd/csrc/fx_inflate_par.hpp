@@ -364,13 +364,23 @@ __global__ __launch_bounds__(64) P_WPE void k_bgzf_decode_par(const uint8_t *__r
                                                          const int32_t *__restrict__ cdata_len, const int64_t *__restrict__ uoff,
                                                          const int32_t *__restrict__ isize, int64_t nmem, uint8_t *__restrict__ data,
                                                          int32_t *__restrict__ status, uint64_t *__restrict__ match_map, int dbg, int lds_payload,
-                                                         int32_t *__restrict__ par_status, uint32_t *__restrict__ symbuf, int sym_rows) {
+                                                         int32_t *__restrict__ par_status, uint32_t *__restrict__ symbuf, int sym_rows, int *next_member) {
     extern __shared__ __attribute__((aligned(16))) uint8_t p_smem[];
     PTab &T = *reinterpret_cast<PTab *>(p_smem);
     const int lane = threadIdx.x;
     uint32_t *const sb = REPLAY ? symbuf + (size_t)blockIdx.x * (size_t)sym_rows * 64u + (uint32_t)lane : nullptr;   // this lane's column
-  for (int64_t m = blockIdx.x; m < nmem; m += gridDim.x) {
+  // The members are handed out by a counter (next_member, zeroed by the host), not m, m + grid, ...: 46 723 members over 2 560 waves are
+  // 18.25 each -- with fixed shares a quarter of the waves decodes a 19th member while the others are through, and a wave whose
+  // members happen to be slow holds the kernel alone at the end.  (nullptr: the fixed shares.)
+  for (int64_t mi = blockIdx.x;; mi += gridDim.x) {
     __syncthreads();                                         // (the tables of the member before are done with)
+    int64_t m = mi;
+    if (next_member) {
+        if (lane == 0) T.hdr[6] = atomicAdd(next_member, 1);
+        __syncthreads();
+        m = T.hdr[6];
+    }
+    if (m >= nmem) break;
 #ifdef FX_BGZF_LDS_MAP
     for (int i = lane; i < 2048; i += 64) T.map[i] = 0;
 #endif

@@ -984,11 +984,11 @@ static int bgzf_inflate_staged(fx_handle *h, const uint8_t *d_cp, const int64_t 
     // where the matches of a member begin: one bit per output byte (k_bgzf_decode sets them, k_bgzf_copy walks them)
     ScratchBuf<uint64_t> d_map;
     if ((rc = d_map.alloc(h->device, nmem * BM_WORDS, h->stream))) return rc;
-    if ((rc = d_status.alloc(h->device, nmem, h->stream)) || (rc = d_pstatus.alloc(h->device, nmem, h->stream))) return rc;
+    if ((rc = d_status.alloc(h->device, nmem, h->stream)) || (rc = d_pstatus.alloc(h->device, nmem + 1, h->stream))) return rc;      // (+ 1: the counter the waves take their members from)
     ScratchBuf<uint16_t> d_gsym;                             // canonical symbol order of every member's tables (slow path of the decoder)
     if ((rc = d_gsym.alloc(h->device, nmem * GSYM, h->stream))) return rc;
     HIPCHK(hipMemsetAsync(d_status.p, 0xFF, (size_t)nmem * 4, h->stream));
-    HIPCHK(hipMemsetAsync(d_pstatus.p, 0, (size_t)nmem * 4, h->stream));
+    HIPCHK(hipMemsetAsync(d_pstatus.p, 0, (size_t)(nmem + 1) * 4, h->stream));
     HIPCHK(hipMemsetAsync(d_map.p, 0, (size_t)nmem * BM_WORDS * 8, h->stream));
     if (m_first < 0 && (rc = alloc_blob(h, total))) return rc;
     lap("allocations");
@@ -999,6 +999,7 @@ static int bgzf_inflate_staged(fx_handle *h, const uint8_t *d_cp, const int64_t 
     // LDS of a wave: the tables + the member's payload (sized for the largest member of the file, at most 64 KiB of the 160 per CU)
     const int lds_payload = (int)std::min<int64_t>(((int64_t)clen_max + 16 + 255) & ~255ll, 65536);
     static const bool stage = [] { const char *e = getenv("FX_BGZF_STAGE"); return e && atoi(e) != 0; }();   // the payload through LDS (experiment)
+    static const bool fixed_shares = [] { const char *e = getenv("FX_BGZF_FIXED_SHARES"); return e && atoi(e) != 0; }();   // members m, m + grid, ... per wave (the form before; comparison)
     static const bool replay = [] { const char *e = getenv("FX_BGZF_REPLAY"); return e && atoi(e) != 0; }();   // phase B replays the symbols phase A left behind (experiment: no faster -- what B costs is its stores)
     const size_t par_lds = ((sizeof(PTab) + 15) & ~(size_t)15) + (stage ? (size_t)lds_payload : 0);
     const auto par_kernel = stage ? (replay ? k_bgzf_decode_par<true, true> : k_bgzf_decode_par<true, false>)
@@ -1024,7 +1025,7 @@ static int bgzf_inflate_staged(fx_handle *h, const uint8_t *d_cp, const int64_t 
     if (!serial_only) {
         h->prof.begin(K_BGZF_INFLATE, h->stream);
         hipLaunchKernelGGL(par_kernel, dim3(par_grid), dim3(64), par_lds, h->stream, d_cp, d_coff, d_clen, d_uoff, d_isize, nmem,
-                           h->d_data, d_status.p, d_map.p, dbg_par, lds_payload, d_pstatus.p, d_sym.p, SYM_ROWS);
+                           h->d_data, d_status.p, d_map.p, dbg_par, lds_payload, d_pstatus.p, d_sym.p, SYM_ROWS, fixed_shares ? nullptr : d_pstatus.p + nmem);
         h->prof.end(h->stream);
         if (trace) {                                         // how many members the wave-per-member kernel handed over, and why
             std::vector<int32_t> stv((size_t)nmem);
@@ -1039,9 +1040,10 @@ static int bgzf_inflate_staged(fx_handle *h, const uint8_t *d_cp, const int64_t 
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipStreamSynchronize(h->stream);
+        (void)hipMemsetAsync(d_pstatus.p + nmem, 0, 4, h->stream);       // (the members' counter, used up by the launch above)
         (void)hipEventRecord(e0, h->stream);
         hipLaunchKernelGGL(par_kernel, dim3(par_grid), dim3(64), par_lds, h->stream, d_cp, d_coff, d_clen, d_uoff, d_isize, nmem,
-                           h->d_data, d_status.p, d_map.p, dbg_par, lds_payload, d_pstatus.p, d_sym.p, SYM_ROWS);
+                           h->d_data, d_status.p, d_map.p, dbg_par, lds_payload, d_pstatus.p, d_sym.p, SYM_ROWS, fixed_shares ? nullptr : d_pstatus.p + nmem);
         (void)hipEventRecord(e1, h->stream);
         (void)hipStreamSynchronize(h->stream);
         float ms = 0.f;
