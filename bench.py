@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--c3-reference-full", action="store_true", help="the compiled reference on the FULL configs[2] file as well (pyfastx.Fastq(path, full_index=True): ~5 minutes on one core, "
                                                                       "a second 10 GB index file), every `read` row + base / meta / stat compared (profiles/r05_c3_full_reference.json holds one such run)")
     ap.add_argument("--c4-ref-queries", type=int, default=100_000, help="queries of the C4 leg that the reference answers too (ascending offsets, through its restart points)")
-    ap.add_argument("--c4-reference-full", action="store_true", help="ALL queries of the C4 leg through the reference (builder-run: profiles/r06_v9_c4_full_reference.json; minutes of one core)")
+    ap.add_argument("--c4-reference-full", action="store_true", help="ALL queries of the C4 leg through the reference (builder-run: profiles/r06_c4_full_reference.json; minutes of one core)")
     ap.add_argument("--pmc-file", default=None, help=argparse.SUPPRESS)                  # the counter passes' child opens this file instead of generating the stream
     return ap.parse_args()
 
@@ -609,7 +609,7 @@ def c3_full_file(a, path, n, cols, theirs_rows, m):
            "sqlite_integrity_check": integrity, "integrity_check_s": round(t5 - t4, 1), "rows_sample_equal_generator": bool(rows_ok),
            "rows_of_the_first_%d_reads_equal_reference" % m: prefix_equal, "name_probe_ok": bool(by_name), "fetch_sample_equal_file_bytes": bool(ok),
            # (the reference takes ~3 minutes of one core for the whole file: not part of the default run)
-           "reference_on_the_whole_file": full_ref if full_ref is not None else "builder-run, see profiles/r06_v7_c3_full_reference.json (all 10^8 read rows + base / meta / stat equal, 183 s of the reference; `--c3-reference-full` repeats it)"}
+           "reference_on_the_whole_file": full_ref if full_ref is not None else "builder-run, see profiles/r06_c3_full_reference.json (all 10^8 read rows + base / meta / stat equal, 183 s of the reference; `--c3-reference-full` repeats it)"}
     if (a.c3_integrity and integrity != "ok") or not rows_ok or not ok or prefix_equal is False or not by_name:
         raise SystemExit("PARITY FAILURE (C3 at full size from a file): %r" % (res,))
     return res
@@ -754,7 +754,7 @@ def leg_c4(a, host, plan, q, tmpdir, plain_digest=None):
         out["rows_equal_reference"] = bool(theirs["seq"] == ours["seq"] and theirs["stat"][0][:2] == ours["stat"][0][:2])
         out["fetch_sample_equal_reference"] = bool(eq)
         if not a.c4_reference_full:
-            out["reference_on_all_queries"] = "builder-run, see profiles/r06_v9_c4_full_reference.json (all 1 000 000 queries equal; `--c4-reference-full` repeats it)"
+            out["reference_on_all_queries"] = "builder-run, see profiles/r06_c4_full_reference.json (all 1 000 000 queries equal; `--c4-reference-full` repeats it)"
         out["index_speedup_vs_cpu"] = round((t3 - t2) / max(_median(t_ctor), 1e-9), 1)
         if not (out["rows_equal_reference"] and eq):
             raise SystemExit("PARITY FAILURE (C4 vs the reference)")
