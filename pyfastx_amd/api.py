@@ -1328,7 +1328,6 @@ class Fastq(_fxobj.FastqCore):
         """pyfastx_fastq_create_index (fastq.c:8-182) with the scan on the GPU."""
         # a large plain file: the index file is created now and grows to its estimated size while the input is staged
         # (fxi.presize_fastq; the pages that fill it are formatted on the device once the table exists)
-        tok = None
         fits = True
         if not self.is_gzip and self._st.windowed is not None and self._st._blob is None:
             from . import windows
