@@ -15,7 +15,7 @@
 #   bgzf_pmc[:gbp] counter passes over the BGZF kernels, whole file in ONE launch (FX_BGZF_GROUP=0)
 #   bgzf_libs:gbp:lib[@K=V,...]:...   k_bgzf_* times for experiment builds (build/libfxgpu_*.so; pyfastx_amd/csrc/libfxgpu.so = the product)
 #   bgzf_dbg[:gbp] the phase probes of k_bgzf_decode_par (FX_BGZF_DBG=8 / 1 / 2 / 4: header+tables / +A / +A2 / +B without stores)
-#   pmc_fq[:n] pmc_fq_one[:n] pmc_fqcomp[:n] pmc_comp[:filter] pmc_fetch pmc_fxi[:n]   the standing counter passes (traffic, SQ, TCC) of a probe
+#   pmc_fq[:n] pmc_fq_one[:n] pmc_fqcomp[:n] pmc_comp[:filter] pmc_fetch pmc_fxi[:n] pmc_sort[:n]   the standing counter passes (traffic, SQ, TCC) of a probe
 #   prof_fastx     kernel trace of the kseq walk (tools/fastx_scale.py), default and walk-only
 #   py:<script>:args...   any tools/*.py probe, stdout to <script>.json
 TAG=${1:-run}; shift
@@ -81,11 +81,12 @@ for STEP in "$@"; do
     export FX_PROBE_FILE=/tmp/c4_probe.fa.gz FX_BGZF_GROUP=0
     for d in 8 1 2 4 5; do FX_BGZF_DBG=$d python tools/bgzf_decode_probe.py ${A1:-3.0} 2>&1 | grep "dbg=" | tail -1; done | tee $OUT/bgzf_dbg.txt
     unset FX_BGZF_GROUP ;;
-  pmc_fq|pmc_fq_one|pmc_fqcomp|pmc_comp|pmc_fetch|pmc_fxi)
+  pmc_fq|pmc_fq_one|pmc_fqcomp|pmc_comp|pmc_fetch|pmc_fxi|pmc_sort)
     # the standing counter passes of a probe, one rocprofv3 run per set (counters in runs of their own, kernel trace only):
     #   pmc_fq[:n]      tools/fq_build_bench.py   k_fastq        pmc_fq_one[:n]  tools/fq_one_probe.py  k_fastq (one-read build)
     #   pmc_fqcomp[:n]  tools/fq_comp_probe.py    k_fastq_comp   pmc_comp        bench.py (2 steps)     k_fasta_comp / k_scan_comp / k_span_scan
     #   pmc_fetch       tools/fetch_probe.py      fetch          pmc_fxi[:n]     tools/fxi_pmc_probe.py k_fxi
+    #   pmc_sort[:n]    tools/sort_probe.py       k_sort_* / k_rs_* (the name sort alone)
     case $S in
       pmc_fq) P="python tools/fq_build_bench.py ${A1:-2e7}"; F=k_fastq ;;
       pmc_fq_one) P="python tools/fq_one_probe.py ${A1:-2e7}"; F=k_fastq ;;
@@ -93,6 +94,7 @@ for STEP in "$@"; do
       pmc_comp) P="python bench.py --no-pmc --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-c3 --no-c4"; F=${A1:-k_} ;;
       pmc_fetch) P="python tools/fetch_probe.py 3.0 2e7"; F=fetch ;;
       pmc_fxi) P="python tools/fxi_pmc_probe.py ${A1:-2e7}"; F=k_fxi ;;
+      pmc_sort) P="python tools/sort_probe.py ${A1:-1e8}"; F=k_ ;;
     esac
     pmc_pass ${S}_fetch $F $P -- FETCH_SIZE
     pmc_pass ${S}_write $F $P -- WRITE_SIZE
