@@ -193,11 +193,14 @@ static std::vector<SortGroup> sort_groups(const uint64_t *orand, int nchunk) {
 }
 
 // ------------------------------------------------------------------ stable 8-bit counting pass over (key, value) pairs
-// A workgroup of 4 waves owns a tile of RS_TILE = 4096 consecutive pairs, wave w the 1024 pairs [w * 1024, ...) of it in
-// 16 rounds of 64 consecutive pairs -- so "earlier in the input" is (workgroup, wave, round, lane), and a pair's place
+// A workgroup of 4 waves owns a tile of RS_TILE = 2048 consecutive pairs, wave w the 512 pairs [w * 512, ...) of it in
+// 8 rounds of 64 consecutive pairs -- so "earlier in the input" is (workgroup, wave, round, lane), and a pair's place
 // in the output is   start of its digit's bucket  +  pairs with that digit in earlier workgroups  (k_rs_scan)
 //                  + ... in earlier waves of the workgroup + ... in earlier rounds of the wave + ... in lower lanes.
-constexpr int RS_BLOCK = 256, RS_ROUNDS = 16, RS_TILE = RS_BLOCK * RS_ROUNDS;
+#ifndef FX_RS_ROUNDS
+#define FX_RS_ROUNDS 8                                   // 2048 pairs per tile (28 KB of LDS, five workgroups per CU): 10^8 names 19.0-19.5 ms; 12: 19.6; 16 (53 KB, two per CU): 20.2-21.0
+#endif
+constexpr int RS_BLOCK = 256, RS_ROUNDS = FX_RS_ROUNDS, RS_TILE = RS_BLOCK * RS_ROUNDS;
 
 __device__ __forceinline__ uint32_t rs_incl_scan64(uint32_t v) {     // inclusive prefix sum over the wave (DPP, as wave_incl_scan)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
