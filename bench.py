@@ -609,7 +609,7 @@ def c3_full_file(a, path, n, cols, theirs_rows, m):
            "sqlite_integrity_check": integrity, "integrity_check_s": round(t5 - t4, 1), "rows_sample_equal_generator": bool(rows_ok),
            "rows_of_the_first_%d_reads_equal_reference" % m: prefix_equal, "name_probe_ok": bool(by_name), "fetch_sample_equal_file_bytes": bool(ok),
            # (the reference takes ~3 minutes of one core for the whole file: not part of the default run)
-           "reference_on_the_whole_file": full_ref if full_ref is not None else "builder-run, see profiles/r06_c3_full_reference.json (all 10^8 read rows + base / meta / stat equal, 183 s of the reference; `--c3-reference-full` repeats it)"}
+           "reference_on_the_whole_file": full_ref if full_ref is not None else "builder-run, see profiles/r06_c3_full_reference.json (all 10^8 read rows + base / meta / stat equal, 179 s of the reference; `--c3-reference-full` repeats it)"}
     if (a.c3_integrity and integrity != "ok") or not rows_ok or not ok or prefix_equal is False or not by_name:
         raise SystemExit("PARITY FAILURE (C3 at full size from a file): %r" % (res,))
     return res
